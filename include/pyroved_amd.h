@@ -1,0 +1,177 @@
+/*
+ * pyroved_amd.h — C ABI of libpyroved_amd.so: the MI355X (gfx950) implementation of
+ * pyroVED's SVI training hot path (encoder -> reparameterise -> coordinate-grid
+ * spatial decoder -> ELBO -> gradients -> Adam).
+ *
+ * The reference (ziatdinovmax/pyroVED) has no FFI of its own: its boundary is the
+ * Python API.  Each entry point below replaces the torch/Pyro call sequence of
+ * the reference function it cites (paths relative to /root/reference/pyroved).
+ * The Python host side (pyroved_amd/_abi.py) binds them with ctypes; the stub a
+ * maintainer would add to the reference itself is in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 unless stated;
+ *    weights use torch.nn.Linear layout (out_features, in_features), row-major;
+ *  - the caller owns every buffer (including the workspace); the library never
+ *    allocates device memory, never frees, never keeps a pointer past the call;
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *    void*); no implicit device synchronisation; safe inside stream capture;
+ *  - return value: 0 on success, otherwise a hipError_t (>0) or a PV_E* code (<0);
+ *    nothing throws across the ABI.
+ */
+#ifndef PYROVED_AMD_H
+#define PYROVED_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PV_ABI_VERSION 1
+
+/* error codes (negative; positive values are hipError_t) */
+#define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
+#define PV_EWS      (-2)   /* workspace too small */
+
+/* activations: utils/nn.py:118-124 (get_activation) + the output sigmoid */
+enum pv_act {
+  PV_ACT_NONE = 0, PV_ACT_TANH = 1, PV_ACT_RELU = 2, PV_ACT_LRELU = 3,
+  PV_ACT_SOFTPLUS = 4, PV_ACT_GELU = 5, PV_ACT_SIGMOID = 6
+};
+
+/* decoder likelihoods: utils/prob.py:25-29 (get_sampler) */
+enum pv_lik { PV_LIK_BERNOULLI = 0, PV_LIK_GAUSSIAN = 1 };
+
+#define PV_MAX_LAYERS 8
+
+/* One nn.Linear(+activation) of make_fc_layers (nets/fc.py:307-324).  Offsets are
+ * in floats into the flat parameter buffer (and, identically, the flat gradient
+ * and Adam-moment buffers).  b_off < 0: no bias. */
+typedef struct pv_layer {
+  int32_t in_dim;
+  int32_t out_dim;
+  int32_t act;
+  int32_t _pad;
+  int64_t w_off;
+  int64_t b_off;
+} pv_layer;
+
+/* Everything one SVI step of models.iVAE needs (models/ivae.py:122-221,
+ * models/base.py:47-119, trainers/svi.py:64-115).  Plain data: filled by the
+ * caller, read by the library during the call only. */
+typedef struct pv_ivae_plan {
+  /* ---- problem ---- */
+  int32_t batch;          /* B: samples in this (local) minibatch                         */
+  int32_t n_pix;          /* N = prod(data_dim)                                           */
+  int32_t coord_dim;      /* 0: vanilla VAE (fcDecoderNet); 1: 1-D grid; 2: 2-D grid      */
+  int32_t z_dim;          /* latent_dim + coord (ivae.py:159)                             */
+  int32_t latent_dim;     /* content latents (last entries of z)                          */
+  int32_t c_dim;          /* class-conditioning width (0 = none)                          */
+  int32_t has_r, has_t, has_s;   /* invariances (base.py:110-118: fixed order r,t,s)      */
+  float   t_prior[2];     /* base.py:73-77                                                */
+  float   sc_prior;       /* base.py:79-80                                                */
+  float   beta;           /* KL scale_factor (ivae.py:175,214)                            */
+  int32_t lik;            /* enum pv_lik                                                  */
+  int32_t sigmoid_out;    /* sigmoid_d (ivae.py:153)                                      */
+  float   decoder_sig;    /* Normal scale for the gaussian sampler (prob.py:28)           */
+  int32_t fused;          /* 1: use the fused persistent spatial-decoder kernel when the
+                             architecture allows it; 0: force the layer-by-layer path     */
+  /* ---- networks ---- */
+  int32_t  n_enc;                  /* hidden layers of encoder_z.fc_layers (fc.py:44-45)  */
+  int32_t  n_dec;                  /* hidden layers of decoder.fc_layers                  */
+  pv_layer enc[PV_MAX_LAYERS];
+  pv_layer head;                   /* fc11 and fc12 (fc.py:46-47,59-60) as ONE Linear of out_dim 2*z_dim:
+                                      rows [0,z_dim) = fc11.weight, rows [z_dim,2*z_dim) = fc12.weight,
+                                      bias = [fc11.bias | fc12.bias]; the caller lays the two tensors
+                                      out adjacently in the flat buffer                      */
+  pv_layer fc_coord, fc_latent;    /* coord_latent (fc.py:216-217); unused if coord_dim=0 */
+  pv_layer dec[PV_MAX_LAYERS];
+  pv_layer out;                    /* decoder.out (fc.py:186 / fc.py:140)                 */
+  /* ---- caller-owned device buffers ---- */
+  float*       params;    /* flat parameters, n_params floats                             */
+  float*       grads;     /* flat gradients (written, not accumulated)                    */
+  float*       adam_m;    /* flat first moments                                           */
+  float*       adam_v;    /* flat second moments                                          */
+  int64_t      n_params;
+  const float* x;         /* (B, N) observations                                          */
+  const float* y;         /* (B, c_dim) or NULL                                           */
+  const float* eps;       /* (B, z_dim) standard-normal draws of Normal.rsample           */
+  const float* grid;      /* (N, coord_dim) generate_grid(data_dim) (coord.py:21-44)      */
+  void*        ws;        /* workspace, >= pv_ivae_workspace_bytes(plan) bytes            */
+  int64_t      ws_bytes;
+  float*       scalars;   /* out, 4 floats: loss, sum log p(x|z), beta*sum log p(z), beta*sum log q(z|x) */
+  float*       z_loc;     /* out (B, z_dim), may be NULL                                  */
+  float*       z_scale;   /* out (B, z_dim), may be NULL                                  */
+  float*       loc;       /* out (B, N) decoder output, may be NULL                       */
+  /* ---- Adam (torch.optim.Adam defaults via pyro.optim.Adam, svi.py:79-81) ---- */
+  float   lr, adam_beta1, adam_beta2, adam_eps;
+  int32_t adam_step;      /* 1-based step count of THIS update                            */
+  int32_t _pad2;
+} pv_ivae_plan;
+
+/* Library / ABI version (PV_ABI_VERSION). */
+int pv_version(void);
+
+/* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
+ * layer widths).  Returns < 0 on an unsupported plan. */
+int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan);
+
+/* Trace_ELBO.loss_and_grads for iVAE.guide + iVAE.model (models/ivae.py:165-221,
+ * pyro's Trace_ELBO with one particle): writes plan->scalars and, when
+ * want_grads != 0, d(loss)/d(params) into plan->grads (every entry overwritten).
+ * Replaces: trainers/svi.py:107 `self.svi.step(x)` up to (not including) the
+ * optimizer.  */
+int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* stream);
+
+/* pyro.optim.Adam / torch.optim.Adam step over the flat buffers, then grads set
+ * to zero (pyro.infer.util.zero_grads).  `n` floats starting at each pointer. */
+int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n,
+                 float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* loss_and_grads + adam in one call (single-GPU SVI.step, trainers/svi.py:107). */
+int pv_ivae_step(const pv_ivae_plan* plan, void* stream);
+
+/* baseVAE._encode inner call (models/base.py:131-135): encoder_z(x[,y]) ->
+ * z_loc, z_scale (B, z_dim) each. */
+int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream);
+
+/* baseVAE._decode inner call (models/base.py:153-170): decoder(grid', z) with the
+ * grid transformed once by (angle, shift, scale); z is (B, latent_dim + c_dim).
+ * loc: (B, N). */
+int pv_ivae_decode(const pv_ivae_plan* plan, const float* z, float angle, float shift_x,
+                   float shift_y, float scale, float* loc, void* stream);
+
+/* ---- building blocks (also used directly by pyroved_amd.nets.*.forward) ---- */
+
+/* Scratch bytes pv_linear_fwd / pv_linear_bwd need for a layer of these dimensions. */
+int64_t pv_linear_workspace_bytes(int64_t M, int64_t K, int64_t N);
+
+/* y[M,N] = act(x[M,K] @ w[N,K]^T + b[N])   (nn.Linear + activation; fc.py:321-323).
+ * ldx / ldy: row strides in floats.  b may be NULL.  If pre != NULL the
+ * pre-activation is stored there too (ldy stride) — needed by GELU's backward. */
+int pv_linear_fwd(const float* x, int64_t ldx, const float* w, const float* b,
+                  float* y, float* pre, int64_t ldy, int64_t M, int64_t K, int64_t N,
+                  int act, void* ws, int64_t ws_bytes, void* stream);
+
+/* Backward of the above given dpre[M,N] = dL/d(pre-activation):
+ *   dx[M,K]  = (dpre @ w) * act'(xact)   (xact/xpre: output / pre-activation of the layer that
+ *                                          produced x; act_prev = PV_ACT_NONE -> no factor)
+ *   dw[N,K]  = dpre^T @ x,   db[N] = colsum(dpre)
+ * dx, dw, db may each be NULL to skip. */
+int pv_linear_bwd(const float* dpre, int64_t lddp, const float* x, int64_t ldx, const float* w,
+                  float* dx, int64_t lddx, const float* xact, const float* xpre, int64_t ldxa,
+                  int act_prev, float* dw, float* db, int64_t M, int64_t K, int64_t N,
+                  void* ws, int64_t ws_bytes, void* stream);
+
+/* utils/coord.py:47-88 transform_coordinates on a batch: out[b,n,:] =
+ * rotate(grid[n], phi[b]) * scale[b] + shift[b,:].  phi / scale: (B) or NULL
+ * (0 / 1); shift: (B, coord_dim) or NULL.  */
+int pv_transform_coordinates(const float* grid, int64_t n_pix, int coord_dim, const float* phi,
+                             const float* shift, const float* scale, int64_t batch, float* out,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYROVED_AMD_H */

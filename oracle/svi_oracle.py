@@ -1,0 +1,335 @@
+"""
+oracle/svi_oracle.py — CPU restatement of pyroVED's SVI training hot path.
+
+TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+bench.py's `cpu_baseline` leg may import this module; the product package
+(pyroved_amd/) never does, and fails loudly when its HIP library is missing.
+
+What it restates (citations are /root/reference/pyroved/...):
+  generate_grid / imcoordgrid / grid2xy      utils/coord.py:7-44
+  transform_coordinates (+rotate, scale)     utils/coord.py:47-88
+  split_latent                               models/base.py:97-119
+  encoder_forward  (fcEncoderNet)            nets/fc.py:51-61, 307-324
+  sdecoder_forward (sDecoderNet+coord_latent) nets/fc.py:189-199, 220-237
+  fcdecoder_forward (fcDecoderNet)           nets/fc.py:143-152
+  elbo            (iVAE.guide + iVAE.model under Trace_ELBO)
+                                             models/ivae.py:165-221, utils/prob.py:25-29,
+                                             trainers/svi.py:79-91
+  SVIOracle.step  (SVI.step: loss, backward, per-parameter Adam, zero grads)
+                                             trainers/svi.py:104-113 + pyro-ppl (see below)
+  SVIOracle.train_epoch / evaluate_epoch     trainers/svi.py:95-137
+
+It is an eager, op-for-op torch-CPU restatement: the same torch ops the
+reference executes (F.linear, torch.bmm, tanh, torch.distributions.Normal /
+Bernoulli log_prob, torch.optim.Adam), so on CPU in fp32 it is bit-identical
+to the reference for everything that lives under /root/reference.  It is
+functional: parameters come in as a state_dict-keyed dict of tensors (key
+names of SURVEY §3.1), so it shares no code with the product's nn.Modules.
+
+Third-party arithmetic that is NOT under /root/reference: `pyro-ppl`, pinned
+by the reference only as `>=1.6.0` (setup.py:29, requirements.txt:3).  Its
+published algorithm on this path (Trace_ELBO with one particle: sampled
+log p(x|z) + beta*log p(z) - beta*log q(z|x), summed over the batch; SVI.step =
+backward + one torch.optim.Adam per parameter + grads zeroed to zero tensors)
+is restated here.
+
+Pinning status: the oracle is checked in tests/test_oracle_golden.py against
+fixtures produced by running the reference's OWN modules and its OWN
+SVItrainer in this container (tests/golden/make_golden.py).  The reference's
+nets / coordinate transform / split-latent / model()/guide() bodies /
+SVItrainer loop ran for real; the Pyro runtime underneath them was a minimal
+restatement (tests/golden/_minipyro.py) because pyro-ppl cannot be installed
+here.  So: PINNED for every function under /root/reference; PARITY UNPINNED at
+the Pyro boundary (Trace_ELBO / SVI / optim.Adam glue), where neither the
+reference's tests nor a runnable Pyro hold a number.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+import torch.distributions as td
+
+Params = Dict[str, torch.Tensor]
+
+
+@dataclass
+class Config:
+    data_dim: Tuple[int, ...]
+    latent_dim: int = 2
+    invariances: Optional[Sequence[str]] = None
+    c_dim: int = 0
+    n_hidden_e: int = 2            # number of hidden Linear layers in encoder_z.fc_layers
+    n_hidden_d: int = 2
+    activation: str = "tanh"
+    sampler: str = "bernoulli"
+    sigmoid_d: bool = True
+    dx_prior: float = 0.1
+    dy_prior: Optional[float] = None
+    sc_prior: float = 0.1
+    decoder_sig: float = 0.5
+
+    @property
+    def ndim(self):
+        return len(self.data_dim)
+
+    @property
+    def coord(self):
+        # models/base.py:56-67
+        if self.invariances is None:
+            return 0
+        c = len(self.invariances)
+        if "t" in self.invariances and self.ndim == 2:
+            c += 1
+        return c
+
+    @property
+    def z_dim(self):
+        return self.latent_dim + self.coord
+
+    @property
+    def n_pix(self):
+        n = 1
+        for d in self.data_dim:
+            n *= d
+        return n
+
+
+_ACT = {
+    "tanh": torch.tanh,
+    "relu": torch.relu,
+    "lrelu": lambda t: F.leaky_relu(t, 0.01),
+    "softplus": F.softplus,
+    "gelu": F.gelu,
+}
+
+
+# ---------------------------------------------------------------- coordinates
+def generate_grid(data_dim, dtype=torch.float32):
+    """utils/coord.py:21-44 (2-D rows n=i*W+j -> (xx[i], yy[j]); 1-D: (L,1))."""
+    if len(data_dim) == 1:
+        return torch.linspace(1, -1, data_dim[0])[:, None].to(dtype)
+    xx = torch.linspace(-1, 1, data_dim[0])
+    yy = torch.linspace(1, -1, data_dim[1])
+    x0, x1 = torch.meshgrid(xx, yy, indexing="ij")
+    return torch.stack((x0.reshape(-1), x1.reshape(-1)), 1).to(dtype)
+
+
+def transform_coordinates(coord, phi=0, coord_dx=0, scale=1.0):
+    """utils/coord.py:47-88: rotate -> scale -> translate; 1-D: translate only."""
+    if coord.shape[-1] == 1:
+        return coord + coord_dx
+    if not torch.is_tensor(phi) or torch.sum(phi) == 0:
+        phi = coord.new_zeros(coord.shape[0])
+    r1 = torch.stack([torch.cos(phi), torch.sin(phi)], 1)
+    r2 = torch.stack([-torch.sin(phi), torch.cos(phi)], 1)
+    rot = torch.stack([r1, r2], 1)
+    coord = torch.bmm(coord, rot)
+    sm = coord.new_zeros(coord.shape[0], 2, 2)
+    sm[:, 0, 0] = scale
+    sm[:, 1, 1] = scale
+    coord = torch.bmm(coord, sm)
+    return coord + coord_dx
+
+
+def split_latent(cfg: Config, z):
+    """models/base.py:97-119: [phi | dx,dy | s | content] regardless of list order."""
+    if cfg.ndim == 1:
+        return None, z[:, 0:1], None, z[:, 1:]
+    phi = z.new_tensor(0.0)
+    dx = z.new_tensor(0.0)
+    sc = z.new_tensor(1.0)
+    if "r" in cfg.invariances:
+        phi, z = z[:, 0], z[:, 1:]
+    if "t" in cfg.invariances:
+        dx, z = z[:, :2], z[:, 2:]
+    if "s" in cfg.invariances:
+        sc = sc + cfg.sc_prior * z[:, 0]
+        z = z[:, 1:]
+    return phi, dx, sc, z
+
+
+def t_prior(cfg: Config, like):
+    """models/base.py:73-77."""
+    dy = cfg.dx_prior if cfg.dy_prior is None else cfg.dy_prior
+    if cfg.ndim == 2:
+        return like.new_tensor([cfg.dx_prior, dy])
+    return like.new_tensor(cfg.dx_prior)
+
+
+# ---------------------------------------------------------------------- nets
+def _fc_stack(p: Params, prefix: str, n_layers: int, act, h):
+    # make_fc_layers: Sequential(Linear, act, Linear, act, ...) -> indices 0, 2, 4 (nets/fc.py:307-324)
+    for i in range(n_layers):
+        h = act(F.linear(h, p["%s.%d.weight" % (prefix, 2 * i)], p["%s.%d.bias" % (prefix, 2 * i)]))
+    return h
+
+
+def encoder_forward(p: Params, cfg: Config, x, y=None):
+    """fcEncoderNet.forward (nets/fc.py:51-61); Concat of [x, y] (utils/nn.py:62-74)."""
+    act = _ACT[cfg.activation]
+    h = x.reshape(x.shape[0], -1)
+    if y is not None:
+        h = torch.cat([h, y], -1)
+    h = _fc_stack(p, "encoder_z.fc_layers", cfg.n_hidden_e, act, h)
+    mu = F.linear(h, p["encoder_z.fc11.weight"], p["encoder_z.fc11.bias"])
+    sigma = F.softplus(F.linear(h, p["encoder_z.fc12.weight"], p["encoder_z.fc12.bias"]))
+    return mu, sigma
+
+
+def sdecoder_forward(p: Params, cfg: Config, x_coord, z):
+    """sDecoderNet.forward + coord_latent.forward (nets/fc.py:189-199, 220-237)."""
+    act = _ACT[cfg.activation]
+    b, n = x_coord.shape[:2]
+    h_x = F.linear(x_coord.reshape(b * n, -1), p["decoder.coord_latent.fc_coord.weight"],
+                   p["decoder.coord_latent.fc_coord.bias"]).reshape(b, n, -1)
+    h_z = F.linear(z, p["decoder.coord_latent.fc_latent.weight"])
+    h = torch.tanh((h_x + h_z.unsqueeze(1)).reshape(b * n, -1))     # coord_latent's tanh is hard-wired (fc.py:218)
+    h = _fc_stack(p, "decoder.fc_layers", cfg.n_hidden_d, act, h)
+    out = F.linear(h, p["decoder.out.weight"], p["decoder.out.bias"])
+    if cfg.sigmoid_d:
+        out = torch.sigmoid(out)
+    return out.view(-1, *cfg.data_dim)
+
+
+def fcdecoder_forward(p: Params, cfg: Config, z):
+    """fcDecoderNet.forward (nets/fc.py:143-152)."""
+    act = _ACT[cfg.activation]
+    h = _fc_stack(p, "decoder.fc_layers", cfg.n_hidden_d, act, z)
+    out = F.linear(h, p["decoder.out.weight"], p["decoder.out.bias"])
+    if cfg.sigmoid_d:
+        out = torch.sigmoid(out)
+    return out.view(-1, *cfg.data_dim)
+
+
+def decode_from_latent(p: Params, cfg: Config, z, y=None, grid=None):
+    """The decoder half of iVAE.model (models/ivae.py:184-198): split, transform, decode."""
+    b = z.shape[0]
+    if cfg.coord > 0:
+        if grid is None:
+            grid = generate_grid(cfg.data_dim, z.dtype)
+        phi, dx, sc, zc = split_latent(cfg, z)
+        if "t" in cfg.invariances:
+            dx = (dx * t_prior(cfg, z)).unsqueeze(1)
+        xc = transform_coordinates(grid.expand(b, *grid.shape), phi, dx, sc)
+        if y is not None:
+            zc = torch.cat([zc, y], -1)
+        return sdecoder_forward(p, cfg, xc, zc), xc
+    if y is not None:
+        z = torch.cat([z, y], -1)
+    return fcdecoder_forward(p, cfg, z), None
+
+
+def likelihood(cfg: Config, loc):
+    """utils/prob.py:25-29."""
+    if cfg.sampler == "bernoulli":
+        return td.Bernoulli(loc, validate_args=False)
+    if cfg.sampler == "continuous_bernoulli":
+        return td.ContinuousBernoulli(loc)
+    if cfg.sampler == "gaussian":
+        return td.Normal(loc, cfg.decoder_sig)
+    raise KeyError(cfg.sampler)
+
+
+# ---------------------------------------------------------------------- ELBO
+def elbo(p: Params, cfg: Config, x, eps, beta=1.0, y=None, grid=None):
+    """One-particle Trace_ELBO of iVAE.guide/model (models/ivae.py:165-221).
+
+    loss = -( sum_b log p(x_b|z_b) + beta*sum_b log N(z_b;0,1) - beta*sum_b log N(z_b;mu_b,sigma_b) ),
+    z = mu + sigma*eps (Normal.rsample), summed — not averaged — over the batch.
+    """
+    b = x.shape[0]
+    z_loc, z_scale = encoder_forward(p, cfg, x, y)
+    z = z_loc + z_scale * eps
+    logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)                      # guide site "latent"
+    logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)   # model site "latent"
+    loc, xc = decode_from_latent(p, cfg, z, y, grid)
+    ll = likelihood(cfg, loc.reshape(b, -1)).log_prob(x.reshape(b, -1)).sum(-1)     # model site "obs"
+    t_ll, t_lp, t_lq = ll.sum(), (beta * logp).sum(), (beta * logq).sum()
+    loss = -(t_ll + t_lp - t_lq)
+    return dict(loss=loss, ll=t_ll, logpz=t_lp, logqz=t_lq, z_loc=z_loc, z_scale=z_scale, z=z,
+                loc=loc, x_coord_prime=xc, ll_per_sample=ll)
+
+
+def param_order(p: Params, cfg: Config) -> List[str]:
+    """state_dict order == construction order."""
+    return list(p.keys())
+
+
+class SVIOracle:
+    """SVI.step restated: Trace_ELBO loss -> backward -> Adam(lr, betas=(0.9,0.999), eps=1e-8)
+    -> grads set to zero tensors.  `params` is updated in place; tensors are leaf
+    tensors owned by this object (cloned from the dict passed in)."""
+
+    def __init__(self, params: Params, cfg: Config, lr: float = 1e-3, dtype=torch.float32):
+        self.cfg = cfg
+        self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+        self.grid = generate_grid(cfg.data_dim, dtype) if cfg.coord > 0 else None
+        # one Adam over all tensors is elementwise-identical to Pyro's one-Adam-per-tensor
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)
+        self.dtype = dtype
+        self.last = None
+        self.last_grads = None
+
+    def loss_and_grads(self, x, eps, beta=1.0, y=None):
+        out = elbo(self.p, self.cfg, x.to(self.dtype), eps.to(self.dtype), beta,
+                   None if y is None else y.to(self.dtype), self.grid)
+        if out["loss"].requires_grad:
+            out["loss"].backward()
+        self.last = out
+        return out
+
+    def step(self, x, eps, beta=1.0, y=None) -> float:
+        out = self.loss_and_grads(x, eps, beta, y)
+        self.last_grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in self.p.items()}
+        # Under torch.no_grad() (SVItrainer.evaluate, trainers/svi.py:126-135) there is no backward,
+        # but the optimizer still runs on whatever .grad holds (zero tensors after any training step).
+        if any(v.grad is not None for v in self.p.values()):
+            self.opt.step()
+        for v in self.p.values():
+            if v.grad is not None:
+                v.grad = torch.zeros_like(v.grad)
+        return out["loss"].item()
+
+    def draw_eps(self, b):
+        """Normal.rsample's draw: torch.empty(shape).normal_() on the global CPU generator."""
+        return torch.empty(b, self.cfg.z_dim).normal_()
+
+    def train_epoch(self, loader, beta=1.0) -> float:
+        """SVItrainer.train (trainers/svi.py:95-115)."""
+        total = 0.0
+        for data in loader:
+            x = data[0]
+            y = data[1] if len(data) > 1 else None
+            total += self.step(x, self.draw_eps(x.shape[0]), beta, y)
+        return total / len(loader.dataset)
+
+    def evaluate_epoch(self, loader, beta=1.0) -> float:
+        """SVItrainer.evaluate (trainers/svi.py:117-137): svi.step under no_grad."""
+        total = 0.0
+        with torch.no_grad():
+            for data in loader:
+                x = data[0]
+                y = data[1] if len(data) > 1 else None
+                total += self.step(x, self.draw_eps(x.shape[0]), beta, y)
+        return total / len(loader.dataset)
+
+    # inference API (models/base.py:121-171, models/ivae.py:230-275)
+    def encode(self, x, y=None):
+        with torch.no_grad():
+            return encoder_forward(self.p, self.cfg, x.to(self.dtype), y)
+
+    def decode(self, z, y=None, angle=0.0, shift=0.0, scale=1.0):
+        cfg = self.cfg
+        with torch.no_grad():
+            z = z.to(self.dtype)
+            if y is not None:
+                z = torch.cat([z, y.to(self.dtype)], -1)
+            if cfg.coord > 0:
+                g = self.grid.unsqueeze(0)
+                a = torch.as_tensor(angle, dtype=self.dtype).reshape(1)
+                t = torch.as_tensor(shift, dtype=self.dtype).unsqueeze(0)
+                s = torch.as_tensor(scale, dtype=self.dtype).reshape(1)
+                g = transform_coordinates(g, a, t, s).squeeze(0)
+                return sdecoder_forward(self.p, cfg, g.expand(z.shape[0], *g.shape), z)
+            return fcdecoder_forward(self.p, cfg, z)

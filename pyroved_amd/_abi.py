@@ -1,0 +1,130 @@
+"""
+_abi.py — ctypes binding of libpyroved_amd.so (the C ABI declared in include/pyroved_amd.h).
+
+The library is the product's only compute path.  There is no CPU or pure-PyTorch
+fallback: `lib()` raises if the shared object is missing or does not export every
+symbol of the header, and every wrapper raises on a non-zero return code.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
+
+PV_ABI_VERSION = 1
+PV_MAX_LAYERS = 8
+
+# enum pv_act / pv_lik (include/pyroved_amd.h)
+ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "lrelu": 3, "softplus": 4, "gelu": 5, "sigmoid": 6}
+LIK = {"bernoulli": 0, "gaussian": 1}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyroved_amd.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class pv_layer(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32), ("_pad", C.c_int32),
+                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class pv_ivae_plan(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("n_pix", C.c_int32), ("coord_dim", C.c_int32), ("z_dim", C.c_int32),
+        ("latent_dim", C.c_int32), ("c_dim", C.c_int32),
+        ("has_r", C.c_int32), ("has_t", C.c_int32), ("has_s", C.c_int32),
+        ("t_prior", C.c_float * 2), ("sc_prior", C.c_float), ("beta", C.c_float),
+        ("lik", C.c_int32), ("sigmoid_out", C.c_int32), ("decoder_sig", C.c_float), ("fused", C.c_int32),
+        ("n_enc", C.c_int32), ("n_dec", C.c_int32),
+        ("enc", pv_layer * PV_MAX_LAYERS), ("head", pv_layer),
+        ("fc_coord", pv_layer), ("fc_latent", pv_layer),
+        ("dec", pv_layer * PV_MAX_LAYERS), ("out", pv_layer),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+        ("n_params", C.c_int64),
+        ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p), ("grid", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
+        ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+        ("adam_step", C.c_int32), ("_pad2", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); must list every function include/pyroved_amd.h declares
+SIGNATURES = {
+    "pv_version": (C.c_int, []),
+    "pv_ivae_workspace_bytes": (C.c_int64, [C.POINTER(pv_ivae_plan)]),
+    "pv_ivae_loss_and_grads": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
+    "pv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "pv_ivae_step": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p]),
+    "pv_ivae_encode": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_ivae_decode": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_void_p, C.c_void_p]),
+    "pv_linear_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "pv_linear_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                C.c_void_p]),
+    "pv_linear_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pv_transform_coordinates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class PvError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libpyroved_amd.so once.  Raises if it is missing or incomplete — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PvError(
+                "pyroved_amd: HIP library %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C pyroved_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise PvError("pyroved_amd: %s does not export %s" % (LIB_PATH, name)) from e
+            fn.restype = res
+            fn.argtypes = args
+        v = handle.pv_version()
+        if v != PV_ABI_VERSION:
+            raise PvError("pyroved_amd: ABI version mismatch (library %d, binding %d)" % (v, PV_ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        kind = "hipError_t" if code > 0 else {-1: "PV_EINVAL", -2: "PV_EWS"}.get(code, "PV error")
+        raise PvError("pyroved_amd: %s failed with %s (%d)" % (what, kind, code))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise PvError("pyroved_amd: %s must live on a HIP device (got %s); the compute path is GPU-only "
+                      "and has no CPU fallback" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise PvError("pyroved_amd: %s must be float32 (got %s)" % (what, t.dtype))
+
+
+def current_stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

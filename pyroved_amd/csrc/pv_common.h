@@ -1,0 +1,82 @@
+// pv_common.h — shared device helpers for libpyroved_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pyroved_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PV_LAUNCH_CHECK()                      \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+#define PV_TRY(expr)                           \
+  do {                                         \
+    int r__ = (expr);                          \
+    if (r__ != 0) return r__;                  \
+  } while (0)
+
+static inline int64_t pv_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// ---- activations (utils/nn.py:118-124) -------------------------------------------------------
+__device__ __forceinline__ float pv_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float pv_softplus(float x) {
+  // torch.nn.Softplus(beta=1, threshold=20)
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+
+__device__ __forceinline__ float pv_act_fwd(float x, int act) {
+  switch (act) {
+    case PV_ACT_TANH: return tanhf(x);
+    case PV_ACT_RELU: return x > 0.0f ? x : 0.0f;
+    case PV_ACT_LRELU: return x > 0.0f ? x : 0.01f * x;
+    case PV_ACT_SOFTPLUS: return pv_softplus(x);
+    case PV_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case PV_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    default: return x;
+  }
+}
+
+// derivative of the activation expressed through its output y (and, for GELU, its input).
+__device__ __forceinline__ float pv_act_grad(float y, float pre, int act) {
+  switch (act) {
+    case PV_ACT_TANH: return 1.0f - y * y;
+    case PV_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+    case PV_ACT_LRELU: return y > 0.0f ? 1.0f : 0.01f;
+    case PV_ACT_SOFTPLUS: return 1.0f - expf(-y);   // sigmoid(x) with y = softplus(x)
+    case PV_ACT_GELU:
+      return 0.5f * (1.0f + erff(pre * 0.70710678118654752440f)) +
+             pre * expf(-0.5f * pre * pre) * 0.39894228040143267794f;
+    case PV_ACT_SIGMOID: return y * (1.0f - y);
+    default: return 1.0f;
+  }
+}
+
+__device__ __forceinline__ float pv_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// internal launchers shared between translation units -------------------------------------------
+struct PvGemm {
+  const float* A; int64_t a_rs, a_cs;   // A(m,k) = A[m*a_rs + k*a_cs]
+  const float* B; int64_t b_rs, b_cs;   // B(k,n) = B[k*b_rs + n*b_cs]
+  float* C; int64_t ldc;                // C(m,n) = C[m*ldc + n]
+  int M, N, K;
+  const float* bias;                    // [N] or null
+  int act;                              // applied after bias
+  float* pre;                           // optional pre-activation store (ldc stride)
+  const float* aux; const float* auxpre; int64_t ldaux; int act_aux;   // C *= act'(aux)
+};
+// Runs C = epilogue(A*B).  splits > 1 => partial sums through ws (needs splits*M*N floats).
+int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t s);
+int pv_gemm_pick_splits(int M, int N, int K);
+// out[i] = sum_p part[p*stride + i], p ascending (deterministic)
+int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
+int pv_colsum(const float* x, int64_t ldx, int64_t M, int N, float* out, void* ws, int64_t ws_bytes, hipStream_t s);
+int64_t pv_colsum_ws(int64_t M, int N);

@@ -1,0 +1,539 @@
+// pv_elementwise.hip — the non-GEMM kernels of the iVAE SVI step (all HBM-/latency-bound):
+//   head_fwd      Normal.rsample + log q(z|x) + log p(z) + _split_latent      (ivae.py:179-189,217-221; base.py:97-119)
+//   coordlat_fwd  transform_coordinates fused into coord_latent's K=2 layer   (coord.py:47-88; fc.py:220-237)
+//   out_lik       decoder.out + sigmoid + likelihood log_prob + d/dlogit      (fc.py:196; prob.py:25-29)
+//   coordlat_bwd  backward of coordlat_fwd (dWc, dhz, d(phi,shift,scale))
+//   head_bwd      backward of head_fwd
+//   adam          torch.optim.Adam single-tensor update + zero_grads
+// Reductions are tree/ordered (no float atomics): results are bit-reproducible run to run.
+#include "pv_common.h"
+#include "pv_kernels.h"
+
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define BERN_EPS 1.1920928955078125e-07f   // torch.finfo(float32).eps used by clamp_probs
+
+// deterministic block-wide sum (blockDim.x == 256); result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats */) {
+  v = pv_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// head_fwd: one workgroup; B*z_dim elements.
+__global__ __launch_bounds__(256) void pv_head_fwd_kernel(PvHead h) {
+  __shared__ float sm[4];
+  const int total = h.B * h.z_dim;
+  float lp = 0.0f, lq = 0.0f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / h.z_dim, i = e % h.z_dim;
+    const float mu = h.head[(int64_t)b * 2 * h.z_dim + i];
+    const float sp = h.head[(int64_t)b * 2 * h.z_dim + h.z_dim + i];
+    const float sig = pv_softplus(sp);
+    const float ep = h.eps[e];
+    const float z = mu + sig * ep;
+    h.z[e] = z;
+    h.z_scale[e] = sig;
+    if (h.z_loc_out) h.z_loc_out[e] = mu;
+    if (h.z_scale_out) h.z_scale_out[e] = sig;
+    const float d = z - mu;
+    // torch.distributions.Normal.log_prob
+    lq += -(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI;
+    lp += -(z * z) / 2.0f - LOG_SQRT_2PI;
+  }
+  lp = block_sum_256(lp, sm);
+  lq = block_sum_256(lq, sm);
+  if (threadIdx.x == 0) {
+    h.scalars[2] = h.beta * lp;
+    h.scalars[3] = h.beta * lq;
+  }
+  __syncthreads();
+  // per-sample transform parameters (base.py:97-119, ivae.py:187-189) and decoder latent input
+  for (int b = threadIdx.x; b < h.B; b += 256) {
+    const float* zb = h.z + (int64_t)b * h.z_dim;
+    int idx = 0;
+    float c = 1.0f, s = 0.0f, sc = 1.0f, tx = 0.0f, ty = 0.0f;
+    if (h.coord_dim == 1) {
+      if (h.has_t) { tx = zb[0] * h.tp0; idx = 1; }
+    } else if (h.coord_dim == 2) {
+      if (h.has_r) { const float phi = zb[idx++]; c = cosf(phi); s = sinf(phi); }
+      if (h.has_t) { tx = zb[idx] * h.tp0; ty = zb[idx + 1] * h.tp1; idx += 2; }
+      if (h.has_s) { sc = 1.0f + h.sc_prior * zb[idx++]; }
+    }
+    if (h.tp) {
+      float* t = h.tp + (int64_t)b * 8;
+      t[0] = c; t[1] = s; t[2] = sc; t[3] = tx; t[4] = ty;
+    }
+    if (h.zy) {   // cat([z_content, y]) (ivae.py:194-195)
+      const int L = h.z_dim - idx;
+      float* o = h.zy + (int64_t)b * (L + h.c_dim);
+      for (int i = 0; i < L; ++i) o[i] = zb[idx + i];
+      for (int i = 0; i < h.c_dim; ++i) o[L + i] = h.y[(int64_t)b * h.c_dim + i];
+    }
+  }
+}
+
+int pv_head_fwd(const PvHead& h, hipStream_t s) {
+  hipLaunchKernelGGL(pv_head_fwd_kernel, dim3(1), dim3(256), 0, s, h);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// fills identical transform parameters for every sample (baseVAE._decode: angle/shift/scale kwargs)
+__global__ void pv_fill_tp_kernel(float* tp, int B, float c, float s, float sc, float tx, float ty) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    float* t = tp + (int64_t)b * 8;
+    t[0] = c; t[1] = s; t[2] = sc; t[3] = tx; t[4] = ty;
+  }
+}
+
+int pv_fill_tp(float* tp, int B, float angle, float sc, float tx, float ty, hipStream_t s) {
+  hipLaunchKernelGGL(pv_fill_tp_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tp, B, cosf(angle), sinf(angle), sc,
+                     tx, ty);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[b, :] = cat(a[b, :na], y[b, :nb])
+__global__ void pv_concat_kernel(const float* a, int64_t lda, int na, const float* y, int64_t ldy, int nb, float* out,
+                                 int64_t B) {
+  const int w = na + nb;
+  const int64_t total = B * w;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / w;
+    const int i = (int)(e % w);
+    out[e] = i < na ? a[b * lda + i] : y[b * ldy + (i - na)];
+  }
+}
+
+int pv_concat(const float* a, int64_t lda, int na, const float* y, int64_t ldy, int nb, float* out, int64_t B,
+              hipStream_t s) {
+  const int64_t total = B * (na + nb);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(pv_concat_kernel, dim3(blocks), dim3(256), 0, s, a, lda, na, y, ldy, nb, out, B);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transformed coordinate of flattened row (b, n):  x' = (grid[n] . R(phi_b)) * s_b + shift_b
+__device__ __forceinline__ void pv_xprime(const float* __restrict__ grid, int cd, int n, const float* __restrict__ t,
+                                          float& x0, float& x1, float& u0, float& u1) {
+  if (cd == 2) {
+    const float gx = grid[2 * n], gy = grid[2 * n + 1];
+    u0 = gx * t[0] - gy * t[1];      // coord.py:71-74: [x y] @ [[c, s], [-s, c]]
+    u1 = gx * t[1] + gy * t[0];
+    x0 = u0 * t[2] + t[3];
+    x1 = u1 * t[2] + t[4];
+  } else {
+    u0 = grid[n]; u1 = 0.0f;
+    x0 = u0 + t[3]; x1 = 0.0f;      // coord.py:56-57: 1-D grids only translate
+  }
+}
+
+#define CL_ROWS 32
+__global__ __launch_bounds__(256) void pv_coordlat_fwd_kernel(PvCoordLat p) {
+  __shared__ float xs[CL_ROWS][2];
+  __shared__ int bs[CL_ROWS];
+  const int64_t r0 = (int64_t)blockIdx.x * CL_ROWS;
+  const int t = threadIdx.x;
+  if (t < CL_ROWS) {
+    const int64_t row = r0 + t;
+    if (row < p.M) {
+      const int b = (int)(row / p.N), n = (int)(row % p.N);
+      float x0, x1, u0, u1;
+      pv_xprime(p.grid, p.cd, n, p.tp + (int64_t)b * 8, x0, x1, u0, u1);
+      xs[t][0] = x0; xs[t][1] = x1; bs[t] = b;
+    }
+  }
+  __syncthreads();
+  const int H = p.H0;
+  for (int e = t; e < CL_ROWS * H; e += 256) {
+    const int r = e / H, j = e % H;
+    const int64_t row = r0 + r;
+    if (row >= p.M) break;
+    float v = p.Wc[j * p.cd] * xs[r][0];
+    if (p.cd == 2) v += p.Wc[j * 2 + 1] * xs[r][1];
+    v += p.bc[j];
+    v += p.hz[(int64_t)bs[r] * H + j];
+    p.h0[row * H + j] = tanhf(v);      // coord_latent's activation is hard-wired tanh (fc.py:218)
+  }
+}
+
+int pv_coordlat_fwd(const PvCoordLat& p, hipStream_t s) {
+  const int64_t blocks = (p.M + CL_ROWS - 1) / CL_ROWS;
+  hipLaunchKernelGGL(pv_coordlat_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// standalone utils.transform_coordinates (coord.py:47-60)
+__global__ void pv_transform_kernel(const float* grid, int64_t N, int cd, const float* phi, const float* shift,
+                                    const float* scale, int64_t B, float* out) {
+  const int64_t total = B * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / N;
+    const int n = (int)(e % N);
+    if (cd == 1) {
+      out[e] = grid[n] + (shift ? shift[b] : 0.0f);
+    } else {
+      const float ph = phi ? phi[b] : 0.0f, sc = scale ? scale[b] : 1.0f;
+      const float c = cosf(ph), s = sinf(ph);
+      const float gx = grid[2 * n], gy = grid[2 * n + 1];
+      out[2 * e] = (gx * c - gy * s) * sc + (shift ? shift[2 * b] : 0.0f);
+      out[2 * e + 1] = (gx * s + gy * c) * sc + (shift ? shift[2 * b + 1] : 0.0f);
+    }
+  }
+}
+
+extern "C" int pv_transform_coordinates(const float* grid, int64_t n_pix, int coord_dim, const float* phi,
+                                        const float* shift, const float* scale, int64_t batch, float* out,
+                                        void* stream) {
+  if (coord_dim != 1 && coord_dim != 2) return PV_EINVAL;
+  const int64_t total = batch * n_pix;
+  if (total <= 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pv_transform_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grid, n_pix, coord_dim, phi,
+                     shift, scale, batch, out);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out_lik: a = h . wo + bo ; likelihood ; dL/da ; dpre of the last hidden layer ; partial dwo/dbo
+#define OL_ROWS 64
+#define OL_MAXJ 8     // supports hidden widths up to 512
+__global__ __launch_bounds__(256) void pv_out_lik_kernel(PvOutLik p) {
+  __shared__ float red[4][64 * OL_MAXJ];
+  __shared__ float redb[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = p.H;
+  float wo[OL_MAXJ], acc[OL_MAXJ];
+#pragma unroll
+  for (int jj = 0; jj < OL_MAXJ; ++jj) {
+    const int j = lane + 64 * jj;
+    wo[jj] = j < H ? p.wo[j] : 0.0f;
+    acc[jj] = 0.0f;
+  }
+  const float bo = p.bo ? p.bo[0] : 0.0f;
+  float accb = 0.0f;
+  const int64_t rbeg = (int64_t)blockIdx.x * OL_ROWS + wave * (OL_ROWS / 4);
+  for (int i = 0; i < OL_ROWS / 4; ++i) {
+    const int64_t row = rbeg + i;
+    if (row >= p.M) break;
+    const float* hr = p.h + row * p.ldh;
+    float hv[OL_MAXJ];
+    float dot = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < OL_MAXJ; ++jj) {
+      const int j = lane + 64 * jj;
+      hv[jj] = j < H ? hr[j] : 0.0f;
+      dot += hv[jj] * wo[jj];
+    }
+    const float a = pv_wave_sum(dot) + bo;
+    const float x = p.x[row];
+    float ll, dlda, locv;
+    if (p.lik == PV_LIK_BERNOULLI) {
+      // torch.distributions.Bernoulli(probs=sigmoid(a), validate_args=False).log_prob(x):
+      //   probs -> clamp_probs -> logits = log(p) - log1p(-p) -> -BCEWithLogits(logits, x)
+      const float pr = 1.0f / (1.0f + expf(-a));
+      const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
+      const float lg = logf(pc) - log1pf(-pc);
+      ll = -(fmaxf(lg, 0.0f) - lg * x + log1pf(expf(-fabsf(lg))));
+      const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;   // clamp's gradient
+      dlda = (1.0f / (1.0f + expf(-lg)) - x) * mask;
+      locv = pr;
+    } else {
+      const float pr = p.sigmoid_out ? 1.0f / (1.0f + expf(-a)) : a;
+      const float d = x - pr;
+      ll = -(d * d) / (2.0f * p.sig * p.sig) - logf(p.sig) - LOG_SQRT_2PI;
+      dlda = -d / (p.sig * p.sig) * (p.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+      locv = pr;
+    }
+    if (lane == 0) {
+      if (p.llrow) p.llrow[row] = ll;
+      if (p.loc) p.loc[row] = locv;
+    }
+    if (p.dpre) {
+      float* dr = p.dpre + row * p.ldh;
+      const float* pr_ = p.hpre ? p.hpre + row * p.ldh : nullptr;
+#pragma unroll
+      for (int jj = 0; jj < OL_MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j < H) {
+          dr[j] = dlda * wo[jj] * pv_act_grad(hv[jj], pr_ ? pr_[j] : 0.0f, p.act_last);
+          acc[jj] += dlda * hv[jj];
+        }
+      }
+      accb += dlda;
+    }
+  }
+  if (!p.dpre) return;
+#pragma unroll
+  for (int jj = 0; jj < OL_MAXJ; ++jj) red[wave][lane + 64 * jj] = acc[jj];
+  if (lane == 0) redb[wave] = accb;
+  __syncthreads();
+  for (int j = threadIdx.x; j < H; j += 256)
+    p.part_dwo[(int64_t)blockIdx.x * H + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  if (threadIdx.x == 0) p.part_dbo[blockIdx.x] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
+}
+
+int64_t pv_out_lik_blocks(int64_t M) { return (M + OL_ROWS - 1) / OL_ROWS; }
+
+int pv_out_lik(const PvOutLik& p, hipStream_t s) {
+  if (p.H > 64 * OL_MAXJ) return PV_EINVAL;
+  hipLaunchKernelGGL(pv_out_lik_kernel, dim3((unsigned)pv_out_lik_blocks(p.M)), dim3(256), 0, s, p);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// per-sample sums: out[b] = sum_n v[b*N + n]; then scalars (one workgroup per sample, tree-ordered)
+__global__ __launch_bounds__(256) void pv_segsum_kernel(const float* __restrict__ v, int64_t N, float* __restrict__ out) {
+  __shared__ float sm[4];
+  const float* vb = v + (int64_t)blockIdx.x * N;
+  float a = 0.0f;
+  for (int64_t n = threadIdx.x; n < N; n += 256) a += vb[n];
+  a = block_sum_256(a, sm);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
+int pv_segsum(const float* v, int64_t nseg, int64_t N, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pv_segsum_kernel, dim3((unsigned)nseg), dim3(256), 0, s, v, N, out);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// scalars[1] = sum_b ll_b ; scalars[0] = -(ll + beta*logp - beta*logq)
+__global__ __launch_bounds__(256) void pv_finish_scalars_kernel(const float* __restrict__ llb, int B, float* scalars) {
+  __shared__ float sm[4];
+  float a = 0.0f;
+  for (int b = threadIdx.x; b < B; b += 256) a += llb[b];
+  a = block_sum_256(a, sm);
+  if (threadIdx.x == 0) {
+    scalars[1] = a;
+    scalars[0] = -(a + scalars[2] - scalars[3]);
+  }
+}
+
+int pv_finish_scalars(const float* llb, int B, float* scalars, hipStream_t s) {
+  hipLaunchKernelGGL(pv_finish_scalars_kernel, dim3(1), dim3(256), 0, s, llb, B, scalars);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// coordlat_bwd: given dpre0[M,H0] (= dL/d(pre-tanh of coord_latent)), per (sample, row-chunk):
+//   part_hz[b,c,j]   = sum_rows dpre0[row,j]                      -> dhz (and dbc)
+//   part_wc[b,c,j,k] = sum_rows dpre0[row,j] * x'[row,k]          -> dWc
+//   part_tp[b,c,0:4] = sum_rows (dphi, dscale, dtx, dty)          -> d(latent coordinates)
+#define CB_MAXJ 8
+__global__ __launch_bounds__(256) void pv_coordlat_bwd_kernel(PvCoordLatBwd p) {
+  __shared__ float red[4][64 * CB_MAXJ * 3];
+  __shared__ float redt[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, c = blockIdx.x, H = p.H0;
+  const int n_beg = c * p.rows_per_chunk;
+  const int n_end = min(p.N, n_beg + p.rows_per_chunk);
+  const float* t = p.tp + (int64_t)b * 8;
+  float w0[CB_MAXJ], w1[CB_MAXJ], sj[CB_MAXJ], sx[CB_MAXJ], sy[CB_MAXJ];
+#pragma unroll
+  for (int jj = 0; jj < CB_MAXJ; ++jj) {
+    const int j = lane + 64 * jj;
+    w0[jj] = j < H ? p.Wc[j * p.cd] : 0.0f;
+    w1[jj] = (j < H && p.cd == 2) ? p.Wc[j * 2 + 1] : 0.0f;
+    sj[jj] = sx[jj] = sy[jj] = 0.0f;
+  }
+  float dphi = 0.0f, dsc = 0.0f, dtx = 0.0f, dty = 0.0f;
+  for (int n = n_beg + wave; n < n_end; n += 4) {
+    const int64_t row = (int64_t)b * p.N + n;
+    float x0, x1, u0, u1;
+    pv_xprime(p.grid, p.cd, n, t, x0, x1, u0, u1);
+    const float* dr = p.dpre0 + row * H;
+    float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < CB_MAXJ; ++jj) {
+      const int j = lane + 64 * jj;
+      const float v = j < H ? dr[j] : 0.0f;
+      sj[jj] += v; sx[jj] += v * x0; sy[jj] += v * x1;
+      d0 += v * w0[jj]; d1 += v * w1[jj];
+    }
+    d0 = pv_wave_sum(d0);
+    d1 = pv_wave_sum(d1);
+    // x'0 = s*u0 + tx, x'1 = s*u1 + ty ; du0/dphi = -u1, du1/dphi = u0
+    dphi += t[2] * (d1 * u0 - d0 * u1);
+    dsc += d0 * u0 + d1 * u1;
+    dtx += d0; dty += d1;
+  }
+#pragma unroll
+  for (int jj = 0; jj < CB_MAXJ; ++jj) {
+    red[wave][(lane + 64 * jj) * 3 + 0] = sj[jj];
+    red[wave][(lane + 64 * jj) * 3 + 1] = sx[jj];
+    red[wave][(lane + 64 * jj) * 3 + 2] = sy[jj];
+  }
+  if (lane == 0) { redt[wave][0] = dphi; redt[wave][1] = dsc; redt[wave][2] = dtx; redt[wave][3] = dty; }
+  __syncthreads();
+  const int64_t pc = (int64_t)b * gridDim.x + c;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    float v[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = (red[0][j * 3 + q] + red[1][j * 3 + q]) + (red[2][j * 3 + q] + red[3][j * 3 + q]);
+    p.part_hz[pc * H + j] = v[0];
+    p.part_wc[(pc * H + j) * p.cd] = v[1];
+    if (p.cd == 2) p.part_wc[(pc * H + j) * 2 + 1] = v[2];
+  }
+  if (threadIdx.x < 4)
+    p.part_tp[pc * 4 + threadIdx.x] =
+        (redt[0][threadIdx.x] + redt[1][threadIdx.x]) + (redt[2][threadIdx.x] + redt[3][threadIdx.x]);
+}
+
+int pv_coordlat_bwd(const PvCoordLatBwd& p, int nchunk, int B, hipStream_t s) {
+  if (p.H0 > 64 * CB_MAXJ) return PV_EINVAL;
+  hipLaunchKernelGGL(pv_coordlat_bwd_kernel, dim3(nchunk, B), dim3(256), 0, s, p);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[b, i] = sum_c part[(b*nc + c)*n + i]  (ordered)
+__global__ void pv_reduce_mid_kernel(const float* __restrict__ part, int nb, int nc, int n, float* __restrict__ out) {
+  const int64_t total = (int64_t)nb * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / n;
+    const int i = (int)(e % n);
+    float v = 0.0f;
+    for (int c = 0; c < nc; ++c) v += part[(b * nc + c) * n + i];
+    out[e] = v;
+  }
+}
+
+int pv_reduce_mid(const float* part, int nb, int nc, int n, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)nb * n;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(pv_reduce_mid_kernel, dim3(blocks), dim3(256), 0, s, part, nb, nc, n, out);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// head_bwd: dL/d(mu), dL/d(softplus input) from the decoder's dL/dz and the sampled-KL terms.
+__global__ void pv_head_bwd_kernel(PvHeadBwd h) {
+  const int total = h.B * h.z_dim;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int b = e / h.z_dim, i = e % h.z_dim;
+  float dz;
+  if (h.coord_dim == 0) {
+    dz = h.dzc[(int64_t)b * h.ldzc + i];
+  } else {
+    const float* tpg = h.dtp + (int64_t)b * 4;      // dphi, dscale, dtx, dty
+    int idx = 0;
+    dz = 0.0f;
+    bool done = false;
+    if (h.coord_dim == 1) {
+      if (h.has_t) { if (i == 0) { dz = tpg[2] * h.tp0; done = true; } idx = 1; }
+    } else {
+      if (h.has_r) { if (i == idx) { dz = tpg[0]; done = true; } idx += 1; }
+      if (h.has_t) {
+        if (i == idx) { dz = tpg[2] * h.tp0; done = true; }
+        if (i == idx + 1) { dz = tpg[3] * h.tp1; done = true; }
+        idx += 2;
+      }
+      if (h.has_s) { if (i == idx) { dz = tpg[1] * h.sc_prior; done = true; } idx += 1; }
+    }
+    if (!done) dz = h.dzc[(int64_t)b * h.ldzc + (i - idx)];
+  }
+  const float z = h.z[e], sig = h.z_scale[e], ep = h.eps[e];
+  const float sp = h.head[(int64_t)b * 2 * h.z_dim + h.z_dim + i];
+  const float g = dz + h.beta * z;                 // d(-ll - beta*log p(z))/dz
+  const float dsig = g * ep - h.beta / sig;        // + beta * d(log q)/d(sigma) (total derivative)
+  const float sgm = sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp));   // softplus'
+  h.dhead[(int64_t)b * 2 * h.z_dim + i] = g;
+  h.dhead[(int64_t)b * 2 * h.z_dim + h.z_dim + i] = dsig * sgm;
+}
+
+int pv_head_bwd(const PvHeadBwd& h, hipStream_t s) {
+  const int total = h.B * h.z_dim;
+  hipLaunchKernelGGL(pv_head_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, h);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// torch.optim.Adam (single-tensor form, no amsgrad / weight decay) + zero_grads
+__global__ void pv_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                               float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
+                               float bc2_sqrt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * b2 + (1.0f - b2) * gi * gi;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m[i] = mi; v[i] = vi;
+    g[i] = 0.0f;                                       // pyro.infer.util.zero_grads
+  }
+}
+
+extern "C" int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int32_t step, void* stream) {
+  if (n <= 0) return 0;
+  if (step < 1) return PV_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pv_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, beta1,
+                     beta2, eps, step_size, bc2_sqrt);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise likelihood for the vanilla fcDecoderNet path (fc.py:143-152): a[M] logits -> loc, ll, dL/da
+__global__ void pv_lik_elem_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t M, int lik,
+                                   int sigmoid_out, float sig, float* __restrict__ loc, float* __restrict__ llrow,
+                                   float* __restrict__ dlda) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M; e += (int64_t)gridDim.x * blockDim.x) {
+    const float av = a[e], xv = x[e];
+    float ll, d, lv;
+    if (lik == PV_LIK_BERNOULLI) {
+      const float pr = 1.0f / (1.0f + expf(-av));
+      const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
+      const float lg = logf(pc) - log1pf(-pc);
+      ll = -(fmaxf(lg, 0.0f) - lg * xv + log1pf(expf(-fabsf(lg))));
+      const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
+      d = (1.0f / (1.0f + expf(-lg)) - xv) * mask;
+      lv = pr;
+    } else {
+      const float pr = sigmoid_out ? 1.0f / (1.0f + expf(-av)) : av;
+      const float df = xv - pr;
+      ll = -(df * df) / (2.0f * sig * sig) - logf(sig) - LOG_SQRT_2PI;
+      d = -df / (sig * sig) * (sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+      lv = pr;
+    }
+    if (loc) loc[e] = lv;
+    if (llrow) llrow[e] = ll;
+    if (dlda) dlda[e] = d;
+  }
+}
+
+int pv_lik_elem(const float* a, const float* x, int64_t M, int lik, int sigmoid_out, float sig, float* loc,
+                float* llrow, float* dlda, hipStream_t s) {
+  int blocks = (int)((M + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(pv_lik_elem_kernel, dim3(blocks), dim3(256), 0, s, a, x, M, lik, sigmoid_out, sig, loc, llrow,
+                     dlda);
+  PV_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,242 @@
+// pv_gemm.hip — generic fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), with the
+// fused epilogues the Linear(+activation) layers of pyroVED's fc nets need (nets/fc.py:307-324).
+//
+// This is the GENERAL path: any layer width, any of the reference's activations, any batch.
+// The default-architecture hot loop (sDecoderNet 128-128, tanh) has its own fused persistent
+// kernel in pv_sdec_fused.hip; this file serves the encoder, the heads, non-default hidden sizes,
+// and is the layer-by-layer cross-check of the fused kernel.
+//
+// Tiling: 64x64 output tile per 256-thread workgroup (4 waves, 2x2, one 32x32 MFMA block each),
+// K advanced 16 at a time through LDS (k-major images, row stride 66 floats so both the k-contiguous
+// and the m-contiguous global layouts stage without >2-way ds_write conflicts and every MFMA operand
+// read is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave).  Operands are
+// described by (row stride, col stride) so NT (forward), NN (dgrad) and TN (wgrad) share the kernel.
+// fp32 MFMA == an fmaf chain bit-for-bit, so results are exact-fp32-class (no TF32 on gfx950).
+#include "pv_common.h"
+
+#define GT 64      // tile edge
+#define GK 16      // k per stage
+#define GLD 66     // LDS row stride (floats)
+
+template <bool KCONTIG>   // true: the k index is the contiguous one in global memory
+__device__ __forceinline__ void g_load(const float* __restrict__ P, int64_t rs, int64_t cs, int x0, int xlim,
+                                       int k0, int klim, bool vec, int t, float (&r)[4]) {
+  // tile is 64 (x: m or n) by 16 (k).  P(x,k) = P[x*rs + k*cs]
+  if (KCONTIG) {
+    const int x = x0 + (t >> 2), k = k0 + (t & 3) * 4;
+    const float* p = P + (int64_t)x * rs + k;
+    if (x < xlim && k + 3 < klim && vec) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = (x < xlim && k + i < klim) ? p[(int64_t)i * cs] : 0.0f;
+    }
+  } else {
+    const int k = k0 + (t >> 4), x = x0 + (t & 15) * 4;
+    const float* p = P + (int64_t)k * cs + (int64_t)x * rs;
+    if (k < klim && x + 3 < xlim && vec) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = (k < klim && x + i < xlim) ? p[(int64_t)i * rs] : 0.0f;
+    }
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void g_store_lds(float (*S)[GLD], int t, const float (&r)[4]) {
+  if (KCONTIG) {
+    const int x = t >> 2, k = (t & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[k + i][x] = r[i];
+  } else {
+    const int k = t >> 4, x = (t & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[k][x + i] = r[i];
+  }
+}
+
+struct GemmK {
+  PvGemm g;
+  int k_chunk;
+  float* part;     // != null: raw partial sums part[z][M][N]
+  int a_vec, b_vec;
+};
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
+  __shared__ float As[GK][GLD];
+  __shared__ float Bs[GK][GLD];
+  const PvGemm& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
+  const int kbeg = blockIdx.z * p.k_chunk;
+  const int kend = min(g.K, kbeg + p.k_chunk);
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+  float ra[4], rb[4];
+  if (kbeg < kend) {
+    g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, kbeg, kend, p.a_vec, t, ra);
+    g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, kbeg, kend, p.b_vec, t, rb);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    g_store_lds<AK>(As, t, ra);
+    g_store_lds<BK>(Bs, t, rb);
+    __syncthreads();
+    if (k0 + GK < kend) {
+      g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, k0 + GK, kend, p.a_vec, t, ra);
+      g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, k0 + GK, kend, p.b_vec, t, rb);
+    }
+    const int i = lane & 31, kk = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < GK / 2; ++ks) {
+      const float a = As[2 * ks + kk][wm * 32 + i];
+      const float b = Bs[2 * ks + kk][wn * 32 + i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int n = n0 + wn * 32 + (lane & 31);
+  if (n >= g.N) return;
+  const float bias = (g.bias && !p.part) ? g.bias[n] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m >= g.M) continue;
+    float v = acc[r];
+    if (p.part) {
+      p.part[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+    } else {
+      v += bias;
+      if (g.pre) g.pre[(int64_t)m * g.ldc + n] = v;
+      v = pv_act_fwd(v, g.act);
+      if (g.aux) {
+        const float y = g.aux[(int64_t)m * g.ldaux + n];
+        const float pr = g.auxpre ? g.auxpre[(int64_t)m * g.ldaux + n] : 0.0f;
+        v *= pv_act_grad(y, pr, g.act_aux);
+      }
+      g.C[(int64_t)m * g.ldc + n] = v;
+    }
+  }
+}
+
+// sums the split-K partials in ascending split order (deterministic) and applies the epilogue
+__global__ __launch_bounds__(256) void pv_gemm_finish_kernel(GemmK p, int splits) {
+  const PvGemm& g = p.g;
+  const int64_t total = (int64_t)g.M * g.N;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / g.N), n = (int)(e % g.N);
+    float v = 0.0f;
+    for (int z = 0; z < splits; ++z) v += p.part[(int64_t)z * total + e];
+    if (g.bias) v += g.bias[n];
+    if (g.pre) g.pre[(int64_t)m * g.ldc + n] = v;
+    v = pv_act_fwd(v, g.act);
+    if (g.aux) {
+      const float y = g.aux[(int64_t)m * g.ldaux + n];
+      const float pr = g.auxpre ? g.auxpre[(int64_t)m * g.ldaux + n] : 0.0f;
+      v *= pv_act_grad(y, pr, g.act_aux);
+    }
+    g.C[(int64_t)m * g.ldc + n] = v;
+  }
+}
+
+int pv_gemm_pick_splits(int M, int N, int K) {
+  // aim for >= ~512 workgroups (2 per CU) when the contraction is long enough to split
+  const int64_t tiles = (int64_t)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+  if (tiles >= 512 || K <= 4 * GK) return 1;
+  int64_t s = (512 + tiles - 1) / tiles;
+  const int64_t maxs = (K + 4 * GK - 1) / (4 * GK);     // at least 64 of k per split
+  if (s > maxs) s = maxs;
+  if (s > 1024) s = 1024;
+  return (int)(s < 1 ? 1 : s);
+}
+
+int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0) return 0;
+  if (g.K <= 0) return PV_EINVAL;
+  GemmK p;
+  p.g = g;
+  if (splits < 1) splits = 1;
+  int k_chunk = (g.K + splits - 1) / splits;
+  k_chunk = (k_chunk + GK - 1) / GK * GK;           // keep split boundaries on stage boundaries
+  splits = (g.K + k_chunk - 1) / k_chunk;
+  p.k_chunk = k_chunk;
+  p.part = nullptr;
+  if (splits > 1) {
+    const int64_t need = (int64_t)splits * g.M * g.N * (int64_t)sizeof(float);
+    if (!ws || ws_bytes < need) return PV_EWS;
+    p.part = (float*)ws;
+  }
+  const bool ak = (g.a_cs == 1), bk = (g.b_rs == 1);
+  // 16-byte vector loads need an aligned base and a stride that keeps rows aligned
+  auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  p.a_vec = al(g.A) && (ak ? (g.a_rs % 4 == 0) : (g.a_rs == 1 && g.a_cs % 4 == 0));
+  p.b_vec = al(g.B) && (bk ? (g.b_cs % 4 == 0) : (g.b_cs == 1 && g.b_rs % 4 == 0));
+  dim3 grid((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, splits);
+  if (grid.y > 65535) return PV_EINVAL;
+  if (ak && bk) hipLaunchKernelGGL((pv_gemm_kernel<true, true>), grid, dim3(256), 0, s, p);
+  else if (ak && !bk) hipLaunchKernelGGL((pv_gemm_kernel<true, false>), grid, dim3(256), 0, s, p);
+  else if (!ak && bk) hipLaunchKernelGGL((pv_gemm_kernel<false, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((pv_gemm_kernel<false, false>), grid, dim3(256), 0, s, p);
+  PV_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t total = (int64_t)g.M * g.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pv_gemm_finish_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
+    PV_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- deterministic reductions ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void pv_reduce_partials_kernel(const float* __restrict__ part, int nparts,
+                                                                 int64_t stride, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = 0.0f;
+    for (int q = 0; q < nparts; ++q) v += part[(int64_t)q * stride + i];
+    out[i] = v;
+  }
+}
+
+int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pv_reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, stride, out, n);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// column sums of x[M,N] (bias gradients): row-chunked partials, then the ordered reduction above
+#define CS_ROWS 256
+__global__ __launch_bounds__(256) void pv_colsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int N,
+                                                        float* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+  const int64_t r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float v = 0.0f;
+    for (int64_t r = r0; r < r1; ++r) v += x[r * ldx + n];
+    part[(int64_t)blockIdx.x * N + n] = v;
+  }
+}
+
+int64_t pv_colsum_ws(int64_t M, int N) { return ((M + CS_ROWS - 1) / CS_ROWS) * (int64_t)N * (int64_t)sizeof(float); }
+
+int pv_colsum(const float* x, int64_t ldx, int64_t M, int N, float* out, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (N <= 0) return 0;
+  const int64_t chunks = (M + CS_ROWS - 1) / CS_ROWS;
+  if (chunks <= 0) return PV_EINVAL;
+  if (!ws || ws_bytes < pv_colsum_ws(M, N)) return PV_EWS;
+  hipLaunchKernelGGL(pv_colsum_kernel, dim3((unsigned)chunks), dim3(256), 0, s, x, ldx, M, N, (float*)ws);
+  PV_LAUNCH_CHECK();
+  return pv_reduce_partials((const float*)ws, (int)chunks, N, out, N, s);
+}

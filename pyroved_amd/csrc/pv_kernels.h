@@ -1,0 +1,85 @@
+// pv_kernels.h — argument blocks and host launchers of the non-GEMM kernels (pv_elementwise.hip).
+#pragma once
+#include "pv_common.h"
+
+struct PvHead {
+  const float* head;     // (B, 2*z_dim): [mu | softplus input]  (fc11 | fc12 of fcEncoderNet, fc.py:59-60)
+  const float* eps;      // (B, z_dim)
+  const float* y;        // (B, c_dim) or null
+  float* z;              // (B, z_dim)
+  float* z_scale;        // (B, z_dim)
+  float* z_loc_out;      // optional copies for the caller
+  float* z_scale_out;
+  float* tp;             // (B, 8): cos, sin, scale, tx, ty  (null when coord_dim == 0)
+  float* zy;             // (B, latent + c_dim) decoder latent input when c_dim > 0, else null
+  float* scalars;        // [.., .., beta*logp, beta*logq]
+  int B, z_dim, c_dim, coord_dim, has_r, has_t, has_s;
+  float tp0, tp1, sc_prior, beta;
+};
+int pv_head_fwd(const PvHead& h, hipStream_t s);
+int pv_fill_tp(float* tp, int B, float angle, float sc, float tx, float ty, hipStream_t s);
+int pv_concat(const float* a, int64_t lda, int na, const float* y, int64_t ldy, int nb, float* out, int64_t B,
+              hipStream_t s);
+
+struct PvCoordLat {
+  const float* grid;     // (N, cd)
+  const float* tp;       // (B, 8)
+  const float* Wc;       // (H0, cd)  decoder.coord_latent.fc_coord.weight
+  const float* bc;       // (H0)
+  const float* hz;       // (B, H0) = fc_latent(z)
+  float* h0;             // (M, H0)
+  int64_t M;
+  int N, cd, H0;
+};
+int pv_coordlat_fwd(const PvCoordLat& p, hipStream_t s);
+
+struct PvOutLik {
+  const float* h;        // (M, H) last hidden activation
+  const float* hpre;     // its pre-activation (GELU only) or null
+  int64_t ldh;
+  const float* wo;       // (H)  decoder.out.weight (1, H)
+  const float* bo;       // (1)
+  const float* x;        // (M) observations
+  float* loc;            // (M) or null
+  float* llrow;          // (M) or null
+  float* dpre;           // (M, H) dL/d(pre-activation of the last hidden layer), or null (no grads)
+  float* part_dwo;       // (blocks, H)
+  float* part_dbo;       // (blocks)
+  int64_t M;
+  int H, lik, sigmoid_out, act_last;
+  float sig;
+};
+int pv_out_lik(const PvOutLik& p, hipStream_t s);
+int64_t pv_out_lik_blocks(int64_t M);
+int pv_segsum(const float* v, int64_t nseg, int64_t N, float* out, hipStream_t s);
+int pv_finish_scalars(const float* llb, int B, float* scalars, hipStream_t s);
+
+struct PvCoordLatBwd {
+  const float* dpre0;    // (M, H0)
+  const float* grid;
+  const float* tp;
+  const float* Wc;
+  float* part_hz;        // (B*nchunk, H0)
+  float* part_wc;        // (B*nchunk, H0, cd)
+  float* part_tp;        // (B*nchunk, 4)
+  int N, cd, H0, rows_per_chunk;
+};
+int pv_coordlat_bwd(const PvCoordLatBwd& p, int nchunk, int B, hipStream_t s);
+int pv_reduce_mid(const float* part, int nb, int nc, int n, float* out, hipStream_t s);
+
+struct PvHeadBwd {
+  const float* dzc;      // (B, ldzc): dL/d(decoder latent input) (content [+ y] columns)
+  int64_t ldzc;
+  const float* dtp;      // (B, 4): dphi, dscale, dtx, dty  (null when coord_dim == 0)
+  const float* z;
+  const float* z_scale;
+  const float* eps;
+  const float* head;     // (B, 2*z_dim)
+  float* dhead;          // (B, 2*z_dim): [dL/dmu | dL/d(softplus input)]
+  int B, z_dim, coord_dim, has_r, has_t, has_s;
+  float tp0, tp1, sc_prior, beta;
+};
+int pv_head_bwd(const PvHeadBwd& h, hipStream_t s);
+
+int pv_lik_elem(const float* a, const float* x, int64_t M, int lik, int sigmoid_out, float sig, float* loc,
+                float* llrow, float* dlda, hipStream_t s);

@@ -1,0 +1,476 @@
+// pv_plan.hip — host-side orchestration of one iVAE SVI step behind the C ABI (include/pyroved_amd.h).
+// Enqueues, on the caller's stream, the kernel sequence that replaces
+//   SVItrainer.train's `self.svi.step(x)` (trainers/svi.py:104-113)
+//     -> Trace_ELBO.loss_and_grads(iVAE.model, iVAE.guide) (models/ivae.py:165-221)
+//     -> pyro.optim.Adam -> zero_grads.
+// No allocation, no synchronisation, no retained state: everything lives in the caller's plan.
+#include "pv_common.h"
+#include "pv_kernels.h"
+#include "pv_sdec_fused.h"
+
+namespace {
+
+struct Carver {
+  char* base;
+  int64_t off;
+  float* take(int64_t nfloats) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += pv_align_up(nfloats * (int64_t)sizeof(float), 256);
+    return p;
+  }
+};
+
+int64_t gemm_ws_need(int64_t M, int64_t N, int64_t K) {
+  const int s = pv_gemm_pick_splits((int)M, (int)N, (int)K);
+  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+}
+
+struct Layout {
+  // encoder
+  float* xin; float* eact[PV_MAX_LAYERS]; float* epre[PV_MAX_LAYERS];
+  float* head; float* dhead; float* z; float* z_scale; float* tp; float* zy;
+  float* ebuf[2];
+  // decoder
+  float* hz; float* h0; float* dact[PV_MAX_LAYERS]; float* dpre_[PV_MAX_LAYERS];
+  float* logits; float* llrow; float* llb; float* dbuf[2];
+  float* part_dwo; float* part_dbo; float* part_hz; float* part_wc; float* part_tp;
+  float* dhz; float* dtp; float* dzc;
+  void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
+  int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
+  int nchunk, rows_per_chunk;
+  int64_t total;
+};
+
+bool valid_plan(const pv_ivae_plan* p) {
+  if (!p || p->batch <= 0 || p->n_pix <= 0 || p->z_dim <= 0) return false;
+  if (p->coord_dim < 0 || p->coord_dim > 2) return false;
+  if (p->n_enc < 1 || p->n_enc > PV_MAX_LAYERS || p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
+  if (p->head.out_dim != 2 * p->z_dim) return false;
+  if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN) return false;
+  if (p->lik == PV_LIK_BERNOULLI && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
+  if (p->coord_dim > 0 && p->out.out_dim != 1) return false;
+  if (p->coord_dim == 0 && p->out.out_dim != p->n_pix) return false;
+  return true;
+}
+
+void carve(const pv_ivae_plan* p, char* base, Layout& L) {
+  Carver c{base, 0};
+  const int64_t B = p->batch, N = p->n_pix, z = p->z_dim;
+  const int64_t lat_in = (p->coord_dim > 0 ? p->latent_dim : p->z_dim) + p->c_dim;
+  L.rows = p->coord_dim > 0 ? B * N : B;
+  const int64_t R = L.rows;
+  L.xin = p->c_dim > 0 ? c.take(B * (N + p->c_dim)) : nullptr;
+  int64_t maxe = 0;
+  for (int i = 0; i < p->n_enc; ++i) {
+    L.eact[i] = c.take(B * p->enc[i].out_dim);
+    L.epre[i] = p->enc[i].act == PV_ACT_GELU ? c.take(B * p->enc[i].out_dim) : nullptr;
+    if (p->enc[i].out_dim > maxe) maxe = p->enc[i].out_dim;
+  }
+  L.head = c.take(B * 2 * z);
+  L.dhead = c.take(B * 2 * z);
+  L.z = c.take(B * z);
+  L.z_scale = c.take(B * z);
+  L.tp = c.take(B * 8);
+  L.zy = p->c_dim > 0 ? c.take(B * lat_in) : nullptr;
+  L.ebuf[0] = c.take(B * maxe);
+  L.ebuf[1] = c.take(B * maxe);
+  int64_t maxd = 0;
+  for (int i = 0; i < p->n_dec; ++i) {
+    L.dact[i] = c.take(R * p->dec[i].out_dim);
+    L.dpre_[i] = p->dec[i].act == PV_ACT_GELU ? c.take(R * p->dec[i].out_dim) : nullptr;
+    if (p->dec[i].out_dim > maxd) maxd = p->dec[i].out_dim;
+  }
+  int64_t scratch = 0;
+  auto upd = [&](int64_t v) { if (v > scratch) scratch = v; };
+  if (p->coord_dim > 0) {
+    const int64_t H0 = p->fc_coord.out_dim;
+    if (H0 > maxd) maxd = H0;
+    L.hz = c.take(B * H0);
+    L.h0 = c.take(R * H0);
+    L.logits = nullptr;
+    L.llrow = c.take(R);
+    const int64_t ob = pv_out_lik_blocks(R);
+    L.part_dwo = c.take(ob * p->out.in_dim);
+    L.part_dbo = c.take(ob);
+    // row chunks per sample for the coord_latent backward: >= ~1024 workgroups overall
+    int nchunk = (int)((1024 + B - 1) / B);
+    if (nchunk > (N + 31) / 32) nchunk = (int)((N + 31) / 32);
+    if (nchunk < 1) nchunk = 1;
+    L.rows_per_chunk = (int)((N + nchunk - 1) / nchunk);
+    L.nchunk = (int)((N + L.rows_per_chunk - 1) / L.rows_per_chunk);
+    L.part_hz = c.take(B * L.nchunk * H0);
+    L.part_wc = c.take(B * L.nchunk * H0 * p->coord_dim);
+    L.part_tp = c.take(B * L.nchunk * 4);
+    L.dhz = c.take(B * H0);
+    L.dtp = c.take(B * 4);
+    L.dzc = c.take(B * lat_in);
+    upd(gemm_ws_need(B, H0, lat_in));          // hz
+    upd(gemm_ws_need(H0, lat_in, B));          // dWz
+    upd(gemm_ws_need(B, lat_in, H0));          // dzc
+  } else {
+    L.hz = L.h0 = nullptr;
+    L.logits = c.take(B * N);
+    L.llrow = c.take(B * N);
+    L.part_dwo = L.part_dbo = L.part_hz = L.part_wc = L.part_tp = L.dhz = L.dtp = nullptr;
+    L.nchunk = L.rows_per_chunk = 0;
+    L.dzc = c.take(B * lat_in);
+    if (N > maxd) maxd = N;
+    upd(gemm_ws_need(B, N, p->out.in_dim));
+    upd(gemm_ws_need(N, p->out.in_dim, B));
+    upd(gemm_ws_need(B, p->out.in_dim, N));
+    upd(pv_colsum_ws(B, (int)N));
+  }
+  L.llb = c.take(B);
+  L.dbuf[0] = c.take(R * maxd);
+  L.dbuf[1] = c.take(R * maxd);
+  // scratch: the largest split-K / colsum requirement of any single call
+  for (int i = 0; i < p->n_enc; ++i) {
+    upd(gemm_ws_need(B, p->enc[i].out_dim, p->enc[i].in_dim));
+    upd(gemm_ws_need(p->enc[i].out_dim, p->enc[i].in_dim, B));
+    upd(gemm_ws_need(B, p->enc[i].in_dim, p->enc[i].out_dim));
+    upd(pv_colsum_ws(B, p->enc[i].out_dim));
+  }
+  upd(gemm_ws_need(B, 2 * z, p->head.in_dim));
+  upd(gemm_ws_need(2 * z, p->head.in_dim, B));
+  upd(gemm_ws_need(B, p->head.in_dim, 2 * z));
+  upd(pv_colsum_ws(B, (int)(2 * z)));
+  for (int i = 0; i < p->n_dec; ++i) {
+    upd(gemm_ws_need(R, p->dec[i].out_dim, p->dec[i].in_dim));
+    upd(gemm_ws_need(p->dec[i].out_dim, p->dec[i].in_dim, R));
+    upd(gemm_ws_need(R, p->dec[i].in_dim, p->dec[i].out_dim));
+    upd(pv_colsum_ws(R, p->dec[i].out_dim));
+  }
+  upd(pv_sdec_fused_ws_bytes(p));
+  L.scratch_bytes = pv_align_up(scratch, 256);
+  L.scratch = base ? (void*)(base + c.off) : nullptr;
+  c.off += L.scratch_bytes;
+  L.total = c.off;
+}
+
+// y = act(x W^T + b)
+int linear_fwd(const float* x, int64_t ldx, const float* W, const float* b, float* y, float* pre, int64_t ldy,
+               int64_t M, int64_t K, int64_t N, int act, void* ws, int64_t wsb, hipStream_t s) {
+  PvGemm g{};
+  g.A = x; g.a_rs = ldx; g.a_cs = 1;
+  g.B = W; g.b_rs = 1; g.b_cs = K;            // B(k,n) = W[n][k]
+  g.C = y; g.ldc = ldy; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.bias = b; g.act = act; g.pre = pre;
+  return pv_gemm(g, pv_gemm_pick_splits((int)M, (int)N, (int)K), ws, wsb, s);
+}
+
+// dx = (dpre W) * act'(xact)
+int linear_dgrad(const float* dpre, int64_t lddp, const float* W, float* dx, int64_t lddx, const float* xact,
+                 const float* xpre, int64_t ldxa, int act_prev, int64_t M, int64_t K, int64_t N, void* ws, int64_t wsb,
+                 hipStream_t s) {
+  PvGemm g{};
+  g.A = dpre; g.a_rs = lddp; g.a_cs = 1;      // (M, N)
+  g.B = W; g.b_rs = K; g.b_cs = 1;            // B(n,k) = W[n][k]
+  g.C = dx; g.ldc = lddx; g.M = (int)M; g.N = (int)K; g.K = (int)N;
+  g.act = PV_ACT_NONE;
+  if (act_prev != PV_ACT_NONE) { g.aux = xact; g.auxpre = xpre; g.ldaux = ldxa; g.act_aux = act_prev; }
+  return pv_gemm(g, pv_gemm_pick_splits((int)M, (int)K, (int)N), ws, wsb, s);
+}
+
+// dw = dpre^T x ; db = colsum(dpre)
+int linear_wgrad(const float* dpre, int64_t lddp, const float* x, int64_t ldx, float* dw, float* db, int64_t M,
+                 int64_t K, int64_t N, void* ws, int64_t wsb, hipStream_t s) {
+  if (dw) {
+    PvGemm g{};
+    g.A = dpre; g.a_rs = 1; g.a_cs = lddp;    // A(n, row) = dpre[row][n]
+    g.B = x; g.b_rs = ldx; g.b_cs = 1;        // B(row, k) = x[row][k]
+    g.C = dw; g.ldc = K; g.M = (int)N; g.N = (int)K; g.K = (int)M;
+    g.act = PV_ACT_NONE;
+    PV_TRY(pv_gemm(g, pv_gemm_pick_splits((int)N, (int)K, (int)M), ws, wsb, s));
+  }
+  if (db) PV_TRY(pv_colsum(dpre, lddp, M, (int)N, db, ws, wsb, s));
+  return 0;
+}
+
+int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+  const int64_t B = p->batch;
+  const float* in = p->x;
+  int64_t ldin = p->n_pix;
+  if (p->c_dim > 0) {
+    if (!p->y) return PV_EINVAL;
+    PV_TRY(pv_concat(p->x, p->n_pix, p->n_pix, p->y, p->c_dim, p->c_dim, L.xin, B, s));
+    in = L.xin; ldin = p->n_pix + p->c_dim;
+  }
+  for (int i = 0; i < p->n_enc; ++i) {
+    const pv_layer& l = p->enc[i];
+    if (l.in_dim != ldin) return PV_EINVAL;
+    PV_TRY(linear_fwd(in, ldin, p->params + l.w_off, l.b_off >= 0 ? p->params + l.b_off : nullptr, L.eact[i],
+                      L.epre[i], l.out_dim, B, l.in_dim, l.out_dim, l.act, L.scratch, L.scratch_bytes, s));
+    in = L.eact[i]; ldin = l.out_dim;
+  }
+  const pv_layer& h = p->head;
+  if (h.in_dim != ldin) return PV_EINVAL;
+  return linear_fwd(in, ldin, p->params + h.w_off, h.b_off >= 0 ? p->params + h.b_off : nullptr, L.head, nullptr,
+                    h.out_dim, B, h.in_dim, h.out_dim, PV_ACT_NONE, L.scratch, L.scratch_bytes, s);
+}
+
+// decoder forward from the decoder's latent input zin (B, lat_in); tp must be filled for coord_dim > 0.
+// leaves the last hidden activation in L.dact[n_dec-1]; for coord_dim == 0 also the logits in L.logits
+int decoder_hidden_fwd(const pv_ivae_plan* p, const Layout& L, const float* zin, int64_t ldz, int64_t lat_in,
+                       hipStream_t s) {
+  const int64_t B = p->batch, R = L.rows;
+  const float* in;
+  int64_t ldin;
+  if (p->coord_dim > 0) {
+    const int64_t H0 = p->fc_coord.out_dim;
+    if (p->fc_latent.in_dim != lat_in || p->fc_latent.out_dim != H0 || p->fc_coord.in_dim != p->coord_dim)
+      return PV_EINVAL;
+    PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H0, B, lat_in, H0,
+                      PV_ACT_NONE, L.scratch, L.scratch_bytes, s));
+    PvCoordLat c{};
+    c.grid = p->grid; c.tp = L.tp; c.Wc = p->params + p->fc_coord.w_off; c.bc = p->params + p->fc_coord.b_off;
+    c.hz = L.hz; c.h0 = L.h0; c.M = R; c.N = p->n_pix; c.cd = p->coord_dim; c.H0 = (int)H0;
+    PV_TRY(pv_coordlat_fwd(c, s));
+    in = L.h0; ldin = H0;
+  } else {
+    in = zin; ldin = ldz;
+    if (p->dec[0].in_dim != lat_in) return PV_EINVAL;
+  }
+  for (int i = 0; i < p->n_dec; ++i) {
+    const pv_layer& l = p->dec[i];
+    if (i > 0 || p->coord_dim > 0) { if (l.in_dim != ldin) return PV_EINVAL; }
+    PV_TRY(linear_fwd(in, ldin, p->params + l.w_off, l.b_off >= 0 ? p->params + l.b_off : nullptr, L.dact[i],
+                      L.dpre_[i], l.out_dim, R, l.in_dim, l.out_dim, l.act, L.scratch, L.scratch_bytes, s));
+    in = L.dact[i]; ldin = l.out_dim;
+  }
+  if (p->out.in_dim != ldin) return PV_EINVAL;
+  if (p->coord_dim == 0) {
+    PV_TRY(linear_fwd(in, ldin, p->params + p->out.w_off, p->out.b_off >= 0 ? p->params + p->out.b_off : nullptr,
+                      L.logits, nullptr, p->n_pix, B, p->out.in_dim, p->n_pix, PV_ACT_NONE, L.scratch,
+                      L.scratch_bytes, s));
+  }
+  return 0;
+}
+
+int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
+  const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
+  const int64_t lat_in = (p->coord_dim > 0 ? p->latent_dim : p->z_dim) + p->c_dim;
+  float* G = p->grads;
+  void* ws = L.scratch;
+  const int64_t wsb = L.scratch_bytes;
+  const int nd = p->n_dec, ne = p->n_enc;
+
+  // ---------------- forward ----------------
+  PV_TRY(encoder_fwd(p, L, s));
+  PvHead h{};
+  h.head = L.head; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
+  h.z_loc_out = p->z_loc; h.z_scale_out = p->z_scale;
+  h.tp = p->coord_dim > 0 ? L.tp : nullptr; h.zy = L.zy; h.scalars = p->scalars;
+  h.B = (int)B; h.z_dim = (int)z; h.c_dim = p->c_dim; h.coord_dim = p->coord_dim;
+  h.has_r = p->has_r; h.has_t = p->has_t; h.has_s = p->has_s;
+  h.tp0 = p->t_prior[0]; h.tp1 = p->t_prior[1]; h.sc_prior = p->sc_prior; h.beta = p->beta;
+  PV_TRY(pv_head_fwd(h, s));
+  const int coord = (int)(z - p->latent_dim);
+  const float* zin = p->c_dim > 0 ? L.zy : (p->coord_dim > 0 ? L.z + coord : L.z);
+  const int64_t ldz = p->c_dim > 0 ? lat_in : z;
+  PV_TRY(decoder_hidden_fwd(p, L, zin, ldz, lat_in, s));
+
+  float* cur = L.dbuf[0];      // dL/d(pre-activation) of the layer being processed
+  float* oth = L.dbuf[1];
+  const float* hlast = L.dact[nd - 1];
+  const int Hl = p->dec[nd - 1].out_dim;
+  if (p->coord_dim > 0) {
+    PvOutLik o{};
+    o.h = hlast; o.hpre = L.dpre_[nd - 1]; o.ldh = Hl; o.wo = p->params + p->out.w_off;
+    o.bo = p->out.b_off >= 0 ? p->params + p->out.b_off : nullptr; o.x = p->x; o.loc = p->loc; o.llrow = L.llrow;
+    o.dpre = want_grads ? cur : nullptr; o.part_dwo = L.part_dwo; o.part_dbo = L.part_dbo; o.M = R; o.H = Hl;
+    o.lik = p->lik; o.sigmoid_out = p->sigmoid_out; o.act_last = p->dec[nd - 1].act; o.sig = p->decoder_sig;
+    PV_TRY(pv_out_lik(o, s));
+  } else {
+    // oth <- dL/dlogits (B, N)
+    PV_TRY(pv_lik_elem(L.logits, p->x, B * N, p->lik, p->sigmoid_out, p->decoder_sig, p->loc, L.llrow,
+                       want_grads ? oth : nullptr, s));
+  }
+  PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
+  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, s));
+  if (!want_grads) return 0;
+
+  // ---------------- backward: decoder ----------------
+  if (p->coord_dim > 0) {
+    const int64_t ob = pv_out_lik_blocks(R);
+    PV_TRY(pv_reduce_partials(L.part_dwo, (int)ob, Hl, G + p->out.w_off, Hl, s));
+    if (p->out.b_off >= 0) PV_TRY(pv_reduce_partials(L.part_dbo, (int)ob, 1, G + p->out.b_off, 1, s));
+  } else {
+    // out layer of the vanilla decoder: logits = hlast Wout^T + bout
+    PV_TRY(linear_wgrad(oth, N, hlast, Hl, G + p->out.w_off, p->out.b_off >= 0 ? G + p->out.b_off : nullptr, B, Hl, N,
+                        ws, wsb, s));
+    PV_TRY(linear_dgrad(oth, N, p->params + p->out.w_off, cur, Hl, hlast, L.dpre_[nd - 1], Hl, p->dec[nd - 1].act, B,
+                        Hl, N, ws, wsb, s));
+  }
+  for (int i = nd - 1; i >= 0; --i) {
+    const pv_layer& l = p->dec[i];
+    const float* in; const float* inpre; int64_t ldin; int act_in;
+    if (i > 0) { in = L.dact[i - 1]; inpre = L.dpre_[i - 1]; ldin = p->dec[i - 1].out_dim; act_in = p->dec[i - 1].act; }
+    else if (p->coord_dim > 0) { in = L.h0; inpre = nullptr; ldin = p->fc_coord.out_dim; act_in = PV_ACT_TANH; }
+    else { in = zin; inpre = nullptr; ldin = ldz; act_in = PV_ACT_NONE; }
+    PV_TRY(linear_wgrad(cur, l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, R, l.in_dim,
+                        l.out_dim, ws, wsb, s));
+    if (i > 0 || p->coord_dim > 0) {
+      PV_TRY(linear_dgrad(cur, l.out_dim, p->params + l.w_off, oth, l.in_dim, in, inpre, ldin, act_in, R, l.in_dim,
+                          l.out_dim, ws, wsb, s));
+      float* t = cur; cur = oth; oth = t;
+    } else {
+      // vanilla decoder: dL/d(decoder latent input) (B, lat_in)
+      PV_TRY(linear_dgrad(cur, l.out_dim, p->params + l.w_off, L.dzc, lat_in, nullptr, nullptr, 0, PV_ACT_NONE, R,
+                          l.in_dim, l.out_dim, ws, wsb, s));
+    }
+  }
+  if (p->coord_dim > 0) {
+    // cur = dL/d(pre-tanh of coord_latent) (R, H0)
+    const int H0 = p->fc_coord.out_dim;
+    PvCoordLatBwd cb{};
+    cb.dpre0 = cur; cb.grid = p->grid; cb.tp = L.tp; cb.Wc = p->params + p->fc_coord.w_off;
+    cb.part_hz = L.part_hz; cb.part_wc = L.part_wc; cb.part_tp = L.part_tp;
+    cb.N = (int)N; cb.cd = p->coord_dim; cb.H0 = H0; cb.rows_per_chunk = L.rows_per_chunk;
+    PV_TRY(pv_coordlat_bwd(cb, L.nchunk, (int)B, s));
+    const int np = (int)(B * L.nchunk);
+    PV_TRY(pv_reduce_mid(L.part_hz, (int)B, L.nchunk, H0, L.dhz, s));
+    PV_TRY(pv_reduce_partials(L.part_hz, np, H0, G + p->fc_coord.b_off, H0, s));
+    PV_TRY(pv_reduce_partials(L.part_wc, np, (int64_t)H0 * p->coord_dim, G + p->fc_coord.w_off,
+                              (int64_t)H0 * p->coord_dim, s));
+    PV_TRY(pv_reduce_mid(L.part_tp, (int)B, L.nchunk, 4, L.dtp, s));
+    // fc_latent: hz = zin Wz^T
+    PV_TRY(linear_wgrad(L.dhz, H0, zin, ldz, G + p->fc_latent.w_off, nullptr, B, lat_in, H0, ws, wsb, s));
+    PV_TRY(linear_dgrad(L.dhz, H0, p->params + p->fc_latent.w_off, L.dzc, lat_in, nullptr, nullptr, 0, PV_ACT_NONE, B,
+                        lat_in, H0, ws, wsb, s));
+  }
+
+  // ---------------- backward: latent + encoder ----------------
+  PvHeadBwd hb{};
+  hb.dzc = L.dzc; hb.ldzc = lat_in; hb.dtp = L.dtp; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;
+  hb.head = L.head; hb.dhead = L.dhead; hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
+  hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
+  hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
+  PV_TRY(pv_head_bwd(hb, s));
+  const pv_layer& hd = p->head;
+  const float* elast = L.eact[ne - 1];
+  PV_TRY(linear_wgrad(L.dhead, 2 * z, elast, hd.in_dim, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B,
+                      hd.in_dim, 2 * z, ws, wsb, s));
+  float* ecur = L.ebuf[0];
+  float* eoth = L.ebuf[1];
+  PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + hd.w_off, ecur, hd.in_dim, elast, L.epre[ne - 1], hd.in_dim,
+                      p->enc[ne - 1].act, B, hd.in_dim, 2 * z, ws, wsb, s));
+  const float* xin = p->c_dim > 0 ? L.xin : p->x;
+  const int64_t ldx = p->n_pix + p->c_dim;
+  for (int i = ne - 1; i >= 0; --i) {
+    const pv_layer& l = p->enc[i];
+    const float* in = i > 0 ? L.eact[i - 1] : xin;
+    const int64_t ldin = i > 0 ? p->enc[i - 1].out_dim : ldx;
+    PV_TRY(linear_wgrad(ecur, l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, B, l.in_dim,
+                        l.out_dim, ws, wsb, s));
+    if (i > 0) {
+      PV_TRY(linear_dgrad(ecur, l.out_dim, p->params + l.w_off, eoth, l.in_dim, in, L.epre[i - 1], ldin,
+                          p->enc[i - 1].act, B, l.in_dim, l.out_dim, ws, wsb, s));
+      float* t = ecur; ecur = eoth; eoth = t;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pv_version(void) { return PV_ABI_VERSION; }
+
+extern "C" int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan) {
+  if (!valid_plan(plan)) return PV_EINVAL;
+  Layout L;
+  carve(plan, nullptr, L);
+  return L.total;
+}
+
+extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* stream) {
+  if (!valid_plan(plan) || !plan->params || !plan->x || !plan->eps || !plan->scalars || !plan->ws) return PV_EINVAL;
+  if (want_grads && !plan->grads) return PV_EINVAL;
+  if (plan->coord_dim > 0 && !plan->grid) return PV_EINVAL;
+  Layout L;
+  carve(plan, (char*)plan->ws, L);
+  if (plan->ws_bytes < L.total) return PV_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  if (plan->fused && pv_sdec_fused_supported(plan))
+    return pv_ivae_loss_and_grads_fused(plan, want_grads, s);
+  return loss_and_grads_layered(plan, L, want_grads, s);
+}
+
+extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
+  PV_TRY(pv_ivae_loss_and_grads(plan, 1, stream));
+  return pv_adam_step(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->lr,
+                      plan->adam_beta1, plan->adam_beta2, plan->adam_eps, plan->adam_step, stream);
+}
+
+extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream) {
+  if (!valid_plan(plan) || !plan->params || !plan->x || !plan->ws || !z_loc || !z_scale) return PV_EINVAL;
+  Layout L;
+  carve(plan, (char*)plan->ws, L);
+  if (plan->ws_bytes < L.total) return PV_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  PV_TRY(encoder_fwd(plan, L, s));
+  // split the merged head: z_loc = head[:, :z], z_scale = softplus(head[:, z:])  (fc.py:59-60)
+  PvHead h{};
+  h.head = L.head; h.eps = L.z_scale /* unused values; any valid buffer */; h.z = L.z; h.z_scale = L.z_scale;
+  h.z_loc_out = z_loc; h.z_scale_out = z_scale; h.tp = nullptr; h.zy = nullptr; h.scalars = (float*)L.dhead;
+  h.B = plan->batch; h.z_dim = plan->z_dim; h.c_dim = 0; h.coord_dim = 0; h.beta = 0.0f;
+  return pv_head_fwd(h, s);
+}
+
+extern "C" int pv_ivae_decode(const pv_ivae_plan* plan, const float* z, float angle, float shift_x, float shift_y,
+                              float scale, float* loc, void* stream) {
+  if (!valid_plan(plan) || !plan->params || !plan->ws || !z || !loc) return PV_EINVAL;
+  if (plan->coord_dim > 0 && !plan->grid) return PV_EINVAL;
+  Layout L;
+  carve(plan, (char*)plan->ws, L);
+  if (plan->ws_bytes < L.total) return PV_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t B = plan->batch, N = plan->n_pix, R = L.rows;
+  const int64_t lat_in = (plan->coord_dim > 0 ? plan->latent_dim : plan->z_dim) + plan->c_dim;
+  if (plan->coord_dim > 0) PV_TRY(pv_fill_tp(L.tp, (int)B, angle, scale, shift_x, shift_y, s));
+  PV_TRY(decoder_hidden_fwd(plan, L, z, lat_in, lat_in, s));
+  const int nd = plan->n_dec;
+  if (plan->coord_dim > 0) {
+    PvOutLik o{};
+    o.h = L.dact[nd - 1]; o.ldh = plan->dec[nd - 1].out_dim; o.wo = plan->params + plan->out.w_off;
+    o.bo = plan->out.b_off >= 0 ? plan->params + plan->out.b_off : nullptr;
+    o.x = L.llrow /* unused for loc */; o.loc = loc; o.llrow = nullptr; o.dpre = nullptr; o.M = R;
+    o.H = plan->dec[nd - 1].out_dim; o.lik = PV_LIK_GAUSSIAN; o.sigmoid_out = plan->sigmoid_out; o.sig = 1.0f;
+    o.act_last = plan->dec[nd - 1].act;
+    return pv_out_lik(o, s);
+  }
+  return pv_lik_elem(L.logits, L.logits, B * N, PV_LIK_GAUSSIAN, plan->sigmoid_out, 1.0f, loc, nullptr, nullptr, s);
+}
+
+// ---- building blocks -------------------------------------------------------------------------
+extern "C" int64_t pv_linear_workspace_bytes(int64_t M, int64_t K, int64_t N) {
+  if (M < 0 || K <= 0 || N <= 0) return PV_EINVAL;
+  int64_t need = gemm_ws_need(M, N, K);
+  const int64_t a = gemm_ws_need(M, K, N), b = gemm_ws_need(N, K, M), c = pv_colsum_ws(M, (int)N);
+  if (a > need) need = a;
+  if (b > need) need = b;
+  if (c > need) need = c;
+  return pv_align_up(need, 256);
+}
+
+extern "C" int pv_linear_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y, float* pre,
+                             int64_t ldy, int64_t M, int64_t K, int64_t N, int act, void* ws, int64_t ws_bytes,
+                             void* stream) {
+  if (!x || !w || !y || M < 0 || K <= 0 || N <= 0) return PV_EINVAL;
+  return linear_fwd(x, ldx, w, b, y, pre, ldy, M, K, N, act, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pv_linear_bwd(const float* dpre, int64_t lddp, const float* x, int64_t ldx, const float* w, float* dx,
+                             int64_t lddx, const float* xact, const float* xpre, int64_t ldxa, int act_prev, float* dw,
+                             float* db, int64_t M, int64_t K, int64_t N, void* ws, int64_t ws_bytes, void* stream) {
+  if (!dpre || M < 0 || K <= 0 || N <= 0) return PV_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    if (!w) return PV_EINVAL;
+    PV_TRY(linear_dgrad(dpre, lddp, w, dx, lddx, xact, xpre, ldxa, act_prev, M, K, N, ws, ws_bytes, s));
+  }
+  if (dw || db) {
+    if (dw && !x) return PV_EINVAL;
+    PV_TRY(linear_wgrad(dpre, lddp, x, ldx, dw, db, M, K, N, ws, ws_bytes, s));
+  }
+  return 0;
+}

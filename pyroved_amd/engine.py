@@ -1,0 +1,306 @@
+"""
+engine.py — host-side driver of the HIP SVI step for models.iVAE.
+
+Owns the device memory layout the C ABI works on:
+  * ONE flat fp32 parameter buffer; every nn.Parameter of the model's encoder_z
+    and decoder is re-pointed to a view of it (state_dict keys and values are
+    unchanged, save/load keep working), laid out so that fc11/fc12 are adjacent
+    (the kernels treat them as one Linear of width 2*z_dim);
+  * flat gradient buffer with 4 trailing slots for the ELBO scalars, so that the
+    data-parallel path needs exactly one all-reduce (grads + loss);
+  * flat Adam moment buffers and the workspace.
+and fills a `pv_ivae_plan` (include/pyroved_amd.h) per call.
+
+Replaces, for the product, what Pyro's SVI/Trace_ELBO/PyroOptim objects hold in
+the reference (pyroved/trainers/svi.py:79-91).
+"""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .nets.fc import fcEncoderNet, fcDecoderNet, sDecoderNet
+
+ALIGN = 64      # floats: every tensor starts on a 256-byte boundary of the flat buffer
+N_SCALARS = 4   # loss, ll, beta*log p(z), beta*log q(z|x)
+
+
+class UnsupportedModel(NotImplementedError):
+    pass
+
+
+def _linears(seq: nn.Sequential) -> List[nn.Linear]:
+    return [m for m in seq if isinstance(m, nn.Linear)]
+
+
+class IVAEEngine:
+    """Binds an iVAE-like model (encoder_z: fcEncoderNet, decoder: sDecoderNet | fcDecoderNet)
+    to the HIP library."""
+
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: bool = True):
+        self.model = model
+        self.lr, self.betas, self.adam_eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.fused = bool(fused)
+        self.adam_t = 0                 # number of optimizer steps taken (incl. evaluate()'s, see SVItrainer)
+        self.grads_live = False         # reference: .grad is None until the first backward
+        self.device = None
+        self.flat = self.grad = self.m = self.v = None
+        self.ws = None
+        self._layout: Dict[str, int] = {}
+        self._views: Dict[str, torch.Tensor] = {}
+        self._check_model()
+        self.bind()
+
+    # ------------------------------------------------------------------ structure
+    def _check_model(self):
+        m = self.model
+        enc, dec = m.encoder_z, m.decoder
+        if not isinstance(enc, fcEncoderNet):
+            raise UnsupportedModel("the HIP SVI path needs encoder_z to be pyroved_amd.nets.fcEncoderNet "
+                                   "(got %s)" % type(enc).__name__)
+        if not isinstance(dec, (sDecoderNet, fcDecoderNet)):
+            raise UnsupportedModel("the HIP SVI path needs decoder to be sDecoderNet or fcDecoderNet "
+                                   "(got %s)" % type(dec).__name__)
+        if not enc.softplus_out:
+            raise UnsupportedModel("encoder without softplus_out is not supported")
+        if m.coord > 0 and not isinstance(dec, sDecoderNet):
+            raise UnsupportedModel("invariant models need the spatial decoder")
+        if m.coord == 0 and not isinstance(dec, fcDecoderNet):
+            raise UnsupportedModel("vanilla models need fcDecoderNet")
+        name = m.sampler_d.name
+        if name not in _abi.LIK:
+            raise UnsupportedModel("decoder sampler %r is not implemented in the HIP path yet" % name)
+        if name == "bernoulli" and not dec.sigmoid_out:
+            raise UnsupportedModel("bernoulli likelihood needs sigmoid_d=True")
+        if len(_linears(enc.fc_layers)) > _abi.PV_MAX_LAYERS or len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
+            raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
+
+    def _param_order(self):
+        """(key, tensor) in flat-buffer order: state_dict order, except fc12.weight follows
+        fc11.weight and fc12.bias follows fc11.bias (merged head)."""
+        named = dict(self.model.named_parameters())
+        keys = list(named.keys())
+        order = []
+        for k in keys:
+            if k in ("encoder_z.fc11.bias", "encoder_z.fc12.weight"):
+                continue
+            order.append(k)
+            if k == "encoder_z.fc11.weight":
+                order.append("encoder_z.fc12.weight")
+                order.append("encoder_z.fc11.bias")
+        return [(k, named[k]) for k in order]
+
+    def bind(self):
+        """(Re)builds the flat buffers from the model's current parameters and re-points the
+        parameters at them.  Called at construction and whenever the parameters were moved."""
+        items = self._param_order()
+        dev = items[0][1].device
+        if dev.type != "cuda":
+            raise _abi.PvError(
+                "pyroved_amd: the model lives on %s; the SVI path runs only on a HIP device "
+                "(no CPU fallback). Construct the model with device='cuda'." % dev)
+        _abi.lib()
+        off = 0
+        layout = {}
+        for k, p in items:
+            # tensors that the kernels address as one matrix must be packed back to back
+            packed = k in ("encoder_z.fc12.weight", "encoder_z.fc12.bias")
+            if not packed:
+                off = (off + ALIGN - 1) // ALIGN * ALIGN
+            layout[k] = off
+            off += p.numel()
+        total = (off + ALIGN - 1) // ALIGN * ALIGN
+        old_m, old_v, old_layout = self.m, self.v, self._layout
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        for k, p in items:
+            flat[layout[k]:layout[k] + p.numel()].copy_(p.detach().reshape(-1))
+        self.flat = flat
+        self.grad = torch.zeros(total + N_SCALARS, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(total, device=dev, dtype=torch.float32)
+        if old_m is not None and old_layout == layout and old_m.numel() == total:
+            self.m.copy_(old_m)
+            self.v.copy_(old_v)
+        self._views = {}
+        for k, p in items:
+            view = flat[layout[k]:layout[k] + p.numel()].view(p.shape)
+            p.data = view
+            self._views[k] = view
+        self._layout = layout
+        self.n_flat = total
+        self.device = dev
+        self.scalars = self.grad[total:total + N_SCALARS]
+        self.grid = self.model.grid.to(dev).contiguous() if self.model.coord > 0 else None
+        self.ws = None
+        self._static = self._static_plan()
+
+    def _bound(self) -> bool:
+        named = dict(self.model.named_parameters())
+        if len(named) != len(self._views):
+            return False
+        for k, v in self._views.items():
+            p = named.get(k)
+            if p is None or p.data_ptr() != v.data_ptr() or p.shape != v.shape:
+                return False
+        return True
+
+    def ensure_bound(self):
+        if not self._bound():
+            self.bind()
+
+    # ------------------------------------------------------------------ plan
+    def _layer(self, prefix: str, lin: nn.Linear, act) -> _abi.pv_layer:
+        l = _abi.pv_layer()
+        l.in_dim, l.out_dim, l.act = lin.in_features, lin.out_features, _abi.ACT[act]
+        l.w_off = self._layout[prefix + ".weight"]
+        l.b_off = self._layout[prefix + ".bias"] if lin.bias is not None else -1
+        return l
+
+    def _static_plan(self) -> _abi.pv_ivae_plan:
+        m = self.model
+        enc, dec = m.encoder_z, m.decoder
+        p = _abi.pv_ivae_plan()
+        p.n_pix = 1
+        for d in m.data_dim:
+            p.n_pix *= int(d)
+        p.coord_dim = 0 if m.coord == 0 else (1 if m.ndim == 1 else 2)
+        p.z_dim, p.c_dim = m.z_dim, m.c_dim
+        p.latent_dim = m.z_dim - m.coord
+        inv = m.invariances or []
+        p.has_r, p.has_t, p.has_s = int('r' in inv), int('t' in inv), int('s' in inv)
+        tp = getattr(m, "t_prior", None)
+        if tp is not None:
+            tpl = tp.detach().cpu().reshape(-1).tolist()
+            p.t_prior[0] = tpl[0]
+            p.t_prior[1] = tpl[1] if len(tpl) > 1 else tpl[0]
+        sp = getattr(m, "sc_prior", None)
+        p.sc_prior = float(sp) if sp is not None else 0.0
+        p.lik = _abi.LIK[m.sampler_d.name]
+        p.sigmoid_out = int(dec.sigmoid_out)
+        p.decoder_sig = m.sampler_d.decoder_sig
+        p.fused = int(self.fused)
+        idx = [i for i, mod in enumerate(enc.fc_layers) if isinstance(mod, nn.Linear)]
+        p.n_enc = len(idx)
+        for j, i in enumerate(idx):
+            p.enc[j] = self._layer("encoder_z.fc_layers.%d" % i, enc.fc_layers[i], enc.activation)
+        h = _abi.pv_layer()
+        h.in_dim, h.out_dim, h.act = enc.fc11.in_features, 2 * m.z_dim, 0
+        h.w_off, h.b_off = self._layout["encoder_z.fc11.weight"], self._layout["encoder_z.fc11.bias"]
+        assert self._layout["encoder_z.fc12.weight"] == h.w_off + enc.fc11.weight.numel()
+        assert self._layout["encoder_z.fc12.bias"] == h.b_off + enc.fc11.bias.numel()
+        p.head = h
+        if p.coord_dim > 0:
+            p.fc_coord = self._layer("decoder.coord_latent.fc_coord", dec.coord_latent.fc_coord, "tanh")
+            p.fc_latent = self._layer("decoder.coord_latent.fc_latent", dec.coord_latent.fc_latent, None)
+        idx = [i for i, mod in enumerate(dec.fc_layers) if isinstance(mod, nn.Linear)]
+        p.n_dec = len(idx)
+        for j, i in enumerate(idx):
+            p.dec[j] = self._layer("decoder.fc_layers.%d" % i, dec.fc_layers[i], dec.activation)
+        p.out = self._layer("decoder.out", dec.out, None)
+        p.params = self.flat.data_ptr()
+        p.grads = self.grad.data_ptr()
+        p.adam_m = self.m.data_ptr()
+        p.adam_v = self.v.data_ptr()
+        p.n_params = self.n_flat
+        p.grid = self.grid.data_ptr() if self.grid is not None else None
+        p.scalars = self.scalars.data_ptr()
+        p.lr, p.adam_beta1, p.adam_beta2, p.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
+        return p
+
+    def _plan(self, batch: int, beta: float = 1.0) -> _abi.pv_ivae_plan:
+        p = self._static
+        p.batch = batch
+        p.beta = float(beta)
+        p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
+        need = _abi.lib().pv_ivae_workspace_bytes(C.byref(p))
+        if need < 0:
+            raise _abi.PvError("pyroved_amd: unsupported plan (pv_ivae_workspace_bytes -> %d)" % need)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(int(need), device=self.device, dtype=torch.uint8)
+        p.ws = self.ws.data_ptr()
+        p.ws_bytes = self.ws.numel()
+        return p
+
+    def _prep(self, t: Optional[torch.Tensor], what: str, shape=None) -> Optional[torch.Tensor]:
+        if t is None:
+            return None
+        _abi.require_device(t, what)
+        t = t.contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            t = t.reshape(shape)
+        return t
+
+    # ------------------------------------------------------------------ calls
+    def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
+                       scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None):
+        """Enqueues Trace_ELBO.loss_and_grads on the current stream.  Results land in
+        self.scalars (device, 4 floats) and self.grad[:n_flat]; nothing is synchronised."""
+        self.ensure_bound()
+        b = x.shape[0]
+        p = self._plan(b, beta)
+        x = self._prep(x, "x", (b, p.n_pix))
+        eps = self._prep(eps, "eps", (b, p.z_dim))
+        y = self._prep(y, "y", (b, p.c_dim)) if p.c_dim > 0 else None
+        if p.c_dim > 0 and y is None:
+            raise ValueError("class-conditioned model (c_dim=%d) needs y" % p.c_dim)
+        p.x, p.eps = x.data_ptr(), eps.data_ptr()
+        p.y = y.data_ptr() if y is not None else None
+        if z_out is not None:
+            p.z_loc, p.z_scale = z_out[0].data_ptr(), z_out[1].data_ptr()
+        if loc_out is not None:
+            p.loc = loc_out.data_ptr()
+        if scalars_out is not None:
+            p.scalars = scalars_out.data_ptr()
+        try:
+            _abi.check(_abi.lib().pv_ivae_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),
+                       "pv_ivae_loss_and_grads")
+        finally:
+            p.scalars = self.scalars.data_ptr()
+        if want_grads:
+            self.grads_live = True
+        self._keep = (x, eps, y)     # keep inputs alive until the stream has consumed them
+
+    def adam_step(self):
+        """pyro.optim.Adam over every parameter + zero_grads (one fused kernel)."""
+        self.adam_t += 1
+        _abi.check(_abi.lib().pv_adam_step(
+            _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), self.n_flat,
+            self.lr, self.betas[0], self.betas[1], self.adam_eps, self.adam_t, _abi.current_stream()),
+            "pv_adam_step")
+
+    def encode(self, x, y=None):
+        self.ensure_bound()
+        b = x.shape[0]
+        p = self._plan(b)
+        x = self._prep(x, "x", (b, p.n_pix))
+        y = self._prep(y, "y", (b, p.c_dim)) if p.c_dim > 0 else None
+        if p.c_dim > 0 and y is None:
+            raise ValueError("class-conditioned model (c_dim=%d) needs y" % p.c_dim)
+        p.x = x.data_ptr()
+        p.y = y.data_ptr() if y is not None else None
+        z_loc = torch.empty(b, p.z_dim, device=self.device, dtype=torch.float32)
+        z_scale = torch.empty_like(z_loc)
+        _abi.check(_abi.lib().pv_ivae_encode(C.byref(p), _abi.ptr(z_loc), _abi.ptr(z_scale), _abi.current_stream()),
+                   "pv_ivae_encode")
+        self._keep = (x, y)
+        return z_loc, z_scale
+
+    def decode(self, z, angle: float = 0.0, shift=(0.0, 0.0), scale: float = 1.0):
+        """z: (B, latent_dim + c_dim) content latents [+ class vector]."""
+        self.ensure_bound()
+        b = z.shape[0]
+        p = self._plan(b)
+        lat_in = (p.latent_dim if p.coord_dim > 0 else p.z_dim) + p.c_dim
+        z = self._prep(z, "z", (b, lat_in))
+        loc = torch.empty(b, p.n_pix, device=self.device, dtype=torch.float32)
+        _abi.check(_abi.lib().pv_ivae_decode(C.byref(p), _abi.ptr(z), float(angle), float(shift[0]), float(shift[1]),
+                                             float(scale), _abi.ptr(loc), _abi.current_stream()), "pv_ivae_decode")
+        self._keep = (z,)
+        return loc.view(b, *self.model.data_dim)
+
+    # views for tests / data-parallel reduction
+    def grad_of(self, key: str) -> torch.Tensor:
+        n = self._views[key].numel()
+        return self.grad[self._layout[key]:self._layout[key] + n].view(self._views[key].shape)

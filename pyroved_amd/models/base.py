@@ -1,0 +1,155 @@
+"""
+base.py — variational encoder-decoder base class; host-side mirror of
+pyroved/models/base.py:21-192 (same constructor logic, attributes, state_dict keys,
+`_split_latent`, `_encode`, `_decode`, `set_encoder/decoder`, `save/load_weights`).
+
+The batched `_encode` / `_decode` run the encoder / decoder through the HIP library
+(pv_ivae_encode / pv_ivae_decode) instead of eager torch modules.
+"""
+from typing import Tuple, Type, Union, List
+from abc import abstractmethod
+
+import torch
+import torch.nn as nn
+
+from ..utils import init_dataloader, generate_grid
+
+tt = torch.tensor
+
+
+class baseVAE(nn.Module):
+    """Base class for regular and invariant variational encoder-decoder models.
+
+    Args:
+        data_dim: (height, width) for images or (length,) for spectra.
+        invariances: list with invariances to enforce: 'r' (rotation), 't'
+            (translation), 's' (scale) for 2D; 't' for 1D; None = vanilla VAE.
+
+    Keyword Args:
+        device: defaults to 'cuda' if a GPU is available, else 'cpu' (on which the
+            model can be built and inspected, but not run: the compute path is HIP only).
+        dx_prior, dy_prior: translational priors; sc_prior: scale prior.
+    """
+    def __init__(self, *args, **kwargs: str):
+        super(baseVAE, self).__init__()
+        data_dim, invariances = args
+        self.device = kwargs.get(
+            "device", 'cuda' if torch.cuda.is_available() else 'cpu')
+        self.data_dim = tuple(int(d) for d in data_dim)
+        self.ndim = len(data_dim)
+        # number and type of invariances (pyroved/models/base.py:56-67)
+        if invariances is None:
+            coord = 0
+        else:
+            coord = len(invariances)
+            if self.ndim == 1:
+                if coord > 1 or invariances[0] != 't':
+                    raise ValueError(
+                        "For 1D data, the only invariance to enforce "
+                        "is translation ('t')")
+            if 't' in invariances and self.ndim == 2:
+                coord = coord + 1
+        self.coord = coord
+        self.invariances = invariances
+        if self.coord > 0:
+            self.grid = generate_grid(data_dim).to(self.device)
+        # prior "belief" about the degree of translational disorder (base.py:73-77)
+        if self.coord > 0 and 't' in self.invariances:
+            dx_pri = tt(kwargs.get("dx_prior", 0.1))
+            dy_pri = kwargs.get("dy_prior", dx_pri.clone())
+            self.t_prior = (tt([dx_pri, dy_pri]) if self.ndim == 2
+                            else dx_pri).to(self.device)
+        # prior "belief" about the degree of scale disorder (base.py:79-80)
+        if self.coord > 0 and 's' in self.invariances:
+            self.sc_prior = tt(kwargs.get("sc_prior", 0.1)).to(self.device)
+        self.encoder_z = None
+        self.decoder = None
+        self._engine = None
+
+    @abstractmethod
+    def model(self, *args, **kwargs):
+        raise NotImplementedError
+
+    @abstractmethod
+    def guide(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def _split_latent(self, z: torch.Tensor) -> Tuple[torch.Tensor]:
+        """Splits a latent vector into the parts associated with coordinate transformations
+        and image content: always [phi | dx, dy | scale | content] (base.py:97-119).
+        Pure slicing of the caller's tensor (any device)."""
+        if self.ndim == 1:
+            dx = z[:, 0:1]
+            z = z[:, 1:]
+            return None, dx, None, z
+        phi = tt(0).to(z.device)
+        dx = tt(0).to(z.device)
+        sc = tt(1).to(z.device)
+        if 'r' in self.invariances:
+            phi = z[:, 0]
+            z = z[:, 1:]
+        if 't' in self.invariances:
+            dx = z[:, :2]
+            z = z[:, 2:]
+        if 's' in self.invariances:
+            sc = sc + self.sc_prior.to(z.device) * z[:, 0]
+            z = z[:, 1:]
+        return phi, dx, sc, z
+
+    # ------------------------------------------------------------------ HIP engine
+    def engine(self, **kw):
+        """The HIP driver bound to this model's parameters (created on first use)."""
+        from ..engine import IVAEEngine
+        if self._engine is None:
+            self._engine = IVAEEngine(self, **kw)
+        return self._engine
+
+    def _encode(self, *input_args, device: str = None, **kwargs: int) -> torch.Tensor:
+        """Encodes data batch-by-batch with the trained encoder (base.py:121-143);
+        returns cat([z_loc, z_scale], -1) on the CPU."""
+        eng = self.engine()
+        loader = init_dataloader(*input_args, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
+        z_encoded = []
+        for data in loader:
+            x = data[0].to(eng.device, torch.float32)
+            y = data[1].to(eng.device, torch.float32) if len(data) > 1 else None
+            z_loc, z_scale = eng.encode(x, y)
+            z_encoded.append(torch.cat([z_loc, z_scale], -1).cpu())
+        return torch.cat(z_encoded)
+
+    def _decode(self, z_new: torch.Tensor, device: str = None, **kwargs: int) -> torch.Tensor:
+        """Decodes latent coordinates batch-by-batch (base.py:145-171).  kwargs: batch_size,
+        and for invariant models angle / shift / scale of the coordinate grid."""
+        eng = self.engine()
+        loader = init_dataloader(z_new, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
+        angle, shift, scale = 0.0, (0.0, 0.0), 1.0
+        if self.invariances:
+            angle = float(kwargs.get("angle", 0.0))
+            t = kwargs.get("shift", 0.0)
+            t = torch.as_tensor(t, dtype=torch.float32).reshape(-1).tolist()
+            shift = (t[0], t[1] if len(t) > 1 else t[0])
+            scale = float(kwargs.get("scale", 1.0))
+        x_decoded = []
+        for (z,) in loader:
+            loc = eng.decode(z.to(eng.device, torch.float32), angle, shift, scale)
+            x_decoded.append(loc.cpu())
+        return torch.cat(x_decoded)
+
+    def set_encoder(self, encoder_net: Type[torch.nn.Module]) -> None:
+        """Sets a user-defined encoder neural network."""
+        self.encoder_z = encoder_net.to(self.device)
+        self._engine = None
+
+    def set_decoder(self, decoder_net: Type[torch.nn.Module]) -> None:
+        """Sets a user-defined decoder neural network."""
+        self.decoder = decoder_net.to(self.device)
+        self._engine = None
+
+    def save_weights(self, filepath: str) -> None:
+        """Saves trained weights of encoder(s) and decoder (same keys as the reference)."""
+        torch.save(self.state_dict(), filepath + '.pt')
+
+    def load_weights(self, filepath: str) -> None:
+        """Loads saved weights of encoder(s) and decoder."""
+        weights = torch.load(filepath, map_location=self.device)
+        self.load_state_dict(weights)

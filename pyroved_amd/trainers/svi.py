@@ -1,0 +1,166 @@
+"""
+svi.py — stochastic variational inference trainer; host-side mirror of
+pyroved/trainers/svi.py:11-175 (same constructor, train / evaluate / step /
+print_statistics, loss_history, current_epoch).
+
+What the reference delegates to Pyro (`infer.SVI(model.model, guide, optim.Adam, Trace_ELBO)`)
+is executed here by the HIP library: per minibatch one `pv_ivae_loss_and_grads` + one
+`pv_adam_step` on the current stream (engine.py), with exactly one gradient all-reduce in
+between when torch.distributed is initialised (dist.py).
+
+RNG / data-order contract: the trainer re-seeds in its constructor, iterates
+the caller's DataLoader (whose shuffling consumes the global CPU generator exactly as in the
+reference), and draws `eps = torch.empty(B, z_dim).normal_()` on the global CPU generator once
+per step — the stream a CPU run of the reference consumes — so that the same seed yields the
+same numbers as the reference's CPU path.  `rng="device"` draws eps on the GPU instead.
+"""
+from typing import Type, Optional, Union
+
+import torch
+
+from ..utils import set_deterministic_mode
+from .. import dist as pvdist
+
+
+class SVItrainer:
+    """
+    SVI trainer for unsupervised and class-conditioned VED models consisting
+    of one encoder and one decoder.
+
+    Args:
+        model: initialized model (pyroved_amd.models.iVAE)
+        optimizer: None (Adam, lr 1e-3) or a dict of Adam arguments {"lr", "betas", "eps"}
+        loss: None / "Trace_ELBO" (the one-particle ELBO the reference defaults to)
+        enumerate_parallel: exact enumeration of discrete latents (jiVAE; not in this build yet)
+        seed: enforces reproducibility
+
+    Keyword Args:
+        lr: learning rate (Default: 1e-3)
+        device: device of the model (defaults to the model's)
+        rng: "cpu" (default; bit-compatible with the reference's CPU stream) or "device"
+        fused: use the fused persistent decoder kernel when available (default True)
+        process_group: torch.distributed group for data-parallel training (default: WORLD if initialised)
+        mirror_evaluate_update: keep the reference's behaviour of stepping the optimizer inside
+            evaluate() (svi.py:126-135 calls svi.step under no_grad) — default True
+    """
+    def __init__(self,
+                 model: Type[torch.nn.Module],
+                 optimizer=None,
+                 loss=None,
+                 enumerate_parallel: bool = False,
+                 seed: int = 1,
+                 **kwargs: Union[str, float]
+                 ) -> None:
+        set_deterministic_mode(seed)
+        self.device = kwargs.get("device", model.device)
+        if enumerate_parallel:
+            raise NotImplementedError("enumerate_parallel (jiVAE) is not part of this build yet")
+        if loss is not None and loss != "Trace_ELBO":
+            raise NotImplementedError("only the default Trace_ELBO objective is implemented (got %r)" % (loss,))
+        adam = {"lr": kwargs.get("lr", 1e-3), "betas": (0.9, 0.999), "eps": 1e-8}
+        if optimizer is not None:
+            if not isinstance(optimizer, dict):
+                raise TypeError("optimizer must be None or a dict of Adam arguments (Pyro optimizer objects "
+                                "cannot be used: Pyro is not a dependency of this build)")
+            adam.update(optimizer)
+        self.model = model
+        self.rng = kwargs.get("rng", "cpu")
+        self.group = kwargs.get("process_group", None)
+        self.mirror_evaluate_update = bool(kwargs.get("mirror_evaluate_update", True))
+        self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
+                                   fused=kwargs.get("fused", True))
+        self.engine.lr, self.engine.betas, self.engine.adam_eps = float(adam["lr"]), tuple(adam["betas"]), float(adam["eps"])
+        self.loss_history = {"training_loss": [], "test_loss": []}
+        self.current_epoch = 0
+        self._hist = None
+        rank, world = pvdist.world(self.group)
+        if world > 1:      # replicas start from rank 0's parameters
+            pvdist.broadcast_(self.engine.flat, 0, self.group)
+
+    # ------------------------------------------------------------------ one minibatch
+    def _draw_eps(self, b: int) -> torch.Tensor:
+        z_dim = self.model.z_dim
+        if self.rng == "cpu":
+            return torch.empty(b, z_dim).normal_()
+        return torch.empty(b, z_dim, device=self.engine.device).normal_()
+
+    def _svi_step(self, i: int, x: torch.Tensor, y: Optional[torch.Tensor], train: bool, **kwargs) -> None:
+        """SVI.step on one (global) minibatch; the loss lands in slot i of the device history."""
+        eng = self.engine
+        beta = float(kwargs.get("scale_factor", 1.))
+        b = x.shape[0]
+        eps = self._draw_eps(b)                       # global batch: identical on every rank
+        rank, world = pvdist.world(self.group)
+        lo, hi = pvdist.shard_bounds(b, rank, world)
+        dev = eng.device
+        if hi > lo:
+            xs = x[lo:hi].to(dev, torch.float32)
+            es = eps[lo:hi].to(dev, torch.float32)
+            ys = None if y is None else y[lo:hi].to(dev, torch.float32)
+            eng.loss_and_grads(xs, es, beta, ys, want_grads=train)
+        else:                                          # more ranks than samples: contribute zeros
+            eng.grad.zero_()
+        if world > 1:
+            if not train:                              # only the scalars need reducing
+                pvdist.allreduce_sum_(eng.scalars, self.group)
+            else:
+                pvdist.allreduce_sum_(eng.grad, self.group)
+        if train or (self.mirror_evaluate_update and eng.grads_live):
+            eng.adam_step()
+        if self._hist is None or self._hist.shape[0] <= i:
+            new = torch.zeros(max(64, 2 * (i + 1)), 4, device=dev, dtype=torch.float32)
+            if self._hist is not None:
+                new[:self._hist.shape[0]].copy_(self._hist)
+            self._hist = new
+        self._hist[i].copy_(eng.scalars)
+
+    def _epoch(self, loader, train: bool, **kwargs) -> float:
+        n = 0
+        for data in loader:
+            if len(data) == 1:  # VAE mode
+                self._svi_step(n, data[0], None, train, **kwargs)
+            else:  # VED or cVAE mode
+                self._svi_step(n, data[0], data[1], train, **kwargs)
+            n += 1
+        # one device->host read per epoch; python-float accumulation like the reference's `epoch_loss += loss`
+        losses = self._hist[:n, 0].cpu().tolist() if n else []
+        epoch_loss = 0.
+        for v in losses:
+            epoch_loss += v
+        return epoch_loss / len(loader.dataset)
+
+    # ------------------------------------------------------------------ reference API
+    def train(self, train_loader: Type[torch.utils.data.DataLoader], **kwargs: float) -> float:
+        """Trains a single epoch; returns the summed loss divided by the dataset size."""
+        return self._epoch(train_loader, True, **kwargs)
+
+    def evaluate(self, test_loader: Type[torch.utils.data.DataLoader], **kwargs: float) -> float:
+        """Evaluates the current model state on a single epoch (no gradients)."""
+        return self._epoch(test_loader, False, **kwargs)
+
+    def step(self,
+             train_loader: Type[torch.utils.data.DataLoader],
+             test_loader: Optional[Type[torch.utils.data.DataLoader]] = None,
+             **kwargs: float) -> None:
+        """Single training and (optionally) evaluation step.
+
+        Keyword Args:
+            scale_factor: scale factor for the KL terms (default 1)
+        """
+        train_loss = self.train(train_loader, **kwargs)
+        self.loss_history["training_loss"].append(train_loss)
+        if test_loader is not None:
+            test_loss = self.evaluate(test_loader, **kwargs)
+            self.loss_history["test_loss"].append(test_loss)
+        self.current_epoch += 1
+
+    def print_statistics(self) -> None:
+        """Prints training and test (if any) losses for current epoch."""
+        e = self.current_epoch
+        if len(self.loss_history["test_loss"]) > 0:
+            template = 'Epoch: {} Training loss: {:.4f}, Test loss: {:.4f}'
+            print(template.format(e, self.loss_history["training_loss"][-1],
+                                  self.loss_history["test_loss"][-1]))
+        else:
+            template = 'Epoch: {} Training loss: {:.4f}'
+            print(template.format(e, self.loss_history["training_loss"][-1]))

@@ -1,0 +1,69 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def make_x(kind, n, data_dim, seed=0):
+    """Same synthetic inputs as tests/golden/make_golden.py:make_x."""
+    g = torch.Generator().manual_seed(seed)
+    if kind == "rand":
+        return torch.rand(n, *data_dim, generator=g)
+    if kind == "randn":
+        return torch.randn(n, *data_dim, generator=g)
+    if kind == "blobs":
+        x = torch.rand(n, *data_dim, generator=g)
+        return (x > 0.8).float() * torch.rand(n, *data_dim, generator=g)
+    raise KeyError(kind)
+
+
+def digest_sample_idx(n, k=64):
+    return torch.linspace(0, n - 1, min(k, n)).round().long()
+
+
+def check_digest(t, gold, prefix, rtol, atol, what=""):
+    """Compares a tensor with the (sum, l2, strided sample) digest stored under `prefix`."""
+    a = t.detach().double().flatten().cpu()
+    assert tuple(gold[prefix + ".shape"]) == tuple(t.shape), (what, prefix)
+    l2 = float(gold[prefix + ".l2"])
+    np.testing.assert_allclose(a.norm().item(), l2, rtol=rtol, atol=atol, err_msg="%s %s l2" % (what, prefix))
+    idx = digest_sample_idx(a.numel())
+    scale = max(l2 / max(a.numel(), 1) ** 0.5, 1e-30)       # rms magnitude of the tensor
+    np.testing.assert_allclose(a[idx].numpy(), gold[prefix + ".sample"].astype(np.float64),
+                               rtol=rtol, atol=max(atol, rtol * scale), err_msg="%s %s sample" % (what, prefix))
+    np.testing.assert_allclose(a.sum().item(), float(gold[prefix + ".sum"]), rtol=rtol,
+                               atol=max(atol, rtol * scale * a.numel() ** 0.5 * 8), err_msg="%s %s sum" % (what, prefix))
+
+
+def meta_of(gold):
+    inv = str(gold["meta.invariances"])
+    return dict(data_dim=tuple(int(v) for v in gold["meta.data_dim"]),
+                invariances=list(inv) if inv else None,
+                batch=int(gold["meta.batch"]) if "meta.batch" in gold else None,
+                latent_dim=int(gold["meta.latent_dim"]) if "meta.latent_dim" in gold else 2,
+                xkind=str(gold["meta.xkind"]),
+                steps=int(gold["meta.steps"]) if "meta.steps" in gold else 0,
+                beta=float(gold["meta.scale_factor"]) if "meta.scale_factor" in gold else 1.0)
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

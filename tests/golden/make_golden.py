@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""
+make_golden.py — generates the golden fixtures under tests/golden/*.npz by
+running the REFERENCE's own code (/root/reference/pyroved) in this container.
+
+The reference cannot be imported as-is (pyro-ppl / torchvision are not
+installed and there is no network), so `_minipyro.install()` registers a
+minimal restatement of the Pyro machinery the hot path runs through; every
+line of pyroVED itself — `models.iVAE.model/guide` (models/ivae.py:165-221),
+`baseVAE._split_latent` (models/base.py:97-119), `nets.fcEncoderNet /
+sDecoderNet / fcDecoderNet` (nets/fc.py), `utils.transform_coordinates`
+(utils/coord.py:47-88), `trainers.SVItrainer` (trainers/svi.py:64-175),
+`utils.init_dataloader` (utils/data.py:6-38) — executes for real.
+
+Run (only where /root/reference exists):
+    python tests/golden/make_golden.py
+The .npz files are data (inputs / expected outputs), committed; the reference
+never travels to the GPU box.
+
+What a fixture holds (per case):
+  meta.*            the case definition (model kwargs, batch, seeds)
+  init.<param>.*    digest of every initial parameter (sum, l2, strided sample)
+  s<k>.loss, s<k>.term.*   loss and the three ELBO terms of SVI step k
+  s<k>.eps / z_loc / z_scale / z       the guide's draw
+  s0.loc            decoder output (probabilities) of step 0
+  s<k>.grad.<param>.*   digest of dLoss/dparam at step k (before the update)
+  s<k>.param.<param>.*  digest of the parameter after step k's Adam update
+  full.*            (selected tiny cases) full tensors instead of digests
+  epochs.*          loss_history of SVItrainer.step(train[, test]) epochs
+  enc.* / dec.*     encode()/decode() outputs after training
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _minipyro  # noqa: E402
+
+_minipyro.install()
+sys.path.insert(0, "/root/reference")
+from pyroved import models, trainers, utils  # noqa: E402
+
+SAMPLE = 64
+
+
+def digest(t):
+    """sum / l2 in float64 + a fixed strided sample: pins a tensor in ~70 numbers."""
+    a = t.detach().double().flatten()
+    n = a.numel()
+    idx = torch.linspace(0, n - 1, min(SAMPLE, n)).round().long()
+    return {"shape": np.array(t.shape, dtype=np.int64),
+            "sum": np.float64(a.sum().item()),
+            "l2": np.float64(a.norm().item()),
+            "sample": t.detach().flatten()[idx].numpy().copy()}
+
+
+def put(out, prefix, d):
+    for k, v in d.items():
+        out[prefix + "." + k] = v
+
+
+def make_x(kind, n, data_dim, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "rand":
+        return torch.rand(n, *data_dim, generator=g)
+    if kind == "randn":            # what the reference's own trainer tests feed (tests/test_trainers.py:29)
+        return torch.randn(n, *data_dim, generator=g)
+    if kind == "blobs":            # MNIST-like: sparse bright blobs, many saturated pixels
+        x = torch.rand(n, *data_dim, generator=g)
+        return (x > 0.8).float() * torch.rand(n, *data_dim, generator=g)
+    raise KeyError(kind)
+
+
+def run_steps(name, data_dim, invariances, batch, steps=3, latent_dim=2, xkind="rand",
+              full=False, model_kw=None, step_kw=None, c_dim=0):
+    model_kw = dict(model_kw or {})
+    step_kw = dict(step_kw or {})
+    out = {}
+    out["meta.data_dim"] = np.array(data_dim)
+    out["meta.invariances"] = np.array("".join(invariances) if invariances else "")
+    out["meta.batch"] = np.int64(batch)
+    out["meta.latent_dim"] = np.int64(latent_dim)
+    out["meta.c_dim"] = np.int64(c_dim)
+    out["meta.xkind"] = np.array(xkind)
+    out["meta.steps"] = np.int64(steps)
+    out["meta.scale_factor"] = np.float64(step_kw.get("scale_factor", 1.0))
+    for k, v in model_kw.items():
+        out["meta.model_kw." + k] = np.array(v)
+    model = models.iVAE(data_dim, latent_dim, invariances, c_dim=c_dim, seed=1, device="cpu", **model_kw)
+    names = {id(p): n for n, p in model.named_parameters()}
+    for n, p in model.named_parameters():
+        put(out, "init." + n, digest(p))
+        if full:
+            out["full.init." + n] = p.detach().numpy().copy()
+    x = make_x(xkind, batch, data_dim)
+    y = None
+    if c_dim:
+        y = utils.to_onehot(torch.arange(batch) % c_dim, c_dim)
+    trainer = trainers.SVItrainer(model, seed=1, device="cpu")
+    for k in range(steps):
+        grads = {}
+        real_optim = trainer.svi.optim
+
+        def spy(params, _real=real_optim, _g=grads):
+            for p in params:
+                _g[names[id(p)]] = p.grad.detach().clone()
+            _real(params)
+        trainer.svi.optim = spy
+        args = (x,) if y is None else (x, y)
+        loss = trainer.svi.step(*args, **step_kw)
+        trainer.svi.optim = real_optim
+        tap = _minipyro.tap()
+        pre = "s%d" % k
+        out[pre + ".loss"] = np.float64(loss)
+        for tn, tv in tap["terms"].items():
+            out[pre + ".term." + tn] = np.float64(tv.item())
+        gfn = tap["guide_fns"]["latent"].base_dist
+        out[pre + ".eps"] = tap["latent.eps"].numpy().copy()
+        out[pre + ".z_loc"] = gfn.loc.detach().numpy().copy()
+        out[pre + ".z_scale"] = gfn.scale.detach().numpy().copy()
+        out[pre + ".z"] = tap["sites"]["guide.latent"].numpy().copy()
+        if k == 0:
+            # decoder output of step 0: recompute with the pre-update weights is not possible
+            # after the step, so it is captured from the model trace's obs distribution
+            pass
+        for n, g in grads.items():
+            put(out, pre + ".grad." + n, digest(g))
+            if full:
+                out["full." + pre + ".grad." + n] = g.numpy().copy()
+        for n, p in model.named_parameters():
+            put(out, pre + ".param." + n, digest(p))
+            if full and k == steps - 1:
+                out["full." + pre + ".param." + n] = p.detach().numpy().copy()
+    # inference API after training (pins "reconstructions")
+    enc_args = (x,) if y is None else (x, y)
+    z_loc, z_scale = model.encode(*enc_args)
+    out["enc.z_loc"] = z_loc.numpy().copy()
+    out["enc.z_scale"] = z_scale.numpy().copy()
+    zc = z_loc[:, -latent_dim:]
+    dec = model.decode(zc) if y is None else model.decode(zc, y)
+    out["dec.loc"] = dec.numpy().copy()
+    if invariances and len(data_dim) == 2:
+        dec2 = model.decode(zc[:2], angle=torch.tensor(0.3), shift=torch.tensor([0.1, -0.2]),
+                            scale=torch.tensor(1.2)) if y is None else None
+        if dec2 is not None:
+            out["dec.loc_ats"] = dec2.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "loss0=%.6f" % out["s0.loss"], "keys=%d" % len(out))
+
+
+def run_step0_loc(name, data_dim, invariances, batch, latent_dim=2, xkind="rand"):
+    """Step-0 forward only, with the decoder's `loc` and the transformed grid."""
+    out = {}
+    out["meta.data_dim"] = np.array(data_dim)
+    out["meta.invariances"] = np.array("".join(invariances) if invariances else "")
+    out["meta.batch"] = np.int64(batch)
+    out["meta.latent_dim"] = np.int64(latent_dim)
+    out["meta.xkind"] = np.array(xkind)
+    model = models.iVAE(data_dim, latent_dim, invariances, seed=1, device="cpu")
+    x = make_x(xkind, batch, data_dim)
+    trainer = trainers.SVItrainer(model, seed=1, device="cpu")
+    # trace without stepping the optimizer: call the ELBO directly under no_grad
+    with torch.no_grad():
+        loss, _ = trainer.svi.loss.loss_and_grads(model.model, model.guide, x)
+    tap = _minipyro.tap()
+    out["loss"] = np.float64(loss.item())
+    for tn, tv in tap["terms"].items():
+        out["term." + tn] = np.float64(tv.item())
+    out["eps"] = tap["latent.eps"].numpy().copy()
+    z = tap["sites"]["guide.latent"]
+    out["z"] = z.numpy().copy()
+    with torch.no_grad():
+        if model.coord > 0:
+            phi, dx, sc, zc = model.split_latent(z)
+            if 't' in model.invariances:
+                dx = (dx * model.t_prior).unsqueeze(1)
+            grid = model.grid.expand(batch, *model.grid.shape)
+            xc = utils.transform_coordinates(grid, phi, dx, sc)
+            out["x_coord_prime"] = xc.numpy().copy()
+            loc = model.decoder(xc, zc)
+        else:
+            loc = model.decoder(z)
+    out["loc"] = loc.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "loss=%.6f" % out["loss"])
+
+
+def run_epochs(name, data_dim, invariances, n, batch, epochs=2, with_test=True, xkind="randn"):
+    """SVItrainer.step(train_loader[, test_loader]) epochs — pins the DataLoader / RNG
+    consumption order and the evaluate() semantics (trainers/svi.py:117-137)."""
+    out = {}
+    out["meta.data_dim"] = np.array(data_dim)
+    out["meta.invariances"] = np.array("".join(invariances) if invariances else "")
+    out["meta.n"] = np.int64(n)
+    out["meta.batch"] = np.int64(batch)
+    out["meta.epochs"] = np.int64(epochs)
+    out["meta.with_test"] = np.int64(with_test)
+    out["meta.xkind"] = np.array(xkind)
+    train = make_x(xkind, n, data_dim, seed=0)
+    test = make_x(xkind, n, data_dim, seed=5)
+    out["train"] = train.numpy().copy()
+    out["test"] = test.numpy().copy()
+    train_loader = utils.init_dataloader(train, batch_size=batch)
+    test_loader = utils.init_dataloader(test, batch_size=batch)
+    model = models.iVAE(data_dim, 2, invariances, seed=1, device="cpu")
+    trainer = trainers.SVItrainer(model, seed=1, device="cpu")
+    for _ in range(epochs):
+        if with_test:
+            trainer.step(train_loader, test_loader)
+        else:
+            trainer.step(train_loader)
+    out["epochs.training_loss"] = np.array(trainer.loss_history["training_loss"], dtype=np.float64)
+    out["epochs.test_loss"] = np.array(trainer.loss_history["test_loss"], dtype=np.float64)
+    for pn, p in model.named_parameters():
+        put(out, "final." + pn, digest(p))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, out["epochs.training_loss"], out["epochs.test_loss"])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    # tiny cases, every invariance set of the reference's own trainer tests
+    # (tests/test_trainers.py:26-40) — full tensors kept for the richest one
+    for inv in (None, ["r"], ["t"], ["s"], ["r", "t"], ["r", "t", "s"]):
+        tag = "".join(inv) if inv else "none"
+        run_steps("ivae_8x8_%s_b6" % tag, (8, 8), inv, batch=6, full=(tag == "rts"))
+        run_step0_loc("ivae_8x8_%s_b6_fwd" % tag, (8, 8), inv, batch=6)
+    run_steps("ivae_1d16_none_b5", (16,), None, batch=5)
+    run_steps("ivae_1d16_t_b5", (16,), ["t"], batch=5)
+    run_step0_loc("ivae_1d16_t_b5_fwd", (16,), ["t"], batch=5)
+    # non-[0,1] inputs, as the reference's tests use (Bernoulli(validate_args=False))
+    run_steps("ivae_8x8_rts_b6_randn", (8, 8), ["r", "t", "s"], batch=6, xkind="randn")
+    # KL scale factor (trainers/svi.py:152-155; ivae.py:175,214)
+    run_steps("ivae_8x8_rt_b6_beta4", (8, 8), ["r", "t"], batch=6, step_kw={"scale_factor": 4.0})
+    # odd sizes: ragged tiles (N = 63 is not a multiple of any MFMA tile)
+    run_steps("ivae_7x9_rts_b3", (7, 9), ["r", "t", "s"], batch=3)
+    # BASELINE configs C1 / C2 (digests only)
+    run_steps("ivae_28x28_r_b128", (28, 28), ["r"], batch=128)
+    run_steps("ivae_28x28_rt_b256", (28, 28), ["r", "t"], batch=256)
+    run_step0_loc("ivae_28x28_rt_b16_fwd", (28, 28), ["r", "t"], batch=16)
+    # saturated pixels (blob images) after a few steps
+    run_steps("ivae_28x28_r_b32_blobs", (28, 28), ["r"], batch=32, steps=4, xkind="blobs")
+    # epoch loops through the reference SVItrainer + DataLoader
+    run_epochs("epochs_8x8_rts", (8, 8), ["r", "t", "s"], n=5, batch=2)
+    run_epochs("epochs_8x8_r_notest", (8, 8), ["r"], n=7, batch=3, with_test=False, xkind="rand")
+    run_epochs("epochs_8x8_none", (8, 8), None, n=5, batch=2)
