@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""
+bench.py — throughput of the SVI training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+Workload (BASELINE.json configs[1]): iVAE, data_dim (28, 28), latent_dim 2, invariances ['r','t'],
+Bernoulli likelihood, batch 256 PER GPU (weak scaling), fp32 arithmetic (the parity mode: fp32-input
+MFMA), synthetic data torch.rand(..., seed 0), model/trainer seed 1, random-init weights.
+A step = Trace_ELBO loss + gradients over one minibatch already resident in HBM
+(pv_ivae_loss_and_grads) + [one all-reduce of the flat gradient when N > 1] + Adam (pv_adam_step).
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline     the dominant kernel against the fp32-MFMA roof, its duration measured with HIP
+               events recorded on the launch stream inside the timed region,
+  cpu_baseline the CPU oracle (eager-torch restatement of the reference) timed on this host's cores
+               on a bounded sample of the same workload (rank 0, N = 1 only),
+  elbo         per-image loss of the first timed step next to the oracle's value on the same inputs.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DATA_DIM = (28, 28)
+INVARIANCES = ["r", "t"]
+LATENT_DIM = 2
+BATCH_PER_GPU = 256
+N_RING = 16                      # distinct resident minibatches (n = 16 * B)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* f32-in peak
+HBM_PEAK_GBS = 8000.0
+
+
+def decoder_flops_per_image(n_pix, hidden=128, coord_dim=2):
+    """Algorithmic fwd+bwd FLOPs of the spatial decoder per image:
+    per pixel fwd = 2*(cd*H) + 2*H*H + 2*H*H + 2*H ; fwd+bwd = 3x."""
+    per_pix = 2 * coord_dim * hidden + 2 * hidden * hidden * 2 + 2 * hidden
+    return 3 * n_pix * per_pix
+
+
+def encoder_flops_per_image(n_pix, z_dim, hidden=128, latent=2):
+    return 3 * (2 * (n_pix * hidden + hidden * hidden + 2 * hidden * z_dim) + 2 * hidden * latent)
+
+
+class HipEvents:
+    """Raw hipEvent_t pairs (the library records them on the stream it launches on)."""
+    def __init__(self, n):
+        self.hip = C.CDLL("libamdhip64.so.7")      # already loaded by torch: the same runtime instance
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.pairs = []
+        for _ in range(n):
+            a, b = C.c_void_p(), C.c_void_p()
+            assert self.hip.hipEventCreate(C.byref(a)) == 0 and self.hip.hipEventCreate(C.byref(b)) == 0
+            self.pairs.append((a, b))
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = C.c_float()
+            if self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0:
+                out.append(ms.value)
+        return out
+
+
+def cpu_baseline(budget_s=15.0):
+    """The CPU oracle (a restatement of the reference's eager-torch path) on the same workload."""
+    import pyroved_amd as pv
+    from oracle import svi_oracle as orc
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    model = pv.models.iVAE(DATA_DIM, LATENT_DIM, INVARIANCES, seed=1, device="cpu")
+    cfg = orc.Config(data_dim=DATA_DIM, latent_dim=LATENT_DIM, invariances=INVARIANCES)
+    o = orc.SVIOracle(model.state_dict(), cfg)
+    x = torch.rand(BATCH_PER_GPU, *DATA_DIM, generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(1)
+    eps0 = torch.empty(BATCH_PER_GPU, cfg.z_dim).normal_()
+    loss0 = o.step(x, eps0)                    # also the warm-up step
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        o.step(x, o.draw_eps(BATCH_PER_GPU))
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 3) or n >= 200:
+            break
+    return dict(value=n * BATCH_PER_GPU / el, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d SVI steps of batch %d (%.1f s) of the same iVAE 28x28 ['r','t'] workload, eager torch CPU "
+                       "oracle (oracle/svi_oracle.py), %d threads" % (n, BATCH_PER_GPU, el, torch.get_num_threads()),
+                ms_per_step=1e3 * el / n), loss0 / BATCH_PER_GPU
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as td
+    if world > 1:
+        td.init_process_group("nccl", device_id=dev)
+
+    import pyroved_amd as pv
+    from pyroved_amd import dist as pvdist
+
+    B = args.batch
+    model = pv.models.iVAE(DATA_DIM, LATENT_DIM, INVARIANCES, seed=1, device=dev)
+    eng = model.engine(fused=bool(args.fused))
+    if world > 1:
+        pvdist.broadcast_(eng.flat)
+    n_pix = DATA_DIM[0] * DATA_DIM[1]
+    # synthetic data, resident in HBM before the timed region; every rank gets its own shard of a
+    # global ring of N_RING * world minibatches (weak scaling: B per GPU)
+    g = torch.Generator().manual_seed(0)
+    ring = torch.rand(N_RING * world * B, *DATA_DIM, generator=g)
+    ring = ring.view(N_RING, world, B, n_pix)[:, rank].contiguous().to(dev)
+    total_steps = args.warmup + args.steps
+    torch.manual_seed(1)
+    eps_all = torch.empty(total_steps, world, B, model.z_dim).normal_()[:, rank].contiguous().to(dev)
+    events = HipEvents(args.steps)
+    hist = torch.zeros(total_steps, 4, device=dev)
+
+    def step(i, timed_idx=None):
+        eng.events = events.pairs[timed_idx] if timed_idx is not None else (None, None)
+        eng.loss_and_grads(ring[i % N_RING], eps_all[i])
+        if world > 1:
+            pvdist.allreduce_sum_(eng.grad)
+        eng.adam_step()
+        hist[i].copy_(eng.scalars)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, i)
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    elapsed = t.item()
+
+    kms = events.elapsed_ms()
+    losses = hist[:, 0].cpu()
+    if rank == 0:
+        images = args.steps * B * world
+        value = images / elapsed
+        dec_fl = decoder_flops_per_image(n_pix)
+        k_avg_ms = sum(kms) / max(len(kms), 1)
+        # which kernel the events bracket depends on the path (see pv_plan.hip / pv_sdec_fused.hip)
+        fused_used = eng.uses_fused(B)
+        if fused_used:
+            kname = "pv_sdec_fused_kernel (decoder fwd+bwd, all layers)"
+            flops_per_launch = dec_fl * B
+        else:
+            kname = "pv_gemm_kernel<NT> (decoder hidden layer fwd, M=B*N, K=N=128)"
+            flops_per_launch = 2.0 * B * n_pix * 128 * 128
+        achieved = flops_per_launch / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
+        out = {
+            "metric": "images/sec (SVI step)", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "iVAE 28x28 invariances=['r','t'] latent_dim=2 bernoulli, batch %d per GPU "
+                                   "(global %d), fp32 (f32-input MFMA), SVI step = ELBO+grads+%sAdam"
+                                   % (B, B * world, "allreduce+" if world > 1 else ""),
+                       "parallelism": "dp%d" % world, "path": "fused" if fused_used else "layered"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": kname,
+                         "kernel_ms": k_avg_ms, "flops_per_launch": flops_per_launch},
+            "step_frac_of_mfma_roof": value / world * (dec_fl + encoder_flops_per_image(n_pix, model.z_dim))
+            / (MFMA_F32_PEAK_TFLOPS * 1e12),
+            "elbo": {"loss_per_image_first_timed_step": losses[args.warmup].item() / (B * world),
+                     "loss_per_image_last_step": losses[-1].item() / (B * world),
+                     "loss_per_image_step0": losses[0].item() / (B * world)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, loss0 = cpu_baseline()
+            out["cpu_baseline"] = cb
+            out["elbo"]["oracle_loss_per_image_step0"] = loss0
+            if B == BATCH_PER_GPU:
+                out["elbo"]["rel_err_step0"] = abs(out["elbo"]["loss_per_image_step0"] - loss0) / abs(loss0)
+        print(json.dumps(out))
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,9 @@ typedef struct pv_ivae_plan {
   float   lr, adam_beta1, adam_beta2, adam_eps;
   int32_t adam_step;      /* 1-based step count of THIS update                            */
   int32_t _pad2;
+  /* ---- optional instrumentation ---- */
+  void*   ev_start;       /* hipEvent_t recorded on `stream` right before the dominant decoder  */
+  void*   ev_stop;        /* kernel's launch and right after it (NULL: no recording)            */
 } pv_ivae_plan;
 
 /* Library / ABI version (PV_ABI_VERSION). */
@@ -116,6 +119,11 @@ int pv_version(void);
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
  * layer widths).  Returns < 0 on an unsupported plan. */
 int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan);
+
+/* 1 if pv_ivae_loss_and_grads will run this plan on the fused persistent spatial-decoder
+ * kernel, 0 if it will take the layer-by-layer path (plan->fused == 0 or an architecture the
+ * fused kernel is not specialised for). */
+int pv_ivae_uses_fused(const pv_ivae_plan* plan);
 
 /* Trace_ELBO.loss_and_grads for iVAE.guide + iVAE.model (models/ivae.py:165-221,
  * pyro's Trace_ELBO with one particle): writes plan->scalars and, when

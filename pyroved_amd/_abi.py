@@ -47,6 +47,7 @@ class pv_ivae_plan(C.Structure):
         ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
+        ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
     ]
 
 
@@ -54,6 +55,7 @@ class pv_ivae_plan(C.Structure):
 SIGNATURES = {
     "pv_version": (C.c_int, []),
     "pv_ivae_workspace_bytes": (C.c_int64, [C.POINTER(pv_ivae_plan)]),
+    "pv_ivae_uses_fused": (C.c_int, [C.POINTER(pv_ivae_plan)]),
     "pv_ivae_loss_and_grads": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
     "pv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),

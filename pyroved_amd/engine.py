@@ -48,6 +48,7 @@ class IVAEEngine:
         self.device = None
         self.flat = self.grad = self.m = self.v = None
         self.ws = None
+        self.events = (None, None)      # optional raw hipEvent_t pair recorded around the dominant kernel
         self._layout: Dict[str, int] = {}
         self._views: Dict[str, torch.Tensor] = {}
         self._check_model()
@@ -214,6 +215,7 @@ class IVAEEngine:
         p.batch = batch
         p.beta = float(beta)
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
+        p.ev_start, p.ev_stop = self.events
         need = _abi.lib().pv_ivae_workspace_bytes(C.byref(p))
         if need < 0:
             raise _abi.PvError("pyroved_amd: unsupported plan (pv_ivae_workspace_bytes -> %d)" % need)
@@ -299,6 +301,10 @@ class IVAEEngine:
                                              float(scale), _abi.ptr(loc), _abi.current_stream()), "pv_ivae_decode")
         self._keep = (z,)
         return loc.view(b, *self.model.data_dim)
+
+    def uses_fused(self, batch: int) -> bool:
+        """Whether loss_and_grads runs the fused persistent decoder kernel for this batch size."""
+        return bool(_abi.lib().pv_ivae_uses_fused(C.byref(self._plan(batch))))
 
     # views for tests / data-parallel reduction
     def grad_of(self, key: str) -> torch.Tensor:

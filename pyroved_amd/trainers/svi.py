@@ -67,8 +67,12 @@ class SVItrainer:
         self.rng = kwargs.get("rng", "cpu")
         self.group = kwargs.get("process_group", None)
         self.mirror_evaluate_update = bool(kwargs.get("mirror_evaluate_update", True))
-        self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
-                                   fused=kwargs.get("fused", True))
+        if kwargs.get("engine") is not None:
+            # test hook: a stand-in engine (tests drive the data-parallel host logic on CPU/gloo with it)
+            self.engine = kwargs["engine"]
+        else:
+            self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
+                                       fused=kwargs.get("fused", True))
         self.engine.lr, self.engine.betas, self.engine.adam_eps = float(adam["lr"]), tuple(adam["betas"]), float(adam["eps"])
         self.loss_history = {"training_loss": [], "test_loss": []}
         self.current_epoch = 0

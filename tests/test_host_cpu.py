@@ -1,0 +1,263 @@
+"""
+CPU tests of the host side: the C-ABI library loads and exports every symbol the header
+declares (no compute calls), the reference-API mirror behaves like the reference's own shape /
+type tests (tests/test_models.py:50-97 of the reference), the product refuses to compute on the
+CPU, and the trainer's host logic — data order, eps stream, evaluate semantics, and the
+data-parallel shard / all-reduce path with world_size 2 over gloo — reproduces the reference
+trainer's numbers when driven with a stand-in engine.
+"""
+import ctypes as C
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, check_digest
+
+import pyroved_amd as pv
+from pyroved_amd import _abi, dist as pvdist
+from oracle import svi_oracle as orc
+from _oracle_engine import OracleEngine
+
+tt = torch.tensor
+
+
+# ------------------------------------------------------------------------------- C ABI
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "pyroved_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pv_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_abi_exports_every_header_symbol():
+    names = header_functions()
+    assert "pv_ivae_loss_and_grads" in names and "pv_adam_step" in names and len(names) >= 11
+    assert sorted(_abi.SIGNATURES.keys()) == names, "ctypes binding and header disagree"
+    lib = _abi.lib()           # raises if the .so is missing or incomplete
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.pv_version() == _abi.PV_ABI_VERSION
+
+
+def test_plan_struct_matches_header_layout():
+    """sizeof/offsets of the ctypes mirror vs the C struct, through a compiled probe."""
+    import subprocess
+    import tempfile
+    probe = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "pyroved_amd.h"
+int main() {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(pv_layer), sizeof(pv_ivae_plan), offsetof(pv_ivae_plan, enc),
+         offsetof(pv_ivae_plan, out), offsetof(pv_ivae_plan, params), offsetof(pv_ivae_plan, scalars),
+         offsetof(pv_ivae_plan, adam_step));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(probe)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o",
+                               os.path.join(d, "p")])
+        out = subprocess.check_output([os.path.join(d, "p")]).split()
+    got = [int(v) for v in out]
+    P = _abi.pv_ivae_plan
+    want = [C.sizeof(_abi.pv_layer), C.sizeof(P), P.enc.offset, P.out.offset, P.params.offset, P.scalars.offset,
+            P.adam_step.offset]
+    assert got == want
+
+
+def test_workspace_query_runs_without_gpu():
+    """pv_ivae_workspace_bytes is pure host arithmetic: callable on the CPU box."""
+    lib = _abi.lib()
+    assert lib.pv_linear_workspace_bytes(200704, 128, 128) > 0
+    assert lib.pv_linear_workspace_bytes(-1, 128, 128) < 0
+
+
+# ------------------------------------------------------------------------------- API mirror
+@pytest.mark.parametrize("invariances, coord_exp", [(None, 0), (['t'], 1)])
+def test_base_vae_1d(invariances, coord_exp):
+    m = pv.models.baseVAE((8,), invariances, device="cpu")
+    assert m.coord == coord_exp
+
+
+@pytest.mark.parametrize("invariances, coord_exp",
+                         [(None, 0), (['r'], 1), (['t'], 2), (['s'], 1), (['r', 's', 't'], 4)])
+def test_base_vae_2d(invariances, coord_exp):
+    m = pv.models.baseVAE((8, 8), invariances, device="cpu")
+    assert m.coord == coord_exp
+
+
+@pytest.mark.parametrize("invariances", [['r'], ['s'], ['r', 't']])
+def test_base_vae_1d_exception(invariances):
+    with pytest.raises(ValueError):
+        pv.models.baseVAE((8,), invariances, device="cpu")
+
+
+def test_split_latent_shapes():
+    z = torch.randn(5, 3)
+    m = pv.models.baseVAE((8,), ['t'], device="cpu")
+    phi, dx, sc, zc = m._split_latent(z)
+    assert phi is None and sc is None and dx.shape == (5, 1) and zc.shape == (5, 2)
+    m = pv.models.baseVAE((8, 8), ['r', 't', 's'], device="cpu")
+    z = torch.randn(5, 6)
+    phi, dx, sc, zc = m._split_latent(z)
+    assert phi.shape == (5,) and dx.shape == (5, 2) and sc.shape == (5,) and zc.shape == (5, 2)
+    o = orc.split_latent(orc.Config((8, 8), 2, ['r', 't', 's']), z)
+    for a, b in zip((phi, dx, sc, zc), o):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("invariances, n_params", [(['r'], 151559), (['r', 't'], 152075)])
+def test_ivae_parameter_inventory(invariances, n_params):
+    """parameter count and state_dict keys of the 28x28 models."""
+    m = pv.models.iVAE((28, 28), 2, invariances, device="cpu")
+    assert sum(p.numel() for p in m.parameters()) == n_params
+    assert list(m.state_dict().keys()) == [
+        'encoder_z.fc_layers.0.weight', 'encoder_z.fc_layers.0.bias', 'encoder_z.fc_layers.2.weight',
+        'encoder_z.fc_layers.2.bias', 'encoder_z.fc11.weight', 'encoder_z.fc11.bias', 'encoder_z.fc12.weight',
+        'encoder_z.fc12.bias', 'decoder.coord_latent.fc_coord.weight', 'decoder.coord_latent.fc_coord.bias',
+        'decoder.coord_latent.fc_latent.weight', 'decoder.fc_layers.0.weight', 'decoder.fc_layers.0.bias',
+        'decoder.fc_layers.2.weight', 'decoder.fc_layers.2.bias', 'decoder.out.weight', 'decoder.out.bias']
+    assert m.z_dim == 2 + m.coord and m.c_dim == 0 and m.ndim == 2
+    assert m.grid.shape == (784, 2)
+
+
+def test_vanilla_uses_fc_decoder_and_samplers():
+    m = pv.models.iVAE((8, 8), 2, None, device="cpu")
+    assert isinstance(m.decoder, pv.nets.fcDecoderNet) and m.decoder.out.weight.shape == (64, 128)
+    with pytest.raises(KeyError):
+        pv.utils.get_sampler("poisson")
+    assert pv.utils.get_sampler("gaussian", decoder_sig=0.3).decoder_sig == pytest.approx(0.3)
+
+
+def test_save_load_weights_roundtrip(tmp_path):
+    m = pv.models.iVAE((8, 8), 2, ['r'], seed=1, device="cpu")
+    m.save_weights(str(tmp_path / "w"))
+    m2 = pv.models.iVAE((8, 8), 2, ['r'], seed=7, device="cpu")
+    assert not torch.equal(m.decoder.out.weight, m2.decoder.out.weight)
+    m2.load_weights(str(tmp_path / "w.pt"))
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_no_cpu_fallback():
+    """The product refuses to run without a HIP device instead of silently computing on the CPU."""
+    m = pv.models.iVAE((8, 8), 2, ['r'], seed=1, device="cpu")
+    with pytest.raises(_abi.PvError):
+        pv.trainers.SVItrainer(m)
+    with pytest.raises(_abi.PvError):
+        m.encode(torch.rand(3, 8, 8))
+    with pytest.raises(_abi.PvError):
+        pv.utils.transform_coordinates(torch.zeros(2, 4, 2))
+    with pytest.raises(_abi.PvError):
+        m.encoder_z(torch.rand(3, 8, 8))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pyroved_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+# ------------------------------------------------------------------------------- trainer host logic
+def _trainer_run(name, engine_factory, **kw):
+    gold = load_golden(name)
+    inv = str(gold["meta.invariances"])
+    data_dim = tuple(int(v) for v in gold["meta.data_dim"])
+    train, test = torch.from_numpy(gold["train"]), torch.from_numpy(gold["test"])
+    batch = int(gold["meta.batch"])
+    train_loader = pv.utils.init_dataloader(train, batch_size=batch)
+    test_loader = pv.utils.init_dataloader(test, batch_size=batch)
+    model = pv.models.iVAE(data_dim, 2, list(inv) if inv else None, seed=1, device="cpu")
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=list(inv) if inv else None)
+    eng = engine_factory(model, cfg)
+    trainer = pv.trainers.SVItrainer(model, seed=1, engine=eng, device="cpu", **kw)
+    for _ in range(int(gold["meta.epochs"])):
+        if int(gold["meta.with_test"]):
+            trainer.step(train_loader, test_loader)
+        else:
+            trainer.step(train_loader)
+    return gold, trainer, eng
+
+
+@pytest.mark.parametrize("name", ["epochs_8x8_rts", "epochs_8x8_r_notest", "epochs_8x8_none"])
+def test_trainer_host_logic_reproduces_reference_epochs(name, capsys):
+    """SVItrainer's loop (data order, eps draws, evaluate-steps-the-optimizer, normalisation by
+    len(dataset), history, print format) around a stand-in engine == the reference's trainer."""
+    gold, trainer, eng = _trainer_run(name, OracleEngine)
+    np.testing.assert_allclose(trainer.loss_history["training_loss"], gold["epochs.training_loss"], rtol=1e-5)
+    np.testing.assert_allclose(trainer.loss_history["test_loss"], gold["epochs.test_loss"], rtol=1e-5)
+    for key in eng.o.p:
+        check_digest(eng.o.p[key], gold, "final." + key, rtol=1e-4, atol=1e-7, what=name)
+    trainer.print_statistics()
+    out = capsys.readouterr().out.strip()
+    if len(gold["epochs.test_loss"]):
+        assert out == 'Epoch: {} Training loss: {:.4f}, Test loss: {:.4f}'.format(
+            trainer.current_epoch, trainer.loss_history["training_loss"][-1], trainer.loss_history["test_loss"][-1])
+    else:
+        assert out == 'Epoch: {} Training loss: {:.4f}'.format(
+            trainer.current_epoch, trainer.loss_history["training_loss"][-1])
+
+
+def test_shard_bounds_cover_batch():
+    for n in (0, 1, 5, 7, 256, 257):
+        for w in (1, 2, 3, 8):
+            spans = [pvdist.shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and b >= a
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, name, q):
+    import torch.distributed as td
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        gold, trainer, eng = _trainer_run(name, OracleEngine)
+        q.put((rank, trainer.loss_history, {k: v.detach().numpy().copy() for k, v in eng.o.p.items()}))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["epochs_8x8_rts", "epochs_8x8_r_notest"])
+def test_data_parallel_world2_gloo_matches_single_process(name):
+    """Two ranks over gloo, each computing its contiguous shard of every global minibatch (incl. the
+    odd-sized and last partial batches), ONE all-reduce of [grads | scalars] per step: the loss history
+    and the final weights equal the single-process reference run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    gold = load_golden(name)
+    res.sort(key=lambda t: t[0])
+    for rank, hist, params in res:
+        np.testing.assert_allclose(hist["training_loss"], gold["epochs.training_loss"], rtol=2e-5)
+        np.testing.assert_allclose(hist["test_loss"], gold["epochs.test_loss"], rtol=2e-5)
+        for key, p in params.items():
+            check_digest(torch.from_numpy(p), gold, "final." + key, rtol=2e-4, atol=1e-7,
+                         what="%s rank %d" % (name, rank))
+    for key in res[0][2]:     # replicas stay in lock-step
+        assert np.array_equal(res[0][2][key], res[1][2][key]), key
