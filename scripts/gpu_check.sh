@@ -12,6 +12,7 @@ echo "== pytest"; timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no
 tail -5 $OUT/pytest.log
 echo "== bench"; timeout 900 python bench.py --steps 50 --warmup 10 > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/bench.log
 tail -2 $OUT/bench.log
-echo "== rocprof"; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1; echo "rocprof rc=$?")
+echo "== rocprof"; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1; echo "rocprof rc=$?")
 find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null
+find /tmp/prof_$TAG -type f | head -20
 ls -la $OUT
