@@ -432,7 +432,8 @@ __global__ void pv_head_bwd_kernel(PvHeadBwd h) {
   if (h.coord_dim == 0) {
     dz = h.dzc[(int64_t)b * h.ldzc + i];
   } else {
-    const float* tpg = h.dtp + (int64_t)b * 4;      // dphi, dscale, dtx, dty
+    const float* tb = h.dtp + (int64_t)b * h.dtp_sb;
+    const float tpg[4] = {tb[0], tb[h.dtp_sc], tb[2 * h.dtp_sc], tb[3 * h.dtp_sc]};   // dphi, dscale, dtx, dty
     int idx = 0;
     dz = 0.0f;
     bool done = false;

@@ -207,8 +207,33 @@ __global__ __launch_bounds__(256) void pv_reduce_partials_kernel(const float* __
   }
 }
 
+// many partials, few outputs: 4 outputs x 64 partial-slices per workgroup, fixed-order LDS tree
+__global__ __launch_bounds__(256) void pv_reduce_partials_deep_kernel(const float* __restrict__ part, int nparts,
+                                                                      int64_t stride, float* __restrict__ out,
+                                                                      int64_t n) {
+  __shared__ float sm[64][4];
+  const int o = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 4 + o;
+  float v = 0.0f;
+  if (i < n)
+    for (int q = sl; q < nparts; q += 64) v += part[(int64_t)q * stride + i];
+  sm[sl][o] = v;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (sl < w) sm[sl][o] += sm[sl + w][o];
+    __syncthreads();
+  }
+  if (sl == 0 && i < n) out[i] = sm[0][o];
+}
+
 int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s) {
   if (n <= 0) return 0;
+  if (nparts > 32 && n <= 4 * 65535) {
+    hipLaunchKernelGGL(pv_reduce_partials_deep_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nparts,
+                       stride, out, n);
+    PV_LAUNCH_CHECK();
+    return 0;
+  }
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pv_reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, stride, out, n);
@@ -220,12 +245,26 @@ int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out
 #define CS_ROWS 256
 __global__ __launch_bounds__(256) void pv_colsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int N,
                                                         float* __restrict__ part) {
+  __shared__ float sm[256];
   const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
   const int64_t r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  // narrow matrices: split the rows of the chunk over 256/width thread groups, combine in fixed order
+  const int width = N > 128 ? 256 : (N > 64 ? 128 : 64);
+  const int groups = 256 / width;
+  const int c = threadIdx.x % width, rg = threadIdx.x / width;
+  for (int n0 = 0; n0 < N; n0 += width) {
+    const int n = n0 + c;
     float v = 0.0f;
-    for (int64_t r = r0; r < r1; ++r) v += x[r * ldx + n];
-    part[(int64_t)blockIdx.x * N + n] = v;
+    if (n < N)
+      for (int64_t r = r0 + rg; r < r1; r += groups) v += x[r * ldx + n];
+    __syncthreads();
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+      float a = sm[c];
+      for (int g = 1; g < groups; ++g) a += sm[g * width + c];
+      part[(int64_t)blockIdx.x * N + n] = a;
+    }
   }
 }
 

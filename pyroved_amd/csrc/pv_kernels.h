@@ -70,7 +70,8 @@ int pv_reduce_mid(const float* part, int nb, int nc, int n, float* out, hipStrea
 struct PvHeadBwd {
   const float* dzc;      // (B, ldzc): dL/d(decoder latent input) (content [+ y] columns)
   int64_t ldzc;
-  const float* dtp;      // (B, 4): dphi, dscale, dtx, dty  (null when coord_dim == 0)
+  const float* dtp;      // dphi, dscale, dtx, dty of sample b at dtp[b*dtp_sb + c*dtp_sc] (null when coord_dim == 0)
+  int dtp_sb, dtp_sc;
   const float* z;
   const float* z_scale;
   const float* eps;

@@ -38,6 +38,9 @@ struct Layout {
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
+  // fused persistent decoder path
+  bool fused; int f_grid, f_kmax;
+  float* f_part; float* f_part_hz; float* f_rowtp;
   int64_t total;
 };
 
@@ -75,9 +78,12 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
   L.ebuf[0] = c.take(B * maxe);
   L.ebuf[1] = c.take(B * maxe);
   int64_t maxd = 0;
+  L.fused = p->fused && pv_sdec_fused_supported(p);
+  L.f_grid = L.f_kmax = 0;
+  L.f_part = L.f_part_hz = L.f_rowtp = nullptr;
   for (int i = 0; i < p->n_dec; ++i) {
-    L.dact[i] = c.take(R * p->dec[i].out_dim);
-    L.dpre_[i] = p->dec[i].act == PV_ACT_GELU ? c.take(R * p->dec[i].out_dim) : nullptr;
+    L.dact[i] = L.fused ? nullptr : c.take(R * p->dec[i].out_dim);
+    L.dpre_[i] = (!L.fused && p->dec[i].act == PV_ACT_GELU) ? c.take(R * p->dec[i].out_dim) : nullptr;
     if (p->dec[i].out_dim > maxd) maxd = p->dec[i].out_dim;
   }
   int64_t scratch = 0;
@@ -86,7 +92,16 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
     const int64_t H0 = p->fc_coord.out_dim;
     if (H0 > maxd) maxd = H0;
     L.hz = c.take(B * H0);
-    L.h0 = c.take(R * H0);
+    L.h0 = L.fused ? nullptr : c.take(R * H0);
+    if (L.fused) {
+      const int64_t units = R / FD_UNIT;
+      L.f_grid = pv_sdec_fused_grid(units);
+      L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
+      L.f_part = c.take((int64_t)L.f_grid * FD_REC);
+      L.f_part_hz = c.take(B * L.f_kmax * H0);
+      L.f_rowtp = c.take(4 * R);
+      upd(pv_colsum_ws(B, (int)H0));
+    }
     L.logits = nullptr;
     L.llrow = c.take(R);
     const int64_t ob = pv_out_lik_blocks(R);
@@ -121,8 +136,8 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
     upd(pv_colsum_ws(B, (int)N));
   }
   L.llb = c.take(B);
-  L.dbuf[0] = c.take(R * maxd);
-  L.dbuf[1] = c.take(R * maxd);
+  L.dbuf[0] = L.fused ? nullptr : c.take(R * maxd);
+  L.dbuf[1] = L.fused ? nullptr : c.take(R * maxd);
   // scratch: the largest split-K / colsum requirement of any single call
   for (int i = 0; i < p->n_enc; ++i) {
     upd(gemm_ws_need(B, p->enc[i].out_dim, p->enc[i].in_dim));
@@ -140,7 +155,6 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
     upd(gemm_ws_need(R, p->dec[i].in_dim, p->dec[i].out_dim));
     upd(pv_colsum_ws(R, p->dec[i].out_dim));
   }
-  upd(pv_sdec_fused_ws_bytes(p));
   L.scratch_bytes = pv_align_up(scratch, 256);
   L.scratch = base ? (void*)(base + c.off) : nullptr;
   c.off += L.scratch_bytes;
@@ -250,24 +264,114 @@ int decoder_hidden_fwd(const pv_ivae_plan* p, const Layout& L, const float* zin,
   return 0;
 }
 
+// dL/dz from the decoder (dzc: content/y columns; dtp: phi, scale, tx, ty) -> head -> encoder layers
+int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, int dtp_sb, int dtp_sc,
+                       hipStream_t s) {
+  const int64_t B = p->batch, z = p->z_dim;
+  float* G = p->grads;
+  void* ws = L.scratch;
+  const int64_t wsb = L.scratch_bytes;
+  const int ne = p->n_enc;
+  PvHeadBwd hb{};
+  hb.dzc = L.dzc; hb.ldzc = lat_in; hb.dtp = L.dtp; hb.dtp_sb = dtp_sb; hb.dtp_sc = dtp_sc; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;
+  hb.head = L.head; hb.dhead = L.dhead; hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
+  hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
+  hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
+  PV_TRY(pv_head_bwd(hb, s));
+  const pv_layer& hd = p->head;
+  const float* elast = L.eact[ne - 1];
+  PV_TRY(linear_wgrad(L.dhead, 2 * z, elast, hd.in_dim, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B,
+                      hd.in_dim, 2 * z, ws, wsb, s));
+  float* ecur = L.ebuf[0];
+  float* eoth = L.ebuf[1];
+  PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + hd.w_off, ecur, hd.in_dim, elast, L.epre[ne - 1], hd.in_dim,
+                      p->enc[ne - 1].act, B, hd.in_dim, 2 * z, ws, wsb, s));
+  const float* xin = p->c_dim > 0 ? L.xin : p->x;
+  const int64_t ldx = p->n_pix + p->c_dim;
+  for (int i = ne - 1; i >= 0; --i) {
+    const pv_layer& l = p->enc[i];
+    const float* in = i > 0 ? L.eact[i - 1] : xin;
+    const int64_t ldin = i > 0 ? p->enc[i - 1].out_dim : ldx;
+    PV_TRY(linear_wgrad(ecur, l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, B, l.in_dim,
+                        l.out_dim, ws, wsb, s));
+    if (i > 0) {
+      PV_TRY(linear_dgrad(ecur, l.out_dim, p->params + l.w_off, eoth, l.in_dim, in, L.epre[i - 1], ldin,
+                          p->enc[i - 1].act, B, l.in_dim, l.out_dim, ws, wsb, s));
+      float* t = ecur; ecur = eoth; eoth = t;
+    }
+  }
+  return 0;
+}
+
+// guide: encoder -> (z_loc, z_scale) -> z = z_loc + z_scale*eps, sampled-KL terms, transform parameters
+int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+  PV_TRY(encoder_fwd(p, L, s));
+  PvHead h{};
+  h.head = L.head; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
+  h.z_loc_out = p->z_loc; h.z_scale_out = p->z_scale;
+  h.tp = p->coord_dim > 0 ? L.tp : nullptr; h.zy = L.zy; h.scalars = p->scalars;
+  h.B = p->batch; h.z_dim = p->z_dim; h.c_dim = p->c_dim; h.coord_dim = p->coord_dim;
+  h.has_r = p->has_r; h.has_t = p->has_t; h.has_s = p->has_s;
+  h.tp0 = p->t_prior[0]; h.tp1 = p->t_prior[1]; h.sc_prior = p->sc_prior; h.beta = p->beta;
+  return pv_head_fwd(h, s);
+}
+
+// loss_and_grads with the fused persistent spatial-decoder kernel (pv_sdec_fused.hip)
+int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
+  const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
+  const int64_t lat_in = p->latent_dim + p->c_dim;
+  const int H = FD_H;
+  float* G = p->grads;
+  PV_TRY(guide_fwd(p, L, s));
+  const int coord = (int)(z - p->latent_dim);
+  const float* zin = p->c_dim > 0 ? L.zy : L.z + coord;
+  const int64_t ldz = p->c_dim > 0 ? lat_in : z;
+  if (p->fc_latent.in_dim != lat_in) return PV_EINVAL;
+  PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
+                    L.scratch, L.scratch_bytes, s));
+  PvFused f{};
+  f.x = p->x; f.grid = p->grid; f.tp = L.tp; f.hz = L.hz;
+  f.Wc = p->params + p->fc_coord.w_off; f.bc = p->params + p->fc_coord.b_off;
+  f.W1 = p->params + p->dec[0].w_off; f.b1 = p->params + p->dec[0].b_off;
+  f.W2 = p->params + p->dec[1].w_off; f.b2 = p->params + p->dec[1].b_off;
+  f.wo = p->params + p->out.w_off; f.bo = p->params + p->out.b_off;
+  f.llrow = L.llrow; f.loc = p->loc; f.rowtp = L.f_rowtp; f.part_hz = L.f_part_hz; f.part = L.f_part;
+  f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)B; f.lik = p->lik;
+  f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
+  if (want_grads) {
+    hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(B * L.f_kmax * H) * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_start, s);
+  PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
+  if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_stop, s);
+  PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
+  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, s));
+  if (!want_grads) return 0;
+  PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
+                   p->fc_coord.w_off, p->out.w_off, p->out.b_off};
+  PV_TRY(pv_sdec_fused_reduce(L.f_part, L.f_grid, G, o, p->coord_dim, s));
+  // per-sample d(phi, scale, tx, ty): 4 planes of B sums over each sample's N rows
+  PV_TRY(pv_segsum(L.f_rowtp, 4 * B, N, L.dtp, s));
+  PV_TRY(pv_reduce_mid(L.f_part_hz, (int)B, L.f_kmax, H, L.dhz, s));
+  PV_TRY(pv_colsum(L.dhz, H, B, H, G + p->fc_coord.b_off, L.scratch, L.scratch_bytes, s));
+  PV_TRY(linear_wgrad(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, nullptr, B, lat_in, H, L.scratch, L.scratch_bytes,
+                      s));
+  PV_TRY(linear_dgrad(L.dhz, H, p->params + p->fc_latent.w_off, L.dzc, lat_in, nullptr, nullptr, 0, PV_ACT_NONE, B,
+                      lat_in, H, L.scratch, L.scratch_bytes, s));
+  return latent_encoder_bwd(p, L, lat_in, 1, (int)B, s);
+}
+
 int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
   const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
   const int64_t lat_in = (p->coord_dim > 0 ? p->latent_dim : p->z_dim) + p->c_dim;
   float* G = p->grads;
   void* ws = L.scratch;
   const int64_t wsb = L.scratch_bytes;
-  const int nd = p->n_dec, ne = p->n_enc;
+  const int nd = p->n_dec;
 
   // ---------------- forward ----------------
-  PV_TRY(encoder_fwd(p, L, s));
-  PvHead h{};
-  h.head = L.head; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
-  h.z_loc_out = p->z_loc; h.z_scale_out = p->z_scale;
-  h.tp = p->coord_dim > 0 ? L.tp : nullptr; h.zy = L.zy; h.scalars = p->scalars;
-  h.B = (int)B; h.z_dim = (int)z; h.c_dim = p->c_dim; h.coord_dim = p->coord_dim;
-  h.has_r = p->has_r; h.has_t = p->has_t; h.has_s = p->has_s;
-  h.tp0 = p->t_prior[0]; h.tp1 = p->t_prior[1]; h.sc_prior = p->sc_prior; h.beta = p->beta;
-  PV_TRY(pv_head_fwd(h, s));
+  PV_TRY(guide_fwd(p, L, s));
   const int coord = (int)(z - p->latent_dim);
   const float* zin = p->c_dim > 0 ? L.zy : (p->coord_dim > 0 ? L.z + coord : L.z);
   const int64_t ldz = p->c_dim > 0 ? lat_in : z;
@@ -343,36 +447,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
                         lat_in, H0, ws, wsb, s));
   }
 
-  // ---------------- backward: latent + encoder ----------------
-  PvHeadBwd hb{};
-  hb.dzc = L.dzc; hb.ldzc = lat_in; hb.dtp = L.dtp; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;
-  hb.head = L.head; hb.dhead = L.dhead; hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
-  hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
-  hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
-  PV_TRY(pv_head_bwd(hb, s));
-  const pv_layer& hd = p->head;
-  const float* elast = L.eact[ne - 1];
-  PV_TRY(linear_wgrad(L.dhead, 2 * z, elast, hd.in_dim, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B,
-                      hd.in_dim, 2 * z, ws, wsb, s));
-  float* ecur = L.ebuf[0];
-  float* eoth = L.ebuf[1];
-  PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + hd.w_off, ecur, hd.in_dim, elast, L.epre[ne - 1], hd.in_dim,
-                      p->enc[ne - 1].act, B, hd.in_dim, 2 * z, ws, wsb, s));
-  const float* xin = p->c_dim > 0 ? L.xin : p->x;
-  const int64_t ldx = p->n_pix + p->c_dim;
-  for (int i = ne - 1; i >= 0; --i) {
-    const pv_layer& l = p->enc[i];
-    const float* in = i > 0 ? L.eact[i - 1] : xin;
-    const int64_t ldin = i > 0 ? p->enc[i - 1].out_dim : ldx;
-    PV_TRY(linear_wgrad(ecur, l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, B, l.in_dim,
-                        l.out_dim, ws, wsb, s));
-    if (i > 0) {
-      PV_TRY(linear_dgrad(ecur, l.out_dim, p->params + l.w_off, eoth, l.in_dim, in, L.epre[i - 1], ldin,
-                          p->enc[i - 1].act, B, l.in_dim, l.out_dim, ws, wsb, s));
-      float* t = ecur; ecur = eoth; eoth = t;
-    }
-  }
-  return 0;
+  return latent_encoder_bwd(p, L, lat_in, 4, 1, s);
 }
 
 }  // namespace
@@ -383,7 +458,14 @@ extern "C" int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan) {
   if (!valid_plan(plan)) return PV_EINVAL;
   Layout L;
   carve(plan, nullptr, L);
-  return L.total;
+  int64_t total = L.total;
+  if (L.fused) {                      // encode / decode always use the layered layout
+    pv_ivae_plan q = *plan;
+    q.fused = 0;
+    carve(&q, nullptr, L);
+    if (L.total > total) total = L.total;
+  }
+  return total;
 }
 
 extern "C" int pv_ivae_uses_fused(const pv_ivae_plan* plan) {
@@ -398,8 +480,7 @@ extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, 
   carve(plan, (char*)plan->ws, L);
   if (plan->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
-  if (plan->fused && pv_sdec_fused_supported(plan))
-    return pv_ivae_loss_and_grads_fused(plan, want_grads, s);
+  if (L.fused) return loss_and_grads_fused(plan, L, want_grads, s);
   return loss_and_grads_layered(plan, L, want_grads, s);
 }
 
@@ -411,6 +492,9 @@ extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
 
 extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream) {
   if (!valid_plan(plan) || !plan->params || !plan->x || !plan->ws || !z_loc || !z_scale) return PV_EINVAL;
+  pv_ivae_plan lay = *plan;
+  lay.fused = 0;
+  plan = &lay;
   Layout L;
   carve(plan, (char*)plan->ws, L);
   if (plan->ws_bytes < L.total) return PV_EWS;
@@ -428,6 +512,9 @@ extern "C" int pv_ivae_decode(const pv_ivae_plan* plan, const float* z, float an
                               float scale, float* loc, void* stream) {
   if (!valid_plan(plan) || !plan->params || !plan->ws || !z || !loc) return PV_EINVAL;
   if (plan->coord_dim > 0 && !plan->grid) return PV_EINVAL;
+  pv_ivae_plan lay = *plan;
+  lay.fused = 0;
+  plan = &lay;
   Layout L;
   carve(plan, (char*)plan->ws, L);
   if (plan->ws_bytes < L.total) return PV_EWS;
