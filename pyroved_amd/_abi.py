@@ -19,7 +19,7 @@ ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "lrelu": 3, "softplus": 4, "gel
 LIK = {"bernoulli": 0, "gaussian": 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyroved_amd.so")
+LIB_PATH = os.environ.get("PV_LIB_PATH") or os.path.join(_HERE, "libpyroved_amd.so")   # override: kernel experiments only
 
 c_float_p = C.POINTER(C.c_float)
 

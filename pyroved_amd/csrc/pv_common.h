@@ -72,6 +72,7 @@ struct PvGemm {
   int act;                              // applied after bias
   float* pre;                           // optional pre-activation store (ldc stride)
   const float* aux; const float* auxpre; int64_t ldaux; int act_aux;   // C *= act'(aux)
+  float* rowsumA;                       // optional: rowsumA[m] = sum_k A(m,k)  (bias gradient of a wgrad GEMM)
 };
 // Runs C = epilogue(A*B).  splits > 1 => partial sums through ws (needs splits*M*N floats).
 int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t s);

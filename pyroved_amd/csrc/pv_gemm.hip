@@ -62,6 +62,7 @@ struct GemmK {
   PvGemm g;
   int k_chunk;
   float* part;     // != null: raw partial sums part[z][M][N]
+  float* part_rs;  // != null: partial row sums of A, part_rs[z][M]
   int a_vec, b_vec;
 };
 
@@ -79,6 +80,8 @@ __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const bool do_rs = g.rowsumA != nullptr && blockIdx.y == 0 && t < GT;
+  float rs = 0.0f;
 
   float ra[4], rb[4];
   if (kbeg < kend) {
@@ -93,6 +96,10 @@ __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
       g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, k0 + GK, kend, p.a_vec, t, ra);
       g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, k0 + GK, kend, p.b_vec, t, rb);
     }
+    if (do_rs) {
+#pragma unroll
+      for (int k = 0; k < GK; ++k) rs += As[k][t];
+    }
     const int i = lane & 31, kk = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < GK / 2; ++ks) {
@@ -103,6 +110,10 @@ __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
     __syncthreads();
   }
 
+  if (do_rs && m0 + t < g.M) {
+    if (p.part_rs) p.part_rs[(int64_t)blockIdx.z * g.M + m0 + t] = rs;
+    else g.rowsumA[m0 + t] = rs;
+  }
   // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int n = n0 + wn * 32 + (lane & 31);
   if (n >= g.N) return;
@@ -146,6 +157,13 @@ __global__ __launch_bounds__(256) void pv_gemm_finish_kernel(GemmK p, int splits
     }
     g.C[(int64_t)m * g.ldc + n] = v;
   }
+  if (p.part_rs) {
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < g.M; m += (int64_t)gridDim.x * 256) {
+      float v = 0.0f;
+      for (int z = 0; z < splits; ++z) v += p.part_rs[(int64_t)z * g.M + m];
+      g.rowsumA[m] = v;
+    }
+  }
 }
 
 int pv_gemm_pick_splits(int M, int N, int K) {
@@ -170,10 +188,12 @@ int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t
   splits = (g.K + k_chunk - 1) / k_chunk;
   p.k_chunk = k_chunk;
   p.part = nullptr;
+  p.part_rs = nullptr;
   if (splits > 1) {
-    const int64_t need = (int64_t)splits * g.M * g.N * (int64_t)sizeof(float);
+    const int64_t need = (int64_t)splits * g.M * (g.N + (g.rowsumA ? 1 : 0)) * (int64_t)sizeof(float);
     if (!ws || ws_bytes < need) return PV_EWS;
     p.part = (float*)ws;
+    if (g.rowsumA) p.part_rs = p.part + (int64_t)splits * g.M * g.N;
   }
   const bool ak = (g.a_cs == 1), bk = (g.b_rs == 1);
   // 16-byte vector loads need an aligned base and a stride that keeps rows aligned

@@ -22,7 +22,7 @@ struct Carver {
 
 int64_t gemm_ws_need(int64_t M, int64_t N, int64_t K) {
   const int s = pv_gemm_pick_splits((int)M, (int)N, (int)K);
-  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+  return s > 1 ? (int64_t)s * M * (N + 1) * (int64_t)sizeof(float) : 0;     // + row-sum partials
 }
 
 struct Layout {
@@ -194,7 +194,9 @@ int linear_wgrad(const float* dpre, int64_t lddp, const float* x, int64_t ldx, f
     g.B = x; g.b_rs = ldx; g.b_cs = 1;        // B(row, k) = x[row][k]
     g.C = dw; g.ldc = K; g.M = (int)N; g.N = (int)K; g.K = (int)M;
     g.act = PV_ACT_NONE;
+    g.rowsumA = db;                            // db[n] = sum_rows dpre[row][n], fused into the same pass
     PV_TRY(pv_gemm(g, pv_gemm_pick_splits((int)N, (int)K, (int)M), ws, wsb, s));
+    return 0;
   }
   if (db) PV_TRY(pv_colsum(dpre, lddp, M, (int)N, db, ws, wsb, s));
   return 0;

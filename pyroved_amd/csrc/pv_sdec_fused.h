@@ -25,6 +25,8 @@ struct PvFused {
   int64_t M;             // rows
   int64_t units;         // M / FD_UNIT
   int N, cd, B, lik, sigmoid_out, kmax;
+  int ablate;            // profiling only (env PV_FD_ABLATE): 1 skip wgrad exchanges, 2 skip coord-layer exchange,
+                         // 4 skip dgrad, 8 skip d(wo) reduction  -> wrong gradients, used to price the phases
   float sig;
 };
 

@@ -24,6 +24,7 @@
 //     pv_sdec_fused_reduce (no float atomics: bit-reproducible).
 // LDS: W1, W2 (2 x 66 KiB), staging (18 KiB), small vectors: 157.5 KiB of the CU's 160 KiB.
 #include "pv_sdec_fused.h"
+#include <stdlib.h>
 
 #define LDW 132        // LDS row stride of the weight images (floats): conflict-free ds_read_b128 over 16 rows
 #define LDST 144       // LDS row stride of the staging buffers: stride % 32 == 16 -> conflict-free operand reads
@@ -50,62 +51,112 @@
 // (which would need hundreds of VGPRs); the partner wave on the SIMD hides the ds_read latency instead
 #define FD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#ifdef FD_EXP_NO_LDS_OPERANDS   // experiment build only: MFMA weight operands come from one LDS word (no traffic)
+#define FD_WADDR(x) 0
+#else
+#define FD_WADDR(x) (x)
+#endif
 
-// tanh to ~5e-7 absolute: odd polynomial for small |x| (no cancellation), 1 - 2/(e^{2x}+1) elsewhere
+// tanh(x) = 1 - 2 / (e^{2x} + 1) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each): 5 VALU issues.
+// On gfx950 the f32-input MFMA shares the FP32 ALUs with VALU work (measured: every VALU instruction placed
+// between two v_mfma_f32_16x16x4_f32 adds ~3.5 cycles to the stream, scripts/ubench/mfma_f32.hip), so the
+// activation's instruction count is paid in full.  Absolute error <= ~2e-7 (cancellation near 0 is absolute,
+// not relative: harmless for the sums it feeds); FD_TANH_POLY adds an odd polynomial for |x| < 0.125 (+7 issues).
 __device__ __forceinline__ float fd_tanh(float x) {
+#ifdef FD_EXP_NO_TANH      // experiment build only: prices the VALU cost of the activations
+  return x * 0.5f;
+#endif
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);       // e^{2x}
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+#ifdef FD_TANH_POLY
   const float x2 = x * x;
-  const float p = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
-  const float e = __expf(2.0f * x);
-  const float t = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
-  return fabsf(x) < 0.25f ? p : t;
+  const float p = x * (1.0f + x2 * (-0.33333334f + x2 * 0.13333334f));
+  return fabsf(x) < 0.125f ? p : t;
+#else
+  return t;
+#endif
 }
 
-// D[j][r] = b[j] + sum_k W[j][k] in[r][k];  out = tanh(D).   (transposed layer, see header)
+// D[j][r] = b[j] + sum_k W[j][k] in[r][k]   (transposed layer, see header); `out` is left PRE-activation
+// except that, when ACT_HALF0, tanh is applied to out[0..3] while out[4..7] is still accumulating.
+// The stream is 16 groups of (4 x ds_read_b128 -> 16 MFMAs); the next group's operands are fetched before the
+// current group's MFMAs issue (explicit double buffer) and the scheduling fence keeps the compiler from hoisting
+// more.  VALU work is placed INSIDE the groups so it issues in the shadow of this wave's own MFMAs (the two waves
+// of a SIMD run in lock-step, so the partner cannot be relied on to cover it):
+//   prep(jb) produces the input block in[jb] one group before its first use (the previous layer's activation),
+//   and the finished half of the outputs is activated during the second half's groups.
+template <bool ACT_HALF0, class Prep>
 __device__ __forceinline__ void fd_layer_fwd(const float* __restrict__ Ws, const float* __restrict__ bs,
-                                             const f32x4 (&in)[8], f32x4 (&out)[8], int r, int q) {
+                                             f32x4 (&in)[8], f32x4 (&out)[8], int r, int q, Prep prep) {
+  prep(0);
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
+  const float* wb = Ws + r * LDW + 4 * q;
+  f32x4 a[2][4];
 #pragma unroll
-  for (int jb = 0; jb < 8; ++jb) {
+  for (int o = 0; o < 4; ++o) a[0][o] = *reinterpret_cast<const f32x4*>(wb + FD_WADDR(16 * o * LDW));
 #pragma unroll
-    for (int oh = 0; oh < 8; oh += 4) {
-      f32x4 a[4];
+  for (int g = 0; g < 16; ++g) {
+    const int half = g >> 3, jb = g & 7, oh = 4 * half;
+    if (g + 1 < 16) {
+      const int hn = (g + 1) >> 3, jn = (g + 1) & 7;
 #pragma unroll
       for (int o = 0; o < 4; ++o)
-        a[o] = *reinterpret_cast<const f32x4*>(Ws + (16 * (oh + o) + r) * LDW + 16 * jb + 4 * q);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) out[oh + o] = MFMA(a[o][i], in[jb][i], out[oh + o]);
-      FD_SCHED_FENCE();
+        a[(g + 1) & 1][o] = *reinterpret_cast<const f32x4*>(wb + FD_WADDR(16 * (4 * hn + o) * LDW + 16 * jn));
     }
+    FD_SCHED_FENCE();        // the prefetch must ISSUE before this group's MFMAs (else it is sunk behind them)
+    if (half == 0 && jb + 1 < 8) prep(jb + 1);
+    if (ACT_HALF0 && half == 1) {
+      out[(2 * jb) >> 2][(2 * jb) & 3] = fd_tanh(out[(2 * jb) >> 2][(2 * jb) & 3]);
+      out[(2 * jb + 1) >> 2][(2 * jb + 1) & 3] = fd_tanh(out[(2 * jb + 1) >> 2][(2 * jb + 1) & 3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) out[oh + o] = MFMA(a[g & 1][o][i], in[jb][i], out[oh + o]);
+    FD_SCHED_FENCE();
   }
-#pragma unroll
-  for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[ob][i] = fd_tanh(out[ob][i]);
 }
 
-// D[k][r] = sum_j W[j][k] dp[r][j];  out = D * (1 - hin^2)   (dgrad through a tanh layer)
+// D[k][r] = sum_j W[j][k] dp[r][j]   (dgrad); 32 groups of (8 x ds_read_b32 -> 8 MFMAs), operands double-buffered.
+// side(g) is independent VALU work issued in the shadow of group g's MFMAs.  No epilogue here.
+template <class Side>
 __device__ __forceinline__ void fd_layer_dgrad(const float* __restrict__ Ws, const f32x4 (&dp)[8],
-                                               const f32x4 (&hin)[8], f32x4 (&out)[8], int r, int q) {
+                                               f32x4 (&out)[8], int r, int q, Side side) {
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) out[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const float* wb = Ws + 4 * q * LDW + r;
+  float a[2][8];
 #pragma unroll
-  for (int jb = 0; jb < 8; ++jb) {
+  for (int kb = 0; kb < 8; ++kb) a[0][kb] = wb[16 * kb];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float* wrow = Ws + (16 * jb + 4 * q + i) * LDW + r;
+  for (int g = 0; g < 32; ++g) {
+    const int jb = g >> 2, i = g & 3;
+    if (g + 1 < 32) {
+      const int jn = (g + 1) >> 2, in_ = (g + 1) & 3;
 #pragma unroll
-      for (int kb = 0; kb < 8; ++kb) out[kb] = MFMA(wrow[16 * kb], dp[jb][i], out[kb]);
-      FD_SCHED_FENCE();
+      for (int kb = 0; kb < 8; ++kb) a[(g + 1) & 1][kb] = wb[(16 * jn + in_) * LDW + 16 * kb];
     }
+    FD_SCHED_FENCE();
+    side(g);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) out[kb] = MFMA(a[g & 1][kb], dp[jb][i], out[kb]);
+    FD_SCHED_FENCE();
   }
+}
+
+// out *= 1 - h^2   (through the tanh that produced h)
+__device__ __forceinline__ void fd_mul_dtanh(f32x4 (&out)[8], const f32x4 (&h)[8]) {
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out[kb][i] *= 1.0f - hin[kb][i] * hin[kb][i];
+    for (int i = 0; i < 4; ++i) out[kb][i] *= 1.0f - h[kb][i] * h[kb][i];
 }
+
+// raw-instruction transcendental helpers (v_exp_f32 / v_log_f32 / v_rcp_f32: 1 ulp)
+__device__ __forceinline__ float fd_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fd_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fd_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 __device__ __forceinline__ void fd_stage_write(float* __restrict__ st, const f32x4 (&v)[8], int r, int q) {
 #pragma unroll
@@ -115,13 +166,23 @@ __device__ __forceinline__ void fd_stage_write(float* __restrict__ st, const f32
 // dW[16*wave + ..][k] += sum over the 16 staged rows of dpre[row][16*wave + j'] * h[row][k]
 __device__ __forceinline__ void fd_wgrad_consume(const float* __restrict__ stA, const float* __restrict__ stB,
                                                  f32x4 (&accW)[8], float& db, int wave, int r, int q) {
+  const float* ab = stA + q * LDST + 16 * wave + r;
+  const float* bb = stB + q * LDST + r;
+  float a[2], bv[2][8];
+  a[0] = ab[0];
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) bv[0][kb] = bb[16 * kb];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const float a = stA[(4 * s + q) * LDST + 16 * wave + r];
-    db += a;
-    const float* brow = stB + (4 * s + q) * LDST + r;
+    if (s + 1 < 4) {
+      a[(s + 1) & 1] = ab[4 * (s + 1) * LDST];
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) accW[kb] = MFMA(a, brow[16 * kb], accW[kb]);
+      for (int kb = 0; kb < 8; ++kb) bv[(s + 1) & 1][kb] = bb[4 * (s + 1) * LDST + 16 * kb];
+    }
+    FD_SCHED_FENCE();
+    db += a[s & 1];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) accW[kb] = MFMA(a[s & 1], bv[s & 1][kb], accW[kb]);
     FD_SCHED_FENCE();
   }
 }
@@ -189,26 +250,24 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
   for (int64_t u0 = u_lo; u0 < u_hi; u0 += FD_WAVES) {
     const int nact = (int)((u_hi - u0) < FD_WAVES ? (u_hi - u0) : FD_WAVES);
     const bool active = wave < nact;
-    const int64_t row = (u0 + (active ? wave : 0)) * FD_UNIT + r;
-    const int b = (int)(row / f.N), n = (int)(row - (int64_t)b * f.N);
+    const int unit = (int)u0 + (active ? wave : 0);          // 32-bit index math: units < 2^31 / 16
+    const int b = unit / upb, n = (unit - b * upb) * FD_UNIT + r;
+    const int64_t row = (int64_t)unit * FD_UNIT + r;
     // three register tiles (16 rows x 128 cols each, 32 VGPRs) are rotated through the roles
     // h0 -> h1 -> h2/dpre2 -> dpre1 -> h0 (recomputed) -> dpre0 so that at most three are live
     f32x4 tA[8], tB[8], tC[8];
     float x0 = 0.0f, x1 = 0.0f, u0c = 0.0f, u1c = 0.0f, sc = 1.0f;
     const float* hzb = f.hz + (int64_t)b * FD_H;
 
-    // coordinate layer: h0 = tanh(Wc x' + bc + hz[b])   (fc.py:226-237)
-    auto coord_layer = [&](f32x4 (&h0)[8]) {
+    // coordinate layer, one 16-column block: h0[jb] = tanh(Wc x' + bc + hz[b])   (fc.py:226-237)
+    auto coord_block = [&](f32x4 (&h0)[8], int jb) {
+      const int j = 16 * jb + 4 * q;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + OFF_WC0 + j);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + OFF_WC1 + j);
+      const f32x4 bc = *reinterpret_cast<const f32x4*>(sm + OFF_BC + j);
+      const f32x4 hz = *reinterpret_cast<const f32x4*>(hzb + j);
 #pragma unroll
-      for (int jb = 0; jb < 8; ++jb) {
-        const int j = 16 * jb + 4 * q;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + OFF_WC0 + j);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + OFF_WC1 + j);
-        const f32x4 bc = *reinterpret_cast<const f32x4*>(sm + OFF_BC + j);
-        const f32x4 hz = *reinterpret_cast<const f32x4*>(hzb + j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h0[jb][i] = fd_tanh(w0[i] * x0 + w1[i] * x1 + bc[i] + hz[i]);
-      }
+      for (int i = 0; i < 4; ++i) h0[jb][i] = fd_tanh(w0[i] * x0 + w1[i] * x1 + bc[i] + hz[i]);
     };
 
     if (active) {
@@ -225,9 +284,17 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
         u0c = f.grid[n];
         x0 = u0c + t[3];
       }
-      coord_layer(tA);                                   // tA = h0
-      fd_layer_fwd(W1s, sm + OFF_B1, tA, tB, r, q);     // tB = h1
-      fd_layer_fwd(W2s, sm + OFF_B2, tB, tC, r, q);     // tC = h2
+      // layer 1: its input h0 (tA) is produced block by block inside the MFMA stream; tB = pre-activation 1
+      fd_layer_fwd<false>(W1s, sm + OFF_B1, tA, tB, r, q, [&](int jb) { coord_block(tA, jb); });
+      // layer 2: activates its own input in place (tB -> h1) one block ahead; tC[0..3] = h2, tC[4..7] raw
+      fd_layer_fwd<true>(W2s, sm + OFF_B2, tB, tC, r, q, [&](int jb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tB[jb][i] = fd_tanh(tB[jb][i]);
+      });
+#pragma unroll
+      for (int ob = 4; ob < 8; ++ob)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tC[ob][i] = fd_tanh(tC[ob][i]);
       // ---- output layer + likelihood ----
       float part = 0.0f;
 #pragma unroll
@@ -241,17 +308,17 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
       float ll, dlda, locv;
       if (f.lik == PV_LIK_BERNOULLI) {
         // torch Bernoulli(probs=sigmoid(a)).log_prob(x): clamp_probs -> logits -> -BCEWithLogits
-        const float pr = 1.0f / (1.0f + expf(-a));
+        const float pr = fd_rcp(1.0f + fd_exp(-a));
         const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
-        const float lg = logf(pc) - log1pf(-pc);
-        ll = -(fmaxf(lg, 0.0f) - lg * xv + log1pf(expf(-fabsf(lg))));
+        const float lg = fd_log(pc) - fd_log(1.0f - pc);
+        ll = -(fmaxf(lg, 0.0f) - lg * xv + fd_log(1.0f + fd_exp(-fabsf(lg))));
         const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
-        dlda = (1.0f / (1.0f + expf(-lg)) - xv) * mask;
+        dlda = (fd_rcp(1.0f + fd_exp(-lg)) - xv) * mask;
         locv = pr;
       } else {
-        const float pr = f.sigmoid_out ? 1.0f / (1.0f + expf(-a)) : a;
+        const float pr = f.sigmoid_out ? fd_rcp(1.0f + fd_exp(-a)) : a;
         const float d = xv - pr;
-        ll = -(d * d) / (2.0f * f.sig * f.sig) - logf(f.sig) - LOG_SQRT_2PI;
+        ll = -(d * d) / (2.0f * f.sig * f.sig) - fd_log(f.sig) - LOG_SQRT_2PI;
         dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
         locv = pr;
       }
@@ -263,6 +330,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
         if (q == 0) dbo += dlda;
         // d(wo) partial: sum over this unit's rows, accumulated in the wave's private LDS slot
         float* dwo = sm + OFF_DWO + wave * FD_H;
+        if (!(f.ablate & 8))
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
           f32x4 tv;
@@ -285,19 +353,22 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
     if (!GRADS) continue;
 
     // ---- wgrad of layer 2: exchange (dpre2 = tC, h1 = tB) one unit at a time ----
-    for (int c = 0; c < nact; ++c) {
+    const int nex = (f.ablate & 1) ? 0 : nact;
+    for (int c = 0; c < nex; ++c) {
       if (wave == c) { fd_stage_write(stA, tC, r, q); fd_stage_write(stB, tB, r, q); }
       __syncthreads();
       fd_wgrad_consume(stA, stB, accW2, db2, wave, r, q);
       __syncthreads();
     }
-    if (active) {
-      fd_layer_dgrad(W2s, tC, tB, tA, r, q);            // tA = dpre1 = (dpre2 W2) * (1 - h1^2)
-      coord_layer(tB);                                   // tB = h0 (recomputed: cheaper than keeping it live)
-      fd_layer_dgrad(W1s, tA, tB, tC, r, q);            // tC = dpre0 = (dpre1 W1) * (1 - h0^2)
+    if (active && !(f.ablate & 4)) {
+      fd_layer_dgrad(W2s, tC, tA, r, q, [](int) {});
+      fd_mul_dtanh(tA, tB);                              // tA = dpre1 = (dpre2 W2) * (1 - h1^2)
+      // tB = h0, recomputed (cheaper than keeping it live) in the shadow of the next dgrad's MFMAs
+      fd_layer_dgrad(W1s, tA, tC, r, q, [&](int g) { if ((g & 3) == 0) coord_block(tB, g >> 2); });
+      fd_mul_dtanh(tC, tB);                              // tC = dpre0 = (dpre1 W1) * (1 - h0^2)
     }
     // ---- wgrad of layer 1: exchange (dpre1 = tA, h0 = tB) ----
-    for (int c = 0; c < nact; ++c) {
+    for (int c = 0; c < nex; ++c) {
       if (wave == c) { fd_stage_write(stA, tA, r, q); fd_stage_write(stB, tB, r, q); }
       __syncthreads();
       fd_wgrad_consume(stA, stB, accW1, db1, wave, r, q);
@@ -323,7 +394,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
       }
     }
     // ---- coordinate layer backward, cross-row part: dWc, dbc/dhz via staged dpre0 ----
-    for (int c = 0; c < nact; ++c) {
+    for (int c = 0; c < ((f.ablate & 2) ? 0 : nact); ++c) {
       if (wave == c) {
         fd_stage_write(stA, tC, r, q);
         if (q == 0) { sm[OFF_INFO + r] = x0; sm[OFF_INFO + 16 + r] = x1; }
@@ -383,13 +454,23 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
 }
 
 // ---- per-workgroup records -> flat gradient buffer (fixed summation order) ---------------------------
+// 64 outputs x 4 slices of the workgroup range per 256-thread block; slices combined in fixed order
 __global__ __launch_bounds__(256) void pv_sdec_fused_reduce_kernel(const float* __restrict__ part, int G_,
                                                                    float* __restrict__ Gr, PvFusedOffsets o, int cd) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float sm[4][64];
   const int HH = FD_H * FD_H;
-  if (e >= 2 * HH + 5 * FD_H + 1) return;
+  const int total = 2 * HH + 5 * FD_H + 1;
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + c;
+  const int per = (G_ + 3) / 4;
+  const int w0 = sl * per, w1 = min(G_, w0 + per);
   float v = 0.0f;
-  for (int w = 0; w < G_; ++w) v += part[(int64_t)w * FD_REC + e];
+  if (e < total)
+    for (int w = w0; w < w1; ++w) v += part[(int64_t)w * FD_REC + e];
+  sm[sl][c] = v;
+  __syncthreads();
+  if (sl != 0 || e >= total) return;
+  v = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
   if (e < HH) Gr[o.W1 + e] = v;
   else if (e < 2 * HH) Gr[o.W2 + (e - HH)] = v;
   else {
@@ -405,7 +486,7 @@ __global__ __launch_bounds__(256) void pv_sdec_fused_reduce_kernel(const float* 
 
 int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, hipStream_t s) {
   const int total = 2 * FD_H * FD_H + 5 * FD_H + 1;
-  hipLaunchKernelGGL(pv_sdec_fused_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, grid, G, o, cd);
+  hipLaunchKernelGGL(pv_sdec_fused_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, grid, G, o, cd);
   PV_LAUNCH_CHECK();
   return 0;
 }
@@ -449,7 +530,11 @@ int pv_sdec_fused_kmax(int n_pix, int64_t units, int grid) {
   return (int)((upb * grid) / (units > 0 ? units : 1)) + 2;
 }
 
-int pv_sdec_fused_launch(const PvFused& f, int grid, bool grads, hipStream_t s) {
+int pv_sdec_fused_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {
+  PvFused f = f_in;
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }
+  f.ablate = ablate;
   const size_t lds = FD_LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
