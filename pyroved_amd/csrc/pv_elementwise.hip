@@ -309,20 +309,30 @@ int pv_segsum(const float* v, int64_t nseg, int64_t N, float* out, hipStream_t s
   return 0;
 }
 
-// scalars[1] = sum_b ll_b ; scalars[0] = -(ll + beta*logp - beta*logq)
-__global__ __launch_bounds__(256) void pv_finish_scalars_kernel(const float* __restrict__ llb, int B, float* scalars) {
+// scalars[1] = sum_b ll_b ; [2], [3] from the encoder kernel's partials when given ; scalars[0] = -(ll + lp - lq)
+__global__ __launch_bounds__(256) void pv_finish_scalars_kernel(const float* __restrict__ llb, int B, float* scalars,
+                                                                const float* __restrict__ kl_part, int n_part,
+                                                                float beta) {
   __shared__ float sm[4];
   float a = 0.0f;
   for (int b = threadIdx.x; b < B; b += 256) a += llb[b];
   a = block_sum_256(a, sm);
+  float lp = 0.0f, lq = 0.0f;
+  if (kl_part) {
+    for (int i = threadIdx.x; i < n_part; i += 256) { lp += kl_part[2 * i]; lq += kl_part[2 * i + 1]; }
+    lp = block_sum_256(lp, sm);
+    lq = block_sum_256(lq, sm);
+  }
   if (threadIdx.x == 0) {
+    if (kl_part) { scalars[2] = beta * lp; scalars[3] = beta * lq; }
     scalars[1] = a;
     scalars[0] = -(a + scalars[2] - scalars[3]);
   }
 }
 
-int pv_finish_scalars(const float* llb, int B, float* scalars, hipStream_t s) {
-  hipLaunchKernelGGL(pv_finish_scalars_kernel, dim3(1), dim3(256), 0, s, llb, B, scalars);
+int pv_finish_scalars(const float* llb, int B, float* scalars, const float* kl_part, int n_part, float beta,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(pv_finish_scalars_kernel, dim3(1), dim3(256), 0, s, llb, B, scalars, kl_part, n_part, beta);
   PV_LAUNCH_CHECK();
   return 0;
 }
@@ -423,33 +433,31 @@ int pv_reduce_mid(const float* part, int nb, int nc, int n, float* out, hipStrea
 
 // ---------------------------------------------------------------------------------------------
 // head_bwd: dL/d(mu), dL/d(softplus input) from the decoder's dL/dz and the sampled-KL terms.
-__global__ void pv_head_bwd_kernel(PvHeadBwd h) {
-  const int total = h.B * h.z_dim;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int b = e / h.z_dim, i = e % h.z_dim;
+// dz_coord(c) returns d(phi), d(scale), d(tx), d(ty) of the sample for c = 0..3; dz_content(k) the gradient
+// w.r.t. the k-th column of the decoder's latent input.
+template <class FC, class FK>
+__device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int i, FC dz_coord, FK dz_content) {
   float dz;
   if (h.coord_dim == 0) {
-    dz = h.dzc[(int64_t)b * h.ldzc + i];
+    dz = dz_content(i);
   } else {
-    const float* tb = h.dtp + (int64_t)b * h.dtp_sb;
-    const float tpg[4] = {tb[0], tb[h.dtp_sc], tb[2 * h.dtp_sc], tb[3 * h.dtp_sc]};   // dphi, dscale, dtx, dty
     int idx = 0;
     dz = 0.0f;
     bool done = false;
     if (h.coord_dim == 1) {
-      if (h.has_t) { if (i == 0) { dz = tpg[2] * h.tp0; done = true; } idx = 1; }
+      if (h.has_t) { if (i == 0) { dz = dz_coord(2) * h.tp0; done = true; } idx = 1; }
     } else {
-      if (h.has_r) { if (i == idx) { dz = tpg[0]; done = true; } idx += 1; }
+      if (h.has_r) { if (i == idx) { dz = dz_coord(0); done = true; } idx += 1; }
       if (h.has_t) {
-        if (i == idx) { dz = tpg[2] * h.tp0; done = true; }
-        if (i == idx + 1) { dz = tpg[3] * h.tp1; done = true; }
+        if (i == idx) { dz = dz_coord(2) * h.tp0; done = true; }
+        if (i == idx + 1) { dz = dz_coord(3) * h.tp1; done = true; }
         idx += 2;
       }
-      if (h.has_s) { if (i == idx) { dz = tpg[1] * h.sc_prior; done = true; } idx += 1; }
+      if (h.has_s) { if (i == idx) { dz = dz_coord(1) * h.sc_prior; done = true; } idx += 1; }
     }
-    if (!done) dz = h.dzc[(int64_t)b * h.ldzc + (i - idx)];
+    if (!done) dz = dz_content(i - idx);
   }
+  const int e = b * h.z_dim + i;
   const float z = h.z[e], sig = h.z_scale[e], ep = h.eps[e];
   const float sp = h.head[(int64_t)b * 2 * h.z_dim + h.z_dim + i];
   const float g = dz + h.beta * z;                 // d(-ll - beta*log p(z))/dz
@@ -459,9 +467,66 @@ __global__ void pv_head_bwd_kernel(PvHeadBwd h) {
   h.dhead[(int64_t)b * 2 * h.z_dim + h.z_dim + i] = dsig * sgm;
 }
 
+__global__ void pv_head_bwd_kernel(PvHeadBwd h) {
+  const int total = h.B * h.z_dim;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int b = e / h.z_dim, i = e % h.z_dim;
+  pv_head_bwd_elem(
+      h, b, i, [&](int c) { return h.dtp[(int64_t)b * h.dtp_sb + (int64_t)c * h.dtp_sc]; },
+      [&](int k) { return h.dzc[(int64_t)b * h.ldzc + k]; });
+}
+
 int pv_head_bwd(const PvHeadBwd& h, hipStream_t s) {
   const int total = h.B * h.z_dim;
   hipLaunchKernelGGL(pv_head_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, h);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// latent_bwd (fused decoder path): one workgroup per sample gathers everything that flows from the decoder
+// kernel back into that sample's latent code: ll_b and d(phi, scale, tx, ty) (sums over the sample's N rows),
+// dL/d(hz[b]) (sum of the workgroup partials), dL/d(z content) = dhz Wz, then head_bwd.  Fixed-order sums.
+__global__ __launch_bounds__(256) void pv_latent_bwd_kernel(PvLatentBwd p) {
+  __shared__ float sm[4];
+  __shared__ float sh_dhz[512];
+  __shared__ float sh_dzc[64];
+  __shared__ float sh_tp[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int64_t r0 = (int64_t)b * p.N;
+  float a[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int n = t; n < p.N; n += 256) {
+    a[0] += p.llrow[r0 + n];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[1 + c] += p.rowtp[(int64_t)c * p.M + r0 + n];
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c) a[c] = block_sum_256(a[c], sm);
+  if (t == 0) {
+    p.llb[b] = a[0];
+    for (int c = 0; c < 4; ++c) sh_tp[c] = a[1 + c];
+  }
+  for (int j = t; j < p.H; j += 256) {
+    float v = 0.0f;
+    for (int k = 0; k < p.kmax; ++k) v += p.part_hz[((int64_t)b * p.kmax + k) * p.H + j];
+    p.dhz[(int64_t)b * p.H + j] = v;
+    sh_dhz[j] = v;
+  }
+  __syncthreads();
+  for (int i = 0; i < p.lat_in; ++i) {
+    float v = 0.0f;
+    for (int j = t; j < p.H; j += 256) v += sh_dhz[j] * p.Wz[j * p.lat_in + i];
+    v = block_sum_256(v, sm);
+    if (t == 0) sh_dzc[i] = v;
+  }
+  __syncthreads();
+  if (t < p.hb.z_dim)
+    pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; });
+}
+
+int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s) {
+  if (p.H > 512 || p.lat_in > 64 || p.hb.z_dim > 256) return PV_EINVAL;
+  hipLaunchKernelGGL(pv_latent_bwd_kernel, dim3(p.hb.B), dim3(256), 0, s, p);
   PV_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,245 @@
+// pv_encoder.hip — the encoder side of the SVI step as two compact kernels.
+//   pv_enc_fwd   fcEncoderNet.forward (nets/fc.py:51-61) + Normal.rsample + log q(z|x) + log p(z) +
+//                _split_latent (ivae.py:179-189, 217-221; base.py:97-119) + fc_latent(z) (fc.py:230)
+//   pv_enc_dgrad the dgrad chain head -> hidden layers of the encoder's backward
+// The encoder is < 1 % of the step's FLOPs but, as a chain of tiny dependent GEMMs, it used to be a third of
+// the step's wall time (launch-bound).  Here one workgroup carries 16 samples through the whole stack with
+// the activations in LDS: one launch each way.  MFMA formulation as in pv_sdec_fused.hip (transposed layers,
+// v_mfma_f32_16x16x4_f32, weights streamed from L2 as the A operand).
+// Supported: hidden widths <= 128 and multiples of 16, input width a multiple of 16, any activation but GELU;
+// anything else takes the generic GEMM path of pv_plan.hip.
+#include "pv_common.h"
+#include "pv_kernels.h"
+
+#define EN_ROWS 16
+#define EN_LD 132
+#define EN_THREADS 512
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float en_block_sum(float v, float* sm /* 8 floats */) {
+  v = pv_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((sm[0] + sm[1]) + (sm[2] + sm[3])) + ((sm[4] + sm[5]) + (sm[6] + sm[7]));
+}
+
+// one transposed layer for this wave's output blocks: D[j][r] = sum_k W[j][k] in[r][k]
+//   in: global (GLOBAL_IN, row stride ldin) or LDS (stride EN_LD); K % 16 == 0; out rows j >= out_dim are zero
+template <bool GLOBAL_IN>
+__device__ __forceinline__ f32x4 en_layer_block(const float* __restrict__ W, int K, int out_dim, int ob,
+                                                const float* __restrict__ in, int64_t ldin, int r, int q) {
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int j = 16 * ob + r;                       // this lane's A row
+  const bool jok = j < out_dim;
+  const float* wrow = W + (int64_t)(jok ? j : 0) * K + 4 * q;
+  const float* irow = in + (int64_t)r * ldin + 4 * q;
+#pragma unroll 4
+  for (int k = 0; k < K; k += 16) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(wrow + k);
+    if (!jok) a = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4 b = *reinterpret_cast<const f32x4*>(irow + k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = MFMA(a[i], b[i], acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
+  __shared__ __attribute__((aligned(16))) float act[2][EN_ROWS][EN_LD];
+  __shared__ float sm[8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * EN_ROWS;
+  const int rowc = min(row0 + r, e.B - 1);         // clamped row for loads
+  const bool rok = row0 + r < e.B;
+  int cur = 0;
+  // ---- hidden layers ----
+  for (int li = 0; li < e.n_enc; ++li) {
+    const pv_layer l = e.enc[li];
+    const float* W = e.params + l.w_off;
+    const float* bias = l.b_off >= 0 ? e.params + l.b_off : nullptr;
+    for (int ob = wave; 16 * ob < l.out_dim; ob += EN_THREADS / 64) {
+      f32x4 acc = li == 0 ? en_layer_block<true>(W, l.in_dim, l.out_dim, ob, e.x + (int64_t)(rowc - r) * e.ldx, e.ldx, r, q)
+                          : en_layer_block<false>(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], EN_LD, r, q);
+      // C/D layout: lane (col r, q), reg i -> output j = 16*ob + 4*q + i of row r
+      f32x4 y;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * ob + 4 * q + i;
+        y[i] = pv_act_fwd(acc[i] + (bias && j < l.out_dim ? bias[j] : 0.0f), l.act);
+      }
+      *reinterpret_cast<f32x4*>(&act[cur ^ 1][r][16 * ob + 4 * q]) = y;
+      if (rok) *reinterpret_cast<f32x4*>(e.eact[li] + (int64_t)(row0 + r) * l.out_dim + 16 * ob + 4 * q) = y;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- head: [mu | softplus input] (fc11 | fc12) ----
+  {
+    const pv_layer l = e.head;
+    const float* W = e.params + l.w_off;
+    const float* bias = l.b_off >= 0 ? e.params + l.b_off : nullptr;
+    for (int ob = wave; 16 * ob < l.out_dim; ob += EN_THREADS / 64) {
+      f32x4 acc = en_layer_block<false>(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], EN_LD, r, q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * ob + 4 * q + i;
+        if (j < l.out_dim) {
+          const float v = acc[i] + (bias ? bias[j] : 0.0f);
+          act[cur ^ 1][r][j] = v;
+          if (rok) e.head_out[(int64_t)(row0 + r) * l.out_dim + j] = v;
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- z = mu + softplus(s) * eps; sampled-KL terms ----
+  const int zd = e.z_dim;
+  float lp = 0.0f, lq = 0.0f;
+  for (int t = tid; t < EN_ROWS * zd; t += EN_THREADS) {
+    const int rr = t / zd, i = t % zd, row = row0 + rr;
+    if (row < e.B) {
+      const float mu = act[cur][rr][i], sp = act[cur][rr][zd + i];
+      const float sig = pv_softplus(sp);
+      const float ep = e.eps[(int64_t)row * zd + i];
+      const float z = mu + sig * ep;
+      e.z[(int64_t)row * zd + i] = z;
+      e.z_scale[(int64_t)row * zd + i] = sig;
+      if (e.z_loc_out) e.z_loc_out[(int64_t)row * zd + i] = mu;
+      if (e.z_scale_out) e.z_scale_out[(int64_t)row * zd + i] = sig;
+      const float d = z - mu;
+      lq += -(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI;      // torch Normal.log_prob
+      lp += -(z * z) / 2.0f - LOG_SQRT_2PI;
+      act[cur ^ 1][rr][i] = z;                     // keep z for the split below
+    }
+  }
+  lp = en_block_sum(lp, sm);
+  lq = en_block_sum(lq, sm);
+  if (tid == 0) {
+    e.kl_part[2 * blockIdx.x] = lp;
+    e.kl_part[2 * blockIdx.x + 1] = lq;
+  }
+  __syncthreads();
+  cur ^= 1;                                         // act[cur][rr][0..zd) = z
+  // ---- _split_latent: transform parameters + decoder latent input (base.py:97-119, ivae.py:187-195) ----
+  int coord = 0;
+  if (e.coord_dim == 1) coord = e.has_t ? 1 : 0;
+  else if (e.coord_dim == 2) coord = e.has_r + 2 * e.has_t + e.has_s;
+  const int L = zd - coord, lat_in = L + e.c_dim;
+  if (tid < EN_ROWS && row0 + tid < e.B) {
+    const int row = row0 + tid;
+    const float* zb = &act[cur][tid][0];
+    int idx = 0;
+    float c = 1.0f, s = 0.0f, sc = 1.0f, tx = 0.0f, ty = 0.0f;
+    if (e.coord_dim == 1) {
+      if (e.has_t) { tx = zb[0] * e.tp0; idx = 1; }
+    } else if (e.coord_dim == 2) {
+      if (e.has_r) { const float phi = zb[idx++]; c = cosf(phi); s = sinf(phi); }
+      if (e.has_t) { tx = zb[idx] * e.tp0; ty = zb[idx + 1] * e.tp1; idx += 2; }
+      if (e.has_s) { sc = 1.0f + e.sc_prior * zb[idx++]; }
+    }
+    if (e.tp) {
+      float* t = e.tp + (int64_t)row * 8;
+      t[0] = c; t[1] = s; t[2] = sc; t[3] = tx; t[4] = ty;
+    }
+    if (e.zy) {
+      float* o = e.zy + (int64_t)row * lat_in;
+      for (int i = 0; i < L; ++i) o[i] = zb[coord + i];
+      for (int i = 0; i < e.c_dim; ++i) o[L + i] = e.y[(int64_t)row * e.c_dim + i];
+    }
+  }
+  // ---- hz = fc_latent(cat(z_content, y)) (no bias; fc.py:217,230) ----
+  if (e.hz) {
+    for (int t = tid; t < EN_ROWS * e.H0; t += EN_THREADS) {
+      const int rr = t / e.H0, j = t % e.H0, row = row0 + rr;
+      if (row >= e.B) continue;
+      const float* wz = e.Wz + (int64_t)j * lat_in;
+      float v = 0.0f;
+      for (int i = 0; i < L; ++i) v += act[cur][rr][coord + i] * wz[i];
+      for (int i = 0; i < e.c_dim; ++i) v += e.y[(int64_t)row * e.c_dim + i] * wz[L + i];
+      e.hz[(int64_t)row * e.H0 + j] = v;
+    }
+  }
+}
+
+bool pv_enc_compact_supported(const pv_ivae_plan* p) {
+  if (p->n_enc < 1) return false;
+  int in = p->n_pix + p->c_dim;
+  if (in % 16 != 0) return false;
+  for (int i = 0; i < p->n_enc; ++i) {
+    const pv_layer& l = p->enc[i];
+    if (l.in_dim != in || l.out_dim > 128 || l.out_dim % 16 != 0 || l.act == PV_ACT_GELU) return false;
+    if (l.w_off % 4 != 0) return false;
+    in = l.out_dim;
+  }
+  if (p->head.in_dim != in || p->head.out_dim > 128 || p->head.w_off % 4 != 0) return false;
+  if (p->z_dim > 64) return false;
+  return true;
+}
+
+int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
+  hipLaunchKernelGGL(pv_enc_fwd_kernel, dim3((e.B + EN_ROWS - 1) / EN_ROWS), dim3(EN_THREADS), 0, s, e);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// encoder dgrad chain: edp[last] = (dhead Whead) * act'(eact[last]); edp[i-1] = (edp[i] W_i) * act'(eact[i-1])
+__global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) {
+  __shared__ __attribute__((aligned(16))) float buf[2][EN_ROWS][EN_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * EN_ROWS;
+  const int ne = e.n_enc;
+  int cur = 0;
+  {
+    // from the head: K = 2*z_dim is tiny -> plain FMAs
+    const pv_layer hd = e.head;
+    const pv_layer ll = e.enc[ne - 1];
+    const float* Wh = e.params + hd.w_off;
+    for (int t = tid; t < EN_ROWS * ll.out_dim; t += EN_THREADS) {
+      const int rr = t / ll.out_dim, k = t % ll.out_dim, row = row0 + rr;
+      float v = 0.0f;
+      if (row < e.B) {
+        const float* dh = e.dhead + (int64_t)row * hd.out_dim;
+        for (int o = 0; o < hd.out_dim; ++o) v += dh[o] * Wh[(int64_t)o * hd.in_dim + k];
+        v *= pv_act_grad(e.eact[ne - 1][(int64_t)row * ll.out_dim + k], 0.0f, ll.act);
+        e.edp[ne - 1][(int64_t)row * ll.out_dim + k] = v;
+      }
+      buf[cur][rr][k] = v;
+    }
+    __syncthreads();
+  }
+  for (int li = ne - 1; li > 0; --li) {
+    const pv_layer l = e.enc[li];          // edp[li] (16 x l.out_dim) in buf[cur]; produce edp[li-1] (16 x l.in_dim)
+    const pv_layer lp = e.enc[li - 1];
+    const float* W = e.params + l.w_off;
+    for (int kb = wave; 16 * kb < l.in_dim; kb += EN_THREADS / 64) {
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      const float* wcol = W + 16 * kb + r;                 // A lane (k' = r, q): W[j][16*kb + k']
+      for (int j0 = 0; j0 < l.out_dim; j0 += 16) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&buf[cur][r][j0 + 4 * q]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = MFMA(wcol[(int64_t)(j0 + 4 * q + i) * l.in_dim], b[i], acc);
+      }
+      const int row = row0 + r;
+      f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < e.B) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(e.eact[li - 1] + (int64_t)row * lp.out_dim + 16 * kb + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = acc[i] * pv_act_grad(h[i], 0.0f, lp.act);
+        *reinterpret_cast<f32x4*>(e.edp[li - 1] + (int64_t)row * lp.out_dim + 16 * kb + 4 * q) = y;
+      }
+      *reinterpret_cast<f32x4*>(&buf[cur ^ 1][r][16 * kb + 4 * q]) = y;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+int pv_enc_dgrad(const PvEncDgrad& e, hipStream_t s) {
+  hipLaunchKernelGGL(pv_enc_dgrad_kernel, dim3((e.B + EN_ROWS - 1) / EN_ROWS), dim3(EN_THREADS), 0, s, e);
+  PV_LAUNCH_CHECK();
+  return 0;
+}

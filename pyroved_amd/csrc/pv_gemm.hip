@@ -67,20 +67,18 @@ struct GemmK {
 };
 
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
-  __shared__ float As[GK][GLD];
-  __shared__ float Bs[GK][GLD];
+__device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], float (*Bs)[GLD], int bx, int by, int bz) {
   const PvGemm& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
-  const int kbeg = blockIdx.z * p.k_chunk;
+  const int m0 = bx * GT, n0 = by * GT;
+  const int kbeg = bz * p.k_chunk;
   const int kend = min(g.K, kbeg + p.k_chunk);
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  const bool do_rs = g.rowsumA != nullptr && blockIdx.y == 0 && t < GT;
+  const bool do_rs = g.rowsumA != nullptr && by == 0 && t < GT;
   float rs = 0.0f;
 
   float ra[4], rb[4];
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
   }
 
   if (do_rs && m0 + t < g.M) {
-    if (p.part_rs) p.part_rs[(int64_t)blockIdx.z * g.M + m0 + t] = rs;
+    if (p.part_rs) p.part_rs[(int64_t)bz * g.M + m0 + t] = rs;
     else g.rowsumA[m0 + t] = rs;
   }
   // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
     if (m >= g.M) continue;
     float v = acc[r];
     if (p.part) {
-      p.part[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+      p.part[((int64_t)bz * g.M + m) * g.N + n] = v;
     } else {
       v += bias;
       if (g.pre) g.pre[(int64_t)m * g.ldc + n] = v;
@@ -137,6 +135,33 @@ __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
       g.C[(int64_t)m * g.ldc + n] = v;
     }
   }
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
+  __shared__ float As[GK][GLD];
+  __shared__ float Bs[GK][GLD];
+  gemm_tile<AK, BK>(p, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// several independent small GEMMs of the same operand-layout class in ONE launch (no split-K): the
+// encoder's weight gradients are a handful of 10x128 .. 128x784 outputs, each worth less than a launch
+#define GM_MAX 4
+struct GemmMulti {
+  GemmK p[GM_MAX];
+  int tile_start[GM_MAX + 1];
+  int tiles_m[GM_MAX];
+  int n;
+};
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void pv_gemm_multi_kernel(GemmMulti mp) {
+  __shared__ float As[GK][GLD];
+  __shared__ float Bs[GK][GLD];
+  int i = 0;
+  while (i + 1 < mp.n && (int)blockIdx.x >= mp.tile_start[i + 1]) ++i;
+  const int local = blockIdx.x - mp.tile_start[i];
+  gemm_tile<AK, BK>(mp.p[i], As, Bs, local % mp.tiles_m[i], local / mp.tiles_m[i], 0);
 }
 
 // sums the split-K partials in ascending split order (deterministic) and applies the epilogue
@@ -167,9 +192,10 @@ __global__ __launch_bounds__(256) void pv_gemm_finish_kernel(GemmK p, int splits
 }
 
 int pv_gemm_pick_splits(int M, int N, int K) {
-  // aim for >= ~512 workgroups (2 per CU) when the contraction is long enough to split
+  // aim for >= ~512 workgroups (2 per CU) when the contraction is long enough to split; a split costs a
+  // second (finish) launch, ~6 us on the stream, so short contractions are never split
   const int64_t tiles = (int64_t)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
-  if (tiles >= 512 || K <= 4 * GK) return 1;
+  if (tiles >= 512 || K <= 1024) return 1;
   int64_t s = (512 + tiles - 1) / tiles;
   const int64_t maxs = (K + 4 * GK - 1) / (4 * GK);     // at least 64 of k per split
   if (s > maxs) s = maxs;
@@ -214,6 +240,43 @@ int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t
     hipLaunchKernelGGL(pv_gemm_finish_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
     PV_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+int pv_gemm_multi(const PvGemm* gs, int n, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (n > GM_MAX) return PV_EINVAL;
+  GemmMulti mp;
+  mp.n = 0;
+  int total = 0;
+  bool ak = false, bk = false;
+  auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  for (int i = 0; i < n; ++i) {
+    const PvGemm& g = gs[i];
+    if (g.M <= 0 || g.N <= 0) continue;
+    if (g.K <= 0) return PV_EINVAL;
+    const bool a = (g.a_cs == 1), b = (g.b_rs == 1);
+    if (mp.n == 0) { ak = a; bk = b; }
+    else if (a != ak || b != bk) return PV_EINVAL;       // one operand-layout class per launch
+    GemmK& p = mp.p[mp.n];
+    p.g = g;
+    p.k_chunk = (g.K + GK - 1) / GK * GK;
+    p.part = nullptr;
+    p.part_rs = nullptr;
+    p.a_vec = al(g.A) && (ak ? (g.a_rs % 4 == 0) : (g.a_rs == 1 && g.a_cs % 4 == 0));
+    p.b_vec = al(g.B) && (bk ? (g.b_cs % 4 == 0) : (g.b_cs == 1 && g.b_rs % 4 == 0));
+    mp.tiles_m[mp.n] = (g.M + GT - 1) / GT;
+    mp.tile_start[mp.n] = total;
+    total += mp.tiles_m[mp.n] * ((g.N + GT - 1) / GT);
+    ++mp.n;
+  }
+  if (mp.n == 0) return 0;
+  mp.tile_start[mp.n] = total;
+  if (ak && bk) hipLaunchKernelGGL((pv_gemm_multi_kernel<true, true>), dim3(total), dim3(256), 0, s, mp);
+  else if (ak && !bk) hipLaunchKernelGGL((pv_gemm_multi_kernel<true, false>), dim3(total), dim3(256), 0, s, mp);
+  else if (!ak && bk) hipLaunchKernelGGL((pv_gemm_multi_kernel<false, true>), dim3(total), dim3(256), 0, s, mp);
+  else hipLaunchKernelGGL((pv_gemm_multi_kernel<false, false>), dim3(total), dim3(256), 0, s, mp);
+  PV_LAUNCH_CHECK();
   return 0;
 }
 

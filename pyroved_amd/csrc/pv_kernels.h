@@ -52,7 +52,10 @@ struct PvOutLik {
 int pv_out_lik(const PvOutLik& p, hipStream_t s);
 int64_t pv_out_lik_blocks(int64_t M);
 int pv_segsum(const float* v, int64_t nseg, int64_t N, float* out, hipStream_t s);
-int pv_finish_scalars(const float* llb, int B, float* scalars, hipStream_t s);
+// scalars[1] = sum_b llb; if kl_part: scalars[2] = beta*sum kl_part[2i], scalars[3] = beta*sum kl_part[2i+1];
+// scalars[0] = -(scalars[1] + scalars[2] - scalars[3])
+int pv_finish_scalars(const float* llb, int B, float* scalars, const float* kl_part, int n_part, float beta,
+                      hipStream_t s);
 
 struct PvCoordLatBwd {
   const float* dpre0;    // (M, H0)
@@ -82,5 +85,48 @@ struct PvHeadBwd {
 };
 int pv_head_bwd(const PvHeadBwd& h, hipStream_t s);
 
+struct PvLatentBwd {
+  const float* llrow;    // (M)
+  const float* rowtp;    // (4, M)
+  const float* part_hz;  // (B*kmax, H)
+  const float* Wz;       // (H, lat_in) decoder.coord_latent.fc_latent.weight
+  float* llb;            // (B)
+  float* dhz;            // (B, H)
+  int64_t M;
+  int N, kmax, H, lat_in;
+  PvHeadBwd hb;          // dzc / dtp fields unused (values stay in LDS)
+};
+int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
+
 int pv_lik_elem(const float* a, const float* x, int64_t M, int lik, int sigmoid_out, float sig, float* loc,
                 float* llrow, float* dlda, hipStream_t s);
+
+// ---- compact encoder kernels (pv_encoder.hip) ----
+struct PvEncFwd {
+  const float* params;
+  pv_layer enc[PV_MAX_LAYERS];
+  pv_layer head;
+  int n_enc;
+  const float* x; int64_t ldx;      // (B, ldx) encoder input (x or cat(x, y))
+  const float* eps; const float* y;
+  float* eact[PV_MAX_LAYERS];       // hidden activations (B, out_i)
+  float* head_out;                  // (B, 2*z_dim)
+  float* z; float* z_scale; float* z_loc_out; float* z_scale_out;
+  float* tp; float* zy; float* kl_part;   // kl_part: (blocks, 2) partial sums of log p(z), log q(z|x)
+  float* hz; const float* Wz; int H0;     // fc_latent (null hz: skip)
+  int B, z_dim, c_dim, coord_dim, has_r, has_t, has_s;
+  float tp0, tp1, sc_prior;
+};
+bool pv_enc_compact_supported(const pv_ivae_plan* p);
+int pv_enc_fwd(const PvEncFwd& e, hipStream_t s);
+
+struct PvEncDgrad {
+  const float* params;
+  pv_layer enc[PV_MAX_LAYERS];
+  pv_layer head;
+  int n_enc, B;
+  const float* dhead;               // (B, 2*z_dim)
+  const float* eact[PV_MAX_LAYERS];
+  float* edp[PV_MAX_LAYERS];        // out: dL/d(pre-activation) of every hidden layer
+};
+int pv_enc_dgrad(const PvEncDgrad& e, hipStream_t s);

@@ -29,7 +29,8 @@ struct Layout {
   // encoder
   float* xin; float* eact[PV_MAX_LAYERS]; float* epre[PV_MAX_LAYERS];
   float* head; float* dhead; float* z; float* z_scale; float* tp; float* zy;
-  float* ebuf[2];
+  float* edp[PV_MAX_LAYERS];               // dL/d(pre-activation) of every encoder hidden layer
+  bool enc_compact; float* kl_part; int kl_blocks;   // compact encoder kernels (pv_encoder.hip)
   // decoder
   float* hz; float* h0; float* dact[PV_MAX_LAYERS]; float* dpre_[PV_MAX_LAYERS];
   float* logits; float* llrow; float* llb; float* dbuf[2];
@@ -75,8 +76,10 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
   L.z_scale = c.take(B * z);
   L.tp = c.take(B * 8);
   L.zy = p->c_dim > 0 ? c.take(B * lat_in) : nullptr;
-  L.ebuf[0] = c.take(B * maxe);
-  L.ebuf[1] = c.take(B * maxe);
+  for (int i = 0; i < p->n_enc; ++i) L.edp[i] = c.take(B * p->enc[i].out_dim);
+  L.enc_compact = pv_enc_compact_supported(p);
+  L.kl_blocks = (int)((B + 15) / 16);
+  L.kl_part = c.take(2 * L.kl_blocks);
   int64_t maxd = 0;
   L.fused = p->fused && pv_sdec_fused_supported(p);
   L.f_grid = L.f_kmax = 0;
@@ -266,47 +269,100 @@ int decoder_hidden_fwd(const pv_ivae_plan* p, const Layout& L, const float* zin,
   return 0;
 }
 
-// dL/dz from the decoder (dzc: content/y columns; dtp: phi, scale, tx, ty) -> head -> encoder layers
-int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, int dtp_sb, int dtp_sc,
-                       hipStream_t s) {
+// wgrad problem of one Linear: dw[N,K] = dpre[M,N]^T x[M,K], db[N] = colsum(dpre)
+PvGemm wgrad_problem(const float* dpre, int64_t lddp, const float* x, int64_t ldx, float* dw, float* db, int64_t M,
+                     int64_t K, int64_t N) {
+  PvGemm g{};
+  g.A = dpre; g.a_rs = 1; g.a_cs = lddp;
+  g.B = x; g.b_rs = ldx; g.b_cs = 1;
+  g.C = dw; g.ldc = K; g.M = (int)N; g.N = (int)K; g.K = (int)M;
+  g.act = PV_ACT_NONE;
+  g.rowsumA = db;
+  return g;
+}
+
+// encoder backward from dL/d(head pre-activations) (L.dhead): the dgrad chain through the hidden layers, then
+// every weight gradient of the encoder (plus `extra`, e.g. fc_latent's) in one multi-GEMM launch per 4 problems
+int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, hipStream_t s) {
   const int64_t B = p->batch, z = p->z_dim;
   float* G = p->grads;
   void* ws = L.scratch;
   const int64_t wsb = L.scratch_bytes;
   const int ne = p->n_enc;
-  PvHeadBwd hb{};
-  hb.dzc = L.dzc; hb.ldzc = lat_in; hb.dtp = L.dtp; hb.dtp_sb = dtp_sb; hb.dtp_sc = dtp_sc; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;
-  hb.head = L.head; hb.dhead = L.dhead; hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
-  hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
-  hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
-  PV_TRY(pv_head_bwd(hb, s));
   const pv_layer& hd = p->head;
   const float* elast = L.eact[ne - 1];
-  PV_TRY(linear_wgrad(L.dhead, 2 * z, elast, hd.in_dim, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B,
-                      hd.in_dim, 2 * z, ws, wsb, s));
-  float* ecur = L.ebuf[0];
-  float* eoth = L.ebuf[1];
-  PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + hd.w_off, ecur, hd.in_dim, elast, L.epre[ne - 1], hd.in_dim,
-                      p->enc[ne - 1].act, B, hd.in_dim, 2 * z, ws, wsb, s));
+  if (L.enc_compact) {
+    PvEncDgrad d{};
+    d.params = p->params; d.n_enc = ne; d.B = (int)B; d.head = hd; d.dhead = L.dhead;
+    for (int i = 0; i < ne; ++i) { d.enc[i] = p->enc[i]; d.eact[i] = L.eact[i]; d.edp[i] = L.edp[i]; }
+    PV_TRY(pv_enc_dgrad(d, s));
+  } else {
+    PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + hd.w_off, L.edp[ne - 1], hd.in_dim, elast, L.epre[ne - 1],
+                        hd.in_dim, p->enc[ne - 1].act, B, hd.in_dim, 2 * z, ws, wsb, s));
+    for (int i = ne - 1; i > 0; --i) {
+      const pv_layer& l = p->enc[i];
+      PV_TRY(linear_dgrad(L.edp[i], l.out_dim, p->params + l.w_off, L.edp[i - 1], l.in_dim, L.eact[i - 1],
+                          L.epre[i - 1], p->enc[i - 1].out_dim, p->enc[i - 1].act, B, l.in_dim, l.out_dim, ws, wsb,
+                          s));
+    }
+  }
+  PvGemm probs[PV_MAX_LAYERS + 4];
+  int np = 0;
+  for (int i = 0; i < n_extra; ++i) probs[np++] = extra[i];
+  probs[np++] = wgrad_problem(L.dhead, 2 * z, elast, hd.in_dim, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr,
+                              B, hd.in_dim, 2 * z);
   const float* xin = p->c_dim > 0 ? L.xin : p->x;
   const int64_t ldx = p->n_pix + p->c_dim;
   for (int i = ne - 1; i >= 0; --i) {
     const pv_layer& l = p->enc[i];
     const float* in = i > 0 ? L.eact[i - 1] : xin;
     const int64_t ldin = i > 0 ? p->enc[i - 1].out_dim : ldx;
-    PV_TRY(linear_wgrad(ecur, l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, B, l.in_dim,
-                        l.out_dim, ws, wsb, s));
-    if (i > 0) {
-      PV_TRY(linear_dgrad(ecur, l.out_dim, p->params + l.w_off, eoth, l.in_dim, in, L.epre[i - 1], ldin,
-                          p->enc[i - 1].act, B, l.in_dim, l.out_dim, ws, wsb, s));
-      float* t = ecur; ecur = eoth; eoth = t;
-    }
+    probs[np++] = wgrad_problem(L.edp[i], l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, B,
+                                l.in_dim, l.out_dim);
+  }
+  if (B <= 4096) {
+    for (int i = 0; i < np; i += 4) PV_TRY(pv_gemm_multi(probs + i, np - i < 4 ? np - i : 4, s));
+  } else {                                   // long contractions: split-K GEMMs, one launch pair each
+    for (int i = 0; i < np; ++i)
+      PV_TRY(pv_gemm(probs[i], pv_gemm_pick_splits(probs[i].M, probs[i].N, probs[i].K), ws, wsb, s));
   }
   return 0;
 }
 
+// dL/dz from the decoder (dzc: content/y columns; dtp: phi, scale, tx, ty) -> head -> encoder
+int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, int dtp_sb, int dtp_sc,
+                       hipStream_t s) {
+  PvHeadBwd hb{};
+  hb.dzc = L.dzc; hb.ldzc = lat_in; hb.dtp = L.dtp; hb.dtp_sb = dtp_sb; hb.dtp_sc = dtp_sc;
+  hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;
+  hb.head = L.head; hb.dhead = L.dhead; hb.B = p->batch; hb.z_dim = p->z_dim; hb.coord_dim = p->coord_dim;
+  hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
+  hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
+  PV_TRY(pv_head_bwd(hb, s));
+  return encoder_bwd(p, L, nullptr, 0, s);
+}
+
 // guide: encoder -> (z_loc, z_scale) -> z = z_loc + z_scale*eps, sampled-KL terms, transform parameters
 int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+  if (L.enc_compact) {
+    PvEncFwd e{};
+    e.params = p->params; e.n_enc = p->n_enc; e.head = p->head;
+    for (int i = 0; i < p->n_enc; ++i) { e.enc[i] = p->enc[i]; e.eact[i] = L.eact[i]; }
+    e.x = p->x; e.ldx = p->n_pix;
+    if (p->c_dim > 0) {
+      if (!p->y) return PV_EINVAL;
+      PV_TRY(pv_concat(p->x, p->n_pix, p->n_pix, p->y, p->c_dim, p->c_dim, L.xin, p->batch, s));
+      e.x = L.xin; e.ldx = p->n_pix + p->c_dim;
+    }
+    e.eps = p->eps; e.y = p->y; e.head_out = L.head; e.z = L.z; e.z_scale = L.z_scale;
+    e.z_loc_out = p->z_loc; e.z_scale_out = p->z_scale;
+    e.tp = p->coord_dim > 0 ? L.tp : nullptr; e.zy = L.zy; e.kl_part = L.kl_part;
+    if (p->coord_dim > 0) { e.hz = L.hz; e.Wz = p->params + p->fc_latent.w_off; e.H0 = p->fc_coord.out_dim; }
+    e.B = p->batch; e.z_dim = p->z_dim; e.c_dim = p->c_dim; e.coord_dim = p->coord_dim;
+    e.has_r = p->has_r; e.has_t = p->has_t; e.has_s = p->has_s;
+    e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;
+    return pv_enc_fwd(e, s);
+  }
   PV_TRY(encoder_fwd(p, L, s));
   PvHead h{};
   h.head = L.head; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
@@ -329,8 +385,9 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   const float* zin = p->c_dim > 0 ? L.zy : L.z + coord;
   const int64_t ldz = p->c_dim > 0 ? lat_in : z;
   if (p->fc_latent.in_dim != lat_in) return PV_EINVAL;
-  PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
-                    L.scratch, L.scratch_bytes, s));
+  if (!L.enc_compact)
+    PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
+                      L.scratch, L.scratch_bytes, s));
   PvFused f{};
   f.x = p->x; f.grid = p->grid; f.tp = L.tp; f.hz = L.hz;
   f.Wc = p->params + p->fc_coord.w_off; f.bc = p->params + p->fc_coord.b_off;
@@ -347,21 +404,27 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_start, s);
   PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
   if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_stop, s);
-  PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
-  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, s));
-  if (!want_grads) return 0;
+  if (!want_grads) {
+    PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
+    return pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta, s);
+  }
   PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
                    p->fc_coord.w_off, p->out.w_off, p->out.b_off};
   PV_TRY(pv_sdec_fused_reduce(L.f_part, L.f_grid, G, o, p->coord_dim, s));
-  // per-sample d(phi, scale, tx, ty): 4 planes of B sums over each sample's N rows
-  PV_TRY(pv_segsum(L.f_rowtp, 4 * B, N, L.dtp, s));
-  PV_TRY(pv_reduce_mid(L.f_part_hz, (int)B, L.f_kmax, H, L.dhz, s));
-  PV_TRY(pv_colsum(L.dhz, H, B, H, G + p->fc_coord.b_off, L.scratch, L.scratch_bytes, s));
-  PV_TRY(linear_wgrad(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, nullptr, B, lat_in, H, L.scratch, L.scratch_bytes,
-                      s));
-  PV_TRY(linear_dgrad(L.dhz, H, p->params + p->fc_latent.w_off, L.dzc, lat_in, nullptr, nullptr, 0, PV_ACT_NONE, B,
-                      lat_in, H, L.scratch, L.scratch_bytes, s));
-  return latent_encoder_bwd(p, L, lat_in, 1, (int)B, s);
+  // per sample: ll_b, d(phi, scale, tx, ty), dL/d(hz), dL/d(z content), head backward -> L.dhead
+  PvLatentBwd lb{};
+  lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;
+  lb.llb = L.llb; lb.dhz = L.dhz; lb.M = R; lb.N = (int)N; lb.kmax = L.f_kmax; lb.H = H; lb.lat_in = (int)lat_in;
+  PvHeadBwd& hb = lb.hb;
+  hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps; hb.head = L.head; hb.dhead = L.dhead;
+  hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
+  hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
+  hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
+  PV_TRY(pv_latent_bwd(lb, s));
+  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta, s));
+  // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
+  const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, B, lat_in, H);
+  return encoder_bwd(p, L, &wz, 1, s);
 }
 
 int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
@@ -396,7 +459,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
                        want_grads ? oth : nullptr, s));
   }
   PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
-  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, s));
+  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta, s));
   if (!want_grads) return 0;
 
   // ---------------- backward: decoder ----------------

@@ -154,7 +154,7 @@ def test_steps_vs_golden_and_oracle(gpu_device, name, fused):
         eng.adam_step()
         for key, p in model.state_dict().items():
             check_digest(p, gold, pre + ".param." + key, rtol=1e-4, atol=2e-6, what=name)
-            assert rel_l2(p, o.p[key].detach()) < 2e-5
+            assert rel_l2(p, o.p[key].detach()) < 5e-5
     z_loc, z_scale = model.encode(x)
     np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(z_scale.numpy(), gold["enc.z_scale"], rtol=1e-4, atol=5e-6)
