@@ -118,7 +118,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "1")),
+                    help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     args = ap.parse_args()
@@ -139,7 +140,7 @@ def main():
 
     B = args.batch
     model = pv.models.iVAE(DATA_DIM, LATENT_DIM, INVARIANCES, seed=1, device=dev)
-    eng = model.engine(fused=bool(args.fused))
+    eng = model.engine(fused=args.fused)
     if world > 1:
         pvdist.broadcast_(eng.flat)
     n_pix = DATA_DIM[0] * DATA_DIM[1]

@@ -75,8 +75,9 @@ typedef struct pv_ivae_plan {
   int32_t lik;            /* enum pv_lik                                                  */
   int32_t sigmoid_out;    /* sigmoid_d (ivae.py:153)                                      */
   float   decoder_sig;    /* Normal scale for the gaussian sampler (prob.py:28)           */
-  int32_t fused;          /* 1: use the fused persistent spatial-decoder kernel when the
-                             architecture allows it; 0: force the layer-by-layer path     */
+  int32_t fused;          /* spatial-decoder path when the architecture allows a fused persistent kernel:
+                             0 layer-by-layer kernels; 1 fused, f32-input MFMA; 2 fused, bf16 split-
+                             precision MFMA (x = hi + lo, three products, fp32 accumulate)               */
   /* ---- networks ---- */
   int32_t  n_enc;                  /* hidden layers of encoder_z.fc_layers (fc.py:44-45)  */
   int32_t  n_dec;                  /* hidden layers of decoder.fc_layers                  */

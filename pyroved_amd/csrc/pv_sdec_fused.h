@@ -5,8 +5,10 @@
 #define FD_H 128               // hidden width the kernel is specialised for (hidden_dim_d = [128, 128])
 #define FD_UNIT 16             // rows per wave tile (one 16x16x4 MFMA column block)
 #define FD_WAVES 8             // waves per workgroup (2 per SIMD)
-#define FD_REC (2 * FD_H * FD_H + 6 * FD_H)   // floats of one per-workgroup partial-gradient record:
-// [dW1 HxH | dW2 HxH | db1 H | db2 H | dWc0 H | dWc1 H | dwo H | dbo (1, padded to H)]
+#define FD_REC (2 * FD_H * FD_H + 14 * FD_H)  // floats of one per-workgroup partial-gradient record:
+// [dW1 HxH | dW2 HxH | db1 H | db2 H | dWc0 H | dWc1 H | dwo H | dbo (1, padded to H) | 8 per-wave dwo slots x H]
+// (the f32 kernel sums its d(wo) in LDS into the `dwo` segment; the bf16x3 kernel, out of LDS, keeps one slot
+//  per wave in the record's tail and the reduction adds the 8 slots)
 
 struct PvFused {
   const float* x;        // (M) observations, M = B*N rows (b, n)
@@ -38,6 +40,9 @@ int pv_sdec_fused_grid(int64_t units);
 int pv_sdec_fused_kmax(int n_pix, int64_t units, int grid);
 // launches the kernel (grads = false: forward + likelihood only)
 int pv_sdec_fused_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
+// same interface, bf16 split-precision ("bf16x3") matrix math (pv_sdec_fused_bf16.hip)
+int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
 struct PvFusedOffsets { int64_t W1, b1, W2, b2, Wc, wo, bo; };
-int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, hipStream_t s);
+int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int dwo_slots,
+                         hipStream_t s);

@@ -456,7 +456,8 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
 // ---- per-workgroup records -> flat gradient buffer (fixed summation order) ---------------------------
 // 64 outputs x 4 slices of the workgroup range per 256-thread block; slices combined in fixed order
 __global__ __launch_bounds__(256) void pv_sdec_fused_reduce_kernel(const float* __restrict__ part, int G_,
-                                                                   float* __restrict__ Gr, PvFusedOffsets o, int cd) {
+                                                                   float* __restrict__ Gr, PvFusedOffsets o, int cd,
+                                                                   int dwo_slots) {
   __shared__ float sm[4][64];
   const int HH = FD_H * FD_H;
   const int total = 2 * HH + 5 * FD_H + 1;
@@ -465,8 +466,19 @@ __global__ __launch_bounds__(256) void pv_sdec_fused_reduce_kernel(const float* 
   const int per = (G_ + 3) / 4;
   const int w0 = sl * per, w1 = min(G_, w0 + per);
   float v = 0.0f;
-  if (e < total)
-    for (int w = w0; w < w1; ++w) v += part[(int64_t)w * FD_REC + e];
+  if (e < total) {
+    const bool slots = dwo_slots && e >= 2 * HH + 4 * FD_H && e < 2 * HH + 5 * FD_H;   // d(wo): 8 per-wave slots
+    for (int w = w0; w < w1; ++w) {
+      if (slots) {
+        const float* p8 = part + (int64_t)w * FD_REC + 2 * HH + 6 * FD_H + (e - (2 * HH + 4 * FD_H));
+        float a = 0.0f;
+        for (int k = 0; k < FD_WAVES; ++k) a += p8[k * FD_H];
+        v += a;
+      } else {
+        v += part[(int64_t)w * FD_REC + e];
+      }
+    }
+  }
   sm[sl][c] = v;
   __syncthreads();
   if (sl != 0 || e >= total) return;
@@ -484,9 +496,11 @@ __global__ __launch_bounds__(256) void pv_sdec_fused_reduce_kernel(const float* 
   }
 }
 
-int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, hipStream_t s) {
+int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int dwo_slots,
+                         hipStream_t s) {
   const int total = 2 * FD_H * FD_H + 5 * FD_H + 1;
-  hipLaunchKernelGGL(pv_sdec_fused_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, grid, G, o, cd);
+  hipLaunchKernelGGL(pv_sdec_fused_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, grid, G, o, cd,
+                     dwo_slots);
   PV_LAUNCH_CHECK();
   return 0;
 }

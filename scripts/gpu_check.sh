@@ -16,3 +16,4 @@ echo "== rocprof"; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --ou
 find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null
 find /tmp/prof_$TAG -type f | head -20
 ls -la $OUT
+echo "== bench fused=2"; timeout 600 python bench.py --steps 50 --warmup 10 --fused 2 --no-cpu-baseline > $OUT/bench_f2.log 2>&1; tail -1 $OUT/bench_f2.log | cut -c1-400

@@ -38,7 +38,7 @@ disp = collections.Counter()
 for r in rows:
     disp[(r['Kernel_Name'][:48], r['Counter_Name'])] += 1
 for k in agg:
-    if 'fused_kernel' in k or 'gemm_kernel' in k:
+    if 'fused' in k and 'reduce' not in k:
         print(k, {c: round(v / disp[(k, c)], 1) for c, v in agg[k].items()})
 EOF
 done

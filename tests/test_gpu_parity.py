@@ -29,7 +29,7 @@ EPOCH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GO
 
 RTOL_ELBO = 2e-5      # ELBO terms (bar: 1e-4)
 RTOL_GRAD = 1e-4      # per-tensor relative L2 error of gradients vs the fp32 oracle
-FUSED = [False, True]
+FUSED = [0, 1, 2]       # 0 layer-by-layer kernels, 1 fused f32-MFMA decoder, 2 fused bf16 split-precision decoder
 
 
 def rel_l2(a, b):
@@ -154,7 +154,9 @@ def test_steps_vs_golden_and_oracle(gpu_device, name, fused):
         eng.adam_step()
         for key, p in model.state_dict().items():
             check_digest(p, gold, pre + ".param." + key, rtol=1e-4, atol=2e-6, what=name)
-            assert rel_l2(p, o.p[key].detach()) < 5e-5
+            # Adam normalises the gradient, so tiny-gradient entries amplify rounding: 1e-4 for the
+            # split-precision path, 5e-5 for the f32 paths
+            assert rel_l2(p, o.p[key].detach()) < (1e-4 if fused == 2 else 5e-5)
     z_loc, z_scale = model.encode(x)
     np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(z_scale.numpy(), gold["enc.z_scale"], rtol=1e-4, atol=5e-6)
