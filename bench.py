@@ -36,7 +36,11 @@ LATENT_DIM = 2
 BATCH_PER_GPU = 256
 N_RING = 16                      # distinct resident minibatches (n = 16 * B)
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* f32-in peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the guide's
+# gfx950 correction + WRITE_SIZE, KiB -> bytes), batch 256: see profiles/r01_pmc_*.txt.  None: not collected.
+TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1359 * 1024 + 37579 * 1024}
 
 
 def decoder_flops_per_image(n_pix, hidden=128, coord_dim=2):
@@ -118,7 +122,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "1")),
+    ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "2")),
                     help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
@@ -189,25 +193,35 @@ def main():
         k_avg_ms = sum(kms) / max(len(kms), 1)
         # which kernel the events bracket depends on the path (see pv_plan.hip / pv_sdec_fused.hip)
         fused_used = eng.uses_fused(B)
-        if fused_used:
-            kname = "pv_sdec_fused_kernel (decoder fwd+bwd, all layers)"
-            flops_per_launch = dec_fl * B
+        mode = args.fused if fused_used else 0
+        if mode == 2:
+            # split-precision bf16 MFMA: `achieved` counts the ALGORITHMIC fp32 FLOPs once, although
+            # the kernel issues 3 bf16 MFMAs per product; the peak is the dense bf16 MFMA peak it runs on
+            kname = "pv_sdec_fused_bf16_kernel (decoder fwd+bwd, all layers, bf16x3 split precision)"
+            flops_per_launch, peak, dtype = dec_fl * B, MFMA_BF16_PEAK_TFLOPS, "bf16x3"
+            arith = "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)"
+        elif mode == 1:
+            kname = "pv_sdec_fused_kernel (decoder fwd+bwd, all layers, f32-input MFMA)"
+            flops_per_launch, peak, dtype = dec_fl * B, MFMA_F32_PEAK_TFLOPS, "f32"
+            arith = "fp32 (f32-input MFMA)"
         else:
             kname = "pv_gemm_kernel<NT> (decoder hidden layer fwd, M=B*N, K=N=128)"
-            flops_per_launch = 2.0 * B * n_pix * 128 * 128
+            flops_per_launch, peak, dtype = 2.0 * B * n_pix * 128 * 128, MFMA_F32_PEAK_TFLOPS, "f32"
+            arith = "fp32 (f32-input MFMA)"
         achieved = flops_per_launch / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         out = {
             "metric": "images/sec (SVI step)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "iVAE 28x28 invariances=['r','t'] latent_dim=2 bernoulli, batch %d per GPU "
-                                   "(global %d), fp32 (f32-input MFMA), SVI step = ELBO+grads+%sAdam"
-                                   % (B, B * world, "allreduce+" if world > 1 else ""),
-                       "parallelism": "dp%d" % world, "path": "fused" if fused_used else "layered"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": kname,
-                         "kernel_ms": k_avg_ms, "flops_per_launch": flops_per_launch},
-            "step_frac_of_mfma_roof": value / world * (dec_fl + encoder_flops_per_image(n_pix, model.z_dim))
+                                   "(global %d), %s, SVI step = ELBO+grads+%sAdam"
+                                   % (B, B * world, arith, "allreduce+" if world > 1 else ""),
+                       "parallelism": "dp%d" % world, "path": {0: "layered", 1: "fused-f32", 2: "fused-bf16x3"}[mode]},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": TRAFFIC_BYTES.get(mode), "kernel": kname,
+                         "kernel_ms": k_avg_ms, "flops_per_launch": flops_per_launch,
+                         "frac_of_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS},
+            "step_frac_of_f32_mfma_roof": value / world * (dec_fl + encoder_flops_per_image(n_pix, model.z_dim))
             / (MFMA_F32_PEAK_TFLOPS * 1e12),
             "elbo": {"loss_per_image_first_timed_step": losses[args.warmup].item() / (B * world),
                      "loss_per_image_last_step": losses[-1].item() / (B * world),

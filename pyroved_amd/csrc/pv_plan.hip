@@ -411,7 +411,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   }
   PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
                    p->fc_coord.w_off, p->out.w_off, p->out.b_off};
-  PV_TRY(pv_sdec_fused_reduce(L.f_part, L.f_grid, G, o, p->coord_dim, p->fused == 2 ? 1 : 0, s));
+  PV_TRY(pv_sdec_fused_reduce(L.f_part, L.f_grid, G, o, p->coord_dim, 0, s));
   // per sample: ll_b, d(phi, scale, tx, ty), dL/d(hz), dL/d(z content), head backward -> L.dhead
   PvLatentBwd lb{};
   lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;

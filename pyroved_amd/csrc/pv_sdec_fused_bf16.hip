@@ -25,6 +25,7 @@
 //   * the wgrad stages bf16 hi/lo rows and uses v_mfma_f32_16x16x16_bf16 (k = the unit's 16 rows), operands by
 //     ds_read_b64_tr_b16; bias gradients ride along as an MFMA against a column of ones.
 #include "pv_sdec_fused.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -38,7 +39,8 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define TILE_UNITS (FB_WAVES * UPW)   // units per workgroup tile
 #define LDB 136                  // bf16 elements per LDS row of the weight / staging images (272 B)
 #define W_IMG (FD_H * LDB)       // elements of one weight image
-#define ST_IMG (FD_UNIT * LDB)   // elements of one staging image
+#define LDS2 144                 // staging images: 72-dword rows -> the 4x16 transposing reads are conflict-free
+#define ST_IMG (FD_UNIT * LDS2)  // elements of one staging image
 // byte offsets in dynamic LDS
 #define BO_W1H 0
 #define BO_W1L (BO_W1H + 2 * W_IMG)
@@ -51,7 +53,8 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define BO_VEC (BO_SBL + 2 * ST_IMG)      // fp32 vectors: Wc0, Wc1, bc, wo, b1, b2 (128 each)
 #define BO_INFO (BO_VEC + 6 * FD_H * 4)
 #define BO_RED (BO_INFO + 256)
-#define FB_LDS_BYTES (BO_RED + 256)
+#define BO_DWO (BO_RED + 256)              // per-wave d(wo) partial sums: FB_WAVES x 128 floats
+#define FB_LDS_BYTES (BO_DWO + FB_WAVES * FD_H * 4)
 #define FB_THREADS (64 * FB_WAVES)
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
@@ -88,6 +91,16 @@ __device__ __forceinline__ bf16x8 fb_cat(const bf16x4& a, const bf16x4& b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// LDS weight images are stored with their columns permuted inside every block of 32: logical column
+// k = 32m + 16h + 4q + i (h in {0,1}, q in 0..3, i in 0..3) sits at physical column 32m + 8q + 4h + i, so that the
+// 8 k's a lane feeds to one v_mfma_f32_16x16x32_bf16 ({32m+4q+i} and {32m+16+4q+i}: the C/D layout of the
+// producing layer) are CONTIGUOUS: the forward A operand is one ds_read_b128 (a pair of ds_read_b64 gets fused
+// into ds_read2_b64, whose 32-bank addressing runs at a quarter of the rate on this row stride).  Groups of 4
+// consecutive logical columns stay contiguous, which is all the transposing dgrad read needs.
+__device__ __forceinline__ int fb_pcol(int k) {
+  return (k & ~31) | (((k >> 2) & 3) << 3) | (((k >> 4) & 1) << 2) | (k & 3);
+}
+
 __device__ __forceinline__ bf16x4 fb_tr(const __bf16* p) {
   const short4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)p);
   return __builtin_bit_cast(bf16x4, v);
@@ -105,16 +118,16 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
 #pragma unroll
     for (int u = 0; u < UPW; ++u) out[u][ob] = bias;
   }
-  const __bf16* ah = Wh + r * LDB + 4 * q;
-  const __bf16* al = Wl + r * LDB + 4 * q;
+  const __bf16* ah = Wh + r * LDB + 8 * q;
+  const __bf16* al = Wl + r * LDB + 8 * q;
   bf16x8 wh[2][2], wl[2][2];
   auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
     const int m = g >> 2, op = (g & 3) * 2;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const int off = 16 * (op + o) * LDB + 32 * m;
-      h[o] = fb_cat(*reinterpret_cast<const bf16x4*>(ah + off), *reinterpret_cast<const bf16x4*>(ah + off + 16));
-      l[o] = fb_cat(*reinterpret_cast<const bf16x4*>(al + off), *reinterpret_cast<const bf16x4*>(al + off + 16));
+      h[o] = *reinterpret_cast<const bf16x8*>(ah + off);
+      l[o] = *reinterpret_cast<const bf16x8*>(al + off);
     }
   };
   load(0, wh[0], wl[0]);
@@ -155,7 +168,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
     for (int u = 0; u < UPW; ++u) out[u][kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   // lane i of 16-lane group q points at W[j0 + i/4][16*kb + 4*(i%4)], j0 = 32m + 4q (+16): after the transpose
   // lane k' holds W[j0 .. j0+3][16*kb + k']
-  const int toff = (4 * q + (r >> 2)) * LDB + 4 * (r & 3);
+  const int toff = (4 * q + (r >> 2)) * LDB + 8 * (r & 3);
   const __bf16* ah = Wh + toff;
   const __bf16* al = Wl + toff;
   bf16x8 wh[2][2], wl[2][2];
@@ -163,7 +176,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
     const int m = g >> 2, kp = (g & 3) * 2;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-      const int off = 32 * m * LDB + 16 * (kp + o);
+      const int off = 32 * m * LDB + 32 * ((kp + o) >> 1) + 4 * ((kp + o) & 1);
       h[o] = fb_cat(fb_tr(ah + off), fb_tr(ah + off + 16 * LDB));
       l[o] = fb_cat(fb_tr(al + off), fb_tr(al + off + 16 * LDB));
     }
@@ -211,16 +224,20 @@ __device__ __forceinline__ void fb_mul_dtanh(f32x4 (&out)[8], const f32x4 (&h)[8
     for (int i = 0; i < 4; ++i) out[kb][i] *= 1.0f - h[kb][i] * h[kb][i];
 }
 
-// owner wave: rows of one unit -> staging images (bf16 hi / lo, row-major [16][LDB])
-__device__ __forceinline__ void fb_stage_write(__bf16* __restrict__ sh, __bf16* __restrict__ sl, const f32x4 (&v)[8],
-                                               int r, int q) {
+// rows of one unit -> (hi, lo) bf16 in registers, done by every wave BEFORE the exchange loop so that the
+// owner's turn inside the loop is only 16 ds_write_b64 (the other waves wait at the barrier meanwhile)
+__device__ __forceinline__ void fb_presplit(const f32x4 (&v)[8], bf16x4 (&h)[8], bf16x4 (&l)[8]) {
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { __bf16 a, b; fb_split(v[jb][i], a, b); h[jb][i] = a; l[jb][i] = b; }
+}
+__device__ __forceinline__ void fb_stage_store(__bf16* __restrict__ sh, __bf16* __restrict__ sl, const bf16x4 (&h)[8],
+                                               const bf16x4 (&l)[8], int r, int q) {
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
-    bf16x4 h, l;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { __bf16 a, b; fb_split(v[jb][i], a, b); h[i] = a; l[i] = b; }
-    *reinterpret_cast<bf16x4*>(sh + r * LDB + 16 * jb + 4 * q) = h;
-    *reinterpret_cast<bf16x4*>(sl + r * LDB + 16 * jb + 4 * q) = l;
+    *reinterpret_cast<bf16x4*>(sh + r * LDS2 + 16 * jb + 4 * q) = h[jb];
+    *reinterpret_cast<bf16x4*>(sl + r * LDS2 + 16 * jb + 4 * q) = l[jb];
   }
 }
 
@@ -229,7 +246,7 @@ __device__ __forceinline__ void fb_stage_write(__bf16* __restrict__ sh, __bf16* 
 __device__ __forceinline__ void fb_wgrad_consume(const __bf16* sah, const __bf16* sal, const __bf16* sbh,
                                                  const __bf16* sbl, f32x4 (&accW)[2][8], f32x4 (&accB)[2], int wave,
                                                  int r, int q) {
-  const int toff = (4 * q + (r >> 2)) * LDB + 4 * (r & 3);
+  const int toff = (4 * q + (r >> 2)) * LDS2 + 4 * (r & 3);
   short4_ a_h[2], a_l[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -280,13 +297,27 @@ __device__ __forceinline__ float fb_sum_q(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// sum over the 16 lanes of a DPP row (= one q group), result in every lane: quad swaps, then the two mirrors
+template <int CTRL>
+__device__ __forceinline__ float fb_dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float fb_sum_r(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+  v += fb_dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += fb_dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += fb_dpp_mov<0x141>(v);     // row_half_mirror
+  v += fb_dpp_mov<0x140>(v);     // row_mirror
   return v;
 }
+
+// phase-timing trace (profiling only, enabled by PV_FD_ABLATE bit 256): shader-clock stamps of workgroup 0 /
+// wave 0 for its first tiles; read back with pv_debug_read_trace()
+__device__ long long fb_trace[256];
+#define FB_STAMP(k)                                                                        \
+  do {                                                                                     \
+    if ((f.ablate & 256) && g == 0 && tid == 0 && tile_no < 4)                             \
+      fb_trace[tile_no * 16 + (k)] = (long long)__builtin_readcyclecounter();              \
+  } while (0)
 
 template <bool GRADS>
 __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f) {
@@ -318,10 +349,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_split(w1[i], a, b); h1[i] = a; l1[i] = b;
       fb_split(w2[i], a, b); h2[i] = a; l2[i] = b;
     }
-    *reinterpret_cast<bf16x4*>(W1h + row * LDB + 4 * c4) = h1;
-    *reinterpret_cast<bf16x4*>(W1l + row * LDB + 4 * c4) = l1;
-    *reinterpret_cast<bf16x4*>(W2h + row * LDB + 4 * c4) = h2;
-    *reinterpret_cast<bf16x4*>(W2l + row * LDB + 4 * c4) = l2;
+    const int pc = fb_pcol(4 * c4);
+    *reinterpret_cast<bf16x4*>(W1h + row * LDB + pc) = h1;
+    *reinterpret_cast<bf16x4*>(W1l + row * LDB + pc) = l1;
+    *reinterpret_cast<bf16x4*>(W2h + row * LDB + pc) = h2;
+    *reinterpret_cast<bf16x4*>(W2l + row * LDB + pc) = l2;
   }
   for (int j = tid; j < FD_H; j += FB_THREADS) {
     vec[j] = f.Wc[j * f.cd];
@@ -350,13 +382,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   // this wave's private d(wo) slots in the record's tail (slot `wave` for its first unit, `4 + wave` for its
   // second): written and re-read only by lanes (r == 0, q) — one thread per address, so plain same-thread
   // ordering suffices
-  float* dwo_g = rec + 2 * FD_H * FD_H + 6 * FD_H + wave * FD_H;
-  if (GRADS && r == 0) {
+  float* dwo_g = reinterpret_cast<float*>(smb + BO_DWO) + wave * FD_H;     // this wave's LDS slot
+  if (r == 0) {
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-      *reinterpret_cast<f32x4*>(dwo_g + 16 * jb + 4 * q) = f32x4{0, 0, 0, 0};
-      *reinterpret_cast<f32x4*>(dwo_g + FB_WAVES * FD_H + 16 * jb + 4 * q) = f32x4{0, 0, 0, 0};
-    }
+    for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<f32x4*>(dwo_g + 16 * jb + 4 * q) = f32x4{0, 0, 0, 0};
   }
 
   auto flush_hz = [&](int b) {
@@ -372,7 +401,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   };
 
   const int64_t u_lo = (int64_t)g * f.units / G, u_hi = (int64_t)(g + 1) * f.units / G;
+  int tile_no = -1;
   for (int64_t ut = u_lo; ut < u_hi; ut += TILE_UNITS) {
+    ++tile_no;
+    FB_STAMP(0);
     const int nact = (int)((u_hi - ut) < TILE_UNITS ? (u_hi - ut) : TILE_UNITS);
     int opq = 0;
     asm volatile("" : "+v"(opq));       // loop-variant zero: keeps LICM from hoisting the LDS-resident vectors
@@ -429,10 +461,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     if (wave_active) {
 #pragma unroll
       for (int u = 0; u < UPW; ++u) coord_layer(tA[u], u);          // tA = h0
+      FB_STAMP(1);
       fb_layer_fwd(W1h, W1l, b1s, tA, tB, r, q);
+      FB_STAMP(2);
 #pragma unroll
       for (int u = 0; u < UPW; ++u) fb_tanh8(tB[u]);                // tB = h1
       fb_layer_fwd(W2h, W2l, b2s, tB, tC, r, q);
+      FB_STAMP(3);
 #pragma unroll
       for (int u = 0; u < UPW; ++u) fb_tanh8(tC[u]);                // tC = h2
       // ---- output layer + likelihood (fp32) ----
@@ -470,7 +505,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         }
         if (GRADS) {
           if (q == 0) dbo += dlda;
-          float* dwo = dwo_g + u * FB_WAVES * FD_H;        // slots wave (unit 0) and 4 + wave (unit 1)
+          float* dwo = dwo_g;
 #pragma unroll
           for (int jb = 0; jb < 8; ++jb) {
             f32x4 tv;
@@ -490,19 +525,31 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         }
       }
     }
+    FB_STAMP(4);
     if (!GRADS) continue;
 
     // ---- wgrad of layer 2: exchange (dpre2 = tC, h1 = tB) one unit at a time ----
+    bf16x4 pAh[UPW][8], pAl[UPW][8], pBh[UPW][8], pBl[UPW][8];
+    if (wave_active) {
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) { fb_presplit(tC[u], pAh[u], pAl[u]); fb_presplit(tB[u], pBh[u], pBl[u]); }
+    }
+    FB_STAMP(5);
     for (int c = 0; c < nact; ++c) {
 #pragma unroll
       for (int u = 0; u < UPW; ++u)
-        if (c == UPW * wave + u) { fb_stage_write(sAh, sAl, tC[u], r, q); fb_stage_write(sBh, sBl, tB[u], r, q); }
+        if (c == UPW * wave + u) {
+          fb_stage_store(sAh, sAl, pAh[u], pAl[u], r, q);
+          fb_stage_store(sBh, sBl, pBh[u], pBl[u], r, q);
+        }
       __syncthreads();
       fb_wgrad_consume(sAh, sAl, sBh, sBl, accW2, accB2, wave, r, q);
       __syncthreads();
     }
+    FB_STAMP(6);
     if (wave_active) {
       fb_layer_dgrad(W2h, W2l, tC, tA, r, q);
+      FB_STAMP(7);
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
         fb_mul_dtanh(tA[u], tB[u]);                        // tA = dpre1
@@ -512,15 +559,24 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
 #pragma unroll
       for (int u = 0; u < UPW; ++u) fb_mul_dtanh(tC[u], tB[u]);   // tC = dpre0
     }
+    FB_STAMP(8);
     // ---- wgrad of layer 1: exchange (dpre1 = tA, h0 = tB) ----
+    if (wave_active) {
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) { fb_presplit(tA[u], pAh[u], pAl[u]); fb_presplit(tB[u], pBh[u], pBl[u]); }
+    }
     for (int c = 0; c < nact; ++c) {
 #pragma unroll
       for (int u = 0; u < UPW; ++u)
-        if (c == UPW * wave + u) { fb_stage_write(sAh, sAl, tA[u], r, q); fb_stage_write(sBh, sBl, tB[u], r, q); }
+        if (c == UPW * wave + u) {
+          fb_stage_store(sAh, sAl, pAh[u], pAl[u], r, q);
+          fb_stage_store(sBh, sBl, pBh[u], pBl[u], r, q);
+        }
       __syncthreads();
       fb_wgrad_consume(sAh, sAl, sBh, sBl, accW1, accB1, wave, r, q);
       __syncthreads();
     }
+    FB_STAMP(10);
     // ---- coordinate layer backward (fp32): row-local part ----
     if (wave_active) {
 #pragma unroll
@@ -544,6 +600,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
     }
     // ---- cross-row part: dWc, dbc / dhz from dpre0 staged in fp32 over the (now idle) staging images ----
+    FB_STAMP(11);
     float* st32 = reinterpret_cast<float*>(smb + BO_SAH);      // 16 rows x 136 floats = 8704 B <= 4 x 4352 B
     for (int c = 0; c < nact; ++c) {
 #pragma unroll
@@ -573,6 +630,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
       __syncthreads();
     }
+    FB_STAMP(12);
   }
   if (!GRADS) return;
 
@@ -605,6 +663,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   const float tb = pv_wave_sum(dbo);
   if (lane == 0) red[wave] = tb;
   __syncthreads();
+  if (tid < FD_H) {
+    const float* d = reinterpret_cast<const float*>(smb + BO_DWO);
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < FB_WAVES; ++w) v += d[w * FD_H + tid];
+    rec[2 * FD_H * FD_H + 4 * FD_H + tid] = v;
+  }
   if (tid == 0) {
     float v = 0.0f;
     for (int w = 0; w < FB_WAVES; ++w) v += red[w];
@@ -612,7 +677,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   }
 }
 
-int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, hipStream_t s) {
+extern "C" int pv_debug_read_trace(long long* out, int n) {
+  if (n > 256) n = 256;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_trace), n * sizeof(long long));
+}
+
+int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {
+  PvFused f = f_in;
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }
+  f.ablate = ablate;
   const size_t lds = FB_LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {

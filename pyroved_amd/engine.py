@@ -39,7 +39,7 @@ class IVAEEngine:
     """Binds an iVAE-like model (encoder_z: fcEncoderNet, decoder: sDecoderNet | fcDecoderNet)
     to the HIP library."""
 
-    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: bool = True):
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: int = 2):
         self.model = model
         self.lr, self.betas, self.adam_eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.fused = int(fused)         # 0 layered kernels, 1 fused f32-MFMA decoder, 2 fused bf16x3 decoder

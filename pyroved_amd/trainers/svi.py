@@ -38,7 +38,8 @@ class SVItrainer:
         lr: learning rate (Default: 1e-3)
         device: device of the model (defaults to the model's)
         rng: "cpu" (default; bit-compatible with the reference's CPU stream) or "device"
-        fused: use the fused persistent decoder kernel when available (default True)
+        fused: spatial-decoder kernel path: 2 (default) fused persistent kernel with bf16 split-precision
+            matrix math (fp32-class results), 1 fused kernel on the f32-input MFMA, 0 layer-by-layer kernels
         process_group: torch.distributed group for data-parallel training (default: WORLD if initialised)
         mirror_evaluate_update: keep the reference's behaviour of stepping the optimizer inside
             evaluate() (svi.py:126-135 calls svi.step under no_grad) — default True
@@ -72,7 +73,7 @@ class SVItrainer:
             self.engine = kwargs["engine"]
         else:
             self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
-                                       fused=kwargs.get("fused", True))
+                                       fused=int(kwargs.get("fused", 2)))
         self.engine.lr, self.engine.betas, self.engine.adam_eps = float(adam["lr"]), tuple(adam["betas"]), float(adam["eps"])
         self.loss_history = {"training_loss": [], "test_loss": []}
         self.current_epoch = 0
