@@ -120,7 +120,9 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
   }
   const __bf16* ah = Wh + r * LDB + 8 * q;
   const __bf16* al = Wl + r * LDB + 8 * q;
-  bf16x8 wh[2][2], wl[2][2];
+  // operands are fetched TWO groups ahead (three rotating register sets): a group is only 6 MFMAs (~100 cycles),
+  // shorter than the LDS latency, and this wave is alone on its SIMD
+  bf16x8 wh[3][2], wl[3][2];
   auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
     const int m = g >> 2, op = (g & 3) * 2;
 #pragma unroll
@@ -131,18 +133,19 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
     }
   };
   load(0, wh[0], wl[0]);
+  load(1, wh[1], wl[1]);
   bf16x8 bh[UPW], bl[UPW];
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int m = g >> 2, op = (g & 3) * 2;
-    if (g + 1 < 16) load(g + 1, wh[(g + 1) & 1], wl[(g + 1) & 1]);
+    if (g + 2 < 16) load(g + 2, wh[(g + 2) % 3], wl[(g + 2) % 3]);
     FB_FENCE();
     if ((g & 3) == 0) {
 #pragma unroll
       for (int u = 0; u < UPW; ++u) fb_split8(in[u][2 * m], in[u][2 * m + 1], bh[u], bl[u]);
     }
-    const bf16x8(&h)[2] = wh[g & 1];
-    const bf16x8(&l)[2] = wl[g & 1];
+    const bf16x8(&h)[2] = wh[g % 3];
+    const bf16x8(&l)[2] = wl[g % 3];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -171,7 +174,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
   const int toff = (4 * q + (r >> 2)) * LDB + 8 * (r & 3);
   const __bf16* ah = Wh + toff;
   const __bf16* al = Wl + toff;
-  bf16x8 wh[2][2], wl[2][2];
+  bf16x8 wh[3][2], wl[3][2];
   auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
     const int m = g >> 2, kp = (g & 3) * 2;
 #pragma unroll
@@ -182,18 +185,19 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
     }
   };
   load(0, wh[0], wl[0]);
+  load(1, wh[1], wl[1]);
   bf16x8 bh[UPW], bl[UPW];
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int m = g >> 2, kp = (g & 3) * 2;
-    if (g + 1 < 16) load(g + 1, wh[(g + 1) & 1], wl[(g + 1) & 1]);
+    if (g + 2 < 16) load(g + 2, wh[(g + 2) % 3], wl[(g + 2) % 3]);
     FB_FENCE();
     if ((g & 3) == 0) {
 #pragma unroll
       for (int u = 0; u < UPW; ++u) fb_split8(dp[u][2 * m], dp[u][2 * m + 1], bh[u], bl[u]);
     }
-    const bf16x8(&h)[2] = wh[g & 1];
-    const bf16x8(&l)[2] = wl[g & 1];
+    const bf16x8(&h)[2] = wh[g % 3];
+    const bf16x8(&l)[2] = wl[g % 3];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -542,9 +546,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
           fb_stage_store(sAh, sAl, pAh[u], pAl[u], r, q);
           fb_stage_store(sBh, sBl, pBh[u], pBl[u], r, q);
         }
+      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[128 + 4 * c] = (long long)__builtin_readcyclecounter();
       __syncthreads();
+      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[129 + 4 * c] = (long long)__builtin_readcyclecounter();
       fb_wgrad_consume(sAh, sAl, sBh, sBl, accW2, accB2, wave, r, q);
+      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[130 + 4 * c] = (long long)__builtin_readcyclecounter();
       __syncthreads();
+      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[131 + 4 * c] = (long long)__builtin_readcyclecounter();
     }
     FB_STAMP(6);
     if (wave_active) {

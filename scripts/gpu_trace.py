@@ -1,6 +1,6 @@
 """Phase timing of the fused bf16 kernel (PV_FD_ABLATE=256): prints cycles per phase for workgroup 0 / wave 0."""
 import ctypes as C, os, sys
-os.environ["PV_FD_ABLATE"] = "256"
+os.environ["PV_FD_ABLATE"] = os.environ.get("PV_TRACE_MASK", "256")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pyroved_amd as pv
@@ -25,3 +25,10 @@ for t in range(4):
         if st[k]:
             out.append("%s=%d" % (names[k], st[k] - prev)); prev = st[k]
     print("tile", t, "total", prev - st[0], " ".join(out))
+if int(os.environ.get("PV_FD_ABLATE", "0")) & 512:
+    buf2 = (C.c_longlong * 160)()
+    lib.pv_debug_read_trace(buf2, 160)
+    base = buf2[128]
+    print("exchange L2 chunks (cycles since first stamp): store_done, after_bar1, after_consume, after_bar2")
+    for c in range(4):
+        print(" chunk", c, [buf2[128 + 4 * c + k] - base for k in range(4)])
