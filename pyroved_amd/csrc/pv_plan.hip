@@ -41,7 +41,7 @@ struct Layout {
   int nchunk, rows_per_chunk;
   // fused persistent decoder path
   bool fused; int f_grid, f_kmax;
-  float* f_part; float* f_part_hz; float* f_rowtp;
+  float* f_part; float* f_part_hz; float* f_rowtp; float* f_wimg;
   int64_t total;
 };
 
@@ -83,7 +83,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
   int64_t maxd = 0;
   L.fused = p->fused && pv_sdec_fused_supported(p);
   L.f_grid = L.f_kmax = 0;
-  L.f_part = L.f_part_hz = L.f_rowtp = nullptr;
+  L.f_part = L.f_part_hz = L.f_rowtp = L.f_wimg = nullptr;
   for (int i = 0; i < p->n_dec; ++i) {
     L.dact[i] = L.fused ? nullptr : c.take(R * p->dec[i].out_dim);
     L.dpre_[i] = (!L.fused && p->dec[i].act == PV_ACT_GELU) ? c.take(R * p->dec[i].out_dim) : nullptr;
@@ -103,6 +103,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
       L.f_part_hz = c.take(B * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);
+      L.f_wimg = c.take(FB_WIMG_BYTES / (int64_t)sizeof(float));
       upd(pv_colsum_ws(B, (int)H0));
     }
     L.logits = nullptr;
@@ -395,9 +396,12 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.W2 = p->params + p->dec[1].w_off; f.b2 = p->params + p->dec[1].b_off;
   f.wo = p->params + p->out.w_off; f.bo = p->params + p->out.b_off;
   f.llrow = L.llrow; f.loc = p->loc; f.rowtp = L.f_rowtp; f.part_hz = L.f_part_hz; f.part = L.f_part;
+  f.wimg = L.f_wimg;
   f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)B; f.lik = p->lik;
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
-  if (want_grads) {
+  if (p->fused == 2) {
+    PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, s));      // weight images + zero fill of part_hz
+  } else if (want_grads) {
     hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(B * L.f_kmax * H) * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
   }

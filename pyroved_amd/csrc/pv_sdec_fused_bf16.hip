@@ -9,53 +9,71 @@
 //
 // Mapping.  One persistent 256-thread workgroup per CU = 4 waves, ONE per SIMD, each with the full 512-register
 // budget (the 8-wave / 256-register form of this kernel spilled its persistent accumulators to scratch every
-// tile: 243 MB of scratch writes per launch and 66 % of wave time in s_waitcnt).  A wave carries TWO 16-row
-// units at a time: every weight operand read from LDS feeds both units' MFMAs (half the LDS traffic) and the
-// two units' accumulators give the in-order wave independent MFMA chains.  As in pv_sdec_fused.hip:
+// tile).  A tile is 64 rows: each wave carries one 16-row unit.  As in pv_sdec_fused.hip:
 //   * layers are computed transposed, D[j][r] = sum_k W[j][k] h[r][k], so the 16x16 C/D layout of one layer is
 //     the B-operand layout of the next: activations stay in registers through forward and dgrad;
 //   * a wave owns two 16x128 slices of dW1 and dW2 in accumulators for the whole kernel and the workgroup
-//     exchanges (dpre, h) through LDS, one unit at a time, for the wgrad;
+//     exchanges (dpre, h) through LDS for the wgrad;
 //   * per-workgroup partial gradients are reduced in a fixed order afterwards (no float atomics).
 // What the bf16 split changes:
-//   * weights live in LDS as bf16 hi and lo images, row-major [128][136]; the forward reads a lane's A operand
-//     with two ds_read_b64 (k = 32m+4q.. and 32m+16+4q..), the dgrad reads the TRANSPOSED operand from the same
+//   * weights live in LDS as bf16 hi and lo images, row-major [128][136] with permuted columns (fb_pcol); the
+//     forward reads a lane's A operand with one ds_read_b128, the dgrad reads the TRANSPOSED operand from the same
 //     image with ds_read_b64_tr_b16 (hardware 4x16 transpose), so one image serves both orientations;
-//   * activations are split to (hi, lo) on the fly (3 VALU per element);
-//   * the wgrad stages bf16 hi/lo rows and uses v_mfma_f32_16x16x16_bf16 (k = the unit's 16 rows), operands by
-//     ds_read_b64_tr_b16; bias gradients ride along as an MFMA against a column of ones.
+//   * activations are split to (hi, lo) once per tensor (3 VALU per element) and the split feeds both the next
+//     contraction and the wgrad exchange;
+//   * LDS OVERLAY.  The two layers' weight images fill 136 of the 160 KB, which leaves no room to stage a whole
+//     tile's (dpre, h) for the wgrad.  So the staging area of layer 2's wgrad lies OVER W1's images (idle between
+//     the forward of layer 1 and the dgrad of layer 1) and that of layer 1's wgrad and of the coordinate layer's
+//     reductions OVER W2's images (idle from the dgrad of layer 2 to the next tile's forward of layer 2); the
+//     overwritten images come back by LDS-DMA (global_load_lds_dwordx4, no registers, asynchronous) from a
+//     pre-split global copy made once per step (pv_fb_prep_kernel), under the dgrad of layer 2 resp. the next
+//     tile's coordinate layer + forward of layer 1.  One staging pass per layer then covers all 64 rows: the
+//     wgrad contracts 32 rows per v_mfma_f32_16x16x32_bf16 (operands by ds_read_b64_tr_b16; bias gradients ride
+//     along as an MFMA against ones) and a tile needs 8 workgroup barriers instead of 24.
 #include "pv_sdec_fused.h"
 #include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4_ __attribute__((ext_vector_type(4)));
+typedef short short8_ __attribute__((ext_vector_type(8)));
+typedef int int4_ __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4_ lds_short4;
 
-#define FB_WAVES 4               // waves per workgroup (one per SIMD)
-#ifndef UPW
-#define UPW 1                    // units (16 rows) a wave carries at a time
-#endif
-#define TILE_UNITS (FB_WAVES * UPW)   // units per workgroup tile
-#define LDB 136                  // bf16 elements per LDS row of the weight / staging images (272 B)
+#define FB_WAVES 4               // waves per workgroup (one per SIMD), one 16-row unit each
+#define TILE_UNITS FB_WAVES      // units per workgroup tile
+#define TILE_ROWS (TILE_UNITS * FD_UNIT)
+#define LDB 128                  // bf16 elements per LDS row of the weight images: unpadded, 16-byte chunks XOR-swizzled
 #define W_IMG (FD_H * LDB)       // elements of one weight image
-#define LDS2 144                 // staging images: 72-dword rows -> the 4x16 transposing reads are conflict-free
-#define ST_IMG (FD_UNIT * LDS2)  // elements of one staging image
-// byte offsets in dynamic LDS
-#define BO_W1H 0
-#define BO_W1L (BO_W1H + 2 * W_IMG)
-#define BO_W2H (BO_W1L + 2 * W_IMG)
-#define BO_W2L (BO_W2H + 2 * W_IMG)
-#define BO_SAH (BO_W2L + 2 * W_IMG)       // staged dpre: hi, lo
-#define BO_SAL (BO_SAH + 2 * ST_IMG)
-#define BO_SBH (BO_SAL + 2 * ST_IMG)      // staged h: hi, lo
-#define BO_SBL (BO_SBH + 2 * ST_IMG)
-#define BO_VEC (BO_SBL + 2 * ST_IMG)      // fp32 vectors: Wc0, Wc1, bc, wo, b1, b2 (128 each)
-#define BO_INFO (BO_VEC + 6 * FD_H * 4)
-#define BO_RED (BO_INFO + 256)
+#define IMG_BYTES (2 * W_IMG)    // 32,768
+#define LDS2 144                 // staging arrays: 72-dword rows -> the 4x16 transposing reads are conflict-free
+#define ST_ARR (TILE_ROWS * LDS2)          // elements of one staging array (64 rows)
+#define ST_BYTES (2 * ST_ARR)              // 18,432
+// byte offsets in dynamic LDS:  [ W1h W1l | gap | W2h W2l | vectors ... ]
+//   wgrad-2 staging (4 arrays) = W1 images + gap ;  wgrad-1 / coordinate staging = gap + W2 images
+#define BO_R1 0
+#define BO_GAP (2 * IMG_BYTES)
+#define GAP_BYTES (4 * ST_BYTES - 2 * IMG_BYTES)      // 8192
+#define BO_R2 (BO_GAP + GAP_BYTES)
+#define BO_VEC (BO_R2 + 2 * IMG_BYTES)     // fp32 vectors: Wc0, Wc1, bc, wo, b1, b2 (128 each)
+#define BO_INFO (BO_VEC + 6 * FD_H * 4)    // x0[64], x1[64], sample index of the 4 units
+#define BO_RED (BO_INFO + 768)
 #define BO_DWO (BO_RED + 256)              // per-wave d(wo) partial sums: FB_WAVES x 128 floats
-#define FB_LDS_BYTES (BO_DWO + FB_WAVES * FD_H * 4)
+#define BO_CHZ (BO_DWO + FB_WAVES * FD_H * 4)   // next tile's per-unit inputs, fetched by LDS-DMA a tile ahead:
+#define BO_CTP (BO_CHZ + FB_WAVES * FD_H * 4)   //   hz[b] (128 floats), tp[b] (8 of 64 floats), grid rows (16*cd of 64)
+#define BO_CGR (BO_CTP + FB_WAVES * 256)
+#define FB_LDS_BYTES (BO_CGR + FB_WAVES * 256)
 #define FB_THREADS (64 * FB_WAVES)
+#ifndef FB_GB
+#define FB_GB 2                  // output blocks per operand group of the layer loops (8 / FB_GB groups per k-block)
+#endif
+#define FB_GPM (8 / FB_GB)
+#ifndef FB_DGD
+#define FB_DGD 1                 // operand prefetch distance (groups) of the dgrad loops
+#endif
+static_assert(GAP_BYTES >= 0, "staging overlays");
+static_assert((2 * IMG_BYTES) % (FB_WAVES * 1024) == 0, "image reload: whole 1 KB LDS-DMA pieces per wave");
+static_assert(FB_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define BERN_EPS 1.1920928955078125e-07f
@@ -101,115 +119,136 @@ __device__ __forceinline__ int fb_pcol(int k) {
   return (k & ~31) | (((k >> 2) & 3) << 3) | (((k >> 4) & 1) << 2) | (k & 3);
 }
 
+// ... and every row R of an image has its sixteen 16-byte chunks XOR-swizzled by fb_swz(R) = 4*(R&3) + SL[(R>>2)&3],
+// SL = {0,2,3,1}: (a) the forward's ds_read_b128 (lane (r,q): row 16*ob + r, chunk 4m + q; serviced in the 16-lane
+// groups {0-3,12-15,20-27}, ...) touches 16 distinct chunks per group = all 64 banks; (b) the dgrad's transposing
+// 8-byte reads (32 lanes: 8 rows x 4 chunks, one half of each chunk) are 2-way, the minimum while all lanes want
+// the same half.  Unpadded rows make an image exactly 32 KB.
+__device__ __forceinline__ int fb_sl(int t) { return (0x78 >> (2 * t)) & 3; }
+__device__ __forceinline__ int fb_swz(int R) { return 4 * (R & 3) + fb_sl((R >> 2) & 3); }
+// element index of (row R, permuted column pc) in an image
+__device__ __forceinline__ int fb_wel(int R, int pc) { return R * LDB + 8 * ((pc >> 3) ^ fb_swz(R)) + (pc & 7); }
+
+// a zero the compiler cannot see through: lane-address arithmetic that depends on it is redone where it is used
+// instead of being hoisted out of the tile loop and held in (or spilled from) registers for the whole kernel
+__device__ __forceinline__ int fb_opaque0() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+
 __device__ __forceinline__ bf16x4 fb_tr(const __bf16* p) {
   const short4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)p);
   return __builtin_bit_cast(bf16x4, v);
 }
 
-// forward layer for the wave's two units: out[u] = bias + W in[u]  (pre-activation on return).
-// Stream: per k-block m (32 k's) split both units' inputs; per pair of output blocks read 4 weight operands
-// (hi/lo x 2 blocks, double-buffered one group ahead) and issue 12 MFMAs (3 split terms x 2 blocks x 2 units).
-__device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
-                                             const float* __restrict__ bs, const f32x4 (&in)[UPW][8],
-                                             f32x4 (&out)[UPW][8], int r, int q) {
+// ---- LDS-DMA: 16 B per lane from global straight into LDS at (wave-uniform byte address) + 16 * lane.  hipcc
+// does not count these in its s_waitcnt bookkeeping: fb_wait_vm0() before the landed data is read, and no
+// compiler-visible global load may be pending when one is issued (the callers drain first).
+__device__ __forceinline__ void fb_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void fb_glds4(const void* gsrc, unsigned lds_dst) {     // 4 B per lane, 256 B per wave
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void fb_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// one layer's hi + lo images (68 KB) from their global copy: 17 one-KB pieces per wave
+__device__ __forceinline__ void fb_reload(const char* __restrict__ gimg, unsigned lds_dst, int wave, int lane) {
+  constexpr int PIECES = 2 * IMG_BYTES / (FB_WAVES * 1024);
 #pragma unroll
-  for (int ob = 0; ob < 8; ++ob) {
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
-#pragma unroll
-    for (int u = 0; u < UPW; ++u) out[u][ob] = bias;
+  for (int c = 0; c < PIECES; ++c) {
+    const int off = (wave * PIECES + c) * 1024;
+    fb_glds16(gimg + off + lane * 16, lds_dst + off);
   }
-  const __bf16* ah = Wh + r * LDB + 8 * q;
-  const __bf16* al = Wl + r * LDB + 8 * q;
-  // operands are fetched TWO groups ahead (three rotating register sets): a group is only 6 MFMAs (~100 cycles),
-  // shorter than the LDS latency, and this wave is alone on its SIMD
-  bf16x8 wh[3][2], wl[3][2];
-  auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
-    const int m = g >> 2, op = (g & 3) * 2;
+}
+
+// forward layer of the wave's unit: out = bias + W in (pre-activation on return); `in` arrives split (hi, lo per
+// C/D block).  Stream: per k-block m (32 k's) and group of four output blocks read 8 weight operands (hi/lo,
+// one group ahead) and issue 12 MFMAs (3 split terms x 4 blocks: four independent accumulator chains).
+__device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
+                                             const float* __restrict__ bs, const bf16x4 (&ih)[8],
+                                             const bf16x4 (&il)[8], f32x4 (&out)[8], int r, int q) {
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int off = 16 * (op + o) * LDB + 32 * m;
+  for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
+  // row 16*ob + r, logical chunk 4m + q  ->  physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])
+  r |= fb_opaque0();
+  const int lbase = r * LDB + 8 * (q ^ fb_sl(r >> 2));
+  const __bf16* ah = Wh + lbase;
+  const __bf16* al = Wl + lbase;
+  int xm[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) xm[m] = 32 * (m ^ (r & 3));
+  bf16x8 wh[2][FB_GB], wl[2][FB_GB];
+  auto load = [&](int g, bf16x8 (&h)[FB_GB], bf16x8 (&l)[FB_GB]) {
+    const int m = g / FB_GPM, op = (g % FB_GPM) * FB_GB;
+#pragma unroll
+    for (int o = 0; o < FB_GB; ++o) {
+      const int off = 16 * (op + o) * LDB + xm[m];
       h[o] = *reinterpret_cast<const bf16x8*>(ah + off);
       l[o] = *reinterpret_cast<const bf16x8*>(al + off);
     }
   };
   load(0, wh[0], wl[0]);
-  load(1, wh[1], wl[1]);
-  bf16x8 bh[UPW], bl[UPW];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int m = g >> 2, op = (g & 3) * 2;
-    if (g + 2 < 16) load(g + 2, wh[(g + 2) % 3], wl[(g + 2) % 3]);
+  for (int g = 0; g < 4 * FB_GPM; ++g) {
+    const int m = g / FB_GPM, op = (g % FB_GPM) * FB_GB;
+    if (g + 1 < 4 * FB_GPM) load(g + 1, wh[(g + 1) & 1], wl[(g + 1) & 1]);
     FB_FENCE();
-    if ((g & 3) == 0) {
+    const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]), bl = fb_cat(il[2 * m], il[2 * m + 1]);
+    const bf16x8(&h)[FB_GB] = wh[g & 1];
+    const bf16x8(&l)[FB_GB] = wl[g & 1];
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) fb_split8(in[u][2 * m], in[u][2 * m + 1], bh[u], bl[u]);
-    }
-    const bf16x8(&h)[2] = wh[g % 3];
-    const bf16x8(&l)[2] = wl[g % 3];
+    for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(h[o], bh, out[op + o]);
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(h[o], bl, out[op + o]);
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) out[u][op + o] = MFMA32(h[o], bh[u], out[u][op + o]);
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) out[u][op + o] = MFMA32(h[o], bl[u], out[u][op + o]);
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) out[u][op + o] = MFMA32(l[o], bh[u], out[u][op + o]);
+    for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(l[o], bh, out[op + o]);
     FB_FENCE();
   }
 }
 
-// dgrad for the wave's two units: out[u][k] = sum_j W[j][k] dp[u][j]; A = W^T via the transposing LDS read
+// dgrad of the wave's unit: out[k] = sum_j W[j][k] dp[j]; A = W^T via the transposing LDS read; dp arrives split
 __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
-                                               const f32x4 (&dp)[UPW][8], f32x4 (&out)[UPW][8], int r, int q) {
+                                               const bf16x4 (&ih)[8], const bf16x4 (&il)[8], f32x4 (&out)[8], int r,
+                                               int q) {
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-    for (int u = 0; u < UPW; ++u) out[u][kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int kb = 0; kb < 8; ++kb) out[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   // lane i of 16-lane group q points at W[j0 + i/4][16*kb + 4*(i%4)], j0 = 32m + 4q (+16): after the transpose
   // lane k' holds W[j0 .. j0+3][16*kb + k']
-  const int toff = (4 * q + (r >> 2)) * LDB + 8 * (r & 3);
+  // (rows j0 + r/4 with j0 = 32m + 4q (+16): swizzle 4*(r>>2) + SL[q]; logical chunk 4*kk + (r&3), kk = kb/2)
+  r |= fb_opaque0();
+  const int toff = (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q));
   const __bf16* ah = Wh + toff;
   const __bf16* al = Wl + toff;
-  bf16x8 wh[3][2], wl[3][2];
-  auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
-    const int m = g >> 2, kp = (g & 3) * 2;
+  int xk[4];
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int off = 32 * m * LDB + 32 * ((kp + o) >> 1) + 4 * ((kp + o) & 1);
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = 32 * (kk ^ (r >> 2));
+  bf16x8 wh[FB_DGD + 1][FB_GB], wl[FB_DGD + 1][FB_GB];      // operands FB_DGD groups ahead (transposing reads are slow)
+  auto load = [&](int g, bf16x8 (&h)[FB_GB], bf16x8 (&l)[FB_GB]) {
+    const int m = g / FB_GPM, kp = (g % FB_GPM) * FB_GB;
+#pragma unroll
+    for (int o = 0; o < FB_GB; ++o) {
+      const int off = 32 * m * LDB + xk[(kp + o) >> 1] + 4 * ((kp + o) & 1);
       h[o] = fb_cat(fb_tr(ah + off), fb_tr(ah + off + 16 * LDB));
       l[o] = fb_cat(fb_tr(al + off), fb_tr(al + off + 16 * LDB));
     }
   };
-  load(0, wh[0], wl[0]);
-  load(1, wh[1], wl[1]);
-  bf16x8 bh[UPW], bl[UPW];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int m = g >> 2, kp = (g & 3) * 2;
-    if (g + 2 < 16) load(g + 2, wh[(g + 2) % 3], wl[(g + 2) % 3]);
+  for (int g = 0; g < FB_DGD; ++g) load(g, wh[g], wl[g]);
+#pragma unroll
+  for (int g = 0; g < 4 * FB_GPM; ++g) {
+    const int m = g / FB_GPM, kp = (g % FB_GPM) * FB_GB;
+    if (g + FB_DGD < 4 * FB_GPM) load(g + FB_DGD, wh[(g + FB_DGD) % (FB_DGD + 1)], wl[(g + FB_DGD) % (FB_DGD + 1)]);
     FB_FENCE();
-    if ((g & 3) == 0) {
+    const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]), bl = fb_cat(il[2 * m], il[2 * m + 1]);
+    const bf16x8(&h)[FB_GB] = wh[g % (FB_DGD + 1)];
+    const bf16x8(&l)[FB_GB] = wl[g % (FB_DGD + 1)];
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) fb_split8(dp[u][2 * m], dp[u][2 * m + 1], bh[u], bl[u]);
-    }
-    const bf16x8(&h)[2] = wh[g % 3];
-    const bf16x8(&l)[2] = wl[g % 3];
+    for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(h[o], bh, out[kp + o]);
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(h[o], bl, out[kp + o]);
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) out[u][kp + o] = MFMA32(h[o], bh[u], out[u][kp + o]);
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) out[u][kp + o] = MFMA32(h[o], bl[u], out[u][kp + o]);
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) out[u][kp + o] = MFMA32(l[o], bh[u], out[u][kp + o]);
+    for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(l[o], bh, out[kp + o]);
     FB_FENCE();
   }
 }
@@ -228,71 +267,94 @@ __device__ __forceinline__ void fb_mul_dtanh(f32x4 (&out)[8], const f32x4 (&h)[8
     for (int i = 0; i < 4; ++i) out[kb][i] *= 1.0f - h[kb][i] * h[kb][i];
 }
 
-// rows of one unit -> (hi, lo) bf16 in registers, done by every wave BEFORE the exchange loop so that the
-// owner's turn inside the loop is only 16 ds_write_b64 (the other waves wait at the barrier meanwhile)
+// a unit's rows -> (hi, lo) bf16 per C/D block
 __device__ __forceinline__ void fb_presplit(const f32x4 (&v)[8], bf16x4 (&h)[8], bf16x4 (&l)[8]) {
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { __bf16 a, b; fb_split(v[jb][i], a, b); h[jb][i] = a; l[jb][i] = b; }
 }
+__device__ __forceinline__ void fb_zero8(bf16x4 (&h)[8], bf16x4 (&l)[8]) {
+  const short4_ z = {0, 0, 0, 0};
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) { h[jb] = __builtin_bit_cast(bf16x4, z); l[jb] = __builtin_bit_cast(bf16x4, z); }
+}
+// the wave's 16 rows (row = 16 * wave + r) of one staged tensor: hi and lo arrays, row-major [64][LDS2].  Inside
+// every 16-column block the four 8-byte pieces are XOR-swizzled by (row>>2)&3: ds_write_b64 is banked mod 32 and
+// serviced 16 lanes (16 rows, one q) at a time, and 72-dword rows alone would put rows r and r+4 on the same banks
+// (4-way); the transposing reads (fb_stage_toff) undo the swizzle and stay conflict-free.
 __device__ __forceinline__ void fb_stage_store(__bf16* __restrict__ sh, __bf16* __restrict__ sl, const bf16x4 (&h)[8],
-                                               const bf16x4 (&l)[8], int r, int q) {
+                                               const bf16x4 (&l)[8], int row, int q) {
+  row |= fb_opaque0();
+  const int e = row * LDS2 + 4 * (q ^ ((row >> 2) & 3));
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
-    *reinterpret_cast<bf16x4*>(sh + r * LDS2 + 16 * jb + 4 * q) = h[jb];
-    *reinterpret_cast<bf16x4*>(sl + r * LDS2 + 16 * jb + 4 * q) = l[jb];
+    *reinterpret_cast<bf16x4*>(sh + e + 16 * jb) = h[jb];
+    *reinterpret_cast<bf16x4*>(sl + e + 16 * jb) = l[jb];
   }
 }
+// lane offset of the transposing read of staged rows R0 + 4q .. 4q+3 (R0 a multiple of 16), columns 16*blk ..
+__device__ __forceinline__ int fb_stage_toff(int r, int q) { return (4 * q + (r >> 2)) * LDS2 + 4 * ((r & 3) ^ q); }
 
-// wgrad for the wave's two 16-row slices (rows 16*(2*wave + s) ..) over the staged unit's 16 rows:
+// wgrad of the wave's two 16-row slices (rows 16*(2*wave + s) ..) over the staged tile's 64 rows:
 //   dW[j][k] += sum_rows dpre[row][j] h[row][k];   db[j] += sum_rows dpre[row][j]  (MFMA against ones)
-__device__ __forceinline__ void fb_wgrad_consume(const __bf16* sah, const __bf16* sal, const __bf16* sbh,
-                                                 const __bf16* sbl, f32x4 (&accW)[2][8], f32x4 (&accB)[2], int wave,
-                                                 int r, int q) {
-  const int toff = (4 * q + (r >> 2)) * LDS2 + 4 * (r & 3);
-  short4_ a_h[2], a_l[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    a_h[s] = __builtin_bit_cast(short4_, fb_tr(sah + toff + 16 * (2 * wave + s)));
-    a_l[s] = __builtin_bit_cast(short4_, fb_tr(sal + toff + 16 * (2 * wave + s)));
-  }
+// k-step ks contracts rows 32ks .. 32ks+31: lane group q feeds rows 32ks + {4q..4q+3, 16+4q..16+4q+3} of BOTH
+// operands (two transposing reads each), which is all the contraction needs.
+__device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)[2][8], f32x4 (&accB)[2], int wave,
+                                                 int r, int q, int ksteps) {
+  const __bf16* sah = st;
+  const __bf16* sal = st + ST_ARR;
+  const __bf16* sbh = st + 2 * ST_ARR;
+  const __bf16* sbl = st + 3 * ST_ARR;
+  const int toff = fb_stage_toff(r | fb_opaque0(), q);
   const short one = 0x3f80;                           // bf16 1.0
-  const short4_ ones = {one, one, one, one};
-  short4_ bh[2][2], bl[2][2];
-  auto load = [&](int kp, short4_ (&h)[2], short4_ (&l)[2]) {
+  const short8_ ones_s = {one, one, one, one, one, one, one, one};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int koff = toff + 32 * ks * LDS2;
+    bf16x8 a_h[2], a_l[2];
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      h[o] = __builtin_bit_cast(short4_, fb_tr(sbh + toff + 16 * (kp + o)));
-      l[o] = __builtin_bit_cast(short4_, fb_tr(sbl + toff + 16 * (kp + o)));
+    for (int s = 0; s < 2; ++s) {
+      const int off = koff + 16 * (2 * wave + s);
+      a_h[s] = fb_cat(fb_tr(sah + off), fb_tr(sah + off + 16 * LDS2));
+      a_l[s] = fb_cat(fb_tr(sal + off), fb_tr(sal + off + 16 * LDS2));
     }
-  };
-  load(0, bh[0], bl[0]);
+    bf16x8 bh[2][2], bl[2][2];
+    auto load = [&](int kp, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    accB[s] = MFMA16(a_h[s], ones, accB[s]);
-    accB[s] = MFMA16(a_l[s], ones, accB[s]);
-  }
+      for (int o = 0; o < 2; ++o) {
+        const int off = koff + 16 * (kp + o);
+        h[o] = fb_cat(fb_tr(sbh + off), fb_tr(sbh + off + 16 * LDS2));
+        l[o] = fb_cat(fb_tr(sbl + off), fb_tr(sbl + off + 16 * LDS2));
+      }
+    };
+    load(0, bh[0], bl[0]);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int kp = 2 * g;
-    if (g + 1 < 4) load(kp + 2, bh[(g + 1) & 1], bl[(g + 1) & 1]);
-    FB_FENCE();
-    const short4_(&h)[2] = bh[g & 1];
-    const short4_(&l)[2] = bl[g & 1];
+    for (int s = 0; s < 2; ++s) {
+      accB[s] = MFMA32(a_h[s], ones, accB[s]);
+      accB[s] = MFMA32(a_l[s], ones, accB[s]);
+    }
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int g = 0; g < 4; ++g) {
+      const int kp = 2 * g;
+      if (g + 1 < 4) load(kp + 2, bh[(g + 1) & 1], bl[(g + 1) & 1]);
+      FB_FENCE();
+      const bf16x8(&h)[2] = bh[g & 1];
+      const bf16x8(&l)[2] = bl[g & 1];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA16(a_h[s], h[o], accW[s][kp + o]);
+      for (int o = 0; o < 2; ++o)
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+        for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_h[s], h[o], accW[s][kp + o]);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA16(a_h[s], l[o], accW[s][kp + o]);
+      for (int o = 0; o < 2; ++o)
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+        for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_h[s], l[o], accW[s][kp + o]);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA16(a_l[s], h[o], accW[s][kp + o]);
-    FB_FENCE();
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_l[s], h[o], accW[s][kp + o]);
+      FB_FENCE();
+    }
   }
 }
 
@@ -323,29 +385,16 @@ __device__ long long fb_trace[256];
       fb_trace[tile_no * 16 + (k)] = (long long)__builtin_readcyclecounter();              \
   } while (0)
 
-template <bool GRADS>
-__global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f) {
-  extern __shared__ __attribute__((aligned(16))) char smb[];
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = blockIdx.x, G = gridDim.x;
-  __bf16* W1h = reinterpret_cast<__bf16*>(smb + BO_W1H);
-  __bf16* W1l = reinterpret_cast<__bf16*>(smb + BO_W1L);
-  __bf16* W2h = reinterpret_cast<__bf16*>(smb + BO_W2H);
-  __bf16* W2l = reinterpret_cast<__bf16*>(smb + BO_W2L);
-  __bf16* sAh = reinterpret_cast<__bf16*>(smb + BO_SAH);
-  __bf16* sAl = reinterpret_cast<__bf16*>(smb + BO_SAL);
-  __bf16* sBh = reinterpret_cast<__bf16*>(smb + BO_SBH);
-  __bf16* sBl = reinterpret_cast<__bf16*>(smb + BO_SBL);
-  float* vec = reinterpret_cast<float*>(smb + BO_VEC);
-  float* info = reinterpret_cast<float*>(smb + BO_INFO);
-  float* red = reinterpret_cast<float*>(smb + BO_RED);
-
-  // ---- split the weights into bf16 hi / lo LDS images (once per kernel) ----
-  for (int idx = tid; idx < FD_H * (FD_H / 4); idx += FB_THREADS) {
-    const int row = idx >> 5, c4 = idx & 31;
-    const f32x4 w1 = reinterpret_cast<const f32x4*>(f.W1)[idx];
-    const f32x4 w2 = reinterpret_cast<const f32x4*>(f.W2)[idx];
+// once per step: the hidden layers' weights as bf16 hi / lo images in the kernel's LDS layout (W1h W1l W2h W2l,
+// row-major [128][128], columns permuted by fb_pcol, chunks swizzled by fb_swz), and the zero fill of the dL/d(hz) partial-sum slots
+__global__ __launch_bounds__(256) void pv_fb_prep_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                         __bf16* __restrict__ img, float* __restrict__ zero,
+                                                         int64_t nzero4) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, T = (int64_t)gridDim.x * 256;
+  for (int64_t idx = t; idx < FD_H * (FD_H / 4); idx += T) {
+    const int row = (int)(idx >> 5), c4 = (int)(idx & 31);
+    const f32x4 w1 = reinterpret_cast<const f32x4*>(W1)[idx];
+    const f32x4 w2 = reinterpret_cast<const f32x4*>(W2)[idx];
     bf16x4 h1, l1, h2, l2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -353,12 +402,36 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_split(w1[i], a, b); h1[i] = a; l1[i] = b;
       fb_split(w2[i], a, b); h2[i] = a; l2[i] = b;
     }
-    const int pc = fb_pcol(4 * c4);
-    *reinterpret_cast<bf16x4*>(W1h + row * LDB + pc) = h1;
-    *reinterpret_cast<bf16x4*>(W1l + row * LDB + pc) = l1;
-    *reinterpret_cast<bf16x4*>(W2h + row * LDB + pc) = h2;
-    *reinterpret_cast<bf16x4*>(W2l + row * LDB + pc) = l2;
+    const int e = fb_wel(row, fb_pcol(4 * c4));
+    *reinterpret_cast<bf16x4*>(img + e) = h1;
+    *reinterpret_cast<bf16x4*>(img + W_IMG + e) = l1;
+    *reinterpret_cast<bf16x4*>(img + 2 * W_IMG + e) = h2;
+    *reinterpret_cast<bf16x4*>(img + 3 * W_IMG + e) = l2;
   }
+  for (int64_t idx = t; idx < nzero4; idx += T) reinterpret_cast<f32x4*>(zero)[idx] = f32x4{0, 0, 0, 0};
+}
+
+template <bool GRADS>
+__global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f) {
+  extern __shared__ __attribute__((aligned(16))) char smb[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x, G = gridDim.x;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smb);
+  const __bf16* W1h = reinterpret_cast<const __bf16*>(smb + BO_R1);
+  const __bf16* W1l = W1h + W_IMG;
+  const __bf16* W2h = reinterpret_cast<const __bf16*>(smb + BO_R2);
+  const __bf16* W2l = W2h + W_IMG;
+  __bf16* st2 = reinterpret_cast<__bf16*>(smb + BO_R1);       // wgrad-2 staging: over W1 (+ gap)
+  __bf16* st1 = reinterpret_cast<__bf16*>(smb + BO_GAP);      // wgrad-1 staging: over (gap +) W2
+  float* vec = reinterpret_cast<float*>(smb + BO_VEC);
+  float* info = reinterpret_cast<float*>(smb + BO_INFO);
+  float* red = reinterpret_cast<float*>(smb + BO_RED);
+  const char* gimg = reinterpret_cast<const char*>(f.wimg);
+
+  // ---- weight images by LDS-DMA, fp32 vectors by hand ----
+  fb_reload(gimg, lds0 + BO_R1, wave, lane);
+  fb_reload(gimg + 2 * IMG_BYTES, lds0 + BO_R2, wave, lane);
   for (int j = tid; j < FD_H; j += FB_THREADS) {
     vec[j] = f.Wc[j * f.cd];
     vec[FD_H + j] = f.cd == 2 ? f.Wc[j * 2 + 1] : 0.0f;
@@ -367,6 +440,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     vec[4 * FD_H + j] = f.b1[j];
     vec[5 * FD_H + j] = f.b2[j];
   }
+  fb_wait_vm0();
   __syncthreads();
   const float bo = f.bo[0];
 
@@ -379,14 +453,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) { accW1[s][kb] = f32x4{0, 0, 0, 0}; accW2[s][kb] = f32x4{0, 0, 0, 0}; }
   }
-  float aWc0[2] = {0.0f, 0.0f}, aWc1[2] = {0.0f, 0.0f}, ahz[2] = {0.0f, 0.0f}, dbo = 0.0f;
+  // coordinate layer: column 0 = sum over the current sample's rows of dpre0 (= dL/d(hz[b]), flushed per sample),
+  // column 1 / 2 = sums of dpre0 * x'_0 / x'_1 (dWc), for rows 16*(2*wave + s) + 4q + i
+  f32x4 accC[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+  float dbo = 0.0f;
   int cur_b = -1;
   const int upb = f.N / FD_UNIT;
   float* rec = f.part + (int64_t)g * FD_REC;
-  // this wave's private d(wo) slots in the record's tail (slot `wave` for its first unit, `4 + wave` for its
-  // second): written and re-read only by lanes (r == 0, q) — one thread per address, so plain same-thread
-  // ordering suffices
-  float* dwo_g = reinterpret_cast<float*>(smb + BO_DWO) + wave * FD_H;     // this wave's LDS slot
+  // this wave's private d(wo) slot in LDS: written and re-read only by lanes (r == 0, q) — one thread per
+  // address, so plain same-thread ordering suffices
+  float* dwo_g = reinterpret_cast<float*>(smb + BO_DWO) + wave * FD_H;
   if (r == 0) {
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<f32x4*>(dwo_g + 16 * jb + 4 * q) = f32x4{0, 0, 0, 0};
@@ -396,15 +472,40 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     // sample b's rows end (or the workgroup's do): publish this workgroup's partial dL/d(hz[b])
     const int64_t ub = (int64_t)b * upb;
     const int gfirst = (int)(((ub + 1) * G + f.units - 1) / f.units) - 1;
+    if (r == 0) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const float t = fb_sum_q(ahz[s]);
-      if (q == 0) f.part_hz[((int64_t)b * f.kmax + (g - gfirst)) * FD_H + 16 * (2 * wave + s) + r] = t;
-      ahz[s] = 0.0f;
+      for (int s = 0; s < 2; ++s) {
+        *reinterpret_cast<f32x4*>(f.part_hz + ((int64_t)b * f.kmax + (g - gfirst)) * FD_H + 16 * (2 * wave + s) + 4 * q) =
+            accC[s];
+        accC[s] = f32x4{0, 0, 0, 0};
+      }
     }
   };
 
   const int64_t u_lo = (int64_t)g * f.units / G, u_hi = (int64_t)(g + 1) * f.units / G;
+  // the wave's observations are fetched one tile ahead (an HBM miss, and loads retire in order: fetched in the
+  // tile itself it would hold up the coordinate layer's own small loads)
+  auto x_of_tile = [&](int64_t ut_) -> float {
+    const int64_t un = ut_ + wave;
+    return f.x[(un < u_hi ? un : u_lo) * FD_UNIT + r];
+  };
+  float xv_next = x_of_tile(u_lo);
+  // ... and so are its other per-unit inputs (hz[b], tp[b], the unit's grid rows), by LDS-DMA into the wave's own
+  // slots: the coordinate layer then starts from LDS instead of waiting ~1.5k cycles on dependent global loads
+  float* chz = reinterpret_cast<float*>(smb + BO_CHZ) + wave * FD_H;
+  float* ctp = reinterpret_cast<float*>(smb + BO_CTP) + wave * 64;
+  float* cgr = reinterpret_cast<float*>(smb + BO_CGR) + wave * 64;
+  auto fetch_unit_inputs = [&](int64_t ut_) {
+    const int64_t un = ut_ + wave;
+    const int unit_ = (int)(un < u_hi ? un : u_lo);
+    const int b_ = unit_ / upb;
+    const int n0 = (unit_ - b_ * upb) * FD_UNIT;
+    fb_glds4(f.hz + (int64_t)b_ * FD_H + lane, lds0 + BO_CHZ + wave * (FD_H * 4));
+    fb_glds4(f.hz + (int64_t)b_ * FD_H + 64 + lane, lds0 + BO_CHZ + wave * (FD_H * 4) + 256);
+    fb_glds4(f.tp + (int64_t)b_ * 8 + (lane & 7), lds0 + BO_CTP + wave * 256);
+    fb_glds4(f.grid + (int64_t)n0 * f.cd + (lane & (16 * f.cd - 1)), lds0 + BO_CGR + wave * 256);
+  };
+  fetch_unit_inputs(u_lo);
   int tile_no = -1;
   for (int64_t ut = u_lo; ut < u_hi; ut += TILE_UNITS) {
     ++tile_no;
@@ -419,226 +520,254 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     const float* b1s = vec + 4 * FD_H + opq;
     const float* b2s = vec + 5 * FD_H + opq;
 
-    // per-unit row bookkeeping; an inactive unit (partial last tile) re-reads the tile's first unit and has its
-    // dL/dlogit forced to zero, so everything it would contribute vanishes
-    bool act[UPW];
-    int bu[UPW];
-    int64_t row[UPW];
-    float x0[UPW], x1[UPW], u0c[UPW], u1c[UPW], sc[UPW];
-    const float* hzb[UPW];
-    f32x4 tA[UPW][8], tB[UPW][8], tC[UPW][8];
-#pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-      act[u] = UPW * wave + u < nact;
-      const int unit = (int)ut + (act[u] ? UPW * wave + u : 0);
-      bu[u] = unit / upb;
-      const int n = (unit - bu[u] * upb) * FD_UNIT + r;
-      row[u] = (int64_t)unit * FD_UNIT + r;
-      const float* t = f.tp + (int64_t)bu[u] * 8;
+    // the wave's unit; an inactive wave (partial last tile) computes nothing and stages zeros
+    const bool act = wave < nact;
+    const int unit = (int)ut + (act ? wave : 0);
+    const int bu = unit / upb;
+    const int64_t row = (int64_t)unit * FD_UNIT + r;
+    float x0, x1, u0c, u1c, sc;
+    fb_wait_vm0();                        // this wave's LDS-DMA of the tile's inputs (issued a tile ago)
+    {
+      const float* t = ctp + opq;
+      const float* gr = cgr + opq;
       if (f.cd == 2) {
-        const float gx = f.grid[2 * n], gy = f.grid[2 * n + 1];
-        u0c[u] = gx * t[0] - gy * t[1];
-        u1c[u] = gx * t[1] + gy * t[0];
-        sc[u] = t[2];
-        x0[u] = u0c[u] * sc[u] + t[3];
-        x1[u] = u1c[u] * sc[u] + t[4];
+        const float gx = gr[2 * r], gy = gr[2 * r + 1];
+        u0c = gx * t[0] - gy * t[1];
+        u1c = gx * t[1] + gy * t[0];
+        sc = t[2];
+        x0 = u0c * sc + t[3];
+        x1 = u1c * sc + t[4];
       } else {
-        u0c[u] = f.grid[n]; u1c[u] = 0.0f; sc[u] = 1.0f;
-        x0[u] = u0c[u] + t[3]; x1[u] = 0.0f;
+        u0c = gr[r]; u1c = 0.0f; sc = 1.0f;
+        x0 = u0c + t[3]; x1 = 0.0f;
       }
-      hzb[u] = f.hz + (int64_t)bu[u] * FD_H;
     }
-    auto coord_layer = [&](f32x4 (&h0)[8], int u) {
+    const float* hzb = chz + opq;
+    const float xv = xv_next;
+
+    f32x4 h0[8], tA[8], tB[8], tC[8];
+    bf16x4 pAh[8], pAl[8], pBh[8], pBl[8];
+    if (act) {
+      // ---- coordinate layer (fp32): h0 = tanh(Wc x' + bc + hz[b]) ----
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) {
         const int j = 16 * jb + 4 * q;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc0 + j);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc1 + j);
         const f32x4 bc = *reinterpret_cast<const f32x4*>(bcs + j);
-        const f32x4 hz = *reinterpret_cast<const f32x4*>(hzb[u] + j);
+        const f32x4 hz = *reinterpret_cast<const f32x4*>(hzb + j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h0[jb][i] = fb_tanh(w0[i] * x0[u] + w1[i] * x1[u] + bc[i] + hz[i]);
+        for (int i = 0; i < 4; ++i) h0[jb][i] = fb_tanh(w0[i] * x0 + w1[i] * x1 + bc[i] + hz[i]);
       }
-    };
-
-    const bool wave_active = UPW * wave < nact;
-    if (wave_active) {
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) coord_layer(tA[u], u);          // tA = h0
-      FB_STAMP(1);
-      fb_layer_fwd(W1h, W1l, b1s, tA, tB, r, q);
-      FB_STAMP(2);
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) fb_tanh8(tB[u]);                // tB = h1
-      fb_layer_fwd(W2h, W2l, b2s, tB, tC, r, q);
-      FB_STAMP(3);
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) fb_tanh8(tC[u]);                // tC = h2
+      fb_presplit(h0, pBh, pBl);
+    }
+    FB_STAMP(1);
+    fetch_unit_inputs(ut + TILE_UNITS);          // the slots were consumed by the coordinate layer above
+    if (GRADS && tile_no > 0) {
+      // W2's images were the previous tile's staging area: bring them back under the forward of layer 1.
+      // (every compiler-visible load above has been consumed; none is issued before the barrier below)
+      fb_wait_vm0();
+      fb_reload(gimg + 2 * IMG_BYTES, lds0 + BO_R2, wave, lane);
+    }
+    if (act) {
+      fb_layer_fwd(W1h, W1l, b1s, pBh, pBl, tB, r, q);
+      fb_tanh8(tB);                                              // tB = h1
+      fb_presplit(tB, pBh, pBl);                                 // feeds layer 2 and its wgrad
+    }
+    FB_STAMP(2);
+    if (GRADS) {
+      fb_wait_vm0();
+      __syncthreads();      // W2 landed everywhere; every wave is past its reads of W1 (staging may overwrite it)
+    }
+    FB_STAMP(3);
+    float dlda = 0.0f;
+    if (act) {
+      fb_layer_fwd(W2h, W2l, b2s, pBh, pBl, tC, r, q);
+      fb_tanh8(tC);                                              // tC = h2
       // ---- output layer + likelihood (fp32) ----
+      float part = 0.0f;
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) {
-        float part = 0.0f;
+      for (int jb = 0; jb < 8; ++jb) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * jb + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += tC[jb][i] * wv[i];
+      }
+      const float a = fb_sum_q(part) + bo;
+      float ll, locv;
+      if (f.lik == PV_LIK_BERNOULLI) {
+        const float pr = fb_rcp(1.0f + fb_exp(-a));
+        const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
+        const float lg = fb_log(pc) - fb_log(1.0f - pc);
+        ll = -(fmaxf(lg, 0.0f) - lg * xv + fb_log(1.0f + fb_exp(-fabsf(lg))));
+        const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
+        dlda = (fb_rcp(1.0f + fb_exp(-lg)) - xv) * mask;
+        locv = pr;
+      } else {
+        const float pr = f.sigmoid_out ? fb_rcp(1.0f + fb_exp(-a)) : a;
+        const float d = xv - pr;
+        ll = -(d * d) / (2.0f * f.sig * f.sig) - fb_log(f.sig) - LOG_SQRT_2PI;
+        dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+        locv = pr;
+      }
+      if (q == 0) {
+        f.llrow[row] = ll;
+        if (f.loc) f.loc[row] = locv;
+      }
+      xv_next = x_of_tile(ut + TILE_UNITS);     // lands long before the next LDS-DMA issue point drains loads
+      if (GRADS) {
+        if (q == 0) dbo += dlda;
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+          f32x4 tv;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tv[i] = fb_sum_r(dlda * tC[jb][i]);
+          if (r == 0) {
+            f32x4* p = reinterpret_cast<f32x4*>(dwo_g + 16 * jb + 4 * q);
+            *p = *p + tv;
+          }
+        }
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * jb + 4 * q);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part += tC[u][jb][i] * wv[i];
+          for (int i = 0; i < 4; ++i) tC[jb][i] = dlda * wv[i] * (1.0f - tC[jb][i] * tC[jb][i]);  // dpre2
         }
-        const float a = fb_sum_q(part) + bo;
-        const float xv = f.x[row[u]];
-        float ll, dlda, locv;
-        if (f.lik == PV_LIK_BERNOULLI) {
-          const float pr = fb_rcp(1.0f + fb_exp(-a));
-          const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
-          const float lg = fb_log(pc) - fb_log(1.0f - pc);
-          ll = -(fmaxf(lg, 0.0f) - lg * xv + fb_log(1.0f + fb_exp(-fabsf(lg))));
-          const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
-          dlda = (fb_rcp(1.0f + fb_exp(-lg)) - xv) * mask;
-          locv = pr;
-        } else {
-          const float pr = f.sigmoid_out ? fb_rcp(1.0f + fb_exp(-a)) : a;
-          const float d = xv - pr;
-          ll = -(d * d) / (2.0f * f.sig * f.sig) - fb_log(f.sig) - LOG_SQRT_2PI;
-          dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
-          locv = pr;
-        }
-        if (!act[u]) dlda = 0.0f;
-        if (q == 0 && act[u]) {
-          f.llrow[row[u]] = ll;
-          if (f.loc) f.loc[row[u]] = locv;
-        }
-        if (GRADS) {
-          if (q == 0) dbo += dlda;
-          float* dwo = dwo_g;
-#pragma unroll
-          for (int jb = 0; jb < 8; ++jb) {
-            f32x4 tv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tv[i] = fb_sum_r(dlda * tC[u][jb][i]);
-            if (r == 0) {
-              f32x4* p = reinterpret_cast<f32x4*>(dwo + 16 * jb + 4 * q);
-              *p = *p + tv;
-            }
-          }
-#pragma unroll
-          for (int jb = 0; jb < 8; ++jb) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * jb + 4 * q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tC[u][jb][i] = dlda * wv[i] * (1.0f - tC[u][jb][i] * tC[u][jb][i]);  // dpre2
-          }
-        }
+        fb_presplit(tC, pAh, pAl);                               // feeds the wgrad and the dgrad of layer 2
       }
     }
     FB_STAMP(4);
     if (!GRADS) continue;
+    if (!act) { fb_zero8(pAh, pAl); fb_zero8(pBh, pBl); }
+    const int ksteps = nact > 2 ? 2 : 1;          // rows 32.. are only staged (as zeros or not) when a unit owns them
 
-    // ---- wgrad of layer 2: exchange (dpre2 = tC, h1 = tB) one unit at a time ----
-    bf16x4 pAh[UPW][8], pAl[UPW][8], pBh[UPW][8], pBl[UPW][8];
-    if (wave_active) {
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) { fb_presplit(tC[u], pAh[u], pAl[u]); fb_presplit(tB[u], pBh[u], pBl[u]); }
-    }
+    // ---- wgrad of layer 2: stage (dpre2, h1) of all 64 rows over W1's images, one pass ----
+    fb_stage_store(st2, st2 + ST_ARR, pAh, pAl, 16 * wave + r, q);
+    fb_stage_store(st2 + 2 * ST_ARR, st2 + 3 * ST_ARR, pBh, pBl, 16 * wave + r, q);
+    __syncthreads();
     FB_STAMP(5);
-    for (int c = 0; c < nact; ++c) {
-#pragma unroll
-      for (int u = 0; u < UPW; ++u)
-        if (c == UPW * wave + u) {
-          fb_stage_store(sAh, sAl, pAh[u], pAl[u], r, q);
-          fb_stage_store(sBh, sBl, pBh[u], pBl[u], r, q);
-        }
-      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[128 + 4 * c] = (long long)__builtin_readcyclecounter();
-      __syncthreads();
-      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[129 + 4 * c] = (long long)__builtin_readcyclecounter();
-      fb_wgrad_consume(sAh, sAl, sBh, sBl, accW2, accB2, wave, r, q);
-      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[130 + 4 * c] = (long long)__builtin_readcyclecounter();
-      __syncthreads();
-      if ((f.ablate & 512) && g == 0 && tid == 0 && tile_no == 1) fb_trace[131 + 4 * c] = (long long)__builtin_readcyclecounter();
-    }
+    fb_wgrad_consume(st2, accW2, accB2, wave, r, q, ksteps);
+    __syncthreads();
     FB_STAMP(6);
-    if (wave_active) {
-      fb_layer_dgrad(W2h, W2l, tC, tA, r, q);
-      FB_STAMP(7);
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) {
-        fb_mul_dtanh(tA[u], tB[u]);                        // tA = dpre1
-        coord_layer(tB[u], u);                             // tB = h0 (recomputed)
-      }
-      fb_layer_dgrad(W1h, W1l, tA, tC, r, q);
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) fb_mul_dtanh(tC[u], tB[u]);   // tC = dpre0
+    fb_wait_vm0();                                   // (stores only: nothing the compiler still waits for)
+    fb_reload(gimg, lds0 + BO_R1, wave, lane);       // W1 comes back under the dgrad of layer 2
+    if (act) {
+      fb_layer_dgrad(W2h, W2l, pAh, pAl, tA, r, q);
+      fb_mul_dtanh(tA, tB);                                      // tA = dpre1
+      fb_presplit(tA, pAh, pAl);                                 // feeds the dgrad and the wgrad of layer 1
     }
+    FB_STAMP(7);
+    fb_wait_vm0();
+    __syncthreads();        // W1 landed everywhere; every wave is past its reads of W2
     FB_STAMP(8);
-    // ---- wgrad of layer 1: exchange (dpre1 = tA, h0 = tB) ----
-    if (wave_active) {
-#pragma unroll
-      for (int u = 0; u < UPW; ++u) { fb_presplit(tA[u], pAh[u], pAl[u]); fb_presplit(tB[u], pBh[u], pBl[u]); }
+    if (act) {
+      fb_layer_dgrad(W1h, W1l, pAh, pAl, tC, r, q);
+      fb_mul_dtanh(tC, h0);                                      // tC = dpre0
+      fb_presplit(h0, pBh, pBl);
     }
-    for (int c = 0; c < nact; ++c) {
-#pragma unroll
-      for (int u = 0; u < UPW; ++u)
-        if (c == UPW * wave + u) {
-          fb_stage_store(sAh, sAl, pAh[u], pAl[u], r, q);
-          fb_stage_store(sBh, sBl, pBh[u], pBl[u], r, q);
-        }
-      __syncthreads();
-      fb_wgrad_consume(sAh, sAl, sBh, sBl, accW1, accB1, wave, r, q);
-      __syncthreads();
-    }
+    FB_STAMP(9);
+    // ---- wgrad of layer 1: stage (dpre1, h0) over W2's images ----
+    fb_stage_store(st1, st1 + ST_ARR, pAh, pAl, 16 * wave + r, q);
+    fb_stage_store(st1 + 2 * ST_ARR, st1 + 3 * ST_ARR, pBh, pBl, 16 * wave + r, q);
+    __syncthreads();
     FB_STAMP(10);
+    fb_wgrad_consume(st1, accW1, accB1, wave, r, q, ksteps);
     // ---- coordinate layer backward (fp32): row-local part ----
-    if (wave_active) {
+    if (act) {
+      float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) {
-        float d0 = 0.0f, d1 = 0.0f;
+      for (int jb = 0; jb < 8; ++jb) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc0 + 16 * jb + 4 * q);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc1 + 16 * jb + 4 * q);
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc0 + 16 * jb + 4 * q);
-          const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc1 + 16 * jb + 4 * q);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { d0 += tC[u][jb][i] * w0[i]; d1 += tC[u][jb][i] * w1[i]; }
-        }
-        d0 = fb_sum_q(d0);
-        d1 = fb_sum_q(d1);
-        if (q == 0 && act[u]) {
-          f.rowtp[row[u]] = sc[u] * (d1 * u0c[u] - d0 * u1c[u]);
-          f.rowtp[f.M + row[u]] = d0 * u0c[u] + d1 * u1c[u];
-          f.rowtp[2 * f.M + row[u]] = d0;
-          f.rowtp[3 * f.M + row[u]] = d1;
-        }
+        for (int i = 0; i < 4; ++i) { d0 += tC[jb][i] * w0[i]; d1 += tC[jb][i] * w1[i]; }
+      }
+      d0 = fb_sum_q(d0);
+      d1 = fb_sum_q(d1);
+      if (q == 0) {
+        f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
+        f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
+        f.rowtp[2 * f.M + row] = d0;
+        f.rowtp[3 * f.M + row] = d1;
       }
     }
-    // ---- cross-row part: dWc, dbc / dhz from dpre0 staged in fp32 over the (now idle) staging images ----
+    __syncthreads();
     FB_STAMP(11);
-    float* st32 = reinterpret_cast<float*>(smb + BO_SAH);      // 16 rows x 136 floats = 8704 B <= 4 x 4352 B
-    for (int c = 0; c < nact; ++c) {
+    // ---- cross-row part: dhz / dWc are wgrads too: [dpre0]^T [1 | x'_0 | x'_1] over the tile's rows.  dpre0 goes
+    // through the staging area's A arrays (split, swizzled); the 16-column B operand is built in registers.
+    if (act) fb_presplit(tC, pAh, pAl);
+    fb_stage_store(st1, st1 + ST_ARR, pAh, pAl, 16 * wave + r, q);
+    if (act) {
+      if (q == 0) { info[16 * wave + r] = x0; info[TILE_ROWS + 16 * wave + r] = x1; }
+      if (lane == 0) reinterpret_cast<int*>(info)[2 * TILE_ROWS + wave] = bu;
+    }
+    __syncthreads();
+    FB_STAMP(12);
+    {
+      const int toff = fb_stage_toff(r | fb_opaque0(), q);
+      bf16x8 a_h[2][2], a_l[2][2];
 #pragma unroll
-      for (int u = 0; u < UPW; ++u)
-        if (c == UPW * wave + u) {
-#pragma unroll
-          for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<f32x4*>(st32 + r * LDB + 16 * jb + 4 * q) = tC[u][jb];
-          if (q == 0) { info[r] = x0[u]; info[16 + r] = x1[u]; }
-          if (lane == 0) reinterpret_cast<int*>(info)[32] = bu[u];
-        }
-      __syncthreads();
-      const int bcur = reinterpret_cast<const int*>(info)[32];
-      if (bcur != cur_b) {
-        if (cur_b >= 0) flush_hz(cur_b);
-        cur_b = bcur;
-      }
-#pragma unroll
-      for (int sgm = 0; sgm < 4; ++sgm) {
-        const float xa = info[4 * sgm + q], xb = info[16 + 4 * sgm + q];
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const float v = st32[(4 * sgm + q) * LDB + 16 * (2 * wave + s) + r];
-          ahz[s] += v;
-          aWc0[s] += v * xa;
-          aWc1[s] += v * xb;
+          const int off = toff + 32 * ks * LDS2 + 16 * (2 * wave + s);
+          a_h[ks][s] = fb_cat(fb_tr(st1 + off), fb_tr(st1 + off + 16 * LDS2));
+          a_l[ks][s] = fb_cat(fb_tr(st1 + ST_ARR + off), fb_tr(st1 + ST_ARR + off + 16 * LDS2));
         }
+      // lane (column c = r, q) feeds rows 32ks + {4q.., 16+4q..}: c = 0 -> 1, c = 1 -> x'_0, c = 2 -> x'_1, else 0
+      f32x4 cv[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int rr = 32 * ks + 16 * hf + 4 * q;
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(info + rr);
+          const f32x4 xb = *reinterpret_cast<const f32x4*>(info + TILE_ROWS + rr);
+          const f32x4 one4 = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+          cv[ks][hf] = r == 0 ? one4 : r == 1 ? xa : r == 2 ? xb : zero4;
+        }
+      // one pass per run of units that belong to the same sample (one run unless a sample ends inside the tile)
+      const int4_ bus = *reinterpret_cast<const int4_*>(reinterpret_cast<const int*>(info) + 2 * TILE_ROWS);
+      int bs[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bs[c] = __builtin_amdgcn_readfirstlane(bus[c]);
+      int c0 = 0;
+      while (c0 < nact) {
+        const int bseg = bs[0] * (c0 == 0) + bs[1] * (c0 == 1) + bs[2] * (c0 == 2) + bs[3] * (c0 == 3);
+        int c1 = c0 + 1;
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+          if (c == c1 && c < nact && bs[c] == bseg) ++c1;
+        if (bseg != cur_b) {
+          if (cur_b >= 0) flush_hz(cur_b);
+          cur_b = bseg;
+        }
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bool in0 = 2 * ks >= c0 && 2 * ks < c1, in1 = 2 * ks + 1 >= c0 && 2 * ks + 1 < c1;
+          fb_split8(in0 ? cv[ks][0] : zero4, in1 ? cv[ks][1] : zero4, bh[ks], bl[ks]);
+        }
+        f32x4 t[2][2];                               // four independent chains; rows outside the run are zero in B
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) t[ks][s] = MFMA32(a_h[ks][s], bh[ks], zero4);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) t[ks][s] = MFMA32(a_h[ks][s], bl[ks], t[ks][s]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) t[ks][s] = MFMA32(a_l[ks][s], bh[ks], t[ks][s]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) accC[s] += t[0][s] + t[1][s];
+        c0 = c1;
       }
-      __syncthreads();
     }
-    FB_STAMP(12);
+    __syncthreads();        // the staging area is free again (the next tile's W2 reload lands here)
+    FB_STAMP(13);
   }
   if (!GRADS) return;
 
@@ -662,10 +791,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         rec[2 * FD_H * FD_H + FD_H + j0 + 4 * q + i] = accB2[s][i];
       }
     }
-    const float tc0 = fb_sum_q(aWc0[s]), tc1 = fb_sum_q(aWc1[s]);
-    if (q == 0) {
-      rec[2 * FD_H * FD_H + 2 * FD_H + j0 + r] = tc0;
-      rec[2 * FD_H * FD_H + 3 * FD_H + j0 + r] = tc1;
+    if (r == 1 || r == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rec[2 * FD_H * FD_H + (1 + r) * FD_H + j0 + 4 * q + i] = accC[s][i];
     }
   }
   const float tb = pv_wave_sum(dbo);
@@ -688,6 +816,19 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
 extern "C" int pv_debug_read_trace(long long* out, int n) {
   if (n > 256) n = 256;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_trace), n * sizeof(long long));
+}
+
+int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s) {
+  static_assert(FB_WIMG_BYTES == 4 * IMG_BYTES, "pv_sdec_fused.h and the LDS image layout disagree");
+  if (!f.wimg) return PV_EINVAL;
+  const int64_t nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
+  const int64_t work = nzero4 > FD_H * (FD_H / 4) ? nzero4 : FD_H * (FD_H / 4);
+  int blocks = (int)((work + 255) / 256);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(pv_fb_prep_kernel, dim3(blocks), dim3(256), 0, s, f.W1, f.W2, reinterpret_cast<__bf16*>(f.wimg),
+                     f.part_hz, nzero4);
+  PV_LAUNCH_CHECK();
+  return 0;
 }
 
 int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {

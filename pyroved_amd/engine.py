@@ -38,6 +38,8 @@ def _linears(seq: nn.Sequential) -> List[nn.Linear]:
 class IVAEEngine:
     """Binds an iVAE-like model (encoder_z: fcEncoderNet, decoder: sDecoderNet | fcDecoderNet)
     to the HIP library."""
+    supports_scalars_out = True      # loss_and_grads can write the 4 loss scalars to a caller-given device slot
+
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: int = 2):
         self.model = model

@@ -98,11 +98,20 @@ class SVItrainer:
         rank, world = pvdist.world(self.group)
         lo, hi = pvdist.shard_bounds(b, rank, world)
         dev = eng.device
+        if self._hist is None or self._hist.shape[0] <= i:
+            new = torch.zeros(max(64, 2 * (i + 1)), 4, device=dev, dtype=torch.float32)
+            if self._hist is not None:
+                new[:self._hist.shape[0]].copy_(self._hist)
+            self._hist = new
+        direct = world == 1 and getattr(eng, "supports_scalars_out", False)   # single process: the loss lands in the history slot
         if hi > lo:
             xs = x[lo:hi].to(dev, torch.float32)
             es = eps[lo:hi].to(dev, torch.float32)
             ys = None if y is None else y[lo:hi].to(dev, torch.float32)
-            eng.loss_and_grads(xs, es, beta, ys, want_grads=train)
+            if direct:
+                eng.loss_and_grads(xs, es, beta, ys, want_grads=train, scalars_out=self._hist[i])
+            else:
+                eng.loss_and_grads(xs, es, beta, ys, want_grads=train)
         else:                                          # more ranks than samples: contribute zeros
             eng.grad.zero_()
         if world > 1:
@@ -112,12 +121,8 @@ class SVItrainer:
                 pvdist.allreduce_sum_(eng.grad, self.group)
         if train or (self.mirror_evaluate_update and eng.grads_live):
             eng.adam_step()
-        if self._hist is None or self._hist.shape[0] <= i:
-            new = torch.zeros(max(64, 2 * (i + 1)), 4, device=dev, dtype=torch.float32)
-            if self._hist is not None:
-                new[:self._hist.shape[0]].copy_(self._hist)
-            self._hist = new
-        self._hist[i].copy_(eng.scalars)
+        if not direct:
+            self._hist[i].copy_(eng.scalars)
 
     def _epoch(self, loader, train: bool, **kwargs) -> float:
         n = 0

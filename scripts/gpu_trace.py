@@ -16,19 +16,14 @@ torch.cuda.synchronize()
 lib = C.CDLL(_abi.LIB_PATH)
 buf = (C.c_longlong * 64)()
 print("rc", lib.pv_debug_read_trace(buf, 64))
-names = ["start", "coord+loads", "fwd L1", "fwd L2(+tanh)", "tanh+loss+dwo", "presplit", "exch L2", "dgrad L2", "dgrad L1(+h0)", "-", "presplit+exch L1", "rowlocal", "exch 0"]
+names = ["start", "coord+split", "fwd L1+tanh+split", "W2 wait+bar", "fwd L2..lik+dpre2", "stage L2+bar", "wgrad L2+bar",
+         "dgrad L2+split", "W1 wait+bar", "dgrad L1+split", "stage L1+bar", "wgrad L1+rowlocal+bar", "split+stage dpre0+bar",
+         "coord sums (MFMA)+bar"]
 for t in range(4):
-    st = [buf[t * 16 + k] for k in range(13)]
+    st = [buf[t * 16 + k] for k in range(14)]
     if st[0] == 0: continue
     prev = st[0]; out = []
-    for k in range(1, 13):
+    for k in range(1, 14):
         if st[k]:
             out.append("%s=%d" % (names[k], st[k] - prev)); prev = st[k]
     print("tile", t, "total", prev - st[0], " ".join(out))
-if int(os.environ.get("PV_FD_ABLATE", "0")) & 512:
-    buf2 = (C.c_longlong * 160)()
-    lib.pv_debug_read_trace(buf2, 160)
-    base = buf2[128]
-    print("exchange L2 chunks (cycles since first stamp): store_done, after_bar1, after_consume, after_bar2")
-    for c in range(4):
-        print(" chunk", c, [buf2[128 + 4 * c + k] - base for k in range(4)])
