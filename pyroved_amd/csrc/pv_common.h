@@ -79,6 +79,8 @@ int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t
 int pv_gemm_pick_splits(int M, int N, int K);
 // up to 4 independent GEMMs of one operand-layout class in one launch (no split-K, fused epilogues)
 int pv_gemm_multi(const PvGemm* gs, int n, hipStream_t s);
+// up to 4 plain wgrad problems (short contraction, wide output) in one launch, one wave per 16x16 tile (pv_wgrad.hip)
+int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s);
 // out[i] = sum_p part[p*stride + i], p ascending (deterministic)
 int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 int pv_colsum(const float* x, int64_t ldx, int64_t M, int N, float* out, void* ws, int64_t ws_bytes, hipStream_t s);

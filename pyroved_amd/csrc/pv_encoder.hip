@@ -1,11 +1,14 @@
-// pv_encoder.hip — the encoder side of the SVI step as two compact kernels.
+// pv_encoder.hip — the encoder side of the SVI step as three compact kernels.
 //   pv_enc_fwd   fcEncoderNet.forward (nets/fc.py:51-61) + Normal.rsample + log q(z|x) + log p(z) +
 //                _split_latent (ivae.py:179-189, 217-221; base.py:97-119) + fc_latent(z) (fc.py:230)
+//                = pv_enc_l1_kernel (first layer: the wide one, K = n_pix) + pv_enc_fwd_kernel (everything after)
 //   pv_enc_dgrad the dgrad chain head -> hidden layers of the encoder's backward
-// The encoder is < 1 % of the step's FLOPs but, as a chain of tiny dependent GEMMs, it used to be a third of
-// the step's wall time (launch-bound).  Here one workgroup carries 16 samples through the whole stack with
-// the activations in LDS: one launch each way.  MFMA formulation as in pv_sdec_fused.hip (transposed layers,
-// v_mfma_f32_16x16x4_f32, weights streamed from L2 as the A operand).
+// The encoder is < 1 % of the step's FLOPs but, as a chain of tiny dependent GEMMs, it is latency-bound.  The
+// first layer (K = 784) is spread over (row blocks x column blocks) workgroups whose 4 waves split K and keep
+// whole register batches of operands in flight; after it one workgroup carries 16 samples through the rest of
+// the stack with the activations in LDS and every weight operand of a layer requested before its first MFMA.
+// MFMA formulation as in pv_sdec_fused.hip (transposed layers, v_mfma_f32_16x16x4_f32, weights streamed from L2
+// as the A operand).
 // Supported: hidden widths <= 128 and multiples of 16, input width a multiple of 16, any activation but GELU;
 // anything else takes the generic GEMM path of pv_plan.hip.
 #include "pv_common.h"
@@ -27,41 +30,117 @@ __device__ __forceinline__ float en_block_sum(float v, float* sm /* 8 floats */)
 
 // one transposed layer for this wave's output blocks: D[j][r] = sum_k W[j][k] in[r][k]
 //   in: global (GLOBAL_IN, row stride ldin) or LDS (stride EN_LD); K % 16 == 0; out rows j >= out_dim are zero
-template <bool GLOBAL_IN>
+//   K <= 128: the block's whole weight operand (<= 8 float4 per lane) is requested before the first MFMA
 __device__ __forceinline__ f32x4 en_layer_block(const float* __restrict__ W, int K, int out_dim, int ob,
-                                                const float* __restrict__ in, int64_t ldin, int r, int q) {
-  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                                                const float* __restrict__ in /* LDS */, int r, int q) {
   const int j = 16 * ob + r;                       // this lane's A row
   const bool jok = j < out_dim;
   const float* wrow = W + (int64_t)(jok ? j : 0) * K + 4 * q;
-  const float* irow = in + (int64_t)r * ldin + 4 * q;
-#pragma unroll 4
-  for (int k = 0; k < K; k += 16) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(wrow + k);
-    if (!jok) a = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const f32x4 b = *reinterpret_cast<const f32x4*>(irow + k);
+  const float* irow = in + r * EN_LD + 4 * q;
+  f32x4 a[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc = MFMA(a[i], b[i], acc);
+  for (int t = 0; t < 8; ++t) {
+    const bool ok = jok && 16 * t < K;
+    a[t] = *reinterpret_cast<const f32x4*>(wrow + (16 * t < K ? 16 * t : 0));
+    if (!ok) a[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  return acc;
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (16 * t < K) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(irow + 16 * t);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i & 1) acc1 = MFMA(a[t][i], b[i], acc1); else acc0 = MFMA(a[t][i], b[i], acc0);
+      }
+    }
+  }
+  return acc0 + acc1;
 }
+
+// ---------------------------------------------------------------------------------------------
+// first encoder layer: eact[0] = act(x W0^T + b0), one workgroup per (16 rows x 16 outputs), K split over 4 waves
+#define L1_WAVES 4
+#define L1_STEPS 4             // k16-steps per register batch
+__global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
+  __shared__ float part[L1_WAVES][EN_ROWS][17];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const pv_layer l = e.enc[0];
+  const int ob = blockIdx.x, row0 = blockIdx.y * EN_ROWS, K = l.in_dim;
+  const int rowc = min(row0 + r, e.B - 1);
+  const int j = 16 * ob + r;
+  const bool jok = j < l.out_dim;
+  const float* wrow = e.params + l.w_off + (int64_t)(jok ? j : 0) * K + 4 * q;
+  const float* xrow = e.x + (int64_t)rowc * e.ldx + 4 * q;
+  // wave w takes k16-steps w, w + 4, w + 8, ...; a register batch is L1_STEPS of them (stride 64 * L1_STEPS k's)
+  f32x4 a[2][L1_STEPS], b[2][L1_STEPS];
+  auto load = [&](int k0, f32x4 (&av)[L1_STEPS], f32x4 (&bv)[L1_STEPS]) {
+#pragma unroll
+    for (int s = 0; s < L1_STEPS; ++s) {
+      const int k = k0 + 16 * L1_WAVES * s;
+      const int kc = k < K ? k : 0;
+      av[s] = *reinterpret_cast<const f32x4*>(wrow + kc);
+      bv[s] = *reinterpret_cast<const f32x4*>(xrow + kc);
+      if (k >= K || !jok) av[s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+  auto consume = [&](const f32x4 (&av)[L1_STEPS], const f32x4 (&bv)[L1_STEPS]) {
+#pragma unroll
+    for (int s = 0; s < L1_STEPS; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i & 1] = MFMA(av[s][i], bv[s][i], acc[i & 1]);
+  };
+  const int KB = 16 * L1_WAVES * L1_STEPS;         // k's per batch over the whole workgroup
+  load(16 * wave, a[0], b[0]);
+  for (int k0 = 16 * wave; k0 < K; k0 += 2 * KB) {
+    const bool more1 = k0 + KB < K, more2 = k0 + 2 * KB < K;
+    if (more1) load(k0 + KB, a[1], b[1]);
+    consume(a[0], b[0]);
+    if (more2) load(k0 + 2 * KB, a[0], b[0]);
+    if (more1) consume(a[1], b[1]);
+  }
+  const f32x4 c = acc[0] + acc[1];
+  // C/D layout: lane (batch row r, q), reg i -> output 16*ob + 4q + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[wave][r][4 * q + i] = c[i];
+  __syncthreads();
+  {
+    const int rr = tid >> 4, jj = tid & 15, jo = 16 * ob + jj, row = row0 + rr;
+    if (jo < l.out_dim && row < e.B) {
+      float v = (part[0][rr][jj] + part[1][rr][jj]) + (part[2][rr][jj] + part[3][rr][jj]);
+      v += l.b_off >= 0 ? e.params[l.b_off + jo] : 0.0f;
+      e.eact[0][(int64_t)row * l.out_dim + jo] = pv_act_fwd(v, l.act);
+    }
+  }
+}
+
 
 __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
   __shared__ __attribute__((aligned(16))) float act[2][EN_ROWS][EN_LD];
   __shared__ float sm[8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * EN_ROWS;
-  const int rowc = min(row0 + r, e.B - 1);         // clamped row for loads
   const bool rok = row0 + r < e.B;
   int cur = 0;
-  // ---- hidden layers ----
-  for (int li = 0; li < e.n_enc; ++li) {
+  // ---- the first layer's output (pv_enc_l1_kernel) into LDS; rows past the batch repeat the last one ----
+  {
+    const int w0 = e.enc[0].out_dim;
+    for (int t = tid; t < EN_ROWS * (w0 / 4); t += EN_THREADS) {
+      const int rr = t / (w0 / 4), c4 = t % (w0 / 4);
+      *reinterpret_cast<f32x4*>(&act[0][rr][4 * c4]) =
+          *reinterpret_cast<const f32x4*>(e.eact[0] + (int64_t)min(row0 + rr, e.B - 1) * w0 + 4 * c4);
+    }
+    __syncthreads();
+  }
+  // ---- hidden layers 1.. ----
+  for (int li = 1; li < e.n_enc; ++li) {
     const pv_layer l = e.enc[li];
     const float* W = e.params + l.w_off;
     const float* bias = l.b_off >= 0 ? e.params + l.b_off : nullptr;
     for (int ob = wave; 16 * ob < l.out_dim; ob += EN_THREADS / 64) {
-      f32x4 acc = li == 0 ? en_layer_block<true>(W, l.in_dim, l.out_dim, ob, e.x + (int64_t)(rowc - r) * e.ldx, e.ldx, r, q)
-                          : en_layer_block<false>(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], EN_LD, r, q);
+      f32x4 acc = en_layer_block(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], r, q);
       // C/D layout: lane (col r, q), reg i -> output j = 16*ob + 4*q + i of row r
       f32x4 y;
 #pragma unroll
@@ -81,7 +160,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     const float* W = e.params + l.w_off;
     const float* bias = l.b_off >= 0 ? e.params + l.b_off : nullptr;
     for (int ob = wave; 16 * ob < l.out_dim; ob += EN_THREADS / 64) {
-      f32x4 acc = en_layer_block<false>(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], EN_LD, r, q);
+      f32x4 acc = en_layer_block(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], r, q);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = 16 * ob + 4 * q + i;
@@ -180,7 +259,10 @@ bool pv_enc_compact_supported(const pv_ivae_plan* p) {
 }
 
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
-  hipLaunchKernelGGL(pv_enc_fwd_kernel, dim3((e.B + EN_ROWS - 1) / EN_ROWS), dim3(EN_THREADS), 0, s, e);
+  const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
+  hipLaunchKernelGGL(pv_enc_l1_kernel, dim3((e.enc[0].out_dim + 15) / 16, rb), dim3(64 * L1_WAVES), 0, s, e);
+  PV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pv_enc_fwd_kernel, dim3(rb), dim3(EN_THREADS), 0, s, e);
   PV_LAUNCH_CHECK();
   return 0;
 }
@@ -216,13 +298,28 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
     const pv_layer lp = e.enc[li - 1];
     const float* W = e.params + l.w_off;
     for (int kb = wave; 16 * kb < l.in_dim; kb += EN_THREADS / 64) {
-      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
       const float* wcol = W + 16 * kb + r;                 // A lane (k' = r, q): W[j][16*kb + k']
-      for (int j0 = 0; j0 < l.out_dim; j0 += 16) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&buf[cur][r][j0 + 4 * q]);
+      float a[8][4];                                       // out_dim <= 128: the whole operand in flight at once
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = MFMA(wcol[(int64_t)(j0 + 4 * q + i) * l.in_dim], b[i], acc);
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = 16 * t + 4 * q + i;
+          const float v = wcol[(int64_t)(j < l.out_dim ? j : 0) * l.in_dim];
+          a[t][i] = j < l.out_dim ? v : 0.0f;
+        }
+      f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (16 * t < l.out_dim) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(&buf[cur][r][16 * t + 4 * q]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i & 1) acc1 = MFMA(a[t][i], b[i], acc1); else acc0 = MFMA(a[t][i], b[i], acc0);
+          }
+        }
       }
+      const f32x4 acc = acc0 + acc1;
       const int row = row0 + r;
       f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
       if (row < e.B) {

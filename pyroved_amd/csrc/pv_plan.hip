@@ -322,7 +322,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
                                 l.in_dim, l.out_dim);
   }
   if (B <= 4096) {
-    for (int i = 0; i < np; i += 4) PV_TRY(pv_gemm_multi(probs + i, np - i < 4 ? np - i : 4, s));
+    for (int i = 0; i < np; i += 4) PV_TRY(pv_wgrad_small(probs + i, np - i < 4 ? np - i : 4, s));
   } else {                                   // long contractions: split-K GEMMs, one launch pair each
     for (int i = 0; i < np; ++i)
       PV_TRY(pv_gemm(probs[i], pv_gemm_pick_splits(probs[i].M, probs[i].N, probs[i].K), ws, wsb, s));

@@ -1,0 +1,107 @@
+// pv_wgrad.hip — weight gradients of the small Linear layers around the spatial decoder (encoder, fc_latent):
+//     dW[m][n] = sum_k A(m,k) B(k,n),   A = dpre^T (stored [K][M], k = minibatch sample),  B = layer input [K][N]
+//     db[m]    = sum_k A(m,k)
+// (torch.nn.Linear backward: grad_weight = grad_output^T input, grad_bias = grad_output.sum(0).)
+// These problems have a SHORT contraction (K = minibatch, a few hundred) and a wide output (128 x 784 for the
+// first encoder layer): an LDS-tiled 64x64 GEMM gives ~30 workgroups each looping over K behind barriers, i.e.
+// latency-bound at ~24 us.  Here a workgroup owns one 16x16 output tile and its 4 waves split K in 64-k register
+// batches (wave w takes batches w, w+4, ...): at K = 256 every operand of the whole launch is requested at once,
+// one memory latency in all.  Operands stream from L2 straight into registers and feed v_mfma_f32_16x16x4_f32
+// (fp32 in, fp32 accumulate) on four independent accumulators; the 4 partial tiles meet in LDS.  Up to 4
+// problems share one launch (~470 workgroups for the iVAE 28x28 step, several resident per CU).
+#include "pv_common.h"
+
+#define WG_WAVES 4
+#define WG_CHUNK 64            // k's per register batch (16 MFMAs)
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+struct PvWgradSmall {
+  PvGemm g[4];
+  int tile_end[4];             // exclusive prefix sums of the problems' tile counts
+  int n;
+};
+
+__global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSmall w) {
+  __shared__ float part[WG_WAVES][16][17];
+  __shared__ float rpart[WG_WAVES][16];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  int pi = 0;
+  while (t >= w.tile_end[pi]) ++pi;
+  if (pi > 0) t -= w.tile_end[pi - 1];
+  const PvGemm& g = w.g[pi];
+  const int nbs = (g.N + 15) / 16;
+  const int mb = t / nbs, nb = t - mb * nbs;
+  // MFMA operands: A lane (m = r, k = q), B lane (n = r, k = q); one instruction covers 4 k's
+  const int m = 16 * mb + r, n = 16 * nb + r;
+  const bool mok = m < g.M, nok = n < g.N;
+  const float* ap = g.A + (int64_t)(mok ? m : 0) * g.a_rs;
+  const float* bp = g.B + (int64_t)(nok ? n : 0) * g.b_cs;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float rs = 0.0f;
+  float a[2][WG_CHUNK / 4], b[2][WG_CHUNK / 4];
+  auto load = [&](int k0, float (&av)[WG_CHUNK / 4], float (&bv)[WG_CHUNK / 4]) {
+#pragma unroll
+    for (int s = 0; s < WG_CHUNK / 4; ++s) {
+      const int k = k0 + 4 * s + q;
+      const int kc = k < g.K ? k : g.K - 1;
+      const float x = ap[(int64_t)kc * g.a_cs], y = bp[(int64_t)kc * g.b_rs];
+      av[s] = (k < g.K && mok) ? x : 0.0f;
+      bv[s] = (k < g.K && nok) ? y : 0.0f;
+    }
+  };
+  auto consume = [&](const float (&av)[WG_CHUNK / 4], const float (&bv)[WG_CHUNK / 4]) {
+#pragma unroll
+    for (int s = 0; s < WG_CHUNK / 4; ++s) {
+      acc[s & 3] = MFMA4(av[s], bv[s], acc[s & 3]);
+      rs += av[s];
+    }
+  };
+  const int KS = WG_CHUNK * WG_WAVES;                         // k stride between a wave's batches
+  if (WG_CHUNK * wave < g.K) {
+    load(WG_CHUNK * wave, a[0], b[0]);
+    for (int k0 = WG_CHUNK * wave; k0 < g.K; k0 += 2 * KS) {  // two register batches, the other one in flight
+      const bool more1 = k0 + KS < g.K, more2 = k0 + 2 * KS < g.K;
+      if (more1) load(k0 + KS, a[1], b[1]);
+      consume(a[0], b[0]);
+      if (more2) load(k0 + 2 * KS, a[0], b[0]);
+      if (more1) consume(a[1], b[1]);
+    }
+  }
+  const f32x4 c = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  // C/D layout: lane (n = r, q), reg i -> m = 16*mb + 4q + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[wave][4 * q + i][r] = c[i];
+  rs += __shfl_xor(rs, 16, 64);
+  rs += __shfl_xor(rs, 32, 64);
+  if (q == 0) rpart[wave][r] = rs;
+  __syncthreads();
+  {
+    const int mm = tid >> 4, nn = tid & 15, mo = 16 * mb + mm, no = 16 * nb + nn;
+    if (mo < g.M && no < g.N)
+      g.C[(int64_t)mo * g.ldc + no] = (part[0][mm][nn] + part[1][mm][nn]) + (part[2][mm][nn] + part[3][mm][nn]);
+    if (g.rowsumA && nb == 0 && tid < 16 && 16 * mb + tid < g.M)
+      g.rowsumA[16 * mb + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
+  }
+}
+
+// gs[i]: plain wgrad problems (no bias / activation / aux epilogue); any strides, any M, N, K >= 1
+int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s) {
+  if (n < 1 || n > 4) return PV_EINVAL;
+  PvWgradSmall w{};
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (gs[i].bias || gs[i].aux || gs[i].pre || gs[i].act != PV_ACT_NONE || gs[i].K < 1) return PV_EINVAL;
+    w.g[i] = gs[i];
+    tiles += ((gs[i].M + 15) / 16) * ((gs[i].N + 15) / 16);
+    w.tile_end[i] = tiles;
+  }
+  for (int i = n; i < 4; ++i) w.tile_end[i] = tiles;
+  w.n = n;
+  hipLaunchKernelGGL(pv_wgrad_small_kernel, dim3(tiles), dim3(64 * WG_WAVES), 0, s, w);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
