@@ -8,6 +8,7 @@
 // Reductions are tree/ordered (no float atomics): results are bit-reproducible run to run.
 #include "pv_common.h"
 #include "pv_kernels.h"
+#include "pv_sdec_fused.h"
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define BERN_EPS 1.1920928955078125e-07f   // torch.finfo(float32).eps used by clamp_probs
@@ -309,25 +310,11 @@ int pv_segsum(const float* v, int64_t nseg, int64_t N, float* out, hipStream_t s
   return 0;
 }
 
-// scalars[1] = sum_b ll_b ; [2], [3] from the encoder kernel's partials when given ; scalars[0] = -(ll + lp - lq)
 __global__ __launch_bounds__(256) void pv_finish_scalars_kernel(const float* __restrict__ llb, int B, float* scalars,
                                                                 const float* __restrict__ kl_part, int n_part,
                                                                 float beta) {
-  __shared__ float sm[4];
-  float a = 0.0f;
-  for (int b = threadIdx.x; b < B; b += 256) a += llb[b];
-  a = block_sum_256(a, sm);
-  float lp = 0.0f, lq = 0.0f;
-  if (kl_part) {
-    for (int i = threadIdx.x; i < n_part; i += 256) { lp += kl_part[2 * i]; lq += kl_part[2 * i + 1]; }
-    lp = block_sum_256(lp, sm);
-    lq = block_sum_256(lq, sm);
-  }
-  if (threadIdx.x == 0) {
-    if (kl_part) { scalars[2] = beta * lp; scalars[3] = beta * lq; }
-    scalars[1] = a;
-    scalars[0] = -(a + scalars[2] - scalars[3]);
-  }
+  __shared__ float sm[16];
+  pv_finish_scalars_block(llb, B, scalars, kl_part, n_part, beta, sm);
 }
 
 int pv_finish_scalars(const float* llb, int B, float* scalars, const float* kl_part, int n_part, float beta,
@@ -487,12 +474,12 @@ int pv_head_bwd(const PvHeadBwd& h, hipStream_t s) {
 // latent_bwd (fused decoder path): one workgroup per sample gathers everything that flows from the decoder
 // kernel back into that sample's latent code: ll_b and d(phi, scale, tx, ty) (sums over the sample's N rows),
 // dL/d(hz[b]) (sum of the workgroup partials), dL/d(z content) = dhz Wz, then head_bwd.  Fixed-order sums.
-__global__ __launch_bounds__(256) void pv_latent_bwd_kernel(PvLatentBwd p) {
+__device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b) {
   __shared__ float sm[4];
   __shared__ float sh_dhz[512];
   __shared__ float sh_dzc[64];
   __shared__ float sh_tp[4];
-  const int b = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
   const int64_t r0 = (int64_t)b * p.N;
   float a[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   for (int n = t; n < p.N; n += 256) {
@@ -522,6 +509,27 @@ __global__ __launch_bounds__(256) void pv_latent_bwd_kernel(PvLatentBwd p) {
   __syncthreads();
   if (t < p.hb.z_dim)
     pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; });
+}
+
+__global__ __launch_bounds__(256) void pv_latent_bwd_kernel(PvLatentBwd p) { pv_latent_bwd_block(p, blockIdx.x); }
+
+// one launch for the two consumers of the fused decoder kernel's outputs, which do not depend on each other:
+// workgroups [0, PV_FUSED_REDUCE_BLOCKS) sum the per-workgroup gradient records, the rest run latent_bwd
+__global__ __launch_bounds__(256) void pv_latent_bwd_reduce_kernel(PvLatentBwd p, const float* __restrict__ part,
+                                                                   int G_, float* __restrict__ Gr, PvFusedOffsets o,
+                                                                   int cd) {
+  __shared__ f32x4 smr[4][64];
+  if ((int)blockIdx.x < PV_FUSED_REDUCE_BLOCKS) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, blockIdx.x, smr);
+  else pv_latent_bwd_block(p, blockIdx.x - PV_FUSED_REDUCE_BLOCKS);
+}
+
+int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
+                         hipStream_t s) {
+  if (p.H > 512 || p.lat_in > 64 || p.hb.z_dim > 256) return PV_EINVAL;
+  hipLaunchKernelGGL(pv_latent_bwd_reduce_kernel, dim3(PV_FUSED_REDUCE_BLOCKS + p.hb.B), dim3(256), 0, s, p, part, grid,
+                     G, o, cd);
+  PV_LAUNCH_CHECK();
+  return 0;
 }
 
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s) {

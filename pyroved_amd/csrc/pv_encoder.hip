@@ -66,6 +66,12 @@ __global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
   __shared__ float part[L1_WAVES][EN_ROWS][17];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
+  if ((int)blockIdx.y >= rb) {                     // guest work: the decoder kernel's weight images (pv_fb_layout.h)
+    const int64_t blk = (int64_t)(blockIdx.y - rb) * gridDim.x + blockIdx.x;
+    pv_fb_prep(e.prep, blk * (64 * L1_WAVES) + tid, (int64_t)(gridDim.y - rb) * gridDim.x * (64 * L1_WAVES));
+    return;
+  }
   const pv_layer l = e.enc[0];
   const int ob = blockIdx.x, row0 = blockIdx.y * EN_ROWS, K = l.in_dim;
   const int rowc = min(row0 + r, e.B - 1);
@@ -260,7 +266,14 @@ bool pv_enc_compact_supported(const pv_ivae_plan* p) {
 
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
   const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
-  hipLaunchKernelGGL(pv_enc_l1_kernel, dim3((e.enc[0].out_dim + 15) / 16, rb), dim3(64 * L1_WAVES), 0, s, e);
+  const int cb = (e.enc[0].out_dim + 15) / 16;
+  int extra = 0;                                   // rows of guest workgroups for the weight-image preparation
+  if (e.prep.img) {
+    const int64_t work = e.prep.nzero4 > 128 * 32 ? e.prep.nzero4 : 128 * 32;
+    extra = (int)((work + (int64_t)cb * 64 * L1_WAVES - 1) / ((int64_t)cb * 64 * L1_WAVES));
+    if (extra > 16) extra = 16;
+  }
+  hipLaunchKernelGGL(pv_enc_l1_kernel, dim3(cb, rb + extra), dim3(64 * L1_WAVES), 0, s, e);
   PV_LAUNCH_CHECK();
   hipLaunchKernelGGL(pv_enc_fwd_kernel, dim3(rb), dim3(EN_THREADS), 0, s, e);
   PV_LAUNCH_CHECK();
@@ -272,6 +285,10 @@ int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
 __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) {
   __shared__ __attribute__((aligned(16))) float buf[2][EN_ROWS][EN_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  if ((int)blockIdx.x == (e.B + EN_ROWS - 1) / EN_ROWS) {        // guest workgroup: the step's loss scalars
+    pv_finish_scalars_block(e.fin_llb, e.B, e.fin_scalars, e.fin_kl_part, e.fin_n_part, e.fin_beta, &buf[0][0][0]);
+    return;
+  }
   const int row0 = blockIdx.x * EN_ROWS;
   const int ne = e.n_enc;
   int cur = 0;
@@ -336,7 +353,8 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
 }
 
 int pv_enc_dgrad(const PvEncDgrad& e, hipStream_t s) {
-  hipLaunchKernelGGL(pv_enc_dgrad_kernel, dim3((e.B + EN_ROWS - 1) / EN_ROWS), dim3(EN_THREADS), 0, s, e);
+  hipLaunchKernelGGL(pv_enc_dgrad_kernel, dim3((e.B + EN_ROWS - 1) / EN_ROWS + (e.fin_scalars ? 1 : 0)),
+                     dim3(EN_THREADS), 0, s, e);
   PV_LAUNCH_CHECK();
   return 0;
 }

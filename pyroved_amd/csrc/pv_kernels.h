@@ -1,6 +1,7 @@
 // pv_kernels.h — argument blocks and host launchers of the non-GEMM kernels (pv_elementwise.hip).
 #pragma once
 #include "pv_common.h"
+#include "pv_fb_layout.h"
 
 struct PvHead {
   const float* head;     // (B, 2*z_dim): [mu | softplus input]  (fc11 | fc12 of fcEncoderNet, fc.py:59-60)
@@ -97,11 +98,44 @@ struct PvLatentBwd {
   PvHeadBwd hb;          // dzc / dtp fields unused (values stay in LDS)
 };
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
+struct PvFusedOffsets;
+int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
+                         hipStream_t s);
 
 int pv_lik_elem(const float* a, const float* x, int64_t M, int lik, int sigmoid_out, float sig, float* loc,
                 float* llrow, float* dlda, hipStream_t s);
 
 // ---- compact encoder kernels (pv_encoder.hip) ----
+// deterministic block-wide sum for any blockDim.x that is a multiple of 64 (<= 1024); result valid in every thread
+__device__ __forceinline__ float pv_block_sum(float v, float* sm /* >= 16 floats */) {
+  v = pv_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+  return t;
+}
+// scalars[1] = sum_b ll_b ; [2], [3] from the encoder kernel's partials when given ; scalars[0] = -(ll + lp - lq)
+__device__ __forceinline__ void pv_finish_scalars_block(const float* __restrict__ llb, int B, float* scalars,
+                                                        const float* __restrict__ kl_part, int n_part, float beta,
+                                                        float* sm /* >= 16 floats */) {
+  float a = 0.0f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) a += llb[b];
+  a = pv_block_sum(a, sm);
+  float lp = 0.0f, lq = 0.0f;
+  if (kl_part) {
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) { lp += kl_part[2 * i]; lq += kl_part[2 * i + 1]; }
+    lp = pv_block_sum(lp, sm);
+    lq = pv_block_sum(lq, sm);
+  }
+  if (threadIdx.x == 0) {
+    if (kl_part) { scalars[2] = beta * lp; scalars[3] = beta * lq; }
+    scalars[1] = a;
+    scalars[0] = -(a + scalars[2] - scalars[3]);
+  }
+}
+
 struct PvEncFwd {
   const float* params;
   pv_layer enc[PV_MAX_LAYERS];
@@ -116,6 +150,7 @@ struct PvEncFwd {
   float* hz; const float* Wz; int H0;     // fc_latent (null hz: skip)
   int B, z_dim, c_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior;
+  PvFbPrep prep;                    // hosted in the first-layer launch when prep.img is set (bf16x3 decoder path)
 };
 bool pv_enc_compact_supported(const pv_ivae_plan* p);
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s);
@@ -128,5 +163,7 @@ struct PvEncDgrad {
   const float* dhead;               // (B, 2*z_dim)
   const float* eact[PV_MAX_LAYERS];
   float* edp[PV_MAX_LAYERS];        // out: dL/d(pre-activation) of every hidden layer
+  // hosted in one extra workgroup when fin_scalars is set: the step's loss scalars (pv_finish_scalars)
+  const float* fin_llb; float* fin_scalars; const float* fin_kl_part; int fin_n_part; float fin_beta;
 };
 int pv_enc_dgrad(const PvEncDgrad& e, hipStream_t s);

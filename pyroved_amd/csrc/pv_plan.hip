@@ -284,7 +284,10 @@ PvGemm wgrad_problem(const float* dpre, int64_t lddp, const float* x, int64_t ld
 
 // encoder backward from dL/d(head pre-activations) (L.dhead): the dgrad chain through the hidden layers, then
 // every weight gradient of the encoder (plus `extra`, e.g. fc_latent's) in one multi-GEMM launch per 4 problems
-int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, hipStream_t s) {
+struct PvFinish { const float* llb; int B; float* scalars; const float* kl_part; int n_part; float beta; };
+
+int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, hipStream_t s,
+                const PvFinish* fin = nullptr) {
   const int64_t B = p->batch, z = p->z_dim;
   float* G = p->grads;
   void* ws = L.scratch;
@@ -296,6 +299,10 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     PvEncDgrad d{};
     d.params = p->params; d.n_enc = ne; d.B = (int)B; d.head = hd; d.dhead = L.dhead;
     for (int i = 0; i < ne; ++i) { d.enc[i] = p->enc[i]; d.eact[i] = L.eact[i]; d.edp[i] = L.edp[i]; }
+    if (fin) {
+      d.fin_llb = fin->llb; d.fin_scalars = fin->scalars; d.fin_kl_part = fin->kl_part; d.fin_n_part = fin->n_part;
+      d.fin_beta = fin->beta;
+    }
     PV_TRY(pv_enc_dgrad(d, s));
   } else {
     PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + hd.w_off, L.edp[ne - 1], hd.in_dim, elast, L.epre[ne - 1],
@@ -344,9 +351,10 @@ int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, i
 }
 
 // guide: encoder -> (z_loc, z_scale) -> z = z_loc + z_scale*eps, sampled-KL terms, transform parameters
-int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr) {
   if (L.enc_compact) {
     PvEncFwd e{};
+    if (prep) e.prep = *prep;
     e.params = p->params; e.n_enc = p->n_enc; e.head = p->head;
     for (int i = 0; i < p->n_enc; ++i) { e.enc[i] = p->enc[i]; e.eact[i] = L.eact[i]; }
     e.x = p->x; e.ldx = p->n_pix;
@@ -364,6 +372,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;
     return pv_enc_fwd(e, s);
   }
+  if (prep) return PV_EINVAL;                    // (callers run the stand-alone preparation on this path)
   PV_TRY(encoder_fwd(p, L, s));
   PvHead h{};
   h.head = L.head; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
@@ -381,14 +390,10 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   const int64_t lat_in = p->latent_dim + p->c_dim;
   const int H = FD_H;
   float* G = p->grads;
-  PV_TRY(guide_fwd(p, L, s));
   const int coord = (int)(z - p->latent_dim);
   const float* zin = p->c_dim > 0 ? L.zy : L.z + coord;
   const int64_t ldz = p->c_dim > 0 ? lat_in : z;
   if (p->fc_latent.in_dim != lat_in) return PV_EINVAL;
-  if (!L.enc_compact)
-    PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
-                      L.scratch, L.scratch_bytes, s));
   PvFused f{};
   f.x = p->x; f.grid = p->grid; f.tp = L.tp; f.hz = L.hz;
   f.Wc = p->params + p->fc_coord.w_off; f.bc = p->params + p->fc_coord.b_off;
@@ -399,12 +404,22 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.wimg = L.f_wimg;
   f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)B; f.lik = p->lik;
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
-  if (p->fused == 2) {
-    PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, s));      // weight images + zero fill of part_hz
-  } else if (want_grads) {
-    hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(B * L.f_kmax * H) * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+  // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
+  if (p->fused == 2 && L.enc_compact) {
+    const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0);
+    PV_TRY(guide_fwd(p, L, s, &prep));
+  } else {
+    PV_TRY(guide_fwd(p, L, s));
+    if (p->fused == 2) {
+      PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, s));
+    } else if (want_grads) {
+      hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(B * L.f_kmax * H) * sizeof(float), s);
+      if (e != hipSuccess) return (int)e;
+    }
   }
+  if (!L.enc_compact)
+    PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
+                      L.scratch, L.scratch_bytes, s));
   if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_start, s);
   if (p->fused == 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, s));
   else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
@@ -415,8 +430,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   }
   PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
                    p->fc_coord.w_off, p->out.w_off, p->out.b_off};
-  PV_TRY(pv_sdec_fused_reduce(L.f_part, L.f_grid, G, o, p->coord_dim, 0, s));
-  // per sample: ll_b, d(phi, scale, tx, ty), dL/d(hz), dL/d(z content), head backward -> L.dhead
+  // per sample: ll_b, d(phi, scale, tx, ty), dL/d(hz), dL/d(z content), head backward -> L.dhead ; in the same
+  // launch: the per-workgroup gradient records summed into the flat gradient
   PvLatentBwd lb{};
   lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;
   lb.llb = L.llb; lb.dhz = L.dhz; lb.M = R; lb.N = (int)N; lb.kmax = L.f_kmax; lb.H = H; lb.lat_in = (int)lat_in;
@@ -425,11 +440,13 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
   hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
   hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
-  PV_TRY(pv_latent_bwd(lb, s));
-  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta, s));
+  PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s));
+  // the loss scalars ride in the encoder dgrad launch (compact encoder) or get their own
+  PvFinish fin{L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta};
+  if (!L.enc_compact) PV_TRY(pv_finish_scalars(fin.llb, fin.B, fin.scalars, fin.kl_part, fin.n_part, fin.beta, s));
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
   const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, B, lat_in, H);
-  return encoder_bwd(p, L, &wz, 1, s);
+  return encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr);
 }
 
 int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {

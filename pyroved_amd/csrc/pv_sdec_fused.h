@@ -45,8 +45,64 @@ int pv_sdec_fused_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
 // same interface, bf16 split-precision ("bf16x3") matrix math (pv_sdec_fused_bf16.hip); _prep must run first on the
 // same stream, once per parameter state: it writes f.wimg and, with grads, zero-fills f.part_hz
 int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s);
+// ... or, as arguments for a kernel that hosts the preparation (pv_fb_layout.h: pv_fb_prep)
+struct PvFbPrep;
+PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads);
 int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
 struct PvFusedOffsets { int64_t W1, b1, W2, b2, Wc, wo, bo; };
 int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int dwo_slots,
                          hipStream_t s);
+
+// ---- the reduction's workgroup body (256 threads), shared with the launch that also hosts pv_latent_bwd -------
+// 64 float4 outputs x 4 slices of the workgroup range per 256-thread block (a wave reads 1 KB per record, eight
+// records in flight); slices combined in fixed order
+#define PV_FUSED_REDUCE_BLOCKS (((2 * FD_H * FD_H + 5 * FD_H + 1 + 3) / 4 + 63) / 64)
+__device__ __forceinline__ void pv_sdec_fused_reduce_block(const float* __restrict__ part, int G_,
+                                                           float* __restrict__ Gr, const PvFusedOffsets& o, int cd,
+                                                           int dwo_slots, int block, f32x4 (*sm)[64]) {
+  const int HH = FD_H * FD_H;
+  const int total = 2 * HH + 5 * FD_H + 1;          // the record is padded well past this: whole float4s are readable
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = (block * 64 + c) * 4;
+  const int per = (G_ + 3) / 4;
+  const int w0 = sl * per, w1 = min(G_, w0 + per);
+  f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (e < total) {
+    const bool slots = dwo_slots && e >= 2 * HH + 4 * FD_H && e < 2 * HH + 5 * FD_H;   // d(wo): 8 per-wave slots
+    if (slots) {
+      for (int w = w0; w < w1; ++w) {
+        const float* p8 = part + (int64_t)w * FD_REC + 2 * HH + 6 * FD_H + (e - (2 * HH + 4 * FD_H));
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < FD_WAVES; ++k) a += *reinterpret_cast<const f32x4*>(p8 + k * FD_H);
+        v += a;
+      }
+    } else {
+      const float* p = part + e;
+#pragma unroll 8
+      for (int w = w0; w < w1; ++w) v += *reinterpret_cast<const f32x4*>(p + (int64_t)w * FD_REC);
+    }
+  }
+  sm[sl][c] = v;
+  __syncthreads();
+  if (sl != 0 || e >= total) return;
+  v = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ei = e + i;
+    if (ei >= total) break;
+    if (ei < HH) Gr[o.W1 + ei] = v[i];
+    else if (ei < 2 * HH) Gr[o.W2 + (ei - HH)] = v[i];
+    else {
+      const int k = ei - 2 * HH, seg = k / FD_H, j = k % FD_H;
+      if (seg == 0) Gr[o.b1 + j] = v[i];
+      else if (seg == 1) Gr[o.b2 + j] = v[i];
+      else if (seg == 2) Gr[o.Wc + j * cd] = v[i];
+      else if (seg == 3) { if (cd == 2) Gr[o.Wc + j * 2 + 1] = v[i]; }
+      else if (seg == 4) Gr[o.wo + j] = v[i];
+      else Gr[o.bo] = v[i];
+    }
+  }
+}
+
+

@@ -31,10 +31,9 @@
 //     wgrad contracts 32 rows per v_mfma_f32_16x16x32_bf16 (operands by ds_read_b64_tr_b16; bias gradients ride
 //     along as an MFMA against ones) and a tile needs 8 workgroup barriers instead of 24.
 #include "pv_sdec_fused.h"
+#include "pv_fb_layout.h"
 #include <stdlib.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4_ __attribute__((ext_vector_type(4)));
 typedef short short8_ __attribute__((ext_vector_type(8)));
 typedef int int4_ __attribute__((ext_vector_type(4)));
@@ -43,9 +42,6 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define FB_WAVES 4               // waves per workgroup (one per SIMD), one 16-row unit each
 #define TILE_UNITS FB_WAVES      // units per workgroup tile
 #define TILE_ROWS (TILE_UNITS * FD_UNIT)
-#define LDB 128                  // bf16 elements per LDS row of the weight images: unpadded, 16-byte chunks XOR-swizzled
-#define W_IMG (FD_H * LDB)       // elements of one weight image
-#define IMG_BYTES (2 * W_IMG)    // 32,768
 #define LDS2 144                 // staging arrays: 72-dword rows -> the 4x16 transposing reads are conflict-free
 #define ST_ARR (TILE_ROWS * LDS2)          // elements of one staging array (64 rows)
 #define ST_BYTES (2 * ST_ARR)              // 18,432
@@ -89,12 +85,6 @@ __device__ __forceinline__ float fb_exp(float x) { return __builtin_amdgcn_exp2f
 __device__ __forceinline__ float fb_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float fb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// x -> (hi, lo) bf16 with hi + lo = x to ~2^-17 relative
-__device__ __forceinline__ void fb_split(float x, __bf16& hi, __bf16& lo) {
-  hi = (__bf16)x;
-  lo = (__bf16)(x - (float)hi);
-}
-
 // two D-layout blocks (4 + 4 consecutive k of this lane) -> the lane's 8-element hi / lo operands
 __device__ __forceinline__ void fb_split8(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -108,26 +98,6 @@ __device__ __forceinline__ void fb_split8(const f32x4& u, const f32x4& v, bf16x8
 __device__ __forceinline__ bf16x8 fb_cat(const bf16x4& a, const bf16x4& b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-
-// LDS weight images are stored with their columns permuted inside every block of 32: logical column
-// k = 32m + 16h + 4q + i (h in {0,1}, q in 0..3, i in 0..3) sits at physical column 32m + 8q + 4h + i, so that the
-// 8 k's a lane feeds to one v_mfma_f32_16x16x32_bf16 ({32m+4q+i} and {32m+16+4q+i}: the C/D layout of the
-// producing layer) are CONTIGUOUS: the forward A operand is one ds_read_b128 (a pair of ds_read_b64 gets fused
-// into ds_read2_b64, whose 32-bank addressing runs at a quarter of the rate on this row stride).  Groups of 4
-// consecutive logical columns stay contiguous, which is all the transposing dgrad read needs.
-__device__ __forceinline__ int fb_pcol(int k) {
-  return (k & ~31) | (((k >> 2) & 3) << 3) | (((k >> 4) & 1) << 2) | (k & 3);
-}
-
-// ... and every row R of an image has its sixteen 16-byte chunks XOR-swizzled by fb_swz(R) = 4*(R&3) + SL[(R>>2)&3],
-// SL = {0,2,3,1}: (a) the forward's ds_read_b128 (lane (r,q): row 16*ob + r, chunk 4m + q; serviced in the 16-lane
-// groups {0-3,12-15,20-27}, ...) touches 16 distinct chunks per group = all 64 banks; (b) the dgrad's transposing
-// 8-byte reads (32 lanes: 8 rows x 4 chunks, one half of each chunk) are 2-way, the minimum while all lanes want
-// the same half.  Unpadded rows make an image exactly 32 KB.
-__device__ __forceinline__ int fb_sl(int t) { return (0x78 >> (2 * t)) & 3; }
-__device__ __forceinline__ int fb_swz(int R) { return 4 * (R & 3) + fb_sl((R >> 2) & 3); }
-// element index of (row R, permuted column pc) in an image
-__device__ __forceinline__ int fb_wel(int R, int pc) { return R * LDB + 8 * ((pc >> 3) ^ fb_swz(R)) + (pc & 7); }
 
 // a zero the compiler cannot see through: lane-address arithmetic that depends on it is redone where it is used
 // instead of being hoisted out of the tile loop and held in (or spilled from) registers for the whole kernel
@@ -385,30 +355,10 @@ __device__ long long fb_trace[256];
       fb_trace[tile_no * 16 + (k)] = (long long)__builtin_readcyclecounter();              \
   } while (0)
 
-// once per step: the hidden layers' weights as bf16 hi / lo images in the kernel's LDS layout (W1h W1l W2h W2l,
-// row-major [128][128], columns permuted by fb_pcol, chunks swizzled by fb_swz), and the zero fill of the dL/d(hz) partial-sum slots
-__global__ __launch_bounds__(256) void pv_fb_prep_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
-                                                         __bf16* __restrict__ img, float* __restrict__ zero,
-                                                         int64_t nzero4) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, T = (int64_t)gridDim.x * 256;
-  for (int64_t idx = t; idx < FD_H * (FD_H / 4); idx += T) {
-    const int row = (int)(idx >> 5), c4 = (int)(idx & 31);
-    const f32x4 w1 = reinterpret_cast<const f32x4*>(W1)[idx];
-    const f32x4 w2 = reinterpret_cast<const f32x4*>(W2)[idx];
-    bf16x4 h1, l1, h2, l2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __bf16 a, b;
-      fb_split(w1[i], a, b); h1[i] = a; l1[i] = b;
-      fb_split(w2[i], a, b); h2[i] = a; l2[i] = b;
-    }
-    const int e = fb_wel(row, fb_pcol(4 * c4));
-    *reinterpret_cast<bf16x4*>(img + e) = h1;
-    *reinterpret_cast<bf16x4*>(img + W_IMG + e) = l1;
-    *reinterpret_cast<bf16x4*>(img + 2 * W_IMG + e) = h2;
-    *reinterpret_cast<bf16x4*>(img + 3 * W_IMG + e) = l2;
-  }
-  for (int64_t idx = t; idx < nzero4; idx += T) reinterpret_cast<f32x4*>(zero)[idx] = f32x4{0, 0, 0, 0};
+// stand-alone form of the per-step preparation (pv_fb_layout.h); the SVI step runs it inside the encoder's
+// first-layer launch instead (pv_encoder.hip)
+__global__ __launch_bounds__(256) void pv_fb_prep_kernel(PvFbPrep p) {
+  pv_fb_prep(p, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
 template <bool GRADS>
@@ -818,15 +768,21 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_trace), n * sizeof(long long));
 }
 
-int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s) {
+PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads) {
   static_assert(FB_WIMG_BYTES == 4 * IMG_BYTES, "pv_sdec_fused.h and the LDS image layout disagree");
+  PvFbPrep p{};
+  p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz;
+  p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
+  return p;
+}
+
+int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s) {
   if (!f.wimg) return PV_EINVAL;
-  const int64_t nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
-  const int64_t work = nzero4 > FD_H * (FD_H / 4) ? nzero4 : FD_H * (FD_H / 4);
+  const PvFbPrep p = pv_sdec_fused_bf16_prep_args(f, grads);
+  const int64_t work = p.nzero4 > FD_H * (FD_H / 4) ? p.nzero4 : FD_H * (FD_H / 4);
   int blocks = (int)((work + 255) / 256);
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(pv_fb_prep_kernel, dim3(blocks), dim3(256), 0, s, f.W1, f.W2, reinterpret_cast<__bf16*>(f.wimg),
-                     f.part_hz, nzero4);
+  hipLaunchKernelGGL(pv_fb_prep_kernel, dim3(blocks), dim3(256), 0, s, p);
   PV_LAUNCH_CHECK();
   return 0;
 }

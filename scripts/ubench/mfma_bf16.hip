@@ -57,7 +57,11 @@ int main() {
   run<8, 4>("acc8 valu4", 512, d);
   run<8, 6>("acc8 valu6", 512, d);
   run<8, 8>("acc8 valu8", 512, d);
+  run<8, 1>("acc8 valu1", 256, d);
+  run<8, 2>("acc8 valu2", 256, d);
+  run<8, 3>("acc8 valu3", 256, d);
   run<8, 4>("acc8 valu4", 256, d);
+  run<8, 6>("acc8 valu6", 256, d);
   run<8, 8>("acc8 valu8", 256, d);
   return 0;
 }
