@@ -178,6 +178,73 @@ def test_steps_vs_golden_and_oracle(gpu_device, name, fused):
         np.testing.assert_allclose(dec2.numpy(), gold["dec.loc_ats"], rtol=1e-4, atol=2e-6)
 
 
+# model variants the reference's constructor allows (models/ivae.py:122-135), each against the CPU oracle on the same
+# seeded inputs: class-conditioning (c_dim), Gaussian likelihood with / without the output sigmoid, other activations,
+# other hidden widths (these leave the specialised kernels for the generic layer path), prior scales, 1-D data
+VARIANTS = {
+    "cdim3_rt": dict(data_dim=(8, 8), invariances=["r", "t"], c_dim=3),
+    "cdim2_none": dict(data_dim=(8, 8), invariances=None, c_dim=2),
+    "gauss_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], sampler_d="gaussian"),
+    "gauss_nosig_r": dict(data_dim=(8, 8), invariances=["r"], sampler_d="gaussian", sigmoid_d=False),
+    "gauss_sig02_t": dict(data_dim=(8, 8), invariances=["t"], sampler_d="gaussian", decoder_sig=0.2),
+    "relu_rt": dict(data_dim=(8, 8), invariances=["r", "t"], activation="relu"),
+    "softplus_s": dict(data_dim=(8, 8), invariances=["s"], activation="softplus"),
+    "lrelu_none": dict(data_dim=(8, 8), invariances=None, activation="lrelu"),
+    "hid64_rt": dict(data_dim=(8, 8), invariances=["r", "t"], hidden_dim_e=[64, 64], hidden_dim_d=[64, 64]),
+    "hid3layers_r": dict(data_dim=(8, 8), invariances=["r"], hidden_dim_e=[128, 64, 32], hidden_dim_d=[32, 48, 16]),
+    "priors_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], dx_prior=0.3, dy_prior=0.05, sc_prior=0.25),
+    "latent5_rt": dict(data_dim=(16, 16), invariances=["r", "t"], latent_dim=5),
+    "1d32_t_cdim2": dict(data_dim=(32,), invariances=["t"], c_dim=2),
+    "rect_12x20_rts": dict(data_dim=(12, 20), invariances=["r", "t", "s"]),
+}
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("vname", sorted(VARIANTS))
+def test_model_variants_vs_oracle(gpu_device, vname, fused):
+    kw = dict(VARIANTS[vname])
+    data_dim = kw.pop("data_dim")
+    inv = kw.pop("invariances")
+    latent_dim = kw.pop("latent_dim", 2)
+    model = pv.models.iVAE(data_dim, latent_dim, inv, seed=3, device="cuda", **kw)
+    he, hd = kw.get("hidden_dim_e") or [128, 128], kw.get("hidden_dim_d") or [128, 128]
+    cfg = orc.Config(data_dim=data_dim, latent_dim=latent_dim, invariances=inv, c_dim=kw.get("c_dim", 0),
+                     n_hidden_e=len(he), n_hidden_d=len(hd), activation=kw.get("activation", "tanh"),
+                     sampler=kw.get("sampler_d", "bernoulli"), sigmoid_d=kw.get("sigmoid_d", True),
+                     dx_prior=kw.get("dx_prior", 0.1), dy_prior=kw.get("dy_prior"), sc_prior=kw.get("sc_prior", 0.1),
+                     decoder_sig=kw.get("decoder_sig", 0.5))
+    eng = model.engine(fused=fused)
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    b = 7
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(b, *data_dim, generator=g)
+    y = None
+    if cfg.c_dim:
+        y = torch.zeros(b, cfg.c_dim)
+        y[torch.arange(b), torch.randint(0, cfg.c_dim, (b,), generator=g)] = 1.0
+    beta = 1.7
+    for k in range(2):
+        eps = torch.randn(b, cfg.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), beta, None if y is None else y.cuda())
+        s = eng.scalars.cpu().numpy()
+        o.step(x, eps, beta, y)
+        np.testing.assert_allclose(s[0], o.last["loss"].item(), rtol=RTOL_ELBO, err_msg="%s loss" % vname)
+        for key in o.p:
+            err = rel_l2(eng.grad_of(key), o.last_grads[key])
+            assert err < RTOL_GRAD, "%s step %d grad %s: rel l2 error %.3e" % (vname, k, key, err)
+        eng.adam_step()
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})     # identical state for the next step
+    # inference API (models/ivae.py:230-275) with the conditioning vector
+    args = (x,) if y is None else (x, y)
+    z_loc, z_scale = model.encode(*args)
+    zl, zs = o.encode(x, y)
+    np.testing.assert_allclose(z_loc.numpy(), zl.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z_scale.numpy(), zs.numpy(), rtol=1e-4, atol=5e-6)
+    zc = zl[:, -latent_dim:]
+    dec = model.decode(zc) if y is None else model.decode(zc, y)
+    np.testing.assert_allclose(dec.numpy(), o.decode(zc, y).numpy(), rtol=1e-4, atol=2e-6)
+
+
 @pytest.mark.parametrize("name", EPOCH_CASES)
 def test_trainer_epochs_vs_golden(gpu_device, name):
     """The product's SVItrainer driven exactly like the reference's (same DataLoader, same seeds):
