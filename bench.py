@@ -6,14 +6,17 @@ bench.py — throughput of the SVI training hot path on MI355X.
   (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
 Workload (BASELINE.json configs[1]): iVAE, data_dim (28, 28), latent_dim 2, invariances ['r','t'],
-Bernoulli likelihood, batch 256 PER GPU (weak scaling), fp32 arithmetic (the parity mode: fp32-input
-MFMA), synthetic data torch.rand(..., seed 0), model/trainer seed 1, random-init weights.
+Bernoulli likelihood, batch 256 PER GPU (weak scaling); decoder contractions on the bf16 MFMA in split
+precision ("bf16x3": hi+lo operands, 3 products, fp32 accumulate — fp32-class results, the 1e-4 parity mode;
+--fused 1 selects the f32-input MFMA kernel, --fused 0 the layer-by-layer path), fp32 everywhere
+else; synthetic data torch.rand(..., seed 0), model/trainer seed 1, random-init weights.
 A step = Trace_ELBO loss + gradients over one minibatch already resident in HBM
 (pv_ivae_loss_and_grads) + [one all-reduce of the flat gradient when N > 1] + Adam (pv_adam_step).
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline     the dominant kernel against the fp32-MFMA roof, its duration measured with HIP
-               events recorded on the launch stream inside the timed region,
+  roofline     the dominant kernel (the fused decoder kernel) against the dense MFMA peak of the instruction it
+               runs on, its duration measured with HIP events recorded on the launch stream inside the timed
+               region (every 8th step: an event pair costs ~10 us of stream bubbles),
   cpu_baseline the CPU oracle (eager-torch restatement of the reference) timed on this host's cores
                on a bounded sample of the same workload (rank 0, N = 1 only),
   elbo         per-image loss of the first timed step next to the oracle's value on the same inputs.
@@ -39,8 +42,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* f32-in peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the guide's
-# gfx950 correction + WRITE_SIZE, KiB -> bytes), batch 256: see profiles/r01_pmc_*.txt.  None: not collected.
-TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1359 * 1024 + 37579 * 1024}
+# gfx950 correction + WRITE_SIZE, KiB -> bytes), batch 256: see profiles/r01*_pmc_*.txt.  None: not collected.
+TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1592 * 1024 + 37880 * 1024}   # 2: profiles/r01e_pmc_*
 
 
 def decoder_flops_per_image(n_pix, hidden=128, coord_dim=2):
