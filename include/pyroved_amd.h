@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 1
+#define PV_ABI_VERSION 2
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -78,6 +78,12 @@ typedef struct pv_ivae_plan {
   int32_t fused;          /* spatial-decoder path when the architecture allows a fused persistent kernel:
                              0 layer-by-layer kernels; 1 fused, f32-input MFMA; 2 fused, bf16 split-
                              precision MFMA (x = hi + lo, three products, fp32 accumulate)               */
+  int32_t discrete_dim;   /* models.jiVAE (models/jivae.py:109-220): K classes of the joint discrete latent,
+                             enumerated exactly in the ELBO (TraceEnum_ELBO, trainers/svi.py:83-90); 0: iVAE.
+                             Then `head` has out_dim 2*z_dim + K (fc13 appended, softmax -> alpha), fc_latent
+                             in_dim latent_dim + K, and the decoder runs on K*B rows ordered [k][b]           */
+  float   beta_disc;      /* scale_factor of the discrete KL term (jivae.py:161-165); `beta` scales the
+                             continuous one                                                                  */
   /* ---- networks ---- */
   int32_t  n_enc;                  /* hidden layers of encoder_z.fc_layers (fc.py:44-45)  */
   int32_t  n_dec;                  /* hidden layers of decoder.fc_layers                  */
@@ -104,7 +110,8 @@ typedef struct pv_ivae_plan {
   float*       scalars;   /* out, 4 floats: loss, sum log p(x|z), beta*sum log p(z), beta*sum log q(z|x) */
   float*       z_loc;     /* out (B, z_dim), may be NULL                                  */
   float*       z_scale;   /* out (B, z_dim), may be NULL                                  */
-  float*       loc;       /* out (B, N) decoder output, may be NULL                       */
+  float*       loc;       /* out (B, N) decoder output, may be NULL ((K*B, N) for jiVAE)  */
+  float*       alpha;     /* out (B, discrete_dim) class probabilities q(k|x), may be NULL */
   /* ---- Adam (torch.optim.Adam defaults via pyro.optim.Adam, svi.py:79-81) ---- */
   float   lr, adam_beta1, adam_beta2, adam_eps;
   int32_t adam_step;      /* 1-based step count of THIS update                            */
@@ -142,7 +149,7 @@ int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n,
 int pv_ivae_step(const pv_ivae_plan* plan, void* stream);
 
 /* baseVAE._encode inner call (models/base.py:131-135): encoder_z(x[,y]) ->
- * z_loc, z_scale (B, z_dim) each. */
+ * z_loc, z_scale (B, z_dim) each; jiVAE: also plan->alpha (B, discrete_dim) when not NULL. */
 int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream);
 
 /* baseVAE._decode inner call (models/base.py:153-170): decoder(grid', z) with the

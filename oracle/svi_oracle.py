@@ -46,6 +46,8 @@ reference's tests nor a runnable Pyro hold a number.
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import math
+
 import torch
 import torch.nn.functional as F
 import torch.distributions as td
@@ -59,6 +61,7 @@ class Config:
     latent_dim: int = 2
     invariances: Optional[Sequence[str]] = None
     c_dim: int = 0
+    discrete_dim: int = 0          # > 0: jiVAE (models/jivae.py), K classes enumerated in the ELBO
     n_hidden_e: int = 2            # number of hidden Linear layers in encoder_z.fc_layers
     n_hidden_d: int = 2
     activation: str = "tanh"
@@ -177,6 +180,16 @@ def encoder_forward(p: Params, cfg: Config, x, y=None):
     return mu, sigma
 
 
+def jencoder_forward(p: Params, cfg: Config, x):
+    """jfcEncoderNet.forward (nets/fc.py:97-108): (mu, softplus sigma, softmax alpha)."""
+    act = _ACT[cfg.activation]
+    h = _fc_stack(p, "encoder_z.fc_layers", cfg.n_hidden_e, act, x.reshape(x.shape[0], -1))
+    mu = F.linear(h, p["encoder_z.fc11.weight"], p["encoder_z.fc11.bias"])
+    sigma = F.softplus(F.linear(h, p["encoder_z.fc12.weight"], p["encoder_z.fc12.bias"]))
+    alpha = torch.softmax(F.linear(h, p["encoder_z.fc13.weight"], p["encoder_z.fc13.bias"]), dim=-1)
+    return mu, sigma, alpha
+
+
 def sdecoder_forward(p: Params, cfg: Config, x_coord, z):
     """sDecoderNet.forward + coord_latent.forward (nets/fc.py:189-199, 220-237)."""
     act = _ACT[cfg.activation]
@@ -251,6 +264,40 @@ def elbo(p: Params, cfg: Config, x, eps, beta=1.0, y=None, grid=None):
                 loc=loc, x_coord_prime=xc, ll_per_sample=ll)
 
 
+def jelbo(p: Params, cfg: Config, x, eps, beta=1.0, grid=None):
+    """TraceEnum_ELBO of jiVAE.guide/model (models/jivae.py:152-220) with the guide's OneHotCategorical site
+    enumerated in parallel (trainers/svi.py:83-90):
+
+    loss = -sum_b [ b0*(log N(z_b;0,1) - log N(z_b;mu_b,sigma_b))
+                    + sum_k alpha_bk * ( log p(x_b | z_b, k) + b1*log(1/K) - b1*log alpha_bk ) ]
+    z = mu + sigma*eps;  the decoder runs on K*B rows ordered [k][b] (z.repeat(K, 1), jivae.py:181) with the one-hot
+    class appended to the content part of z (jivae.py:189-192); scale_factor: scalar -> both, [cont, disc].
+    """
+    if cfg.coord == 0:
+        raise NotImplementedError("oracle: jiVAE without invariances (fcDecoderNet) is not restated")
+    b0, b1 = (beta, beta) if not isinstance(beta, (list, tuple)) else beta
+    bsz, K = x.shape[0], cfg.discrete_dim
+    z_loc, z_scale, alpha = jencoder_forward(p, cfg, x)
+    z = z_loc + z_scale * eps
+    logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)
+    logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)
+    z_disc = torch.eye(K, dtype=z.dtype).repeat_interleave(bsz, 0)              # (K*B, K): rows [k][b] = onehot(k)
+    loc, xc = decode_from_latent(p, cfg, z.repeat(K, 1), z_disc, grid)
+    ll = likelihood(cfg, loc.reshape(K, bsz, -1)).log_prob(x.reshape(bsz, -1)).sum(-1)       # (K, B)
+    w = alpha.t()                                                                           # q(k | x_b), (K, B)
+    logq_d = td.OneHotCategorical(probs=alpha).log_prob(torch.eye(K, dtype=z.dtype).unsqueeze(1))   # (K, B)
+    logp_d = torch.full_like(logq_d, -math.log(K))
+    t_ll = (w * ll).sum()
+    t_lp = (b0 * logp).sum() + (w * b1 * logp_d).sum()
+    t_lq = (b0 * logq).sum() + (w * b1 * logq_d).sum()
+    loss = -(t_ll + t_lp - t_lq)
+    return dict(loss=loss, ll=t_ll, logpz=t_lp, logqz=t_lq, z_loc=z_loc, z_scale=z_scale, z=z, alpha=alpha,
+                loc=loc, x_coord_prime=xc, ll_per_sample=ll,
+                terms={"model.latent_cont": (b0 * logp).sum(), "model.latent_disc": (w * b1 * logp_d).sum(),
+                       "model.obs": t_ll, "guide.latent_cont": (b0 * logq).sum(),
+                       "guide.latent_disc": (w * b1 * logq_d).sum()})
+
+
 def param_order(p: Params, cfg: Config) -> List[str]:
     """state_dict order == construction order."""
     return list(p.keys())
@@ -272,8 +319,11 @@ class SVIOracle:
         self.last_grads = None
 
     def loss_and_grads(self, x, eps, beta=1.0, y=None):
-        out = elbo(self.p, self.cfg, x.to(self.dtype), eps.to(self.dtype), beta,
-                   None if y is None else y.to(self.dtype), self.grid)
+        if self.cfg.discrete_dim > 0:
+            out = jelbo(self.p, self.cfg, x.to(self.dtype), eps.to(self.dtype), beta, self.grid)
+        else:
+            out = elbo(self.p, self.cfg, x.to(self.dtype), eps.to(self.dtype), beta,
+                       None if y is None else y.to(self.dtype), self.grid)
         if out["loss"].requires_grad:
             out["loss"].backward()
         self.last = out
@@ -317,6 +367,8 @@ class SVIOracle:
     # inference API (models/base.py:121-171, models/ivae.py:230-275)
     def encode(self, x, y=None):
         with torch.no_grad():
+            if self.cfg.discrete_dim > 0:
+                return jencoder_forward(self.p, self.cfg, x.to(self.dtype))      # (mu, sigma, alpha)
             return encoder_forward(self.p, self.cfg, x.to(self.dtype), y)
 
     def decode(self, z, y=None, angle=0.0, shift=0.0, scale=1.0):

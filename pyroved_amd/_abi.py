@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 1
+PV_ABI_VERSION = 2
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -36,6 +36,7 @@ class pv_ivae_plan(C.Structure):
         ("has_r", C.c_int32), ("has_t", C.c_int32), ("has_s", C.c_int32),
         ("t_prior", C.c_float * 2), ("sc_prior", C.c_float), ("beta", C.c_float),
         ("lik", C.c_int32), ("sigmoid_out", C.c_int32), ("decoder_sig", C.c_float), ("fused", C.c_int32),
+        ("discrete_dim", C.c_int32), ("beta_disc", C.c_float),
         ("n_enc", C.c_int32), ("n_dec", C.c_int32),
         ("enc", pv_layer * PV_MAX_LAYERS), ("head", pv_layer),
         ("fc_coord", pv_layer), ("fc_latent", pv_layer),
@@ -45,6 +46,7 @@ class pv_ivae_plan(C.Structure):
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p), ("grid", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
+        ("alpha", C.c_void_p),
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),

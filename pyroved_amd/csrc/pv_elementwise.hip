@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void pv_head_fwd_kernel(PvHead h) {
   float lp = 0.0f, lq = 0.0f;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int b = e / h.z_dim, i = e % h.z_dim;
-    const float mu = h.head[(int64_t)b * 2 * h.z_dim + i];
-    const float sp = h.head[(int64_t)b * 2 * h.z_dim + h.z_dim + i];
+    const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
+    const float mu = h.head[(int64_t)b * ldh + i];
+    const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
     const float sig = pv_softplus(sp);
     const float ep = h.eps[e];
     const float z = mu + sig * ep;
@@ -446,12 +447,13 @@ __device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int 
   }
   const int e = b * h.z_dim + i;
   const float z = h.z[e], sig = h.z_scale[e], ep = h.eps[e];
-  const float sp = h.head[(int64_t)b * 2 * h.z_dim + h.z_dim + i];
+  const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
+  const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
   const float g = dz + h.beta * z;                 // d(-ll - beta*log p(z))/dz
   const float dsig = g * ep - h.beta / sig;        // + beta * d(log q)/d(sigma) (total derivative)
   const float sgm = sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp));   // softplus'
-  h.dhead[(int64_t)b * 2 * h.z_dim + i] = g;
-  h.dhead[(int64_t)b * 2 * h.z_dim + h.z_dim + i] = dsig * sgm;
+  h.dhead[(int64_t)b * ldh + i] = g;
+  h.dhead[(int64_t)b * ldh + h.z_dim + i] = dsig * sgm;
 }
 
 __global__ void pv_head_bwd_kernel(PvHeadBwd h) {
@@ -471,6 +473,23 @@ int pv_head_bwd(const PvHeadBwd& h, hipStream_t s) {
   return 0;
 }
 
+// alpha[b][:] = softmax(logits[b][:])  (jfcEncoderNet.forward, nets/fc.py:106) for pv_ivae_encode
+__global__ void pv_softmax_rows_kernel(const float* __restrict__ logits, int64_t ld, int B, int K, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* l = logits + (int64_t)b * ld;
+  float mx = l[0];
+  for (int k = 1; k < K; ++k) mx = fmaxf(mx, l[k]);
+  float s = 0.0f;
+  for (int k = 0; k < K; ++k) s += expf(l[k] - mx);
+  for (int k = 0; k < K; ++k) out[(int64_t)b * K + k] = expf(l[k] - mx) / s;
+}
+int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pv_softmax_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, logits, ld, B, K, out);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
 // latent_bwd (fused decoder path): one workgroup per sample gathers everything that flows from the decoder
 // kernel back into that sample's latent code: ll_b and d(phi, scale, tx, ty) (sums over the sample's N rows),
 // dL/d(hz[b]) (sum of the workgroup partials), dL/d(z content) = dhz Wz, then head_bwd.  Fixed-order sums.
@@ -479,28 +498,47 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   __shared__ float sh_dhz[512];
   __shared__ float sh_dzc[64];
   __shared__ float sh_tp[4];
+  __shared__ float sh_ll[128];
   const int t = threadIdx.x;
-  const int64_t r0 = (int64_t)b * p.N;
-  float a[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  for (int n = t; n < p.N; n += 256) {
-    a[0] += p.llrow[r0 + n];
+  const int K = p.K > 0 ? p.K : 1, Bq = p.hb.B;
+  float tp_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int j = t; j < p.H; j += 256) sh_dhz[j] = 0.0f;
+  for (int k = 0; k < K; ++k) {
+    const int64_t s = (int64_t)k * Bq + b;            // decoder sample (k, b)
+    const int64_t r0 = s * p.N;
+    float a[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int n = t; n < p.N; n += 256) {
+      a[0] += p.llrow[r0 + n];
+      if (!p.fwd_only) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a[1 + c] += p.rowtp[(int64_t)c * p.M + r0 + n];
-  }
+        for (int c = 0; c < 4; ++c) a[1 + c] += p.rowtp[(int64_t)c * p.M + r0 + n];
+      }
+    }
+    a[0] = block_sum_256(a[0], sm);
+    if (t == 0) sh_ll[k] = a[0];
+    if (p.fwd_only) continue;
 #pragma unroll
-  for (int c = 0; c < 5; ++c) a[c] = block_sum_256(a[c], sm);
-  if (t == 0) {
-    p.llb[b] = a[0];
-    for (int c = 0; c < 4; ++c) sh_tp[c] = a[1 + c];
-  }
-  for (int j = t; j < p.H; j += 256) {
-    float v = 0.0f;
-    for (int k = 0; k < p.kmax; ++k) v += p.part_hz[((int64_t)b * p.kmax + k) * p.H + j];
-    p.dhz[(int64_t)b * p.H + j] = v;
-    sh_dhz[j] = v;
+    for (int c = 0; c < 4; ++c) tp_acc[c] += block_sum_256(a[1 + c], sm);
+    for (int j = t; j < p.H; j += 256) {
+      float v = 0.0f;
+      for (int kk = 0; kk < p.kmax; ++kk) v += p.part_hz[(s * p.kmax + kk) * p.H + j];
+      p.dhz[s * p.H + j] = v;
+      sh_dhz[j] += v;                                  // the same thread owns j in every pass
+    }
   }
   __syncthreads();
-  for (int i = 0; i < p.lat_in; ++i) {
+  if (t == 0) {
+    float ll = sh_ll[0];
+    if (p.K > 0) {
+      ll = 0.0f;
+      for (int k = 0; k < K; ++k) ll += p.alpha[(int64_t)b * K + k] * sh_ll[k];
+    }
+    p.llb[b] = ll;
+    for (int c = 0; c < 4; ++c) sh_tp[c] = tp_acc[c];
+  }
+  if (p.fwd_only) return;
+  const int n_content = p.lat_in - (p.K > 0 ? p.K : 0);        // the one-hot class columns carry no gradient to z
+  for (int i = 0; i < n_content; ++i) {
     float v = 0.0f;
     for (int j = t; j < p.H; j += 256) v += sh_dhz[j] * p.Wz[j * p.lat_in + i];
     v = block_sum_256(v, sm);
@@ -509,6 +547,22 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   __syncthreads();
   if (t < p.hb.z_dim)
     pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; });
+  if (p.K > 0 && t == 0) {
+    // loss = -sum_k alpha_k (ll_k + b1 log(1/K) - b1 log alpha_k):  dloss/dalpha_k = -(ll_k - b1 log K - b1 log alpha_k - b1)
+    // then softmax backward: dlogit_k = alpha_k (dalpha_k - sum_j alpha_j dalpha_j)
+    const float b1 = p.beta_disc, lK = logf((float)K);
+    const float* al = p.alpha + (int64_t)b * K;
+    float dot = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      const float da = -(sh_ll[k] - b1 * lK - b1 * logf(al[k]) - b1);
+      dot += al[k] * da;
+    }
+    const int ldh = p.hb.ldh > 0 ? p.hb.ldh : 2 * p.hb.z_dim;
+    for (int k = 0; k < K; ++k) {
+      const float da = -(sh_ll[k] - b1 * lK - b1 * logf(al[k]) - b1);
+      p.hb.dhead[(int64_t)b * ldh + 2 * p.hb.z_dim + k] = al[k] * (da - dot);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void pv_latent_bwd_kernel(PvLatentBwd p) { pv_latent_bwd_block(p, blockIdx.x); }
@@ -525,7 +579,7 @@ __global__ __launch_bounds__(256) void pv_latent_bwd_reduce_kernel(PvLatentBwd p
 
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
                          hipStream_t s) {
-  if (p.H > 512 || p.lat_in > 64 || p.hb.z_dim > 256) return PV_EINVAL;
+  if (p.H > 512 || p.lat_in > 64 + (p.K > 0 ? p.K : 0) || p.hb.z_dim > 256 || p.K > 128) return PV_EINVAL;
   hipLaunchKernelGGL(pv_latent_bwd_reduce_kernel, dim3(PV_FUSED_REDUCE_BLOCKS + p.hb.B), dim3(256), 0, s, p, part, grid,
                      G, o, cd);
   PV_LAUNCH_CHECK();
@@ -533,7 +587,7 @@ int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, floa
 }
 
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s) {
-  if (p.H > 512 || p.lat_in > 64 || p.hb.z_dim > 256) return PV_EINVAL;
+  if (p.H > 512 || p.lat_in > 64 + (p.K > 0 ? p.K : 0) || p.hb.z_dim > 256 || p.K > 128) return PV_EINVAL;
   hipLaunchKernelGGL(pv_latent_bwd_kernel, dim3(p.hb.B), dim3(256), 0, s, p);
   PV_LAUNCH_CHECK();
   return 0;

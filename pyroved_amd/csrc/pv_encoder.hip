@@ -200,11 +200,34 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       act[cur ^ 1][rr][i] = z;                     // keep z for the split below
     }
   }
+  // ---- jiVAE: alpha = softmax(class logits) (nets/fc.py:106); discrete KL terms; decoder row weights ----
+  const int K = e.K;
+  float lpd = 0.0f, lqd = 0.0f;
+  if (K > 0 && tid < EN_ROWS && row0 + tid < e.B) {
+    const int row = row0 + tid;
+    const float* lg = &act[cur][tid][2 * zd];
+    float mx = lg[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[k]);
+    float se = 0.0f;
+    for (int k = 0; k < K; ++k) se += expf(lg[k] - mx);
+    const float lse = logf(se);
+    for (int k = 0; k < K; ++k) {
+      const float la = lg[k] - mx - lse, a = expf(la);      // log_softmax, softmax
+      e.alpha[(int64_t)row * K + k] = a;
+      e.sw[(int64_t)k * e.B + row] = a;
+      lqd += a * la;                                         // sum_k alpha log alpha
+    }
+    lpd = -logf((float)K);                                   // sum_k alpha log(1/K)
+  }
   lp = en_block_sum(lp, sm);
   lq = en_block_sum(lq, sm);
+  if (K > 0) {
+    lpd = en_block_sum(lpd, sm);
+    lqd = en_block_sum(lqd, sm);
+  }
   if (tid == 0) {
-    e.kl_part[2 * blockIdx.x] = lp;
-    e.kl_part[2 * blockIdx.x + 1] = lq;
+    e.kl_part[2 * blockIdx.x] = e.beta * lp + e.beta_disc * lpd;
+    e.kl_part[2 * blockIdx.x + 1] = e.beta * lq + e.beta_disc * lqd;
   }
   __syncthreads();
   cur ^= 1;                                         // act[cur][rr][0..zd) = z
@@ -212,7 +235,8 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
   int coord = 0;
   if (e.coord_dim == 1) coord = e.has_t ? 1 : 0;
   else if (e.coord_dim == 2) coord = e.has_r + 2 * e.has_t + e.has_s;
-  const int L = zd - coord, lat_in = L + e.c_dim;
+  const int L = zd - coord, lat_in = L + e.c_dim + (K > 0 ? K : 0);
+  const int KK = K > 0 ? K : 1;                     // decoder samples per input: (k, b) at row k*B + b
   if (tid < EN_ROWS && row0 + tid < e.B) {
     const int row = row0 + tid;
     const float* zb = &act[cur][tid][0];
@@ -225,14 +249,18 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       if (e.has_t) { tx = zb[idx] * e.tp0; ty = zb[idx + 1] * e.tp1; idx += 2; }
       if (e.has_s) { sc = 1.0f + e.sc_prior * zb[idx++]; }
     }
-    if (e.tp) {
-      float* t = e.tp + (int64_t)row * 8;
-      t[0] = c; t[1] = s; t[2] = sc; t[3] = tx; t[4] = ty;
-    }
-    if (e.zy) {
-      float* o = e.zy + (int64_t)row * lat_in;
-      for (int i = 0; i < L; ++i) o[i] = zb[coord + i];
-      for (int i = 0; i < e.c_dim; ++i) o[L + i] = e.y[(int64_t)row * e.c_dim + i];
+    for (int k = 0; k < KK; ++k) {
+      const int64_t srow = (int64_t)k * e.B + row;
+      if (e.tp) {
+        float* t = e.tp + srow * 8;
+        t[0] = c; t[1] = s; t[2] = sc; t[3] = tx; t[4] = ty;
+      }
+      if (e.zy) {
+        float* o = e.zy + srow * lat_in;
+        for (int i = 0; i < L; ++i) o[i] = zb[coord + i];
+        for (int i = 0; i < e.c_dim; ++i) o[L + i] = e.y[(int64_t)row * e.c_dim + i];
+        for (int i = 0; i < K; ++i) o[L + e.c_dim + i] = i == k ? 1.0f : 0.0f;        // one-hot class (jivae.py:189)
+      }
     }
   }
   // ---- hz = fc_latent(cat(z_content, y)) (no bias; fc.py:217,230) ----
@@ -244,7 +272,11 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       float v = 0.0f;
       for (int i = 0; i < L; ++i) v += act[cur][rr][coord + i] * wz[i];
       for (int i = 0; i < e.c_dim; ++i) v += e.y[(int64_t)row * e.c_dim + i] * wz[L + i];
-      e.hz[(int64_t)row * e.H0 + j] = v;
+      if (K > 0) {
+        for (int k = 0; k < K; ++k) e.hz[((int64_t)k * e.B + row) * e.H0 + j] = v + wz[L + e.c_dim + k];
+      } else {
+        e.hz[(int64_t)row * e.H0 + j] = v;
+      }
     }
   }
 }
@@ -260,7 +292,7 @@ bool pv_enc_compact_supported(const pv_ivae_plan* p) {
     in = l.out_dim;
   }
   if (p->head.in_dim != in || p->head.out_dim > 128 || p->head.w_off % 4 != 0) return false;
-  if (p->z_dim > 64) return false;
+  if (p->z_dim > 64 || p->discrete_dim > 64) return false;
   return true;
 }
 

@@ -16,6 +16,7 @@ struct PvHead {
   float* scalars;        // [.., .., beta*logp, beta*logq]
   int B, z_dim, c_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior, beta;
+  int ldh;               // row stride of head (0: 2*z_dim)
 };
 int pv_head_fwd(const PvHead& h, hipStream_t s);
 int pv_fill_tp(float* tp, int B, float angle, float sc, float tx, float ty, hipStream_t s);
@@ -79,10 +80,11 @@ struct PvHeadBwd {
   const float* z;
   const float* z_scale;
   const float* eps;
-  const float* head;     // (B, 2*z_dim)
-  float* dhead;          // (B, 2*z_dim): [dL/dmu | dL/d(softplus input)]
+  const float* head;     // (B, ldh)
+  float* dhead;          // (B, ldh): [dL/dmu | dL/d(softplus input) | (jiVAE) dL/d(class logits)]
   int B, z_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior, beta;
+  int ldh;               // row stride of head / dhead (0: 2*z_dim)
 };
 int pv_head_bwd(const PvHeadBwd& h, hipStream_t s);
 
@@ -96,8 +98,15 @@ struct PvLatentBwd {
   int64_t M;
   int N, kmax, H, lat_in;
   PvHeadBwd hb;          // dzc / dtp fields unused (values stay in LDS)
+  // jiVAE (K > 0): the decoder ran on K*B samples ordered [k][b] with its rows already weighted by alpha[b][k];
+  // llb[b] = sum_k alpha_bk ll_kb, and the class logits get their gradient (softmax backward) in dhead[:, 2z..]
+  int K;                 // 0: iVAE
+  const float* alpha;    // (B, K)
+  float beta_disc;
+  int fwd_only;          // 1: only llb (evaluation)
 };
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
+int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, hipStream_t s);
 struct PvFusedOffsets;
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
                          hipStream_t s);
@@ -150,6 +159,10 @@ struct PvEncFwd {
   float* hz; const float* Wz; int H0;     // fc_latent (null hz: skip)
   int B, z_dim, c_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior;
+  float beta, beta_disc;            // the KL partials in kl_part are stored scaled by these
+  // jiVAE (K > 0): head = [mu | softplus input | class logits]; alpha = softmax(logits); tp, zy, hz are written for
+  // the K*B decoder samples ordered [k][b] (zy = [z content | onehot(k)]); sw[k*B + b] = alpha[b][k]
+  int K; float* alpha; float* sw;
   PvFbPrep prep;                    // hosted in the first-layer launch when prep.img is set (bf16x3 decoder path)
 };
 bool pv_enc_compact_supported(const pv_ivae_plan* p);

@@ -36,6 +36,7 @@ struct Layout {
   float* logits; float* llrow; float* llb; float* dbuf[2];
   float* part_dwo; float* part_dbo; float* part_hz; float* part_wc; float* part_tp;
   float* dhz; float* dtp; float* dzc;
+  float* alpha; float* sw;                 // jiVAE: class probabilities (B, K), decoder row weights (K*B)
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
@@ -45,11 +46,20 @@ struct Layout {
   int64_t total;
 };
 
+// jiVAE (discrete_dim = K > 0): K decoder samples per input, ordered [k][b]; head = [mu | softplus input | class logits]
+static inline int64_t plan_K(const pv_ivae_plan* p) { return p->discrete_dim > 0 ? p->discrete_dim : 0; }
+static inline int64_t plan_S(const pv_ivae_plan* p) { return (plan_K(p) > 0 ? plan_K(p) : 1) * (int64_t)p->batch; }
+static inline int64_t plan_head_w(const pv_ivae_plan* p) { return 2 * (int64_t)p->z_dim + plan_K(p); }
+static inline int64_t plan_lat_in(const pv_ivae_plan* p) {
+  return (p->coord_dim > 0 ? p->latent_dim : p->z_dim) + p->c_dim + plan_K(p);
+}
+
 bool valid_plan(const pv_ivae_plan* p) {
   if (!p || p->batch <= 0 || p->n_pix <= 0 || p->z_dim <= 0) return false;
   if (p->coord_dim < 0 || p->coord_dim > 2) return false;
   if (p->n_enc < 1 || p->n_enc > PV_MAX_LAYERS || p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
-  if (p->head.out_dim != 2 * p->z_dim) return false;
+  if (p->discrete_dim < 0 || p->head.out_dim != plan_head_w(p)) return false;
+  if (p->discrete_dim > 0 && (p->coord_dim == 0 || p->c_dim != 0)) return false;   // jiVAE: spatial decoder, no y
   if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN) return false;
   if (p->lik == PV_LIK_BERNOULLI && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
   if (p->coord_dim > 0 && p->out.out_dim != 1) return false;
@@ -57,11 +67,12 @@ bool valid_plan(const pv_ivae_plan* p) {
   return true;
 }
 
-void carve(const pv_ivae_plan* p, char* base, Layout& L) {
+// inference_only: encode / decode process B samples (jiVAE's K-fold enumeration exists only in the training step)
+void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = false) {
   Carver c{base, 0};
   const int64_t B = p->batch, N = p->n_pix, z = p->z_dim;
-  const int64_t lat_in = (p->coord_dim > 0 ? p->latent_dim : p->z_dim) + p->c_dim;
-  L.rows = p->coord_dim > 0 ? B * N : B;
+  const int64_t lat_in = plan_lat_in(p), K = plan_K(p), S = inference_only ? p->batch : plan_S(p), hw = plan_head_w(p);
+  L.rows = p->coord_dim > 0 ? S * N : B;
   const int64_t R = L.rows;
   L.xin = p->c_dim > 0 ? c.take(B * (N + p->c_dim)) : nullptr;
   int64_t maxe = 0;
@@ -70,12 +81,14 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
     L.epre[i] = p->enc[i].act == PV_ACT_GELU ? c.take(B * p->enc[i].out_dim) : nullptr;
     if (p->enc[i].out_dim > maxe) maxe = p->enc[i].out_dim;
   }
-  L.head = c.take(B * 2 * z);
-  L.dhead = c.take(B * 2 * z);
+  L.head = c.take(B * hw);
+  L.dhead = c.take(B * hw);
   L.z = c.take(B * z);
   L.z_scale = c.take(B * z);
-  L.tp = c.take(B * 8);
-  L.zy = p->c_dim > 0 ? c.take(B * lat_in) : nullptr;
+  L.tp = c.take(S * 8);
+  L.zy = (p->c_dim > 0 || K > 0) ? c.take(S * lat_in) : nullptr;
+  L.alpha = K > 0 ? c.take(B * K) : nullptr;
+  L.sw = K > 0 ? c.take(S) : nullptr;
   for (int i = 0; i < p->n_enc; ++i) L.edp[i] = c.take(B * p->enc[i].out_dim);
   L.enc_compact = pv_enc_compact_supported(p);
   L.kl_blocks = (int)((B + 15) / 16);
@@ -94,14 +107,14 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
   if (p->coord_dim > 0) {
     const int64_t H0 = p->fc_coord.out_dim;
     if (H0 > maxd) maxd = H0;
-    L.hz = c.take(B * H0);
+    L.hz = c.take(S * H0);
     L.h0 = L.fused ? nullptr : c.take(R * H0);
     if (L.fused) {
       const int64_t units = R / FD_UNIT;
       L.f_grid = pv_sdec_fused_grid(units);
       L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
-      L.f_part_hz = c.take(B * L.f_kmax * H0);
+      L.f_part_hz = c.take(S * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);
       L.f_wimg = c.take(FB_WIMG_BYTES / (int64_t)sizeof(float));
       upd(pv_colsum_ws(B, (int)H0));
@@ -120,7 +133,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
     L.part_hz = c.take(B * L.nchunk * H0);
     L.part_wc = c.take(B * L.nchunk * H0 * p->coord_dim);
     L.part_tp = c.take(B * L.nchunk * 4);
-    L.dhz = c.take(B * H0);
+    L.dhz = c.take(S * H0);
     L.dtp = c.take(B * 4);
     L.dzc = c.take(B * lat_in);
     upd(gemm_ws_need(B, H0, lat_in));          // hz
@@ -149,10 +162,10 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L) {
     upd(gemm_ws_need(B, p->enc[i].in_dim, p->enc[i].out_dim));
     upd(pv_colsum_ws(B, p->enc[i].out_dim));
   }
-  upd(gemm_ws_need(B, 2 * z, p->head.in_dim));
-  upd(gemm_ws_need(2 * z, p->head.in_dim, B));
-  upd(gemm_ws_need(B, p->head.in_dim, 2 * z));
-  upd(pv_colsum_ws(B, (int)(2 * z)));
+  upd(gemm_ws_need(B, hw, p->head.in_dim));
+  upd(gemm_ws_need(hw, p->head.in_dim, B));
+  upd(gemm_ws_need(B, p->head.in_dim, hw));
+  upd(pv_colsum_ws(B, (int)hw));
   for (int i = 0; i < p->n_dec; ++i) {
     upd(gemm_ws_need(R, p->dec[i].out_dim, p->dec[i].in_dim));
     upd(gemm_ws_need(p->dec[i].out_dim, p->dec[i].in_dim, R));
@@ -305,8 +318,8 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     }
     PV_TRY(pv_enc_dgrad(d, s));
   } else {
-    PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + hd.w_off, L.edp[ne - 1], hd.in_dim, elast, L.epre[ne - 1],
-                        hd.in_dim, p->enc[ne - 1].act, B, hd.in_dim, 2 * z, ws, wsb, s));
+    PV_TRY(linear_dgrad(L.dhead, hd.out_dim, p->params + hd.w_off, L.edp[ne - 1], hd.in_dim, elast, L.epre[ne - 1],
+                        hd.in_dim, p->enc[ne - 1].act, B, hd.in_dim, hd.out_dim, ws, wsb, s));
     for (int i = ne - 1; i > 0; --i) {
       const pv_layer& l = p->enc[i];
       PV_TRY(linear_dgrad(L.edp[i], l.out_dim, p->params + l.w_off, L.edp[i - 1], l.in_dim, L.eact[i - 1],
@@ -317,8 +330,8 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
   PvGemm probs[PV_MAX_LAYERS + 4];
   int np = 0;
   for (int i = 0; i < n_extra; ++i) probs[np++] = extra[i];
-  probs[np++] = wgrad_problem(L.dhead, 2 * z, elast, hd.in_dim, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr,
-                              B, hd.in_dim, 2 * z);
+  probs[np++] = wgrad_problem(L.dhead, hd.out_dim, elast, hd.in_dim, G + hd.w_off,
+                              hd.b_off >= 0 ? G + hd.b_off : nullptr, B, hd.in_dim, hd.out_dim);
   const float* xin = p->c_dim > 0 ? L.xin : p->x;
   const int64_t ldx = p->n_pix + p->c_dim;
   for (int i = ne - 1; i >= 0; --i) {
@@ -366,13 +379,14 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     e.eps = p->eps; e.y = p->y; e.head_out = L.head; e.z = L.z; e.z_scale = L.z_scale;
     e.z_loc_out = p->z_loc; e.z_scale_out = p->z_scale;
     e.tp = p->coord_dim > 0 ? L.tp : nullptr; e.zy = L.zy; e.kl_part = L.kl_part;
+    e.beta = p->beta; e.beta_disc = p->beta_disc; e.K = (int)plan_K(p); e.alpha = L.alpha; e.sw = L.sw;
     if (p->coord_dim > 0) { e.hz = L.hz; e.Wz = p->params + p->fc_latent.w_off; e.H0 = p->fc_coord.out_dim; }
     e.B = p->batch; e.z_dim = p->z_dim; e.c_dim = p->c_dim; e.coord_dim = p->coord_dim;
     e.has_r = p->has_r; e.has_t = p->has_t; e.has_s = p->has_s;
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;
     return pv_enc_fwd(e, s);
   }
-  if (prep) return PV_EINVAL;                    // (callers run the stand-alone preparation on this path)
+  if (prep || plan_K(p) > 0) return PV_EINVAL;    // (stand-alone preparation on this path; jiVAE needs the compact encoder)
   PV_TRY(encoder_fwd(p, L, s));
   PvHead h{};
   h.head = L.head; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
@@ -387,13 +401,16 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
 // loss_and_grads with the fused persistent spatial-decoder kernel (pv_sdec_fused.hip)
 int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
   const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
-  const int64_t lat_in = p->latent_dim + p->c_dim;
+  const int64_t K = plan_K(p), S = plan_S(p);        // jiVAE: S = K*B decoder samples, rows R = S*N
+  const int64_t lat_in = plan_lat_in(p);
   const int H = FD_H;
   float* G = p->grads;
   const int coord = (int)(z - p->latent_dim);
-  const float* zin = p->c_dim > 0 ? L.zy : L.z + coord;
-  const int64_t ldz = p->c_dim > 0 ? lat_in : z;
+  const bool cat_in = p->c_dim > 0 || K > 0;         // the decoder's latent input is a materialised concatenation
+  const float* zin = cat_in ? L.zy : L.z + coord;
+  const int64_t ldz = cat_in ? lat_in : z;
   if (p->fc_latent.in_dim != lat_in) return PV_EINVAL;
+  if (K > 0 && !L.enc_compact) return PV_EINVAL;
   PvFused f{};
   f.x = p->x; f.grid = p->grid; f.tp = L.tp; f.hz = L.hz;
   f.Wc = p->params + p->fc_coord.w_off; f.bc = p->params + p->fc_coord.b_off;
@@ -402,7 +419,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.wo = p->params + p->out.w_off; f.bo = p->params + p->out.b_off;
   f.llrow = L.llrow; f.loc = p->loc; f.rowtp = L.f_rowtp; f.part_hz = L.f_part_hz; f.part = L.f_part;
   f.wimg = L.f_wimg;
-  f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)B; f.lik = p->lik;
+  f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)S; f.lik = p->lik;
+  f.sw = L.sw; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
   // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
   if (p->fused == 2 && L.enc_compact) {
@@ -413,7 +431,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     if (p->fused == 2) {
       PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, s));
     } else if (want_grads) {
-      hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(B * L.f_kmax * H) * sizeof(float), s);
+      hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(S * L.f_kmax * H) * sizeof(float), s);
       if (e != hipSuccess) return (int)e;
     }
   }
@@ -424,9 +442,16 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   if (p->fused == 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, s));
   else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
   if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_stop, s);
+  if (!want_grads && K > 0) {                        // llb[b] = sum_k alpha_bk ll_kb
+    PvLatentBwd lf{};
+    lf.llrow = L.llrow; lf.llb = L.llb; lf.M = R; lf.N = (int)N; lf.H = 0; lf.K = (int)K; lf.alpha = L.alpha;
+    lf.hb.B = (int)B; lf.fwd_only = 1;
+    PV_TRY(pv_latent_bwd(lf, s));
+    return pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, L.kl_blocks, 1.0f, s);
+  }
   if (!want_grads) {
     PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
-    return pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta, s);
+    return pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s);
   }
   PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
                    p->fc_coord.w_off, p->out.w_off, p->out.b_off};
@@ -440,16 +465,20 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
   hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
   hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
+  hb.ldh = (int)plan_head_w(p);
+  lb.K = (int)K; lb.alpha = L.alpha; lb.beta_disc = p->beta_disc;
   PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s));
   // the loss scalars ride in the encoder dgrad launch (compact encoder) or get their own
-  PvFinish fin{L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta};
+  PvFinish fin{L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* scaled */};
   if (!L.enc_compact) PV_TRY(pv_finish_scalars(fin.llb, fin.B, fin.scalars, fin.kl_part, fin.n_part, fin.beta, s));
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
-  const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, B, lat_in, H);
+  // (jiVAE: over the K*B decoder samples, zin = [z content | onehot(k)])
+  const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
   return encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr);
 }
 
 int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
+  if (plan_K(p) > 0) return PV_EINVAL;             // jiVAE runs on the fused decoder kernels only
   const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
   const int64_t lat_in = (p->coord_dim > 0 ? p->latent_dim : p->z_dim) + p->c_dim;
   float* G = p->grads;
@@ -481,7 +510,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
                        want_grads ? oth : nullptr, s));
   }
   PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
-  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, p->beta, s));
+  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
   if (!want_grads) return 0;
 
   // ---------------- backward: decoder ----------------
@@ -541,15 +570,31 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
 
 extern "C" int pv_version(void) { return PV_ABI_VERSION; }
 
+// the plan pv_ivae_decode works on: layered layout; jiVAE.decode(z, y) (jivae.py:255-267) is one decoder row block
+// per given (z, one-hot class) pair — the class vector is a conditioning input there, not an enumeration axis
+static pv_ivae_plan decode_plan(const pv_ivae_plan* plan) {
+  pv_ivae_plan lay = *plan;
+  lay.fused = 0;
+  if (lay.discrete_dim > 0) {
+    lay.c_dim += lay.discrete_dim;
+    lay.head.out_dim -= lay.discrete_dim;
+    lay.discrete_dim = 0;
+  }
+  return lay;
+}
+
 extern "C" int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan) {
   if (!valid_plan(plan)) return PV_EINVAL;
   Layout L;
   carve(plan, nullptr, L);
   int64_t total = L.total;
-  if (L.fused) {                      // encode / decode always use the layered layout
+  if (L.fused || plan->discrete_dim > 0) {     // encode / decode always use the layered layout, B samples
     pv_ivae_plan q = *plan;
     q.fused = 0;
-    carve(&q, nullptr, L);
+    carve(&q, nullptr, L, true);
+    if (L.total > total) total = L.total;
+    q = decode_plan(plan);
+    carve(&q, nullptr, L, true);
     if (L.total > total) total = L.total;
   }
   return total;
@@ -583,7 +628,7 @@ extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_s
   lay.fused = 0;
   plan = &lay;
   Layout L;
-  carve(plan, (char*)plan->ws, L);
+  carve(plan, (char*)plan->ws, L, true);
   if (plan->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
   PV_TRY(encoder_fwd(plan, L, s));
@@ -592,22 +637,25 @@ extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_s
   h.head = L.head; h.eps = L.z_scale /* unused values; any valid buffer */; h.z = L.z; h.z_scale = L.z_scale;
   h.z_loc_out = z_loc; h.z_scale_out = z_scale; h.tp = nullptr; h.zy = nullptr; h.scalars = (float*)L.dhead;
   h.B = plan->batch; h.z_dim = plan->z_dim; h.c_dim = 0; h.coord_dim = 0; h.beta = 0.0f;
-  return pv_head_fwd(h, s);
+  h.ldh = (int)plan_head_w(plan);
+  PV_TRY(pv_head_fwd(h, s));
+  if (plan->discrete_dim > 0 && plan->alpha)
+    PV_TRY(pv_softmax_rows(L.head + 2 * plan->z_dim, plan_head_w(plan), plan->batch, plan->discrete_dim, plan->alpha, s));
+  return 0;
 }
 
 extern "C" int pv_ivae_decode(const pv_ivae_plan* plan, const float* z, float angle, float shift_x, float shift_y,
                               float scale, float* loc, void* stream) {
   if (!valid_plan(plan) || !plan->params || !plan->ws || !z || !loc) return PV_EINVAL;
   if (plan->coord_dim > 0 && !plan->grid) return PV_EINVAL;
-  pv_ivae_plan lay = *plan;
-  lay.fused = 0;
+  pv_ivae_plan lay = decode_plan(plan);
   plan = &lay;
   Layout L;
-  carve(plan, (char*)plan->ws, L);
+  carve(plan, (char*)plan->ws, L, true);
   if (plan->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = plan->batch, N = plan->n_pix, R = L.rows;
-  const int64_t lat_in = (plan->coord_dim > 0 ? plan->latent_dim : plan->z_dim) + plan->c_dim;
+  const int64_t lat_in = plan_lat_in(plan);
   if (plan->coord_dim > 0) PV_TRY(pv_fill_tp(L.tp, (int)B, angle, scale, shift_x, shift_y, s));
   PV_TRY(decoder_hidden_fwd(plan, L, z, lat_in, lat_in, s));
   const int nd = plan->n_dec;

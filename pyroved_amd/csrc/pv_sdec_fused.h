@@ -25,6 +25,8 @@ struct PvFused {
   float* rowtp;          // (4, M) per-row d(phi), d(scale), d(tx), d(ty)
   float* part_hz;        // (B * kmax, H) partial sums of dL/d(hz), zero-filled by the caller
   float* part;           // (G, FD_REC) per-workgroup partial gradients
+  const float* sw;       // per-sample weight of dL/dlogit (jiVAE: alpha[b][k] of sample (k, b)); null: 1
+  int64_t x_units;       // > 0: the observations repeat every x_units units (jiVAE: B*N/16; x is (B, N)); 0: x is (M)
   void* wimg;            // bf16x3 kernel only: FB_WIMG_BYTES of pre-split weight images (pv_sdec_fused_bf16_prep)
   int64_t M;             // rows
   int64_t units;         // M / FD_UNIT

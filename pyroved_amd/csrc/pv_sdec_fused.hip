@@ -304,7 +304,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
         for (int i = 0; i < 4; ++i) part += tC[jb][i] * wv[i];
       }
       const float a = fd_sum_q(part) + bo;
-      const float xv = f.x[row];
+      const float xv = f.x[f.x_units > 0 ? row % (f.x_units * FD_UNIT) : row];
       float ll, dlda, locv;
       if (f.lik == PV_LIK_BERNOULLI) {
         // torch Bernoulli(probs=sigmoid(a)).log_prob(x): clamp_probs -> logits -> -BCEWithLogits
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
         dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
         locv = pr;
       }
+      if (f.sw) dlda *= f.sw[row / f.N];          // (jiVAE) weight of the row's sample
       if (q == 0) {
         f.llrow[row] = ll;
         if (f.loc) f.loc[row] = locv;

@@ -435,9 +435,12 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   const int64_t u_lo = (int64_t)g * f.units / G, u_hi = (int64_t)(g + 1) * f.units / G;
   // the wave's observations are fetched one tile ahead (an HBM miss, and loads retire in order: fetched in the
   // tile itself it would hold up the coordinate layer's own small loads)
+  float sw_next = 1.0f;                  // (jiVAE) weight of the unit's sample, fetched with its observations
   auto x_of_tile = [&](int64_t ut_) -> float {
     const int64_t un = ut_ + wave;
-    return f.x[(un < u_hi ? un : u_lo) * FD_UNIT + r];
+    const int64_t uc = un < u_hi ? un : u_lo;
+    if (f.sw) sw_next = f.sw[uc / upb];
+    return f.x[(f.x_units > 0 ? uc % f.x_units : uc) * FD_UNIT + r];
   };
   float xv_next = x_of_tile(u_lo);
   // ... and so are its other per-unit inputs (hz[b], tp[b], the unit's grid rows), by LDS-DMA into the wave's own
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
     }
     const float* hzb = chz + opq;
-    const float xv = xv_next;
+    const float xv = xv_next, swv = sw_next;
 
     f32x4 h0[8], tA[8], tB[8], tC[8];
     bf16x4 pAh[8], pAl[8], pBh[8], pBl[8];
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
         locv = pr;
       }
+      dlda *= swv;
       if (q == 0) {
         f.llrow[row] = ll;
         if (f.loc) f.loc[row] = locv;

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi
-from .nets.fc import fcEncoderNet, fcDecoderNet, sDecoderNet
+from .nets.fc import fcEncoderNet, jfcEncoderNet, fcDecoderNet, sDecoderNet
 
 ALIGN = 64      # floats: every tensor starts on a 256-byte boundary of the flat buffer
 N_SCALARS = 4   # loss, ll, beta*log p(z), beta*log q(z|x)
@@ -60,9 +60,12 @@ class IVAEEngine:
     def _check_model(self):
         m = self.model
         enc, dec = m.encoder_z, m.decoder
-        if not isinstance(enc, fcEncoderNet):
-            raise UnsupportedModel("the HIP SVI path needs encoder_z to be pyroved_amd.nets.fcEncoderNet "
-                                   "(got %s)" % type(enc).__name__)
+        if not isinstance(enc, (fcEncoderNet, jfcEncoderNet)):
+            raise UnsupportedModel("the HIP SVI path needs encoder_z to be pyroved_amd.nets.fcEncoderNet / "
+                                   "jfcEncoderNet (got %s)" % type(enc).__name__)
+        self.K = int(getattr(m, "discrete_dim", 0)) if isinstance(enc, jfcEncoderNet) else 0
+        if self.K > 0 and m.coord == 0:
+            raise UnsupportedModel("jiVAE without invariances (fcDecoderNet) is not implemented in the HIP path yet")
         if not isinstance(dec, (sDecoderNet, fcDecoderNet)):
             raise UnsupportedModel("the HIP SVI path needs decoder to be sDecoderNet or fcDecoderNet "
                                    "(got %s)" % type(dec).__name__)
@@ -81,18 +84,17 @@ class IVAEEngine:
             raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
 
     def _param_order(self):
-        """(key, tensor) in flat-buffer order: state_dict order, except fc12.weight follows
-        fc11.weight and fc12.bias follows fc11.bias (merged head)."""
+        """(key, tensor) in flat-buffer order: state_dict order, except that the heads are merged:
+        fc11.weight, fc12.weight[, fc13.weight], then fc11.bias, fc12.bias[, fc13.bias]."""
         named = dict(self.model.named_parameters())
-        keys = list(named.keys())
+        heads = ["fc11", "fc12"] + (["fc13"] if self.K > 0 else [])
+        merged = ["encoder_z.%s.weight" % h for h in heads] + ["encoder_z.%s.bias" % h for h in heads]
         order = []
-        for k in keys:
-            if k in ("encoder_z.fc11.bias", "encoder_z.fc12.weight"):
-                continue
-            order.append(k)
-            if k == "encoder_z.fc11.weight":
-                order.append("encoder_z.fc12.weight")
-                order.append("encoder_z.fc11.bias")
+        for k in named:
+            if k == merged[0]:
+                order.extend(merged)
+            elif k not in merged:
+                order.append(k)
         return [(k, named[k]) for k in order]
 
     def bind(self):
@@ -109,7 +111,7 @@ class IVAEEngine:
         layout = {}
         for k, p in items:
             # tensors that the kernels address as one matrix must be packed back to back
-            packed = k in ("encoder_z.fc12.weight", "encoder_z.fc12.bias")
+            packed = k in ("encoder_z.fc12.weight", "encoder_z.fc12.bias", "encoder_z.fc13.weight", "encoder_z.fc13.bias")
             if not packed:
                 off = (off + ALIGN - 1) // ALIGN * ALIGN
             layout[k] = off
@@ -189,10 +191,14 @@ class IVAEEngine:
         for j, i in enumerate(idx):
             p.enc[j] = self._layer("encoder_z.fc_layers.%d" % i, enc.fc_layers[i], enc.activation)
         h = _abi.pv_layer()
-        h.in_dim, h.out_dim, h.act = enc.fc11.in_features, 2 * m.z_dim, 0
+        h.in_dim, h.out_dim, h.act = enc.fc11.in_features, 2 * m.z_dim + self.K, 0
         h.w_off, h.b_off = self._layout["encoder_z.fc11.weight"], self._layout["encoder_z.fc11.bias"]
         assert self._layout["encoder_z.fc12.weight"] == h.w_off + enc.fc11.weight.numel()
         assert self._layout["encoder_z.fc12.bias"] == h.b_off + enc.fc11.bias.numel()
+        p.discrete_dim = self.K
+        if self.K > 0:
+            assert self._layout["encoder_z.fc13.weight"] == h.w_off + 2 * enc.fc11.weight.numel()
+            assert self._layout["encoder_z.fc13.bias"] == h.b_off + 2 * enc.fc11.bias.numel()
         p.head = h
         if p.coord_dim > 0:
             p.fc_coord = self._layer("decoder.coord_latent.fc_coord", dec.coord_latent.fc_coord, "tanh")
@@ -215,8 +221,12 @@ class IVAEEngine:
     def _plan(self, batch: int, beta: float = 1.0) -> _abi.pv_ivae_plan:
         p = self._static
         p.batch = batch
-        p.beta = float(beta)
-        p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
+        if isinstance(beta, (list, tuple)) or (torch.is_tensor(beta) and beta.ndim > 0):
+            b0, b1 = (float(v) for v in beta)            # jiVAE: [continuous, discrete] KL scale factors
+        else:
+            b0 = b1 = float(beta)
+        p.beta, p.beta_disc = b0, b1
+        p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = None
         p.ev_start, p.ev_stop = self.events
         need = _abi.lib().pv_ivae_workspace_bytes(C.byref(p))
         if need < 0:
@@ -286,9 +296,14 @@ class IVAEEngine:
         p.y = y.data_ptr() if y is not None else None
         z_loc = torch.empty(b, p.z_dim, device=self.device, dtype=torch.float32)
         z_scale = torch.empty_like(z_loc)
+        alpha = torch.empty(b, self.K, device=self.device, dtype=torch.float32) if self.K > 0 else None
+        if alpha is not None:
+            p.alpha = alpha.data_ptr()
         _abi.check(_abi.lib().pv_ivae_encode(C.byref(p), _abi.ptr(z_loc), _abi.ptr(z_scale), _abi.current_stream()),
                    "pv_ivae_encode")
         self._keep = (x, y)
+        if alpha is not None:
+            return z_loc, z_scale, alpha
         return z_loc, z_scale
 
     def decode(self, z, angle: float = 0.0, shift=(0.0, 0.0), scale: float = 1.0):
@@ -296,7 +311,7 @@ class IVAEEngine:
         self.ensure_bound()
         b = z.shape[0]
         p = self._plan(b)
-        lat_in = (p.latent_dim if p.coord_dim > 0 else p.z_dim) + p.c_dim
+        lat_in = (p.latent_dim if p.coord_dim > 0 else p.z_dim) + p.c_dim + self.K
         z = self._prep(z, "z", (b, lat_in))
         loc = torch.empty(b, p.n_pix, device=self.device, dtype=torch.float32)
         _abi.check(_abi.lib().pv_ivae_decode(C.byref(p), _abi.ptr(z), float(angle), float(shift[0]), float(shift[1]),

@@ -1,5 +1,6 @@
 """Variational autoencoder models of the SVI hot path."""
 from .base import baseVAE
 from .ivae import iVAE
+from .jivae import jiVAE
 
-__all__ = ['iVAE']
+__all__ = ['iVAE', 'jiVAE']

@@ -113,8 +113,7 @@ class baseVAE(nn.Module):
         for data in loader:
             x = data[0].to(eng.device, torch.float32)
             y = data[1].to(eng.device, torch.float32) if len(data) > 1 else None
-            z_loc, z_scale = eng.encode(x, y)
-            z_encoded.append(torch.cat([z_loc, z_scale], -1).cpu())
+            z_encoded.append(torch.cat(eng.encode(x, y), -1).cpu())     # (z_loc, z_scale[, class probabilities])
         return torch.cat(z_encoded)
 
     def _decode(self, z_new: torch.Tensor, device: str = None, **kwargs: int) -> torch.Tensor:

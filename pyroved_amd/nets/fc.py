@@ -75,6 +75,39 @@ class fcEncoderNet(nn.Module):
         return mu, sigma
 
 
+class jfcEncoderNet(nn.Module):
+    """Fully-connected encoder for the joint VAE: mean, (softplus) standard deviation and class
+    probabilities softmax(fc13(h)) (pyroved/nets/fc.py:64-108)."""
+    def __init__(self, in_dim: Tuple[int], latent_dim: int = 2, discrete_dim: int = 0,
+                 hidden_dim: List[int] = None, activation: str = 'tanh',
+                 softplus_out: bool = True, flat: bool = True) -> None:
+        super(jfcEncoderNet, self).__init__()
+        if len(in_dim) not in [1, 2, 3]:
+            raise ValueError("in_dim must be (h, w), (h, w, c), or (l,)")
+        self.in_dim = _prod(in_dim)
+        if hidden_dim is None:
+            hidden_dim = [128, 128]
+        self.flat = flat
+        self.activation = activation
+        self.softplus_out = softplus_out
+        self.discrete_dim = discrete_dim
+        self.concat = Concat()
+        self.fc_layers = make_fc_layers(self.in_dim, hidden_dim, activation)
+        self.fc11 = nn.Linear(hidden_dim[-1], latent_dim)
+        self.fc12 = nn.Linear(hidden_dim[-1], latent_dim)
+        self.fc13 = nn.Linear(hidden_dim[-1], discrete_dim)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor]:
+        x = self.concat(x)
+        if self.flat:
+            x = x.reshape(-1, self.in_dim)
+        h = _run_stack(self.fc_layers, self.activation, x)
+        mu = ops.linear_act(h, self.fc11.weight, self.fc11.bias, None)
+        sigma = ops.linear_act(h, self.fc12.weight, self.fc12.bias, "softplus" if self.softplus_out else None)
+        alpha = torch.softmax(ops.linear_act(h, self.fc13.weight, self.fc13.bias, None), dim=-1)
+        return mu, sigma, alpha
+
+
 class fcDecoderNet(nn.Module):
     """Standard fully-connected decoder (pyroved/nets/fc.py:111-152)."""
     def __init__(self, out_dim: Tuple[int], latent_dim: int, c_dim: int = 0,

@@ -31,7 +31,7 @@ class SVItrainer:
         model: initialized model (pyroved_amd.models.iVAE)
         optimizer: None (Adam, lr 1e-3) or a dict of Adam arguments {"lr", "betas", "eps"}
         loss: None / "Trace_ELBO" (the one-particle ELBO the reference defaults to)
-        enumerate_parallel: exact enumeration of discrete latents (jiVAE; not in this build yet)
+        enumerate_parallel: exact enumeration of the discrete latent (required for models.jiVAE)
         seed: enforces reproducibility
 
     Keyword Args:
@@ -54,8 +54,12 @@ class SVItrainer:
                  ) -> None:
         set_deterministic_mode(seed)
         self.device = kwargs.get("device", model.device)
-        if enumerate_parallel:
-            raise NotImplementedError("enumerate_parallel (jiVAE) is not part of this build yet")
+        is_joint = int(getattr(model, "discrete_dim", 0)) > 0
+        if is_joint and not enumerate_parallel:
+            raise NotImplementedError("jiVAE is trained with exact enumeration of the discrete latent: pass "
+                                      "enumerate_parallel=True (the sampled-class estimator is not implemented)")
+        if enumerate_parallel and not is_joint:
+            raise ValueError("enumerate_parallel=True needs a model with a discrete latent (models.jiVAE)")
         if loss is not None and loss != "Trace_ELBO":
             raise NotImplementedError("only the default Trace_ELBO objective is implemented (got %r)" % (loss,))
         adam = {"lr": kwargs.get("lr", 1e-3), "betas": (0.9, 0.999), "eps": 1e-8}
@@ -92,7 +96,10 @@ class SVItrainer:
     def _svi_step(self, i: int, x: torch.Tensor, y: Optional[torch.Tensor], train: bool, **kwargs) -> None:
         """SVI.step on one (global) minibatch; the loss lands in slot i of the device history."""
         eng = self.engine
-        beta = float(kwargs.get("scale_factor", 1.))
+        beta = kwargs.get("scale_factor", 1.)          # jiVAE: scalar or [continuous, discrete] (jivae.py:161-165)
+        if torch.is_tensor(beta):
+            beta = beta.tolist()
+        beta = [float(v) for v in beta] if isinstance(beta, (list, tuple)) else float(beta)
         b = x.shape[0]
         eps = self._draw_eps(b)                       # global batch: identical on every rank
         rank, world = pvdist.world(self.group)

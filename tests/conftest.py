@@ -67,3 +67,29 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def jmeta_of(gold):
+    """Case definition of a jivae_* fixture (tests/golden/make_golden.py:run_jsteps)."""
+    inv = str(gold["meta.invariances"])
+    return dict(data_dim=tuple(int(v) for v in gold["meta.data_dim"]),
+                invariances=list(inv) if inv else None,
+                batch=int(gold["meta.batch"]), latent_dim=int(gold["meta.latent_dim"]),
+                discrete_dim=int(gold["meta.discrete_dim"]), xkind=str(gold["meta.xkind"]),
+                steps=int(gold["meta.steps"]), beta=[float(v) for v in gold["meta.scale_factor"]])
+
+
+def jivae_grad_tol(key):
+    """Per-tensor relative-L2 bar for jiVAE gradients.  The class logits' gradient is
+    alpha_k * ((ll_k - sum_j alpha_j ll_j) + ...): differences of per-class log-likelihoods (~ -500 each at 28x28,
+    0.1 apart) computed in fp32, so it carries ~1e-3 of summation-order noise in ANY fp32 implementation (the
+    reference's included); it also feeds the encoder trunk.  Decoder tensors keep the 1e-4 bar."""
+    if "fc13" in key:
+        return 5e-3
+    if key == "decoder.out.bias":      # one scalar = the sum of K*B*N signed terms alpha*(p - x): judged on an
+        return None                    # absolute scale by the caller (1e-6 of the sum of |terms|)
+    if key.startswith("decoder.") and key.endswith(".bias"):     # sums of alpha-weighted signed terms over all rows
+        return 3e-4
+    if key.startswith("encoder_z."):
+        return 1e-3
+    return 1e-4

@@ -233,18 +233,15 @@ class TraceEnum_ELBO(Trace_ELBO):
         logq = e["log_prob"]                      # (K, B)
         w = logq.exp()                            # q(k | x_b), (K, B)
         elbo = 0.0
-        for s in m.sites.values():
-            lp = s["scale"] * s["log_prob"]
-            if lp.dim() == 2:                     # depends on the enumerated value: (K, B)
-                elbo = elbo + (w * lp).sum()
-            else:                                 # (B,)
-                elbo = elbo + lp.sum()
-        for s in g.sites.values():
-            lp = s["scale"] * s["log_prob"]
-            if lp.dim() == 2:
-                elbo = elbo - (w * lp).sum()
-            else:
-                elbo = elbo - lp.sum()
+        wterms = {}
+        for pre, tr, sign in (("model.", m, 1.0), ("guide.", g, -1.0)):
+            for n, s in tr.sites.items():
+                lp = s["scale"] * s["log_prob"]
+                t = (w * lp).sum() if lp.dim() == 2 else lp.sum()   # (K, B): depends on the enumerated value
+                wterms[pre + n] = t.detach()
+                elbo = elbo + sign * t
+        _TAP["enum_terms"] = wterms
+        _TAP["enum_weights"] = w.detach().clone()
         return elbo
 
 

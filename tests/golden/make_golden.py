@@ -151,6 +151,69 @@ def run_steps(name, data_dim, invariances, batch, steps=3, latent_dim=2, xkind="
     print("wrote", name, "loss0=%.6f" % out["s0.loss"], "keys=%d" % len(out))
 
 
+def run_jsteps(name, data_dim, invariances, discrete_dim, batch, steps=3, latent_dim=2, xkind="rand",
+               scale_factor=None, full=False):
+    """jiVAE (models/jivae.py:109-220) through SVItrainer(enumerate_parallel=True) (trainers/svi.py:83-90):
+    TraceEnum_ELBO with the guide's OneHotCategorical site enumerated in parallel."""
+    out = {}
+    out["meta.data_dim"] = np.array(data_dim)
+    out["meta.invariances"] = np.array("".join(invariances) if invariances else "")
+    out["meta.batch"] = np.int64(batch)
+    out["meta.latent_dim"] = np.int64(latent_dim)
+    out["meta.discrete_dim"] = np.int64(discrete_dim)
+    out["meta.xkind"] = np.array(xkind)
+    out["meta.steps"] = np.int64(steps)
+    sf = [1.0, 1.0] if scale_factor is None else (list(scale_factor) if isinstance(scale_factor, (list, tuple))
+                                                   else [scale_factor, scale_factor])
+    out["meta.scale_factor"] = np.array(sf, dtype=np.float64)
+    model = models.jiVAE(data_dim, latent_dim, discrete_dim, invariances, seed=1, device="cpu")
+    names = {id(p): n for n, p in model.named_parameters()}
+    for n, p in model.named_parameters():
+        put(out, "init." + n, digest(p))
+    x = make_x(xkind, batch, data_dim)
+    trainer = trainers.SVItrainer(model, enumerate_parallel=True, seed=1, device="cpu")
+    step_kw = {} if scale_factor is None else {"scale_factor": scale_factor}
+    for k in range(steps):
+        grads = {}
+        real_optim = trainer.svi.optim
+
+        def spy(params, _real=real_optim, _g=grads):
+            for p in params:
+                _g[names[id(p)]] = p.grad.detach().clone()
+            _real(params)
+        trainer.svi.optim = spy
+        loss = trainer.svi.step(x, **step_kw)
+        trainer.svi.optim = real_optim
+        tap = _minipyro.tap()
+        pre = "s%d" % k
+        out[pre + ".loss"] = np.float64(loss)
+        for tn, tv in tap["enum_terms"].items():
+            out[pre + ".term." + tn] = np.float64(tv.item())
+        gfn = tap["guide_fns"]["latent_cont"].base_dist
+        out[pre + ".eps"] = tap["latent_cont.eps"].numpy().copy()
+        out[pre + ".z_loc"] = gfn.loc.detach().numpy().copy()
+        out[pre + ".z_scale"] = gfn.scale.detach().numpy().copy()
+        out[pre + ".z"] = tap["sites"]["guide.latent_cont"].numpy().copy()
+        out[pre + ".alpha"] = tap["enum_weights"].t().numpy().copy()          # (B, K) = q(k | x_b)
+        for n, g in grads.items():
+            put(out, pre + ".grad." + n, digest(g))
+            if full:
+                out["full." + pre + ".grad." + n] = g.numpy().copy()
+        for n, p in model.named_parameters():
+            put(out, pre + ".param." + n, digest(p))
+    z_loc, z_scale, logits = model.encode(x, logits=True)
+    out["enc.z_loc"] = z_loc.numpy().copy()
+    out["enc.z_scale"] = z_scale.numpy().copy()
+    out["enc.alpha"] = logits.numpy().copy()
+    _, _, classes = model.encode(x)
+    out["enc.classes"] = classes.numpy().copy()
+    zc = z_loc[:, -latent_dim:]
+    yy = utils.to_onehot(torch.arange(batch) % discrete_dim, discrete_dim)
+    out["dec.loc"] = model.decode(zc, yy).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "loss0=%.6f" % out["s0.loss"], "keys=%d" % len(out))
+
+
 def run_step0_loc(name, data_dim, invariances, batch, latent_dim=2, xkind="rand"):
     """Step-0 forward only, with the decoder's `loc` and the transformed grid."""
     out = {}
@@ -222,6 +285,9 @@ def run_epochs(name, data_dim, invariances, n, batch, epochs=2, with_test=True, 
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    only = sys.argv[1:] or None          # e.g. `make_golden.py jivae`: only (re)generate that family
+    if only is not None:
+        run_steps = run_step0_loc = lambda *a, **k: None      # noqa: E731
     # tiny cases, every invariance set of the reference's own trainer tests
     # (tests/test_trainers.py:26-40) — full tensors kept for the richest one
     for inv in (None, ["r"], ["t"], ["s"], ["r", "t"], ["r", "t", "s"]):
@@ -243,6 +309,15 @@ if __name__ == "__main__":
     run_step0_loc("ivae_28x28_rt_b16_fwd", (28, 28), ["r", "t"], batch=16)
     # saturated pixels (blob images) after a few steps
     run_steps("ivae_28x28_r_b32_blobs", (28, 28), ["r"], batch=32, steps=4, xkind="blobs")
+    # jiVAE: joint continuous + discrete latent, enumerated ELBO (BASELINE config 3 family)
+    if only is None or "jivae" in only:
+        run_jsteps("jivae_8x8_r_k3_b5", (8, 8), ["r"], 3, batch=5, full=True)
+        run_jsteps("jivae_8x8_rts_k4_b6", (8, 8), ["r", "t", "s"], 4, batch=6)
+        run_jsteps("jivae_8x8_rt_k3_b4_sf", (8, 8), ["r", "t"], 3, batch=4, scale_factor=[2.0, 3.0])
+        run_jsteps("jivae_1d16_t_k2_b5", (16,), ["t"], 2, batch=5)
+        run_jsteps("jivae_28x28_r_k10_b16", (28, 28), ["r"], 10, batch=16, steps=2)
+    if only is not None:
+        sys.exit(0)
     # epoch loops through the reference SVItrainer + DataLoader
     run_epochs("epochs_8x8_rts", (8, 8), ["r", "t", "s"], n=5, batch=2)
     run_epochs("epochs_8x8_r_notest", (8, 8), ["r"], n=7, batch=3, with_test=False, xkind="rand")

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, make_x, check_digest, meta_of
+from conftest import GOLDEN, load_golden, make_x, check_digest, meta_of, jmeta_of, jivae_grad_tol
 
 import pyroved_amd as pv
 from pyroved_amd import _abi
@@ -25,6 +25,7 @@ pytestmark = pytest.mark.gpu
 STEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ivae_*.npz"))
                     if not p.endswith("_fwd.npz"))
 FWD_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ivae_*_fwd.npz")))
+JSTEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "jivae_*.npz")))
 EPOCH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "epochs_*.npz")))
 
 RTOL_ELBO = 2e-5      # ELBO terms (bar: 1e-4)
@@ -243,6 +244,94 @@ def test_model_variants_vs_oracle(gpu_device, vname, fused):
     zc = zl[:, -latent_dim:]
     dec = model.decode(zc) if y is None else model.decode(zc, y)
     np.testing.assert_allclose(dec.numpy(), o.decode(zc, y).numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("fused", [1, 2])
+@pytest.mark.parametrize("name", JSTEP_CASES)
+def test_jivae_steps_vs_golden_and_oracle(gpu_device, name, fused):
+    """models.jiVAE through the HIP path (K*B decoder rows in the fused kernels, alpha-weighted) vs the reference's
+    recorded SVItrainer(enumerate_parallel=True) steps and the CPU oracle: loss, site terms, class probabilities,
+    gradients, parameters; then encode()/decode()."""
+    gold = load_golden(name)
+    meta = jmeta_of(gold)
+    K = meta["discrete_dim"]
+    model = pv.models.jiVAE(meta["data_dim"], meta["latent_dim"], K, meta["invariances"], seed=1, device="cuda")
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     discrete_dim=K)
+    eng = model.engine(fused=fused)
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    xg = x.cuda()
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eng.loss_and_grads(xg, eps.cuda(), meta["beta"])
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=RTOL_ELBO, err_msg="loss")
+        np.testing.assert_allclose(s[1], float(gold[pre + ".term.model.obs"]), rtol=RTOL_ELBO)
+        np.testing.assert_allclose(s[2], float(gold[pre + ".term.model.latent_cont"]) +
+                                   float(gold[pre + ".term.model.latent_disc"]), rtol=1e-4)
+        np.testing.assert_allclose(s[3], float(gold[pre + ".term.guide.latent_cont"]) +
+                                   float(gold[pre + ".term.guide.latent_disc"]), rtol=1e-4)
+        o.step(x, eps, meta["beta"])
+        for key in o.p:
+            g = eng.grad_of(key)
+            tol = jivae_grad_tol(key)
+            if tol is None:
+                # d(loss)/d(out.bias) = sum over the B*N pixels (and K classes, weights summing to 1) of alpha*(p - x):
+                # |terms| sum to ~B*N/4 and cancel to ~1e-4 of that; fp32 summation is good to ~1e-6 of it
+                bound = 1e-6 * meta["batch"] * int(np.prod(meta["data_dim"]))
+                assert (g.cpu() - o.last_grads[key]).abs().max().item() < bound, key
+                continue
+            err = rel_l2(g, o.last_grads[key])
+            assert err < tol, "step %d grad %s: rel l2 error %.3e vs oracle" % (k, key, err)
+            check_digest(g, gold, pre + ".grad." + key, rtol=5 * tol, atol=tol * float(gold[pre + ".grad." + key + ".l2"]) / 4,
+                         what=name)
+        eng.adam_step()
+        for key, p in model.state_dict().items():
+            # Adam turns a noise-sized gradient entry into a +-lr step: tensors whose gradient carries the class-logit
+            # cancellation noise (jivae_grad_tol) are held to a few such steps, the rest to the usual bar
+            loose = (jivae_grad_tol(key) or 1.0) > 3e-4
+            check_digest(p, gold, pre + ".param." + key, rtol=1e-4, atol=5e-3 if loose else 2e-6, what=name)
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})     # identical state for the next step
+    # inference API: tight against the oracle on the same (its own) parameters; against the reference's recorded
+    # outputs within the few-lr drift that the class-logit noise leaves in the parameters after Adam
+    z_loc, z_scale, alpha = model.encode(x, logits=True)
+    zl, zs, al = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), zl.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z_scale.numpy(), zs.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(alpha.numpy(), al.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(alpha.numpy(), gold["enc.alpha"], rtol=5e-3, atol=1e-4)
+    _, _, classes = model.encode(x)
+    assert (classes.numpy() == al.argmax(1).numpy()).all()
+    yy = pv.utils.to_onehot(torch.arange(meta["batch"]) % K, K)
+    zc = torch.from_numpy(gold["enc.z_loc"])[:, -meta["latent_dim"]:]
+    dec = model.decode(zc, yy)
+    np.testing.assert_allclose(dec.numpy(), o.decode(zc, yy).numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(dec.numpy(), gold["dec.loc"], rtol=2e-3, atol=2e-4)
+
+
+def test_jivae_trainer_epochs_vs_oracle(gpu_device):
+    """SVItrainer(jiVAE, enumerate_parallel=True).step(loader, scale_factor=[b0, b1]) against the oracle driven
+    through the same DataLoader / eps stream (trainers/svi.py:139-162)."""
+    data_dim, K = (8, 8), 3
+    x = make_x("rand", 10, data_dim)
+    losses = {}
+    for which in ("gpu", "cpu"):
+        model = pv.models.jiVAE(data_dim, 2, K, ["r", "t"], seed=1, device="cuda" if which == "gpu" else "cpu")
+        loader = pv.utils.init_dataloader(x, batch_size=4)
+        if which == "gpu":
+            tr = pv.trainers.SVItrainer(model, enumerate_parallel=True, seed=1)
+            for _ in range(2):
+                tr.step(loader, scale_factor=[1.5, 2.5])
+            losses[which] = tr.loss_history["training_loss"]
+        else:
+            cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=["r", "t"], discrete_dim=K)
+            pv.utils.set_deterministic_mode(1)
+            o = orc.SVIOracle(model.state_dict(), cfg)
+            losses[which] = [o.train_epoch(loader, [1.5, 2.5]) for _ in range(2)]
+    np.testing.assert_allclose(losses["gpu"], losses["cpu"], rtol=1e-4)
 
 
 @pytest.mark.parametrize("name", EPOCH_CASES)

@@ -152,3 +152,46 @@ def test_oracle_epochs_match_reference_trainer(name):
     np.testing.assert_allclose(te, gold["epochs.test_loss"], rtol=1e-5)
     for key in o.p:
         check_digest(o.p[key], gold, "final." + key, rtol=1e-4, atol=1e-7, what=name)
+
+
+# ---------------------------------------------------------------- jiVAE (models/jivae.py, TraceEnum_ELBO)
+JSTEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "jivae_*.npz")))
+
+
+def test_jivae_fixture_inventory():
+    assert len(JSTEP_CASES) >= 5
+
+
+@pytest.mark.parametrize("name", JSTEP_CASES)
+def test_jivae_oracle_steps_match_reference(name):
+    """The product's jiVAE constructor reproduces the reference's initial weights, and the oracle's enumerated ELBO
+    (oracle.jelbo) reproduces the reference's jiVAE.model/guide run through SVItrainer(enumerate_parallel=True):
+    loss, the five site terms, class probabilities, gradients, parameters after Adam, for every recorded step."""
+    from conftest import jmeta_of, jivae_grad_tol
+    gold = load_golden(name)
+    meta = jmeta_of(gold)
+    model = pv.models.jiVAE(meta["data_dim"], meta["latent_dim"], meta["discrete_dim"], meta["invariances"],
+                            seed=1, device="cpu")
+    for n, p in model.named_parameters():
+        check_digest(p, gold, "init." + n, rtol=0, atol=0, what=name)
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     discrete_dim=meta["discrete_dim"])
+    o = orc.SVIOracle(model.state_dict(), cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        loss = o.step(x, torch.from_numpy(gold[pre + ".eps"]), meta["beta"])
+        np.testing.assert_allclose(loss, float(gold[pre + ".loss"]), rtol=2e-6)
+        for t, v in o.last["terms"].items():
+            np.testing.assert_allclose(v.item(), float(gold[pre + ".term." + t]), rtol=2e-6, err_msg=t)
+        np.testing.assert_allclose(o.last["alpha"].detach().numpy(), gold[pre + ".alpha"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(o.last["z"].detach().numpy(), gold[pre + ".z"], rtol=1e-6, atol=1e-7)
+        for n in o.p:
+            tol = jivae_grad_tol(n) or 1e-3
+            check_digest(o.last_grads[n], gold, pre + ".grad." + n, rtol=2 * tol, atol=tol * float(gold[pre + ".grad." + n + ".l2"]) / 8,
+                         what=name)
+            check_digest(o.p[n], gold, pre + ".param." + n, rtol=1e-4, atol=2e-6, what=name)
+    z_loc, z_scale, alpha = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(alpha.numpy(), gold["enc.alpha"], rtol=1e-4, atol=1e-6)
+    assert (alpha.argmax(1).numpy() == gold["enc.classes"]).all()
