@@ -41,6 +41,8 @@ class SVItrainer:
         fused: spatial-decoder kernel path: 2 (default) fused persistent kernel with bf16 split-precision
             matrix math (fp32-class results), 1 fused kernel on the f32-input MFMA, 0 layer-by-layer kernels
         process_group: torch.distributed group for data-parallel training (default: WORLD if initialised)
+        device_feed: keep TensorDataset loaders' data on the device and gather minibatches there, in the order the
+            loader's own sampler produces (default True; same numbers as iterating the loader)
         mirror_evaluate_update: keep the reference's behaviour of stepping the optimizer inside
             evaluate() (svi.py:126-135 calls svi.step under no_grad) — default True
     """
@@ -72,6 +74,8 @@ class SVItrainer:
         self.rng = kwargs.get("rng", "cpu")
         self.group = kwargs.get("process_group", None)
         self.mirror_evaluate_update = bool(kwargs.get("mirror_evaluate_update", True))
+        self.device_feed = bool(kwargs.get("device_feed", True))
+        self._feed_cache = None
         if kwargs.get("engine") is not None:
             # test hook: a stand-in engine (tests drive the data-parallel host logic on CPU/gloo with it)
             self.engine = kwargs["engine"]
@@ -93,15 +97,17 @@ class SVItrainer:
             return torch.empty(b, z_dim).normal_()
         return torch.empty(b, z_dim, device=self.engine.device).normal_()
 
-    def _svi_step(self, i: int, x: torch.Tensor, y: Optional[torch.Tensor], train: bool, **kwargs) -> None:
-        """SVI.step on one (global) minibatch; the loss lands in slot i of the device history."""
+    def _svi_step(self, i: int, x: torch.Tensor, y: Optional[torch.Tensor], train: bool, eps=None, **kwargs) -> None:
+        """SVI.step on one (global) minibatch; the loss lands in slot i of the device history.
+        x / y / eps may already live on the device (device feed, _epoch_device_feed)."""
         eng = self.engine
         beta = kwargs.get("scale_factor", 1.)          # jiVAE: scalar or [continuous, discrete] (jivae.py:161-165)
         if torch.is_tensor(beta):
             beta = beta.tolist()
         beta = [float(v) for v in beta] if isinstance(beta, (list, tuple)) else float(beta)
         b = x.shape[0]
-        eps = self._draw_eps(b)                       # global batch: identical on every rank
+        if eps is None:
+            eps = self._draw_eps(b)                   # global batch: identical on every rank
         rank, world = pvdist.world(self.group)
         lo, hi = pvdist.shard_bounds(b, rank, world)
         dev = eng.device
@@ -131,14 +137,57 @@ class SVItrainer:
         if not direct:
             self._hist[i].copy_(eng.scalars)
 
+    # ------------------------------------------------------------------ data feed
+    def _device_dataset(self, tensors):
+        """Device-resident copy of the loader's TensorDataset, cached until the tensors change."""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+        if self._feed_cache is None or self._feed_cache[0] != key:
+            dev = self.engine.device
+            self._feed_cache = (key, [t.to(dev, torch.float32) for t in tensors])
+        return self._feed_cache[1]
+
+    def _epoch_device_feed(self, loader, train: bool, **kwargs) -> Optional[int]:
+        """One epoch without per-batch host work on the data: the dataset lives on the device, the
+        minibatch ORDER is still produced by the caller's own sampler — iterated through a DataLoader over the
+        indices, so the global CPU generator is consumed exactly as `for data in loader` consumes it (one base-seed
+        draw per iterator, one sampler-seed draw per epoch) — and every step's eps is drawn on the CPU generator in
+        step order (same stream as the per-batch path), then shipped in one copy.  Returns the number of steps, or
+        None when the loader is not a plain TensorDataset loader (the caller falls back to iterating it)."""
+        from torch.utils.data import DataLoader, TensorDataset
+        ds = getattr(loader, "dataset", None)
+        if (not self.device_feed or not isinstance(loader, DataLoader) or not isinstance(ds, TensorDataset)
+                or loader.num_workers != 0 or loader.batch_sampler is None or len(ds.tensors) not in (1, 2)
+                or getattr(self.engine, "device", None) is None or self.rng != "cpu"):
+            return None
+        idx_loader = DataLoader(range(len(ds)), batch_sampler=loader.batch_sampler)     # same sampler object
+        batches = [b for b in idx_loader]                      # LongTensors of sample indices, the loader's order
+        if not batches:
+            return 0
+        eps = [self._draw_eps(len(b)) for b in batches]
+        dev = self.engine.device
+        data = self._device_dataset(ds.tensors)
+        sizes = [len(b) for b in batches]
+        idx_dev = torch.cat(batches).to(dev)
+        eps_dev = torch.cat(eps).to(dev, torch.float32)
+        off = 0
+        for n, bsz in enumerate(sizes):
+            idx = idx_dev[off:off + bsz]
+            x = data[0].index_select(0, idx)
+            y = data[1].index_select(0, idx) if len(data) > 1 else None
+            self._svi_step(n, x, y, train, eps=eps_dev[off:off + bsz], **kwargs)
+            off += bsz
+        return len(sizes)
+
     def _epoch(self, loader, train: bool, **kwargs) -> float:
-        n = 0
-        for data in loader:
-            if len(data) == 1:  # VAE mode
-                self._svi_step(n, data[0], None, train, **kwargs)
-            else:  # VED or cVAE mode
-                self._svi_step(n, data[0], data[1], train, **kwargs)
-            n += 1
+        n = self._epoch_device_feed(loader, train, **kwargs)
+        if n is None:
+            n = 0
+            for data in loader:
+                if len(data) == 1:  # VAE mode
+                    self._svi_step(n, data[0], None, train, **kwargs)
+                else:  # VED or cVAE mode
+                    self._svi_step(n, data[0], data[1], train, **kwargs)
+                n += 1
         # one device->host read per epoch; python-float accumulation like the reference's `epoch_loss += loss`
         losses = self._hist[:n, 0].cpu().tolist() if n else []
         epoch_loss = 0.

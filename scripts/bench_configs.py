@@ -1,0 +1,39 @@
+"""Throughput of the other BASELINE.json configurations the HIP path covers (secondary numbers for DESIGN.md §5;
+bench.py stays the contract for the headline config).  One GPU, inputs resident in HBM, eps pre-generated."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pyroved_amd as pv
+
+CASES = [
+    ("C1  iVAE 28x28 ['r'] B=128", lambda: pv.models.iVAE((28, 28), 2, ["r"], seed=1, device="cuda"), 128, (28, 28), 1),
+    ("C2  iVAE 28x28 ['r','t'] B=256", lambda: pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda"), 256, (28, 28), 1),
+    ("C3  jiVAE K=10 28x28 ['r'] B=512", lambda: pv.models.jiVAE((28, 28), 2, 10, ["r"], seed=1, device="cuda"), 512, (28, 28), 10),
+    ("C4' iVAE 64x64 ['r','t','s'] fc encoder B=128/GPU", lambda: pv.models.iVAE((64, 64), 2, ["r", "t", "s"], seed=1, device="cuda"), 128, (64, 64), 1),
+    ("    iVAE 28x28 ['r','t'] B=1024", lambda: pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda"), 1024, (28, 28), 1),
+]
+steps, warm = int(os.environ.get("STEPS", 60)), 10
+for name, make, B, dd, K in CASES:
+    model = make()
+    eng = model.engine(fused=2)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(4, B, *dd, generator=g).cuda()
+    eps = torch.randn(steps + warm, B, model.z_dim, generator=g).cuda()
+    hist = torch.zeros(steps + warm, 4, device="cuda")
+    def step(i):
+        eng.loss_and_grads(x[i % 4], eps[i], 1.0, scalars_out=hist[i])
+        eng.adam_step()
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_pix = dd[0] * dd[1]
+    fl = 3 * n_pix * 66304 * K * B          # algorithmic decoder FLOPs of the step, K decoder passes
+    print("%-52s %8.3f ms/step  %9.0f images/s  %6.1f TF algorithmic  loss/img %.3f -> %.3f" % (
+        name, dt * 1e3, B / dt, fl / dt / 1e12, hist[warm, 0].item() / B, hist[-1, 0].item() / B), flush=True)
+    del eng, model
+    torch.cuda.empty_cache()

@@ -204,6 +204,32 @@ def test_trainer_host_logic_reproduces_reference_epochs(name, capsys):
             trainer.current_epoch, trainer.loss_history["training_loss"][-1])
 
 
+@pytest.mark.parametrize("name", ["epochs_8x8_rts", "epochs_8x8_r_notest"])
+def test_device_feed_equals_loader_iteration(name):
+    """The device-resident data feed (default) and plain iteration of the caller's DataLoader consume the RNG streams
+    identically: same minibatch order, same eps, same loss history (both equal the reference's, test above)."""
+    _, fed, _ = _trainer_run(name, OracleEngine, device_feed=True)
+    _, plain, _ = _trainer_run(name, OracleEngine, device_feed=False)
+    assert fed._feed_cache is not None and plain._feed_cache is None
+    assert fed.loss_history == plain.loss_history
+
+
+def test_device_feed_falls_back_on_custom_loaders():
+    """Anything but a plain TensorDataset loader is iterated as given."""
+    class Loader:
+        def __init__(self, x):
+            self.dataset = x
+            self.x = x
+        def __iter__(self):
+            for i in range(0, len(self.x), 2):
+                yield (self.x[i:i + 2],)
+    model = pv.models.iVAE((8, 8), 2, ["r"], seed=1, device="cpu")
+    cfg = orc.Config(data_dim=(8, 8), latent_dim=2, invariances=["r"])
+    tr = pv.trainers.SVItrainer(model, seed=1, engine=OracleEngine(model, cfg), device="cpu")
+    tr.step(Loader(torch.rand(5, 8, 8)))
+    assert tr._feed_cache is None and len(tr.loss_history["training_loss"]) == 1
+
+
 def test_shard_bounds_cover_batch():
     for n in (0, 1, 5, 7, 256, 257):
         for w in (1, 2, 3, 8):
