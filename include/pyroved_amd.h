@@ -187,6 +187,80 @@ int pv_transform_coordinates(const float* grid, int64_t n_pix, int coord_dim, co
                              const float* shift, const float* scale, int64_t batch, float* out,
                              void* stream);
 
+/* ===================================================================================================
+ * models.VED (models/ved.py:89-163): convolutional encoder -> z -> convolutional decoder, Bernoulli /
+ * Gaussian likelihood of a target y (image-to-spectrum and the like).  The networks are described as
+ * op sequences read off nets/conv.py's FeatureExtractor (conv.py:150-213) and Upsampler (conv.py:216-262).
+ * Tensors cross the ABI in the reference's layout, (B, channels, *spatial) row-major; inside the library
+ * activations are channels-last.  Scope: 1-D / 2-D data, kernel 3 (padding 1) and kernel 1 convolutions,
+ * stride 1, 2x max-pooling, 2x nearest-neighbour upsampling, no batch normalisation.
+ * =================================================================================================== */
+#define PV_MAX_OPS 32
+
+enum pv_op_kind {
+  PV_OP_CONV = 1,        /* nn.ConvNd(cin, cout, ksize, 1, ksize/2) + activation `act` (weights in the torch
+                            layout (cout, cin, *kernel) at w_off, bias at b_off)                        */
+  PV_OP_MAXPOOL2 = 2,    /* nn.MaxPoolNd(2, 2)                                                          */
+  PV_OP_UPSAMPLE2 = 3    /* F.interpolate(scale_factor=2, mode="nearest")                               */
+};
+
+typedef struct pv_op {
+  int32_t kind;          /* enum pv_op_kind */
+  int32_t cin, cout;     /* CONV only       */
+  int32_t ksize;         /* CONV: 1 or 3    */
+  int32_t act;           /* CONV: enum pv_act applied to the output */
+  int32_t _pad;
+  int64_t w_off, b_off;  /* CONV: offsets in floats into the flat parameter buffer */
+} pv_op;
+
+typedef struct pv_ved_plan {
+  int32_t batch;
+  int32_t ndim_in, ndim_out;       /* 1 or 2                                                            */
+  int32_t in_dim[2], out_dim[2];   /* spatial sizes (second entry unused for 1-D)                       */
+  int32_t in_ch, out_ch;
+  int32_t z_dim;
+  float   beta;                    /* KL scale_factor (ved.py:133,155)                                  */
+  int32_t lik;                     /* enum pv_lik                                                       */
+  int32_t sigmoid_out;
+  float   decoder_sig;
+  int32_t n_enc_ops, n_dec_ops;
+  pv_op   enc[PV_MAX_OPS];         /* encoder_z.feature_extractor.layers                                */
+  pv_op   dec[PV_MAX_OPS];         /* decoder.upsampler.layers (an UpsampleBlock = UPSAMPLE2 + CONV k1)  */
+  pv_layer head;                   /* features2latent.fc_latent: in = C*prod(spatial) in the torch flatten
+                                      order (c, spatial), out = 2*z_dim = [mu | softplus input]         */
+  pv_layer l2f;                    /* latent2features.fc: in = z_dim, out = dec_c0*prod(dec_dim0), same order */
+  int32_t dec_c0, dec_dim0[2];
+  int32_t _pad;
+  float*       params;
+  float*       grads;
+  float*       adam_m;
+  float*       adam_v;
+  int64_t      n_params;
+  const float* x;         /* (B, in_ch, *in_dim)                                                        */
+  const float* y;         /* (B, out_ch, *out_dim) target                                               */
+  const float* eps;       /* (B, z_dim)                                                                 */
+  void*        ws;
+  int64_t      ws_bytes;
+  float*       scalars;   /* out, 4 floats as in pv_ivae_plan                                           */
+  float*       z_loc;     /* out (B, z_dim), may be NULL                                                */
+  float*       z_scale;
+  float*       loc;       /* out (B, out_ch, *out_dim) decoder output, may be NULL                      */
+} pv_ved_plan;
+
+/* Workspace bytes for pv_ved_* calls with this plan; < 0: unsupported plan. */
+int64_t pv_ved_workspace_bytes(const pv_ved_plan* plan);
+
+/* Trace_ELBO.loss_and_grads for VED.guide + VED.model (models/ved.py:122-163): plan->scalars and, when
+ * want_grads != 0, plan->grads (every entry overwritten).  Replaces trainers/svi.py:109 `self.svi.step(x, y)`
+ * up to the optimizer (pv_adam_step). */
+int pv_ved_loss_and_grads(const pv_ved_plan* plan, int want_grads, void* stream);
+
+/* convEncoderNet.forward (nets/conv.py:56-64): z_loc, z_scale (B, z_dim). */
+int pv_ved_encode(const pv_ved_plan* plan, float* z_loc, float* z_scale, void* stream);
+
+/* convDecoderNet.forward (nets/conv.py:95-102): loc (B, out_ch, *out_dim) for z (B, z_dim). */
+int pv_ved_decode(const pv_ved_plan* plan, const float* z, float* loc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,6 +298,129 @@ def jelbo(p: Params, cfg: Config, x, eps, beta=1.0, grid=None):
                        "guide.latent_disc": (w * b1 * logq_d).sum()})
 
 
+# ======================================================================= VED (models/ved.py, nets/conv.py)
+@dataclass
+class VedConfig:
+    """models.VED constructor arguments that shape the computation (models/ved.py:89-118)."""
+    input_dim: Tuple[int, ...]
+    output_dim: Tuple[int, ...]
+    input_channels: int = 1
+    output_channels: int = 1
+    latent_dim: int = 2
+    hidden_dim_e: Optional[Sequence[Sequence[int]]] = None      # default [(32,), (64, 64), (128, 128)]
+    hidden_dim_d: Optional[Sequence[Sequence[int]]] = None      # default [(128, 128), (64, 64), (32,)]
+    activation: str = "lrelu"
+    sampler: str = "bernoulli"
+    sigmoid_d: bool = True
+    decoder_sig: float = 0.5
+
+    @property
+    def z_dim(self):
+        return self.latent_dim
+
+    @property
+    def he(self):
+        return [tuple(b) for b in (self.hidden_dim_e or [(32,), (64, 64), (128, 128)])]
+
+    @property
+    def hd(self):
+        return [tuple(b) for b in (self.hidden_dim_d or [(128, 128), (64, 64), (32,)])]
+
+
+def _conv(ndim):
+    return {1: F.conv1d, 2: F.conv2d}[ndim]
+
+
+def conv_encoder_forward(p: Params, cfg: VedConfig, x):
+    """convEncoderNet.forward (nets/conv.py:24-64): FeatureExtractor (conv k3 s1 p1 + activation per filter, a 2x
+    max-pool after every block but the last; conv.py:150-213) -> flatten (C, spatial) -> Linear -> (mu, softplus)."""
+    act, nd = _ACT[cfg.activation], len(cfg.input_dim)
+    h, idx = x, 0
+    blocks = cfg.he
+    for bi, block in enumerate(blocks):
+        for _ in block:
+            pre = "encoder_z.feature_extractor.layers.%d" % idx
+            h = act(_conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"], stride=1, padding=1))
+            idx += 2                                   # conv, activation
+        if bi + 1 < len(blocks):
+            h = (F.max_pool1d if nd == 1 else F.max_pool2d)(h, 2, 2)
+            idx += 1
+    enc = F.linear(h.reshape(h.shape[0], -1), p["encoder_z.features2latent.fc_latent.weight"],
+                   p["encoder_z.features2latent.fc_latent.bias"])
+    mu, sigma = enc.split(cfg.latent_dim, 1)
+    return mu, F.softplus(sigma)
+
+
+def conv_decoder_forward(p: Params, cfg: VedConfig, z):
+    """convDecoderNet.forward (nets/conv.py:67-102): Linear -> (C0, *out_dim / 2^blocks) -> per block [conv k3 +
+    activation per filter, then UpsampleBlock = 2x interpolate (nearest in 1-D, bilinear in 2-D; conv.py:105-147) +
+    conv k1] -> conv k1 to the output channels -> sigmoid (conv.py:216-262)."""
+    act, nd = _ACT[cfg.activation], len(cfg.output_dim)
+    blocks = cfg.hd
+    d0 = [int(v) // 2 ** len(blocks) for v in cfg.output_dim]
+    h = F.linear(z, p["decoder.latent2features.fc.weight"], p["decoder.latent2features.fc.bias"])
+    h = h.view(-1, blocks[0][0], *d0)
+    idx = 0
+    for block in blocks:
+        for _ in block:
+            pre = "decoder.upsampler.layers.%d" % idx
+            h = act(_conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"], stride=1, padding=1))
+            idx += 2
+        pre = "decoder.upsampler.layers.%d.conv" % idx
+        h = F.interpolate(h, scale_factor=2, mode="nearest" if nd == 1 else "bilinear")
+        h = _conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"])
+        idx += 1
+    pre = "decoder.upsampler.layers.%d" % idx
+    h = _conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"])
+    return torch.sigmoid(h) if cfg.sigmoid_d else h
+
+
+def ved_elbo(p: Params, cfg: VedConfig, x, y, eps, beta=1.0):
+    """Trace_ELBO of VED.guide/model (models/ved.py:122-163): z = mu + sigma*eps,
+    loss = -( sum_b log p(y_b | z_b) + beta*sum_b log N(z_b;0,1) - beta*sum_b log N(z_b;mu_b,sigma_b) )."""
+    b = x.shape[0]
+    z_loc, z_scale = conv_encoder_forward(p, cfg, x)
+    z = z_loc + z_scale * eps
+    logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)
+    logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)
+    loc = conv_decoder_forward(p, cfg, z)
+    ll = likelihood(cfg, loc.flatten(1)).log_prob(y.reshape(b, -1)).sum(-1)
+    t_ll, t_lp, t_lq = ll.sum(), (beta * logp).sum(), (beta * logq).sum()
+    return dict(loss=-(t_ll + t_lp - t_lq), ll=t_ll, logpz=t_lp, logqz=t_lq, z_loc=z_loc, z_scale=z_scale, z=z, loc=loc)
+
+
+class VedOracle:
+    """SVI.step for VED restated (same conventions as SVIOracle)."""
+
+    def __init__(self, params: Params, cfg: VedConfig, lr: float = 1e-3, dtype=torch.float32):
+        self.cfg = cfg
+        self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)
+        self.dtype = dtype
+        self.last = self.last_grads = None
+
+    def step(self, x, y, eps, beta=1.0) -> float:
+        out = ved_elbo(self.p, self.cfg, x.to(self.dtype), y.to(self.dtype), eps.to(self.dtype), beta)
+        if out["loss"].requires_grad:
+            out["loss"].backward()
+        self.last = out
+        self.last_grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in self.p.items()}
+        if any(v.grad is not None for v in self.p.values()):
+            self.opt.step()
+        for v in self.p.values():
+            if v.grad is not None:
+                v.grad = torch.zeros_like(v.grad)
+        return out["loss"].item()
+
+    def encode(self, x):
+        with torch.no_grad():
+            return conv_encoder_forward(self.p, self.cfg, x.to(self.dtype))
+
+    def decode(self, z):
+        with torch.no_grad():
+            return conv_decoder_forward(self.p, self.cfg, z.to(self.dtype))
+
+
 def param_order(p: Params, cfg: Config) -> List[str]:
     """state_dict order == construction order."""
     return list(p.keys())

@@ -53,10 +53,41 @@ class pv_ivae_plan(C.Structure):
     ]
 
 
+PV_MAX_OPS = 32
+OP = {"conv": 1, "maxpool2": 2, "upsample2": 3}
+
+
+class pv_op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
+                ("act", C.c_int32), ("_pad", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class pv_ved_plan(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("ndim_in", C.c_int32), ("ndim_out", C.c_int32),
+        ("in_dim", C.c_int32 * 2), ("out_dim", C.c_int32 * 2),
+        ("in_ch", C.c_int32), ("out_ch", C.c_int32), ("z_dim", C.c_int32),
+        ("beta", C.c_float), ("lik", C.c_int32), ("sigmoid_out", C.c_int32), ("decoder_sig", C.c_float),
+        ("n_enc_ops", C.c_int32), ("n_dec_ops", C.c_int32),
+        ("enc", pv_op * PV_MAX_OPS), ("dec", pv_op * PV_MAX_OPS),
+        ("head", pv_layer), ("l2f", pv_layer),
+        ("dec_c0", C.c_int32), ("dec_dim0", C.c_int32 * 2), ("_pad", C.c_int32),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+        ("n_params", C.c_int64),
+        ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every function include/pyroved_amd.h declares
 SIGNATURES = {
     "pv_version": (C.c_int, []),
     "pv_ivae_workspace_bytes": (C.c_int64, [C.POINTER(pv_ivae_plan)]),
+    "pv_ved_workspace_bytes": (C.c_int64, [C.POINTER(pv_ved_plan)]),
+    "pv_ved_loss_and_grads": (C.c_int, [C.POINTER(pv_ved_plan), C.c_int, C.c_void_p]),
+    "pv_ved_encode": (C.c_int, [C.POINTER(pv_ved_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_ved_decode": (C.c_int, [C.POINTER(pv_ved_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pv_ivae_uses_fused": (C.c_int, [C.POINTER(pv_ivae_plan)]),
     "pv_ivae_loss_and_grads": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
     "pv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

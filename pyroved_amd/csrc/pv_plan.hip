@@ -7,6 +7,7 @@
 #include "pv_common.h"
 #include "pv_kernels.h"
 #include "pv_sdec_fused.h"
+#include "pv_linear.h"
 
 namespace {
 
@@ -20,10 +21,14 @@ struct Carver {
   }
 };
 
+}  // namespace
+
 int64_t gemm_ws_need(int64_t M, int64_t N, int64_t K) {
   const int s = pv_gemm_pick_splits((int)M, (int)N, (int)K);
   return s > 1 ? (int64_t)s * M * (N + 1) * (int64_t)sizeof(float) : 0;     // + row-sum partials
 }
+
+namespace {
 
 struct Layout {
   // encoder
@@ -178,6 +183,9 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.total = c.off;
 }
 
+}  // namespace
+
+// ---- generic nn.Linear building blocks (exported to other translation units through pv_linear.h) ----
 // y = act(x W^T + b)
 int linear_fwd(const float* x, int64_t ldx, const float* W, const float* b, float* y, float* pre, int64_t ldy,
                int64_t M, int64_t K, int64_t N, int act, void* ws, int64_t wsb, hipStream_t s) {
@@ -218,6 +226,8 @@ int linear_wgrad(const float* dpre, int64_t lddp, const float* x, int64_t ldx, f
   if (db) PV_TRY(pv_colsum(dpre, lddp, M, (int)N, db, ws, wsb, s));
   return 0;
 }
+
+namespace {
 
 int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   const int64_t B = p->batch;

@@ -1,0 +1,302 @@
+// pv_ved.hip — host-side orchestration of one SVI step of models.VED behind the C ABI (include/pyroved_amd.h):
+//   convEncoderNet(x) -> (mu, sigma) -> z = mu + sigma*eps -> convDecoderNet(z) -> log p(y | z) -> ELBO -> gradients
+// (models/ved.py:122-163, nets/conv.py).  The networks arrive as op sequences (pv_op); every convolution is a GEMM
+// over channels-last activations (im2col for kernel 3, the activation itself for kernel 1) on the f32-input MFMA
+// GEMM of pv_gemm.hip with bias + activation fused; pooling / upsampling / layout changes are the gathers of
+// pv_conv.hip.  Backward walks the same sequence in reverse, re-creating each im2col instead of keeping it.
+// No allocation, no synchronisation, no retained state: buffers are carved from the caller's workspace.
+#include "pv_common.h"
+#include "pv_kernels.h"
+#include "pv_linear.h"
+#include "pv_conv.h"
+
+namespace {
+
+struct Shape { int H, W, C; int64_t elems(int64_t B) const { return B * H * W * C; } };
+
+struct VCarver {
+  char* base; int64_t off;
+  float* take(int64_t n) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += pv_align_up((n > 0 ? n : 1) * (int64_t)sizeof(float), 256);
+    return p;
+  }
+};
+
+struct VLayout {
+  Shape es[PV_MAX_OPS + 1], ds[PV_MAX_OPS + 1];       // activation shapes: es[0] = input, ds[0] = decoder seed
+  float* ea[PV_MAX_OPS + 1]; float* da[PV_MAX_OPS + 1];
+  float* x_nsc; float* y_nsc; float* loc_nsc;
+  float* feat; float* head; float* dhead; float* z; float* z_scale; float* dzc;
+  float* f0; float* df0;
+  float* llrow; float* dlda; float* llb;
+  float* g[2];                                         // gradient ping-pong (largest activation)
+  float* col;                                          // im2col / dcol scratch
+  void* scratch; int64_t scratch_bytes;
+  int64_t F;                                           // flattened feature size C*S of the encoder output
+  int64_t total;
+};
+
+bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
+  out = in;
+  if (o.kind == PV_OP_CONV) {
+    if (o.cin != in.C || o.cout < 1 || (o.ksize != 1 && o.ksize != 3)) return false;
+    out.C = o.cout;
+  } else if (o.kind == PV_OP_MAXPOOL2) {
+    out.H = in.H / 2; out.W = nd == 2 ? in.W / 2 : 1;
+    if (out.H < 1 || out.W < 1) return false;
+  } else if (o.kind == PV_OP_UPSAMPLE2) {
+    out.H = in.H * 2; out.W = nd == 2 ? in.W * 2 : 1;
+  } else {
+    return false;
+  }
+  return true;
+}
+
+bool valid_ved(const pv_ved_plan* p) {
+  if (!p || p->batch <= 0 || p->z_dim <= 0 || p->z_dim > 256) return false;
+  if ((p->ndim_in != 1 && p->ndim_in != 2) || (p->ndim_out != 1 && p->ndim_out != 2)) return false;
+  if (p->in_ch < 1 || p->out_ch < 1 || p->n_enc_ops < 1 || p->n_enc_ops > PV_MAX_OPS || p->n_dec_ops < 1 ||
+      p->n_dec_ops > PV_MAX_OPS)
+    return false;
+  if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN) return false;
+  if (p->lik == PV_LIK_BERNOULLI && !p->sigmoid_out) return false;
+  if (p->head.out_dim != 2 * p->z_dim || p->l2f.in_dim != p->z_dim) return false;
+  return true;
+}
+
+// shapes + workspace carving; false on an inconsistent plan
+bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
+  VCarver c{base, 0};
+  const int64_t B = p->batch, z = p->z_dim;
+  int64_t maxact = 0, maxcol = 0, scratch = 0;
+  auto upd = [](int64_t& m, int64_t v) { if (v > m) m = v; };
+  // ---- encoder ----
+  L.es[0] = Shape{p->in_dim[0], p->ndim_in == 2 ? p->in_dim[1] : 1, p->in_ch};
+  L.x_nsc = p->in_ch > 1 ? c.take(L.es[0].elems(B)) : nullptr;
+  L.ea[0] = nullptr;                                   // = x (or x_nsc), set by the caller
+  upd(maxact, L.es[0].elems(B));
+  for (int i = 0; i < p->n_enc_ops; ++i) {
+    if (!op_shape(p->enc[i], p->ndim_in, L.es[i], L.es[i + 1])) return false;
+    L.ea[i + 1] = c.take(L.es[i + 1].elems(B));
+    upd(maxact, L.es[i + 1].elems(B));
+    if (p->enc[i].kind == PV_OP_CONV) {
+      const int64_t rows = B * L.es[i].H * L.es[i].W, kk = p->enc[i].ksize == 3 ? (p->ndim_in == 2 ? 9 : 3) : 1;
+      const int64_t K = (int64_t)p->enc[i].cin * kk, N = p->enc[i].cout;
+      if (p->enc[i].ksize == 3) upd(maxcol, rows * K);
+      upd(scratch, gemm_ws_need(rows, N, K)); upd(scratch, gemm_ws_need(N, K, rows)); upd(scratch, gemm_ws_need(rows, K, N));
+    }
+  }
+  const Shape& fe = L.es[p->n_enc_ops];
+  L.F = (int64_t)fe.H * fe.W * fe.C;
+  if (p->head.in_dim != L.F) return false;
+  L.feat = c.take(B * L.F);
+  L.head = c.take(B * 2 * z); L.dhead = c.take(B * 2 * z);
+  L.z = c.take(B * z); L.z_scale = c.take(B * z); L.dzc = c.take(B * z);
+  upd(scratch, gemm_ws_need(B, 2 * z, L.F)); upd(scratch, gemm_ws_need(2 * z, L.F, B)); upd(scratch, gemm_ws_need(B, L.F, 2 * z));
+  // ---- decoder ----
+  L.ds[0] = Shape{p->dec_dim0[0], p->ndim_out == 2 ? p->dec_dim0[1] : 1, p->dec_c0};
+  const int64_t F0 = (int64_t)L.ds[0].H * L.ds[0].W * L.ds[0].C;
+  if (p->l2f.out_dim != F0) return false;
+  L.f0 = c.take(B * F0); L.df0 = c.take(B * F0);
+  L.da[0] = c.take(B * F0);
+  upd(maxact, B * F0);
+  upd(scratch, gemm_ws_need(B, F0, z)); upd(scratch, gemm_ws_need(F0, z, B)); upd(scratch, gemm_ws_need(B, z, F0));
+  for (int i = 0; i < p->n_dec_ops; ++i) {
+    if (!op_shape(p->dec[i], p->ndim_out, L.ds[i], L.ds[i + 1])) return false;
+    L.da[i + 1] = c.take(L.ds[i + 1].elems(B));
+    upd(maxact, L.ds[i + 1].elems(B));
+    if (p->dec[i].kind == PV_OP_CONV) {
+      const int64_t rows = B * L.ds[i].H * L.ds[i].W, kk = p->dec[i].ksize == 3 ? (p->ndim_out == 2 ? 9 : 3) : 1;
+      const int64_t K = (int64_t)p->dec[i].cin * kk, N = p->dec[i].cout;
+      if (p->dec[i].ksize == 3) upd(maxcol, rows * K);
+      upd(scratch, gemm_ws_need(rows, N, K)); upd(scratch, gemm_ws_need(N, K, rows)); upd(scratch, gemm_ws_need(rows, K, N));
+    }
+  }
+  const Shape& od = L.ds[p->n_dec_ops];
+  if (od.H != p->out_dim[0] || od.W != (p->ndim_out == 2 ? p->out_dim[1] : 1) || od.C != p->out_ch) return false;
+  const int64_t OUT = od.elems(B);
+  L.y_nsc = p->out_ch > 1 ? c.take(OUT) : nullptr;
+  L.loc_nsc = p->out_ch > 1 ? c.take(OUT) : nullptr;
+  L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B);
+  L.g[0] = c.take(maxact); L.g[1] = c.take(maxact);
+  L.col = c.take(maxcol);
+  L.scratch_bytes = pv_align_up(scratch, 256);
+  L.scratch = base ? (void*)(base + c.off) : nullptr;
+  c.off += L.scratch_bytes;
+  L.total = c.off;
+  return true;
+}
+
+int kk_of(const pv_op& o, int nd) { return o.ksize == 3 ? (nd == 2 ? 9 : 3) : 1; }
+
+// one op forward: in (shape si) -> out (shape so)
+int op_fwd(const pv_ved_plan* p, const pv_op& o, int nd, const float* in, const Shape& si, float* out, const VLayout& L,
+           hipStream_t s) {
+  const int B = p->batch;
+  if (o.kind == PV_OP_CONV) {
+    const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
+    const float* a = in;
+    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, L.col, B, si.H, si.W, si.C, nd, s)); a = L.col; }
+    return linear_fwd(a, K, p->params + o.w_off, o.b_off >= 0 ? p->params + o.b_off : nullptr, out, nullptr, o.cout,
+                      rows, K, o.cout, o.act, L.scratch, L.scratch_bytes, s);
+  }
+  if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
+  return pv_upsample2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
+}
+
+// one op backward: g = dL/d(out) (post-activation for CONV; modified in place), writes parameter gradients and, when
+// gin != null, dL/d(in)
+int op_bwd(const pv_ved_plan* p, const pv_op& o, int nd, const float* in, const Shape& si, const float* out,
+           const Shape& so, float* g, float* gin, const VLayout& L, hipStream_t s) {
+  const int B = p->batch;
+  if (o.kind == PV_OP_CONV) {
+    const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
+    PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));                       // g = dL/d(pre-activation)
+    const float* a = in;
+    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, L.col, B, si.H, si.W, si.C, nd, s)); a = L.col; }
+    PV_TRY(linear_wgrad(g, o.cout, a, K, p->grads + o.w_off, o.b_off >= 0 ? p->grads + o.b_off : nullptr, rows, K,
+                        o.cout, L.scratch, L.scratch_bytes, s));
+    if (!gin) return 0;
+    float* dcol = o.ksize == 3 ? L.col : gin;
+    PV_TRY(linear_dgrad(g, o.cout, p->params + o.w_off, dcol, K, nullptr, nullptr, 0, PV_ACT_NONE, rows, K, o.cout,
+                        L.scratch, L.scratch_bytes, s));
+    if (o.ksize == 3) PV_TRY(pv_col2im3(dcol, gin, B, si.H, si.W, si.C, nd, s));
+    return 0;
+  }
+  if (!gin) return 0;
+  if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s);
+  return pv_upsample2_bwd(g, gin, B, si.H, si.W, si.C, nd, s);
+}
+
+// encoder forward up to (head, z, z_scale[, KL scalars]); eps == null: inference (z = unused)
+int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z_scale_out, bool with_kl, hipStream_t s) {
+  const int64_t B = p->batch;
+  const Shape& s0 = L.es[0];
+  const float* x = p->x;
+  if (p->in_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->x, L.x_nsc, B, p->in_ch, (int64_t)s0.H * s0.W, s)); x = L.x_nsc; }
+  L.ea[0] = const_cast<float*>(x);
+  for (int i = 0; i < p->n_enc_ops; ++i)
+    PV_TRY(op_fwd(p, p->enc[i], p->ndim_in, L.ea[i], L.es[i], L.ea[i + 1], L, s));
+  const Shape& fe = L.es[p->n_enc_ops];
+  // torch flattens (C, spatial): features2latent sees channels-first order
+  PV_TRY(pv_nsc_to_ncs(L.ea[p->n_enc_ops], L.feat, B, fe.C, (int64_t)fe.H * fe.W, s));
+  PV_TRY(linear_fwd(L.feat, L.F, p->params + p->head.w_off, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr,
+                    L.head, nullptr, 2 * p->z_dim, B, L.F, 2 * p->z_dim, PV_ACT_NONE, L.scratch, L.scratch_bytes, s));
+  PvHead h{};
+  h.head = L.head; h.eps = with_kl ? p->eps : L.z_scale; h.z = L.z; h.z_scale = L.z_scale;
+  h.z_loc_out = z_loc_out; h.z_scale_out = z_scale_out;
+  h.scalars = with_kl ? p->scalars : L.dhead;       // (inference: the KL slots land in scratch)
+  h.B = (int)B; h.z_dim = p->z_dim; h.beta = with_kl ? p->beta : 0.0f;
+  return pv_head_fwd(h, s);
+}
+
+// decoder forward from z (B, z_dim) to the logits / pre-sigmoid output in L.da[n_dec_ops]
+int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_t s) {
+  const int64_t B = p->batch;
+  const Shape& d0 = L.ds[0];
+  const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
+  PV_TRY(linear_fwd(z, p->z_dim, p->params + p->l2f.w_off, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr,
+                    L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.scratch, L.scratch_bytes, s));
+  PV_TRY(pv_ncs_to_nsc(L.f0, L.da[0], B, d0.C, (int64_t)d0.H * d0.W, s));       // view(-1, C0, *dims) -> channels-last
+  for (int i = 0; i < p->n_dec_ops; ++i)
+    PV_TRY(op_fwd(p, p->dec[i], p->ndim_out, L.da[i], L.ds[i], L.da[i + 1], L, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t pv_ved_workspace_bytes(const pv_ved_plan* plan) {
+  if (!valid_ved(plan)) return PV_EINVAL;
+  VLayout L;
+  if (!vcarve(plan, nullptr, L)) return PV_EINVAL;
+  return L.total;
+}
+
+extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void* stream) {
+  if (!valid_ved(p) || !p->params || !p->x || !p->y || !p->eps || !p->scalars || !p->ws) return PV_EINVAL;
+  if (want_grads && !p->grads) return PV_EINVAL;
+  VLayout L;
+  if (!vcarve(p, (char*)p->ws, L)) return PV_EINVAL;
+  if (p->ws_bytes < L.total) return PV_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t B = p->batch, z = p->z_dim;
+  PV_TRY(ved_encoder_fwd(p, L, p->z_loc, p->z_scale, true, s));
+  PV_TRY(ved_decoder_fwd(p, L, L.z, s));
+  // ---- likelihood of the target (ved.py:141-145) ----
+  const Shape& od = L.ds[p->n_dec_ops];
+  const int64_t OUT = od.elems(B), per = OUT / B, S = (int64_t)od.H * od.W;
+  const float* y = p->y;
+  if (p->out_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->y, L.y_nsc, B, p->out_ch, S, s)); y = L.y_nsc; }
+  float* loc = p->loc ? (p->out_ch > 1 ? L.loc_nsc : p->loc) : nullptr;
+  PV_TRY(pv_lik_elem(L.da[p->n_dec_ops], y, OUT, p->lik, p->sigmoid_out, p->decoder_sig, loc, L.llrow,
+                     want_grads ? L.dlda : nullptr, s));
+  if (p->loc && p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, p->loc, B, p->out_ch, S, s));
+  PV_TRY(pv_segsum(L.llrow, B, per, L.llb, s));
+  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, nullptr, 0, p->beta, s));
+  if (!want_grads) return 0;
+
+  // ---- backward: decoder ops in reverse ----
+  float* g = L.dlda;                                   // dL/d(output of the last op), loss = -ELBO folded in by lik_elem
+  int pp = 0;
+  for (int i = p->n_dec_ops - 1; i >= 0; --i) {
+    float* gin = L.g[pp];
+    PV_TRY(op_bwd(p, p->dec[i], p->ndim_out, L.da[i], L.ds[i], L.da[i + 1], L.ds[i + 1], g, gin, L, s));
+    g = gin; pp ^= 1;
+  }
+  const Shape& d0 = L.ds[0];
+  const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
+  PV_TRY(pv_nsc_to_ncs(g, L.df0, B, d0.C, (int64_t)d0.H * d0.W, s));
+  PV_TRY(linear_wgrad(L.df0, F0, L.z, z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, B,
+                      z, F0, L.scratch, L.scratch_bytes, s));
+  PV_TRY(linear_dgrad(L.df0, F0, p->params + p->l2f.w_off, L.dzc, z, nullptr, nullptr, 0, PV_ACT_NONE, B, z, F0,
+                      L.scratch, L.scratch_bytes, s));
+  // ---- reparameterised sample + sampled KL -> head ----
+  PvHeadBwd hb{};
+  hb.dzc = L.dzc; hb.ldzc = z; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps; hb.head = L.head; hb.dhead = L.dhead;
+  hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = 0; hb.beta = p->beta;
+  PV_TRY(pv_head_bwd(hb, s));
+  PV_TRY(linear_wgrad(L.dhead, 2 * z, L.feat, L.F, p->grads + p->head.w_off,
+                      p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, B, L.F, 2 * z, L.scratch, L.scratch_bytes, s));
+  float* dfeat = L.g[pp];
+  PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + p->head.w_off, dfeat, L.F, nullptr, nullptr, 0, PV_ACT_NONE, B, L.F,
+                      2 * z, L.scratch, L.scratch_bytes, s));
+  pp ^= 1;
+  const Shape& fe = L.es[p->n_enc_ops];
+  g = L.g[pp];
+  PV_TRY(pv_ncs_to_nsc(dfeat, g, B, fe.C, (int64_t)fe.H * fe.W, s));
+  pp ^= 1;
+  // ---- encoder ops in reverse (no input gradient for the first one) ----
+  for (int i = p->n_enc_ops - 1; i >= 0; --i) {
+    float* gin = i > 0 ? L.g[pp] : nullptr;
+    PV_TRY(op_bwd(p, p->enc[i], p->ndim_in, L.ea[i], L.es[i], L.ea[i + 1], L.es[i + 1], g, gin, L, s));
+    g = gin; pp ^= 1;
+  }
+  return 0;
+}
+
+extern "C" int pv_ved_encode(const pv_ved_plan* p, float* z_loc, float* z_scale, void* stream) {
+  if (!valid_ved(p) || !p->params || !p->x || !p->ws || !z_loc || !z_scale) return PV_EINVAL;
+  VLayout L;
+  if (!vcarve(p, (char*)p->ws, L)) return PV_EINVAL;
+  if (p->ws_bytes < L.total) return PV_EWS;
+  return ved_encoder_fwd(p, L, z_loc, z_scale, false, (hipStream_t)stream);
+}
+
+extern "C" int pv_ved_decode(const pv_ved_plan* p, const float* z, float* loc, void* stream) {
+  if (!valid_ved(p) || !p->params || !p->ws || !z || !loc) return PV_EINVAL;
+  VLayout L;
+  if (!vcarve(p, (char*)p->ws, L)) return PV_EINVAL;
+  if (p->ws_bytes < L.total) return PV_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t B = p->batch;
+  PV_TRY(ved_decoder_fwd(p, L, z, s));
+  const Shape& od = L.ds[p->n_dec_ops];
+  const int64_t OUT = od.elems(B), S = (int64_t)od.H * od.W;
+  float* out = p->out_ch > 1 ? L.loc_nsc : loc;
+  // the output non-linearity only (no likelihood): reuse lik_elem's `loc` output
+  PV_TRY(pv_lik_elem(L.da[p->n_dec_ops], L.da[p->n_dec_ops], OUT, PV_LIK_GAUSSIAN, p->sigmoid_out, 1.0f, out, nullptr,
+                     nullptr, s));
+  if (p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, loc, B, p->out_ch, S, s));
+  return 0;
+}

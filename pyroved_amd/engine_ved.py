@@ -1,0 +1,218 @@
+"""
+engine_ved.py — host-side driver of the HIP SVI step for models.VED (conv encoder -> z -> conv decoder).
+
+Same device-memory contract as engine.IVAEEngine (one flat fp32 parameter buffer the nn.Parameters are views of,
+flat gradient buffer with 4 trailing ELBO scalars, flat Adam moments, caller-owned workspace), driving
+pv_ved_loss_and_grads / pv_ved_encode / pv_ved_decode (include/pyroved_amd.h) with a pv_ved_plan read off the
+modules' layer sequences (nets/conv.py: FeatureExtractor.layers, Upsampler.layers).
+
+Replaces what Pyro's SVI / Trace_ELBO hold for VED in the reference (models/ved.py:122-163, trainers/svi.py:109).
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .engine import IVAEEngine, UnsupportedModel
+from .nets.conv import convEncoderNet, convDecoderNet, UpsampleBlock
+
+
+def _conv_types():
+    return (nn.Conv1d, nn.Conv2d)
+
+
+class VEDEngine(IVAEEngine):
+    """Binds a VED model (encoder_z: convEncoderNet, decoder: convDecoderNet) to the HIP library."""
+
+    # ------------------------------------------------------------------ structure
+    def _check_model(self):
+        m = self.model
+        enc, dec = m.encoder_z, m.decoder
+        self.K = 0
+        if not isinstance(enc, convEncoderNet) or not isinstance(dec, convDecoderNet):
+            raise UnsupportedModel("the HIP VED path needs convEncoderNet / convDecoderNet (got %s / %s)"
+                                   % (type(enc).__name__, type(dec).__name__))
+        if not enc.softplus_out:
+            raise UnsupportedModel("encoder without softplus_out is not supported")
+        if len(enc.input_dim) not in (1, 2) or len(dec.output_dim) not in (1, 2):
+            raise UnsupportedModel("the HIP conv path covers 1-D and 2-D data")
+        name = m.sampler_d.name
+        if name not in _abi.LIK:
+            raise UnsupportedModel("decoder sampler %r is not implemented in the HIP path yet" % name)
+        if name == "bernoulli" and not dec.sigmoid_out:
+            raise UnsupportedModel("bernoulli likelihood needs sigmoid_d=True")
+        self._ops(enc.feature_extractor.layers, enc.feature_extractor.activation)      # validates
+        self._ops(dec.upsampler.layers, dec.upsampler.activation)
+
+    def _param_order(self):
+        return list(self.model.named_parameters())          # state_dict order, nothing merged
+
+    def _ops(self, layers: nn.Sequential, activation, prefix: Optional[str] = None):
+        """nn.Sequential of nets/conv.py -> list of (kind, conv module | None, act, key prefix)."""
+        mods = list(layers)
+        ops, i = [], 0
+        while i < len(mods):
+            mod, pos = mods[i], i
+            if isinstance(mod, _conv_types()):
+                k = mod.kernel_size[0]
+                if (any(v != k for v in mod.kernel_size) or k not in (1, 3) or any(v != 1 for v in mod.stride)
+                        or any(v != k // 2 for v in mod.padding) or any(v != 1 for v in mod.dilation) or mod.groups != 1):
+                    raise UnsupportedModel("conv layers must be kernel 3 / padding 1 or kernel 1, stride 1")
+                act = None
+                if i + 1 < len(mods) and not isinstance(mods[i + 1], _conv_types() + (UpsampleBlock, nn.MaxPool1d,
+                                                                                       nn.MaxPool2d)):
+                    if isinstance(mods[i + 1], (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+                        raise UnsupportedModel("batch normalisation is not implemented in the HIP conv path")
+                    act = activation
+                    i += 1
+                    if i + 1 < len(mods) and isinstance(mods[i + 1], (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+                        raise UnsupportedModel("batch normalisation is not implemented in the HIP conv path")
+                ops.append(("conv", mod, act, None if prefix is None else "%s.%d" % (prefix, pos)))
+            elif isinstance(mod, (nn.MaxPool1d, nn.MaxPool2d)):
+                ops.append(("maxpool2", None, None, None))
+            elif isinstance(mod, UpsampleBlock):
+                if mod.mode != "nearest" or mod.scale_factor != 2:
+                    raise UnsupportedModel("2-D decoders (bilinear upsampling) are not implemented in the HIP path yet")
+                ops.append(("upsample2", None, None, None))
+                ops.append(("conv", mod.conv, None, None if prefix is None else "%s.%d.conv" % (prefix, i)))
+            else:
+                raise UnsupportedModel("unsupported layer %s in a conv stack" % type(mod).__name__)
+            i += 1
+        if len(ops) > _abi.PV_MAX_OPS:
+            raise UnsupportedModel("more than %d ops in a conv stack" % _abi.PV_MAX_OPS)
+        return ops
+
+    def _fill_ops(self, arr, ops):
+        for j, (kind, mod, act, key) in enumerate(ops):
+            o = arr[j]
+            o.kind = _abi.OP[kind]
+            if kind == "conv":
+                o.cin, o.cout, o.ksize = mod.in_channels, mod.out_channels, mod.kernel_size[0]
+                o.act = _abi.ACT[act]
+                o.w_off = self._layout[key + ".weight"]
+                o.b_off = self._layout[key + ".bias"] if mod.bias is not None else -1
+        return len(ops)
+
+    def _static_plan(self):
+        m = self.model
+        enc, dec = m.encoder_z, m.decoder
+        p = _abi.pv_ved_plan()
+        p.ndim_in, p.ndim_out = len(enc.input_dim), len(dec.output_dim)
+        for i, d in enumerate(enc.input_dim):
+            p.in_dim[i] = d
+        for i, d in enumerate(dec.output_dim):
+            p.out_dim[i] = d
+        p.in_ch, p.out_ch, p.z_dim = enc.input_channels, dec.output_channels, m.z_dim
+        p.lik = _abi.LIK[m.sampler_d.name]
+        p.sigmoid_out = int(dec.sigmoid_out)
+        p.decoder_sig = m.sampler_d.decoder_sig
+        p.n_enc_ops = self._fill_ops(p.enc, self._ops(enc.feature_extractor.layers, enc.feature_extractor.activation,
+                                                      "encoder_z.feature_extractor.layers"))
+        p.n_dec_ops = self._fill_ops(p.dec, self._ops(dec.upsampler.layers, dec.upsampler.activation,
+                                                      "decoder.upsampler.layers"))
+        p.head = self._layer("encoder_z.features2latent.fc_latent", enc.features2latent.fc_latent, None)
+        p.l2f = self._layer("decoder.latent2features.fc", dec.latent2features.fc, None)
+        shape0 = [int(v) for v in dec.latent2features.reshape_]
+        p.dec_c0 = shape0[0]
+        for i, d in enumerate(shape0[1:]):
+            p.dec_dim0[i] = d
+        p.params, p.grads = self.flat.data_ptr(), self.grad.data_ptr()
+        p.adam_m, p.adam_v = self.m.data_ptr(), self.v.data_ptr()
+        p.n_params = self.n_flat
+        p.scalars = self.scalars.data_ptr()
+        return p
+
+    def _plan(self, batch: int, beta: float = 1.0):
+        p = self._static
+        p.batch = batch
+        p.beta = float(beta)
+        p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
+        need = _abi.lib().pv_ved_workspace_bytes(C.byref(p))
+        if need < 0:
+            raise _abi.PvError("pyroved_amd: unsupported VED plan (pv_ved_workspace_bytes -> %d)" % need)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(int(need), device=self.device, dtype=torch.uint8)
+        p.ws, p.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        return p
+
+    def _in_shape(self, b):
+        e = self.model.encoder_z
+        return (b, e.input_channels) + tuple(e.input_dim)
+
+    def _out_shape(self, b):
+        d = self.model.decoder
+        return (b, d.output_channels) + tuple(d.output_dim)
+
+    # ------------------------------------------------------------------ calls
+    def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
+                       scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None):
+        """Enqueues Trace_ELBO.loss_and_grads(VED.model, VED.guide) on the current stream: x (B, C, *input_dim),
+        target y (B, C', *output_dim), eps (B, z_dim)."""
+        self.ensure_bound()
+        if y is None:
+            raise ValueError("VED needs the target y")
+        b = x.shape[0]
+        p = self._plan(b, beta)
+        x = self._prep(x, "x", self._in_shape(b))
+        y = self._prep(y, "y", self._out_shape(b))
+        eps = self._prep(eps, "eps", (b, p.z_dim))
+        p.x, p.y, p.eps = x.data_ptr(), y.data_ptr(), eps.data_ptr()
+        if z_out is not None:
+            p.z_loc, p.z_scale = z_out[0].data_ptr(), z_out[1].data_ptr()
+        if loc_out is not None:
+            p.loc = loc_out.data_ptr()
+        if scalars_out is not None:
+            p.scalars = scalars_out.data_ptr()
+        try:
+            _abi.check(_abi.lib().pv_ved_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),
+                       "pv_ved_loss_and_grads")
+        finally:
+            p.scalars = self.scalars.data_ptr()
+        if want_grads:
+            self.grads_live = True
+        self._keep = (x, y, eps)
+
+    def encode(self, x, y=None):
+        self.ensure_bound()
+        b = x.shape[0]
+        p = self._plan(b)
+        x = self._prep(x, "x", self._in_shape(b))
+        p.x = x.data_ptr()
+        z_loc = torch.empty(b, p.z_dim, device=self.device, dtype=torch.float32)
+        z_scale = torch.empty_like(z_loc)
+        _abi.check(_abi.lib().pv_ved_encode(C.byref(p), _abi.ptr(z_loc), _abi.ptr(z_scale), _abi.current_stream()),
+                   "pv_ved_encode")
+        self._keep = (x,)
+        return z_loc, z_scale
+
+    def decode(self, z, *unused, **unused_kw):
+        self.ensure_bound()
+        b = z.shape[0]
+        p = self._plan(b)
+        z = self._prep(z, "z", (b, p.z_dim))
+        loc = torch.empty(self._out_shape(b), device=self.device, dtype=torch.float32)
+        _abi.check(_abi.lib().pv_ved_decode(C.byref(p), _abi.ptr(z), _abi.ptr(loc), _abi.current_stream()),
+                   "pv_ved_decode")
+        self._keep = (z,)
+        return loc
+
+    def uses_fused(self, batch: int) -> bool:
+        return False
+
+
+def _owner_engine(net):
+    eng = getattr(net, "_pv_engine", None)
+    if eng is None:
+        raise _abi.PvError("pyroved_amd: conv nets run through the model's HIP engine (models.VED); a stand-alone "
+                           "convEncoderNet / convDecoderNet has no forward of its own in this build")
+    return eng
+
+
+def conv_encoder_forward(net, x):
+    return _owner_engine(net).encode(x)
+
+
+def conv_decoder_forward(net, z):
+    return _owner_engine(net).decode(z)

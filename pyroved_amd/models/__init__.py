@@ -2,5 +2,6 @@
 from .base import baseVAE
 from .ivae import iVAE
 from .jivae import jiVAE
+from .ved import VED
 
-__all__ = ['iVAE', 'jiVAE']
+__all__ = ['iVAE', 'jiVAE', 'VED']

@@ -214,6 +214,62 @@ def run_jsteps(name, data_dim, invariances, discrete_dim, batch, steps=3, latent
     print("wrote", name, "loss0=%.6f" % out["s0.loss"], "keys=%d" % len(out))
 
 
+def run_ved_steps(name, input_dim, output_dim, batch, steps=3, latent_dim=2, model_kw=None, scale_factor=None):
+    """VED (models/ved.py:89-163: conv encoder -> z -> conv decoder, Bernoulli on the target) through
+    SVItrainer.svi.step(x, y): loss, ELBO terms, eps, z, gradients and parameters per step, then encode/decode."""
+    model_kw = dict(model_kw or {})
+    out = {}
+    out["meta.input_dim"] = np.array(input_dim)
+    out["meta.output_dim"] = np.array(output_dim)
+    out["meta.batch"] = np.int64(batch)
+    out["meta.latent_dim"] = np.int64(latent_dim)
+    out["meta.steps"] = np.int64(steps)
+    out["meta.scale_factor"] = np.float64(1.0 if scale_factor is None else scale_factor)
+    for k, v in model_kw.items():
+        out["meta.model_kw." + k] = np.array(str(v))
+    model = models.VED(input_dim, output_dim, latent_dim=latent_dim, seed=1, **model_kw)
+    names = {id(p): n for n, p in model.named_parameters()}
+    for n, p in model.named_parameters():
+        put(out, "init." + n, digest(p))
+    g = torch.Generator().manual_seed(0)
+    in_ch, out_ch = model_kw.get("input_channels", 1), model_kw.get("output_channels", 1)
+    x = torch.rand(batch, in_ch, *input_dim, generator=g)
+    y = torch.rand(batch, out_ch, *output_dim, generator=g)
+    out["x"], out["y"] = x.numpy().copy(), y.numpy().copy()
+    trainer = trainers.SVItrainer(model, seed=1, device="cpu")
+    step_kw = {} if scale_factor is None else {"scale_factor": scale_factor}
+    for k in range(steps):
+        grads = {}
+        real_optim = trainer.svi.optim
+
+        def spy(params, _real=real_optim, _g=grads):
+            for p in params:
+                _g[names[id(p)]] = p.grad.detach().clone()
+            _real(params)
+        trainer.svi.optim = spy
+        loss = trainer.svi.step(x, y, **step_kw)
+        trainer.svi.optim = real_optim
+        tap = _minipyro.tap()
+        pre = "s%d" % k
+        out[pre + ".loss"] = np.float64(loss)
+        for tn, tv in tap["terms"].items():
+            out[pre + ".term." + tn] = np.float64(tv.item())
+        gfn = tap["guide_fns"]["z"].base_dist
+        out[pre + ".eps"] = tap["z.eps"].numpy().copy()
+        out[pre + ".z_loc"] = gfn.loc.detach().numpy().copy()
+        out[pre + ".z_scale"] = gfn.scale.detach().numpy().copy()
+        out[pre + ".z"] = tap["sites"]["guide.z"].numpy().copy()
+        for n, gr in grads.items():
+            put(out, pre + ".grad." + n, digest(gr))
+        for n, p in model.named_parameters():
+            put(out, pre + ".param." + n, digest(p))
+    z_loc, z_scale = model.encode(x)
+    out["enc.z_loc"], out["enc.z_scale"] = z_loc.numpy().copy(), z_scale.numpy().copy()
+    out["dec.loc"] = model.decode(z_loc).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "loss0=%.6f" % out["s0.loss"], "keys=%d" % len(out))
+
+
 def run_step0_loc(name, data_dim, invariances, batch, latent_dim=2, xkind="rand"):
     """Step-0 forward only, with the decoder's `loc` and the transformed grid."""
     out = {}
@@ -316,6 +372,15 @@ if __name__ == "__main__":
         run_jsteps("jivae_8x8_rt_k3_b4_sf", (8, 8), ["r", "t"], 3, batch=4, scale_factor=[2.0, 3.0])
         run_jsteps("jivae_1d16_t_k2_b5", (16,), ["t"], 2, batch=5)
         run_jsteps("jivae_28x28_r_k10_b16", (28, 28), ["r"], 10, batch=16, steps=2)
+    # VED: conv encoder / conv decoder (BASELINE config 5 family: 2-D image -> 1-D spectrum)
+    if only is None or "ved" in only:
+        small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])
+        run_ved_steps("ved_16x16_to_32_small_b5", (16, 16), (32,), batch=5, model_kw=small)
+        run_ved_steps("ved_16x16_to_32_small_b5_relu_sf", (16, 16), (32,), batch=5, scale_factor=2.5,
+                      model_kw=dict(small, activation="relu"))
+        run_ved_steps("ved_12x20_to_24_small_b3_l3", (12, 20), (24,), batch=3, latent_dim=3, model_kw=small)
+        run_ved_steps("ved_1d32_to_1d32_small_b4", (32,), (32,), batch=4, model_kw=small)
+        run_ved_steps("ved_64x64_to_128_b4", (64, 64), (128,), batch=4, steps=2)
     if only is not None:
         sys.exit(0)
     # epoch loops through the reference SVItrainer + DataLoader

@@ -334,6 +334,91 @@ def test_jivae_trainer_epochs_vs_oracle(gpu_device):
     np.testing.assert_allclose(losses["gpu"], losses["cpu"], rtol=1e-4)
 
 
+VED_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ved_*.npz")))
+
+
+@pytest.mark.parametrize("name", VED_CASES)
+def test_ved_steps_vs_golden_and_oracle(gpu_device, name):
+    """models.VED through the HIP path (conv stacks as im2col + MFMA GEMMs, pooling / upsampling gathers) vs the
+    reference's recorded SVI steps and the CPU oracle: loss, ELBO terms, z, gradients, parameters; encode / decode."""
+    from test_oracle_golden import ved_case
+    gold = load_golden(name)
+    c = ved_case(gold)
+    model = pv.models.VED(c["input_dim"], c["output_dim"], latent_dim=c["latent_dim"], seed=1, device="cuda", **c["kw"])
+    cfg = orc.VedConfig(input_dim=c["input_dim"], output_dim=c["output_dim"], latent_dim=c["latent_dim"],
+                        hidden_dim_e=c["kw"].get("hidden_dim_e"), hidden_dim_d=c["kw"].get("hidden_dim_d"),
+                        activation=c["kw"].get("activation", "lrelu"))
+    eng = model.engine()
+    o = orc.VedOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x, y = torch.from_numpy(gold["x"]), torch.from_numpy(gold["y"])
+    b = x.shape[0]
+    zl, zs = torch.empty(b, cfg.z_dim, device="cuda"), torch.empty(b, cfg.z_dim, device="cuda")
+    for k in range(c["steps"]):
+        pre = "s%d" % k
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eng.loss_and_grads(x.cuda(), eps.cuda(), c["beta"], y.cuda(), z_out=(zl, zs))
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=RTOL_ELBO, err_msg="loss")
+        np.testing.assert_allclose(s[1], float(gold[pre + ".term.model.obs"]), rtol=RTOL_ELBO)
+        np.testing.assert_allclose(s[2], float(gold[pre + ".term.model.z"]), rtol=1e-4)
+        np.testing.assert_allclose(s[3], float(gold[pre + ".term.guide.z"]), rtol=1e-4)
+        np.testing.assert_allclose(zl.cpu().numpy(), gold[pre + ".z_loc"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(zs.cpu().numpy(), gold[pre + ".z_scale"], rtol=1e-4, atol=2e-6)
+        o.step(x, y, eps, c["beta"])
+        for key in o.p:
+            g = eng.grad_of(key)
+            err = rel_l2(g, o.last_grads[key])
+            assert err < RTOL_GRAD, "step %d grad %s: rel l2 error %.3e vs oracle" % (k, key, err)
+            check_digest(g, gold, pre + ".grad." + key, rtol=5e-4, atol=1e-6, what=name)
+        eng.adam_step()
+        for key, p in model.state_dict().items():
+            gref = o.last_grads[key]
+            ill = (gref.abs() < 1e-5 * gref.abs().max()).reshape(p.shape)        # see test_steps_vs_golden_and_oracle
+            pc, pr = p.detach().cpu(), o.p[key].detach()
+            # (dead relu / lrelu units give many exactly-zero gradients: no bound on how many entries are `ill`)
+            assert not ill.any() or (pc - pr)[ill].abs().max().item() <= 2e-3, key
+            assert rel_l2(pc[~ill], pr[~ill]) < 5e-5, key
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+    z_loc, z_scale = model.encode(x)
+    zlo, zso = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), zlo.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z_scale.numpy(), zso.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=2e-3, atol=2e-4)
+    dec = model.decode(torch.from_numpy(gold["enc.z_loc"]))
+    np.testing.assert_allclose(dec.numpy(), o.decode(torch.from_numpy(gold["enc.z_loc"])).numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(dec.numpy(), gold["dec.loc"], rtol=2e-3, atol=2e-4)
+    mu, sd = model.predict(x[:2])
+    assert mu.shape == dec[:2].shape and sd.shape == mu.shape and torch.isfinite(mu).all()
+
+
+def test_ved_trainer_epochs_vs_oracle(gpu_device):
+    """SVItrainer(VED).step(loader of (x, y)) vs the oracle driven through the same DataLoader / eps stream."""
+    small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.rand(9, 1, 16, 16, generator=g), torch.rand(9, 1, 32, generator=g)
+    losses = {}
+    for which in ("gpu", "cpu"):
+        model = pv.models.VED((16, 16), (32,), seed=1, device="cuda" if which == "gpu" else "cpu", **small)
+        loader = pv.utils.init_dataloader(x, y, batch_size=4)
+        if which == "gpu":
+            tr = pv.trainers.SVItrainer(model, seed=1)
+            for _ in range(2):
+                tr.step(loader, scale_factor=1.5)
+            losses[which] = tr.loss_history["training_loss"]
+        else:
+            cfg = orc.VedConfig(input_dim=(16, 16), output_dim=(32,), **small)
+            pv.utils.set_deterministic_mode(1)
+            o = orc.VedOracle(model.state_dict(), cfg)
+            hist = []
+            for _ in range(2):
+                tot = 0.0
+                for xb, yb in loader:
+                    tot += o.step(xb, yb, torch.empty(xb.shape[0], 2).normal_(), 1.5)
+                hist.append(tot / len(loader.dataset))
+            losses[which] = hist
+    np.testing.assert_allclose(losses["gpu"], losses["cpu"], rtol=1e-4)
+
+
 @pytest.mark.parametrize("name", EPOCH_CASES)
 def test_trainer_epochs_vs_golden(gpu_device, name):
     """The product's SVItrainer driven exactly like the reference's (same DataLoader, same seeds):

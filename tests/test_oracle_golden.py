@@ -195,3 +195,55 @@ def test_jivae_oracle_steps_match_reference(name):
     np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(alpha.numpy(), gold["enc.alpha"], rtol=1e-4, atol=1e-6)
     assert (alpha.argmax(1).numpy() == gold["enc.classes"]).all()
+
+
+# ---------------------------------------------------------------- VED (models/ved.py, nets/conv.py)
+VED_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ved_*.npz")))
+
+
+def ved_case(gold):
+    import ast
+    kw = {}
+    for k in gold:
+        if k.startswith("meta.model_kw."):
+            v = str(gold[k])
+            kw[k[len("meta.model_kw."):]] = ast.literal_eval(v) if v[0] in "[(" else v
+    return dict(input_dim=tuple(int(v) for v in gold["meta.input_dim"]),
+                output_dim=tuple(int(v) for v in gold["meta.output_dim"]),
+                latent_dim=int(gold["meta.latent_dim"]), steps=int(gold["meta.steps"]),
+                beta=float(gold["meta.scale_factor"]), kw=kw)
+
+
+def test_ved_fixture_inventory():
+    assert len(VED_CASES) >= 5
+
+
+@pytest.mark.parametrize("name", VED_CASES)
+def test_ved_oracle_steps_match_reference(name):
+    """The product's VED constructor (conv nets mirror) reproduces the reference's initial weights under the same
+    state_dict keys, and the oracle's conv restatement (oracle.ved_elbo) reproduces the reference's VED.model/guide
+    through SVItrainer.svi.step(x, y): loss, gradients, parameters after Adam per step, then encode / decode."""
+    gold = load_golden(name)
+    c = ved_case(gold)
+    model = pv.models.VED(c["input_dim"], c["output_dim"], latent_dim=c["latent_dim"], seed=1, device="cpu", **c["kw"])
+    keys = sorted(k[len("init."):-len(".sum")] for k in gold if k.startswith("init.") and k.endswith(".sum"))
+    assert keys == sorted(n for n, _ in model.named_parameters())
+    for n, p in model.named_parameters():
+        check_digest(p, gold, "init." + n, rtol=0, atol=0, what=name)
+    cfg = orc.VedConfig(input_dim=c["input_dim"], output_dim=c["output_dim"], latent_dim=c["latent_dim"],
+                        hidden_dim_e=c["kw"].get("hidden_dim_e"), hidden_dim_d=c["kw"].get("hidden_dim_d"),
+                        activation=c["kw"].get("activation", "lrelu"))
+    o = orc.VedOracle(model.state_dict(), cfg)
+    x, y = torch.from_numpy(gold["x"]), torch.from_numpy(gold["y"])
+    for k in range(c["steps"]):
+        pre = "s%d" % k
+        loss = o.step(x, y, torch.from_numpy(gold[pre + ".eps"]), c["beta"])
+        np.testing.assert_allclose(loss, float(gold[pre + ".loss"]), rtol=3e-6)
+        np.testing.assert_allclose(o.last["ll"].item(), float(gold[pre + ".term.model.obs"]), rtol=3e-6)
+        np.testing.assert_allclose(o.last["z"].detach().numpy(), gold[pre + ".z"], rtol=1e-5, atol=1e-6)
+        for n in o.p:
+            check_digest(o.last_grads[n], gold, pre + ".grad." + n, rtol=2e-4, atol=1e-6, what=name)
+            check_digest(o.p[n], gold, pre + ".param." + n, rtol=1e-5, atol=1e-6, what=name)
+    z_loc, z_scale = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o.decode(z_loc).numpy(), gold["dec.loc"], rtol=1e-5, atol=1e-6)
