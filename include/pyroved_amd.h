@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 2
+#define PV_ABI_VERSION 3
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -56,6 +56,26 @@ typedef struct pv_layer {
   int64_t w_off;
   int64_t b_off;
 } pv_layer;
+
+/* ---- convolutional op sequences (nets/conv.py FeatureExtractor / Upsampler), used by pv_ved_plan and by
+ * pv_ivae_plan's optional convolutional encoder ---- */
+#define PV_MAX_OPS 32
+
+enum pv_op_kind {
+  PV_OP_CONV = 1,        /* nn.ConvNd(cin, cout, ksize, 1, ksize/2) + activation `act` (weights in the torch
+                            layout (cout, cin, *kernel) at w_off, bias at b_off)                        */
+  PV_OP_MAXPOOL2 = 2,    /* nn.MaxPoolNd(2, 2)                                                          */
+  PV_OP_UPSAMPLE2 = 3    /* F.interpolate(scale_factor=2, mode="nearest")                               */
+};
+
+typedef struct pv_op {
+  int32_t kind;          /* enum pv_op_kind */
+  int32_t cin, cout;     /* CONV only       */
+  int32_t ksize;         /* CONV: 1 or 3    */
+  int32_t act;           /* CONV: enum pv_act applied to the output */
+  int32_t _pad;
+  int64_t w_off, b_off;  /* CONV: offsets in floats into the flat parameter buffer */
+} pv_op;
 
 /* Everything one SVI step of models.iVAE needs (models/ivae.py:122-221,
  * models/base.py:47-119, trainers/svi.py:64-115).  Plain data: filled by the
@@ -95,6 +115,14 @@ typedef struct pv_ivae_plan {
   pv_layer fc_coord, fc_latent;    /* coord_latent (fc.py:216-217); unused if coord_dim=0 */
   pv_layer dec[PV_MAX_LAYERS];
   pv_layer out;                    /* decoder.out (fc.py:186 / fc.py:140)                 */
+  /* ---- optional convolutional encoder: iVAE.set_encoder(convEncoderNet(data_dim, latent_dim=z_dim))
+   * (models/base.py:173-177, nets/conv.py:24-64).  n_enc_ops > 0: `enc` / n_enc are ignored, the encoder is this
+   * op sequence over x viewed as (B, 1, *enc_in_dim), and `head` is features2latent.fc_latent (in_dim = C *
+   * prod(spatial) in torch's flatten order, out_dim = 2*z_dim = [mu | softplus input]).  c_dim must be 0. ---- */
+  int32_t  n_enc_ops;
+  int32_t  enc_ndim;               /* 1 or 2                                              */
+  int32_t  enc_in_dim[2];
+  pv_op    enc_ops[PV_MAX_OPS];
   /* ---- caller-owned device buffers ---- */
   float*       params;    /* flat parameters, n_params floats                             */
   float*       grads;     /* flat gradients (written, not accumulated)                    */
@@ -195,24 +223,6 @@ int pv_transform_coordinates(const float* grid, int64_t n_pix, int coord_dim, co
  * activations are channels-last.  Scope: 1-D / 2-D data, kernel 3 (padding 1) and kernel 1 convolutions,
  * stride 1, 2x max-pooling, 2x nearest-neighbour upsampling, no batch normalisation.
  * =================================================================================================== */
-#define PV_MAX_OPS 32
-
-enum pv_op_kind {
-  PV_OP_CONV = 1,        /* nn.ConvNd(cin, cout, ksize, 1, ksize/2) + activation `act` (weights in the torch
-                            layout (cout, cin, *kernel) at w_off, bias at b_off)                        */
-  PV_OP_MAXPOOL2 = 2,    /* nn.MaxPoolNd(2, 2)                                                          */
-  PV_OP_UPSAMPLE2 = 3    /* F.interpolate(scale_factor=2, mode="nearest")                               */
-};
-
-typedef struct pv_op {
-  int32_t kind;          /* enum pv_op_kind */
-  int32_t cin, cout;     /* CONV only       */
-  int32_t ksize;         /* CONV: 1 or 3    */
-  int32_t act;           /* CONV: enum pv_act applied to the output */
-  int32_t _pad;
-  int64_t w_off, b_off;  /* CONV: offsets in floats into the flat parameter buffer */
-} pv_op;
-
 typedef struct pv_ved_plan {
   int32_t batch;
   int32_t ndim_in, ndim_out;       /* 1 or 2                                                            */

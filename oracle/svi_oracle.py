@@ -62,6 +62,8 @@ class Config:
     invariances: Optional[Sequence[str]] = None
     c_dim: int = 0
     discrete_dim: int = 0          # > 0: jiVAE (models/jivae.py), K classes enumerated in the ELBO
+    conv_encoder: Optional[Sequence[Sequence[int]]] = None   # iVAE.set_encoder(convEncoderNet(data_dim, z_dim, hidden_dim=...)): conv filters per block
+    conv_activation: str = "lrelu"
     n_hidden_e: int = 2            # number of hidden Linear layers in encoder_z.fc_layers
     n_hidden_d: int = 2
     activation: str = "tanh"
@@ -252,7 +254,7 @@ def elbo(p: Params, cfg: Config, x, eps, beta=1.0, y=None, grid=None):
     z = mu + sigma*eps (Normal.rsample), summed — not averaged — over the batch.
     """
     b = x.shape[0]
-    z_loc, z_scale = encoder_forward(p, cfg, x, y)
+    z_loc, z_scale = _encode_any(p, cfg, x, y)
     z = z_loc + z_scale * eps
     logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)                      # guide site "latent"
     logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)   # model site "latent"
@@ -421,6 +423,16 @@ class VedOracle:
             return conv_decoder_forward(self.p, self.cfg, z.to(self.dtype))
 
 
+def _encode_any(p: Params, cfg: Config, x, y=None):
+    """encoder_z(x): fcEncoderNet, or the convEncoderNet a user installed with set_encoder (models/base.py:173-177),
+    which sees x as (B, 1, *data_dim)."""
+    if cfg.conv_encoder is not None:
+        vc = VedConfig(input_dim=cfg.data_dim, output_dim=cfg.data_dim, latent_dim=cfg.z_dim,
+                       hidden_dim_e=cfg.conv_encoder, activation=cfg.conv_activation)
+        return conv_encoder_forward(p, vc, x.reshape(x.shape[0], 1, *cfg.data_dim))
+    return encoder_forward(p, cfg, x, y)
+
+
 def param_order(p: Params, cfg: Config) -> List[str]:
     """state_dict order == construction order."""
     return list(p.keys())
@@ -492,7 +504,7 @@ class SVIOracle:
         with torch.no_grad():
             if self.cfg.discrete_dim > 0:
                 return jencoder_forward(self.p, self.cfg, x.to(self.dtype))      # (mu, sigma, alpha)
-            return encoder_forward(self.p, self.cfg, x.to(self.dtype), y)
+            return _encode_any(self.p, self.cfg, x.to(self.dtype), y)
 
     def decode(self, z, y=None, angle=0.0, shift=0.0, scale=1.0):
         cfg = self.cfg

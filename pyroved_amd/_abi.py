@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 2
+PV_ABI_VERSION = 3
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -29,6 +29,15 @@ class pv_layer(C.Structure):
                 ("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 
+PV_MAX_OPS = 32
+OP = {"conv": 1, "maxpool2": 2, "upsample2": 3}
+
+
+class pv_op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
+                ("act", C.c_int32), ("_pad", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
 class pv_ivae_plan(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("n_pix", C.c_int32), ("coord_dim", C.c_int32), ("z_dim", C.c_int32),
@@ -41,6 +50,8 @@ class pv_ivae_plan(C.Structure):
         ("enc", pv_layer * PV_MAX_LAYERS), ("head", pv_layer),
         ("fc_coord", pv_layer), ("fc_latent", pv_layer),
         ("dec", pv_layer * PV_MAX_LAYERS), ("out", pv_layer),
+        ("n_enc_ops", C.c_int32), ("enc_ndim", C.c_int32), ("enc_in_dim", C.c_int32 * 2),
+        ("enc_ops", pv_op * PV_MAX_OPS),
         ("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
         ("n_params", C.c_int64),
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p), ("grid", C.c_void_p),
@@ -51,15 +62,6 @@ class pv_ivae_plan(C.Structure):
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
     ]
-
-
-PV_MAX_OPS = 32
-OP = {"conv": 1, "maxpool2": 2, "upsample2": 3}
-
-
-class pv_op(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
-                ("act", C.c_int32), ("_pad", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 
 class pv_ved_plan(C.Structure):

@@ -1,0 +1,114 @@
+// pv_convstack.h — a convolutional op sequence (pv_op[]: conv k3/k1 + activation, 2x max-pool, 2x nearest upsample) over
+// channels-last activations: shapes, workspace needs, forward and backward.  Shared by the VED step (pv_ved.hip) and
+// the iVAE step with a convolutional encoder (pv_plan.hip).  Every convolution is a GEMM (im2col for kernel 3, the
+// activation itself for kernel 1) on pv_gemm.hip's f32-input MFMA kernel with bias + activation fused; backward
+// re-creates each im2col instead of keeping it.
+#pragma once
+#include "pv_common.h"
+#include "pv_linear.h"
+#include "pv_conv.h"
+
+namespace pvcs {
+
+struct Shape { int H, W, C; int64_t elems(int64_t B) const { return B * H * W * C; } };
+
+inline bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
+  out = in;
+  if (o.kind == PV_OP_CONV) {
+    if (o.cin != in.C || o.cout < 1 || (o.ksize != 1 && o.ksize != 3)) return false;
+    out.C = o.cout;
+  } else if (o.kind == PV_OP_MAXPOOL2) {
+    out.H = in.H / 2; out.W = nd == 2 ? in.W / 2 : 1;
+    if (out.H < 1 || out.W < 1) return false;
+  } else if (o.kind == PV_OP_UPSAMPLE2) {
+    out.H = in.H * 2; out.W = nd == 2 ? in.W * 2 : 1;
+  } else {
+    return false;
+  }
+  return true;
+}
+
+inline int kk_of(const pv_op& o, int nd) { return o.ksize == 3 ? (nd == 2 ? 9 : 3) : 1; }
+
+// scratch the stack's GEMMs and im2col need for B samples: running maxima
+struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0; };
+inline void upd(int64_t& m, int64_t v) { if (v > m) m = v; }
+
+// shapes s[0..n] from s[0]; accumulates workspace needs; false on an inconsistent sequence
+inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, Needs& nd_) {
+  upd(nd_.maxact, s[0].elems(B));
+  for (int i = 0; i < n; ++i) {
+    if (!op_shape(ops[i], nd, s[i], s[i + 1])) return false;
+    upd(nd_.maxact, s[i + 1].elems(B));
+    if (ops[i].kind == PV_OP_CONV) {
+      const int64_t rows = B * s[i].H * s[i].W, K = (int64_t)ops[i].cin * kk_of(ops[i], nd), N = ops[i].cout;
+      if (ops[i].ksize == 3) upd(nd_.maxcol, rows * K);
+      upd(nd_.scratch, gemm_ws_need(rows, N, K));
+      upd(nd_.scratch, gemm_ws_need(N, K, rows));
+      upd(nd_.scratch, gemm_ws_need(rows, K, N));
+    }
+  }
+  return true;
+}
+
+struct Scratch { float* col; void* ws; int64_t ws_bytes; };
+
+// one op forward: in (shape si) -> out
+inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const float* in, const Shape& si, float* out,
+                  const Scratch& sc, hipStream_t s) {
+  if (o.kind == PV_OP_CONV) {
+    const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
+    const float* a = in;
+    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, sc.col, B, si.H, si.W, si.C, nd, s)); a = sc.col; }
+    return linear_fwd(a, K, params + o.w_off, o.b_off >= 0 ? params + o.b_off : nullptr, out, nullptr, o.cout, rows, K,
+                      o.cout, o.act, sc.ws, sc.ws_bytes, s);
+  }
+  if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
+  return pv_upsample2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
+}
+
+// one op backward: g = dL/d(out) (post-activation for CONV; modified in place), writes parameter gradients and, when
+// gin != null, dL/d(in)
+inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int B, const float* in, const Shape& si,
+                  const float* out, float* g, float* gin, const Scratch& sc, hipStream_t s) {
+  if (o.kind == PV_OP_CONV) {
+    const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
+    PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));                       // g = dL/d(pre-activation)
+    const float* a = in;
+    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, sc.col, B, si.H, si.W, si.C, nd, s)); a = sc.col; }
+    PV_TRY(linear_wgrad(g, o.cout, a, K, grads + o.w_off, o.b_off >= 0 ? grads + o.b_off : nullptr, rows, K, o.cout,
+                        sc.ws, sc.ws_bytes, s));
+    if (!gin) return 0;
+    float* dcol = o.ksize == 3 ? sc.col : gin;
+    PV_TRY(linear_dgrad(g, o.cout, params + o.w_off, dcol, K, nullptr, nullptr, 0, PV_ACT_NONE, rows, K, o.cout, sc.ws,
+                        sc.ws_bytes, s));
+    if (o.ksize == 3) PV_TRY(pv_col2im3(dcol, gin, B, si.H, si.W, si.C, nd, s));
+    return 0;
+  }
+  if (!gin) return 0;
+  if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s);
+  return pv_upsample2_bwd(g, gin, B, si.H, si.W, si.C, nd, s);
+}
+
+// whole stack forward: a[0] given, a[1..n] written
+inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B, float* const* a, const Shape* sh,
+                     const Scratch& sc, hipStream_t s) {
+  for (int i = 0; i < n; ++i) PV_TRY(op_fwd(params, ops[i], nd, B, a[i], sh[i], a[i + 1], sc, s));
+  return 0;
+}
+
+// whole stack backward: g = dL/d(a[n]) (clobbered); gbuf[2] ping-pong buffers; returns in *gout the buffer holding
+// dL/d(a[0]) (null when need_input_grad is false: the first op then skips its dgrad)
+inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n, int nd, int B, float* const* a,
+                     const Shape* sh, float* g, float* const* gbuf, int& pp, bool need_input_grad, float** gout,
+                     const Scratch& sc, hipStream_t s) {
+  for (int i = n - 1; i >= 0; --i) {
+    float* gin = (i > 0 || need_input_grad) ? gbuf[pp] : nullptr;
+    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, sc, s));
+    g = gin; pp ^= 1;
+  }
+  if (gout) *gout = g;
+  return 0;
+}
+
+}  // namespace pvcs

@@ -8,6 +8,7 @@
 #include "pv_kernels.h"
 #include "pv_sdec_fused.h"
 #include "pv_linear.h"
+#include "pv_convstack.h"
 
 namespace {
 
@@ -42,6 +43,9 @@ struct Layout {
   float* part_dwo; float* part_dbo; float* part_hz; float* part_wc; float* part_tp;
   float* dhz; float* dtp; float* dzc;
   float* alpha; float* sw;                 // jiVAE: class probabilities (B, K), decoder row weights (K*B)
+  // convolutional encoder (plan->n_enc_ops > 0): activation shapes / buffers, flattened features, gradient ping-pong
+  bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
+  float* ccol; int64_t cF;
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
@@ -62,7 +66,10 @@ static inline int64_t plan_lat_in(const pv_ivae_plan* p) {
 bool valid_plan(const pv_ivae_plan* p) {
   if (!p || p->batch <= 0 || p->n_pix <= 0 || p->z_dim <= 0) return false;
   if (p->coord_dim < 0 || p->coord_dim > 2) return false;
-  if (p->n_enc < 1 || p->n_enc > PV_MAX_LAYERS || p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
+  if (p->n_enc_ops < 0 || p->n_enc_ops > PV_MAX_OPS) return false;
+  if (p->n_enc_ops > 0 && (p->c_dim != 0 || p->discrete_dim != 0 || (p->enc_ndim != 1 && p->enc_ndim != 2))) return false;
+  if (p->n_enc_ops == 0 && (p->n_enc < 1 || p->n_enc > PV_MAX_LAYERS)) return false;
+  if (p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
   if (p->discrete_dim < 0 || p->head.out_dim != plan_head_w(p)) return false;
   if (p->discrete_dim > 0 && (p->coord_dim == 0 || p->c_dim != 0)) return false;   // jiVAE: spatial decoder, no y
   if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN) return false;
@@ -81,7 +88,25 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   const int64_t R = L.rows;
   L.xin = p->c_dim > 0 ? c.take(B * (N + p->c_dim)) : nullptr;
   int64_t maxe = 0;
-  for (int i = 0; i < p->n_enc; ++i) {
+  L.enc_conv = p->n_enc_ops > 0;
+  const int n_enc = L.enc_conv ? 0 : p->n_enc;
+  pvcs::Needs cnd;
+  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = nullptr; L.cF = 0;
+  if (L.enc_conv) {
+    L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
+    if ((int64_t)L.ces[0].H * L.ces[0].W == N && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
+      L.cea[0] = nullptr;
+      for (int i = 0; i < p->n_enc_ops; ++i) L.cea[i + 1] = c.take(L.ces[i + 1].elems(B));
+      const pvcs::Shape& fe = L.ces[p->n_enc_ops];
+      L.cF = (int64_t)fe.H * fe.W * fe.C;
+      L.cfeat = c.take(B * L.cF);
+      L.cg[0] = c.take(cnd.maxact); L.cg[1] = c.take(cnd.maxact);
+      L.ccol = c.take(cnd.maxcol);
+    } else {
+      L.cF = -1;                                   // inconsistent op sequence: rejected by the entry points
+    }
+  }
+  for (int i = 0; i < n_enc; ++i) {
     L.eact[i] = c.take(B * p->enc[i].out_dim);
     L.epre[i] = p->enc[i].act == PV_ACT_GELU ? c.take(B * p->enc[i].out_dim) : nullptr;
     if (p->enc[i].out_dim > maxe) maxe = p->enc[i].out_dim;
@@ -94,8 +119,8 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.zy = (p->c_dim > 0 || K > 0) ? c.take(S * lat_in) : nullptr;
   L.alpha = K > 0 ? c.take(B * K) : nullptr;
   L.sw = K > 0 ? c.take(S) : nullptr;
-  for (int i = 0; i < p->n_enc; ++i) L.edp[i] = c.take(B * p->enc[i].out_dim);
-  L.enc_compact = pv_enc_compact_supported(p);
+  for (int i = 0; i < n_enc; ++i) L.edp[i] = c.take(B * p->enc[i].out_dim);
+  L.enc_compact = !L.enc_conv && pv_enc_compact_supported(p);
   L.kl_blocks = (int)((B + 15) / 16);
   L.kl_part = c.take(2 * L.kl_blocks);
   int64_t maxd = 0;
@@ -161,7 +186,8 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.dbuf[0] = L.fused ? nullptr : c.take(R * maxd);
   L.dbuf[1] = L.fused ? nullptr : c.take(R * maxd);
   // scratch: the largest split-K / colsum requirement of any single call
-  for (int i = 0; i < p->n_enc; ++i) {
+  upd(cnd.scratch);
+  for (int i = 0; i < n_enc; ++i) {
     upd(gemm_ws_need(B, p->enc[i].out_dim, p->enc[i].in_dim));
     upd(gemm_ws_need(p->enc[i].out_dim, p->enc[i].in_dim, B));
     upd(gemm_ws_need(B, p->enc[i].in_dim, p->enc[i].out_dim));
@@ -229,7 +255,23 @@ int linear_wgrad(const float* dpre, int64_t lddp, const float* x, int64_t ldx, f
 
 namespace {
 
+// convolutional encoder: x viewed as (B, 1, *enc_in_dim) -> op sequence -> flatten (C, spatial) -> L.head
+int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+  const int64_t B = p->batch;
+  if (L.cF < 0 || p->head.in_dim != L.cF) return PV_EINVAL;
+  float* a[PV_MAX_OPS + 1];
+  a[0] = const_cast<float*>(p->x);                  // one input channel: (B, 1, H, W) is already channels-last
+  for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
+  const pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes};
+  PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
+  const pvcs::Shape& fe = L.ces[p->n_enc_ops];
+  PV_TRY(pv_nsc_to_ncs(L.cea[p->n_enc_ops], L.cfeat, B, fe.C, (int64_t)fe.H * fe.W, s));
+  return linear_fwd(L.cfeat, L.cF, p->params + p->head.w_off, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr,
+                    L.head, nullptr, p->head.out_dim, B, L.cF, p->head.out_dim, PV_ACT_NONE, L.scratch, L.scratch_bytes, s);
+}
+
 int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+  if (L.enc_conv) return conv_encoder_fwd(p, L, s);
   const int64_t B = p->batch;
   const float* in = p->x;
   int64_t ldin = p->n_pix;
@@ -317,6 +359,25 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
   const int64_t wsb = L.scratch_bytes;
   const int ne = p->n_enc;
   const pv_layer& hd = p->head;
+  if (L.enc_conv) {
+    // head (features2latent.fc_latent) backward, then the op sequence in reverse; the other small wgrads ride along
+    PV_TRY(linear_wgrad(L.dhead, hd.out_dim, L.cfeat, L.cF, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B, L.cF,
+                        hd.out_dim, ws, wsb, s));
+    PV_TRY(linear_dgrad(L.dhead, hd.out_dim, p->params + hd.w_off, L.cg[0], L.cF, nullptr, nullptr, 0, PV_ACT_NONE, B,
+                        L.cF, hd.out_dim, ws, wsb, s));
+    const pvcs::Shape& fe = L.ces[p->n_enc_ops];
+    PV_TRY(pv_ncs_to_nsc(L.cg[0], L.cg[1], B, fe.C, (int64_t)fe.H * fe.W, s));
+    float* a[PV_MAX_OPS + 1];
+    a[0] = const_cast<float*>(p->x);
+    for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
+    const pvcs::Scratch sc{L.ccol, ws, wsb};
+    int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
+    PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
+                           nullptr, sc, s));
+    if (fin) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
+    for (int i = 0; i < n_extra; i += 4) PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s));
+    return 0;
+  }
   const float* elast = L.eact[ne - 1];
   if (L.enc_compact) {
     PvEncDgrad d{};

@@ -7,12 +7,11 @@
 // No allocation, no synchronisation, no retained state: buffers are carved from the caller's workspace.
 #include "pv_common.h"
 #include "pv_kernels.h"
-#include "pv_linear.h"
-#include "pv_conv.h"
+#include "pv_convstack.h"
 
 namespace {
 
-struct Shape { int H, W, C; int64_t elems(int64_t B) const { return B * H * W * C; } };
+using pvcs::Shape;
 
 struct VCarver {
   char* base; int64_t off;
@@ -31,27 +30,10 @@ struct VLayout {
   float* f0; float* df0;
   float* llrow; float* dlda; float* llb;
   float* g[2];                                         // gradient ping-pong (largest activation)
-  float* col;                                          // im2col / dcol scratch
-  void* scratch; int64_t scratch_bytes;
+  pvcs::Scratch sc;                                    // im2col / dcol scratch + GEMM split-K scratch
   int64_t F;                                           // flattened feature size C*S of the encoder output
   int64_t total;
 };
-
-bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
-  out = in;
-  if (o.kind == PV_OP_CONV) {
-    if (o.cin != in.C || o.cout < 1 || (o.ksize != 1 && o.ksize != 3)) return false;
-    out.C = o.cout;
-  } else if (o.kind == PV_OP_MAXPOOL2) {
-    out.H = in.H / 2; out.W = nd == 2 ? in.W / 2 : 1;
-    if (out.H < 1 || out.W < 1) return false;
-  } else if (o.kind == PV_OP_UPSAMPLE2) {
-    out.H = in.H * 2; out.W = nd == 2 ? in.W * 2 : 1;
-  } else {
-    return false;
-  }
-  return true;
-}
 
 bool valid_ved(const pv_ved_plan* p) {
   if (!p || p->batch <= 0 || p->z_dim <= 0 || p->z_dim > 256) return false;
@@ -69,104 +51,44 @@ bool valid_ved(const pv_ved_plan* p) {
 bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   VCarver c{base, 0};
   const int64_t B = p->batch, z = p->z_dim;
-  int64_t maxact = 0, maxcol = 0, scratch = 0;
-  auto upd = [](int64_t& m, int64_t v) { if (v > m) m = v; };
+  pvcs::Needs nd;
   // ---- encoder ----
   L.es[0] = Shape{p->in_dim[0], p->ndim_in == 2 ? p->in_dim[1] : 1, p->in_ch};
+  if (!pvcs::stack_shapes(p->enc, p->n_enc_ops, p->ndim_in, B, L.es, nd)) return false;
   L.x_nsc = p->in_ch > 1 ? c.take(L.es[0].elems(B)) : nullptr;
   L.ea[0] = nullptr;                                   // = x (or x_nsc), set by the caller
-  upd(maxact, L.es[0].elems(B));
-  for (int i = 0; i < p->n_enc_ops; ++i) {
-    if (!op_shape(p->enc[i], p->ndim_in, L.es[i], L.es[i + 1])) return false;
-    L.ea[i + 1] = c.take(L.es[i + 1].elems(B));
-    upd(maxact, L.es[i + 1].elems(B));
-    if (p->enc[i].kind == PV_OP_CONV) {
-      const int64_t rows = B * L.es[i].H * L.es[i].W, kk = p->enc[i].ksize == 3 ? (p->ndim_in == 2 ? 9 : 3) : 1;
-      const int64_t K = (int64_t)p->enc[i].cin * kk, N = p->enc[i].cout;
-      if (p->enc[i].ksize == 3) upd(maxcol, rows * K);
-      upd(scratch, gemm_ws_need(rows, N, K)); upd(scratch, gemm_ws_need(N, K, rows)); upd(scratch, gemm_ws_need(rows, K, N));
-    }
-  }
+  for (int i = 0; i < p->n_enc_ops; ++i) L.ea[i + 1] = c.take(L.es[i + 1].elems(B));
   const Shape& fe = L.es[p->n_enc_ops];
   L.F = (int64_t)fe.H * fe.W * fe.C;
   if (p->head.in_dim != L.F) return false;
   L.feat = c.take(B * L.F);
   L.head = c.take(B * 2 * z); L.dhead = c.take(B * 2 * z);
   L.z = c.take(B * z); L.z_scale = c.take(B * z); L.dzc = c.take(B * z);
-  upd(scratch, gemm_ws_need(B, 2 * z, L.F)); upd(scratch, gemm_ws_need(2 * z, L.F, B)); upd(scratch, gemm_ws_need(B, L.F, 2 * z));
+  pvcs::upd(nd.scratch, gemm_ws_need(B, 2 * z, L.F)); pvcs::upd(nd.scratch, gemm_ws_need(2 * z, L.F, B));
+  pvcs::upd(nd.scratch, gemm_ws_need(B, L.F, 2 * z));
   // ---- decoder ----
   L.ds[0] = Shape{p->dec_dim0[0], p->ndim_out == 2 ? p->dec_dim0[1] : 1, p->dec_c0};
   const int64_t F0 = (int64_t)L.ds[0].H * L.ds[0].W * L.ds[0].C;
   if (p->l2f.out_dim != F0) return false;
+  if (!pvcs::stack_shapes(p->dec, p->n_dec_ops, p->ndim_out, B, L.ds, nd)) return false;
   L.f0 = c.take(B * F0); L.df0 = c.take(B * F0);
   L.da[0] = c.take(B * F0);
-  upd(maxact, B * F0);
-  upd(scratch, gemm_ws_need(B, F0, z)); upd(scratch, gemm_ws_need(F0, z, B)); upd(scratch, gemm_ws_need(B, z, F0));
-  for (int i = 0; i < p->n_dec_ops; ++i) {
-    if (!op_shape(p->dec[i], p->ndim_out, L.ds[i], L.ds[i + 1])) return false;
-    L.da[i + 1] = c.take(L.ds[i + 1].elems(B));
-    upd(maxact, L.ds[i + 1].elems(B));
-    if (p->dec[i].kind == PV_OP_CONV) {
-      const int64_t rows = B * L.ds[i].H * L.ds[i].W, kk = p->dec[i].ksize == 3 ? (p->ndim_out == 2 ? 9 : 3) : 1;
-      const int64_t K = (int64_t)p->dec[i].cin * kk, N = p->dec[i].cout;
-      if (p->dec[i].ksize == 3) upd(maxcol, rows * K);
-      upd(scratch, gemm_ws_need(rows, N, K)); upd(scratch, gemm_ws_need(N, K, rows)); upd(scratch, gemm_ws_need(rows, K, N));
-    }
-  }
+  pvcs::upd(nd.scratch, gemm_ws_need(B, F0, z)); pvcs::upd(nd.scratch, gemm_ws_need(F0, z, B));
+  pvcs::upd(nd.scratch, gemm_ws_need(B, z, F0));
+  for (int i = 0; i < p->n_dec_ops; ++i) L.da[i + 1] = c.take(L.ds[i + 1].elems(B));
   const Shape& od = L.ds[p->n_dec_ops];
   if (od.H != p->out_dim[0] || od.W != (p->ndim_out == 2 ? p->out_dim[1] : 1) || od.C != p->out_ch) return false;
   const int64_t OUT = od.elems(B);
   L.y_nsc = p->out_ch > 1 ? c.take(OUT) : nullptr;
   L.loc_nsc = p->out_ch > 1 ? c.take(OUT) : nullptr;
   L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B);
-  L.g[0] = c.take(maxact); L.g[1] = c.take(maxact);
-  L.col = c.take(maxcol);
-  L.scratch_bytes = pv_align_up(scratch, 256);
-  L.scratch = base ? (void*)(base + c.off) : nullptr;
-  c.off += L.scratch_bytes;
+  L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
+  L.sc.col = c.take(nd.maxcol);
+  L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
+  L.sc.ws = base ? (void*)(base + c.off) : nullptr;
+  c.off += L.sc.ws_bytes;
   L.total = c.off;
   return true;
-}
-
-int kk_of(const pv_op& o, int nd) { return o.ksize == 3 ? (nd == 2 ? 9 : 3) : 1; }
-
-// one op forward: in (shape si) -> out (shape so)
-int op_fwd(const pv_ved_plan* p, const pv_op& o, int nd, const float* in, const Shape& si, float* out, const VLayout& L,
-           hipStream_t s) {
-  const int B = p->batch;
-  if (o.kind == PV_OP_CONV) {
-    const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
-    const float* a = in;
-    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, L.col, B, si.H, si.W, si.C, nd, s)); a = L.col; }
-    return linear_fwd(a, K, p->params + o.w_off, o.b_off >= 0 ? p->params + o.b_off : nullptr, out, nullptr, o.cout,
-                      rows, K, o.cout, o.act, L.scratch, L.scratch_bytes, s);
-  }
-  if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
-  return pv_upsample2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
-}
-
-// one op backward: g = dL/d(out) (post-activation for CONV; modified in place), writes parameter gradients and, when
-// gin != null, dL/d(in)
-int op_bwd(const pv_ved_plan* p, const pv_op& o, int nd, const float* in, const Shape& si, const float* out,
-           const Shape& so, float* g, float* gin, const VLayout& L, hipStream_t s) {
-  const int B = p->batch;
-  if (o.kind == PV_OP_CONV) {
-    const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
-    PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));                       // g = dL/d(pre-activation)
-    const float* a = in;
-    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, L.col, B, si.H, si.W, si.C, nd, s)); a = L.col; }
-    PV_TRY(linear_wgrad(g, o.cout, a, K, p->grads + o.w_off, o.b_off >= 0 ? p->grads + o.b_off : nullptr, rows, K,
-                        o.cout, L.scratch, L.scratch_bytes, s));
-    if (!gin) return 0;
-    float* dcol = o.ksize == 3 ? L.col : gin;
-    PV_TRY(linear_dgrad(g, o.cout, p->params + o.w_off, dcol, K, nullptr, nullptr, 0, PV_ACT_NONE, rows, K, o.cout,
-                        L.scratch, L.scratch_bytes, s));
-    if (o.ksize == 3) PV_TRY(pv_col2im3(dcol, gin, B, si.H, si.W, si.C, nd, s));
-    return 0;
-  }
-  if (!gin) return 0;
-  if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s);
-  return pv_upsample2_bwd(g, gin, B, si.H, si.W, si.C, nd, s);
 }
 
 // encoder forward up to (head, z, z_scale[, KL scalars]); eps == null: inference (z = unused)
@@ -176,13 +98,12 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
   const float* x = p->x;
   if (p->in_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->x, L.x_nsc, B, p->in_ch, (int64_t)s0.H * s0.W, s)); x = L.x_nsc; }
   L.ea[0] = const_cast<float*>(x);
-  for (int i = 0; i < p->n_enc_ops; ++i)
-    PV_TRY(op_fwd(p, p->enc[i], p->ndim_in, L.ea[i], L.es[i], L.ea[i + 1], L, s));
+  PV_TRY(pvcs::stack_fwd(p->params, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, L.sc, s));
   const Shape& fe = L.es[p->n_enc_ops];
   // torch flattens (C, spatial): features2latent sees channels-first order
   PV_TRY(pv_nsc_to_ncs(L.ea[p->n_enc_ops], L.feat, B, fe.C, (int64_t)fe.H * fe.W, s));
   PV_TRY(linear_fwd(L.feat, L.F, p->params + p->head.w_off, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr,
-                    L.head, nullptr, 2 * p->z_dim, B, L.F, 2 * p->z_dim, PV_ACT_NONE, L.scratch, L.scratch_bytes, s));
+                    L.head, nullptr, 2 * p->z_dim, B, L.F, 2 * p->z_dim, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
   PvHead h{};
   h.head = L.head; h.eps = with_kl ? p->eps : L.z_scale; h.z = L.z; h.z_scale = L.z_scale;
   h.z_loc_out = z_loc_out; h.z_scale_out = z_scale_out;
@@ -197,11 +118,9 @@ int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
   PV_TRY(linear_fwd(z, p->z_dim, p->params + p->l2f.w_off, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr,
-                    L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.scratch, L.scratch_bytes, s));
+                    L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
   PV_TRY(pv_ncs_to_nsc(L.f0, L.da[0], B, d0.C, (int64_t)d0.H * d0.W, s));       // view(-1, C0, *dims) -> channels-last
-  for (int i = 0; i < p->n_dec_ops; ++i)
-    PV_TRY(op_fwd(p, p->dec[i], p->ndim_out, L.da[i], L.ds[i], L.da[i + 1], L, s));
-  return 0;
+  return pvcs::stack_fwd(p->params, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.sc, s);
 }
 
 }  // namespace
@@ -237,42 +156,35 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (!want_grads) return 0;
 
   // ---- backward: decoder ops in reverse ----
-  float* g = L.dlda;                                   // dL/d(output of the last op), loss = -ELBO folded in by lik_elem
+  float* g = nullptr;                                  // (dlda = dL/d(output of the last op), loss = -ELBO)
   int pp = 0;
-  for (int i = p->n_dec_ops - 1; i >= 0; --i) {
-    float* gin = L.g[pp];
-    PV_TRY(op_bwd(p, p->dec[i], p->ndim_out, L.da[i], L.ds[i], L.da[i + 1], L.ds[i + 1], g, gin, L, s));
-    g = gin; pp ^= 1;
-  }
+  PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.g, pp, true,
+                         &g, L.sc, s));
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
   PV_TRY(pv_nsc_to_ncs(g, L.df0, B, d0.C, (int64_t)d0.H * d0.W, s));
   PV_TRY(linear_wgrad(L.df0, F0, L.z, z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, B,
-                      z, F0, L.scratch, L.scratch_bytes, s));
+                      z, F0, L.sc.ws, L.sc.ws_bytes, s));
   PV_TRY(linear_dgrad(L.df0, F0, p->params + p->l2f.w_off, L.dzc, z, nullptr, nullptr, 0, PV_ACT_NONE, B, z, F0,
-                      L.scratch, L.scratch_bytes, s));
+                      L.sc.ws, L.sc.ws_bytes, s));
   // ---- reparameterised sample + sampled KL -> head ----
   PvHeadBwd hb{};
   hb.dzc = L.dzc; hb.ldzc = z; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps; hb.head = L.head; hb.dhead = L.dhead;
   hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = 0; hb.beta = p->beta;
   PV_TRY(pv_head_bwd(hb, s));
   PV_TRY(linear_wgrad(L.dhead, 2 * z, L.feat, L.F, p->grads + p->head.w_off,
-                      p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, B, L.F, 2 * z, L.scratch, L.scratch_bytes, s));
+                      p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, B, L.F, 2 * z, L.sc.ws, L.sc.ws_bytes, s));
   float* dfeat = L.g[pp];
   PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + p->head.w_off, dfeat, L.F, nullptr, nullptr, 0, PV_ACT_NONE, B, L.F,
-                      2 * z, L.scratch, L.scratch_bytes, s));
+                      2 * z, L.sc.ws, L.sc.ws_bytes, s));
   pp ^= 1;
   const Shape& fe = L.es[p->n_enc_ops];
   g = L.g[pp];
   PV_TRY(pv_ncs_to_nsc(dfeat, g, B, fe.C, (int64_t)fe.H * fe.W, s));
   pp ^= 1;
   // ---- encoder ops in reverse (no input gradient for the first one) ----
-  for (int i = p->n_enc_ops - 1; i >= 0; --i) {
-    float* gin = i > 0 ? L.g[pp] : nullptr;
-    PV_TRY(op_bwd(p, p->enc[i], p->ndim_in, L.ea[i], L.es[i], L.ea[i + 1], L.es[i + 1], g, gin, L, s));
-    g = gin; pp ^= 1;
-  }
-  return 0;
+  return pvcs::stack_bwd(p->params, p->grads, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, g, L.g, pp, false,
+                         nullptr, L.sc, s);
 }
 
 extern "C" int pv_ved_encode(const pv_ved_plan* p, float* z_loc, float* z_scale, void* stream) {

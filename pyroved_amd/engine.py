@@ -22,13 +22,11 @@ import torch.nn as nn
 
 from . import _abi
 from .nets.fc import fcEncoderNet, jfcEncoderNet, fcDecoderNet, sDecoderNet
+from .nets.conv import convEncoderNet
+from ._convplan import UnsupportedModel, conv_ops, fill_ops
 
 ALIGN = 64      # floats: every tensor starts on a 256-byte boundary of the flat buffer
 N_SCALARS = 4   # loss, ll, beta*log p(z), beta*log q(z|x)
-
-
-class UnsupportedModel(NotImplementedError):
-    pass
 
 
 def _linears(seq: nn.Sequential) -> List[nn.Linear]:
@@ -60,9 +58,16 @@ class IVAEEngine:
     def _check_model(self):
         m = self.model
         enc, dec = m.encoder_z, m.decoder
-        if not isinstance(enc, (fcEncoderNet, jfcEncoderNet)):
+        self.conv_enc = isinstance(enc, convEncoderNet)          # iVAE.set_encoder(convEncoderNet(...))
+        if self.conv_enc:
+            if tuple(enc.input_dim) != tuple(int(d) for d in m.data_dim) or enc.input_channels != 1:
+                raise UnsupportedModel("conv encoder: input_dim must equal the model's data_dim, one input channel")
+            if enc.latent_dim != m.z_dim or getattr(m, "c_dim", 0) != 0:
+                raise UnsupportedModel("conv encoder: latent_dim must equal the model's z_dim (latent + coord); no c_dim")
+            conv_ops(enc.feature_extractor.layers, enc.feature_extractor.activation)      # validates
+        elif not isinstance(enc, (fcEncoderNet, jfcEncoderNet)):
             raise UnsupportedModel("the HIP SVI path needs encoder_z to be pyroved_amd.nets.fcEncoderNet / "
-                                   "jfcEncoderNet (got %s)" % type(enc).__name__)
+                                   "jfcEncoderNet / convEncoderNet (got %s)" % type(enc).__name__)
         self.K = int(getattr(m, "discrete_dim", 0)) if isinstance(enc, jfcEncoderNet) else 0
         if self.K > 0 and m.coord == 0:
             raise UnsupportedModel("jiVAE without invariances (fcDecoderNet) is not implemented in the HIP path yet")
@@ -80,13 +85,16 @@ class IVAEEngine:
             raise UnsupportedModel("decoder sampler %r is not implemented in the HIP path yet" % name)
         if name == "bernoulli" and not dec.sigmoid_out:
             raise UnsupportedModel("bernoulli likelihood needs sigmoid_d=True")
-        if len(_linears(enc.fc_layers)) > _abi.PV_MAX_LAYERS or len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
+        if (not self.conv_enc and len(_linears(enc.fc_layers)) > _abi.PV_MAX_LAYERS) or \
+                len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
             raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
 
     def _param_order(self):
         """(key, tensor) in flat-buffer order: state_dict order, except that the heads are merged:
         fc11.weight, fc12.weight[, fc13.weight], then fc11.bias, fc12.bias[, fc13.bias]."""
         named = dict(self.model.named_parameters())
+        if self.conv_enc:
+            return list(named.items())           # features2latent.fc_latent already is the merged [mu | sigma] head
         heads = ["fc11", "fc12"] + (["fc13"] if self.K > 0 else [])
         merged = ["encoder_z.%s.weight" % h for h in heads] + ["encoder_z.%s.bias" % h for h in heads]
         order = []
@@ -163,6 +171,22 @@ class IVAEEngine:
         l.b_off = self._layout[prefix + ".bias"] if lin.bias is not None else -1
         return l
 
+    def _fc_encoder_plan(self, p, enc, m):
+        idx = [i for i, mod in enumerate(enc.fc_layers) if isinstance(mod, nn.Linear)]
+        p.n_enc = len(idx)
+        for j, i in enumerate(idx):
+            p.enc[j] = self._layer("encoder_z.fc_layers.%d" % i, enc.fc_layers[i], enc.activation)
+        h = _abi.pv_layer()
+        h.in_dim, h.out_dim, h.act = enc.fc11.in_features, 2 * m.z_dim + self.K, 0
+        h.w_off, h.b_off = self._layout["encoder_z.fc11.weight"], self._layout["encoder_z.fc11.bias"]
+        assert self._layout["encoder_z.fc12.weight"] == h.w_off + enc.fc11.weight.numel()
+        assert self._layout["encoder_z.fc12.bias"] == h.b_off + enc.fc11.bias.numel()
+        p.discrete_dim = self.K
+        if self.K > 0:
+            assert self._layout["encoder_z.fc13.weight"] == h.w_off + 2 * enc.fc11.weight.numel()
+            assert self._layout["encoder_z.fc13.bias"] == h.b_off + 2 * enc.fc11.bias.numel()
+        p.head = h
+
     def _static_plan(self) -> _abi.pv_ivae_plan:
         m = self.model
         enc, dec = m.encoder_z, m.decoder
@@ -186,20 +210,17 @@ class IVAEEngine:
         p.sigmoid_out = int(dec.sigmoid_out)
         p.decoder_sig = m.sampler_d.decoder_sig
         p.fused = int(self.fused)
-        idx = [i for i, mod in enumerate(enc.fc_layers) if isinstance(mod, nn.Linear)]
-        p.n_enc = len(idx)
-        for j, i in enumerate(idx):
-            p.enc[j] = self._layer("encoder_z.fc_layers.%d" % i, enc.fc_layers[i], enc.activation)
-        h = _abi.pv_layer()
-        h.in_dim, h.out_dim, h.act = enc.fc11.in_features, 2 * m.z_dim + self.K, 0
-        h.w_off, h.b_off = self._layout["encoder_z.fc11.weight"], self._layout["encoder_z.fc11.bias"]
-        assert self._layout["encoder_z.fc12.weight"] == h.w_off + enc.fc11.weight.numel()
-        assert self._layout["encoder_z.fc12.bias"] == h.b_off + enc.fc11.bias.numel()
-        p.discrete_dim = self.K
-        if self.K > 0:
-            assert self._layout["encoder_z.fc13.weight"] == h.w_off + 2 * enc.fc11.weight.numel()
-            assert self._layout["encoder_z.fc13.bias"] == h.b_off + 2 * enc.fc11.bias.numel()
-        p.head = h
+        if self.conv_enc:
+            p.n_enc = 0
+            p.enc_ndim = len(enc.input_dim)
+            for i, d in enumerate(enc.input_dim):
+                p.enc_in_dim[i] = d
+            p.n_enc_ops = fill_ops(p.enc_ops, conv_ops(enc.feature_extractor.layers, enc.feature_extractor.activation,
+                                                       "encoder_z.feature_extractor.layers"), self._layout)
+            p.head = self._layer("encoder_z.features2latent.fc_latent", enc.features2latent.fc_latent, None)
+            p.discrete_dim = 0
+        else:
+            self._fc_encoder_plan(p, enc, m)
         if p.coord_dim > 0:
             p.fc_coord = self._layer("decoder.coord_latent.fc_coord", dec.coord_latent.fc_coord, "tanh")
             p.fc_latent = self._layer("decoder.coord_latent.fc_latent", dec.coord_latent.fc_latent, None)

@@ -16,11 +16,8 @@ import torch.nn as nn
 
 from . import _abi
 from .engine import IVAEEngine, UnsupportedModel
-from .nets.conv import convEncoderNet, convDecoderNet, UpsampleBlock
-
-
-def _conv_types():
-    return (nn.Conv1d, nn.Conv2d)
+from ._convplan import conv_ops, fill_ops
+from .nets.conv import convEncoderNet, convDecoderNet
 
 
 class VEDEngine(IVAEEngine):
@@ -49,51 +46,11 @@ class VEDEngine(IVAEEngine):
     def _param_order(self):
         return list(self.model.named_parameters())          # state_dict order, nothing merged
 
-    def _ops(self, layers: nn.Sequential, activation, prefix: Optional[str] = None):
-        """nn.Sequential of nets/conv.py -> list of (kind, conv module | None, act, key prefix)."""
-        mods = list(layers)
-        ops, i = [], 0
-        while i < len(mods):
-            mod, pos = mods[i], i
-            if isinstance(mod, _conv_types()):
-                k = mod.kernel_size[0]
-                if (any(v != k for v in mod.kernel_size) or k not in (1, 3) or any(v != 1 for v in mod.stride)
-                        or any(v != k // 2 for v in mod.padding) or any(v != 1 for v in mod.dilation) or mod.groups != 1):
-                    raise UnsupportedModel("conv layers must be kernel 3 / padding 1 or kernel 1, stride 1")
-                act = None
-                if i + 1 < len(mods) and not isinstance(mods[i + 1], _conv_types() + (UpsampleBlock, nn.MaxPool1d,
-                                                                                       nn.MaxPool2d)):
-                    if isinstance(mods[i + 1], (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
-                        raise UnsupportedModel("batch normalisation is not implemented in the HIP conv path")
-                    act = activation
-                    i += 1
-                    if i + 1 < len(mods) and isinstance(mods[i + 1], (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
-                        raise UnsupportedModel("batch normalisation is not implemented in the HIP conv path")
-                ops.append(("conv", mod, act, None if prefix is None else "%s.%d" % (prefix, pos)))
-            elif isinstance(mod, (nn.MaxPool1d, nn.MaxPool2d)):
-                ops.append(("maxpool2", None, None, None))
-            elif isinstance(mod, UpsampleBlock):
-                if mod.mode != "nearest" or mod.scale_factor != 2:
-                    raise UnsupportedModel("2-D decoders (bilinear upsampling) are not implemented in the HIP path yet")
-                ops.append(("upsample2", None, None, None))
-                ops.append(("conv", mod.conv, None, None if prefix is None else "%s.%d.conv" % (prefix, i)))
-            else:
-                raise UnsupportedModel("unsupported layer %s in a conv stack" % type(mod).__name__)
-            i += 1
-        if len(ops) > _abi.PV_MAX_OPS:
-            raise UnsupportedModel("more than %d ops in a conv stack" % _abi.PV_MAX_OPS)
-        return ops
+    def _ops(self, layers, activation, prefix=None):
+        return conv_ops(layers, activation, prefix)
 
     def _fill_ops(self, arr, ops):
-        for j, (kind, mod, act, key) in enumerate(ops):
-            o = arr[j]
-            o.kind = _abi.OP[kind]
-            if kind == "conv":
-                o.cin, o.cout, o.ksize = mod.in_channels, mod.out_channels, mod.kernel_size[0]
-                o.act = _abi.ACT[act]
-                o.w_off = self._layout[key + ".weight"]
-                o.b_off = self._layout[key + ".bias"] if mod.bias is not None else -1
-        return len(ops)
+        return fill_ops(arr, ops, self._layout)
 
     def _static_plan(self):
         m = self.model

@@ -37,3 +37,21 @@ for name, make, B, dd, K in CASES:
         name, dt * 1e3, B / dt, fl / dt / 1e12, hist[warm, 0].item() / B, hist[-1, 0].item() / B), flush=True)
     del eng, model
     torch.cuda.empty_cache()
+
+# ---- C5: VED im2spec 64x64 -> 128, batch 256 per GPU
+import warnings; warnings.filterwarnings("ignore")
+model = pv.models.VED((64, 64), (128,), seed=1, device="cuda")
+eng = model.engine()
+B = 256
+g = torch.Generator().manual_seed(0)
+x = torch.rand(2, B, 1, 64, 64, generator=g).cuda(); y = torch.rand(2, B, 1, 128, generator=g).cuda()
+eps = torch.randn(steps + warm, B, 2, generator=g).cuda()
+hist = torch.zeros(steps + warm, 4, device="cuda")
+def vstep(i):
+    eng.loss_and_grads(x[i % 2], eps[i], 1.0, y[i % 2], scalars_out=hist[i]); eng.adam_step()
+for i in range(warm): vstep(i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(steps): vstep(warm + i)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+print("%-52s %8.3f ms/step  %9.0f images/s  %6.1f TF algorithmic (0.709 GFLOP/img)  loss/img %.3f -> %.3f" % (
+    "C5  VED 64x64 -> 128 B=256/GPU", dt * 1e3, B / dt, 0.709e9 * B / dt / 1e12, hist[warm, 0].item() / B, hist[-1, 0].item() / B))

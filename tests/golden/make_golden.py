@@ -77,6 +77,7 @@ def make_x(kind, n, data_dim, seed=0):
 def run_steps(name, data_dim, invariances, batch, steps=3, latent_dim=2, xkind="rand",
               full=False, model_kw=None, step_kw=None, c_dim=0):
     model_kw = dict(model_kw or {})
+    conv_enc = model_kw.pop("conv_encoder", None)
     step_kw = dict(step_kw or {})
     out = {}
     out["meta.data_dim"] = np.array(data_dim)
@@ -90,12 +91,20 @@ def run_steps(name, data_dim, invariances, batch, steps=3, latent_dim=2, xkind="
     for k, v in model_kw.items():
         out["meta.model_kw." + k] = np.array(v)
     model = models.iVAE(data_dim, latent_dim, invariances, c_dim=c_dim, seed=1, device="cpu", **model_kw)
+    if conv_enc is not None:
+        # a convolutional encoder installed the way the reference documents it (models/base.py:173-177); the
+        # module is built right after the model, on the same RNG stream
+        from pyroved.nets import convEncoderNet
+        model.set_encoder(convEncoderNet(data_dim, latent_dim=model.z_dim, hidden_dim=conv_enc))
+        out["meta.conv_encoder"] = np.array(str(conv_enc))
     names = {id(p): n for n, p in model.named_parameters()}
     for n, p in model.named_parameters():
         put(out, "init." + n, digest(p))
         if full:
             out["full.init." + n] = p.detach().numpy().copy()
     x = make_x(xkind, batch, data_dim)
+    if conv_enc is not None:
+        x = x.unsqueeze(1)                 # conv encoders take (B, C, H, W)
     y = None
     if c_dim:
         y = utils.to_onehot(torch.arange(batch) % c_dim, c_dim)
@@ -342,6 +351,7 @@ def run_epochs(name, data_dim, invariances, n, batch, epochs=2, with_test=True, 
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:] or None          # e.g. `make_golden.py jivae`: only (re)generate that family
+    _run_steps_real = run_steps
     if only is not None:
         run_steps = run_step0_loc = lambda *a, **k: None      # noqa: E731
     # tiny cases, every invariance set of the reference's own trainer tests
@@ -372,6 +382,12 @@ if __name__ == "__main__":
         run_jsteps("jivae_8x8_rt_k3_b4_sf", (8, 8), ["r", "t"], 3, batch=4, scale_factor=[2.0, 3.0])
         run_jsteps("jivae_1d16_t_k2_b5", (16,), ["t"], 2, batch=5)
         run_jsteps("jivae_28x28_r_k10_b16", (28, 28), ["r"], 10, batch=16, steps=2)
+    # iVAE with a convolutional encoder (BASELINE config 4 family)
+    if only is None or "convenc" in only:
+        _rs = globals()["_run_steps_real"]
+        _rs("ivaeconv_8x8_rts_b5", (8, 8), ["r", "t", "s"], batch=5, model_kw={"conv_encoder": [(4,), (8, 8)]})
+        _rs("ivaeconv_16x16_rt_b4", (16, 16), ["r", "t"], batch=4, model_kw={"conv_encoder": [(4,), (8, 8), (16, 16)]})
+        _rs("ivaeconv_1d16_t_b5", (16,), ["t"], batch=5, model_kw={"conv_encoder": [(4,), (8, 8)]})
     # VED: conv encoder / conv decoder (BASELINE config 5 family: 2-D image -> 1-D spectrum)
     if only is None or "ved" in only:
         small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])

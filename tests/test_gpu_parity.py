@@ -419,6 +419,45 @@ def test_ved_trainer_epochs_vs_oracle(gpu_device):
     np.testing.assert_allclose(losses["gpu"], losses["cpu"], rtol=1e-4)
 
 
+CONVENC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ivaeconv_*.npz")))
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("name", CONVENC_CASES)
+def test_convenc_steps_vs_golden_and_oracle(gpu_device, name, fused):
+    """iVAE with set_encoder(convEncoderNet) (BASELINE config 4 family): conv encoder ops + the spatial decoder
+    kernels, vs the reference's recorded steps and the oracle."""
+    from test_oracle_golden import convenc_model
+    gold = load_golden(name)
+    meta, model, cfg = convenc_model(gold, "cuda")
+    eng = model.engine(fused=fused)
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"])
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=RTOL_ELBO, err_msg="loss")
+        o.step(x, eps, meta["beta"])
+        for key in o.p:
+            if key == "decoder.out.bias":
+                # one scalar = the sum of B*N signed terms (p - x): |terms| sum to ~B*N/4 and cancel; fp32 summation
+                # is good to ~1e-6 of that (see test_jivae_steps_vs_golden_and_oracle)
+                bound = 1e-6 * meta["batch"] * int(np.prod(meta["data_dim"]))
+                assert (eng.grad_of(key).cpu() - o.last_grads[key]).abs().max().item() < bound
+                continue
+            err = rel_l2(eng.grad_of(key), o.last_grads[key])
+            assert err < RTOL_GRAD, "step %d grad %s: rel l2 error %.3e vs oracle" % (k, key, err)
+            check_digest(eng.grad_of(key), gold, pre + ".grad." + key, rtol=5e-4, atol=1e-6, what=name)
+        eng.adam_step()
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+    z_loc, z_scale = model.encode(x.unsqueeze(1))
+    zlo, zso = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), zlo.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z_scale.numpy(), zso.numpy(), rtol=1e-4, atol=5e-6)
+
+
 @pytest.mark.parametrize("name", EPOCH_CASES)
 def test_trainer_epochs_vs_golden(gpu_device, name):
     """The product's SVItrainer driven exactly like the reference's (same DataLoader, same seeds):

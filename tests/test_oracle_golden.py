@@ -247,3 +247,38 @@ def test_ved_oracle_steps_match_reference(name):
     z_loc, z_scale = o.encode(x)
     np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(o.decode(z_loc).numpy(), gold["dec.loc"], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- iVAE with a convolutional encoder (set_encoder)
+CONVENC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ivaeconv_*.npz")))
+
+
+def convenc_model(gold, device):
+    """iVAE + set_encoder(convEncoderNet(data_dim, latent_dim=z_dim, hidden_dim=...)) built like the fixture's model."""
+    import ast
+    meta = meta_of(gold)
+    hid = ast.literal_eval(str(gold["meta.conv_encoder"]))
+    model = pv.models.iVAE(meta["data_dim"], meta["latent_dim"], meta["invariances"], seed=1, device=device)
+    model.set_encoder(pv.nets.convEncoderNet(meta["data_dim"], latent_dim=model.z_dim, hidden_dim=hid))
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     conv_encoder=hid)
+    return meta, model, cfg
+
+
+@pytest.mark.parametrize("name", CONVENC_CASES)
+def test_convenc_oracle_steps_match_reference(name):
+    gold = load_golden(name)
+    meta, model, cfg = convenc_model(gold, "cpu")
+    for n, p in model.named_parameters():
+        check_digest(p, gold, "init." + n, rtol=0, atol=0, what=name)
+    o = orc.SVIOracle(model.state_dict(), cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        loss = o.step(x, torch.from_numpy(gold[pre + ".eps"]), meta["beta"])
+        np.testing.assert_allclose(loss, float(gold[pre + ".loss"]), rtol=3e-6)
+        for n in o.p:
+            check_digest(o.last_grads[n], gold, pre + ".grad." + n, rtol=2e-4, atol=1e-6, what=name)
+            check_digest(o.p[n], gold, pre + ".param." + n, rtol=1e-5, atol=1e-6, what=name)
+    z_loc, z_scale = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-5, atol=1e-6)
