@@ -55,3 +55,21 @@ for i in range(steps): vstep(warm + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 print("%-52s %8.3f ms/step  %9.0f images/s  %6.1f TF algorithmic (0.709 GFLOP/img)  loss/img %.3f -> %.3f" % (
     "C5  VED 64x64 -> 128 B=256/GPU", dt * 1e3, B / dt, 0.709e9 * B / dt / 1e12, hist[warm, 0].item() / B, hist[-1, 0].item() / B))
+
+# ---- C4: iVAE 64x64 ['r','t','s'] with the convolutional encoder, batch 128 per GPU
+model = pv.models.iVAE((64, 64), 2, ["r", "t", "s"], seed=1, device="cuda")
+model.set_encoder(pv.nets.convEncoderNet((64, 64), latent_dim=model.z_dim))
+eng = model.engine(fused=2)
+B = 128
+x = torch.rand(2, B, 64, 64, generator=g).cuda()
+eps = torch.randn(steps + warm, B, model.z_dim, generator=g).cuda()
+hist = torch.zeros(steps + warm, 4, device="cuda")
+def cstep(i):
+    eng.loss_and_grads(x[i % 2], eps[i], 1.0, scalars_out=hist[i]); eng.adam_step()
+for i in range(warm): cstep(i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(steps): cstep(warm + i)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+print("%-52s %8.3f ms/step  %9.0f images/s  (1.50 GFLOP/img -> %.1f TF algorithmic)  loss/img %.3f -> %.3f" % (
+    "C4  iVAE 64x64 ['r','t','s'] conv encoder B=128/GPU", dt * 1e3, B / dt, 1.50e9 * B / dt / 1e12,
+    hist[warm, 0].item() / B, hist[-1, 0].item() / B))
