@@ -73,6 +73,12 @@ struct PvGemm {
   float* pre;                           // optional pre-activation store (ldc stride)
   const float* aux; const float* auxpre; int64_t ldaux; int act_aux;   // C *= act'(aux)
   float* rowsumA;                       // optional: rowsumA[m] = sum_k A(m,k)  (bias gradient of a wgrad GEMM)
+  // implicit im2col operands (convolutions, kernel 3 / padding 1 / stride 1 over channels-last [B][H][W][C]): the
+  // operand is never materialised; element (row = (b, y, x), j = ci*KK + tap) is gathered from the activation.
+  //   conv_a: A(m, k) = im2col(A)[row = m][j = k]          (forward / dgrad: rows are the GEMM's M)
+  //   conv_b: B(k, n) = im2col(B)[row = k][j = n]          (wgrad: rows are the GEMM's K)
+  int conv_a, conv_b;
+  int cH, cW, cC, cnd;                  // activation geometry (cnd = 1: W = 1, 3 taps; cnd = 2: 9 taps)
 };
 // Runs C = epilogue(A*B).  splits > 1 => partial sums through ws (needs splits*M*N floats).
 int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t s);

@@ -3,8 +3,6 @@
 #pragma once
 #include "pv_common.h"
 
-int pv_im2col3(const float* in, float* col, int B, int H, int W, int C, int nd, hipStream_t s);
-int pv_col2im3(const float* dcol, float* din, int B, int H, int W, int C, int nd, hipStream_t s);
 int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s);
 int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s);
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s);
@@ -12,3 +10,4 @@ int pv_upsample2_bwd(const float* dout, float* din, int B, int H, int W, int C, 
 int pv_ncs_to_nsc(const float* in, float* out, int64_t B, int C, int64_t S, hipStream_t s);
 int pv_nsc_to_ncs(const float* in, float* out, int64_t B, int C, int64_t S, hipStream_t s);
 int pv_act_bwd(float* dy, const float* y, int64_t n, int act, hipStream_t s);
+int pv_conv_wflip(const float* w, float* wt, int Cout, int Cin, int KK, hipStream_t s);

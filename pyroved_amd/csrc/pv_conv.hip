@@ -1,9 +1,8 @@
 // pv_conv.hip — the data-movement kernels around the convolutional nets of models.VED (nets/conv.py): everything a
-// conv / pool / upsample stack needs besides its GEMMs.  Activations are channels-last, [B][spatial...][C], so a
-// convolution is  Y[B*S, Cout] = act(col[B*S, Cin*k^d] W^T + b)  with the torch weight (Cout, Cin, *kernel) used as
-// it lies in memory: the column index of `col` is ci*k^d + tap, taps in the kernel's own (ky, kx) order.
-// All of these are HBM-bound gathers / scatters written as gathers (one thread per OUTPUT element, no atomics):
-//   im2col / col2im      (kernel 3, stride 1, padding 1; 1-D and 2-D)
+// conv / pool / upsample stack needs besides its GEMMs (the convolutions themselves gather their patches inside
+// pv_gemm.hip's tile loads).  Activations are channels-last, [B][spatial...][C].
+// All of these are HBM-bound gathers (one thread per OUTPUT element, no atomics):
+//   conv_wflip           (the flipped / channel-swapped weight of a convolution's dgrad)
 //   maxpool2 fwd / bwd   (2x, stride 2; ties resolved as torch: first maximum in window scan order)
 //   upsample2 fwd / bwd  (nearest)
 //   ncs <-> nsc          ((B, C, S) <-> (B, S, C) transposes at the torch-layout boundaries)
@@ -16,44 +15,6 @@
 static inline int conv_blocks(int64_t n) {
   int64_t b = (n + CONV_THREADS - 1) / CONV_THREADS;
   return (int)(b > 65535 * 16 ? 65535 * 16 : (b < 1 ? 1 : b));
-}
-
-// col[(b, y, x)][ci*KK + t] = in[b][y + dy(t)][x + dx(t)][ci]   (zero outside); W = 1, KK = 3 for 1-D
-__global__ void pv_im2col3_kernel(const float* __restrict__ in, float* __restrict__ col, int B, int H, int W, int C,
-                                  int nd) {
-  const int KK = nd == 2 ? 9 : 3;
-  const int64_t total = (int64_t)B * H * W * C * KK;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int t = (int)(e % KK);
-    const int ci = (int)((e / KK) % C);
-    const int64_t row = e / ((int64_t)KK * C);
-    const int x = (int)(row % W), y = (int)((row / W) % H);
-    const int64_t b = row / ((int64_t)W * H);
-    // 2-D: t = ky*3 + kx over (H, W); 1-D: the single spatial axis is H (W == 1), t = k
-    const int yy = y + (nd == 2 ? t / 3 : t) - 1, xx = nd == 2 ? x + t % 3 - 1 : x;
-    float v = 0.0f;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((b * H + yy) * W + xx) * C + ci];
-    col[e] = v;
-  }
-}
-
-// din[b][y][x][ci] = sum_t dcol[(b, y - dy(t), x - dx(t))][ci*KK + t]
-__global__ void pv_col2im3_kernel(const float* __restrict__ dcol, float* __restrict__ din, int B, int H, int W, int C,
-                                  int nd) {
-  const int KK = nd == 2 ? 9 : 3;
-  const int64_t total = (int64_t)B * H * W * C;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(e % C);
-    const int64_t pix = e / C;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H);
-    const int64_t b = pix / ((int64_t)W * H);
-    float v = 0.0f;
-    for (int t = 0; t < KK; ++t) {
-      const int yy = y - ((nd == 2 ? t / 3 : t) - 1), xx = nd == 2 ? x - (t % 3 - 1) : x;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v += dcol[(((b * H + yy) * W + xx) * C + ci) * KK + t];
-    }
-    din[e] = v;
-  }
 }
 
 // out[b][y][x][c] = max over the 2x2 (2-D) / 2 (1-D) window of in
@@ -158,6 +119,16 @@ __global__ void pv_act_bwd_kernel(float* __restrict__ dy, const float* __restric
     dy[e] *= pv_act_grad(y[e], 0.0f, act);
 }
 
+// dgrad of a kernel-3 convolution = the same convolution of dY with the taps flipped and the channel roles swapped:
+//   wt[ci][co*KK + t] = w[co][ci*KK + (KK-1-t)]
+__global__ void pv_conv_wflip_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int KK) {
+  const int total = Cout * Cin * KK;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int t = e % KK, co = (e / KK) % Cout, ci = e / (KK * Cout);
+    wt[e] = w[((int64_t)co * Cin + ci) * KK + (KK - 1 - t)];
+  }
+}
+
 #define CONV_LAUNCH(kernel, n, ...)                                                                   \
   do {                                                                                                \
     if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(conv_blocks(n)), dim3(CONV_THREADS), 0, s, __VA_ARGS__); \
@@ -165,12 +136,6 @@ __global__ void pv_act_bwd_kernel(float* __restrict__ dy, const float* __restric
     return 0;                                                                                         \
   } while (0)
 
-int pv_im2col3(const float* in, float* col, int B, int H, int W, int C, int nd, hipStream_t s) {
-  CONV_LAUNCH(pv_im2col3_kernel, (int64_t)B * H * W * C * (nd == 2 ? 9 : 3), in, col, B, H, W, C, nd);
-}
-int pv_col2im3(const float* dcol, float* din, int B, int H, int W, int C, int nd, hipStream_t s) {
-  CONV_LAUNCH(pv_col2im3_kernel, (int64_t)B * H * W * C, dcol, din, B, H, W, C, nd);
-}
 int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s) {
   CONV_LAUNCH(pv_maxpool2_fwd_kernel, (int64_t)B * (H / 2) * (nd == 2 ? W / 2 : 1) * C, in, out, B, H, W, C, nd);
 }
@@ -193,4 +158,7 @@ int pv_act_bwd(float* dy, const float* y, int64_t n, int act, hipStream_t s) {
   if (act == PV_ACT_NONE) return 0;
   if (act == PV_ACT_GELU) return PV_EINVAL;           // needs the pre-activation; not kept on this path
   CONV_LAUNCH(pv_act_bwd_kernel, n, dy, y, n, act);
+}
+int pv_conv_wflip(const float* w, float* wt, int Cout, int Cin, int KK, hipStream_t s) {
+  CONV_LAUNCH(pv_conv_wflip_kernel, (int64_t)Cout * Cin * KK, w, wt, Cout, Cin, KK);
 }

@@ -42,26 +42,27 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
     upd(nd_.maxact, s[i + 1].elems(B));
     if (ops[i].kind == PV_OP_CONV) {
       const int64_t rows = B * s[i].H * s[i].W, K = (int64_t)ops[i].cin * kk_of(ops[i], nd), N = ops[i].cout;
-      if (ops[i].ksize == 3) upd(nd_.maxcol, rows * K);
-      upd(nd_.scratch, gemm_ws_need(rows, N, K));
-      upd(nd_.scratch, gemm_ws_need(N, K, rows));
-      upd(nd_.scratch, gemm_ws_need(rows, K, N));
+      if (ops[i].ksize == 3) upd(nd_.maxcol, N * K);                 // flipped weights of the dgrad-as-convolution
+      upd(nd_.scratch, gemm_ws_need(rows, N, K));                    // forward
+      upd(nd_.scratch, gemm_ws_need(N, K, rows));                    // wgrad
+      upd(nd_.scratch, gemm_ws_need(rows, K, N));                    // dgrad, kernel 1
+      upd(nd_.scratch, gemm_ws_need(rows, ops[i].cin, N * kk_of(ops[i], nd)));   // dgrad, kernel 3
     }
   }
   return true;
 }
 
-struct Scratch { float* col; void* ws; int64_t ws_bytes; };
+struct Scratch { float* col /* flipped-weight scratch (maxcol floats) */; void* ws; int64_t ws_bytes; };
 
 // one op forward: in (shape si) -> out
 inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const float* in, const Shape& si, float* out,
                   const Scratch& sc, hipStream_t s) {
   if (o.kind == PV_OP_CONV) {
     const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
-    const float* a = in;
-    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, sc.col, B, si.H, si.W, si.C, nd, s)); a = sc.col; }
-    return linear_fwd(a, K, params + o.w_off, o.b_off >= 0 ? params + o.b_off : nullptr, out, nullptr, o.cout, rows, K,
-                      o.cout, o.act, sc.ws, sc.ws_bytes, s);
+    const float* bias = o.b_off >= 0 ? params + o.b_off : nullptr;
+    if (o.ksize == 3)
+      return conv3_fwd(in, B, si.H, si.W, si.C, nd, params + o.w_off, bias, out, o.cout, o.act, sc.ws, sc.ws_bytes, s);
+    return linear_fwd(in, K, params + o.w_off, bias, out, nullptr, o.cout, rows, K, o.cout, o.act, sc.ws, sc.ws_bytes, s);
   }
   if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
   return pv_upsample2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
@@ -74,16 +75,18 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
   if (o.kind == PV_OP_CONV) {
     const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
     PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));                       // g = dL/d(pre-activation)
-    const float* a = in;
-    if (o.ksize == 3) { PV_TRY(pv_im2col3(in, sc.col, B, si.H, si.W, si.C, nd, s)); a = sc.col; }
-    PV_TRY(linear_wgrad(g, o.cout, a, K, grads + o.w_off, o.b_off >= 0 ? grads + o.b_off : nullptr, rows, K, o.cout,
-                        sc.ws, sc.ws_bytes, s));
+    float* db = o.b_off >= 0 ? grads + o.b_off : nullptr;
+    if (o.ksize == 3) {
+      PV_TRY(conv3_wgrad(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
+      if (!gin) return 0;
+      // dX = conv3(dpre; taps flipped, channel roles swapped) — same spatial size, C = cout -> cin
+      PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
+      return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);
+    }
+    PV_TRY(linear_wgrad(g, o.cout, in, K, grads + o.w_off, db, rows, K, o.cout, sc.ws, sc.ws_bytes, s));
     if (!gin) return 0;
-    float* dcol = o.ksize == 3 ? sc.col : gin;
-    PV_TRY(linear_dgrad(g, o.cout, params + o.w_off, dcol, K, nullptr, nullptr, 0, PV_ACT_NONE, rows, K, o.cout, sc.ws,
-                        sc.ws_bytes, s));
-    if (o.ksize == 3) PV_TRY(pv_col2im3(dcol, gin, B, si.H, si.W, si.C, nd, s));
-    return 0;
+    return linear_dgrad(g, o.cout, params + o.w_off, gin, K, nullptr, nullptr, 0, PV_ACT_NONE, rows, K, o.cout, sc.ws,
+                        sc.ws_bytes, s);
   }
   if (!gin) return 0;
   if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s);

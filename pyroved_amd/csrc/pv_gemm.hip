@@ -18,6 +18,37 @@
 #define GK 16      // k per stage
 #define GLD 66     // LDS row stride (floats)
 
+// implicit im2col: element (row = (b, y, x), j = ci*KK + tap) of the never-materialised patch matrix
+struct ConvGeom { int H, W, C, nd; };
+__device__ __forceinline__ float g_im2col(const float* __restrict__ in, const ConvGeom& cg, int64_t row, int j) {
+  const int KK = cg.nd == 2 ? 9 : 3;
+  const int ci = j / KK, t = j - ci * KK;
+  const int x = (int)(row % cg.W);
+  const int64_t ry = row / cg.W;
+  const int y = (int)(ry % cg.H);
+  const int64_t b = ry / cg.H;
+  const int yy = y + (cg.nd == 2 ? t / 3 : t) - 1, xx = cg.nd == 2 ? x + t % 3 - 1 : x;
+  if (yy < 0 || yy >= cg.H || xx < 0 || xx >= cg.W) return 0.0f;
+  return in[((b * cg.H + yy) * cg.W + xx) * cg.C + ci];
+}
+
+// conv-mode tile loads: same (x, k) thread mapping as g_load; `rows_on_x`: the patch-matrix row is the tile's x index
+template <bool KCONTIG>
+__device__ __forceinline__ void g_load_conv(const float* __restrict__ P, const ConvGeom& cg, bool rows_on_x, int x0,
+                                            int xlim, int k0, int klim, int t, float (&r)[4]) {
+  if (KCONTIG) {
+    const int x = x0 + (t >> 2), k = k0 + (t & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      r[i] = (x < xlim && k + i < klim) ? (rows_on_x ? g_im2col(P, cg, x, k + i) : g_im2col(P, cg, k + i, x)) : 0.0f;
+  } else {
+    const int k = k0 + (t >> 4), x = x0 + (t & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      r[i] = (k < klim && x + i < xlim) ? (rows_on_x ? g_im2col(P, cg, x + i, k) : g_im2col(P, cg, k, x + i)) : 0.0f;
+  }
+}
+
 template <bool KCONTIG>   // true: the k index is the contiguous one in global memory
 __device__ __forceinline__ void g_load(const float* __restrict__ P, int64_t rs, int64_t cs, int x0, int xlim,
                                        int k0, int klim, bool vec, int t, float (&r)[4]) {
@@ -66,7 +97,7 @@ struct GemmK {
   int a_vec, b_vec;
 };
 
-template <bool AK, bool BK>
+template <bool AK, bool BK, bool CA = false, bool CB = false>   // CA / CB: implicit im2col A / B operand
 __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], float (*Bs)[GLD], int bx, int by, int bz) {
   const PvGemm& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -82,18 +113,21 @@ __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], floa
   float rs = 0.0f;
 
   float ra[4], rb[4];
-  if (kbeg < kend) {
-    g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, kbeg, kend, p.a_vec, t, ra);
-    g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, kbeg, kend, p.b_vec, t, rb);
-  }
+  const ConvGeom cg{g.cH, g.cW, g.cC, g.cnd};
+  auto load_a = [&](int k0) {
+    if (CA) g_load_conv<AK>(g.A, cg, true, m0, g.M, k0, kend, t, ra);              // A(m, k): row = m, j = k
+    else g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, k0, kend, p.a_vec, t, ra);
+  };
+  auto load_b = [&](int k0) {
+    if (CB) g_load_conv<BK>(g.B, cg, false, n0, g.N, k0, kend, t, rb);             // B(k, n): row = k, j = n
+    else g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, k0, kend, p.b_vec, t, rb);
+  };
+  if (kbeg < kend) { load_a(kbeg); load_b(kbeg); }
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
     g_store_lds<AK>(As, t, ra);
     g_store_lds<BK>(Bs, t, rb);
     __syncthreads();
-    if (k0 + GK < kend) {
-      g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, k0 + GK, kend, p.a_vec, t, ra);
-      g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, k0 + GK, kend, p.b_vec, t, rb);
-    }
+    if (k0 + GK < kend) { load_a(k0 + GK); load_b(k0 + GK); }
     if (do_rs) {
 #pragma unroll
       for (int k = 0; k < GK; ++k) rs += As[k][t];
@@ -137,11 +171,11 @@ __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], floa
   }
 }
 
-template <bool AK, bool BK>
+template <bool AK, bool BK, bool CA = false, bool CB = false>
 __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
   __shared__ float As[GK][GLD];
   __shared__ float Bs[GK][GLD];
-  gemm_tile<AK, BK>(p, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_tile<AK, BK, CA, CB>(p, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // several independent small GEMMs of the same operand-layout class in ONE launch (no split-K): the
@@ -226,9 +260,16 @@ int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t
   auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   p.a_vec = al(g.A) && (ak ? (g.a_rs % 4 == 0) : (g.a_rs == 1 && g.a_cs % 4 == 0));
   p.b_vec = al(g.B) && (bk ? (g.b_cs % 4 == 0) : (g.b_cs == 1 && g.b_rs % 4 == 0));
+  if (g.conv_a && g.K > g.cC * 9) return PV_EINVAL;
   dim3 grid((g.M + GT - 1) / GT, (g.N + GT - 1) / GT, splits);
   if (grid.y > 65535) return PV_EINVAL;
-  if (ak && bk) hipLaunchKernelGGL((pv_gemm_kernel<true, true>), grid, dim3(256), 0, s, p);
+  if (g.conv_a || g.conv_b) {
+    // convolution operands: forward / dgrad-as-convolution (A = patches, k-contiguous; B = weights, k-contiguous)
+    // and wgrad (A = dpre^T, B = patches with the patch row on k)
+    if (g.conv_a && !g.conv_b && ak && bk) hipLaunchKernelGGL((pv_gemm_kernel<true, true, true, false>), grid, dim3(256), 0, s, p);
+    else if (g.conv_b && !g.conv_a && !ak && !bk) hipLaunchKernelGGL((pv_gemm_kernel<false, false, false, true>), grid, dim3(256), 0, s, p);
+    else return PV_EINVAL;
+  } else if (ak && bk) hipLaunchKernelGGL((pv_gemm_kernel<true, true>), grid, dim3(256), 0, s, p);
   else if (ak && !bk) hipLaunchKernelGGL((pv_gemm_kernel<true, false>), grid, dim3(256), 0, s, p);
   else if (!ak && bk) hipLaunchKernelGGL((pv_gemm_kernel<false, true>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((pv_gemm_kernel<false, false>), grid, dim3(256), 0, s, p);

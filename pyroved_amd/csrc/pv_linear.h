@@ -13,3 +13,9 @@ int linear_dgrad(const float* dpre, int64_t lddp, const float* W, float* dx, int
 // dw[N,K] = dpre^T x ; db[N] = colsum(dpre)
 int linear_wgrad(const float* dpre, int64_t lddp, const float* x, int64_t ldx, float* dw, float* db, int64_t M,
                  int64_t K, int64_t N, void* ws, int64_t wsb, hipStream_t s);
+
+// convolutions (kernel 3, padding 1, stride 1, channels-last [B][H][W][C]; nd = 1: W = 1) on an implicit im2col operand
+int conv3_fwd(const float* in, int B, int H, int W_, int C, int nd, const float* W, const float* b, float* y, int Cout,
+              int act, void* ws, int64_t wsb, hipStream_t s);
+int conv3_wgrad(const float* dpre, const float* in, int B, int H, int W_, int C, int nd, float* dw, float* db, int Cout,
+                void* ws, int64_t wsb, hipStream_t s);

@@ -253,6 +253,32 @@ int linear_wgrad(const float* dpre, int64_t lddp, const float* x, int64_t ldx, f
   return 0;
 }
 
+// ---- convolutions (kernel 3, padding 1, stride 1; channels-last) as GEMMs over an IMPLICIT im2col operand ----
+// y[(b,y,x)][co] = act(sum_j patch[(b,y,x)][j] W[co][j] + b[co]),  j = ci*KK + tap;  W = the torch weight as it lies
+int conv3_fwd(const float* in, int B, int H, int W_, int C, int nd, const float* W, const float* b, float* y, int Cout,
+              int act, void* ws, int64_t wsb, hipStream_t s) {
+  const int64_t rows = (int64_t)B * H * W_, K = (int64_t)C * (nd == 2 ? 9 : 3);
+  PvGemm g{};
+  g.A = in; g.a_rs = K; g.a_cs = 1; g.conv_a = 1; g.cH = H; g.cW = W_; g.cC = C; g.cnd = nd;
+  g.B = W; g.b_rs = 1; g.b_cs = K;
+  g.C = y; g.ldc = Cout; g.M = (int)rows; g.N = Cout; g.K = (int)K;
+  g.bias = b; g.act = act;
+  return pv_gemm(g, pv_gemm_pick_splits((int)rows, Cout, (int)K), ws, wsb, s);
+}
+
+// dw[co][j] = sum_rows dpre[row][co] patch[row][j] ; db[co] = sum_rows dpre[row][co]
+int conv3_wgrad(const float* dpre, const float* in, int B, int H, int W_, int C, int nd, float* dw, float* db, int Cout,
+                void* ws, int64_t wsb, hipStream_t s) {
+  const int64_t rows = (int64_t)B * H * W_, K = (int64_t)C * (nd == 2 ? 9 : 3);
+  PvGemm g{};
+  g.A = dpre; g.a_rs = 1; g.a_cs = Cout;
+  g.B = in; g.b_rs = K; g.b_cs = 1; g.conv_b = 1; g.cH = H; g.cW = W_; g.cC = C; g.cnd = nd;
+  g.C = dw; g.ldc = K; g.M = Cout; g.N = (int)K; g.K = (int)rows;
+  g.act = PV_ACT_NONE;
+  g.rowsumA = db;
+  return pv_gemm(g, pv_gemm_pick_splits(Cout, (int)K, (int)rows), ws, wsb, s);
+}
+
 namespace {
 
 // convolutional encoder: x viewed as (B, 1, *enc_in_dim) -> op sequence -> flatten (C, spatial) -> L.head
