@@ -41,7 +41,7 @@ enum pv_act {
 };
 
 /* decoder likelihoods: utils/prob.py:25-29 (get_sampler) */
-enum pv_lik { PV_LIK_BERNOULLI = 0, PV_LIK_GAUSSIAN = 1 };
+enum pv_lik { PV_LIK_BERNOULLI = 0, PV_LIK_GAUSSIAN = 1, PV_LIK_CBERNOULLI = 2 /* ContinuousBernoulli(probs) */ };
 
 #define PV_MAX_LAYERS 8
 

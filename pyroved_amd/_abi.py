@@ -16,7 +16,7 @@ PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
 ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "lrelu": 3, "softplus": 4, "gelu": 5, "sigmoid": 6}
-LIK = {"bernoulli": 0, "gaussian": 1}
+LIK = {"bernoulli": 0, "gaussian": 1, "continuous_bernoulli": 2}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_LIB_PATH") or os.path.join(_HERE, "libpyroved_amd.so")   # override: kernel experiments only

@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256) void pv_out_lik_kernel(PvOutLik p) {
       const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;   // clamp's gradient
       dlda = (1.0f / (1.0f + expf(-lg)) - x) * mask;
       locv = pr;
+    } else if (p.lik == PV_LIK_CBERNOULLI) {
+      pv_cbern(a, x, ll, dlda, locv);
     } else {
       const float pr = p.sigmoid_out ? 1.0f / (1.0f + expf(-a)) : a;
       const float d = x - pr;
@@ -642,6 +644,8 @@ __global__ void pv_lik_elem_kernel(const float* __restrict__ a, const float* __r
       const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
       d = (1.0f / (1.0f + expf(-lg)) - xv) * mask;
       lv = pr;
+    } else if (lik == PV_LIK_CBERNOULLI) {
+      pv_cbern(av, xv, ll, d, lv);
     } else {
       const float pr = sigmoid_out ? 1.0f / (1.0f + expf(-av)) : av;
       const float df = xv - pr;

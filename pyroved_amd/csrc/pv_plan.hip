@@ -72,8 +72,8 @@ bool valid_plan(const pv_ivae_plan* p) {
   if (p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
   if (p->discrete_dim < 0 || p->head.out_dim != plan_head_w(p)) return false;
   if (p->discrete_dim > 0 && (p->coord_dim == 0 || p->c_dim != 0)) return false;   // jiVAE: spatial decoder, no y
-  if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN) return false;
-  if (p->lik == PV_LIK_BERNOULLI && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
+  if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN && p->lik != PV_LIK_CBERNOULLI) return false;
+  if (p->lik != PV_LIK_GAUSSIAN && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
   if (p->coord_dim > 0 && p->out.out_dim != 1) return false;
   if (p->coord_dim == 0 && p->out.out_dim != p->n_pix) return false;
   return true;

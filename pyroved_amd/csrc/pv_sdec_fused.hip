@@ -315,6 +315,8 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
         const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
         dlda = (fd_rcp(1.0f + fd_exp(-lg)) - xv) * mask;
         locv = pr;
+      } else if (f.lik == PV_LIK_CBERNOULLI) {
+        pv_cbern(a, xv, ll, dlda, locv);
       } else {
         const float pr = f.sigmoid_out ? fd_rcp(1.0f + fd_exp(-a)) : a;
         const float d = xv - pr;

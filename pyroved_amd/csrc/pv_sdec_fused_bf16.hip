@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256) void pv_fb_prep_kernel(PvFbPrep p) {
   pv_fb_prep(p, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
-template <bool GRADS>
+// LIK: the likelihood is a compile-time choice (the rarely used ones must not cost the Bernoulli kernel registers)
+template <bool GRADS, int LIK>
 __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f) {
   extern __shared__ __attribute__((aligned(16))) char smb[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
       const float a = fb_sum_q(part) + bo;
       float ll, locv;
-      if (f.lik == PV_LIK_BERNOULLI) {
+      if (LIK == PV_LIK_BERNOULLI) {
         const float pr = fb_rcp(1.0f + fb_exp(-a));
         const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
         const float lg = fb_log(pc) - fb_log(1.0f - pc);
@@ -555,6 +556,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
         dlda = (fb_rcp(1.0f + fb_exp(-lg)) - xv) * mask;
         locv = pr;
+      } else if (LIK == PV_LIK_CBERNOULLI) {
+        pv_cbern(a, xv, ll, dlda, locv);
       } else {
         const float pr = f.sigmoid_out ? fb_rcp(1.0f + fb_exp(-a)) : a;
         const float d = xv - pr;
@@ -797,20 +800,28 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, hipStre
   if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }
   f.ablate = ablate;
   const size_t lds = FB_LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_sdec_fused_bf16_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_sdec_fused_bf16_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
-    attr_set = true;
+  const void* fn = nullptr;
+#define FB_PICK(G, L) fn = reinterpret_cast<const void*>(&pv_sdec_fused_bf16_kernel<G, L>)
+  if (grads) {
+    if (f.lik == PV_LIK_BERNOULLI) FB_PICK(true, PV_LIK_BERNOULLI);
+    else if (f.lik == PV_LIK_GAUSSIAN) FB_PICK(true, PV_LIK_GAUSSIAN);
+    else FB_PICK(true, PV_LIK_CBERNOULLI);
+  } else {
+    if (f.lik == PV_LIK_BERNOULLI) FB_PICK(false, PV_LIK_BERNOULLI);
+    else if (f.lik == PV_LIK_GAUSSIAN) FB_PICK(false, PV_LIK_GAUSSIAN);
+    else FB_PICK(false, PV_LIK_CBERNOULLI);
   }
-  if (grads)
-    hipLaunchKernelGGL(pv_sdec_fused_bf16_kernel<true>, dim3(grid), dim3(FB_THREADS), lds, s, f);
-  else
-    hipLaunchKernelGGL(pv_sdec_fused_bf16_kernel<false>, dim3(grid), dim3(FB_THREADS), lds, s, f);
+#undef FB_PICK
+  static const void* configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const int slot = (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
+  if (configured[slot] != fn) {                     // (idempotent: a race between host threads only repeats the call)
+    hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess) return (int)e1;
+    configured[slot] = fn;
+  }
+  void* args[] = {&f};
+  hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(FB_THREADS), args, lds, s);
+  if (e2 != hipSuccess) return (int)e2;
   PV_LAUNCH_CHECK();
   return 0;
 }

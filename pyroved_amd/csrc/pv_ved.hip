@@ -41,8 +41,8 @@ bool valid_ved(const pv_ved_plan* p) {
   if (p->in_ch < 1 || p->out_ch < 1 || p->n_enc_ops < 1 || p->n_enc_ops > PV_MAX_OPS || p->n_dec_ops < 1 ||
       p->n_dec_ops > PV_MAX_OPS)
     return false;
-  if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN) return false;
-  if (p->lik == PV_LIK_BERNOULLI && !p->sigmoid_out) return false;
+  if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN && p->lik != PV_LIK_CBERNOULLI) return false;
+  if (p->lik != PV_LIK_GAUSSIAN && !p->sigmoid_out) return false;
   if (p->head.out_dim != 2 * p->z_dim || p->l2f.in_dim != p->z_dim) return false;
   return true;
 }

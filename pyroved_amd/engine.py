@@ -83,8 +83,8 @@ class IVAEEngine:
         name = m.sampler_d.name
         if name not in _abi.LIK:
             raise UnsupportedModel("decoder sampler %r is not implemented in the HIP path yet" % name)
-        if name == "bernoulli" and not dec.sigmoid_out:
-            raise UnsupportedModel("bernoulli likelihood needs sigmoid_d=True")
+        if name in ("bernoulli", "continuous_bernoulli") and not dec.sigmoid_out:
+            raise UnsupportedModel("%s likelihood needs sigmoid_d=True" % name)
         if (not self.conv_enc and len(_linears(enc.fc_layers)) > _abi.PV_MAX_LAYERS) or \
                 len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
             raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)

@@ -38,8 +38,8 @@ class VEDEngine(IVAEEngine):
         name = m.sampler_d.name
         if name not in _abi.LIK:
             raise UnsupportedModel("decoder sampler %r is not implemented in the HIP path yet" % name)
-        if name == "bernoulli" and not dec.sigmoid_out:
-            raise UnsupportedModel("bernoulli likelihood needs sigmoid_d=True")
+        if name in ("bernoulli", "continuous_bernoulli") and not dec.sigmoid_out:
+            raise UnsupportedModel("%s likelihood needs sigmoid_d=True" % name)
         self._ops(enc.feature_extractor.layers, enc.feature_extractor.activation)      # validates
         self._ops(dec.upsampler.layers, dec.upsampler.activation)
 

@@ -188,6 +188,9 @@ VARIANTS = {
     "gauss_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], sampler_d="gaussian"),
     "gauss_nosig_r": dict(data_dim=(8, 8), invariances=["r"], sampler_d="gaussian", sigmoid_d=False),
     "gauss_sig02_t": dict(data_dim=(8, 8), invariances=["t"], sampler_d="gaussian", decoder_sig=0.2),
+    "cbern_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], sampler_d="continuous_bernoulli"),
+    "cbern_none": dict(data_dim=(8, 8), invariances=None, sampler_d="continuous_bernoulli"),
+    "cbern_16x16_r": dict(data_dim=(16, 16), invariances=["r"], sampler_d="continuous_bernoulli"),
     "relu_rt": dict(data_dim=(8, 8), invariances=["r", "t"], activation="relu"),
     "softplus_s": dict(data_dim=(8, 8), invariances=["s"], activation="softplus"),
     "lrelu_none": dict(data_dim=(8, 8), invariances=None, activation="lrelu"),
@@ -200,7 +203,7 @@ VARIANTS = {
 }
 
 
-@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("vname", sorted(VARIANTS))
 def test_model_variants_vs_oracle(gpu_device, vname, fused):
     kw = dict(VARIANTS[vname])
@@ -215,7 +218,11 @@ def test_model_variants_vs_oracle(gpu_device, vname, fused):
                      dx_prior=kw.get("dx_prior", 0.1), dy_prior=kw.get("dy_prior"), sc_prior=kw.get("sc_prior", 0.1),
                      decoder_sig=kw.get("decoder_sig", 0.5))
     eng = model.engine(fused=fused)
-    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    # ContinuousBernoulli: torch's closed form of d log C(p)/dp cancels catastrophically near p = 1/2 (where every
+    # pixel of a fresh model sits), so the fp32 reference gradient itself carries ~1e-3 noise; the HIP path uses a
+    # series there and is judged against the fp64 evaluation of the reference's formula
+    odt = torch.float64 if kw.get("sampler_d") == "continuous_bernoulli" else torch.float32
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg, dtype=odt)
     b = 7
     g = torch.Generator().manual_seed(11)
     x = torch.rand(b, *data_dim, generator=g)
@@ -229,12 +236,15 @@ def test_model_variants_vs_oracle(gpu_device, vname, fused):
         eng.loss_and_grads(x.cuda(), eps.cuda(), beta, None if y is None else y.cuda())
         s = eng.scalars.cpu().numpy()
         o.step(x, eps, beta, y)
-        np.testing.assert_allclose(s[0], o.last["loss"].item(), rtol=RTOL_ELBO, err_msg="%s loss" % vname)
+        # (ContinuousBernoulli: per-pixel log-densities are ~ -log 2 + log 2 near p = 1/2: the summed loss is a few
+        #  units made of B*N terms of size 0.7 each good to an fp32 ulp -> absolute bar of 1e-6 per term)
+        atol = 1e-6 * b * int(np.prod(data_dim)) if odt == torch.float64 else 0.0
+        np.testing.assert_allclose(s[0], o.last["loss"].item(), rtol=RTOL_ELBO, atol=atol, err_msg="%s loss" % vname)
         for key in o.p:
             err = rel_l2(eng.grad_of(key), o.last_grads[key])
             assert err < RTOL_GRAD, "%s step %d grad %s: rel l2 error %.3e" % (vname, k, key, err)
         eng.adam_step()
-        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})     # identical state for the next step
+        model.load_state_dict({k_: v_.detach().float() for k_, v_ in o.p.items()})     # identical state for the next step
     # inference API (models/ivae.py:230-275) with the conditioning vector
     args = (x,) if y is None else (x, y)
     z_loc, z_scale = model.encode(*args)
