@@ -65,7 +65,8 @@ enum pv_op_kind {
   PV_OP_CONV = 1,        /* nn.ConvNd(cin, cout, ksize, 1, ksize/2) + activation `act` (weights in the torch
                             layout (cout, cin, *kernel) at w_off, bias at b_off)                        */
   PV_OP_MAXPOOL2 = 2,    /* nn.MaxPoolNd(2, 2)                                                          */
-  PV_OP_UPSAMPLE2 = 3    /* F.interpolate(scale_factor=2, mode="nearest")                               */
+  PV_OP_UPSAMPLE2 = 3,   /* F.interpolate(scale_factor=2, mode="nearest")                               */
+  PV_OP_UPSAMPLE2_BILINEAR = 4   /* F.interpolate(scale_factor=2, mode="bilinear"), 2-D only (align_corners=False) */
 };
 
 typedef struct pv_op {
@@ -221,7 +222,7 @@ int pv_transform_coordinates(const float* grid, int64_t n_pix, int coord_dim, co
  * op sequences read off nets/conv.py's FeatureExtractor (conv.py:150-213) and Upsampler (conv.py:216-262).
  * Tensors cross the ABI in the reference's layout, (B, channels, *spatial) row-major; inside the library
  * activations are channels-last.  Scope: 1-D / 2-D data, kernel 3 (padding 1) and kernel 1 convolutions,
- * stride 1, 2x max-pooling, 2x nearest-neighbour upsampling, no batch normalisation.
+ * stride 1, 2x max-pooling, 2x nearest-neighbour (1-D, 2-D) or bilinear (2-D) upsampling, no batch normalisation.
  * =================================================================================================== */
 typedef struct pv_ved_plan {
   int32_t batch;

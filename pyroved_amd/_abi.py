@@ -30,7 +30,7 @@ class pv_layer(C.Structure):
 
 
 PV_MAX_OPS = 32
-OP = {"conv": 1, "maxpool2": 2, "upsample2": 3}
+OP = {"conv": 1, "maxpool2": 2, "upsample2": 3, "upsample2_bilinear": 4}
 
 
 class pv_op(C.Structure):

@@ -43,9 +43,9 @@ def conv_ops(layers: nn.Sequential, activation, prefix: Optional[str] = None):
         elif isinstance(mod, (nn.MaxPool1d, nn.MaxPool2d)):
             ops.append(("maxpool2", None, None, None))
         elif isinstance(mod, UpsampleBlock):
-            if mod.mode != "nearest" or mod.scale_factor != 2:
-                raise UnsupportedModel("2-D decoders (bilinear upsampling) are not implemented in the HIP path yet")
-            ops.append(("upsample2", None, None, None))
+            if mod.scale_factor != 2 or mod.mode not in ("nearest", "bilinear"):
+                raise UnsupportedModel("upsampling must be 2x nearest or bilinear")
+            ops.append(("upsample2" if mod.mode == "nearest" else "upsample2_bilinear", None, None, None))
             ops.append(("conv", mod.conv, None, None if prefix is None else "%s.%d.conv" % (prefix, pos)))
         else:
             raise UnsupportedModel("unsupported layer %s in a conv stack" % type(mod).__name__)

@@ -96,6 +96,65 @@ __global__ void pv_upsample2_bwd_kernel(const float* __restrict__ dout, float* _
   }
 }
 
+// F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) along one axis of length n: output o reads
+// inputs i0, i1 with weights (1 - l), l:  src = max((o + 0.5)/2 - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, n - 1)
+__device__ __forceinline__ void bil_src(int o, int n, int& i0, int& i1, float& l) {
+  float src = (o + 0.5f) * 0.5f - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  i0 = (int)src;
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  l = src - (float)i0;
+}
+
+__global__ void pv_upsample2_bil_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                            int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t pix = e / C;
+    const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho);
+    const int64_t b = pix / ((int64_t)Wo * Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_src(y, H, y0, y1, ly);
+    bil_src(x, W, x0, x1, lx);
+    const float* p = in + b * H * W * C + c;
+    const float v00 = p[((int64_t)y0 * W + x0) * C], v01 = p[((int64_t)y0 * W + x1) * C];
+    const float v10 = p[((int64_t)y1 * W + x0) * C], v11 = p[((int64_t)y1 * W + x1) * C];
+    out[e] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+  }
+}
+
+// gather form of the transpose: every input pixel collects from the (up to 4 x 4) outputs whose stencil touches it
+__global__ void pv_upsample2_bil_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
+                                            int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t pix = e / C;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    float v = 0.0f;
+    for (int oy = 2 * y - 2; oy <= 2 * y + 2; ++oy) {
+      if (oy < 0 || oy >= Ho) continue;
+      int y0, y1; float ly;
+      bil_src(oy, H, y0, y1, ly);
+      const float wy = (y0 == y ? 1.0f - ly : 0.0f) + (y1 == y ? ly : 0.0f);
+      if (wy == 0.0f) continue;
+      for (int ox = 2 * x - 2; ox <= 2 * x + 2; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        int x0, x1; float lx;
+        bil_src(ox, W, x0, x1, lx);
+        const float wx = (x0 == x ? 1.0f - lx : 0.0f) + (x1 == x ? lx : 0.0f);
+        if (wx != 0.0f) v += wy * wx * dout[((b * Ho + oy) * Wo + ox) * C + c];
+      }
+    }
+    din[e] = v;
+  }
+}
+
 // out[b][s][c] = in[b][c][s]   (to_nsc)   /   out[b][c][s] = in[b][s][c]   (to_ncs)
 __global__ void pv_ncs_nsc_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t B, int C, int64_t S,
                                   int to_nsc) {
@@ -161,4 +220,10 @@ int pv_act_bwd(float* dy, const float* y, int64_t n, int act, hipStream_t s) {
 }
 int pv_conv_wflip(const float* w, float* wt, int Cout, int Cin, int KK, hipStream_t s) {
   CONV_LAUNCH(pv_conv_wflip_kernel, (int64_t)Cout * Cin * KK, w, wt, Cout, Cin, KK);
+}
+int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+  CONV_LAUNCH(pv_upsample2_bil_fwd_kernel, (int64_t)B * 4 * H * W * C, in, out, B, H, W, C);
+}
+int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s) {
+  CONV_LAUNCH(pv_upsample2_bil_bwd_kernel, (int64_t)B * H * W * C, dout, din, B, H, W, C);
 }

@@ -22,6 +22,9 @@ inline bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
     if (out.H < 1 || out.W < 1) return false;
   } else if (o.kind == PV_OP_UPSAMPLE2) {
     out.H = in.H * 2; out.W = nd == 2 ? in.W * 2 : 1;
+  } else if (o.kind == PV_OP_UPSAMPLE2_BILINEAR) {
+    if (nd != 2) return false;
+    out.H = in.H * 2; out.W = in.W * 2;
   } else {
     return false;
   }
@@ -65,6 +68,7 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
     return linear_fwd(in, K, params + o.w_off, bias, out, nullptr, o.cout, rows, K, o.cout, o.act, sc.ws, sc.ws_bytes, s);
   }
   if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
+  if (o.kind == PV_OP_UPSAMPLE2_BILINEAR) return pv_upsample2_bil_fwd(in, out, B, si.H, si.W, si.C, s);
   return pv_upsample2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
 }
 
@@ -90,6 +94,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
   }
   if (!gin) return 0;
   if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s);
+  if (o.kind == PV_OP_UPSAMPLE2_BILINEAR) return pv_upsample2_bil_bwd(g, gin, B, si.H, si.W, si.C, s);
   return pv_upsample2_bwd(g, gin, B, si.H, si.W, si.C, nd, s);
 }
 

@@ -8,8 +8,8 @@ parameters and describe the layer sequence: the arithmetic runs in HIP kernels t
 library (no CPU path).
 
 Scope of this build: 1-D and 2-D data, kernel 3 / stride 1 / padding 1 convolutions, 2x max-pooling,
-2x nearest-neighbour upsampling (the reference's own fallback for 1-D decoders, nets/conv.py:126-130), no batch
-normalisation.  2-D decoders (bilinear upsampling) and batchnorm raise NotImplementedError at engine binding.
+2x upsampling (nearest — the reference's own fallback for 1-D decoders, nets/conv.py:126-130 — or bilinear in 2-D),
+no batch normalisation (raises at engine binding).
 """
 from typing import List, Tuple, Union
 from warnings import warn

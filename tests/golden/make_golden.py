@@ -397,6 +397,10 @@ if __name__ == "__main__":
         run_ved_steps("ved_12x20_to_24_small_b3_l3", (12, 20), (24,), batch=3, latent_dim=3, model_kw=small)
         run_ved_steps("ved_1d32_to_1d32_small_b4", (32,), (32,), batch=4, model_kw=small)
         run_ved_steps("ved_64x64_to_128_b4", (64, 64), (128,), batch=4, steps=2)
+    if only is None or "ved2d" in only:
+        small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])
+        run_ved_steps("ved_16x16_to_8x12_small_b4", (16, 16), (8, 12), batch=4, model_kw=small)     # bilinear upsampling
+        run_ved_steps("ved_1d32_to_16x16_small_b3", (32,), (16, 16), batch=3, model_kw=small)
     if only is not None:
         sys.exit(0)
     # epoch loops through the reference SVItrainer + DataLoader
