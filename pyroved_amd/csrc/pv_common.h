@@ -121,8 +121,6 @@ struct PvGemm {
 // Runs C = epilogue(A*B).  splits > 1 => partial sums through ws (needs splits*M*N floats).
 int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t s);
 int pv_gemm_pick_splits(int M, int N, int K);
-// up to 4 independent GEMMs of one operand-layout class in one launch (no split-K, fused epilogues)
-int pv_gemm_multi(const PvGemm* gs, int n, hipStream_t s);
 // up to 4 plain wgrad problems (short contraction, wide output) in one launch, one wave per 16x16 tile (pv_wgrad.hip)
 int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s);
 // out[i] = sum_p part[p*stride + i], p ascending (deterministic)

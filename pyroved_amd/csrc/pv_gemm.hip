@@ -178,26 +178,6 @@ __global__ __launch_bounds__(256) void pv_gemm_kernel(GemmK p) {
   gemm_tile<AK, BK, CA, CB>(p, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// several independent small GEMMs of the same operand-layout class in ONE launch (no split-K): the
-// encoder's weight gradients are a handful of 10x128 .. 128x784 outputs, each worth less than a launch
-#define GM_MAX 4
-struct GemmMulti {
-  GemmK p[GM_MAX];
-  int tile_start[GM_MAX + 1];
-  int tiles_m[GM_MAX];
-  int n;
-};
-
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256) void pv_gemm_multi_kernel(GemmMulti mp) {
-  __shared__ float As[GK][GLD];
-  __shared__ float Bs[GK][GLD];
-  int i = 0;
-  while (i + 1 < mp.n && (int)blockIdx.x >= mp.tile_start[i + 1]) ++i;
-  const int local = blockIdx.x - mp.tile_start[i];
-  gemm_tile<AK, BK>(mp.p[i], As, Bs, local % mp.tiles_m[i], local / mp.tiles_m[i], 0);
-}
-
 // sums the split-K partials in ascending split order (deterministic) and applies the epilogue
 __global__ __launch_bounds__(256) void pv_gemm_finish_kernel(GemmK p, int splits) {
   const PvGemm& g = p.g;
@@ -281,43 +261,6 @@ int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t
     hipLaunchKernelGGL(pv_gemm_finish_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
     PV_LAUNCH_CHECK();
   }
-  return 0;
-}
-
-int pv_gemm_multi(const PvGemm* gs, int n, hipStream_t s) {
-  if (n <= 0) return 0;
-  if (n > GM_MAX) return PV_EINVAL;
-  GemmMulti mp;
-  mp.n = 0;
-  int total = 0;
-  bool ak = false, bk = false;
-  auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  for (int i = 0; i < n; ++i) {
-    const PvGemm& g = gs[i];
-    if (g.M <= 0 || g.N <= 0) continue;
-    if (g.K <= 0) return PV_EINVAL;
-    const bool a = (g.a_cs == 1), b = (g.b_rs == 1);
-    if (mp.n == 0) { ak = a; bk = b; }
-    else if (a != ak || b != bk) return PV_EINVAL;       // one operand-layout class per launch
-    GemmK& p = mp.p[mp.n];
-    p.g = g;
-    p.k_chunk = (g.K + GK - 1) / GK * GK;
-    p.part = nullptr;
-    p.part_rs = nullptr;
-    p.a_vec = al(g.A) && (ak ? (g.a_rs % 4 == 0) : (g.a_rs == 1 && g.a_cs % 4 == 0));
-    p.b_vec = al(g.B) && (bk ? (g.b_cs % 4 == 0) : (g.b_cs == 1 && g.b_rs % 4 == 0));
-    mp.tiles_m[mp.n] = (g.M + GT - 1) / GT;
-    mp.tile_start[mp.n] = total;
-    total += mp.tiles_m[mp.n] * ((g.N + GT - 1) / GT);
-    ++mp.n;
-  }
-  if (mp.n == 0) return 0;
-  mp.tile_start[mp.n] = total;
-  if (ak && bk) hipLaunchKernelGGL((pv_gemm_multi_kernel<true, true>), dim3(total), dim3(256), 0, s, mp);
-  else if (ak && !bk) hipLaunchKernelGGL((pv_gemm_multi_kernel<true, false>), dim3(total), dim3(256), 0, s, mp);
-  else if (!ak && bk) hipLaunchKernelGGL((pv_gemm_multi_kernel<false, true>), dim3(total), dim3(256), 0, s, mp);
-  else hipLaunchKernelGGL((pv_gemm_multi_kernel<false, false>), dim3(total), dim3(256), 0, s, mp);
-  PV_LAUNCH_CHECK();
   return 0;
 }
 
