@@ -501,6 +501,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   __shared__ float sh_dzc[64];
   __shared__ float sh_tp[4];
   __shared__ float sh_ll[128];
+  __shared__ float sm5[5][4];
   const int t = threadIdx.x;
   const int K = p.K > 0 ? p.K : 1, Bq = p.hb.B;
   float tp_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -516,11 +517,21 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
         for (int c = 0; c < 4; ++c) a[1 + c] += p.rowtp[(int64_t)c * p.M + r0 + n];
       }
     }
-    a[0] = block_sum_256(a[0], sm);
+    // the five row sums in ONE block reduction (fixed order: wave sums, then waves 0..3)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) a[c] = pv_wave_sum(a[c]);
+    __syncthreads();
+    if ((t & 63) == 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) sm5[c][t >> 6] = a[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 5; ++c) a[c] = (sm5[c][0] + sm5[c][1]) + (sm5[c][2] + sm5[c][3]);
     if (t == 0) sh_ll[k] = a[0];
     if (p.fwd_only) continue;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) tp_acc[c] += block_sum_256(a[1 + c], sm);
+    for (int c = 0; c < 4; ++c) tp_acc[c] += a[1 + c];
     for (int j = t; j < p.H; j += 256) {
       float v = 0.0f;
       for (int kk = 0; kk < p.kmax; ++kk) v += p.part_hz[(s * p.kmax + kk) * p.H + j];
