@@ -30,20 +30,22 @@ __device__ __forceinline__ float en_block_sum(float v, float* sm /* 8 floats */)
 
 // one transposed layer for this wave's output blocks: D[j][r] = sum_k W[j][k] in[r][k]
 //   in: global (GLOBAL_IN, row stride ldin) or LDS (stride EN_LD); K % 16 == 0; out rows j >= out_dim are zero
-//   K <= 128: the block's whole weight operand (<= 8 float4 per lane) is requested before the first MFMA
-__device__ __forceinline__ f32x4 en_layer_block(const float* __restrict__ W, int K, int out_dim, int ob,
-                                                const float* __restrict__ in /* LDS */, int r, int q) {
+//   K <= 128: the block's whole weight operand (<= 8 float4 per lane) is requested before the first MFMA — and, for
+//   the layers the kernel can see coming, before anything else the kernel does (en_load_w at its top)
+__device__ __forceinline__ void en_load_w(const float* __restrict__ W, int K, int out_dim, int ob, int r, int q,
+                                          f32x4 (&a)[8]) {
   const int j = 16 * ob + r;                       // this lane's A row
   const bool jok = j < out_dim;
   const float* wrow = W + (int64_t)(jok ? j : 0) * K + 4 * q;
-  const float* irow = in + r * EN_LD + 4 * q;
-  f32x4 a[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const bool ok = jok && 16 * t < K;
     a[t] = *reinterpret_cast<const f32x4*>(wrow + (16 * t < K ? 16 * t : 0));
     if (!ok) a[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
+}
+__device__ __forceinline__ f32x4 en_mma(const f32x4 (&a)[8], int K, const float* __restrict__ in /* LDS */, int r, int q) {
+  const float* irow = in + r * EN_LD + 4 * q;
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -56,6 +58,23 @@ __device__ __forceinline__ f32x4 en_layer_block(const float* __restrict__ W, int
     }
   }
   return acc0 + acc1;
+}
+__device__ __forceinline__ f32x4 en_layer_block(const float* __restrict__ W, int K, int out_dim, int ob,
+                                                const float* __restrict__ in /* LDS */, int r, int q) {
+  f32x4 a[8];
+  en_load_w(W, K, out_dim, ob, r, q, a);
+  return en_mma(a, K, in, r, q);
+}
+__device__ __forceinline__ f32x4 en_load_bias(const float* bias, int out_dim, int ob, int q) {
+  f32x4 b = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * ob + 4 * q + i;
+      b[i] = j < out_dim ? bias[j] : 0.0f;
+    }
+  }
+  return b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -130,6 +149,32 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
   const int row0 = blockIdx.x * EN_ROWS;
   const bool rok = row0 + r < e.B;
   int cur = 0;
+  // ---- everything that does not depend on computed data is requested NOW (one memory latency for the whole kernel
+  // instead of one per phase): this wave's weight / bias operands of hidden layer 1 and of the head, eps ----
+  const bool pf1 = e.n_enc > 1 && 16 * wave < e.enc[1].out_dim;      // the wave's first block of layer 1
+  const bool pfh = 16 * wave < e.head.out_dim;                        // the wave's first block of the head
+  f32x4 w1[8], wh[8], b1v = {0.0f, 0.0f, 0.0f, 0.0f}, bhv = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (pf1) {
+    en_load_w(e.params + e.enc[1].w_off, e.enc[1].in_dim, e.enc[1].out_dim, wave, r, q, w1);
+    b1v = en_load_bias(e.enc[1].b_off >= 0 ? e.params + e.enc[1].b_off : nullptr, e.enc[1].out_dim, wave, q);
+  }
+  if (pfh) {
+    en_load_w(e.params + e.head.w_off, e.head.in_dim, e.head.out_dim, wave, r, q, wh);
+    bhv = en_load_bias(e.head.b_off >= 0 ? e.params + e.head.b_off : nullptr, e.head.out_dim, wave, q);
+  }
+  // fc_latent's row of this thread's output column (its column is the same in every pass when H0 divides the block)
+  const bool pfz = e.hz != nullptr && EN_THREADS % e.H0 == 0;
+  float wzp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (pfz) {
+    const int lat_all = (e.z_dim - (e.coord_dim == 1 ? (e.has_t ? 1 : 0) : e.coord_dim == 2 ? e.has_r + 2 * e.has_t + e.has_s : 0)) +
+                        e.c_dim + (e.K > 0 ? e.K : 0);
+    const float* wz = e.Wz + (int64_t)(tid % e.H0) * lat_all;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wzp[i] = i < lat_all ? wz[i] : 0.0f;
+  }
+  float eps_pf = 0.0f;                               // thread t < 16*z_dim handles (row t / z, column t % z)
+  if (tid < EN_ROWS * e.z_dim && row0 + tid / e.z_dim < e.B)
+    eps_pf = e.eps[(int64_t)(row0 + tid / e.z_dim) * e.z_dim + tid % e.z_dim];
   // ---- the first layer's output (pv_enc_l1_kernel) into LDS; rows past the batch repeat the last one ----
   {
     const int w0 = e.enc[0].out_dim;
@@ -146,14 +191,14 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     const float* W = e.params + l.w_off;
     const float* bias = l.b_off >= 0 ? e.params + l.b_off : nullptr;
     for (int ob = wave; 16 * ob < l.out_dim; ob += EN_THREADS / 64) {
-      f32x4 acc = en_layer_block(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], r, q);
+      const bool pre = li == 1 && ob == wave;          // operands already in registers
+      const f32x4 acc = pre ? en_mma(w1, l.in_dim, &act[cur][0][0], r, q)
+                            : en_layer_block(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], r, q);
+      const f32x4 bv = pre ? b1v : en_load_bias(bias, l.out_dim, ob, q);
       // C/D layout: lane (col r, q), reg i -> output j = 16*ob + 4*q + i of row r
       f32x4 y;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * ob + 4 * q + i;
-        y[i] = pv_act_fwd(acc[i] + (bias && j < l.out_dim ? bias[j] : 0.0f), l.act);
-      }
+      for (int i = 0; i < 4; ++i) y[i] = pv_act_fwd(acc[i] + bv[i], l.act);
       *reinterpret_cast<f32x4*>(&act[cur ^ 1][r][16 * ob + 4 * q]) = y;
       if (rok) *reinterpret_cast<f32x4*>(e.eact[li] + (int64_t)(row0 + r) * l.out_dim + 16 * ob + 4 * q) = y;
     }
@@ -166,12 +211,15 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     const float* W = e.params + l.w_off;
     const float* bias = l.b_off >= 0 ? e.params + l.b_off : nullptr;
     for (int ob = wave; 16 * ob < l.out_dim; ob += EN_THREADS / 64) {
-      f32x4 acc = en_layer_block(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], r, q);
+      const bool pre = ob == wave;
+      const f32x4 acc = pre ? en_mma(wh, l.in_dim, &act[cur][0][0], r, q)
+                            : en_layer_block(W, l.in_dim, l.out_dim, ob, &act[cur][0][0], r, q);
+      const f32x4 bv = pre ? bhv : en_load_bias(bias, l.out_dim, ob, q);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = 16 * ob + 4 * q + i;
         if (j < l.out_dim) {
-          const float v = acc[i] + (bias ? bias[j] : 0.0f);
+          const float v = acc[i] + bv[i];
           act[cur ^ 1][r][j] = v;
           if (rok) e.head_out[(int64_t)(row0 + r) * l.out_dim + j] = v;
         }
@@ -188,7 +236,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     if (row < e.B) {
       const float mu = act[cur][rr][i], sp = act[cur][rr][zd + i];
       const float sig = pv_softplus(sp);
-      const float ep = e.eps[(int64_t)row * zd + i];
+      const float ep = t == tid ? eps_pf : e.eps[(int64_t)row * zd + i];
       const float z = mu + sig * ep;
       e.z[(int64_t)row * zd + i] = z;
       e.z_scale[(int64_t)row * zd + i] = sig;
@@ -270,7 +318,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       if (row >= e.B) continue;
       const float* wz = e.Wz + (int64_t)j * lat_in;
       float v = 0.0f;
-      for (int i = 0; i < L; ++i) v += act[cur][rr][coord + i] * wz[i];
+      for (int i = 0; i < L; ++i) v += act[cur][rr][coord + i] * ((pfz && i < 4) ? wzp[i] : wz[i]);
       for (int i = 0; i < e.c_dim; ++i) v += e.y[(int64_t)row * e.c_dim + i] * wz[L + i];
       if (K > 0) {
         for (int k = 0; k < K; ++k) e.hz[((int64_t)k * e.B + row) * e.H0 + j] = v + wz[L + e.c_dim + k];
@@ -324,18 +372,48 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
   const int row0 = blockIdx.x * EN_ROWS;
   const int ne = e.n_enc;
   int cur = 0;
+  // ---- requested up front (one memory latency for the kernel): the wave's strided weight operand and activation
+  // tile of the first MFMA layer, and the head-weight column of the thread's output in the first phase ----
+  float a0[8][4];
+  f32x4 h0 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool pf = ne > 1 && 16 * wave < e.enc[ne - 1].in_dim;
+  if (pf) {
+    const pv_layer l = e.enc[ne - 1];
+    const float* wcol = e.params + l.w_off + 16 * wave + r;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * t + 4 * q + i;
+        const float v = wcol[(int64_t)(j < l.out_dim ? j : 0) * l.in_dim];
+        a0[t][i] = j < l.out_dim ? v : 0.0f;
+      }
+    if (row0 + r < e.B)
+      h0 = *reinterpret_cast<const f32x4*>(e.eact[ne - 2] + (int64_t)(row0 + r) * e.enc[ne - 2].out_dim + 16 * wave + 4 * q);
+  }
   {
     // from the head: K = 2*z_dim is tiny -> plain FMAs
     const pv_layer hd = e.head;
     const pv_layer ll = e.enc[ne - 1];
     const float* Wh = e.params + hd.w_off;
+    const bool fastk = EN_THREADS % ll.out_dim == 0;        // then a thread keeps its column k in every pass
+    float whp[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+      whp[o] = (fastk && o < hd.out_dim) ? Wh[(int64_t)o * hd.in_dim + tid % ll.out_dim] : 0.0f;
     for (int t = tid; t < EN_ROWS * ll.out_dim; t += EN_THREADS) {
       const int rr = t / ll.out_dim, k = t % ll.out_dim, row = row0 + rr;
       float v = 0.0f;
       if (row < e.B) {
         const float* dh = e.dhead + (int64_t)row * hd.out_dim;
-        for (int o = 0; o < hd.out_dim; ++o) v += dh[o] * Wh[(int64_t)o * hd.in_dim + k];
-        v *= pv_act_grad(e.eact[ne - 1][(int64_t)row * ll.out_dim + k], 0.0f, ll.act);
+        const float hv = e.eact[ne - 1][(int64_t)row * ll.out_dim + k];
+        float dv[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) dv[o] = o < hd.out_dim ? dh[o] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) v += dv[o] * (fastk ? whp[o] : (o < hd.out_dim ? Wh[(int64_t)o * hd.in_dim + k] : 0.0f));
+        for (int o = 16; o < hd.out_dim; ++o) v += dh[o] * Wh[(int64_t)o * hd.in_dim + k];
+        v *= pv_act_grad(hv, 0.0f, ll.act);
         e.edp[ne - 1][(int64_t)row * ll.out_dim + k] = v;
       }
       buf[cur][rr][k] = v;
@@ -348,12 +426,14 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
     const float* W = e.params + l.w_off;
     for (int kb = wave; 16 * kb < l.in_dim; kb += EN_THREADS / 64) {
       const float* wcol = W + 16 * kb + r;                 // A lane (k' = r, q): W[j][16*kb + k']
+      const bool pre = pf && li == ne - 1 && kb == wave;   // operands requested at the top of the kernel
       float a[8][4];                                       // out_dim <= 128: the whole operand in flight at once
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int j = 16 * t + 4 * q + i;
+          if (pre) { a[t][i] = a0[t][i]; continue; }
           const float v = wcol[(int64_t)(j < l.out_dim ? j : 0) * l.in_dim];
           a[t][i] = j < l.out_dim ? v : 0.0f;
         }
@@ -372,7 +452,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
       const int row = row0 + r;
       f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
       if (row < e.B) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(e.eact[li - 1] + (int64_t)row * lp.out_dim + 16 * kb + 4 * q);
+        const f32x4 h = pre ? h0 : *reinterpret_cast<const f32x4*>(e.eact[li - 1] + (int64_t)row * lp.out_dim + 16 * kb + 4 * q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = acc[i] * pv_act_grad(h[i], 0.0f, lp.act);
         *reinterpret_cast<f32x4*>(e.edp[li - 1] + (int64_t)row * lp.out_dim + 16 * kb + 4 * q) = y;
