@@ -273,10 +273,9 @@ def jelbo(p: Params, cfg: Config, x, eps, beta=1.0, grid=None):
     loss = -sum_b [ b0*(log N(z_b;0,1) - log N(z_b;mu_b,sigma_b))
                     + sum_k alpha_bk * ( log p(x_b | z_b, k) + b1*log(1/K) - b1*log alpha_bk ) ]
     z = mu + sigma*eps;  the decoder runs on K*B rows ordered [k][b] (z.repeat(K, 1), jivae.py:181) with the one-hot
-    class appended to the content part of z (jivae.py:189-192); scale_factor: scalar -> both, [cont, disc].
+    class appended to the content part of z (jivae.py:189-192; without invariances Concat broadcasts z over the K
+    enumerated classes, utils/nn.py:62-74, which is the same row set); scale_factor: scalar -> both, [cont, disc].
     """
-    if cfg.coord == 0:
-        raise NotImplementedError("oracle: jiVAE without invariances (fcDecoderNet) is not restated")
     b0, b1 = (beta, beta) if not isinstance(beta, (list, tuple)) else beta
     bsz, K = x.shape[0], cfg.discrete_dim
     z_loc, z_scale, alpha = jencoder_forward(p, cfg, x)

@@ -492,6 +492,55 @@ int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, h
   return 0;
 }
 
+// jiVAE with the vanilla decoder (layer-by-layer path): per input b, from the K enumerated decoder passes [k][b]:
+//   llb[b] = sum_k alpha_bk ll_kb ; dzc[b][:] += sum_{k>=1} dzc[(k,b)][:] (first n_content columns; in place in block
+//   k = 0) ; dhead[b][2z + k] = softmax backward of dloss/dalpha_bk = -(ll_kb - b1 log K - b1 log alpha_bk - b1)
+__global__ void pv_jiv_combine_kernel(const float* __restrict__ llkb, const float* __restrict__ alpha, float* __restrict__ llb,
+                                      float* __restrict__ dzc, int ld_dzc, int n_content, float* __restrict__ dhead, int ldh,
+                                      int z_dim, int B, int K, float beta_disc, int want_grads) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* al = alpha + (int64_t)b * K;
+  float ll = 0.0f;
+  for (int k = 0; k < K; ++k) ll += al[k] * llkb[(int64_t)k * B + b];
+  llb[b] = ll;
+  if (!want_grads) return;
+  for (int i = 0; i < n_content; ++i) {
+    float v = dzc[(int64_t)b * ld_dzc + i];
+    for (int k = 1; k < K; ++k) v += dzc[((int64_t)k * B + b) * ld_dzc + i];
+    dzc[(int64_t)b * ld_dzc + i] = v;
+  }
+  const float lK = logf((float)K);
+  float dot = 0.0f;
+  for (int k = 0; k < K; ++k)
+    dot += al[k] * -(llkb[(int64_t)k * B + b] - beta_disc * lK - beta_disc * logf(al[k]) - beta_disc);
+  for (int k = 0; k < K; ++k) {
+    const float da = -(llkb[(int64_t)k * B + b] - beta_disc * lK - beta_disc * logf(al[k]) - beta_disc);
+    dhead[(int64_t)b * ldh + 2 * z_dim + k] = al[k] * (da - dot);
+  }
+}
+int pv_jiv_combine(const float* llkb, const float* alpha, float* llb, float* dzc, int ld_dzc, int n_content, float* dhead,
+                   int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s) {
+  hipLaunchKernelGGL(pv_jiv_combine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, llkb, alpha, llb, dzc, ld_dzc, n_content,
+                     dhead, ldh, z_dim, B, K, beta_disc, want_grads);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+// v[row][:] *= w[row]
+__global__ void pv_scale_rows_kernel(float* __restrict__ v, const float* __restrict__ w, int64_t rows, int64_t N) {
+  const int64_t total = rows * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    v[e] *= w[e / N];
+}
+int pv_scale_rows(float* v, const float* w, int64_t rows, int64_t N, hipStream_t s) {
+  int64_t blocks = (rows * N + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(pv_scale_rows_kernel, dim3((int)blocks), dim3(256), 0, s, v, w, rows, N);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
 // latent_bwd (fused decoder path): one workgroup per sample gathers everything that flows from the decoder
 // kernel back into that sample's latent code: ll_b and d(phi, scale, tx, ty) (sums over the sample's N rows),
 // dL/d(hz[b]) (sum of the workgroup partials), dL/d(z content) = dhz Wz, then head_bwd.  Fixed-order sums.

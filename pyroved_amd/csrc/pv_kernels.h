@@ -107,6 +107,9 @@ struct PvLatentBwd {
 };
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
 int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, hipStream_t s);
+int pv_jiv_combine(const float* llkb, const float* alpha, float* llb, float* dzc, int ld_dzc, int n_content, float* dhead,
+                   int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s);
+int pv_scale_rows(float* v, const float* w, int64_t rows, int64_t N, hipStream_t s);
 struct PvFusedOffsets;
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
                          hipStream_t s);

@@ -42,7 +42,7 @@ struct Layout {
   float* logits; float* llrow; float* llb; float* dbuf[2];
   float* part_dwo; float* part_dbo; float* part_hz; float* part_wc; float* part_tp;
   float* dhz; float* dtp; float* dzc;
-  float* alpha; float* sw;                 // jiVAE: class probabilities (B, K), decoder row weights (K*B)
+  float* alpha; float* sw; float* llkb;    // jiVAE: class probabilities (B, K), decoder row weights (K*B), ll per (k, b)
   // convolutional encoder (plan->n_enc_ops > 0): activation shapes / buffers, flattened features, gradient ping-pong
   bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
   float* ccol; int64_t cF;
@@ -71,7 +71,7 @@ bool valid_plan(const pv_ivae_plan* p) {
   if (p->n_enc_ops == 0 && (p->n_enc < 1 || p->n_enc > PV_MAX_LAYERS)) return false;
   if (p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
   if (p->discrete_dim < 0 || p->head.out_dim != plan_head_w(p)) return false;
-  if (p->discrete_dim > 0 && (p->coord_dim == 0 || p->c_dim != 0)) return false;   // jiVAE: spatial decoder, no y
+  if (p->discrete_dim > 0 && p->c_dim != 0) return false;                            // jiVAE: no conditioning vector
   if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN && p->lik != PV_LIK_CBERNOULLI) return false;
   if (p->lik != PV_LIK_GAUSSIAN && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
   if (p->coord_dim > 0 && p->out.out_dim != 1) return false;
@@ -84,7 +84,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   Carver c{base, 0};
   const int64_t B = p->batch, N = p->n_pix, z = p->z_dim;
   const int64_t lat_in = plan_lat_in(p), K = plan_K(p), S = inference_only ? p->batch : plan_S(p), hw = plan_head_w(p);
-  L.rows = p->coord_dim > 0 ? S * N : B;
+  L.rows = p->coord_dim > 0 ? S * N : S;
   const int64_t R = L.rows;
   L.xin = p->c_dim > 0 ? c.take(B * (N + p->c_dim)) : nullptr;
   int64_t maxe = 0;
@@ -171,18 +171,19 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
     upd(gemm_ws_need(B, lat_in, H0));          // dzc
   } else {
     L.hz = L.h0 = nullptr;
-    L.logits = c.take(B * N);
-    L.llrow = c.take(B * N);
+    L.logits = c.take(S * N);
+    L.llrow = c.take(S * N);
     L.part_dwo = L.part_dbo = L.part_hz = L.part_wc = L.part_tp = L.dhz = L.dtp = nullptr;
     L.nchunk = L.rows_per_chunk = 0;
-    L.dzc = c.take(B * lat_in);
+    L.dzc = c.take(S * lat_in);
     if (N > maxd) maxd = N;
-    upd(gemm_ws_need(B, N, p->out.in_dim));
-    upd(gemm_ws_need(N, p->out.in_dim, B));
-    upd(gemm_ws_need(B, p->out.in_dim, N));
-    upd(pv_colsum_ws(B, (int)N));
+    upd(gemm_ws_need(S, N, p->out.in_dim));
+    upd(gemm_ws_need(N, p->out.in_dim, S));
+    upd(gemm_ws_need(S, p->out.in_dim, N));
+    upd(pv_colsum_ws(S, (int)N));
   }
   L.llb = c.take(B);
+  L.llkb = K > 0 ? c.take(S) : nullptr;
   L.dbuf[0] = L.fused ? nullptr : c.take(R * maxd);
   L.dbuf[1] = L.fused ? nullptr : c.take(R * maxd);
   // scratch: the largest split-K / colsum requirement of any single call
@@ -355,7 +356,7 @@ int decoder_hidden_fwd(const pv_ivae_plan* p, const Layout& L, const float* zin,
   if (p->out.in_dim != ldin) return PV_EINVAL;
   if (p->coord_dim == 0) {
     PV_TRY(linear_fwd(in, ldin, p->params + p->out.w_off, p->out.b_off >= 0 ? p->params + p->out.b_off : nullptr,
-                      L.logits, nullptr, p->n_pix, B, p->out.in_dim, p->n_pix, PV_ACT_NONE, L.scratch,
+                      L.logits, nullptr, p->n_pix, R, p->out.in_dim, p->n_pix, PV_ACT_NONE, L.scratch,
                       L.scratch_bytes, s));
   }
   return 0;
@@ -456,6 +457,7 @@ int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, i
   hb.head = L.head; hb.dhead = L.dhead; hb.B = p->batch; hb.z_dim = p->z_dim; hb.coord_dim = p->coord_dim;
   hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
   hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
+  hb.ldh = (int)plan_head_w(p);
   PV_TRY(pv_head_bwd(hb, s));
   return encoder_bwd(p, L, nullptr, 0, s);
 }
@@ -575,9 +577,10 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
 }
 
 int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
-  if (plan_K(p) > 0) return PV_EINVAL;             // jiVAE runs on the fused decoder kernels only
+  const int64_t K = plan_K(p);
+  if (K > 0 && (p->coord_dim > 0 || !L.enc_compact)) return PV_EINVAL;   // invariant jiVAE: fused decoder kernels only
   const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
-  const int64_t lat_in = (p->coord_dim > 0 ? p->latent_dim : p->z_dim) + p->c_dim;
+  const int64_t lat_in = plan_lat_in(p);
   float* G = p->grads;
   void* ws = L.scratch;
   const int64_t wsb = L.scratch_bytes;
@@ -586,8 +589,9 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
   // ---------------- forward ----------------
   PV_TRY(guide_fwd(p, L, s));
   const int coord = (int)(z - p->latent_dim);
-  const float* zin = p->c_dim > 0 ? L.zy : (p->coord_dim > 0 ? L.z + coord : L.z);
-  const int64_t ldz = p->c_dim > 0 ? lat_in : z;
+  const bool cat_in = p->c_dim > 0 || K > 0;
+  const float* zin = cat_in ? L.zy : (p->coord_dim > 0 ? L.z + coord : L.z);
+  const int64_t ldz = cat_in ? lat_in : z;
   PV_TRY(decoder_hidden_fwd(p, L, zin, ldz, lat_in, s));
 
   float* cur = L.dbuf[0];      // dL/d(pre-activation) of the layer being processed
@@ -602,11 +606,23 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
     o.lik = p->lik; o.sigmoid_out = p->sigmoid_out; o.act_last = p->dec[nd - 1].act; o.sig = p->decoder_sig;
     PV_TRY(pv_out_lik(o, s));
   } else {
-    // oth <- dL/dlogits (B, N)
-    PV_TRY(pv_lik_elem(L.logits, p->x, B * N, p->lik, p->sigmoid_out, p->decoder_sig, p->loc, L.llrow,
-                       want_grads ? oth : nullptr, s));
+    // oth <- dL/dlogits (R, N); jiVAE: one pass per enumerated class against the same observations, rows then
+    // weighted by alpha (the decoder's gradients become the enumerated expectation)
+    for (int64_t k = 0; k < (K > 0 ? K : 1); ++k)
+      PV_TRY(pv_lik_elem(L.logits + k * B * N, p->x, B * N, p->lik, p->sigmoid_out, p->decoder_sig,
+                         p->loc ? p->loc + k * B * N : nullptr, L.llrow + k * B * N, want_grads ? oth + k * B * N : nullptr, s));
+    if (K > 0 && want_grads) PV_TRY(pv_scale_rows(oth, L.sw, R, N, s));
   }
-  PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
+  if (K > 0) {
+    PV_TRY(pv_segsum(L.llrow, R, N, L.llkb, s));
+    if (!want_grads) PV_TRY(pv_jiv_combine(L.llkb, L.alpha, L.llb, nullptr, 0, 0, nullptr, 0, (int)z, (int)B, (int)K,
+                                           p->beta_disc, 0, s));
+  } else {
+    PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
+  }
+  if (K > 0 && want_grads) {
+    // (llb is formed by pv_jiv_combine at the end of the decoder backward; the scalars are finished there)
+  } else
   PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
   if (!want_grads) return 0;
 
@@ -617,9 +633,9 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
     if (p->out.b_off >= 0) PV_TRY(pv_reduce_partials(L.part_dbo, (int)ob, 1, G + p->out.b_off, 1, s));
   } else {
     // out layer of the vanilla decoder: logits = hlast Wout^T + bout
-    PV_TRY(linear_wgrad(oth, N, hlast, Hl, G + p->out.w_off, p->out.b_off >= 0 ? G + p->out.b_off : nullptr, B, Hl, N,
+    PV_TRY(linear_wgrad(oth, N, hlast, Hl, G + p->out.w_off, p->out.b_off >= 0 ? G + p->out.b_off : nullptr, R, Hl, N,
                         ws, wsb, s));
-    PV_TRY(linear_dgrad(oth, N, p->params + p->out.w_off, cur, Hl, hlast, L.dpre_[nd - 1], Hl, p->dec[nd - 1].act, B,
+    PV_TRY(linear_dgrad(oth, N, p->params + p->out.w_off, cur, Hl, hlast, L.dpre_[nd - 1], Hl, p->dec[nd - 1].act, R,
                         Hl, N, ws, wsb, s));
   }
   for (int i = nd - 1; i >= 0; --i) {
@@ -660,6 +676,12 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
                         lat_in, H0, ws, wsb, s));
   }
 
+  if (K > 0) {
+    // sum the K replicas' dL/dz, form ll_b and the class-logit gradients; then the loss scalars
+    PV_TRY(pv_jiv_combine(L.llkb, L.alpha, L.llb, L.dzc, (int)lat_in, (int)(lat_in - K), L.dhead, (int)plan_head_w(p), (int)z,
+                          (int)B, (int)K, p->beta_disc, 1, s));
+    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, L.kl_blocks, 1.0f, s));
+  }
   return latent_encoder_bwd(p, L, lat_in, 4, 1, s);
 }
 

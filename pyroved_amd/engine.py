@@ -69,8 +69,6 @@ class IVAEEngine:
             raise UnsupportedModel("the HIP SVI path needs encoder_z to be pyroved_amd.nets.fcEncoderNet / "
                                    "jfcEncoderNet / convEncoderNet (got %s)" % type(enc).__name__)
         self.K = int(getattr(m, "discrete_dim", 0)) if isinstance(enc, jfcEncoderNet) else 0
-        if self.K > 0 and m.coord == 0:
-            raise UnsupportedModel("jiVAE without invariances (fcDecoderNet) is not implemented in the HIP path yet")
         if not isinstance(dec, (sDecoderNet, fcDecoderNet)):
             raise UnsupportedModel("the HIP SVI path needs decoder to be sDecoderNet or fcDecoderNet "
                                    "(got %s)" % type(dec).__name__)

@@ -382,6 +382,9 @@ if __name__ == "__main__":
         run_jsteps("jivae_8x8_rt_k3_b4_sf", (8, 8), ["r", "t"], 3, batch=4, scale_factor=[2.0, 3.0])
         run_jsteps("jivae_1d16_t_k2_b5", (16,), ["t"], 2, batch=5)
         run_jsteps("jivae_28x28_r_k10_b16", (28, 28), ["r"], 10, batch=16, steps=2)
+    if only is None or "jvanilla" in only:
+        run_jsteps("jivae_8x8_none_k3_b5", (8, 8), None, 3, batch=5)          # fcDecoderNet (constructor default)
+        run_jsteps("jivae_1d16_none_k4_b6_sf", (16,), None, 4, batch=6, scale_factor=[1.5, 0.5])
     # iVAE with a convolutional encoder (BASELINE config 4 family)
     if only is None or "convenc" in only:
         _rs = globals()["_run_steps_real"]
