@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 3
+#define PV_ABI_VERSION 4
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -141,6 +141,15 @@ typedef struct pv_ivae_plan {
   float*       z_scale;   /* out (B, z_dim), may be NULL                                  */
   float*       loc;       /* out (B, N) decoder output, may be NULL ((K*B, N) for jiVAE)  */
   float*       alpha;     /* out (B, discrete_dim) class probabilities q(k|x), may be NULL */
+  /* ---- external encoder: a user-supplied encoder_z (iVAE.set_encoder(any nn.Module), models/base.py:173-177) runs
+   * in the caller's framework.  ext_encoder != 0: the library does not run an encoder; ext_head (B, 2*z_dim) holds
+   * [z_loc | z_scale] = encoder_z(x) (scale already positive) and, with want_grads, ext_dhead (B, 2*z_dim) receives
+   * [dloss/dz_loc | dloss/dz_scale] for the caller to back-propagate; `enc`, `enc_ops` and `head` are ignored and
+   * only the decoder's parameters live in the flat buffers.  Not combined with discrete_dim / c_dim. ---- */
+  const float* ext_head;
+  float*       ext_dhead;
+  int32_t      ext_encoder;
+  int32_t      _pad3;
   /* ---- Adam (torch.optim.Adam defaults via pyro.optim.Adam, svi.py:79-81) ---- */
   float   lr, adam_beta1, adam_beta2, adam_eps;
   int32_t adam_step;      /* 1-based step count of THIS update                            */

@@ -64,6 +64,7 @@ class Config:
     discrete_dim: int = 0          # > 0: jiVAE (models/jivae.py), K classes enumerated in the ELBO
     conv_encoder: Optional[Sequence[Sequence[int]]] = None   # iVAE.set_encoder(convEncoderNet(data_dim, z_dim, hidden_dim=...)): conv filters per block
     conv_activation: str = "lrelu"
+    custom_encoder: Optional[object] = None     # iVAE.set_encoder(user module): a callable x -> (z_loc, z_scale) in torch
     n_hidden_e: int = 2            # number of hidden Linear layers in encoder_z.fc_layers
     n_hidden_d: int = 2
     activation: str = "tanh"
@@ -425,6 +426,8 @@ class VedOracle:
 def _encode_any(p: Params, cfg: Config, x, y=None):
     """encoder_z(x): fcEncoderNet, or the convEncoderNet a user installed with set_encoder (models/base.py:173-177),
     which sees x as (B, 1, *data_dim)."""
+    if cfg.custom_encoder is not None:
+        return cfg.custom_encoder(x)
     if cfg.conv_encoder is not None:
         vc = VedConfig(input_dim=cfg.data_dim, output_dim=cfg.data_dim, latent_dim=cfg.z_dim,
                        hidden_dim_e=cfg.conv_encoder, activation=cfg.conv_activation)

@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 3
+PV_ABI_VERSION = 4
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -57,7 +57,8 @@ class pv_ivae_plan(C.Structure):
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p), ("grid", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
-        ("alpha", C.c_void_p),
+        ("alpha", C.c_void_p), ("ext_head", C.c_void_p), ("ext_dhead", C.c_void_p),
+        ("ext_encoder", C.c_int32), ("_pad3", C.c_int32),
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),

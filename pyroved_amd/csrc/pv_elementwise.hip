@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void pv_head_fwd_kernel(PvHead h) {
     const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
     const float mu = h.head[(int64_t)b * ldh + i];
     const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
-    const float sig = pv_softplus(sp);
+    const float sig = h.scale_direct ? sp : pv_softplus(sp);
     const float ep = h.eps[e];
     const float z = mu + sig * ep;
     h.z[e] = z;
@@ -453,7 +453,7 @@ __device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int 
   const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
   const float g = dz + h.beta * z;                 // d(-ll - beta*log p(z))/dz
   const float dsig = g * ep - h.beta / sig;        // + beta * d(log q)/d(sigma) (total derivative)
-  const float sgm = sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp));   // softplus'
+  const float sgm = h.scale_direct ? 1.0f : (sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp)));   // softplus'
   h.dhead[(int64_t)b * ldh + i] = g;
   h.dhead[(int64_t)b * ldh + h.z_dim + i] = dsig * sgm;
 }

@@ -17,6 +17,7 @@ struct PvHead {
   int B, z_dim, c_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior, beta;
   int ldh;               // row stride of head (0: 2*z_dim)
+  int scale_direct;      // 1: the second half of head IS z_scale (external encoder), not its softplus input
 };
 int pv_head_fwd(const PvHead& h, hipStream_t s);
 int pv_fill_tp(float* tp, int B, float angle, float sc, float tx, float ty, hipStream_t s);
@@ -85,6 +86,7 @@ struct PvHeadBwd {
   int B, z_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior, beta;
   int ldh;               // row stride of head / dhead (0: 2*z_dim)
+  int scale_direct;      // 1: head's second half is z_scale itself: dhead's second half = dloss/dz_scale
 };
 int pv_head_bwd(const PvHeadBwd& h, hipStream_t s);
 

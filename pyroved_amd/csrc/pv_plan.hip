@@ -44,6 +44,7 @@ struct Layout {
   float* dhz; float* dtp; float* dzc;
   float* alpha; float* sw; float* llkb;    // jiVAE: class probabilities (B, K), decoder row weights (K*B), ll per (k, b)
   // convolutional encoder (plan->n_enc_ops > 0): activation shapes / buffers, flattened features, gradient ping-pong
+  bool enc_ext;                            // external encoder: (z_loc, z_scale) given, gradients handed back
   bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
   float* ccol; int64_t cF;
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
@@ -68,9 +69,10 @@ bool valid_plan(const pv_ivae_plan* p) {
   if (p->coord_dim < 0 || p->coord_dim > 2) return false;
   if (p->n_enc_ops < 0 || p->n_enc_ops > PV_MAX_OPS) return false;
   if (p->n_enc_ops > 0 && (p->c_dim != 0 || p->discrete_dim != 0 || (p->enc_ndim != 1 && p->enc_ndim != 2))) return false;
-  if (p->n_enc_ops == 0 && (p->n_enc < 1 || p->n_enc > PV_MAX_LAYERS)) return false;
+  if (p->ext_encoder && (p->c_dim != 0 || p->discrete_dim != 0)) return false;
+  if (!p->ext_encoder && p->n_enc_ops == 0 && (p->n_enc < 1 || p->n_enc > PV_MAX_LAYERS)) return false;
   if (p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
-  if (p->discrete_dim < 0 || p->head.out_dim != plan_head_w(p)) return false;
+  if (p->discrete_dim < 0 || (!p->ext_encoder && p->head.out_dim != plan_head_w(p))) return false;
   if (p->discrete_dim > 0 && p->c_dim != 0) return false;                            // jiVAE: no conditioning vector
   if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN && p->lik != PV_LIK_CBERNOULLI) return false;
   if (p->lik != PV_LIK_GAUSSIAN && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
@@ -88,8 +90,9 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   const int64_t R = L.rows;
   L.xin = p->c_dim > 0 ? c.take(B * (N + p->c_dim)) : nullptr;
   int64_t maxe = 0;
-  L.enc_conv = p->n_enc_ops > 0;
-  const int n_enc = L.enc_conv ? 0 : p->n_enc;
+  L.enc_ext = p->ext_encoder != 0;
+  L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
+  const int n_enc = (L.enc_conv || L.enc_ext) ? 0 : p->n_enc;
   pvcs::Needs cnd;
   L.cfeat = L.cg[0] = L.cg[1] = L.ccol = nullptr; L.cF = 0;
   if (L.enc_conv) {
@@ -120,7 +123,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.alpha = K > 0 ? c.take(B * K) : nullptr;
   L.sw = K > 0 ? c.take(S) : nullptr;
   for (int i = 0; i < n_enc; ++i) L.edp[i] = c.take(B * p->enc[i].out_dim);
-  L.enc_compact = !L.enc_conv && pv_enc_compact_supported(p);
+  L.enc_compact = !L.enc_conv && !L.enc_ext && pv_enc_compact_supported(p);
   L.kl_blocks = (int)((B + 15) / 16);
   L.kl_part = c.take(2 * L.kl_blocks);
   int64_t maxd = 0;
@@ -194,10 +197,12 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
     upd(gemm_ws_need(B, p->enc[i].in_dim, p->enc[i].out_dim));
     upd(pv_colsum_ws(B, p->enc[i].out_dim));
   }
-  upd(gemm_ws_need(B, hw, p->head.in_dim));
-  upd(gemm_ws_need(hw, p->head.in_dim, B));
-  upd(gemm_ws_need(B, p->head.in_dim, hw));
-  upd(pv_colsum_ws(B, (int)hw));
+  if (!L.enc_ext) {
+    upd(gemm_ws_need(B, hw, p->head.in_dim));
+    upd(gemm_ws_need(hw, p->head.in_dim, B));
+    upd(gemm_ws_need(B, p->head.in_dim, hw));
+    upd(pv_colsum_ws(B, (int)hw));
+  }
   for (int i = 0; i < p->n_dec; ++i) {
     upd(gemm_ws_need(R, p->dec[i].out_dim, p->dec[i].in_dim));
     upd(gemm_ws_need(p->dec[i].out_dim, p->dec[i].in_dim, R));
@@ -386,6 +391,11 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
   const int64_t wsb = L.scratch_bytes;
   const int ne = p->n_enc;
   const pv_layer& hd = p->head;
+  if (L.enc_ext) {                                   // dhead already sits in the caller's ext_dhead
+    if (fin) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
+    for (int i = 0; i < n_extra; i += 4) PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s));
+    return 0;
+  }
   if (L.enc_conv) {
     // head (features2latent.fc_latent) backward, then the op sequence in reverse; the other small wgrads ride along
     PV_TRY(linear_wgrad(L.dhead, hd.out_dim, L.cfeat, L.cF, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B, L.cF,
@@ -454,10 +464,11 @@ int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, i
   PvHeadBwd hb{};
   hb.dzc = L.dzc; hb.ldzc = lat_in; hb.dtp = L.dtp; hb.dtp_sb = dtp_sb; hb.dtp_sc = dtp_sc;
   hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;
-  hb.head = L.head; hb.dhead = L.dhead; hb.B = p->batch; hb.z_dim = p->z_dim; hb.coord_dim = p->coord_dim;
+  hb.head = L.enc_ext ? p->ext_head : L.head; hb.dhead = L.enc_ext ? p->ext_dhead : L.dhead;
+  hb.scale_direct = L.enc_ext ? 1 : 0; hb.B = p->batch; hb.z_dim = p->z_dim; hb.coord_dim = p->coord_dim;
   hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
   hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
-  hb.ldh = (int)plan_head_w(p);
+  hb.ldh = L.enc_ext ? 0 : (int)plan_head_w(p);
   PV_TRY(pv_head_bwd(hb, s));
   return encoder_bwd(p, L, nullptr, 0, s);
 }
@@ -486,9 +497,9 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     return pv_enc_fwd(e, s);
   }
   if (prep || plan_K(p) > 0) return PV_EINVAL;    // (stand-alone preparation on this path; jiVAE needs the compact encoder)
-  PV_TRY(encoder_fwd(p, L, s));
+  if (!L.enc_ext) PV_TRY(encoder_fwd(p, L, s));
   PvHead h{};
-  h.head = L.head; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
+  h.head = L.enc_ext ? p->ext_head : L.head; h.scale_direct = L.enc_ext ? 1 : 0; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
   h.z_loc_out = p->z_loc; h.z_scale_out = p->z_scale;
   h.tp = p->coord_dim > 0 ? L.tp : nullptr; h.zy = L.zy; h.scalars = p->scalars;
   h.B = p->batch; h.z_dim = p->z_dim; h.c_dim = p->c_dim; h.coord_dim = p->coord_dim;
@@ -560,11 +571,13 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;
   lb.llb = L.llb; lb.dhz = L.dhz; lb.M = R; lb.N = (int)N; lb.kmax = L.f_kmax; lb.H = H; lb.lat_in = (int)lat_in;
   PvHeadBwd& hb = lb.hb;
-  hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps; hb.head = L.head; hb.dhead = L.dhead;
+  hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;
+  hb.head = L.enc_ext ? p->ext_head : L.head; hb.dhead = L.enc_ext ? p->ext_dhead : L.dhead;
+  hb.scale_direct = L.enc_ext ? 1 : 0;
   hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = p->coord_dim;
   hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
   hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
-  hb.ldh = (int)plan_head_w(p);
+  hb.ldh = L.enc_ext ? 0 : (int)plan_head_w(p);
   lb.K = (int)K; lb.alpha = L.alpha; lb.beta_disc = p->beta_disc;
   PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s));
   // the loss scalars ride in the encoder dgrad launch (compact encoder) or get their own
@@ -726,6 +739,7 @@ extern "C" int pv_ivae_uses_fused(const pv_ivae_plan* plan) {
 extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* stream) {
   if (!valid_plan(plan) || !plan->params || !plan->x || !plan->eps || !plan->scalars || !plan->ws) return PV_EINVAL;
   if (want_grads && !plan->grads) return PV_EINVAL;
+  if (plan->ext_encoder && (!plan->ext_head || (want_grads && !plan->ext_dhead))) return PV_EINVAL;
   if (plan->coord_dim > 0 && !plan->grid) return PV_EINVAL;
   Layout L;
   carve(plan, (char*)plan->ws, L);
@@ -742,7 +756,7 @@ extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
 }
 
 extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream) {
-  if (!valid_plan(plan) || !plan->params || !plan->x || !plan->ws || !z_loc || !z_scale) return PV_EINVAL;
+  if (!valid_plan(plan) || plan->ext_encoder || !plan->params || !plan->x || !plan->ws || !z_loc || !z_scale) return PV_EINVAL;
   pv_ivae_plan lay = *plan;
   lay.fused = 0;
   plan = &lay;

@@ -49,6 +49,8 @@ class IVAEEngine:
         self.flat = self.grad = self.m = self.v = None
         self.ws = None
         self.events = (None, None)      # optional raw hipEvent_t pair recorded around the dominant kernel
+        self._enc_opt = None            # torch.optim.Adam of a user-defined encoder's parameters (ext_enc)
+        self._enc_params = []
         self._layout: Dict[str, int] = {}
         self._views: Dict[str, torch.Tensor] = {}
         self._check_model()
@@ -59,7 +61,15 @@ class IVAEEngine:
         m = self.model
         enc, dec = m.encoder_z, m.decoder
         self.conv_enc = isinstance(enc, convEncoderNet)          # iVAE.set_encoder(convEncoderNet(...))
-        if self.conv_enc:
+        # any other user module (models/base.py:173-177: "Sets a user-defined encoder neural network") runs in PyTorch
+        # on the device: its (z_loc, z_scale) outputs enter the HIP step through plan.ext_head, the gradients come back
+        # through plan.ext_dhead and are back-propagated with torch.autograd; its parameters get their own Adam
+        self.ext_enc = not isinstance(enc, (fcEncoderNet, jfcEncoderNet, convEncoderNet))
+        self.K = 0
+        if self.ext_enc:
+            if getattr(m, "c_dim", 0) != 0 or getattr(m, "discrete_dim", 0):
+                raise UnsupportedModel("a user-defined encoder cannot be combined with c_dim / discrete latents here")
+        elif self.conv_enc:
             if tuple(enc.input_dim) != tuple(int(d) for d in m.data_dim) or enc.input_channels != 1:
                 raise UnsupportedModel("conv encoder: input_dim must equal the model's data_dim, one input channel")
             if enc.latent_dim != m.z_dim or getattr(m, "c_dim", 0) != 0:
@@ -69,10 +79,19 @@ class IVAEEngine:
             raise UnsupportedModel("the HIP SVI path needs encoder_z to be pyroved_amd.nets.fcEncoderNet / "
                                    "jfcEncoderNet / convEncoderNet (got %s)" % type(enc).__name__)
         self.K = int(getattr(m, "discrete_dim", 0)) if isinstance(enc, jfcEncoderNet) else 0
+        if self.ext_enc and isinstance(dec, (sDecoderNet, fcDecoderNet)):
+            if len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
+                raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
+            name = m.sampler_d.name
+            if name not in _abi.LIK or (name != "gaussian" and not dec.sigmoid_out):
+                raise UnsupportedModel("decoder sampler %r / sigmoid_d combination is not implemented" % name)
+            if (m.coord > 0) != isinstance(dec, sDecoderNet):
+                raise UnsupportedModel("invariant models need the spatial decoder, vanilla models fcDecoderNet")
+            return
         if not isinstance(dec, (sDecoderNet, fcDecoderNet)):
             raise UnsupportedModel("the HIP SVI path needs decoder to be sDecoderNet or fcDecoderNet "
                                    "(got %s)" % type(dec).__name__)
-        if not enc.softplus_out:
+        if not self.ext_enc and not enc.softplus_out:
             raise UnsupportedModel("encoder without softplus_out is not supported")
         if m.coord > 0 and not isinstance(dec, sDecoderNet):
             raise UnsupportedModel("invariant models need the spatial decoder")
@@ -91,6 +110,8 @@ class IVAEEngine:
         """(key, tensor) in flat-buffer order: state_dict order, except that the heads are merged:
         fc11.weight, fc12.weight[, fc13.weight], then fc11.bias, fc12.bias[, fc13.bias]."""
         named = dict(self.model.named_parameters())
+        if self.ext_enc:                         # only the decoder lives in the flat buffers
+            return [(k, v) for k, v in named.items() if not k.startswith("encoder_z.")]
         if self.conv_enc:
             return list(named.items())           # features2latent.fc_latent already is the merged [mu | sigma] head
         heads = ["fc11", "fc12"] + (["fc13"] if self.K > 0 else [])
@@ -145,10 +166,16 @@ class IVAEEngine:
         self.scalars = self.grad[total:total + N_SCALARS]
         self.grid = self.model.grid.to(dev).contiguous() if self.model.coord > 0 else None
         self.ws = None
+        if self.ext_enc:
+            self._enc_params = [q for q in self.model.encoder_z.parameters() if q.requires_grad]
+            if self._enc_opt is None or [id(q) for q in self._enc_opt.param_groups[0]["params"]] != [id(q) for q in self._enc_params]:
+                self._enc_opt = torch.optim.Adam(self._enc_params, lr=self.lr, betas=self.betas, eps=self.adam_eps)
         self._static = self._static_plan()
 
     def _bound(self) -> bool:
         named = dict(self.model.named_parameters())
+        if self.ext_enc:
+            named = {k: v for k, v in named.items() if not k.startswith("encoder_z.")}
         if len(named) != len(self._views):
             return False
         for k, v in self._views.items():
@@ -208,7 +235,12 @@ class IVAEEngine:
         p.sigmoid_out = int(dec.sigmoid_out)
         p.decoder_sig = m.sampler_d.decoder_sig
         p.fused = int(self.fused)
-        if self.conv_enc:
+        if self.ext_enc:
+            p.n_enc = 0
+            p.discrete_dim = 0
+            p.ext_encoder = 1
+            p.head.in_dim, p.head.out_dim = 1, 2 * m.z_dim
+        elif self.conv_enc:
             p.n_enc = 0
             p.enc_ndim = len(enc.input_dim)
             for i, d in enumerate(enc.input_dim):
@@ -245,7 +277,7 @@ class IVAEEngine:
         else:
             b0 = b1 = float(beta)
         p.beta, p.beta_disc = b0, b1
-        p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = None
+        p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = p.ext_head = p.ext_dhead = None
         p.ev_start, p.ev_stop = self.events
         need = _abi.lib().pv_ivae_workspace_bytes(C.byref(p))
         if need < 0:
@@ -273,6 +305,16 @@ class IVAEEngine:
         self.ensure_bound()
         b = x.shape[0]
         p = self._plan(b, beta)
+        head = dhead = None
+        if self.ext_enc:
+            # the user's encoder in PyTorch on the same stream; its outputs are the step's (z_loc, z_scale)
+            with torch.set_grad_enabled(want_grads):
+                z_loc, z_scale = self.model.encoder_z(x)
+            head = torch.cat([z_loc, z_scale], -1).detach().to(torch.float32).contiguous()
+            if tuple(head.shape) != (b, 2 * p.z_dim):
+                raise ValueError("encoder_z must return (z_loc, z_scale) of shape (batch, %d) each" % p.z_dim)
+            dhead = torch.empty_like(head)
+            p.ext_head, p.ext_dhead = head.data_ptr(), dhead.data_ptr()
         x = self._prep(x, "x", (b, p.n_pix))
         eps = self._prep(eps, "eps", (b, p.z_dim))
         y = self._prep(y, "y", (b, p.c_dim)) if p.c_dim > 0 else None
@@ -291,9 +333,15 @@ class IVAEEngine:
                        "pv_ivae_loss_and_grads")
         finally:
             p.scalars = self.scalars.data_ptr()
+            p.ext_head = p.ext_dhead = None
+        if self.ext_enc and want_grads:
+            zd = p.z_dim
+            for q in self._enc_params:
+                q.grad = None
+            torch.autograd.backward([z_loc, z_scale], [dhead[:, :zd], dhead[:, zd:]])
         if want_grads:
             self.grads_live = True
-        self._keep = (x, eps, y)     # keep inputs alive until the stream has consumed them
+        self._keep = (x, eps, y, head, dhead)     # keep inputs alive until the stream has consumed them
 
     def adam_step(self):
         """pyro.optim.Adam over every parameter + zero_grads (one fused kernel)."""
@@ -302,9 +350,25 @@ class IVAEEngine:
             _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), self.n_flat,
             self.lr, self.betas[0], self.betas[1], self.adam_eps, self.adam_t, _abi.current_stream()),
             "pv_adam_step")
+        if self.ext_enc and any(q.grad is not None for q in self._enc_params):
+            for g_ in self._enc_opt.param_groups:
+                g_["lr"], g_["betas"], g_["eps"] = self.lr, self.betas, self.adam_eps
+            self._enc_opt.step()
+            for q in self._enc_params:               # pyro.infer.util.zero_grads: zero tensors, not None
+                if q.grad is not None:
+                    q.grad = torch.zeros_like(q.grad)
+
+    def extra_grads(self):
+        """Gradient tensors that live outside the flat buffer (a user-defined encoder's): reduced separately in
+        data-parallel runs."""
+        return [q.grad for q in self._enc_params if q.grad is not None] if self.ext_enc else []
 
     def encode(self, x, y=None):
         self.ensure_bound()
+        if self.ext_enc:
+            with torch.no_grad():
+                z_loc, z_scale = self.model.encoder_z(x)
+            return z_loc.to(torch.float32), z_scale.to(torch.float32)
         b = x.shape[0]
         p = self._plan(b)
         x = self._prep(x, "x", (b, p.n_pix))

@@ -132,6 +132,8 @@ class SVItrainer:
                 pvdist.allreduce_sum_(eng.scalars, self.group)
             else:
                 pvdist.allreduce_sum_(eng.grad, self.group)
+                for g_ in (eng.extra_grads() if hasattr(eng, "extra_grads") else []):
+                    pvdist.allreduce_sum_(g_, self.group)        # a user-defined encoder's gradients
         if train or (self.mirror_evaluate_update and eng.grads_live):
             eng.adam_step()
         if not direct:

@@ -468,6 +468,73 @@ def test_convenc_steps_vs_golden_and_oracle(gpu_device, name, fused):
     np.testing.assert_allclose(z_scale.numpy(), zso.numpy(), rtol=1e-4, atol=5e-6)
 
 
+class _UserEncoder(torch.nn.Module):
+    """A user-defined encoder in the sense of iVAE.set_encoder (models/base.py:173-177): any module that maps the
+    batch to (z_loc, z_scale).  Deliberately unlike the built-in ones (a 1x1-free conv + pooling + GELU MLP)."""
+    def __init__(self, data_dim, z_dim):
+        super().__init__()
+        self.data_dim = data_dim
+        self.conv = torch.nn.Conv2d(1, 3, 5, padding=2)
+        self.fc = torch.nn.Linear(3 * (data_dim[0] // 2) * (data_dim[1] // 2), 24)
+        self.mu = torch.nn.Linear(24, z_dim)
+        self.sig = torch.nn.Linear(24, z_dim)
+
+    def forward(self, x):
+        h = torch.nn.functional.avg_pool2d(torch.nn.functional.gelu(self.conv(x.reshape(-1, 1, *self.data_dim))), 2)
+        h = torch.tanh(self.fc(h.flatten(1)))
+        return self.mu(h), torch.nn.functional.softplus(self.sig(h)) + 1e-3
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("inv", [["r", "t", "s"], None])
+def test_user_defined_encoder(gpu_device, inv, fused):
+    """iVAE.set_encoder(user module): the module runs in PyTorch on the device, the rest of the SVI step in the HIP
+    library (plan.ext_head / ext_dhead); loss, decoder gradients, the module's own gradients and both Adam updates
+    against the oracle with the same module on the CPU."""
+    data_dim, b = (8, 8), 6
+    torch.manual_seed(5)
+    model = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+    user = _UserEncoder(data_dim, model.z_dim)
+    ref = _UserEncoder(data_dim, model.z_dim)
+    ref.load_state_dict(user.state_dict())
+    model.set_encoder(user)
+    eng = model.engine(fused=fused)
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, custom_encoder=ref)
+    dec_params = {k: v.cpu() for k, v in model.state_dict().items() if not k.startswith("encoder_z.")}
+    o = orc.SVIOracle(dec_params, cfg)
+    ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(b, *data_dim, generator=g)
+    for k in range(3):
+        eps = torch.randn(b, model.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), 1.3)
+        ref_opt.zero_grad()
+        o.step(x, eps, 1.3)
+        np.testing.assert_allclose(eng.scalars[0].item(), o.last["loss"].item(), rtol=RTOL_ELBO)
+        for key in o.p:
+            if key == "decoder.out.bias":
+                continue
+            assert rel_l2(eng.grad_of(key), o.last_grads[key]) < RTOL_GRAD, key
+        for (n, pu), pr in zip(user.named_parameters(), ref.parameters()):
+            assert rel_l2(pu.grad, pr.grad) < 2e-4, "encoder %s" % n
+        eng.adam_step()
+        ref_opt.step()
+        for (n, pu), pr in zip(user.named_parameters(), ref.parameters()):
+            assert rel_l2(pu.detach(), pr.detach()) < 1e-4, "encoder %s after Adam" % n
+            assert pu.grad is not None and float(pu.grad.abs().sum()) == 0.0        # zero_grads semantics
+        model.load_state_dict({**{k_: v_.detach() for k_, v_ in o.p.items()},
+                               **{"encoder_z." + k_: v_ for k_, v_ in ref.state_dict().items()}})
+    z_loc, z_scale = model.encode(x)
+    with torch.no_grad():
+        zl, zs = ref(x)
+    np.testing.assert_allclose(z_loc.numpy(), zl.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(z_scale.numpy(), zs.numpy(), rtol=1e-4, atol=1e-5)
+    # trainer epochs run through the same path
+    tr = pv.trainers.SVItrainer(model, seed=1)
+    tr.step(pv.utils.init_dataloader(x, batch_size=4))
+    assert np.isfinite(tr.loss_history["training_loss"][0])
+
+
 @pytest.mark.parametrize("name", EPOCH_CASES)
 def test_trainer_epochs_vs_golden(gpu_device, name):
     """The product's SVItrainer driven exactly like the reference's (same DataLoader, same seeds):
