@@ -18,35 +18,36 @@
 #define GK 16      // k per stage
 #define GLD 66     // LDS row stride (floats)
 
-// implicit im2col: element (row = (b, y, x), j = ci*KK + tap) of the never-materialised patch matrix
+// implicit im2col: element (row = (b, y, x), j = ci*KK + tap) of the never-materialised patch matrix.  The two
+// halves of the address are decoded separately so that whichever is fixed for a thread over the whole k-loop (the
+// patch row in the forward, the patch column in the wgrad) is decoded once per tile.
 struct ConvGeom { int H, W, C, nd; };
-__device__ __forceinline__ float g_im2col(const float* __restrict__ in, const ConvGeom& cg, int64_t row, int j) {
+struct ConvRow { int64_t base; int y, x; bool ok; };        // base = ((b*H + y)*W + x)*C
+struct ConvCol { int off, dy, dx; bool ok; };               // off = (dy*W + dx)*C + ci
+__device__ __forceinline__ ConvRow g_conv_row(const ConvGeom& cg, int64_t row, bool ok) {
+  ConvRow r;
+  r.x = (int)(row % cg.W);
+  const int64_t ry = row / cg.W;
+  r.y = (int)(ry % cg.H);
+  r.base = row * cg.C;
+  r.ok = ok;
+  return r;
+}
+__device__ __forceinline__ ConvCol g_conv_col(const ConvGeom& cg, int j, bool ok) {
   const int KK = cg.nd == 2 ? 9 : 3;
   const int ci = j / KK, t = j - ci * KK;
-  const int x = (int)(row % cg.W);
-  const int64_t ry = row / cg.W;
-  const int y = (int)(ry % cg.H);
-  const int64_t b = ry / cg.H;
-  const int yy = y + (cg.nd == 2 ? t / 3 : t) - 1, xx = cg.nd == 2 ? x + t % 3 - 1 : x;
-  if (yy < 0 || yy >= cg.H || xx < 0 || xx >= cg.W) return 0.0f;
-  return in[((b * cg.H + yy) * cg.W + xx) * cg.C + ci];
+  ConvCol c;
+  c.dy = (cg.nd == 2 ? t / 3 : t) - 1;
+  c.dx = cg.nd == 2 ? t % 3 - 1 : 0;
+  c.off = (c.dy * cg.W + c.dx) * cg.C + ci;
+  c.ok = ok;
+  return c;
 }
-
-// conv-mode tile loads: same (x, k) thread mapping as g_load; `rows_on_x`: the patch-matrix row is the tile's x index
-template <bool KCONTIG>
-__device__ __forceinline__ void g_load_conv(const float* __restrict__ P, const ConvGeom& cg, bool rows_on_x, int x0,
-                                            int xlim, int k0, int klim, int t, float (&r)[4]) {
-  if (KCONTIG) {
-    const int x = x0 + (t >> 2), k = k0 + (t & 3) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      r[i] = (x < xlim && k + i < klim) ? (rows_on_x ? g_im2col(P, cg, x, k + i) : g_im2col(P, cg, k + i, x)) : 0.0f;
-  } else {
-    const int k = k0 + (t >> 4), x = x0 + (t & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      r[i] = (k < klim && x + i < xlim) ? (rows_on_x ? g_im2col(P, cg, x + i, k) : g_im2col(P, cg, k, x + i)) : 0.0f;
-  }
+__device__ __forceinline__ float g_conv_at(const float* __restrict__ in, const ConvGeom& cg, const ConvRow& r,
+                                           const ConvCol& c) {
+  const int yy = r.y + c.dy, xx = r.x + c.dx;
+  if (!r.ok || !c.ok || yy < 0 || yy >= cg.H || xx < 0 || xx >= cg.W) return 0.0f;
+  return in[r.base + c.off];
 }
 
 template <bool KCONTIG>   // true: the k index is the contiguous one in global memory
@@ -114,13 +115,33 @@ __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], floa
 
   float ra[4], rb[4];
   const ConvGeom cg{g.cH, g.cW, g.cC, g.cnd};
+  // conv operands: A (forward / dgrad-as-convolution): thread = (row m0 + t/4 fixed, 4 consecutive patch columns per
+  // k-step); B (wgrad): thread = (4 consecutive patch columns n0 + 4*(t%16).. fixed, one patch row per k-step)
+  ConvRow arow{};
+  ConvCol bcol[4] = {};
+  if (CA) arow = g_conv_row(cg, m0 + (t >> 2), m0 + (t >> 2) < g.M);
+  if (CB) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bcol[i] = g_conv_col(cg, n0 + (t & 15) * 4 + i, n0 + (t & 15) * 4 + i < g.N);
+  }
   auto load_a = [&](int k0) {
-    if (CA) g_load_conv<AK>(g.A, cg, true, m0, g.M, k0, kend, t, ra);              // A(m, k): row = m, j = k
-    else g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, k0, kend, p.a_vec, t, ra);
+    if (CA) {
+      const int k = k0 + (t & 3) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = g_conv_at(g.A, cg, arow, g_conv_col(cg, k + i, k + i < kend));
+    } else {
+      g_load<AK>(g.A, g.a_rs, g.a_cs, m0, g.M, k0, kend, p.a_vec, t, ra);
+    }
   };
   auto load_b = [&](int k0) {
-    if (CB) g_load_conv<BK>(g.B, cg, false, n0, g.N, k0, kend, t, rb);             // B(k, n): row = k, j = n
-    else g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, k0, kend, p.b_vec, t, rb);
+    if (CB) {
+      const int k = k0 + (t >> 4);
+      const ConvRow br = g_conv_row(cg, k, k < kend);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = g_conv_at(g.B, cg, br, bcol[i]);
+    } else {
+      g_load<BK>(g.B, g.b_cs, g.b_rs, n0, g.N, k0, kend, p.b_vec, t, rb);
+    }
   };
   if (kbeg < kend) { load_a(kbeg); load_b(kbeg); }
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
