@@ -205,8 +205,17 @@ __global__ __launch_bounds__(256) void pv_gemm_finish_kernel(GemmK p, int splits
   const int64_t total = (int64_t)g.M * g.N;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int m = (int)(e / g.N), n = (int)(e % g.N);
-    float v = 0.0f;
-    for (int z = 0; z < splits; ++z) v += p.part[(int64_t)z * total + e];
+    // ascending split order (deterministic); four independent chains keep 8+ loads in flight per thread
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    int z = 0;
+    for (; z + 3 < splits; z += 4) {
+      v0 += p.part[(int64_t)z * total + e];
+      v1 += p.part[(int64_t)(z + 1) * total + e];
+      v2 += p.part[(int64_t)(z + 2) * total + e];
+      v3 += p.part[(int64_t)(z + 3) * total + e];
+    }
+    for (; z < splits; ++z) v0 += p.part[(int64_t)z * total + e];
+    float v = (v0 + v1) + (v2 + v3);
     if (g.bias) v += g.bias[n];
     if (g.pre) g.pre[(int64_t)m * g.ldc + n] = v;
     v = pv_act_fwd(v, g.act);
