@@ -146,6 +146,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       const int64_t units = R / FD_UNIT;
       L.f_grid = pv_sdec_fused_grid(units);
       L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
+      if (p->fused == 2) L.f_kmax *= 4;             // the bf16x3 kernel publishes dL/d(hz) per wave (4 per workgroup)
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
       L.f_part_hz = c.take(S * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);

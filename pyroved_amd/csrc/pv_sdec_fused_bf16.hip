@@ -52,10 +52,10 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define GAP_BYTES (4 * ST_BYTES - 2 * IMG_BYTES)      // 8192
 #define BO_R2 (BO_GAP + GAP_BYTES)
 #define BO_VEC (BO_R2 + 2 * IMG_BYTES)     // fp32 vectors: Wc0, Wc1, bc, wo, b1, b2 (128 each)
-#define BO_INFO (BO_VEC + 6 * FD_H * 4)    // x0[64], x1[64], sample index of the 4 units
+#define BO_INFO (BO_VEC + 6 * FD_H * 4)    // x0[64], x1[64] of the tile's rows (each wave its own 16)
 #define BO_RED (BO_INFO + 768)
-#define BO_DWO (BO_RED + 256)              // per-wave d(wo) partial sums: FB_WAVES x 128 floats
-#define BO_CHZ (BO_DWO + FB_WAVES * FD_H * 4)   // next tile's per-unit inputs, fetched by LDS-DMA a tile ahead:
+#define BO_DWO (BO_RED + 256)              // per-wave column sums: FB_WAVES x [d(wo) | dhz | dWc0 | dWc1] x 128 floats
+#define BO_CHZ (BO_DWO + FB_WAVES * 4 * FD_H * 4)   // next tile's per-unit inputs, fetched by LDS-DMA a tile ahead:
 #define BO_CTP (BO_CHZ + FB_WAVES * FD_H * 4)   //   hz[b] (128 floats), tp[b] (8 of 64 floats), grid rows (16*cd of 64)
 #define BO_CGR (BO_CTP + FB_WAVES * 256)
 #define FB_LDS_BYTES (BO_CGR + FB_WAVES * 256)
@@ -346,13 +346,53 @@ __device__ __forceinline__ float fb_sum_r(float v) {
   return v;
 }
 
+// Column sums over a unit's 16 rows of a C/D-layout tensor v (lane (r, q): row r, columns 16*jb + 4q + i), optionally
+// also weighted by two per-row scalars: wave-local transpose through LDS.  The wave writes its 16 x 128 fp32 tile
+// into `tmp` (its OWN 16 rows of two adjacent staging arrays: 72 + 72 floats per row, which it is about to overwrite
+// with its staging anyway), then lane l sums columns 2l, 2l+1 over the rows and adds them into its accumulator slots
+// (one owner per address: plain read-modify-write).  No workgroup barrier, no cross-lane VALU.
+template <bool WEIGHTED>
+__device__ __forceinline__ void fb_colsum(const f32x4 (&v)[8], float* __restrict__ tmp /* &arrA[16*wave][0] */,
+                                          float* __restrict__ acc0, float* __restrict__ acc1, float* __restrict__ acc2,
+                                          const float* __restrict__ w1, const float* __restrict__ w2, int lane, int r,
+                                          int q) {
+  // row r: columns 0..63 at tmp[r*72 ..], columns 64..127 at tmp[ST_ARR/2 .. ] (the next array's same row; float units)
+  constexpr int HALF = ST_ARR / 2;                       // one bf16 staging array, in floats
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    float* p = tmp + (jb < 4 ? 0 : HALF) + r * (LDS2 / 2) + 16 * (jb & 3) + 4 * q;
+    *reinterpret_cast<f32x4*>(p) = v[jb];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own stores have landed
+  const float* c = tmp + (lane < 32 ? 0 : HALF) + 2 * (lane & 31);
+  float s0 = 0.0f, s1 = 0.0f, a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const float2 x = *reinterpret_cast<const float2*>(c + rr * (LDS2 / 2));
+    s0 += x.x; s1 += x.y;
+    if (WEIGHTED) {
+      const float u = w1[rr], t = w2[rr];
+      a0 += x.x * u; a1 += x.y * u;
+      b0 += x.x * t; b1 += x.y * t;
+    }
+  }
+  float2* d0 = reinterpret_cast<float2*>(acc0 + 2 * lane);
+  *d0 = float2{d0->x + s0, d0->y + s1};
+  if (WEIGHTED) {
+    float2* d1 = reinterpret_cast<float2*>(acc1 + 2 * lane);
+    float2* d2 = reinterpret_cast<float2*>(acc2 + 2 * lane);
+    *d1 = float2{d1->x + a0, d1->y + a1};
+    *d2 = float2{d2->x + b0, d2->y + b1};
+  }
+}
+
 // phase-timing trace (profiling only, enabled by PV_FD_ABLATE bit 256): shader-clock stamps of workgroup 0 /
 // wave 0 for its first tiles; read back with pv_debug_read_trace()
 __device__ long long fb_trace[256];
 #define FB_STAMP(k)                                                                        \
   do {                                                                                     \
     if ((f.ablate & 256) && g == 0 && tid == 0 && tile_no < 4)                             \
-      fb_trace[tile_no * 16 + (k)] = (long long)__builtin_readcyclecounter();              \
+      fb_trace[tile_no * 32 + (k)] = (long long)__builtin_readcyclecounter();              \
   } while (0)
 
 // stand-alone form of the per-step preparation (pv_fb_layout.h); the SVI step runs it inside the encoder's
@@ -404,33 +444,29 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) { accW1[s][kb] = f32x4{0, 0, 0, 0}; accW2[s][kb] = f32x4{0, 0, 0, 0}; }
   }
-  // coordinate layer: column 0 = sum over the current sample's rows of dpre0 (= dL/d(hz[b]), flushed per sample),
-  // column 1 / 2 = sums of dpre0 * x'_0 / x'_1 (dWc), for rows 16*(2*wave + s) + 4q + i
-  f32x4 accC[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
   float dbo = 0.0f;
-  int cur_b = -1;
+  int cur_b = -1;                                    // the sample whose dL/d(hz) this WAVE is accumulating
   const int upb = f.N / FD_UNIT;
   float* rec = f.part + (int64_t)g * FD_REC;
   // this wave's private d(wo) slot in LDS: written and re-read only by lanes (r == 0, q) — one thread per
   // address, so plain same-thread ordering suffices
-  float* dwo_g = reinterpret_cast<float*>(smb + BO_DWO) + wave * FD_H;
-  if (r == 0) {
+  // this wave's column-sum accumulators in LDS (lane l owns columns 2l, 2l+1 of each): d(wo), dL/d(hz[cur_b]) (flushed
+  // when the wave's sample changes), dWc0, dWc1
+  float* dwo_g = reinterpret_cast<float*>(smb + BO_DWO) + wave * 4 * FD_H;
+  float* dhz_g = dwo_g + FD_H;
+  float* dwc0_g = dwo_g + 2 * FD_H;
+  float* dwc1_g = dwo_g + 3 * FD_H;
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<f32x4*>(dwo_g + 16 * jb + 4 * q) = f32x4{0, 0, 0, 0};
-  }
+  for (int a = 0; a < 4; ++a) *reinterpret_cast<float2*>(dwo_g + a * FD_H + 2 * lane) = float2{0.0f, 0.0f};
 
   auto flush_hz = [&](int b) {
-    // sample b's rows end (or the workgroup's do): publish this workgroup's partial dL/d(hz[b])
+    // the wave's rows of sample b end (or the workgroup's do): publish its partial dL/d(hz[b]) in its own slot
+    // (kmax counts FB_WAVES slots per workgroup that can touch a sample; unused slots stay zero)
     const int64_t ub = (int64_t)b * upb;
     const int gfirst = (int)(((ub + 1) * G + f.units - 1) / f.units) - 1;
-    if (r == 0) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        *reinterpret_cast<f32x4*>(f.part_hz + ((int64_t)b * f.kmax + (g - gfirst)) * FD_H + 16 * (2 * wave + s) + 4 * q) =
-            accC[s];
-        accC[s] = f32x4{0, 0, 0, 0};
-      }
-    }
+    float2* acc = reinterpret_cast<float2*>(dhz_g + 2 * lane);
+    *reinterpret_cast<float2*>(f.part_hz + ((int64_t)b * f.kmax + (g - gfirst) * FB_WAVES + wave) * FD_H + 2 * lane) = *acc;
+    *acc = float2{0.0f, 0.0f};
   };
 
   const int64_t u_lo = (int64_t)g * f.units / G, u_hi = (int64_t)(g + 1) * f.units / G;
@@ -537,7 +573,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     float dlda = 0.0f;
     if (act) {
       fb_layer_fwd(W2h, W2l, b2s, pBh, pBl, tC, r, q);
+      FB_STAMP(16);
       fb_tanh8(tC);                                              // tC = h2
+      FB_STAMP(17);
       // ---- output layer + likelihood (fp32) ----
       float part = 0.0f;
 #pragma unroll
@@ -565,6 +603,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
         locv = pr;
       }
+      FB_STAMP(18);
       dlda *= swv;
       if (q == 0) {
         f.llrow[row] = ll;
@@ -573,22 +612,23 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       xv_next = x_of_tile(ut + TILE_UNITS);     // lands long before the next LDS-DMA issue point drains loads
       if (GRADS) {
         if (q == 0) dbo += dlda;
+        {
+          // d(wo)[j] += sum_rows dlda * h2[row][j]: W1's images are dead since the barrier above (the wgrad-2 staging
+          // goes there next), so the wave's own staging rows serve as the transpose buffer
+          f32x4 pv_[8];
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-          f32x4 tv;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) tv[i] = fb_sum_r(dlda * tC[jb][i]);
-          if (r == 0) {
-            f32x4* p = reinterpret_cast<f32x4*>(dwo_g + 16 * jb + 4 * q);
-            *p = *p + tv;
-          }
+          for (int jb = 0; jb < 8; ++jb) pv_[jb] = dlda * tC[jb];
+          fb_colsum<false>(pv_, reinterpret_cast<float*>(st2) + (16 * wave) * (LDS2 / 2), dwo_g, nullptr, nullptr, nullptr,
+                           nullptr, lane, r, q);
         }
+        FB_STAMP(19);
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * jb + 4 * q);
 #pragma unroll
           for (int i = 0; i < 4; ++i) tC[jb][i] = dlda * wv[i] * (1.0f - tC[jb][i] * tC[jb][i]);  // dpre2
         }
+        FB_STAMP(20);
         fb_presplit(tC, pAh, pAl);                               // feeds the wgrad and the dgrad of layer 2
       }
     }
@@ -619,6 +659,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     if (act) {
       fb_layer_dgrad(W1h, W1l, pAh, pAl, tC, r, q);
       fb_mul_dtanh(tC, h0);                                      // tC = dpre0
+      // ---- coordinate layer, cross-row part: dhz[b] = sum_rows dpre0, dWc_k = sum_rows dpre0 * x'_k.  Wave-local
+      // (the unit's rows all belong to this wave and to one sample): W2's images are dead since the barrier above, so
+      // the wave's own rows of the wgrad-1 staging area serve as the transpose buffer.  No workgroup barrier.
+      if (bu != cur_b) {
+        if (cur_b >= 0) flush_hz(cur_b);
+        cur_b = bu;
+      }
+      if (q == 0) { info[16 * wave + r] = x0; info[TILE_ROWS + 16 * wave + r] = x1; }
+      fb_colsum<true>(tC, reinterpret_cast<float*>(st1) + (16 * wave) * (LDS2 / 2), dhz_g, dwc0_g, dwc1_g,
+                      info + 16 * wave, info + TILE_ROWS + 16 * wave, lane, r, q);
       fb_presplit(h0, pBh, pBl);
     }
     FB_STAMP(9);
@@ -628,6 +678,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     __syncthreads();
     FB_STAMP(10);
     fb_wgrad_consume(st1, accW1, accB1, wave, r, q, ksteps);
+    FB_STAMP(21);
     // ---- coordinate layer backward (fp32): row-local part ----
     if (act) {
       float d0 = 0.0f, d1 = 0.0f;
@@ -647,82 +698,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         f.rowtp[3 * f.M + row] = d1;
       }
     }
-    __syncthreads();
-    FB_STAMP(11);
-    // ---- cross-row part: dhz / dWc are wgrads too: [dpre0]^T [1 | x'_0 | x'_1] over the tile's rows.  dpre0 goes
-    // through the staging area's A arrays (split, swizzled); the 16-column B operand is built in registers.
-    if (act) fb_presplit(tC, pAh, pAl);
-    fb_stage_store(st1, st1 + ST_ARR, pAh, pAl, 16 * wave + r, q);
-    if (act) {
-      if (q == 0) { info[16 * wave + r] = x0; info[TILE_ROWS + 16 * wave + r] = x1; }
-      if (lane == 0) reinterpret_cast<int*>(info)[2 * TILE_ROWS + wave] = bu;
-    }
-    __syncthreads();
-    FB_STAMP(12);
-    {
-      const int toff = fb_stage_toff(r | fb_opaque0(), q);
-      bf16x8 a_h[2][2], a_l[2][2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int off = toff + 32 * ks * LDS2 + 16 * (2 * wave + s);
-          a_h[ks][s] = fb_cat(fb_tr(st1 + off), fb_tr(st1 + off + 16 * LDS2));
-          a_l[ks][s] = fb_cat(fb_tr(st1 + ST_ARR + off), fb_tr(st1 + ST_ARR + off + 16 * LDS2));
-        }
-      // lane (column c = r, q) feeds rows 32ks + {4q.., 16+4q..}: c = 0 -> 1, c = 1 -> x'_0, c = 2 -> x'_1, else 0
-      f32x4 cv[2][2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const int rr = 32 * ks + 16 * hf + 4 * q;
-          const f32x4 xa = *reinterpret_cast<const f32x4*>(info + rr);
-          const f32x4 xb = *reinterpret_cast<const f32x4*>(info + TILE_ROWS + rr);
-          const f32x4 one4 = {1.0f, 1.0f, 1.0f, 1.0f}, zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-          cv[ks][hf] = r == 0 ? one4 : r == 1 ? xa : r == 2 ? xb : zero4;
-        }
-      // one pass per run of units that belong to the same sample (one run unless a sample ends inside the tile)
-      const int4_ bus = *reinterpret_cast<const int4_*>(reinterpret_cast<const int*>(info) + 2 * TILE_ROWS);
-      int bs[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bs[c] = __builtin_amdgcn_readfirstlane(bus[c]);
-      int c0 = 0;
-      while (c0 < nact) {
-        const int bseg = bs[0] * (c0 == 0) + bs[1] * (c0 == 1) + bs[2] * (c0 == 2) + bs[3] * (c0 == 3);
-        int c1 = c0 + 1;
-#pragma unroll
-        for (int c = 1; c < 4; ++c)
-          if (c == c1 && c < nact && bs[c] == bseg) ++c1;
-        if (bseg != cur_b) {
-          if (cur_b >= 0) flush_hz(cur_b);
-          cur_b = bseg;
-        }
-        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        bf16x8 bh[2], bl[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bool in0 = 2 * ks >= c0 && 2 * ks < c1, in1 = 2 * ks + 1 >= c0 && 2 * ks + 1 < c1;
-          fb_split8(in0 ? cv[ks][0] : zero4, in1 ? cv[ks][1] : zero4, bh[ks], bl[ks]);
-        }
-        f32x4 t[2][2];                               // four independent chains; rows outside the run are zero in B
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) t[ks][s] = MFMA32(a_h[ks][s], bh[ks], zero4);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) t[ks][s] = MFMA32(a_h[ks][s], bl[ks], t[ks][s]);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) t[ks][s] = MFMA32(a_l[ks][s], bh[ks], t[ks][s]);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) accC[s] += t[0][s] + t[1][s];
-        c0 = c1;
-      }
-    }
+    FB_STAMP(22);
     __syncthreads();        // the staging area is free again (the next tile's W2 reload lands here)
     FB_STAMP(13);
   }
@@ -748,20 +724,23 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         rec[2 * FD_H * FD_H + FD_H + j0 + 4 * q + i] = accB2[s][i];
       }
     }
-    if (r == 1 || r == 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rec[2 * FD_H * FD_H + (1 + r) * FD_H + j0 + 4 * q + i] = accC[s][i];
-    }
   }
   const float tb = pv_wave_sum(dbo);
   if (lane == 0) red[wave] = tb;
   __syncthreads();
   if (tid < FD_H) {
+    // per-wave column sums -> the record (waves in ascending order): dWc0 | dWc1 | dwo
     const float* d = reinterpret_cast<const float*>(smb + BO_DWO);
-    float v = 0.0f;
+    float vo = 0.0f, v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
-    for (int w = 0; w < FB_WAVES; ++w) v += d[w * FD_H + tid];
-    rec[2 * FD_H * FD_H + 4 * FD_H + tid] = v;
+    for (int w = 0; w < FB_WAVES; ++w) {
+      vo += d[(4 * w + 0) * FD_H + tid];
+      v0 += d[(4 * w + 2) * FD_H + tid];
+      v1 += d[(4 * w + 3) * FD_H + tid];
+    }
+    rec[2 * FD_H * FD_H + 2 * FD_H + tid] = v0;
+    rec[2 * FD_H * FD_H + 3 * FD_H + tid] = v1;
+    rec[2 * FD_H * FD_H + 4 * FD_H + tid] = vo;
   }
   if (tid == 0) {
     float v = 0.0f;

@@ -19,8 +19,16 @@ print("rc", lib.pv_debug_read_trace(buf, 64))
 names = ["start", "coord+split", "fwd L1+tanh+split", "W2 wait+bar", "fwd L2..lik+dpre2", "stage L2+bar", "wgrad L2+bar",
          "dgrad L2+split", "W1 wait+bar", "dgrad L1+split", "stage L1+bar", "wgrad L1+rowlocal+bar", "split+stage dpre0+bar",
          "coord sums (MFMA)+bar"]
+buf = (C.c_longlong * 128)()
+lib.pv_debug_read_trace(buf, 128)
+sub = {16: "fwdL2 mfma", 17: "tanh8", 18: "logit+lik", 19: "dwo", 20: "dpre2", 21: "wgrad L1 consume", 22: "rowlocal"}
 for t in range(4):
-    st = [buf[t * 16 + k] for k in range(14)]
+    st = [buf[t * 32 + k] for k in range(14)]
+    fine = {k: buf[t * 32 + k] for k in sub}
+    if st[0]:
+        seq = [3, 16, 17, 18, 19, 20, 4]
+        print("  tile", t, "fwdL2..dpre2 detail:", " ".join("%s=%d" % (sub.get(b, "presplit"), (fine.get(b) or st[b]) - (fine.get(a) or st[a])) for a, b in zip(seq, seq[1:])),
+              "| tail: consume=%d rowlocal=%d bar=%d" % (fine[21] - st[10], fine[22] - fine[21], st[11] - fine[22]))
     if st[0] == 0: continue
     prev = st[0]; out = []
     for k in range(1, 14):
