@@ -366,12 +366,20 @@ __device__ __forceinline__ void fb_colsum(const f32x4 (&v)[8], float* __restrict
   __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own stores have landed
   const float* c = tmp + (lane < 32 ? 0 : HALF) + 2 * (lane & 31);
   float s0 = 0.0f, s1 = 0.0f, a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+  f32x4 wv1[4], wv2[4];                                  // the 16 rows' weights: 8 broadcast ds_read_b128
+  if (WEIGHTED) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      wv1[k] = *reinterpret_cast<const f32x4*>(w1 + 4 * k);
+      wv2[k] = *reinterpret_cast<const f32x4*>(w2 + 4 * k);
+    }
+  }
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     const float2 x = *reinterpret_cast<const float2*>(c + rr * (LDS2 / 2));
     s0 += x.x; s1 += x.y;
     if (WEIGHTED) {
-      const float u = w1[rr], t = w2[rr];
+      const float u = wv1[rr >> 2][rr & 3], t = wv2[rr >> 2][rr & 3];
       a0 += x.x * u; a1 += x.y * u;
       b0 += x.x * t; b1 += x.y * t;
     }
