@@ -16,12 +16,13 @@
 //     exchanges (dpre, h) through LDS for the wgrad;
 //   * per-workgroup partial gradients are reduced in a fixed order afterwards (no float atomics).
 // What the bf16 split changes:
-//   * weights live in LDS as bf16 hi and lo images, row-major [128][136] with permuted columns (fb_pcol); the
+//   * weights live in LDS as bf16 hi and lo images, row-major [128][128] with permuted columns and XOR-swizzled
+//     16-byte chunks (pv_fb_layout.h); the
 //     forward reads a lane's A operand with one ds_read_b128, the dgrad reads the TRANSPOSED operand from the same
 //     image with ds_read_b64_tr_b16 (hardware 4x16 transpose), so one image serves both orientations;
 //   * activations are split to (hi, lo) once per tensor (3 VALU per element) and the split feeds both the next
 //     contraction and the wgrad exchange;
-//   * LDS OVERLAY.  The two layers' weight images fill 136 of the 160 KB, which leaves no room to stage a whole
+//   * LDS OVERLAY.  The two layers' weight images fill 128 of the 160 KB, which leaves no room to stage a whole
 //     tile's (dpre, h) for the wgrad.  So the staging area of layer 2's wgrad lies OVER W1's images (idle between
 //     the forward of layer 1 and the dgrad of layer 1) and that of layer 1's wgrad and of the coordinate layer's
 //     reductions OVER W2's images (idle from the dgrad of layer 2 to the next tile's forward of layer 2); the
@@ -29,7 +30,9 @@
 //     pre-split global copy made once per step (pv_fb_prep_kernel), under the dgrad of layer 2 resp. the next
 //     tile's coordinate layer + forward of layer 1.  One staging pass per layer then covers all 64 rows: the
 //     wgrad contracts 32 rows per v_mfma_f32_16x16x32_bf16 (operands by ds_read_b64_tr_b16; bias gradients ride
-//     along as an MFMA against ones) and a tile needs 8 workgroup barriers instead of 24.
+//     along as an MFMA against ones) and a tile needs 6 workgroup barriers instead of 24;
+//   * column sums that need no other wave's rows (d(wo), and dhz / dWc of the coordinate layer) are wave-local
+//     transposes through the wave's own rows of whichever staging area is dead at that moment (fb_colsum).
 #include "pv_sdec_fused.h"
 #include "pv_fb_layout.h"
 #include <stdlib.h>
@@ -84,16 +87,6 @@ __device__ __forceinline__ float fb_tanh(float x) {
 __device__ __forceinline__ float fb_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float fb_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float fb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-// two D-layout blocks (4 + 4 consecutive k of this lane) -> the lane's 8-element hi / lo operands
-__device__ __forceinline__ void fb_split8(const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    __bf16 h, l;
-    fb_split(u[i], h, l); hi[i] = h; lo[i] = l;
-    fb_split(v[i], h, l); hi[4 + i] = h; lo[4 + i] = l;
-  }
-}
 
 __device__ __forceinline__ bf16x8 fb_cat(const bf16x4& a, const bf16x4& b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -333,19 +326,6 @@ __device__ __forceinline__ float fb_sum_q(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
-// sum over the 16 lanes of a DPP row (= one q group), result in every lane: quad swaps, then the two mirrors
-template <int CTRL>
-__device__ __forceinline__ float fb_dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float fb_sum_r(float v) {
-  v += fb_dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += fb_dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += fb_dpp_mov<0x141>(v);     // row_half_mirror
-  v += fb_dpp_mov<0x140>(v);     // row_mirror
-  return v;
-}
-
 // Column sums over a unit's 16 rows of a C/D-layout tensor v (lane (r, q): row r, columns 16*jb + 4q + i), optionally
 // also weighted by two per-row scalars: wave-local transpose through LDS.  The wave writes its 16 x 128 fp32 tile
 // into `tmp` (its OWN 16 rows of two adjacent staging arrays: 72 + 72 floats per row, which it is about to overwrite
