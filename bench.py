@@ -43,7 +43,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the guide's
 # gfx950 correction + WRITE_SIZE, KiB -> bytes), batch 256: see profiles/r01*_pmc_*.txt.  None: not collected.
-TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1371 * 1024 + 37649 * 1024}   # 2: profiles/r01f_pmc_*
+TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1342 * 1024 + 37943 * 1024}   # 2: profiles/r01g_pmc_*
 
 
 def decoder_flops_per_image(n_pix, hidden=128, coord_dim=2):

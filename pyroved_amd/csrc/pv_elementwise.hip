@@ -582,8 +582,16 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
 #pragma unroll
     for (int c = 0; c < 4; ++c) tp_acc[c] += a[1 + c];
     for (int j = t; j < p.H; j += 256) {
-      float v = 0.0f;
-      for (int kk = 0; kk < p.kmax; ++kk) v += p.part_hz[(s * p.kmax + kk) * p.H + j];
+      // ascending slot order (fixed); four independent chains keep the loads in flight
+      const float* ph = p.part_hz + (s * p.kmax) * p.H + j;
+      float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+      int kk = 0;
+      for (; kk + 3 < p.kmax; kk += 4) {
+        v0 += ph[(int64_t)kk * p.H]; v1 += ph[(int64_t)(kk + 1) * p.H];
+        v2 += ph[(int64_t)(kk + 2) * p.H]; v3 += ph[(int64_t)(kk + 3) * p.H];
+      }
+      for (; kk < p.kmax; ++kk) v0 += ph[(int64_t)kk * p.H];
+      const float v = (v0 + v1) + (v2 + v3);
       p.dhz[s * p.H + j] = v;
       sh_dhz[j] += v;                                  // the same thread owns j in every pass
     }
