@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "2")),
-                    help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3")
+                    help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3 (fp32-class), 3 fused plain bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     args = ap.parse_args()
@@ -212,6 +212,10 @@ def main():
             kname = "pv_sdec_fused_bf16_kernel (decoder fwd+bwd, all layers, bf16x3 split precision)"
             flops_per_launch, peak, dtype = dec_fl * B, MFMA_BF16_PEAK_TFLOPS, "bf16x3"
             arith = "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)"
+        elif mode == 3:
+            kname = "pv_sdec_fused_bf16_kernel<X3=false> (decoder fwd+bwd, all layers, plain bf16 operands)"
+            flops_per_launch, peak, dtype = dec_fl * B, MFMA_BF16_PEAK_TFLOPS, "bf16"
+            arith = "bf16 MFMA operands for the hidden-layer contractions (fp32 accumulate; fp32 elsewhere)"
         elif mode == 1:
             kname = "pv_sdec_fused_kernel (decoder fwd+bwd, all layers, f32-input MFMA)"
             flops_per_launch, peak, dtype = dec_fl * B, MFMA_F32_PEAK_TFLOPS, "f32"
@@ -228,7 +232,7 @@ def main():
             "config": {"workload": "iVAE 28x28 invariances=['r','t'] latent_dim=2 bernoulli, batch %d per GPU "
                                    "(global %d), %s, SVI step = ELBO+grads+%sAdam"
                                    % (B, B * world, arith, "allreduce+" if world > 1 else ""),
-                       "parallelism": "dp%d" % world, "path": {0: "layered", 1: "fused-f32", 2: "fused-bf16x3"}[mode]},
+                       "parallelism": "dp%d" % world, "path": {0: "layered", 1: "fused-f32", 2: "fused-bf16x3", 3: "fused-bf16"}[mode]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": TRAFFIC_BYTES.get(mode), "kernel": kname,
                          "kernel_ms": k_avg_ms, "flops_per_launch": flops_per_launch,

@@ -98,7 +98,9 @@ typedef struct pv_ivae_plan {
   float   decoder_sig;    /* Normal scale for the gaussian sampler (prob.py:28)           */
   int32_t fused;          /* spatial-decoder path when the architecture allows a fused persistent kernel:
                              0 layer-by-layer kernels; 1 fused, f32-input MFMA; 2 fused, bf16 split-
-                             precision MFMA (x = hi + lo, three products, fp32 accumulate)               */
+                             precision MFMA (x = hi + lo, three products, fp32 accumulate: fp32-class
+                             results); 3 fused, plain bf16 operands for the two hidden layers' contractions
+                             (one product, fp32 accumulate; everything else fp32) — mixed-precision training */
   int32_t discrete_dim;   /* models.jiVAE (models/jivae.py:109-220): K classes of the joint discrete latent,
                              enumerated exactly in the ELBO (TraceEnum_ELBO, trainers/svi.py:83-90); 0: iVAE.
                              Then `head` has out_dim 2*z_dim + K (fc13 appended, softmax -> alpha), fc_latent

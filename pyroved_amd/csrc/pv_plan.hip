@@ -146,7 +146,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       const int64_t units = R / FD_UNIT;
       L.f_grid = pv_sdec_fused_grid(units);
       L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
-      if (p->fused == 2) L.f_kmax *= 4;             // the bf16x3 kernel publishes dL/d(hz) per wave (4 per workgroup)
+      if (p->fused >= 2) L.f_kmax *= 4;             // the bf16 kernels publish dL/d(hz) per wave (4 per workgroup)
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
       L.f_part_hz = c.take(S * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);
@@ -534,12 +534,12 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.sw = L.sw; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
   // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
-  if (p->fused == 2 && L.enc_compact) {
+  if (p->fused >= 2 && L.enc_compact) {
     const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0);
     PV_TRY(guide_fwd(p, L, s, &prep));
   } else {
     PV_TRY(guide_fwd(p, L, s));
-    if (p->fused == 2) {
+    if (p->fused >= 2) {
       PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, s));
     } else if (want_grads) {
       hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(S * L.f_kmax * H) * sizeof(float), s);
@@ -550,7 +550,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
                       L.scratch, L.scratch_bytes, s));
   if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_start, s);
-  if (p->fused == 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, s));
+  if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s));
   else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
   if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_stop, s);
   if (!want_grads && K > 0) {                        // llb[b] = sum_k alpha_bk ll_kb

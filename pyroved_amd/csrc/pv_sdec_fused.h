@@ -50,7 +50,7 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s);
 // ... or, as arguments for a kernel that hosts the preparation (pv_fb_layout.h: pv_fb_prep)
 struct PvFbPrep;
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads);
-int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
+int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
 struct PvFusedOffsets { int64_t W1, b1, W2, b2, Wc, wo, bo; };
 int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int dwo_slots,

@@ -71,6 +71,17 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define FB_DGD 1                 // operand prefetch distance (groups) of the dgrad loops
 #endif
 static_assert(GAP_BYTES >= 0, "staging overlays");
+// Plain bf16 (X3 = false) has no lo images and no lo staging arrays: both weight images and both staging areas fit side
+// by side — no overlay, no reloads, and only the two stage -> consume barriers per tile remain.  Everything from
+// BO_VEC on sits at the same offsets in both modes.
+template <bool X3> struct FbLds {
+  static constexpr int R1 = 0;
+  static constexpr int R2 = X3 ? BO_R2 : IMG_BYTES;
+  static constexpr int ST2 = X3 ? BO_R1 : 2 * IMG_BYTES;
+  static constexpr int ST1 = X3 ? BO_GAP : 2 * IMG_BYTES + 2 * ST_BYTES;
+  static constexpr int NARR = X3 ? 2 : 1;            // staging arrays per operand (hi, lo | hi)
+};
+static_assert(2 * IMG_BYTES + 4 * ST_BYTES == BO_VEC, "plain-bf16 layout ends where the vectors start");
 static_assert((2 * IMG_BYTES) % (FB_WAVES * 1024) == 0, "image reload: whole 1 KB LDS-DMA pieces per wave");
 static_assert(FB_LDS_BYTES <= 160 * 1024, "LDS budget");
 
@@ -116,8 +127,10 @@ __device__ __forceinline__ void fb_glds4(const void* gsrc, unsigned lds_dst) {  
 }
 __device__ __forceinline__ void fb_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // one layer's hi + lo images (68 KB) from their global copy: 17 one-KB pieces per wave
+// (X3 = false, plain bf16: only the hi image, 8 pieces per wave)
+template <bool X3>
 __device__ __forceinline__ void fb_reload(const char* __restrict__ gimg, unsigned lds_dst, int wave, int lane) {
-  constexpr int PIECES = 2 * IMG_BYTES / (FB_WAVES * 1024);
+  constexpr int PIECES = (X3 ? 2 : 1) * IMG_BYTES / (FB_WAVES * 1024);
 #pragma unroll
   for (int c = 0; c < PIECES; ++c) {
     const int off = (wave * PIECES + c) * 1024;
@@ -128,6 +141,7 @@ __device__ __forceinline__ void fb_reload(const char* __restrict__ gimg, unsigne
 // forward layer of the wave's unit: out = bias + W in (pre-activation on return); `in` arrives split (hi, lo per
 // C/D block).  Stream: per k-block m (32 k's) and group of four output blocks read 8 weight operands (hi/lo,
 // one group ahead) and issue 12 MFMAs (3 split terms x 4 blocks: four independent accumulator chains).
+template <bool X3>
 __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
                                              const float* __restrict__ bs, const bf16x4 (&ih)[8],
                                              const bf16x4 (&il)[8], f32x4 (&out)[8], int r, int q) {
@@ -148,7 +162,7 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
     for (int o = 0; o < FB_GB; ++o) {
       const int off = 16 * (op + o) * LDB + xm[m];
       h[o] = *reinterpret_cast<const bf16x8*>(ah + off);
-      l[o] = *reinterpret_cast<const bf16x8*>(al + off);
+      if (X3) l[o] = *reinterpret_cast<const bf16x8*>(al + off);
     }
   };
   load(0, wh[0], wl[0]);
@@ -162,15 +176,18 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
     const bf16x8(&l)[FB_GB] = wl[g & 1];
 #pragma unroll
     for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(h[o], bh, out[op + o]);
+    if (X3) {
 #pragma unroll
-    for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(h[o], bl, out[op + o]);
+      for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(h[o], bl, out[op + o]);
 #pragma unroll
-    for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(l[o], bh, out[op + o]);
+      for (int o = 0; o < FB_GB; ++o) out[op + o] = MFMA32(l[o], bh, out[op + o]);
+    }
     FB_FENCE();
   }
 }
 
 // dgrad of the wave's unit: out[k] = sum_j W[j][k] dp[j]; A = W^T via the transposing LDS read; dp arrives split
+template <bool X3>
 __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
                                                const bf16x4 (&ih)[8], const bf16x4 (&il)[8], f32x4 (&out)[8], int r,
                                                int q) {
@@ -193,7 +210,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
     for (int o = 0; o < FB_GB; ++o) {
       const int off = 32 * m * LDB + xk[(kp + o) >> 1] + 4 * ((kp + o) & 1);
       h[o] = fb_cat(fb_tr(ah + off), fb_tr(ah + off + 16 * LDB));
-      l[o] = fb_cat(fb_tr(al + off), fb_tr(al + off + 16 * LDB));
+      if (X3) l[o] = fb_cat(fb_tr(al + off), fb_tr(al + off + 16 * LDB));
     }
   };
 #pragma unroll
@@ -208,10 +225,12 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
     const bf16x8(&l)[FB_GB] = wl[g % (FB_DGD + 1)];
 #pragma unroll
     for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(h[o], bh, out[kp + o]);
+    if (X3) {
 #pragma unroll
-    for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(h[o], bl, out[kp + o]);
+      for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(h[o], bl, out[kp + o]);
 #pragma unroll
-    for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(l[o], bh, out[kp + o]);
+      for (int o = 0; o < FB_GB; ++o) out[kp + o] = MFMA32(l[o], bh, out[kp + o]);
+    }
     FB_FENCE();
   }
 }
@@ -231,11 +250,15 @@ __device__ __forceinline__ void fb_mul_dtanh(f32x4 (&out)[8], const f32x4 (&h)[8
 }
 
 // a unit's rows -> (hi, lo) bf16 per C/D block
+template <bool X3>
 __device__ __forceinline__ void fb_presplit(const f32x4 (&v)[8], bf16x4 (&h)[8], bf16x4 (&l)[8]) {
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { __bf16 a, b; fb_split(v[jb][i], a, b); h[jb][i] = a; l[jb][i] = b; }
+    for (int i = 0; i < 4; ++i) {
+      if (X3) { __bf16 a, b; fb_split(v[jb][i], a, b); h[jb][i] = a; l[jb][i] = b; }
+      else h[jb][i] = (__bf16)v[jb][i];
+    }
 }
 __device__ __forceinline__ void fb_zero8(bf16x4 (&h)[8], bf16x4 (&l)[8]) {
   const short4_ z = {0, 0, 0, 0};
@@ -246,6 +269,7 @@ __device__ __forceinline__ void fb_zero8(bf16x4 (&h)[8], bf16x4 (&l)[8]) {
 // every 16-column block the four 8-byte pieces are XOR-swizzled by (row>>2)&3: ds_write_b64 is banked mod 32 and
 // serviced 16 lanes (16 rows, one q) at a time, and 72-dword rows alone would put rows r and r+4 on the same banks
 // (4-way); the transposing reads (fb_stage_toff) undo the swizzle and stay conflict-free.
+template <bool X3>
 __device__ __forceinline__ void fb_stage_store(__bf16* __restrict__ sh, __bf16* __restrict__ sl, const bf16x4 (&h)[8],
                                                const bf16x4 (&l)[8], int row, int q) {
   row |= fb_opaque0();
@@ -253,7 +277,7 @@ __device__ __forceinline__ void fb_stage_store(__bf16* __restrict__ sh, __bf16* 
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
     *reinterpret_cast<bf16x4*>(sh + e + 16 * jb) = h[jb];
-    *reinterpret_cast<bf16x4*>(sl + e + 16 * jb) = l[jb];
+    if (X3) *reinterpret_cast<bf16x4*>(sl + e + 16 * jb) = l[jb];
   }
 }
 // lane offset of the transposing read of staged rows R0 + 4q .. 4q+3 (R0 a multiple of 16), columns 16*blk ..
@@ -263,12 +287,13 @@ __device__ __forceinline__ int fb_stage_toff(int r, int q) { return (4 * q + (r 
 //   dW[j][k] += sum_rows dpre[row][j] h[row][k];   db[j] += sum_rows dpre[row][j]  (MFMA against ones)
 // k-step ks contracts rows 32ks .. 32ks+31: lane group q feeds rows 32ks + {4q..4q+3, 16+4q..16+4q+3} of BOTH
 // operands (two transposing reads each), which is all the contraction needs.
+template <bool X3>
 __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)[2][8], f32x4 (&accB)[2], int wave,
                                                  int r, int q, int ksteps) {
   const __bf16* sah = st;
   const __bf16* sal = st + ST_ARR;
-  const __bf16* sbh = st + 2 * ST_ARR;
-  const __bf16* sbl = st + 3 * ST_ARR;
+  const __bf16* sbh = st + FbLds<X3>::NARR * ST_ARR;
+  const __bf16* sbl = sbh + ST_ARR;
   const int toff = fb_stage_toff(r | fb_opaque0(), q);
   const short one = 0x3f80;                           // bf16 1.0
   const short8_ ones_s = {one, one, one, one, one, one, one, one};
@@ -280,7 +305,7 @@ __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)
     for (int s = 0; s < 2; ++s) {
       const int off = koff + 16 * (2 * wave + s);
       a_h[s] = fb_cat(fb_tr(sah + off), fb_tr(sah + off + 16 * LDS2));
-      a_l[s] = fb_cat(fb_tr(sal + off), fb_tr(sal + off + 16 * LDS2));
+      if (X3) a_l[s] = fb_cat(fb_tr(sal + off), fb_tr(sal + off + 16 * LDS2));
     }
     bf16x8 bh[2][2], bl[2][2];
     auto load = [&](int kp, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
@@ -288,14 +313,14 @@ __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)
       for (int o = 0; o < 2; ++o) {
         const int off = koff + 16 * (kp + o);
         h[o] = fb_cat(fb_tr(sbh + off), fb_tr(sbh + off + 16 * LDS2));
-        l[o] = fb_cat(fb_tr(sbl + off), fb_tr(sbl + off + 16 * LDS2));
+        if (X3) l[o] = fb_cat(fb_tr(sbl + off), fb_tr(sbl + off + 16 * LDS2));
       }
     };
     load(0, bh[0], bl[0]);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       accB[s] = MFMA32(a_h[s], ones, accB[s]);
-      accB[s] = MFMA32(a_l[s], ones, accB[s]);
+      if (X3) accB[s] = MFMA32(a_l[s], ones, accB[s]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -308,14 +333,16 @@ __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)
       for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_h[s], h[o], accW[s][kp + o]);
+      if (X3) {
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+        for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_h[s], l[o], accW[s][kp + o]);
+          for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_h[s], l[o], accW[s][kp + o]);
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+        for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_l[s], h[o], accW[s][kp + o]);
+          for (int s = 0; s < 2; ++s) accW[s][kp + o] = MFMA32(a_l[s], h[o], accW[s][kp + o]);
+      }
       FB_FENCE();
     }
   }
@@ -390,7 +417,8 @@ __global__ __launch_bounds__(256) void pv_fb_prep_kernel(PvFbPrep p) {
 }
 
 // LIK: the likelihood is a compile-time choice (the rarely used ones must not cost the Bernoulli kernel registers)
-template <bool GRADS, int LIK>
+// X3: split precision (three products per contraction, fp32-class results) or plain bf16 operands (one product)
+template <bool GRADS, int LIK, bool X3>
 __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f) {
   extern __shared__ __attribute__((aligned(16))) char smb[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -399,18 +427,19 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smb);
   const __bf16* W1h = reinterpret_cast<const __bf16*>(smb + BO_R1);
   const __bf16* W1l = W1h + W_IMG;
-  const __bf16* W2h = reinterpret_cast<const __bf16*>(smb + BO_R2);
+  const __bf16* W2h = reinterpret_cast<const __bf16*>(smb + FbLds<X3>::R2);
   const __bf16* W2l = W2h + W_IMG;
-  __bf16* st2 = reinterpret_cast<__bf16*>(smb + BO_R1);       // wgrad-2 staging: over W1 (+ gap)
-  __bf16* st1 = reinterpret_cast<__bf16*>(smb + BO_GAP);      // wgrad-1 staging: over (gap +) W2
+  __bf16* st2 = reinterpret_cast<__bf16*>(smb + FbLds<X3>::ST2);   // wgrad-2 staging (X3: over W1 (+ gap))
+  __bf16* st1 = reinterpret_cast<__bf16*>(smb + FbLds<X3>::ST1);   // wgrad-1 staging (X3: over (gap +) W2)
+  constexpr int SB = FbLds<X3>::NARR * ST_ARR;                     // the second operand's arrays follow the first's
   float* vec = reinterpret_cast<float*>(smb + BO_VEC);
   float* info = reinterpret_cast<float*>(smb + BO_INFO);
   float* red = reinterpret_cast<float*>(smb + BO_RED);
   const char* gimg = reinterpret_cast<const char*>(f.wimg);
 
   // ---- weight images by LDS-DMA, fp32 vectors by hand ----
-  fb_reload(gimg, lds0 + BO_R1, wave, lane);
-  fb_reload(gimg + 2 * IMG_BYTES, lds0 + BO_R2, wave, lane);
+  fb_reload<X3>(gimg, lds0 + BO_R1, wave, lane);
+  fb_reload<X3>(gimg + 2 * IMG_BYTES, lds0 + FbLds<X3>::R2, wave, lane);
   for (int j = tid; j < FD_H; j += FB_THREADS) {
     vec[j] = f.Wc[j * f.cd];
     vec[FD_H + j] = f.cd == 2 ? f.Wc[j * 2 + 1] : 0.0f;
@@ -537,30 +566,30 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
 #pragma unroll
         for (int i = 0; i < 4; ++i) h0[jb][i] = fb_tanh(w0[i] * x0 + w1[i] * x1 + bc[i] + hz[i]);
       }
-      fb_presplit(h0, pBh, pBl);
+      fb_presplit<X3>(h0, pBh, pBl);
     }
     FB_STAMP(1);
     fetch_unit_inputs(ut + TILE_UNITS);          // the slots were consumed by the coordinate layer above
-    if (GRADS && tile_no > 0) {
+    if (X3 && GRADS && tile_no > 0) {
       // W2's images were the previous tile's staging area: bring them back under the forward of layer 1.
       // (every compiler-visible load above has been consumed; none is issued before the barrier below)
       fb_wait_vm0();
-      fb_reload(gimg + 2 * IMG_BYTES, lds0 + BO_R2, wave, lane);
+      fb_reload<X3>(gimg + 2 * IMG_BYTES, lds0 + FbLds<X3>::R2, wave, lane);
     }
     if (act) {
-      fb_layer_fwd(W1h, W1l, b1s, pBh, pBl, tB, r, q);
+      fb_layer_fwd<X3>(W1h, W1l, b1s, pBh, pBl, tB, r, q);
       fb_tanh8(tB);                                              // tB = h1
-      fb_presplit(tB, pBh, pBl);                                 // feeds layer 2 and its wgrad
+      fb_presplit<X3>(tB, pBh, pBl);                                 // feeds layer 2 and its wgrad
     }
     FB_STAMP(2);
-    if (GRADS) {
+    if (X3 && GRADS) {
       fb_wait_vm0();
       __syncthreads();      // W2 landed everywhere; every wave is past its reads of W1 (staging may overwrite it)
     }
     FB_STAMP(3);
     float dlda = 0.0f;
     if (act) {
-      fb_layer_fwd(W2h, W2l, b2s, pBh, pBl, tC, r, q);
+      fb_layer_fwd<X3>(W2h, W2l, b2s, pBh, pBl, tC, r, q);
       FB_STAMP(16);
       fb_tanh8(tC);                                              // tC = h2
       FB_STAMP(17);
@@ -617,7 +646,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
           for (int i = 0; i < 4; ++i) tC[jb][i] = dlda * wv[i] * (1.0f - tC[jb][i] * tC[jb][i]);  // dpre2
         }
         FB_STAMP(20);
-        fb_presplit(tC, pAh, pAl);                               // feeds the wgrad and the dgrad of layer 2
+        fb_presplit<X3>(tC, pAh, pAl);                               // feeds the wgrad and the dgrad of layer 2
       }
     }
     FB_STAMP(4);
@@ -626,26 +655,30 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     const int ksteps = nact > 2 ? 2 : 1;          // rows 32.. are only staged (as zeros or not) when a unit owns them
 
     // ---- wgrad of layer 2: stage (dpre2, h1) of all 64 rows over W1's images, one pass ----
-    fb_stage_store(st2, st2 + ST_ARR, pAh, pAl, 16 * wave + r, q);
-    fb_stage_store(st2 + 2 * ST_ARR, st2 + 3 * ST_ARR, pBh, pBl, 16 * wave + r, q);
+    fb_stage_store<X3>(st2, st2 + ST_ARR, pAh, pAl, 16 * wave + r, q);
+    fb_stage_store<X3>(st2 + SB, st2 + SB + ST_ARR, pBh, pBl, 16 * wave + r, q);
     __syncthreads();
     FB_STAMP(5);
-    fb_wgrad_consume(st2, accW2, accB2, wave, r, q, ksteps);
-    __syncthreads();
-    FB_STAMP(6);
-    fb_wait_vm0();                                   // (stores only: nothing the compiler still waits for)
-    fb_reload(gimg, lds0 + BO_R1, wave, lane);       // W1 comes back under the dgrad of layer 2
+    fb_wgrad_consume<X3>(st2, accW2, accB2, wave, r, q, ksteps);
+    if (X3) {
+      __syncthreads();
+      FB_STAMP(6);
+      fb_wait_vm0();                                   // (stores only: nothing the compiler still waits for)
+      fb_reload<X3>(gimg, lds0 + BO_R1, wave, lane);   // W1 comes back under the dgrad of layer 2
+    }
     if (act) {
-      fb_layer_dgrad(W2h, W2l, pAh, pAl, tA, r, q);
+      fb_layer_dgrad<X3>(W2h, W2l, pAh, pAl, tA, r, q);
       fb_mul_dtanh(tA, tB);                                      // tA = dpre1
-      fb_presplit(tA, pAh, pAl);                                 // feeds the dgrad and the wgrad of layer 1
+      fb_presplit<X3>(tA, pAh, pAl);                                 // feeds the dgrad and the wgrad of layer 1
     }
     FB_STAMP(7);
-    fb_wait_vm0();
-    __syncthreads();        // W1 landed everywhere; every wave is past its reads of W2
+    if (X3) {
+      fb_wait_vm0();
+      __syncthreads();      // W1 landed everywhere; every wave is past its reads of W2
+    }
     FB_STAMP(8);
     if (act) {
-      fb_layer_dgrad(W1h, W1l, pAh, pAl, tC, r, q);
+      fb_layer_dgrad<X3>(W1h, W1l, pAh, pAl, tC, r, q);
       fb_mul_dtanh(tC, h0);                                      // tC = dpre0
       // ---- coordinate layer, cross-row part: dhz[b] = sum_rows dpre0, dWc_k = sum_rows dpre0 * x'_k.  Wave-local
       // (the unit's rows all belong to this wave and to one sample): W2's images are dead since the barrier above, so
@@ -657,15 +690,15 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       if (q == 0) { info[16 * wave + r] = x0; info[TILE_ROWS + 16 * wave + r] = x1; }
       fb_colsum<true>(tC, reinterpret_cast<float*>(st1) + (16 * wave) * (LDS2 / 2), dhz_g, dwc0_g, dwc1_g,
                       info + 16 * wave, info + TILE_ROWS + 16 * wave, lane, r, q);
-      fb_presplit(h0, pBh, pBl);
+      fb_presplit<X3>(h0, pBh, pBl);
     }
     FB_STAMP(9);
     // ---- wgrad of layer 1: stage (dpre1, h0) over W2's images ----
-    fb_stage_store(st1, st1 + ST_ARR, pAh, pAl, 16 * wave + r, q);
-    fb_stage_store(st1 + 2 * ST_ARR, st1 + 3 * ST_ARR, pBh, pBl, 16 * wave + r, q);
+    fb_stage_store<X3>(st1, st1 + ST_ARR, pAh, pAl, 16 * wave + r, q);
+    fb_stage_store<X3>(st1 + SB, st1 + SB + ST_ARR, pBh, pBl, 16 * wave + r, q);
     __syncthreads();
     FB_STAMP(10);
-    fb_wgrad_consume(st1, accW1, accB1, wave, r, q, ksteps);
+    fb_wgrad_consume<X3>(st1, accW1, accB1, wave, r, q, ksteps);
     FB_STAMP(21);
     // ---- coordinate layer backward (fp32): row-local part ----
     if (act) {
@@ -687,7 +720,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
     }
     FB_STAMP(22);
-    __syncthreads();        // the staging area is free again (the next tile's W2 reload lands here)
+    if (X3) __syncthreads();   // the staging area is free again (the next tile's W2 reload lands here)
     FB_STAMP(13);
   }
   if (!GRADS) return;
@@ -761,14 +794,16 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s) {
   return 0;
 }
 
-int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {
+int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s) {
   PvFused f = f_in;
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }
   f.ablate = ablate;
   const size_t lds = FB_LDS_BYTES;
   const void* fn = nullptr;
-#define FB_PICK(G, L) fn = reinterpret_cast<const void*>(&pv_sdec_fused_bf16_kernel<G, L>)
+#define FB_PICK(G, L)                                                                          \
+  fn = x3 ? reinterpret_cast<const void*>(&pv_sdec_fused_bf16_kernel<G, L, true>)              \
+          : reinterpret_cast<const void*>(&pv_sdec_fused_bf16_kernel<G, L, false>)
   if (grads) {
     if (f.lik == PV_LIK_BERNOULLI) FB_PICK(true, PV_LIK_BERNOULLI);
     else if (f.lik == PV_LIK_GAUSSIAN) FB_PICK(true, PV_LIK_GAUSSIAN);
@@ -779,8 +814,8 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, hipStre
     else FB_PICK(false, PV_LIK_CBERNOULLI);
   }
 #undef FB_PICK
-  static const void* configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  const int slot = (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
+  static const void* configured[12] = {};
+  const int slot = (x3 ? 6 : 0) + (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
   if (configured[slot] != fn) {                     // (idempotent: a race between host threads only repeats the call)
     hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e1 != hipSuccess) return (int)e1;
