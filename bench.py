@@ -6,10 +6,12 @@ bench.py — throughput of the SVI training hot path on MI355X.
   (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
 Workload (BASELINE.json configs[1]): iVAE, data_dim (28, 28), latent_dim 2, invariances ['r','t'],
-Bernoulli likelihood, batch 256 PER GPU (weak scaling); decoder contractions on the bf16 MFMA in split
-precision ("bf16x3": hi+lo operands, 3 products, fp32 accumulate — fp32-class results, the 1e-4 parity mode;
---fused 1 selects the f32-input MFMA kernel, --fused 0 the layer-by-layer path), fp32 everywhere
-else; synthetic data torch.rand(..., seed 0), model/trainer seed 1, random-init weights.
+Bernoulli likelihood, batch 256 PER GPU (weak scaling), bf16 as that config names it: the decoder's hidden-layer
+contractions take bf16 operands on the MFMA with fp32 accumulation (--fused 3: ELBO within 1e-5 of the fp32 oracle,
+gradients to ~1e-2 — mixed-precision training), everything else fp32.  The same run then repeats the measurement on
+the library's default fp32-class path (--fused 2, "bf16x3": hi+lo operands, 3 products — the 1e-4 parity mode for
+gradients too) and reports it as `fp32_class`; --fused 1 selects the f32-input MFMA kernel, --fused 0 the
+layer-by-layer path.  Synthetic data torch.rand(..., seed 0), model/trainer seed 1, random-init weights.
 A step = Trace_ELBO loss + gradients over one minibatch already resident in HBM
 (pv_ivae_loss_and_grads) + [one all-reduce of the flat gradient when N > 1] + Adam (pv_adam_step).
 
@@ -43,7 +45,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the guide's
 # gfx950 correction + WRITE_SIZE, KiB -> bytes), batch 256: see profiles/r01*_pmc_*.txt.  None: not collected.
-TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1342 * 1024 + 37943 * 1024}   # 2: profiles/r01g_pmc_*
+TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1331 * 1024 + 37943 * 1024,
+                 3: 2 * 994 * 1024 + 37925 * 1024}   # 2, 3: profiles/r01h_pmc_*
 
 
 def decoder_flops_per_image(n_pix, hidden=128, coord_dim=2):
@@ -128,9 +131,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "2")),
+    ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "3")),
                     help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3 (fp32-class), 3 fused plain bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the fp32-class path) of the default run")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     args = ap.parse_args()
 
@@ -149,11 +153,30 @@ def main():
     from pyroved_amd import dist as pvdist
 
     B = args.batch
+    n_pix = DATA_DIM[0] * DATA_DIM[1]
+
+    def run(fused):
+        """warm-up + the timed region on one decoder path; -> (elapsed s (max over ranks), kernel ms samples, losses, engine)"""
+        return _run(args, fused, pv, pvdist, td, dev, rank, world, B, n_pix)
+
+    elapsed, kms, losses, eng, model = run(args.fused)
+    alt = None
+    if args.fused == 3 and not args.no_alt:
+        # the same workload on the fp32-class path (bf16 split precision), reported next to the headline
+        a_el, a_kms, a_losses, _, _ = run(2)
+        alt = {"path": "fused-bf16x3", "dtype": "bf16x3", "value": args.steps * B * world / a_el, "unit": "images/s",
+               "ms_per_step": 1e3 * a_el / args.steps, "kernel_ms": sum(a_kms) / max(len(a_kms), 1),
+               "loss_per_image_step0": a_losses[0].item() / (B * world)}
+    _report(args, rank, world, B, n_pix, elapsed, kms, losses, eng, model, alt)
+    if world > 1:
+        td.destroy_process_group()
+
+
+def _run(args, fused, pv, pvdist, td, dev, rank, world, B, n_pix):
     model = pv.models.iVAE(DATA_DIM, LATENT_DIM, INVARIANCES, seed=1, device=dev)
-    eng = model.engine(fused=args.fused)
+    eng = model.engine(fused=fused)
     if world > 1:
         pvdist.broadcast_(eng.flat)
-    n_pix = DATA_DIM[0] * DATA_DIM[1]
     # synthetic data, resident in HBM before the timed region; every rank gets its own shard of a
     # global ring of N_RING * world minibatches (weak scaling: B per GPU)
     g = torch.Generator().manual_seed(0)
@@ -196,8 +219,10 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
     elapsed = t.item()
 
-    kms = events.elapsed_ms()
-    losses = hist[:, 0].cpu()
+    return elapsed, events.elapsed_ms(), hist[:, 0].cpu(), eng, model
+
+
+def _report(args, rank, world, B, n_pix, elapsed, kms, losses, eng, model, alt):
     if rank == 0:
         images = args.steps * B * world
         value = images / elapsed
@@ -249,9 +274,9 @@ def main():
             out["elbo"]["oracle_loss_per_image_step0"] = loss0
             if B == BATCH_PER_GPU:
                 out["elbo"]["rel_err_step0"] = abs(out["elbo"]["loss_per_image_step0"] - loss0) / abs(loss0)
+        if alt is not None:
+            out["fp32_class"] = alt
         print(json.dumps(out))
-    if world > 1:
-        td.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -404,11 +404,15 @@ __device__ __forceinline__ void fb_colsum(const f32x4 (&v)[8], float* __restrict
 // phase-timing trace (profiling only, enabled by PV_FD_ABLATE bit 256): shader-clock stamps of workgroup 0 /
 // wave 0 for its first tiles; read back with pv_debug_read_trace()
 __device__ long long fb_trace[256];
+#ifdef FB_TRACE
 #define FB_STAMP(k)                                                                        \
   do {                                                                                     \
     if ((f.ablate & 256) && g == 0 && tid == 0 && tile_no < 4)                             \
       fb_trace[tile_no * 32 + (k)] = (long long)__builtin_readcyclecounter();              \
   } while (0)
+#else
+#define FB_STAMP(k) do { } while (0)     // (the stamps split basic blocks: compiled in only for scripts/gpu_trace.py)
+#endif
 
 // stand-alone form of the per-step preparation (pv_fb_layout.h); the SVI step runs it inside the encoder's
 // first-layer launch instead (pv_encoder.hip)
@@ -462,6 +466,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     for (int kb = 0; kb < 8; ++kb) { accW1[s][kb] = f32x4{0, 0, 0, 0}; accW2[s][kb] = f32x4{0, 0, 0, 0}; }
   }
   float dbo = 0.0f;
+  // plain bf16 has the registers to keep d(wo) per lane (row r's share of columns 16*jb + 4q + i) for the whole kernel:
+  // one cross-row reduction at the end instead of one per tile
+  f32x4 accWo[X3 ? 1 : 8];
+#pragma unroll
+  for (int jb = 0; jb < (X3 ? 1 : 8); ++jb) accWo[jb] = f32x4{0, 0, 0, 0};
   int cur_b = -1;                                    // the sample whose dL/d(hz) this WAVE is accumulating
   const int upb = f.N / FD_UNIT;
   float* rec = f.part + (int64_t)g * FD_REC;
@@ -629,7 +638,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       xv_next = x_of_tile(ut + TILE_UNITS);     // lands long before the next LDS-DMA issue point drains loads
       if (GRADS) {
         if (q == 0) dbo += dlda;
-        {
+        if (!X3) {
+#pragma unroll
+          for (int jb = 0; jb < 8; ++jb) accWo[jb] += dlda * tC[jb];
+        } else {
           // d(wo)[j] += sum_rows dlda * h2[row][j]: W1's images are dead since the barrier above (the wgrad-2 staging
           // goes there next), so the wave's own staging rows serve as the transpose buffer
           f32x4 pv_[8];
@@ -726,6 +738,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   if (!GRADS) return;
 
   if (cur_b >= 0) flush_hz(cur_b);
+  if (!X3) {
+    // (every wave is past the last tile's barriers: the wgrad-2 staging rows are free)
+    f32x4 t[8];
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) t[jb] = accWo[X3 ? 0 : jb];
+    fb_colsum<false>(t, reinterpret_cast<float*>(st2) + (16 * wave) * (LDS2 / 2), dwo_g, nullptr, nullptr, nullptr, nullptr,
+                     lane, r, q);
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int j0 = 16 * (2 * wave + s);

@@ -42,7 +42,7 @@ class IVAEEngine:
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: int = 2):
         self.model = model
         self.lr, self.betas, self.adam_eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
-        self.fused = int(fused)         # 0 layered kernels, 1 fused f32-MFMA decoder, 2 fused bf16x3 decoder
+        self.fused = int(fused)         # 0 layered kernels, 1 fused f32-MFMA decoder, 2 fused bf16x3 decoder, 3 fused plain-bf16 decoder
         self.adam_t = 0                 # number of optimizer steps taken (incl. evaluate()'s, see SVItrainer)
         self.grads_live = False         # reference: .grad is None until the first backward
         self.device = None

@@ -561,7 +561,7 @@ def test_trainer_epochs_vs_golden(gpu_device, name):
     assert trainer.current_epoch == int(gold["meta.epochs"])
 
 
-@pytest.mark.parametrize("fused", FUSED)
+@pytest.mark.parametrize("fused", FUSED + [3])
 @pytest.mark.parametrize("cfgname", ["c2_28x28_rt_b256", "64x64_rts_b32"])
 def test_full_size_properties(gpu_device, cfgname, fused):
     """Size-independent properties at BASELINE sizes: run-to-run bit reproducibility, and additivity
@@ -589,6 +589,68 @@ def test_full_size_properties(gpu_device, cfgname, fused):
     np.testing.assert_allclose((s0 + s1).cpu().numpy(), s_full.cpu().numpy(), rtol=2e-6)
     assert rel_l2(g0 + g1, g_full) < 2e-6
     assert torch.isfinite(g_full).all()
+
+
+BF16_CASES = ["ivae_28x28_rt_b256", "ivae_28x28_r_b128", "ivae_28x28_r_b32_blobs", "ivae_8x8_rts_b6", "ivae_8x8_r_b6",
+              "ivae_1d16_t_b5", "ivae_8x8_rts_b6_randn", "ivae_8x8_rt_b6_beta4"]
+
+
+@pytest.mark.parametrize("name", BF16_CASES)
+def test_bf16_mode_steps_vs_golden_and_oracle(gpu_device, name):
+    """The mixed-precision mode (fused=3 / SVItrainer(precision="bf16")): the two hidden-layer contractions of the
+    spatial decoder take bf16 operands (fp32 accumulate), everything else is fp32.  Bars: the ELBO to BASELINE.json's
+    1e-4 at the benchmark sizes (batch >= 128 at 28x28; rounding errors do not average out on a handful of 8x8
+    samples: 5e-4 there), the encoder's outputs as in fp32, every gradient tensor to 3e-2 relative L2 of the fp32
+    oracle's (measured: 2e-4 .. 1.5e-2) from identical parameters at every step."""
+    gold = load_golden(name)
+    meta = meta_of(gold)
+    if meta["batch"] > 64:
+        torch.set_num_threads(8)
+    model, cfg, eng = build(meta, 3)
+    assert eng.uses_fused(meta["batch"])
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    xg = x.cuda()
+    b = meta["batch"]
+    big = b >= 128
+    zl, zs = torch.empty(b, cfg.z_dim, device="cuda"), torch.empty(b, cfg.z_dim, device="cuda")
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eng.loss_and_grads(xg, eps.cuda(), meta["beta"], z_out=(zl, zs))
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=1e-4 if big else 5e-4, err_msg="loss")
+        np.testing.assert_allclose(s[1], float(gold[pre + ".term.model.obs"]), rtol=1e-4 if big else 5e-4)
+        np.testing.assert_allclose(s[2], float(gold[pre + ".term.model.latent"]), rtol=1e-4)
+        np.testing.assert_allclose(s[3], float(gold[pre + ".term.guide.latent"]), rtol=1e-4)
+        np.testing.assert_allclose(zl.cpu().numpy(), gold[pre + ".z_loc"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(zs.cpu().numpy(), gold[pre + ".z_scale"], rtol=1e-4, atol=2e-6)
+        o.step(x, eps, meta["beta"])
+        for key in o.p:
+            err = rel_l2(eng.grad_of(key), o.last_grads[key])
+            assert err < 3e-2, "step %d grad %s: rel l2 error %.3e vs oracle" % (k, key, err)
+        eng.adam_step()
+        for key, p in model.state_dict().items():     # Adam's own bound: |dp| <= lr / (1 - beta1) early on
+            assert (p.detach().cpu() - o.p[key].detach()).abs().max().item() <= 2.5e-3, key
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+
+
+def test_bf16_mode_trainer_tracks_fp32(gpu_device):
+    """SVItrainer(precision="bf16") against precision="fp32" from the same seeds: 6 epochs of 8 minibatches of 128
+    28x28 images; the per-epoch ELBO stays within 1e-3 (it drifts as any mixed-precision run does: Adam turns a 1 %
+    gradient difference into a slightly different trajectory)."""
+    data = make_x("rand", 1024, (28, 28))
+    hist = {}
+    for prec in ("fp32", "bf16"):
+        model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+        tr = pv.trainers.SVItrainer(model, seed=1, precision=prec)
+        assert tr.engine.fused == (3 if prec == "bf16" else 2)
+        loader = pv.utils.init_dataloader(data, batch_size=128)
+        for _ in range(6):
+            tr.step(loader)
+        hist[prec] = np.array(tr.loss_history["training_loss"])
+    assert np.all(np.diff(hist["bf16"]) < 0), hist["bf16"]
+    np.testing.assert_allclose(hist["bf16"], hist["fp32"], rtol=1e-3)
 
 
 def test_fails_loudly_on_cpu_tensors(gpu_device):
