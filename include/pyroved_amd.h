@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 4
+#define PV_ABI_VERSION 5
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -152,6 +152,17 @@ typedef struct pv_ivae_plan {
   float*       ext_dhead;
   int32_t      ext_encoder;
   int32_t      _pad3;
+  /* ---- per-sample weights and extra outputs: what the semi-supervised models (models/ssivae.py, models/ss_reg_ivae.py)
+   * need from the same step.  With e_b = log p(x_b|z_b,y_b) + beta (log p(z_b) - log q(z_b|x_b,y_b)):
+   *   row_w    (B) or NULL: loss = -sum_b row_w[b] e_b (scalars and every gradient weighted accordingly) — the
+   *            enumerated-label expectation of TraceEnum_ELBO with row_w = q(y|x) (ssivae.py:197-211);
+   *   row_elbo (B) out or NULL: the unweighted e_b;
+   *   dy       (B, c_dim) out or NULL (want_grads, c_dim > 0): dloss/dy — y is a reparameterised sample in
+   *            ss_reg_iVAE.guide (ss_reg_ivae.py:196-199).
+   * Not combined with discrete_dim, the convolutional or an external encoder. ---- */
+  const float* row_w;
+  float*       row_elbo;
+  float*       dy;
   /* ---- Adam (torch.optim.Adam defaults via pyro.optim.Adam, svi.py:79-81) ---- */
   float   lr, adam_beta1, adam_beta2, adam_eps;
   int32_t adam_step;      /* 1-based step count of THIS update                            */
@@ -282,6 +293,51 @@ int pv_ved_encode(const pv_ved_plan* plan, float* z_loc, float* z_scale, void* s
 
 /* convDecoderNet.forward (nets/conv.py:95-102): loc (B, out_ch, *out_dim) for z (B, z_dim). */
 int pv_ved_decode(const pv_ved_plan* plan, const float* z, float* loc, void* stream);
+
+/* ===================================================================================================
+ * Semi-supervised models (models/ssivae.py ssiVAE, models/ss_reg_ivae.py ss_reg_iVAE) trained by
+ * trainers/auxsvi.py auxSVItrainer: every step is pv_ivae_loss_and_grads on encoder_z / decoder with the label
+ * vector as the conditioning input y (observed; enumerated over the K classes with row_w = q(y|x) — the caller
+ * lays the K*B (x, onehot(k)) rows out [k][b]; or sampled, with dy handed back), plus the label network
+ * encoder_y below and the small objective kernels.  All parameters share one flat buffer (one pv_adam_step).
+ * =================================================================================================== */
+enum pv_mlp_out { PV_MLP_LINEAR = 0 /* fcRegressorNet, nets/fc.py:274-304 */, PV_MLP_SOFTMAX = 1 /* fcClassifierNet, fc.py:240-271 */ };
+enum pv_ss_task { PV_SS_CLASSIFICATION = 0, PV_SS_REGRESSION = 1 };
+
+typedef struct pv_mlp_plan {
+  int32_t  batch, in_dim, n_layers, out_kind;
+  pv_layer layers[PV_MAX_LAYERS];   /* make_fc_layers(in_dim, hidden_dim, activation)                     */
+  pv_layer out;                     /* .out (act ignored)                                                 */
+  float*       params;              /* flat parameters (offsets of `layers` / `out` index it)             */
+  float*       grads;               /* flat gradients: the network's entries are overwritten by backward  */
+  const float* x;                   /* (B, in_dim)                                                        */
+  void*        ws;                  /* >= pv_mlp_workspace_bytes; holds the activations between forward and backward */
+  int64_t      ws_bytes;
+} pv_mlp_plan;
+
+int64_t pv_mlp_workspace_bytes(const pv_mlp_plan* plan);
+/* out (B, out.out_dim) = net(x): probabilities (PV_MLP_SOFTMAX) or the linear output. */
+int pv_mlp_forward(const pv_mlp_plan* plan, float* out, void* stream);
+/* Gradients of the network's parameters from dout = dloss/d(out) (B, out_dim), after pv_mlp_forward with the same
+ * plan, x and workspace; `out` = that forward's result (needed for the softmax backward; may be NULL for linear). */
+int pv_mlp_backward(const pv_mlp_plan* plan, const float* out, const float* dout, void* stream);
+
+/* Enumerated-label ELBO (TraceEnum_ELBO over ssiVAE.guide's "y", auxsvi.py:73-77): alpha (B, K) = q(y|x),
+ * row_elbo (K*B) ordered [k][b] from the weighted iVAE step.  loss_add[0] = sum_bk alpha (log alpha + log K)
+ * (add to the step's scalars[0]); dalpha (B, K) = dloss/dalpha (may be NULL). */
+int pv_ss_enum_terms(const float* alpha, const float* row_elbo, int64_t batch, int32_t n_classes, float* dalpha,
+                     float* loss_add, void* stream);
+/* model_aux (ssivae.py:215-228, ss_reg_ivae.py:221-234): loss[0] = -multiplier * sum_b log p(y_b | out_b) with
+ * out = encoder_y(x) (class probabilities / regression means), dout = dloss/dout (may be NULL). */
+int pv_ss_aux_loss(int32_t task, const float* out, const float* y, int64_t batch, int32_t dim, float multiplier,
+                   float reg_sig, float* dout, float* loss, void* stream);
+/* ss_reg_iVAE.guide's label sample ys = c + reg_sig * eps (ss_reg_ivae.py:196-199). */
+int pv_ss_reg_sample(const float* c, const float* eps, int64_t batch, int32_t dim, float reg_sig, float* ys, void* stream);
+/* The label's own ELBO terms.  Sampled label (c != NULL): loss_add[0] = -sum(log N(ys; 0, sig) - log N(ys; c, sig)),
+ * dc = dy + ys / sig^2 with dy = plan->dy of the iVAE step.  Observed label (c == NULL; eps, dy, dc unused):
+ * loss_add[0] = -sum log N(ys; 0, sig). */
+int pv_ss_reg_terms(const float* c, const float* eps, const float* ys, const float* dy, int64_t batch, int32_t dim,
+                    float reg_sig, float* dc, float* loss_add, void* stream);
 
 #ifdef __cplusplus
 }

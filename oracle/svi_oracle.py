@@ -522,3 +522,153 @@ class SVIOracle:
                 g = transform_coordinates(g, a, t, s).squeeze(0)
                 return sdecoder_forward(self.p, cfg, g.expand(z.shape[0], *g.shape), z)
             return fcdecoder_forward(self.p, cfg, z)
+
+
+# ======================================================================================
+# Semi-supervised models: ssiVAE (models/ssivae.py), ss_reg_iVAE (models/ss_reg_ivae.py) trained by
+# auxSVItrainer (trainers/auxsvi.py).  `cfg.c_dim` is num_classes / reg_dim; the label network encoder_y is
+# fcClassifierNet (nets/fc.py:240-271) or fcRegressorNet (nets/fc.py:274-304).
+# ======================================================================================
+def label_net_forward(p: Params, cfg: Config, x, task: str, n_hidden: int = 2):
+    act = _ACT[cfg.activation]
+    h = _fc_stack(p, "encoder_y.fc_layers", n_hidden, act, x.reshape(x.shape[0], -1))
+    out = F.linear(h, p["encoder_y.out.weight"], p["encoder_y.out.bias"])
+    return torch.softmax(out, dim=-1) if task == "classification" else out
+
+
+def ss_elbo(p: Params, cfg: Config, task: str, x, eps, ys=None, eps_y=None, beta=1.0, reg_sig=0.5, grid=None):
+    """The ELBO step of auxSVItrainer.compute_loss (auxsvi.py:88-99) = SVI(model.model, guide, ...) with
+      classification: TraceEnum_ELBO, the guide's label site enumerated in parallel when ys is None
+                      (ssivae.py:150-211; auxsvi.py:73-77): rows [k][b], eps (K, B, z_dim) in one draw;
+      regression:     Trace_ELBO, the guide's label a reparameterised Normal(encoder_y(x), reg_sig) sample
+                      (ss_reg_ivae.py:158-199), drawn BEFORE z.
+    With ys given the label is observed: iVAE's ELBO with y = ys plus the constant -sum log p(ys)."""
+    b = x.shape[0]
+    xf = x.reshape(b, -1)
+    K = cfg.c_dim
+    if task == "classification":
+        if ys is None:
+            alpha = label_net_forward(p, cfg, xf, task)                      # (B, K)
+            y_rep = torch.eye(K, dtype=xf.dtype).repeat_interleave(b, 0)     # rows [k][b] = onehot(k)
+            out = elbo(p, cfg, xf.repeat(K, 1), eps.reshape(K * b, -1), beta, y_rep, grid)
+            # per-row terms: ll + beta (log p(z) - log q(z))
+            z, z_loc, z_scale = out["z"], out["z_loc"], out["z_scale"]
+            logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)
+            logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)
+            e = (out["ll_per_sample"] + beta * (logp - logq)).reshape(K, b)
+            w = alpha.t()
+            logq_y = td.OneHotCategorical(probs=alpha).log_prob(torch.eye(K, dtype=xf.dtype).unsqueeze(1))   # (K, B)
+            logp_y = torch.full_like(logq_y, -math.log(K))
+            loss = -((w * e).sum() + (w * (logp_y - logq_y)).sum())
+            return dict(loss=loss, alpha=alpha, row_elbo=e, inner=out)
+        out = elbo(p, cfg, xf, eps, beta, ys, grid)
+        logp_y = td.OneHotCategorical(probs=torch.full_like(ys, 1.0 / K)).log_prob(ys).sum()
+        return dict(loss=out["loss"] - logp_y, inner=out)
+    if ys is None:
+        c = label_net_forward(p, cfg, xf, task)
+        y = c + reg_sig * eps_y
+        logq_y = td.Normal(c, reg_sig).log_prob(y).sum()
+        logp_y = td.Normal(torch.zeros_like(y), reg_sig).log_prob(y).sum()
+        out = elbo(p, cfg, xf, eps, beta, y, grid)
+        return dict(loss=out["loss"] - (logp_y - logq_y), c=c, ys=y, inner=out)
+    out = elbo(p, cfg, xf, eps, beta, ys, grid)
+    logp_y = td.Normal(torch.zeros_like(ys), reg_sig).log_prob(ys).sum()
+    return dict(loss=out["loss"] - logp_y, inner=out)
+
+
+def ss_aux_loss(p: Params, cfg: Config, task: str, x, ys, mult=20.0, reg_sig=0.5):
+    """model_aux under Trace_ELBO with the empty guide_aux (ssivae.py:215-234 / ss_reg_ivae.py:221-240)."""
+    out = label_net_forward(p, cfg, x.reshape(x.shape[0], -1), task)
+    if task == "classification":
+        return -(mult * td.OneHotCategorical(probs=out).log_prob(ys)).sum()
+    return -(mult * td.Normal(out, reg_sig).log_prob(ys).sum(-1)).sum()
+
+
+class SSOracle:
+    """auxSVItrainer restated: compute_loss = SVI step on the ELBO + SVI step on the auxiliary loss, both through the
+    SAME per-parameter Adam (auxsvi.py:60-84, 88-99): with ys = None the auxiliary step has no loss and no backward,
+    yet the optimizer is still called on every parameter of the module (pyro.module registers them all), so every
+    parameter that has ever had a gradient takes a momentum-only Adam step."""
+
+    def __init__(self, params: Params, cfg: Config, task: str = "classification", lr: float = 5e-4, reg_sig: float = 0.5,
+                 dtype=torch.float32):
+        self.cfg, self.task, self.reg_sig, self.dtype = cfg, task, reg_sig, dtype
+        self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+        self.grid = generate_grid(cfg.data_dim, dtype) if cfg.coord > 0 else None
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)
+        self.last_grads = {}
+
+    def _svi_step(self, loss, which):
+        if torch.is_tensor(loss) and loss.requires_grad:
+            loss.backward()
+        self.last_grads[which] = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in self.p.items()}
+        if any(v.grad is not None for v in self.p.values()):
+            self.opt.step()
+        for v in self.p.values():
+            if v.grad is not None:
+                v.grad = torch.zeros_like(v.grad)
+        return loss.item() if torch.is_tensor(loss) else float(loss)
+
+    def draw(self, b, unlabeled):
+        """The guide's draws on the global CPU generator, in the guide's order."""
+        cfg, eps_y = self.cfg, None
+        if self.task == "classification":
+            shape = (cfg.c_dim, b, cfg.z_dim) if unlabeled else (b, cfg.z_dim)
+        else:
+            if unlabeled:
+                eps_y = torch.empty(b, cfg.c_dim).normal_()
+            shape = (b, cfg.z_dim)
+        return torch.empty(shape).normal_(), eps_y
+
+    def compute_loss(self, x, ys=None, eps=None, eps_y=None, beta=1.0, mult=20.0):
+        x = x.to(self.dtype)
+        if eps is None:
+            eps, eps_y = self.draw(x.shape[0], ys is None)
+        out = ss_elbo(self.p, self.cfg, self.task, x, eps.to(self.dtype), None if ys is None else ys.to(self.dtype),
+                      None if eps_y is None else eps_y.to(self.dtype), beta, self.reg_sig, self.grid)
+        self.last = out
+        l1 = self._svi_step(out["loss"], "elbo")
+        aux = ss_aux_loss(self.p, self.cfg, self.task, x, ys.to(self.dtype), mult, self.reg_sig) if ys is not None else 0.0
+        l2 = self._svi_step(aux, "aux")
+        return l1, l2
+
+    def train_epoch(self, loader_unsup, loader_sup, beta=1.0, mult=20.0) -> float:
+        """auxSVItrainer.train (auxsvi.py:101-127)."""
+        p = (len(loader_sup) + len(loader_unsup)) // len(loader_sup)
+        it_sup = iter(loader_sup)
+        total, count = 0.0, 0
+        for i, (xs,) in enumerate(loader_unsup):
+            total += sum(self.compute_loss(xs, beta=beta, mult=mult))
+            count += xs.shape[0]
+            if i % p == 1:
+                xs, ys = next(it_sup)
+                self.compute_loss(xs, ys, beta=beta, mult=mult)
+        return total / count
+
+    def predict(self, x):
+        with torch.no_grad():
+            out = label_net_forward(self.p, self.cfg, x.to(self.dtype), self.task)
+        return out.argmax(-1) if self.task == "classification" else out
+
+    def evaluate(self, loader_val) -> float:
+        """auxSVItrainer.evaluate_cls / evaluate_reg (auxsvi.py:139-163)."""
+        correct, total = 0.0, 0
+        for data, labels in loader_val:
+            # model.classifier / model.regressor wrap the batch in their own DataLoader (ssivae.py:262-266): creating its
+            # iterator draws a base seed from the global CPU generator, which is part of the run's RNG stream
+            inner = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data), batch_size=100, shuffle=False)
+            pred = torch.cat([self.predict(x_i) for (x_i,) in inner])
+            if self.task == "classification":
+                correct += (pred == labels.argmax(-1)).sum().item()
+                total += data.shape[0]
+            else:
+                correct += F.mse_loss(pred, labels.to(self.dtype)).item()
+                total += 1
+        return correct / total
+
+    def encode(self, x, y):
+        with torch.no_grad():
+            return encoder_forward(self.p, self.cfg, x.to(self.dtype), y.to(self.dtype))
+
+    def decode(self, z, y):
+        return SVIOracle.decode(self, z, y)

@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 4
+PV_ABI_VERSION = 5
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -59,6 +59,7 @@ class pv_ivae_plan(C.Structure):
         ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
         ("alpha", C.c_void_p), ("ext_head", C.c_void_p), ("ext_dhead", C.c_void_p),
         ("ext_encoder", C.c_int32), ("_pad3", C.c_int32),
+        ("row_w", C.c_void_p), ("row_elbo", C.c_void_p), ("dy", C.c_void_p),
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
@@ -80,6 +81,19 @@ class pv_ved_plan(C.Structure):
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
+    ]
+
+
+MLP_OUT = {"linear": 0, "softmax": 1}
+SS_TASK = {"classification": 0, "regression": 1}
+
+
+class pv_mlp_plan(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("in_dim", C.c_int32), ("n_layers", C.c_int32), ("out_kind", C.c_int32),
+        ("layers", pv_layer * PV_MAX_LAYERS), ("out", pv_layer),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("x", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 
@@ -106,6 +120,15 @@ SIGNATURES = {
     "pv_linear_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pv_mlp_workspace_bytes": (C.c_int64, [C.POINTER(pv_mlp_plan)]),
+    "pv_mlp_forward": (C.c_int, [C.POINTER(pv_mlp_plan), C.c_void_p, C.c_void_p]),
+    "pv_mlp_backward": (C.c_int, [C.POINTER(pv_mlp_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_ss_enum_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_ss_aux_loss": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_ss_reg_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "pv_ss_reg_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "pv_transform_coordinates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_void_p]),
 }

@@ -41,9 +41,10 @@ __global__ __launch_bounds__(256) void pv_head_fwd_kernel(PvHead h) {
     if (h.z_loc_out) h.z_loc_out[e] = mu;
     if (h.z_scale_out) h.z_scale_out[e] = sig;
     const float d = z - mu;
+    const float wb = h.w ? h.w[b] : 1.0f;
     // torch.distributions.Normal.log_prob
-    lq += -(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI;
-    lp += -(z * z) / 2.0f - LOG_SQRT_2PI;
+    lq += wb * (-(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI);
+    lp += wb * (-(z * z) / 2.0f - LOG_SQRT_2PI);
   }
   lp = block_sum_256(lp, sm);
   lq = block_sum_256(lq, sm);
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(256) void pv_out_lik_kernel(PvOutLik p) {
       if (p.llrow) p.llrow[row] = ll;
       if (p.loc) p.loc[row] = locv;
     }
+    if (p.sw) dlda *= p.sw[row / p.N];
     if (p.dpre) {
       float* dr = p.dpre + row * p.ldh;
       const float* pr_ = p.hpre ? p.hpre + row * p.ldh : nullptr;
@@ -451,8 +453,9 @@ __device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int 
   const float z = h.z[e], sig = h.z_scale[e], ep = h.eps[e];
   const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
   const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
-  const float g = dz + h.beta * z;                 // d(-ll - beta*log p(z))/dz
-  const float dsig = g * ep - h.beta / sig;        // + beta * d(log q)/d(sigma) (total derivative)
+  const float bw = h.w ? h.beta * h.w[b] : h.beta;
+  const float g = dz + bw * z;                     // d(-ll - beta*log p(z))/dz
+  const float dsig = g * ep - bw / sig;            // + beta * d(log q)/d(sigma) (total derivative)
   const float sgm = h.scale_direct ? 1.0f : (sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp)));   // softplus'
   h.dhead[(int64_t)b * ldh + i] = g;
   h.dhead[(int64_t)b * ldh + h.z_dim + i] = dsig * sgm;
@@ -541,6 +544,41 @@ int pv_scale_rows(float* v, const float* w, int64_t rows, int64_t N, hipStream_t
   return 0;
 }
 
+__global__ void pv_row_elbo_kernel(const float* __restrict__ row_ll, const float* __restrict__ z, const float* __restrict__ head,
+                                   const float* __restrict__ z_scale, int B, int zd, int ldh, float beta, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float kl = 0.0f;
+  for (int i = 0; i < zd; ++i) {
+    const float zz = z[(int64_t)b * zd + i], mu = head[(int64_t)b * ldh + i], sig = z_scale[(int64_t)b * zd + i];
+    const float d = zz - mu;
+    const float lq = -(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI;
+    const float lp = -(zz * zz) / 2.0f - LOG_SQRT_2PI;
+    kl += lp - lq;
+  }
+  out[b] = row_ll[b] + beta * kl;
+}
+int pv_row_elbo(const float* row_ll, const float* z, const float* head, const float* z_scale, int B, int z_dim, int ldh,
+                float beta, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pv_row_elbo_kernel, dim3((B + 63) / 64), dim3(64), 0, s, row_ll, z, head, z_scale, B, z_dim, ldh, beta,
+                     out);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void pv_add_cols_kernel(float* __restrict__ dst, int64_t ldd, const float* __restrict__ src, int64_t lds, int64_t B,
+                                   int n) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * n) return;
+  const int64_t b = e / n;
+  const int i = (int)(e % n);
+  dst[b * ldd + i] += src[b * lds + i];
+}
+int pv_add_cols(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t B, int n, hipStream_t s) {
+  hipLaunchKernelGGL(pv_add_cols_kernel, dim3((unsigned)((B * n + 255) / 256)), dim3(256), 0, s, dst, ldd, src, lds, B, n);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
 // latent_bwd (fused decoder path): one workgroup per sample gathers everything that flows from the decoder
 // kernel back into that sample's latent code: ll_b and d(phi, scale, tx, ty) (sums over the sample's N rows),
 // dL/d(hz[b]) (sum of the workgroup partials), dL/d(z content) = dhz Wz, then head_bwd.  Fixed-order sums.
@@ -603,7 +641,8 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
       ll = 0.0f;
       for (int k = 0; k < K; ++k) ll += p.alpha[(int64_t)b * K + k] * sh_ll[k];
     }
-    p.llb[b] = ll;
+    if (p.row_ll) p.row_ll[b] = ll;
+    p.llb[b] = p.hb.w ? p.hb.w[b] * ll : ll;
     for (int c = 0; c < 4; ++c) sh_tp[c] = tp_acc[c];
   }
   if (p.fwd_only) return;
@@ -615,6 +654,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     if (t == 0) sh_dzc[i] = v;
   }
   __syncthreads();
+  if (p.dzc_out && t < n_content) p.dzc_out[(int64_t)b * p.lat_in + t] = sh_dzc[t];
   if (t < p.hb.z_dim)
     pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; });
   if (p.K > 0 && t == 0) {

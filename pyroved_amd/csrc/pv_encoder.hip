@@ -243,8 +243,9 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       if (e.z_loc_out) e.z_loc_out[(int64_t)row * zd + i] = mu;
       if (e.z_scale_out) e.z_scale_out[(int64_t)row * zd + i] = sig;
       const float d = z - mu;
-      lq += -(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI;      // torch Normal.log_prob
-      lp += -(z * z) / 2.0f - LOG_SQRT_2PI;
+      const float wb = e.w ? e.w[row] : 1.0f;
+      lq += wb * (-(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI);      // torch Normal.log_prob
+      lp += wb * (-(z * z) / 2.0f - LOG_SQRT_2PI);
       act[cur ^ 1][rr][i] = z;                     // keep z for the split below
     }
   }

@@ -18,6 +18,7 @@ struct PvHead {
   float tp0, tp1, sc_prior, beta;
   int ldh;               // row stride of head (0: 2*z_dim)
   int scale_direct;      // 1: the second half of head IS z_scale (external encoder), not its softplus input
+  const float* w;        // (B) per-sample weights of the KL sums (plan->row_w) or null
 };
 int pv_head_fwd(const PvHead& h, hipStream_t s);
 int pv_fill_tp(float* tp, int B, float angle, float sc, float tx, float ty, hipStream_t s);
@@ -51,6 +52,8 @@ struct PvOutLik {
   int64_t M;
   int H, lik, sigmoid_out, act_last;
   float sig;
+  const float* sw;       // per-sample weights of the gradients (row / N indexes it) or null
+  int N;                 // rows per sample (used with sw)
 };
 int pv_out_lik(const PvOutLik& p, hipStream_t s);
 int64_t pv_out_lik_blocks(int64_t M);
@@ -87,6 +90,8 @@ struct PvHeadBwd {
   float tp0, tp1, sc_prior, beta;
   int ldh;               // row stride of head / dhead (0: 2*z_dim)
   int scale_direct;      // 1: head's second half is z_scale itself: dhead's second half = dloss/dz_scale
+  const float* w;        // (B) per-sample weights (plan->row_w): scale the KL terms' derivatives (the decoder's arrive
+                         // weighted already) or null
 };
 int pv_head_bwd(const PvHeadBwd& h, hipStream_t s);
 
@@ -106,12 +111,19 @@ struct PvLatentBwd {
   const float* alpha;    // (B, K)
   float beta_disc;
   int fwd_only;          // 1: only llb (evaluation)
+  float* row_ll;         // optional (B): the unweighted ll_b (llb gets hb.w[b] * ll_b when hb.w is set)
+  float* dzc_out;        // optional (B, lat_in): dL/d(decoder latent input) (content and y columns)
 };
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
 int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, hipStream_t s);
 int pv_jiv_combine(const float* llkb, const float* alpha, float* llb, float* dzc, int ld_dzc, int n_content, float* dhead,
                    int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s);
 int pv_scale_rows(float* v, const float* w, int64_t rows, int64_t N, hipStream_t s);
+// out[b] = row_ll[b] + beta * sum_i (log p(z_bi) - log q(z_bi | x_b))   (mu = head[b*ldh + i])
+int pv_row_elbo(const float* row_ll, const float* z, const float* head, const float* z_scale, int B, int z_dim, int ldh,
+                float beta, float* out, hipStream_t s);
+// dst[b][i] += src[b*lds + i], i < n
+int pv_add_cols(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t B, int n, hipStream_t s);
 struct PvFusedOffsets;
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
                          hipStream_t s);
@@ -168,6 +180,7 @@ struct PvEncFwd {
   // jiVAE (K > 0): head = [mu | softplus input | class logits]; alpha = softmax(logits); tp, zy, hz are written for
   // the K*B decoder samples ordered [k][b] (zy = [z content | onehot(k)]); sw[k*B + b] = alpha[b][k]
   int K; float* alpha; float* sw;
+  const float* w;                   // (B) per-sample weights of the KL partial sums (plan->row_w) or null
   PvFbPrep prep;                    // hosted in the first-layer launch when prep.img is set (bf16x3 decoder path)
 };
 bool pv_enc_compact_supported(const pv_ivae_plan* p);

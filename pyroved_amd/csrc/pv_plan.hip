@@ -42,6 +42,7 @@ struct Layout {
   float* logits; float* llrow; float* llb; float* dbuf[2];
   float* part_dwo; float* part_dbo; float* part_hz; float* part_wc; float* part_tp;
   float* dhz; float* dtp; float* dzc;
+  float* row_ll;                           // (B) unweighted ll_b (plan->row_elbo)
   float* alpha; float* sw; float* llkb;    // jiVAE: class probabilities (B, K), decoder row weights (K*B), ll per (k, b)
   // convolutional encoder (plan->n_enc_ops > 0): activation shapes / buffers, flattened features, gradient ping-pong
   bool enc_ext;                            // external encoder: (z_loc, z_scale) given, gradients handed back
@@ -74,6 +75,8 @@ bool valid_plan(const pv_ivae_plan* p) {
   if (p->n_dec < 1 || p->n_dec > PV_MAX_LAYERS) return false;
   if (p->discrete_dim < 0 || (!p->ext_encoder && p->head.out_dim != plan_head_w(p))) return false;
   if (p->discrete_dim > 0 && p->c_dim != 0) return false;                            // jiVAE: no conditioning vector
+  if ((p->row_w || p->row_elbo || p->dy) && (p->discrete_dim > 0 || p->n_enc_ops > 0 || p->ext_encoder)) return false;
+  if (p->dy && p->c_dim == 0) return false;
   if (p->lik != PV_LIK_BERNOULLI && p->lik != PV_LIK_GAUSSIAN && p->lik != PV_LIK_CBERNOULLI) return false;
   if (p->lik != PV_LIK_GAUSSIAN && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
   if (p->coord_dim > 0 && p->out.out_dim != 1) return false;
@@ -187,6 +190,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
     upd(pv_colsum_ws(S, (int)N));
   }
   L.llb = c.take(B);
+  L.row_ll = c.take(B);
   L.llkb = K > 0 ? c.take(S) : nullptr;
   L.dbuf[0] = L.fused ? nullptr : c.take(R * maxd);
   L.dbuf[1] = L.fused ? nullptr : c.take(R * maxd);
@@ -459,6 +463,37 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
   return 0;
 }
 
+// plan->row_w / row_elbo on the paths that form ll_b with pv_segsum: keep the unweighted ll_b, weight what the loss sums
+int weigh_llb(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+  if (p->row_elbo) {
+    hipError_t e = hipMemcpyAsync(L.row_ll, L.llb, (size_t)p->batch * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (p->row_w) PV_TRY(pv_scale_rows(L.llb, p->row_w, p->batch, 1, s));
+  return 0;
+}
+
+// plan->row_elbo (per-sample ELBO terms) and plan->dy (dloss/dy = the y columns of dL/d(encoder input) and of
+// dL/d(decoder latent input) `dzc`), after the step's other work
+int extra_outputs(const pv_ivae_plan* p, const Layout& L, const float* dzc, int64_t lat_in, hipStream_t s) {
+  const int64_t B = p->batch;
+  if (p->row_elbo)
+    PV_TRY(pv_row_elbo(L.row_ll, L.z, L.head, L.z_scale, (int)B, p->z_dim, (int)plan_head_w(p), p->beta, p->row_elbo, s));
+  if (p->dy && dzc) {
+    const pv_layer& l0 = p->enc[0];
+    const int64_t N = p->n_pix, c = p->c_dim;
+    if (l0.in_dim != N + c) return PV_EINVAL;
+    PvGemm g{};
+    g.A = L.edp[0]; g.a_rs = l0.out_dim; g.a_cs = 1;                         // (B, H)
+    g.B = p->params + l0.w_off + N; g.b_rs = l0.in_dim; g.b_cs = 1;          // B(j, i) = W0[j][N + i]
+    g.C = p->dy; g.ldc = c; g.M = (int)B; g.N = (int)c; g.K = l0.out_dim;
+    g.act = PV_ACT_NONE;
+    PV_TRY(pv_gemm(g, 1, L.scratch, L.scratch_bytes, s));
+    PV_TRY(pv_add_cols(p->dy, c, dzc + (lat_in - c), lat_in, B, (int)c, s));
+  }
+  return 0;
+}
+
 // dL/dz from the decoder (dzc: content/y columns; dtp: phi, scale, tx, ty) -> head -> encoder
 int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, int dtp_sb, int dtp_sc,
                        hipStream_t s) {
@@ -470,8 +505,10 @@ int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, i
   hb.has_r = p->has_r; hb.has_t = p->has_t; hb.has_s = p->has_s;
   hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
   hb.ldh = L.enc_ext ? 0 : (int)plan_head_w(p);
+  hb.w = p->row_w;
   PV_TRY(pv_head_bwd(hb, s));
-  return encoder_bwd(p, L, nullptr, 0, s);
+  PV_TRY(encoder_bwd(p, L, nullptr, 0, s));
+  return extra_outputs(p, L, L.dzc, lat_in, s);
 }
 
 // guide: encoder -> (z_loc, z_scale) -> z = z_loc + z_scale*eps, sampled-KL terms, transform parameters
@@ -491,6 +528,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     e.z_loc_out = p->z_loc; e.z_scale_out = p->z_scale;
     e.tp = p->coord_dim > 0 ? L.tp : nullptr; e.zy = L.zy; e.kl_part = L.kl_part;
     e.beta = p->beta; e.beta_disc = p->beta_disc; e.K = (int)plan_K(p); e.alpha = L.alpha; e.sw = L.sw;
+    e.w = p->row_w;
     if (p->coord_dim > 0) { e.hz = L.hz; e.Wz = p->params + p->fc_latent.w_off; e.H0 = p->fc_coord.out_dim; }
     e.B = p->batch; e.z_dim = p->z_dim; e.c_dim = p->c_dim; e.coord_dim = p->coord_dim;
     e.has_r = p->has_r; e.has_t = p->has_t; e.has_s = p->has_s;
@@ -506,6 +544,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
   h.B = p->batch; h.z_dim = p->z_dim; h.c_dim = p->c_dim; h.coord_dim = p->coord_dim;
   h.has_r = p->has_r; h.has_t = p->has_t; h.has_s = p->has_s;
   h.tp0 = p->t_prior[0]; h.tp1 = p->t_prior[1]; h.sc_prior = p->sc_prior; h.beta = p->beta;
+  h.w = p->row_w;
   return pv_head_fwd(h, s);
 }
 
@@ -531,7 +570,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.llrow = L.llrow; f.loc = p->loc; f.rowtp = L.f_rowtp; f.part_hz = L.f_part_hz; f.part = L.f_part;
   f.wimg = L.f_wimg;
   f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)S; f.lik = p->lik;
-  f.sw = L.sw; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
+  f.sw = K > 0 ? L.sw : p->row_w; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
   // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
   if (p->fused >= 2 && L.enc_compact) {
@@ -562,7 +601,9 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   }
   if (!want_grads) {
     PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
-    return pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s);
+    PV_TRY(weigh_llb(p, L, s));
+    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
+    return extra_outputs(p, L, nullptr, lat_in, s);
   }
   PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
                    p->fc_coord.w_off, p->out.w_off, p->out.b_off};
@@ -580,6 +621,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   hb.tp0 = p->t_prior[0]; hb.tp1 = p->t_prior[1]; hb.sc_prior = p->sc_prior; hb.beta = p->beta;
   hb.ldh = L.enc_ext ? 0 : (int)plan_head_w(p);
   lb.K = (int)K; lb.alpha = L.alpha; lb.beta_disc = p->beta_disc;
+  hb.w = p->row_w; lb.row_ll = p->row_elbo ? L.row_ll : nullptr; lb.dzc_out = p->dy ? L.dzc : nullptr;
   PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s));
   // the loss scalars ride in the encoder dgrad launch (compact encoder) or get their own
   PvFinish fin{L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* scaled */};
@@ -587,7 +629,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
   // (jiVAE: over the K*B decoder samples, zin = [z content | onehot(k)])
   const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
-  return encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr);
+  PV_TRY(encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr));
+  return extra_outputs(p, L, L.dzc, lat_in, s);
 }
 
 int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
@@ -618,6 +661,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
     o.bo = p->out.b_off >= 0 ? p->params + p->out.b_off : nullptr; o.x = p->x; o.loc = p->loc; o.llrow = L.llrow;
     o.dpre = want_grads ? cur : nullptr; o.part_dwo = L.part_dwo; o.part_dbo = L.part_dbo; o.M = R; o.H = Hl;
     o.lik = p->lik; o.sigmoid_out = p->sigmoid_out; o.act_last = p->dec[nd - 1].act; o.sig = p->decoder_sig;
+    o.sw = p->row_w; o.N = (int)N;
     PV_TRY(pv_out_lik(o, s));
   } else {
     // oth <- dL/dlogits (R, N); jiVAE: one pass per enumerated class against the same observations, rows then
@@ -626,6 +670,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
       PV_TRY(pv_lik_elem(L.logits + k * B * N, p->x, B * N, p->lik, p->sigmoid_out, p->decoder_sig,
                          p->loc ? p->loc + k * B * N : nullptr, L.llrow + k * B * N, want_grads ? oth + k * B * N : nullptr, s));
     if (K > 0 && want_grads) PV_TRY(pv_scale_rows(oth, L.sw, R, N, s));
+    if (K == 0 && p->row_w && want_grads) PV_TRY(pv_scale_rows(oth, p->row_w, R, N, s));
   }
   if (K > 0) {
     PV_TRY(pv_segsum(L.llrow, R, N, L.llkb, s));
@@ -633,12 +678,13 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
                                            p->beta_disc, 0, s));
   } else {
     PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
+    PV_TRY(weigh_llb(p, L, s));
   }
   if (K > 0 && want_grads) {
     // (llb is formed by pv_jiv_combine at the end of the decoder backward; the scalars are finished there)
   } else
   PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
-  if (!want_grads) return 0;
+  if (!want_grads) return extra_outputs(p, L, nullptr, lat_in, s);
 
   // ---------------- backward: decoder ----------------
   if (p->coord_dim > 0) {

@@ -278,6 +278,7 @@ class IVAEEngine:
             b0 = b1 = float(beta)
         p.beta, p.beta_disc = b0, b1
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = p.ext_head = p.ext_dhead = None
+        p.row_w = p.row_elbo = p.dy = None
         p.ev_start, p.ev_stop = self.events
         need = _abi.lib().pv_ivae_workspace_bytes(C.byref(p))
         if need < 0:
@@ -299,9 +300,13 @@ class IVAEEngine:
 
     # ------------------------------------------------------------------ calls
     def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
-                       scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None):
+                       scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None,
+                       row_w: Optional[torch.Tensor] = None, row_elbo: Optional[torch.Tensor] = None,
+                       dy: Optional[torch.Tensor] = None):
         """Enqueues Trace_ELBO.loss_and_grads on the current stream.  Results land in
-        self.scalars (device, 4 floats) and self.grad[:n_flat]; nothing is synchronised."""
+        self.scalars (device, 4 floats) and self.grad[:n_flat]; nothing is synchronised.
+        row_w (B): per-sample weights of the ELBO terms; row_elbo (B) / dy (B, c_dim): extra outputs
+        (include/pyroved_amd.h: pv_ivae_plan.row_w / row_elbo / dy)."""
         self.ensure_bound()
         b = x.shape[0]
         p = self._plan(b, beta)
@@ -328,12 +333,22 @@ class IVAEEngine:
             p.loc = loc_out.data_ptr()
         if scalars_out is not None:
             p.scalars = scalars_out.data_ptr()
+        row_w = self._prep(row_w, "row_w", (b,))
+        for t_, name_, shape_ in ((row_elbo, "row_elbo", (b,)), (dy, "dy", (b, p.c_dim))):
+            if t_ is not None:
+                _abi.require_device(t_, name_)
+                if not t_.is_contiguous() or tuple(t_.shape) != shape_:
+                    raise ValueError("%s must be a contiguous float32 tensor of shape %s" % (name_, shape_))
+        p.row_w = row_w.data_ptr() if row_w is not None else None
+        p.row_elbo = row_elbo.data_ptr() if row_elbo is not None else None
+        p.dy = dy.data_ptr() if dy is not None else None
         try:
             _abi.check(_abi.lib().pv_ivae_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),
                        "pv_ivae_loss_and_grads")
         finally:
             p.scalars = self.scalars.data_ptr()
             p.ext_head = p.ext_dhead = None
+            p.row_w = p.row_elbo = p.dy = None
         if self.ext_enc and want_grads:
             zd = p.z_dim
             for q in self._enc_params:
@@ -341,7 +356,7 @@ class IVAEEngine:
             torch.autograd.backward([z_loc, z_scale], [dhead[:, :zd], dhead[:, zd:]])
         if want_grads:
             self.grads_live = True
-        self._keep = (x, eps, y, head, dhead)     # keep inputs alive until the stream has consumed them
+        self._keep = (x, eps, y, head, dhead, row_w)     # keep inputs alive until the stream has consumed them
 
     def adam_step(self):
         """pyro.optim.Adam over every parameter + zero_grads (one fused kernel)."""

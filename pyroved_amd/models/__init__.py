@@ -3,5 +3,6 @@ from .base import baseVAE
 from .ivae import iVAE
 from .jivae import jiVAE
 from .ved import VED
+from .ssivae import ssiVAE, ss_reg_iVAE
 
-__all__ = ['iVAE', 'jiVAE', 'VED']
+__all__ = ['iVAE', 'jiVAE', 'VED', 'ssiVAE', 'ss_reg_iVAE']

@@ -174,3 +174,43 @@ class sDecoderNet(nn.Module):
             "sDecoderNet.forward(x_coord, z) with explicit coordinates is not exposed; decode through "
             "iVAE.decode / baseVAE._decode (pv_ivae_decode), which fuses the coordinate transform into the "
             "decoder's first layer")
+
+
+class fcClassifierNet(nn.Module):
+    """Fully-connected classifier: softmax(out(fc_layers(x))) (pyroved/nets/fc.py:240-271)."""
+    def __init__(self, in_dim: Tuple[int], num_classes: int, hidden_dim: List[int] = None,
+                 activation: str = 'tanh') -> None:
+        super(fcClassifierNet, self).__init__()
+        if len(in_dim) not in [1, 2, 3]:
+            raise ValueError("in_dim must be (h, w), (h, w, c), or (l,)")
+        self.in_dim = _prod(in_dim)
+        if hidden_dim is None:
+            hidden_dim = [128, 128]
+        self.activation = activation
+        self.fc_layers = make_fc_layers(self.in_dim, hidden_dim, activation)
+        self.out = nn.Linear(hidden_dim[-1], num_classes)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.reshape(-1, self.in_dim)
+        h = _run_stack(self.fc_layers, self.activation, x)
+        return torch.softmax(ops.linear_act(h, self.out.weight, self.out.bias, None), dim=-1)
+
+
+class fcRegressorNet(nn.Module):
+    """Fully-connected regressor: out(fc_layers(x)) (pyroved/nets/fc.py:274-304)."""
+    def __init__(self, in_dim: Tuple[int], c_dim: int, hidden_dim: List[int] = None,
+                 activation: str = 'tanh') -> None:
+        super(fcRegressorNet, self).__init__()
+        if len(in_dim) not in [1, 2, 3]:
+            raise ValueError("in_dim must be (h, w), (h, w, c), or (l,)")
+        self.in_dim = _prod(in_dim)
+        if hidden_dim is None:
+            hidden_dim = [128, 128]
+        self.activation = activation
+        self.fc_layers = make_fc_layers(self.in_dim, hidden_dim, activation)
+        self.out = nn.Linear(hidden_dim[-1], c_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.reshape(-1, self.in_dim)
+        h = _run_stack(self.fc_layers, self.activation, x)
+        return ops.linear_act(h, self.out.weight, self.out.bias, None)

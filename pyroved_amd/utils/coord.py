@@ -62,3 +62,39 @@ def transform_coordinates(coord: torch.Tensor,
         _abi.ptr(base), n, cd, _abi.ptr(phi_t), _abi.ptr(dx_t), _abi.ptr(sc_t), b, _abi.ptr(out),
         _abi.current_stream()), "pv_transform_coordinates")
     return out
+
+
+def generate_latent_grid(d, **kwargs):
+    """Grid of 2-D latent coordinates (pyroved/utils/coord.py:91-109): inverse normal CDF of linspace(0.05, 0.95)
+    unless z_coord=[z1, z2, z3, z4] is given.  Returns (z (d0*d1, 2), (grid_x, grid_y))."""
+    import torch.distributions as td
+    if isinstance(d, int):
+        d = [d, d]
+    z_coord = kwargs.get("z_coord")
+    if z_coord:
+        z1, z2, z3, z4 = z_coord
+        grid_x = torch.linspace(z2, z1, d[0])
+        grid_y = torch.linspace(z3, z4, d[1])
+    else:
+        grid_x = td.Normal(0, 1).icdf(torch.linspace(0.95, 0.05, d[0]))
+        grid_y = td.Normal(0, 1).icdf(torch.linspace(0.05, 0.95, d[1]))
+    z = [torch.tensor([xi, yi]).float().unsqueeze(0) for xi in grid_x for yi in grid_y]
+    return torch.cat(z), (grid_x, grid_y)
+
+
+def generate_latent_grid_traversal(d: int, cont_dim: int, disc_dim: int, cont_idx: int, cont_idx_fixed: int,
+                                   num_samples: int):
+    """Continuous and discrete grids for a latent-space traversal (pyroved/utils/coord.py:112-133)."""
+    import torch.distributions as td
+    samples_cont = torch.zeros(size=(num_samples, cont_dim)) + cont_idx_fixed
+    cont_traversal = td.Normal(0, 1).icdf(torch.linspace(0.95, 0.05, d))
+    for i in range(d):
+        for j in range(d):
+            samples_cont[i * d + j, cont_idx] = cont_traversal[j]
+    n = torch.arange(0, disc_dim).tile(d // disc_dim + 1)[:d]
+    samples_disc = []
+    for i in range(d):
+        block = torch.zeros((d, disc_dim))
+        block[:, n[i]] = 1
+        samples_disc.append(block)
+    return samples_cont, torch.cat(samples_disc)

@@ -21,3 +21,11 @@ def init_dataloader(*args: torch.Tensor,
             dataset=tensor_set, batch_size=batch_size, sampler=sampler, generator=generator_)
     return torch.utils.data.DataLoader(
         dataset=tensor_set, batch_size=batch_size, shuffle=shuffle, generator=generator_)
+
+
+def init_ssvae_dataloaders(data_unsup: torch.Tensor, data_sup, data_val, **kwargs: int):
+    """Dataloaders for the semi-supervised models (pyroved/utils/data.py:41-52): unlabeled, labeled, validation."""
+    loader_unsup = init_dataloader(data_unsup, **kwargs)
+    loader_sup = init_dataloader(*data_sup, sampler=True, **kwargs)
+    loader_val = init_dataloader(*data_val, **kwargs)
+    return loader_unsup, loader_sup, loader_val

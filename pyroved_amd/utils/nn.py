@@ -81,3 +81,15 @@ def activation_name(module: nn.Module) -> str:
         if isinstance(module, cls):
             return name
     raise NotImplementedError("unsupported activation module %r" % (module,))
+
+
+def average_weights(ensemble):
+    """Averages the weights of all state_dicts in the ensemble {epoch: state_dict} (pyroved/utils/nn.py:11-34);
+    batch-norm statistics are taken from the first one."""
+    from copy import deepcopy as dc
+    ensemble = {k - min(ensemble.keys()): v for (k, v) in ensemble.items()}
+    out = dc(ensemble[0])
+    for name in [n for n in out.keys() if n.split('_')[-1] not in ["mean", "var", "tracked"]]:
+        ws = [dc(sd[name]) for sd in ensemble.values() if name in sd]
+        out[name].copy_(sum(ws) / float(len(ws)))
+    return out

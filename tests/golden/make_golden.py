@@ -279,6 +279,113 @@ def run_ved_steps(name, input_dim, output_dim, batch, steps=3, latent_dim=2, mod
     print("wrote", name, "loss0=%.6f" % out["s0.loss"], "keys=%d" % len(out))
 
 
+def _ss_data(task, n_u, n_s, data_dim, dim):
+    """Flattened inputs as the reference's own trainer tests feed them (tests/test_trainers.py:57-75)."""
+    g = torch.Generator().manual_seed(0)
+    n_pix = int(np.prod(data_dim))
+    xu = torch.rand(n_u, n_pix, generator=g)
+    xs = torch.rand(n_s, n_pix, generator=g)
+    if task == "classification":
+        ys = utils.to_onehot(torch.arange(n_s) % dim, dim)
+    else:
+        ys = torch.randn(n_s, dim, generator=g)
+    return xu, xs, ys
+
+
+def run_ss(name, task, data_dim, invariances, dim, batch_u, batch_s, rounds=2, latent_dim=2, epochs=2, n_u=7, n_s=4,
+           step_kw=None, model_kw=None):
+    """ssiVAE (models/ssivae.py) / ss_reg_iVAE (models/ss_reg_ivae.py) through auxSVItrainer (trainers/auxsvi.py):
+    `rounds` x [compute_loss(unlabeled batch), compute_loss(labeled batch)] with everything recorded, then
+    auxSVItrainer.step epochs on small loaders, then the inference API."""
+    step_kw = dict(step_kw or {})
+    model_kw = dict(model_kw or {})
+    cls = task == "classification"
+    out = {"meta.task": np.array(task), "meta.data_dim": np.array(data_dim),
+           "meta.invariances": np.array("".join(invariances) if invariances else ""),
+           "meta.dim": np.int64(dim), "meta.latent_dim": np.int64(latent_dim), "meta.rounds": np.int64(rounds),
+           "meta.batch_u": np.int64(batch_u), "meta.batch_s": np.int64(batch_s), "meta.epochs": np.int64(epochs),
+           "meta.n_u": np.int64(n_u), "meta.n_s": np.int64(n_s),
+           "meta.scale_factor": np.float64(step_kw.get("scale_factor", 1.0)),
+           "meta.aux_loss_multiplier": np.float64(step_kw.get("aux_loss_multiplier", 20.0))}
+    for k, v in model_kw.items():
+        out["meta.model_kw." + k] = np.array(v)
+
+    def build():
+        ctor = models.ssiVAE if cls else models.ss_reg_iVAE
+        m = ctor(data_dim, latent_dim, dim, invariances, seed=1, device="cpu", **model_kw)
+        t = trainers.auxSVItrainer(m, task=task, seed=1, device="cpu")
+        return m, t
+    model, trainer = build()
+    names = {id(p): n for n, p in model.named_parameters()}
+    for n, p in model.named_parameters():
+        put(out, "init." + n, digest(p))
+    xu, xs, ys = _ss_data(task, max(n_u, batch_u), max(n_s, batch_s), data_dim, dim)
+    out["xu"], out["xs"], out["ys"] = xu.numpy().copy(), xs.numpy().copy(), ys.numpy().copy()
+    optim = trainer.loss_basic.optim
+    assert trainer.loss_aux.optim is optim
+    call = 0
+    for r in range(rounds):
+        for kind in ("u", "s"):
+            args = (xu[:batch_u],) if kind == "u" else (xs[:batch_s], ys[:batch_s])
+            pre = "c%d" % call
+            out[pre + ".kind"] = np.array(kind)
+            # the two SVI steps of compute_loss (auxsvi.py:88-99), with the optimizer spied on
+            for which, svi in (("elbo", trainer.loss_basic), ("aux", trainer.loss_aux)):
+                grads = {}
+
+                def spy(params, _g=grads):
+                    for q in params:
+                        if q.grad is not None:
+                            _g[names[id(q)]] = q.grad.detach().clone()
+                    optim(params)
+                svi.optim = spy
+                loss = svi.step(*(args if len(args) == 2 else (args[0], None)), **step_kw)
+                svi.optim = optim
+                tap = _minipyro.tap()
+                out["%s.%s.loss" % (pre, which)] = np.float64(loss)
+                if which == "elbo":
+                    out[pre + ".eps"] = tap["z.eps"].numpy().copy()
+                    if not cls and kind == "u":
+                        out[pre + ".eps_y"] = tap["y.eps"].numpy().copy()
+                    if cls and kind == "u":
+                        out[pre + ".alpha"] = tap["enum_weights"].t().numpy().copy()
+                    terms = tap["enum_terms"] if (cls and kind == "u") else tap["terms"]
+                    for tn, tv in terms.items():
+                        out["%s.term.%s" % (pre, tn)] = np.float64(tv.item())
+                for n, gr in grads.items():
+                    put(out, "%s.%s.grad.%s" % (pre, which, n), digest(gr))
+            for n, q in model.named_parameters():
+                put(out, pre + ".param." + n, digest(q))
+            call += 1
+    out["meta.calls"] = np.int64(call)
+    # inference API on the trained model
+    if cls:
+        z_loc, z_scale, y_pred = model.encode(xu[:batch_u])
+        out["enc.y_pred"] = y_pred.numpy().copy()
+        out["cls.pred"] = model.classifier(xs).numpy().copy()
+        yy = utils.to_onehot(torch.arange(batch_u) % dim, dim)
+    else:
+        z_loc, z_scale, y_hat = model.encode(xu[:batch_u])
+        out["enc.y"] = y_hat.numpy().copy()
+        out["reg.pred"] = model.regressor(xs).numpy().copy()
+        yy = ys[:1].expand(batch_u, dim).contiguous()
+    out["enc.z_loc"], out["enc.z_scale"] = z_loc.numpy().copy(), z_scale.numpy().copy()
+    out["dec.y"] = yy.numpy().copy()
+    out["dec.loc"] = model.decode(z_loc[:, -latent_dim:], yy).numpy().copy()
+    # epochs through auxSVItrainer.step on loaders (fresh model: pins loader / RNG order, auxsvi.py:101-127)
+    model, trainer = build()
+    lu, ls, lv = utils.init_ssvae_dataloaders(xu[:n_u], (xs[:n_s], ys[:n_s]), (xs[:n_s], ys[:n_s]), batch_size=batch_s)
+    for _ in range(epochs):
+        trainer.step(lu, ls, lv, **step_kw)
+    out["epochs.training_loss"] = np.array(trainer.history["training_loss"], dtype=np.float64)
+    out["epochs.test"] = np.array([float(v) for v in trainer.history["test"]], dtype=np.float64)
+    for pn, q in model.named_parameters():
+        put(out, "final." + pn, digest(q))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "c0 elbo=%.6f aux=%.6f" % (out["c0.elbo.loss"], out["c0.aux.loss"]),
+          "epochs", out["epochs.training_loss"], out["epochs.test"], "keys=%d" % len(out))
+
+
 def run_step0_loc(name, data_dim, invariances, batch, latent_dim=2, xkind="rand"):
     """Step-0 forward only, with the decoder's `loc` and the transformed grid."""
     out = {}
@@ -404,6 +511,21 @@ if __name__ == "__main__":
         small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])
         run_ved_steps("ved_16x16_to_8x12_small_b4", (16, 16), (8, 12), batch=4, model_kw=small)     # bilinear upsampling
         run_ved_steps("ved_1d32_to_16x16_small_b3", (32,), (16, 16), batch=3, model_kw=small)
+    # semi-supervised models through auxSVItrainer
+    if only is None or "ss" in only:
+        run_ss("sscls_8x8_rt_k3", "classification", (8, 8), ["r", "t"], 3, batch_u=4, batch_s=3)
+        run_ss("sscls_8x8_none_k3", "classification", (8, 8), None, 3, batch_u=4, batch_s=3)
+        run_ss("sscls_8x8_rts_k4_sf", "classification", (8, 8), ["r", "t", "s"], 4, batch_u=3, batch_s=2,
+               step_kw={"scale_factor": 2.0, "aux_loss_multiplier": 50})
+        run_ss("sscls_1d16_t_k2", "classification", (16,), ["t"], 2, batch_u=5, batch_s=3)
+        run_ss("sscls_28x28_r_k10", "classification", (28, 28), ["r"], 10, batch_u=16, batch_s=8, rounds=1, epochs=1,
+               n_u=16, n_s=8)
+        run_ss("ssreg_8x8_rt_c2", "regression", (8, 8), ["r", "t"], 2, batch_u=4, batch_s=3)
+        run_ss("ssreg_8x8_none_c1", "regression", (8, 8), None, 1, batch_u=4, batch_s=3)
+        run_ss("ssreg_8x8_rts_c2_sf", "regression", (8, 8), ["r", "t", "s"], 2, batch_u=3, batch_s=2,
+               step_kw={"scale_factor": 3.0, "aux_loss_multiplier": 5})
+        run_ss("ssreg_28x28_r_c2", "regression", (28, 28), ["r"], 2, batch_u=16, batch_s=8, rounds=1, epochs=1,
+               n_u=16, n_s=8)
     if only is not None:
         sys.exit(0)
     # epoch loops through the reference SVItrainer + DataLoader

@@ -282,3 +282,91 @@ def test_convenc_oracle_steps_match_reference(name):
             check_digest(o.p[n], gold, pre + ".param." + n, rtol=1e-5, atol=1e-6, what=name)
     z_loc, z_scale = o.encode(x)
     np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# semi-supervised models (ssiVAE / ss_reg_iVAE through auxSVItrainer): fixtures produced by the reference's own
+# models/ssivae.py, models/ss_reg_ivae.py and trainers/auxsvi.py
+SS_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ss*_*.npz")))
+
+
+def test_ss_fixture_inventory():
+    assert len(SS_CASES) >= 9
+
+
+@pytest.mark.parametrize("name", SS_CASES)
+def test_ss_oracle_matches_reference(name):
+    from conftest import ssmeta_of, ss_build
+    gold = load_golden(name)
+    meta = ssmeta_of(gold)
+    model = ss_build(meta, "cpu")
+    keys = [k[len("init."):-len(".sum")] for k in gold if k.startswith("init.") and k.endswith(".sum")]
+    assert sorted(keys) == sorted(model.state_dict().keys())
+    for k, p in model.state_dict().items():
+        check_digest(p, gold, "init." + k, rtol=0, atol=0, what=name)
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     c_dim=meta["dim"])
+    o = orc.SSOracle(model.state_dict(), cfg, meta["task"])
+    xu, xs, ys = (torch.from_numpy(gold[k]) for k in ("xu", "xs", "ys"))
+    for c in range(meta["calls"]):
+        pre = "c%d" % c
+        unl = str(gold[pre + ".kind"]) == "u"
+        x = xu[:meta["batch_u"]] if unl else xs[:meta["batch_s"]]
+        y = None if unl else ys[:meta["batch_s"]]
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eps_y = torch.from_numpy(gold[pre + ".eps_y"]) if (pre + ".eps_y") in gold else None
+        l1, l2 = o.compute_loss(x, y, eps, eps_y, meta["beta"], meta["mult"])
+        np.testing.assert_allclose(l1, float(gold[pre + ".elbo.loss"]), rtol=3e-6 if c == 0 else 1e-4)
+        np.testing.assert_allclose(l2, float(gold[pre + ".aux.loss"]), rtol=3e-6 if c < 2 else 2e-3, atol=1e-12)
+        if (pre + ".alpha") in gold:
+            np.testing.assert_allclose(o.last["alpha"].detach().numpy(), gold[pre + ".alpha"], rtol=1e-5, atol=1e-7)
+        for which in ("elbo", "aux"):
+            for key in o.p:
+                gk = "%s.%s.grad.%s" % (pre, which, key)
+                g = o.last_grads[which][key]
+                if gk + ".sum" in gold:
+                    # from the second call on the two runs stand on parameters that differ by Adam's noise-decided entries
+                    check_digest(g, gold, gk, rtol=3e-4 if c == 0 else 5e-3, atol=2e-7, what=name)
+                else:
+                    assert g is None, "%s: oracle has a gradient the reference run did not" % gk
+        for key in o.p:
+            # (5e-4 = lr: up to ~10 noise-decided entries per 100k may land on the other side of Adam's first steps)
+            check_digest(o.p[key], gold, pre + ".param." + key, rtol=2e-5, atol=1.1e-3, what=name,
+                         sum_slack=1e-2 * 5e-4 * o.p[key].numel() ** 0.5)
+    # inference API
+    if meta["task"] == "classification":
+        np.testing.assert_array_equal(o.predict(xs).numpy(), gold["cls.pred"])
+        yq = pv.utils.to_onehot(torch.from_numpy(gold["enc.y_pred"]), meta["dim"])
+    else:
+        np.testing.assert_allclose(o.predict(xs).numpy(), gold["reg.pred"], rtol=1e-4, atol=1e-6)
+        yq = torch.from_numpy(gold["enc.y"])
+    z_loc, z_scale = o.encode(xu[:meta["batch_u"]], yq)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(z_scale.numpy(), gold["enc.z_scale"], rtol=1e-4, atol=1e-6)
+    dec = o.decode(torch.from_numpy(gold["enc.z_loc"])[:, -meta["latent_dim"]:], torch.from_numpy(gold["dec.y"]))
+    np.testing.assert_allclose(dec.numpy().reshape(gold["dec.loc"].shape), gold["dec.loc"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", SS_CASES)
+def test_ss_oracle_epochs_match_reference_trainer(name):
+    """auxSVItrainer.step epochs (loader order, the interleaving of labeled batches, RNG stream, test metric)."""
+    from conftest import ssmeta_of, ss_build
+    gold = load_golden(name)
+    meta = ssmeta_of(gold)
+    model = ss_build(meta, "cpu")
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     c_dim=meta["dim"])
+    xu, xs, ys = (torch.from_numpy(gold[k]) for k in ("xu", "xs", "ys"))
+    pv.utils.set_deterministic_mode(1)                   # auxSVItrainer.__init__ re-seeds (auxsvi.py:60)
+    o = orc.SSOracle(model.state_dict(), cfg, meta["task"])
+    lu, ls, lv = pv.utils.init_ssvae_dataloaders(xu[:meta["n_u"]], (xs[:meta["n_s"]], ys[:meta["n_s"]]),
+                                                 (xs[:meta["n_s"]], ys[:meta["n_s"]]), batch_size=meta["batch_s"])
+    tr, te = [], []
+    for _ in range(meta["epochs"]):
+        tr.append(o.train_epoch(lu, ls, meta["beta"], meta["mult"]))
+        te.append(o.evaluate(lv))
+    np.testing.assert_allclose(tr, gold["epochs.training_loss"], rtol=1e-5)
+    np.testing.assert_allclose(te, gold["epochs.test"], rtol=1e-4, atol=1e-7)
+    for key in o.p:      # (after several Adam steps: noise-decided entries, see above)
+        check_digest(o.p[key], gold, "final." + key, rtol=1e-4, atol=1.1e-3, what=name,
+                     sum_slack=1e-2 * 5e-4 * o.p[key].numel() ** 0.5)
