@@ -1,0 +1,168 @@
+"""
+auxsvi.py — SVI trainer for variational models with auxiliary losses; host-side mirror of
+pyroved/trainers/auxsvi.py:14-225 (same constructor, compute_loss / train / evaluate / step / save_running_weights /
+average_weights / print_statistics, history, current_epoch).
+
+What the reference delegates to Pyro — two SVI objects sharing one optimizer: SVI(model.model, guide, Adam,
+TraceEnum_ELBO | Trace_ELBO) and SVI(model.model_aux, model.guide_aux, Adam, Trace_ELBO) (auxsvi.py:60-84) — is executed
+by the HIP library through engine_ss.SSEngine: per compute_loss call the ELBO step (loss + gradients + Adam) and the
+auxiliary step (loss + gradients + Adam).  As in the reference, the auxiliary step of an UNLABELED batch has no loss
+and no gradient but still runs the optimizer over every parameter (pyro.module registers them all in model_aux, and
+zero_grads leaves zero tensors): a momentum-only Adam step.
+
+RNG contract: the trainer re-seeds in its constructor and draws the guide's noise on the global CPU generator in the
+guide's order (classification: one (K, B, z_dim) draw for an unlabeled batch; regression: the label's (B, reg_dim) draw,
+then (B, z_dim)), so the same seed yields the reference's CPU stream.
+"""
+from collections import OrderedDict
+from copy import deepcopy as dc
+from typing import Type, Optional, Union, Dict
+
+import torch
+import torch.nn as nn
+
+from ..utils import set_deterministic_mode, average_weights
+from .. import dist as pvdist
+
+
+class auxSVItrainer:
+    """
+    SVI trainer for variational models with auxiliary losses (models.ssiVAE, models.ss_reg_iVAE).
+
+    Args:
+        model: initialized model
+        task: "classification" (models.ssiVAE) or "regression" (models.ss_reg_iVAE)
+        optimizer: None (Adam, lr 5e-4) or a dict of Adam arguments {"lr", "betas", "eps"}
+        seed: enforces reproducibility
+
+    Keyword Args:
+        lr: learning rate (Default: 5e-4)
+        device: device of the model (defaults to the model's)
+        precision / fused: as in trainers.SVItrainer
+    """
+    def __init__(self, model: Type[nn.Module], task: str = "classification", optimizer=None, seed: int = 1,
+                 **kwargs: Union[str, float]) -> None:
+        set_deterministic_mode(seed)
+        if task not in ["classification", "regression"]:
+            raise ValueError("Choose between 'classification' and 'regression' tasks")
+        self.task = task
+        self.device = kwargs.get("device", model.device)
+        adam = {"lr": kwargs.get("lr", 5e-4), "betas": (0.9, 0.999), "eps": 1e-8}
+        if optimizer is not None:
+            if not isinstance(optimizer, dict):
+                raise TypeError("optimizer must be None or a dict of Adam arguments (Pyro optimizer objects "
+                                "cannot be used: Pyro is not a dependency of this build)")
+            adam.update(optimizer)
+        if pvdist.world(kwargs.get("process_group", None))[1] > 1:
+            raise NotImplementedError("auxSVItrainer is single-process in this build (trainers.SVItrainer is data-parallel)")
+        precision = kwargs.get("precision", "fp32")
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16' (got %r)" % (precision,))
+        self.model = model
+        self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
+                                   fused=int(kwargs.get("fused", 3 if precision == "bf16" else 2)))
+        if self.engine.task != task:
+            raise ValueError("task=%r does not match the model's label network (%s)" % (task, self.engine.task))
+        self.engine.lr, self.engine.betas, self.engine.adam_eps = float(adam["lr"]), tuple(adam["betas"]), float(adam["eps"])
+        self.history = {"training_loss": [], "test": []}
+        self.current_epoch = 0
+        self.running_weights = {}
+
+    def compute_loss(self, xs: torch.Tensor, ys: Optional[torch.Tensor] = None, **kwargs: float) -> float:
+        """Computes the basic (ELBO) and the auxiliary loss and takes the two optimizer steps (auxsvi.py:88-99)."""
+        eng, m = self.engine, self.model
+        beta = kwargs.get("scale_factor", 1.)
+        mult = kwargs.get("aux_loss_multiplier", 20)
+        b = xs.shape[0]
+        xs = xs.to(eng.device, torch.float32).reshape(b, -1)
+        if ys is not None:
+            ys = ys.to(eng.device, torch.float32)
+        eps_y = None
+        if self.task == "classification":
+            shape = (m.num_classes, b, m.z_dim) if ys is None else (b, m.z_dim)
+        else:
+            if ys is None:
+                eps_y = torch.empty(b, m.reg_dim).normal_().to(eng.device)
+            shape = (b, m.z_dim)
+        eps = torch.empty(shape).normal_().to(eng.device)
+        loss = eng.elbo_loss_and_grads(xs, eps, ys, eps_y, beta)
+        eng.adam_step()
+        if ys is not None:
+            loss = loss + eng.aux_loss_and_grads(xs, ys, mult)
+        if eng.grads_live:                       # (no parameter has a .grad before the very first backward)
+            eng.adam_step()
+        return float(loss.item())
+
+    def train(self, loader_unsup, loader_sup, **kwargs: float) -> float:
+        """Train a single epoch (auxsvi.py:101-127)."""
+        sup_batches = len(loader_sup)
+        unsup_batches = len(loader_unsup)
+        p = (sup_batches + unsup_batches) // sup_batches
+        loader_sup = iter(loader_sup)
+        epoch_loss = 0.
+        unsup_count = 0
+        for i, (xs,) in enumerate(loader_unsup):
+            epoch_loss += self.compute_loss(xs, **kwargs)
+            unsup_count += xs.shape[0]
+            if i % p == 1:
+                xs, ys = next(loader_sup)
+                _ = self.compute_loss(xs, ys, **kwargs)
+        return epoch_loss / unsup_count
+
+    def evaluate(self, loader_val) -> float:
+        """Evaluates the model's current state on labeled test data (auxsvi.py:129-163)."""
+        if self.task == "classification":
+            return self.evaluate_cls(loader_val)
+        return self.evaluate_reg(loader_val)
+
+    def evaluate_cls(self, loader_val) -> float:
+        correct, total = 0, 0
+        for data, labels in loader_val:
+            predicted = self.model.classifier(data)
+            _, lab_idx = torch.max(labels.cpu(), 1)
+            correct += (predicted == lab_idx).sum().item()
+            total += data.size(0)
+        return correct / total
+
+    def evaluate_reg(self, loader_val) -> float:
+        correct, total = 0, 0
+        for data, gt in loader_val:
+            predicted = self.model.regressor(data)
+            correct += nn.functional.mse_loss(predicted, gt.cpu())
+            total += 1
+        return correct / total
+
+    def step(self, loader_unsup, loader_sup, loader_val=None, **kwargs: float) -> None:
+        """Single train (and evaluation, if any) step (auxsvi.py:165-194).  kwargs: scale_factor (KL scale, default 1),
+        aux_loss_multiplier (default 20)."""
+        train_loss = self.train(loader_unsup, loader_sup, **kwargs)
+        self.history["training_loss"].append(train_loss)
+        if loader_val is not None:
+            self.history["test"].append(self.evaluate(loader_val))
+        self.current_epoch += 1
+
+    def save_running_weights(self, net: str) -> None:
+        """Saves the running weights of the specified network, e.g. "encoder_y" (auxsvi.py:196-205)."""
+        net = getattr(self.model, net)
+        state_dict_ = OrderedDict()
+        for k, v in net.state_dict().items():
+            state_dict_[k] = dc(v).cpu()
+        self.running_weights[self.current_epoch] = state_dict_
+
+    def average_weights(self, net: str) -> Dict[int, Dict[str, torch.Tensor]]:
+        """Updates the selected network with the average of the saved weights (auxsvi.py:207-213)."""
+        net = getattr(self.model, net)
+        net.load_state_dict(average_weights(self.running_weights))
+
+    def print_statistics(self) -> None:
+        """Prints training loss and test metric (if any) of the current epoch (auxsvi.py:215-225)."""
+        e = self.current_epoch
+        if len(self.history["test"]) > 0:
+            if self.task == "classification":
+                template = 'Epoch: {} Training loss: {:.4f}, Test accuracy: {:.4f}'
+            else:
+                template = 'Epoch: {} Training loss: {:.4f}, Test MSE: {:.4f}'
+            print(template.format(e, self.history["training_loss"][-1], self.history["test"][-1]))
+        else:
+            template = 'Epoch: {} Training loss: {:.4f}'
+            print(template.format(e, self.history["training_loss"][-1]))

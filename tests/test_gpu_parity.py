@@ -653,6 +653,116 @@ def test_bf16_mode_trainer_tracks_fp32(gpu_device):
     np.testing.assert_allclose(hist["bf16"], hist["fp32"], rtol=1e-3)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# semi-supervised models through the C ABI: pv_ivae_loss_and_grads (row weights / per-row ELBO / dy), pv_mlp_*, pv_ss_*
+SS_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ss*_*.npz")))
+
+
+def _ss_grad_tol(key, task):
+    # the label network's gradient in the enumerated pass is a difference of K nearly equal per-class terms (as for
+    # jiVAE's class logits): cancellation amplifies the summation-order noise of the decoder's ll sums
+    if key.startswith("encoder_y."):
+        return 2e-3 if task == "classification" else 3e-4
+    return 3e-4
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+@pytest.mark.parametrize("name", SS_CASES)
+def test_ss_compute_loss_vs_golden_and_oracle(gpu_device, name, fused):
+    """auxSVItrainer.compute_loss call by call (unlabeled, labeled, ...): both losses vs the fixture produced by the
+    reference's own ssiVAE / ss_reg_iVAE / auxSVItrainer code, the gradients of both SVI steps vs the CPU oracle from
+    identical parameters, the parameters after both Adam updates; then the inference API."""
+    from conftest import ssmeta_of, ss_build
+    gold = load_golden(name)
+    meta = ssmeta_of(gold)
+    model = ss_build(meta, "cuda")
+    eng = model.engine(lr=5e-4, fused=fused)
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     c_dim=meta["dim"])
+    o = orc.SSOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg, meta["task"])
+    xu, xs, ys = (torch.from_numpy(gold[k]) for k in ("xu", "xs", "ys"))
+    lr = 5e-4
+    for c in range(meta["calls"]):
+        pre = "c%d" % c
+        unl = str(gold[pre + ".kind"]) == "u"
+        x = xu[:meta["batch_u"]] if unl else xs[:meta["batch_s"]]
+        y = None if unl else ys[:meta["batch_s"]]
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eps_y = torch.from_numpy(gold[pre + ".eps_y"]) if (pre + ".eps_y") in gold else None
+        l1o, l2o = o.compute_loss(x, y, eps, eps_y, meta["beta"], meta["mult"])
+        # --- product: the ELBO step
+        loss = eng.elbo_loss_and_grads(x.cuda(), eps.cuda(), None if y is None else y.cuda(),
+                                       None if eps_y is None else eps_y.cuda(), meta["beta"])
+        np.testing.assert_allclose(loss.item(), l1o, rtol=2e-5)
+        if c == 0:
+            np.testing.assert_allclose(loss.item(), float(gold[pre + ".elbo.loss"]), rtol=2e-5)
+        for key in o.p:
+            g, go = eng.grad_of(key), o.last_grads["elbo"][key]
+            if go is None:
+                assert float(g.abs().max()) == 0.0, key
+                continue
+            err = rel_l2(g, go)
+            assert err < _ss_grad_tol(key, meta["task"]), "call %d elbo grad %s: rel l2 %.3e" % (c, key, err)
+        eng.adam_step()
+        # --- the auxiliary step
+        if y is not None:
+            aux = eng.aux_loss_and_grads(x.cuda(), y.cuda(), meta["mult"])
+            np.testing.assert_allclose(aux.item(), l2o, rtol=2e-5)
+            if c == 1:
+                np.testing.assert_allclose(aux.item(), float(gold[pre + ".aux.loss"]), rtol=1e-4)
+            for key in o.p:
+                g, go = eng.grad_of(key), o.last_grads["aux"][key]
+                if key.startswith("encoder_y."):
+                    assert rel_l2(g, go) < 1e-4, "call %d aux grad %s" % (c, key)
+                else:
+                    assert float(g.abs().max()) == 0.0, key
+        eng.adam_step()
+        for key, p in model.state_dict().items():
+            pc, pr = p.detach().cpu(), o.p[key].detach()
+            d = (pc - pr).abs()
+            assert d.max().item() <= 4.2 * lr, key                     # two Adam steps: |dp| <= 2 * lr / (1 - beta1)... early on
+            assert (d > 1e-6 + 1e-4 * pr.abs()).float().mean().item() < 0.02, "%s: too many entries off" % key
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+    # inference API against the oracle on the synchronised parameters
+    if meta["task"] == "classification":
+        np.testing.assert_array_equal(model.classifier(xs).numpy(), o.predict(xs).numpy())
+        z_loc, z_scale, y_pred = model.encode(xu[:meta["batch_u"]])
+        yq = pv.utils.to_onehot(y_pred, meta["dim"])
+    else:
+        np.testing.assert_allclose(model.regressor(xs).numpy(), o.predict(xs).numpy(), rtol=1e-4, atol=2e-6)
+        z_loc, z_scale, yq = model.encode(xu[:meta["batch_u"]])
+    zo, so = o.encode(xu[:meta["batch_u"]], yq)
+    np.testing.assert_allclose(z_loc.numpy(), zo.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z_scale.numpy(), so.numpy(), rtol=1e-4, atol=5e-6)
+    yd = torch.from_numpy(gold["dec.y"])
+    dec = model.decode(z_loc[:, -meta["latent_dim"]:], yd)
+    deo = o.decode(z_loc[:, -meta["latent_dim"]:], yd)
+    np.testing.assert_allclose(dec.numpy().reshape(deo.shape), deo.numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", [n for n in SS_CASES if "28x28" not in n])
+def test_ss_trainer_epochs_vs_golden(gpu_device, name):
+    """auxSVItrainer.step epochs through the reference API (loaders, interleaved labeled batches, CPU RNG stream, test
+    metric) against the reference trainer's recorded history."""
+    from conftest import ssmeta_of, ss_build
+    gold = load_golden(name)
+    meta = ssmeta_of(gold)
+    model = ss_build(meta, "cuda")
+    trainer = pv.trainers.auxSVItrainer(model, task=meta["task"], seed=1)
+    xu, xs, ys = (torch.from_numpy(gold[k]) for k in ("xu", "xs", "ys"))
+    lu, ls, lv = pv.utils.init_ssvae_dataloaders(xu[:meta["n_u"]], (xs[:meta["n_s"]], ys[:meta["n_s"]]),
+                                                 (xs[:meta["n_s"]], ys[:meta["n_s"]]), batch_size=meta["batch_s"])
+    kw = {"scale_factor": meta["beta"], "aux_loss_multiplier": meta["mult"]}
+    for _ in range(meta["epochs"]):
+        trainer.step(lu, ls, lv, **kw)
+    np.testing.assert_allclose(trainer.history["training_loss"], gold["epochs.training_loss"], rtol=2e-4)
+    np.testing.assert_allclose([float(v) for v in trainer.history["test"]], gold["epochs.test"], rtol=2e-3, atol=1e-6)
+    assert trainer.current_epoch == meta["epochs"]
+    trainer.save_running_weights("encoder_y")
+    trainer.average_weights("encoder_y")
+    trainer.print_statistics()
+
+
 def test_fails_loudly_on_cpu_tensors(gpu_device):
     model = pv.models.iVAE((8, 8), 2, ["r"], seed=1, device="cuda")
     eng = model.engine()
