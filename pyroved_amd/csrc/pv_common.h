@@ -125,5 +125,10 @@ int pv_gemm_pick_splits(int M, int N, int K);
 int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s);
 // out[i] = sum_p part[p*stride + i], p ascending (deterministic)
 int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
+// Workgroup barrier for kernels whose waves communicate through LDS only: waits for the wave's LDS traffic, not for
+// its outstanding global stores (__syncthreads() fences those too — a ~1 us store round trip per barrier in the
+// latency-bound encoder kernels, whose global outputs are consumed by LATER launches only).
+__device__ __forceinline__ void pv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 int pv_colsum(const float* x, int64_t ldx, int64_t M, int N, float* out, void* ws, int64_t ws_bytes, hipStream_t s);
 int64_t pv_colsum_ws(int64_t M, int N);

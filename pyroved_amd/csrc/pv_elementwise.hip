@@ -16,9 +16,9 @@
 // deterministic block-wide sum (blockDim.x == 256); result valid in every thread
 __device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats */) {
   v = pv_wave_sum(v);
-  __syncthreads();
+  pv_lds_barrier();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
+  pv_lds_barrier();
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
@@ -607,12 +607,12 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     // the five row sums in ONE block reduction (fixed order: wave sums, then waves 0..3)
 #pragma unroll
     for (int c = 0; c < 5; ++c) a[c] = pv_wave_sum(a[c]);
-    __syncthreads();
+    pv_lds_barrier();
     if ((t & 63) == 0) {
 #pragma unroll
       for (int c = 0; c < 5; ++c) sm5[c][t >> 6] = a[c];
     }
-    __syncthreads();
+    pv_lds_barrier();
 #pragma unroll
     for (int c = 0; c < 5; ++c) a[c] = (sm5[c][0] + sm5[c][1]) + (sm5[c][2] + sm5[c][3]);
     if (t == 0) sh_ll[k] = a[0];
@@ -634,7 +634,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
       sh_dhz[j] += v;                                  // the same thread owns j in every pass
     }
   }
-  __syncthreads();
+  pv_lds_barrier();
   if (t == 0) {
     float ll = sh_ll[0];
     if (p.K > 0) {
@@ -653,7 +653,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     v = block_sum_256(v, sm);
     if (t == 0) sh_dzc[i] = v;
   }
-  __syncthreads();
+  pv_lds_barrier();
   if (p.dzc_out && t < n_content) p.dzc_out[(int64_t)b * p.lat_in + t] = sh_dzc[t];
   if (t < p.hb.z_dim)
     pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; });

@@ -22,9 +22,9 @@
 
 __device__ __forceinline__ float en_block_sum(float v, float* sm /* 8 floats */) {
   v = pv_wave_sum(v);
-  __syncthreads();
+  pv_lds_barrier();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
+  pv_lds_barrier();
   return ((sm[0] + sm[1]) + (sm[2] + sm[3])) + ((sm[4] + sm[5]) + (sm[6] + sm[7]));
 }
 
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
   // C/D layout: lane (batch row r, q), reg i -> output 16*ob + 4q + i
 #pragma unroll
   for (int i = 0; i < 4; ++i) part[wave][r][4 * q + i] = c[i];
-  __syncthreads();
+  pv_lds_barrier();
   {
     const int rr = tid >> 4, jj = tid & 15, jo = 16 * ob + jj, row = row0 + rr;
     if (jo < l.out_dim && row < e.B) {
@@ -142,6 +142,16 @@ __global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
 }
 
 
+#ifdef EN_TRACE
+__device__ long long en_trace[64];
+#define EN_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) en_trace[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+extern "C" int pv_debug_read_enc_trace(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(en_trace), (n > 64 ? 64 : n) * sizeof(long long));
+}
+#else
+#define EN_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
   __shared__ __attribute__((aligned(16))) float act[2][EN_ROWS][EN_LD];
   __shared__ float sm[8];
@@ -149,6 +159,16 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
   const int row0 = blockIdx.x * EN_ROWS;
   const bool rok = row0 + r < e.B;
   int cur = 0;
+  EN_STAMP(0);
+  // ---- the first layer's output (pv_enc_l1_kernel): requested before anything else — loads return in order, and the
+  // first barrier waits only for this one ----
+  const int w0_ = e.enc[0].out_dim;
+  const bool l0ok = tid < EN_ROWS * (w0_ / 4);                       // (w0 <= 128: one float4 per thread)
+  f32x4 l0v = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (l0ok) {
+    const int rr = tid / (w0_ / 4), c4 = tid % (w0_ / 4);
+    l0v = *reinterpret_cast<const f32x4*>(e.eact[0] + (int64_t)min(row0 + rr, e.B - 1) * w0_ + 4 * c4);
+  }
   // ---- everything that does not depend on computed data is requested NOW (one memory latency for the whole kernel
   // instead of one per phase): this wave's weight / bias operands of hidden layer 1 and of the head, eps ----
   const bool pf1 = e.n_enc > 1 && 16 * wave < e.enc[1].out_dim;      // the wave's first block of layer 1
@@ -177,14 +197,10 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     eps_pf = e.eps[(int64_t)(row0 + tid / e.z_dim) * e.z_dim + tid % e.z_dim];
   // ---- the first layer's output (pv_enc_l1_kernel) into LDS; rows past the batch repeat the last one ----
   {
-    const int w0 = e.enc[0].out_dim;
-    for (int t = tid; t < EN_ROWS * (w0 / 4); t += EN_THREADS) {
-      const int rr = t / (w0 / 4), c4 = t % (w0 / 4);
-      *reinterpret_cast<f32x4*>(&act[0][rr][4 * c4]) =
-          *reinterpret_cast<const f32x4*>(e.eact[0] + (int64_t)min(row0 + rr, e.B - 1) * w0 + 4 * c4);
-    }
-    __syncthreads();
+    if (l0ok) *reinterpret_cast<f32x4*>(&act[0][tid / (w0_ / 4)][4 * (tid % (w0_ / 4))]) = l0v;
+    pv_lds_barrier();
   }
+  EN_STAMP(1);
   // ---- hidden layers 1.. ----
   for (int li = 1; li < e.n_enc; ++li) {
     const pv_layer l = e.enc[li];
@@ -202,9 +218,10 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       *reinterpret_cast<f32x4*>(&act[cur ^ 1][r][16 * ob + 4 * q]) = y;
       if (rok) *reinterpret_cast<f32x4*>(e.eact[li] + (int64_t)(row0 + r) * l.out_dim + 16 * ob + 4 * q) = y;
     }
-    __syncthreads();
+    pv_lds_barrier();
     cur ^= 1;
   }
+  EN_STAMP(2);
   // ---- head: [mu | softplus input] (fc11 | fc12) ----
   {
     const pv_layer l = e.head;
@@ -225,9 +242,10 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
         }
       }
     }
-    __syncthreads();
+    pv_lds_barrier();
     cur ^= 1;
   }
+  EN_STAMP(3);
   // ---- z = mu + softplus(s) * eps; sampled-KL terms ----
   const int zd = e.z_dim;
   float lp = 0.0f, lq = 0.0f;
@@ -268,6 +286,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     }
     lpd = -logf((float)K);                                   // sum_k alpha log(1/K)
   }
+  EN_STAMP(4);
   lp = en_block_sum(lp, sm);
   lq = en_block_sum(lq, sm);
   if (K > 0) {
@@ -278,7 +297,8 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     e.kl_part[2 * blockIdx.x] = e.beta * lp + e.beta_disc * lpd;
     e.kl_part[2 * blockIdx.x + 1] = e.beta * lq + e.beta_disc * lqd;
   }
-  __syncthreads();
+  pv_lds_barrier();
+  EN_STAMP(5);
   cur ^= 1;                                         // act[cur][rr][0..zd) = z
   // ---- _split_latent: transform parameters + decoder latent input (base.py:97-119, ivae.py:187-195) ----
   int coord = 0;
@@ -312,6 +332,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       }
     }
   }
+  EN_STAMP(6);
   // ---- hz = fc_latent(cat(z_content, y)) (no bias; fc.py:217,230) ----
   if (e.hz) {
     for (int t = tid; t < EN_ROWS * e.H0; t += EN_THREADS) {
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
       }
       buf[cur][rr][k] = v;
     }
-    __syncthreads();
+    pv_lds_barrier();
   }
   for (int li = ne - 1; li > 0; --li) {
     const pv_layer l = e.enc[li];          // edp[li] (16 x l.out_dim) in buf[cur]; produce edp[li-1] (16 x l.in_dim)
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
       }
       *reinterpret_cast<f32x4*>(&buf[cur ^ 1][r][16 * kb + 4 * q]) = y;
     }
-    __syncthreads();
+    pv_lds_barrier();
     cur ^= 1;
   }
 }

@@ -135,9 +135,9 @@ int pv_lik_elem(const float* a, const float* x, int64_t M, int lik, int sigmoid_
 // deterministic block-wide sum for any blockDim.x that is a multiple of 64 (<= 1024); result valid in every thread
 __device__ __forceinline__ float pv_block_sum(float v, float* sm /* >= 16 floats */) {
   v = pv_wave_sum(v);
-  __syncthreads();
+  pv_lds_barrier();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
+  pv_lds_barrier();
   float t = 0.0f;
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
   return t;

@@ -35,3 +35,14 @@ for t in range(4):
         if st[k]:
             out.append("%s=%d" % (names[k], st[k] - prev)); prev = st[k]
     print("tile", t, "total", prev - st[0], " ".join(out))
+# raw view: every stamp of tile 1 sorted by time (the phase names above assume the x3 kernel's barrier structure)
+labels = {0: "tile start", 1: "coord layer done", 2: "fwd L1+tanh+cvt done", 3: "(x3 barrier) before fwd L2", 16: "fwd L2 mfma done",
+          17: "tanh8 done", 18: "logit+lik done", 19: "d(wo) done", 20: "dpre2 done", 4: "cvt dpre2 done", 5: "stage L2 + barrier done",
+          6: "(x3) consume2 barrier", 7: "dgrad L2 + cvt done", 8: "(x3 barrier) before dgrad L1", 9: "dgrad L1 + coord sums + cvt done",
+          10: "stage L1 + barrier done", 21: "wgrad L1 consume done", 22: "row-local done", 13: "tile end"}
+for t in (1, 2):
+    st = sorted((buf[t * 32 + k], k) for k in labels if buf[t * 32 + k])
+    if not st: continue
+    print("tile", t, "raw:")
+    for (a, ka), (b, kb) in zip(st, st[1:]):
+        print("   %6d  -> %s" % (b - a, labels[kb]))
