@@ -11,5 +11,14 @@ int pv_ncs_to_nsc(const float* in, float* out, int64_t B, int C, int64_t S, hipS
 int pv_nsc_to_ncs(const float* in, float* out, int64_t B, int C, int64_t S, hipStream_t s);
 int pv_act_bwd(float* dy, const float* y, int64_t n, int act, hipStream_t s);
 int pv_conv_wflip(const float* w, float* wt, int Cout, int Cin, int KK, hipStream_t s);
+// direct kernel-3 convolution on the matrix cores (pv_conv_direct.hip); wt_scratch: pv_conv3_direct_wt_floats floats
+bool pv_conv3_direct_supported(int C, int Cout, int nd, int act);
+int64_t pv_conv3_direct_wt_floats(int C, int Cout, int nd);
+bool pv_conv3_wgrad_direct_supported(int C, int Cout, int nd);
+int64_t pv_conv3_wgrad_direct_ws(int B, int H, int W, int C, int Cout, int nd);
+int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db, int Cout,
+                          void* ws, int64_t ws_bytes, hipStream_t s);
+int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
+                    float* out, int act, float* wt_scratch, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);

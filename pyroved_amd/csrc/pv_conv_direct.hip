@@ -1,0 +1,325 @@
+// pv_conv_direct.hip — kernel-3 (padding 1, stride 1) convolution over channels-last activations as a DIRECT
+// convolution on the f32-input matrix cores: the forward of nn.ConvNd in nets/conv.py's FeatureExtractor / Upsampler
+// stacks, and — with the taps flipped and the channel roles swapped — its input gradient.
+//
+// pv_gemm.hip's implicit-im2col form gathers every A element through (row -> b,y,x ; column -> ci,tap) index
+// arithmetic and re-reads each input pixel for its 9 taps from L2.  Here a workgroup owns an 8x8 (2-D) / 64x1 (1-D)
+// tile of output pixels x 64 output channels and walks the input channels in chunks of 16: the tile's input patch WITH
+// ITS HALO (10x10 pixels x 16 channels) and the chunk's weights (taps x 64 x 16) are staged in LDS once and all 9 taps
+// contract out of LDS.  D[co][pixel] = sum_{tap, ci} W[co][ci][tap] * in[pixel + tap][ci] (weights are the MFMA A
+// operand, the patch the B operand), so a lane ends up with 4 consecutive output channels of one pixel: bias +
+// activation + one 16-byte store.  Within a k-step s the MFMA's k slot kq stands for channel 4*kq + s of the chunk:
+// both operands are then single ds_read_b128 out of the natural [row][16 channels] LDS layouts.
+// The weights come pre-tiled ([co tile][chunk][tap][64][16], zero-padded) from pv_conv3_wprep, which also does the
+// flip / role swap of the dgrad form, so staging them is a straight 16-byte copy.
+#include "pv_common.h"
+#include "pv_conv.h"
+
+#define CD_TN 64                 // output channels per workgroup
+#define CD_KC 16                 // input channels per stage
+#define CD_PIX 64                // output pixels per workgroup
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+struct ConvD {
+  const float* in; const float* wt; const float* bias; float* out;
+  int B, H, W, Cin, Cout, nd, act, KK, tiles_x, tiles_y;
+};
+
+// raw torch weight w[Co][Ci][KK] -> tiled logical matrix Wl[n][c][t]:
+//   flip == 0 (forward):  Wl[n = co][c = ci][t] = w[co][ci][t]                (N = Co, C = Ci)
+//   flip == 1 (dgrad):    Wl[n = ci][c = co][t] = w[co][ci][KK - 1 - t]       (N = Ci, C = Co)
+// laid out [n tile][chunk][t][64][16], rows n >= N zero
+__global__ void pv_conv3_wprep_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int Ci, int KK, int flip) {
+  const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+  const int nt = (N + CD_TN - 1) / CD_TN, nch = C / CD_KC;
+  const int64_t total = (int64_t)nt * nch * KK * CD_TN * CD_KC;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int cl = (int)(e % CD_KC), nl = (int)((e / CD_KC) % CD_TN), t = (int)((e / (CD_KC * CD_TN)) % KK);
+    const int ch = (int)((e / ((int64_t)CD_KC * CD_TN * KK)) % nch), tile = (int)(e / ((int64_t)CD_KC * CD_TN * KK * nch));
+    const int n = tile * CD_TN + nl, c = ch * CD_KC + cl;
+    float v = 0.0f;
+    if (n < N) v = flip ? w[((int64_t)c * Ci + n) * KK + (KK - 1 - t)] : w[((int64_t)n * Ci + c) * KK + t];
+    wt[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : CD_PIX + 2, NPIX = PH * PW;
+  float* wl = smem;                                  // [KK][64][16]
+  float* patch = smem + KK * CD_TN * CD_KC;          // [NPIX][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;           // pixel half, channel half of the 64 x 64 tile
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+  const int y0 = ty * (p.nd == 2 ? 8 : CD_PIX), x0 = tx * 8;
+  const int cot = blockIdx.y;
+  const int nch = p.Cin / CD_KC;
+  const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // this lane's two B rows (output pixels) as patch indices of tap (0, 0)
+  int pidx[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int n = wm * 32 + pb * 16 + r;
+    pidx[pb] = p.nd == 2 ? (n >> 3) * PW + (n & 7) : n;
+  }
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();                                 // the previous chunk's reads are done
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.wt + ((int64_t)cot * nch + ch) * KK * CD_TN * CD_KC);
+      f32x4* dst = reinterpret_cast<f32x4*>(wl);
+      for (int e = tid; e < KK * CD_TN * CD_KC / 4; e += 256) dst[e] = src[e];
+    }
+    for (int e = tid; e < NPIX * 4; e += 256) {
+      const int pix = e >> 2, f4 = e & 3;
+      const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
+      const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+        v = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + ch * CD_KC + 4 * f4);
+      *reinterpret_cast<f32x4*>(patch + pix * CD_KC + 4 * f4) = v;
+    }
+    __syncthreads();
+    for (int tap = 0; tap < KK; ++tap) {
+      const int toff = p.nd == 2 ? (tap / 3) * PW + (tap % 3) : tap;
+      f32x4 a[2], bb[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+        a[cb] = *reinterpret_cast<const f32x4*>(wl + ((tap * CD_TN) + wn * 32 + cb * 16 + r) * CD_KC + 4 * q);
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+        bb[pb] = *reinterpret_cast<const f32x4*>(patch + (pidx[pb] + toff) * CD_KC + 4 * q);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA4(a[cb][s], bb[pb][s], acc[cb][pb]);
+    }
+  }
+  // C/D layout: lane (column = pixel r, q), reg i -> output channel 16*cb + 4q + i of the wave's half
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int n = wm * 32 + pb * 16 + r;
+    const int y = p.nd == 2 ? y0 + (n >> 3) : y0 + n, x = p.nd == 2 ? x0 + (n & 7) : 0;
+    if (y >= p.H || x >= p.W) continue;
+    float* orow = p.out + (((int64_t)b * p.H + y) * p.W + x) * p.Cout;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int co = cot * CD_TN + wn * 32 + cb * 16 + 4 * q;
+      if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+        f32x4 v = acc[cb][pb];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = pv_act_fwd(v[i], p.act);
+        *reinterpret_cast<f32x4*>(orow + co) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (co + i < p.Cout) orow[co + i] = pv_act_fwd(acc[cb][pb][i] + (p.bias ? p.bias[co + i] : 0.0f), p.act);
+      }
+    }
+  }
+}
+
+bool pv_conv3_direct_supported(int C, int Cout, int nd, int act) {
+  return C >= CD_KC && C % CD_KC == 0 && Cout >= 8 && (nd == 1 || nd == 2) && act != PV_ACT_GELU;
+}
+
+int64_t pv_conv3_direct_wt_floats(int C, int Cout, int nd) {
+  const int KK = nd == 2 ? 9 : 3;
+  const int64_t n = Cout > C ? Cout : C;            // either orientation (forward / dgrad) fits
+  return ((n + CD_TN - 1) / CD_TN) * CD_TN * (int64_t)(Cout > C ? Cout : C) * KK + 64;
+}
+
+// w: raw torch weight (Co, Ci, KK).  flip == 0: out[.., Co] = act(conv(in[.., Ci]) + bias).
+// flip == 1: out[.., Ci] = conv of in[.., Co] with the flipped / role-swapped weights (the input gradient).
+int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
+                    float* out, int act, float* wt_scratch, hipStream_t s) {
+  const int KK = nd == 2 ? 9 : 3;
+  const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+  if (!pv_conv3_direct_supported(C, N, nd, act)) return PV_EINVAL;
+  const int nt = (N + CD_TN - 1) / CD_TN;
+  const int64_t total = (int64_t)nt * (C / CD_KC) * KK * CD_TN * CD_KC;
+  int pb = (int)((total + 255) / 256);
+  if (pb > 2048) pb = 2048;
+  hipLaunchKernelGGL(pv_conv3_wprep_kernel, dim3(pb), dim3(256), 0, s, w, wt_scratch, Co, Ci, KK, flip);
+  PV_LAUNCH_CHECK();
+  ConvD p{};
+  p.in = in; p.wt = wt_scratch; p.bias = bias; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = N; p.nd = nd; p.act = act; p.KK = KK;
+  p.tiles_x = nd == 2 ? (W + 7) / 8 : 1;
+  p.tiles_y = nd == 2 ? (H + 7) / 8 : (H + CD_PIX - 1) / CD_PIX;
+  const int npix = nd == 2 ? 100 : CD_PIX + 2;
+  const size_t lds = (size_t)(KK * CD_TN * CD_KC + npix * CD_KC) * sizeof(float);
+  hipLaunchKernelGGL(pv_conv3_direct_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt), dim3(256), lds, s, p);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution, direct form:
+//   dW[co][ci][tap] = sum_{b, pixel} dY[b, pixel][co] * in[b, pixel + tap][ci] ;   db[co] = sum dY[b, pixel][co]
+// A workgroup owns (64 output channels) x (16 input channels) x all taps and walks a contiguous range of 8x8 / 64x1
+// pixel tiles (split s of nsplit): per tile the dY tile (64 pixels x 64 channels) and the input patch with its halo
+// (x 16 channels) are staged in LDS, the contraction over the tile's pixels runs on the f32-input matrix cores
+// (A = dY^T, B = the patch shifted by the tap), and the 9 tap blocks of the wave's 16 output channels stay in
+// accumulators across tiles.  Partial results per split are summed in split order afterwards (no atomics).
+#define WG_LDY 68                // LDS row strides (floats): 2-way instead of 4-way bank conflicts on the scalar reads
+#define WG_LDP 20
+
+struct ConvWg {
+  const float* dy; const float* in; float* part; float* part_b;
+  int B, H, W, Cin, Cout, nd, KK, tiles_x, tiles_y, nsplit;
+};
+
+__global__ __launch_bounds__(256) void pv_conv3_wgrad_direct_kernel(ConvWg p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : CD_PIX + 2, NPIX = PH * PW;
+  float* dyl = smem;                                 // [64 pixels][WG_LDY]
+  float* patch = smem + CD_PIX * WG_LDY;             // [NPIX][WG_LDP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int split = blockIdx.x, ch = blockIdx.y, cot = blockIdx.z;
+  const int64_t T = (int64_t)p.B * p.tiles_y * p.tiles_x;
+  const int64_t t_lo = T * split / p.nsplit, t_hi = T * (split + 1) / p.nsplit;
+  f32x4 acc[9], accb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int64_t tt = t_lo; tt < t_hi; ++tt) {
+    int t = (int)tt;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+    const int y0 = ty * (p.nd == 2 ? 8 : CD_PIX), x0 = tx * 8;
+    __syncthreads();
+    for (int e = tid; e < CD_PIX * 16; e += 256) {               // dY tile: pixel n, channels 4*c4 .. 4*c4+3
+      const int n = e >> 4, c4 = e & 15;
+      const int y = p.nd == 2 ? y0 + (n >> 3) : y0 + n, x = p.nd == 2 ? x0 + (n & 7) : 0;
+      const int co = cot * CD_TN + 4 * c4;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y < p.H && x < p.W) {
+        const float* src = p.dy + (((int64_t)b * p.H + y) * p.W + x) * p.Cout + co;
+        if (co + 3 < p.Cout && (p.Cout & 3) == 0) v = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (co + i < p.Cout) v[i] = src[i];
+        }
+      }
+      *reinterpret_cast<f32x4*>(dyl + n * WG_LDY + 4 * c4) = v;
+    }
+    const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin;
+    for (int e = tid; e < NPIX * 4; e += 256) {
+      const int pix = e >> 2, f4 = e & 3;
+      const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
+      const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+        v = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + ch * CD_KC + 4 * f4);
+      *reinterpret_cast<f32x4*>(patch + pix * WG_LDP + 4 * f4) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {                                // 16 pixels: k slot kq of step s is pixel 16g + 4kq + s
+      float a[4];
+      int pbase[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int n = 16 * g + 4 * q + s;
+        a[s] = dyl[n * WG_LDY + 16 * wave + r];
+        pbase[s] = (p.nd == 2 ? (n >> 3) * PW + (n & 7) : n) * WG_LDP + r;
+      }
+      if (ch == 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) accb = MFMA4(a[s], 1.0f, accb);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < KK) {
+          const int toff = (p.nd == 2 ? (tap / 3) * PW + (tap % 3) : tap) * WG_LDP;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[tap] = MFMA4(a[s], patch[pbase[s] + toff], acc[tap]);
+        }
+      }
+    }
+  }
+  // C/D layout: lane (column = ci r, q), reg i -> output channel 16*wave + 4q + i
+  const int ci = ch * CD_KC + r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = cot * CD_TN + 16 * wave + 4 * q + i;
+    if (co >= p.Cout) continue;
+    float* dst = p.part + (((int64_t)split * p.Cout + co) * p.Cin + ci) * KK;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      if (tap < KK) dst[tap] = acc[tap][i];
+    if (ch == 0 && r == 0 && p.part_b) p.part_b[(int64_t)split * p.Cout + co] = accb[i];
+  }
+}
+
+// out[e] = sum_s part[s][e] in split order
+__global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {
+      v0 += part[(int64_t)s * n + e]; v1 += part[(int64_t)(s + 1) * n + e];
+      v2 += part[(int64_t)(s + 2) * n + e]; v3 += part[(int64_t)(s + 3) * n + e];
+    }
+    for (; s < nsplit; ++s) v0 += part[(int64_t)s * n + e];
+    out[e] = (v0 + v1) + (v2 + v3);
+  }
+}
+
+static int wgd_splits(int B, int H, int W, int C, int Cout, int nd) {
+  const int tiles_x = nd == 2 ? (W + 7) / 8 : 1, tiles_y = nd == 2 ? (H + 7) / 8 : (H + CD_PIX - 1) / CD_PIX;
+  const int64_t T = (int64_t)B * tiles_x * tiles_y;
+  const int64_t owners = (int64_t)(C / CD_KC) * ((Cout + CD_TN - 1) / CD_TN);
+  int64_t ns = (768 + owners - 1) / owners;                     // ~3 workgroups per CU in all
+  if (ns > T) ns = T;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+bool pv_conv3_wgrad_direct_supported(int C, int Cout, int nd) {
+  return C >= CD_KC && C % CD_KC == 0 && Cout >= 8 && (nd == 1 || nd == 2);
+}
+
+int64_t pv_conv3_wgrad_direct_ws(int B, int H, int W, int C, int Cout, int nd) {
+  if (!pv_conv3_wgrad_direct_supported(C, Cout, nd)) return 0;
+  const int KK = nd == 2 ? 9 : 3;
+  return (int64_t)wgd_splits(B, H, W, C, Cout, nd) * ((int64_t)Cout * C * KK + Cout) * (int64_t)sizeof(float) + 256;
+}
+
+int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db, int Cout,
+                          void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (!pv_conv3_wgrad_direct_supported(C, Cout, nd)) return PV_EINVAL;
+  if (ws_bytes < pv_conv3_wgrad_direct_ws(B, H, W, C, Cout, nd)) return PV_EWS;
+  const int KK = nd == 2 ? 9 : 3;
+  ConvWg p{};
+  p.dy = dy; p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = Cout; p.nd = nd; p.KK = KK;
+  p.tiles_x = nd == 2 ? (W + 7) / 8 : 1;
+  p.tiles_y = nd == 2 ? (H + 7) / 8 : (H + CD_PIX - 1) / CD_PIX;
+  p.nsplit = wgd_splits(B, H, W, C, Cout, nd);
+  const int64_t nw = (int64_t)Cout * C * KK;
+  p.part = reinterpret_cast<float*>(ws);
+  p.part_b = db ? p.part + (int64_t)p.nsplit * nw : nullptr;
+  const int npix = nd == 2 ? 100 : CD_PIX + 2;
+  const size_t lds = (size_t)(CD_PIX * WG_LDY + npix * WG_LDP) * sizeof(float);
+  hipLaunchKernelGGL(pv_conv3_wgrad_direct_kernel, dim3((unsigned)p.nsplit, (unsigned)(C / CD_KC), (unsigned)((Cout + CD_TN - 1) / CD_TN)),
+                     dim3(256), lds, s, p);
+  PV_LAUNCH_CHECK();
+  int fb = (int)((nw + 255) / 256);
+  if (fb > 1024) fb = 1024;
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw);
+  PV_LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, p.part_b, p.nsplit, (int64_t)Cout, db);
+    PV_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -45,9 +45,13 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
     upd(nd_.maxact, s[i + 1].elems(B));
     if (ops[i].kind == PV_OP_CONV) {
       const int64_t rows = B * s[i].H * s[i].W, K = (int64_t)ops[i].cin * kk_of(ops[i], nd), N = ops[i].cout;
-      if (ops[i].ksize == 3) upd(nd_.maxcol, N * K);                 // flipped weights of the dgrad-as-convolution
+      if (ops[i].ksize == 3) {
+        upd(nd_.maxcol, N * K);                                      // flipped weights of the dgrad-as-convolution
+        upd(nd_.maxcol, pv_conv3_direct_wt_floats(ops[i].cin, ops[i].cout, nd));   // tiled weights of the direct kernel
+      }
       upd(nd_.scratch, gemm_ws_need(rows, N, K));                    // forward
       upd(nd_.scratch, gemm_ws_need(N, K, rows));                    // wgrad
+      if (ops[i].ksize == 3) upd(nd_.scratch, pv_conv3_wgrad_direct_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
       upd(nd_.scratch, gemm_ws_need(rows, K, N));                    // dgrad, kernel 1
       upd(nd_.scratch, gemm_ws_need(rows, ops[i].cin, N * kk_of(ops[i], nd)));   // dgrad, kernel 3
     }
@@ -63,8 +67,11 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
   if (o.kind == PV_OP_CONV) {
     const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
     const float* bias = o.b_off >= 0 ? params + o.b_off : nullptr;
-    if (o.ksize == 3)
+    if (o.ksize == 3) {
+      if (pv_conv3_direct_supported(o.cin, o.cout, nd, o.act))
+        return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s);
       return conv3_fwd(in, B, si.H, si.W, si.C, nd, params + o.w_off, bias, out, o.cout, o.act, sc.ws, sc.ws_bytes, s);
+    }
     return linear_fwd(in, K, params + o.w_off, bias, out, nullptr, o.cout, rows, K, o.cout, o.act, sc.ws, sc.ws_bytes, s);
   }
   if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
@@ -81,9 +88,14 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));                       // g = dL/d(pre-activation)
     float* db = o.b_off >= 0 ? grads + o.b_off : nullptr;
     if (o.ksize == 3) {
-      PV_TRY(conv3_wgrad(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
+      if (pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
+        PV_TRY(pv_conv3_wgrad_direct(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
+      else
+        PV_TRY(conv3_wgrad(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
       if (!gin) return 0;
       // dX = conv3(dpre; taps flipped, channel roles swapped) — same spatial size, C = cout -> cin
+      if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE))
+        return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s);
       PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
       return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);
     }
