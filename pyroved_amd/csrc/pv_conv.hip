@@ -64,6 +64,42 @@ __global__ void pv_maxpool2_bwd_kernel(const float* __restrict__ in, const float
   }
 }
 
+// the same for even H (and W) and C % 4 == 0: one thread per (window, 4 channels) — reads the window once, 16-byte accesses
+__global__ void pv_maxpool2_bwd4_kernel(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ din,
+                                        int B, int H, int W, int C, int nd) {
+  const int Ho = H / 2, Wo = nd == 2 ? W / 2 : 1, C4 = C / 4, nx = nd == 2 ? 2 : 1;
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % C4);
+    const int64_t w = e / C4;
+    const int ox = (int)(w % Wo), oy = (int)((w / Wo) % Ho);
+    const int64_t b = w / ((int64_t)Wo * Ho);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dout + w * C + 4 * c4);
+    f32x4 v[4];
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < nx; ++dx)
+        v[dy * 2 + dx] = *reinterpret_cast<const f32x4*>(in + ((b * H + 2 * oy + dy) * W + (nd == 2 ? 2 * ox + dx : 0)) * C + 4 * c4);
+    int best[4] = {0, 0, 0, 0};
+    f32x4 m = v[0];
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < nx; ++dx) {
+        const int k = dy * 2 + dx;
+        if (k == 0) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (v[k][i] > m[i]) { m[i] = v[k][i]; best[i] = k; }      // strict >: the FIRST maximum wins (torch)
+      }
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < nx; ++dx) {
+        const int k = dy * 2 + dx;
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = best[i] == k ? g[i] : 0.0f;
+        *reinterpret_cast<f32x4*>(din + ((b * H + 2 * oy + dy) * W + (nd == 2 ? 2 * ox + dx : 0)) * C + 4 * c4) = o;
+      }
+  }
+}
+
 // out[b][y][x][c] = in[b][y/2][x/2][c]
 __global__ void pv_upsample2_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
                                         int nd) {
@@ -199,6 +235,8 @@ int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int
   CONV_LAUNCH(pv_maxpool2_fwd_kernel, (int64_t)B * (H / 2) * (nd == 2 ? W / 2 : 1) * C, in, out, B, H, W, C, nd);
 }
 int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s) {
+  if (C % 4 == 0 && H % 2 == 0 && (nd == 1 || W % 2 == 0))
+    CONV_LAUNCH(pv_maxpool2_bwd4_kernel, (int64_t)B * (H / 2) * (nd == 2 ? W / 2 : 1) * (C / 4), in, dout, din, B, H, W, C, nd);
   CONV_LAUNCH(pv_maxpool2_bwd_kernel, (int64_t)B * H * W * C, in, dout, din, B, H, W, C, nd);
 }
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s) {

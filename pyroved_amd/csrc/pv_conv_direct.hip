@@ -261,8 +261,16 @@ __global__ __launch_bounds__(256) void pv_conv3_wgrad_direct_kernel(ConvWg p) {
   }
 }
 
-// out[e] = sum_s part[s][e] in split order
-__global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out) {
+// out[e] = sum_s part[s][e] in split order (and out_b likewise)
+__global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
+                                             const float* __restrict__ part_b, int nb, float* __restrict__ out_b) {
+  if (part_b && blockIdx.x == gridDim.x - 1) {          // the bias gradient rides in the last workgroup
+    for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+      float v = 0.0f;
+      for (int s = 0; s < nsplit; ++s) v += part_b[(int64_t)s * nb + e];
+      out_b[e] = v;
+    }
+  }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
     int s = 0;
@@ -315,11 +323,7 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
   PV_LAUNCH_CHECK();
   int fb = (int)((nw + 255) / 256);
   if (fb > 1024) fb = 1024;
-  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw);
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
   PV_LAUNCH_CHECK();
-  if (db) {
-    hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, p.part_b, p.nsplit, (int64_t)Cout, db);
-    PV_LAUNCH_CHECK();
-  }
   return 0;
 }

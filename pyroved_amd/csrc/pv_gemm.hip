@@ -235,6 +235,44 @@ __global__ __launch_bounds__(256) void pv_gemm_finish_kernel(GemmK p, int splits
   }
 }
 
+// many splits, few outputs (wgrads of small layers over ~1e6 rows): the loop above is a chain of dependent-latency loads
+// in a handful of workgroups.  Here a workgroup takes 4 outputs x 64 split slices and meets in a fixed-order LDS tree.
+__global__ __launch_bounds__(256) void pv_gemm_finish_deep_kernel(GemmK p, int splits) {
+  __shared__ float sm[64][4];
+  const PvGemm& g = p.g;
+  const int64_t total = (int64_t)g.M * g.N, nrs = p.part_rs ? g.M : 0;
+  const int o = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 4 + o;          // [0, total): C entries; [total, total + M): row sums
+  float v = 0.0f;
+  if (i < total) {
+    for (int z = sl; z < splits; z += 64) v += p.part[(int64_t)z * total + i];
+  } else if (i < total + nrs) {
+    for (int z = sl; z < splits; z += 64) v += p.part_rs[(int64_t)z * g.M + (i - total)];
+  }
+  sm[sl][o] = v;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (sl < w) sm[sl][o] += sm[sl + w][o];
+    __syncthreads();
+  }
+  if (sl != 0) return;
+  v = sm[0][o];
+  if (i < total) {
+    const int m = (int)(i / g.N), n = (int)(i % g.N);
+    if (g.bias) v += g.bias[n];
+    if (g.pre) g.pre[(int64_t)m * g.ldc + n] = v;
+    v = pv_act_fwd(v, g.act);
+    if (g.aux) {
+      const float y = g.aux[(int64_t)m * g.ldaux + n];
+      const float pr = g.auxpre ? g.auxpre[(int64_t)m * g.ldaux + n] : 0.0f;
+      v *= pv_act_grad(y, pr, g.act_aux);
+    }
+    g.C[(int64_t)m * g.ldc + n] = v;
+  } else if (i < total + nrs) {
+    g.rowsumA[i - total] = v;
+  }
+}
+
 int pv_gemm_pick_splits(int M, int N, int K) {
   // aim for >= ~512 workgroups (2 per CU) when the contraction is long enough to split; a split costs a
   // second (finish) launch, ~6 us on the stream, so short contractions are never split
@@ -286,6 +324,11 @@ int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t
   PV_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t total = (int64_t)g.M * g.N;
+    if (splits >= 32 && total + g.M <= 4 * 16384) {
+      hipLaunchKernelGGL(pv_gemm_finish_deep_kernel, dim3((unsigned)((total + g.M + 3) / 4)), dim3(256), 0, s, p, splits);
+      PV_LAUNCH_CHECK();
+      return 0;
+    }
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pv_gemm_finish_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
