@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 5
+#define PV_ABI_VERSION 6
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -66,7 +66,11 @@ enum pv_op_kind {
                             layout (cout, cin, *kernel) at w_off, bias at b_off)                        */
   PV_OP_MAXPOOL2 = 2,    /* nn.MaxPoolNd(2, 2)                                                          */
   PV_OP_UPSAMPLE2 = 3,   /* F.interpolate(scale_factor=2, mode="nearest")                               */
-  PV_OP_UPSAMPLE2_BILINEAR = 4   /* F.interpolate(scale_factor=2, mode="bilinear"), 2-D only (align_corners=False) */
+  PV_OP_UPSAMPLE2_BILINEAR = 4,  /* F.interpolate(scale_factor=2, mode="bilinear"), 2-D only (align_corners=False) */
+  PV_OP_BATCHNORM = 5    /* nn.BatchNormNd(cin) (affine, momentum 0.1, eps 1e-5; nets/conv.py:185-186, 239-240): weight at
+                            w_off, bias at b_off, running_mean / running_var at aux0_off / aux1_off — all in the flat
+                            parameter buffer (the running statistics never receive a gradient, so Adam leaves them).
+                            Batch statistics unless the plan's bn_eval is set                              */
 };
 
 typedef struct pv_op {
@@ -75,7 +79,8 @@ typedef struct pv_op {
   int32_t ksize;         /* CONV: 1 or 3    */
   int32_t act;           /* CONV: enum pv_act applied to the output */
   int32_t _pad;
-  int64_t w_off, b_off;  /* CONV: offsets in floats into the flat parameter buffer */
+  int64_t w_off, b_off;  /* CONV / BATCHNORM: offsets in floats into the flat parameter buffer */
+  int64_t aux0_off, aux1_off;   /* BATCHNORM: running_mean, running_var */
 } pv_op;
 
 /* Everything one SVI step of models.iVAE needs (models/ivae.py:122-221,
@@ -151,7 +156,8 @@ typedef struct pv_ivae_plan {
   const float* ext_head;
   float*       ext_dhead;
   int32_t      ext_encoder;
-  int32_t      _pad3;
+  int32_t      bn_eval;   /* batch-norm layers of the convolutional encoder use their running statistics (the module is
+                             in eval() mode) instead of batch statistics                                            */
   /* ---- per-sample weights and extra outputs: what the semi-supervised models (models/ssivae.py, models/ss_reg_ivae.py)
    * need from the same step.  With e_b = log p(x_b|z_b,y_b) + beta (log p(z_b) - log q(z_b|x_b,y_b)):
    *   row_w    (B) or NULL: loss = -sum_b row_w[b] e_b (scalars and every gradient weighted accordingly) — the
@@ -244,7 +250,8 @@ int pv_transform_coordinates(const float* grid, int64_t n_pix, int coord_dim, co
  * op sequences read off nets/conv.py's FeatureExtractor (conv.py:150-213) and Upsampler (conv.py:216-262).
  * Tensors cross the ABI in the reference's layout, (B, channels, *spatial) row-major; inside the library
  * activations are channels-last.  Scope: 1-D / 2-D data, kernel 3 (padding 1) and kernel 1 convolutions,
- * stride 1, 2x max-pooling, 2x nearest-neighbour (1-D, 2-D) or bilinear (2-D) upsampling, no batch normalisation.
+ * stride 1, 2x max-pooling, 2x nearest-neighbour (1-D, 2-D) or bilinear (2-D) upsampling, batch normalisation after the
+ * activation (the reference's order).
  * =================================================================================================== */
 typedef struct pv_ved_plan {
   int32_t batch;
@@ -263,7 +270,8 @@ typedef struct pv_ved_plan {
                                       order (c, spatial), out = 2*z_dim = [mu | softplus input]         */
   pv_layer l2f;                    /* latent2features.fc: in = z_dim, out = dec_c0*prod(dec_dim0), same order */
   int32_t dec_c0, dec_dim0[2];
-  int32_t _pad;
+  int32_t bn_eval;                 /* batch-norm layers use their running statistics (module.eval(): VED.encode / decode /
+                                      manifold2d switch to it and nothing switches back, models/ved.py:178,193,230)  */
   float*       params;
   float*       grads;
   float*       adam_m;

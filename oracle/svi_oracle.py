@@ -315,6 +315,7 @@ class VedConfig:
     sampler: str = "bernoulli"
     sigmoid_d: bool = True
     decoder_sig: float = 0.5
+    batchnorm: bool = False        # nn.BatchNormNd after every conv + activation (nets/conv.py:185-186, 239-240)
 
     @property
     def z_dim(self):
@@ -333,7 +334,17 @@ def _conv(ndim):
     return {1: F.conv1d, 2: F.conv2d}[ndim]
 
 
-def conv_encoder_forward(p: Params, cfg: VedConfig, x):
+def _bn(p: Params, bufs, pre: str, h, training: bool):
+    """nn.BatchNormNd.forward: batch statistics + in-place update of the running estimates in training mode, the running
+    estimates in eval mode (F.batch_norm, momentum 0.1, eps 1e-5).  `bufs`: dict of the running_mean / running_var /
+    num_batches_tracked tensors (plain tensors, no gradient)."""
+    if training:
+        bufs[pre + ".num_batches_tracked"] += 1
+    return F.batch_norm(h, bufs[pre + ".running_mean"], bufs[pre + ".running_var"], p[pre + ".weight"], p[pre + ".bias"],
+                        training, 0.1, 1e-5)
+
+
+def conv_encoder_forward(p: Params, cfg: VedConfig, x, bufs=None, training=True):
     """convEncoderNet.forward (nets/conv.py:24-64): FeatureExtractor (conv k3 s1 p1 + activation per filter, a 2x
     max-pool after every block but the last; conv.py:150-213) -> flatten (C, spatial) -> Linear -> (mu, softplus)."""
     act, nd = _ACT[cfg.activation], len(cfg.input_dim)
@@ -344,6 +355,9 @@ def conv_encoder_forward(p: Params, cfg: VedConfig, x):
             pre = "encoder_z.feature_extractor.layers.%d" % idx
             h = act(_conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"], stride=1, padding=1))
             idx += 2                                   # conv, activation
+            if cfg.batchnorm:
+                h = _bn(p, bufs, "encoder_z.feature_extractor.layers.%d" % idx, h, training)
+                idx += 1
         if bi + 1 < len(blocks):
             h = (F.max_pool1d if nd == 1 else F.max_pool2d)(h, 2, 2)
             idx += 1
@@ -353,7 +367,7 @@ def conv_encoder_forward(p: Params, cfg: VedConfig, x):
     return mu, F.softplus(sigma)
 
 
-def conv_decoder_forward(p: Params, cfg: VedConfig, z):
+def conv_decoder_forward(p: Params, cfg: VedConfig, z, bufs=None, training=True):
     """convDecoderNet.forward (nets/conv.py:67-102): Linear -> (C0, *out_dim / 2^blocks) -> per block [conv k3 +
     activation per filter, then UpsampleBlock = 2x interpolate (nearest in 1-D, bilinear in 2-D; conv.py:105-147) +
     conv k1] -> conv k1 to the output channels -> sigmoid (conv.py:216-262)."""
@@ -368,6 +382,9 @@ def conv_decoder_forward(p: Params, cfg: VedConfig, z):
             pre = "decoder.upsampler.layers.%d" % idx
             h = act(_conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"], stride=1, padding=1))
             idx += 2
+            if cfg.batchnorm:
+                h = _bn(p, bufs, "decoder.upsampler.layers.%d" % idx, h, training)
+                idx += 1
         pre = "decoder.upsampler.layers.%d.conv" % idx
         h = F.interpolate(h, scale_factor=2, mode="nearest" if nd == 1 else "bilinear")
         h = _conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"])
@@ -377,15 +394,15 @@ def conv_decoder_forward(p: Params, cfg: VedConfig, z):
     return torch.sigmoid(h) if cfg.sigmoid_d else h
 
 
-def ved_elbo(p: Params, cfg: VedConfig, x, y, eps, beta=1.0):
+def ved_elbo(p: Params, cfg: VedConfig, x, y, eps, beta=1.0, bufs=None, training=True):
     """Trace_ELBO of VED.guide/model (models/ved.py:122-163): z = mu + sigma*eps,
     loss = -( sum_b log p(y_b | z_b) + beta*sum_b log N(z_b;0,1) - beta*sum_b log N(z_b;mu_b,sigma_b) )."""
     b = x.shape[0]
-    z_loc, z_scale = conv_encoder_forward(p, cfg, x)
+    z_loc, z_scale = conv_encoder_forward(p, cfg, x, bufs, training)
     z = z_loc + z_scale * eps
     logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)
     logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)
-    loc = conv_decoder_forward(p, cfg, z)
+    loc = conv_decoder_forward(p, cfg, z, bufs, training)
     ll = likelihood(cfg, loc.flatten(1)).log_prob(y.reshape(b, -1)).sum(-1)
     t_ll, t_lp, t_lq = ll.sum(), (beta * logp).sum(), (beta * logq).sum()
     return dict(loss=-(t_ll + t_lp - t_lq), ll=t_ll, logpz=t_lp, logqz=t_lq, z_loc=z_loc, z_scale=z_scale, z=z, loc=loc)
@@ -396,13 +413,18 @@ class VedOracle:
 
     def __init__(self, params: Params, cfg: VedConfig, lr: float = 1e-3, dtype=torch.float32):
         self.cfg = cfg
-        self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+        # `params`: a state_dict; batch-norm buffers (running_mean / running_var / num_batches_tracked) are split off
+        is_buf = lambda k: k.rsplit(".", 1)[-1] in ("running_mean", "running_var", "num_batches_tracked")
+        self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items() if not is_buf(k)}
+        self.bufs = {k: v.detach().clone() for k, v in params.items() if is_buf(k)}
+        self.training = True            # nn.Module.training: VED.encode / decode switch to eval() and nothing switches back
         self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)
         self.dtype = dtype
         self.last = self.last_grads = None
 
     def step(self, x, y, eps, beta=1.0) -> float:
-        out = ved_elbo(self.p, self.cfg, x.to(self.dtype), y.to(self.dtype), eps.to(self.dtype), beta)
+        out = ved_elbo(self.p, self.cfg, x.to(self.dtype), y.to(self.dtype), eps.to(self.dtype), beta, self.bufs,
+                       self.training)
         if out["loss"].requires_grad:
             out["loss"].backward()
         self.last = out
@@ -415,12 +437,14 @@ class VedOracle:
         return out["loss"].item()
 
     def encode(self, x):
+        self.training = False                              # models/ved.py:178
         with torch.no_grad():
-            return conv_encoder_forward(self.p, self.cfg, x.to(self.dtype))
+            return conv_encoder_forward(self.p, self.cfg, x.to(self.dtype), self.bufs, False)
 
     def decode(self, z):
+        self.training = False                              # models/ved.py:193
         with torch.no_grad():
-            return conv_decoder_forward(self.p, self.cfg, z.to(self.dtype))
+            return conv_decoder_forward(self.p, self.cfg, z.to(self.dtype), self.bufs, False)
 
 
 def _encode_any(p: Params, cfg: Config, x, y=None):

@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 5
+PV_ABI_VERSION = 6
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -30,12 +30,13 @@ class pv_layer(C.Structure):
 
 
 PV_MAX_OPS = 32
-OP = {"conv": 1, "maxpool2": 2, "upsample2": 3, "upsample2_bilinear": 4}
+OP = {"conv": 1, "maxpool2": 2, "upsample2": 3, "upsample2_bilinear": 4, "batchnorm": 5}
 
 
 class pv_op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
-                ("act", C.c_int32), ("_pad", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
+                ("act", C.c_int32), ("_pad", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64),
+                ("aux0_off", C.c_int64), ("aux1_off", C.c_int64)]
 
 
 class pv_ivae_plan(C.Structure):
@@ -58,7 +59,7 @@ class pv_ivae_plan(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
         ("alpha", C.c_void_p), ("ext_head", C.c_void_p), ("ext_dhead", C.c_void_p),
-        ("ext_encoder", C.c_int32), ("_pad3", C.c_int32),
+        ("ext_encoder", C.c_int32), ("bn_eval", C.c_int32),
         ("row_w", C.c_void_p), ("row_elbo", C.c_void_p), ("dy", C.c_void_p),
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
@@ -75,7 +76,7 @@ class pv_ved_plan(C.Structure):
         ("n_enc_ops", C.c_int32), ("n_dec_ops", C.c_int32),
         ("enc", pv_op * PV_MAX_OPS), ("dec", pv_op * PV_MAX_OPS),
         ("head", pv_layer), ("l2f", pv_layer),
-        ("dec_c0", C.c_int32), ("dec_dim0", C.c_int32 * 2), ("_pad", C.c_int32),
+        ("dec_c0", C.c_int32), ("dec_dim0", C.c_int32 * 2), ("bn_eval", C.c_int32),
         ("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
         ("n_params", C.c_int64),
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p),

@@ -30,16 +30,19 @@ def conv_ops(layers: nn.Sequential, activation, prefix: Optional[str] = None):
                     or any(v != k // 2 for v in mod.padding) or any(v != 1 for v in mod.dilation) or mod.groups != 1):
                 raise UnsupportedModel("conv layers must be kernel 3 / padding 1 or kernel 1, stride 1")
             act = None
-            bn = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
-            if i + 1 < len(mods) and not isinstance(mods[i + 1], _conv_types() + (UpsampleBlock, nn.MaxPool1d,
-                                                                                   nn.MaxPool2d)):
-                if isinstance(mods[i + 1], bn):
-                    raise UnsupportedModel("batch normalisation is not implemented in the HIP conv path")
+            bn = (nn.BatchNorm1d, nn.BatchNorm2d)
+            if i + 1 < len(mods) and not isinstance(mods[i + 1], _conv_types() + bn + (UpsampleBlock, nn.MaxPool1d,
+                                                                                        nn.MaxPool2d)):
                 act = activation
                 i += 1
-                if i + 1 < len(mods) and isinstance(mods[i + 1], bn):
-                    raise UnsupportedModel("batch normalisation is not implemented in the HIP conv path")
             ops.append(("conv", mod, act, None if prefix is None else "%s.%d" % (prefix, pos)))
+            if i + 1 < len(mods) and isinstance(mods[i + 1], bn):          # conv -> activation -> batch norm
+                i += 1
+                b_ = mods[i]
+                if (not b_.affine or not b_.track_running_stats or b_.momentum != 0.1 or b_.eps != 1e-5
+                        or b_.num_features != mod.out_channels):
+                    raise UnsupportedModel("batch-norm layers must be the reference's nn.BatchNormNd(channels) defaults")
+                ops.append(("batchnorm", b_, None, None if prefix is None else "%s.%d" % (prefix, i)))
         elif isinstance(mod, (nn.MaxPool1d, nn.MaxPool2d)):
             ops.append(("maxpool2", None, None, None))
         elif isinstance(mod, UpsampleBlock):
@@ -65,4 +68,13 @@ def fill_ops(arr, ops, layout) -> int:
             o.act = _abi.ACT[act]
             o.w_off = layout[key + ".weight"]
             o.b_off = layout[key + ".bias"] if mod.bias is not None else -1
+        elif kind == "batchnorm":
+            o.cin = o.cout = mod.num_features
+            o.w_off, o.b_off = layout[key + ".weight"], layout[key + ".bias"]
+            o.aux0_off, o.aux1_off = layout[key + ".running_mean"], layout[key + ".running_var"]
     return len(ops)
+
+
+def bn_modules(ops):
+    """The batch-norm modules of an op list (their num_batches_tracked counters are kept by the host)."""
+    return [mod for kind, mod, _, _ in ops if kind == "batchnorm"]

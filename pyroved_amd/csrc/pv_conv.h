@@ -22,3 +22,10 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
                     float* out, int act, float* wt_scratch, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
+// nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)
+int64_t pv_bn_ws(int64_t R, int C);
+int pv_bn_fwd(const float* x, float* y, int64_t R, int C, const float* gamma, const float* beta, float* rmean, float* rvar,
+              int eval, float momentum, float eps, float* stats, void* ws, int64_t ws_bytes, hipStream_t s);
+// dy -> dx (dx may be null), dgamma, dbeta; x = the layer's input, stats from the forward
+int pv_bn_bwd(const float* x, const float* dy, float* dx, int64_t R, int C, const float* gamma, const float* stats, int eval,
+              float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, hipStream_t s);

@@ -265,3 +265,128 @@ int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s) {
   CONV_LAUNCH(pv_upsample2_bil_bwd_kernel, (int64_t)B * H * W * C, dout, din, B, H, W, C);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nn.BatchNormNd (training mode: batch statistics, biased variance for the normalisation, unbiased for the running
+// estimate; torch.nn.functional.batch_norm) over channels-last rows x[R][C].  Per-channel reductions are two-stage and
+// deterministic: BN_BLOCKS row chunks x all channels -> partials -> fixed-order finish.
+#define BN_BLOCKS 512
+#define BN_MAXC 1024
+// mode 0: sum x ; mode 1: sum (x - mean)^2 ; mode 2: a0 = sum dy, a1 = sum dy * xhat
+template <int MODE>
+__global__ __launch_bounds__(256) void pv_bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           int64_t R, int C, int cb /* pow2 >= min(C, 256) */,
+                                                           const float* __restrict__ stats, float* __restrict__ part) {
+  __shared__ float sm0[256], sm1[256];
+  const int t = threadIdx.x, tc = t % cb, tr = t / cb, nrt = 256 / cb;
+  const int64_t r0 = R * blockIdx.x / gridDim.x, r1 = R * (blockIdx.x + 1) / gridDim.x;
+  for (int c0 = 0; c0 < C; c0 += cb) {
+    const int c = c0 + tc;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (c < C) {
+      const float mean = MODE >= 1 ? stats[c] : 0.0f, inv = MODE == 2 ? stats[C + c] : 0.0f;
+      for (int64_t r = r0 + tr; r < r1; r += nrt) {
+        const float v = x[r * C + c];
+        if (MODE == 0) a0 += v;
+        else if (MODE == 1) { const float d = v - mean; a0 += d * d; }
+        else { const float g = dy[r * C + c]; a0 += g; a1 += g * ((v - mean) * inv); }
+      }
+    }
+    sm0[t] = a0; sm1[t] = a1;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+      float s0 = 0.0f, s1 = 0.0f;
+      for (int k = 0; k < nrt; ++k) { s0 += sm0[k * cb + tc]; s1 += sm1[k * cb + tc]; }
+      part[((int64_t)blockIdx.x * 2) * C + c] = s0;
+      part[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    }
+    __syncthreads();
+  }
+}
+
+// step 0: mean = sum / R.  step 1: var -> invstd, running statistics.  step 2: dgamma, dbeta (sums kept in part[0..2C))
+__global__ void pv_bn_finish_kernel(float* __restrict__ part, int nblk, int64_t R, int C, int step, float* __restrict__ stats,
+                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.0f, s1 = 0.0f;
+  for (int b = 0; b < nblk; ++b) { s0 += part[((int64_t)b * 2) * C + c]; s1 += part[((int64_t)b * 2 + 1) * C + c]; }
+  if (step == 0) {
+    stats[c] = s0 / (float)R;
+  } else if (step == 1) {
+    const float var = s0 / (float)R;
+    stats[C + c] = 1.0f / sqrtf(var + eps);
+    if (rmean) {
+      rmean[c] = (1.0f - momentum) * rmean[c] + momentum * stats[c];
+      rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (R > 1 ? s0 / (float)(R - 1) : var);
+    }
+  } else {
+    dbeta[c] = s0; dgamma[c] = s1;
+    stats[2 * C + c] = s0; stats[3 * C + c] = s1;       // for the dx pass
+  }
+}
+
+__global__ void pv_bn_running_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
+                                     float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { stats[c] = rmean[c]; stats[C + c] = 1.0f / sqrtf(rvar[c] + eps); }
+}
+
+__global__ void pv_bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    y[e] = (x[e] - stats[c]) * stats[C + c] * gamma[c] + beta[c];
+  }
+}
+
+// training: dx = gamma * invstd * (dy - sum(dy)/R - xhat * sum(dy*xhat)/R) ; eval: dx = gamma * invstd * dy
+__global__ void pv_bn_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n,
+                                int C, float invR, int eval, const float* __restrict__ gamma, const float* __restrict__ stats) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const float inv = stats[C + c];
+    float g = dy[e];
+    if (!eval) g = g - stats[2 * C + c] * invR - ((x[e] - stats[c]) * inv) * stats[3 * C + c] * invR;
+    dx[e] = gamma[c] * inv * g;
+  }
+}
+
+static int bn_cb(int C) { int cb = 1; while (cb < C && cb < 256) cb <<= 1; return cb; }
+static int bn_blocks(int64_t R) { return (int)(R < BN_BLOCKS ? (R > 0 ? R : 1) : BN_BLOCKS); }
+
+int64_t pv_bn_ws(int64_t R, int C) { return (int64_t)bn_blocks(R) * 2 * C * (int64_t)sizeof(float) + 256; }
+
+int pv_bn_fwd(const float* x, float* y, int64_t R, int C, const float* gamma, const float* beta, float* rmean, float* rvar,
+              int eval, float momentum, float eps, float* stats, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (C < 1 || C > BN_MAXC || R < 1 || ws_bytes < pv_bn_ws(R, C)) return C > BN_MAXC ? PV_EINVAL : PV_EWS;
+  float* part = reinterpret_cast<float*>(ws);
+  const int nb = bn_blocks(R), cb = bn_cb(C), cg = (C + 63) / 64;
+  if (eval) {
+    hipLaunchKernelGGL(pv_bn_running_kernel, dim3(cg), dim3(64), 0, s, rmean, rvar, C, eps, stats);
+  } else {
+    hipLaunchKernelGGL(pv_bn_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, x, (const float*)nullptr, R, C, cb, stats, part);
+    hipLaunchKernelGGL(pv_bn_finish_kernel, dim3(cg), dim3(64), 0, s, part, nb, R, C, 0, stats, (float*)nullptr, (float*)nullptr,
+                       momentum, eps, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(pv_bn_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, x, (const float*)nullptr, R, C, cb, stats, part);
+    hipLaunchKernelGGL(pv_bn_finish_kernel, dim3(cg), dim3(64), 0, s, part, nb, R, C, 1, stats, rmean, rvar, momentum, eps,
+                       (float*)nullptr, (float*)nullptr);
+  }
+  PV_LAUNCH_CHECK();
+  CONV_LAUNCH(pv_bn_apply_kernel, R * C, x, y, R * C, C, gamma, beta, stats);
+}
+
+int pv_bn_bwd(const float* x, const float* dy, float* dx, int64_t R, int C, const float* gamma, const float* stats_, int eval,
+              float* dgamma, float* dbeta, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (C < 1 || C > BN_MAXC || R < 1 || ws_bytes < pv_bn_ws(R, C)) return C > BN_MAXC ? PV_EINVAL : PV_EWS;
+  float* stats = const_cast<float*>(stats_);          // [2C, 4C): the two gradient sums, written here
+  float* part = reinterpret_cast<float*>(ws);
+  const int nb = bn_blocks(R), cb = bn_cb(C), cg = (C + 63) / 64;
+  hipLaunchKernelGGL(pv_bn_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, x, dy, R, C, cb, stats, part);
+  hipLaunchKernelGGL(pv_bn_finish_kernel, dim3(cg), dim3(64), 0, s, part, nb, R, C, 2, stats, (float*)nullptr, (float*)nullptr,
+                     0.0f, 0.0f, dgamma, dbeta);
+  PV_LAUNCH_CHECK();
+  if (!dx) return 0;
+  CONV_LAUNCH(pv_bn_dx_kernel, R * C, x, dy, dx, R * C, C, 1.0f / (float)R, eval, gamma, stats);
+}

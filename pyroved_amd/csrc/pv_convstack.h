@@ -25,6 +25,8 @@ inline bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
   } else if (o.kind == PV_OP_UPSAMPLE2_BILINEAR) {
     if (nd != 2) return false;
     out.H = in.H * 2; out.W = in.W * 2;
+  } else if (o.kind == PV_OP_BATCHNORM) {
+    if (o.cin != in.C || o.b_off < 0 || o.aux0_off < 0 || o.aux1_off < 0) return false;
   } else {
     return false;
   }
@@ -34,7 +36,9 @@ inline bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
 inline int kk_of(const pv_op& o, int nd) { return o.ksize == 3 ? (nd == 2 ? 9 : 3) : 1; }
 
 // scratch the stack's GEMMs and im2col need for B samples: running maxima
-struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0; };
+struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0; int bn_maxC = 0; };
+#define PVCS_BN_SLOTS (2 * PV_MAX_OPS)        // per-op statistics slots: stack 0 (encoder) and stack 1 (decoder)
+inline int64_t bn_floats(const Needs& n) { return (int64_t)PVCS_BN_SLOTS * 4 * n.bn_maxC; }
 inline void upd(int64_t& m, int64_t v) { if (v > m) m = v; }
 
 // shapes s[0..n] from s[0]; accumulates workspace needs; false on an inconsistent sequence
@@ -43,6 +47,10 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
   for (int i = 0; i < n; ++i) {
     if (!op_shape(ops[i], nd, s[i], s[i + 1])) return false;
     upd(nd_.maxact, s[i + 1].elems(B));
+    if (ops[i].kind == PV_OP_BATCHNORM) {
+      if (ops[i].cin > nd_.bn_maxC) nd_.bn_maxC = ops[i].cin;
+      upd(nd_.scratch, pv_bn_ws(B * s[i].H * s[i].W, ops[i].cin));
+    }
     if (ops[i].kind == PV_OP_CONV) {
       const int64_t rows = B * s[i].H * s[i].W, K = (int64_t)ops[i].cin * kk_of(ops[i], nd), N = ops[i].cout;
       if (ops[i].ksize == 3) {
@@ -59,11 +67,20 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
   return true;
 }
 
-struct Scratch { float* col /* flipped-weight scratch (maxcol floats) */; void* ws; int64_t ws_bytes; };
+struct Scratch {
+  float* col /* flipped-weight scratch (maxcol floats) */; void* ws; int64_t ws_bytes;
+  float* bn = nullptr; int bn_maxC = 0; int bn_eval = 0;     // batch-norm statistics slots (bn_floats), mode
+};
+inline float* bn_slot(const Scratch& sc, int slot) { return sc.bn + (int64_t)slot * 4 * sc.bn_maxC; }
 
 // one op forward: in (shape si) -> out
 inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const float* in, const Shape& si, float* out,
-                  const Scratch& sc, hipStream_t s) {
+                  const Scratch& sc, int slot, hipStream_t s) {
+  if (o.kind == PV_OP_BATCHNORM) {
+    float* P = const_cast<float*>(params);             // the running statistics live in the parameter buffer
+    return pv_bn_fwd(in, out, (int64_t)B * si.H * si.W, si.C, params + o.w_off, params + o.b_off, P + o.aux0_off,
+                     P + o.aux1_off, sc.bn_eval, 0.1f, 1e-5f, bn_slot(sc, slot), sc.ws, sc.ws_bytes, s);
+  }
   if (o.kind == PV_OP_CONV) {
     const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
     const float* bias = o.b_off >= 0 ? params + o.b_off : nullptr;
@@ -82,7 +99,10 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
 // one op backward: g = dL/d(out) (post-activation for CONV; modified in place), writes parameter gradients and, when
 // gin != null, dL/d(in)
 inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int B, const float* in, const Shape& si,
-                  const float* out, float* g, float* gin, const Scratch& sc, hipStream_t s) {
+                  const float* out, float* g, float* gin, const Scratch& sc, int slot, hipStream_t s) {
+  if (o.kind == PV_OP_BATCHNORM)
+    return pv_bn_bwd(in, g, gin, (int64_t)B * si.H * si.W, si.C, params + o.w_off, bn_slot(sc, slot), sc.bn_eval,
+                     grads + o.w_off, grads + o.b_off, sc.ws, sc.ws_bytes, s);
   if (o.kind == PV_OP_CONV) {
     const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
     PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));                       // g = dL/d(pre-activation)
@@ -112,8 +132,9 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
 
 // whole stack forward: a[0] given, a[1..n] written
 inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B, float* const* a, const Shape* sh,
-                     const Scratch& sc, hipStream_t s) {
-  for (int i = 0; i < n; ++i) PV_TRY(op_fwd(params, ops[i], nd, B, a[i], sh[i], a[i + 1], sc, s));
+                     const Scratch& sc, hipStream_t s, int stack_id = 0) {
+  for (int i = 0; i < n; ++i)
+    PV_TRY(op_fwd(params, ops[i], nd, B, a[i], sh[i], a[i + 1], sc, stack_id * PV_MAX_OPS + i, s));
   return 0;
 }
 
@@ -121,10 +142,10 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
 // dL/d(a[0]) (null when need_input_grad is false: the first op then skips its dgrad)
 inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n, int nd, int B, float* const* a,
                      const Shape* sh, float* g, float* const* gbuf, int& pp, bool need_input_grad, float** gout,
-                     const Scratch& sc, hipStream_t s) {
+                     const Scratch& sc, hipStream_t s, int stack_id = 0) {
   for (int i = n - 1; i >= 0; --i) {
     float* gin = (i > 0 || need_input_grad) ? gbuf[pp] : nullptr;
-    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, sc, s));
+    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, sc, stack_id * PV_MAX_OPS + i, s));
     g = gin; pp ^= 1;
   }
   if (gout) *gout = g;

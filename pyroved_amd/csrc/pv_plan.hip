@@ -47,7 +47,7 @@ struct Layout {
   // convolutional encoder (plan->n_enc_ops > 0): activation shapes / buffers, flattened features, gradient ping-pong
   bool enc_ext;                            // external encoder: (z_loc, z_scale) given, gradients handed back
   bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
-  float* ccol; int64_t cF;
+  float* ccol; int64_t cF; float* cbn; int cbn_maxC;
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
@@ -97,7 +97,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
   const int n_enc = (L.enc_conv || L.enc_ext) ? 0 : p->n_enc;
   pvcs::Needs cnd;
-  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = nullptr; L.cF = 0;
+  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0;
   if (L.enc_conv) {
     L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
     if ((int64_t)L.ces[0].H * L.ces[0].W == N && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
@@ -108,6 +108,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       L.cfeat = c.take(B * L.cF);
       L.cg[0] = c.take(cnd.maxact); L.cg[1] = c.take(cnd.maxact);
       L.ccol = c.take(cnd.maxcol);
+      L.cbn = c.take(pvcs::bn_floats(cnd)); L.cbn_maxC = cnd.bn_maxC;
     } else {
       L.cF = -1;                                   // inconsistent op sequence: rejected by the entry points
     }
@@ -299,7 +300,7 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   float* a[PV_MAX_OPS + 1];
   a[0] = const_cast<float*>(p->x);                  // one input channel: (B, 1, H, W) is already channels-last
   for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-  const pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes};
+  const pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval};
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
   const pvcs::Shape& fe = L.ces[p->n_enc_ops];
   PV_TRY(pv_nsc_to_ncs(L.cea[p->n_enc_ops], L.cfeat, B, fe.C, (int64_t)fe.H * fe.W, s));
@@ -412,7 +413,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     float* a[PV_MAX_OPS + 1];
     a[0] = const_cast<float*>(p->x);
     for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-    const pvcs::Scratch sc{L.ccol, ws, wsb};
+    const pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval};
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
                            nullptr, sc, s));

@@ -84,6 +84,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B);
   L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
   L.sc.col = c.take(nd.maxcol);
+  L.sc.bn = c.take(pvcs::bn_floats(nd)); L.sc.bn_maxC = nd.bn_maxC; L.sc.bn_eval = p->bn_eval;
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
   L.sc.ws = base ? (void*)(base + c.off) : nullptr;
   c.off += L.sc.ws_bytes;
@@ -120,7 +121,7 @@ int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_
   PV_TRY(linear_fwd(z, p->z_dim, p->params + p->l2f.w_off, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr,
                     L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
   PV_TRY(pv_ncs_to_nsc(L.f0, L.da[0], B, d0.C, (int64_t)d0.H * d0.W, s));       // view(-1, C0, *dims) -> channels-last
-  return pvcs::stack_fwd(p->params, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.sc, s);
+  return pvcs::stack_fwd(p->params, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.sc, s, 1);
 }
 
 }  // namespace
@@ -159,7 +160,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   float* g = nullptr;                                  // (dlda = dL/d(output of the last op), loss = -ELBO)
   int pp = 0;
   PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.g, pp, true,
-                         &g, L.sc, s));
+                         &g, L.sc, s, 1));
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
   PV_TRY(pv_nsc_to_ncs(g, L.df0, B, d0.C, (int64_t)d0.H * d0.W, s));

@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import _abi
 from .nets.fc import fcEncoderNet, jfcEncoderNet, fcDecoderNet, sDecoderNet
 from .nets.conv import convEncoderNet
-from ._convplan import UnsupportedModel, conv_ops, fill_ops
+from ._convplan import UnsupportedModel, conv_ops, fill_ops, bn_modules
 
 ALIGN = 64      # floats: every tensor starts on a 256-byte boundary of the flat buffer
 N_SCALARS = 4   # loss, ll, beta*log p(z), beta*log q(z|x)
@@ -49,6 +49,7 @@ class IVAEEngine:
         self.flat = self.grad = self.m = self.v = None
         self.ws = None
         self.events = (None, None)      # optional raw hipEvent_t pair recorded around the dominant kernel
+        self._bn_enc, self._bn_dec = [], []   # batch-norm modules of the convolutional stacks
         self._enc_opt = None            # torch.optim.Adam of a user-defined encoder's parameters (ext_enc)
         self._enc_params = []
         self._layout: Dict[str, int] = {}
@@ -124,10 +125,18 @@ class IVAEEngine:
                 order.append(k)
         return [(k, named[k]) for k in order]
 
+    def _stat_buffers(self):
+        """(key, tensor) of the batch-norm running statistics: they live in the flat buffer next to the parameters (the
+        kernels update them in place; they never get a gradient, so Adam leaves them alone)."""
+        return [(k, b) for k, b in self.model.named_buffers()
+                if k.endswith(".running_mean") or k.endswith(".running_var")]
+
     def bind(self):
         """(Re)builds the flat buffers from the model's current parameters and re-points the
         parameters at them.  Called at construction and whenever the parameters were moved."""
         items = self._param_order()
+        n_par = len(items)
+        items = items + self._stat_buffers()
         dev = items[0][1].device
         if dev.type != "cuda":
             raise _abi.PvError(
@@ -156,9 +165,13 @@ class IVAEEngine:
             self.m.copy_(old_m)
             self.v.copy_(old_v)
         self._views = {}
-        for k, p in items:
+        for j, (k, p) in enumerate(items):
             view = flat[layout[k]:layout[k] + p.numel()].view(p.shape)
-            p.data = view
+            if j < n_par:
+                p.data = view
+            else:                                    # a registered buffer: re-point the module's entry
+                owner, _, leaf = k.rpartition(".")
+                self.model.get_submodule(owner)._buffers[leaf] = view
             self._views[k] = view
         self._layout = layout
         self.n_flat = total
@@ -176,6 +189,7 @@ class IVAEEngine:
         named = dict(self.model.named_parameters())
         if self.ext_enc:
             named = {k: v for k, v in named.items() if not k.startswith("encoder_z.")}
+        named.update(dict(self._stat_buffers()))
         if len(named) != len(self._views):
             return False
         for k, v in self._views.items():
@@ -245,8 +259,10 @@ class IVAEEngine:
             p.enc_ndim = len(enc.input_dim)
             for i, d in enumerate(enc.input_dim):
                 p.enc_in_dim[i] = d
-            p.n_enc_ops = fill_ops(p.enc_ops, conv_ops(enc.feature_extractor.layers, enc.feature_extractor.activation,
-                                                       "encoder_z.feature_extractor.layers"), self._layout)
+            eops = conv_ops(enc.feature_extractor.layers, enc.feature_extractor.activation,
+                            "encoder_z.feature_extractor.layers")
+            p.n_enc_ops = fill_ops(p.enc_ops, eops, self._layout)
+            self._bn_enc = bn_modules(eops)
             p.head = self._layer("encoder_z.features2latent.fc_latent", enc.features2latent.fc_latent, None)
             p.discrete_dim = 0
         else:
@@ -277,6 +293,7 @@ class IVAEEngine:
         else:
             b0 = b1 = float(beta)
         p.beta, p.beta_disc = b0, b1
+        p.bn_eval = int(not self.model.training)
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = p.ext_head = p.ext_dhead = None
         p.row_w = p.row_elbo = p.dy = None
         p.ev_start, p.ev_stop = self.events
@@ -356,7 +373,15 @@ class IVAEEngine:
             torch.autograd.backward([z_loc, z_scale], [dhead[:, :zd], dhead[:, zd:]])
         if want_grads:
             self.grads_live = True
+        self._count_bn(self._bn_enc)
         self._keep = (x, eps, y, head, dhead, row_w)     # keep inputs alive until the stream has consumed them
+
+    def _count_bn(self, mods):
+        """nn.BatchNorm's num_batches_tracked (a forward in training mode counts; the statistics themselves are updated
+        by the kernels)."""
+        if self.model.training:
+            for b_ in mods:
+                b_.num_batches_tracked += 1
 
     def adam_step(self):
         """pyro.optim.Adam over every parameter + zero_grads (one fused kernel)."""
@@ -399,6 +424,7 @@ class IVAEEngine:
             p.alpha = alpha.data_ptr()
         _abi.check(_abi.lib().pv_ivae_encode(C.byref(p), _abi.ptr(z_loc), _abi.ptr(z_scale), _abi.current_stream()),
                    "pv_ivae_encode")
+        self._count_bn(self._bn_enc)
         self._keep = (x, y)
         if alpha is not None:
             return z_loc, z_scale, alpha

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _abi
 from .engine import IVAEEngine, UnsupportedModel
-from ._convplan import conv_ops, fill_ops
+from ._convplan import conv_ops, fill_ops, bn_modules
 from .nets.conv import convEncoderNet, convDecoderNet
 
 
@@ -65,10 +65,11 @@ class VEDEngine(IVAEEngine):
         p.lik = _abi.LIK[m.sampler_d.name]
         p.sigmoid_out = int(dec.sigmoid_out)
         p.decoder_sig = m.sampler_d.decoder_sig
-        p.n_enc_ops = self._fill_ops(p.enc, self._ops(enc.feature_extractor.layers, enc.feature_extractor.activation,
-                                                      "encoder_z.feature_extractor.layers"))
-        p.n_dec_ops = self._fill_ops(p.dec, self._ops(dec.upsampler.layers, dec.upsampler.activation,
-                                                      "decoder.upsampler.layers"))
+        eops = self._ops(enc.feature_extractor.layers, enc.feature_extractor.activation, "encoder_z.feature_extractor.layers")
+        dops = self._ops(dec.upsampler.layers, dec.upsampler.activation, "decoder.upsampler.layers")
+        p.n_enc_ops = self._fill_ops(p.enc, eops)
+        p.n_dec_ops = self._fill_ops(p.dec, dops)
+        self._bn_enc, self._bn_dec = bn_modules(eops), bn_modules(dops)
         p.head = self._layer("encoder_z.features2latent.fc_latent", enc.features2latent.fc_latent, None)
         p.l2f = self._layer("decoder.latent2features.fc", dec.latent2features.fc, None)
         shape0 = [int(v) for v in dec.latent2features.reshape_]
@@ -85,6 +86,7 @@ class VEDEngine(IVAEEngine):
         p = self._static
         p.batch = batch
         p.beta = float(beta)
+        p.bn_eval = int(not self.model.training)
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
         need = _abi.lib().pv_ved_workspace_bytes(C.byref(p))
         if need < 0:
@@ -129,6 +131,7 @@ class VEDEngine(IVAEEngine):
             p.scalars = self.scalars.data_ptr()
         if want_grads:
             self.grads_live = True
+        self._count_bn(self._bn_enc + self._bn_dec)
         self._keep = (x, y, eps)
 
     def encode(self, x, y=None):
@@ -141,6 +144,7 @@ class VEDEngine(IVAEEngine):
         z_scale = torch.empty_like(z_loc)
         _abi.check(_abi.lib().pv_ved_encode(C.byref(p), _abi.ptr(z_loc), _abi.ptr(z_scale), _abi.current_stream()),
                    "pv_ved_encode")
+        self._count_bn(self._bn_enc)
         self._keep = (x,)
         return z_loc, z_scale
 
@@ -152,6 +156,7 @@ class VEDEngine(IVAEEngine):
         loc = torch.empty(self._out_shape(b), device=self.device, dtype=torch.float32)
         _abi.check(_abi.lib().pv_ved_decode(C.byref(p), _abi.ptr(z), _abi.ptr(loc), _abi.current_stream()),
                    "pv_ved_decode")
+        self._count_bn(self._bn_dec)
         self._keep = (z,)
         return loc
 

@@ -79,13 +79,17 @@ class VED(baseVAE):
             "use trainers.SVItrainer or VED.encode")
 
     def encode(self, x_new: torch.Tensor, **kwargs: int) -> torch.Tensor:
-        """(z_loc, z_scale) of the encoded distributions, on the CPU (models/ved.py:165-181).  kwargs: batch_size."""
+        """(z_loc, z_scale) of the encoded distributions, on the CPU (models/ved.py:165-181).  kwargs: batch_size.
+        As in the reference this puts the module in eval() mode (batch-norm layers then use their running statistics)
+        and nothing switches it back."""
+        self.eval()
         z = self._encode(x_new, **kwargs)
         z_loc, z_scale = z.split(self.z_dim, 1)
         return z_loc, z_scale
 
     def decode(self, z: torch.Tensor, **kwargs: int) -> torch.Tensor:
         """Decodes latent coordinates into the target space (models/ved.py:183-196).  kwargs: batch_size."""
+        self.eval()
         return self._decode(z.to(torch.float32).cpu(), **kwargs)
 
     def predict(self, x_new: torch.Tensor, **kwargs: int) -> torch.Tensor:
@@ -107,6 +111,7 @@ class VED(baseVAE):
         if plot:
             raise NotImplementedError("plotting is not part of this build; call with plot=False")
         import torch.distributions as td
+        self.eval()
         dd = [d, d] if isinstance(d, int) else d
         z_coord = kwargs.get("z_coord")
         if z_coord:

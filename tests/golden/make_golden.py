@@ -275,6 +275,28 @@ def run_ved_steps(name, input_dim, output_dim, batch, steps=3, latent_dim=2, mod
     z_loc, z_scale = model.encode(x)
     out["enc.z_loc"], out["enc.z_scale"] = z_loc.numpy().copy(), z_scale.numpy().copy()
     out["dec.loc"] = model.decode(z_loc).numpy().copy()
+    if model_kw.get("batchnorm"):
+        # encode() / decode() left the module in eval() mode (models/ved.py:178,193): the next training step runs with
+        # the batch-norm layers on their running statistics — recorded as step "e0"
+        for n, b_ in model.named_buffers():
+            put(out, "buf." + n, digest(b_.float()))
+        grads = {}
+        real_optim = trainer.svi.optim
+
+        def spy2(params, _real=real_optim, _g=grads):
+            for p in params:
+                _g[names[id(p)]] = p.grad.detach().clone()
+            _real(params)
+        trainer.svi.optim = spy2
+        loss = trainer.svi.step(x, y, **step_kw)
+        trainer.svi.optim = real_optim
+        tap = _minipyro.tap()
+        out["e0.loss"] = np.float64(loss)
+        out["e0.eps"] = tap["z.eps"].numpy().copy()
+        for n, gr in grads.items():
+            put(out, "e0.grad." + n, digest(gr))
+        for n, p in model.named_parameters():
+            put(out, "e0.param." + n, digest(p))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name, "loss0=%.6f" % out["s0.loss"], "keys=%d" % len(out))
 
@@ -507,6 +529,11 @@ if __name__ == "__main__":
         run_ved_steps("ved_12x20_to_24_small_b3_l3", (12, 20), (24,), batch=3, latent_dim=3, model_kw=small)
         run_ved_steps("ved_1d32_to_1d32_small_b4", (32,), (32,), batch=4, model_kw=small)
         run_ved_steps("ved_64x64_to_128_b4", (64, 64), (128,), batch=4, steps=2)
+    if only is None or "vedbn" in only:
+        small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)], batchnorm=True)
+        run_ved_steps("vedbn_16x16_to_32_small_b5", (16, 16), (32,), batch=5, model_kw=small)
+        run_ved_steps("vedbn_16x16_to_8x12_small_b4", (16, 16), (8, 12), batch=4, model_kw=small)
+        run_ved_steps("vedbn_1d32_to_1d32_small_b4_relu", (32,), (32,), batch=4, model_kw=dict(small, activation="relu"))
     if only is None or "ved2d" in only:
         small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])
         run_ved_steps("ved_16x16_to_8x12_small_b4", (16, 16), (8, 12), batch=4, model_kw=small)     # bilinear upsampling

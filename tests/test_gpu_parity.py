@@ -401,6 +401,78 @@ def test_ved_steps_vs_golden_and_oracle(gpu_device, name):
     assert mu.shape == dec[:2].shape and sd.shape == mu.shape and torch.isfinite(mu).all()
 
 
+VEDBN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "vedbn_*.npz")))
+
+
+@pytest.mark.parametrize("name", VEDBN_CASES)
+def test_vedbn_steps_vs_oracle(gpu_device, name):
+    """VED(batchnorm=True) on the HIP path against the oracle from identical parameters AND running statistics at every
+    step: training-mode steps (batch statistics, running estimates updated in the flat buffer), encode / decode in eval()
+    mode, then a training step on the running statistics (the reference never switches back to train())."""
+    from test_oracle_golden import vedbn_oracle
+    gold = load_golden(name)
+    c, model, cfg = vedbn_oracle(gold, "cuda")
+    eng = model.engine()
+    o = orc.VedOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x, y = torch.from_numpy(gold["x"]), torch.from_numpy(gold["y"])
+
+    def resync():
+        sd = {k_: v_.detach() for k_, v_ in o.p.items()}
+        sd.update(o.bufs)
+        model.load_state_dict(sd)
+
+    def one_step(eps, first):
+        eng.loss_and_grads(x.cuda(), eps.cuda(), c["beta"], y.cuda())
+        loss = eng.scalars[0].item()
+        ref = o.step(x, y, eps, c["beta"])
+        np.testing.assert_allclose(loss, ref, rtol=3e-5, err_msg="loss")
+        if first:
+            np.testing.assert_allclose(loss, float(gold["s0.loss"]), rtol=3e-5)
+        for key in o.p:
+            g, go = eng.grad_of(key), o.last_grads[key]
+            if go.abs().max() < 1e-4 * max(v.abs().max() for v in o.last_grads.values()):
+                assert (g.cpu() - go).abs().max() < 1e-5, key       # (the biases in front of a batch norm: ~0 gradient)
+                continue
+            assert rel_l2(g, go) < 2e-4, "grad %s: rel l2 %.3e" % (key, rel_l2(g, go))
+        eng.adam_step()
+        for k_, b_ in model.named_buffers():                        # running statistics, num_batches_tracked
+            np.testing.assert_allclose(b_.detach().cpu().double().numpy(), o.bufs[k_].double().numpy(), rtol=2e-5, atol=1e-6,
+                                       err_msg=k_)
+        resync()
+
+    for k in range(c["steps"]):
+        one_step(torch.from_numpy(gold["s%d.eps" % k]), k == 0)
+    assert model.training
+    z_loc, z_scale = model.encode(x)
+    assert not model.training                                        # VED.encode -> self.eval() (models/ved.py:178)
+    zlo, zso = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), zlo.numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z_scale.numpy(), zso.numpy(), rtol=1e-4, atol=5e-6)
+    dec = model.decode(zlo)
+    np.testing.assert_allclose(dec.numpy(), o.decode(zlo).numpy(), rtol=1e-4, atol=2e-6)
+    one_step(torch.from_numpy(gold["e0.eps"]), False)                # trains on the running statistics from here on
+
+
+def test_convenc_batchnorm_runs(gpu_device):
+    """iVAE.set_encoder(convEncoderNet(..., batchnorm=True)): the same batch-norm kernels inside the iVAE step (the
+    arithmetic is pinned by test_vedbn_steps_vs_oracle): finite decreasing loss, running statistics move, state_dict
+    keeps the reference's keys."""
+    model = pv.models.iVAE((16, 16), 2, ["r", "t"], seed=1, device="cuda")
+    model.set_encoder(pv.nets.convEncoderNet((16, 16), latent_dim=model.z_dim, hidden_dim=[(8,), (16, 16)], batchnorm=True))
+    tr = pv.trainers.SVItrainer(model, seed=1)
+    rm0 = model.encoder_z.feature_extractor.layers[2].running_mean.clone()
+    loader = pv.utils.init_dataloader(make_x("rand", 64, (16, 16)), batch_size=16)
+    for _ in range(3):
+        tr.step(loader)
+    h = tr.loss_history["training_loss"]
+    assert all(np.isfinite(h)) and h[-1] < h[0]
+    bn = model.encoder_z.feature_extractor.layers[2]
+    assert not torch.equal(bn.running_mean, rm0) and int(bn.num_batches_tracked) == 12
+    assert "encoder_z.feature_extractor.layers.2.running_var" in model.state_dict()
+    z_loc, z_scale = model.encode(make_x("rand", 8, (16, 16)))
+    assert torch.isfinite(z_loc).all() and (z_scale > 0).all()
+
+
 def test_ved_trainer_epochs_vs_oracle(gpu_device):
     """SVItrainer(VED).step(loader of (x, y)) vs the oracle driven through the same DataLoader / eps stream."""
     small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])

@@ -207,7 +207,7 @@ def ved_case(gold):
     for k in gold:
         if k.startswith("meta.model_kw."):
             v = str(gold[k])
-            kw[k[len("meta.model_kw."):]] = ast.literal_eval(v) if v[0] in "[(" else v
+            kw[k[len("meta.model_kw."):]] = ast.literal_eval(v) if (v[0] in "[(" or v in ("True", "False")) else v
     return dict(input_dim=tuple(int(v) for v in gold["meta.input_dim"]),
                 output_dim=tuple(int(v) for v in gold["meta.output_dim"]),
                 latent_dim=int(gold["meta.latent_dim"]), steps=int(gold["meta.steps"]),
@@ -247,6 +247,51 @@ def test_ved_oracle_steps_match_reference(name):
     z_loc, z_scale = o.encode(x)
     np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(o.decode(z_loc).numpy(), gold["dec.loc"], rtol=1e-5, atol=1e-6)
+
+
+VEDBN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "vedbn_*.npz")))
+
+
+def vedbn_oracle(gold, device="cpu"):
+    c = ved_case(gold)
+    model = pv.models.VED(c["input_dim"], c["output_dim"], latent_dim=c["latent_dim"], seed=1, device=device, **c["kw"])
+    cfg = orc.VedConfig(input_dim=c["input_dim"], output_dim=c["output_dim"], latent_dim=c["latent_dim"],
+                        hidden_dim_e=c["kw"].get("hidden_dim_e"), hidden_dim_d=c["kw"].get("hidden_dim_d"),
+                        activation=c["kw"].get("activation", "lrelu"), batchnorm=True)
+    return c, model, cfg
+
+
+@pytest.mark.parametrize("name", VEDBN_CASES)
+def test_vedbn_oracle_steps_match_reference(name):
+    """VED(batchnorm=True): batch statistics + running estimates while training, and — after encode() / decode() left the
+    module in eval() mode, as the reference does — one more training step on the running statistics ("e0")."""
+    gold = load_golden(name)
+    c, model, cfg = vedbn_oracle(gold)
+    assert c["kw"]["batchnorm"] is True
+    for n, p in model.named_parameters():
+        check_digest(p, gold, "init." + n, rtol=0, atol=0, what=name)
+    o = orc.VedOracle(model.state_dict(), cfg)
+    x, y = torch.from_numpy(gold["x"]), torch.from_numpy(gold["y"])
+    for k in range(c["steps"]):
+        pre = "s%d" % k
+        loss = o.step(x, y, torch.from_numpy(gold[pre + ".eps"]), c["beta"])
+        np.testing.assert_allclose(loss, float(gold[pre + ".loss"]), rtol=5e-6 if k == 0 else 1e-4)
+        for n in o.p:
+            check_digest(o.last_grads[n], gold, pre + ".grad." + n, rtol=3e-4 if k == 0 else 2e-2, atol=2e-6, what=name)
+            check_digest(o.p[n], gold, pre + ".param." + n, rtol=1e-5, atol=2.2e-3, what=name, sum_slack=0.02 * o.p[n].numel() ** 0.5 * 1e-3)   # (gradients of the biases in front of a batch norm are noise-sized: Adam sign flips)
+    z_loc, z_scale = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(o.decode(z_loc).numpy(), gold["dec.loc"], rtol=2e-3, atol=1e-4)
+    for n, b_ in o.bufs.items():
+        check_digest(b_.float(), gold, "buf." + n, rtol=1e-3, atol=1e-5, what=name)
+    # the eval-mode step: by now the two runs stand on parameters that differ by Adam's noise-decided entries and the
+    # batches are 4-5 samples behind (leaky) ReLU kinks, so only the loss and the gradients' norms are compared here; the
+    # eval-mode arithmetic itself is pinned by the GPU tests against this oracle from identical parameters
+    loss = o.step(x, y, torch.from_numpy(gold["e0.eps"]), c["beta"])
+    np.testing.assert_allclose(loss, float(gold["e0.loss"]), rtol=2e-3)
+    for n in o.p:
+        np.testing.assert_allclose(o.last_grads[n].double().norm().item(), float(gold["e0.grad." + n + ".l2"]), rtol=0.1,
+                                   atol=1e-5, err_msg=n)
 
 
 # ---------------------------------------------------------------- iVAE with a convolutional encoder (set_encoder)
