@@ -261,25 +261,31 @@ __global__ __launch_bounds__(256) void pv_conv3_wgrad_direct_kernel(ConvWg p) {
   }
 }
 
-// out[e] = sum_s part[s][e] in split order (and out_b likewise)
-__global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
-                                             const float* __restrict__ part_b, int nb, float* __restrict__ out_b) {
-  if (part_b && blockIdx.x == gridDim.x - 1) {          // the bias gradient rides in the last workgroup
-    for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-      float v = 0.0f;
-      for (int s = 0; s < nsplit; ++s) v += part_b[(int64_t)s * nb + e];
-      out_b[e] = v;
+// out[e] = sum_s part[s][e] (and out_b likewise), in a fixed order: a workgroup takes 32 outputs x 8 split slices
+// (slice k sums splits k, k+8, ... ; the slices then meet in LDS in slice order) — hundreds of splits are a chain of
+// dependent-latency loads otherwise
+__global__ __launch_bounds__(256) void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n,
+                                                                     float* __restrict__ out, const float* __restrict__ part_b,
+                                                                     int nb, float* __restrict__ out_b) {
+  __shared__ float sm[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t nblk = (n + 31) / 32;
+  for (int64_t blk = blockIdx.x; blk < nblk + (part_b ? (nb + 31) / 32 : 0); blk += gridDim.x) {
+    const bool isb = blk >= nblk;
+    const int64_t e = (isb ? blk - nblk : blk) * 32 + o, lim = isb ? nb : n;
+    const float* src = isb ? part_b : part;
+    float v = 0.0f;
+    if (e < lim)
+      for (int s = sl; s < nsplit; s += 8) v += src[(int64_t)s * lim + e];
+    sm[sl][o] = v;
+    __syncthreads();
+    if (sl == 0 && e < lim) {
+      float t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += sm[k][o];
+      (isb ? out_b : out)[e] = t;
     }
-  }
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-    int s = 0;
-    for (; s + 3 < nsplit; s += 4) {
-      v0 += part[(int64_t)s * n + e]; v1 += part[(int64_t)(s + 1) * n + e];
-      v2 += part[(int64_t)(s + 2) * n + e]; v3 += part[(int64_t)(s + 3) * n + e];
-    }
-    for (; s < nsplit; ++s) v0 += part[(int64_t)s * n + e];
-    out[e] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
   }
 }
 
@@ -321,8 +327,8 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
   hipLaunchKernelGGL(pv_conv3_wgrad_direct_kernel, dim3((unsigned)p.nsplit, (unsigned)(C / CD_KC), (unsigned)((Cout + CD_TN - 1) / CD_TN)),
                      dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
-  int fb = (int)((nw + 255) / 256);
-  if (fb > 1024) fb = 1024;
+  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
+  if (fb > 4096) fb = 4096;
   hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
   PV_LAUNCH_CHECK();
   return 0;
