@@ -4,7 +4,9 @@
 #include "pv_common.h"
 
 int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s);
-int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s);
+// eg_act != NONE: din *= act'(in) (in = the pooled tensor = the producing conv's post-activation output)
+int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s,
+                    int eg_act = 0);
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s);
 int pv_upsample2_bwd(const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s);
 int pv_ncs_to_nsc(const float* in, float* out, int64_t B, int C, int64_t S, hipStream_t s);
@@ -18,8 +20,10 @@ bool pv_conv3_wgrad_direct_supported(int C, int Cout, int nd);
 int64_t pv_conv3_wgrad_direct_ws(int B, int H, int W, int C, int Cout, int nd);
 int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db, int Cout,
                           void* ws, int64_t ws_bytes, hipStream_t s);
+// eg_y / eg_act: optionally out *= act'(eg_y) (eg_y shaped like out): the producing layer's activation backward fused
+// into the input-gradient form
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
-                    float* out, int act, float* wt_scratch, hipStream_t s);
+                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y = nullptr, int eg_act = 0);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

@@ -39,7 +39,7 @@ __global__ void pv_maxpool2_fwd_kernel(const float* __restrict__ in, float* __re
 
 // din[b][y][x][c] = dout of its window if in[...] is the window's FIRST maximum (torch's argmax rule), else 0
 __global__ void pv_maxpool2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
-                                       float* __restrict__ din, int B, int H, int W, int C, int nd) {
+                                       float* __restrict__ din, int B, int H, int W, int C, int nd, int eg_act) {
   const int Ho = H / 2, Wo = nd == 2 ? W / 2 : 1;
   const int64_t total = (int64_t)B * H * W * C;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -60,13 +60,14 @@ __global__ void pv_maxpool2_bwd_kernel(const float* __restrict__ in, const float
       const int mine = (y - 2 * oy) * 2 + (nd == 2 ? x - 2 * ox : 0);
       if (mine == best) g = dout[((b * Ho + oy) * Wo + ox) * C + c];
     }
+    if (eg_act != PV_ACT_NONE) g *= pv_act_grad(in[e], 0.0f, eg_act);
     din[e] = g;
   }
 }
 
 // the same for even H (and W) and C % 4 == 0: one thread per (window, 4 channels) — reads the window once, 16-byte accesses
 __global__ void pv_maxpool2_bwd4_kernel(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ din,
-                                        int B, int H, int W, int C, int nd) {
+                                        int B, int H, int W, int C, int nd, int eg_act) {
   const int Ho = H / 2, Wo = nd == 2 ? W / 2 : 1, C4 = C / 4, nx = nd == 2 ? 2 : 1;
   const int64_t total = (int64_t)B * Ho * Wo * C4;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -94,7 +95,8 @@ __global__ void pv_maxpool2_bwd4_kernel(const float* __restrict__ in, const floa
         const int k = dy * 2 + dx;
         f32x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = best[i] == k ? g[i] : 0.0f;
+        for (int i = 0; i < 4; ++i)
+          o[i] = best[i] == k ? (eg_act != PV_ACT_NONE ? g[i] * pv_act_grad(v[k][i], 0.0f, eg_act) : g[i]) : 0.0f;
         *reinterpret_cast<f32x4*>(din + ((b * H + 2 * oy + dy) * W + (nd == 2 ? 2 * ox + dx : 0)) * C + 4 * c4) = o;
       }
   }
@@ -234,10 +236,13 @@ __global__ void pv_conv_wflip_kernel(const float* __restrict__ w, float* __restr
 int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s) {
   CONV_LAUNCH(pv_maxpool2_fwd_kernel, (int64_t)B * (H / 2) * (nd == 2 ? W / 2 : 1) * C, in, out, B, H, W, C, nd);
 }
-int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s) {
+int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s,
+                    int eg_act) {
+  if (eg_act == PV_ACT_GELU) return PV_EINVAL;
   if (C % 4 == 0 && H % 2 == 0 && (nd == 1 || W % 2 == 0))
-    CONV_LAUNCH(pv_maxpool2_bwd4_kernel, (int64_t)B * (H / 2) * (nd == 2 ? W / 2 : 1) * (C / 4), in, dout, din, B, H, W, C, nd);
-  CONV_LAUNCH(pv_maxpool2_bwd_kernel, (int64_t)B * H * W * C, in, dout, din, B, H, W, C, nd);
+    CONV_LAUNCH(pv_maxpool2_bwd4_kernel, (int64_t)B * (H / 2) * (nd == 2 ? W / 2 : 1) * (C / 4), in, dout, din, B, H, W, C, nd,
+                eg_act);
+  CONV_LAUNCH(pv_maxpool2_bwd_kernel, (int64_t)B * H * W * C, in, dout, din, B, H, W, C, nd, eg_act);
 }
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s) {
   CONV_LAUNCH(pv_upsample2_fwd_kernel, (int64_t)B * 2 * H * (nd == 2 ? 2 * W : 1) * C, in, out, B, H, W, C, nd);

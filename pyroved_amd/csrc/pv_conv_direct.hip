@@ -22,6 +22,7 @@
 
 struct ConvD {
   const float* in; const float* wt; const float* bias; float* out;
+  const float* eg_y; int eg_act;      // optional: out *= act'(eg_y) elementwise (the producing layer's activation backward)
   int B, H, W, Cin, Cout, nd, act, KK, tiles_x, tiles_y;
 };
 
@@ -118,11 +119,20 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = pv_act_fwd(v[i], p.act);
+        if (p.eg_y) {
+          const f32x4 yy = *reinterpret_cast<const f32x4*>(p.eg_y + (orow - p.out) + co);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] *= pv_act_grad(yy[i], 0.0f, p.eg_act);
+        }
         *reinterpret_cast<f32x4*>(orow + co) = v;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (co + i < p.Cout) orow[co + i] = pv_act_fwd(acc[cb][pb][i] + (p.bias ? p.bias[co + i] : 0.0f), p.act);
+          if (co + i < p.Cout) {
+            float v = pv_act_fwd(acc[cb][pb][i] + (p.bias ? p.bias[co + i] : 0.0f), p.act);
+            if (p.eg_y) v *= pv_act_grad(p.eg_y[(orow - p.out) + co + i], 0.0f, p.eg_act);
+            orow[co + i] = v;
+          }
       }
     }
   }
@@ -141,7 +151,7 @@ int64_t pv_conv3_direct_wt_floats(int C, int Cout, int nd) {
 // w: raw torch weight (Co, Ci, KK).  flip == 0: out[.., Co] = act(conv(in[.., Ci]) + bias).
 // flip == 1: out[.., Ci] = conv of in[.., Co] with the flipped / role-swapped weights (the input gradient).
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
-                    float* out, int act, float* wt_scratch, hipStream_t s) {
+                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y, int eg_act) {
   const int KK = nd == 2 ? 9 : 3;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   if (!pv_conv3_direct_supported(C, N, nd, act)) return PV_EINVAL;
@@ -153,6 +163,7 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
   PV_LAUNCH_CHECK();
   ConvD p{};
   p.in = in; p.wt = wt_scratch; p.bias = bias; p.out = out;
+  p.eg_y = (eg_y && eg_act != PV_ACT_NONE) ? eg_y : nullptr; p.eg_act = eg_act;
   p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = N; p.nd = nd; p.act = act; p.KK = KK;
   p.tiles_x = nd == 2 ? (W + 7) / 8 : 1;
   p.tiles_y = nd == 2 ? (H + 7) / 8 : (H + CD_PIX - 1) / CD_PIX;

@@ -98,14 +98,20 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
 
 // one op backward: g = dL/d(out) (post-activation for CONV; modified in place), writes parameter gradients and, when
 // gin != null, dL/d(in)
+// g_is_pre: g already is dL/d(pre-activation) (the consumer's backward applied this layer's activation derivative);
+// fuse_act != NONE: the PRODUCER of `in` is a convolution with that activation — apply act'(in) to gin here (returns
+// *fused = true when done) instead of a separate elementwise pass in the producer's backward
 inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int B, const float* in, const Shape& si,
-                  const float* out, float* g, float* gin, const Scratch& sc, int slot, hipStream_t s) {
+                  const float* out, float* g, float* gin, const Scratch& sc, int slot, hipStream_t s, bool g_is_pre = false,
+                  int fuse_act = PV_ACT_NONE, bool* fused = nullptr) {
+  if (fused) *fused = false;
+  if (fuse_act == PV_ACT_GELU) fuse_act = PV_ACT_NONE;
   if (o.kind == PV_OP_BATCHNORM)
     return pv_bn_bwd(in, g, gin, (int64_t)B * si.H * si.W, si.C, params + o.w_off, bn_slot(sc, slot), sc.bn_eval,
                      grads + o.w_off, grads + o.b_off, sc.ws, sc.ws_bytes, s);
   if (o.kind == PV_OP_CONV) {
     const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
-    PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));                       // g = dL/d(pre-activation)
+    if (!g_is_pre) PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));         // g = dL/d(pre-activation)
     float* db = o.b_off >= 0 ? grads + o.b_off : nullptr;
     if (o.ksize == 3) {
       if (pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
@@ -114,8 +120,11 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
         PV_TRY(conv3_wgrad(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
       if (!gin) return 0;
       // dX = conv3(dpre; taps flipped, channel roles swapped) — same spatial size, C = cout -> cin
-      if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE))
-        return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s);
+      if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
+        if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+        return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s,
+                               in, fuse_act);
+      }
       PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
       return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);
     }
@@ -125,7 +134,10 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
                         sc.ws_bytes, s);
   }
   if (!gin) return 0;
-  if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s);
+  if (o.kind == PV_OP_MAXPOOL2) {
+    if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+    return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s, fuse_act);
+  }
   if (o.kind == PV_OP_UPSAMPLE2_BILINEAR) return pv_upsample2_bil_bwd(g, gin, B, si.H, si.W, si.C, s);
   return pv_upsample2_bwd(g, gin, B, si.H, si.W, si.C, nd, s);
 }
@@ -143,9 +155,15 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
 inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n, int nd, int B, float* const* a,
                      const Shape* sh, float* g, float* const* gbuf, int& pp, bool need_input_grad, float** gout,
                      const Scratch& sc, hipStream_t s, int stack_id = 0) {
+  bool g_is_pre = false;
   for (int i = n - 1; i >= 0; --i) {
     float* gin = (i > 0 || need_input_grad) ? gbuf[pp] : nullptr;
-    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, sc, stack_id * PV_MAX_OPS + i, s));
+    // the layer below is a convolution with an activation: let this op's backward apply act'(a[i]) to gin
+    const int fuse_act = (i > 0 && gin && ops[i - 1].kind == PV_OP_CONV) ? ops[i - 1].act : PV_ACT_NONE;
+    bool fused = false;
+    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, sc, stack_id * PV_MAX_OPS + i, s, g_is_pre,
+                  fuse_act, &fused));
+    g_is_pre = fused;
     g = gin; pp ^= 1;
   }
   if (gout) *gout = g;
