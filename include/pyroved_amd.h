@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 6
+#define PV_ABI_VERSION 7
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -272,6 +272,12 @@ typedef struct pv_ved_plan {
   int32_t dec_c0, dec_dim0[2];
   int32_t bn_eval;                 /* batch-norm layers use their running statistics (module.eval(): VED.encode / decode /
                                       manifold2d switch to it and nothing switches back, models/ved.py:178,193,230)  */
+  int32_t conv_bf16;               /* mixed precision: kernel-3 convolutions with a multiple of 32 input channels run
+                                      forward and input gradient on the bf16 matrix cores in split precision (hi + lo,
+                                      3 products: ~2^-16 per product — gradients that are sums with heavy cancellation
+                                      lose digits, measured 7e-3 on the first layer's weights); 0: f32-input MFMA.
+                                      (pv_ivae_plan's convolutional encoder: selected by fused == 3)                */
+  int32_t _pad;
   float*       params;
   float*       grads;
   float*       adam_m;

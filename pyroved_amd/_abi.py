@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 6
+PV_ABI_VERSION = 7
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -77,6 +77,7 @@ class pv_ved_plan(C.Structure):
         ("enc", pv_op * PV_MAX_OPS), ("dec", pv_op * PV_MAX_OPS),
         ("head", pv_layer), ("l2f", pv_layer),
         ("dec_c0", C.c_int32), ("dec_dim0", C.c_int32 * 2), ("bn_eval", C.c_int32),
+        ("conv_bf16", C.c_int32), ("_pad", C.c_int32),
         ("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
         ("n_params", C.c_int64),
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p),

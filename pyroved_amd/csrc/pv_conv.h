@@ -23,7 +23,8 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
 // eg_y / eg_act: optionally out *= act'(eg_y) (eg_y shaped like out): the producing layer's activation backward fused
 // into the input-gradient form
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
-                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y = nullptr, int eg_act = 0);
+                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y = nullptr, int eg_act = 0,
+                    int use_bf16 = 0);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

@@ -14,6 +14,7 @@
 // flip / role swap of the dgrad form, so staging them is a straight 16-byte copy.
 #include "pv_common.h"
 #include "pv_conv.h"
+#include <stdlib.h>
 
 #define CD_TN 64                 // output channels per workgroup
 #define CD_KC 16                 // input channels per stage
@@ -138,6 +139,10 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
   }
 }
 
+// (bf16 split-precision forms: defined at the end of this file)
+__global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Co, int Ci, int KK, int flip);
+__global__ void pv_conv3_direct_bf16_kernel(ConvD p);
+
 bool pv_conv3_direct_supported(int C, int Cout, int nd, int act) {
   return C >= CD_KC && C % CD_KC == 0 && Cout >= 8 && (nd == 1 || nd == 2) && act != PV_ACT_GELU;
 }
@@ -151,7 +156,7 @@ int64_t pv_conv3_direct_wt_floats(int C, int Cout, int nd) {
 // w: raw torch weight (Co, Ci, KK).  flip == 0: out[.., Co] = act(conv(in[.., Ci]) + bias).
 // flip == 1: out[.., Ci] = conv of in[.., Co] with the flipped / role-swapped weights (the input gradient).
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
-                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y, int eg_act) {
+                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int use_bf16) {
   const int KK = nd == 2 ? 9 : 3;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   if (!pv_conv3_direct_supported(C, N, nd, act)) return PV_EINVAL;
@@ -159,7 +164,12 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
   const int64_t total = (int64_t)nt * (C / CD_KC) * KK * CD_TN * CD_KC;
   int pb = (int)((total + 255) / 256);
   if (pb > 2048) pb = 2048;
-  hipLaunchKernelGGL(pv_conv3_wprep_kernel, dim3(pb), dim3(256), 0, s, w, wt_scratch, Co, Ci, KK, flip);
+  const bool bf16 = use_bf16 && C % 32 == 0;
+  if (bf16)      // (the hi + lo bf16 arrays take the same bytes as the fp32 tiling)
+    hipLaunchKernelGGL(pv_conv3_wprep_bf16_kernel, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wt_scratch), Co, Ci,
+                       KK, flip);
+  else
+    hipLaunchKernelGGL(pv_conv3_wprep_kernel, dim3(pb), dim3(256), 0, s, w, wt_scratch, Co, Ci, KK, flip);
   PV_LAUNCH_CHECK();
   ConvD p{};
   p.in = in; p.wt = wt_scratch; p.bias = bias; p.out = out;
@@ -168,6 +178,12 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
   p.tiles_x = nd == 2 ? (W + 7) / 8 : 1;
   p.tiles_y = nd == 2 ? (H + 7) / 8 : (H + CD_PIX - 1) / CD_PIX;
   const int npix = nd == 2 ? 100 : CD_PIX + 2;
+  if (bf16) {
+    const size_t ldsb = (size_t)(2 * 3 * CD_TN * 32 + 2 * npix * 32) * 2;
+    hipLaunchKernelGGL(pv_conv3_direct_bf16_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt), dim3(256), ldsb, s, p);
+    PV_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = (size_t)(KK * CD_TN * CD_KC + npix * CD_KC) * sizeof(float);
   hipLaunchKernelGGL(pv_conv3_direct_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt), dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
@@ -343,4 +359,142 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
   hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
   PV_LAUNCH_CHECK();
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same direct convolution on the bf16 matrix cores in split precision (x = hi + lo, three products, fp32
+// accumulate) for layers with a multiple of 32 input channels — the mixed-precision mode (plan->conv_bf16): ~2^-16 per
+// product is not enough for the 1e-4 gradient bar where a gradient is a sum with heavy cancellation (the first
+// layer's weights: 7e-3), so the default stays on the f32-input MFMA kernel above.
+// v_mfma_f32_16x16x32_bf16 contracts a whole 32-channel chunk of one tap per instruction, 3 instead of 8 MFMAs per
+// 32 channels at half the cycles each.  Operands are split once: the weights by pv_conv3_wprep_bf16 (tiled
+// [co tile][chunk][tap][64][32], a hi and a lo array), the patch while it is staged.  LDS holds the chunk's patch and
+// the weights of one kernel row (3 taps) at a time: 37 KB, so several workgroups per CU overlap staging and MFMAs.
+typedef __bf16 cbf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf4 __attribute__((ext_vector_type(4)));
+#define CB_KC 32
+#define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Co, int Ci, int KK, int flip) {
+  const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+  const int nt = (N + CD_TN - 1) / CD_TN, nch = C / CB_KC;
+  const int64_t total = (int64_t)nt * nch * KK * CD_TN * CB_KC;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int cl = (int)(e % CB_KC), nl = (int)((e / CB_KC) % CD_TN), t = (int)((e / (CB_KC * CD_TN)) % KK);
+    const int ch = (int)((e / ((int64_t)CB_KC * CD_TN * KK)) % nch), tile = (int)(e / ((int64_t)CB_KC * CD_TN * KK * nch));
+    const int n = tile * CD_TN + nl, c = ch * CB_KC + cl;
+    float v = 0.0f;
+    if (n < N) v = flip ? w[((int64_t)c * Ci + n) * KK + (KK - 1 - t)] : w[((int64_t)n * Ci + c) * KK + t];
+    const __bf16 hi = (__bf16)v;
+    wt[e] = hi;
+    wt[total + e] = (__bf16)(v - (float)hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void pv_conv3_direct_bf16_kernel(ConvD p) {
+  extern __shared__ __attribute__((aligned(16))) char smb_[];
+  const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : CD_PIX + 2, NPIX = PH * PW;
+  const int TG = 3;                                  // taps per weight stage: one kernel row (2-D) / all three (1-D)
+  __bf16* wh = reinterpret_cast<__bf16*>(smb_);                       // [TG][64][32]
+  __bf16* wl = wh + TG * CD_TN * CB_KC;
+  __bf16* ph = wl + TG * CD_TN * CB_KC;                               // [NPIX][32]
+  __bf16* pl = ph + NPIX * CB_KC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+  const int y0 = ty * (p.nd == 2 ? 8 : CD_PIX), x0 = tx * 8;
+  const int cot = blockIdx.y;
+  const int nch = p.Cin / CB_KC;
+  const int64_t wtot = (int64_t)gridDim.y * nch * KK * CD_TN * CB_KC;      // elements of the hi array
+  const __bf16* wt = reinterpret_cast<const __bf16*>(p.wt);
+  const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  int pidx[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int n = wm * 32 + pb * 16 + r;
+    pidx[pb] = p.nd == 2 ? (n >> 3) * PW + (n & 7) : n;
+  }
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();                                 // the previous chunk's reads of the patch are done
+    for (int e = tid; e < NPIX * 8; e += 256) {      // patch: pixel, channels 4*f4 .. 4*f4+3 -> (hi, lo)
+      const int pix = e >> 3, f4 = e & 7;
+      const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
+      const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+        v = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + ch * CB_KC + 4 * f4);
+      cbf4 h4, l4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const __bf16 hh = (__bf16)v[i]; h4[i] = hh; l4[i] = (__bf16)(v[i] - (float)hh); }
+      *reinterpret_cast<cbf4*>(ph + pix * CB_KC + 4 * f4) = h4;
+      *reinterpret_cast<cbf4*>(pl + pix * CB_KC + 4 * f4) = l4;
+    }
+    for (int tg = 0; tg < KK; tg += TG) {
+      if (tg > 0) __syncthreads();                   // the previous tap group's reads of the weights are done
+      {
+        const int64_t src0 = (((int64_t)cot * nch + ch) * KK + tg) * CD_TN * CB_KC;
+        const int4* sh = reinterpret_cast<const int4*>(wt + src0);
+        const int4* sl = reinterpret_cast<const int4*>(wt + wtot + src0);
+        int4* dh = reinterpret_cast<int4*>(wh);
+        int4* dl = reinterpret_cast<int4*>(wl);
+        for (int e = tid; e < TG * CD_TN * CB_KC / 8; e += 256) { dh[e] = sh[e]; dl[e] = sl[e]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < TG; ++tt) {
+        const int tap = tg + tt;
+        const int toff = p.nd == 2 ? (tap / 3) * PW + (tap % 3) : tap;
+        cbf8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const int o = ((tt * CD_TN) + wn * 32 + cb * 16 + r) * CB_KC + 8 * q;
+          ah[cb] = *reinterpret_cast<const cbf8*>(wh + o);
+          al[cb] = *reinterpret_cast<const cbf8*>(wl + o);
+        }
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          const int o = (pidx[pb] + toff) * CB_KC + 8 * q;
+          bh[pb] = *reinterpret_cast<const cbf8*>(ph + o);
+          bl[pb] = *reinterpret_cast<const cbf8*>(pl + o);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA32B(ah[cb], bh[pb], acc[cb][pb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA32B(ah[cb], bl[pb], acc[cb][pb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA32B(al[cb], bh[pb], acc[cb][pb]);
+      }
+    }
+  }
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int n = wm * 32 + pb * 16 + r;
+    const int y = p.nd == 2 ? y0 + (n >> 3) : y0 + n, x = p.nd == 2 ? x0 + (n & 7) : 0;
+    if (y >= p.H || x >= p.W) continue;
+    float* orow = p.out + (((int64_t)b * p.H + y) * p.W + x) * p.Cout;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int co = cot * CD_TN + wn * 32 + cb * 16 + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (co + i < p.Cout) {
+          float v = pv_act_fwd(acc[cb][pb][i] + (p.bias ? p.bias[co + i] : 0.0f), p.act);
+          if (p.eg_y) v *= pv_act_grad(p.eg_y[(orow - p.out) + co + i], 0.0f, p.eg_act);
+          orow[co + i] = v;
+        }
+    }
+  }
 }

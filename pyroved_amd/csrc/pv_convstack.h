@@ -70,6 +70,7 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
 struct Scratch {
   float* col /* flipped-weight scratch (maxcol floats) */; void* ws; int64_t ws_bytes;
   float* bn = nullptr; int bn_maxC = 0; int bn_eval = 0;     // batch-norm statistics slots (bn_floats), mode
+  int conv_bf16 = 0;                                         // kernel-3 convolutions on the bf16 matrix cores (x3)
 };
 inline float* bn_slot(const Scratch& sc, int slot) { return sc.bn + (int64_t)slot * 4 * sc.bn_maxC; }
 
@@ -86,7 +87,8 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
     const float* bias = o.b_off >= 0 ? params + o.b_off : nullptr;
     if (o.ksize == 3) {
       if (pv_conv3_direct_supported(o.cin, o.cout, nd, o.act))
-        return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s);
+        return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr,
+                               0, sc.conv_bf16);
       return conv3_fwd(in, B, si.H, si.W, si.C, nd, params + o.w_off, bias, out, o.cout, o.act, sc.ws, sc.ws_bytes, s);
     }
     return linear_fwd(in, K, params + o.w_off, bias, out, nullptr, o.cout, rows, K, o.cout, o.act, sc.ws, sc.ws_bytes, s);
@@ -123,7 +125,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s,
-                               in, fuse_act);
+                               in, fuse_act, sc.conv_bf16);
       }
       PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
       return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);

@@ -300,7 +300,7 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   float* a[PV_MAX_OPS + 1];
   a[0] = const_cast<float*>(p->x);                  // one input channel: (B, 1, H, W) is already channels-last
   for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-  const pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval};
+  const pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
   const pvcs::Shape& fe = L.ces[p->n_enc_ops];
   PV_TRY(pv_nsc_to_ncs(L.cea[p->n_enc_ops], L.cfeat, B, fe.C, (int64_t)fe.H * fe.W, s));
@@ -413,7 +413,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     float* a[PV_MAX_OPS + 1];
     a[0] = const_cast<float*>(p->x);
     for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-    const pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval};
+    const pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
                            nullptr, sc, s));

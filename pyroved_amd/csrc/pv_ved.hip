@@ -85,6 +85,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
   L.sc.col = c.take(nd.maxcol);
   L.sc.bn = c.take(pvcs::bn_floats(nd)); L.sc.bn_maxC = nd.bn_maxC; L.sc.bn_eval = p->bn_eval;
+  L.sc.conv_bf16 = p->conv_bf16;
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
   L.sc.ws = base ? (void*)(base + c.off) : nullptr;
   c.off += L.sc.ws_bytes;

@@ -87,6 +87,7 @@ class VEDEngine(IVAEEngine):
         p.batch = batch
         p.beta = float(beta)
         p.bn_eval = int(not self.model.training)
+        p.conv_bf16 = int(self.fused == 3)           # SVItrainer(precision="bf16")
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
         need = _abi.lib().pv_ved_workspace_bytes(C.byref(p))
         if need < 0:

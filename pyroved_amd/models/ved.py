@@ -63,7 +63,6 @@ class VED(baseVAE):
     def engine(self, **kw):
         from ..engine_ved import VEDEngine
         if self._engine is None:
-            kw.pop("fused", None)
             self._engine = VEDEngine(self, **kw)
             self.encoder_z._pv_engine = self.decoder._pv_engine = self._engine
         return self._engine

@@ -68,7 +68,7 @@ def timed(eng, B, z_dim, make_args):
 
 if ONLY == "C5":      # VED im2spec 64x64 -> 128, batch 256 per GPU
     model = pv.models.VED((64, 64), (128,), seed=1, device="cuda")
-    eng, B = model.engine(), 256
+    eng, B = model.engine(fused=FUSED), 256
     x = torch.rand(2, B, 1, 64, 64, generator=g).cuda(); y = torch.rand(2, B, 1, 128, generator=g).cuda()
     dt, hist = timed(eng, B, 2, lambda i, e: (x[i % 2], e, 1.0, y[i % 2]))
     print("%-52s %8.3f ms/step  %9.0f images/s  %6.1f TF algorithmic (0.709 GFLOP/img)  loss/img %.3f -> %.3f" % (

@@ -401,6 +401,34 @@ def test_ved_steps_vs_golden_and_oracle(gpu_device, name):
     assert mu.shape == dec[:2].shape and sd.shape == mu.shape and torch.isfinite(mu).all()
 
 
+def test_ved_bf16_mode_vs_oracle(gpu_device):
+    """VED in the mixed-precision mode (SVItrainer(precision="bf16") -> plan.conv_bf16: the kernel-3 convolutions with a
+    multiple of 32 input channels run forward and input gradient on the bf16 matrix cores in split precision): the
+    full-size 64x64 -> 128 net against the fp32 oracle from identical parameters.  ELBO to 1e-4; gradients to 3e-2
+    (measured: <= 1e-4 everywhere except the cancellation-heavy first encoder layer, 7e-3)."""
+    from test_oracle_golden import ved_case
+    gold = load_golden("ved_64x64_to_128_b4")
+    c = ved_case(gold)
+    model = pv.models.VED(c["input_dim"], c["output_dim"], latent_dim=c["latent_dim"], seed=1, device="cuda", **c["kw"])
+    cfg = orc.VedConfig(input_dim=c["input_dim"], output_dim=c["output_dim"], latent_dim=c["latent_dim"])
+    eng = model.engine(fused=3)
+    o = orc.VedOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x, y = torch.from_numpy(gold["x"]), torch.from_numpy(gold["y"])
+    worst = 0.0
+    for k in range(c["steps"]):
+        eps = torch.from_numpy(gold["s%d.eps" % k])
+        eng.loss_and_grads(x.cuda(), eps.cuda(), c["beta"], y.cuda())
+        ref = o.step(x, y, eps, c["beta"])
+        np.testing.assert_allclose(eng.scalars[0].item(), ref, rtol=1e-4)
+        for key in o.p:
+            err = rel_l2(eng.grad_of(key), o.last_grads[key])
+            worst = max(worst, err)
+            assert err < 3e-2, "step %d grad %s: rel l2 %.3e" % (k, key, err)
+        eng.adam_step()
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+    print("worst gradient rel l2 in the bf16 conv mode: %.2e" % worst)
+
+
 VEDBN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "vedbn_*.npz")))
 
 
