@@ -156,3 +156,9 @@ class iVAE(baseVAE):
             y = y.unsqueeze(1) if 0 < y.ndim < 2 else y
             return self.decode(z, y.expand(z.shape[0], *y.shape[1:]), **kwargs)
         return self.decode(z, **kwargs)
+
+    def predict_on_latent(self, train_data, gp_labels, gp_iterations: int = 1, d: int = 12, plot: bool = False):
+        """Gaussian-process regression of labels over the latent space (models/ivae.py:312-364).  It is built on
+        pyro.contrib.gp (utils/gp.py), which is not a dependency of this build: encode with `iVAE.encode`, decode the
+        grid with `iVAE.manifold2d(d)` and fit the GP with the library of your choice."""
+        raise NotImplementedError("predict_on_latent needs pyro.contrib.gp; use encode() / manifold2d() with an external GP")
