@@ -53,20 +53,35 @@ class auxSVItrainer:
                 raise TypeError("optimizer must be None or a dict of Adam arguments (Pyro optimizer objects "
                                 "cannot be used: Pyro is not a dependency of this build)")
             adam.update(optimizer)
-        if pvdist.world(kwargs.get("process_group", None))[1] > 1:
-            raise NotImplementedError("auxSVItrainer is single-process in this build (trainers.SVItrainer is data-parallel)")
+        self.group = kwargs.get("process_group", None)
         precision = kwargs.get("precision", "fp32")
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16' (got %r)" % (precision,))
         self.model = model
-        self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
-                                   fused=int(kwargs.get("fused", 3 if precision == "bf16" else 2)))
+        if kwargs.get("engine") is not None:
+            # test hook: a stand-in engine (tests drive the data-parallel host logic on CPU/gloo with it)
+            self.engine = kwargs["engine"]
+        else:
+            self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
+                                       fused=int(kwargs.get("fused", 3 if precision == "bf16" else 2)))
         if self.engine.task != task:
             raise ValueError("task=%r does not match the model's label network (%s)" % (task, self.engine.task))
         self.engine.lr, self.engine.betas, self.engine.adam_eps = float(adam["lr"]), tuple(adam["betas"]), float(adam["eps"])
         self.history = {"training_loss": [], "test": []}
         self.current_epoch = 0
         self.running_weights = {}
+        if pvdist.world(self.group)[1] > 1:      # replicas start from rank 0's parameters
+            pvdist.broadcast_(self.engine.flat, 0, self.group)
+
+    def _reduced(self, loss):
+        """Data parallel: ONE all-reduce(SUM) of [flat gradient | loss] (the loss rides in the first of the gradient
+        buffer's trailing scalar slots); single process: nothing to do."""
+        eng = self.engine
+        if pvdist.world(self.group)[1] == 1:
+            return loss
+        eng.scalars[0] = loss
+        pvdist.allreduce_sum_(eng.grad, self.group)
+        return eng.scalars[0].clone()
 
     def compute_loss(self, xs: torch.Tensor, ys: Optional[torch.Tensor] = None, **kwargs: float) -> float:
         """Computes the basic (ELBO) and the auxiliary loss and takes the two optimizer steps (auxsvi.py:88-99)."""
@@ -74,21 +89,39 @@ class auxSVItrainer:
         beta = kwargs.get("scale_factor", 1.)
         mult = kwargs.get("aux_loss_multiplier", 20)
         b = xs.shape[0]
-        xs = xs.to(eng.device, torch.float32).reshape(b, -1)
-        if ys is not None:
-            ys = ys.to(eng.device, torch.float32)
+        # the guide's noise for the GLOBAL batch (identical on every rank), then this rank's contiguous slice of
+        # samples: every term of both objectives is a sum over samples, so shard gradients and losses add up
         eps_y = None
+        enum = self.task == "classification" and ys is None
         if self.task == "classification":
             shape = (m.num_classes, b, m.z_dim) if ys is None else (b, m.z_dim)
         else:
             if ys is None:
-                eps_y = torch.empty(b, m.reg_dim).normal_().to(eng.device)
+                eps_y = torch.empty(b, m.reg_dim).normal_()
             shape = (b, m.z_dim)
-        eps = torch.empty(shape).normal_().to(eng.device)
-        loss = eng.elbo_loss_and_grads(xs, eps, ys, eps_y, beta)
+        eps = torch.empty(shape).normal_()
+        rank, world = pvdist.world(self.group)
+        lo, hi = pvdist.shard_bounds(b, rank, world)
+        dev = eng.device
+        zero = torch.zeros((), device=dev)
+        if hi > lo:
+            xs = xs[lo:hi].to(dev, torch.float32).reshape(hi - lo, -1)
+            ys = None if ys is None else ys[lo:hi].to(dev, torch.float32)
+            eps = (eps[:, lo:hi] if enum else eps[lo:hi]).contiguous().to(dev)
+            eps_y = None if eps_y is None else eps_y[lo:hi].to(dev)
+            loss = eng.elbo_loss_and_grads(xs, eps, ys, eps_y, beta)
+        else:                                    # more ranks than samples: contribute zeros
+            eng.grad.zero_()
+            loss = zero
+        loss = self._reduced(loss)
         eng.adam_step()
         if ys is not None:
-            loss = loss + eng.aux_loss_and_grads(xs, ys, mult)
+            if hi > lo:
+                aux = eng.aux_loss_and_grads(xs, ys, mult)
+            else:
+                eng.grad.zero_()
+                aux = zero
+            loss = loss + self._reduced(aux)
         if eng.grads_live:                       # (no parameter has a .grad before the very first backward)
             eng.adam_step()
         return float(loss.item())

@@ -287,3 +287,71 @@ def test_data_parallel_world2_gloo_matches_single_process(name):
                          what="%s rank %d" % (name, rank))
     for key in res[0][2]:     # replicas stay in lock-step
         assert np.array_equal(res[0][2][key], res[1][2][key]), key
+
+
+# ------------------------------------------------------------------------------- auxSVItrainer host logic
+def _aux_trainer_run(name):
+    from conftest import ssmeta_of, ss_build
+    from _oracle_ss_engine import OracleSSEngine
+    gold = load_golden(name)
+    meta = ssmeta_of(gold)
+    model = ss_build(meta, "cpu")
+    model.engine = lambda **kw: eng                      # model.classifier / regressor go through the stand-in too
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     c_dim=meta["dim"])
+    eng = OracleSSEngine(model, cfg, meta["task"])
+    trainer = pv.trainers.auxSVItrainer(model, task=meta["task"], seed=1, engine=eng, device="cpu")
+    xu, xs, ys = (torch.from_numpy(gold[k]) for k in ("xu", "xs", "ys"))
+    lu, ls, lv = pv.utils.init_ssvae_dataloaders(xu[:meta["n_u"]], (xs[:meta["n_s"]], ys[:meta["n_s"]]),
+                                                 (xs[:meta["n_s"]], ys[:meta["n_s"]]), batch_size=meta["batch_s"])
+    for _ in range(meta["epochs"]):
+        trainer.step(lu, ls, lv, scale_factor=meta["beta"], aux_loss_multiplier=meta["mult"])
+    return gold, trainer, eng
+
+
+@pytest.mark.parametrize("name", ["sscls_8x8_rt_k3", "ssreg_8x8_rt_c2", "sscls_8x8_rts_k4_sf"])
+def test_aux_trainer_host_logic_reproduces_reference_epochs(name):
+    """auxSVItrainer's loop around a stand-in engine == the reference trainer: loader interleaving, the guide's noise
+    stream (one (K, B, z) draw for unlabeled classification batches; label noise first for regression), two optimizer
+    steps per call, the test metric."""
+    gold, trainer, _ = _aux_trainer_run(name)
+    np.testing.assert_allclose(trainer.history["training_loss"], gold["epochs.training_loss"], rtol=2e-5)
+    np.testing.assert_allclose([float(v) for v in trainer.history["test"]], gold["epochs.test"], rtol=1e-4, atol=1e-7)
+
+
+def _aux_dp_worker(rank, world, port, name, q):
+    import torch.distributed as td
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        gold, trainer, eng = _aux_trainer_run(name)
+        q.put((rank, trainer.history["training_loss"], [float(v) for v in trainer.history["test"]],
+               {k: v.detach().numpy().copy() for k, v in eng.o.p.items()}))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["sscls_8x8_rt_k3", "ssreg_8x8_rts_c2_sf"])
+def test_aux_trainer_data_parallel_world2_gloo(name):
+    """Two ranks over gloo: every compute_loss call shards its (global) batch by samples — the K enumerated passes of
+    an unlabeled classification batch stay with their sample — and all-reduces [gradients | loss] once per SVI step; the
+    histories equal the single-process reference run and the replicas stay in lock-step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_aux_dp_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    gold = load_golden(name)
+    res.sort(key=lambda t: t[0])
+    for rank, tr, te, params in res:
+        np.testing.assert_allclose(tr, gold["epochs.training_loss"], rtol=5e-5)
+        np.testing.assert_allclose(te, gold["epochs.test"], rtol=1e-3, atol=1e-6)
+    for key in res[0][3]:
+        assert np.array_equal(res[0][3][key], res[1][3][key]), key
