@@ -48,8 +48,9 @@ __global__ void pv_conv3_wprep_kernel(const float* __restrict__ w, float* __rest
 __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : CD_PIX + 2, NPIX = PH * PW;
-  float* wl = smem;                                  // [KK][64][16]
-  float* patch = smem + KK * CD_TN * CD_KC;          // [NPIX][16]
+  constexpr int TG = 3;                              // taps per weight stage: one kernel row (2-D) / all three (1-D)
+  float* wl = smem;                                  // [TG][64][16]
+  float* patch = smem + TG * CD_TN * CD_KC;          // [NPIX][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;           // pixel half, channel half of the 64 x 64 tile
   int t = blockIdx.x;
@@ -73,11 +74,6 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
   }
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();                                 // the previous chunk's reads are done
-    {
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.wt + ((int64_t)cot * nch + ch) * KK * CD_TN * CD_KC);
-      f32x4* dst = reinterpret_cast<f32x4*>(wl);
-      for (int e = tid; e < KK * CD_TN * CD_KC / 4; e += 256) dst[e] = src[e];
-    }
     for (int e = tid; e < NPIX * 4; e += 256) {
       const int pix = e >> 2, f4 = e & 3;
       const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
@@ -87,13 +83,22 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
         v = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + ch * CD_KC + 4 * f4);
       *reinterpret_cast<f32x4*>(patch + pix * CD_KC + 4 * f4) = v;
     }
+    for (int tg = 0; tg < KK; tg += TG) {
+    if (tg > 0) __syncthreads();                     // the previous tap group's reads of the weights are done
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.wt + (((int64_t)cot * nch + ch) * KK + tg) * CD_TN * CD_KC);
+      f32x4* dst = reinterpret_cast<f32x4*>(wl);
+      for (int e = tid; e < TG * CD_TN * CD_KC / 4; e += 256) dst[e] = src[e];
+    }
     __syncthreads();
-    for (int tap = 0; tap < KK; ++tap) {
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) {
+      const int tap = tg + tt;
       const int toff = p.nd == 2 ? (tap / 3) * PW + (tap % 3) : tap;
       f32x4 a[2], bb[2];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
-        a[cb] = *reinterpret_cast<const f32x4*>(wl + ((tap * CD_TN) + wn * 32 + cb * 16 + r) * CD_KC + 4 * q);
+        a[cb] = *reinterpret_cast<const f32x4*>(wl + ((tt * CD_TN) + wn * 32 + cb * 16 + r) * CD_KC + 4 * q);
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
         bb[pb] = *reinterpret_cast<const f32x4*>(patch + (pidx[pb] + toff) * CD_KC + 4 * q);
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
           for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA4(a[cb][s], bb[pb][s], acc[cb][pb]);
+    }
     }
   }
   // C/D layout: lane (column = pixel r, q), reg i -> output channel 16*cb + 4q + i of the wave's half
@@ -184,7 +190,7 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
     PV_LAUNCH_CHECK();
     return 0;
   }
-  const size_t lds = (size_t)(KK * CD_TN * CD_KC + npix * CD_KC) * sizeof(float);
+  const size_t lds = (size_t)(3 * CD_TN * CD_KC + npix * CD_KC) * sizeof(float);
   hipLaunchKernelGGL(pv_conv3_direct_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt), dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
   return 0;
