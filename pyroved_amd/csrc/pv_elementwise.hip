@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void pv_out_lik_kernel(PvOutLik p) {
       dot += hv[jj] * wo[jj];
     }
     const float a = pv_wave_sum(dot) + bo;
-    const float x = p.x[row];
+    const float x = p.x[p.xmod > 0 ? row % p.xmod : row];
     float ll, dlda, locv;
     if (p.lik == PV_LIK_BERNOULLI) {
       // torch.distributions.Bernoulli(probs=sigmoid(a), validate_args=False).log_prob(x):
@@ -500,7 +500,7 @@ int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, h
 //   k = 0) ; dhead[b][2z + k] = softmax backward of dloss/dalpha_bk = -(ll_kb - b1 log K - b1 log alpha_bk - b1)
 __global__ void pv_jiv_combine_kernel(const float* __restrict__ llkb, const float* __restrict__ alpha, float* __restrict__ llb,
                                       float* __restrict__ dzc, int ld_dzc, int n_content, float* __restrict__ dhead, int ldh,
-                                      int z_dim, int B, int K, float beta_disc, int want_grads) {
+                                      int z_dim, int B, int K, float beta_disc, int want_grads, float* __restrict__ dtp) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* al = alpha + (int64_t)b * K;
@@ -513,6 +513,13 @@ __global__ void pv_jiv_combine_kernel(const float* __restrict__ llkb, const floa
     for (int k = 1; k < K; ++k) v += dzc[((int64_t)k * B + b) * ld_dzc + i];
     dzc[(int64_t)b * ld_dzc + i] = v;
   }
+  if (dtp) {                                            // transform-parameter gradients of the K passes (4 per sample)
+    for (int c = 0; c < 4; ++c) {
+      float v = dtp[(int64_t)b * 4 + c];
+      for (int k = 1; k < K; ++k) v += dtp[((int64_t)k * B + b) * 4 + c];
+      dtp[(int64_t)b * 4 + c] = v;
+    }
+  }
   const float lK = logf((float)K);
   float dot = 0.0f;
   for (int k = 0; k < K; ++k)
@@ -523,9 +530,49 @@ __global__ void pv_jiv_combine_kernel(const float* __restrict__ llkb, const floa
   }
 }
 int pv_jiv_combine(const float* llkb, const float* alpha, float* llb, float* dzc, int ld_dzc, int n_content, float* dhead,
-                   int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s) {
+                   int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s, float* dtp) {
   hipLaunchKernelGGL(pv_jiv_combine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, llkb, alpha, llb, dzc, ld_dzc, n_content,
-                     dhead, ldh, z_dim, B, K, beta_disc, want_grads);
+                     dhead, ldh, z_dim, B, K, beta_disc, want_grads, dtp);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void pv_jiv_expand_kernel(const float* __restrict__ head, int ldh, const float* __restrict__ z,
+                                                            int z_dim, int n_content, float* __restrict__ tp,
+                                                            float* __restrict__ zy, float* __restrict__ alpha,
+                                                            float* __restrict__ sw, float* scalars, float beta_disc, int B, int K) {
+  __shared__ float sm[4];
+  float lqd = 0.0f, lpd = 0.0f;
+  const int lat_in = n_content + K, coord = z_dim - n_content;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* lg = head + (int64_t)b * ldh + 2 * z_dim;
+    float mx = lg[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[k]);
+    float se = 0.0f;
+    for (int k = 0; k < K; ++k) se += expf(lg[k] - mx);
+    const float lse = logf(se);
+    for (int k = 0; k < K; ++k) {
+      const float la = lg[k] - mx - lse, a = expf(la);
+      alpha[(int64_t)b * K + k] = a;
+      sw[(int64_t)k * B + b] = a;
+      lqd += a * la;
+      const int64_t srow = (int64_t)k * B + b;
+      if (tp && k > 0)
+        for (int c = 0; c < 8; ++c) tp[srow * 8 + c] = tp[(int64_t)b * 8 + c];
+      float* o = zy + srow * lat_in;
+      for (int i = 0; i < n_content; ++i) o[i] = z[(int64_t)b * z_dim + coord + i];
+      for (int i = 0; i < K; ++i) o[n_content + i] = i == k ? 1.0f : 0.0f;
+    }
+    lpd += -logf((float)K);
+  }
+  lqd = block_sum_256(lqd, sm);
+  lpd = block_sum_256(lpd, sm);
+  if (threadIdx.x == 0) { scalars[2] += beta_disc * lpd; scalars[3] += beta_disc * lqd; }
+}
+int pv_jiv_expand(const float* head, int ldh, const float* z, int z_dim, int n_content, float* tp, float* zy, float* alpha,
+                  float* sw, float* scalars, float beta_disc, int B, int K, hipStream_t s) {
+  hipLaunchKernelGGL(pv_jiv_expand_kernel, dim3(1), dim3(256), 0, s, head, ldh, z, z_dim, n_content, tp, zy, alpha, sw, scalars,
+                     beta_disc, B, K);
   PV_LAUNCH_CHECK();
   return 0;
 }

@@ -54,6 +54,7 @@ struct PvOutLik {
   float sig;
   const float* sw;       // per-sample weights of the gradients (row / N indexes it) or null
   int N;                 // rows per sample (used with sw)
+  int64_t xmod;          // > 0: observations are x[row % xmod] (jiVAE: the K decoder passes score the same B*N pixels)
 };
 int pv_out_lik(const PvOutLik& p, hipStream_t s);
 int64_t pv_out_lik_blocks(int64_t M);
@@ -117,7 +118,12 @@ struct PvLatentBwd {
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
 int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, hipStream_t s);
 int pv_jiv_combine(const float* llkb, const float* alpha, float* llb, float* dzc, int ld_dzc, int n_content, float* dhead,
-                   int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s);
+                   int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s, float* dtp = nullptr);
+// jiVAE on the generic encoder path, after pv_head_fwd: alpha = softmax(head[:, 2z:]), sw[k*B + b] = alpha_bk, the
+// discrete KL terms added to scalars[2], scalars[3], tp rows and the decoder's latent input zy = [z content | onehot(k)]
+// for the K*B decoder samples ordered [k][b]
+int pv_jiv_expand(const float* head, int ldh, const float* z, int z_dim, int n_content, float* tp, float* zy, float* alpha,
+                  float* sw, float* scalars, float beta_disc, int B, int K, hipStream_t s);
 int pv_scale_rows(float* v, const float* w, int64_t rows, int64_t N, hipStream_t s);
 // out[b] = row_ll[b] + beta * sum_i (log p(z_bi) - log q(z_bi | x_b))   (mu = head[b*ldh + i])
 int pv_row_elbo(const float* row_ll, const float* z, const float* head, const float* z_scale, int B, int z_dim, int ldh,

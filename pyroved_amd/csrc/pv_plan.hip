@@ -131,7 +131,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.kl_blocks = (int)((B + 15) / 16);
   L.kl_part = c.take(2 * L.kl_blocks);
   int64_t maxd = 0;
-  L.fused = p->fused && pv_sdec_fused_supported(p);
+  L.fused = p->fused && pv_sdec_fused_supported(p) && !(K > 0 && !L.enc_compact);   // (jiVAE + generic encoder: layered)
   L.f_grid = L.f_kmax = 0;
   L.f_part = L.f_part_hz = L.f_rowtp = L.f_wimg = nullptr;
   for (int i = 0; i < p->n_dec; ++i) {
@@ -168,15 +168,15 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
     if (nchunk < 1) nchunk = 1;
     L.rows_per_chunk = (int)((N + nchunk - 1) / nchunk);
     L.nchunk = (int)((N + L.rows_per_chunk - 1) / L.rows_per_chunk);
-    L.part_hz = c.take(B * L.nchunk * H0);
-    L.part_wc = c.take(B * L.nchunk * H0 * p->coord_dim);
-    L.part_tp = c.take(B * L.nchunk * 4);
+    L.part_hz = c.take(S * L.nchunk * H0);
+    L.part_wc = c.take(S * L.nchunk * H0 * p->coord_dim);
+    L.part_tp = c.take(S * L.nchunk * 4);
     L.dhz = c.take(S * H0);
-    L.dtp = c.take(B * 4);
-    L.dzc = c.take(B * lat_in);
-    upd(gemm_ws_need(B, H0, lat_in));          // hz
-    upd(gemm_ws_need(H0, lat_in, B));          // dWz
-    upd(gemm_ws_need(B, lat_in, H0));          // dzc
+    L.dtp = c.take(S * 4);
+    L.dzc = c.take(S * lat_in);
+    upd(gemm_ws_need(S, H0, lat_in));          // hz
+    upd(gemm_ws_need(H0, lat_in, S));          // dWz
+    upd(gemm_ws_need(S, lat_in, H0));          // dzc
   } else {
     L.hz = L.h0 = nullptr;
     L.logits = c.take(S * N);
@@ -335,7 +335,8 @@ int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
 // leaves the last hidden activation in L.dact[n_dec-1]; for coord_dim == 0 also the logits in L.logits
 int decoder_hidden_fwd(const pv_ivae_plan* p, const Layout& L, const float* zin, int64_t ldz, int64_t lat_in,
                        hipStream_t s) {
-  const int64_t B = p->batch, R = L.rows;
+  const int64_t R = L.rows;
+  const int64_t B = p->coord_dim > 0 ? R / p->n_pix : R;       // decoder samples (jiVAE: K per input)
   const float* in;
   int64_t ldin;
   if (p->coord_dim > 0) {
@@ -536,7 +537,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;
     return pv_enc_fwd(e, s);
   }
-  if (prep || plan_K(p) > 0) return PV_EINVAL;    // (stand-alone preparation on this path; jiVAE needs the compact encoder)
+  if (prep) return PV_EINVAL;                     // (stand-alone preparation on this path)
   if (!L.enc_ext) PV_TRY(encoder_fwd(p, L, s));
   PvHead h{};
   h.head = L.enc_ext ? p->ext_head : L.head; h.scale_direct = L.enc_ext ? 1 : 0; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
@@ -546,7 +547,18 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
   h.has_r = p->has_r; h.has_t = p->has_t; h.has_s = p->has_s;
   h.tp0 = p->t_prior[0]; h.tp1 = p->t_prior[1]; h.sc_prior = p->sc_prior; h.beta = p->beta;
   h.w = p->row_w;
-  return pv_head_fwd(h, s);
+  h.ldh = L.enc_ext ? 0 : (int)plan_head_w(p);
+  const int64_t K = plan_K(p);
+  if (K > 0) h.zy = nullptr;                      // (written per decoder sample below)
+  PV_TRY(pv_head_fwd(h, s));
+  if (K > 0) {
+    const int coord = p->z_dim - p->latent_dim;
+    const int n_content = p->coord_dim > 0 ? p->latent_dim : p->z_dim;
+    (void)coord;
+    PV_TRY(pv_jiv_expand(L.head, (int)plan_head_w(p), L.z, p->z_dim, n_content, p->coord_dim > 0 ? L.tp : nullptr, L.zy,
+                         L.alpha, L.sw, p->scalars, p->beta_disc, p->batch, (int)K, s));
+  }
+  return 0;
 }
 
 // loss_and_grads with the fused persistent spatial-decoder kernel (pv_sdec_fused.hip)
@@ -636,8 +648,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
 
 int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
   const int64_t K = plan_K(p);
-  if (K > 0 && (p->coord_dim > 0 || !L.enc_compact)) return PV_EINVAL;   // invariant jiVAE: fused decoder kernels only
   const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
+  const int64_t S = plan_S(p);                       // decoder samples (jiVAE: K per input, ordered [k][b])
   const int64_t lat_in = plan_lat_in(p);
   float* G = p->grads;
   void* ws = L.scratch;
@@ -662,7 +674,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
     o.bo = p->out.b_off >= 0 ? p->params + p->out.b_off : nullptr; o.x = p->x; o.loc = p->loc; o.llrow = L.llrow;
     o.dpre = want_grads ? cur : nullptr; o.part_dwo = L.part_dwo; o.part_dbo = L.part_dbo; o.M = R; o.H = Hl;
     o.lik = p->lik; o.sigmoid_out = p->sigmoid_out; o.act_last = p->dec[nd - 1].act; o.sig = p->decoder_sig;
-    o.sw = p->row_w; o.N = (int)N;
+    o.sw = K > 0 ? L.sw : p->row_w; o.N = (int)N; o.xmod = K > 0 ? B * N : 0;
     PV_TRY(pv_out_lik(o, s));
   } else {
     // oth <- dL/dlogits (R, N); jiVAE: one pass per enumerated class against the same observations, rows then
@@ -674,7 +686,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
     if (K == 0 && p->row_w && want_grads) PV_TRY(pv_scale_rows(oth, p->row_w, R, N, s));
   }
   if (K > 0) {
-    PV_TRY(pv_segsum(L.llrow, R, N, L.llkb, s));
+    PV_TRY(pv_segsum(L.llrow, S, N, L.llkb, s));
     if (!want_grads) PV_TRY(pv_jiv_combine(L.llkb, L.alpha, L.llb, nullptr, 0, 0, nullptr, 0, (int)z, (int)B, (int)K,
                                            p->beta_disc, 0, s));
   } else {
@@ -724,24 +736,24 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
     cb.dpre0 = cur; cb.grid = p->grid; cb.tp = L.tp; cb.Wc = p->params + p->fc_coord.w_off;
     cb.part_hz = L.part_hz; cb.part_wc = L.part_wc; cb.part_tp = L.part_tp;
     cb.N = (int)N; cb.cd = p->coord_dim; cb.H0 = H0; cb.rows_per_chunk = L.rows_per_chunk;
-    PV_TRY(pv_coordlat_bwd(cb, L.nchunk, (int)B, s));
-    const int np = (int)(B * L.nchunk);
-    PV_TRY(pv_reduce_mid(L.part_hz, (int)B, L.nchunk, H0, L.dhz, s));
+    PV_TRY(pv_coordlat_bwd(cb, L.nchunk, (int)S, s));
+    const int np = (int)(S * L.nchunk);
+    PV_TRY(pv_reduce_mid(L.part_hz, (int)S, L.nchunk, H0, L.dhz, s));
     PV_TRY(pv_reduce_partials(L.part_hz, np, H0, G + p->fc_coord.b_off, H0, s));
     PV_TRY(pv_reduce_partials(L.part_wc, np, (int64_t)H0 * p->coord_dim, G + p->fc_coord.w_off,
                               (int64_t)H0 * p->coord_dim, s));
-    PV_TRY(pv_reduce_mid(L.part_tp, (int)B, L.nchunk, 4, L.dtp, s));
+    PV_TRY(pv_reduce_mid(L.part_tp, (int)S, L.nchunk, 4, L.dtp, s));
     // fc_latent: hz = zin Wz^T
-    PV_TRY(linear_wgrad(L.dhz, H0, zin, ldz, G + p->fc_latent.w_off, nullptr, B, lat_in, H0, ws, wsb, s));
-    PV_TRY(linear_dgrad(L.dhz, H0, p->params + p->fc_latent.w_off, L.dzc, lat_in, nullptr, nullptr, 0, PV_ACT_NONE, B,
+    PV_TRY(linear_wgrad(L.dhz, H0, zin, ldz, G + p->fc_latent.w_off, nullptr, S, lat_in, H0, ws, wsb, s));
+    PV_TRY(linear_dgrad(L.dhz, H0, p->params + p->fc_latent.w_off, L.dzc, lat_in, nullptr, nullptr, 0, PV_ACT_NONE, S,
                         lat_in, H0, ws, wsb, s));
   }
 
   if (K > 0) {
     // sum the K replicas' dL/dz, form ll_b and the class-logit gradients; then the loss scalars
     PV_TRY(pv_jiv_combine(L.llkb, L.alpha, L.llb, L.dzc, (int)lat_in, (int)(lat_in - K), L.dhead, (int)plan_head_w(p), (int)z,
-                          (int)B, (int)K, p->beta_disc, 1, s));
-    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, L.kl_blocks, 1.0f, s));
+                          (int)B, (int)K, p->beta_disc, 1, s, p->coord_dim > 0 ? L.dtp : nullptr));
+    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f, s));
   }
   return latent_encoder_bwd(p, L, lat_in, 4, 1, s);
 }

@@ -1,0 +1,127 @@
+"""Randomised parity sweep on the GPU: random iVAE / jiVAE / ssiVAE / ss_reg_iVAE configurations (data shapes incl. odd and
+1-D, invariance sets, widths, activations, samplers, conditioning, batch sizes incl. 1 and non-multiples of 16, decoder
+paths) against the CPU oracle from identical parameters: loss to 2e-5, every gradient tensor to a relative-L2 bar.
+Prints one line per case and a summary; exit code 1 on any failure.    python scripts/gpu_fuzz.py [n_cases] [seed]"""
+import os, sys, random, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import pyroved_amd as pv
+from oracle import svi_oracle as orc
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def case():
+    one_d = rng.random() < 0.2
+    if one_d:
+        data_dim = (rng.choice([16, 24, 32, 40]),)
+        inv = rng.choice([None, ["t"]])
+    else:
+        data_dim = rng.choice([(8, 8), (12, 20), (16, 16), (7, 9), (28, 28), (16, 8)])
+        inv = rng.choice([None, ["r"], ["t"], ["s"], ["r", "t"], ["r", "s"], ["t", "s"], ["r", "t", "s"]])
+    family = rng.choice(os.environ.get("FAMILIES", "ivae,ivae,ivae,jivae,sscls,ssreg").split(","))
+    wide = rng.random() < 0.6                      # default widths (fused decoder / compact encoder) or custom ones
+    hid = [128, 128] if wide else rng.choice([[64, 64], [32, 48], [128, 64, 32], [16]])
+    act = "tanh" if rng.random() < 0.6 else rng.choice(["relu", "lrelu", "softplus"])
+    sampler = rng.choice(["bernoulli", "bernoulli", "gaussian"])
+    b = rng.choice([1, 2, 5, 7, 16, 19, 33])
+    return dict(family=family, data_dim=data_dim, inv=inv, hid=hid, act=act, sampler=sampler, b=b,
+                latent=rng.choice([2, 2, 3]), c_dim=rng.choice([0, 0, 2, 3]), K=rng.choice([2, 3, 5]),
+                fused=rng.choice([0, 1, 2, 2]), beta=rng.choice([1.0, 1.0, 2.5]))
+
+
+def run(c):
+    g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+    dd, inv, hid = c["data_dim"], c["inv"], c["hid"]
+    kw = dict(hidden_dim_e=hid, hidden_dim_d=hid, activation=c["act"], sampler_d=c["sampler"], seed=rng.randrange(100),
+              device="cuda")
+    b, fam = c["b"], c["family"]
+    x = torch.rand(b, *dd, generator=g)
+    base = dict(data_dim=dd, latent_dim=c["latent"], invariances=inv, n_hidden_e=len(hid), n_hidden_d=len(hid),
+                activation=c["act"], sampler=c["sampler"])
+    tol = 2e-4
+    if fam == "ivae":
+        model = pv.models.iVAE(dd, c["latent"], inv, c_dim=c["c_dim"], **kw)
+        cfg = orc.Config(c_dim=c["c_dim"], **base)
+        eng = model.engine(fused=c["fused"])
+        o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+        y = None
+        if c["c_dim"]:
+            y = torch.zeros(b, c["c_dim"]); y[torch.arange(b), torch.randint(0, c["c_dim"], (b,), generator=g)] = 1.0
+        eps = torch.randn(b, cfg.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), c["beta"], None if y is None else y.cuda())
+        loss = eng.scalars[0].item()
+        ref = o.step(x, eps, c["beta"], y)
+        grads = o.last_grads
+    elif fam == "jivae":
+        model = pv.models.jiVAE(dd, c["latent"], c["K"], inv, **kw)
+        cfg = orc.Config(discrete_dim=c["K"], **base)
+        eng = model.engine(fused=c["fused"])
+        eps = torch.randn(b, cfg.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), c["beta"])
+        o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+        loss = eng.scalars[0].item()
+        ref = o.step(x, eps, c["beta"])
+        grads = o.last_grads
+        tol = 6e-3                                   # class-logit cancellation (see tests: jivae_grad_tol)
+    else:
+        task = "classification" if fam == "sscls" else "regression"
+        dim = c["K"] if fam == "sscls" else rng.choice([1, 2])
+        ctor = pv.models.ssiVAE if fam == "sscls" else pv.models.ss_reg_iVAE
+        kw2 = dict(kw); he = kw2.pop("hidden_dim_e"); hd = kw2.pop("hidden_dim_d")
+        model = ctor(dd, c["latent"], dim, inv, hidden_dim_e=he, hidden_dim_d=hd, **kw2)
+        cfg = orc.Config(c_dim=dim, **base)
+        eng = model.engine(lr=5e-4, fused=c["fused"])
+        o = orc.SSOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg, task)
+        labeled = rng.random() < 0.4
+        xf = x.reshape(b, -1)
+        ys = None
+        if labeled:
+            ys = torch.randn(b, dim, generator=g) if task == "regression" else torch.eye(dim)[torch.randint(0, dim, (b,), generator=g)]
+        eps = torch.randn((dim, b, cfg.z_dim) if (task == "classification" and not labeled) else (b, cfg.z_dim), generator=g)
+        eps_y = torch.randn(b, dim, generator=g) if (task == "regression" and not labeled) else None
+        lt = eng.elbo_loss_and_grads(xf.cuda(), eps.cuda(), None if ys is None else ys.cuda(),
+                                     None if eps_y is None else eps_y.cuda(), c["beta"])
+        loss = lt.item()
+        out = orc.ss_elbo(o.p, cfg, task, xf, eps, ys, eps_y, c["beta"], 0.5, o.grid)
+        out["loss"].backward()
+        ref = out["loss"].item()
+        grads = {k: (torch.zeros_like(v) if v.grad is None else v.grad) for k, v in o.p.items()}
+        tol = 3e-3
+    msg = []
+    if abs(loss - ref) > 3e-5 * abs(ref) + 1e-4:
+        msg.append("loss %.6f vs %.6f" % (loss, ref))
+    gmax = max(v.abs().max().item() for v in grads.values())
+    for k, gr in grads.items():
+        gq = eng.grad_of(k)
+        if gr.abs().max().item() < 1e-6 * gmax:
+            if (gq.cpu() - gr).abs().max().item() > 1e-5 * gmax:
+                msg.append("%s (tiny) abs %.1e" % (k, (gq.cpu() - gr).abs().max().item()))
+            continue
+        e = rel_l2(gq, gr)
+        if not e < tol:
+            msg.append("%s %.1e" % (k, e))
+    return "ok" if not msg else "FAIL " + "; ".join(msg[:4])
+
+
+bad = 0
+for i in range(n_cases):
+    c = case()
+    try:
+        res = run(c)
+    except Exception as e:                               # noqa: BLE001
+        res = "ERROR " + "".join(traceback.format_exception_only(type(e), e)).strip()[:160]
+    if not (res == "ok" or res.startswith("skip")):
+        bad += 1
+    print("%3d %-6s %-9s inv=%-6s hid=%-14s %-8s %-9s b=%-3d c=%d K=%d fused=%d beta=%.1f -> %s" % (
+        i, c["family"], "x".join(map(str, c["data_dim"])), "".join(c["inv"] or ["-"]), c["hid"], c["act"], c["sampler"], c["b"],
+        c["c_dim"], c["K"], c["fused"], c["beta"], res), flush=True)
+print("failures: %d of %d" % (bad, n_cases))
+sys.exit(1 if bad else 0)

@@ -8,7 +8,7 @@ g = torch.Generator().manual_seed(0)
 if which == "ved":
     model = pv.models.VED((64, 64), (128,), seed=1, device="cuda"); B = 256
     x = torch.rand(B, 1, 64, 64, generator=g).cuda(); y = torch.rand(B, 1, 128, generator=g).cuda()
-    eng = model.engine(); eps = torch.randn(B, 2, generator=g).cuda()
+    eng = model.engine(fused=int(os.environ.get("FUSED", 2))); eps = torch.randn(B, 2, generator=g).cuda()
     step = lambda: (eng.loss_and_grads(x, eps, 1.0, y), eng.adam_step())
 else:
     model = pv.models.iVAE((64, 64), 2, ["r", "t", "s"], seed=1, device="cuda"); B = 128
