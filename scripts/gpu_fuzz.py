@@ -26,7 +26,7 @@ def case():
     else:
         data_dim = rng.choice([(8, 8), (12, 20), (16, 16), (7, 9), (28, 28), (16, 8)])
         inv = rng.choice([None, ["r"], ["t"], ["s"], ["r", "t"], ["r", "s"], ["t", "s"], ["r", "t", "s"]])
-    family = rng.choice(os.environ.get("FAMILIES", "ivae,ivae,ivae,jivae,sscls,ssreg").split(","))
+    family = rng.choice(os.environ.get("FAMILIES", "ivae,ivae,ivae,jivae,jivae,sscls,ssreg,ved").split(","))
     wide = rng.random() < 0.6                      # default widths (fused decoder / compact encoder) or custom ones
     hid = [128, 128] if wide else rng.choice([[64, 64], [32, 48], [128, 64, 32], [16]])
     act = "tanh" if rng.random() < 0.6 else rng.choice(["relu", "lrelu", "softplus"])
@@ -37,7 +37,12 @@ def case():
                 fused=rng.choice([0, 1, 2, 2]), beta=rng.choice([1.0, 1.0, 2.5]))
 
 
+FORCE_FUSED = os.environ.get("FORCE_FUSED")        # e.g. 3: the mixed-precision mode everywhere (bars widened to 5e-2 / 5e-4)
+
+
 def run(c):
+    if FORCE_FUSED is not None:
+        c["fused"] = int(FORCE_FUSED)
     g = torch.Generator().manual_seed(rng.randrange(1 << 30))
     dd, inv, hid = c["data_dim"], c["inv"], c["hid"]
     kw = dict(hidden_dim_e=hid, hidden_dim_d=hid, activation=c["act"], sampler_d=c["sampler"], seed=rng.randrange(100),
@@ -71,6 +76,33 @@ def run(c):
         ref = o.step(x, eps, c["beta"])
         grads = o.last_grads
         tol = 6e-3                                   # class-logit cancellation (see tests: jivae_grad_tol)
+    elif fam == "ved":
+        import warnings; warnings.filterwarnings("ignore")
+        in_dim = rng.choice([(16, 16), (12, 20), (32,), (16, 8), (24,)])
+        out_dim = rng.choice([(16,), (32,), (8, 12), (16, 16)])
+        chans = lambda: rng.choice([4, 8, 16, 32])
+        c1, c2, c3 = chans(), chans(), chans()
+        # (a last encoder block with a single conv is inconsistent in the reference itself: its pooling rule then
+        #  disagrees with the feature size convEncoderNet computes — not generated)
+        he = rng.choice([[(c1,), (c2, c2)], [(c1, c1), (c2, c2)], [(c1,), (c2,), (c3, c3)]])
+        hd = rng.choice([[(c2, c2), (c1,)], [(c3,), (c2, c2)], [(c2,), (c1,)]])
+        bn = rng.random() < 0.4
+        act = rng.choice(["lrelu", "relu", "tanh"])
+        model = pv.models.VED(in_dim, out_dim, latent_dim=c["latent"], hidden_dim_e=he, hidden_dim_d=hd, activation=act,
+                              batchnorm=bn, sampler_d=c["sampler"], seed=rng.randrange(100), device="cuda")
+        vcfg = orc.VedConfig(input_dim=in_dim, output_dim=out_dim, latent_dim=c["latent"], hidden_dim_e=he, hidden_dim_d=hd,
+                             activation=act, batchnorm=bn, sampler=c["sampler"])
+        b = max(b, 2) if bn else b
+        eng = model.engine(fused=c["fused"])
+        o = orc.VedOracle({k: v.cpu() for k, v in model.state_dict().items()}, vcfg)
+        xv = torch.rand(b, 1, *in_dim, generator=g); yv = torch.rand(b, 1, *out_dim, generator=g)
+        eps = torch.randn(b, c["latent"], generator=g)
+        eng.loss_and_grads(xv.cuda(), eps.cuda(), c["beta"], yv.cuda())
+        loss = eng.scalars[0].item()
+        ref = o.step(xv, yv, eps, c["beta"])
+        grads = o.last_grads
+        c["data_dim"] = in_dim; c["hid"] = "%s%s" % (he, "+bn" if bn else ""); c["act"] = act; c["b"] = b
+        tol = 3e-2 if c["fused"] == 3 else (2e-3 if bn else 3e-4)
     else:
         task = "classification" if fam == "sscls" else "regression"
         dim = c["K"] if fam == "sscls" else rng.choice([1, 2])
@@ -96,7 +128,10 @@ def run(c):
         grads = {k: (torch.zeros_like(v) if v.grad is None else v.grad) for k, v in o.p.items()}
         tol = 3e-3
     msg = []
-    if abs(loss - ref) > 3e-5 * abs(ref) + 1e-4:
+    ltol = 3e-5
+    if c["fused"] == 3:
+        tol, ltol = max(tol, 5e-2), 5e-4
+    if abs(loss - ref) > ltol * abs(ref) + 1e-4:
         msg.append("loss %.6f vs %.6f" % (loss, ref))
     gmax = max(v.abs().max().item() for v in grads.values())
     for k, gr in grads.items():
@@ -121,7 +156,7 @@ for i in range(n_cases):
     if not (res == "ok" or res.startswith("skip")):
         bad += 1
     print("%3d %-6s %-9s inv=%-6s hid=%-14s %-8s %-9s b=%-3d c=%d K=%d fused=%d beta=%.1f -> %s" % (
-        i, c["family"], "x".join(map(str, c["data_dim"])), "".join(c["inv"] or ["-"]), c["hid"], c["act"], c["sampler"], c["b"],
+        i, c["family"], "x".join(map(str, c["data_dim"])), "".join(c["inv"] or ["-"]), str(c["hid"]), c["act"], c["sampler"], c["b"],
         c["c_dim"], c["K"], c["fused"], c["beta"], res), flush=True)
 print("failures: %d of %d" % (bad, n_cases))
 sys.exit(1 if bad else 0)
