@@ -64,6 +64,9 @@ class Config:
     discrete_dim: int = 0          # > 0: jiVAE (models/jivae.py), K classes enumerated in the ELBO
     conv_encoder: Optional[Sequence[Sequence[int]]] = None   # iVAE.set_encoder(convEncoderNet(data_dim, z_dim, hidden_dim=...)): conv filters per block
     conv_activation: str = "lrelu"
+    conv_batchnorm: bool = False   # convEncoderNet(..., batchnorm=True); the running statistics travel in Config.bufs
+    bufs: Optional[dict] = None    # batch-norm buffers of the conv encoder (set by SVIOracle), always training mode: the
+                                   # reference's iVAE never calls eval() (models/base.py:121-143)
     custom_encoder: Optional[object] = None     # iVAE.set_encoder(user module): a callable x -> (z_loc, z_scale) in torch
     n_hidden_e: int = 2            # number of hidden Linear layers in encoder_z.fc_layers
     n_hidden_d: int = 2
@@ -454,8 +457,8 @@ def _encode_any(p: Params, cfg: Config, x, y=None):
         return cfg.custom_encoder(x)
     if cfg.conv_encoder is not None:
         vc = VedConfig(input_dim=cfg.data_dim, output_dim=cfg.data_dim, latent_dim=cfg.z_dim,
-                       hidden_dim_e=cfg.conv_encoder, activation=cfg.conv_activation)
-        return conv_encoder_forward(p, vc, x.reshape(x.shape[0], 1, *cfg.data_dim))
+                       hidden_dim_e=cfg.conv_encoder, activation=cfg.conv_activation, batchnorm=cfg.conv_batchnorm)
+        return conv_encoder_forward(p, vc, x.reshape(x.shape[0], 1, *cfg.data_dim), cfg.bufs, True)
     return encoder_forward(p, cfg, x, y)
 
 
@@ -471,7 +474,12 @@ class SVIOracle:
 
     def __init__(self, params: Params, cfg: Config, lr: float = 1e-3, dtype=torch.float32):
         self.cfg = cfg
-        self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+        is_buf = lambda k: k.rsplit(".", 1)[-1] in ("running_mean", "running_var", "num_batches_tracked")
+        self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items() if not is_buf(k)}
+        self.bufs = {k: v.detach().clone() for k, v in params.items() if is_buf(k)}     # (batch-norm conv encoder)
+        if self.bufs:
+            import dataclasses
+            self.cfg = cfg = dataclasses.replace(cfg, bufs=self.bufs)
         self.grid = generate_grid(cfg.data_dim, dtype) if cfg.coord > 0 else None
         # one Adam over all tensors is elementwise-identical to Pyro's one-Adam-per-tensor
         self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)

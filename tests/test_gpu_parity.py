@@ -531,6 +531,44 @@ def test_vedbn_steps_vs_oracle(gpu_device, name):
     one_step(torch.from_numpy(gold["e0.eps"]), False)                # trains on the running statistics from here on
 
 
+@pytest.mark.parametrize("fused", [0, 2])
+def test_convenc_batchnorm_vs_oracle(gpu_device, fused):
+    """iVAE.set_encoder(convEncoderNet(..., batchnorm=True)) against the oracle from identical parameters and running
+    statistics: the batch-norm kernels inside the iVAE step (pv_plan.hip's conv-encoder branch); training mode
+    throughout (the reference's iVAE never calls eval())."""
+    dd, inv, hid, b = (16, 16), ["r", "t"], [(8,), (16, 16)], 6
+    model = pv.models.iVAE(dd, 2, inv, seed=1, device="cuda")
+    model.set_encoder(pv.nets.convEncoderNet(dd, latent_dim=model.z_dim, hidden_dim=hid, batchnorm=True))
+    cfg = orc.Config(data_dim=dd, latent_dim=2, invariances=inv, conv_encoder=hid, conv_batchnorm=True)
+    eng = model.engine(fused=fused)
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(b, *dd, generator=g)
+    for k in range(3):
+        eps = torch.randn(b, cfg.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0)
+        ref = o.step(x, eps, 1.0)
+        np.testing.assert_allclose(eng.scalars[0].item(), ref, rtol=3e-5)
+        gmax = max(v.abs().max().item() for v in o.last_grads.values())
+        for key in o.p:
+            gq, go = eng.grad_of(key), o.last_grads[key]
+            if go.abs().max().item() < 1e-4 * gmax:        # (conv biases in front of a batch norm: ~0)
+                assert (gq.cpu() - go).abs().max().item() < 1e-5 * gmax, key
+                continue
+            if key == "decoder.out.bias":
+                assert (gq.cpu() - go).abs().max().item() < 1e-6 * b * 256 + 1e-5
+                continue
+            assert rel_l2(gq, go) < 3e-4, "step %d grad %s: rel l2 %.3e" % (k, key, rel_l2(gq, go))
+        eng.adam_step()
+        for k_, b_ in model.named_buffers():
+            if k_ in o.bufs:
+                np.testing.assert_allclose(b_.detach().cpu().double().numpy(), o.bufs[k_].double().numpy(), rtol=2e-5, atol=1e-6,
+                                           err_msg=k_)
+        sd = {k_: v_.detach() for k_, v_ in o.p.items()}
+        sd.update(o.bufs)
+        model.load_state_dict(sd)
+
+
 def test_convenc_batchnorm_runs(gpu_device):
     """iVAE.set_encoder(convEncoderNet(..., batchnorm=True)): the same batch-norm kernels inside the iVAE step (the
     arithmetic is pinned by test_vedbn_steps_vs_oracle): finite decreasing loss, running statistics move, state_dict
