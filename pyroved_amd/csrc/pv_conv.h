@@ -22,6 +22,8 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
                           void* ws, int64_t ws_bytes, hipStream_t s);
 // eg_y / eg_act: optionally out *= act'(eg_y) (eg_y shaped like out): the producing layer's activation backward fused
 // into the input-gradient form
+int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db,
+                               int Cout, void* ws, int64_t ws_bytes, hipStream_t s);     // C % 32 == 0 (mixed precision)
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
                     float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y = nullptr, int eg_act = 0,
                     int use_bf16 = 0);

@@ -504,3 +504,147 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_bf16_kernel(ConvD p) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The direct weight gradient on the bf16 matrix cores in split precision (mixed-precision mode, plan->conv_bf16), for
+// layers with a multiple of 32 input channels.  Same ownership as pv_conv3_wgrad_direct_kernel (64 output channels x one
+// 32-channel chunk x all taps per workgroup, a range of pixel tiles per split); the dY tile and the patch are staged as
+// bf16 (hi, lo) in their natural [pixel][channel] layouts and BOTH MFMA operands — which need 8 consecutive PIXELS per
+// lane — come out of LDS through the transposing read ds_read_b64_tr_b16: lane (r, q) gets rows 4q .. 4q+3 of column r.
+typedef short cshort4 __attribute__((ext_vector_type(4)));
+typedef short short8_cd __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) cshort4 lds_cshort4;
+__device__ __forceinline__ cbf4 cw_tr(const __bf16* p) {
+  const cshort4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cshort4*)p);
+  return __builtin_bit_cast(cbf4, v);
+}
+__device__ __forceinline__ cbf8 cw_cat(const cbf4& a, const cbf4& b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+#define CW_LDY 72                // dY rows: 64 channels + 8 (bf16 elements)
+#define CW_LDP 40                // patch rows: 32 channels + 8
+
+__global__ __launch_bounds__(256) void pv_conv3_wgrad_bf16_kernel(ConvWg p) {
+  extern __shared__ __attribute__((aligned(16))) char smb_[];
+  const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : CD_PIX + 2, NPIX = PH * PW;
+  __bf16* yh = reinterpret_cast<__bf16*>(smb_);                       // [64][CW_LDY]
+  __bf16* yl = yh + CD_PIX * CW_LDY;
+  __bf16* ph = yl + CD_PIX * CW_LDY;                                  // [NPIX][CW_LDP]
+  __bf16* pl = ph + NPIX * CW_LDP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int split = blockIdx.x, ch = blockIdx.y, cot = blockIdx.z;
+  const int64_t T = (int64_t)p.B * p.tiles_y * p.tiles_x;
+  const int64_t t_lo = T * split / p.nsplit, t_hi = T * (split + 1) / p.nsplit;
+  f32x4 acc[9][2], accb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[t][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+  const short one = 0x3f80;
+  const short8_cd ones_s = {one, one, one, one, one, one, one, one};
+  const cbf8 ones = __builtin_bit_cast(cbf8, ones_s);
+  for (int64_t tt = t_lo; tt < t_hi; ++tt) {
+    int t = (int)tt;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+    const int y0 = ty * (p.nd == 2 ? 8 : CD_PIX), x0 = tx * 8;
+    __syncthreads();
+    for (int e = tid; e < CD_PIX * 16; e += 256) {               // dY tile: pixel n, channels 4*c4 .. 4*c4+3 -> (hi, lo)
+      const int n = e >> 4, c4 = e & 15;
+      const int y = p.nd == 2 ? y0 + (n >> 3) : y0 + n, x = p.nd == 2 ? x0 + (n & 7) : 0;
+      const int co = cot * CD_TN + 4 * c4;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y < p.H && x < p.W) {
+        const float* src = p.dy + (((int64_t)b * p.H + y) * p.W + x) * p.Cout + co;
+        if (co + 3 < p.Cout && (p.Cout & 3) == 0) v = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (co + i < p.Cout) v[i] = src[i];
+        }
+      }
+      cbf4 h4, l4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const __bf16 hh = (__bf16)v[i]; h4[i] = hh; l4[i] = (__bf16)(v[i] - (float)hh); }
+      *reinterpret_cast<cbf4*>(yh + n * CW_LDY + 4 * c4) = h4;
+      *reinterpret_cast<cbf4*>(yl + n * CW_LDY + 4 * c4) = l4;
+    }
+    const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin;
+    for (int e = tid; e < NPIX * 8; e += 256) {
+      const int pix = e >> 3, f4 = e & 7;
+      const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
+      const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+        v = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + ch * CB_KC + 4 * f4);
+      cbf4 h4, l4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const __bf16 hh = (__bf16)v[i]; h4[i] = hh; l4[i] = (__bf16)(v[i] - (float)hh); }
+      *reinterpret_cast<cbf4*>(ph + pix * CW_LDP + 4 * f4) = h4;
+      *reinterpret_cast<cbf4*>(pl + pix * CW_LDP + 4 * f4) = l4;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < 2; ++ks) {                             // 32 pixels: k slots 8q+i <-> pixel 4q+i, 8q+4+i <-> 16+4q+i
+      const int pa = 32 * ks + 4 * q;                            // this lane group's first pixel of the first half
+      const int arow = (pa + (r >> 2)) * CW_LDY + 16 * wave + 4 * (r & 3);
+      const cbf8 ah = cw_cat(cw_tr(yh + arow), cw_tr(yh + arow + 16 * CW_LDY));
+      const cbf8 al = cw_cat(cw_tr(yl + arow), cw_tr(yl + arow + 16 * CW_LDY));
+      if (ch == 0) { accb = MFMA32B(ah, ones, accb); accb = MFMA32B(al, ones, accb); }
+      // patch rows of the two halves' pixels (4 consecutive pixels of one image row each)
+      const int p0 = p.nd == 2 ? (pa >> 3) * PW + (pa & 7) : pa;
+      const int half = p.nd == 2 ? 2 * PW : 16;                  // 16 pixels further: two image rows down (2-D)
+      const int brow = (p0 + (r >> 2)) * CW_LDP + 4 * (r & 3);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < KK) {
+          const int toff = (p.nd == 2 ? (tap / 3) * PW + (tap % 3) : tap) * CW_LDP;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const int o = brow + toff + 16 * cb;
+            const cbf8 bh = cw_cat(cw_tr(ph + o), cw_tr(ph + o + half * CW_LDP));
+            const cbf8 bl = cw_cat(cw_tr(pl + o), cw_tr(pl + o + half * CW_LDP));
+            acc[tap][cb] = MFMA32B(ah, bh, acc[tap][cb]);
+            acc[tap][cb] = MFMA32B(ah, bl, acc[tap][cb]);
+            acc[tap][cb] = MFMA32B(al, bh, acc[tap][cb]);
+          }
+        }
+      }
+    }
+  }
+  // C/D layout: lane (column = ci r, q), reg i -> output channel 16*wave + 4q + i
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int ci = ch * CB_KC + 16 * cb + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = cot * CD_TN + 16 * wave + 4 * q + i;
+      if (co >= p.Cout) continue;
+      float* dst = p.part + (((int64_t)split * p.Cout + co) * p.Cin + ci) * KK;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        if (tap < KK) dst[tap] = acc[tap][cb][i];
+      if (cb == 0 && ch == 0 && r == 0 && p.part_b) p.part_b[(int64_t)split * p.Cout + co] = accb[i];
+    }
+  }
+}
+
+int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db,
+                               int Cout, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (!pv_conv3_wgrad_direct_supported(C, Cout, nd) || C % CB_KC != 0) return PV_EINVAL;
+  if (ws_bytes < pv_conv3_wgrad_direct_ws(B, H, W, C, Cout, nd)) return PV_EWS;
+  const int KK = nd == 2 ? 9 : 3;
+  ConvWg p{};
+  p.dy = dy; p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = Cout; p.nd = nd; p.KK = KK;
+  p.tiles_x = nd == 2 ? (W + 7) / 8 : 1;
+  p.tiles_y = nd == 2 ? (H + 7) / 8 : (H + CD_PIX - 1) / CD_PIX;
+  p.nsplit = wgd_splits(B, H, W, C, Cout, nd);          // (sized for 16-channel chunks: half as many owners here — fine)
+  const int64_t nw = (int64_t)Cout * C * KK;
+  p.part = reinterpret_cast<float*>(ws);
+  p.part_b = db ? p.part + (int64_t)p.nsplit * nw : nullptr;
+  const int npix = nd == 2 ? 100 : CD_PIX + 2;
+  const size_t lds = (size_t)(2 * CD_PIX * CW_LDY + 2 * npix * CW_LDP) * 2;
+  hipLaunchKernelGGL(pv_conv3_wgrad_bf16_kernel, dim3((unsigned)p.nsplit, (unsigned)(C / CB_KC), (unsigned)((Cout + CD_TN - 1) / CD_TN)),
+                     dim3(256), lds, s, p);
+  PV_LAUNCH_CHECK();
+  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
+  if (fb > 4096) fb = 4096;
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
