@@ -143,11 +143,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    # test hook (one-GPU boxes): PV_BENCH_BACKEND=gloo PV_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 over gloo, to
+    # exercise the multi-rank code path end to end where no second GPU exists; the numbers then mean nothing
+    backend = os.environ.get("PV_BENCH_BACKEND", "nccl")
+    if os.environ.get("PV_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as td
     if world > 1:
-        td.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group(backend)
 
     import pyroved_amd as pv
     from pyroved_amd import dist as pvdist

@@ -951,6 +951,28 @@ def test_ss_trainer_epochs_vs_golden(gpu_device, name):
     trainer.print_statistics()
 
 
+def test_bench_multirank_path_on_one_gpu(gpu_device):
+    """bench.py's N > 1 code path end to end (process group, replica broadcast, per-step all-reduce of [gradients | loss],
+    barrier + max-over-ranks timing, one JSON line from rank 0) with two ranks sharing this box's single GPU over gloo
+    (bench.py's test hook): the line must parse and both precision legs must report the same ELBO as a one-rank run
+    would for a global batch of 512 (loss per image of step 0 within 1e-4 of the single-GPU value at batch 256 scale)."""
+    import json
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PV_BENCH_BACKEND="gloo", PV_BENCH_ONE_DEVICE="1")
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
+    assert "fp32_class" in d and abs(d["fp32_class"]["loss_per_image_step0"] - d["elbo"]["loss_per_image_step0"]) < 1e-2
+    assert 500 < d["elbo"]["loss_per_image_step0"] < 600
+
+
 def test_fails_loudly_on_cpu_tensors(gpu_device):
     model = pv.models.iVAE((8, 8), 2, ["r"], seed=1, device="cuda")
     eng = model.engine()
