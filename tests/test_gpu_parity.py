@@ -973,6 +973,30 @@ def test_bench_multirank_path_on_one_gpu(gpu_device):
     assert 500 < d["elbo"]["loss_per_image_step0"] < 600
 
 
+@pytest.mark.parametrize("kind", ["ivae", "ssivae"])
+def test_trainer_data_parallel_two_ranks_one_gpu(gpu_device, kind):
+    """The trainers' data-parallel path with the REAL engine: two ranks (gloo, sharing this box's GPU) shard every global
+    minibatch, all-reduce [gradients | loss] once per SVI step and must reproduce the single-process loss history and
+    weights (sums over samples: sharding is exact up to fp32 summation order)."""
+    import json
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "_dp_gpu_worker.py")
+
+    def run(nproc, port):
+        cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), worker, kind]
+        out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0]
+        return json.loads(line[len("RESULT "):])
+    one, two = run(1, 29541), run(2, 29543)
+    np.testing.assert_allclose(two["train"], one["train"], rtol=2e-5)
+    np.testing.assert_allclose(two["test"], one["test"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(two["wsum"], one["wsum"], rtol=1e-5)
+
+
 def test_fails_loudly_on_cpu_tensors(gpu_device):
     model = pv.models.iVAE((8, 8), 2, ["r"], seed=1, device="cuda")
     eng = model.engine()
