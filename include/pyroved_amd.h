@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 7
+#define PV_ABI_VERSION 8
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -169,6 +169,18 @@ typedef struct pv_ivae_plan {
   const float* row_w;
   float*       row_elbo;
   float*       dy;
+  /* ---- external decoder: a user-supplied decoder (baseVAE.set_decoder(any nn.Module), models/base.py:179-183) runs in
+   * the caller's framework together with the coordinate transform and the likelihood.  ext_decoder != 0: the step is
+   * pv_ivae_guide (encoder, reparameterisation, sampled-KL terms; the sampled z (B, z_dim) lands in ext_z) -> the
+   * caller's decoder forward / backward -> pv_ivae_guide_backward (ext_ll[0] = sum log p(x|z), ext_dz (B, z_dim) =
+   * d(-sum log p(x|z))/dz: loss scalars, head and encoder backward).  `fc_coord`, `fc_latent`, `dec`, `out` are
+   * ignored and only the encoder's parameters live in the flat buffers.  The workspace must stay untouched between the
+   * two calls.  Not combined with discrete_dim or the row_w / row_elbo / dy fields. ---- */
+  float*       ext_z;
+  const float* ext_dz;
+  const float* ext_ll;
+  int32_t      ext_decoder;
+  int32_t      _pad4;
   /* ---- Adam (torch.optim.Adam defaults via pyro.optim.Adam, svi.py:79-81) ---- */
   float   lr, adam_beta1, adam_beta2, adam_eps;
   int32_t adam_step;      /* 1-based step count of THIS update                            */
@@ -201,6 +213,12 @@ int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* strea
  * to zero (pyro.infer.util.zero_grads).  `n` floats starting at each pointer. */
 int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n,
                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* The two halves of the step around an external decoder (plan->ext_decoder, see the struct): the guide (iVAE.guide,
+ * models/ivae.py:204-221, plus the prior / posterior log-densities of the sampled z) and, after the caller's decoder
+ * forward + backward, the rest of the backward pass.  want_grads == 0 in the second call: loss scalars only. */
+int pv_ivae_guide(const pv_ivae_plan* plan, void* stream);
+int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, void* stream);
 
 /* loss_and_grads + adam in one call (single-GPU SVI.step, trainers/svi.py:107). */
 int pv_ivae_step(const pv_ivae_plan* plan, void* stream);

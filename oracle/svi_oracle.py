@@ -68,6 +68,7 @@ class Config:
     bufs: Optional[dict] = None    # batch-norm buffers of the conv encoder (set by SVIOracle), always training mode: the
                                    # reference's iVAE never calls eval() (models/base.py:121-143)
     custom_encoder: Optional[object] = None     # iVAE.set_encoder(user module): a callable x -> (z_loc, z_scale) in torch
+    custom_decoder: Optional[object] = None     # iVAE.set_decoder(user module): (x_coord_prime, z) -> loc, or z -> loc (vanilla)
     n_hidden_e: int = 2            # number of hidden Linear layers in encoder_z.fc_layers
     n_hidden_d: int = 2
     activation: str = "tanh"
@@ -233,9 +234,13 @@ def decode_from_latent(p: Params, cfg: Config, z, y=None, grid=None):
         xc = transform_coordinates(grid.expand(b, *grid.shape), phi, dx, sc)
         if y is not None:
             zc = torch.cat([zc, y], -1)
+        if cfg.custom_decoder is not None:
+            return cfg.custom_decoder(xc, zc), xc
         return sdecoder_forward(p, cfg, xc, zc), xc
     if y is not None:
         z = torch.cat([z, y], -1)
+    if cfg.custom_decoder is not None:
+        return cfg.custom_decoder(z), None
     return fcdecoder_forward(p, cfg, z), None
 
 

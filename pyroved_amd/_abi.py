@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 7
+PV_ABI_VERSION = 8
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -61,6 +61,8 @@ class pv_ivae_plan(C.Structure):
         ("alpha", C.c_void_p), ("ext_head", C.c_void_p), ("ext_dhead", C.c_void_p),
         ("ext_encoder", C.c_int32), ("bn_eval", C.c_int32),
         ("row_w", C.c_void_p), ("row_elbo", C.c_void_p), ("dy", C.c_void_p),
+        ("ext_z", C.c_void_p), ("ext_dz", C.c_void_p), ("ext_ll", C.c_void_p),
+        ("ext_decoder", C.c_int32), ("_pad4", C.c_int32),
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
@@ -112,6 +114,8 @@ SIGNATURES = {
     "pv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "pv_ivae_step": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p]),
+    "pv_ivae_guide": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p]),
+    "pv_ivae_guide_backward": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
     "pv_ivae_encode": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pv_ivae_decode": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_void_p, C.c_void_p]),

@@ -775,7 +775,16 @@ static pv_ivae_plan decode_plan(const pv_ivae_plan* plan) {
   return lay;
 }
 
+static pv_ivae_plan guide_plan(const pv_ivae_plan* plan);
+
 extern "C" int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan) {
+  if (plan && plan->ext_decoder) {                       // only the guide half runs in the library
+    const pv_ivae_plan q = guide_plan(plan);
+    if (!valid_plan(&q)) return PV_EINVAL;
+    Layout L;
+    carve(&q, nullptr, L);
+    return L.total;
+  }
   if (!valid_plan(plan)) return PV_EINVAL;
   Layout L;
   carve(plan, nullptr, L);
@@ -797,6 +806,7 @@ extern "C" int pv_ivae_uses_fused(const pv_ivae_plan* plan) {
 }
 
 extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* stream) {
+  if (plan && plan->ext_decoder) return PV_EINVAL;      // (pv_ivae_guide / pv_ivae_guide_backward)
   if (!valid_plan(plan) || !plan->params || !plan->x || !plan->eps || !plan->scalars || !plan->ws) return PV_EINVAL;
   if (want_grads && !plan->grads) return PV_EINVAL;
   if (plan->ext_encoder && (!plan->ext_head || (want_grads && !plan->ext_dhead))) return PV_EINVAL;
@@ -809,6 +819,49 @@ extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, 
   return loss_and_grads_layered(plan, L, want_grads, s);
 }
 
+// ---- external decoder (plan->ext_decoder): the library's half of the step works on a copy of the plan whose decoder is
+// a placeholder vanilla one (all of z is "content": no transform parameters, no fc_latent product)
+static pv_ivae_plan guide_plan(const pv_ivae_plan* plan) {
+  pv_ivae_plan q = *plan;
+  q.fused = 0; q.coord_dim = 0; q.has_r = q.has_t = q.has_s = 0; q.latent_dim = q.z_dim;
+  q.lik = PV_LIK_GAUSSIAN; q.sigmoid_out = 1;
+  q.n_dec = 1;
+  q.dec[0] = pv_layer{q.z_dim + q.c_dim, 16, PV_ACT_NONE, 0, 0, -1};
+  q.out = pv_layer{16, q.n_pix, PV_ACT_NONE, 0, 0, -1};
+  q.row_w = nullptr; q.row_elbo = nullptr; q.dy = nullptr;
+  return q;
+}
+
+extern "C" int pv_ivae_guide(const pv_ivae_plan* plan, void* stream) {
+  if (!plan || !plan->ext_decoder || plan->discrete_dim > 0 || plan->row_w || plan->row_elbo || plan->dy) return PV_EINVAL;
+  const pv_ivae_plan q = guide_plan(plan);
+  if (!valid_plan(&q) || !q.params || !q.x || !q.eps || !q.scalars || !q.ws || !q.ext_z) return PV_EINVAL;
+  if (q.ext_encoder && !q.ext_head) return PV_EINVAL;
+  Layout L;
+  carve(&q, (char*)q.ws, L);
+  if (q.ws_bytes < L.total) return PV_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  PV_TRY(guide_fwd(&q, L, s));
+  hipError_t e = hipMemcpyAsync(q.ext_z, L.z, (size_t)q.batch * q.z_dim * sizeof(float), hipMemcpyDeviceToDevice, s);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, void* stream) {
+  if (!plan || !plan->ext_decoder || plan->discrete_dim > 0) return PV_EINVAL;
+  const pv_ivae_plan q = guide_plan(plan);
+  if (!valid_plan(&q) || !q.params || !q.eps || !q.scalars || !q.ws || !q.ext_ll) return PV_EINVAL;
+  if (want_grads && (!q.ext_dz || (!q.ext_encoder && !q.grads) || (q.ext_encoder && !q.ext_dhead))) return PV_EINVAL;
+  Layout L;
+  carve(&q, (char*)q.ws, L);
+  if (q.ws_bytes < L.total) return PV_EWS;
+  hipStream_t s = (hipStream_t)stream;
+  // scalars[1] = sum log p(x|z) from the caller; [2], [3] from the guide (kernel partials on the compact encoder path)
+  PV_TRY(pv_finish_scalars(q.ext_ll, 1, q.scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f, s));
+  if (!want_grads) return 0;
+  L.dzc = const_cast<float*>(q.ext_dz);                // d(-ll)/dz for every column of z
+  return latent_encoder_bwd(&q, L, q.z_dim, 4, 1, s);
+}
+
 extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
   PV_TRY(pv_ivae_loss_and_grads(plan, 1, stream));
   return pv_adam_step(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->lr,
@@ -816,8 +869,9 @@ extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
 }
 
 extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream) {
-  if (!valid_plan(plan) || plan->ext_encoder || !plan->params || !plan->x || !plan->ws || !z_loc || !z_scale) return PV_EINVAL;
-  pv_ivae_plan lay = *plan;
+  if (!plan) return PV_EINVAL;
+  pv_ivae_plan lay = plan->ext_decoder ? guide_plan(plan) : *plan;
+  if (!valid_plan(&lay) || plan->ext_encoder || !plan->params || !plan->x || !plan->ws || !z_loc || !z_scale) return PV_EINVAL;
   lay.fused = 0;
   plan = &lay;
   Layout L;

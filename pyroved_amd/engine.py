@@ -66,7 +66,16 @@ class IVAEEngine:
         # on the device: its (z_loc, z_scale) outputs enter the HIP step through plan.ext_head, the gradients come back
         # through plan.ext_dhead and are back-propagated with torch.autograd; its parameters get their own Adam
         self.ext_enc = not isinstance(enc, (fcEncoderNet, jfcEncoderNet, convEncoderNet))
+        # a user-defined decoder (models/base.py:179-183) likewise: the library runs the guide half of the step
+        # (pv_ivae_guide / pv_ivae_guide_backward), the decoder, the coordinate transform and the likelihood run in PyTorch
+        self.ext_dec = not isinstance(dec, (sDecoderNet, fcDecoderNet))
         self.K = 0
+        if self.ext_dec:
+            if self.ext_enc or getattr(m, "discrete_dim", 0):
+                raise UnsupportedModel("a user-defined decoder cannot be combined with a user-defined encoder / discrete "
+                                       "latents here")
+            if m.sampler_d.name not in _abi.LIK:
+                raise UnsupportedModel("decoder sampler %r is not implemented" % m.sampler_d.name)
         if self.ext_enc:
             if getattr(m, "c_dim", 0) != 0 or getattr(m, "discrete_dim", 0):
                 raise UnsupportedModel("a user-defined encoder cannot be combined with c_dim / discrete latents here")
@@ -89,11 +98,12 @@ class IVAEEngine:
             if (m.coord > 0) != isinstance(dec, sDecoderNet):
                 raise UnsupportedModel("invariant models need the spatial decoder, vanilla models fcDecoderNet")
             return
-        if not isinstance(dec, (sDecoderNet, fcDecoderNet)):
-            raise UnsupportedModel("the HIP SVI path needs decoder to be sDecoderNet or fcDecoderNet "
-                                   "(got %s)" % type(dec).__name__)
         if not self.ext_enc and not enc.softplus_out:
             raise UnsupportedModel("encoder without softplus_out is not supported")
+        if not self.conv_enc and len(_linears(enc.fc_layers)) > _abi.PV_MAX_LAYERS:
+            raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
+        if self.ext_dec:
+            return
         if m.coord > 0 and not isinstance(dec, sDecoderNet):
             raise UnsupportedModel("invariant models need the spatial decoder")
         if m.coord == 0 and not isinstance(dec, fcDecoderNet):
@@ -103,8 +113,7 @@ class IVAEEngine:
             raise UnsupportedModel("decoder sampler %r is not implemented in the HIP path yet" % name)
         if name in ("bernoulli", "continuous_bernoulli") and not dec.sigmoid_out:
             raise UnsupportedModel("%s likelihood needs sigmoid_d=True" % name)
-        if (not self.conv_enc and len(_linears(enc.fc_layers)) > _abi.PV_MAX_LAYERS) or \
-                len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
+        if len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
             raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
 
     def _param_order(self):
@@ -113,6 +122,8 @@ class IVAEEngine:
         named = dict(self.model.named_parameters())
         if self.ext_enc:                         # only the decoder lives in the flat buffers
             return [(k, v) for k, v in named.items() if not k.startswith("encoder_z.")]
+        if self.ext_dec:                         # only the encoder does
+            named = {k: v for k, v in named.items() if not k.startswith("decoder.")}
         if self.conv_enc:
             return list(named.items())           # features2latent.fc_latent already is the merged [mu | sigma] head
         heads = ["fc11", "fc12"] + (["fc13"] if self.K > 0 else [])
@@ -179,8 +190,9 @@ class IVAEEngine:
         self.scalars = self.grad[total:total + N_SCALARS]
         self.grid = self.model.grid.to(dev).contiguous() if self.model.coord > 0 else None
         self.ws = None
-        if self.ext_enc:
-            self._enc_params = [q for q in self.model.encoder_z.parameters() if q.requires_grad]
+        if self.ext_enc or self.ext_dec:         # the user module's parameters: their own torch Adam (zero_grads semantics)
+            owner = self.model.encoder_z if self.ext_enc else self.model.decoder
+            self._enc_params = [q for q in owner.parameters() if q.requires_grad]
             if self._enc_opt is None or [id(q) for q in self._enc_opt.param_groups[0]["params"]] != [id(q) for q in self._enc_params]:
                 self._enc_opt = torch.optim.Adam(self._enc_params, lr=self.lr, betas=self.betas, eps=self.adam_eps)
         self._static = self._static_plan()
@@ -189,6 +201,8 @@ class IVAEEngine:
         named = dict(self.model.named_parameters())
         if self.ext_enc:
             named = {k: v for k, v in named.items() if not k.startswith("encoder_z.")}
+        if self.ext_dec:
+            named = {k: v for k, v in named.items() if not k.startswith("decoder.")}
         named.update(dict(self._stat_buffers()))
         if len(named) != len(self._views):
             return False
@@ -246,8 +260,9 @@ class IVAEEngine:
         sp = getattr(m, "sc_prior", None)
         p.sc_prior = float(sp) if sp is not None else 0.0
         p.lik = _abi.LIK[m.sampler_d.name]
-        p.sigmoid_out = int(dec.sigmoid_out)
+        p.sigmoid_out = int(getattr(dec, "sigmoid_out", True))
         p.decoder_sig = m.sampler_d.decoder_sig
+        p.ext_decoder = int(self.ext_dec)
         p.fused = int(self.fused)
         if self.ext_enc:
             p.n_enc = 0
@@ -267,14 +282,15 @@ class IVAEEngine:
             p.discrete_dim = 0
         else:
             self._fc_encoder_plan(p, enc, m)
-        if p.coord_dim > 0:
-            p.fc_coord = self._layer("decoder.coord_latent.fc_coord", dec.coord_latent.fc_coord, "tanh")
-            p.fc_latent = self._layer("decoder.coord_latent.fc_latent", dec.coord_latent.fc_latent, None)
-        idx = [i for i, mod in enumerate(dec.fc_layers) if isinstance(mod, nn.Linear)]
-        p.n_dec = len(idx)
-        for j, i in enumerate(idx):
-            p.dec[j] = self._layer("decoder.fc_layers.%d" % i, dec.fc_layers[i], dec.activation)
-        p.out = self._layer("decoder.out", dec.out, None)
+        if not self.ext_dec:
+            if p.coord_dim > 0:
+                p.fc_coord = self._layer("decoder.coord_latent.fc_coord", dec.coord_latent.fc_coord, "tanh")
+                p.fc_latent = self._layer("decoder.coord_latent.fc_latent", dec.coord_latent.fc_latent, None)
+            idx = [i for i, mod in enumerate(dec.fc_layers) if isinstance(mod, nn.Linear)]
+            p.n_dec = len(idx)
+            for j, i in enumerate(idx):
+                p.dec[j] = self._layer("decoder.fc_layers.%d" % i, dec.fc_layers[i], dec.activation)
+            p.out = self._layer("decoder.out", dec.out, None)
         p.params = self.flat.data_ptr()
         p.grads = self.grad.data_ptr()
         p.adam_m = self.m.data_ptr()
@@ -296,6 +312,7 @@ class IVAEEngine:
         p.bn_eval = int(not self.model.training)
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = p.ext_head = p.ext_dhead = None
         p.row_w = p.row_elbo = p.dy = None
+        p.ext_z = p.ext_dz = p.ext_ll = None
         p.ev_start, p.ev_stop = self.events
         need = _abi.lib().pv_ivae_workspace_bytes(C.byref(p))
         if need < 0:
@@ -325,6 +342,8 @@ class IVAEEngine:
         row_w (B): per-sample weights of the ELBO terms; row_elbo (B) / dy (B, c_dim): extra outputs
         (include/pyroved_amd.h: pv_ivae_plan.row_w / row_elbo / dy)."""
         self.ensure_bound()
+        if self.ext_dec:
+            return self._loss_and_grads_ext_decoder(x, eps, beta, y, want_grads, scalars_out, z_out, loc_out)
         b = x.shape[0]
         p = self._plan(b, beta)
         head = dhead = None
@@ -376,6 +395,87 @@ class IVAEEngine:
         self._count_bn(self._bn_enc)
         self._keep = (x, eps, y, head, dhead, row_w)     # keep inputs alive until the stream has consumed them
 
+    # ------------------------------------------------------------------ user-defined decoder (torch) around the HIP guide
+    def _torch_decode(self, z, y=None, angle=None, shift=None, scale=None):
+        """iVAE.model's decoder half in PyTorch (models/ivae.py:184-198): split, scale by the priors, transform the grid,
+        decode.  Differentiable w.r.t. z and the decoder's parameters.  angle / shift / scale: the fixed transform of
+        baseVAE._decode (models/base.py:153-170) instead of the one read off z (z is then the content part)."""
+        m = self.model
+        b = z.shape[0]
+        if m.coord == 0:
+            return m.decoder(z if y is None else torch.cat([z, y], -1))
+        grid = m.grid.to(z.device).expand(b, *m.grid.shape)
+        if angle is None:
+            phi, dx, sc, zc = m._split_latent(z)
+            if 't' in m.invariances:
+                dx = (dx * m.t_prior.to(z.device)).unsqueeze(1)
+        else:
+            phi = torch.full((b,), float(angle), device=z.device)
+            dx = torch.tensor([float(shift[0]), float(shift[1])][:m.ndim], device=z.device).expand(b, 1, m.ndim)
+            sc = torch.full((b,), float(scale), device=z.device)
+            zc = z
+        if m.ndim == 1:
+            xc = grid + dx
+        else:
+            phi = phi if phi.ndim else phi.expand(b)
+            sc = sc if sc.ndim else sc.expand(b)
+            rot = torch.stack([torch.stack([torch.cos(phi), torch.sin(phi)], 1),
+                               torch.stack([-torch.sin(phi), torch.cos(phi)], 1)], 1)
+            xc = torch.bmm(grid, rot) * sc.reshape(b, 1, 1) + dx                # utils/coord.py:47-88
+        if y is not None:
+            zc = torch.cat([zc, y], -1)
+        return m.decoder(xc, zc)
+
+    def _torch_likelihood(self, loc):
+        import torch.distributions as td
+        s = self.model.sampler_d
+        if s.name == "bernoulli":
+            return td.Bernoulli(loc, validate_args=False)
+        if s.name == "continuous_bernoulli":
+            return td.ContinuousBernoulli(loc)
+        return td.Normal(loc, s.decoder_sig)
+
+    def _loss_and_grads_ext_decoder(self, x, eps, beta, y, want_grads, scalars_out, z_out, loc_out):
+        b = x.shape[0]
+        p = self._plan(b, beta)
+        x = self._prep(x, "x", (b, p.n_pix))
+        eps = self._prep(eps, "eps", (b, p.z_dim))
+        y = self._prep(y, "y", (b, p.c_dim)) if p.c_dim > 0 else None
+        if p.c_dim > 0 and y is None:
+            raise ValueError("class-conditioned model (c_dim=%d) needs y" % p.c_dim)
+        z = torch.empty(b, p.z_dim, device=self.device, dtype=torch.float32)
+        p.x, p.eps, p.y, p.ext_z = x.data_ptr(), eps.data_ptr(), (y.data_ptr() if y is not None else None), z.data_ptr()
+        if z_out is not None:
+            p.z_loc, p.z_scale = z_out[0].data_ptr(), z_out[1].data_ptr()
+        if scalars_out is not None:
+            p.scalars = scalars_out.data_ptr()
+        try:
+            _abi.check(_abi.lib().pv_ivae_guide(C.byref(p), _abi.current_stream()), "pv_ivae_guide")
+            zt = z.detach().requires_grad_(want_grads)
+            with torch.set_grad_enabled(want_grads):
+                loc = self._torch_decode(zt, y)
+                ll = self._torch_likelihood(loc.reshape(b, -1)).log_prob(x).sum()
+            if loc_out is not None:
+                loc_out.copy_(loc.detach().reshape(loc_out.shape))
+            dz = None
+            if want_grads:
+                for q in self._enc_params:
+                    q.grad = None
+                (-ll).backward()
+                dz = zt.grad.contiguous()
+                p.ext_dz = dz.data_ptr()
+            ll1 = ll.detach().reshape(1).to(torch.float32)
+            p.ext_ll = ll1.data_ptr()
+            _abi.check(_abi.lib().pv_ivae_guide_backward(C.byref(p), int(want_grads), _abi.current_stream()),
+                       "pv_ivae_guide_backward")
+        finally:
+            p.scalars = self.scalars.data_ptr()
+            p.ext_z = p.ext_dz = p.ext_ll = None
+        if want_grads:
+            self.grads_live = True
+        self._count_bn(self._bn_enc)
+        self._keep = (x, eps, y, z, dz, ll1)
+
     def _count_bn(self, mods):
         """nn.BatchNorm's num_batches_tracked (a forward in training mode counts; the statistics themselves are updated
         by the kernels)."""
@@ -390,7 +490,7 @@ class IVAEEngine:
             _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), self.n_flat,
             self.lr, self.betas[0], self.betas[1], self.adam_eps, self.adam_t, _abi.current_stream()),
             "pv_adam_step")
-        if self.ext_enc and any(q.grad is not None for q in self._enc_params):
+        if (self.ext_enc or self.ext_dec) and any(q.grad is not None for q in self._enc_params):
             for g_ in self._enc_opt.param_groups:
                 g_["lr"], g_["betas"], g_["eps"] = self.lr, self.betas, self.adam_eps
             self._enc_opt.step()
@@ -401,7 +501,7 @@ class IVAEEngine:
     def extra_grads(self):
         """Gradient tensors that live outside the flat buffer (a user-defined encoder's): reduced separately in
         data-parallel runs."""
-        return [q.grad for q in self._enc_params if q.grad is not None] if self.ext_enc else []
+        return [q.grad for q in self._enc_params if q.grad is not None] if (self.ext_enc or self.ext_dec) else []
 
     def encode(self, x, y=None):
         self.ensure_bound()
@@ -433,6 +533,10 @@ class IVAEEngine:
     def decode(self, z, angle: float = 0.0, shift=(0.0, 0.0), scale: float = 1.0):
         """z: (B, latent_dim + c_dim) content latents [+ class vector]."""
         self.ensure_bound()
+        if self.ext_dec:
+            with torch.no_grad():
+                loc = self._torch_decode(z.to(self.device, torch.float32), None, angle, shift, scale)
+            return loc.reshape(z.shape[0], *self.model.data_dim)
         b = z.shape[0]
         p = self._plan(b)
         lat_in = (p.latent_dim if p.coord_dim > 0 else p.z_dim) + p.c_dim + self.K

@@ -723,6 +723,92 @@ def test_user_defined_encoder(gpu_device, inv, fused):
     assert np.isfinite(tr.loss_history["training_loss"][0])
 
 
+class _UserSpatialDecoder(torch.nn.Module):
+    """A user-defined decoder in the sense of baseVAE.set_decoder (models/base.py:179-183) for an invariant model: any
+    module mapping (x_coord_prime (B, N, 2), z (B, L)) to the image.  Deliberately unlike sDecoderNet (sinusoidal
+    coordinate features, GELU, a multiplicative latent gate)."""
+    def __init__(self, data_dim, latent_dim):
+        super().__init__()
+        self.data_dim = data_dim
+        self.fx = torch.nn.Linear(4, 24)
+        self.fz = torch.nn.Linear(latent_dim, 24)
+        self.h = torch.nn.Linear(24, 16)
+        self.o = torch.nn.Linear(16, 1)
+
+    def forward(self, xc, z):
+        feat = torch.cat([torch.sin(3.0 * xc), torch.cos(3.0 * xc)], -1)
+        h = torch.nn.functional.gelu(self.fx(feat)) * torch.sigmoid(self.fz(z)).unsqueeze(1)
+        return torch.sigmoid(self.o(torch.tanh(self.h(h)))).reshape(-1, *self.data_dim)
+
+
+class _UserVanillaDecoder(torch.nn.Module):
+    def __init__(self, data_dim, z_dim):
+        super().__init__()
+        self.data_dim = data_dim
+        self.a = torch.nn.Linear(z_dim, 20)
+        self.b = torch.nn.Linear(20, data_dim[0] * data_dim[1])
+
+    def forward(self, z):
+        return torch.sigmoid(self.b(torch.nn.functional.softplus(self.a(z)))).reshape(-1, *self.data_dim)
+
+
+@pytest.mark.parametrize("inv", [["r", "t", "s"], ["t"], None])
+def test_user_defined_decoder(gpu_device, inv):
+    """iVAE.set_decoder(user module): the HIP library runs the guide half of the step (encoder, reparameterisation,
+    sampled KL: pv_ivae_guide), the user's decoder + coordinate transform + likelihood run in PyTorch on the device, and
+    pv_ivae_guide_backward carries d(-ll)/dz into the encoder.  Loss, encoder gradients, the module's gradients and both
+    Adam updates against the oracle with the same module on the CPU; decode() with a fixed transform; a trainer epoch."""
+    data_dim, b = (8, 8), 6
+    torch.manual_seed(7)
+    model = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+    mk = (lambda: _UserSpatialDecoder(data_dim, 2)) if inv else (lambda: _UserVanillaDecoder(data_dim, 2))
+    user, ref = mk(), mk()
+    ref.load_state_dict(user.state_dict())
+    model.set_decoder(user)
+    eng = model.engine()
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, custom_decoder=ref)
+    enc_params = {k: v.cpu() for k, v in model.state_dict().items() if k.startswith("encoder_z.")}
+    o = orc.SVIOracle(enc_params, cfg)
+    ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(b, *data_dim, generator=g)
+    for k in range(3):
+        eps = torch.randn(b, model.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), 1.3)
+        ref_opt.zero_grad()
+        o.step(x, eps, 1.3)
+        np.testing.assert_allclose(eng.scalars[0].item(), o.last["loss"].item(), rtol=RTOL_ELBO)
+        np.testing.assert_allclose(eng.scalars[1].item(), o.last["ll"].item(), rtol=RTOL_ELBO)
+        for key in o.p:
+            assert rel_l2(eng.grad_of(key), o.last_grads[key]) < 2e-4, key
+        for (n, pu), pr in zip(user.named_parameters(), ref.parameters()):
+            assert rel_l2(pu.grad, pr.grad) < 2e-4, "decoder %s" % n
+        eng.adam_step()
+        ref_opt.step()
+        for (n, pu), pr in zip(user.named_parameters(), ref.parameters()):
+            assert rel_l2(pu.detach(), pr.detach()) < 1e-4, "decoder %s after Adam" % n
+        model.load_state_dict({**{k_: v_.detach() for k_, v_ in o.p.items()},
+                               **{"decoder." + k_: v_ for k_, v_ in ref.state_dict().items()}})
+    z_loc, z_scale = model.encode(x)
+    zl, zs = o.encode(x)
+    np.testing.assert_allclose(z_loc.numpy(), zl.numpy(), rtol=1e-4, atol=5e-6)
+    zc = zl[:, -2:]
+    with torch.no_grad():
+        if inv:
+            grid = orc.generate_grid(data_dim)
+            kw = dict(angle=0.3, shift=[0.1, -0.2], scale=1.2) if inv == ["r", "t", "s"] else dict(shift=[0.1, -0.2])
+            gt = orc.transform_coordinates(grid.unsqueeze(0), torch.tensor([kw.get("angle", 0.0)]),
+                                           torch.tensor(kw["shift"]).unsqueeze(0), torch.tensor([kw.get("scale", 1.0)]))
+            want = ref(gt.expand(b, *grid.shape), zc)
+            got = model.decode(zc, **{k_: torch.tensor(v_) for k_, v_ in kw.items()})
+        else:
+            want, got = ref(zc), model.decode(zc)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-6)
+    tr = pv.trainers.SVItrainer(model, seed=1)
+    tr.step(pv.utils.init_dataloader(x, batch_size=4), pv.utils.init_dataloader(x, batch_size=3))
+    assert np.isfinite(tr.loss_history["training_loss"][0]) and np.isfinite(tr.loss_history["test_loss"][0])
+
+
 @pytest.mark.parametrize("name", EPOCH_CASES)
 def test_trainer_epochs_vs_golden(gpu_device, name):
     """The product's SVItrainer driven exactly like the reference's (same DataLoader, same seeds):
