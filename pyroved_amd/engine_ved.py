@@ -27,7 +27,7 @@ class VEDEngine(IVAEEngine):
     def _check_model(self):
         m = self.model
         enc, dec = m.encoder_z, m.decoder
-        self.K, self.ext_enc, self.conv_enc = 0, False, False
+        self.K, self.ext_enc, self.ext_dec, self.conv_enc = 0, False, False, False
         if not isinstance(enc, convEncoderNet) or not isinstance(dec, convDecoderNet):
             raise UnsupportedModel("the HIP VED path needs convEncoderNet / convDecoderNet (got %s / %s)"
                                    % (type(enc).__name__, type(dec).__name__))
