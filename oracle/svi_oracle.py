@@ -69,6 +69,7 @@ class Config:
                                    # reference's iVAE never calls eval() (models/base.py:121-143)
     custom_encoder: Optional[object] = None     # iVAE.set_encoder(user module): a callable x -> (z_loc, z_scale) in torch
     custom_decoder: Optional[object] = None     # iVAE.set_decoder(user module): (x_coord_prime, z) -> loc, or z -> loc (vanilla)
+    custom_label_net: Optional[object] = None   # ssiVAE.set_classifier / ss_reg_iVAE.set_regressor(user module): x -> probabilities / means
     n_hidden_e: int = 2            # number of hidden Linear layers in encoder_z.fc_layers
     n_hidden_d: int = 2
     activation: str = "tanh"
@@ -567,6 +568,8 @@ class SVIOracle:
 # fcClassifierNet (nets/fc.py:240-271) or fcRegressorNet (nets/fc.py:274-304).
 # ======================================================================================
 def label_net_forward(p: Params, cfg: Config, x, task: str, n_hidden: int = 2):
+    if cfg.custom_label_net is not None:
+        return cfg.custom_label_net(x.reshape(x.shape[0], -1))
     act = _ACT[cfg.activation]
     h = _fc_stack(p, "encoder_y.fc_layers", n_hidden, act, x.reshape(x.shape[0], -1))
     out = F.linear(h, p["encoder_y.out.weight"], p["encoder_y.out.bias"])

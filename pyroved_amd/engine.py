@@ -124,6 +124,8 @@ class IVAEEngine:
             return [(k, v) for k, v in named.items() if not k.startswith("encoder_z.")]
         if self.ext_dec:                         # only the encoder does
             named = {k: v for k, v in named.items() if not k.startswith("decoder.")}
+        if getattr(self, "ext_y", False):        # a user-defined label network (semi-supervised models) stays in torch
+            named = {k: v for k, v in named.items() if not k.startswith("encoder_y.")}
         if self.conv_enc:
             return list(named.items())           # features2latent.fc_latent already is the merged [mu | sigma] head
         heads = ["fc11", "fc12"] + (["fc13"] if self.K > 0 else [])
@@ -190,8 +192,9 @@ class IVAEEngine:
         self.scalars = self.grad[total:total + N_SCALARS]
         self.grid = self.model.grid.to(dev).contiguous() if self.model.coord > 0 else None
         self.ws = None
-        if self.ext_enc or self.ext_dec:         # the user module's parameters: their own torch Adam (zero_grads semantics)
-            owner = self.model.encoder_z if self.ext_enc else self.model.decoder
+        if self.ext_enc or self.ext_dec or getattr(self, "ext_y", False):
+            # the user module's parameters: their own torch Adam (zero_grads semantics)
+            owner = self.model.encoder_z if self.ext_enc else (self.model.decoder if self.ext_dec else self.model.encoder_y)
             self._enc_params = [q for q in owner.parameters() if q.requires_grad]
             if self._enc_opt is None or [id(q) for q in self._enc_opt.param_groups[0]["params"]] != [id(q) for q in self._enc_params]:
                 self._enc_opt = torch.optim.Adam(self._enc_params, lr=self.lr, betas=self.betas, eps=self.adam_eps)
@@ -203,6 +206,8 @@ class IVAEEngine:
             named = {k: v for k, v in named.items() if not k.startswith("encoder_z.")}
         if self.ext_dec:
             named = {k: v for k, v in named.items() if not k.startswith("decoder.")}
+        if getattr(self, "ext_y", False):
+            named = {k: v for k, v in named.items() if not k.startswith("encoder_y.")}
         named.update(dict(self._stat_buffers()))
         if len(named) != len(self._views):
             return False
@@ -490,7 +495,7 @@ class IVAEEngine:
             _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), self.n_flat,
             self.lr, self.betas[0], self.betas[1], self.adam_eps, self.adam_t, _abi.current_stream()),
             "pv_adam_step")
-        if (self.ext_enc or self.ext_dec) and any(q.grad is not None for q in self._enc_params):
+        if (self.ext_enc or self.ext_dec or getattr(self, "ext_y", False)) and any(q.grad is not None for q in self._enc_params):
             for g_ in self._enc_opt.param_groups:
                 g_["lr"], g_["betas"], g_["eps"] = self.lr, self.betas, self.adam_eps
             self._enc_opt.step()
@@ -501,7 +506,8 @@ class IVAEEngine:
     def extra_grads(self):
         """Gradient tensors that live outside the flat buffer (a user-defined encoder's): reduced separately in
         data-parallel runs."""
-        return [q.grad for q in self._enc_params if q.grad is not None] if (self.ext_enc or self.ext_dec) else []
+        ext = self.ext_enc or self.ext_dec or getattr(self, "ext_y", False)
+        return [q.grad for q in self._enc_params if q.grad is not None] if ext else []
 
     def encode(self, x, y=None):
         self.ensure_bound()

@@ -26,14 +26,16 @@ class SSEngine(IVAEEngine):
     supports_scalars_out = False
 
     def _check_model(self):
-        super()._check_model()
         m = self.model
         net = m.encoder_y
-        self.task = "classification" if isinstance(net, fcClassifierNet) else "regression"
-        if not isinstance(net, (fcClassifierNet, fcRegressorNet)):
-            raise UnsupportedModel("the HIP path needs encoder_y to be pyroved_amd.nets.fcClassifierNet / fcRegressorNet "
-                                   "(got %s)" % type(net).__name__)
-        if len([q for q in net.fc_layers if isinstance(q, nn.Linear)]) > _abi.PV_MAX_LAYERS:
+        # a user-defined label network (set_classifier / set_regressor, ssivae.py:236-240) runs in PyTorch on the device:
+        # its output enters the HIP steps, dloss/d(output) comes back and torch.autograd carries it into the module
+        self.ext_y = not isinstance(net, (fcClassifierNet, fcRegressorNet))
+        super()._check_model()
+        if self.ext_enc or self.ext_dec:
+            raise UnsupportedModel("user-defined encoder_z / decoder are not combined with the semi-supervised models here")
+        self.task = "classification" if hasattr(m, "num_classes") else "regression"
+        if not self.ext_y and len([q for q in net.fc_layers if isinstance(q, nn.Linear)]) > _abi.PV_MAX_LAYERS:
             raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
         self.reg_sig = float(getattr(m, "reg_sig", 0.5))
         self.ws_y = None
@@ -41,7 +43,9 @@ class SSEngine(IVAEEngine):
     def bind(self):
         super().bind()
         self._scal = torch.zeros(8, device=self.device, dtype=torch.float32)      # loss_add, aux loss
-        self._mlp = self._mlp_plan()
+        self._mlp = None if self.ext_y else self._mlp_plan()
+        self._in_dim = self.model.encoder_z.in_dim - self.model.c_dim
+        self._y_graph = None
         self.ws_y = None
 
     def _mlp_plan(self) -> _abi.pv_mlp_plan:
@@ -73,7 +77,12 @@ class SSEngine(IVAEEngine):
     # ------------------------------------------------------------------ label network
     def label_forward(self, x: torch.Tensor) -> torch.Tensor:
         """encoder_y(x): class probabilities (B, K) or regression means (B, c)."""
-        x = self._prep(x, "x", (x.shape[0], self._mlp.in_dim))
+        x = self._prep(x, "x", (x.shape[0], self._in_dim))
+        if self.ext_y:
+            with torch.set_grad_enabled(torch.is_grad_enabled()):
+                out = self.model.encoder_y(x)
+            self._y_graph = out if out.requires_grad else None
+            return out.detach().to(torch.float32).contiguous()
         q = self._mlp_for(x)
         out = torch.empty(x.shape[0], q.out.out_dim, device=self.device, dtype=torch.float32)
         _abi.check(_abi.lib().pv_mlp_forward(C.byref(q), _abi.ptr(out), _abi.current_stream()), "pv_mlp_forward")
@@ -82,6 +91,15 @@ class SSEngine(IVAEEngine):
 
     def label_backward(self, x: torch.Tensor, out: torch.Tensor, dout: torch.Tensor) -> None:
         """Gradients of encoder_y's parameters from dloss/d(out), after label_forward(x)."""
+        if self.ext_y:
+            if self._y_graph is None:
+                raise RuntimeError("label_backward needs a preceding label_forward with gradients enabled")
+            for q in self._enc_params:
+                q.grad = None
+            torch.autograd.backward([self._y_graph], [dout.to(self._y_graph.dtype)])
+            self._y_graph = None
+            self.grads_live = True
+            return
         x = self._prep(x, "x", (x.shape[0], self._mlp.in_dim))
         q = self._mlp_for(x)
         _abi.check(_abi.lib().pv_mlp_backward(C.byref(q), _abi.ptr(out), _abi.ptr(dout), _abi.current_stream()),
@@ -95,7 +113,7 @@ class SSEngine(IVAEEngine):
         gradients land in self.grad."""
         lib, st = _abi.lib(), _abi.current_stream
         b = x.shape[0]
-        x = self._prep(x, "x", (b, self._mlp.in_dim))
+        x = self._prep(x, "x", (b, self._in_dim))
         c = self.model.c_dim
         add = self._scal[0:1]
         if ys is not None:                                    # observed label: iVAE's ELBO with y = ys + a constant

@@ -62,7 +62,8 @@ class _ssBase(baseVAE):
         loader = init_dataloader(x_new, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
         out = []
         for (x_i,) in loader:
-            out.append(eng.label_forward(x_i.to(eng.device, torch.float32)).cpu())
+            with torch.no_grad():
+                out.append(eng.label_forward(x_i.to(eng.device, torch.float32)).cpu())
         return torch.cat(out)
 
     def decode(self, z: torch.Tensor, y: torch.Tensor, **kwargs: int) -> torch.Tensor:

@@ -809,6 +809,81 @@ def test_user_defined_decoder(gpu_device, inv):
     assert np.isfinite(tr.loss_history["training_loss"][0]) and np.isfinite(tr.loss_history["test_loss"][0])
 
 
+class _UserLabelNet(torch.nn.Module):
+    """A user-defined label network (ssiVAE.set_classifier / ss_reg_iVAE.set_regressor, ssivae.py:236-240)."""
+    def __init__(self, n_in, n_out, softmax):
+        super().__init__()
+        self.a, self.b, self.softmax = torch.nn.Linear(n_in, 12), torch.nn.Linear(12, n_out), softmax
+
+    def forward(self, x):
+        h = self.b(torch.nn.functional.silu(self.a(x.reshape(x.shape[0], -1))))
+        return torch.softmax(h, -1) if self.softmax else h
+
+
+@pytest.mark.parametrize("task", ["classification", "regression"])
+def test_user_defined_label_network(gpu_device, task):
+    """set_classifier / set_regressor(user module): the module runs in PyTorch (its output feeds the HIP steps, dloss/dout
+    comes back through torch.autograd, its parameters take the same two Adam steps per call); everything else as before.
+    Unlabeled and labeled calls against the oracle with the same module on the CPU."""
+    dd, dim, b = (8, 8), 3 if task == "classification" else 2, 5
+    cls = task == "classification"
+    torch.manual_seed(9)
+    ctor = pv.models.ssiVAE if cls else pv.models.ss_reg_iVAE
+    model = ctor(dd, 2, dim, ["r", "t"], seed=1, device="cuda")
+    user, ref = _UserLabelNet(64, dim, cls), _UserLabelNet(64, dim, cls)
+    ref.load_state_dict(user.state_dict())
+    (model.set_classifier if cls else model.set_regressor)(user)
+    eng = model.engine(lr=5e-4)
+    cfg = orc.Config(data_dim=dd, latent_dim=2, invariances=["r", "t"], c_dim=dim, custom_label_net=ref)
+    o = orc.SSOracle({k: v.cpu() for k, v in model.state_dict().items() if not k.startswith("encoder_y.")}, cfg, task)
+    ref_opt = torch.optim.Adam(ref.parameters(), lr=5e-4)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(b, 64, generator=g)
+    ys = torch.eye(dim)[torch.randint(0, dim, (b,), generator=g)] if cls else torch.randn(b, dim, generator=g)
+    for labeled in (False, True, False):
+        y = ys if labeled else None
+        eps = torch.randn((dim, b, model.z_dim) if (cls and not labeled) else (b, model.z_dim), generator=g)
+        eps_y = torch.randn(b, dim, generator=g) if (not cls and not labeled) else None
+        loss = eng.elbo_loss_and_grads(x.cuda(), eps.cuda(), None if y is None else y.cuda(),
+                                       None if eps_y is None else eps_y.cuda(), 1.0)
+        ref_opt.zero_grad(set_to_none=False)      # (pyro zero_grads: zero tensors, not None)
+        out = orc.ss_elbo(o.p, cfg, task, x, eps, y, eps_y, 1.0, 0.5, o.grid)
+        for v in o.p.values():
+            v.grad = None
+        out["loss"].backward()
+        np.testing.assert_allclose(loss.item(), out["loss"].item(), rtol=2e-5)
+        for key, v in o.p.items():
+            assert rel_l2(eng.grad_of(key), v.grad) < 3e-4, key
+        if not labeled:
+            for (n, pu), pr in zip(user.named_parameters(), ref.parameters()):
+                assert rel_l2(pu.grad, pr.grad) < (2e-3 if cls else 3e-4), "label net %s" % n
+        eng.adam_step(); o.opt.step(); ref_opt.step()
+        for v in o.p.values():
+            v.grad = torch.zeros_like(v)
+        if labeled:
+            aux = eng.aux_loss_and_grads(x.cuda(), y.cuda(), 20.0)
+            ref_opt.zero_grad(set_to_none=False)      # (pyro zero_grads: zero tensors, not None)
+            la = orc.ss_aux_loss(o.p, cfg, task, x, y, 20.0, 0.5)
+            la.backward()
+            np.testing.assert_allclose(aux.item(), la.item(), rtol=2e-5)
+            for (n, pu), pr in zip(user.named_parameters(), ref.parameters()):
+                assert rel_l2(pu.grad, pr.grad) < 2e-4, "label net (aux) %s" % n
+        else:
+            for pr in ref.parameters():
+                pr.grad = torch.zeros_like(pr)                    # zero_grads: a momentum-only step follows
+        eng.adam_step(); o.opt.step(); ref_opt.step()
+        for v in o.p.values():
+            v.grad = torch.zeros_like(v)
+        for (n, pu), pr in zip(user.named_parameters(), ref.parameters()):
+            assert rel_l2(pu.detach(), pr.detach()) < 1e-4, "label net %s after Adam" % n
+        model.load_state_dict({**{k_: v_.detach() for k_, v_ in o.p.items()},
+                               **{"encoder_y." + k_: v_ for k_, v_ in ref.state_dict().items()}})
+    pred = model.classifier(x) if cls else model.regressor(x)
+    with torch.no_grad():
+        want = ref(x).argmax(-1) if cls else ref(x)
+    np.testing.assert_allclose(pred.numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", EPOCH_CASES)
 def test_trainer_epochs_vs_golden(gpu_device, name):
     """The product's SVItrainer driven exactly like the reference's (same DataLoader, same seeds):
