@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 8
+#define PV_ABI_VERSION 9
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -196,6 +196,13 @@ int pv_version(void);
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
  * layer widths).  Returns < 0 on an unsupported plan. */
 int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan);
+/* The same for one entry point only: the training step's layout is much smaller than the layered one pv_ivae_decode
+ * uses at the same batch, so a trainer that never decodes `batch` samples at once need not pay for it. */
+#define PV_WS_ALL    0
+#define PV_WS_STEP   1   /* pv_ivae_loss_and_grads / pv_ivae_step / pv_ivae_guide(_backward) */
+#define PV_WS_ENCODE 2   /* pv_ivae_encode */
+#define PV_WS_DECODE 3   /* pv_ivae_decode */
+int64_t pv_ivae_workspace_bytes_for(const pv_ivae_plan* plan, int what);
 
 /* 1 if pv_ivae_loss_and_grads will run this plan on the fused persistent spatial-decoder
  * kernel, 0 if it will take the layer-by-layer path (plan->fused == 0 or an architecture the

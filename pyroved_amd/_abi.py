@@ -11,7 +11,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 8
+PV_ABI_VERSION = 9
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -105,6 +105,7 @@ class pv_mlp_plan(C.Structure):
 SIGNATURES = {
     "pv_version": (C.c_int, []),
     "pv_ivae_workspace_bytes": (C.c_int64, [C.POINTER(pv_ivae_plan)]),
+    "pv_ivae_workspace_bytes_for": (C.c_int64, [C.POINTER(pv_ivae_plan), C.c_int]),
     "pv_ved_workspace_bytes": (C.c_int64, [C.POINTER(pv_ved_plan)]),
     "pv_ved_loss_and_grads": (C.c_int, [C.POINTER(pv_ved_plan), C.c_int, C.c_void_p]),
     "pv_ved_encode": (C.c_int, [C.POINTER(pv_ved_plan), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -85,13 +85,14 @@ bool valid_plan(const pv_ivae_plan* p) {
 }
 
 // inference_only: encode / decode process B samples (jiVAE's K-fold enumeration exists only in the training step)
-void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = false) {
+// encode_only (with inference_only): none of the decoder's per-row buffers is touched, so they get no room
+void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = false, bool encode_only = false) {
   Carver c{base, 0};
-  const int64_t B = p->batch, N = p->n_pix, z = p->z_dim;
+  const int64_t B = p->batch, N = encode_only ? 0 : p->n_pix, z = p->z_dim;
   const int64_t lat_in = plan_lat_in(p), K = plan_K(p), S = inference_only ? p->batch : plan_S(p), hw = plan_head_w(p);
   L.rows = p->coord_dim > 0 ? S * N : S;
   const int64_t R = L.rows;
-  L.xin = p->c_dim > 0 ? c.take(B * (N + p->c_dim)) : nullptr;
+  L.xin = p->c_dim > 0 ? c.take(B * (p->n_pix + p->c_dim)) : nullptr;
   int64_t maxe = 0;
   L.enc_ext = p->ext_encoder != 0;
   L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
@@ -100,7 +101,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0;
   if (L.enc_conv) {
     L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
-    if ((int64_t)L.ces[0].H * L.ces[0].W == N && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
+    if ((int64_t)L.ces[0].H * L.ces[0].W == p->n_pix && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
       L.cea[0] = nullptr;
       for (int i = 0; i < p->n_enc_ops; ++i) L.cea[i + 1] = c.take(L.ces[i + 1].elems(B));
       const pvcs::Shape& fe = L.ces[p->n_enc_ops];
@@ -167,6 +168,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
     if (nchunk > (N + 31) / 32) nchunk = (int)((N + 31) / 32);
     if (nchunk < 1) nchunk = 1;
     L.rows_per_chunk = (int)((N + nchunk - 1) / nchunk);
+    if (L.rows_per_chunk < 1) L.rows_per_chunk = 1;
     L.nchunk = (int)((N + L.rows_per_chunk - 1) / L.rows_per_chunk);
     L.part_hz = c.take(S * L.nchunk * H0);
     L.part_wc = c.take(S * L.nchunk * H0 * p->coord_dim);
@@ -209,7 +211,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
     upd(gemm_ws_need(B, p->head.in_dim, hw));
     upd(pv_colsum_ws(B, (int)hw));
   }
-  for (int i = 0; i < p->n_dec; ++i) {
+  for (int i = 0; i < p->n_dec && !L.fused; ++i) {
     upd(gemm_ws_need(R, p->dec[i].out_dim, p->dec[i].in_dim));
     upd(gemm_ws_need(p->dec[i].out_dim, p->dec[i].in_dim, R));
     upd(gemm_ws_need(R, p->dec[i].in_dim, p->dec[i].out_dim));
@@ -777,29 +779,39 @@ static pv_ivae_plan decode_plan(const pv_ivae_plan* plan) {
 
 static pv_ivae_plan guide_plan(const pv_ivae_plan* plan);
 
-extern "C" int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan) {
+// what: PV_WS_ALL = enough for every entry point at this batch; PV_WS_STEP / _ENCODE / _DECODE = for that call alone
+// (the training step's fused layout is far smaller than the layered one pv_ivae_decode uses at the same batch)
+extern "C" int64_t pv_ivae_workspace_bytes_for(const pv_ivae_plan* plan, int what) {
+  if (what < PV_WS_ALL || what > PV_WS_DECODE) return PV_EINVAL;
   if (plan && plan->ext_decoder) {                       // only the guide half runs in the library
     const pv_ivae_plan q = guide_plan(plan);
     if (!valid_plan(&q)) return PV_EINVAL;
     Layout L;
-    carve(&q, nullptr, L);
+    carve(&q, nullptr, L, what == PV_WS_ENCODE, what == PV_WS_ENCODE);
     return L.total;
   }
   if (!valid_plan(plan)) return PV_EINVAL;
   Layout L;
-  carve(plan, nullptr, L);
-  int64_t total = L.total;
-  if (L.fused || plan->discrete_dim > 0) {     // encode / decode always use the layered layout, B samples
+  int64_t total = 0;
+  if (what == PV_WS_ALL || what == PV_WS_STEP) {
+    carve(plan, nullptr, L);
+    total = L.total;
+  }
+  if (what == PV_WS_ALL || what == PV_WS_ENCODE) {   // encode / decode always use the layered layout, B samples
     pv_ivae_plan q = *plan;
     q.fused = 0;
-    carve(&q, nullptr, L, true);
+    carve(&q, nullptr, L, true, true);
     if (L.total > total) total = L.total;
-    q = decode_plan(plan);
+  }
+  if (what == PV_WS_ALL || what == PV_WS_DECODE) {
+    pv_ivae_plan q = decode_plan(plan);
     carve(&q, nullptr, L, true);
     if (L.total > total) total = L.total;
   }
   return total;
 }
+
+extern "C" int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan) { return pv_ivae_workspace_bytes_for(plan, PV_WS_ALL); }
 
 extern "C" int pv_ivae_uses_fused(const pv_ivae_plan* plan) {
   return valid_plan(plan) && plan->fused && pv_sdec_fused_supported(plan) ? 1 : 0;
@@ -875,7 +887,7 @@ extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_s
   lay.fused = 0;
   plan = &lay;
   Layout L;
-  carve(plan, (char*)plan->ws, L, true);
+  carve(plan, (char*)plan->ws, L, true, true);
   if (plan->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
   PV_TRY(encoder_fwd(plan, L, s));

@@ -306,7 +306,8 @@ class IVAEEngine:
         p.lr, p.adam_beta1, p.adam_beta2, p.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
         return p
 
-    def _plan(self, batch: int, beta: float = 1.0) -> _abi.pv_ivae_plan:
+    def _plan(self, batch: int, beta: float = 1.0, what: int = 1) -> _abi.pv_ivae_plan:
+        """what: 1 = training step, 2 = encode, 3 = decode (PV_WS_*): the workspace grows to what that call needs."""
         p = self._static
         p.batch = batch
         if isinstance(beta, (list, tuple)) or (torch.is_tensor(beta) and beta.ndim > 0):
@@ -319,9 +320,9 @@ class IVAEEngine:
         p.row_w = p.row_elbo = p.dy = None
         p.ext_z = p.ext_dz = p.ext_ll = None
         p.ev_start, p.ev_stop = self.events
-        need = _abi.lib().pv_ivae_workspace_bytes(C.byref(p))
+        need = _abi.lib().pv_ivae_workspace_bytes_for(C.byref(p), what)
         if need < 0:
-            raise _abi.PvError("pyroved_amd: unsupported plan (pv_ivae_workspace_bytes -> %d)" % need)
+            raise _abi.PvError("pyroved_amd: unsupported plan (pv_ivae_workspace_bytes_for -> %d)" % need)
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(int(need), device=self.device, dtype=torch.uint8)
         p.ws = self.ws.data_ptr()
@@ -516,7 +517,7 @@ class IVAEEngine:
                 z_loc, z_scale = self.model.encoder_z(x)
             return z_loc.to(torch.float32), z_scale.to(torch.float32)
         b = x.shape[0]
-        p = self._plan(b)
+        p = self._plan(b, what=2)
         x = self._prep(x, "x", (b, p.n_pix))
         y = self._prep(y, "y", (b, p.c_dim)) if p.c_dim > 0 else None
         if p.c_dim > 0 and y is None:
@@ -544,7 +545,7 @@ class IVAEEngine:
                 loc = self._torch_decode(z.to(self.device, torch.float32), None, angle, shift, scale)
             return loc.reshape(z.shape[0], *self.model.data_dim)
         b = z.shape[0]
-        p = self._plan(b)
+        p = self._plan(b, what=3)
         lat_in = (p.latent_dim if p.coord_dim > 0 else p.z_dim) + p.c_dim + self.K
         z = self._prep(z, "z", (b, lat_in))
         loc = torch.empty(b, p.n_pix, device=self.device, dtype=torch.float32)

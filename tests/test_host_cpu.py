@@ -76,6 +76,43 @@ def test_workspace_query_runs_without_gpu():
     assert lib.pv_linear_workspace_bytes(-1, 128, 128) < 0
 
 
+def _headline_plan(batch, fused):
+    """BASELINE configs[1] by hand (offsets are irrelevant to the sizing arithmetic)."""
+    p = _abi.pv_ivae_plan()
+    p.batch, p.n_pix, p.coord_dim, p.z_dim, p.latent_dim = batch, 784, 2, 5, 2
+    p.has_r = p.has_t = 1
+    p.lik, p.sigmoid_out, p.fused = _abi.LIK["bernoulli"], 1, fused
+    def layer(i, o, act):
+        l = _abi.pv_layer()
+        l.in_dim, l.out_dim, l.act, l.b_off = i, o, _abi.ACT[act], 0
+        return l
+    p.n_enc = 2
+    p.enc[0], p.enc[1] = layer(784, 128, "tanh"), layer(128, 128, "tanh")
+    p.head = layer(128, 10, None)
+    p.fc_coord, p.fc_latent = layer(2, 128, "tanh"), layer(2, 128, None)
+    p.n_dec = 2
+    p.dec[0], p.dec[1] = layer(128, 128, "tanh"), layer(128, 128, "tanh")
+    p.out = layer(128, 1, None)
+    return p
+
+
+def test_workspace_by_purpose():
+    """pv_ivae_workspace_bytes_for: the fused training step needs a small fraction of what a layered decode of the same
+    batch needs; PV_WS_ALL (= pv_ivae_workspace_bytes) covers all three."""
+    lib = _abi.lib()
+    for fused in (2, 3):
+        p = _headline_plan(4096, fused)
+        step, enc, dec = (lib.pv_ivae_workspace_bytes_for(C.byref(p), w) for w in (1, 2, 3))
+        allb = lib.pv_ivae_workspace_bytes(C.byref(p))
+        assert min(step, enc, dec) > 0 and allb == max(step, enc, dec) == lib.pv_ivae_workspace_bytes_for(C.byref(p), 0)
+        assert enc < 64 << 20 and step < dec // 4
+        # step: ~0.1 MB per image (per-row outputs + per-sample partials), not the layered path's ~1.9 MB
+        assert step < 4096 * 200_000
+    assert lib.pv_ivae_workspace_bytes_for(C.byref(p), 4) < 0
+    p.fused = 0
+    assert lib.pv_ivae_workspace_bytes_for(C.byref(p), 1) > 4096 * 1_000_000
+
+
 # ------------------------------------------------------------------------------- API mirror
 @pytest.mark.parametrize("invariances, coord_exp", [(None, 0), (['t'], 1)])
 def test_base_vae_1d(invariances, coord_exp):
