@@ -146,6 +146,14 @@ class coord_latent(nn.Module):
         self.fc_latent = nn.Linear(latent_dim, out_dim, bias=False)
         self.activation = nn.Tanh() if activation_out else None
 
+    def forward(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """tanh(fc_coord(x_coord) + fc_latent(z)[:, None, :]) flattened to (B*N, out_dim) (fc.py:220-237)."""
+        batch_dim, n = x_coord.shape[0], x_coord.shape[1]
+        h_x = ops.linear_act(x_coord.reshape(batch_dim * n, -1), self.fc_coord.weight, self.fc_coord.bias, None)
+        h_z = ops.linear_act(z.reshape(batch_dim, -1), self.fc_latent.weight, None, None)
+        h = (h_x.view(batch_dim, n, -1) + h_z.unsqueeze(1)).reshape(batch_dim * n, -1)
+        return self.activation(h) if self.activation is not None else h
+
 
 class sDecoderNet(nn.Module):
     """Spatial generator (decoder): a per-pixel MLP over transformed coordinates and the
@@ -170,10 +178,17 @@ class sDecoderNet(nn.Module):
         self.out = nn.Linear(hidden_dim[-1], 1)
 
     def forward(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(
-            "sDecoderNet.forward(x_coord, z) with explicit coordinates is not exposed; decode through "
-            "iVAE.decode / baseVAE._decode (pv_ivae_decode), which fuses the coordinate transform into the "
-            "decoder's first layer")
+        """x_coord: (B, N, coord_dim) transformed coordinates, z: (B, latent_dim [+ c_dim]) or the list the
+        reference's Concat takes -> (B, *out_dim) (pyroved/nets/fc.py:189-199, 220-237).  The unfused operator
+        path: every Linear(+activation) is one ops.linear_act (HIP GEMMs, differentiable); SVItrainer and
+        iVAE.decode use the fused kernels behind pv_ivae_loss_and_grads / pv_ivae_decode instead."""
+        z = self.concat(z)
+        h = self.coord_latent(x_coord, z)
+        h = _run_stack(self.fc_layers, self.activation, h)
+        x = ops.linear_act(h, self.out.weight, self.out.bias, "sigmoid" if self.sigmoid_out else None)
+        if self.unflat:
+            return x.view(-1, *self.reshape)
+        return x
 
 
 class fcClassifierNet(nn.Module):

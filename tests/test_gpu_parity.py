@@ -85,6 +85,73 @@ def test_linear_fwd_bwd_blocks(gpu_device, m, k, n, act):
     assert rel_l2(db, bd.grad) < 2e-6
 
 
+@pytest.mark.parametrize("act", ["tanh", "lrelu", "gelu", "softplus"])
+def test_operator_boundary_nets_autograd(gpu_device, act):
+    """SURVEY §8b operator boundary: nets.*.forward on GPU tensors = the library's Linear(+activation) operator,
+    differentiable through torch.autograd (pv_linear_fwd / pv_linear_bwd).  Values and every parameter / input
+    gradient vs the oracle's forward under torch autograd on the CPU.  Tolerance 1e-4 relative (fp32 GEMMs)."""
+    torch.manual_seed(4)
+    cfg = orc.Config((12, 12), 2, ['r', 't'], activation=act)
+    m = pv.models.iVAE((12, 12), 2, ['r', 't'], activation=act, seed=3, device="cuda")
+    P = {k: v.detach().cpu().clone().requires_grad_() for k, v in m.state_dict().items()}
+    b = 6
+    x = torch.rand(b, 12, 12)
+    # encoder
+    mu, sig = m.encoder_z(x.cuda())
+    mu_r, sig_r = orc.encoder_forward(P, cfg, x)
+    assert rel_l2(mu, mu_r.detach()) < 1e-5 and rel_l2(sig, sig_r.detach()) < 1e-5
+    w1, w2 = torch.randn(b, cfg.z_dim), torch.randn(b, cfg.z_dim)
+    ((mu * w1.cuda()).sum() + (sig * w2.cuda()).sum()).backward()
+    ((mu_r * w1).sum() + (sig_r * w2).sum()).backward()
+    for k, v in m.named_parameters():
+        if k.startswith("encoder_z."):
+            assert rel_l2(v.grad, P[k].grad) < 1e-4, k
+    # spatial decoder on explicit coordinates, input gradients too
+    grid = orc.generate_grid((12, 12))
+    xc = orc.transform_coordinates(grid.expand(b, *grid.shape), torch.randn(b), 0.1 * torch.randn(b, 1, 2),
+                                   1 + 0.1 * torch.randn(b))
+    z = torch.randn(b, 2)
+    xc_g, z_g = xc.cuda().requires_grad_(), z.cuda().requires_grad_()
+    xc_r, z_r = xc.clone().requires_grad_(), z.clone().requires_grad_()
+    out = m.decoder(xc_g, z_g)
+    out_r = orc.sdecoder_forward(P, cfg, xc_r, z_r)
+    assert out.shape == (b, 12, 12) and rel_l2(out, out_r.detach()) < 1e-5
+    w = torch.randn(b, 12, 12)
+    (out * w.cuda()).sum().backward()
+    (out_r * w).sum().backward()
+    for k, v in m.named_parameters():
+        if k.startswith("decoder."):
+            assert rel_l2(v.grad, P[k].grad) < 1e-4, k
+    assert rel_l2(xc_g.grad, xc_r.grad) < 1e-4 and rel_l2(z_g.grad, z_r.grad) < 1e-4
+    # the unflat=False form returns (B*N, 1) like the reference (fc.py:196-199)
+    d2 = pv.nets.sDecoderNet((12, 12), 2, unflat=False).cuda()
+    assert d2(xc.cuda(), z.cuda()).shape == (b * 144, 1)
+    # vanilla decoder + classifier / regressor heads
+    cfg0 = orc.Config((12, 12), 2, None, activation=act)
+    m0 = pv.models.iVAE((12, 12), 2, None, activation=act, seed=5, device="cuda")
+    P0 = {k: v.detach().cpu().clone().requires_grad_() for k, v in m0.state_dict().items()}
+    o0 = m0.decoder(z.cuda())
+    o0_r = orc.fcdecoder_forward(P0, cfg0, z)
+    assert rel_l2(o0, o0_r.detach()) < 1e-5
+    (o0 * w.cuda()).sum().backward()
+    (o0_r * w).sum().backward()
+    for k, v in m0.named_parameters():
+        if k.startswith("decoder."):
+            assert rel_l2(v.grad, P0[k].grad) < 1e-4, k
+    for net, task in ((pv.nets.fcClassifierNet((12, 12), 3, activation=act), "classification"),
+                      (pv.nets.fcRegressorNet((12, 12), 3, activation=act), "regression")):
+        net = net.cuda()
+        Pn = {"encoder_y." + k: v.detach().cpu().clone().requires_grad_() for k, v in net.state_dict().items()}
+        o = net(x.cuda())
+        o_r = orc.label_net_forward(Pn, cfg, x, task)
+        assert rel_l2(o, o_r.detach()) < 1e-5
+        wy = torch.randn(b, 3)
+        (o * wy.cuda()).sum().backward()
+        (o_r * wy).sum().backward()
+        for k, v in net.named_parameters():
+            assert rel_l2(v.grad, Pn["encoder_y." + k].grad) < 1e-4, k
+
+
 def test_transform_coordinates(gpu_device):
     g = torch.Generator().manual_seed(3)
     for data_dim in [(8, 8), (28, 28), (7, 9), (16,)]:
