@@ -21,6 +21,16 @@ from ..nets import fcDecoderNet, fcEncoderNet, sDecoderNet
 from ..utils import get_sampler, set_deterministic_mode
 
 
+def _plot_manifold(ndim, loc, d, grid_x, grid_y, kwargs):
+    """The plot=True tail shared by every manifold2d (models/ivae.py:302-309)."""
+    from ..utils.viz import plot_img_grid, plot_spect_grid
+    dd = d[0] if isinstance(d, (list, tuple)) else d
+    if ndim == 2:
+        plot_img_grid(loc, dd, extent=[grid_x.min(), grid_x.max(), grid_y.min(), grid_y.max()], **kwargs)
+    elif ndim == 1:
+        plot_spect_grid(loc, dd, **kwargs)
+
+
 class iVAE(baseVAE):
     """
     Variational autoencoder that enforces rotational, translational,
@@ -127,13 +137,11 @@ class iVAE(baseVAE):
             z = torch.cat([z.cpu(), y.to(torch.float32).cpu()], -1)
         return self._decode(z.cpu(), **kwargs)
 
-    def manifold2d(self, d: int, y: torch.Tensor = None, plot: bool = False,
+    def manifold2d(self, d: int, y: torch.Tensor = None, plot: bool = True,
                    **kwargs: Union[str, int, float]) -> torch.Tensor:
         """Decodes a d x d grid of the 2-D latent space (models/ivae.py:277-310).  The grid is the
         reference's generate_latent_grid: inverse normal CDF of linspace(0.05, 0.95, d) unless
-        z_coord=[z1, z2, z3, z4] is given.  Plotting is out of scope of this build (plot must be False)."""
-        if plot:
-            raise NotImplementedError("plotting is not part of this build; call with plot=False")
+        z_coord=[z1, z2, z3, z4] is given; plot=True draws the mosaic (utils.plot_img_grid / plot_spect_grid)."""
         import torch.distributions as td
         if isinstance(d, int):
             d = [d, d]
@@ -154,8 +162,12 @@ class iVAE(baseVAE):
             if y is None:
                 raise ValueError("To generate a manifold pass a conditional vector y")
             y = y.unsqueeze(1) if 0 < y.ndim < 2 else y
-            return self.decode(z, y.expand(z.shape[0], *y.shape[1:]), **kwargs)
-        return self.decode(z, **kwargs)
+            loc = self.decode(z, y.expand(z.shape[0], *y.shape[1:]), **kwargs)
+        else:
+            loc = self.decode(z, **kwargs)
+        if plot:
+            _plot_manifold(self.ndim, loc, d, grid_x, grid_y, kwargs)
+        return loc
 
     def predict_on_latent(self, train_data, gp_labels, gp_iterations: int = 1, d: int = 12, plot: bool = False):
         """Gaussian-process regression of labels over the latent space (models/ivae.py:312-364).  It is built on

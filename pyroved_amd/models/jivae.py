@@ -20,6 +20,7 @@ from typing import List, Tuple, Union
 import torch
 
 from .base import baseVAE
+from .ivae import _plot_manifold
 from ..nets import fcDecoderNet, jfcEncoderNet, sDecoderNet
 from ..utils import get_sampler, set_deterministic_mode, to_onehot
 
@@ -99,10 +100,8 @@ class jiVAE(baseVAE):
         loc = self._decode(z, **kwargs)
         return loc.view(-1, *self.data_dim)
 
-    def manifold2d(self, d: int, disc_idx: int = 0, plot: bool = False, **kwargs) -> torch.Tensor:
+    def manifold2d(self, d: int, disc_idx: int = 0, plot: bool = True, **kwargs) -> torch.Tensor:
         """Decodes a d x d grid of the continuous latent space for class disc_idx (models/jivae.py:269-296)."""
-        if plot:
-            raise NotImplementedError("plotting is not part of this build; call with plot=False")
         import torch.distributions as td
         dd = [d, d] if isinstance(d, int) else d
         z_coord = kwargs.get("z_coord")
@@ -115,14 +114,15 @@ class jiVAE(baseVAE):
             grid_y = td.Normal(0, 1).icdf(torch.linspace(0.05, 0.95, dd[1]))
         z = torch.cat([torch.tensor([xi, yi]).float().unsqueeze(0) for xi in grid_x for yi in grid_y])
         z_disc = to_onehot(torch.tensor(disc_idx).unsqueeze(0), self.discrete_dim).repeat(z.shape[0], 1)
-        return self.decode(z, z_disc, **kwargs)
+        loc = self.decode(z, z_disc, **kwargs)
+        if plot:
+            _plot_manifold(self.ndim, loc, d, grid_x, grid_y, kwargs)
+        return loc
 
-    def manifold_traversal(self, d: int, cont_idx: int, cont_idx_fixed: int = 0, plot: bool = False,
+    def manifold_traversal(self, d: int, cont_idx: int, cont_idx_fixed: int = 0, plot: bool = True,
                            **kwargs) -> torch.Tensor:
         """Latent traversal over one continuous variable for every class (models/jivae.py:298-330 with
         utils.generate_latent_grid_traversal)."""
-        if plot:
-            raise NotImplementedError("plotting is not part of this build; call with plot=False")
         import torch.distributions as td
         disc_dim, cont_dim = self.discrete_dim, self.z_dim - self.coord
         # d x d grid: column j sweeps the chosen continuous variable, row i fixes a class (classes cycle over rows)
@@ -130,4 +130,8 @@ class jiVAE(baseVAE):
         samples_cont[:, cont_idx] = td.Normal(0, 1).icdf(torch.linspace(0.95, 0.05, d)).repeat(d)
         row_class = torch.arange(d) % disc_dim
         samples_disc = to_onehot(row_class.repeat_interleave(d), disc_dim)
-        return self.decode(samples_cont, samples_disc, **kwargs)
+        decoded = self.decode(samples_cont, samples_disc, **kwargs)
+        if plot:
+            from ..utils.viz import plot_grid_traversal
+            plot_grid_traversal(decoded, d, self.data_dim, disc_dim, **kwargs)
+        return decoded

@@ -13,6 +13,7 @@ from typing import Optional, Tuple, Union, Type, List
 import torch
 
 from .base import baseVAE
+from .ivae import _plot_manifold
 from ..nets import fcDecoderNet, fcEncoderNet, sDecoderNet, fcClassifierNet, fcRegressorNet
 from ..utils import (get_sampler, set_deterministic_mode, to_onehot, init_dataloader, generate_latent_grid,
                      generate_latent_grid_traversal)
@@ -111,25 +112,28 @@ class ssiVAE(_ssBase):
         _, y_pred = torch.max(y, 1)
         return z_loc, z_scale, y_pred
 
-    def manifold2d(self, d: int, plot: bool = False, **kwargs: Union[str, int, float]) -> torch.Tensor:
+    def manifold2d(self, d: int, plot: bool = True, **kwargs: Union[str, int, float]) -> torch.Tensor:
         """Decoded d x d grid of the latent space for the class kwargs['label'] (ssivae.py:309-337)."""
-        if plot:
-            raise NotImplementedError("plotting is not part of this build; call with plot=False")
-        z, _ = generate_latent_grid(d, **kwargs)
+        z, (grid_x, grid_y) = generate_latent_grid(d, **kwargs)
         cls = tt(kwargs.get("label", 0))
         if cls.ndim < 2:
             cls = to_onehot(cls.unsqueeze(0), self.num_classes)
         cls = cls.repeat(z.shape[0], 1)
-        return self.decode(z, cls, **kwargs)
+        loc = self.decode(z, cls, **kwargs)
+        if plot:
+            _plot_manifold(self.ndim, loc, d, grid_x, grid_y, kwargs)
+        return loc
 
-    def manifold_traversal(self, d: int, cont_idx: int, cont_idx_fixed: int = 0, plot: bool = False,
+    def manifold_traversal(self, d: int, cont_idx: int, cont_idx_fixed: int = 0, plot: bool = True,
                            **kwargs: Union[str, int, float]) -> torch.Tensor:
         """Latent-space traversal over one continuous latent and the classes (ssivae.py:339-384)."""
-        if plot:
-            raise NotImplementedError("plotting is not part of this build; call with plot=False")
         samples_cont, samples_disc = generate_latent_grid_traversal(
             d, self.z_dim - self.coord, self.num_classes, cont_idx, cont_idx_fixed, d ** 2)
-        return self.decode(samples_cont, samples_disc, **kwargs)
+        decoded = self.decode(samples_cont, samples_disc, **kwargs)
+        if plot:
+            from ..utils.viz import plot_grid_traversal
+            plot_grid_traversal(decoded, d, self.data_dim, self.num_classes, **kwargs)
+        return decoded
 
 
 class ss_reg_iVAE(_ssBase):
@@ -166,11 +170,12 @@ class ss_reg_iVAE(_ssBase):
         z_loc, z_scale = z.split(self.z_dim, 1)
         return z_loc, z_scale, y
 
-    def manifold2d(self, d: int, y: torch.Tensor, plot: bool = False, **kwargs: Union[str, int, float]) -> torch.Tensor:
+    def manifold2d(self, d: int, y: torch.Tensor, plot: bool = True, **kwargs: Union[str, int, float]) -> torch.Tensor:
         """Decoded d x d grid of the latent space conditioned on y (ss_reg_ivae.py:312-346)."""
-        if plot:
-            raise NotImplementedError("plotting is not part of this build; call with plot=False")
-        z, _ = generate_latent_grid(d, **kwargs)
+        z, (grid_x, grid_y) = generate_latent_grid(d, **kwargs)
         y = y.unsqueeze(1) if 0 < y.ndim < 2 else y
         y = y.expand(z.shape[0], *y.shape[1:])
-        return self.decode(z, y, **kwargs)
+        loc = self.decode(z, y, **kwargs)
+        if plot:
+            _plot_manifold(self.ndim, loc, d, grid_x, grid_y, kwargs)
+        return loc

@@ -105,10 +105,8 @@ class VED(baseVAE):
             sds.append(y.std(0))
         return torch.cat(mus), torch.cat(sds)
 
-    def manifold2d(self, d: int, plot: bool = False, **kwargs: Union[str, int]) -> torch.Tensor:
+    def manifold2d(self, d: int, plot: bool = True, **kwargs: Union[str, int]) -> torch.Tensor:
         """Decodes a d x d grid of the 2-D latent space (models/ved.py:218-243 with utils.generate_latent_grid)."""
-        if plot:
-            raise NotImplementedError("plotting is not part of this build; call with plot=False")
         import torch.distributions as td
         self.eval()
         dd = [d, d] if isinstance(d, int) else d
@@ -121,4 +119,8 @@ class VED(baseVAE):
             grid_x = td.Normal(0, 1).icdf(torch.linspace(0.95, 0.05, dd[0]))
             grid_y = td.Normal(0, 1).icdf(torch.linspace(0.05, 0.95, dd[1]))
         z = torch.cat([torch.tensor([xi, yi]).float().unsqueeze(0) for xi in grid_x for yi in grid_y])
-        return self.decode(z)
+        loc = self.decode(z)
+        if plot:
+            from .ivae import _plot_manifold
+            _plot_manifold(self.ndim, loc, d, grid_x, grid_y, kwargs)
+        return loc

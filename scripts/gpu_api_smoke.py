@@ -1,3 +1,5 @@
+import matplotlib
+matplotlib.use('Agg')
 """Calls every public inference / utility method of every model family once on the GPU (shapes, finiteness, odd batch sizes):
 a crash detector for the host-side mirror of the reference API, not a numerics test."""
 import os, sys, warnings

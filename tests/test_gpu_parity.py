@@ -1225,6 +1225,42 @@ def test_trainer_data_parallel_two_ranks_one_gpu(gpu_device, kind):
     np.testing.assert_allclose(two["wsum"], one["wsum"], rtol=1e-5)
 
 
+def test_manifold2d_matches_decode_and_plots(gpu_device):
+    """manifold2d / manifold_traversal with the reference's default plot=True (models/ivae.py:277-310,
+    jivae.py:268-329, ved.py:218-243): the returned tensor is decode() of utils.generate_latent_grid's points, the
+    same as the oracle's decoder on them, and the matplotlib tail runs (Agg backend)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    for data_dim, inv in (((12, 12), ['r', 't']), ((16,), ['t']), ((10, 10), None)):
+        m = pv.models.iVAE(data_dim, 2, inv, seed=2, device="cuda")
+        cfg = orc.Config(data_dim, 2, inv)
+        P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        loc = m.manifold2d(4)
+        z, _ = pv.utils.generate_latent_grid(4)
+        assert loc.shape == (16, *data_dim)
+        ref, _ = orc.decode_from_latent(P, cfg, torch.cat([torch.zeros(16, cfg.coord), z], -1))   # no transform
+        np.testing.assert_allclose(loc.numpy(), ref.reshape(loc.shape).numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_array_equal(m.manifold2d(4, plot=False).numpy(), loc.numpy())
+        loc2 = m.manifold2d(3, z_coord=[-2., 2., -1., 1.], cmap="viridis", padding=1)
+        assert loc2.shape == (9, *data_dim)
+    mj = pv.models.jiVAE((12, 12), 2, 3, ['r'], seed=2, device="cuda")
+    assert mj.manifold2d(3, disc_idx=1).shape == (9, 12, 12)
+    assert mj.manifold_traversal(4, 0).shape == (16, 12, 12)
+    mv = pv.models.VED((16, 16), (16, 16), hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)], seed=2,
+                       device="cuda")
+    assert mv.manifold2d(3).shape == (9, 1, 16, 16)
+    mv1 = pv.models.VED((16, 16), (32,), hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)], seed=2,
+                        device="cuda")
+    assert mv1.manifold2d(2).shape == (4, 1, 32)
+    ms = pv.models.ssiVAE((12, 12), 2, 3, ['r'], seed=2, device="cuda")
+    assert ms.manifold2d(3, label=1).shape == (9, 12, 12)
+    assert ms.manifold_traversal(3, 1).shape == (9, 12, 12)
+    mr = pv.models.ss_reg_iVAE((12, 12), 2, 1, ['r'], seed=2, device="cuda")
+    assert mr.manifold2d(3, torch.zeros(1, 1)).shape == (9, 12, 12)
+    plt.close("all")
+
+
 def test_fails_loudly_on_cpu_tensors(gpu_device):
     model = pv.models.iVAE((8, 8), 2, ["r"], seed=1, device="cuda")
     eng = model.engine()

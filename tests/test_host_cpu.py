@@ -113,6 +113,30 @@ def test_workspace_by_purpose():
     assert lib.pv_ivae_workspace_bytes_for(C.byref(p), 1) > 4096 * 1_000_000
 
 
+def test_viz_mosaic_and_plots():
+    """utils.viz: the mosaic layout is make_grid's (padding before every cell + a closing border, nrow per row,
+    pad_value fill; pyroved/utils/viz.py:16-18, 66-69) and the three plot helpers run headless."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    from pyroved_amd.utils import viz
+    imgs = torch.arange(5 * 3 * 4, dtype=torch.float32).reshape(5, 3, 4) + 1
+    g = viz.tile_images(imgs, 2, padding=2, pad_value=-1)
+    assert g.shape == (3 * 5 + 2, 2 * 6 + 2)
+    assert (g[:2] == -1).all() and (g[:, :2] == -1).all() and (g[-2:] == -1).all()
+    assert torch.equal(g[2:5, 2:6], imgs[0]) and torch.equal(g[2:5, 8:12], imgs[1])
+    assert torch.equal(g[7:10, 2:6], imgs[2]) and torch.equal(g[12:15, 2:6], imgs[4])
+    assert (g[12:15, 8:12] == -1).all()                    # the empty sixth cell
+    assert torch.equal(viz.tile_images(imgs[:, None], 2, 2, -1), g)
+    with pytest.raises(AssertionError):
+        viz.plot_img_grid(torch.zeros(4, 4), 2)
+    viz.plot_img_grid(torch.rand(4, 6, 6), 2, extent=[torch.tensor(-1.), torch.tensor(1.), torch.tensor(-2.), torch.tensor(2.)])
+    viz.plot_spect_grid(torch.rand(4, 1, 9), 2, ylim=[0, 1])
+    viz.plot_grid_traversal(torch.rand(9, 6, 6), 3, (6, 6), 2)
+    assert len(plt.get_fignums()) == 3
+    plt.close("all")
+
+
 # ------------------------------------------------------------------------------- API mirror
 @pytest.mark.parametrize("invariances, coord_exp", [(None, 0), (['t'], 1)])
 def test_base_vae_1d(invariances, coord_exp):
