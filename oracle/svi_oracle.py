@@ -488,7 +488,8 @@ class SVIOracle:
             self.cfg = cfg = dataclasses.replace(cfg, bufs=self.bufs)
         self.grid = generate_grid(cfg.data_dim, dtype) if cfg.coord > 0 else None
         # one Adam over all tensors is elementwise-identical to Pyro's one-Adam-per-tensor
-        self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)
+        # (no tensor of its own when encoder AND decoder are custom modules: their owner steps them)
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=lr) if self.p else None
         self.dtype = dtype
         self.last = None
         self.last_grads = None

@@ -71,9 +71,8 @@ class IVAEEngine:
         self.ext_dec = not isinstance(dec, (sDecoderNet, fcDecoderNet))
         self.K = 0
         if self.ext_dec:
-            if self.ext_enc or getattr(m, "discrete_dim", 0):
-                raise UnsupportedModel("a user-defined decoder cannot be combined with a user-defined encoder / discrete "
-                                       "latents here")
+            if getattr(m, "discrete_dim", 0):
+                raise UnsupportedModel("a user-defined decoder cannot be combined with discrete latents here")
             if m.sampler_d.name not in _abi.LIK:
                 raise UnsupportedModel("decoder sampler %r is not implemented" % m.sampler_d.name)
         if self.ext_enc:
@@ -89,6 +88,8 @@ class IVAEEngine:
             raise UnsupportedModel("the HIP SVI path needs encoder_z to be pyroved_amd.nets.fcEncoderNet / "
                                    "jfcEncoderNet / convEncoderNet (got %s)" % type(enc).__name__)
         self.K = int(getattr(m, "discrete_dim", 0)) if isinstance(enc, jfcEncoderNet) else 0
+        if self.ext_enc and self.ext_dec:
+            return                                   # both user modules: the library keeps the reparameterisation + KL
         if self.ext_enc and isinstance(dec, (sDecoderNet, fcDecoderNet)):
             if len(_linears(dec.fc_layers)) > _abi.PV_MAX_LAYERS:
                 raise UnsupportedModel("more than %d hidden layers" % _abi.PV_MAX_LAYERS)
@@ -120,8 +121,9 @@ class IVAEEngine:
         """(key, tensor) in flat-buffer order: state_dict order, except that the heads are merged:
         fc11.weight, fc12.weight[, fc13.weight], then fc11.bias, fc12.bias[, fc13.bias]."""
         named = dict(self.model.named_parameters())
-        if self.ext_enc:                         # only the decoder lives in the flat buffers
-            return [(k, v) for k, v in named.items() if not k.startswith("encoder_z.")]
+        if self.ext_enc:                         # only the decoder lives in the flat buffers (nothing if it is a user's too)
+            return [(k, v) for k, v in named.items()
+                    if not k.startswith("encoder_z.") and not (self.ext_dec and k.startswith("decoder."))]
         if self.ext_dec:                         # only the encoder does
             named = {k: v for k, v in named.items() if not k.startswith("decoder.")}
         if getattr(self, "ext_y", False):        # a user-defined label network (semi-supervised models) stays in torch
@@ -150,7 +152,7 @@ class IVAEEngine:
         items = self._param_order()
         n_par = len(items)
         items = items + self._stat_buffers()
-        dev = items[0][1].device
+        dev = items[0][1].device if items else next(self.model.parameters()).device
         if dev.type != "cuda":
             raise _abi.PvError(
                 "pyroved_amd: the model lives on %s; the SVI path runs only on a HIP device "
@@ -165,7 +167,7 @@ class IVAEEngine:
                 off = (off + ALIGN - 1) // ALIGN * ALIGN
             layout[k] = off
             off += p.numel()
-        total = (off + ALIGN - 1) // ALIGN * ALIGN
+        total = max((off + ALIGN - 1) // ALIGN * ALIGN, ALIGN)      # (never empty: the ABI wants non-NULL buffers)
         old_m, old_v, old_layout = self.m, self.v, self._layout
         flat = torch.zeros(total, device=dev, dtype=torch.float32)
         for k, p in items:
@@ -194,8 +196,10 @@ class IVAEEngine:
         self.ws = None
         if self.ext_enc or self.ext_dec or getattr(self, "ext_y", False):
             # the user module's parameters: their own torch Adam (zero_grads semantics)
-            owner = self.model.encoder_z if self.ext_enc else (self.model.decoder if self.ext_dec else self.model.encoder_y)
-            self._enc_params = [q for q in owner.parameters() if q.requires_grad]
+            owners = ([self.model.encoder_z] if self.ext_enc else []) + ([self.model.decoder] if self.ext_dec else [])
+            if not owners:
+                owners = [self.model.encoder_y]
+            self._enc_params = [q for o_ in owners for q in o_.parameters() if q.requires_grad]
             if self._enc_opt is None or [id(q) for q in self._enc_opt.param_groups[0]["params"]] != [id(q) for q in self._enc_params]:
                 self._enc_opt = torch.optim.Adam(self._enc_params, lr=self.lr, betas=self.betas, eps=self.adam_eps)
         self._static = self._static_plan()
@@ -451,6 +455,15 @@ class IVAEEngine:
             raise ValueError("class-conditioned model (c_dim=%d) needs y" % p.c_dim)
         z = torch.empty(b, p.z_dim, device=self.device, dtype=torch.float32)
         p.x, p.eps, p.y, p.ext_z = x.data_ptr(), eps.data_ptr(), (y.data_ptr() if y is not None else None), z.data_ptr()
+        head = dhead = None
+        if self.ext_enc:                             # a user-defined encoder as well: its outputs enter through ext_head
+            with torch.set_grad_enabled(want_grads):
+                z_loc, z_scale = self.model.encoder_z(x.reshape(b, *self.model.data_dim))
+            head = torch.cat([z_loc, z_scale], -1).detach().to(torch.float32).contiguous()
+            if tuple(head.shape) != (b, 2 * p.z_dim):
+                raise ValueError("encoder_z must return (z_loc, z_scale) of shape (batch, %d) each" % p.z_dim)
+            dhead = torch.empty_like(head)
+            p.ext_head, p.ext_dhead = head.data_ptr(), dhead.data_ptr()
         if z_out is not None:
             p.z_loc, p.z_scale = z_out[0].data_ptr(), z_out[1].data_ptr()
         if scalars_out is not None:
@@ -474,13 +487,17 @@ class IVAEEngine:
             p.ext_ll = ll1.data_ptr()
             _abi.check(_abi.lib().pv_ivae_guide_backward(C.byref(p), int(want_grads), _abi.current_stream()),
                        "pv_ivae_guide_backward")
+            if self.ext_enc and want_grads:
+                zd = p.z_dim
+                torch.autograd.backward([z_loc, z_scale], [dhead[:, :zd], dhead[:, zd:]])
         finally:
             p.scalars = self.scalars.data_ptr()
             p.ext_z = p.ext_dz = p.ext_ll = None
+            p.ext_head = p.ext_dhead = None
         if want_grads:
             self.grads_live = True
         self._count_bn(self._bn_enc)
-        self._keep = (x, eps, y, z, dz, ll1)
+        self._keep = (x, eps, y, z, dz, ll1, head, dhead)
 
     def _count_bn(self, mods):
         """nn.BatchNorm's num_batches_tracked (a forward in training mode counts; the statistics themselves are updated

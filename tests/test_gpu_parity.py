@@ -876,6 +876,52 @@ def test_user_defined_decoder(gpu_device, inv):
     assert np.isfinite(tr.loss_history["training_loss"][0]) and np.isfinite(tr.loss_history["test_loss"][0])
 
 
+@pytest.mark.parametrize("inv", [["r", "t", "s"], None])
+def test_user_defined_encoder_and_decoder(gpu_device, inv):
+    """set_encoder AND set_decoder with user modules on the same model (models/base.py:173-183): both run in PyTorch on
+    the device; the library keeps the middle of the step — reparameterisation, the sampled KL terms (pv_ivae_guide with
+    plan.ext_head) and the gradient of the KL + likelihood w.r.t. (z_loc, z_scale) (pv_ivae_guide_backward ->
+    plan.ext_dhead).  Loss terms, both modules' gradients and Adam updates vs the oracle with the same modules."""
+    data_dim, b = (8, 8), 6
+    torch.manual_seed(11)
+    model = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+    mk = (lambda: _UserSpatialDecoder(data_dim, 2)) if inv else (lambda: _UserVanillaDecoder(data_dim, 2))
+    ue, re_ = _UserEncoder(data_dim, model.z_dim), _UserEncoder(data_dim, model.z_dim)
+    ud, rd = mk(), mk()
+    re_.load_state_dict(ue.state_dict())
+    rd.load_state_dict(ud.state_dict())
+    model.set_encoder(ue)
+    model.set_decoder(ud)
+    eng = model.engine()
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, custom_encoder=re_, custom_decoder=rd)
+    o = orc.SVIOracle({}, cfg)
+    ref_params = list(re_.parameters()) + list(rd.parameters())
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(b, *data_dim, generator=g)
+    for k in range(3):
+        eps = torch.randn(b, model.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), 0.8)
+        ref_opt.zero_grad()
+        o.step(x, eps, 0.8)
+        for i, name in enumerate(("loss", "ll")):
+            np.testing.assert_allclose(eng.scalars[i].item(), o.last[name].item(), rtol=RTOL_ELBO)
+        for (n, pu), pr in zip(list(ue.named_parameters()) + list(ud.named_parameters()), ref_params):
+            assert rel_l2(pu.grad, pr.grad) < 2e-4, n
+        eng.adam_step()
+        ref_opt.step()
+        for (n, pu), pr in zip(list(ue.named_parameters()) + list(ud.named_parameters()), ref_params):
+            assert rel_l2(pu.detach(), pr.detach()) < 1e-4, "%s after Adam" % n
+        ue.load_state_dict(re_.state_dict())
+        ud.load_state_dict(rd.state_dict())
+    z_loc, _ = model.encode(x)
+    with torch.no_grad():
+        np.testing.assert_allclose(z_loc.numpy(), re_(x)[0].numpy(), rtol=1e-4, atol=1e-5)
+    tr = pv.trainers.SVItrainer(model, seed=1)
+    tr.step(pv.utils.init_dataloader(x, batch_size=4), pv.utils.init_dataloader(x, batch_size=3))
+    assert np.isfinite(tr.loss_history["training_loss"][0]) and np.isfinite(tr.loss_history["test_loss"][0])
+
+
 class _UserLabelNet(torch.nn.Module):
     """A user-defined label network (ssiVAE.set_classifier / ss_reg_iVAE.set_regressor, ssivae.py:236-240)."""
     def __init__(self, n_in, n_out, softmax):
