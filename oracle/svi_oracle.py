@@ -425,7 +425,8 @@ class VedOracle:
         # `params`: a state_dict; batch-norm buffers (running_mean / running_var / num_batches_tracked) are split off
         is_buf = lambda k: k.rsplit(".", 1)[-1] in ("running_mean", "running_var", "num_batches_tracked")
         self.p = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items() if not is_buf(k)}
-        self.bufs = {k: v.detach().clone() for k, v in params.items() if is_buf(k)}
+        self.bufs = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone())
+                     for k, v in params.items() if is_buf(k)}
         self.training = True            # nn.Module.training: VED.encode / decode switch to eval() and nothing switches back
         self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)
         self.dtype = dtype
