@@ -410,8 +410,14 @@ __device__ long long fb_trace[256];
     if ((f.ablate & 256) && g == 0 && tid == 0 && tile_no < 4)                             \
       fb_trace[tile_no * 32 + (k)] = (long long)__builtin_readcyclecounter();              \
   } while (0)
+#define FB_KSTAMP(k)                                                                       \
+  do {                                                                                     \
+    if ((f.ablate & 256) && blockIdx.x == 0 && threadIdx.x == 0)                           \
+      fb_trace[200 + (k)] = (long long)__builtin_readcyclecounter();                       \
+  } while (0)
 #else
 #define FB_STAMP(k) do { } while (0)     // (the stamps split basic blocks: compiled in only for scripts/gpu_trace.py)
+#define FB_KSTAMP(k) do { } while (0)
 #endif
 
 // stand-alone form of the per-step preparation (pv_fb_layout.h); the SVI step runs it inside the encoder's
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(256) void pv_fb_prep_kernel(PvFbPrep p) {
 template <bool GRADS, int LIK, bool X3>
 __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f) {
   extern __shared__ __attribute__((aligned(16))) char smb[];
+  FB_KSTAMP(0);                                                          // kernel entry
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = blockIdx.x, G = gridDim.x;
@@ -523,6 +530,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   };
   fetch_unit_inputs(u_lo);
   int tile_no = -1;
+  FB_KSTAMP(1);                                                          // prologue done
   for (int64_t ut = u_lo; ut < u_hi; ut += TILE_UNITS) {
     ++tile_no;
     FB_STAMP(0);
@@ -735,6 +743,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     if (X3) __syncthreads();   // the staging area is free again (the next tile's W2 reload lands here)
     FB_STAMP(13);
   }
+  FB_KSTAMP(2);                                                          // last tile done
   if (!GRADS) return;
 
   if (cur_b >= 0) flush_hz(cur_b);
@@ -788,6 +797,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     for (int w = 0; w < FB_WAVES; ++w) v += red[w];
     rec[2 * FD_H * FD_H + 5 * FD_H] = v;
   }
+#ifdef FB_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FB_KSTAMP(3);                                                          // record written
 }
 
 extern "C" int pv_debug_read_trace(long long* out, int n) {

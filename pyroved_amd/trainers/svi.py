@@ -146,6 +146,86 @@ class SVItrainer:
         if not direct:
             self._hist[i].copy_(eng.scalars)
 
+    # ---- the epoch's minibatch order and noise, with the global CPU generator consumed exactly as the reference's
+    # `for data in loader: svi.step(...)` consumes it, but without per-batch Python work
+    def _epoch_batches(self, loader, n: int):
+        """Index batches of one pass over `loader`.  Standard samplers are reproduced directly: iter(DataLoader) draws
+        the base seed (torch/utils/data/dataloader.py: _BaseDataLoaderIter.__init__), RandomSampler.__iter__ draws its
+        seed and permutes on a private generator (torch/utils/data/sampler.py) — the permutation itself does not touch
+        the global stream, so the NEXT epoch's is computed ahead on a background thread from the seed the global
+        generator will produce if nobody draws from it in between, and is used only if the seed really drawn matches
+        (tests/test_host_cpu.py checks order and generator state against a real DataLoader pass).  Anything else
+        (custom samplers / generators / replacement) iterates a DataLoader over the indices with the caller's sampler."""
+        from torch.utils.data import DataLoader, BatchSampler, RandomSampler, SequentialSampler
+        bs = loader.batch_sampler
+        smp = getattr(bs, "sampler", None)
+        std = (type(bs) is BatchSampler and loader.generator is None and len(smp) == n if smp is not None else False)
+        if std and type(smp) is SequentialSampler:
+            torch.empty((), dtype=torch.int64).random_()                    # iter(DataLoader): base seed
+            order = torch.arange(n)
+        elif (std and type(smp) is RandomSampler and not smp.replacement and smp.generator is None
+              and smp._num_samples is None):
+            torch.empty((), dtype=torch.int64).random_()                    # iter(DataLoader): base seed
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())  # RandomSampler.__iter__
+            order = self._perm_for(seed, n)
+            self._rand_n = n                                                # (what _prefetch_perm prepares for)
+        else:
+            idx_loader = DataLoader(range(n), batch_sampler=bs)             # same sampler object
+            return [b for b in idx_loader]
+        batches = list(order.split(bs.batch_size))
+        if bs.drop_last and batches and len(batches[-1]) < bs.batch_size:
+            batches.pop()
+        return batches
+
+    def _perm_for(self, seed: int, n: int) -> torch.Tensor:
+        job = getattr(self, "_perm_job", None)
+        self._perm_job = None
+        if job is not None:
+            job[0].join()
+            if job[1] == (seed, n) and job[2]:
+                return job[2][0]
+        g = torch.Generator()
+        g.manual_seed(seed)
+        return torch.randperm(n, generator=g)
+
+    def _prefetch_perm(self, n: int) -> None:
+        """Starts the next epoch's permutation on a thread, assuming the next two draws from the global CPU generator
+        are that epoch's (base seed, sampler seed); the generator itself is left untouched."""
+        import threading
+        probe = torch.Generator()
+        probe.set_state(torch.get_rng_state())
+        torch.empty((), dtype=torch.int64).random_(generator=probe)
+        seed = int(torch.empty((), dtype=torch.int64).random_(generator=probe).item())
+        out = []
+
+        def work():
+            g = torch.Generator()
+            g.manual_seed(seed)
+            out.append(torch.randperm(n, generator=g))
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        self._perm_job = (t, (seed, n), out)
+
+    def _draw_eps_epoch(self, sizes) -> torch.Tensor:
+        """Every step's eps, drawn on the global CPU generator in step order, as ONE (sum(sizes), z_dim) tensor.  CPU
+        normal_ fills 16 values at a time and re-draws the last 16 of a tensor whose size is not a multiple of 16, so a
+        run of batches with numel % 16 == 0 is one draw of their total; the others are drawn one by one."""
+        z = self.model.z_dim
+        if self.rng != "cpu":
+            return torch.empty(sum(sizes), z, device=self.engine.device).normal_()
+        out, i = [], 0
+        while i < len(sizes):
+            j = i
+            while j < len(sizes) and (sizes[j] * z) % 16 == 0 and sizes[j] * z >= 16:
+                j += 1
+            if j > i:
+                out.append(torch.empty(sum(sizes[i:j]), z).normal_())
+                i = j
+            else:
+                out.append(torch.empty(sizes[i], z).normal_())
+                i += 1
+        return out[0] if len(out) == 1 else torch.cat(out)
+
     # ------------------------------------------------------------------ data feed
     def _device_dataset(self, tensors):
         """Device-resident copy of the loader's TensorDataset, cached until the tensors change."""
@@ -168,16 +248,17 @@ class SVItrainer:
                 or loader.num_workers != 0 or loader.batch_sampler is None or len(ds.tensors) not in (1, 2)
                 or getattr(self.engine, "device", None) is None or self.rng != "cpu"):
             return None
-        idx_loader = DataLoader(range(len(ds)), batch_sampler=loader.batch_sampler)     # same sampler object
-        batches = [b for b in idx_loader]                      # LongTensors of sample indices, the loader's order
+        batches = self._epoch_batches(loader, len(ds))         # LongTensors of sample indices, the loader's order
         if not batches:
             return 0
-        eps = [self._draw_eps(len(b)) for b in batches]
+        eps = self._draw_eps_epoch([len(b) for b in batches])
+        if getattr(self, "_rand_n", None) and self.rng == "cpu":
+            self._prefetch_perm(self._rand_n)                  # the next shuffled epoch's order, off the critical path
         dev = self.engine.device
         data = self._device_dataset(ds.tensors)
         sizes = [len(b) for b in batches]
         idx_dev = torch.cat(batches).to(dev)
-        eps_dev = torch.cat(eps).to(dev, torch.float32)
+        eps_dev = eps.to(dev, torch.float32)
         off = 0
         for n, bsz in enumerate(sizes):
             idx = idx_dev[off:off + bsz]

@@ -46,3 +46,9 @@ for t in (1, 2):
     print("tile", t, "raw:")
     for (a, ka), (b, kb) in zip(st, st[1:]):
         print("   %6d  -> %s" % (b - a, labels[kb]))
+
+kb = (C.c_longlong * 256)()
+lib.pv_debug_read_trace(kb, 256)
+if kb[200]:
+    print("kernel-level (workgroup 0, wave 0): prologue %d cycles, tiles %d, epilogue (record write) %d; whole %d"
+          % (kb[201] - kb[200], kb[202] - kb[201], kb[203] - kb[202], kb[203] - kb[200]))

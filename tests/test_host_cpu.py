@@ -137,6 +137,67 @@ def test_viz_mosaic_and_plots():
     plt.close("all")
 
 
+def test_trainer_epoch_order_and_noise_match_a_dataloader_pass():
+    """SVItrainer's epoch prologue (trainers/svi.py: _epoch_batches, _draw_eps_epoch, the background permutation for
+    the next epoch) against what `for data in loader: eps = torch.empty(b, z).normal_()` does: same minibatch order,
+    same eps, same state of the global CPU generator afterwards — for shuffled / sequential / drop_last / ragged
+    loaders over consecutive epochs, with and without a correctly predicted prefetch."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from pyroved_amd.trainers.svi import SVItrainer
+
+    class _M:
+        z_dim = 5
+    tr = SVItrainer.__new__(SVItrainer)
+    tr.model, tr.rng = _M(), "cpu"
+    x = torch.rand(1003, 4)
+    hits = 0
+    for kw in (dict(batch_size=100, shuffle=True), dict(batch_size=100, shuffle=False),
+               dict(batch_size=64, shuffle=True, drop_last=True), dict(batch_size=7, shuffle=True),
+               dict(batch_size=2048, shuffle=True)):
+        loader = DataLoader(TensorDataset(x), **kw)
+        torch.manual_seed(11)
+        ref, ref_eps = [], []
+        for ep in range(3):                                    # consecutive epochs on one generator stream
+            b_ = [b for b in DataLoader(range(1003), batch_sampler=loader.batch_sampler)]
+            ref.append(b_)
+            ref_eps.append(torch.cat([torch.empty(len(b), 5).normal_() for b in b_]))
+        st = torch.get_rng_state()
+        torch.manual_seed(11)
+        tr._perm_job = None
+        for ep in range(3):
+            job = getattr(tr, "_perm_job", None)
+            got = tr._epoch_batches(loader, 1003)
+            if job is not None:
+                hits += int(bool(job[2]) and kw["shuffle"] and torch.equal(torch.cat(got)[:len(job[2][0])][:10], job[2][0][:10]))
+            eps = tr._draw_eps_epoch([len(b) for b in got])
+            if kw["shuffle"]:
+                tr._prefetch_perm(1003)
+            assert len(got) == len(ref[ep]) and all(torch.equal(a, b) for a, b in zip(got, ref[ep])), (kw, ep)
+            assert torch.equal(eps, ref_eps[ep]), (kw, ep)
+        assert torch.equal(st, torch.get_rng_state()), kw
+        if tr._perm_job is not None:
+            tr._perm_job[0].join()
+    assert hits >= 6                                            # the predicted permutations were the ones used
+    # a wrong prediction (someone drew from the generator in between) is discarded
+    loader = DataLoader(TensorDataset(x), batch_size=100, shuffle=True)
+    torch.manual_seed(5)
+    tr._prefetch_perm(1003)
+    torch.rand(3)
+    st0 = torch.get_rng_state()
+    got = tr._epoch_batches(loader, 1003)
+    torch.set_rng_state(st0)
+    want = [b for b in DataLoader(range(1003), batch_sampler=loader.batch_sampler)]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    # custom sampler: the generic path
+    from torch.utils.data import SubsetRandomSampler
+    l3 = DataLoader(TensorDataset(x), batch_size=50, sampler=SubsetRandomSampler(range(0, 1003, 2)))
+    torch.manual_seed(2)
+    want = [b for b in DataLoader(range(1003), batch_sampler=l3.batch_sampler)]
+    torch.manual_seed(2)
+    got = tr._epoch_batches(l3, 1003)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
 # ------------------------------------------------------------------------------- API mirror
 @pytest.mark.parametrize("invariances, coord_exp", [(None, 0), (['t'], 1)])
 def test_base_vae_1d(invariances, coord_exp):
