@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the guide's
 # gfx950 correction + WRITE_SIZE, KiB -> bytes), batch 256: see profiles/r01*_pmc_*.txt.  None: not collected.
 TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1331 * 1024 + 37943 * 1024,
-                 3: 2 * 994 * 1024 + 37925 * 1024}   # 2, 3: profiles/r01i_pmc_* (same values in r01h)
+                 3: 2 * 994 * 1024 + 37925 * 1024}   # 2, 3: profiles/r01i_pmc_* (same values in r01h, r01j)
 
 
 def decoder_flops_per_image(n_pix, hidden=128, coord_dim=2):
