@@ -1,8 +1,8 @@
 """Plain-bf16 decoder kernel (fused=3) against the CPU oracle on a golden case: ELBO and per-tensor gradient error.
-python scripts/gpu_diag_bf16.py NAME"""
+python tests/tools/gpu_diag_bf16.py NAME"""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from test_gpu_parity import load_golden, meta_of, build, make_x, rel_l2, orc
 name = sys.argv[1]

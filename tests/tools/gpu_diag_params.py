@@ -1,7 +1,7 @@
-"""Per-key gradient / parameter-after-Adam error vs the CPU oracle for one golden case: python scripts/gpu_diag_params.py NAME [fused]"""
+"""Per-key gradient / parameter-after-Adam error vs the CPU oracle for one golden case: python tests/tools/gpu_diag_params.py NAME [fused]"""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from test_gpu_parity import load_golden, meta_of, build, make_x, rel_l2, orc
 name = sys.argv[1]; fused = int(sys.argv[2]) if len(sys.argv) > 2 else 2

@@ -1,9 +1,9 @@
 """Randomised parity sweep on the GPU: random iVAE / jiVAE / ssiVAE / ss_reg_iVAE configurations (data shapes incl. odd and
 1-D, invariance sets, widths, activations, samplers, conditioning, batch sizes incl. 1 and non-multiples of 16, decoder
 paths) against the CPU oracle from identical parameters: loss to 2e-5, every gradient tensor to a relative-L2 bar.
-Prints one line per case and a summary; exit code 1 on any failure.    python scripts/gpu_fuzz.py [n_cases] [seed]"""
+Prints one line per case and a summary; exit code 1 on any failure.    python tests/tools/gpu_fuzz.py [n_cases] [seed]"""
 import os, sys, random, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import pyroved_amd as pv
