@@ -97,6 +97,10 @@ class baseVAE(nn.Module):
         return phi, dx, sc, z
 
     # ------------------------------------------------------------------ HIP engine
+    def _engine_ready(self) -> bool:
+        """Whether the model is a complete VAE (encoder, decoder, likelihood) the plan-based engine can drive."""
+        return self.encoder_z is not None and self.decoder is not None and hasattr(self, "sampler_d")
+
     def engine(self, **kw):
         """The HIP driver bound to this model's parameters (created on first use)."""
         from ..engine import IVAEEngine
@@ -107,9 +111,19 @@ class baseVAE(nn.Module):
     def _encode(self, *input_args, device: str = None, **kwargs: int) -> torch.Tensor:
         """Encodes data batch-by-batch with the trained encoder (base.py:121-143);
         returns cat([z_loc, z_scale], -1) on the CPU."""
-        eng = self.engine()
         loader = init_dataloader(*input_args, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
         z_encoded = []
+        if not self._engine_ready():
+            # a bare baseVAE with only set_encoder() called (the reference's own tests use it so): the network's
+            # operator-level forward (nets.*: HIP Linear(+activation) kernels), as base.py:132-136 calls it
+            dev = torch.device(self.device if device is None else device)
+            for data in loader:
+                data = [d.to(dev, torch.float32) for d in data]
+                with torch.no_grad():
+                    encoded = self.encoder_z(data if len(data) > 1 else data[0])
+                z_encoded.append(torch.cat(encoded, -1).cpu())
+            return torch.cat(z_encoded)
+        eng = self.engine()
         for data in loader:
             x = data[0].to(eng.device, torch.float32)
             y = data[1].to(eng.device, torch.float32) if len(data) > 1 else None
@@ -119,8 +133,27 @@ class baseVAE(nn.Module):
     def _decode(self, z_new: torch.Tensor, device: str = None, **kwargs: int) -> torch.Tensor:
         """Decodes latent coordinates batch-by-batch (base.py:145-171).  kwargs: batch_size,
         and for invariant models angle / shift / scale of the coordinate grid."""
-        eng = self.engine()
         loader = init_dataloader(z_new, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
+        if not self._engine_ready():
+            # bare baseVAE with only set_decoder() called: transform the grid once, then the decoder's own forward
+            from ..utils import transform_coordinates
+            dev = torch.device(self.device if device is None else device)
+            grid = None
+            if self.invariances:
+                g0 = self.grid.to(dev, torch.float32)
+                a = torch.as_tensor(kwargs.get("angle", 0.), dtype=torch.float32).reshape(1).to(dev)
+                t = torch.as_tensor(kwargs.get("shift", 0.), dtype=torch.float32).reshape(-1).to(dev)
+                t = (t if t.numel() == g0.shape[-1] else t[:1].expand(g0.shape[-1])).reshape(1, 1, -1)
+                sc = torch.as_tensor(kwargs.get("scale", 1.), dtype=torch.float32).reshape(1).to(dev)
+                grid = transform_coordinates(g0.unsqueeze(0), a, t, sc).squeeze(0)
+            x_decoded = []
+            for (z,) in loader:
+                z = z.to(dev, torch.float32)
+                with torch.no_grad():
+                    loc = self.decoder(grid.expand(z.shape[0], *grid.shape), z) if grid is not None else self.decoder(z)
+                x_decoded.append(loc.cpu())
+            return torch.cat(x_decoded)
+        eng = self.engine()
         angle, shift, scale = 0.0, (0.0, 0.0), 1.0
         if self.invariances:
             angle = float(kwargs.get("angle", 0.0))

@@ -50,6 +50,12 @@ class UpsampleBlock(nn.Module):
         self.scale_factor = scale_factor
         self.conv = get_conv(ndim)(input_channels, output_channels, kernel_size=1, stride=1, padding=0)
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Stand-alone module forward (conv.py:141-147): interpolate, then the 1-by-1 convolution.  Inside models.VED
+        the block runs as one op of the HIP conv stack (pv_convstack.h) instead."""
+        x = nn.functional.interpolate(x, scale_factor=self.scale_factor, mode=self.mode)
+        return self.conv(x)
+
 
 def _conv_stack(ndim, input_channels, conv_filters, kernel_size, stride, padding, batchnorm, activation, tail):
     """The reference's layer-list construction shared by FeatureExtractor and Upsampler (conv.py:171-193, 238-259):
@@ -118,6 +124,10 @@ class features_to_latent(nn.Module):
         self.reshape_ = int(torch.prod(tt(input_dim)))
         self.fc_latent = nn.Linear(self.reshape_, latent_dim)
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from .. import ops
+        return ops.linear_act(x.reshape(-1, self.reshape_), self.fc_latent.weight, self.fc_latent.bias, None)
+
 
 class latent_to_features(nn.Module):
     """Maps a latent vector to the feature space (pyroved/nets/conv.py): Linear + view (C, spatial...)."""
@@ -125,6 +135,10 @@ class latent_to_features(nn.Module):
         super(latent_to_features, self).__init__()
         self.reshape_ = out_dim
         self.fc = nn.Linear(latent_dim, int(torch.prod(tt(out_dim)).item()))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from .. import ops
+        return ops.linear_act(x, self.fc.weight, self.fc.bias, None).view(-1, *self.reshape_)
 
 
 class convEncoderNet(nn.Module):
@@ -147,8 +161,16 @@ class convEncoderNet(nn.Module):
         self.features2latent = features_to_latent([output_channels, *output_dim], 2 * latent_dim)
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor]:
-        from ..engine_ved import conv_encoder_forward
-        return conv_encoder_forward(self, x)
+        """Inside a model (models.VED, iVAE.set_encoder) the HIP conv stack of the owning engine runs
+        (pv_ved_encode / the plan's encoder ops).  A stand-alone net — any ndim, any number of input channels, as the
+        reference's own unit tests build them — composes its sub-modules (conv.py:57-64): the feature extractor's
+        layers, then the latent Linear through ops.linear_act."""
+        if getattr(self, "_pv_engine", None) is not None:
+            from ..engine_ved import conv_encoder_forward
+            return conv_encoder_forward(self, x)
+        encoded = self.features2latent(self.feature_extractor(x))
+        mu, sigma = encoded.split(self.latent_dim, 1)
+        return mu, (nn.functional.softplus(sigma) if self.softplus_out else sigma)
 
 
 class convDecoderNet(nn.Module):
@@ -169,5 +191,10 @@ class convDecoderNet(nn.Module):
             activation=activation, upsampling_mode=upsampling_mode)
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
-        from ..engine_ved import conv_decoder_forward
-        return conv_decoder_forward(self, z)
+        """As convEncoderNet.forward: the owning engine's HIP conv stack inside a model, the sub-modules' own
+        composition (conv.py:97-102) for a stand-alone net."""
+        if getattr(self, "_pv_engine", None) is not None:
+            from ..engine_ved import conv_decoder_forward
+            return conv_decoder_forward(self, z)
+        x = self.upsampler(self.latent2features(z))
+        return torch.sigmoid(x) if self.sigmoid_out else x
