@@ -170,7 +170,31 @@ class iVAE(baseVAE):
         return loc
 
     def predict_on_latent(self, train_data, gp_labels, gp_iterations: int = 1, d: int = 12, plot: bool = False):
-        """Gaussian-process regression of labels over the latent space (models/ivae.py:312-364).  It is built on
-        pyro.contrib.gp (utils/gp.py), which is not a dependency of this build: encode with `iVAE.encode`, decode the
-        grid with `iVAE.manifold2d(d)` and fit the GP with the library of your choice."""
-        raise NotImplementedError("predict_on_latent needs pyro.contrib.gp; use encode() / manifold2d() with an external GP")
+        """Gaussian-process regression of labels over the latent space, evaluated on the d x d latent grid
+        (models/ivae.py:312-364): encode, fit utils.gp_model on the encoded means, predict on
+        utils.generate_latent_grid(d), decode the grid.  Returns ((z, z_decoded), predictions)."""
+        from ..utils import generate_latent_grid
+        from ..utils.gp import gp_model
+        X = torch.as_tensor(train_data, dtype=torch.float32)
+        y = torch.as_tensor(gp_labels, dtype=torch.float32)
+        encoded_X = self.encode(X)[0]
+        gpr = gp_model(input_dim=encoded_X.shape[1], encoded_X=encoded_X, y=y, gp_iterations=gp_iterations)
+        z, _ = generate_latent_grid(d)
+        z = torch.as_tensor(z, dtype=torch.float32)
+        gpr.eval()
+        with torch.no_grad():
+            predictions, _ = gpr(z)
+        z_decoded = self.manifold2d(d, plot=False)
+        if plot:
+            import matplotlib.pyplot as plt
+            self.manifold2d(d=d, cmap='viridis')
+            plt.figure(figsize=(8, 8))
+            heatmap = plt.imshow(predictions.reshape(d, d), cmap='viridis', aspect='auto')
+            plt.colorbar(heatmap, label='Prediction Value')
+            plt.xticks(fontsize=14)
+            plt.yticks(fontsize=14)
+            plt.xlabel("$z_1$", fontsize=14)
+            plt.ylabel("$z_2$", fontsize=14)
+            plt.title('Predictions Visualization')
+            plt.show()
+        return (z, z_decoded), predictions

@@ -286,3 +286,22 @@ def test_conv_decoder_output(latent_dim, output_dim, output_channels):
     z = torch.randn(5, latent_dim).cuda()
     decoder = nets.convDecoderNet(latent_dim, output_dim, output_channels, hidden_dim=[(8, 8), (8,)]).cuda()
     assert decoder(z).shape == (5, output_channels, *output_dim)
+
+
+# ------------------------------------------------------------------ GP helper (tests/test_utils.py, test_models.py:650-666)
+def test_gp_model_output_shape():
+    encoded_X, y = torch.randn(5, 3), torch.randn(5)
+    gpr = utils.gp_model(3, encoded_X, y)
+    with torch.no_grad():
+        predictions, _ = gpr(encoded_X)
+    assert predictions.shape == y.shape
+
+
+def test_ivae_predict_on_latent():
+    train_data, gp_labels, d = torch.randn(10, 5, 5), torch.randint(0, 2, (10,)), 12
+    vae = models.iVAE((5, 5), latent_dim=2, invariances=None, seed=0)
+    (z, z_decoded), predictions = vae.predict_on_latent(train_data, gp_labels, 1, d, plot=False)
+    assert isinstance(z, torch.Tensor) and isinstance(predictions, torch.Tensor)
+    assert z_decoded.dim() == 3 and predictions.dim() == 1 and z_decoded.shape == (d * d, 5, 5)
+    (_, _), p2 = vae.predict_on_latent(train_data, gp_labels, 1, 4, plot=True)
+    assert p2.shape == (16,)

@@ -198,6 +198,36 @@ def test_trainer_epoch_order_and_noise_match_a_dataloader_pass():
     assert all(torch.equal(a, b) for a, b in zip(got, want))
 
 
+def test_gp_helper_matches_closed_forms():
+    """utils.gp_model (the torch restatement of pyro.contrib.gp's GPRegression + RBF behind predict_on_latent; Pyro is
+    absent, so this is pinned to the textbook formulas only): the loss is -log N(y | 0, K + (noise + jitter) I), the
+    predictive mean K_*f (K_ff + ..)^-1 y, variances non-negative and ~0 at noiseless training points for tiny noise,
+    and one Adam(lr=0.005) step moves each log-parameter by 0.005."""
+    from torch.distributions import MultivariateNormal
+    from pyroved_amd.utils.gp import GPRegression, gp_model
+    torch.manual_seed(0)
+    X, y = torch.randn(7, 3), torch.randn(7)
+    g = GPRegression(X, y)
+    K = g.kernel(X) + (1e-6 + 1.0) * torch.eye(7)
+    want = -MultivariateNormal(torch.zeros(7), covariance_matrix=K).log_prob(y)
+    assert abs(float(g.loss()) - float(want)) < 1e-4
+    with torch.no_grad():
+        mean, var = g(X)
+        np.testing.assert_allclose(mean.numpy(), (g.kernel(X) @ torch.linalg.solve(K, y)).numpy(), atol=1e-5)
+        assert (var >= 0).all()
+        _, cov = g(X, full_cov=True)
+        np.testing.assert_allclose(torch.diagonal(cov).numpy(), var.numpy(), atol=1e-5)
+        g.log_noise.fill_(-12.0)
+        m2, v2 = g(X)
+        np.testing.assert_allclose(m2.numpy(), y.numpy(), atol=2e-3)
+        assert float(v2.max()) < 1e-3
+    t = gp_model(3, X, y, gp_iterations=1)
+    for q in t.parameters():
+        assert abs(abs(float(q)) - 0.005) < 1e-6
+    t3 = gp_model(3, X, y, gp_iterations=3)
+    assert float(t3.loss()) < float(GPRegression(X, y).loss())
+
+
 # ------------------------------------------------------------------------------- API mirror
 @pytest.mark.parametrize("invariances, coord_exp", [(None, 0), (['t'], 1)])
 def test_base_vae_1d(invariances, coord_exp):
