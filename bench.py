@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the fp32-class path) of the default run")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--two-call", action="store_true", help="N=1: pv_ivae_loss_and_grads + pv_adam_step instead of pv_ivae_step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,9 +207,14 @@ def _run(args, fused, pv, pvdist, td, dev, rank, world, B, n_pix):
             eng.loss_and_grads(ring[i % N_RING], eps_all[i])
             pvdist.allreduce_sum_(eng.grad)           # gradients + the 4 loss scalars in one collective
             hist[i].copy_(eng.scalars)
-        else:
+            eng.adam_step()
+        elif args.two_call:
             eng.loss_and_grads(ring[i % N_RING], eps_all[i], scalars_out=hist[i])   # loss lands in the history
-        eng.adam_step()
+            eng.adam_step()
+        else:
+            # single process: SVI.step as ONE library call (pv_ivae_step: ELBO + gradients + Adam; the update rides in
+            # the last gradient launch — bit-identical to the two calls, tests/test_gpu_parity.py)
+            eng.loss_and_grads(ring[i % N_RING], eps_all[i], scalars_out=hist[i], step=True)
 
     for i in range(args.warmup):
         step(i)

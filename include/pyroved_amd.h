@@ -227,7 +227,9 @@ int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n,
 int pv_ivae_guide(const pv_ivae_plan* plan, void* stream);
 int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, void* stream);
 
-/* loss_and_grads + adam in one call (single-GPU SVI.step, trainers/svi.py:107). */
+/* loss_and_grads + adam in one call (single-GPU SVI.step, trainers/svi.py:107).  Same results as the two calls,
+ * bit for bit; on the fused decoder path the update is applied inside the last gradient launch (one launch fewer),
+ * so plan->grads holds the zeroed gradients of pyro's zero_grads afterwards.  Needs adam_m / adam_v / adam_step. */
 int pv_ivae_step(const pv_ivae_plan* plan, void* stream);
 
 /* baseVAE._encode inner call (models/base.py:131-135): encoder_z(x[,y]) ->

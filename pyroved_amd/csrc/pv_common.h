@@ -122,7 +122,26 @@ struct PvGemm {
 int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t s);
 int pv_gemm_pick_splits(int M, int N, int K);
 // up to 4 plain wgrad problems (short contraction, wide output) in one launch, one wave per 16x16 tile (pv_wgrad.hip)
-int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s);
+// Adam fused into a gradient-producing launch (pv_ivae_step): the kernel that finalises a gradient element applies
+// torch.optim.Adam's update to that element right away (and leaves the zeroed gradient pyro's zero_grads leaves);
+// guest workgroups of the same launch update every element the launch does not produce (those were final before it).
+struct PvAdamFuse {
+  float* p; float* g; float* m; float* v;
+  int64_t n;
+  float b1, b2, eps, step_size, bc2_sqrt;
+};
+__device__ __forceinline__ void pv_adam_update(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, int64_t i, float gi, float b1, float b2, float eps,
+                                               float step_size, float bc2_sqrt) {
+  float mi = m[i], vi = v[i];
+  mi = mi + (gi - mi) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1 - beta1)
+  vi = vi * b2 + (1.0f - b2) * gi * gi;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
+  m[i] = mi; v[i] = vi;
+  g[i] = 0.0f;                                       // pyro.infer.util.zero_grads
+}
+int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s, const PvAdamFuse* adam = nullptr);
 // out[i] = sum_p part[p*stride + i], p ascending (deterministic)
 int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 // Workgroup barrier for kernels whose waves communicate through LDS only: waits for the wave's LDS traffic, not for

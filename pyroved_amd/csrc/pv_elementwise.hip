@@ -756,14 +756,7 @@ __global__ void pv_adam_kernel(float* __restrict__ p, float* __restrict__ g, flo
                                float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
                                float bc2_sqrt) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    float mi = m[i], vi = v[i];
-    mi = mi + (gi - mi) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1 - beta1)
-    vi = vi * b2 + (1.0f - b2) * gi * gi;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
-    m[i] = mi; v[i] = vi;
-    g[i] = 0.0f;                                       // pyro.infer.util.zero_grads
+    pv_adam_update(p, g, m, v, i, g[i], b1, b2, eps, step_size, bc2_sqrt);
   }
 }
 

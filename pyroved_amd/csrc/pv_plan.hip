@@ -392,8 +392,10 @@ PvGemm wgrad_problem(const float* dpre, int64_t lddp, const float* x, int64_t ld
 // every weight gradient of the encoder (plus `extra`, e.g. fc_latent's) in one multi-GEMM launch per 4 problems
 struct PvFinish { const float* llb; int B; float* scalars; const float* kl_part; int n_part; float beta; };
 
+// adam / adam_done: pv_ivae_step's optimizer update, applied inside the weight-gradient launch when that single launch
+// finalises every encoder gradient (compact encoder, <= 4 problems); *adam_done tells the caller whether it was
 int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, hipStream_t s,
-                const PvFinish* fin = nullptr) {
+                const PvFinish* fin = nullptr, const PvAdamFuse* adam = nullptr, bool* adam_done = nullptr) {
   const int64_t B = p->batch, z = p->z_dim;
   float* G = p->grads;
   void* ws = L.scratch;
@@ -458,7 +460,10 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     probs[np++] = wgrad_problem(L.edp[i], l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, B,
                                 l.in_dim, l.out_dim);
   }
-  if (B <= 4096) {
+  if (B <= 4096 && np <= 4 && adam && adam_done && L.enc_compact) {
+    PV_TRY(pv_wgrad_small(probs, np, s, adam));
+    *adam_done = true;
+  } else if (B <= 4096) {
     for (int i = 0; i < np; i += 4) PV_TRY(pv_wgrad_small(probs + i, np - i < 4 ? np - i : 4, s));
   } else {                                   // long contractions: split-K GEMMs, one launch pair each
     for (int i = 0; i < np; ++i)
@@ -564,7 +569,8 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
 }
 
 // loss_and_grads with the fused persistent spatial-decoder kernel (pv_sdec_fused.hip)
-int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s) {
+int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s,
+                         const PvAdamFuse* adam = nullptr, bool* adam_done = nullptr) {
   const int64_t B = p->batch, N = p->n_pix, R = L.rows, z = p->z_dim;
   const int64_t K = plan_K(p), S = plan_S(p);        // jiVAE: S = K*B decoder samples, rows R = S*N
   const int64_t lat_in = plan_lat_in(p);
@@ -644,7 +650,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
   // (jiVAE: over the K*B decoder samples, zin = [z content | onehot(k)])
   const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
-  PV_TRY(encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr));
+  PV_TRY(encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr, adam, adam_done));
   return extra_outputs(p, L, L.dzc, lat_in, s);
 }
 
@@ -874,7 +880,28 @@ extern "C" int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, 
   return latent_encoder_bwd(&q, L, q.z_dim, 4, 1, s);
 }
 
+// SVI.step in one call.  On the fused-decoder path with the compact encoder the Adam update rides in the last
+// gradient launch (pv_wgrad.hip: every element is updated by whoever finalises its gradient; bit-identical to
+// pv_ivae_loss_and_grads + pv_adam_step, one launch fewer); everywhere else it is exactly that pair of calls.
 extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
+  if (plan && !plan->ext_decoder && valid_plan(plan) && plan->params && plan->x && plan->eps && plan->scalars && plan->ws &&
+      plan->grads && plan->adam_m && plan->adam_v && plan->adam_step >= 1 && plan->n_params > 0 &&
+      !(plan->coord_dim > 0 && !plan->grid) && !plan->ext_encoder) {
+    Layout L;
+    carve(plan, (char*)plan->ws, L);
+    if (plan->ws_bytes < L.total) return PV_EWS;
+    if (L.fused && L.enc_compact) {
+      const double bc1 = 1.0 - pow((double)plan->adam_beta1, (double)plan->adam_step);
+      const double bc2 = 1.0 - pow((double)plan->adam_beta2, (double)plan->adam_step);
+      const PvAdamFuse ad{plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->adam_beta1,
+                          plan->adam_beta2, plan->adam_eps, (float)((double)plan->lr / bc1), (float)sqrt(bc2)};
+      bool done = false;
+      PV_TRY(loss_and_grads_fused(plan, L, 1, (hipStream_t)stream, &ad, &done));
+      if (done) return 0;
+      return pv_adam_step(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->lr,
+                          plan->adam_beta1, plan->adam_beta2, plan->adam_eps, plan->adam_step, stream);
+    }
+  }
   PV_TRY(pv_ivae_loss_and_grads(plan, 1, stream));
   return pv_adam_step(plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->lr,
                       plan->adam_beta1, plan->adam_beta2, plan->adam_eps, plan->adam_step, stream);

@@ -19,6 +19,11 @@ struct PvWgradSmall {
   PvGemm g[4];
   int tile_end[4];             // exclusive prefix sums of the problems' tile counts
   int n;
+  // fused Adam (pv_common.h: PvAdamFuse): blocks >= tile_end[3] are guests that update every element outside the
+  // launch's own outputs, rng[2i] / rng[2i+1] = problem i's weight / bias gradient range in the flat buffer
+  int adam_on;
+  PvAdamFuse ad;
+  int64_t rng_lo[8], rng_hi[8];
 };
 
 __global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSmall w) {
@@ -27,6 +32,17 @@ __global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSm
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = blockIdx.x;
+  if (w.adam_on && t >= w.tile_end[3]) {              // guest: Adam over everything this launch does not produce
+    const PvAdamFuse& a = w.ad;
+    const int64_t stride = (int64_t)(gridDim.x - w.tile_end[3]) * blockDim.x;
+    for (int64_t i = (int64_t)(t - w.tile_end[3]) * blockDim.x + tid; i < a.n; i += stride) {
+      bool own = false;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) own = own || (i >= w.rng_lo[k] && i < w.rng_hi[k]);
+      if (!own) pv_adam_update(a.p, a.g, a.m, a.v, i, a.g[i], a.b1, a.b2, a.eps, a.step_size, a.bc2_sqrt);
+    }
+    return;
+  }
   int pi = 0;
   while (t >= w.tile_end[pi]) ++pi;
   if (pi > 0) t -= w.tile_end[pi - 1];
@@ -81,15 +97,24 @@ __global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSm
   __syncthreads();
   {
     const int mm = tid >> 4, nn = tid & 15, mo = 16 * mb + mm, no = 16 * nb + nn;
-    if (mo < g.M && no < g.N)
-      g.C[(int64_t)mo * g.ldc + no] = (part[0][mm][nn] + part[1][mm][nn]) + (part[2][mm][nn] + part[3][mm][nn]);
-    if (g.rowsumA && nb == 0 && tid < 16 && 16 * mb + tid < g.M)
-      g.rowsumA[16 * mb + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
+    const PvAdamFuse& a = w.ad;
+    if (mo < g.M && no < g.N) {
+      const float c = (part[0][mm][nn] + part[1][mm][nn]) + (part[2][mm][nn] + part[3][mm][nn]);
+      if (w.adam_on) pv_adam_update(a.p, a.g, a.m, a.v, (g.C - a.g) + (int64_t)mo * g.ldc + no, c, a.b1, a.b2, a.eps,
+                                    a.step_size, a.bc2_sqrt);
+      else g.C[(int64_t)mo * g.ldc + no] = c;
+    }
+    if (g.rowsumA && nb == 0 && tid < 16 && 16 * mb + tid < g.M) {
+      const float c = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
+      if (w.adam_on) pv_adam_update(a.p, a.g, a.m, a.v, (g.rowsumA - a.g) + 16 * mb + tid, c, a.b1, a.b2, a.eps,
+                                    a.step_size, a.bc2_sqrt);
+      else g.rowsumA[16 * mb + tid] = c;
+    }
   }
 }
 
 // gs[i]: plain wgrad problems (no bias / activation / aux epilogue); any strides, any M, N, K >= 1
-int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s) {
+int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s, const PvAdamFuse* adam) {
   if (n < 1 || n > 4) return PV_EINVAL;
   PvWgradSmall w{};
   int tiles = 0;
@@ -101,7 +126,25 @@ int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s) {
   }
   for (int i = n; i < 4; ++i) w.tile_end[i] = tiles;
   w.n = n;
-  hipLaunchKernelGGL(pv_wgrad_small_kernel, dim3(tiles), dim3(64 * WG_WAVES), 0, s, w);
+  int guests = 0;
+  if (adam) {
+    // every output must be a dense block of the flat gradient buffer (the caller guarantees it: nn.Linear weights/biases)
+    for (int i = 0; i < n; ++i) {
+      const int64_t c0 = gs[i].C - adam->g;
+      if (c0 < 0 || c0 + (int64_t)gs[i].M * gs[i].N > adam->n || gs[i].ldc != gs[i].N) return PV_EINVAL;
+      w.rng_lo[2 * i] = c0; w.rng_hi[2 * i] = c0 + (int64_t)gs[i].M * gs[i].N;
+      if (gs[i].rowsumA) {
+        const int64_t r0 = gs[i].rowsumA - adam->g;
+        if (r0 < 0 || r0 + gs[i].M > adam->n) return PV_EINVAL;
+        w.rng_lo[2 * i + 1] = r0; w.rng_hi[2 * i + 1] = r0 + gs[i].M;
+      }
+    }
+    w.adam_on = 1; w.ad = *adam;
+    guests = (int)((adam->n + 1023) / 1024);
+    if (guests > 256) guests = 256;
+    if (guests < 1) guests = 1;
+  }
+  hipLaunchKernelGGL(pv_wgrad_small_kernel, dim3(tiles + guests), dim3(64 * WG_WAVES), 0, s, w);
   PV_LAUNCH_CHECK();
   return 0;
 }

@@ -37,6 +37,7 @@ class IVAEEngine:
     """Binds an iVAE-like model (encoder_z: fcEncoderNet, decoder: sDecoderNet | fcDecoderNet)
     to the HIP library."""
     supports_scalars_out = True      # loss_and_grads can write the 4 loss scalars to a caller-given device slot
+    supports_step = True             # loss_and_grads(step=True) = SVI.step in one library call
 
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: int = 2):
@@ -346,12 +347,16 @@ class IVAEEngine:
     def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
                        scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None,
                        row_w: Optional[torch.Tensor] = None, row_elbo: Optional[torch.Tensor] = None,
-                       dy: Optional[torch.Tensor] = None):
+                       dy: Optional[torch.Tensor] = None, step: bool = False):
         """Enqueues Trace_ELBO.loss_and_grads on the current stream.  Results land in
         self.scalars (device, 4 floats) and self.grad[:n_flat]; nothing is synchronised.
         row_w (B): per-sample weights of the ELBO terms; row_elbo (B) / dy (B, c_dim): extra outputs
-        (include/pyroved_amd.h: pv_ivae_plan.row_w / row_elbo / dy)."""
+        (include/pyroved_amd.h: pv_ivae_plan.row_w / row_elbo / dy).
+        step=True: the whole SVI.step — the Adam update follows in the same library call (pv_ivae_step; on the fused
+        decoder path it rides in the last gradient launch), identical in effect to loss_and_grads() + adam_step()."""
         self.ensure_bound()
+        if step and (self.ext_enc or self.ext_dec or getattr(self, "ext_y", False) or not want_grads):
+            raise ValueError("step=True needs every parameter in the library (no user-defined modules) and want_grads")
         if self.ext_dec:
             return self._loss_and_grads_ext_decoder(x, eps, beta, y, want_grads, scalars_out, z_out, loc_out)
         b = x.shape[0]
@@ -389,8 +394,14 @@ class IVAEEngine:
         p.row_elbo = row_elbo.data_ptr() if row_elbo is not None else None
         p.dy = dy.data_ptr() if dy is not None else None
         try:
-            _abi.check(_abi.lib().pv_ivae_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),
-                       "pv_ivae_loss_and_grads")
+            if step:
+                p.lr, p.adam_beta1, p.adam_beta2, p.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
+                p.adam_step = self.adam_t + 1
+                _abi.check(_abi.lib().pv_ivae_step(C.byref(p), _abi.current_stream()), "pv_ivae_step")
+                self.adam_t += 1
+            else:
+                _abi.check(_abi.lib().pv_ivae_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),
+                           "pv_ivae_loss_and_grads")
         finally:
             p.scalars = self.scalars.data_ptr()
             p.ext_head = p.ext_dhead = None

@@ -23,6 +23,7 @@ from ._convplan import UnsupportedModel
 
 
 class SSEngine(IVAEEngine):
+    supports_step = False            # (pv_ivae_step covers the iVAE / jiVAE plan only)
     supports_scalars_out = False
 
     def _check_model(self):

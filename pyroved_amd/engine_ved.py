@@ -22,6 +22,7 @@ from .nets.conv import convEncoderNet, convDecoderNet
 
 class VEDEngine(IVAEEngine):
     """Binds a VED model (encoder_z: convEncoderNet, decoder: convDecoderNet) to the HIP library."""
+    supports_step = False            # (pv_ivae_step covers the iVAE / jiVAE plan only)
 
     # ------------------------------------------------------------------ structure
     def _check_model(self):

@@ -128,6 +128,11 @@ class SVItrainer:
             xs = x[lo:hi].to(dev, torch.float32)
             es = eps[lo:hi].to(dev, torch.float32)
             ys = None if y is None else y[lo:hi].to(dev, torch.float32)
+            one_call = (direct and train and getattr(eng, "supports_step", False)
+                        and not (getattr(eng, "ext_enc", False) or getattr(eng, "ext_dec", False)))
+            if one_call:                              # loss, gradients and Adam in one library call (pv_ivae_step)
+                eng.loss_and_grads(xs, es, beta, ys, scalars_out=self._hist[i], step=True)
+                return
             if direct:
                 eng.loss_and_grads(xs, es, beta, ys, want_grads=train, scalars_out=self._hist[i])
             else:

@@ -1307,6 +1307,43 @@ def test_manifold2d_matches_decode_and_plots(gpu_device):
     plt.close("all")
 
 
+@pytest.mark.parametrize("kind", ["ivae_f2", "ivae_f3", "ivae_f0", "jivae", "cvae", "convenc", "b5000"])
+def test_one_call_step_is_bit_identical(gpu_device, kind):
+    """loss_and_grads(step=True) (pv_ivae_step: on the fused path Adam rides in the last gradient launch, every element
+    updated by the workgroup that finalises its gradient + guest workgroups for the rest) against loss_and_grads() +
+    adam_step(): parameters, both Adam moments, the zeroed gradients and the loss scalars must be bit-identical over
+    several steps; paths that cannot fuse (layered decoder, conv encoder, long batches) fall back to the same pair."""
+    torch.manual_seed(3)
+    b = 5000 if kind == "b5000" else 37
+    def make():
+        if kind == "jivae":
+            m = pv.models.jiVAE((28, 28), 2, 3, ["r", "t"], seed=1, device="cuda")
+        elif kind == "cvae":
+            m = pv.models.iVAE((28, 28), 2, ["r", "t", "s"], c_dim=3, seed=1, device="cuda")
+        else:
+            m = pv.models.iVAE((28, 28) if kind != "convenc" else (16, 16), 2, ["r", "t"], seed=1, device="cuda")
+            if kind == "convenc":
+                m.set_encoder(pv.nets.convEncoderNet((16, 16), latent_dim=m.z_dim, hidden_dim=[(8,), (8, 8)]))
+        return m, m.engine(fused={"ivae_f3": 3, "ivae_f0": 0}.get(kind, 2))
+    (m1, e1), (m2, e2) = make(), make()
+    dd = m1.data_dim
+    x = torch.rand(b, *dd).cuda()
+    y = pv.utils.to_onehot(torch.randint(0, 3, (b,)), 3).cuda() if kind == "cvae" else None
+    for k in range(3):
+        eps = torch.randn(b, m1.z_dim).cuda()
+        e1.loss_and_grads(x, eps, 1.2, y)
+        s1 = e1.scalars.clone()
+        e1.adam_step()
+        hist = torch.zeros(4, device="cuda")
+        e2.loss_and_grads(x, eps, 1.2, y, scalars_out=hist, step=True)
+        assert torch.equal(s1, hist), (kind, k)
+        assert e1.adam_t == e2.adam_t == k + 1
+        for name, a, b_ in (("params", e1.flat, e2.flat), ("m", e1.m, e2.m), ("v", e1.v, e2.v),
+                            ("grad", e1.grad[:e1.n_flat], e2.grad[:e2.n_flat])):
+            assert torch.equal(a, b_), (kind, k, name, (a - b_).abs().max().item())
+    assert float(e2.grad[:e2.n_flat].abs().sum()) == 0.0
+
+
 def test_fails_loudly_on_cpu_tensors(gpu_device):
     model = pv.models.iVAE((8, 8), 2, ["r"], seed=1, device="cuda")
     eng = model.engine()
