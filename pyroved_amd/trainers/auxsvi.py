@@ -85,6 +85,11 @@ class auxSVItrainer:
 
     def compute_loss(self, xs: torch.Tensor, ys: Optional[torch.Tensor] = None, **kwargs: float) -> float:
         """Computes the basic (ELBO) and the auxiliary loss and takes the two optimizer steps (auxsvi.py:88-99)."""
+        return float(self._compute_loss(xs, ys, **kwargs).item())
+
+    def _compute_loss(self, xs: torch.Tensor, ys: Optional[torch.Tensor] = None, **kwargs: float) -> torch.Tensor:
+        """compute_loss without the device->host read: the loss stays a device scalar (train() reads an epoch's losses
+        back in one copy and adds them up in step order, as the reference's `epoch_loss += loss` does)."""
         eng, m = self.engine, self.model
         beta = kwargs.get("scale_factor", 1.)
         mult = kwargs.get("aux_loss_multiplier", 20)
@@ -124,7 +129,7 @@ class auxSVItrainer:
             loss = loss + self._reduced(aux)
         if eng.grads_live:                       # (no parameter has a .grad before the very first backward)
             eng.adam_step()
-        return float(loss.item())
+        return loss
 
     def train(self, loader_unsup, loader_sup, **kwargs: float) -> float:
         """Train a single epoch (auxsvi.py:101-127)."""
@@ -132,14 +137,17 @@ class auxSVItrainer:
         unsup_batches = len(loader_unsup)
         p = (sup_batches + unsup_batches) // sup_batches
         loader_sup = iter(loader_sup)
-        epoch_loss = 0.
+        losses = []
         unsup_count = 0
         for i, (xs,) in enumerate(loader_unsup):
-            epoch_loss += self.compute_loss(xs, **kwargs)
+            losses.append(self._compute_loss(xs, **kwargs).reshape(1))
             unsup_count += xs.shape[0]
             if i % p == 1:
                 xs, ys = next(loader_sup)
-                _ = self.compute_loss(xs, ys, **kwargs)
+                _ = self._compute_loss(xs, ys, **kwargs)
+        epoch_loss = 0.
+        for v in (torch.cat(losses).cpu().tolist() if losses else []):    # one read per epoch, same addition order
+            epoch_loss += v
         return epoch_loss / unsup_count
 
     def evaluate(self, loader_val) -> float:
