@@ -396,7 +396,7 @@ struct PvFinish { const float* llb; int B; float* scalars; const float* kl_part;
 // finalises every encoder gradient (compact encoder, <= 4 problems); *adam_done tells the caller whether it was
 int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, hipStream_t s,
                 const PvFinish* fin = nullptr, const PvAdamFuse* adam = nullptr, bool* adam_done = nullptr) {
-  const int64_t B = p->batch, z = p->z_dim;
+  const int64_t B = p->batch;
   float* G = p->grads;
   void* ws = L.scratch;
   const int64_t wsb = L.scratch_bytes;
