@@ -609,10 +609,10 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   if (!L.enc_compact)
     PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
                       L.scratch, L.scratch_bytes, s));
-  if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_start, s);
+  if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
   if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s));
   else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
-  if (p->ev_start && p->ev_stop) hipEventRecord((hipEvent_t)p->ev_stop, s);
+  if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_stop, s);
   if (!want_grads && K > 0) {                        // llb[b] = sum_k alpha_bk ll_kb
     PvLatentBwd lf{};
     lf.llrow = L.llrow; lf.llb = L.llb; lf.M = R; lf.N = (int)N; lf.H = 0; lf.K = (int)K; lf.alpha = L.alpha;
