@@ -361,10 +361,10 @@ int decoder_hidden_fwd(const pv_ivae_plan* p, const Layout& L, const float* zin,
     if (i > 0 || p->coord_dim > 0) { if (l.in_dim != ldin) return PV_EINVAL; }
     // instrumentation: the last hidden layer's forward GEMM is the layered path's representative kernel
     const bool timed = (i == p->n_dec - 1) && p->ev_start && p->ev_stop;
-    if (timed) hipEventRecord((hipEvent_t)p->ev_start, s);
+    if (timed) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
     PV_TRY(linear_fwd(in, ldin, p->params + l.w_off, l.b_off >= 0 ? p->params + l.b_off : nullptr, L.dact[i],
                       L.dpre_[i], l.out_dim, R, l.in_dim, l.out_dim, l.act, L.scratch, L.scratch_bytes, s));
-    if (timed) hipEventRecord((hipEvent_t)p->ev_stop, s);
+    if (timed) (void)hipEventRecord((hipEvent_t)p->ev_stop, s);
     in = L.dact[i]; ldin = l.out_dim;
   }
   if (p->out.in_dim != ldin) return PV_EINVAL;
