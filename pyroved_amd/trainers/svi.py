@@ -264,13 +264,25 @@ class SVItrainer:
         sizes = [len(b) for b in batches]
         idx_dev = torch.cat(batches).to(dev)
         eps_dev = eps.to(dev, torch.float32)
-        off = 0
-        for n, bsz in enumerate(sizes):
-            idx = idx_dev[off:off + bsz]
-            x = data[0].index_select(0, idx)
-            y = data[1].index_select(0, idx) if len(data) > 1 else None
-            self._svi_step(n, x, y, train, eps=eps_dev[off:off + bsz], **kwargs)
-            off += bsz
+        # minibatches are gathered a chunk of steps at a time (one index_select per ~256 MB of samples instead of one
+        # small gather kernel in front of every step); a step then takes a contiguous view
+        per_sample = sum(t[0].numel() for t in data) * 4
+        chunk = max(1, int((256 << 20) // max(per_sample * max(sizes), 1)))
+        off, n = 0, 0
+        while n < len(sizes):
+            m = min(chunk, len(sizes) - n)
+            rows = sum(sizes[n:n + m])
+            idx = idx_dev[off:off + rows]
+            xs = data[0].index_select(0, idx)
+            ys = data[1].index_select(0, idx) if len(data) > 1 else None
+            r0 = 0
+            for k in range(m):
+                bsz = sizes[n + k]
+                self._svi_step(n + k, xs[r0:r0 + bsz], None if ys is None else ys[r0:r0 + bsz], train,
+                               eps=eps_dev[off + r0:off + r0 + bsz], **kwargs)
+                r0 += bsz
+            off += rows
+            n += m
         return len(sizes)
 
     def _epoch(self, loader, train: bool, **kwargs) -> float:
