@@ -70,6 +70,8 @@ class auxSVItrainer:
         self.history = {"training_loss": [], "test": []}
         self.current_epoch = 0
         self.running_weights = {}
+        self.device_feed = bool(kwargs.get("device_feed", True))    # TensorDataset loaders are served from device copies
+        self._feed_cache = {}
         if pvdist.world(self.group)[1] > 1:      # replicas start from rank 0's parameters
             pvdist.broadcast_(self.engine.flat, 0, self.group)
 
@@ -131,19 +133,44 @@ class auxSVItrainer:
             eng.adam_step()
         return loss
 
+    def _index_feed(self, loader):
+        """(index loader, device tensors) for a plain TensorDataset DataLoader, else None (the loader is iterated as is)."""
+        from torch.utils.data import DataLoader, TensorDataset
+        ds = getattr(loader, "dataset", None)
+        dev = getattr(self.engine, "device", None)
+        if (not self.device_feed or dev is None or torch.device(dev).type != "cuda" or not isinstance(loader, DataLoader)
+                or not isinstance(ds, TensorDataset) or loader.num_workers != 0 or loader.batch_sampler is None):
+            return None
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ds.tensors)
+        hit = self._feed_cache.get(id(loader))
+        if hit is None or hit[0] != key:
+            hit = (key, [t.to(dev, torch.float32) for t in ds.tensors])
+            self._feed_cache[id(loader)] = hit
+        return DataLoader(range(len(ds)), batch_sampler=loader.batch_sampler), hit[1]
+
     def train(self, loader_unsup, loader_sup, **kwargs: float) -> float:
         """Train a single epoch (auxsvi.py:101-127)."""
         sup_batches = len(loader_sup)
         unsup_batches = len(loader_unsup)
         p = (sup_batches + unsup_batches) // sup_batches
-        loader_sup = iter(loader_sup)
+        # device-resident data: the loaders are iterated over sample INDICES with their own batch samplers (same
+        # iterator creation order and laziness, so the global CPU generator is consumed exactly as by the loaders
+        # themselves) and the minibatches are gathered on the device instead of being collated and copied per step
+        feed_u, feed_s = self._index_feed(loader_unsup), self._index_feed(loader_sup)
+        it_sup = iter(feed_s[0] if feed_s else loader_sup)
         losses = []
         unsup_count = 0
-        for i, (xs,) in enumerate(loader_unsup):
+        for i, item in enumerate(feed_u[0] if feed_u else loader_unsup):
+            xs = feed_u[1][0].index_select(0, item.to(feed_u[1][0].device)) if feed_u else item[0]
             losses.append(self._compute_loss(xs, **kwargs).reshape(1))
             unsup_count += xs.shape[0]
             if i % p == 1:
-                xs, ys = next(loader_sup)
+                item = next(it_sup)
+                if feed_s:
+                    idx = item.to(feed_s[1][0].device)
+                    xs, ys = feed_s[1][0].index_select(0, idx), feed_s[1][1].index_select(0, idx)
+                else:
+                    xs, ys = item
                 _ = self._compute_loss(xs, ys, **kwargs)
         epoch_loss = 0.
         for v in (torch.cat(losses).cpu().tolist() if losses else []):    # one read per epoch, same addition order
