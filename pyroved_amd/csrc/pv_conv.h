@@ -20,6 +20,11 @@ bool pv_conv3_wgrad_direct_supported(int C, int Cout, int nd);
 int64_t pv_conv3_wgrad_direct_ws(int B, int H, int W, int C, int Cout, int nd);
 int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db, int Cout,
                           void* ws, int64_t ws_bytes, hipStream_t s);
+// one input channel (first encoder layer): a streaming reduction instead of a GEMM (pv_conv_direct.hip)
+bool pv_conv3_wgrad_c1_supported(int C, int Cout, int nd);
+int64_t pv_conv3_wgrad_c1_ws(int B, int H, int W, int C, int Cout, int nd);
+int pv_conv3_wgrad_c1(const float* dy, const float* in, int B, int H, int W, int nd, float* dw, float* db, int Cout, void* ws,
+                      int64_t ws_bytes, hipStream_t s);
 // eg_y / eg_act: optionally out *= act'(eg_y) (eg_y shaped like out): the producing layer's activation backward fused
 // into the input-gradient form
 int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db,

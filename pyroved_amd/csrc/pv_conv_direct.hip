@@ -368,6 +368,98 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a kernel-3 convolution with ONE input channel (the first layer of every conv encoder:
+// dW[co][tap] = sum_pixels dpre[pixel][co] * x[pixel + tap], db[co] = sum_pixels dpre[pixel][co]).  It is a pure
+// reduction over B*H*W pixels with a handful of outputs: HBM-bound by the one read of dpre (4*Cout bytes per pixel),
+// nothing for the matrix cores.  A workgroup takes a range of image lines; its threads are (channel, line group):
+// the dpre row of a pixel is one coalesced load across the channel lanes, the 3x3 input window slides along the line
+// in registers.  Per-workgroup partials go through the same fixed-order finish kernel as the direct wgrad.
+#define C1_MAXCO 64
+__global__ __launch_bounds__(256) void pv_conv3_wgrad_c1_kernel(const float* __restrict__ dy, const float* __restrict__ in,
+                                                                int B, int H, int W, int Cout, int nd, int CP, int nsplit,
+                                                                float* __restrict__ part, float* __restrict__ part_b) {
+  __shared__ float sm[256][10];
+  const int tid = threadIdx.x, co = tid % CP, rg = tid / CP, RG = 256 / CP;
+  const int KK = nd == 2 ? 9 : 3;
+  // 1-D data (H = length, W = 1) is one line per sample, taps along the line
+  const int LW = nd == 2 ? W : H, LH = nd == 2 ? H : 1;
+  const int64_t lines = (int64_t)B * LH;
+  const int64_t l_lo = lines * blockIdx.x / nsplit, l_hi = lines * (blockIdx.x + 1) / nsplit;
+  float acc[9], accb = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
+  const bool cok = co < Cout;
+  for (int64_t l = l_lo + rg; l < l_hi; l += RG) {
+    const int y = (int)(l % LH);
+    const float* row1 = in + l * LW;                                   // the pixel's own line
+    const bool up = nd == 2 && y > 0, dn = nd == 2 && y + 1 < LH;
+    const float* row0 = row1 - LW;
+    const float* row2 = row1 + LW;
+    const float* dyl = dy + l * LW * (int64_t)Cout + co;
+    // window columns x-1, x, x+1 of the three lines
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    a1 = up ? row0[0] : 0.0f; b1 = row1[0]; c1 = dn ? row2[0] : 0.0f;
+    for (int x = 0; x < LW; ++x) {
+      const bool nx = x + 1 < LW;
+      a2 = (up && nx) ? row0[x + 1] : 0.0f;
+      b2 = nx ? row1[x + 1] : 0.0f;
+      c2 = (dn && nx) ? row2[x + 1] : 0.0f;
+      const float dp = cok ? dyl[(int64_t)x * Cout] : 0.0f;
+      accb += dp;
+      if (nd == 2) {
+        acc[0] += dp * a0; acc[1] += dp * a1; acc[2] += dp * a2;
+        acc[3] += dp * b0; acc[4] += dp * b1; acc[5] += dp * b2;
+        acc[6] += dp * c0; acc[7] += dp * c1; acc[8] += dp * c2;
+      } else {
+        acc[0] += dp * b0; acc[1] += dp * b1; acc[2] += dp * b2;
+      }
+      a0 = a1; a1 = a2; b0 = b1; b1 = b2; c0 = c1; c1 = c2;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) sm[tid][t] = acc[t];
+  sm[tid][9] = accb;
+  __syncthreads();
+  // (channel, tap) outputs: sum the line groups in group order
+  for (int o = tid; o < Cout * (KK + 1); o += 256) {
+    const int c = o / (KK + 1), t = o % (KK + 1);
+    float v = 0.0f;
+    for (int g = 0; g < RG; ++g) v += sm[g * CP + c][t == KK ? 9 : t];
+    if (t == KK) { if (part_b) part_b[(int64_t)blockIdx.x * Cout + c] = v; }
+    else part[(int64_t)blockIdx.x * Cout * KK + c * KK + t] = v;
+  }
+}
+
+static int c1_splits(int B, int H, int W, int nd) {
+  const int64_t lines = (int64_t)B * (nd == 2 ? H : 1);
+  int64_t ns = 1024;
+  if (ns > lines) ns = lines;
+  return (int)(ns < 1 ? 1 : ns);
+}
+bool pv_conv3_wgrad_c1_supported(int C, int Cout, int nd) { return C == 1 && Cout >= 1 && Cout <= C1_MAXCO && (nd == 1 || nd == 2); }
+int64_t pv_conv3_wgrad_c1_ws(int B, int H, int W, int C, int Cout, int nd) {
+  if (!pv_conv3_wgrad_c1_supported(C, Cout, nd)) return 0;
+  return (int64_t)c1_splits(B, H, W, nd) * ((int64_t)Cout * (nd == 2 ? 9 : 3) + Cout) * (int64_t)sizeof(float) + 256;
+}
+int pv_conv3_wgrad_c1(const float* dy, const float* in, int B, int H, int W, int nd, float* dw, float* db, int Cout, void* ws,
+                      int64_t ws_bytes, hipStream_t s) {
+  if (!pv_conv3_wgrad_c1_supported(1, Cout, nd)) return PV_EINVAL;
+  if (ws_bytes < pv_conv3_wgrad_c1_ws(B, H, W, 1, Cout, nd)) return PV_EWS;
+  const int KK = nd == 2 ? 9 : 3, ns = c1_splits(B, H, W, nd);
+  int CP = 1;
+  while (CP < Cout) CP *= 2;
+  float* part = reinterpret_cast<float*>(ws);
+  float* part_b = db ? part + (int64_t)ns * Cout * KK : nullptr;
+  hipLaunchKernelGGL(pv_conv3_wgrad_c1_kernel, dim3(ns), dim3(256), 0, s, dy, in, B, H, W, Cout, nd, CP, ns, part, part_b);
+  PV_LAUNCH_CHECK();
+  const int64_t nw = (int64_t)Cout * KK;
+  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, part, ns, nw, dw, part_b, Cout, db);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same direct convolution on the bf16 matrix cores in split precision (x = hi + lo, three products, fp32
 // accumulate) for layers with a multiple of 32 input channels — the mixed-precision mode (plan->conv_bf16): ~2^-16 per
 // product is not enough for the 1e-4 gradient bar where a gradient is a sum with heavy cancellation (the first
