@@ -546,6 +546,30 @@ def test_ved_bf16_mode_vs_oracle(gpu_device):
     print("worst gradient rel l2 in the bf16 conv mode: %.2e" % worst)
 
 
+@pytest.mark.parametrize("in_dim, c0, b", [((12, 20), 3, 3), ((7, 9), 5, 1), ((16, 16), 64, 2), ((24,), 6, 5), ((40,), 32, 2),
+                                           ((64, 64), 32, 9)])
+def test_first_layer_wgrad_kernel_vs_oracle(gpu_device, in_dim, c0, b):
+    """pv_conv3_wgrad_c1_kernel (the streaming weight gradient of a one-input-channel convolution) over odd image
+    sizes, channel counts that are not powers of two, the 64-channel limit, 1-D data, fewer image lines than
+    workgroups and the full 64x64 size: the first encoder layer's weight and bias gradients (and everything else)
+    against the oracle.  Tolerance 1e-4 (fp32)."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    he, hd = [(c0,), (8, 8)], [(8, 8), (4,)]
+    out_dim = (16,)
+    torch.manual_seed(4)
+    model = pv.models.VED(in_dim, out_dim, hidden_dim_e=he, hidden_dim_d=hd, activation="tanh", seed=2, device="cuda")
+    cfg = orc.VedConfig(input_dim=in_dim, output_dim=out_dim, latent_dim=2, hidden_dim_e=he, hidden_dim_d=hd, activation="tanh")
+    eng = model.engine()
+    o = orc.VedOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x, y, eps = torch.rand(b, 1, *in_dim), torch.rand(b, 1, *out_dim), torch.randn(b, 2)
+    eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+    ref = o.step(x, y, eps, 1.0)
+    np.testing.assert_allclose(eng.scalars[0].item(), ref, rtol=2e-5)
+    for key in o.p:
+        assert rel_l2(eng.grad_of(key), o.last_grads[key]) < 1e-4, key
+
+
 VEDBN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "vedbn_*.npz")))
 
 
