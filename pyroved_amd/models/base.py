@@ -37,30 +37,21 @@ class baseVAE(nn.Module):
             "device", 'cuda' if torch.cuda.is_available() else 'cpu')
         self.data_dim = tuple(int(d) for d in data_dim)
         self.ndim = len(data_dim)
-        # number and type of invariances (pyroved/models/base.py:56-67)
-        if invariances is None:
-            coord = 0
-        else:
-            coord = len(invariances)
-            if self.ndim == 1:
-                if coord > 1 or invariances[0] != 't':
-                    raise ValueError(
-                        "For 1D data, the only invariance to enforce "
-                        "is translation ('t')")
-            if 't' in invariances and self.ndim == 2:
-                coord = coord + 1
-        self.coord = coord
+        # latent coordinates spent on the enforced invariances (pyroved/models/base.py:56-67): one per symmetry, two
+        # for a 2-D translation; 1-D data only knows 't'
+        inv = list(invariances) if invariances is not None else []
+        if self.ndim == 1 and inv and inv != ['t']:
+            raise ValueError("For 1D data, the only invariance to enforce is translation ('t')")
+        self.coord = len(inv) + (1 if ('t' in inv and self.ndim == 2) else 0)
         self.invariances = invariances
         if self.coord > 0:
             self.grid = generate_grid(data_dim).to(self.device)
-        # prior "belief" about the degree of translational disorder (base.py:73-77)
-        if self.coord > 0 and 't' in self.invariances:
+        # prior widths of the translational / scale disorder (base.py:73-80), defaults 0.1
+        if 't' in inv:
             dx_pri = tt(kwargs.get("dx_prior", 0.1))
             dy_pri = kwargs.get("dy_prior", dx_pri.clone())
-            self.t_prior = (tt([dx_pri, dy_pri]) if self.ndim == 2
-                            else dx_pri).to(self.device)
-        # prior "belief" about the degree of scale disorder (base.py:79-80)
-        if self.coord > 0 and 's' in self.invariances:
+            self.t_prior = (tt([dx_pri, dy_pri]) if self.ndim == 2 else dx_pri).to(self.device)
+        if 's' in inv:
             self.sc_prior = tt(kwargs.get("sc_prior", 0.1)).to(self.device)
         self.encoder_z = None
         self.decoder = None
@@ -79,22 +70,17 @@ class baseVAE(nn.Module):
         and image content: always [phi | dx, dy | scale | content] (base.py:97-119).
         Pure slicing of the caller's tensor (any device)."""
         if self.ndim == 1:
-            dx = z[:, 0:1]
-            z = z[:, 1:]
-            return None, dx, None, z
-        phi = tt(0).to(z.device)
-        dx = tt(0).to(z.device)
-        sc = tt(1).to(z.device)
-        if 'r' in self.invariances:
-            phi = z[:, 0]
-            z = z[:, 1:]
-        if 't' in self.invariances:
-            dx = z[:, :2]
-            z = z[:, 2:]
-        if 's' in self.invariances:
-            sc = sc + self.sc_prior.to(z.device) * z[:, 0]
-            z = z[:, 1:]
-        return phi, dx, sc, z
+            return None, z[:, 0:1], None, z[:, 1:]
+        inv = self.invariances or []
+        dev, k = z.device, 0
+        phi, dx, sc = tt(0).to(dev), tt(0).to(dev), tt(1).to(dev)      # the "no transform" scalars of base.py:104-106
+        if 'r' in inv:
+            phi, k = z[:, k], k + 1
+        if 't' in inv:
+            dx, k = z[:, k:k + 2], k + 2
+        if 's' in inv:
+            sc, k = sc + self.sc_prior.to(dev) * z[:, k], k + 1
+        return phi, dx, sc, z[:, k:]
 
     # ------------------------------------------------------------------ HIP engine
     def _engine_ready(self) -> bool:

@@ -1,5 +1,5 @@
-"""Training loops with stochastic variational inference on the HIP path."""
-from .svi import SVItrainer
-from .auxsvi import auxSVItrainer
+"""Training loops with stochastic variational inference on the HIP path (same names as pyroved.trainers)."""
+from . import auxsvi as _aux, svi as _svi
 
-__all__ = ['SVItrainer', 'auxSVItrainer']
+SVItrainer, auxSVItrainer = _svi.SVItrainer, _aux.auxSVItrainer
+__all__ = ("SVItrainer", "auxSVItrainer")
