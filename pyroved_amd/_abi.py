@@ -5,7 +5,9 @@ The library is the product's only compute path.  There is no CPU or pure-PyTorch
 fallback: `lib()` raises if the shared object is missing or does not export every
 symbol of the header, and every wrapper raises on a non-zero return code.
 """
+import contextlib
 import ctypes as C
+import functools
 import os
 import threading
 
@@ -195,4 +197,28 @@ def require_device(t, what):
 
 
 def current_stream():
+    """The current HIP stream of the CURRENT device: library calls are made under `on_device` / `device_of`, which make
+    the tensors' device current first (kernels launched on device A's stream against device B's pointers fault)."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_of(dev):
+    """Context manager: `dev` (torch.device / tensor device) is the current HIP device inside; free when it already is."""
+    dev = torch.device(dev) if not isinstance(dev, torch.device) else dev
+    if dev.type != "cuda" or dev.index is None or torch.cuda.current_device() == dev.index:
+        return contextlib.nullcontext()
+    return torch.cuda.device(dev)
+
+
+def on_device(method):
+    """Decorator for engine methods that enqueue library work: runs them with `self.device` current, so a model built
+    with device='cuda:1' works whatever the caller's current device is (the reference accepts any device string,
+    models/base.py:51-52)."""
+    @functools.wraps(method)
+    def call(self, *args, **kwargs):
+        dev = getattr(self, "device", None)
+        if dev is None:
+            return method(self, *args, **kwargs)
+        with device_of(dev):
+            return method(self, *args, **kwargs)
+    return call

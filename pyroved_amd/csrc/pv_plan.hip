@@ -886,7 +886,10 @@ extern "C" int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, 
 extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
   if (plan && !plan->ext_decoder && valid_plan(plan) && plan->params && plan->x && plan->eps && plan->scalars && plan->ws &&
       plan->grads && plan->adam_m && plan->adam_v && plan->adam_step >= 1 && plan->n_params > 0 &&
-      !(plan->coord_dim > 0 && !plan->grid) && !plan->ext_encoder) {
+      !(plan->coord_dim > 0 && !plan->grid) && !plan->ext_encoder &&
+      // extra outputs (dy, row_elbo) are computed AFTER the encoder backward from the first-layer weights: with Adam
+      // riding in that launch they would see the updated weights — such plans take the two-call sequence below
+      !plan->dy && !plan->row_elbo) {
     Layout L;
     carve(plan, (char*)plan->ws, L);
     if (plan->ws_bytes < L.total) return PV_EWS;

@@ -40,3 +40,21 @@ def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> None:
     """Makes every replica start from rank `src`'s parameters."""
     if td.is_available() and td.is_initialized() and td.get_world_size(group) > 1:
         td.broadcast(flat, src=src, group=group)
+
+
+def sync_replicas(engine, group=None, src: int = 0) -> None:
+    """Start of a data-parallel run: every replica takes rank `src`'s parameters — the flat buffer (which also holds
+    batch-norm running statistics) AND the parameters of user-defined modules that live outside it
+    (set_encoder / set_decoder / set_classifier: engine._enc_params).
+
+    Batch normalisation: per-shard batch statistics are NOT the global batch's, so a sharded step would differ from the
+    single-process step the parity bar is defined on, and the running estimates would drift apart between replicas.
+    Rejected rather than silently different (the reference has no distributed mode to mirror)."""
+    if not (td.is_available() and td.is_initialized() and td.get_world_size(group) > 1):
+        return
+    if getattr(engine, "_bn_enc", None) or getattr(engine, "_bn_dec", None):
+        raise NotImplementedError("batchnorm=True models are not trained data-parallel: per-shard batch statistics "
+                                  "differ from the global batch's (train them on one GPU, or build with batchnorm=False)")
+    broadcast_(engine.flat, src, group)
+    for q in getattr(engine, "_enc_params", None) or []:
+        td.broadcast(q.data, src=src, group=group)

@@ -205,6 +205,36 @@ class IVAEEngine:
                 self._enc_opt = torch.optim.Adam(self._enc_params, lr=self.lr, betas=self.betas, eps=self.adam_eps)
         self._static = self._static_plan()
 
+    def configure(self, lr=None, betas=None, eps=None, fused=None):
+        """Applies trainer-level settings to an engine that already exists (model.engine(**kw) on a model whose engine
+        was created earlier — by encode(), manifold2d(), a previous trainer — must not silently drop them)."""
+        if lr is not None:
+            self.lr = float(lr)
+        if betas is not None:
+            self.betas = (float(betas[0]), float(betas[1]))
+        if eps is not None:
+            self.adam_eps = float(eps)
+        if fused is not None and int(fused) != self.fused:
+            self.fused = int(fused)
+            self.ws = None
+        if self.flat is not None:
+            self._static = self._static_plan()
+        return self
+
+    def reset_optimizer(self):
+        """A fresh optimizer, as every trainer constructor of the reference makes one (trainers/svi.py:75-81:
+        pyro.clear_param_store() + a new optim.Adam): zero moments, step count 0, no live gradients."""
+        self.adam_t = 0
+        self.grads_live = False
+        if self.m is not None:
+            self.m.zero_()
+            self.v.zero_()
+            self.grad.zero_()
+        if self._enc_opt is not None:
+            self._enc_opt = torch.optim.Adam(self._enc_params, lr=self.lr, betas=self.betas, eps=self.adam_eps)
+            for q in self._enc_params:
+                q.grad = None
+
     def _bound(self) -> bool:
         named = dict(self.model.named_parameters())
         if self.ext_enc:
@@ -344,6 +374,7 @@ class IVAEEngine:
         return t
 
     # ------------------------------------------------------------------ calls
+    @_abi.on_device
     def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
                        scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None,
                        row_w: Optional[torch.Tensor] = None, row_elbo: Optional[torch.Tensor] = None,
@@ -517,6 +548,7 @@ class IVAEEngine:
             for b_ in mods:
                 b_.num_batches_tracked += 1
 
+    @_abi.on_device
     def adam_step(self):
         """pyro.optim.Adam over every parameter + zero_grads (one fused kernel)."""
         self.adam_t += 1
@@ -538,6 +570,7 @@ class IVAEEngine:
         ext = self.ext_enc or self.ext_dec or getattr(self, "ext_y", False)
         return [q.grad for q in self._enc_params if q.grad is not None] if ext else []
 
+    @_abi.on_device
     def encode(self, x, y=None):
         self.ensure_bound()
         if self.ext_enc:
@@ -565,6 +598,7 @@ class IVAEEngine:
             return z_loc, z_scale, alpha
         return z_loc, z_scale
 
+    @_abi.on_device
     def decode(self, z, angle: float = 0.0, shift=(0.0, 0.0), scale: float = 1.0):
         """z: (B, latent_dim + c_dim) content latents [+ class vector]."""
         self.ensure_bound()
@@ -582,6 +616,7 @@ class IVAEEngine:
         self._keep = (z,)
         return loc.view(b, *self.model.data_dim)
 
+    @_abi.on_device
     def uses_fused(self, batch: int) -> bool:
         """Whether loss_and_grads runs the fused persistent decoder kernel for this batch size."""
         return bool(_abi.lib().pv_ivae_uses_fused(C.byref(self._plan(batch))))

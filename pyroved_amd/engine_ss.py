@@ -76,6 +76,7 @@ class SSEngine(IVAEEngine):
         return q
 
     # ------------------------------------------------------------------ label network
+    @_abi.on_device
     def label_forward(self, x: torch.Tensor) -> torch.Tensor:
         """encoder_y(x): class probabilities (B, K) or regression means (B, c)."""
         x = self._prep(x, "x", (x.shape[0], self._in_dim))
@@ -90,6 +91,7 @@ class SSEngine(IVAEEngine):
         self._keep_y = (x, out)
         return out
 
+    @_abi.on_device
     def label_backward(self, x: torch.Tensor, out: torch.Tensor, dout: torch.Tensor) -> None:
         """Gradients of encoder_y's parameters from dloss/d(out), after label_forward(x)."""
         if self.ext_y:
@@ -109,6 +111,7 @@ class SSEngine(IVAEEngine):
         self._keep_y = (x, out, dout)
 
     # ------------------------------------------------------------------ the two SVI steps of auxSVItrainer.compute_loss
+    @_abi.on_device
     def elbo_loss_and_grads(self, x, eps, ys=None, eps_y=None, beta: float = 1.0) -> torch.Tensor:
         """The ELBO step (SVI(model.model, guide): auxsvi.py:73-81).  Returns the loss as a 0-dim device tensor;
         gradients land in self.grad."""
@@ -156,6 +159,7 @@ class SSEngine(IVAEEngine):
         self._keep_ss = (cm, eps_y, ysamp, dy, dc)
         return self.scalars[0] + add[0]
 
+    @_abi.on_device
     def aux_loss_and_grads(self, x, ys, multiplier: float = 20.0) -> torch.Tensor:
         """The auxiliary (supervised) step (SVI(model.model_aux, guide_aux): auxsvi.py:82-84) for a labeled batch."""
         b = x.shape[0]

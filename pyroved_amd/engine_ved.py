@@ -107,6 +107,7 @@ class VEDEngine(IVAEEngine):
         return (b, d.output_channels) + tuple(d.output_dim)
 
     # ------------------------------------------------------------------ calls
+    @_abi.on_device
     def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
                        scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None):
         """Enqueues Trace_ELBO.loss_and_grads(VED.model, VED.guide) on the current stream: x (B, C, *input_dim),
@@ -136,6 +137,7 @@ class VEDEngine(IVAEEngine):
         self._count_bn(self._bn_enc + self._bn_dec)
         self._keep = (x, y, eps)
 
+    @_abi.on_device
     def encode(self, x, y=None):
         self.ensure_bound()
         b = x.shape[0]
@@ -150,6 +152,7 @@ class VEDEngine(IVAEEngine):
         self._keep = (x,)
         return z_loc, z_scale
 
+    @_abi.on_device
     def decode(self, z, *unused, **unused_kw):
         self.ensure_bound()
         b = z.shape[0]

@@ -92,6 +92,8 @@ class baseVAE(nn.Module):
         from ..engine import IVAEEngine
         if self._engine is None:
             self._engine = IVAEEngine(self, **kw)
+        elif kw:
+            self._engine.configure(**kw)      # an engine made earlier (encode, a previous trainer) takes the new settings
         return self._engine
 
     def _encode(self, *input_args, device: str = None, **kwargs: int) -> torch.Tensor:

@@ -42,6 +42,8 @@ class _ssBase(baseVAE):
         from ..engine_ss import SSEngine
         if self._engine is None:
             self._engine = SSEngine(self, **kw)
+        elif kw:
+            self._engine.configure(**kw)      # an engine made earlier (encode, a previous trainer) takes the new settings
         return self._engine
 
     def model(self, xs, ys=None, **kwargs):

@@ -26,7 +26,7 @@ class VED(baseVAE):
         hidden_dim_e: encoder conv filters per block (default [(32,), (64, 64), (128, 128)])
         hidden_dim_d: decoder conv filters per block (default [(128, 128), (64, 64), (32,)])
         activation: 'lrelu' (default), 'tanh', 'softplus', 'relu'
-        batchnorm: not implemented in the HIP path (must be False)
+        batchnorm: batch normalisation after every conv activation (default False; op PV_OP_BATCHNORM of the HIP conv stack)
         sampler_d: 'bernoulli' (default) or 'gaussian'
         sigmoid_d: sigmoid at the decoder output (default True)
         seed: seed used in torch.manual_seed(seed)
@@ -65,6 +65,8 @@ class VED(baseVAE):
         if self._engine is None:
             self._engine = VEDEngine(self, **kw)
             self.encoder_z._pv_engine = self.decoder._pv_engine = self._engine
+        elif kw:
+            self._engine.configure(**kw)      # an engine made earlier (encode, a previous trainer) takes the new settings
         return self._engine
 
     def model(self, x: torch.Tensor = None, y: torch.Tensor = None, **kwargs: float) -> None:

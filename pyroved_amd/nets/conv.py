@@ -9,7 +9,7 @@ library (no CPU path).
 
 Scope of this build: 1-D and 2-D data, kernel 3 / stride 1 / padding 1 convolutions, 2x max-pooling,
 2x upsampling (nearest — the reference's own fallback for 1-D decoders, nets/conv.py:126-130 — or bilinear in 2-D),
-no batch normalisation (raises at engine binding).
+optional batch normalisation after every activation (the reference's order conv -> activation -> BN).
 """
 from typing import List, Tuple, Union
 from warnings import warn

@@ -45,9 +45,10 @@ class _LinearAct(torch.autograd.Function):
         y = torch.empty(m, n, device=x2.device, dtype=torch.float32)
         pre = torch.empty_like(y) if act == "gelu" else None
         ws = _ws(m, k, n, x2.device)
-        _abi.check(L.pv_linear_fwd(_abi.ptr(x2), k, _abi.ptr(weight), _abi.ptr(bias), _abi.ptr(y), _abi.ptr(pre), n,
-                                   m, k, n, _abi.ACT[act], _abi.ptr(ws), ws.numel(), _abi.current_stream()),
-                   "pv_linear_fwd")
+        with _abi.device_of(x2.device):
+            _abi.check(L.pv_linear_fwd(_abi.ptr(x2), k, _abi.ptr(weight), _abi.ptr(bias), _abi.ptr(y), _abi.ptr(pre), n,
+                                       m, k, n, _abi.ACT[act], _abi.ptr(ws), ws.numel(), _abi.current_stream()),
+                       "pv_linear_fwd")
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x2, weight, y, pre)
@@ -65,9 +66,10 @@ class _LinearAct(torch.autograd.Function):
         dw = torch.empty_like(weight) if need_w else None
         db = torch.empty(n, device=dy.device, dtype=torch.float32) if need_b else None
         ws = _ws(m, k, n, dy.device)
-        _abi.check(_abi.lib().pv_linear_bwd(_abi.ptr(dpre), n, _abi.ptr(x2), k, _abi.ptr(weight), _abi.ptr(dx), k,
-                                            None, None, 0, 0, _abi.ptr(dw), _abi.ptr(db), m, k, n,
-                                            _abi.ptr(ws), ws.numel(), _abi.current_stream()), "pv_linear_bwd")
+        with _abi.device_of(dy.device):
+            _abi.check(_abi.lib().pv_linear_bwd(_abi.ptr(dpre), n, _abi.ptr(x2), k, _abi.ptr(weight), _abi.ptr(dx), k,
+                                                None, None, 0, 0, _abi.ptr(dw), _abi.ptr(db), m, k, n,
+                                                _abi.ptr(ws), ws.numel(), _abi.current_stream()), "pv_linear_bwd")
         return dx, dw, db, None
 
 

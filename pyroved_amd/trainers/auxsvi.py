@@ -67,13 +67,15 @@ class auxSVItrainer:
         if self.engine.task != task:
             raise ValueError("task=%r does not match the model's label network (%s)" % (task, self.engine.task))
         self.engine.lr, self.engine.betas, self.engine.adam_eps = float(adam["lr"]), tuple(adam["betas"]), float(adam["eps"])
+        if hasattr(self.engine, "reset_optimizer"):
+            self.engine.reset_optimizer()          # every trainer starts a fresh Adam (auxsvi.py: a new optim.Adam)
         self.history = {"training_loss": [], "test": []}
         self.current_epoch = 0
         self.running_weights = {}
         self.device_feed = bool(kwargs.get("device_feed", True))    # TensorDataset loaders are served from device copies
         self._feed_cache = {}
-        if pvdist.world(self.group)[1] > 1:      # replicas start from rank 0's parameters
-            pvdist.broadcast_(self.engine.flat, 0, self.group)
+        if pvdist.world(self.group)[1] > 1:
+            pvdist.sync_replicas(self.engine, self.group)
 
     def _reduced(self, loss):
         """Data parallel: ONE all-reduce(SUM) of [flat gradient | loss] (the loss rides in the first of the gradient

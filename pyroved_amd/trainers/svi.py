@@ -90,12 +90,14 @@ class SVItrainer:
             self.engine = model.engine(lr=adam["lr"], betas=adam["betas"], eps=adam["eps"],
                                        fused=int(kwargs.get("fused", 3 if precision == "bf16" else 2)))
         self.engine.lr, self.engine.betas, self.engine.adam_eps = float(adam["lr"]), tuple(adam["betas"]), float(adam["eps"])
+        if hasattr(self.engine, "reset_optimizer"):
+            self.engine.reset_optimizer()          # every trainer starts a fresh Adam (svi.py:75-81)
         self.loss_history = {"training_loss": [], "test_loss": []}
         self.current_epoch = 0
         self._hist = None
         rank, world = pvdist.world(self.group)
-        if world > 1:      # replicas start from rank 0's parameters
-            pvdist.broadcast_(self.engine.flat, 0, self.group)
+        if world > 1:
+            pvdist.sync_replicas(self.engine, self.group)
 
     # ------------------------------------------------------------------ one minibatch
     def _draw_eps(self, b: int) -> torch.Tensor:

@@ -58,9 +58,10 @@ def transform_coordinates(coord: torch.Tensor,
     sc_t = _per_sample(scale, b, n, 1, dev) if cd == 2 else None
     dx_t = _per_sample(coord_dx, b, n, cd, dev)
     out = torch.empty(b, n, cd, device=dev, dtype=torch.float32)
-    _abi.check(_abi.lib().pv_transform_coordinates(
-        _abi.ptr(base), n, cd, _abi.ptr(phi_t), _abi.ptr(dx_t), _abi.ptr(sc_t), b, _abi.ptr(out),
-        _abi.current_stream()), "pv_transform_coordinates")
+    with _abi.device_of(dev):
+        _abi.check(_abi.lib().pv_transform_coordinates(
+            _abi.ptr(base), n, cd, _abi.ptr(phi_t), _abi.ptr(dx_t), _abi.ptr(sc_t), b, _abi.ptr(out),
+            _abi.current_stream()), "pv_transform_coordinates")
     return out
 
 
