@@ -113,3 +113,42 @@ def ss_build(meta, device):
     import pyroved_amd as pv
     ctor = pv.models.ssiVAE if meta["task"] == "classification" else pv.models.ss_reg_iVAE
     return ctor(meta["data_dim"], meta["latent_dim"], meta["dim"], meta["invariances"], seed=1, device=device)
+
+
+def variant_of(gold):
+    """Case definition of an ivaevar_* fixture (tests/golden/make_golden.py: VARIANT_CASES): (meta, iVAE constructor
+    kwargs, oracle Config kwargs)."""
+    meta = meta_of(gold)
+    meta["c_dim"] = int(gold["meta.c_dim"])
+    kw = {}
+    for k in gold:
+        if k.startswith("meta.model_kw."):
+            v = gold[k]
+            name = k[len("meta.model_kw."):]
+            if v.dtype.kind in "US":
+                kw[name] = str(v)
+            elif v.dtype.kind == "b":
+                kw[name] = bool(v)
+            elif v.ndim > 0:
+                kw[name] = [int(t) for t in v]
+            else:
+                kw[name] = float(v) if v.dtype.kind == "f" else int(v)
+    he, hd = kw.get("hidden_dim_e") or [128, 128], kw.get("hidden_dim_d") or [128, 128]
+    cfg_kw = dict(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                  c_dim=meta["c_dim"], n_hidden_e=len(he), n_hidden_d=len(hd), activation=kw.get("activation", "tanh"),
+                  sampler=kw.get("sampler_d", "bernoulli"), sigmoid_d=kw.get("sigmoid_d", True),
+                  dx_prior=kw.get("dx_prior", 0.1), dy_prior=kw.get("dy_prior"), sc_prior=kw.get("sc_prior", 0.1),
+                  decoder_sig=kw.get("decoder_sig", 0.5))
+    return meta, kw, cfg_kw
+
+
+def variant_inputs(meta):
+    """x (flattened for class-conditioned models, as the fixture's generator feeds the reference) and the label rows."""
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    y = None
+    if meta["c_dim"]:
+        c = meta["c_dim"]
+        y = torch.zeros(meta["batch"], c)
+        y[torch.arange(meta["batch"]), torch.arange(meta["batch"]) % c] = 1.0
+        x = x.flatten(1)
+    return x, y

@@ -108,6 +108,9 @@ def run_steps(name, data_dim, invariances, batch, steps=3, latent_dim=2, xkind="
     y = None
     if c_dim:
         y = utils.to_onehot(torch.arange(batch) % c_dim, c_dim)
+        # the reference's Concat broadcasts the LEADING axes of [x, y] (utils/nn.py:62-74): class-conditioned models
+        # take flattened samples (B, H*W), as its semi-supervised trainers feed them (tests/test_trainers.py:57-75)
+        x = x.flatten(1)
     trainer = trainers.SVItrainer(model, seed=1, device="cpu")
     for k in range(steps):
         grads = {}
@@ -477,6 +480,30 @@ def run_epochs(name, data_dim, invariances, n, batch, epochs=2, with_test=True, 
     print("wrote", name, out["epochs.training_loss"], out["epochs.test_loss"])
 
 
+# (tests/test_gpu_parity.py::VARIANTS mirrors this table)
+VARIANT_CASES = {
+    "cdim3_rt": dict(data_dim=(8, 8), invariances=["r", "t"], c_dim=3),
+    "cdim2_none": dict(data_dim=(8, 8), invariances=None, c_dim=2),
+    "gauss_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], sampler_d="gaussian"),
+    "gauss_nosig_r": dict(data_dim=(8, 8), invariances=["r"], sampler_d="gaussian", sigmoid_d=False),
+    "gauss_sig02_t": dict(data_dim=(8, 8), invariances=["t"], sampler_d="gaussian", decoder_sig=0.2),
+    "gauss_randn_none": dict(data_dim=(8, 8), invariances=None, sampler_d="gaussian", sigmoid_d=False, xkind="randn"),
+    "cbern_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], sampler_d="continuous_bernoulli"),
+    "cbern_none": dict(data_dim=(8, 8), invariances=None, sampler_d="continuous_bernoulli"),
+    "cbern_16x16_r": dict(data_dim=(16, 16), invariances=["r"], sampler_d="continuous_bernoulli"),
+    "relu_rt": dict(data_dim=(8, 8), invariances=["r", "t"], activation="relu"),
+    "softplus_s": dict(data_dim=(8, 8), invariances=["s"], activation="softplus"),
+    "lrelu_none": dict(data_dim=(8, 8), invariances=None, activation="lrelu"),
+    "gelu_r": dict(data_dim=(8, 8), invariances=["r"], activation="gelu"),
+    "hid64_rt": dict(data_dim=(8, 8), invariances=["r", "t"], hidden_dim_e=[64, 64], hidden_dim_d=[64, 64]),
+    "hid3layers_r": dict(data_dim=(8, 8), invariances=["r"], hidden_dim_e=[128, 64, 32], hidden_dim_d=[32, 48, 16]),
+    "priors_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], dx_prior=0.3, dy_prior=0.05, sc_prior=0.25),
+    "latent5_rt": dict(data_dim=(16, 16), invariances=["r", "t"], latent_dim=5),
+    "1d32_t_cdim2": dict(data_dim=(32,), invariances=["t"], c_dim=2),
+    "rect_12x20_rts": dict(data_dim=(12, 20), invariances=["r", "t", "s"]),
+}
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = sys.argv[1:] or None          # e.g. `make_golden.py jivae`: only (re)generate that family
@@ -520,6 +547,20 @@ if __name__ == "__main__":
         _rs("ivaeconv_8x8_rts_b5", (8, 8), ["r", "t", "s"], batch=5, model_kw={"conv_encoder": [(4,), (8, 8)]})
         _rs("ivaeconv_16x16_rt_b4", (16, 16), ["r", "t"], batch=4, model_kw={"conv_encoder": [(4,), (8, 8), (16, 16)]})
         _rs("ivaeconv_1d16_t_b5", (16,), ["t"], batch=5, model_kw={"conv_encoder": [(4,), (8, 8)]})
+    if only is None or "convenc64" in only:
+        # BASELINE config 4 at its own shape: 64x64, ['r','t','s'], the DEFAULT convEncoderNet stack (nets/conv.py:24-64)
+        _rs = globals()["_run_steps_real"]
+        _rs("ivaeconv_64x64_rts_b4", (64, 64), ["r", "t", "s"], batch=4, steps=2,
+            model_kw={"conv_encoder": [(32,), (64, 64), (128, 128)]})
+    # constructor variants of models/ivae.py:122-163 and the likelihoods of utils/prob.py:25-29: every branch the
+    # HIP-vs-oracle "variants" tests exercise gets a reference-generated pin
+    if only is None or "variants" in only:
+        _rs = globals()["_run_steps_real"]
+        for vname, v in VARIANT_CASES.items():
+            v = dict(v)
+            _rs("ivaevar_" + vname, v.pop("data_dim"), v.pop("invariances"), batch=7, steps=2,
+                latent_dim=v.pop("latent_dim", 2), c_dim=v.pop("c_dim", 0), xkind=v.pop("xkind", "rand"),
+                step_kw=v.pop("step_kw", {"scale_factor": 1.7}), model_kw=v)
     # VED: conv encoder / conv decoder (BASELINE config 5 family: 2-D image -> 1-D spectrum)
     if only is None or "ved" in only:
         small = dict(hidden_dim_e=[(8,), (16, 16)], hidden_dim_d=[(16, 16), (8,)])

@@ -255,6 +255,8 @@ VARIANTS = {
     "gauss_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], sampler_d="gaussian"),
     "gauss_nosig_r": dict(data_dim=(8, 8), invariances=["r"], sampler_d="gaussian", sigmoid_d=False),
     "gauss_sig02_t": dict(data_dim=(8, 8), invariances=["t"], sampler_d="gaussian", decoder_sig=0.2),
+    "gauss_nosig_none": dict(data_dim=(8, 8), invariances=None, sampler_d="gaussian", sigmoid_d=False),
+    "gelu_r": dict(data_dim=(8, 8), invariances=["r"], activation="gelu"),
     "cbern_rts": dict(data_dim=(8, 8), invariances=["r", "t", "s"], sampler_d="continuous_bernoulli"),
     "cbern_none": dict(data_dim=(8, 8), invariances=None, sampler_d="continuous_bernoulli"),
     "cbern_16x16_r": dict(data_dim=(16, 16), invariances=["r"], sampler_d="continuous_bernoulli"),
@@ -321,6 +323,58 @@ def test_model_variants_vs_oracle(gpu_device, vname, fused):
     zc = zl[:, -latent_dim:]
     dec = model.decode(zc) if y is None else model.decode(zc, y)
     np.testing.assert_allclose(dec.numpy(), o.decode(zc, y).numpy(), rtol=1e-4, atol=2e-6)
+
+
+VARIANT_GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ivaevar_*.npz")))
+
+
+@pytest.mark.parametrize("fused", [0, 1, 2])
+@pytest.mark.parametrize("name", VARIANT_GOLD)
+def test_model_variants_vs_golden(gpu_device, name, fused):
+    """The same constructor variants / likelihoods against fixtures produced by the REFERENCE's own code
+    (tests/golden/make_golden.py variants; models/ivae.py:122-163, utils/prob.py:25-29): loss and the three ELBO terms,
+    z, every gradient and every parameter after Adam for each recorded step, then encode / decode."""
+    from conftest import variant_of, variant_inputs
+    gold = load_golden(name)
+    meta, kw, cfg_kw = variant_of(gold)
+    model = pv.models.iVAE(meta["data_dim"], meta["latent_dim"], meta["invariances"], c_dim=meta["c_dim"], seed=1,
+                           device="cuda", **kw)
+    eng = model.engine(fused=fused)
+    x, y = variant_inputs(meta)
+    xg, yg = x.cuda(), (None if y is None else y.cuda())
+    cb = cfg_kw["sampler"] == "continuous_bernoulli"
+    b = meta["batch"]
+    z_dim = model.z_dim
+    zl, zs = torch.empty(b, z_dim, device="cuda"), torch.empty(b, z_dim, device="cuda")
+    # ContinuousBernoulli: torch's closed form of log C(p) cancels catastrophically near p = 1/2 (where every pixel of a
+    # fresh model sits), so the reference's OWN fp32 numbers carry ~1e-3 gradient noise and its loss is a small
+    # remainder of B*N terms of size ~0.7: judged on the scale of the sum of terms / with a wider gradient bar; the
+    # fp64 evaluation of the same formula is the tight check (test_model_variants_vs_oracle)
+    atol = 2e-7 * x.numel() if cb else 0.0
+    gbar = 5e-3 if cb else 5e-4
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        eps = torch.from_numpy(gold[pre + ".eps"]).cuda()
+        eng.loss_and_grads(xg, eps, meta["beta"], yg, z_out=(zl, zs))
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=RTOL_ELBO, atol=atol, err_msg="loss")
+        np.testing.assert_allclose(s[1], float(gold[pre + ".term.model.obs"]), rtol=RTOL_ELBO, atol=atol)
+        np.testing.assert_allclose(s[2], float(gold[pre + ".term.model.latent"]), rtol=1e-4)
+        np.testing.assert_allclose(s[3], float(gold[pre + ".term.guide.latent"]), rtol=1e-4)
+        np.testing.assert_allclose(zl.cpu().numpy(), gold[pre + ".z_loc"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(zs.cpu().numpy(), gold[pre + ".z_scale"], rtol=1e-4, atol=2e-6)
+        for key in model.state_dict():
+            check_digest(eng.grad_of(key), gold, pre + ".grad." + key, rtol=gbar, atol=1e-6, what=name)
+        eng.adam_step()
+        for key, p_ in model.state_dict().items():
+            check_digest(p_, gold, pre + ".param." + key, rtol=1e-4, atol=2e-6, what=name, sum_slack=2e-3 * 8)
+    args = (xg,) if y is None else (xg, yg)
+    z_loc, z_scale = model.encode(*[a.cpu() for a in args])
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(z_scale.numpy(), gold["enc.z_scale"], rtol=2e-4, atol=2e-5)
+    zc = torch.from_numpy(gold["enc.z_loc"])[:, -meta["latent_dim"]:]
+    dec = model.decode(zc) if y is None else model.decode(zc, y)
+    np.testing.assert_allclose(dec.numpy().reshape(gold["dec.loc"].shape), gold["dec.loc"], rtol=1e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("fused", [1, 2])
@@ -1077,6 +1131,89 @@ def test_full_size_properties(gpu_device, cfgname, fused):
     assert torch.isfinite(g_full).all()
 
 
+def _props(eng, call, n_samples, sl):
+    """Bit reproducibility of loss / gradients and additivity over two batch shards, through `call(lo, hi)`."""
+    call(0, n_samples)
+    g_full, s_full = eng.grad[:eng.n_flat].clone(), eng.scalars.clone()
+    call(0, n_samples)
+    assert torch.equal(g_full, eng.grad[:eng.n_flat]) and torch.equal(s_full, eng.scalars), "not reproducible"
+    h = n_samples // 2
+    call(0, h)
+    g0, s0 = eng.grad[:eng.n_flat].clone(), eng.scalars.clone()
+    call(h, n_samples)
+    g1, s1 = eng.grad[:eng.n_flat].clone(), eng.scalars.clone()
+    np.testing.assert_allclose((s0 + s1).cpu().numpy(), s_full.cpu().numpy(), rtol=sl)
+    assert rel_l2(g0 + g1, g_full) < sl
+    assert torch.isfinite(g_full).all()
+    return s_full.cpu().numpy()
+
+
+@pytest.mark.parametrize("fused", [2, 3])
+def test_full_size_c3_jivae(gpu_device, fused):
+    """BASELINE config 3 at its own size: jiVAE K=10, 28x28 ['r'], batch 512 -> 4.0 M decoder rows (unit partition,
+    slot arithmetic and workspace sizes differ from the toy fixtures'): reproducibility, shard additivity, and the
+    enumerated ELBO and its five site terms against the CPU oracle on the same inputs (1e-4; the mixed-precision mode
+    to its own ELBO bar)."""
+    torch.set_num_threads(8)
+    data_dim, inv, k_, b = (28, 28), ["r"], 10, 512
+    model = pv.models.jiVAE(data_dim, 2, k_, inv, seed=1, device="cuda")
+    eng = model.engine(fused=fused)
+    x = make_x("rand", b, data_dim)
+    torch.manual_seed(1)
+    eps = torch.empty(b, model.z_dim).normal_()
+    xg, eg = x.cuda(), eps.cuda()
+    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 5e-6)
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, discrete_dim=k_)
+    with torch.no_grad():
+        out = orc.jelbo({k: v.cpu() for k, v in model.state_dict().items()}, cfg, x, eps)
+    np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
+
+
+@pytest.mark.parametrize("fused", [0, 2, 3])
+def test_full_size_c4_conv_encoder(gpu_device, fused):
+    """BASELINE config 4 at its own shape and per-GPU batch: iVAE 64x64 ['r','t','s'] + set_encoder(convEncoderNet)
+    with the default stack (nets/conv.py:24-64), batch 128 — properties + the ELBO terms vs the oracle."""
+    torch.set_num_threads(8)
+    data_dim, inv, b = (64, 64), ["r", "t", "s"], 128
+    hid = [(32,), (64, 64), (128, 128)]
+    model = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+    model.set_encoder(pv.nets.convEncoderNet(data_dim, latent_dim=model.z_dim))
+    eng = model.engine(fused=fused)
+    x = make_x("rand", b, data_dim)
+    torch.manual_seed(1)
+    eps = torch.empty(b, model.z_dim).normal_()
+    xg, eg = x.cuda(), eps.cuda()
+    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 5e-6)
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, conv_encoder=hid)
+    with torch.no_grad():
+        out = orc.elbo({k: v.cpu() for k, v in model.state_dict().items()}, cfg, x, eps)
+    np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
+    np.testing.assert_allclose(s[1], out["ll"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
+    np.testing.assert_allclose(s[2], out["logpz"].item(), rtol=1e-4)
+    np.testing.assert_allclose(s[3], out["logqz"].item(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_full_size_c5_ved(gpu_device, prec):
+    """BASELINE config 5 at its per-GPU size: VED 64x64 -> 128-point spectrum, batch 256 — properties + ELBO terms
+    vs the oracle."""
+    torch.set_num_threads(8)
+    b = 256
+    model = pv.models.VED((64, 64), (128,), seed=1, device="cuda")
+    eng = model.engine(fused=3 if prec == "bf16" else 2)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(b, 1, 64, 64, generator=g)
+    y = torch.rand(b, 1, 128, generator=g)
+    torch.manual_seed(1)
+    eps = torch.empty(b, model.z_dim).normal_()
+    xg, yg, eg = x.cuda(), y.cuda(), eps.cuda()
+    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi], 1.0, yg[lo:hi]), b, 2e-5)
+    cfg = orc.VedConfig(input_dim=(64, 64), output_dim=(128,), latent_dim=2)
+    with torch.no_grad():
+        out = orc.ved_elbo({k: v.cpu() for k, v in model.state_dict().items()}, cfg, x, y, eps)
+    np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if prec == "bf16" else RTOL_ELBO)
+
+
 BF16_CASES = ["ivae_28x28_rt_b256", "ivae_28x28_r_b128", "ivae_28x28_r_b32_blobs", "ivae_8x8_rts_b6", "ivae_8x8_r_b6",
               "ivae_1d16_t_b5", "ivae_8x8_rts_b6_randn", "ivae_8x8_rt_b6_beta4"]
 
@@ -1373,3 +1510,45 @@ def test_fails_loudly_on_cpu_tensors(gpu_device):
     eng = model.engine()
     with pytest.raises(_abi.PvError):
         eng.loss_and_grads(torch.rand(4, 8, 8), torch.randn(4, 3))
+
+
+def test_trainer_settings_reach_an_existing_engine(gpu_device):
+    """model.engine(**kw) must not drop settings when the engine already exists (created by encode(), an earlier
+    trainer ...), and every trainer starts a fresh Adam like the reference's (trainers/svi.py:75-81)."""
+    x = make_x("rand", 64, (8, 8))
+    loader = pv.utils.init_dataloader(x, batch_size=16)
+
+    def run(pre_touch):
+        model = pv.models.iVAE((8, 8), 2, ["r", "t"], seed=1, device="cuda")
+        if pre_touch:
+            model.encode(x[:4])                                     # creates the engine with default settings
+            t0 = pv.trainers.SVItrainer(model, seed=1)              # an earlier trainer leaves Adam state behind
+            t0.step(loader)
+            model.load_state_dict(ref_state)
+        tr = pv.trainers.SVItrainer(model, seed=1, precision="bf16", lr=5e-3)
+        assert tr.engine.fused == 3 and tr.engine.lr == 5e-3 and tr.engine.adam_t == 0
+        assert not tr.engine.m.any() and not tr.engine.v.any()
+        tr.step(loader)
+        return tr.loss_history["training_loss"][0], {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref_state = {k: v.detach().clone() for k, v in pv.models.iVAE((8, 8), 2, ["r", "t"], seed=1, device="cuda").state_dict().items()}
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
+def test_model_on_a_non_current_device(gpu_device):
+    """A model built on cuda:1 while cuda:0 is the current device: every library call runs on the model's device."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    torch.cuda.set_device(0)
+    x = make_x("rand", 12, (8, 8))
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        model = pv.models.iVAE((8, 8), 2, ["r", "t", "s"], seed=1, device=dev)
+        tr = pv.trainers.SVItrainer(model, seed=1)
+        tr.step(pv.utils.init_dataloader(x, batch_size=6))
+        outs.append((tr.loss_history["training_loss"][0], model.encode(x)[0]))
+        assert torch.cuda.current_device() == 0
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])

@@ -154,6 +154,54 @@ def test_oracle_epochs_match_reference_trainer(name):
         check_digest(o.p[key], gold, "final." + key, rtol=1e-4, atol=1e-7, what=name)
 
 
+# ---------------------------------------------------------------- constructor variants / likelihoods
+# (models/ivae.py:122-163, utils/prob.py:25-29): Gaussian and ContinuousBernoulli likelihoods, sigmoid_d, decoder_sig,
+# c_dim on a plain iVAE, every activation, non-default hidden widths / depths, custom priors, other latent sizes —
+# each branch of the oracle pinned to a fixture the reference's own code produced
+VARIANT_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ivaevar_*.npz")))
+
+
+def test_variant_fixture_inventory():
+    assert len(VARIANT_CASES) >= 19
+
+
+@pytest.mark.parametrize("name", VARIANT_CASES)
+def test_variant_oracle_steps_match_reference(name):
+    from conftest import variant_of, variant_inputs
+    gold = load_golden(name)
+    meta, kw, cfg_kw = variant_of(gold)
+    model = pv.models.iVAE(meta["data_dim"], meta["latent_dim"], meta["invariances"], c_dim=meta["c_dim"], seed=1,
+                           device="cpu", **kw)
+    keys = [k[len("init."):-len(".sum")] for k in gold if k.startswith("init.") and k.endswith(".sum")]
+    assert sorted(keys) == sorted(model.state_dict().keys())
+    for k, p in model.state_dict().items():
+        check_digest(p, gold, "init." + k, rtol=0, atol=0, what=name)
+    cfg = orc.Config(**cfg_kw)
+    o = orc.SVIOracle(model.state_dict(), cfg)
+    x, y = variant_inputs(meta)
+    cb = cfg.sampler == "continuous_bernoulli"
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        loss = o.step(x, torch.from_numpy(gold[pre + ".eps"]), meta["beta"], y)
+        # ContinuousBernoulli on a fresh model: the loss is a few units left over from B*N per-pixel terms of size
+        # ~0.7 that nearly cancel -> compared on the scale of the sum of the terms
+        np.testing.assert_allclose(loss, float(gold[pre + ".loss"]), rtol=3e-6,
+                                   atol=(2e-7 * x.numel()) if cb else 0.0)
+        np.testing.assert_allclose(o.last["ll"].item(), float(gold[pre + ".term.model.obs"]), rtol=3e-6,
+                                   atol=(2e-7 * x.numel()) if cb else 0.0)
+        np.testing.assert_allclose(o.last["logpz"].item(), float(gold[pre + ".term.model.latent"]), rtol=2e-5)
+        np.testing.assert_allclose(o.last["logqz"].item(), float(gold[pre + ".term.guide.latent"]), rtol=2e-5)
+        np.testing.assert_allclose(o.last["z"].detach().numpy(), gold[pre + ".z"], rtol=1e-4, atol=1e-6)
+        for key in o.p:
+            check_digest(o.last_grads[key], gold, pre + ".grad." + key, rtol=2e-4, atol=1e-6, what=name)
+            check_digest(o.p[key], gold, pre + ".param." + key, rtol=2e-5, atol=1e-6, what=name)
+    z_loc, z_scale = o.encode(x, y)
+    np.testing.assert_allclose(z_loc.numpy(), gold["enc.z_loc"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(z_scale.numpy(), gold["enc.z_scale"], rtol=1e-4, atol=1e-6)
+    dec = o.decode(z_loc[:, -meta["latent_dim"]:], y)
+    np.testing.assert_allclose(dec.numpy(), gold["dec.loc"], rtol=1e-4, atol=1e-6)
+
+
 # ---------------------------------------------------------------- jiVAE (models/jivae.py, TraceEnum_ELBO)
 JSTEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "jivae_*.npz")))
 
