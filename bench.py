@@ -2,31 +2,41 @@
 """
 bench.py — throughput of the SVI training hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config C1..C5] [--strong] [--repeats R]
   (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
-Workload (BASELINE.json configs[1]): iVAE, data_dim (28, 28), latent_dim 2, invariances ['r','t'],
-Bernoulli likelihood, batch 256 PER GPU (weak scaling), bf16 as that config names it: the decoder's hidden-layer
-contractions take bf16 operands on the MFMA with fp32 accumulation (--fused 3: ELBO within 1e-5 of the fp32 oracle,
-gradients to ~1e-2 — mixed-precision training), everything else fp32.  The same run then repeats the measurement on
-the library's default fp32-class path (--fused 2, "bf16x3": hi+lo operands, 3 products — the 1e-4 parity mode for
-gradients too) and reports it as `fp32_class`; --fused 1 selects the f32-input MFMA kernel, --fused 0 the
-layer-by-layer path.  Synthetic data torch.rand(..., seed 0), model/trainer seed 1, random-init weights.
-A step = Trace_ELBO loss + gradients over one minibatch already resident in HBM
-(pv_ivae_loss_and_grads) + [one all-reduce of the flat gradient when N > 1] + Adam (pv_adam_step).
+Headline workload (BASELINE.json configs[1], "C2"): iVAE, data_dim (28, 28), latent_dim 2, invariances ['r','t'],
+Bernoulli likelihood, batch 256 PER GPU (weak scaling; --strong: 256 GLOBAL, sharded), bf16 as that config names it:
+the decoder's hidden-layer contractions take bf16 operands on the MFMA with fp32 accumulation (ELBO within 1e-5 of
+the fp32 oracle, gradients to ~1e-2 — mixed-precision training), everything else fp32.  The same run repeats the
+measurement on the library's default fp32-class path ("bf16x3": hi+lo operands, 3 products — the 1e-4 parity mode for
+gradients too) and reports it as `fp32_class`.  Synthetic data torch.rand(..., seed 0), model/trainer seed 1,
+random-init weights.  A step = Trace_ELBO loss + gradients over one minibatch already resident in HBM + [one
+all-reduce of the flat gradient when N > 1] + Adam.
+
+--config selects another BASELINE.json configuration: C1 iVAE 28x28 ['r'] B=128, C3 jiVAE K=10 28x28
+['r'] B=512, C4 iVAE 64x64 ['r','t','s'] + set_encoder(convEncoderNet) B=128/GPU, C5 VED 64x64 -> 128 B=256/GPU.
+The default N=1 run also times C1, C3, C4, C5 (one short subprocess each: a case that follows a much larger one in the
+same process inherits its freed device memory and can measure slower) and carries them in `configs`.
+
+The timed region is EXACTLY --steps steps bracketed by barrier + synchronize, max over ranks; it is repeated
+--repeats times inside the invocation (default 5) and `ms_per_step` / `value` are the MEDIAN region (all regions in
+`ms_per_step_all`), so a 20-step run is not one 3 ms sample.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline     the dominant kernel (the fused decoder kernel) against the dense MFMA peak of the instruction it
                runs on, its duration measured with HIP events recorded on the launch stream inside the timed
                region (every 8th step: an event pair costs ~10 us of stream bubbles),
   cpu_baseline the CPU oracle (eager-torch restatement of the reference) timed on this host's cores
-               on a bounded sample of the same workload (rank 0, N = 1 only),
+               on a bounded sample of the same workload (rank 0, N = 1 only): best thread count and a 1-thread leg,
   elbo         per-image loss of the first timed step next to the oracle's value on the same inputs.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -35,30 +45,38 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DATA_DIM = (28, 28)
-INVARIANCES = ["r", "t"]
-LATENT_DIM = 2
-BATCH_PER_GPU = 256
-N_RING = 16                      # distinct resident minibatches (n = 16 * B)
+N_RING = 16                      # distinct resident minibatches (n = 16 * B) for the 28x28 configs
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* f32-in peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the guide's
-# gfx950 correction + WRITE_SIZE, KiB -> bytes), batch 256: see profiles/r01*_pmc_*.txt.  None: not collected.
-TRAFFIC_BYTES = {1: 2 * 6982 * 1024 + 50298 * 1024, 2: 2 * 1331 * 1024 + 37943 * 1024,
-                 3: 2 * 994 * 1024 + 37925 * 1024}   # 2, 3: profiles/r01i_pmc_* (same values in r01h, r01j)
+DEC_FLOP_PER_PIXEL = 3 * (2 * 2 * 128 + 2 * 128 * 128 * 2 + 2 * 128)   # spatial decoder fwd+bwd: 3 * 66 304
 
-
-def decoder_flops_per_image(n_pix, hidden=128, coord_dim=2):
-    """Algorithmic fwd+bwd FLOPs of the spatial decoder per image:
-    per pixel fwd = 2*(cd*H) + 2*H*H + 2*H*H + 2*H ; fwd+bwd = 3x."""
-    per_pix = 2 * coord_dim * hidden + 2 * hidden * hidden * 2 + 2 * hidden
-    return 3 * n_pix * per_pix
-
-
-def encoder_flops_per_image(n_pix, z_dim, hidden=128, latent=2):
-    return 3 * (2 * (n_pix * hidden + hidden * hidden + 2 * hidden * z_dim) + 2 * hidden * latent)
-
+# name -> workload.  flops_per_image: algorithmic fwd+bwd FLOPs of the whole step per image (measured
+# with FlopCounterMode on the reference's modules).  dec_passes: decoder evaluations per image (K for jiVAE).
+CONFIGS = {
+    "C1": dict(kind="ivae", data_dim=(28, 28), inv=["r"], batch=128, flops_per_image=1.566e8, dec_passes=1, ring=16,
+               desc="iVAE 28x28 invariances=['r'] latent_dim=2 bernoulli"),
+    "C2": dict(kind="ivae", data_dim=(28, 28), inv=["r", "t"], batch=256, flops_per_image=1.566e8, dec_passes=1, ring=16,
+               desc="iVAE 28x28 invariances=['r','t'] latent_dim=2 bernoulli"),
+    "C3": dict(kind="jivae", data_dim=(28, 28), inv=["r"], batch=512, K=10, flops_per_image=1.56e9, dec_passes=10, ring=4,
+               desc="jiVAE discrete_dim=10 latent_dim=2 invariances=['r'] 28x28 bernoulli, exact enumeration"),
+    "C4": dict(kind="ivae_conv", data_dim=(64, 64), inv=["r", "t", "s"], batch=128, flops_per_image=1.50e9, dec_passes=1,
+               ring=4, desc="iVAE 64x64 invariances=['r','t','s'] + set_encoder(convEncoderNet default stack)"),
+    "C5": dict(kind="ved", data_dim=(64, 64), out_dim=(128,), batch=256, flops_per_image=7.09e8, dec_passes=0, ring=2,
+               desc="VED im2spec 64x64 image -> 128-point spectrum, default conv stacks"),
+}
+# HBM bytes per launch of the dominant kernel, from rocprofv3 PMC passes of earlier builds (FETCH_SIZE doubled per the
+# guide's gfx950 correction + WRITE_SIZE), C2 at batch 256.  NOT collected by this run: `traffic_source` says where from.
+TRAFFIC = {("C2", 2): (2 * 1331 * 1024 + 37943 * 1024, "profiles/r01j_pmc_fused_bf16_and_bf16x3.txt"),
+           ("C2", 3): (2 * 994 * 1024 + 37925 * 1024, "profiles/r01j_pmc_fused_bf16_and_bf16x3.txt")}
+_traffic_file = os.path.join(ROOT, "profiles", "traffic.json")     # refreshed by scripts/gpu_pmc.sh when it is run
+if os.path.exists(_traffic_file):
+    try:
+        for k_, v_ in json.load(open(_traffic_file)).items():
+            c_, f_ = k_.split(":")
+            TRAFFIC[(c_, int(f_))] = (int(v_["bytes"]), v_["source"])
+    except Exception:
+        pass
 
 EV_EVERY = 8
 
@@ -84,46 +102,272 @@ class HipEvents:
         return out
 
 
-def cpu_baseline(budget_s=15.0):
-    """The CPU oracle (a restatement of the reference's eager-torch path) on the same workload."""
-    import pyroved_amd as pv
+# --------------------------------------------------------------------------------------------- workloads
+def make_model(pv, cfg, dev):
+    if cfg["kind"] == "ivae":
+        return pv.models.iVAE(cfg["data_dim"], 2, cfg["inv"], seed=1, device=dev)
+    if cfg["kind"] == "jivae":
+        return pv.models.jiVAE(cfg["data_dim"], 2, cfg["K"], cfg["inv"], seed=1, device=dev)
+    if cfg["kind"] == "ivae_conv":
+        m = pv.models.iVAE(cfg["data_dim"], 2, cfg["inv"], seed=1, device=dev)
+        m.set_encoder(pv.nets.convEncoderNet(cfg["data_dim"], latent_dim=m.z_dim))
+        return m
+    if cfg["kind"] == "ved":
+        return pv.models.VED(cfg["data_dim"], cfg["out_dim"], seed=1, device=dev)
+    raise KeyError(cfg["kind"])
+
+
+def make_oracle(cfg, state):
     from oracle import svi_oracle as orc
-    ncores = os.cpu_count() or 1
-    model = pv.models.iVAE(DATA_DIM, LATENT_DIM, INVARIANCES, seed=1, device="cpu")
-    cfg = orc.Config(data_dim=DATA_DIM, latent_dim=LATENT_DIM, invariances=INVARIANCES)
-    o = orc.SVIOracle(model.state_dict(), cfg)
-    x = torch.rand(BATCH_PER_GPU, *DATA_DIM, generator=torch.Generator().manual_seed(0))
+    if cfg["kind"] == "ved":
+        oc = orc.VedConfig(input_dim=cfg["data_dim"], output_dim=cfg["out_dim"], latent_dim=2)
+        return orc.VedOracle(state, oc), 2
+    oc = orc.Config(data_dim=cfg["data_dim"], latent_dim=2, invariances=cfg["inv"], discrete_dim=cfg.get("K", 0),
+                    conv_encoder=[(32,), (64, 64), (128, 128)] if cfg["kind"] == "ivae_conv" else None)
+    return orc.SVIOracle(state, oc), oc.z_dim
+
+
+def make_data(cfg, n, gen):
+    """n samples of the workload: (x,) or (x, y)."""
+    if cfg["kind"] == "ved":
+        return (torch.rand(n, 1, *cfg["data_dim"], generator=gen), torch.rand(n, 1, *cfg["out_dim"], generator=gen))
+    return (torch.rand(n, *cfg["data_dim"], generator=gen),)
+
+
+def host_cpu_info():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
+
+
+def cpu_baseline(name, cfg, budget_s=12.0):
+    """The CPU oracle (a restatement of the reference's eager-torch path) on the same workload: the best of a few
+    thread counts (eager torch does not scale to every hardware thread of a big host on (200704 x 128) operands) for
+    ~budget_s seconds, and a 1-thread leg of a few steps."""
+    import pyroved_amd as pv
+    model_name, n_phys, n_logical = host_cpu_info()
+    B = cfg["batch"]
+    model = make_model(pv, cfg, "cpu")
+    o, z_dim = make_oracle(cfg, model.state_dict())
+    data = make_data(cfg, B, torch.Generator().manual_seed(0))
     torch.manual_seed(1)
-    eps0 = torch.empty(BATCH_PER_GPU, cfg.z_dim).normal_()
-    torch.set_num_threads(min(16, ncores))
-    loss0 = o.step(x, eps0)                    # also the warm-up step
-    # eager torch does not scale to every hardware thread of a big host on (200704 x 128) operands:
-    # probe a few thread counts (one step each) and time the best one
-    best_t, best_n = None, None
+    eps0 = torch.empty(B, z_dim).normal_()
+
+    def one(eps=None):
+        e = torch.empty(B, z_dim).normal_() if eps is None else eps
+        return o.step(data[0], data[1], e) if cfg["kind"] == "ved" else o.step(data[0], e)
+    torch.set_num_threads(min(16, n_logical))
+    loss0 = one(eps0)                          # also the warm-up step
+    best_t, best_n, probes = None, None, {}
     for nt in (8, 16, 32, 64, 128):
-        if nt > ncores:
+        if nt > n_logical:
             break
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
-        o.step(x, o.draw_eps(BATCH_PER_GPU))
+        one()
         dt = time.perf_counter() - t0
+        probes[nt] = dt
         if best_t is None or dt < best_t:
             best_t, best_n = dt, nt
         if dt > 2.5 * best_t:
             break
+    if best_n is None:
+        best_n = n_logical
     torch.set_num_threads(best_n)
-    t0 = time.perf_counter()
-    n = 0
+    t0, n = time.perf_counter(), 0
     while True:
-        o.step(x, o.draw_eps(BATCH_PER_GPU))
+        one()
         n += 1
         el = time.perf_counter() - t0
         if (el > budget_s and n >= 3) or n >= 200:
             break
-    return dict(value=n * BATCH_PER_GPU / el, unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d SVI steps of batch %d (%.1f s) of the same iVAE 28x28 ['r','t'] workload, eager torch CPU "
-                       "oracle (oracle/svi_oracle.py), %d threads" % (n, BATCH_PER_GPU, el, torch.get_num_threads()),
-                ms_per_step=1e3 * el / n), loss0 / BATCH_PER_GPU
+    torch.set_num_threads(1)
+    t1, n1 = time.perf_counter(), 0
+    while True:
+        one()
+        n1 += 1
+        el1 = time.perf_counter() - t1
+        if el1 > 4.0 or n1 >= 20:
+            break
+    torch.set_num_threads(best_n)
+    return dict(value=n * B / el, unit="images/s", cores=best_n, kind="port",
+                sample="%d SVI steps of batch %d (%.1f s) of the same %s workload (%s), eager torch CPU oracle "
+                       "(oracle/svi_oracle.py), %d threads = the fastest of the probed thread counts %s"
+                       % (n, B, el, name, cfg["desc"], best_n, sorted(probes)),
+                ms_per_step=1e3 * el / n, cpu_model=model_name, physical_cores=n_phys, logical_cpus=n_logical,
+                thread_probe_ms={str(k): 1e3 * v for k, v in probes.items()},
+                one_thread={"value": n1 * B / el1, "unit": "images/s", "cores": 1, "ms_per_step": 1e3 * el1 / n1,
+                            "sample": "%d steps (%.1f s)" % (n1, el1)}), loss0 / B
+
+
+# --------------------------------------------------------------------------------------------- the timed run
+def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B):
+    """warm-up + --repeats timed regions of --steps steps on one decoder path.
+    -> (list of region seconds (max over ranks), kernel ms samples, per-step losses (cpu), engine, model)"""
+    model = make_model(pv, cfg, dev)
+    eng = model.engine(fused=fused)
+    if world > 1:
+        pvdist.sync_replicas(eng)
+    ring_n = cfg["ring"]
+    gen = torch.Generator().manual_seed(0)
+    # synthetic data, resident in HBM before the timed region.  Weak scaling: every rank owns B samples of each of the
+    # ring's global minibatches of world*B; strong scaling: the global minibatch is B_global = world*B too (B = global/world)
+    data = make_data(cfg, ring_n * world * B, gen)
+    data = [t.view(ring_n, world, B, *t.shape[1:])[:, rank].contiguous().to(dev) for t in data]
+    R = max(1, args.repeats)
+    total_steps = args.warmup + R * args.steps
+    torch.manual_seed(1)
+    eps_all = torch.empty(total_steps, world, B, model.z_dim).normal_()[:, rank].contiguous().to(dev)
+    n_ev = (args.steps + EV_EVERY - 1) // EV_EVERY
+    events = HipEvents(n_ev * R)
+    hist = torch.zeros(total_steps, 4, device=dev)
+    ved = cfg["kind"] == "ved"
+    one_call = world == 1 and not args.two_call and getattr(eng, "supports_step", False)
+
+    def step(i, ev=None):
+        eng.events = ev if ev is not None else (None, None)
+        x = data[0][i % ring_n]
+        if ved:
+            eng.loss_and_grads(x, eps_all[i], 1.0, data[1][i % ring_n], scalars_out=hist[i] if world == 1 else None)
+            if world > 1:
+                pvdist.allreduce_sum_(eng.grad)
+                hist[i].copy_(eng.scalars)
+            eng.adam_step()
+        elif world > 1:
+            eng.loss_and_grads(x, eps_all[i])
+            pvdist.allreduce_sum_(eng.grad)           # gradients + the 4 loss scalars in one collective
+            if hasattr(eng, "adam_step_hist"):
+                eng.adam_step_hist(hist[i])           # Adam + the history write in one launch
+            else:
+                hist[i].copy_(eng.scalars)
+                eng.adam_step()
+        elif one_call:
+            # single process: SVI.step as ONE library call (pv_ivae_step: ELBO + gradients + Adam; bit-identical to
+            # the two calls, tests/test_gpu_parity.py)
+            eng.loss_and_grads(x, eps_all[i], scalars_out=hist[i], step=True)
+        else:
+            eng.loss_and_grads(x, eps_all[i], scalars_out=hist[i])
+            eng.adam_step()
+
+    # one untimed, state-free pass first (gradients only, no optimizer update, no collective on real data): module
+    # loading and first-launch costs never land in a timed region, whatever --warmup is
+    if ved:
+        eng.loss_and_grads(data[0][0], eps_all[0], 1.0, data[1][0])
+    else:
+        eng.loss_and_grads(data[0][0], eps_all[0])
+    if world > 1:
+        pvdist.allreduce_sum_(torch.zeros_like(eng.grad))
+    for i in range(args.warmup):
+        step(i)
+    regions = []
+    for r in range(R):
+        base = args.warmup + r * args.steps
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(base + i, events.pairs[r * n_ev + i // EV_EVERY] if i % EV_EVERY == 0 else None)
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if world > 1:
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+        regions.append(t.item())
+    kms = events.elapsed_ms() if not ved else []
+    return regions, kms, hist[:, 0].cpu(), eng, model
+
+
+def _paths(cfg, mode, B, n_pix):
+    """(kernel name, flops per launch, peak TF, dtype label, arithmetic description) of the dominant kernel."""
+    dec_fl = DEC_FLOP_PER_PIXEL * n_pix * max(cfg["dec_passes"], 1) * B
+    if mode == 2:
+        return ("pv_sdec_fused_bf16_kernel (decoder fwd+bwd, all layers, bf16x3 split precision)", dec_fl,
+                MFMA_BF16_PEAK_TFLOPS, "bf16x3", "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)")
+    if mode == 3:
+        return ("pv_sdec_fused_bf16_kernel<X3=false> (decoder fwd+bwd, all layers, plain bf16 operands)", dec_fl,
+                MFMA_BF16_PEAK_TFLOPS, "bf16", "bf16 MFMA operands for the hidden-layer contractions (fp32 accumulate; fp32 elsewhere)")
+    if mode == 1:
+        return ("pv_sdec_fused_kernel (decoder fwd+bwd, all layers, f32-input MFMA)", dec_fl, MFMA_F32_PEAK_TFLOPS,
+                "f32", "fp32 (f32-input MFMA)")
+    return ("pv_gemm_kernel<NT> (decoder hidden layer fwd, M=B*N, K=N=128)", 2.0 * B * n_pix * 128 * 128 * max(cfg["dec_passes"], 1),
+            MFMA_F32_PEAK_TFLOPS, "f32", "fp32 (f32-input MFMA)")
+
+
+def measure(args, name, cfg, fused, ctx):
+    """One decoder path of one config -> dict of numbers."""
+    pv, pvdist, td, dev, rank, world, B = ctx
+    regions, kms, losses, eng, model = _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B)
+    med = statistics.median(regions)
+    n_pix = 1
+    for d in cfg["data_dim"]:
+        n_pix *= d
+    ved = cfg["kind"] == "ved"
+    out = {"regions_s": regions, "median_s": med, "ms_per_step": 1e3 * med / args.steps,
+           "ms_per_step_all": [1e3 * r / args.steps for r in regions],
+           "value": args.steps * B * world / med,
+           "loss_per_image_step0": losses[0].item() / (B * world),
+           "loss_per_image_first_timed_step": losses[args.warmup].item() / (B * world),
+           "loss_per_image_last_step": losses[-1].item() / (B * world)}
+    step_tf = out["value"] / world * cfg["flops_per_image"] / 1e12
+    if ved:
+        bf = fused == 3
+        peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
+        out.update(dtype="bf16x3" if bf else "f32", path="conv-bf16x3" if bf else "conv-f32",
+                   arith=("bf16 split-precision MFMA in the k3 convolutions (fp32 accumulate)" if bf
+                          else "fp32 (f32-input MFMA)"),
+                   roofline={"bound": "mfma", "scope": "step", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s",
+                             "frac": step_tf / peak, "traffic": None,
+                             "kernel": "whole step (direct conv fwd/dgrad/wgrad kernels dominate; see profiles/)",
+                             "kernel_ms": out["ms_per_step"], "flops_per_launch": cfg["flops_per_image"] * B})
+        return out
+    mode = fused if eng.uses_fused(B) else 0
+    kname, fl, peak, dtype, arith = _paths(cfg, mode, B, n_pix)
+    k_avg = sum(kms) / max(len(kms), 1)
+    achieved = fl / (k_avg * 1e-3) / 1e12 if k_avg > 0 else 0.0
+    tr = TRAFFIC.get((name, mode)) if B == cfg["batch"] else None
+    out.update(dtype=dtype, arith=arith, path={0: "layered", 1: "fused-f32", 2: "fused-bf16x3", 3: "fused-bf16"}[mode],
+               roofline={"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": tr[0] if tr else None,
+                         "traffic_source": (tr[1] + " (earlier rocprofv3 --pmc run, not collected by this run)") if tr else None,
+                         "kernel": kname, "kernel_ms": k_avg, "kernel_ms_samples": len(kms), "flops_per_launch": fl},
+               step_algorithmic_tflops=step_tf)
+    return out
+
+
+def sub_config(name, args):
+    """Times another config in its own process (N = 1) and returns its compact record."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(args.sub_steps), "--warmup", "10",
+           "--repeats", "3", "--no-cpu-baseline", "--no-configs"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        rec = {"config": name, "workload": d["config"]["workload"], "n_gpus": 1, "dtype": d["dtype"],
+               "ms_per_step": d["ms_per_step"], "ms_per_step_all": d["ms_per_step_all"], "value": d["value"],
+               "unit": d["unit"], "roofline": d["roofline"], "step_algorithmic_tflops": d.get("step_algorithmic_tflops"),
+               "loss_per_image_step0": d["elbo"]["loss_per_image_step0"]}
+        if "fp32_class" in d:
+            rec["fp32_class"] = d["fp32_class"]
+        return rec
+    except Exception as e:       # a failed side measurement must not take the headline line down
+        return {"config": name, "error": repr(e)[:300]}
 
 
 def main():
@@ -131,11 +375,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the config's batch is the GLOBAL batch, sharded")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "3")),
                     help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3 (fp32-class), 3 fused plain bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the fp32-class path) of the default run")
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the fp32-class path)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of C1, C3, C4, C5")
+    ap.add_argument("--sub-steps", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (weak) / global batch (--strong)")
     ap.add_argument("--two-call", action="store_true", help="N=1: pv_ivae_loss_and_grads + pv_adam_step instead of pv_ivae_step")
     args = ap.parse_args()
 
@@ -161,141 +410,56 @@ def main():
     import pyroved_amd as pv
     from pyroved_amd import dist as pvdist
 
-    B = args.batch
-    n_pix = DATA_DIM[0] * DATA_DIM[1]
+    name = args.config
+    cfg = CONFIGS[name]
+    b_cfg = args.batch if args.batch is not None else cfg["batch"]
+    if args.strong:
+        if b_cfg % world:
+            raise SystemExit("--strong: the global batch %d is not divisible by %d ranks" % (b_cfg, world))
+        B = b_cfg // world
+    else:
+        B = b_cfg
+    ctx = (pv, pvdist, td, dev, rank, world, B)
 
-    def run(fused):
-        """warm-up + the timed region on one decoder path; -> (elapsed s (max over ranks), kernel ms samples, losses, engine)"""
-        return _run(args, fused, pv, pvdist, td, dev, rank, world, B, n_pix)
-
-    elapsed, kms, losses, eng, model = run(args.fused)
+    main_leg = measure(args, name, cfg, args.fused, ctx)
     alt = None
     if args.fused == 3 and not args.no_alt:
-        # the same workload on the fp32-class path (bf16 split precision), reported next to the headline
-        a_el, a_kms, a_losses, _, _ = run(2)
-        alt = {"path": "fused-bf16x3", "dtype": "bf16x3", "value": args.steps * B * world / a_el, "unit": "images/s",
-               "ms_per_step": 1e3 * a_el / args.steps, "kernel_ms": sum(a_kms) / max(len(a_kms), 1),
-               "loss_per_image_step0": a_losses[0].item() / (B * world)}
-    _report(args, rank, world, B, n_pix, elapsed, kms, losses, eng, model, alt)
-    if world > 1:
-        td.destroy_process_group()
-
-
-def _run(args, fused, pv, pvdist, td, dev, rank, world, B, n_pix):
-    model = pv.models.iVAE(DATA_DIM, LATENT_DIM, INVARIANCES, seed=1, device=dev)
-    eng = model.engine(fused=fused)
-    if world > 1:
-        pvdist.broadcast_(eng.flat)
-    # synthetic data, resident in HBM before the timed region; every rank gets its own shard of a
-    # global ring of N_RING * world minibatches (weak scaling: B per GPU)
-    g = torch.Generator().manual_seed(0)
-    ring = torch.rand(N_RING * world * B, *DATA_DIM, generator=g)
-    ring = ring.view(N_RING, world, B, n_pix)[:, rank].contiguous().to(dev)
-    total_steps = args.warmup + args.steps
-    torch.manual_seed(1)
-    eps_all = torch.empty(total_steps, world, B, model.z_dim).normal_()[:, rank].contiguous().to(dev)
-    # the dominant kernel is bracketed with HIP events on every EV_EVERY-th timed step (an event pair costs ~10 us
-    # of stream bubbles around the kernel it brackets: sampled so that the clock measures the path, not the probe)
-    n_ev = (args.steps + EV_EVERY - 1) // EV_EVERY
-    events = HipEvents(n_ev)
-    hist = torch.zeros(total_steps, 4, device=dev)
-
-    def step(i, timed_idx=None):
-        sampled = timed_idx is not None and timed_idx % EV_EVERY == 0
-        eng.events = events.pairs[timed_idx // EV_EVERY] if sampled else (None, None)
-        if world > 1:
-            eng.loss_and_grads(ring[i % N_RING], eps_all[i])
-            pvdist.allreduce_sum_(eng.grad)           # gradients + the 4 loss scalars in one collective
-            hist[i].copy_(eng.scalars)
-            eng.adam_step()
-        elif args.two_call:
-            eng.loss_and_grads(ring[i % N_RING], eps_all[i], scalars_out=hist[i])   # loss lands in the history
-            eng.adam_step()
-        else:
-            # single process: SVI.step as ONE library call (pv_ivae_step: ELBO + gradients + Adam; the update rides in
-            # the last gradient launch — bit-identical to the two calls, tests/test_gpu_parity.py)
-            eng.loss_and_grads(ring[i % N_RING], eps_all[i], scalars_out=hist[i], step=True)
-
-    # one untimed, state-free pass first (gradients only, no optimizer update, no collective on real data): module
-    # loading and first-launch costs never land in the timed region, whatever --warmup is
-    eng.loss_and_grads(ring[0], eps_all[0])
-    if world > 1:
-        pvdist.allreduce_sum_(torch.zeros_like(eng.grad))
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, i)
-    if world > 1:
-        td.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-    elapsed = t.item()
-
-    return elapsed, events.elapsed_ms(), hist[:, 0].cpu(), eng, model
-
-
-def _report(args, rank, world, B, n_pix, elapsed, kms, losses, eng, model, alt):
+        alt = measure(args, name, cfg, 2, ctx)      # the same workload on the fp32-class path
     if rank == 0:
-        images = args.steps * B * world
-        value = images / elapsed
-        dec_fl = decoder_flops_per_image(n_pix)
-        k_avg_ms = sum(kms) / max(len(kms), 1)
-        # which kernel the events bracket depends on the path (see pv_plan.hip / pv_sdec_fused.hip)
-        fused_used = eng.uses_fused(B)
-        mode = args.fused if fused_used else 0
-        if mode == 2:
-            # split-precision bf16 MFMA: `achieved` counts the ALGORITHMIC fp32 FLOPs (SURVEY §8d) once, although
-            # the kernel issues 3 bf16 MFMAs per product; the peak is the dense bf16 MFMA peak it runs on
-            kname = "pv_sdec_fused_bf16_kernel (decoder fwd+bwd, all layers, bf16x3 split precision)"
-            flops_per_launch, peak, dtype = dec_fl * B, MFMA_BF16_PEAK_TFLOPS, "bf16x3"
-            arith = "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)"
-        elif mode == 3:
-            kname = "pv_sdec_fused_bf16_kernel<X3=false> (decoder fwd+bwd, all layers, plain bf16 operands)"
-            flops_per_launch, peak, dtype = dec_fl * B, MFMA_BF16_PEAK_TFLOPS, "bf16"
-            arith = "bf16 MFMA operands for the hidden-layer contractions (fp32 accumulate; fp32 elsewhere)"
-        elif mode == 1:
-            kname = "pv_sdec_fused_kernel (decoder fwd+bwd, all layers, f32-input MFMA)"
-            flops_per_launch, peak, dtype = dec_fl * B, MFMA_F32_PEAK_TFLOPS, "f32"
-            arith = "fp32 (f32-input MFMA)"
-        else:
-            kname = "pv_gemm_kernel<NT> (decoder hidden layer fwd, M=B*N, K=N=128)"
-            flops_per_launch, peak, dtype = 2.0 * B * n_pix * 128 * 128, MFMA_F32_PEAK_TFLOPS, "f32"
-            arith = "fp32 (f32-input MFMA)"
-        achieved = flops_per_launch / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         out = {
-            "metric": "images/sec (SVI step)", "value": value, "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "iVAE 28x28 invariances=['r','t'] latent_dim=2 bernoulli, batch %d per GPU "
-                                   "(global %d), %s, SVI step = ELBO+grads+%sAdam"
-                                   % (B, B * world, arith, "allreduce+" if world > 1 else ""),
-                       "parallelism": "dp%d" % world, "path": {0: "layered", 1: "fused-f32", 2: "fused-bf16x3", 3: "fused-bf16"}[mode]},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": TRAFFIC_BYTES.get(mode), "kernel": kname,
-                         "kernel_ms": k_avg_ms, "flops_per_launch": flops_per_launch,
-                         "frac_of_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS},
-            "step_frac_of_f32_mfma_roof": value / world * (dec_fl + encoder_flops_per_image(n_pix, model.z_dim))
-            / (MFMA_F32_PEAK_TFLOPS * 1e12),
-            "elbo": {"loss_per_image_first_timed_step": losses[args.warmup].item() / (B * world),
-                     "loss_per_image_last_step": losses[-1].item() / (B * world),
-                     "loss_per_image_step0": losses[0].item() / (B * world)},
+            "metric": "images/sec (SVI step)", "value": main_leg["value"], "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": main_leg["dtype"], "data": "synthetic",
+            "config": {"workload": "%s %s, batch %d per GPU (global %d), %s, SVI step = ELBO+grads+%sAdam"
+                                   % (name, cfg["desc"], B, B * world, main_leg["arith"], "allreduce+" if world > 1 else ""),
+                       "parallelism": "dp%d" % world, "path": main_leg["path"], "baseline_config": name},
+            "repeats": len(main_leg["regions_s"]), "ms_per_step_all": main_leg["ms_per_step_all"],
+            "ms_per_step_spread": (max(main_leg["ms_per_step_all"]) - min(main_leg["ms_per_step_all"])),
+            "roofline": main_leg["roofline"],
+            "step_algorithmic_tflops": main_leg.get("step_algorithmic_tflops"),
+            "elbo": {k: main_leg[k] for k in ("loss_per_image_first_timed_step", "loss_per_image_last_step",
+                                              "loss_per_image_step0")},
         }
+        if alt is not None:
+            out["fp32_class"] = {"path": alt["path"], "dtype": alt["dtype"], "value": alt["value"], "unit": "images/s",
+                                 "ms_per_step": alt["ms_per_step"], "ms_per_step_all": alt["ms_per_step_all"],
+                                 "kernel_ms": alt["roofline"]["kernel_ms"], "roofline_frac": alt["roofline"]["frac"],
+                                 "loss_per_image_step0": alt["loss_per_image_step0"]}
         if world == 1 and not args.no_cpu_baseline:
-            cb, loss0 = cpu_baseline()
+            cb, loss0 = cpu_baseline(name, cfg)
             out["cpu_baseline"] = cb
             out["elbo"]["oracle_loss_per_image_step0"] = loss0
-            if B == BATCH_PER_GPU:
+            if B == cfg["batch"]:
                 out["elbo"]["rel_err_step0"] = abs(out["elbo"]["loss_per_image_step0"] - loss0) / abs(loss0)
-        if alt is not None:
-            out["fp32_class"] = alt
+        if world == 1 and name == "C2" and not args.no_configs and not args.strong and args.batch is None:
+            # release this process's device memory first, then one short process per side config
+            del main_leg, alt
+            torch.cuda.empty_cache()
+            out["configs"] = [sub_config(c, args) for c in ("C1", "C3", "C4", "C5")]
         print(json.dumps(out))
+    if world > 1:
+        td.destroy_process_group()
 
 
 if __name__ == "__main__":

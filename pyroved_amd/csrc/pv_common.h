@@ -66,26 +66,24 @@ __device__ __forceinline__ void pv_cbern(float a, float x, float& ll, float& dld
   const float pc = fminf(fmaxf(pr, eps), 1.0f - eps);
   const float lg = logf(pc) - log1pf(-pc);
   const float bce = fmaxf(lg, 0.0f) - lg * x + log1pf(expf(-fabsf(lg)));
-  const bool outside = pc <= 0.499f || pc > 0.501f;
   const float t = 1.0f - 2.0f * pc, t2 = t * t;               // log C = log(2 atanh(t) / t)
   float logc, dlogc_da;                                    // d log C / da = (d log C / dp) p (1 - p)
-  if (outside) {
-    const float L = log1pf(-pc) - logf(pc);
-    logc = logf(fabsf(L)) - (pc <= 0.5f ? log1pf(-2.0f * pc) : logf(2.0f * pc - 1.0f));
-  } else {
-    const float d = pc - 0.5f, u = d * d;
-    logc = 0.69314718055994531f + (4.0f / 3.0f + 104.0f / 45.0f * u) * u;
-  }
   if (fabsf(t) < 0.3f) {
-    // the closed form -1/L + 2p(1-p)/(1-2p) cancels catastrophically near p = 1/2 (terms ~1/(4|p-1/2|), result
-    // ~ -t/3): series of the same function, d log C / da = -t s'(t^2) / (2 atanh(t)/t)
+    // torch's closed forms (log|log1p(-p) - log p| - log|1 - 2p| for the value, -1/L + 2p(1-p)/(1-2p) for the
+    // derivative) cancel catastrophically near p = 1/2 — where every pixel of a fresh model sits — so their fp32
+    // value depends on the last bit of the log routines (the reference's own fp32 numbers carry that noise, ~1e-6
+    // per pixel).  Series of the same functions in t^2 (atanh(t)/t = sum t^2k / (2k+1)), exact to fp32 rounding;
+    // inside torch's "unstable region" |p - 1/2| <= 1e-3 they agree with its Taylor branch to 1e-9.
     const float sp = 2.0f / 3 + t2 * (2.0f / 15 + t2 * (2.0f / 35 + t2 * (2.0f / 63 + t2 * (2.0f / 99 + t2 * (2.0f / 143 +
                      t2 * (2.0f / 195 + t2 * (2.0f / 255)))))));
-    const float at = 1.0f + t2 * (1.0f / 3 + t2 * (1.0f / 5 + t2 * (1.0f / 7 + t2 * (1.0f / 9 + t2 * (1.0f / 11 +
-                     t2 * (1.0f / 13 + t2 * (1.0f / 15)))))));
+    const float am1 = t2 * (1.0f / 3 + t2 * (1.0f / 5 + t2 * (1.0f / 7 + t2 * (1.0f / 9 + t2 * (1.0f / 11 +
+                      t2 * (1.0f / 13 + t2 * (1.0f / 15)))))));
+    const float at = 1.0f + am1;
+    logc = 0.69314718055994531f + log1pf(am1);
     dlogc_da = -t * sp / (2.0f * at);
   } else {
     const float L = log1pf(-pc) - logf(pc);
+    logc = logf(fabsf(L)) - (pc <= 0.5f ? log1pf(-2.0f * pc) : logf(2.0f * pc - 1.0f));
     dlogc_da = -1.0f / L + 2.0f * pc * (1.0f - pc) / t;
   }
   const float mask = (pr >= eps && pr <= 1.0f - eps) ? 1.0f : 0.0f;      // clamp's gradient

@@ -350,7 +350,7 @@ def test_model_variants_vs_golden(gpu_device, name, fused):
     # fresh model sits), so the reference's OWN fp32 numbers carry ~1e-3 gradient noise and its loss is a small
     # remainder of B*N terms of size ~0.7: judged on the scale of the sum of terms / with a wider gradient bar; the
     # fp64 evaluation of the same formula is the tight check (test_model_variants_vs_oracle)
-    atol = 2e-7 * x.numel() if cb else 0.0
+    atol = 1e-6 * x.numel() if cb else 0.0       # (1e-6 per term, as test_model_variants_vs_oracle)
     gbar = 5e-3 if cb else 5e-4
     for k in range(meta["steps"]):
         pre = "s%d" % k
