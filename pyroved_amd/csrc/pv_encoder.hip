@@ -342,10 +342,11 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       float v = 0.0f;
       for (int i = 0; i < L; ++i) v += act[cur][rr][coord + i] * ((pfz && i < 4) ? wzp[i] : wz[i]);
       for (int i = 0; i < e.c_dim; ++i) v += e.y[(int64_t)row * e.c_dim + i] * wz[L + i];
+      const float hsc = e.hz_scale != 0.0f ? e.hz_scale : 1.0f;     // (the 8-wave decoder kernel takes C * hz)
       if (K > 0) {
-        for (int k = 0; k < K; ++k) e.hz[((int64_t)k * e.B + row) * e.H0 + j] = v + wz[L + e.c_dim + k];
+        for (int k = 0; k < K; ++k) e.hz[((int64_t)k * e.B + row) * e.H0 + j] = (v + wz[L + e.c_dim + k]) * hsc;
       } else {
-        e.hz[(int64_t)row * e.H0 + j] = v;
+        e.hz[(int64_t)row * e.H0 + j] = v * hsc;
       }
     }
   }

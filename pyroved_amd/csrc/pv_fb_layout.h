@@ -40,13 +40,15 @@ struct PvFbPrep {
   const float* W1; const float* W2;   // (128, 128) fp32, nn.Linear layout
   void* img;                          // 4 * IMG_BYTES
   float* zero; int64_t nzero4;        // float4s to clear (0: none)
+  float scale;                        // images hold scale * W (0: unscaled) — pv_sdec_fused_w8.hip's 2 log2(e)
 };
 __device__ __forceinline__ void pv_fb_prep(const PvFbPrep& p, int64_t t, int64_t T) {
   __bf16* img = reinterpret_cast<__bf16*>(p.img);
   for (int64_t idx = t; idx < 128 * 32; idx += T) {
     const int row = (int)(idx >> 5), c4 = (int)(idx & 31);
-    const f32x4 w1 = reinterpret_cast<const f32x4*>(p.W1)[idx];
-    const f32x4 w2 = reinterpret_cast<const f32x4*>(p.W2)[idx];
+    const float sc = p.scale != 0.0f ? p.scale : 1.0f;
+    const f32x4 w1 = reinterpret_cast<const f32x4*>(p.W1)[idx] * sc;
+    const f32x4 w2 = reinterpret_cast<const f32x4*>(p.W2)[idx] * sc;
     bf16x4 h1, l1, h2, l2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -180,6 +180,7 @@ struct PvEncFwd {
   float* z; float* z_scale; float* z_loc_out; float* z_scale_out;
   float* tp; float* zy; float* kl_part;   // kl_part: (blocks, 2) partial sums of log p(z), log q(z|x)
   float* hz; const float* Wz; int H0;     // fc_latent (null hz: skip)
+  float hz_scale;                   // hz is stored multiplied by this (0: unscaled); see PvFused.hz_scale
   int B, z_dim, c_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior;
   float beta, beta_disc;            // the KL partials in kl_part are stored scaled by these

@@ -151,7 +151,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       const int64_t units = R / FD_UNIT;
       L.f_grid = pv_sdec_fused_grid(units);
       L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
-      if (p->fused >= 2) L.f_kmax *= 4;             // the bf16 kernels publish dL/d(hz) per wave (4 per workgroup)
+      if (p->fused >= 2) L.f_kmax *= pv_sdec_fused_bf16_waves(p->fused == 2);   // the bf16 kernels publish dL/d(hz) per wave
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
       L.f_part_hz = c.take(S * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);
@@ -521,7 +521,8 @@ int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, i
 }
 
 // guide: encoder -> (z_loc, z_scale) -> z = z_loc + z_scale*eps, sampled-KL terms, transform parameters
-int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr) {
+int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr,
+              float hz_scale = 0.0f) {
   if (L.enc_compact) {
     PvEncFwd e{};
     if (prep) e.prep = *prep;
@@ -539,6 +540,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     e.beta = p->beta; e.beta_disc = p->beta_disc; e.K = (int)plan_K(p); e.alpha = L.alpha; e.sw = L.sw;
     e.w = p->row_w;
     if (p->coord_dim > 0) { e.hz = L.hz; e.Wz = p->params + p->fc_latent.w_off; e.H0 = p->fc_coord.out_dim; }
+    e.hz_scale = hz_scale;
     e.B = p->batch; e.z_dim = p->z_dim; e.c_dim = p->c_dim; e.coord_dim = p->coord_dim;
     e.has_r = p->has_r; e.has_t = p->has_t; e.has_s = p->has_s;
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;
@@ -595,12 +597,13 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
   // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
   if (p->fused >= 2 && L.enc_compact) {
-    const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0);
-    PV_TRY(guide_fwd(p, L, s, &prep));
+    const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0, p->fused == 2);
+    f.hz_scale = prep.scale;                          // the compact encoder's last launch writes scale * hz directly
+    PV_TRY(guide_fwd(p, L, s, &prep, f.hz_scale));
   } else {
     PV_TRY(guide_fwd(p, L, s));
     if (p->fused >= 2) {
-      PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, s));
+      PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, p->fused == 2, s));
     } else if (want_grads) {
       hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(S * L.f_kmax * H) * sizeof(float), s);
       if (e != hipSuccess) return (int)e;

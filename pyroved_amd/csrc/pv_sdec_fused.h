@@ -15,7 +15,8 @@ struct PvFused {
   const float* x;        // (M) observations, M = B*N rows (b, n)
   const float* grid;     // (N, cd)
   const float* tp;       // (B, 8) cos, sin, scale, tx, ty
-  const float* hz;       // (B, H) fc_latent(z)
+  const float* hz;       // (B, H) fc_latent(z), multiplied by hz_scale when that is non-zero
+  float hz_scale;        // what the producer of hz already multiplied it by (pv_sdec_fused_w8.hip wants 2 log2(e) * hz)
   const float *Wc, *bc;  // coord_latent.fc_coord (H, cd), (H)
   const float *W1, *b1;  // decoder.fc_layers.0 (H, H), (H)
   const float *W2, *b2;  // decoder.fc_layers.2
@@ -46,11 +47,16 @@ int pv_sdec_fused_kmax(int n_pix, int64_t units, int grid);
 int pv_sdec_fused_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
 // same interface, bf16 split-precision ("bf16x3") matrix math (pv_sdec_fused_bf16.hip); _prep must run first on the
 // same stream, once per parameter state: it writes f.wimg and, with grads, zero-fills f.part_hz
-int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s);
+// x3: split precision (pv_sdec_fused_bf16.hip) or plain bf16 operands (pv_sdec_fused_w8.hip, whose images are
+// pre-scaled by 2 log2(e); PV_W8=0 in the environment selects the older 4-wave plain-bf16 kernel instead)
+int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s);
 // ... or, as arguments for a kernel that hosts the preparation (pv_fb_layout.h: pv_fb_prep)
 struct PvFbPrep;
-PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads);
+PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3);
 int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s);
+int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
+// waves per workgroup that publish a dL/d(hz) slot (sizes part_hz)
+int pv_sdec_fused_bf16_waves(bool x3);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
 struct PvFusedOffsets { int64_t W1, b1, W2, b2, Wc, wo, bo; };
 int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int dwo_slots,

@@ -808,17 +808,26 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_trace), n * sizeof(long long));
 }
 
-PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads) {
+// the plain-bf16 path runs the 8-wave kernel (pv_sdec_fused_w8.hip) unless PV_W8=0 asks for the 4-wave one (A/B runs)
+static bool fb_use_w8() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PV_W8"); v = (e && atoi(e) == 0) ? 0 : 1; }
+  return v != 0;
+}
+int pv_sdec_fused_bf16_waves(bool x3) { return (!x3 && fb_use_w8()) ? 8 : FB_WAVES; }
+
+PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   static_assert(FB_WIMG_BYTES == 4 * IMG_BYTES, "pv_sdec_fused.h and the LDS image layout disagree");
   PvFbPrep p{};
   p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz;
   p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
+  p.scale = (!x3 && fb_use_w8()) ? 2.8853900817779268f : 0.0f;
   return p;
 }
 
-int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s) {
+int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s) {
   if (!f.wimg) return PV_EINVAL;
-  const PvFbPrep p = pv_sdec_fused_bf16_prep_args(f, grads);
+  const PvFbPrep p = pv_sdec_fused_bf16_prep_args(f, grads, x3);
   const int64_t work = p.nzero4 > FD_H * (FD_H / 4) ? p.nzero4 : FD_H * (FD_H / 4);
   int blocks = (int)((work + 255) / 256);
   if (blocks > 256) blocks = 256;
@@ -828,6 +837,7 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, hipStream_t s) {
 }
 
 int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s) {
+  if (!x3 && fb_use_w8()) return pv_sdec_fused_w8_launch(f_in, grid, grads, s);
   PvFused f = f_in;
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }

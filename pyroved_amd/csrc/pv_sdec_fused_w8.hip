@@ -1,0 +1,752 @@
+// pv_sdec_fused_w8.hip — the fused persistent spatial-decoder forward+backward kernel, plain-bf16 operands
+// (SVItrainer(precision="bf16"), plan.fused = 3), re-cut for TWO waves per SIMD.
+//
+// Why.  The 4-wave form of this kernel (pv_sdec_fused_bf16.hip, X3 = false) measured 14 % of the bf16 MFMA peak with the
+// matrix pipe busy 16 % of the time: one wave per SIMD issues about one instruction every 4-5 cycles, and a 64-row tile
+// is ~3.2 k instructions per wave (1.7 k of them VALU) — the tile was ISSUE bound, with nothing to hide fill / drain
+// latencies behind.  This form
+//   * runs 8 waves per workgroup (512 threads, one workgroup per CU, two waves per SIMD, <= 256 registers each), a tile
+//     is 128 rows, each wave carries one 16-row unit and owns ONE 16-row slice of dW1 / dW2 in accumulators;
+//   * moves every small contraction that sat on the VALU onto the matrix cores, which have slack:
+//       - the coordinate layer (K = 2 plus bias) is one v_mfma_f32_16x16x16_bf16 per output block with hi/lo split
+//         operands (w x ~= wh xh + wh xl + wl xh), the per-sample fc_latent term enters as the accumulator's initial value;
+//       - its row-local input gradient (d0, d1 = dpre0 . Wc[:, 0 / 1]) is a 4-MFMA "dgrad" against a 16-row table
+//         [Wc0 hi; Wc0 lo; Wc1 hi; Wc1 lo; 0 ...];
+//       - the column sums over a unit's rows — d(wo) = sum dlda h2, dL/d(hz) = sum dpre0, dWc_k = sum dpre0 x'_k — are
+//         wave-local MFMAs: the wave writes its 16 x 128 bf16 tile into its OWN rows of the staging area, reads it back
+//         transposed (ds_read_b64_tr_b16) as the A operand and contracts against B = [1 | x0 | x1 | dlda (hi / lo columns)];
+//         one 32-register accumulator holds all four sums for the whole kernel (dL/d(hz) is flushed per sample);
+//   * drops the multiply of every tanh: the weight images, the biases and the coordinate layer's operands are stored
+//     pre-scaled by c = 2 log2(e), so the MFMAs deliver c * pre-activation and tanh = 1 - 2 rcp(exp2(.) + 1) is four
+//     instructions; the backward pass then carries c * dpre1 and c^2 * dpre0 and un-scales where a gradient leaves the
+//     kernel (dW1, db1, dWc, dL/d(hz), the per-row transform gradients).
+// Layout, row -> lane mapping, weight images, staging swizzles and the per-workgroup gradient record are those of
+// pv_sdec_fused_bf16.hip (pv_fb_layout.h), so the rest of the step is unchanged.
+//
+// LDS (158,976 B): W1 | W2 images (bf16, 32 KB each) | staging A | staging B (128 rows x 144 bf16 each, shared by the
+// two wgrad rounds of a tile) | wo, c b1, c b2 | coordinate-layer A table | row-local dgrad A table | per-row scalars
+// | per-wave prefetch slots.  Four workgroup barriers per 128-row tile.
+#include "pv_sdec_fused.h"
+#include "pv_fb_layout.h"
+#include <stdlib.h>
+
+typedef short short4_ __attribute__((ext_vector_type(4)));
+typedef short short8_ __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) short4_ lds_short4;
+
+#define W8_WAVES 8
+#define W8_ROWS (W8_WAVES * FD_UNIT)       // 128
+#define W8_THREADS (64 * W8_WAVES)
+#define LDS2 144                           // staging rows: 72 dwords -> conflict-free 4x16 transposing reads
+#define W8_ARR (W8_ROWS * LDS2)            // elements of one staging array
+#define W8_ARR_BYTES (2 * W8_ARR)          // 36,864
+#define WO_W1 0
+#define WO_W2 IMG_BYTES
+#define WO_SA (2 * IMG_BYTES)
+#define WO_SB (WO_SA + W8_ARR_BYTES)
+#define WO_VEC (WO_SB + W8_ARR_BYTES)      // fp32: wo[128], c*b1[128], c*b2[128]
+#define WO_ATAB (WO_VEC + 3 * FD_H * 4)    // coordinate layer, A operands: 8 blocks x 64 lanes x bf16x4
+#define WO_TTAB (WO_ATAB + 8 * 64 * 8)     // row-local dgrad, A operands: 4 k-blocks x 64 lanes x bf16x8
+#define WO_INFO (WO_TTAB + 4 * 64 * 16)    // per row of the tile: x0[128], x1[128], dlda[128]
+#define WO_RED (WO_INFO + 3 * W8_ROWS * 4)
+#define WO_CHZ (WO_RED + 256)              // next tile's per-unit inputs by LDS-DMA: hz[b] (128 floats) per wave
+#define WO_CTP (WO_CHZ + W8_WAVES * FD_H * 4)
+#define WO_CGR (WO_CTP + W8_WAVES * 256)
+#define W8_LDS_BYTES (WO_CGR + W8_WAVES * 256)
+static_assert(W8_LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(2 * IMG_BYTES % (W8_WAVES * 1024) == 0, "image load: whole 1 KB LDS-DMA pieces per wave");
+
+#define W8_C 2.8853900817779268f           // 2 log2(e): tanh(x) = 1 - 2 / (exp2(C x) + 1)
+#define W8_RC (1.0f / W8_C)
+#define W8_RC2 (W8_RC * W8_RC)
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define BERN_EPS 1.1920928955078125e-07f
+#define W8_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 w8_mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4_, a), __builtin_bit_cast(short4_, b), c, 0, 0, 0);
+}
+// tanh of x given C*x
+__device__ __forceinline__ float w8_tanhc(float cx) {
+  const float e = __builtin_amdgcn_exp2f(cx);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float w8_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float w8_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float w8_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ bf16x8 w8_cat(const bf16x4& a, const bf16x4& b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ int w8_opaque0() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+__device__ __forceinline__ bf16x4 w8_tr(const __bf16* p) {
+  const short4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+__device__ __forceinline__ bf16x4 w8_zero4() { const short4_ z = {0, 0, 0, 0}; return __builtin_bit_cast(bf16x4, z); }
+// LDS-DMA (see pv_sdec_fused_bf16.hip: not in hipcc's waitcnt bookkeeping; drain explicitly)
+__device__ __forceinline__ void w8_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void w8_glds4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void w8_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void w8_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); }
+__device__ __forceinline__ float w8_sum_q(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// forward layer of the wave's unit: out = bias + W in, both pre-scaled by C (C * pre-activation on return)
+__device__ __forceinline__ void w8_layer_fwd(const __bf16* __restrict__ Wh, const float* __restrict__ bs,
+                                             const bf16x4 (&ih)[8], f32x4 (&out)[8], int r, int q) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
+  // row 16*ob + r, logical chunk 4m + q  ->  physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])   (pv_fb_layout.h)
+  r |= w8_opaque0();
+  const __bf16* ah = Wh + r * LDB + 8 * (q ^ fb_sl(r >> 2));
+  int xm[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) xm[m] = 32 * (m ^ (r & 3));
+  bf16x8 wh[2][2];
+  auto load = [&](int g, bf16x8 (&h)[2]) {
+    const int m = g >> 2, op = (g & 3) * 2;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) h[o] = *reinterpret_cast<const bf16x8*>(ah + 16 * (op + o) * LDB + xm[m]);
+  };
+  load(0, wh[0]);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int m = g >> 2, op = (g & 3) * 2;
+    if (g + 1 < 16) load(g + 1, wh[(g + 1) & 1]);
+    W8_FENCE();
+    const bf16x8 bh = w8_cat(ih[2 * m], ih[2 * m + 1]);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) out[op + o] = MFMA32(wh[g & 1][o], bh, out[op + o]);
+    W8_FENCE();
+  }
+}
+
+// dgrad of the wave's unit: out[k] = sum_j (C W)[j][k] dp[j]; A = W^T via the transposing LDS read
+__device__ __forceinline__ void w8_layer_dgrad(const __bf16* __restrict__ Wh, const bf16x4 (&ih)[8], f32x4 (&out)[8],
+                                               int r, int q) {
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) out[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  r |= w8_opaque0();
+  const __bf16* ah = Wh + (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q));
+  int xk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = 32 * (kk ^ (r >> 2));
+  bf16x8 wh[2][2];
+  auto load = [&](int g, bf16x8 (&h)[2]) {
+    const int m = g >> 2, kp = (g & 3) * 2;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int off = 32 * m * LDB + xk[(kp + o) >> 1] + 4 * ((kp + o) & 1);
+      h[o] = w8_cat(w8_tr(ah + off), w8_tr(ah + off + 16 * LDB));
+    }
+  };
+  load(0, wh[0]);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int m = g >> 2, kp = (g & 3) * 2;
+    if (g + 1 < 16) load(g + 1, wh[(g + 1) & 1]);
+    W8_FENCE();
+    const bf16x8 bh = w8_cat(ih[2 * m], ih[2 * m + 1]);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) out[kp + o] = MFMA32(wh[g & 1][o], bh, out[kp + o]);
+    W8_FENCE();
+  }
+}
+
+// Elementwise phases are written as STAGES over all 32 values of a lane with scheduling fences in between: left alone,
+// the compiler (at the 256-register limit) walks the values two at a time through the whole dependent chain
+// (exp -> add -> rcp -> fma -> cvt), and an in-order wave then pays every instruction's latency (~10 cycles each).
+// tanh of x given C*x, in place: 1 - 2 rcp(exp2(.) + 1)
+__device__ __forceinline__ void w8_tanh8(f32x4 (&v)[8]) {
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[jb][i] = __builtin_amdgcn_exp2f(v[jb][i]);
+  W8_FENCE();
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) v[jb] = v[jb] + 1.0f;
+  W8_FENCE();
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[jb][i] = __builtin_amdgcn_rcpf(v[jb][i]);
+  W8_FENCE();
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) v[jb] = 1.0f - 2.0f * v[jb];
+  W8_FENCE();
+}
+__device__ __forceinline__ f32x4 w8_f32_of(const bf16x4& h) {
+  typedef unsigned uint2_ __attribute__((ext_vector_type(2)));
+  const uint2_ u = __builtin_bit_cast(uint2_, h);
+  f32x4 f;
+  f[0] = __builtin_bit_cast(float, u[0] << 16);
+  f[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+  f[2] = __builtin_bit_cast(float, u[1] << 16);
+  f[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+  return f;
+}
+// d *= 1 - h^2 with h saved as bf16, four blocks at a time
+__device__ __forceinline__ void w8_mul_dtanh(f32x4 (&d)[8], const bf16x4 (&hb)[8]) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 t[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) t[jb] = w8_f32_of(hb[4 * half + jb]);
+    W8_FENCE();
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) t[jb] = 1.0f - t[jb] * t[jb];
+    W8_FENCE();
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) d[4 * half + jb] = d[4 * half + jb] * t[jb];
+    W8_FENCE();
+  }
+}
+
+__device__ __forceinline__ void w8_cvt8(const f32x4 (&v)[8], bf16x4 (&h)[8]) {
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[jb][i] = (__bf16)v[jb][i];
+}
+// the wave's 16 rows (row = 16 * wave + r) of a staged tensor, row-major [128][LDS2]; inside every 16-column block the
+// four 8-byte pieces are XOR-swizzled by (row>>2)&3 (pv_sdec_fused_bf16.hip: fb_stage_store)
+__device__ __forceinline__ void w8_stage_store(__bf16* __restrict__ sh, const bf16x4 (&h)[8], int row, int q) {
+  row |= w8_opaque0();
+  const int e = row * LDS2 + 4 * (q ^ ((row >> 2) & 3));
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<bf16x4*>(sh + e + 16 * jb) = h[jb];
+}
+// lane offset of the transposing read of staged rows R0 + 4q .. 4q+3 (R0 a multiple of 16), columns 16*blk ..
+__device__ __forceinline__ int w8_stage_toff(int r, int q) { return (4 * q + (r >> 2)) * LDS2 + 4 * ((r & 3) ^ q); }
+
+// wgrad over the staged tile.  Wave (jp = wave >> 1, kh = wave & 1) owns the 32 x 64 block dW[32jp .. +31][64kh .. +63]
+// (2 A operands x 4 B operands per 32 staged rows: 12 transposing reads per 8 MFMAs; a 16 x 128 slice per wave needs
+// 18) and the bias sums of rows 32jp + 16kh .. +15 (an MFMA against ones):
+//   dW[j][k] += sum_rows dpre[row][j] h[row][k];   db[j] += sum_rows dpre[row][j]
+__device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16* sb, f32x4 (&accW)[2][4], f32x4& accB,
+                                                 int wave, int r, int q, int ksteps) {
+  const int toff = w8_stage_toff(r | w8_opaque0(), q);
+  const int jp = wave >> 1, kh = wave & 1;
+  const short one = 0x3f80;                           // bf16 1.0
+  const short8_ ones_s = {one, one, one, one, one, one, one, one};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int koff = toff + 32 * ks * LDS2;
+    bf16x8 a[2], b[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int off = koff + 32 * jp + 16 * s_;
+      a[s_] = w8_cat(w8_tr(sa + off), w8_tr(sa + off + 16 * LDS2));
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int off = koff + 64 * kh + 16 * o;
+      b[o] = w8_cat(w8_tr(sb + off), w8_tr(sb + off + 16 * LDS2));
+    }
+    W8_FENCE();
+    accB = MFMA32(kh ? a[1] : a[0], ones, accB);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) accW[s_][o] = MFMA32(a[s_], b[o], accW[s_][o]);
+    W8_FENCE();
+  }
+}
+
+// wave-local column sums on the matrix cores: accS[jb][.] (D[j][n]) += sum over the unit's 16 rows of t[row][j] * Bn[row][n].
+// The wave stages its bf16 tile `t` in its own rows of `sc` (nobody else reads them at this point of the tile), reads it
+// back transposed as the A operand and contracts against `bop` (lane (n, kq): B[4kq..4kq+3][n]).
+__device__ __forceinline__ void w8_colsum_mfma(__bf16* __restrict__ sc, const bf16x4 (&t)[8], const bf16x4& bop,
+                                               f32x4 (&accS)[8], int wave, int r, int q) {
+  w8_stage_store(sc, t, 16 * wave + r, q);
+  w8_wait_lgkm0();
+  const __bf16* base = sc + (16 * wave) * LDS2 + w8_stage_toff(r | w8_opaque0(), q);
+  bf16x4 a[8];
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) a[jb] = w8_tr(base + 16 * jb);
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) accS[jb] = w8_mfma16(a[jb], bop, accS[jb]);
+}
+
+// phase-timing trace (profiling builds only: -DW8_TRACE): shader-clock stamps of workgroup 0, waves 0 and 7, first tiles
+#ifdef W8_TRACE
+__device__ long long w8_trace[512];
+#define W8_STAMP(k)                                                                              \
+  do {                                                                                           \
+    if (g == 0 && lane == 0 && (wave == 0 || wave == 7) && tile_no < 8)                          \
+      w8_trace[(wave ? 256 : 0) + tile_no * 16 + (k)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int pv_debug_read_trace_w8(long long* out, int n) {
+  if (n > 512) n = 512;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w8_trace), n * sizeof(long long));
+}
+#else
+#define W8_STAMP(k) do { } while (0)
+#endif
+
+// LIK: the likelihood is a compile-time choice
+template <bool GRADS, int LIK>
+__global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
+  extern __shared__ __attribute__((aligned(16))) char smb[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x, G = gridDim.x;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smb);
+  const __bf16* W1h = reinterpret_cast<const __bf16*>(smb + WO_W1);
+  const __bf16* W2h = reinterpret_cast<const __bf16*>(smb + WO_W2);
+  __bf16* sA = reinterpret_cast<__bf16*>(smb + WO_SA);
+  __bf16* sB = reinterpret_cast<__bf16*>(smb + WO_SB);
+  float* vec = reinterpret_cast<float*>(smb + WO_VEC);
+  float* info = reinterpret_cast<float*>(smb + WO_INFO);
+  float* red = reinterpret_cast<float*>(smb + WO_RED);
+  const char* gimg = reinterpret_cast<const char*>(f.wimg);
+
+  // ---- prologue: weight images by LDS-DMA (W1 at image 0, W2 at image 2 of the prepared set), vectors and tables ----
+  {
+    constexpr int PIECES = IMG_BYTES / (W8_WAVES * 1024);
+#pragma unroll
+    for (int c = 0; c < PIECES; ++c) {
+      const int off = (wave * PIECES + c) * 1024;
+      w8_glds16(gimg + off + lane * 16, lds0 + WO_W1 + off);
+      w8_glds16(gimg + 2 * IMG_BYTES + off + lane * 16, lds0 + WO_W2 + off);
+    }
+  }
+  if (tid < FD_H) {
+    vec[tid] = f.wo[tid];
+    vec[FD_H + tid] = W8_C * f.b1[tid];
+    vec[2 * FD_H + tid] = W8_C * f.b2[tid];
+  }
+  {
+    // coordinate layer A operands (v_mfma_f32_16x16x16_bf16: lane (m, kq) holds A[m][4kq .. 4kq+3]), k slots:
+    //   kq 0: [wh0 wh0 wl0 0] x [xh0 xl0 xh0 0]   kq 1: the same for coordinate 1   kq 2: [bch bcl 0 0] x [1 1 0 0]
+    const int jb = tid >> 6, m = lane & 15, kq = lane >> 4, j = 16 * jb + m;
+    float v = 0.0f;
+    if (kq == 0) v = W8_C * f.Wc[j * f.cd];
+    else if (kq == 1) v = f.cd == 2 ? W8_C * f.Wc[j * 2 + 1] : 0.0f;
+    else if (kq == 2) v = W8_C * f.bc[j];
+    __bf16 hi, lo;
+    fb_split(v, hi, lo);
+    bf16x4 a = w8_zero4();
+    if (kq < 2) { a[0] = hi; a[1] = hi; a[2] = lo; }
+    else if (kq == 2) { a[0] = hi; a[1] = lo; }
+    reinterpret_cast<bf16x4*>(smb + WO_ATAB)[tid] = a;
+  }
+  if (tid < 256) {
+    // row-local dgrad A operands (16x16x32: lane (m, kq) holds A[m][k], k = the 8 logical columns a lane feeds as B:
+    // 32mm + 4kq + e (e < 4), 32mm + 16 + 4kq + (e - 4)); rows m: 0 Wc0 hi, 1 Wc0 lo, 2 Wc1 hi, 3 Wc1 lo, others 0
+    const int mm = tid >> 6, m = lane & 15, kq = lane >> 4;
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = 32 * mm + 4 * kq + (e < 4 ? e : 16 + e - 4);
+      float w = 0.0f;
+      if (m < 2) w = f.Wc[j * f.cd];
+      else if (m < 4 && f.cd == 2) w = f.Wc[j * 2 + 1];
+      __bf16 hi, lo;
+      fb_split(w, hi, lo);
+      a[e] = m >= 4 ? (__bf16)0.0f : ((m & 1) ? lo : hi);
+    }
+    reinterpret_cast<bf16x8*>(smb + WO_TTAB)[tid] = a;
+  }
+  w8_wait_vm0();
+  __syncthreads();
+  const float bo = f.bo[0];
+
+  // persistent accumulators: the wave's slice (rows 16*wave .. +15) of dW1 (x C) and dW2, the bias sums, and the
+  // wave-local column sums D[j][n]: n = 0 dL/d(hz) | 1, 5 dWc0 (hi, lo) | 2, 6 dWc1 | 3, 4 d(wo)   (n 0,1,2,5,6 carry C^2)
+  f32x4 accW1[2][4], accW2[2][4], accS[8], accB1 = {0, 0, 0, 0}, accB2 = {0, 0, 0, 0};
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    accW1[kb >> 2][kb & 3] = f32x4{0, 0, 0, 0}; accW2[kb >> 2][kb & 3] = f32x4{0, 0, 0, 0}; accS[kb] = f32x4{0, 0, 0, 0};
+  }
+  float dbo = 0.0f;
+  int cur_b = -1;                                    // the sample whose dL/d(hz) this WAVE is accumulating
+  const int upb = f.N / FD_UNIT;
+  float* rec = f.part + (int64_t)g * FD_REC;
+
+  auto flush_hz = [&](int b) {
+    // the wave's rows of sample b end: publish its partial dL/d(hz[b]) (column 0 of accS: lanes r == 0) in its own slot
+    const int64_t ub = (int64_t)b * upb;
+    const int gfirst = (int)(((ub + 1) * G + f.units - 1) / f.units) - 1;
+    float* dst = f.part_hz + ((int64_t)b * f.kmax + (g - gfirst) * W8_WAVES + wave) * FD_H + 4 * q;
+    if (r == 0) {
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<f32x4*>(dst + 16 * jb) = accS[jb] * W8_RC2;
+    }
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accS[jb][i] = r == 0 ? 0.0f : accS[jb][i];
+  };
+
+  // units are 32-bit here (the launcher falls back to the 4-wave kernel beyond 2^31 rows), and a unit's sample b / offset
+  // inside the sample / observation unit are carried incrementally from tile to tile: no integer division in the loop
+  const int u_lo = (int)((int64_t)g * f.units / G), u_hi = (int)((int64_t)(g + 1) * f.units / G);
+  const int xun = (int)f.x_units;
+  struct Pos { int unit, b, loc, xu; };                 // unit = b * upb + loc ; xu = unit mod x_units (x_units > 0)
+  auto pos_of = [&](int unit_) {
+    Pos p_;
+    p_.unit = unit_; p_.b = unit_ / upb; p_.loc = unit_ - p_.b * upb; p_.xu = xun > 0 ? unit_ % xun : unit_;
+    return p_;
+  };
+  auto advance = [&](Pos& p_, int by) {
+    p_.unit += by; p_.loc += by; p_.xu += by;
+    while (p_.loc >= upb) { p_.loc -= upb; ++p_.b; }
+    if (xun > 0) { while (p_.xu >= xun) p_.xu -= xun; }
+  };
+  const Pos pos_lo = pos_of(u_lo);                      // what an out-of-range wave fetches instead (valid, unused)
+  Pos pos_cur = pos_of(u_lo + wave < u_hi ? u_lo + wave : u_lo);
+  Pos pos_nx = pos_cur;
+  float sw_next = 1.0f;
+  auto x_of = [&](const Pos& p_) -> float {
+    if (f.sw) sw_next = f.sw[p_.b];
+    return f.x[(int64_t)p_.xu * FD_UNIT + r];
+  };
+  float xv_next = x_of(pos_cur);
+  float* chz = reinterpret_cast<float*>(smb + WO_CHZ) + wave * FD_H;
+  float* ctp = reinterpret_cast<float*>(smb + WO_CTP) + wave * 64;
+  float* cgr = reinterpret_cast<float*>(smb + WO_CGR) + wave * 64;
+  auto fetch_unit_inputs = [&](const Pos& p_) {
+    const int n0 = p_.loc * FD_UNIT;
+    w8_glds4(f.hz + (int64_t)p_.b * FD_H + lane, lds0 + WO_CHZ + wave * (FD_H * 4));
+    w8_glds4(f.hz + (int64_t)p_.b * FD_H + 64 + lane, lds0 + WO_CHZ + wave * (FD_H * 4) + 256);
+    w8_glds4(f.tp + (int64_t)p_.b * 8 + (lane & 7), lds0 + WO_CTP + wave * 256);
+    w8_glds4(f.grid + (int64_t)n0 * f.cd + (lane & (16 * f.cd - 1)), lds0 + WO_CGR + wave * 256);
+  };
+  fetch_unit_inputs(pos_cur);
+  int tile_no = -1;
+  for (int ut = u_lo; ut < u_hi; ut += W8_WAVES) {
+    ++tile_no;
+    asm volatile("; W8_TILE_BEGIN");
+    W8_STAMP(0);
+    const int nact = (u_hi - ut) < W8_WAVES ? (u_hi - ut) : W8_WAVES;
+    // the unit this wave fetches for the NEXT tile
+    if (ut + W8_WAVES + wave < u_hi) advance(pos_nx, W8_WAVES);
+    else pos_nx = pos_lo;
+    int opq = 0;
+    asm volatile("" : "+v"(opq));       // loop-variant zero: keeps LICM from hoisting the LDS-resident vectors
+    const float* wos = vec + opq;
+    const float* b1s = vec + FD_H + opq;
+    const float* b2s = vec + 2 * FD_H + opq;
+    const bool act = wave < nact;
+    const int unit = act ? pos_cur.unit : ut;
+    const int bu = pos_cur.b;
+    const int64_t row = (int64_t)unit * FD_UNIT + r;
+    float x0, x1, u0c, u1c, sc;
+    w8_wait_vm0();                        // this wave's LDS-DMA of the tile's inputs (issued a tile ago)
+    {
+      const float* t = ctp + opq;
+      const float* gr = cgr + opq;
+      if (f.cd == 2) {
+        const float gx = gr[2 * r], gy = gr[2 * r + 1];
+        u0c = gx * t[0] - gy * t[1];
+        u1c = gx * t[1] + gy * t[0];
+        sc = t[2];
+        x0 = u0c * sc + t[3];
+        x1 = u1c * sc + t[4];
+      } else {
+        u0c = gr[r]; u1c = 0.0f; sc = 1.0f;
+        x0 = u0c + t[3]; x1 = 0.0f;
+      }
+    }
+    const float xv = xv_next, swv = sw_next;
+    float* inf_x0 = info + 16 * wave + opq;
+    float* inf_x1 = info + W8_ROWS + 16 * wave + opq;
+    float* inf_dl = info + 2 * W8_ROWS + 16 * wave + opq;
+
+    // saved activations live as bf16 only (h0b, h1b): fp32 copies next to the 104 accumulator registers do not fit
+    // two waves per SIMD; the backward pass forms 1 - h^2 from them (bf16-relative precision, like every MFMA operand here)
+    f32x4 tC[8];
+    bf16x4 pA[8], h0b[8], h1b[8];
+    float dlda = 0.0f;
+    if (act) {
+      // ---- coordinate layer on the matrix cores: C h0pre = (C Wc) x' + C bc + C hz[b] ----
+      bf16x4 bx = w8_zero4();
+      {
+        const float v = q == 0 ? x0 : x1;
+        __bf16 vh, vl;
+        fb_split(v, vh, vl);
+        const __bf16 one = (__bf16)1.0f;
+        if (q < 2) { bx[0] = vh; bx[1] = vl; bx[2] = vh; }
+        else if (q == 2) { bx[0] = one; bx[1] = one; }
+      }
+      const bf16x4* atab = reinterpret_cast<const bf16x4*>(smb + WO_ATAB) + lane + opq;
+      const float* hzb = chz + opq;
+      bf16x4 aop[8];
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) {
+        tC[jb] = *reinterpret_cast<const f32x4*>(hzb + 16 * jb + 4 * q);
+        aop[jb] = atab[64 * jb];
+      }
+      if (GRADS && q == 0) { inf_x0[r] = x0; inf_x1[r] = x1; }
+      W8_FENCE();
+      if (f.hz_scale == 0.0f) {                  // hz arrives unscaled only when the generic encoder path produced it
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) tC[jb] = tC[jb] * W8_C;
+      }
+      W8_FENCE();
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) tC[jb] = w8_mfma16(aop[jb], bx, tC[jb]);
+      W8_FENCE();
+      w8_tanh8(tC);
+      w8_cvt8(tC, h0b);
+    }
+    asm volatile("; W8_P1_coord_done");
+    W8_STAMP(1);
+    fetch_unit_inputs(pos_nx);                 // the slots were consumed by the coordinate layer above
+    if (act) {
+      w8_layer_fwd(W1h, b1s, h0b, tC, r, q);
+      w8_tanh8(tC);
+      w8_cvt8(tC, h1b);                                             // feeds layer 2 and its wgrad
+      asm volatile("; W8_P2_l1_done");
+    W8_STAMP(2);
+      w8_layer_fwd(W2h, b2s, h1b, tC, r, q);
+      // ---- h2, output layer + likelihood (fp32); tC <- g = wo (1 - h2^2), pA <- bf16(h2) ----
+      w8_tanh8(tC);                                                // tC = h2
+      f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * jb + 4 * q);
+        part4 = part4 + tC[jb] * wv;
+        if (GRADS) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pA[jb][i] = (__bf16)tC[jb][i];
+          const f32x4 t2 = tC[jb] * tC[jb];
+          tC[jb] = wv - wv * t2;
+        }
+      }
+      const float a = w8_sum_q((part4[0] + part4[1]) + (part4[2] + part4[3])) + bo;
+      float ll, locv;
+      if (LIK == PV_LIK_BERNOULLI) {
+        const float pr = w8_rcp(1.0f + w8_exp(-a));
+        const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
+        const float lg = w8_log(pc) - w8_log(1.0f - pc);
+        ll = -(fmaxf(lg, 0.0f) - lg * xv + w8_log(1.0f + w8_exp(-fabsf(lg))));
+        const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
+        dlda = (w8_rcp(1.0f + w8_exp(-lg)) - xv) * mask;
+        locv = pr;
+      } else if (LIK == PV_LIK_CBERNOULLI) {
+        pv_cbern(a, xv, ll, dlda, locv);
+      } else {
+        const float pr = f.sigmoid_out ? w8_rcp(1.0f + w8_exp(-a)) : a;
+        const float d = xv - pr;
+        ll = -(d * d) / (2.0f * f.sig * f.sig) - w8_log(f.sig) - LOG_SQRT_2PI;
+        dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+        locv = pr;
+      }
+      dlda *= swv;
+      if (q == 0) {
+        f.llrow[row] = ll;
+        if (f.loc) f.loc[row] = locv;
+        if (GRADS) { dbo += dlda; inf_dl[r] = dlda; }
+      }
+      xv_next = x_of(pos_nx);
+    }
+    pos_cur = pos_nx;                          // (unit, bu, row of THIS tile were taken above)
+    asm volatile("; W8_P3_fwd_done");
+    W8_STAMP(3);
+    if (!GRADS) continue;
+    const int ksteps = (nact + 1) >> 1;
+    if (act) {
+      // ---- d(wo) += sum_rows dlda h2 : wave-local MFMA through the wave's own rows of staging A (free: every wave
+      // passed barrier 4 of the previous tile); B = dlda of rows 4q..4q+3 in columns 3 (hi) and 4 (lo)
+      w8_wait_lgkm0();
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(inf_dl + 4 * q);
+      bf16x4 bw = w8_zero4();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __bf16 hi, lo;
+        fb_split(d4[i], hi, lo);
+        bw[i] = r == 3 ? hi : (r == 4 ? lo : (__bf16)0.0f);
+      }
+      w8_colsum_mfma(sA, pA, bw, accS, wave, r, q);
+      // dpre2 = dlda * wo (1 - h2^2)
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) tC[jb] = tC[jb] * dlda;
+      w8_cvt8(tC, pA);                                            // feeds the wgrad and the dgrad of layer 2
+    } else {
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) { pA[jb] = w8_zero4(); h1b[jb] = w8_zero4(); h0b[jb] = w8_zero4(); }
+    }
+    asm volatile("; W8_P4_dwo_done");
+    W8_STAMP(4);
+    // ---- wgrad of layer 2: stage (dpre2, h1) of all 128 rows, one pass ----
+    w8_stage_store(sA, pA, 16 * wave + r, q);
+    w8_stage_store(sB, h1b, 16 * wave + r, q);
+    __syncthreads();                                                // barrier 1
+    asm volatile("; W8_P5_bar1");
+    W8_STAMP(5);
+    w8_wgrad_consume(sA, sB, accW2, accB2, wave, r, q, ksteps);
+    asm volatile("; W8_P6_cons2");
+    W8_STAMP(6);
+    bf16x4 p0[8];
+    if (act) {
+      w8_layer_dgrad(W2h, pA, tC, r, q);                           // tC = C dL/dh1
+      w8_mul_dtanh(tC, h1b);                                      // C dpre1
+      w8_cvt8(tC, pA);                                            // feeds the dgrad and the wgrad of layer 1
+      asm volatile("; W8_P7_dgrad2");
+    W8_STAMP(7);
+      w8_layer_dgrad(W1h, pA, tC, r, q);                           // tC = C^2 dL/dh0
+      w8_mul_dtanh(tC, h0b);                                      // C^2 dpre0
+      w8_cvt8(tC, p0);
+    } else {
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) { pA[jb] = w8_zero4(); p0[jb] = w8_zero4(); }
+    }
+    asm volatile("; W8_P8_dgrad1");
+    W8_STAMP(8);
+    __syncthreads();                                                // barrier 2: round 1 consumed everywhere
+    W8_STAMP(9);
+    // ---- wgrad of layer 1: stage (C dpre1, h0) ----
+    w8_stage_store(sA, pA, 16 * wave + r, q);
+    w8_stage_store(sB, h0b, 16 * wave + r, q);
+    __syncthreads();                                                // barrier 3
+    asm volatile("; W8_P10_bar3");
+    W8_STAMP(10);
+    w8_wgrad_consume(sA, sB, accW1, accB1, wave, r, q, ksteps);
+    asm volatile("; W8_P11_cons1");
+    W8_STAMP(11);
+    if (act) {
+      // ---- coordinate layer backward, row-local part on the matrix cores: D[m][row] = sum_j T[m][j] dpre0[row][j] ----
+      f32x4 dd = {0.0f, 0.0f, 0.0f, 0.0f};
+      const bf16x8* ttab = reinterpret_cast<const bf16x8*>(smb + WO_TTAB) + lane + opq;
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm) dd = MFMA32(ttab[64 * mm], w8_cat(p0[2 * mm], p0[2 * mm + 1]), dd);
+      if (q == 0) {
+        const float d0 = (dd[0] + dd[1]) * W8_RC2, d1 = (dd[2] + dd[3]) * W8_RC2;
+        f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
+        f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
+        f.rowtp[2 * f.M + row] = d0;
+        f.rowtp[3 * f.M + row] = d1;
+      }
+      if (bu != cur_b) {
+        if (cur_b >= 0) flush_hz(cur_b);
+        cur_b = bu;
+      }
+    }
+    asm volatile("; W8_P12_rowlocal");
+    W8_STAMP(12);
+    __syncthreads();                                                // barrier 4: round 2 consumed everywhere
+    asm volatile("; W8_P13_bar4");
+    W8_STAMP(13);
+    if (act) {
+      // ---- dL/d(hz[b]) = sum_rows dpre0, dWc_k = sum_rows dpre0 x'_k : wave-local MFMA, own rows of staging A;
+      // B columns: 0 ones | 1, 5 x0 (hi, lo) | 2, 6 x1 (hi, lo)
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(inf_x0 + 4 * q);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(inf_x1 + 4 * q);
+      bf16x4 bc_ = w8_zero4();
+      const bool use1 = r == 2 || r == 6, lo_col = r >= 5;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __bf16 hi, lo;
+        fb_split(use1 ? a1[i] : a0[i], hi, lo);
+        __bf16 v = lo_col ? lo : hi;
+        if (r == 0) v = (__bf16)1.0f;
+        if (r == 3 || r == 4 || r > 6) v = (__bf16)0.0f;
+        bc_[i] = v;
+      }
+      w8_colsum_mfma(sA, p0, bc_, accS, wave, r, q);
+    }
+    W8_STAMP(14);
+    asm volatile("; W8_TILE_END");
+  }
+  if (!GRADS) return;
+
+  if (cur_b >= 0) flush_hz(cur_b);
+  // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
+  {
+    const int jp = wave >> 1, kh = wave & 1;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16s + 4q + i][64kh + 16o + r]
+          const int e = (32 * jp + 16 * s_ + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
+          rec[e] = accW1[s_][o][i] * W8_RC;
+          rec[FD_H * FD_H + e] = accW2[s_][o][i];
+        }
+    if (r == 0) {
+      const int j0 = 32 * jp + 16 * kh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rec[2 * FD_H * FD_H + j0 + 4 * q + i] = accB1[i] * W8_RC;
+        rec[2 * FD_H * FD_H + FD_H + j0 + 4 * q + i] = accB2[i];
+      }
+    }
+  }
+  // per-wave column sums -> LDS (the staging area is free: every wave is past the last tile's barrier 4 and its own
+  // wave-local reads) -> summed over the waves in ascending order
+  __syncthreads();
+  {
+    float* scr = reinterpret_cast<float*>(smb + WO_SA);            // [wave][n][128] floats = 64 KB
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+      *reinterpret_cast<f32x4*>(scr + ((wave * 16 + r) * FD_H) + 16 * jb + 4 * q) = accS[jb];
+  }
+  const float tb = pv_wave_sum(dbo);
+  if (lane == 0) red[wave] = tb;
+  __syncthreads();
+  if (tid < FD_H) {
+    const float* scr = reinterpret_cast<const float*>(smb + WO_SA);
+    float vo = 0.0f, v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < W8_WAVES; ++w) {
+      const float* s_ = scr + (w * 16) * FD_H + tid;
+      v0 += s_[1 * FD_H] + s_[5 * FD_H];
+      v1 += s_[2 * FD_H] + s_[6 * FD_H];
+      vo += s_[3 * FD_H] + s_[4 * FD_H];
+    }
+    rec[2 * FD_H * FD_H + 2 * FD_H + tid] = v0 * W8_RC2;
+    rec[2 * FD_H * FD_H + 3 * FD_H + tid] = v1 * W8_RC2;
+    rec[2 * FD_H * FD_H + 4 * FD_H + tid] = vo;
+  }
+  if (tid == 0) {
+    float v = 0.0f;
+    for (int w = 0; w < W8_WAVES; ++w) v += red[w];
+    rec[2 * FD_H * FD_H + 5 * FD_H] = v;
+  }
+}
+
+int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {
+  PvFused f = f_in;
+  f.ablate = 0;
+  const size_t lds = W8_LDS_BYTES;
+  const void* fn = nullptr;
+#define W8_PICK(G, L) fn = reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L>)
+  if (grads) {
+    if (f.lik == PV_LIK_BERNOULLI) W8_PICK(true, PV_LIK_BERNOULLI);
+    else if (f.lik == PV_LIK_GAUSSIAN) W8_PICK(true, PV_LIK_GAUSSIAN);
+    else W8_PICK(true, PV_LIK_CBERNOULLI);
+  } else {
+    if (f.lik == PV_LIK_BERNOULLI) W8_PICK(false, PV_LIK_BERNOULLI);
+    else if (f.lik == PV_LIK_GAUSSIAN) W8_PICK(false, PV_LIK_GAUSSIAN);
+    else W8_PICK(false, PV_LIK_CBERNOULLI);
+  }
+#undef W8_PICK
+  static const void* configured[6] = {};
+  const int slot = (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
+  if (configured[slot] != fn) {                     // (idempotent: a race between host threads only repeats the call)
+    hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess) return (int)e1;
+    configured[slot] = fn;
+  }
+  void* args[] = {&f};
+  hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(W8_THREADS), args, lds, s);
+  if (e2 != hipSuccess) return (int)e2;
+  PV_LAUNCH_CHECK();
+  return 0;
+}
