@@ -139,7 +139,10 @@ __device__ __forceinline__ void pv_adam_update(float* __restrict__ p, float* __r
   m[i] = mi; v[i] = vi;
   g[i] = 0.0f;                                       // pyro.infer.util.zero_grads
 }
-int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s, const PvAdamFuse* adam = nullptr);
+// fin: the step's loss scalars finished by one more guest workgroup of the launch (pv_finish_scalars)
+struct PvFinishArgs { const float* llb; int B; float* scalars; const float* kl_part; int n_part; float beta; };
+int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s, const PvAdamFuse* adam = nullptr,
+                   const PvFinishArgs* fin = nullptr);
 // out[i] = sum_p part[p*stride + i], p ascending (deterministic)
 int pv_reduce_partials(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t s);
 // Workgroup barrier for kernels whose waves communicate through LDS only: waits for the wave's LDS traffic, not for

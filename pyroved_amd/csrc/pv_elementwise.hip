@@ -428,7 +428,8 @@ int pv_reduce_mid(const float* part, int nb, int nc, int n, float* out, hipStrea
 // dz_coord(c) returns d(phi), d(scale), d(tx), d(ty) of the sample for c = 0..3; dz_content(k) the gradient
 // w.r.t. the k-th column of the decoder's latent input.
 template <class FC, class FK>
-__device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int i, FC dz_coord, FK dz_content) {
+__device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int i, FC dz_coord, FK dz_content,
+                                                 float* dh_copy = nullptr) {
   float dz;
   if (h.coord_dim == 0) {
     dz = dz_content(i);
@@ -459,6 +460,7 @@ __device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int 
   const float sgm = h.scale_direct ? 1.0f : (sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp)));   // softplus'
   h.dhead[(int64_t)b * ldh + i] = g;
   h.dhead[(int64_t)b * ldh + h.z_dim + i] = dsig * sgm;
+  if (dh_copy) { dh_copy[i] = g; dh_copy[h.z_dim + i] = dsig * sgm; }
 }
 
 __global__ void pv_head_bwd_kernel(PvHeadBwd h) {
@@ -636,8 +638,29 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   __shared__ float sh_tp[4];
   __shared__ float sh_ll[128];
   __shared__ float sm5[5][4];
+  __shared__ float sh_dh[256];          // the sample's dhead row (2*z_dim + K <= 128 + 64 on the compact encoder path)
+  __shared__ float sh_e[2][128];        // encoder dgrad chain (layer widths <= 128)
+  __shared__ float sh_p[2][128];
   const int t = threadIdx.x;
   const int K = p.K > 0 ? p.K : 1, Bq = p.hb.B;
+  // operands of the encoder chain that depend on nothing computed here are requested FIRST: their memory latency
+  // (the weights were last touched a decoder-kernel ago) hides under the row sums instead of heading two dependent phases
+  float wv[64];
+  float pf_act0 = 0.0f, pf_act1 = 0.0f;
+  const int ck = t & 127, chalf = t >> 7;
+  int cj0 = 0, cj1 = 0;
+  if (p.enc_n > 1 && !p.fwd_only) {
+    const pv_layer l = p.enc_l[p.enc_n - 1], lp = p.enc_l[p.enc_n - 2];
+    const int jh = (l.out_dim + 1) >> 1;
+    cj0 = chalf * jh; cj1 = chalf ? l.out_dim : jh;
+    if (ck < l.in_dim) {
+      const float* wc = p.enc_params + l.w_off + ck;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) wv[u] = (cj0 + u < cj1) ? wc[(int64_t)(cj0 + u) * l.in_dim] : 0.0f;
+      if (chalf == 0) pf_act0 = p.enc_act[p.enc_n - 2][(int64_t)b * lp.out_dim + ck];
+    }
+    if (t < l.out_dim) pf_act1 = p.enc_act[p.enc_n - 1][(int64_t)b * l.out_dim + t];
+  }
   float tp_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int j = t; j < p.H; j += 256) sh_dhz[j] = 0.0f;
   for (int k = 0; k < K; ++k) {
@@ -703,7 +726,8 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   pv_lds_barrier();
   if (p.dzc_out && t < n_content) p.dzc_out[(int64_t)b * p.lat_in + t] = sh_dzc[t];
   if (t < p.hb.z_dim)
-    pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; });
+    pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; },
+                     p.enc_n > 0 ? sh_dh : nullptr);
   if (p.K > 0 && t == 0) {
     // loss = -sum_k alpha_k (ll_k + b1 log(1/K) - b1 log alpha_k):  dloss/dalpha_k = -(ll_k - b1 log K - b1 log alpha_k - b1)
     // then softmax backward: dlogit_k = alpha_k (dalpha_k - sum_j alpha_j dalpha_j)
@@ -718,7 +742,56 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     for (int k = 0; k < K; ++k) {
       const float da = -(sh_ll[k] - b1 * lK - b1 * logf(al[k]) - b1);
       p.hb.dhead[(int64_t)b * ldh + 2 * p.hb.z_dim + k] = al[k] * (da - dot);
+      if (p.enc_n > 0) sh_dh[2 * p.hb.z_dim + k] = al[k] * (da - dot);
     }
+  }
+  if (p.enc_n <= 0) return;
+  // ---- the sample's encoder dgrad chain (fixed summation order: ascending j) ----
+  pv_lds_barrier();
+  const int ne = p.enc_n;
+  int cur = 0;
+  {
+    const pv_layer hd = p.enc_head, ll_ = p.enc_l[ne - 1];
+    const float* Wh = p.enc_params + hd.w_off;
+    for (int k = t; k < ll_.out_dim; k += 256) {
+      float v = 0.0f;
+#pragma unroll 16
+      for (int o = 0; o < hd.out_dim; ++o) v += sh_dh[o] * Wh[(int64_t)o * hd.in_dim + k];
+      v *= pv_act_grad((ne > 1 && k == t) ? pf_act1 : p.enc_act[ne - 1][(int64_t)b * ll_.out_dim + k], 0.0f, ll_.act);
+      p.enc_dp[ne - 1][(int64_t)b * ll_.out_dim + k] = v;
+      sh_e[cur][k] = v;
+    }
+    pv_lds_barrier();
+  }
+  for (int li = ne - 1; li > 0; --li) {
+    const pv_layer l = p.enc_l[li], lp = p.enc_l[li - 1];
+    const float* W = p.enc_params + l.w_off;
+    // thread (k = t & 127, half = t >> 7) sums its half of the j range (coalesced across k); halves combined in fixed
+    // order.  Widths <= 128 (pv_enc_compact_supported).  The last layer's operands were requested at the top.
+    const bool pre = li == ne - 1;
+    const int k = ck, half = chalf;
+    const int jh = (l.out_dim + 1) >> 1, j0 = half * jh, j1 = half ? l.out_dim : jh;
+    float v = 0.0f;
+    if (k < l.in_dim) {
+      if (!pre) {
+        const float* wc = W + k;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) wv[u] = (j0 + u < j1) ? wc[(int64_t)(j0 + u) * l.in_dim] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 64; ++u) v += (j0 + u < j1) ? sh_e[cur][j0 + u] * wv[u] : 0.0f;
+    }
+    sh_p[half][k] = v;
+    pv_lds_barrier();
+    if (half == 0 && k < l.in_dim) {
+      float y = sh_p[0][k] + sh_p[1][k];
+      const float hv = pre ? pf_act0 : p.enc_act[li - 1][(int64_t)b * lp.out_dim + k];
+      y *= pv_act_grad(hv, 0.0f, lp.act);
+      p.enc_dp[li - 1][(int64_t)b * lp.out_dim + k] = y;
+      sh_e[cur ^ 1][k] = y;
+    }
+    pv_lds_barrier();
+    cur ^= 1;
   }
 }
 

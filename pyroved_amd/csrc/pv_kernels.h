@@ -114,6 +114,15 @@ struct PvLatentBwd {
   int fwd_only;          // 1: only llb (evaluation)
   float* row_ll;         // optional (B): the unweighted ll_b (llb gets hb.w[b] * ll_b when hb.w is set)
   float* dzc_out;        // optional (B, lat_in): dL/d(decoder latent input) (content and y columns)
+  // compact encoder (enc_n > 0): the sample's encoder dgrad chain follows in the same workgroup — it needs nothing from
+  // other samples: edp[last] = (dhead Whead) * act'(eact[last]); edp[i-1] = (edp[i] W_i) * act'(eact[i-1])
+  // (what pv_enc_dgrad does 16 samples per workgroup on the matrix cores; here one sample, plain FMAs, one launch less)
+  int enc_n;
+  const float* enc_params;
+  pv_layer enc_l[PV_MAX_LAYERS];
+  pv_layer enc_head;
+  const float* enc_act[PV_MAX_LAYERS];
+  float* enc_dp[PV_MAX_LAYERS];
 };
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
 int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, hipStream_t s);

@@ -5,6 +5,7 @@
 //     -> pyro.optim.Adam -> zero_grads.
 // No allocation, no synchronisation, no retained state: everything lives in the caller's plan.
 #include "pv_common.h"
+#include <stdlib.h>
 #include "pv_kernels.h"
 #include "pv_sdec_fused.h"
 #include "pv_linear.h"
@@ -390,12 +391,15 @@ PvGemm wgrad_problem(const float* dpre, int64_t lddp, const float* x, int64_t ld
 
 // encoder backward from dL/d(head pre-activations) (L.dhead): the dgrad chain through the hidden layers, then
 // every weight gradient of the encoder (plus `extra`, e.g. fc_latent's) in one multi-GEMM launch per 4 problems
-struct PvFinish { const float* llb; int B; float* scalars; const float* kl_part; int n_part; float beta; };
+typedef PvFinishArgs PvFinish;
 
 // adam / adam_done: pv_ivae_step's optimizer update, applied inside the weight-gradient launch when that single launch
 // finalises every encoder gradient (compact encoder, <= 4 problems); *adam_done tells the caller whether it was
+// dgrad_done: the compact encoder's dgrad chain already ran (inside pv_latent_bwd_reduce); the loss scalars then ride
+// in the weight-gradient launch
 int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, hipStream_t s,
-                const PvFinish* fin = nullptr, const PvAdamFuse* adam = nullptr, bool* adam_done = nullptr) {
+                const PvFinish* fin = nullptr, const PvAdamFuse* adam = nullptr, bool* adam_done = nullptr,
+                bool dgrad_done = false) {
   const int64_t B = p->batch;
   float* G = p->grads;
   void* ws = L.scratch;
@@ -427,7 +431,9 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     return 0;
   }
   const float* elast = L.eact[ne - 1];
-  if (L.enc_compact) {
+  if (L.enc_compact && dgrad_done) {
+    // nothing to launch here
+  } else if (L.enc_compact) {
     PvEncDgrad d{};
     d.params = p->params; d.n_enc = ne; d.B = (int)B; d.head = hd; d.dhead = L.dhead;
     for (int i = 0; i < ne; ++i) { d.enc[i] = p->enc[i]; d.eact[i] = L.eact[i]; d.edp[i] = L.edp[i]; }
@@ -460,12 +466,15 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     probs[np++] = wgrad_problem(L.edp[i], l.out_dim, in, ldin, G + l.w_off, l.b_off >= 0 ? G + l.b_off : nullptr, B,
                                 l.in_dim, l.out_dim);
   }
+  const PvFinish* fin_w = (L.enc_compact && dgrad_done) ? fin : nullptr;     // (otherwise pv_enc_dgrad hosted it)
   if (B <= 4096 && np <= 4 && adam && adam_done && L.enc_compact) {
-    PV_TRY(pv_wgrad_small(probs, np, s, adam));
+    PV_TRY(pv_wgrad_small(probs, np, s, adam, fin_w));
     *adam_done = true;
   } else if (B <= 4096) {
-    for (int i = 0; i < np; i += 4) PV_TRY(pv_wgrad_small(probs + i, np - i < 4 ? np - i : 4, s));
+    for (int i = 0; i < np; i += 4)
+      PV_TRY(pv_wgrad_small(probs + i, np - i < 4 ? np - i : 4, s, nullptr, i == 0 ? fin_w : nullptr));
   } else {                                   // long contractions: split-K GEMMs, one launch pair each
+    if (fin_w) PV_TRY(pv_finish_scalars(fin_w->llb, fin_w->B, fin_w->scalars, fin_w->kl_part, fin_w->n_part, fin_w->beta, s));
     for (int i = 0; i < np; ++i)
       PV_TRY(pv_gemm(probs[i], pv_gemm_pick_splits(probs[i].M, probs[i].N, probs[i].K), ws, wsb, s));
   }
@@ -646,6 +655,14 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   hb.ldh = L.enc_ext ? 0 : (int)plan_head_w(p);
   lb.K = (int)K; lb.alpha = L.alpha; lb.beta_disc = p->beta_disc;
   hb.w = p->row_w; lb.row_ll = p->row_elbo ? L.row_ll : nullptr; lb.dzc_out = p->dy ? L.dzc : nullptr;
+  // compact encoder: every sample's dgrad chain runs in its latent_bwd workgroup (one dependent launch less)
+  static int chain_env = -1;          // PV_CHAIN=0: keep pv_enc_dgrad as its own launch (A/B timing)
+  if (chain_env < 0) { const char* e_ = getenv("PV_CHAIN"); chain_env = (e_ && atoi(e_) == 0) ? 0 : 1; }
+  const bool chain = chain_env && L.enc_compact && !L.enc_ext && 2 * z + K <= 256;
+  if (chain) {
+    lb.enc_n = p->n_enc; lb.enc_params = p->params; lb.enc_head = p->head;
+    for (int i = 0; i < p->n_enc; ++i) { lb.enc_l[i] = p->enc[i]; lb.enc_act[i] = L.eact[i]; lb.enc_dp[i] = L.edp[i]; }
+  }
   PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s));
   // the loss scalars ride in the encoder dgrad launch (compact encoder) or get their own
   PvFinish fin{L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* scaled */};
@@ -653,7 +670,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
   // (jiVAE: over the K*B decoder samples, zin = [z content | onehot(k)])
   const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
-  PV_TRY(encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr, adam, adam_done));
+  PV_TRY(encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr, adam, adam_done, chain));
   return extra_outputs(p, L, L.dzc, lat_in, s);
 }
 

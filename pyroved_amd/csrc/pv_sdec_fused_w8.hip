@@ -429,6 +429,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   int tile_no = -1;
   for (int ut = u_lo; ut < u_hi; ut += W8_WAVES) {
     ++tile_no;
+    (void)tile_no;                      // (used by the -DW8_TRACE stamps only)
     asm volatile("; W8_TILE_BEGIN");
     W8_STAMP(0);
     const int nact = (u_hi - ut) < W8_WAVES ? (u_hi - ut) : W8_WAVES;

@@ -10,6 +10,7 @@
 // (fp32 in, fp32 accumulate) on four independent accumulators; the 4 partial tiles meet in LDS.  Up to 4
 // problems share one launch (~470 workgroups for the iVAE 28x28 step, several resident per CU).
 #include "pv_common.h"
+#include "pv_kernels.h"
 
 #define WG_WAVES 4
 #define WG_CHUNK 64            // k's per register batch (16 MFMAs)
@@ -24,6 +25,8 @@ struct PvWgradSmall {
   int adam_on;
   PvAdamFuse ad;
   int64_t rng_lo[8], rng_hi[8];
+  // one more guest (the last block) when fin_scalars is set: the step's loss scalars (pv_finish_scalars)
+  const float* fin_llb; float* fin_scalars; const float* fin_kl_part; int fin_B, fin_n_part; float fin_beta;
 };
 
 __global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSmall w) {
@@ -32,9 +35,13 @@ __global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSm
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = blockIdx.x;
+  if (w.fin_scalars && t == (int)gridDim.x - 1) {
+    pv_finish_scalars_block(w.fin_llb, w.fin_B, w.fin_scalars, w.fin_kl_part, w.fin_n_part, w.fin_beta, &part[0][0][0]);
+    return;
+  }
   if (w.adam_on && t >= w.tile_end[3]) {              // guest: Adam over everything this launch does not produce
     const PvAdamFuse& a = w.ad;
-    const int64_t stride = (int64_t)(gridDim.x - w.tile_end[3]) * blockDim.x;
+    const int64_t stride = (int64_t)(gridDim.x - (w.fin_scalars ? 1 : 0) - w.tile_end[3]) * blockDim.x;
     for (int64_t i = (int64_t)(t - w.tile_end[3]) * blockDim.x + tid; i < a.n; i += stride) {
       bool own = false;
 #pragma unroll
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSm
 }
 
 // gs[i]: plain wgrad problems (no bias / activation / aux epilogue); any strides, any M, N, K >= 1
-int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s, const PvAdamFuse* adam) {
+int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s, const PvAdamFuse* adam, const PvFinishArgs* fin) {
   if (n < 1 || n > 4) return PV_EINVAL;
   PvWgradSmall w{};
   int tiles = 0;
@@ -143,6 +150,11 @@ int pv_wgrad_small(const PvGemm* gs, int n, hipStream_t s, const PvAdamFuse* ada
     guests = (int)((adam->n + 1023) / 1024);
     if (guests > 256) guests = 256;
     if (guests < 1) guests = 1;
+  }
+  if (fin && fin->scalars) {
+    w.fin_llb = fin->llb; w.fin_B = fin->B; w.fin_scalars = fin->scalars; w.fin_kl_part = fin->kl_part;
+    w.fin_n_part = fin->n_part; w.fin_beta = fin->beta;
+    guests += 1;
   }
   hipLaunchKernelGGL(pv_wgrad_small_kernel, dim3(tiles + guests), dim3(64 * WG_WAVES), 0, s, w);
   PV_LAUNCH_CHECK();
