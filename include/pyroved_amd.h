@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 9
+#define PV_ABI_VERSION 10
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -220,6 +220,15 @@ int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* strea
  * to zero (pyro.infer.util.zero_grads).  `n` floats starting at each pointer. */
 int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n,
                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* The same, plus (in the same launch) a copy of `n_scalars` floats from `scalars_src` to `scalars_dst` — the
+ * data-parallel step: after the one all-reduce of [flat gradient | 4 loss scalars] (which the caller issues between
+ * pv_ivae_loss_and_grads and this call) the optimizer update and the write of the reduced loss into the caller's
+ * device-side loss history are one launch.  Replaces: the part of Pyro's SVI.step after loss_and_grads
+ * (trainers/svi.py:107: optimizer call, zero_grads, `return loss`).  scalars_src may lie inside `grads` + n. */
+int pv_adam_step_hist(float* params, float* grads, float* m, float* v, int64_t n,
+                      float lr, float beta1, float beta2, float eps, int32_t step,
+                      const float* scalars_src, float* scalars_dst, int32_t n_scalars, void* stream);
 
 /* The two halves of the step around an external decoder (plan->ext_decoder, see the struct): the guide (iVAE.guide,
  * models/ivae.py:204-221, plus the prior / posterior log-densities of the sampled z) and, after the caller's decoder

@@ -13,7 +13,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 9
+PV_ABI_VERSION = 10
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -116,6 +116,9 @@ SIGNATURES = {
     "pv_ivae_loss_and_grads": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
     "pv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "pv_adam_step_hist": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pv_ivae_step": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p]),
     "pv_ivae_guide": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p]),
     "pv_ivae_guide_backward": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),

@@ -833,6 +833,31 @@ __global__ void pv_adam_kernel(float* __restrict__ p, float* __restrict__ g, flo
   }
 }
 
+__global__ void pv_adam_hist_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
+                                    float bc2_sqrt, const float* __restrict__ ssrc, float* __restrict__ sdst, int ns) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < ns) sdst[threadIdx.x] = ssrc[threadIdx.x];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    pv_adam_update(p, g, m, v, i, g[i], b1, b2, eps, step_size, bc2_sqrt);
+  }
+}
+
+extern "C" int pv_adam_step_hist(float* params, float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, int32_t step, const float* scalars_src, float* scalars_dst,
+                                 int32_t n_scalars, void* stream) {
+  if (step < 1 || n < 0 || n_scalars < 0 || n_scalars > 256 || (n_scalars > 0 && (!scalars_src || !scalars_dst)))
+    return PV_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pv_adam_hist_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, beta1,
+                     beta2, eps, (float)((double)lr / bc1), (float)sqrt(bc2), scalars_src, scalars_dst, (int)n_scalars);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, int32_t step, void* stream) {
   if (n <= 0) return 0;

@@ -564,6 +564,19 @@ class IVAEEngine:
                 if q.grad is not None:
                     q.grad = torch.zeros_like(q.grad)
 
+    @_abi.on_device
+    def adam_step_hist(self, hist_slot: torch.Tensor):
+        """adam_step() plus, in the same launch, the copy of the 4 (all-reduced) loss scalars into `hist_slot` — the
+        data-parallel step after its one all-reduce (pv_adam_step_hist)."""
+        if self.ext_enc or self.ext_dec or getattr(self, "ext_y", False):
+            hist_slot.copy_(self.scalars)
+            return self.adam_step()
+        self.adam_t += 1
+        _abi.check(_abi.lib().pv_adam_step_hist(
+            _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), self.n_flat,
+            self.lr, self.betas[0], self.betas[1], self.adam_eps, self.adam_t,
+            _abi.ptr(self.scalars), _abi.ptr(hist_slot), N_SCALARS, _abi.current_stream()), "pv_adam_step_hist")
+
     def extra_grads(self):
         """Gradient tensors that live outside the flat buffer (a user-defined encoder's): reduced separately in
         data-parallel runs."""

@@ -106,19 +106,27 @@ class SVItrainer:
             return torch.empty(b, z_dim).normal_()
         return torch.empty(b, z_dim, device=self.engine.device).normal_()
 
-    def _svi_step(self, i: int, x: torch.Tensor, y: Optional[torch.Tensor], train: bool, eps=None, **kwargs) -> None:
+    def _svi_step(self, i: int, x: torch.Tensor, y: Optional[torch.Tensor], train: bool, eps=None, shard=None,
+                  **kwargs) -> None:
         """SVI.step on one (global) minibatch; the loss lands in slot i of the device history.
-        x / y / eps may already live on the device (device feed, _epoch_device_feed)."""
+        x / y / eps may already live on the device (device feed, _epoch_device_feed).
+        shard = (lo, hi, b): x / y / eps are already THIS rank's rows [lo, hi) of a global minibatch of b samples
+        (the data-parallel device feed gathers nothing else)."""
         eng = self.engine
         beta = kwargs.get("scale_factor", 1.)          # jiVAE: scalar or [continuous, discrete] (jivae.py:161-165)
         if torch.is_tensor(beta):
             beta = beta.tolist()
         beta = [float(v) for v in beta] if isinstance(beta, (list, tuple)) else float(beta)
-        b = x.shape[0]
-        if eps is None:
-            eps = self._draw_eps(b)                   # global batch: identical on every rank
         rank, world = pvdist.world(self.group)
-        lo, hi = pvdist.shard_bounds(b, rank, world)
+        if shard is not None:
+            lo, hi, b = shard
+            x0 = 0                                    # offset of row `lo` inside x / y / eps
+        else:
+            b = x.shape[0]
+            if eps is None:
+                eps = self._draw_eps(b)               # global batch: identical on every rank
+            lo, hi = pvdist.shard_bounds(b, rank, world)
+            x0 = lo
         dev = eng.device
         if self._hist is None or self._hist.shape[0] <= i:
             new = torch.zeros(max(64, 2 * (i + 1)), 4, device=dev, dtype=torch.float32)
@@ -127,9 +135,9 @@ class SVItrainer:
             self._hist = new
         direct = world == 1 and getattr(eng, "supports_scalars_out", False)   # single process: the loss lands in the history slot
         if hi > lo:
-            xs = x[lo:hi].to(dev, torch.float32)
-            es = eps[lo:hi].to(dev, torch.float32)
-            ys = None if y is None else y[lo:hi].to(dev, torch.float32)
+            xs = x[x0:x0 + hi - lo].to(dev, torch.float32)
+            es = eps[x0:x0 + hi - lo].to(dev, torch.float32)
+            ys = None if y is None else y[x0:x0 + hi - lo].to(dev, torch.float32)
             one_call = (direct and train and getattr(eng, "supports_step", False)
                         and not (getattr(eng, "ext_enc", False) or getattr(eng, "ext_dec", False)))
             if one_call:                              # loss, gradients and Adam in one library call (pv_ivae_step)
@@ -148,7 +156,11 @@ class SVItrainer:
                 pvdist.allreduce_sum_(eng.grad, self.group)
                 for g_ in (eng.extra_grads() if hasattr(eng, "extra_grads") else []):
                     pvdist.allreduce_sum_(g_, self.group)        # a user-defined encoder's gradients
-        if train or (self.mirror_evaluate_update and eng.grads_live):
+        step_opt = train or (self.mirror_evaluate_update and eng.grads_live)
+        if step_opt and not direct and hasattr(eng, "adam_step_hist"):
+            eng.adam_step_hist(self._hist[i])          # Adam + the reduced loss into the history, one launch
+            return
+        if step_opt:
             eng.adam_step()
         if not direct:
             self._hist[i].copy_(eng.scalars)
@@ -270,19 +282,40 @@ class SVItrainer:
         # small gather kernel in front of every step); a step then takes a contiguous view
         per_sample = sum(t[0].numel() for t in data) * 4
         chunk = max(1, int((256 << 20) // max(per_sample * max(sizes), 1)))
+        rank, world = pvdist.world(self.group)
         off, n = 0, 0
         while n < len(sizes):
             m = min(chunk, len(sizes) - n)
             rows = sum(sizes[n:n + m])
-            idx = idx_dev[off:off + rows]
-            xs = data[0].index_select(0, idx)
-            ys = data[1].index_select(0, idx) if len(data) > 1 else None
-            r0 = 0
-            for k in range(m):
-                bsz = sizes[n + k]
-                self._svi_step(n + k, xs[r0:r0 + bsz], None if ys is None else ys[r0:r0 + bsz], train,
-                               eps=eps_dev[off + r0:off + r0 + bsz], **kwargs)
-                r0 += bsz
+            if world > 1:
+                # data parallel: this rank gathers ONLY its rows [lo, hi) of every global minibatch of the chunk (the
+                # order is the shared permutation, identical on every rank): 1/world of the gather and of its memory
+                bounds, parts, r0 = [], [], 0
+                for k in range(m):
+                    bsz = sizes[n + k]
+                    lo, hi = pvdist.shard_bounds(bsz, rank, world)
+                    bounds.append((lo, hi, bsz, r0))
+                    parts.append(idx_dev[off + r0 + lo:off + r0 + hi])
+                    r0 += bsz
+                idx = torch.cat(parts)
+                xs = data[0].index_select(0, idx)
+                ys = data[1].index_select(0, idx) if len(data) > 1 else None
+                c0 = 0
+                for k, (lo, hi, bsz, r0) in enumerate(bounds):
+                    w_ = hi - lo
+                    self._svi_step(n + k, xs[c0:c0 + w_], None if ys is None else ys[c0:c0 + w_], train,
+                                   eps=eps_dev[off + r0 + lo:off + r0 + hi], shard=(lo, hi, bsz), **kwargs)
+                    c0 += w_
+            else:
+                idx = idx_dev[off:off + rows]
+                xs = data[0].index_select(0, idx)
+                ys = data[1].index_select(0, idx) if len(data) > 1 else None
+                r0 = 0
+                for k in range(m):
+                    bsz = sizes[n + k]
+                    self._svi_step(n + k, xs[r0:r0 + bsz], None if ys is None else ys[r0:r0 + bsz], train,
+                                   eps=eps_dev[off + r0:off + r0 + bsz], **kwargs)
+                    r0 += bsz
             off += rows
             n += m
         return len(sizes)

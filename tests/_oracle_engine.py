@@ -60,3 +60,8 @@ class OracleEngine:
         self.grad[:self.n_flat].zero_()
         with torch.no_grad():
             self.flat.copy_(torch.cat([self.o.p[k].detach().reshape(-1) for k in self.keys]))
+
+    def adam_step_hist(self, hist_slot):
+        """The data-parallel step's post-all-reduce half (engine.IVAEEngine.adam_step_hist)."""
+        hist_slot.copy_(self.scalars)
+        self.adam_step()

@@ -1391,7 +1391,8 @@ def test_ss_trainer_epochs_vs_golden(gpu_device, name):
     trainer.print_statistics()
 
 
-def test_bench_multirank_path_on_one_gpu(gpu_device):
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_multirank_path_on_one_gpu(gpu_device, mode):
     """bench.py's N > 1 code path end to end (process group, replica broadcast, per-step all-reduce of [gradients | loss],
     barrier + max-over-ranks timing, one JSON line from rank 0) with two ranks sharing this box's single GPU over gloo
     (bench.py's test hook): the line must parse and both precision legs must report the same ELBO as a one-rank run
@@ -1402,15 +1403,22 @@ def test_bench_multirank_path_on_one_gpu(gpu_device):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PV_BENCH_BACKEND="gloo", PV_BENCH_ONE_DEVICE="1")
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"]
+           "--master-port", "29531" if mode == "weak" else "29533", os.path.join(root, "bench.py"), "--gpus", "2",
+           "--steps", "6", "--warmup", "2", "--repeats", "2"] + (["--strong"] if mode == "strong" else [])
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == mode and d["value"] > 0
     assert "fp32_class" in d and abs(d["fp32_class"]["loss_per_image_step0"] - d["elbo"]["loss_per_image_step0"]) < 1e-2
     assert 500 < d["elbo"]["loss_per_image_step0"] < 600
+    assert len(d["ms_per_step_all"]) == 2
+    if mode == "strong":
+        # the global batch stays 256 (128 per rank): the same data and noise as the single-GPU headline run, so the same
+        # ELBO (544.5358 per image from the fp32 oracle; bench.py's own rel_err_step0 line at N = 1)
+        assert "global 256" in d["config"]["workload"]
+        assert abs(d["fp32_class"]["loss_per_image_step0"] - 544.5358) < 0.02
 
 
 @pytest.mark.parametrize("kind", ["ivae", "ssivae"])
