@@ -188,6 +188,16 @@ typedef struct pv_ivae_plan {
   /* ---- optional instrumentation ---- */
   void*   ev_start;       /* hipEvent_t recorded on `stream` right before the dominant decoder  */
   void*   ev_stop;        /* kernel's launch and right after it (NULL: no recording)            */
+  /* ---- jiVAE WITHOUT enumeration (ABI v10): SVItrainer's default enumerate_parallel=False (trainers/svi.py:66, 83-91)
+   * runs Trace_ELBO on a class y_b ~ OneHotCategorical(alpha_b) DRAWN by the guide (models/jivae.py:213-220).
+   * class_onehot (B, discrete_dim) one-hot rows or NULL (= exact enumeration, TraceEnum_ELBO).  When set:
+   *   loss = -sum_b [ log p(x_b|z_b,y_b) + beta (log p(z_b) - log q(z_b)) + beta_disc (log(1/K) - log alpha_b[y_b]) ],
+   *   decoder / encoder-through-z gradients as for a class-conditioned step on y_b, and the class logits receive the
+   *   score-function gradient -log_r_b (onehot_b - alpha_b), log_r_b = the bracket above (Pyro: trace_elbo.py
+   *   _compute_log_r + ScoreParts).  Vanilla decoder only (coord_dim == 0): with invariances the reference's model
+   *   cannot broadcast its K-times repeated z against the drawn class (models/jivae.py:181-189) — PV_EINVAL.
+   *   The caller draws y from `alpha` of pv_ivae_encode on the same x (the guide's order: eps first, then y). ---- */
+  const float* class_onehot;
 } pv_ivae_plan;
 
 /* Library / ABI version (PV_ABI_VERSION). */

@@ -309,6 +309,46 @@ def jelbo(p: Params, cfg: Config, x, eps, beta=1.0, grid=None):
                        "guide.latent_disc": (w * b1 * logq_d).sum()})
 
 
+def jelbo_sampled(p: Params, cfg: Config, x, eps, y_onehot=None, beta=1.0):
+    """Trace_ELBO of jiVAE.guide/model WITHOUT enumeration — SVItrainer's default enumerate_parallel=False
+    (trainers/svi.py:83-91) — for the vanilla decoder (invariances=None; with invariances the reference's own model
+    cannot broadcast its K-times repeated z against the sampled class, models/jivae.py:181-189, and raises).
+
+    The class y_b ~ OneHotCategorical(alpha_b) is a guide site without rsample: Pyro's Trace_ELBO (trace_elbo.py:
+    _compute_log_r, score_parts) differentiates the surrogate
+        sum(model log-probs) - sum(log q of the reparameterised site) + sum_b detach(log_r_b) * log q(y_b | x_b),
+        log_r_b = ll_b + b0 (log p(z_b) - log q(z_b)) + b1 (log(1/K) - log alpha_b[y_b])        (score function unscaled)
+    while the reported loss is -(sum model - sum guide) on the drawn (z, y).  y_onehot None: drawn here, on the global
+    CPU generator, exactly where the guide draws it (after eps).  Returns `loss` carrying the surrogate's gradient."""
+    b0, b1 = (beta, beta) if not isinstance(beta, (list, tuple)) else beta
+    bsz, K = x.shape[0], cfg.discrete_dim
+    if cfg.coord > 0:
+        raise RuntimeError("jiVAE without enumeration is defined for the vanilla decoder only (invariances=None)")
+    z_loc, z_scale, alpha = jencoder_forward(p, cfg, x)
+    z = z_loc + z_scale * eps
+    if y_onehot is None:
+        with torch.no_grad():
+            y_onehot = td.OneHotCategorical(probs=alpha.detach().float()).sample().to(z.dtype)
+    logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)
+    logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)
+    logq_d = td.OneHotCategorical(probs=alpha).log_prob(y_onehot)                        # (B,)
+    logp_d = torch.full_like(logq_d, -math.log(K))
+    loc, xc = decode_from_latent(p, cfg, z, y_onehot, None)
+    ll = likelihood(cfg, loc.reshape(bsz, -1)).log_prob(x.reshape(bsz, -1)).sum(-1)
+    t_ll = ll.sum()
+    t_lp = (b0 * logp).sum() + (b1 * logp_d).sum()
+    t_lq = (b0 * logq).sum() + (b1 * logq_d).sum()
+    elbo_v = t_ll + t_lp - t_lq
+    log_r = (ll + b0 * logp - b0 * logq + b1 * logp_d - b1 * logq_d).detach()
+    surrogate = t_ll + t_lp - (b0 * logq).sum() + (log_r * logq_d).sum()
+    loss = -(surrogate - surrogate.detach() + elbo_v.detach())
+    return dict(loss=loss, ll=t_ll, logpz=t_lp, logqz=t_lq, z_loc=z_loc, z_scale=z_scale, z=z, alpha=alpha,
+                y=y_onehot, loc=loc, log_r=log_r, ll_per_sample=ll,
+                terms={"model.latent_cont": (b0 * logp).sum(), "model.latent_disc": (b1 * logp_d).sum(),
+                       "model.obs": t_ll, "guide.latent_cont": (b0 * logq).sum(),
+                       "guide.latent_disc": (b1 * logq_d).sum()})
+
+
 # ======================================================================= VED (models/ved.py, nets/conv.py)
 @dataclass
 class VedConfig:
@@ -496,7 +536,11 @@ class SVIOracle:
         self.last_grads = None
 
     def loss_and_grads(self, x, eps, beta=1.0, y=None):
-        if self.cfg.discrete_dim > 0:
+        if self.cfg.discrete_dim > 0 and getattr(self, "sampled_class", False):
+            # SVItrainer(jiVAE, enumerate_parallel=False): y = the drawn class (one-hot) or None (drawn inside)
+            out = jelbo_sampled(self.p, self.cfg, x.to(self.dtype), eps.to(self.dtype),
+                                None if y is None else y.to(self.dtype), beta)
+        elif self.cfg.discrete_dim > 0:
             out = jelbo(self.p, self.cfg, x.to(self.dtype), eps.to(self.dtype), beta, self.grid)
         else:
             out = elbo(self.p, self.cfg, x.to(self.dtype), eps.to(self.dtype), beta,

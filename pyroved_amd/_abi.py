@@ -68,6 +68,7 @@ class pv_ivae_plan(C.Structure):
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+        ("class_onehot", C.c_void_p),
     ]
 
 

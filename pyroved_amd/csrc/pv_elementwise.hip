@@ -539,6 +539,85 @@ int pv_jiv_combine(const float* llkb, const float* alpha, float* llb, float* dzc
   return 0;
 }
 
+// ---- jiVAE without enumeration (plan->class_onehot): the decoder still runs on the K*B rows [k][b] of the enumerated
+// path, weighted by onehot(y_b) instead of alpha_b (rows of the classes not drawn carry weight 0).
+// prep: sw <- onehot; fix[0] <- beta_disc * sum_b (log alpha_b[y_b] - sum_k alpha_bk log alpha_bk): what the drawn class
+// changes in the guide's discrete log-probability sum relative to the enumerated expectation the encoder kernels wrote
+__global__ __launch_bounds__(256) void pv_jiv_sampled_prep_kernel(const float* __restrict__ alpha, const float* __restrict__ onehot,
+                                                                  float* __restrict__ sw, float* __restrict__ fix, float beta_disc,
+                                                                  int B, int K) {
+  __shared__ float sm[4];
+  float d = 0.0f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float samp = 0.0f, ent = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      const float a = alpha[(int64_t)b * K + k], o = onehot[(int64_t)b * K + k], la = logf(a);
+      sw[(int64_t)k * B + b] = o;
+      samp += o * la;
+      ent += a * la;
+    }
+    d += samp - ent;
+  }
+  d = block_sum_256(d, sm);
+  if (threadIdx.x == 0) fix[0] = beta_disc * d;
+}
+int pv_jiv_sampled_prep(const float* alpha, const float* onehot, float* sw, float* fix, float beta_disc, int B, int K,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(pv_jiv_sampled_prep_kernel, dim3(1), dim3(256), 0, s, alpha, onehot, sw, fix, beta_disc, B, K);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+// scalars after pv_finish_scalars: the guide's log-probability sum and the loss take the correction
+__global__ void pv_jiv_sampled_fix_kernel(float* scalars, const float* fix) {
+  if (threadIdx.x == 0) { scalars[3] += fix[0]; scalars[0] += fix[0]; }
+}
+int pv_jiv_sampled_fix(float* scalars, const float* fix, hipStream_t s) {
+  hipLaunchKernelGGL(pv_jiv_sampled_fix_kernel, dim3(1), dim3(64), 0, s, scalars, fix);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+// combine for the drawn class: llb[b] = ll of the drawn pass; dzc summed over the passes (only the drawn one is
+// non-zero); class logits: dhead[b][2z + k] = -log_r_b (onehot_bk - alpha_bk) with
+// log_r_b = ll_b + b0 (log p(z_b) - log q(z_b)) + b1 (log(1/K) - log alpha_b[y_b])      (Trace_ELBO's score-function term)
+__global__ void pv_jiv_combine_sampled_kernel(const float* __restrict__ llkb, const float* __restrict__ alpha,
+                                              const float* __restrict__ onehot, float* __restrict__ llb,
+                                              float* __restrict__ dzc, int ld_dzc, int n_content, float* __restrict__ dhead,
+                                              int ldh, int z_dim, int B, int K, float beta, float beta_disc, int want_grads,
+                                              const float* __restrict__ z, const float* __restrict__ head,
+                                              const float* __restrict__ z_scale) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* al = alpha + (int64_t)b * K;
+  const float* oh = onehot + (int64_t)b * K;
+  float ll = 0.0f, lqd = 0.0f;
+  for (int k = 0; k < K; ++k) { ll += oh[k] * llkb[(int64_t)k * B + b]; lqd += oh[k] * logf(al[k]); }
+  llb[b] = ll;
+  if (!want_grads) return;
+  for (int i = 0; i < n_content; ++i) {
+    float v = dzc[(int64_t)b * ld_dzc + i];
+    for (int k = 1; k < K; ++k) v += dzc[((int64_t)k * B + b) * ld_dzc + i];
+    dzc[(int64_t)b * ld_dzc + i] = v;
+  }
+  float kl = 0.0f;                                     // log p(z_b) - log q(z_b | x_b)
+  for (int i = 0; i < z_dim; ++i) {
+    const float zz = z[(int64_t)b * z_dim + i], mu = head[(int64_t)b * ldh + i], sig = z_scale[(int64_t)b * z_dim + i];
+    const float d = zz - mu;
+    const float lq = -(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI;
+    const float lp = -(zz * zz) / 2.0f - LOG_SQRT_2PI;
+    kl += lp - lq;
+  }
+  const float log_r = ll + beta * kl + beta_disc * (-logf((float)K) - lqd);
+  for (int k = 0; k < K; ++k) dhead[(int64_t)b * ldh + 2 * z_dim + k] = -log_r * (oh[k] - al[k]);
+}
+int pv_jiv_combine_sampled(const float* llkb, const float* alpha, const float* onehot, float* llb, float* dzc, int ld_dzc,
+                           int n_content, float* dhead, int ldh, int z_dim, int B, int K, float beta, float beta_disc,
+                           int want_grads, const float* z, const float* head, const float* z_scale, hipStream_t s) {
+  hipLaunchKernelGGL(pv_jiv_combine_sampled_kernel, dim3((B + 63) / 64), dim3(64), 0, s, llkb, alpha, onehot, llb, dzc, ld_dzc,
+                     n_content, dhead, ldh, z_dim, B, K, beta, beta_disc, want_grads, z, head, z_scale);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void pv_jiv_expand_kernel(const float* __restrict__ head, int ldh, const float* __restrict__ z,
                                                             int z_dim, int n_content, float* __restrict__ tp,
                                                             float* __restrict__ zy, float* __restrict__ alpha,

@@ -125,6 +125,13 @@ struct PvLatentBwd {
   float* enc_dp[PV_MAX_LAYERS];
 };
 int pv_latent_bwd(const PvLatentBwd& p, hipStream_t s);
+// jiVAE without enumeration (plan->class_onehot): see pv_elementwise.hip
+int pv_jiv_sampled_prep(const float* alpha, const float* onehot, float* sw, float* fix, float beta_disc, int B, int K,
+                        hipStream_t s);
+int pv_jiv_sampled_fix(float* scalars, const float* fix, hipStream_t s);
+int pv_jiv_combine_sampled(const float* llkb, const float* alpha, const float* onehot, float* llb, float* dzc, int ld_dzc,
+                           int n_content, float* dhead, int ldh, int z_dim, int B, int K, float beta, float beta_disc,
+                           int want_grads, const float* z, const float* head, const float* z_scale, hipStream_t s);
 int pv_softmax_rows(const float* logits, int64_t ld, int B, int K, float* out, hipStream_t s);
 int pv_jiv_combine(const float* llkb, const float* alpha, float* llb, float* dzc, int ld_dzc, int n_content, float* dhead,
                    int ldh, int z_dim, int B, int K, float beta_disc, int want_grads, hipStream_t s, float* dtp = nullptr);

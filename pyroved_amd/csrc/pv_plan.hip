@@ -45,6 +45,7 @@ struct Layout {
   float* dhz; float* dtp; float* dzc;
   float* row_ll;                           // (B) unweighted ll_b (plan->row_elbo)
   float* alpha; float* sw; float* llkb;    // jiVAE: class probabilities (B, K), decoder row weights (K*B), ll per (k, b)
+  float* jfix;                              // jiVAE without enumeration: correction of the guide's discrete log-prob sum
   // convolutional encoder (plan->n_enc_ops > 0): activation shapes / buffers, flattened features, gradient ping-pong
   bool enc_ext;                            // external encoder: (z_loc, z_scale) given, gradients handed back
   bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
@@ -196,6 +197,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.llb = c.take(B);
   L.row_ll = c.take(B);
   L.llkb = K > 0 ? c.take(S) : nullptr;
+  L.jfix = K > 0 ? c.take(4) : nullptr;
   L.dbuf[0] = L.fused ? nullptr : c.take(R * maxd);
   L.dbuf[1] = L.fused ? nullptr : c.take(R * maxd);
   // scratch: the largest split-K / colsum requirement of any single call
@@ -686,6 +688,11 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
 
   // ---------------- forward ----------------
   PV_TRY(guide_fwd(p, L, s));
+  const bool sampled = K > 0 && p->class_onehot != nullptr;       // jiVAE without enumeration (plan->class_onehot)
+  if (sampled) {
+    if (p->coord_dim > 0) return PV_EINVAL;
+    PV_TRY(pv_jiv_sampled_prep(L.alpha, p->class_onehot, L.sw, L.jfix, p->beta_disc, (int)B, (int)K, s));
+  }
   const int coord = (int)(z - p->latent_dim);
   const bool cat_in = p->c_dim > 0 || K > 0;
   const float* zin = cat_in ? L.zy : (p->coord_dim > 0 ? L.z + coord : L.z);
@@ -715,7 +722,10 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
   }
   if (K > 0) {
     PV_TRY(pv_segsum(L.llrow, S, N, L.llkb, s));
-    if (!want_grads) PV_TRY(pv_jiv_combine(L.llkb, L.alpha, L.llb, nullptr, 0, 0, nullptr, 0, (int)z, (int)B, (int)K,
+    if (!want_grads && sampled)
+      PV_TRY(pv_jiv_combine_sampled(L.llkb, L.alpha, p->class_onehot, L.llb, nullptr, 0, 0, nullptr, 0, (int)z, (int)B,
+                                    (int)K, p->beta, p->beta_disc, 0, nullptr, nullptr, nullptr, s));
+    else if (!want_grads) PV_TRY(pv_jiv_combine(L.llkb, L.alpha, L.llb, nullptr, 0, 0, nullptr, 0, (int)z, (int)B, (int)K,
                                            p->beta_disc, 0, s));
   } else {
     PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
@@ -725,6 +735,7 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
     // (llb is formed by pv_jiv_combine at the end of the decoder backward; the scalars are finished there)
   } else
   PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
+  if (!want_grads && sampled) PV_TRY(pv_jiv_sampled_fix(p->scalars, L.jfix, s));
   if (!want_grads) return extra_outputs(p, L, nullptr, lat_in, s);
 
   // ---------------- backward: decoder ----------------
@@ -779,9 +790,15 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
 
   if (K > 0) {
     // sum the K replicas' dL/dz, form ll_b and the class-logit gradients; then the loss scalars
+    if (sampled)
+      PV_TRY(pv_jiv_combine_sampled(L.llkb, L.alpha, p->class_onehot, L.llb, L.dzc, (int)lat_in, (int)(lat_in - K), L.dhead,
+                                    (int)plan_head_w(p), (int)z, (int)B, (int)K, p->beta, p->beta_disc, 1, L.z, L.head,
+                                    L.z_scale, s));
+    else
     PV_TRY(pv_jiv_combine(L.llkb, L.alpha, L.llb, L.dzc, (int)lat_in, (int)(lat_in - K), L.dhead, (int)plan_head_w(p), (int)z,
                           (int)B, (int)K, p->beta_disc, 1, s, p->coord_dim > 0 ? L.dtp : nullptr));
     PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f, s));
+    if (sampled) PV_TRY(pv_jiv_sampled_fix(p->scalars, L.jfix, s));
   }
   return latent_encoder_bwd(p, L, lat_in, 4, 1, s);
 }

@@ -354,6 +354,7 @@ class IVAEEngine:
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = p.ext_head = p.ext_dhead = None
         p.row_w = p.row_elbo = p.dy = None
         p.ext_z = p.ext_dz = p.ext_ll = None
+        p.class_onehot = None
         p.ev_start, p.ev_stop = self.events
         need = _abi.lib().pv_ivae_workspace_bytes_for(C.byref(p), what)
         if need < 0:
@@ -378,13 +379,16 @@ class IVAEEngine:
     def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
                        scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None,
                        row_w: Optional[torch.Tensor] = None, row_elbo: Optional[torch.Tensor] = None,
-                       dy: Optional[torch.Tensor] = None, step: bool = False):
+                       dy: Optional[torch.Tensor] = None, step: bool = False,
+                       class_onehot: Optional[torch.Tensor] = None):
         """Enqueues Trace_ELBO.loss_and_grads on the current stream.  Results land in
         self.scalars (device, 4 floats) and self.grad[:n_flat]; nothing is synchronised.
         row_w (B): per-sample weights of the ELBO terms; row_elbo (B) / dy (B, c_dim): extra outputs
         (include/pyroved_amd.h: pv_ivae_plan.row_w / row_elbo / dy).
         step=True: the whole SVI.step — the Adam update follows in the same library call (pv_ivae_step; on the fused
-        decoder path it rides in the last gradient launch), identical in effect to loss_and_grads() + adam_step()."""
+        decoder path it rides in the last gradient launch), identical in effect to loss_and_grads() + adam_step().
+        class_onehot (B, discrete_dim): jiVAE WITHOUT enumeration — the class the guide drew for every sample
+        (pv_ivae_plan.class_onehot; the trainer's default enumerate_parallel=False)."""
         self.ensure_bound()
         if step and (self.ext_enc or self.ext_dec or getattr(self, "ext_y", False) or not want_grads):
             raise ValueError("step=True needs every parameter in the library (no user-defined modules) and want_grads")
@@ -424,6 +428,10 @@ class IVAEEngine:
         p.row_w = row_w.data_ptr() if row_w is not None else None
         p.row_elbo = row_elbo.data_ptr() if row_elbo is not None else None
         p.dy = dy.data_ptr() if dy is not None else None
+        class_onehot = self._prep(class_onehot, "class_onehot", (b, self.K)) if class_onehot is not None else None
+        if class_onehot is not None and self.K <= 0:
+            raise ValueError("class_onehot needs a model with a discrete latent (models.jiVAE)")
+        p.class_onehot = class_onehot.data_ptr() if class_onehot is not None else None
         try:
             if step:
                 p.lr, p.adam_beta1, p.adam_beta2, p.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
@@ -437,6 +445,7 @@ class IVAEEngine:
             p.scalars = self.scalars.data_ptr()
             p.ext_head = p.ext_dhead = None
             p.row_w = p.row_elbo = p.dy = None
+            p.class_onehot = None
         if self.ext_enc and want_grads:
             zd = p.z_dim
             for q in self._enc_params:
@@ -445,7 +454,7 @@ class IVAEEngine:
         if want_grads:
             self.grads_live = True
         self._count_bn(self._bn_enc)
-        self._keep = (x, eps, y, head, dhead, row_w)     # keep inputs alive until the stream has consumed them
+        self._keep = (x, eps, y, head, dhead, row_w, class_onehot)   # keep inputs alive until the stream has consumed them
 
     # ------------------------------------------------------------------ user-defined decoder (torch) around the HIP guide
     def _torch_decode(self, z, y=None, angle=None, shift=None, scale=None):

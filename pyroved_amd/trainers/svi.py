@@ -61,9 +61,15 @@ class SVItrainer:
         set_deterministic_mode(seed)
         self.device = kwargs.get("device", model.device)
         is_joint = int(getattr(model, "discrete_dim", 0)) > 0
-        if is_joint and not enumerate_parallel:
-            raise NotImplementedError("jiVAE is trained with exact enumeration of the discrete latent: pass "
-                                      "enumerate_parallel=True (the sampled-class estimator is not implemented)")
+        # jiVAE with the reference's DEFAULT enumerate_parallel=False: Trace_ELBO on a class drawn by the guide, score-function
+        # gradient for the class logits (svi.py:83-91; models/jivae.py:213-220).  Defined for the vanilla decoder only: with
+        # invariances the reference's own model raises (z repeated K times cannot broadcast against the (B, K) drawn class,
+        # models/jivae.py:181-189) — the same RuntimeError, at construction instead of at the first step
+        self._sampled_class = is_joint and not enumerate_parallel
+        if self._sampled_class and int(getattr(model, "coord", 0)) > 0:
+            raise RuntimeError("jiVAE with invariances cannot be trained without enumeration (the reference's model cannot "
+                               "broadcast its K-times repeated latent against the drawn class, models/jivae.py:181-189): "
+                               "pass enumerate_parallel=True")
         if enumerate_parallel and not is_joint:
             raise ValueError("enumerate_parallel=True needs a model with a discrete latent (models.jiVAE)")
         if loss is not None and loss != "Trace_ELBO":
@@ -134,6 +140,17 @@ class SVItrainer:
                 new[:self._hist.shape[0]].copy_(self._hist)
             self._hist = new
         direct = world == 1 and getattr(eng, "supports_scalars_out", False)   # single process: the loss lands in the history slot
+        extra = {}
+        if self._sampled_class:
+            # the guide's second draw (after eps): y_b ~ OneHotCategorical(alpha_b), alpha = the encoder's class
+            # probabilities for the GLOBAL batch (every rank computes them, so every rank draws the same classes)
+            xg = x.to(dev, torch.float32)
+            alpha = eng.encode(xg)[2]
+            if self.rng == "cpu":
+                y1h = torch.distributions.OneHotCategorical(probs=alpha.cpu()).sample().to(dev)
+            else:
+                y1h = torch.distributions.OneHotCategorical(probs=alpha).sample()
+            extra["class_onehot"] = y1h[x0:x0 + hi - lo].contiguous()
         if hi > lo:
             xs = x[x0:x0 + hi - lo].to(dev, torch.float32)
             es = eps[x0:x0 + hi - lo].to(dev, torch.float32)
@@ -141,12 +158,12 @@ class SVItrainer:
             one_call = (direct and train and getattr(eng, "supports_step", False)
                         and not (getattr(eng, "ext_enc", False) or getattr(eng, "ext_dec", False)))
             if one_call:                              # loss, gradients and Adam in one library call (pv_ivae_step)
-                eng.loss_and_grads(xs, es, beta, ys, scalars_out=self._hist[i], step=True)
+                eng.loss_and_grads(xs, es, beta, ys, scalars_out=self._hist[i], step=True, **extra)
                 return
             if direct:
-                eng.loss_and_grads(xs, es, beta, ys, want_grads=train, scalars_out=self._hist[i])
+                eng.loss_and_grads(xs, es, beta, ys, want_grads=train, scalars_out=self._hist[i], **extra)
             else:
-                eng.loss_and_grads(xs, es, beta, ys, want_grads=train)
+                eng.loss_and_grads(xs, es, beta, ys, want_grads=train, **extra)
         else:                                          # more ranks than samples: contribute zeros
             eng.grad.zero_()
         if world > 1:
@@ -263,7 +280,7 @@ class SVItrainer:
         None when the loader is not a plain TensorDataset loader (the caller falls back to iterating it)."""
         from torch.utils.data import DataLoader, TensorDataset
         ds = getattr(loader, "dataset", None)
-        if (not self.device_feed or not isinstance(loader, DataLoader) or not isinstance(ds, TensorDataset)
+        if (self._sampled_class or not self.device_feed or not isinstance(loader, DataLoader) or not isinstance(ds, TensorDataset)
                 or loader.num_workers != 0 or loader.batch_sampler is None or len(ds.tensors) not in (1, 2)
                 or getattr(self.engine, "device", None) is None or self.rng != "cpu"):
             return None

@@ -20,9 +20,19 @@ SURVEY.md; none of this arithmetic lives under /root/reference):
 * ``pyro.plate`` with no subsampling is a no-op for log-prob arithmetic
   (the batch dim is already dim -1 of every site; nothing is rescaled).
 * ``Trace_ELBO`` (num_particles=1): ``elbo = sum(model log_prob_sum) -
-  sum(guide log_prob_sum)``; all latent sites on this path are fully
-  reparameterised, so surrogate == elbo; ``loss = -elbo``; ``loss.backward()``
-  unless nothing requires grad (e.g. under ``torch.no_grad()``).
+  sum(guide log_prob_sum)``; with fully reparameterised latent sites
+  surrogate == elbo; ``loss = -elbo``; ``loss.backward()`` unless nothing
+  requires grad (e.g. under ``torch.no_grad()``).
+* A guide site WITHOUT ``rsample`` (jiVAE's ``OneHotCategorical`` when the
+  trainer runs with its default ``enumerate_parallel=False``) is drawn with
+  ``fn.sample()`` and enters the surrogate through the score-function term
+  (pyro/infer/trace_elbo.py ``_compute_log_r`` + ``score_parts``):
+  ``surrogate = sum(model log_prob_sum) - sum(reparameterised guide
+  log_prob_sum) + sum_b detach(log_r_b) * log q(value_b)``, with
+  ``log_r_b = sum over sites of (scaled model log_prob - scaled guide log_prob)``
+  of plate element b and the score function ``log q`` UNscaled
+  (``ScoreParts.scale_and_mask`` leaves ``score_function`` unscaled).  The
+  reported loss stays ``-(sum model - sum guide)``.
 * ``SVI.step``: loss_and_grads → optimizer over every parameter registered by
   ``pyro.module`` during the step → ``zero_grads`` (grads become *zero tensors*,
   not None) → python float of the loss.
@@ -121,14 +131,19 @@ def sample(name, fn, obs=None, infer=None):
             value = fn.enumerate_support(expand=True)
             enumerated = True
         else:
-            state = torch.get_rng_state()
-            value = fn.rsample()
-            after = torch.get_rng_state()
-            torch.set_rng_state(state)
-            _TAP[name + ".eps"] = torch.empty(value.shape).normal_()
-            torch.set_rng_state(after)
+            if fn.has_rsample:
+                state = torch.get_rng_state()
+                value = fn.rsample()
+                after = torch.get_rng_state()
+                torch.set_rng_state(state)
+                _TAP[name + ".eps"] = torch.empty(value.shape).normal_()
+                torch.set_rng_state(after)
+            else:
+                with torch.no_grad():
+                    value = fn.sample()              # score-function site (no reparameterisation)
     ctx.sites[name] = dict(name=name, fn=fn, value=value, scale=scale,
                            is_observed=obs is not None, enumerated=enumerated,
+                           reparam=bool(fn.has_rsample) or obs is not None or ctx.mode == "model",
                            log_prob=fn.log_prob(value))
     return value
 
@@ -198,11 +213,39 @@ class Trace_ELBO(ELBO):
             elbo = elbo - (s["scale"] * s["log_prob"]).sum()
         return elbo
 
+    def _surrogate(self, g, m, elbo):
+        """elbo + the score-function terms of non-reparameterised guide sites (none on the default paths)."""
+        score = [s for s in g.sites.values() if not s["reparam"] and not s["enumerated"]]
+        if not score:
+            return elbo
+        log_r = 0.0                                  # per element of the data plate (dim -1 of every site's log_prob)
+        for s in m.sites.values():
+            log_r = log_r + s["scale"] * s["log_prob"]
+        for s in g.sites.values():
+            log_r = log_r - s["scale"] * s["log_prob"]
+        log_r = log_r.detach()
+        sur = 0.0
+        for s in m.sites.values():
+            sur = sur + (s["scale"] * s["log_prob"]).sum()
+        for s in g.sites.values():
+            if s["reparam"]:
+                sur = sur - (s["scale"] * s["log_prob"]).sum()          # entropy term
+            else:
+                sur = sur + (log_r * s["log_prob"]).sum()               # score function (unscaled log q)
+        _TAP["log_r"] = log_r.clone()
+        return sur
+
     def loss_and_grads(self, model, guide, *args, **kwargs):
         g, m = self._terms(model, guide, *args, **kwargs)
         params = dict(g.params)
         params.update(m.params)
-        loss = -self._elbo(g, m)
+        elbo = self._elbo(g, m)
+        loss = -elbo
+        if not self.enumerate_sites:
+            sur = self._surrogate(g, m, elbo)
+            if sur is not elbo:
+                # the value reported is the ELBO's; gradients come from the surrogate
+                loss = -(sur - sur.detach() + elbo.detach())
         _TAP["terms"] = {k: (s["scale"] * s["log_prob"]).sum().detach()
                          for tr, pre in ((g, "guide."), (m, "model."))
                          for k, s in ((pre + n, s) for n, s in tr.sites.items())}

@@ -164,7 +164,7 @@ def run_steps(name, data_dim, invariances, batch, steps=3, latent_dim=2, xkind="
 
 
 def run_jsteps(name, data_dim, invariances, discrete_dim, batch, steps=3, latent_dim=2, xkind="rand",
-               scale_factor=None, full=False):
+               scale_factor=None, full=False, enumerate_parallel=True):
     """jiVAE (models/jivae.py:109-220) through SVItrainer(enumerate_parallel=True) (trainers/svi.py:83-90):
     TraceEnum_ELBO with the guide's OneHotCategorical site enumerated in parallel."""
     out = {}
@@ -178,12 +178,15 @@ def run_jsteps(name, data_dim, invariances, discrete_dim, batch, steps=3, latent
     sf = [1.0, 1.0] if scale_factor is None else (list(scale_factor) if isinstance(scale_factor, (list, tuple))
                                                    else [scale_factor, scale_factor])
     out["meta.scale_factor"] = np.array(sf, dtype=np.float64)
+    out["meta.enumerate_parallel"] = np.int64(enumerate_parallel)
     model = models.jiVAE(data_dim, latent_dim, discrete_dim, invariances, seed=1, device="cpu")
     names = {id(p): n for n, p in model.named_parameters()}
     for n, p in model.named_parameters():
         put(out, "init." + n, digest(p))
     x = make_x(xkind, batch, data_dim)
-    trainer = trainers.SVItrainer(model, enumerate_parallel=True, seed=1, device="cpu")
+    # enumerate_parallel=False is the trainer's DEFAULT (trainers/svi.py:66): Trace_ELBO with the class drawn by the
+    # guide and a score-function gradient for its logits
+    trainer = trainers.SVItrainer(model, enumerate_parallel=enumerate_parallel, seed=1, device="cpu")
     step_kw = {} if scale_factor is None else {"scale_factor": scale_factor}
     for k in range(steps):
         grads = {}
@@ -199,14 +202,21 @@ def run_jsteps(name, data_dim, invariances, discrete_dim, batch, steps=3, latent
         tap = _minipyro.tap()
         pre = "s%d" % k
         out[pre + ".loss"] = np.float64(loss)
-        for tn, tv in tap["enum_terms"].items():
+        for tn, tv in tap["enum_terms" if enumerate_parallel else "terms"].items():
             out[pre + ".term." + tn] = np.float64(tv.item())
         gfn = tap["guide_fns"]["latent_cont"].base_dist
         out[pre + ".eps"] = tap["latent_cont.eps"].numpy().copy()
         out[pre + ".z_loc"] = gfn.loc.detach().numpy().copy()
         out[pre + ".z_scale"] = gfn.scale.detach().numpy().copy()
         out[pre + ".z"] = tap["sites"]["guide.latent_cont"].numpy().copy()
-        out[pre + ".alpha"] = tap["enum_weights"].t().numpy().copy()          # (B, K) = q(k | x_b)
+        if enumerate_parallel:
+            out[pre + ".alpha"] = tap["enum_weights"].t().numpy().copy()          # (B, K) = q(k | x_b)
+        else:
+            out[pre + ".alpha"] = tap["guide_fns"]["latent_disc"].probs.detach().numpy().copy()
+            out[pre + ".y"] = tap["sites"]["guide.latent_disc"].numpy().copy()      # the drawn one-hot classes (B, K)
+            out[pre + ".log_r"] = tap["log_r"].numpy().copy()
+            # generator state right after the step (pins what the draws consumed: normal_ then multinomial)
+            out[pre + ".rng_probe"] = torch.get_rng_state()[:64].numpy().copy()
         for n, g in grads.items():
             put(out, pre + ".grad." + n, digest(g))
             if full:
@@ -538,6 +548,12 @@ if __name__ == "__main__":
         run_jsteps("jivae_8x8_rt_k3_b4_sf", (8, 8), ["r", "t"], 3, batch=4, scale_factor=[2.0, 3.0])
         run_jsteps("jivae_1d16_t_k2_b5", (16,), ["t"], 2, batch=5)
         run_jsteps("jivae_28x28_r_k10_b16", (28, 28), ["r"], 10, batch=16, steps=2)
+    if only is None or "jsampled" in only:
+        # the trainer's default (enumerate_parallel=False): defined for the vanilla decoder only — with invariances the
+        # reference's model raises (z repeated K times cannot broadcast against the drawn class, models/jivae.py:181-189)
+        run_jsteps("jsivae_8x8_none_k3_b5", (8, 8), None, 3, batch=5, enumerate_parallel=False, full=True)
+        run_jsteps("jsivae_1d16_none_k4_b6_sf", (16,), None, 4, batch=6, scale_factor=[1.5, 0.5], enumerate_parallel=False)
+        run_jsteps("jsivae_28x28_none_k10_b16", (28, 28), None, 10, batch=16, steps=2, enumerate_parallel=False)
     if only is None or "jvanilla" in only:
         run_jsteps("jivae_8x8_none_k3_b5", (8, 8), None, 3, batch=5)          # fcDecoderNet (constructor default)
         run_jsteps("jivae_1d16_none_k4_b6_sf", (16,), None, 4, batch=6, scale_factor=[1.5, 0.5])

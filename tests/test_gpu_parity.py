@@ -458,6 +458,71 @@ JVARIANTS = {
 }
 
 
+JSAMPLED_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "jsivae_*.npz")))
+
+
+@pytest.mark.parametrize("name", JSAMPLED_CASES)
+def test_jivae_sampled_class_steps_vs_golden(gpu_device, name):
+    """jiVAE WITHOUT enumeration — SVItrainer's default enumerate_parallel=False (trainers/svi.py:66, 83-91;
+    models/jivae.py:213-220) — through the C ABI (pv_ivae_plan.class_onehot) against the reference's recorded steps:
+    loss, the five site terms folded into the 4 scalars, class probabilities, every gradient (incl. the score-function
+    gradient of the class logits), parameters after Adam."""
+    gold = load_golden(name)
+    meta = jmeta_of(gold)
+    model = pv.models.jiVAE(meta["data_dim"], meta["latent_dim"], meta["discrete_dim"], None, seed=1, device="cuda")
+    eng = model.engine(fused=2)
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=None,
+                     discrete_dim=meta["discrete_dim"])
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    o.sampled_class = True
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        eps, y = torch.from_numpy(gold[pre + ".eps"]), torch.from_numpy(gold[pre + ".y"])
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"], class_onehot=y.cuda())
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=RTOL_ELBO, err_msg="loss")
+        np.testing.assert_allclose(s[1], float(gold[pre + ".term.model.obs"]), rtol=RTOL_ELBO)
+        np.testing.assert_allclose(s[2], float(gold[pre + ".term.model.latent_cont"]) + float(gold[pre + ".term.model.latent_disc"]), rtol=1e-4)
+        np.testing.assert_allclose(s[3], float(gold[pre + ".term.guide.latent_cont"]) + float(gold[pre + ".term.guide.latent_disc"]), rtol=1e-4)
+        o.step(x, eps, meta["beta"], y)
+        for key in o.p:
+            tol = jivae_grad_tol(key) or 1e-3
+            err = rel_l2(eng.grad_of(key), o.last_grads[key])
+            assert err < tol, "step %d grad %s: rel l2 error %.3e vs oracle" % (k, key, err)
+            check_digest(eng.grad_of(key), gold, pre + ".grad." + key, rtol=2 * tol, atol=1e-5, what=name)
+        eng.adam_step()
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+
+
+def test_jivae_default_trainer_trains_and_matches_oracle(gpu_device):
+    """SVItrainer(jiVAE) with its defaults (the reference's own default path) runs: per-epoch losses against the CPU oracle
+    drawing eps and the classes from the same seed (normal_ then multinomial per step, as the guide does); with
+    invariances the constructor raises what the reference's first step would."""
+    with pytest.raises(RuntimeError):
+        pv.trainers.SVItrainer(pv.models.jiVAE((8, 8), 2, 3, ["r"], seed=1, device="cuda"), seed=1)
+    data = make_x("rand", 24, (8, 8))
+    loader = pv.utils.init_dataloader(data, batch_size=8, shuffle=False)
+    model = pv.models.jiVAE((8, 8), 2, 3, None, seed=1, device="cuda")
+    cfg = orc.Config(data_dim=(8, 8), latent_dim=2, invariances=None, discrete_dim=3)
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    o.sampled_class = True
+    tr = pv.trainers.SVItrainer(model, seed=1)
+    for _ in range(2):
+        tr.step(loader)
+    torch.manual_seed(1)
+    ref = []
+    for _ in range(2):
+        iter(loader)                                    # (creating a DataLoader iterator draws its base seed)
+        tot = 0.0
+        for i in range(0, 24, 8):
+            xb = data[i:i + 8]
+            tot += o.step(xb, o.draw_eps(8), 1.0, None)
+        ref.append(tot / 24)
+    np.testing.assert_allclose(tr.loss_history["training_loss"], ref, rtol=1e-4)
+    assert not np.isnan(tr.loss_history["training_loss"]).any()
+
+
 @pytest.mark.parametrize("fused", [0, 2])
 @pytest.mark.parametrize("vname", sorted(JVARIANTS))
 def test_jivae_variants_vs_oracle(gpu_device, vname, fused):

@@ -245,6 +245,56 @@ def test_jivae_oracle_steps_match_reference(name):
     assert (alpha.argmax(1).numpy() == gold["enc.classes"]).all()
 
 
+# ---------------------------------------------------------------- jiVAE, sampled class (the trainer's default)
+JSAMPLED_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "jsivae_*.npz")))
+
+
+@pytest.mark.parametrize("name", JSAMPLED_CASES)
+def test_jivae_sampled_class_oracle_matches_reference(name):
+    """SVItrainer(jiVAE) with the reference's DEFAULT enumerate_parallel=False (trainers/svi.py:66, 83-91): Trace_ELBO on a
+    class drawn by the guide, score-function gradient for the class logits (oracle.jelbo_sampled).  Loss, the five site
+    terms, log_r, every gradient and parameter per recorded step — first with the recorded draws, then with the oracle
+    drawing eps and the class itself from the trainer's seed (pins the generator contract: normal_ then multinomial)."""
+    from conftest import jmeta_of
+    gold = load_golden(name)
+    meta = jmeta_of(gold)
+    assert int(gold["meta.enumerate_parallel"]) == 0 and meta["invariances"] is None
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=None,
+                     discrete_dim=meta["discrete_dim"])
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    for own_draws in (False, True):
+        model = pv.models.jiVAE(meta["data_dim"], meta["latent_dim"], meta["discrete_dim"], None, seed=1, device="cpu")
+        o = orc.SVIOracle(model.state_dict(), cfg)
+        o.sampled_class = True
+        torch.manual_seed(1)                          # SVItrainer.__init__ (svi.py:76)
+        for k in range(meta["steps"]):
+            pre = "s%d" % k
+            if own_draws:
+                eps = torch.empty(meta["batch"], cfg.z_dim).normal_()
+                np.testing.assert_array_equal(eps.numpy(), gold[pre + ".eps"])
+                loss = o.step(x, eps, meta["beta"], None)
+                np.testing.assert_array_equal(o.last["y"].numpy(), gold[pre + ".y"])
+            else:
+                loss = o.step(x, torch.from_numpy(gold[pre + ".eps"]), meta["beta"], torch.from_numpy(gold[pre + ".y"]))
+            np.testing.assert_allclose(loss, float(gold[pre + ".loss"]), rtol=2e-6)
+            for t, v in o.last["terms"].items():
+                np.testing.assert_allclose(v.item(), float(gold[pre + ".term." + t]), rtol=2e-6, err_msg=t)
+            np.testing.assert_allclose(o.last["log_r"].numpy(), gold[pre + ".log_r"], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(o.last["alpha"].detach().numpy(), gold[pre + ".alpha"], rtol=1e-5, atol=1e-7)
+            for n in o.p:
+                check_digest(o.last_grads[n], gold, pre + ".grad." + n, rtol=2e-4, atol=1e-6, what=name)
+                check_digest(o.p[n], gold, pre + ".param." + n, rtol=2e-5, atol=1e-6, what=name)
+
+
+def test_jivae_sampled_class_needs_the_vanilla_decoder():
+    """With invariances the reference's own model cannot run without enumeration (models/jivae.py:181-189: z is repeated
+    K times and then concatenated with the (B, K) drawn class -> RuntimeError from Concat's broadcast); mirrored."""
+    cfg = orc.Config(data_dim=(8, 8), latent_dim=2, invariances=["r"], discrete_dim=3)
+    model = pv.models.jiVAE((8, 8), 2, 3, ["r"], seed=1, device="cpu")
+    with pytest.raises(RuntimeError):
+        orc.jelbo_sampled(model.state_dict(), cfg, torch.rand(4, 8, 8), torch.randn(4, 3))
+
+
 # ---------------------------------------------------------------- VED (models/ved.py, nets/conv.py)
 VED_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ved_*.npz")))
 
