@@ -153,7 +153,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       const int64_t units = R / FD_UNIT;
       L.f_grid = pv_sdec_fused_grid(units);
       L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
-      if (p->fused >= 2) L.f_kmax *= pv_sdec_fused_bf16_waves(p->fused == 2);   // the bf16 kernels publish dL/d(hz) per wave
+      if (p->fused >= 2) L.f_kmax *= pv_sdec_fused_bf16_waves(p->fused == 2, units);   // the bf16 kernels publish dL/d(hz) per wave
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
       L.f_part_hz = c.take(S * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);

@@ -48,7 +48,8 @@ int pv_sdec_fused_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
 // same interface, bf16 split-precision ("bf16x3") matrix math (pv_sdec_fused_bf16.hip); _prep must run first on the
 // same stream, once per parameter state: it writes f.wimg and, with grads, zero-fills f.part_hz
 // x3: split precision (pv_sdec_fused_bf16.hip) or plain bf16 operands (pv_sdec_fused_w8.hip, whose images are
-// pre-scaled by 2 log2(e); PV_W8=0 in the environment selects the older 4-wave plain-bf16 kernel instead)
+// pre-scaled by 2 log2(e), once a workgroup has enough units to fill its 8-wave tiles; the 4-wave plain-bf16 kernel
+// for smaller problems; PV_W8=0 / 1 in the environment forces one)
 int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s);
 // ... or, as arguments for a kernel that hosts the preparation (pv_fb_layout.h: pv_fb_prep)
 struct PvFbPrep;
@@ -56,7 +57,7 @@ PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3);
 int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s);
 int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
 // waves per workgroup that publish a dL/d(hz) slot (sizes part_hz)
-int pv_sdec_fused_bf16_waves(bool x3);
+int pv_sdec_fused_bf16_waves(bool x3, int64_t units);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
 struct PvFusedOffsets { int64_t W1, b1, W2, b2, Wc, wo, bo; };
 int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int dwo_slots,

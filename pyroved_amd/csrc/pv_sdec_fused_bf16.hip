@@ -808,20 +808,23 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_trace), n * sizeof(long long));
 }
 
-// the plain-bf16 path runs the 8-wave kernel (pv_sdec_fused_w8.hip) unless PV_W8=0 asks for the 4-wave one (A/B runs)
-static bool fb_use_w8() {
+// the plain-bf16 path runs the 8-wave kernel (pv_sdec_fused_w8.hip) when a workgroup gets at least ~6 of the 8 units a
+// tile takes (batch >= ~32 at 28x28; below that most of a 128-row tile would idle and the 4-wave / 64-row kernel here
+// is faster: 26 vs 30 us at batch 16).  PV_W8=0 / 1 in the environment forces one of them (A/B runs).
+static bool fb_use_w8(int64_t units) {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("PV_W8"); v = (e && atoi(e) == 0) ? 0 : 1; }
-  return v != 0;
+  if (v < 0) { const char* e = getenv("PV_W8"); v = e ? (atoi(e) == 0 ? 0 : 1) : 2; }
+  if (v != 2) return v != 0;
+  return units >= 6 * (int64_t)pv_sdec_fused_grid(units) && units * FD_UNIT < (int64_t)1 << 31;
 }
-int pv_sdec_fused_bf16_waves(bool x3) { return (!x3 && fb_use_w8()) ? 8 : FB_WAVES; }
+int pv_sdec_fused_bf16_waves(bool x3, int64_t units) { return (!x3 && fb_use_w8(units)) ? 8 : FB_WAVES; }
 
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   static_assert(FB_WIMG_BYTES == 4 * IMG_BYTES, "pv_sdec_fused.h and the LDS image layout disagree");
   PvFbPrep p{};
   p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz;
   p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
-  p.scale = (!x3 && fb_use_w8()) ? 2.8853900817779268f : 0.0f;
+  p.scale = (!x3 && fb_use_w8(f.units)) ? 2.8853900817779268f : 0.0f;
   return p;
 }
 
@@ -837,7 +840,7 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
 }
 
 int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s) {
-  if (!x3 && fb_use_w8()) return pv_sdec_fused_w8_launch(f_in, grid, grads, s);
+  if (!x3 && fb_use_w8(f_in.units)) return pv_sdec_fused_w8_launch(f_in, grid, grads, s);
   PvFused f = f_in;
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }

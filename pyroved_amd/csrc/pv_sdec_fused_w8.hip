@@ -104,16 +104,25 @@ __device__ __forceinline__ float w8_sum_q(float v) {
 }
 
 // forward layer of the wave's unit: out = bias + W in, both pre-scaled by C (C * pre-activation on return)
+// lane offsets (elements) of the weight reads, computed once per kernel and kept in registers (10 of them):
+//   forward: row 16*ob + r, logical chunk 4m + q -> physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])   (pv_fb_layout.h)
+//   dgrad  : lane i of 16-lane group q points at W[32m + 4q (+16) + r/4][...], swizzle 4*(r>>2) + SL[q]
+struct W8Addr { int fb, fx[4], db, dx[4]; };
+__device__ __forceinline__ W8Addr w8_addr(int r, int q) {
+  W8Addr a;
+  a.fb = r * LDB + 8 * (q ^ fb_sl(r >> 2));
+  a.db = (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q));
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { a.fx[m] = 32 * (m ^ (r & 3)); a.dx[m] = 32 * (m ^ (r >> 2)); }
+  return a;
+}
+
 __device__ __forceinline__ void w8_layer_fwd(const __bf16* __restrict__ Wh, const float* __restrict__ bs,
-                                             const bf16x4 (&ih)[8], f32x4 (&out)[8], int r, int q) {
+                                             const bf16x4 (&ih)[8], f32x4 (&out)[8], const W8Addr& ad, int q) {
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
-  // row 16*ob + r, logical chunk 4m + q  ->  physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])   (pv_fb_layout.h)
-  r |= w8_opaque0();
-  const __bf16* ah = Wh + r * LDB + 8 * (q ^ fb_sl(r >> 2));
-  int xm[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) xm[m] = 32 * (m ^ (r & 3));
+  const __bf16* ah = Wh + ad.fb;
+  const int (&xm)[4] = ad.fx;
   bf16x8 wh[2][2];
   auto load = [&](int g, bf16x8 (&h)[2]) {
     const int m = g >> 2, op = (g & 3) * 2;
@@ -135,14 +144,11 @@ __device__ __forceinline__ void w8_layer_fwd(const __bf16* __restrict__ Wh, cons
 
 // dgrad of the wave's unit: out[k] = sum_j (C W)[j][k] dp[j]; A = W^T via the transposing LDS read
 __device__ __forceinline__ void w8_layer_dgrad(const __bf16* __restrict__ Wh, const bf16x4 (&ih)[8], f32x4 (&out)[8],
-                                               int r, int q) {
+                                               const W8Addr& ad) {
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) out[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  r |= w8_opaque0();
-  const __bf16* ah = Wh + (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q));
-  int xk[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) xk[kk] = 32 * (kk ^ (r >> 2));
+  const __bf16* ah = Wh + ad.db;
+  const int (&xk)[4] = ad.dx;
   bf16x8 wh[2][2];
   auto load = [&](int g, bf16x8 (&h)[2]) {
     const int m = g >> 2, kp = (g & 3) * 2;
@@ -300,7 +306,7 @@ extern "C" int pv_debug_read_trace_w8(long long* out, int n) {
 template <bool GRADS, int LIK>
 __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   extern __shared__ __attribute__((aligned(16))) char smb[];
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = blockIdx.x, G = gridDim.x;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smb);
@@ -426,6 +432,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     w8_glds4(f.grid + (int64_t)n0 * f.cd + (lane & (16 * f.cd - 1)), lds0 + WO_CGR + wave * 256);
   };
   fetch_unit_inputs(pos_cur);
+  const W8Addr wad = w8_addr(r, q);
   int tile_no = -1;
   for (int ut = u_lo; ut < u_hi; ut += W8_WAVES) {
     ++tile_no;
@@ -437,10 +444,13 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     if (ut + W8_WAVES + wave < u_hi) advance(pos_nx, W8_WAVES);
     else pos_nx = pos_lo;
     int opq = 0;
-    asm volatile("" : "+v"(opq));       // loop-variant zero: keeps LICM from hoisting the LDS-resident vectors
-    const float* wos = vec + opq;
-    const float* b1s = vec + FD_H + opq;
-    const float* b2s = vec + 2 * FD_H + opq;
+    asm volatile("" : "+v"(opq));       // a zero the compiler cannot see through, OR-ed into the lane id: every lane-dependent
+    const int lane = lane0 | opq, r = lane & 15, q = lane >> 4;   // address below is then recomputed per tile (one or two
+    // instructions each) instead of being hoisted out of the loop, kept in registers and — at the 256-register limit —
+    // spilled to scratch and reloaded (the first build of this kernel moved 25 MB of scratch per launch that way)
+    const float* wos = vec;
+    const float* b1s = vec + FD_H;
+    const float* b2s = vec + 2 * FD_H;
     const bool act = wave < nact;
     const int unit = act ? pos_cur.unit : ut;
     const int bu = pos_cur.b;
@@ -448,8 +458,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     float x0, x1, u0c, u1c, sc;
     w8_wait_vm0();                        // this wave's LDS-DMA of the tile's inputs (issued a tile ago)
     {
-      const float* t = ctp + opq;
-      const float* gr = cgr + opq;
+      const float* t = ctp;
+      const float* gr = cgr;
       if (f.cd == 2) {
         const float gx = gr[2 * r], gy = gr[2 * r + 1];
         u0c = gx * t[0] - gy * t[1];
@@ -463,16 +473,20 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
       }
     }
     const float xv = xv_next, swv = sw_next;
-    float* inf_x0 = info + 16 * wave + opq;
-    float* inf_x1 = info + W8_ROWS + 16 * wave + opq;
-    float* inf_dl = info + 2 * W8_ROWS + 16 * wave + opq;
+    float* inf_x0 = info + 16 * wave;
+    float* inf_x1 = info + W8_ROWS + 16 * wave;
+    float* inf_dl = info + 2 * W8_ROWS + 16 * wave;
 
     // saved activations live as bf16 only (h0b, h1b): fp32 copies next to the 104 accumulator registers do not fit
     // two waves per SIMD; the backward pass forms 1 - h^2 from them (bf16-relative precision, like every MFMA operand here)
     f32x4 tC[8];
     bf16x4 pA[8], h0b[8], h1b[8];
     float dlda = 0.0f;
-    if (act) {
+    // A wave without a unit of its own (partial last tile) runs the same straight-line code on a valid unit of the
+    // workgroup's range (what its prefetch slots hold) with its dL/dlogit forced to zero: every gradient it stages or
+    // accumulates is then zero and its per-row outputs are not stored.  No wave-uniform branches around the phases —
+    // the merges they create cost register copies of the 104 accumulators' neighbours in every tile.
+    {
       // ---- coordinate layer on the matrix cores: C h0pre = (C Wc) x' + C bc + C hz[b] ----
       bf16x4 bx = w8_zero4();
       {
@@ -483,8 +497,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
         if (q < 2) { bx[0] = vh; bx[1] = vl; bx[2] = vh; }
         else if (q == 2) { bx[0] = one; bx[1] = one; }
       }
-      const bf16x4* atab = reinterpret_cast<const bf16x4*>(smb + WO_ATAB) + lane + opq;
-      const float* hzb = chz + opq;
+      const bf16x4* atab = reinterpret_cast<const bf16x4*>(smb + WO_ATAB) + lane;
+      const float* hzb = chz;
       bf16x4 aop[8];
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) {
@@ -507,13 +521,13 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     asm volatile("; W8_P1_coord_done");
     W8_STAMP(1);
     fetch_unit_inputs(pos_nx);                 // the slots were consumed by the coordinate layer above
-    if (act) {
-      w8_layer_fwd(W1h, b1s, h0b, tC, r, q);
+    {
+      w8_layer_fwd(W1h, b1s, h0b, tC, wad, q);
       w8_tanh8(tC);
       w8_cvt8(tC, h1b);                                             // feeds layer 2 and its wgrad
       asm volatile("; W8_P2_l1_done");
     W8_STAMP(2);
-      w8_layer_fwd(W2h, b2s, h1b, tC, r, q);
+      w8_layer_fwd(W2h, b2s, h1b, tC, wad, q);
       // ---- h2, output layer + likelihood (fp32); tC <- g = wo (1 - h2^2), pA <- bf16(h2) ----
       w8_tanh8(tC);                                                // tC = h2
       f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -547,10 +561,12 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
         dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
         locv = pr;
       }
-      dlda *= swv;
+      dlda *= act ? swv : 0.0f;
       if (q == 0) {
-        f.llrow[row] = ll;
-        if (f.loc) f.loc[row] = locv;
+        if (act) {
+          f.llrow[row] = ll;
+          if (f.loc) f.loc[row] = locv;
+        }
         if (GRADS) { dbo += dlda; inf_dl[r] = dlda; }
       }
       xv_next = x_of(pos_nx);
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     W8_STAMP(3);
     if (!GRADS) continue;
     const int ksteps = (nact + 1) >> 1;
-    if (act) {
+    {
       // ---- d(wo) += sum_rows dlda h2 : wave-local MFMA through the wave's own rows of staging A (free: every wave
       // passed barrier 4 of the previous tile); B = dlda of rows 4q..4q+3 in columns 3 (hi) and 4 (lo)
       w8_wait_lgkm0();
@@ -577,9 +593,6 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) tC[jb] = tC[jb] * dlda;
       w8_cvt8(tC, pA);                                            // feeds the wgrad and the dgrad of layer 2
-    } else {
-#pragma unroll
-      for (int jb = 0; jb < 8; ++jb) { pA[jb] = w8_zero4(); h1b[jb] = w8_zero4(); h0b[jb] = w8_zero4(); }
     }
     asm volatile("; W8_P4_dwo_done");
     W8_STAMP(4);
@@ -593,56 +606,39 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     asm volatile("; W8_P6_cons2");
     W8_STAMP(6);
     bf16x4 p0[8];
-    if (act) {
-      w8_layer_dgrad(W2h, pA, tC, r, q);                           // tC = C dL/dh1
+    {
+      w8_layer_dgrad(W2h, pA, tC, wad);                            // tC = C dL/dh1
       w8_mul_dtanh(tC, h1b);                                      // C dpre1
       w8_cvt8(tC, pA);                                            // feeds the dgrad and the wgrad of layer 1
       asm volatile("; W8_P7_dgrad2");
     W8_STAMP(7);
-      w8_layer_dgrad(W1h, pA, tC, r, q);                           // tC = C^2 dL/dh0
+      w8_layer_dgrad(W1h, pA, tC, wad);                            // tC = C^2 dL/dh0
       w8_mul_dtanh(tC, h0b);                                      // C^2 dpre0
       w8_cvt8(tC, p0);
-    } else {
-#pragma unroll
-      for (int jb = 0; jb < 8; ++jb) { pA[jb] = w8_zero4(); p0[jb] = w8_zero4(); }
     }
     asm volatile("; W8_P8_dgrad1");
     W8_STAMP(8);
     __syncthreads();                                                // barrier 2: round 1 consumed everywhere
     W8_STAMP(9);
-    // ---- wgrad of layer 1: stage (C dpre1, h0) ----
-    w8_stage_store(sA, pA, 16 * wave + r, q);
-    w8_stage_store(sB, h0b, 16 * wave + r, q);
-    __syncthreads();                                                // barrier 3
-    asm volatile("; W8_P10_bar3");
-    W8_STAMP(10);
-    w8_wgrad_consume(sA, sB, accW1, accB1, wave, r, q, ksteps);
-    asm volatile("; W8_P11_cons1");
-    W8_STAMP(11);
-    if (act) {
+    {
+      // (the staging area is free between barrier 2 and the round-2 stores: the wave's own rows serve the dpre0 sums now,
+      //  which ends p0's life before the round-2 consume)
       // ---- coordinate layer backward, row-local part on the matrix cores: D[m][row] = sum_j T[m][j] dpre0[row][j] ----
       f32x4 dd = {0.0f, 0.0f, 0.0f, 0.0f};
-      const bf16x8* ttab = reinterpret_cast<const bf16x8*>(smb + WO_TTAB) + lane + opq;
+      const bf16x8* ttab = reinterpret_cast<const bf16x8*>(smb + WO_TTAB) + lane;
 #pragma unroll
       for (int mm = 0; mm < 4; ++mm) dd = MFMA32(ttab[64 * mm], w8_cat(p0[2 * mm], p0[2 * mm + 1]), dd);
-      if (q == 0) {
+      if (q == 0 && act) {
         const float d0 = (dd[0] + dd[1]) * W8_RC2, d1 = (dd[2] + dd[3]) * W8_RC2;
         f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
         f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
         f.rowtp[2 * f.M + row] = d0;
         f.rowtp[3 * f.M + row] = d1;
       }
-      if (bu != cur_b) {
+      if (act && bu != cur_b) {
         if (cur_b >= 0) flush_hz(cur_b);
         cur_b = bu;
       }
-    }
-    asm volatile("; W8_P12_rowlocal");
-    W8_STAMP(12);
-    __syncthreads();                                                // barrier 4: round 2 consumed everywhere
-    asm volatile("; W8_P13_bar4");
-    W8_STAMP(13);
-    if (act) {
       // ---- dL/d(hz[b]) = sum_rows dpre0, dWc_k = sum_rows dpre0 x'_k : wave-local MFMA, own rows of staging A;
       // B columns: 0 ones | 1, 5 x0 (hi, lo) | 2, 6 x1 (hi, lo)
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(inf_x0 + 4 * q);
@@ -659,7 +655,22 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
         bc_[i] = v;
       }
       w8_colsum_mfma(sA, p0, bc_, accS, wave, r, q);
+      w8_wait_lgkm0();                                              // (own reads done before the rows are re-staged)
     }
+    asm volatile("; W8_P12_rowlocal");
+    W8_STAMP(12);
+    // ---- wgrad of layer 1: stage (C dpre1, h0) ----
+    w8_stage_store(sA, pA, 16 * wave + r, q);
+    w8_stage_store(sB, h0b, 16 * wave + r, q);
+    __syncthreads();                                                // barrier 3
+    asm volatile("; W8_P10_bar3");
+    W8_STAMP(10);
+    w8_wgrad_consume(sA, sB, accW1, accB1, wave, r, q, ksteps);
+    asm volatile("; W8_P11_cons1");
+    W8_STAMP(11);
+    __syncthreads();                                                // barrier 4: round 2 consumed everywhere
+    asm volatile("; W8_P13_bar4");
+    W8_STAMP(13);
     W8_STAMP(14);
     asm volatile("; W8_TILE_END");
   }
