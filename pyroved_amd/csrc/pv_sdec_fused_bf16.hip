@@ -235,18 +235,34 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
   }
 }
 
+// Written as STAGES over all 32 values of a lane with scheduling fences in between (round 2): left alone, hipcc walks the
+// values two at a time through the dependent chain mul -> exp -> add -> rcp -> fma, and the one wave of a SIMD then pays
+// every instruction's latency (~10 cycles each instead of ~6.5; scripts/ubench/valu_rates.hip).
 __device__ __forceinline__ void fb_tanh8(f32x4 (&v)[8]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) v[ob] = v[ob] * 2.8853900817779268f;
+  FB_FENCE();
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[ob][i] = fb_tanh(v[ob][i]);
+    for (int i = 0; i < 4; ++i) v[ob][i] = __builtin_amdgcn_exp2f(v[ob][i]);
+  FB_FENCE();
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) v[ob] = v[ob] + 1.0f;
+  FB_FENCE();
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[ob][i] = __builtin_amdgcn_rcpf(v[ob][i]);
+  FB_FENCE();
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) v[ob] = 1.0f - 2.0f * v[ob];
+  FB_FENCE();
 }
 
 __device__ __forceinline__ void fb_mul_dtanh(f32x4 (&out)[8], const f32x4 (&h)[8]) {
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[kb][i] *= 1.0f - h[kb][i] * h[kb][i];
+  for (int kb = 0; kb < 8; ++kb) out[kb] = out[kb] * (1.0f - h[kb] * h[kb]);
 }
 
 // a unit's rows -> (hi, lo) bf16 per C/D block
@@ -581,8 +597,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         const f32x4 bc = *reinterpret_cast<const f32x4*>(bcs + j);
         const f32x4 hz = *reinterpret_cast<const f32x4*>(hzb + j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h0[jb][i] = fb_tanh(w0[i] * x0 + w1[i] * x1 + bc[i] + hz[i]);
+        for (int i = 0; i < 4; ++i) h0[jb][i] = w0[i] * x0 + w1[i] * x1 + bc[i] + hz[i];
       }
+      fb_tanh8(h0);
       fb_presplit<X3>(h0, pBh, pBl);
     }
     FB_STAMP(1);

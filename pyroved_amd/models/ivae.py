@@ -105,14 +105,16 @@ class iVAE(baseVAE):
         return dict(loss=s[0], ll=s[1], logpz=s[2], logqz=s[3])
 
     def model(self, x: torch.Tensor, y: Optional[torch.Tensor] = None, **kwargs: float) -> None:
-        raise NotImplementedError(
-            "iVAE.model is a Pyro program in the reference; this build evaluates the same objective in HIP "
-            "kernels — use trainers.SVItrainer (training) or iVAE.elbo_terms (evaluation)")
+        """p(x|z)p(z) as a Pyro program (models/ivae.py:165-202) — for users with pyro-ppl (poutine.trace, custom ELBOs,
+        pyro.infer.SVI); raises NotImplementedError without it.  SVItrainer evaluates the same objective in HIP kernels
+        and does not go through here (iVAE.elbo_terms does neither)."""
+        from ._pyro_programs import ivae_model
+        return ivae_model(self, x, y, **kwargs)
 
     def guide(self, x: torch.Tensor, y: Optional[torch.Tensor] = None, **kwargs: float) -> None:
-        raise NotImplementedError(
-            "iVAE.guide is a Pyro program in the reference; this build evaluates the same objective in HIP "
-            "kernels — use trainers.SVItrainer (training) or iVAE.encode (inference)")
+        """q(z|x) as a Pyro program (models/ivae.py:204-221); see `model`."""
+        from ._pyro_programs import ivae_guide
+        return ivae_guide(self, x, y, **kwargs)
 
     def split_latent(self, z: torch.Tensor) -> Tuple[torch.Tensor]:
         """Split latent variable into parts associated with coordinate transformations

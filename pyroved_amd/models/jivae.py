@@ -70,14 +70,15 @@ class jiVAE(baseVAE):
         self.to(self.device)
 
     def model(self, x: torch.Tensor, **kwargs: float) -> None:
-        raise NotImplementedError(
-            "jiVAE.model is a Pyro program in the reference; this build evaluates the same objective in HIP "
-            "kernels — use trainers.SVItrainer(model, enumerate_parallel=True)")
+        """p(x|z,c)p(z)p(c) as a Pyro program (models/jivae.py:152-197) — needs pyro-ppl; SVItrainer evaluates the same
+        objective in HIP kernels and does not go through here."""
+        from ._pyro_programs import jivae_model
+        return jivae_model(self, x, **kwargs)
 
     def guide(self, x: torch.Tensor, **kwargs: float) -> None:
-        raise NotImplementedError(
-            "jiVAE.guide is a Pyro program in the reference; this build evaluates the same objective in HIP "
-            "kernels — use trainers.SVItrainer(model, enumerate_parallel=True) or jiVAE.encode")
+        """q(z,c|x) as a Pyro program (models/jivae.py:199-220); see `model`."""
+        from ._pyro_programs import jivae_guide
+        return jivae_guide(self, x, **kwargs)
 
     def split_latent(self, z: torch.Tensor) -> Tuple[torch.Tensor]:
         return self._split_latent(z)

@@ -70,14 +70,15 @@ class VED(baseVAE):
         return self._engine
 
     def model(self, x: torch.Tensor = None, y: torch.Tensor = None, **kwargs: float) -> None:
-        raise NotImplementedError(
-            "VED.model is a Pyro program in the reference; this build evaluates the same objective in HIP kernels — "
-            "use trainers.SVItrainer")
+        """p(y|z)p(z) as a Pyro program (models/ved.py:122-145) — needs pyro-ppl; SVItrainer evaluates the same objective
+        in HIP kernels and does not go through here."""
+        from ._pyro_programs import ved_model
+        return ved_model(self, x, y, **kwargs)
 
     def guide(self, x: torch.Tensor = None, y: torch.Tensor = None, **kwargs: float) -> None:
-        raise NotImplementedError(
-            "VED.guide is a Pyro program in the reference; this build evaluates the same objective in HIP kernels — "
-            "use trainers.SVItrainer or VED.encode")
+        """q(z|x) as a Pyro program (models/ved.py:147-163); see `model`."""
+        from ._pyro_programs import ved_guide
+        return ved_guide(self, x, y, **kwargs)
 
     def encode(self, x_new: torch.Tensor, **kwargs: int) -> torch.Tensor:
         """(z_loc, z_scale) of the encoded distributions, on the CPU (models/ved.py:165-181).  kwargs: batch_size.

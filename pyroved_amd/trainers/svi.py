@@ -29,9 +29,12 @@ class SVItrainer:
 
     Args:
         model: initialized model (pyroved_amd.models.iVAE)
-        optimizer: None (Adam, lr 1e-3) or a dict of Adam arguments {"lr", "betas", "eps"}
-        loss: None / "Trace_ELBO" (the one-particle ELBO the reference defaults to)
-        enumerate_parallel: exact enumeration of the discrete latent (required for models.jiVAE)
+        optimizer: None (Adam, lr 1e-3) or a dict of Adam arguments {"lr", "betas", "eps"} — the fused HIP route; a
+            pyro.optim object (needs pyro-ppl) selects the generic Pyro route over model.model / model.guide
+        loss: None / "Trace_ELBO" (the one-particle ELBO the reference defaults to); a pyro.infer ELBO object
+            (needs pyro-ppl) selects the generic Pyro route
+        enumerate_parallel: exact enumeration of the discrete latent of models.jiVAE (False, the reference's default:
+            the class is drawn by the guide — vanilla jiVAE only, as in the reference)
         seed: enforces reproducibility
 
     Keyword Args:
@@ -72,15 +75,37 @@ class SVItrainer:
                                "pass enumerate_parallel=True")
         if enumerate_parallel and not is_joint:
             raise ValueError("enumerate_parallel=True needs a model with a discrete latent (models.jiVAE)")
-        if loss is not None and loss != "Trace_ELBO":
-            raise NotImplementedError("only the default Trace_ELBO objective is implemented (got %r)" % (loss,))
+        self.model = model
+        self.svi = None
+        pyro_objects = (optimizer is not None and not isinstance(optimizer, dict)) or \
+                       (loss is not None and loss != "Trace_ELBO")
+        if pyro_objects:
+            # Pyro optimizer / ELBO OBJECTS (the reference's signature, svi.py:66-67): the generic Pyro route —
+            # pyro.infer.SVI over model.model / model.guide (models/_pyro_programs.py), the networks as differentiable
+            # operators over the library's GEMMs.  Any objective Pyro can express; none of the fused kernels.
+            try:
+                import pyro.infer as infer
+                import pyro.optim as poptim
+                import pyro
+            except ImportError as e:
+                raise TypeError("optimizer / loss objects are Pyro objects and need pyro-ppl, which is not installed; "
+                                "pass None or a dict of Adam arguments (the default Trace_ELBO objective runs in the "
+                                "HIP library)") from e
+            pyro.clear_param_store()
+            opt = optimizer if optimizer is not None and not isinstance(optimizer, dict) else \
+                poptim.Adam({"lr": kwargs.get("lr", 1e-3), **(optimizer or {})})
+            if loss is None or loss == "Trace_ELBO":
+                loss = (infer.TraceEnum_ELBO(max_plate_nesting=1, strict_enumeration_warning=False)
+                        if enumerate_parallel else infer.Trace_ELBO())
+            guide = infer.config_enumerate(model.guide, "parallel", expand=True) if enumerate_parallel else model.guide
+            self.svi = infer.SVI(model.model, guide, opt, loss=loss)
+            self.loss_history = {"training_loss": [], "test_loss": []}
+            self.current_epoch = 0
+            self._sampled_class = False
+            return
         adam = {"lr": kwargs.get("lr", 1e-3), "betas": (0.9, 0.999), "eps": 1e-8}
         if optimizer is not None:
-            if not isinstance(optimizer, dict):
-                raise TypeError("optimizer must be None or a dict of Adam arguments (Pyro optimizer objects "
-                                "cannot be used: Pyro is not a dependency of this build)")
             adam.update(optimizer)
-        self.model = model
         self.rng = kwargs.get("rng", "cpu")
         self.group = kwargs.get("process_group", None)
         self.mirror_evaluate_update = bool(kwargs.get("mirror_evaluate_update", True))
@@ -337,7 +362,19 @@ class SVItrainer:
             n += m
         return len(sizes)
 
+    def _epoch_pyro(self, loader, train: bool, **kwargs) -> float:
+        """The reference's own loop (svi.py:95-137) around pyro.infer.SVI: used when the trainer was given Pyro objects."""
+        epoch_loss = 0.
+        ctx = torch.enable_grad() if train else torch.no_grad()
+        with ctx:
+            for data in loader:
+                args = [d.to(self.device, torch.float32) for d in data]
+                epoch_loss += self.svi.step(*args, **kwargs)
+        return epoch_loss / len(loader.dataset)
+
     def _epoch(self, loader, train: bool, **kwargs) -> float:
+        if self.svi is not None:
+            return self._epoch_pyro(loader, train, **kwargs)
         n = self._epoch_device_feed(loader, train, **kwargs)
         if n is None:
             n = 0
