@@ -710,6 +710,18 @@ int pv_add_cols(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t 
 // latent_bwd (fused decoder path): one workgroup per sample gathers everything that flows from the decoder
 // kernel back into that sample's latent code: ll_b and d(phi, scale, tx, ty) (sums over the sample's N rows),
 // dL/d(hz[b]) (sum of the workgroup partials), dL/d(z content) = dhz Wz, then head_bwd.  Fixed-order sums.
+// phase-timing trace (profiling builds only: -DLB_TRACE): shader-clock stamps of sample 0's workgroup, thread 0
+#ifdef LB_TRACE
+__device__ long long lb_trace[32];
+#define LB_STAMP(k) do { if (b == 0 && threadIdx.x == 0) lb_trace[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+extern "C" int pv_debug_read_trace_lb(long long* out, int n) {
+  if (n > 32) n = 32;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lb_trace), n * sizeof(long long));
+}
+#else
+#define LB_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b) {
   __shared__ float sm[4];
   __shared__ float sh_dhz[512];
@@ -718,41 +730,78 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   __shared__ float sh_ll[128];
   __shared__ float sm5[5][4];
   __shared__ float sh_dh[256];          // the sample's dhead row (2*z_dim + K <= 128 + 64 on the compact encoder path)
-  __shared__ float sh_e[2][128];        // encoder dgrad chain (layer widths <= 128)
+  __shared__ __attribute__((aligned(16))) float sh_e[2][128];        // encoder dgrad chain (layer widths <= 128)
   __shared__ float sh_p[2][128];
   const int t = threadIdx.x;
   const int K = p.K > 0 ? p.K : 1, Bq = p.hb.B;
-  // operands of the encoder chain that depend on nothing computed here are requested FIRST: their memory latency
-  // (the weights were last touched a decoder-kernel ago) hides under the row sums instead of heading two dependent phases
-  float wv[64];
+  // Operands of the encoder chain that depend on nothing computed here (its last layer's weight column, the head's, the
+  // saved activations) are requested EARLY — right after the first pass's row loads have been issued (loads return in
+  // order: ahead of them, the row sums would wait on 74 cold weight loads) — so that their memory latency (the weights
+  // were last touched a decoder-kernel ago) hides under the reductions instead of heading two dependent phases.
+  f32x4 wv4[16];
+  float whd[16];
   float pf_act0 = 0.0f, pf_act1 = 0.0f;
   const int ck = t & 127, chalf = t >> 7;
-  int cj0 = 0, cj1 = 0;
-  if (p.enc_n > 1 && !p.fwd_only) {
-    const pv_layer l = p.enc_l[p.enc_n - 1], lp = p.enc_l[p.enc_n - 2];
-    const int jh = (l.out_dim + 1) >> 1;
-    cj0 = chalf * jh; cj1 = chalf ? l.out_dim : jh;
+  const bool chain = p.enc_n > 1 && !p.fwd_only;
+  auto prefetch_chain = [&]() {
+    const pv_layer l = p.enc_l[p.enc_n - 1], lp = p.enc_l[p.enc_n - 2], hd = p.enc_head;
+    const int jh = l.out_dim >> 1, j0 = chalf * jh;      // widths are multiples of 16 (pv_enc_compact_supported)
     if (ck < l.in_dim) {
       const float* wc = p.enc_params + l.w_off + ck;
 #pragma unroll
-      for (int u = 0; u < 64; ++u) wv[u] = (cj0 + u < cj1) ? wc[(int64_t)(cj0 + u) * l.in_dim] : 0.0f;
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv4[u][i] = (4 * u + i < jh) ? wc[(int64_t)(j0 + 4 * u + i) * l.in_dim] : 0.0f;
       if (chalf == 0) pf_act0 = p.enc_act[p.enc_n - 2][(int64_t)b * lp.out_dim + ck];
     }
-    if (t < l.out_dim) pf_act1 = p.enc_act[p.enc_n - 1][(int64_t)b * l.out_dim + t];
-  }
+    if (t < l.out_dim) {
+      pf_act1 = p.enc_act[p.enc_n - 1][(int64_t)b * l.out_dim + t];
+      const float* Wh = p.enc_params + hd.w_off + t;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) whd[o] = o < hd.out_dim ? Wh[(int64_t)o * hd.in_dim] : 0.0f;
+    }
+  };
   float tp_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  LB_STAMP(0);
   for (int j = t; j < p.H; j += 256) sh_dhz[j] = 0.0f;
   for (int k = 0; k < K; ++k) {
     const int64_t s = (int64_t)k * Bq + b;            // decoder sample (k, b)
     const int64_t r0 = s * p.N;
     float a[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int n = t; n < p.N; n += 256) {
-      a[0] += p.llrow[r0 + n];
-      if (!p.fwd_only) {
+    {
+      // four rows per thread and array in flight at once (784 rows = 3.06 per thread)
+      int n = t;
+      for (; n + 768 < p.N; n += 1024) {
+        float v[4][5];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[1 + c] += p.rowtp[(int64_t)c * p.M + r0 + n];
+        for (int u = 0; u < 4; ++u) {
+          v[u][0] = p.llrow[r0 + n + 256 * u];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[u][1 + c] = p.fwd_only ? 0.0f : p.rowtp[(int64_t)c * p.M + r0 + n + 256 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < 5; ++c) a[c] += v[u][c];
+      }
+      float v[3][5];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const bool ok = n + 256 * u < p.N;
+        v[u][0] = ok ? p.llrow[r0 + n + 256 * u] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u][1 + c] = (ok && !p.fwd_only) ? p.rowtp[(int64_t)c * p.M + r0 + n + 256 * u] : 0.0f;
+      }
+      if (k == 0 && chain) prefetch_chain();           // (behind the row loads in the memory pipeline)
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) a[c] += v[u][c];
+      if (n + 768 < p.N) {                               // (not reached: the loop above leaves at most 3 strides)
+        for (n += 768; n < p.N; n += 256) a[0] += p.llrow[r0 + n];
       }
     }
+    LB_STAMP(7);
     // the five row sums in ONE block reduction (fixed order: wave sums, then waves 0..3)
 #pragma unroll
     for (int c = 0; c < 5; ++c) a[c] = pv_wave_sum(a[c]);
@@ -765,6 +814,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
 #pragma unroll
     for (int c = 0; c < 5; ++c) a[c] = (sm5[c][0] + sm5[c][1]) + (sm5[c][2] + sm5[c][3]);
     if (t == 0) sh_ll[k] = a[0];
+    LB_STAMP(1);
     if (p.fwd_only) continue;
 #pragma unroll
     for (int c = 0; c < 4; ++c) tp_acc[c] += a[1 + c];
@@ -783,6 +833,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
       sh_dhz[j] += v;                                  // the same thread owns j in every pass
     }
   }
+  LB_STAMP(2);
   pv_lds_barrier();
   if (t == 0) {
     float ll = sh_ll[0];
@@ -803,6 +854,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     if (t == 0) sh_dzc[i] = v;
   }
   pv_lds_barrier();
+  LB_STAMP(3);
   if (p.dzc_out && t < n_content) p.dzc_out[(int64_t)b * p.lat_in + t] = sh_dzc[t];
   if (t < p.hb.z_dim)
     pv_head_bwd_elem(p.hb, b, t, [&](int c) { return sh_tp[c]; }, [&](int k) { return sh_dzc[k]; },
@@ -824,6 +876,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
       if (p.enc_n > 0) sh_dh[2 * p.hb.z_dim + k] = al[k] * (da - dot);
     }
   }
+  LB_STAMP(4);
   if (p.enc_n <= 0) return;
   // ---- the sample's encoder dgrad chain (fixed summation order: ascending j) ----
   pv_lds_barrier();
@@ -834,14 +887,20 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     const float* Wh = p.enc_params + hd.w_off;
     for (int k = t; k < ll_.out_dim; k += 256) {
       float v = 0.0f;
-#pragma unroll 16
-      for (int o = 0; o < hd.out_dim; ++o) v += sh_dh[o] * Wh[(int64_t)o * hd.in_dim + k];
-      v *= pv_act_grad((ne > 1 && k == t) ? pf_act1 : p.enc_act[ne - 1][(int64_t)b * ll_.out_dim + k], 0.0f, ll_.act);
+      if (chain && k == t) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) v += o < hd.out_dim ? sh_dh[o] * whd[o] : 0.0f;
+        for (int o = 16; o < hd.out_dim; ++o) v += sh_dh[o] * Wh[(int64_t)o * hd.in_dim + k];
+      } else {
+        for (int o = 0; o < hd.out_dim; ++o) v += sh_dh[o] * Wh[(int64_t)o * hd.in_dim + k];
+      }
+      v *= pv_act_grad((chain && k == t) ? pf_act1 : p.enc_act[ne - 1][(int64_t)b * ll_.out_dim + k], 0.0f, ll_.act);
       p.enc_dp[ne - 1][(int64_t)b * ll_.out_dim + k] = v;
       sh_e[cur][k] = v;
     }
     pv_lds_barrier();
   }
+  LB_STAMP(5);
   for (int li = ne - 1; li > 0; --li) {
     const pv_layer l = p.enc_l[li], lp = p.enc_l[li - 1];
     const float* W = p.enc_params + l.w_off;
@@ -849,16 +908,21 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     // order.  Widths <= 128 (pv_enc_compact_supported).  The last layer's operands were requested at the top.
     const bool pre = li == ne - 1;
     const int k = ck, half = chalf;
-    const int jh = (l.out_dim + 1) >> 1, j0 = half * jh, j1 = half ? l.out_dim : jh;
+    const int jh = l.out_dim >> 1, j0 = half * jh;
     float v = 0.0f;
     if (k < l.in_dim) {
       if (!pre) {
         const float* wc = W + k;
 #pragma unroll
-        for (int u = 0; u < 64; ++u) wv[u] = (j0 + u < j1) ? wc[(int64_t)(j0 + u) * l.in_dim] : 0.0f;
-      }
+        for (int u = 0; u < 16; ++u)
 #pragma unroll
-      for (int u = 0; u < 64; ++u) v += (j0 + u < j1) ? sh_e[cur][j0 + u] * wv[u] : 0.0f;
+          for (int i = 0; i < 4; ++i) wv4[u][i] = (4 * u + i < jh) ? wc[(int64_t)(j0 + 4 * u + i) * l.in_dim] : 0.0f;
+      }
+      f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (4 * u < jh) acc4 += *reinterpret_cast<const f32x4*>(&sh_e[cur][j0 + 4 * u]) * wv4[u];
+      v = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     }
     sh_p[half][k] = v;
     pv_lds_barrier();
@@ -872,6 +936,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     pv_lds_barrier();
     cur ^= 1;
   }
+  LB_STAMP(6);
 }
 
 __global__ __launch_bounds__(256) void pv_latent_bwd_kernel(PvLatentBwd p) { pv_latent_bwd_block(p, blockIdx.x); }
