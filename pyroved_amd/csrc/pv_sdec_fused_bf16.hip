@@ -828,10 +828,13 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
 // the plain-bf16 path runs the 8-wave kernel (pv_sdec_fused_w8.hip) when a workgroup gets at least ~6 of the 8 units a
 // tile takes (batch >= ~32 at 28x28; below that most of a 128-row tile would idle and the 4-wave / 64-row kernel here
 // is faster: 26 vs 30 us at batch 16).  PV_W8=0 / 1 in the environment forces one of them (A/B runs).
+static int fb_w8_mode = -1;            // -1: not read yet; 0 / 1: forced; 2: by problem size
+// test / A-B hook: 0 or 1 forces the 4-wave or the 8-wave plain-bf16 kernel, 2 restores the choice by size
+extern "C" void pv_debug_force_w8(int mode) { fb_w8_mode = mode; }
 static bool fb_use_w8(int64_t units) {
-  static int v = -1;
+  int& v = fb_w8_mode;
   if (v < 0) { const char* e = getenv("PV_W8"); v = e ? (atoi(e) == 0 ? 0 : 1) : 2; }
-  if (v != 2) return v != 0;
+  if (v != 2) return v != 0 && units * FD_UNIT < (int64_t)1 << 31;
   return units >= 6 * (int64_t)pv_sdec_fused_grid(units) && units * FD_UNIT < (int64_t)1 << 31;
 }
 int pv_sdec_fused_bf16_waves(bool x3, int64_t units) { return (!x3 && fb_use_w8(units)) ? 8 : FB_WAVES; }

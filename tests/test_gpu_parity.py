@@ -1630,3 +1630,100 @@ def test_model_on_a_non_current_device(gpu_device):
         outs.append((tr.loss_history["training_loss"][0], model.encode(x)[0]))
         assert torch.cuda.current_device() == 0
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+
+
+W8_SMALL = {
+    "ivae_8x8_rts_b6": {}, "ivae_8x8_r_b6": {}, "ivae_1d16_t_b5": {}, "ivae_7x9_rts_b3": {}, "ivae_8x8_rt_b6_beta4": {},
+    "ivae_8x8_rts_b6_randn": {}, "ivae_28x28_r_b32_blobs": {},
+}
+
+
+@pytest.fixture()
+def force_w8():
+    lib = C.CDLL(_abi.LIB_PATH)
+    lib.pv_debug_force_w8(1)
+    try:
+        yield
+    finally:
+        lib.pv_debug_force_w8(2)
+
+
+@pytest.mark.parametrize("name", sorted(W8_SMALL))
+def test_w8_kernel_on_small_and_odd_cases(gpu_device, force_w8, name):
+    """The 8-wave plain-bf16 decoder kernel is chosen by problem size (>= 6 units per workgroup); here it is FORCED on the
+    small / odd fixtures — partial tiles with most waves idle, 1-D data, ragged rows (7x9), non-unit KL scale, randn and
+    saturated inputs — against the reference's recorded losses and the oracle's gradients (the mode's own bars)."""
+    gold = load_golden(name)
+    meta = meta_of(gold)
+    model, cfg, eng = build(meta, 3)
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"])
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=5e-4, err_msg="loss")
+        o.step(x, eps, meta["beta"])
+        for key in o.p:
+            err = rel_l2(eng.grad_of(key), o.last_grads[key])
+            assert err < 3e-2, "step %d grad %s: rel l2 error %.3e vs oracle" % (k, key, err)
+        # the forward-only launch (evaluate) of the same kernel
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"], want_grads=False)
+        np.testing.assert_allclose(eng.scalars[0].item(), s[0], rtol=1e-6)
+        eng.adam_step()
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+
+
+@pytest.mark.parametrize("vname", ["gauss_rts", "gauss_nosig_r", "cbern_16x16_r", "cdim3_rt", "1d32_t_cdim2", "rect_12x20_rts", "priors_rts"])
+def test_w8_kernel_model_variants(gpu_device, force_w8, vname):
+    """Likelihoods, class conditioning, custom priors, 1-D + c_dim and rectangular data on the forced 8-wave kernel vs the
+    oracle (ELBO 5e-4 on these toy sizes, gradients 3e-2: the mixed-precision mode's bars)."""
+    kw = dict(VARIANTS[vname])
+    data_dim, inv, latent_dim = kw.pop("data_dim"), kw.pop("invariances"), kw.pop("latent_dim", 2)
+    model = pv.models.iVAE(data_dim, latent_dim, inv, seed=3, device="cuda", **kw)
+    cfg = orc.Config(data_dim=data_dim, latent_dim=latent_dim, invariances=inv, c_dim=kw.get("c_dim", 0),
+                     sampler=kw.get("sampler_d", "bernoulli"), sigmoid_d=kw.get("sigmoid_d", True),
+                     dx_prior=kw.get("dx_prior", 0.1), dy_prior=kw.get("dy_prior"), sc_prior=kw.get("sc_prior", 0.1),
+                     decoder_sig=kw.get("decoder_sig", 0.5))
+    eng = model.engine(fused=3)
+    odt = torch.float64 if kw.get("sampler_d") == "continuous_bernoulli" else torch.float32
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg, dtype=odt)
+    b = 7
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(b, *data_dim, generator=g)
+    y = None
+    if cfg.c_dim:
+        y = torch.zeros(b, cfg.c_dim)
+        y[torch.arange(b), torch.randint(0, cfg.c_dim, (b,), generator=g)] = 1.0
+    eps = torch.randn(b, cfg.z_dim, generator=g)
+    assert eng.uses_fused(b)
+    eng.loss_and_grads(x.cuda(), eps.cuda(), 1.7, None if y is None else y.cuda())
+    o.step(x, eps, 1.7, y)
+    # (ContinuousBernoulli: the loss is a remainder of a few units of B*N terms of size ~0.7 — bf16 operands leave ~3e-6 of
+    #  that sum; judged on its scale)
+    atol = 1e-5 * b * int(np.prod(data_dim)) if odt == torch.float64 else 0.0
+    np.testing.assert_allclose(eng.scalars[0].item(), o.last["loss"].item(), rtol=5e-4, atol=atol)
+    for key in o.p:
+        err = rel_l2(eng.grad_of(key), o.last_grads[key])
+        assert err < (6e-2 if odt == torch.float64 else 3e-2), "%s grad %s: rel l2 error %.3e" % (vname, key, err)
+
+
+def test_w8_kernel_jivae_and_row_weights(gpu_device, force_w8):
+    """jiVAE (K enumerated passes, rows weighted by alpha, observations addressed modulo B*N) on the forced 8-wave kernel:
+    gradients vs the oracle from the recorded noise."""
+    gold = load_golden("jivae_8x8_rts_k4_b6")
+    meta = jmeta_of(gold)
+    model = pv.models.jiVAE(meta["data_dim"], meta["latent_dim"], meta["discrete_dim"], meta["invariances"], seed=1, device="cuda")
+    eng = model.engine(fused=3)
+    cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"],
+                     discrete_dim=meta["discrete_dim"])
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    eps = torch.from_numpy(gold["s0.eps"])
+    eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"])
+    np.testing.assert_allclose(eng.scalars[0].item(), float(gold["s0.loss"]), rtol=5e-4)
+    o.step(x, eps, meta["beta"])
+    for key in o.p:
+        err = rel_l2(eng.grad_of(key), o.last_grads[key])
+        assert err < 5e-2, "grad %s: rel l2 error %.3e" % (key, err)
