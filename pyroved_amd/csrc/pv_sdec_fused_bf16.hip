@@ -518,39 +518,55 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     *acc = float2{0.0f, 0.0f};
   };
 
+  // A unit's sample b / offset inside the sample / observation unit are carried incrementally from tile to tile (round 2):
+  // the int64 divisions this replaced expanded to ~900 scalar instructions per tile.  Units stay 64-bit here (this kernel
+  // also serves problems beyond 2^31 rows).
   const int64_t u_lo = (int64_t)g * f.units / G, u_hi = (int64_t)(g + 1) * f.units / G;
+  struct Pos { int64_t unit; int b, loc; int64_t xu; };   // unit = b * upb + loc ; xu = unit mod x_units (x_units > 0)
+  auto pos_of = [&](int64_t unit_) {
+    Pos p_;
+    p_.unit = unit_; p_.b = (int)(unit_ / upb); p_.loc = (int)(unit_ - (int64_t)p_.b * upb);
+    p_.xu = f.x_units > 0 ? unit_ % f.x_units : unit_;
+    return p_;
+  };
+  auto advance = [&](Pos& p_, int by) {
+    p_.unit += by; p_.loc += by; p_.xu += by;
+    while (p_.loc >= upb) { p_.loc -= upb; ++p_.b; }
+    if (f.x_units > 0) { while (p_.xu >= f.x_units) p_.xu -= f.x_units; }
+  };
+  const Pos pos_lo = pos_of(u_lo);                      // what an out-of-range wave fetches instead (valid, unused)
+  Pos pos_cur = pos_of(u_lo + wave < u_hi ? u_lo + wave : u_lo);
+  Pos pos_nx = pos_cur;
   // the wave's observations are fetched one tile ahead (an HBM miss, and loads retire in order: fetched in the
   // tile itself it would hold up the coordinate layer's own small loads)
   float sw_next = 1.0f;                  // (jiVAE) weight of the unit's sample, fetched with its observations
-  auto x_of_tile = [&](int64_t ut_) -> float {
-    const int64_t un = ut_ + wave;
-    const int64_t uc = un < u_hi ? un : u_lo;
-    if (f.sw) sw_next = f.sw[uc / upb];
-    return f.x[(f.x_units > 0 ? uc % f.x_units : uc) * FD_UNIT + r];
+  auto x_of = [&](const Pos& p_) -> float {
+    if (f.sw) sw_next = f.sw[p_.b];
+    return f.x[p_.xu * FD_UNIT + r];
   };
-  float xv_next = x_of_tile(u_lo);
+  float xv_next = x_of(pos_cur);
   // ... and so are its other per-unit inputs (hz[b], tp[b], the unit's grid rows), by LDS-DMA into the wave's own
   // slots: the coordinate layer then starts from LDS instead of waiting ~1.5k cycles on dependent global loads
   float* chz = reinterpret_cast<float*>(smb + BO_CHZ) + wave * FD_H;
   float* ctp = reinterpret_cast<float*>(smb + BO_CTP) + wave * 64;
   float* cgr = reinterpret_cast<float*>(smb + BO_CGR) + wave * 64;
-  auto fetch_unit_inputs = [&](int64_t ut_) {
-    const int64_t un = ut_ + wave;
-    const int unit_ = (int)(un < u_hi ? un : u_lo);
-    const int b_ = unit_ / upb;
-    const int n0 = (unit_ - b_ * upb) * FD_UNIT;
+  auto fetch_unit_inputs = [&](const Pos& p_) {
+    const int b_ = p_.b;
+    const int n0 = p_.loc * FD_UNIT;
     fb_glds4(f.hz + (int64_t)b_ * FD_H + lane, lds0 + BO_CHZ + wave * (FD_H * 4));
     fb_glds4(f.hz + (int64_t)b_ * FD_H + 64 + lane, lds0 + BO_CHZ + wave * (FD_H * 4) + 256);
     fb_glds4(f.tp + (int64_t)b_ * 8 + (lane & 7), lds0 + BO_CTP + wave * 256);
     fb_glds4(f.grid + (int64_t)n0 * f.cd + (lane & (16 * f.cd - 1)), lds0 + BO_CGR + wave * 256);
   };
-  fetch_unit_inputs(u_lo);
+  fetch_unit_inputs(pos_cur);
   int tile_no = -1;
   FB_KSTAMP(1);                                                          // prologue done
   for (int64_t ut = u_lo; ut < u_hi; ut += TILE_UNITS) {
     ++tile_no;
     FB_STAMP(0);
     const int nact = (int)((u_hi - ut) < TILE_UNITS ? (u_hi - ut) : TILE_UNITS);
+    if (ut + TILE_UNITS + wave < u_hi) advance(pos_nx, TILE_UNITS);     // the unit this wave fetches for the NEXT tile
+    else pos_nx = pos_lo;
     int opq = 0;
     asm volatile("" : "+v"(opq));       // loop-variant zero: keeps LICM from hoisting the LDS-resident vectors
     const float* Wc0 = vec + opq;
@@ -563,7 +579,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     // the wave's unit; an inactive wave (partial last tile) computes nothing and stages zeros
     const bool act = wave < nact;
     const int unit = (int)ut + (act ? wave : 0);
-    const int bu = unit / upb;
+    const int bu = pos_cur.b;
     const int64_t row = (int64_t)unit * FD_UNIT + r;
     float x0, x1, u0c, u1c, sc;
     fb_wait_vm0();                        // this wave's LDS-DMA of the tile's inputs (issued a tile ago)
@@ -587,7 +603,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
 
     f32x4 h0[8], tA[8], tB[8], tC[8];
     bf16x4 pAh[8], pAl[8], pBh[8], pBl[8];
-    if (act) {
+    // (round 2) A wave without a unit of its own (partial last tile) runs the same straight-line code on a valid unit of
+    // the workgroup's range (what its prefetch slots hold) with its dL/dlogit forced to zero — every gradient it stages or
+    // accumulates is then zero, its per-row outputs are not stored — instead of skipping the phases under wave-uniform
+    // branches: the merges those branches create cost register copies in every tile (pv_sdec_fused_w8.hip).
+    {
       // ---- coordinate layer (fp32): h0 = tanh(Wc x' + bc + hz[b]) ----
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) {
@@ -603,14 +623,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_presplit<X3>(h0, pBh, pBl);
     }
     FB_STAMP(1);
-    fetch_unit_inputs(ut + TILE_UNITS);          // the slots were consumed by the coordinate layer above
+    fetch_unit_inputs(pos_nx);                   // the slots were consumed by the coordinate layer above
     if (X3 && GRADS && tile_no > 0) {
       // W2's images were the previous tile's staging area: bring them back under the forward of layer 1.
       // (every compiler-visible load above has been consumed; none is issued before the barrier below)
       fb_wait_vm0();
       fb_reload<X3>(gimg + 2 * IMG_BYTES, lds0 + FbLds<X3>::R2, wave, lane);
     }
-    if (act) {
+    {
       fb_layer_fwd<X3>(W1h, W1l, b1s, pBh, pBl, tB, r, q);
       fb_tanh8(tB);                                              // tB = h1
       fb_presplit<X3>(tB, pBh, pBl);                                 // feeds layer 2 and its wgrad
@@ -622,7 +642,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     }
     FB_STAMP(3);
     float dlda = 0.0f;
-    if (act) {
+    {
       fb_layer_fwd<X3>(W2h, W2l, b2s, pBh, pBl, tC, r, q);
       FB_STAMP(16);
       fb_tanh8(tC);                                              // tC = h2
@@ -655,12 +675,12 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         locv = pr;
       }
       FB_STAMP(18);
-      dlda *= swv;
-      if (q == 0) {
+      dlda *= act ? swv : 0.0f;
+      if (q == 0 && act) {
         f.llrow[row] = ll;
         if (f.loc) f.loc[row] = locv;
       }
-      xv_next = x_of_tile(ut + TILE_UNITS);     // lands long before the next LDS-DMA issue point drains loads
+      xv_next = x_of(pos_nx);                   // lands long before the next LDS-DMA issue point drains loads
       if (GRADS) {
         if (q == 0) dbo += dlda;
         if (!X3) {
@@ -687,8 +707,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
     }
     FB_STAMP(4);
+    pos_cur = pos_nx;                     // (unit, bu, row of THIS tile were taken above)
     if (!GRADS) continue;
-    if (!act) { fb_zero8(pAh, pAl); fb_zero8(pBh, pBl); }
     const int ksteps = nact > 2 ? 2 : 1;          // rows 32.. are only staged (as zeros or not) when a unit owns them
 
     // ---- wgrad of layer 2: stage (dpre2, h1) of all 64 rows over W1's images, one pass ----
@@ -703,7 +723,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_wait_vm0();                                   // (stores only: nothing the compiler still waits for)
       fb_reload<X3>(gimg, lds0 + BO_R1, wave, lane);   // W1 comes back under the dgrad of layer 2
     }
-    if (act) {
+    {
       fb_layer_dgrad<X3>(W2h, W2l, pAh, pAl, tA, r, q);
       fb_mul_dtanh(tA, tB);                                      // tA = dpre1
       fb_presplit<X3>(tA, pAh, pAl);                                 // feeds the dgrad and the wgrad of layer 1
@@ -714,13 +734,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       __syncthreads();      // W1 landed everywhere; every wave is past its reads of W2
     }
     FB_STAMP(8);
-    if (act) {
+    {
       fb_layer_dgrad<X3>(W1h, W1l, pAh, pAl, tC, r, q);
       fb_mul_dtanh(tC, h0);                                      // tC = dpre0
       // ---- coordinate layer, cross-row part: dhz[b] = sum_rows dpre0, dWc_k = sum_rows dpre0 * x'_k.  Wave-local
       // (the unit's rows all belong to this wave and to one sample): W2's images are dead since the barrier above, so
       // the wave's own rows of the wgrad-1 staging area serve as the transpose buffer.  No workgroup barrier.
-      if (bu != cur_b) {
+      if (act && bu != cur_b) {
         if (cur_b >= 0) flush_hz(cur_b);
         cur_b = bu;
       }
@@ -738,7 +758,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     fb_wgrad_consume<X3>(st1, accW1, accB1, wave, r, q, ksteps);
     FB_STAMP(21);
     // ---- coordinate layer backward (fp32): row-local part ----
-    if (act) {
+    {
       float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) {
@@ -749,7 +769,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
       d0 = fb_sum_q(d0);
       d1 = fb_sum_q(d1);
-      if (q == 0) {
+      if (q == 0 && act) {
         f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
         f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
         f.rowtp[2 * f.M + row] = d0;
