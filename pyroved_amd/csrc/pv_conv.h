@@ -32,6 +32,12 @@ int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, i
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
                     float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y = nullptr, int eg_act = 0,
                     int use_bf16 = 0);
+// 2-D kernel-3 convolution on the bf16 matrix cores with exactly split operands (pv_conv_sp.hip): ns = 3 fp32-class
+// (six products), ns = 2 mixed precision (three); C % 32 == 0.  wt_scratch: pv_conv3_sp_wt_bytes bytes
+bool pv_conv3_sp_supported(int C, int Cout, int nd, int act);
+int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
+int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
+                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

@@ -56,6 +56,7 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
       if (ops[i].ksize == 3) {
         upd(nd_.maxcol, N * K);                                      // flipped weights of the dgrad-as-convolution
         upd(nd_.maxcol, pv_conv3_direct_wt_floats(ops[i].cin, ops[i].cout, nd));   // tiled weights of the direct kernel
+        if (nd == 2) upd(nd_.maxcol, (pv_conv3_sp_wt_bytes(ops[i].cin, ops[i].cout) + 3) / 4);   // ... of the split-operand kernel
       }
       upd(nd_.scratch, gemm_ws_need(rows, N, K));                    // forward
       upd(nd_.scratch, gemm_ws_need(N, K, rows));                    // wgrad
@@ -87,6 +88,9 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
     const int64_t rows = (int64_t)B * si.H * si.W, K = (int64_t)o.cin * kk_of(o, nd);
     const float* bias = o.b_off >= 0 ? params + o.b_off : nullptr;
     if (o.ksize == 3) {
+      if (pv_conv3_sp_supported(o.cin, o.cout, nd, o.act))      // 2-D, Cin % 32 == 0: exactly split operands on the bf16 cores
+        return pv_conv3_sp(in, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr, 0,
+                           sc.conv_bf16 ? 2 : 3);
       if (pv_conv3_direct_supported(o.cin, o.cout, nd, o.act))
         return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr,
                                0, sc.conv_bf16);
@@ -127,6 +131,11 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
         PV_TRY(conv3_wgrad(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
       if (!gin) return 0;
       // dX = conv3(dpre; taps flipped, channel roles swapped) — same spatial size, C = cout -> cin
+      if (pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
+        if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+        return pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act,
+                           sc.conv_bf16 ? 2 : 3);
+      }
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s,
