@@ -38,6 +38,10 @@ bool pv_conv3_sp_supported(int C, int Cout, int nd, int act);
 int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns);
+bool pv_conv3_sp_wgrad_supported(int C, int Cout, int nd);
+int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout);
+int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,
+                      int64_t ws_bytes, hipStream_t s, int ns);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

@@ -397,7 +397,7 @@ extern "C" int pv_debug_conv3(int mode, const float* in, int B, int H, int W, in
 }
 
 extern "C" long long pv_debug_conv3_wgrad_ws(int mode, int B, int H, int W, int C, int Cout, int nd) {
-  (void)mode;
+  if (mode >= 2) return pv_conv3_sp_wgrad_ws(B, H, W, C, Cout);
   return pv_conv3_wgrad_direct_ws(B, H, W, C, Cout, nd);
 }
 
@@ -406,7 +406,7 @@ extern "C" int pv_debug_conv3_wgrad(int mode, const float* dy, const float* in, 
   hipStream_t s = (hipStream_t)stream;
   if (mode == 1) return pv_conv3_wgrad_direct_bf16(dy, in, B, H, W, C, nd, dw, db, Cout, ws, ws_bytes, s);
   if (mode == 0) return pv_conv3_wgrad_direct(dy, in, B, H, W, C, nd, dw, db, Cout, ws, ws_bytes, s);
-  return PV_EINVAL;
+  return nd == 2 ? pv_conv3_sp_wgrad(dy, in, B, H, W, C, dw, db, Cout, ws, ws_bytes, s, mode) : PV_EINVAL;
 }
 
 // resident workgroups per CU the runtime predicts for the forward kernel (ns pieces, 4 channel blocks) at lds bytes
@@ -415,4 +415,241 @@ extern "C" int pv_debug_conv3_sp_occupancy(int ns, int lds) {
   hipError_t e = ns == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pv_conv3_sp_kernel<3, 4>, 256, (size_t)lds)
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pv_conv3_sp_kernel<2, 4>, 256, (size_t)lds);
   return e == hipSuccess ? n : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution with exactly split operands:
+//   dW[co][ci][tap] = sum_{b, pixel} dY[b, pixel][co] * in[b, pixel + tap][ci] ;   db[co] = sum dY[b, pixel][co]
+// A workgroup (4 waves) owns 64 output channels x 64 (or 32) input channels x all 9 taps and walks a contiguous range of
+// 8x8 pixel tiles (split s of nsplit); wave (w&1, w>>1) owns 32 co x 32 (16) ci x 9 taps = up to 36 accumulator blocks
+// that stay in registers across tiles.  The contraction runs over pixels (MFMA k = 32 pixels = 4 tile lines x 8): the dY
+// tile and the input patch with its halo are split into NS bf16 planes while they are staged in their natural
+// [pixel][channel] layouts, and both operands come out of LDS through the transposing read ds_read_b64_tr_b16 (a lane gets
+// 4 consecutive pixels of one channel).  A lane's 8 k values are 8 consecutive pixels of one line, so the three taps
+// dx = 0, 1, 2 of a kernel row are windows of ONE 12-pixel line read: dx = 0 and 2 are register sub-ranges, dx = 1 is
+// four v_alignbit — a third of the patch reads of a per-tap formulation, which is what lets two workgroups per CU run
+// under the LDS bandwidth.  Pixel rows are 160 bytes apart (64 channels + pad) with a per-line skew so that the two
+// 16-lane halves of a transposing read (two adjacent lines) land on disjoint banks.
+// Per-split partial results are summed in split order by pv_conv3_wgrad_finish_kernel (no atomics).
+struct ConvWgSp {
+  const float* dy; const float* in; float* part; float* part_b;
+  int B, H, W, Cin, Cout, tiles_x, tiles_y, nsplit;
+};
+
+typedef short sshort4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) sshort4 lds_sshort4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 sw_tr(const char* p) {
+  const sshort4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_sshort4*)p);
+  return __builtin_bit_cast(u32x2, v);
+}
+__device__ __forceinline__ sbf8 sw_frag(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return __builtin_bit_cast(sbf8, u32x4{a, b, c, d});
+}
+// LDS geometry.  A transposing read's 16-lane group covers 4 consecutive pixels x 32 bytes; its two groups per 32-lane
+// half are two adjacent lines.  Pixel pitches of 160 (64 channels) / 96 (32 channels) bytes put 4 consecutive pixels on
+// disjoint 32-byte bank segments, and line pitches congruent to 128 mod 256 put the adjacent line on the other four.
+#define SW_DYP 160                                 // dY tile: pixel pitch; line (8 pixels) pitch 1408
+#define SW_DYL 1408
+#define SW_DYPLANE (8 * SW_DYL)
+template <int NCIB> struct SwGeo {
+  static constexpr int PP = NCIB == 2 ? 160 : 96;    // patch pixel pitch
+  static constexpr int RP = NCIB == 2 ? 1664 : 1152; // patch line (10 pixels) pitch
+  static constexpr int PLANE = 10 * RP + 2 * PP;     // (+ the two never-used pixels a line window reads past the halo)
+};
+
+template <int NS, int NCIB>
+__global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PP = SwGeo<NCIB>::PP, RP = SwGeo<NCIB>::RP, PPLANE = SwGeo<NCIB>::PLANE;
+  char* dyl = smem;                                  // [NS] planes
+  char* patch = smem + NS * SW_DYPLANE;              // [NS] planes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wco = wave & 1, wci = wave >> 1;
+  const int split = blockIdx.x, cit = blockIdx.y, cot = blockIdx.z;
+  constexpr int CIW = 32 * NCIB;                     // input channels per workgroup
+  const int64_t T = (int64_t)p.B * p.tiles_y * p.tiles_x;
+  const int64_t t_lo = T * split / p.nsplit, t_hi = T * (split + 1) / p.nsplit;
+  f32x4 acc[9][2][NCIB], accb[2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < NCIB; ++c) acc[t][a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  accb[0] = accb[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const sbf8 ones = sw_frag(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  const bool want_b = p.part_b && cit == 0 && wci == 0;
+  // transposing-read addresses: lane r points at pixel (+ r>>2), channels 4 (r&3) .. +3 of the 16-channel block
+  const int a_off = q * SW_DYL + (r >> 2) * SW_DYP + (r & 3) * 8 + wco * 64;
+  int b_off[3];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+    b_off[dy] = (q + dy) * RP + (r >> 2) * PP + (r & 3) * 8 + wci * (NCIB * 32);
+  for (int64_t tt = t_lo; tt < t_hi; ++tt) {
+    int t = (int)tt;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 8;
+    __syncthreads();
+    {                                                // dY tile: pixel n, channels 4*c4 .. +3 -> NS planes
+      f32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = tid + 256 * k, n = e >> 4, c4 = e & 15;
+        const int y = y0 + (n >> 3), x = x0 + (n & 7);
+        const int co = cot * 64 + 4 * c4;
+        v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (y < p.H && x < p.W) {
+          const float* src = p.dy + (((int64_t)b * p.H + y) * p.W + x) * p.Cout + co;
+          if (co + 3 < p.Cout && (p.Cout & 3) == 0) v[k] = *reinterpret_cast<const f32x4*>(src);
+          else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (co + i < p.Cout) v[k][i] = src[i];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = tid + 256 * k, n = e >> 4, c4 = e & 15;
+        u32x2 pl[NS];
+        sp_split4<NS>(v[k], pl);
+        const int o = (n >> 3) * SW_DYL + (n & 7) * SW_DYP + c4 * 8;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(dyl + j * SW_DYPLANE + o) = pl[j];
+      }
+    }
+    {                                                // patch: pixel (row, col) of the 10x10 halo window, CIW channels
+      constexpr int PPT = CIW / 4;                   // float4 pieces per pixel
+      constexpr int PK = (100 * PPT + 255) / 256;
+      const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin + cit * CIW;
+      f32x4 v[PK];
+#pragma unroll
+      for (int k = 0; k < PK; ++k) {
+        const int e = tid + 256 * k, pix = e / PPT, f = e - pix * PPT;
+        const int row = pix / 10, col = pix - row * 10;
+        const int y = y0 - 1 + row, x = x0 - 1 + col;
+        v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (e < 100 * PPT && y >= 0 && y < p.H && x >= 0 && x < p.W)
+          v[k] = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + 4 * f);
+      }
+#pragma unroll
+      for (int k = 0; k < PK; ++k) {
+        const int e = tid + 256 * k, pix = e / PPT, f = e - pix * PPT;
+        const int row = pix / 10, col = pix - row * 10;
+        u32x2 pl[NS];
+        sp_split4<NS>(v[k], pl);
+        const int o = row * RP + col * PP + f * 8;
+        if (e < 100 * PPT) {
+#pragma unroll
+          for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(patch + j * PPLANE + o) = pl[j];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                 // 32 pixels: lane group q <-> tile line 4 ks + q, k slot i <-> x = i
+      sbf8 a[2][NS];
+#pragma unroll
+      for (int cob = 0; cob < 2; ++cob)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          const char* ap = dyl + j * SW_DYPLANE + a_off + ks * (4 * SW_DYL) + cob * 32;
+          const u32x2 lo = sw_tr(ap), hi = sw_tr(ap + 4 * SW_DYP);
+          a[cob][j] = sw_frag(lo[0], lo[1], hi[0], hi[1]);
+        }
+      if (want_b) {
+#pragma unroll
+        for (int cob = 0; cob < 2; ++cob)
+#pragma unroll
+          for (int j = 0; j < NS; ++j) accb[cob] = SP_MFMA(a[cob][j], ones, accb[cob]);
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int cib = 0; cib < NCIB; ++cib) {
+          // one 12-pixel line window per plane: dwords w0..w4 = pixels (0,1) .. (8,9) [(10,11) are never used]
+          sbf8 bb[3][NS];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            const char* bp = patch + j * PPLANE + b_off[dy] + ks * (4 * RP) + cib * 32;
+            const u32x2 w01 = sw_tr(bp), w23 = sw_tr(bp + 4 * PP), w45 = sw_tr(bp + 8 * PP);
+            bb[0][j] = sw_frag(w01[0], w01[1], w23[0], w23[1]);
+            bb[1][j] = sw_frag(__builtin_amdgcn_alignbit(w01[1], w01[0], 16), __builtin_amdgcn_alignbit(w23[0], w01[1], 16),
+                               __builtin_amdgcn_alignbit(w23[1], w23[0], 16), __builtin_amdgcn_alignbit(w45[0], w23[1], 16));
+            bb[2][j] = sw_frag(w01[1], w23[0], w23[1], w45[0]);
+          }
+#define SW_PROD(KA, KB)                                                                                                 \
+  _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) _Pragma("unroll") for (int cob = 0; cob < 2; ++cob)                   \
+      acc[3 * dy + dx][cob][cib] = SP_MFMA(a[cob][KA], bb[dx][KB], acc[3 * dy + dx][cob][cib]);
+          if constexpr (NS == 3) { SW_PROD(1, 1) SW_PROD(2, 0) SW_PROD(0, 2) }
+          SW_PROD(1, 0) SW_PROD(0, 1) SW_PROD(0, 0)
+        }
+      }
+    }
+  }
+  // C/D layout: lane (column = ci r, q), reg i -> output channel 16*cob + 4q + i of the wave's 32
+#pragma unroll
+  for (int cob = 0; cob < 2; ++cob)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = cot * 64 + wco * 32 + cob * 16 + 4 * q + i;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int cib = 0; cib < NCIB; ++cib) {
+        const int ci = cit * CIW + wci * (NCIB * 16) + cib * 16 + r;
+        float* dst = p.part + (((int64_t)split * p.Cout + co) * p.Cin + ci) * 9;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) dst[tap] = acc[tap][cob][cib][i];
+      }
+      if (want_b && r == 0) p.part_b[(int64_t)split * p.Cout + co] = accb[cob][i];
+    }
+}
+
+extern __global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
+                                                    const float* __restrict__ part_b, int nb, float* __restrict__ out_b);
+
+static int sw_splits(int B, int H, int W, int C, int Cout, int nsp) {
+  const int64_t T = (int64_t)B * ((W + 7) / 8) * ((H + 7) / 8);
+  const int ciw = (nsp == 2 && C % 64 == 0) ? 64 : 32;           // input channels per workgroup (three planes: 32, for the LDS)
+  const int64_t owners = (int64_t)(C / ciw) * ((Cout + 63) / 64);
+  int64_t ns = (512 + owners - 1) / owners;                      // two workgroups per CU in all
+  if (ns > T) ns = T;
+  return (int)(ns < 1 ? 1 : ns);
+}
+
+bool pv_conv3_sp_wgrad_supported(int C, int Cout, int nd) { return nd == 2 && C >= 32 && C % 32 == 0 && Cout >= 8; }
+
+int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout) {
+  if (!pv_conv3_sp_wgrad_supported(C, Cout, 2)) return 0;
+  const int n2 = sw_splits(B, H, W, C, Cout, 2), n3 = sw_splits(B, H, W, C, Cout, 3);       // either precision
+  return (int64_t)(n2 > n3 ? n2 : n3) * ((int64_t)Cout * C * 9 + Cout) * (int64_t)sizeof(float) + 256;
+}
+
+int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,
+                      int64_t ws_bytes, hipStream_t s, int ns) {
+  if (!pv_conv3_sp_wgrad_supported(C, Cout, 2) || (ns != 2 && ns != 3)) return PV_EINVAL;
+  if (ws_bytes < pv_conv3_sp_wgrad_ws(B, H, W, C, Cout)) return PV_EWS;
+  ConvWgSp p{};
+  p.dy = dy; p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = Cout;
+  p.tiles_x = (W + 7) / 8; p.tiles_y = (H + 7) / 8;
+  p.nsplit = sw_splits(B, H, W, C, Cout, ns);
+  const int64_t nw = (int64_t)Cout * C * 9;
+  p.part = reinterpret_cast<float*>(ws);
+  p.part_b = db ? p.part + (int64_t)p.nsplit * nw : nullptr;
+  const bool wide = ns == 2 && C % 64 == 0;
+  const dim3 grid((unsigned)p.nsplit, (unsigned)(wide ? C / 64 : C / 32), (unsigned)((Cout + 63) / 64));
+  const size_t lds = (size_t)ns * (SW_DYPLANE + (wide ? SwGeo<2>::PLANE : SwGeo<1>::PLANE));
+  if (ns == 3) {
+    hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<3, 1>), grid, dim3(256), lds, s, p);
+  } else {
+    if (wide) hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 2>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1>), grid, dim3(256), lds, s, p);
+  }
+  PV_LAUNCH_CHECK();
+  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
+  if (fb > 4096) fb = 4096;
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
+  PV_LAUNCH_CHECK();
+  return 0;
 }

@@ -61,6 +61,7 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
       upd(nd_.scratch, gemm_ws_need(rows, N, K));                    // forward
       upd(nd_.scratch, gemm_ws_need(N, K, rows));                    // wgrad
       if (ops[i].ksize == 3) upd(nd_.scratch, pv_conv3_wgrad_direct_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
+      if (ops[i].ksize == 3 && nd == 2) upd(nd_.scratch, pv_conv3_sp_wgrad_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout));
       if (ops[i].ksize == 3) upd(nd_.scratch, pv_conv3_wgrad_c1_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
       upd(nd_.scratch, gemm_ws_need(rows, K, N));                    // dgrad, kernel 1
       upd(nd_.scratch, gemm_ws_need(rows, ops[i].cin, N * kk_of(ops[i], nd)));   // dgrad, kernel 3
@@ -121,7 +122,10 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     if (!g_is_pre) PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));         // g = dL/d(pre-activation)
     float* db = o.b_off >= 0 ? grads + o.b_off : nullptr;
     if (o.ksize == 3) {
-      if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
+      if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd))
+        PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s,
+                                 sc.conv_bf16 ? 2 : 3));
+      else if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_wgrad_direct_bf16(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
       else if (pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_wgrad_direct(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
