@@ -31,13 +31,18 @@ int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, i
                                int Cout, void* ws, int64_t ws_bytes, hipStream_t s);     // C % 32 == 0 (mixed precision)
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
                     float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y = nullptr, int eg_act = 0,
-                    int use_bf16 = 0);
+                    int use_bf16 = 0, const void* wt_ready = nullptr);
 // 2-D kernel-3 convolution on the bf16 matrix cores with exactly split operands (pv_conv_sp.hip): ns = 3 fp32-class
 // (six products), ns = 2 mixed precision (three); C % 32 == 0.  wt_scratch: pv_conv3_sp_wt_bytes bytes
 bool pv_conv3_sp_supported(int C, int Cout, int nd, int act);
 int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
-                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns);
+                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr);
+// all of a step's weight tilings in one launch (per 16 entries).  kind 0: pv_conv3_direct f32, 1: its bf16 two-piece form,
+// 2 / 3: pv_conv3_sp with 2 / 3 pieces; dst sized by pv_conv_wt_bytes
+struct PvWprepEntry { const float* w; char* dst; int Co, Ci, KK, flip, kind; int pad_; int64_t start, total; };
+int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd);
+int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s);
 bool pv_conv3_sp_wgrad_supported(int C, int Cout, int nd);
 int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout);
 int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,

@@ -162,7 +162,8 @@ int64_t pv_conv3_direct_wt_floats(int C, int Cout, int nd) {
 // w: raw torch weight (Co, Ci, KK).  flip == 0: out[.., Co] = act(conv(in[.., Ci]) + bias).
 // flip == 1: out[.., Ci] = conv of in[.., Co] with the flipped / role-swapped weights (the input gradient).
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
-                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int use_bf16) {
+                    float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int use_bf16,
+                    const void* wt_ready) {
   const int KK = nd == 2 ? 9 : 3;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   if (!pv_conv3_direct_supported(C, N, nd, act)) return PV_EINVAL;
@@ -171,12 +172,16 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
   int pb = (int)((total + 255) / 256);
   if (pb > 2048) pb = 2048;
   const bool bf16 = use_bf16 && C % 32 == 0;
-  if (bf16)      // (the hi + lo bf16 arrays take the same bytes as the fp32 tiling)
-    hipLaunchKernelGGL(pv_conv3_wprep_bf16_kernel, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wt_scratch), Co, Ci,
-                       KK, flip);
-  else
-    hipLaunchKernelGGL(pv_conv3_wprep_kernel, dim3(pb), dim3(256), 0, s, w, wt_scratch, Co, Ci, KK, flip);
-  PV_LAUNCH_CHECK();
+  if (wt_ready) {                                    // tiled once per step by pv_conv_wprep_table
+    wt_scratch = const_cast<float*>(reinterpret_cast<const float*>(wt_ready));
+  } else {
+    if (bf16)      // (the hi + lo bf16 arrays take the same bytes as the fp32 tiling)
+      hipLaunchKernelGGL(pv_conv3_wprep_bf16_kernel, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wt_scratch), Co, Ci,
+                         KK, flip);
+    else
+      hipLaunchKernelGGL(pv_conv3_wprep_kernel, dim3(pb), dim3(256), 0, s, w, wt_scratch, Co, Ci, KK, flip);
+    PV_LAUNCH_CHECK();
+  }
   ConvD p{};
   p.in = in; p.wt = wt_scratch; p.bias = bias; p.out = out;
   p.eg_y = (eg_y && eg_act != PV_ACT_NONE) ? eg_y : nullptr; p.eg_act = eg_act;
@@ -300,26 +305,34 @@ __global__ __launch_bounds__(256) void pv_conv3_wgrad_direct_kernel(ConvWg p) {
 __global__ __launch_bounds__(256) void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n,
                                                                      float* __restrict__ out, const float* __restrict__ part_b,
                                                                      int nb, float* __restrict__ out_b) {
-  __shared__ float sm[8][32];
-  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int64_t nblk = (n + 31) / 32;
-  for (int64_t blk = blockIdx.x; blk < nblk + (part_b ? (nb + 31) / 32 : 0); blk += gridDim.x) {
+  __shared__ float sm[256];
+  // few outputs (a first layer's 9 * Cout): 8 outputs x 32 slices per workgroup, otherwise 32 x 8 — the launcher sizes
+  // the grid to match (pv_wgrad_finish_blocks)
+  const int og = n + (part_b ? nb : 0) <= 2048 ? 8 : 32, nsl = 256 / og;
+  const int o = threadIdx.x % og, sl = threadIdx.x / og;
+  const int64_t nblk = (n + og - 1) / og;
+  for (int64_t blk = blockIdx.x; blk < nblk + (part_b ? (nb + og - 1) / og : 0); blk += gridDim.x) {
     const bool isb = blk >= nblk;
-    const int64_t e = (isb ? blk - nblk : blk) * 32 + o, lim = isb ? nb : n;
+    const int64_t e = (isb ? blk - nblk : blk) * og + o, lim = isb ? nb : n;
     const float* src = isb ? part_b : part;
     float v = 0.0f;
     if (e < lim)
-      for (int s = sl; s < nsplit; s += 8) v += src[(int64_t)s * lim + e];
-    sm[sl][o] = v;
+      for (int s = sl; s < nsplit; s += nsl) v += src[(int64_t)s * lim + e];
+    sm[sl * og + o] = v;
     __syncthreads();
     if (sl == 0 && e < lim) {
       float t = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t += sm[k][o];
+      for (int k = 0; k < nsl; ++k) t += sm[k * og + o];
       (isb ? out_b : out)[e] = t;
     }
     __syncthreads();
   }
+}
+
+int pv_wgrad_finish_blocks(int64_t nw, int nb) {
+  const int og = nw + nb <= 2048 ? 8 : 32;
+  int64_t fb = (nw + og - 1) / og + (nb ? (nb + og - 1) / og : 0);
+  return (int)(fb > 4096 ? 4096 : fb);
 }
 
 static int wgd_splits(int B, int H, int W, int C, int Cout, int nd) {
@@ -360,8 +373,7 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
   hipLaunchKernelGGL(pv_conv3_wgrad_direct_kernel, dim3((unsigned)p.nsplit, (unsigned)(C / CD_KC), (unsigned)((Cout + CD_TN - 1) / CD_TN)),
                      dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
-  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
-  if (fb > 4096) fb = 4096;
+  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
   hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
   PV_LAUNCH_CHECK();
   return 0;
@@ -453,7 +465,7 @@ int pv_conv3_wgrad_c1(const float* dy, const float* in, int B, int H, int W, int
   hipLaunchKernelGGL(pv_conv3_wgrad_c1_kernel, dim3(ns), dim3(256), 0, s, dy, in, B, H, W, Cout, nd, CP, ns, part, part_b);
   PV_LAUNCH_CHECK();
   const int64_t nw = (int64_t)Cout * KK;
-  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
+  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
   hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, part, ns, nw, dw, part_b, Cout, db);
   PV_LAUNCH_CHECK();
   return 0;
@@ -734,8 +746,7 @@ int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, i
   hipLaunchKernelGGL(pv_conv3_wgrad_bf16_kernel, dim3((unsigned)p.nsplit, (unsigned)(C / CB_KC), (unsigned)((Cout + CD_TN - 1) / CD_TN)),
                      dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
-  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
-  if (fb > 4096) fb = 4096;
+  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
   hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
   PV_LAUNCH_CHECK();
   return 0;

@@ -96,11 +96,11 @@ template <int NS> __device__ __forceinline__ void sp_split1(float v, unsigned sh
 //   flip == 1 (dgrad):    Wl[n = ci][c = co][t] = w[co][ci][8 - t]            (N = Ci, C = Co)
 // laid out [n tile][chunk][t][plane][64 rows][32 channels, 16-byte slots swizzled], rows n >= N zero
 template <int NS>
-__global__ void pv_conv3_sp_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt, int Co, int Ci, int flip) {
+__device__ __forceinline__ void sp_wprep_elem(const float* __restrict__ w, unsigned short* __restrict__ wt, int Co, int Ci, int flip,
+                                              int64_t e) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
-  const int nt = (N + SP_TN - 1) / SP_TN, nch = C / SP_KC;
-  const int64_t total = (int64_t)nt * nch * 9 * SP_TN * SP_KC;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+  const int nch = C / SP_KC;
+  {
     const int cl = (int)(e % SP_KC), nl = (int)((e / SP_KC) % SP_TN), t = (int)((e / (SP_KC * SP_TN)) % 9);
     const int ch = (int)((e / ((int64_t)SP_KC * SP_TN * 9)) % nch), tile = (int)(e / ((int64_t)SP_KC * SP_TN * 9 * nch));
     const int n = tile * SP_TN + nl, c = ch * SP_KC + cl;
@@ -113,6 +113,80 @@ __global__ void pv_conv3_sp_wprep_kernel(const float* __restrict__ w, unsigned s
 #pragma unroll
     for (int k = 0; k < NS; ++k) wt[((base + k) * SP_TN + nl) * SP_KC + scl] = pl[k];
   }
+}
+
+template <int NS>
+__global__ void pv_conv3_sp_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt, int Co, int Ci, int flip) {
+  const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+  const int64_t total = (int64_t)((N + SP_TN - 1) / SP_TN) * (C / SP_KC) * 9 * SP_TN * SP_KC;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    sp_wprep_elem<NS>(w, wt, Co, Ci, flip, e);
+}
+
+// ---- every weight tiling of a step in one launch: entry k covers element indices [start, start + total) ----------------
+struct WprepTab { PvWprepEntry e[16]; int n; int64_t total; };
+
+__global__ void pv_conv_wprep_table_kernel(WprepTab t) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < t.total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int k = 0;
+    while (k + 1 < t.n && idx >= t.e[k + 1].start) ++k;
+    const PvWprepEntry E = t.e[k];
+    const int64_t e = idx - E.start;
+    const int Co = E.Co, Ci = E.Ci, KK = E.KK, flip = E.flip;
+    if (E.kind >= 2) {
+      if (E.kind == 3) sp_wprep_elem<3>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
+      else sp_wprep_elem<2>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
+      continue;
+    }
+    // pv_conv_direct.hip's tilings: [n tile][chunk][tap][64][KC], KC = 16 fp32 (kind 0) / 32 bf16 hi + lo arrays (kind 1)
+    const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+    const int KC = E.kind == 1 ? 32 : 16, nch = C / KC;
+    const int cl = (int)(e % KC), nl = (int)((e / KC) % 64), tp = (int)((e / (KC * 64)) % KK);
+    const int ch = (int)((e / ((int64_t)KC * 64 * KK)) % nch), tile = (int)(e / ((int64_t)KC * 64 * KK * nch));
+    const int n = tile * 64 + nl, c = ch * KC + cl;
+    float v = 0.0f;
+    if (n < N) v = flip ? E.w[((int64_t)c * Ci + n) * KK + (KK - 1 - tp)] : E.w[((int64_t)n * Ci + c) * KK + tp];
+    if (E.kind == 0) reinterpret_cast<float*>(E.dst)[e] = v;
+    else {
+      const __bf16 hi = (__bf16)v;
+      __bf16* d = reinterpret_cast<__bf16*>(E.dst);
+      d[e] = hi;
+      d[E.total + e] = (__bf16)(v - (float)hi);
+    }
+  }
+}
+
+static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
+  const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+  const int KC = kind == 0 ? 16 : 32;
+  return (int64_t)((N + 63) / 64) * (C / KC) * KK * 64 * KC;
+}
+
+int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd) {
+  if (kind >= 2) return pv_conv3_sp_wt_bytes(Ci, Co);
+  return pv_conv3_direct_wt_floats(Ci, Co, nd) * (int64_t)sizeof(float);
+}
+
+// fills start / total of the entries and launches (16 entries per launch)
+int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s) {
+  for (int lo = 0; lo < n; lo += 16) {
+    WprepTab t{};
+    t.n = n - lo < 16 ? n - lo : 16;
+    int64_t acc = 0;
+    for (int k = 0; k < t.n; ++k) {
+      e[lo + k].total = wprep_elems(e[lo + k].kind, e[lo + k].Co, e[lo + k].Ci, e[lo + k].KK, e[lo + k].flip);
+      e[lo + k].start = acc;
+      acc += e[lo + k].total;
+      t.e[k] = e[lo + k];
+    }
+    t.total = acc;
+    int pb = (int)((acc + 255) / 256);
+    if (pb > 4096) pb = 4096;
+    if (pb < 1) continue;
+    hipLaunchKernelGGL(pv_conv_wprep_table_kernel, dim3(pb), dim3(256), 0, s, t);
+    PV_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 template <int NS, int NCB>
@@ -351,11 +425,13 @@ int64_t pv_conv3_sp_wt_bytes(int C, int Cout) {
 template <int NS>
 static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int flip, char* wt, int nt, int64_t total,
                            hipStream_t s) {
-  int pb = (int)((total + 255) / 256);
-  if (pb > 2048) pb = 2048;
-  hipLaunchKernelGGL(pv_conv3_sp_wprep_kernel<NS>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wt), Co, Ci,
-                     flip);
-  PV_LAUNCH_CHECK();
+  if (wt) {
+    int pb = (int)((total + 255) / 256);
+    if (pb > 2048) pb = 2048;
+    hipLaunchKernelGGL(pv_conv3_sp_wprep_kernel<NS>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wt), Co, Ci,
+                       flip);
+    PV_LAUNCH_CHECK();
+  }
   constexpr int TG = NS == 3 ? 1 : 3;
   static const int lds_pad = getenv("PV_SP_LDS_PAD") ? atoi(getenv("PV_SP_LDS_PAD")) : 0;   // (occupancy experiments)
   const size_t lds = (size_t)NS * SP_PPLANE + (size_t)TG * NS * SP_WPLANE + lds_pad;
@@ -370,18 +446,18 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
 // flip == 1: out[.., Ci] = conv of in[.., Co] with the flipped / role-swapped weights (the input gradient).
 // ns = 3: fp32-class (six products); ns = 2: mixed precision (three products).  wt_scratch: pv_conv3_sp_wt_bytes bytes.
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
-                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns) {
+                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   if (!pv_conv3_sp_supported(C, N, 2, act) || (ns != 2 && ns != 3)) return PV_EINVAL;
   const int nt = (N + SP_TN - 1) / SP_TN;
   const int64_t total = (int64_t)nt * (C / SP_KC) * 9 * SP_TN * SP_KC;
   ConvSp p{};
-  p.in = in; p.wt = reinterpret_cast<const char*>(wt_scratch); p.bias = bias; p.out = out;
+  p.in = in; p.wt = reinterpret_cast<const char*>(wt_ready ? wt_ready : wt_scratch); p.bias = bias; p.out = out;
   p.eg_y = (eg_y && eg_act != PV_ACT_NONE) ? eg_y : nullptr; p.eg_act = eg_act;
   p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = N; p.act = act;
   p.tiles_x = (W + SP_T - 1) / SP_T; p.tiles_y = (H + SP_T - 1) / SP_T;
-  return ns == 3 ? conv3_sp_launch<3>(p, w, Co, Ci, flip, reinterpret_cast<char*>(wt_scratch), nt, total, s)
-                 : conv3_sp_launch<2>(p, w, Co, Ci, flip, reinterpret_cast<char*>(wt_scratch), nt, total, s);
+  char* prep = wt_ready ? nullptr : reinterpret_cast<char*>(wt_scratch);    // null: tiled already (pv_conv_wprep_table)
+  return ns == 3 ? conv3_sp_launch<3>(p, w, Co, Ci, flip, prep, nt, total, s) : conv3_sp_launch<2>(p, w, Co, Ci, flip, prep, nt, total, s);
 }
 
 // test / measurement hook: one convolution call on caller-provided device tensors.
@@ -606,6 +682,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
     }
 }
 
+int pv_wgrad_finish_blocks(int64_t nw, int nb);
 extern __global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
                                                     const float* __restrict__ part_b, int nb, float* __restrict__ out_b);
 
@@ -647,8 +724,7 @@ int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int
     else hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1>), grid, dim3(256), lds, s, p);
   }
   PV_LAUNCH_CHECK();
-  int fb = (int)((nw + 31) / 32 + (db ? (Cout + 31) / 32 : 0));
-  if (fb > 4096) fb = 4096;
+  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
   hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
   PV_LAUNCH_CHECK();
   return 0;

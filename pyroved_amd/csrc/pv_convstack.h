@@ -70,11 +70,61 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
   return true;
 }
 
+// The tiled / split weights of every kernel-3 convolution of a stack, both orientations (forward, input gradient), are
+// written ONCE per step by one launch (pv_conv_wprep_table) instead of before each convolution: the weights change once
+// per Adam step.  off[2 * slot + flip] = byte offset in the region, -1: that convolution does not use tiled weights.
+struct WtPlan {
+  int64_t off[2 * PV_MAX_OPS * 2];
+  int64_t bytes = 0;
+  WtPlan() { for (auto& o : off) o = -1; }
+};
+
 struct Scratch {
   float* col /* flipped-weight scratch (maxcol floats) */; void* ws; int64_t ws_bytes;
   float* bn = nullptr; int bn_maxC = 0; int bn_eval = 0;     // batch-norm statistics slots (bn_floats), mode
   int conv_bf16 = 0;                                         // kernel-3 convolutions on the bf16 matrix cores (x3)
+  const char* wt = nullptr; const WtPlan* wtp = nullptr;     // the step's tiled weights (null: tile per call into col)
 };
+inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
+  if (!sc.wt || !sc.wtp || sc.wtp->off[2 * slot + flip] < 0) return nullptr;
+  return sc.wt + sc.wtp->off[2 * slot + flip];
+}
+
+// which tiling (pv_conv_wprep_table kind) a kernel-3 convolution uses in an orientation; -1: none (GEMM fallback, k1)
+inline int wt_kind(const pv_op& o, int nd, int flip, int conv_bf16) {
+  if (o.kind != PV_OP_CONV || o.ksize != 3) return -1;
+  const int C = flip ? o.cout : o.cin, N = flip ? o.cin : o.cout, act = flip ? PV_ACT_NONE : o.act;
+  if (pv_conv3_sp_supported(C, N, nd, act)) return conv_bf16 ? 2 : 3;
+  if (pv_conv3_direct_supported(C, N, nd, act)) return (conv_bf16 && C % 32 == 0) ? 1 : 0;
+  return -1;
+}
+
+inline void wt_layout(const pv_op* ops, int n, int nd, int stack_id, int conv_bf16, bool need_input_grad, WtPlan& w) {
+  for (int i = 0; i < n; ++i)
+    for (int flip = 0; flip < 2; ++flip) {
+      if (flip && i == 0 && !need_input_grad) continue;
+      const int kind = wt_kind(ops[i], nd, flip, conv_bf16);
+      if (kind < 0) continue;
+      w.off[2 * (stack_id * PV_MAX_OPS + i) + flip] = w.bytes;
+      w.bytes += pv_align_up(pv_conv_wt_bytes(kind, ops[i].cout, ops[i].cin, nd), 256);
+    }
+}
+
+// one launch per 16 tilings: everything wt_layout placed for this stack (flip 1 entries only when with_dgrad)
+inline int wt_prep(const float* params, const pv_op* ops, int n, int nd, int stack_id, int conv_bf16, const WtPlan& w, char* base,
+                   bool with_dgrad, hipStream_t s) {
+  PvWprepEntry e[2 * PV_MAX_OPS];
+  int ne = 0;
+  for (int i = 0; i < n; ++i)
+    for (int flip = 0; flip < (with_dgrad ? 2 : 1); ++flip) {
+      const int64_t off = w.off[2 * (stack_id * PV_MAX_OPS + i) + flip];
+      if (off < 0) continue;
+      PvWprepEntry& E = e[ne++];
+      E.w = params + ops[i].w_off; E.dst = base + off; E.Co = ops[i].cout; E.Ci = ops[i].cin; E.KK = kk_of(ops[i], nd);
+      E.flip = flip; E.kind = wt_kind(ops[i], nd, flip, conv_bf16); E.pad_ = 0; E.start = E.total = 0;
+    }
+  return ne ? pv_conv_wprep_table(e, ne, s) : 0;
+}
 inline float* bn_slot(const Scratch& sc, int slot) { return sc.bn + (int64_t)slot * 4 * sc.bn_maxC; }
 
 // one op forward: in (shape si) -> out
@@ -91,10 +141,10 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
     if (o.ksize == 3) {
       if (pv_conv3_sp_supported(o.cin, o.cout, nd, o.act))      // 2-D, Cin % 32 == 0: exactly split operands on the bf16 cores
         return pv_conv3_sp(in, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr, 0,
-                           sc.conv_bf16 ? 2 : 3);
+                           sc.conv_bf16 ? 2 : 3, wt_ready(sc, slot, 0));
       if (pv_conv3_direct_supported(o.cin, o.cout, nd, o.act))
         return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr,
-                               0, sc.conv_bf16);
+                               0, sc.conv_bf16, wt_ready(sc, slot, 0));
       return conv3_fwd(in, B, si.H, si.W, si.C, nd, params + o.w_off, bias, out, o.cout, o.act, sc.ws, sc.ws_bytes, s);
     }
     return linear_fwd(in, K, params + o.w_off, bias, out, nullptr, o.cout, rows, K, o.cout, o.act, sc.ws, sc.ws_bytes, s);
@@ -138,12 +188,12 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         return pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act,
-                           sc.conv_bf16 ? 2 : 3);
+                           sc.conv_bf16 ? 2 : 3, wt_ready(sc, slot, 1));
       }
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s,
-                               in, fuse_act, sc.conv_bf16);
+                               in, fuse_act, sc.conv_bf16, wt_ready(sc, slot, 1));
       }
       PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
       return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);

@@ -50,6 +50,7 @@ struct Layout {
   bool enc_ext;                            // external encoder: (z_loc, z_scale) given, gradients handed back
   bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
   float* ccol; int64_t cF; float* cbn; int cbn_maxC;
+  pvcs::WtPlan cwtp; char* cwt;                            // the step's tiled conv-encoder weights
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
@@ -111,6 +112,8 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       L.cfeat = c.take(B * L.cF);
       L.cg[0] = c.take(cnd.maxact); L.cg[1] = c.take(cnd.maxact);
       L.ccol = c.take(cnd.maxcol);
+      pvcs::wt_layout(p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, false, L.cwtp);
+      L.cwt = reinterpret_cast<char*>(c.take((L.cwtp.bytes + 3) / 4));
       L.cbn = c.take(pvcs::bn_floats(cnd)); L.cbn_maxC = cnd.bn_maxC;
     } else {
       L.cF = -1;                                   // inconsistent op sequence: rejected by the entry points
@@ -305,7 +308,9 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   float* a[PV_MAX_OPS + 1];
   a[0] = const_cast<float*>(p->x);                  // one input channel: (B, 1, H, W) is already channels-last
   for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-  const pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
+  pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
+  sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // (both orientations: the backward of the same step reuses them)
+  PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s));
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
   const pvcs::Shape& fe = L.ces[p->n_enc_ops];
   PV_TRY(pv_nsc_to_ncs(L.cea[p->n_enc_ops], L.cfeat, B, fe.C, (int64_t)fe.H * fe.W, s));
@@ -424,7 +429,8 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     float* a[PV_MAX_OPS + 1];
     a[0] = const_cast<float*>(p->x);
     for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-    const pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
+    pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
+    sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // tiled by this step's conv_encoder_fwd
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
                            nullptr, sc, s));

@@ -31,6 +31,7 @@ struct VLayout {
   float* llrow; float* dlda; float* llb;
   float* g[2];                                         // gradient ping-pong (largest activation)
   pvcs::Scratch sc;                                    // im2col / dcol scratch + GEMM split-K scratch
+  pvcs::WtPlan wtp; char* wt;                          // the step's tiled conv weights (both stacks, both orientations)
   int64_t F;                                           // flattened feature size C*S of the encoder output
   int64_t total;
 };
@@ -84,13 +85,24 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B);
   L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
   L.sc.col = c.take(nd.maxcol);
+  pvcs::wt_layout(p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, false, L.wtp);
+  pvcs::wt_layout(p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, true, L.wtp);
+  L.wt = reinterpret_cast<char*>(c.take((L.wtp.bytes + 3) / 4));
   L.sc.bn = c.take(pvcs::bn_floats(nd)); L.sc.bn_maxC = nd.bn_maxC; L.sc.bn_eval = p->bn_eval;
   L.sc.conv_bf16 = p->conv_bf16;
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
   L.sc.ws = base ? (void*)(base + c.off) : nullptr;
   c.off += L.sc.ws_bytes;
   L.total = c.off;
+  L.sc.wt = L.wt; L.sc.wtp = &L.wtp;
   return true;
+}
+
+// tile the conv weights the coming launches need: stack 0 / 1 / both, with or without the input-gradient orientation
+int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_dgrad, hipStream_t s) {
+  if (enc) PV_TRY(pvcs::wt_prep(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, L.wtp, L.wt, with_dgrad, s));
+  if (dec) PV_TRY(pvcs::wt_prep(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, s));
+  return 0;
 }
 
 // encoder forward up to (head, z, z_scale[, KL scalars]); eps == null: inference (z = unused)
@@ -142,6 +154,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (p->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = p->batch, z = p->z_dim;
+  PV_TRY(ved_wt_prep(p, L, true, true, want_grads != 0, s));
   PV_TRY(ved_encoder_fwd(p, L, p->z_loc, p->z_scale, true, s));
   PV_TRY(ved_decoder_fwd(p, L, L.z, s));
   // ---- likelihood of the target (ved.py:141-145) ----
@@ -194,6 +207,7 @@ extern "C" int pv_ved_encode(const pv_ved_plan* p, float* z_loc, float* z_scale,
   VLayout L;
   if (!vcarve(p, (char*)p->ws, L)) return PV_EINVAL;
   if (p->ws_bytes < L.total) return PV_EWS;
+  PV_TRY(ved_wt_prep(p, L, true, false, false, (hipStream_t)stream));
   return ved_encoder_fwd(p, L, z_loc, z_scale, false, (hipStream_t)stream);
 }
 
@@ -204,6 +218,7 @@ extern "C" int pv_ved_decode(const pv_ved_plan* p, const float* z, float* loc, v
   if (p->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = p->batch;
+  PV_TRY(ved_wt_prep(p, L, false, true, false, s));
   PV_TRY(ved_decoder_fwd(p, L, z, s));
   const Shape& od = L.ds[p->n_dec_ops];
   const int64_t OUT = od.elems(B), S = (int64_t)od.H * od.W;
