@@ -47,6 +47,14 @@ bool pv_conv3_sp_wgrad_supported(int C, int Cout, int nd);
 int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout);
 int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,
                       int64_t ws_bytes, hipStream_t s, int ns);
+// first encoder block (conv k3 from one channel + activation + 2x max-pool) fused (pv_conv_c1.hip); code: one byte per
+// pooled value
+bool pv_c1_convpool_supported(int Cin, int Cout, int nd, int act, int H, int W);
+int64_t pv_c1_convpool_ws(int B, int H, int W, int Cout);
+int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, const float* bias, int Cout, int act, float* out,
+                       unsigned char* code, hipStream_t s);
+int pv_c1_convpool_bwd(const float* g, const float* y, const unsigned char* code, const float* x, int B, int H, int W, int Cout,
+                       int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

@@ -1,0 +1,212 @@
+// pv_conv_c1.hip — the first block of a 2-D convolutional encoder as ONE forward and ONE backward kernel:
+//   y = maxpool2( act( conv3x3(x; one input channel) + bias ) )            (nets/conv.py: ConvBlock + MaxPool2d, 146-199)
+// With one input channel the convolution is 9 multiply-adds per output: nothing for the matrix cores, and the op-by-op
+// form is bound by the full-resolution activation it writes, re-reads for the pooling, re-reads and re-writes (as a
+// gradient that is zero in three of four places) in the backward and re-reads for the weight gradient — five passes
+// over B*H*W*Cout floats.  Here the full-resolution tensors never exist: the forward writes the pooled activation and a
+// byte per pooled value saying which of the 2x2 positions won (strict >, scan order: the first maximum, like torch);
+// the backward reads the pooled gradient, the pooled activation (the activation derivative is a function of the
+// output) and that byte, and accumulates dW / db straight from the input image.
+#include "pv_common.h"
+#include "pv_conv.h"
+
+struct C1Pool {
+  const float* x; const float* w; const float* bias; float* out; unsigned char* code;
+  int B, H, W, C, act, Hp, Wp;
+};
+
+template <int ACT> __device__ __forceinline__ float c1_act(float v) {
+  if (ACT == PV_ACT_TANH) return tanhf(v);
+  if (ACT == PV_ACT_RELU) return v > 0.0f ? v : 0.0f;
+  if (ACT == PV_ACT_LRELU) return v > 0.0f ? v : 0.01f * v;
+  if (ACT == PV_ACT_SOFTPLUS) return pv_softplus(v);
+  if (ACT == PV_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// one thread per (pooled pixel, 4 channels): the 4x4 input window, 4 convolution outputs x 4 channels
+template <int ACT>
+__global__ __launch_bounds__(256) void pv_c1_convpool_fwd_kernel(C1Pool p) {
+  __shared__ __attribute__((aligned(16))) float wl[10 * 64];          // [tap 0..8 | bias][C]
+  for (int i = threadIdx.x; i < 10 * p.C; i += 256) {
+    const int t = i / p.C, c = i - t * p.C;
+    wl[t * p.C + c] = t < 9 ? p.w[c * 9 + t] : (p.bias ? p.bias[c] : 0.0f);
+  }
+  __syncthreads();
+  const int C4 = p.C / 4;
+  const int64_t total = (int64_t)p.B * p.Hp * p.Wp * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(e % C4);
+    const int64_t w_ = e / C4;
+    const int px = (int)(w_ % p.Wp), py = (int)((w_ / p.Wp) % p.Hp);
+    const int64_t b = w_ / ((int64_t)p.Wp * p.Hp);
+    const float* xb = p.x + b * p.H * p.W;
+    float xw[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int y = 2 * py - 1 + r, x = 2 * px - 1 + c;
+        xw[r][c] = (y >= 0 && y < p.H && x >= 0 && x < p.W) ? xb[y * p.W + x] : 0.0f;
+      }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * p.C + 4 * c4);
+    f32x4 v[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + t * p.C + 4 * c4);
+      const int ty = t / 3, tx = t - 3 * ty;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += wv * xw[(k >> 1) + ty][(k & 1) + tx];
+    }
+    f32x4 m;
+    unsigned best = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float mi = c1_act<ACT>(v[0][i]);
+      unsigned bi = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float a = c1_act<ACT>(v[k][i]);
+        if (a > mi) { mi = a; bi = k; }
+      }
+      m[i] = mi;
+      best |= bi << (8 * i);
+    }
+    *reinterpret_cast<f32x4*>(p.out + w_ * p.C + 4 * c4) = m;
+    *reinterpret_cast<unsigned*>(p.code + w_ * p.C + 4 * c4) = best;
+  }
+}
+
+bool pv_c1_convpool_supported(int Cin, int Cout, int nd, int act, int H, int W) {
+  return Cin == 1 && nd == 2 && Cout >= 4 && Cout <= 64 && Cout % 4 == 0 && act != PV_ACT_GELU && H >= 2 && W >= 2;
+}
+
+int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, const float* bias, int Cout, int act, float* out,
+                       unsigned char* code, hipStream_t s) {
+  if (!pv_c1_convpool_supported(1, Cout, 2, act, H, W)) return PV_EINVAL;
+  C1Pool p{x, w, bias, out, code, B, H, W, Cout, act, H / 2, W / 2};
+  const int64_t total = (int64_t)B * p.Hp * p.Wp * (Cout / 4);
+  int64_t nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (nb < 1) return 0;
+  const dim3 grid((unsigned)nb);
+  switch (act) {
+    case PV_ACT_TANH: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_TANH>, grid, dim3(256), 0, s, p); break;
+    case PV_ACT_RELU: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_RELU>, grid, dim3(256), 0, s, p); break;
+    case PV_ACT_LRELU: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_LRELU>, grid, dim3(256), 0, s, p); break;
+    case PV_ACT_SOFTPLUS: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_SOFTPLUS>, grid, dim3(256), 0, s, p); break;
+    case PV_ACT_SIGMOID: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_SIGMOID>, grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_NONE>, grid, dim3(256), 0, s, p); break;
+  }
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward: dpre = g * act'(y) at the winning position of each pooled value, zero elsewhere;
+//   dW[co][tap] = sum dpre[pixel][co] * x[pixel + tap],  db[co] = sum dpre[pixel][co].
+// A workgroup takes a range of pooled lines; its threads are (channel, line group): g / y / code of a pooled pixel are one
+// coalesced load across the channel lanes, the 4x4 input window of the pooled pixel slides along the line in registers
+// (the same for every channel lane).  Per-workgroup partials go through pv_conv3_wgrad_finish_kernel (fixed order).
+struct C1PoolBwd {
+  const float* g; const float* y; const unsigned char* code; const float* x; float* part; float* part_b;
+  int B, H, W, C, act, Hp, Wp, CP, nsplit;
+};
+
+__global__ __launch_bounds__(256) void pv_c1_convpool_bwd_kernel(C1PoolBwd p) {
+  __shared__ float sm[256][10];
+  const int tid = threadIdx.x, co = tid % p.CP, rg = tid / p.CP, RG = 256 / p.CP;
+  const int64_t lines = (int64_t)p.B * p.Hp;
+  const int64_t l_lo = lines * blockIdx.x / p.nsplit, l_hi = lines * (blockIdx.x + 1) / p.nsplit;
+  float acc[9], accb = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
+  const bool cok = co < p.C;
+  for (int64_t l = l_lo + rg; l < l_hi; l += RG) {
+    const int py = (int)(l % p.Hp);
+    const int64_t b = l / p.Hp;
+    const float* xb = p.x + b * p.H * p.W;
+    const float* rowp[4];
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = 2 * py - 1 + r;
+      rok[r] = y >= 0 && y < p.H;
+      rowp[r] = xb + (int64_t)(rok[r] ? y : 0) * p.W;
+    }
+    float xw[4][4];                                  // columns 2 px - 1 .. 2 px + 2
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xw[r][0] = xw[r][1] = 0.0f;
+      xw[r][2] = 0.0f;                               // column -1 of the first window
+      xw[r][3] = rok[r] ? rowp[r][0] : 0.0f;         // column 0
+    }
+    const int64_t base = l * p.Wp * p.C + co;
+    for (int px = 0; px < p.Wp; ++px) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xw[r][0] = xw[r][2]; xw[r][1] = xw[r][3];
+        const int x1 = 2 * px + 1, x2 = 2 * px + 2;
+        xw[r][2] = (rok[r] && x1 < p.W) ? rowp[r][x1] : 0.0f;
+        xw[r][3] = (rok[r] && x2 < p.W) ? rowp[r][x2] : 0.0f;
+      }
+      float dv = 0.0f;
+      int k = 0;
+      if (cok) {
+        const int64_t o = base + (int64_t)px * p.C;
+        dv = p.g[o] * pv_act_grad(p.y[o], 0.0f, p.act);
+        k = p.code[o];
+      }
+      accb += dv;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float dk = k == kk ? dv : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += dk * xw[(kk >> 1) + t / 3][(kk & 1) + t % 3];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) sm[tid][t] = acc[t];
+  sm[tid][9] = accb;
+  __syncthreads();
+  for (int o = tid; o < p.C * 10; o += 256) {        // (channel, tap) outputs: sum the line groups in group order
+    const int c = o / 10, t = o % 10;
+    float v = 0.0f;
+    for (int g = 0; g < RG; ++g) v += sm[g * p.CP + c][t];
+    if (t == 9) { if (p.part_b) p.part_b[(int64_t)blockIdx.x * p.C + c] = v; }
+    else p.part[(int64_t)blockIdx.x * p.C * 9 + c * 9 + t] = v;
+  }
+}
+
+int pv_wgrad_finish_blocks(int64_t nw, int nb);
+extern __global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
+                                                    const float* __restrict__ part_b, int nb, float* __restrict__ out_b);
+
+static int c1p_splits(int B, int Hp) {
+  const int64_t lines = (int64_t)B * Hp;
+  return (int)(lines < 512 ? (lines < 1 ? 1 : lines) : 512);
+}
+int64_t pv_c1_convpool_ws(int B, int H, int W, int Cout) {
+  return (int64_t)c1p_splits(B, H / 2) * (int64_t)Cout * 10 * (int64_t)sizeof(float) + 256;
+}
+
+// g: dL/d(pooled output), y: the pooled output, code: from the forward.  dw (Cout, 1, 3, 3), db (Cout) or null.
+int pv_c1_convpool_bwd(const float* g, const float* y, const unsigned char* code, const float* x, int B, int H, int W, int Cout,
+                       int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (!pv_c1_convpool_supported(1, Cout, 2, act, H, W)) return PV_EINVAL;
+  if (ws_bytes < pv_c1_convpool_ws(B, H, W, Cout)) return PV_EWS;
+  const int ns = c1p_splits(B, H / 2);
+  int CP = 1;
+  while (CP < Cout) CP *= 2;
+  float* part = reinterpret_cast<float*>(ws);
+  float* part_b = db ? part + (int64_t)ns * Cout * 9 : nullptr;
+  C1PoolBwd p{g, y, code, x, part, part_b, B, H, W, Cout, act, H / 2, W / 2, CP, ns};
+  hipLaunchKernelGGL(pv_c1_convpool_bwd_kernel, dim3(ns), dim3(256), 0, s, p);
+  PV_LAUNCH_CHECK();
+  const int64_t nw = (int64_t)Cout * 9;
+  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, part, ns, nw, dw, part_b, Cout, db);
+  PV_LAUNCH_CHECK();
+  return 0;
+}

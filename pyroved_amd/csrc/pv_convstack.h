@@ -36,14 +36,25 @@ inline bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
 inline int kk_of(const pv_op& o, int nd) { return o.ksize == 3 ? (nd == 2 ? 9 : 3) : 1; }
 
 // scratch the stack's GEMMs and im2col need for B samples: running maxima
-struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0; int bn_maxC = 0; };
+struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0, code_bytes = 0; int bn_maxC = 0; };
 #define PVCS_BN_SLOTS (2 * PV_MAX_OPS)        // per-op statistics slots: stack 0 (encoder) and stack 1 (decoder)
 inline int64_t bn_floats(const Needs& n) { return (int64_t)PVCS_BN_SLOTS * 4 * n.bn_maxC; }
 inline void upd(int64_t& m, int64_t v) { if (v > m) m = v; }
 
+// the first block of a 2-D encoder — conv k3 from ONE channel, activation, 2x max-pool — runs as one forward and one
+// backward kernel that never materialise the full-resolution activation (pv_conv_c1.hip)
+inline bool c1pool_fusable(const pv_op* ops, int n, int nd, const Shape& s0) {
+  return n >= 2 && ops[0].kind == PV_OP_CONV && ops[0].ksize == 3 && ops[1].kind == PV_OP_MAXPOOL2 && s0.C == 1 &&
+         pv_c1_convpool_supported(ops[0].cin, ops[0].cout, nd, ops[0].act, s0.H, s0.W);
+}
+
 // shapes s[0..n] from s[0]; accumulates workspace needs; false on an inconsistent sequence
 inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, Needs& nd_) {
   upd(nd_.maxact, s[0].elems(B));
+  if (c1pool_fusable(ops, n, nd, s[0])) {
+    upd(nd_.code_bytes, B * (s[0].H / 2) * (s[0].W / 2) * ops[0].cout);
+    upd(nd_.scratch, pv_c1_convpool_ws((int)B, s[0].H, s[0].W, ops[0].cout));
+  }
   for (int i = 0; i < n; ++i) {
     if (!op_shape(ops[i], nd, s[i], s[i + 1])) return false;
     upd(nd_.maxact, s[i + 1].elems(B));
@@ -84,6 +95,7 @@ struct Scratch {
   float* bn = nullptr; int bn_maxC = 0; int bn_eval = 0;     // batch-norm statistics slots (bn_floats), mode
   int conv_bf16 = 0;                                         // kernel-3 convolutions on the bf16 matrix cores (x3)
   const char* wt = nullptr; const WtPlan* wtp = nullptr;     // the step's tiled weights (null: tile per call into col)
+  unsigned char* code = nullptr;                             // winners of the fused first block's max-pool (stack 0 only)
 };
 inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
   if (!sc.wt || !sc.wtp || sc.wtp->off[2 * slot + flip] < 0) return nullptr;
@@ -215,7 +227,13 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
 // whole stack forward: a[0] given, a[1..n] written
 inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B, float* const* a, const Shape* sh,
                      const Scratch& sc, hipStream_t s, int stack_id = 0) {
-  for (int i = 0; i < n; ++i)
+  int i0 = 0;
+  if (stack_id == 0 && sc.code && c1pool_fusable(ops, n, nd, sh[0])) {   // a[1] is never written
+    PV_TRY(pv_c1_convpool_fwd(a[0], B, sh[0].H, sh[0].W, params + ops[0].w_off, ops[0].b_off >= 0 ? params + ops[0].b_off : nullptr,
+                              ops[0].cout, ops[0].act, a[2], sc.code, s));
+    i0 = 2;
+  }
+  for (int i = i0; i < n; ++i)
     PV_TRY(op_fwd(params, ops[i], nd, B, a[i], sh[i], a[i + 1], sc, stack_id * PV_MAX_OPS + i, s));
   return 0;
 }
@@ -226,7 +244,14 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
                      const Shape* sh, float* g, float* const* gbuf, int& pp, bool need_input_grad, float** gout,
                      const Scratch& sc, hipStream_t s, int stack_id = 0) {
   bool g_is_pre = false;
+  const bool c1pool = stack_id == 0 && sc.code && !need_input_grad && c1pool_fusable(ops, n, nd, sh[0]);
   for (int i = n - 1; i >= 0; --i) {
+    if (c1pool && i == 1) {                            // g = dL/d(a[2]): the fused backward of ops 1 and 0
+      PV_TRY(pv_c1_convpool_bwd(g, a[2], sc.code, a[0], B, sh[0].H, sh[0].W, ops[0].cout, ops[0].act, grads + ops[0].w_off,
+                                ops[0].b_off >= 0 ? grads + ops[0].b_off : nullptr, sc.ws, sc.ws_bytes, s));
+      g = nullptr;
+      break;
+    }
     float* gin = (i > 0 || need_input_grad) ? gbuf[pp] : nullptr;
     // the layer below is a convolution with an activation: let this op's backward apply act'(a[i]) to gin
     const int fuse_act = (i > 0 && gin && ops[i - 1].kind == PV_OP_CONV) ? ops[i - 1].act : PV_ACT_NONE;

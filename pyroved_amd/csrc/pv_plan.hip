@@ -51,6 +51,7 @@ struct Layout {
   bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
   float* ccol; int64_t cF; float* cbn; int cbn_maxC;
   pvcs::WtPlan cwtp; char* cwt;                            // the step's tiled conv-encoder weights
+  unsigned char* ccode;                                    // max-pool winners of the fused first block
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
@@ -101,7 +102,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
   const int n_enc = (L.enc_conv || L.enc_ext) ? 0 : p->n_enc;
   pvcs::Needs cnd;
-  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0;
+  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr;
   if (L.enc_conv) {
     L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
     if ((int64_t)L.ces[0].H * L.ces[0].W == p->n_pix && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
@@ -114,6 +115,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       L.ccol = c.take(cnd.maxcol);
       pvcs::wt_layout(p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, false, L.cwtp);
       L.cwt = reinterpret_cast<char*>(c.take((L.cwtp.bytes + 3) / 4));
+      L.ccode = cnd.code_bytes ? reinterpret_cast<unsigned char*>(c.take((cnd.code_bytes + 3) / 4)) : nullptr;
       L.cbn = c.take(pvcs::bn_floats(cnd)); L.cbn_maxC = cnd.bn_maxC;
     } else {
       L.cF = -1;                                   // inconsistent op sequence: rejected by the entry points
@@ -310,6 +312,7 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
   pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
   sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // (both orientations: the backward of the same step reuses them)
+  sc.code = L.ccode;
   PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s));
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
   const pvcs::Shape& fe = L.ces[p->n_enc_ops];
@@ -431,6 +434,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
     pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
     sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // tiled by this step's conv_encoder_fwd
+    sc.code = L.ccode;
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
                            nullptr, sc, s));

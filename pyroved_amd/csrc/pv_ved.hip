@@ -88,6 +88,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   pvcs::wt_layout(p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, false, L.wtp);
   pvcs::wt_layout(p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, true, L.wtp);
   L.wt = reinterpret_cast<char*>(c.take((L.wtp.bytes + 3) / 4));
+  L.sc.code = nd.code_bytes ? reinterpret_cast<unsigned char*>(c.take((nd.code_bytes + 3) / 4)) : nullptr;
   L.sc.bn = c.take(pvcs::bn_floats(nd)); L.sc.bn_maxC = nd.bn_maxC; L.sc.bn_eval = p->bn_eval;
   L.sc.conv_bf16 = p->conv_bf16;
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
