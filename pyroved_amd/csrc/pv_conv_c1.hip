@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_fwd_kernel(C1Pool p) {
 }
 
 bool pv_c1_convpool_supported(int Cin, int Cout, int nd, int act, int H, int W) {
-  return Cin == 1 && nd == 2 && Cout >= 4 && Cout <= 64 && Cout % 4 == 0 && act != PV_ACT_GELU && H >= 2 && W >= 2;
+  return Cin == 1 && nd == 2 && Cout >= 4 && Cout <= 64 && Cout % 4 == 0 && act != PV_ACT_GELU && H >= 2 && W >= 2 && W <= 3000;
 }
 
 int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, const float* bias, int Cout, int act, float* out,
@@ -110,53 +110,47 @@ int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, cons
 // (the same for every channel lane).  Per-workgroup partials go through pv_conv3_wgrad_finish_kernel (fixed order).
 struct C1PoolBwd {
   const float* g; const float* y; const unsigned char* code; const float* x; float* part; float* part_b;
-  int B, H, W, C, act, Hp, Wp, CP, nsplit;
+  int B, H, W, C, act, Hp, Wp, CP, nsplit, lpw;
 };
 
+// A workgroup takes lpw consecutive pooled lines: the 4 input lines under each (with a zero halo) are staged in LDS in
+// one go, then thread (channel, pixel group) walks the pooled pixels: g / y / code are one coalesced load across the
+// channel lanes, the 4x4 input window comes out of LDS (the same address for every channel lane).
 __global__ __launch_bounds__(256) void pv_c1_convpool_bwd_kernel(C1PoolBwd p) {
+  extern __shared__ float xs[];                       // [lpw][4][W + 2], column index = image column + 1
   __shared__ float sm[256][10];
   const int tid = threadIdx.x, co = tid % p.CP, rg = tid / p.CP, RG = 256 / p.CP;
   const int64_t lines = (int64_t)p.B * p.Hp;
-  const int64_t l_lo = lines * blockIdx.x / p.nsplit, l_hi = lines * (blockIdx.x + 1) / p.nsplit;
+  const int64_t l_lo = (int64_t)blockIdx.x * p.lpw;
+  const int nl = (int)(lines - l_lo < p.lpw ? lines - l_lo : p.lpw);
+  const int WS = p.W + 2;
+  for (int i = tid; i < nl * 4 * WS; i += 256) {
+    const int li = i / (4 * WS), r = (i / WS) & 3, c = i % WS - 1;
+    const int64_t l = l_lo + li;
+    const int py = (int)(l % p.Hp), y = 2 * py - 1 + r;
+    const int64_t b = l / p.Hp;
+    xs[i] = (y >= 0 && y < p.H && c >= 0 && c < p.W) ? p.x[(b * p.H + y) * p.W + c] : 0.0f;
+  }
+  __syncthreads();
   float acc[9], accb = 0.0f;
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
   const bool cok = co < p.C;
-  for (int64_t l = l_lo + rg; l < l_hi; l += RG) {
-    const int py = (int)(l % p.Hp);
-    const int64_t b = l / p.Hp;
-    const float* xb = p.x + b * p.H * p.W;
-    const float* rowp[4];
-    bool rok[4];
+  const int coc = cok ? co : p.C - 1;
+  const float msk = cok ? 1.0f : 0.0f;
+  for (int li = 0; li < nl; ++li) {
+    const float* xl = xs + li * 4 * WS;
+    const int64_t base = (l_lo + li) * p.Wp * p.C + coc;
+#pragma unroll 4
+    for (int px = rg; px < p.Wp; px += RG) {
+      const int64_t o = base + (int64_t)px * p.C;
+      const float dv = msk * p.g[o] * pv_act_grad(p.y[o], 0.0f, p.act);
+      const int k = p.code[o];
+      float xw[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int y = 2 * py - 1 + r;
-      rok[r] = y >= 0 && y < p.H;
-      rowp[r] = xb + (int64_t)(rok[r] ? y : 0) * p.W;
-    }
-    float xw[4][4];                                  // columns 2 px - 1 .. 2 px + 2
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      xw[r][0] = xw[r][1] = 0.0f;
-      xw[r][2] = 0.0f;                               // column -1 of the first window
-      xw[r][3] = rok[r] ? rowp[r][0] : 0.0f;         // column 0
-    }
-    const int64_t base = l * p.Wp * p.C + co;
-    for (int px = 0; px < p.Wp; ++px) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xw[r][0] = xw[r][2]; xw[r][1] = xw[r][3];
-        const int x1 = 2 * px + 1, x2 = 2 * px + 2;
-        xw[r][2] = (rok[r] && x1 < p.W) ? rowp[r][x1] : 0.0f;
-        xw[r][3] = (rok[r] && x2 < p.W) ? rowp[r][x2] : 0.0f;
-      }
-      float dv = 0.0f;
-      int k = 0;
-      if (cok) {
-        const int64_t o = base + (int64_t)px * p.C;
-        dv = p.g[o] * pv_act_grad(p.y[o], 0.0f, p.act);
-        k = p.code[o];
-      }
+        for (int c = 0; c < 4; ++c) xw[r][c] = xl[r * WS + 2 * px + c];
       accb += dv;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -170,7 +164,7 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_bwd_kernel(C1PoolBwd p) {
   for (int t = 0; t < 9; ++t) sm[tid][t] = acc[t];
   sm[tid][9] = accb;
   __syncthreads();
-  for (int o = tid; o < p.C * 10; o += 256) {        // (channel, tap) outputs: sum the line groups in group order
+  for (int o = tid; o < p.C * 10; o += 256) {        // (channel, tap) outputs: sum the pixel groups in group order
     const int c = o / 10, t = o % 10;
     float v = 0.0f;
     for (int g = 0; g < RG; ++g) v += sm[g * p.CP + c][t];
@@ -183,26 +177,31 @@ int pv_wgrad_finish_blocks(int64_t nw, int nb);
 extern __global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
                                                     const float* __restrict__ part_b, int nb, float* __restrict__ out_b);
 
-static int c1p_splits(int B, int Hp) {
+static int c1p_lpw(int W) {                          // pooled lines per workgroup: up to 8, 48 KB of staged input lines
+  int l = (48 * 1024) / (16 * (W + 2));
+  return l > 8 ? 8 : (l < 1 ? 1 : l);
+}
+static int c1p_splits(int B, int Hp, int W) {
   const int64_t lines = (int64_t)B * Hp;
-  return (int)(lines < 512 ? (lines < 1 ? 1 : lines) : 512);
+  const int lpw = c1p_lpw(W);
+  return (int)((lines + lpw - 1) / lpw);
 }
 int64_t pv_c1_convpool_ws(int B, int H, int W, int Cout) {
-  return (int64_t)c1p_splits(B, H / 2) * (int64_t)Cout * 10 * (int64_t)sizeof(float) + 256;
+  return (int64_t)c1p_splits(B, H / 2, W) * (int64_t)Cout * 10 * (int64_t)sizeof(float) + 256;
 }
 
 // g: dL/d(pooled output), y: the pooled output, code: from the forward.  dw (Cout, 1, 3, 3), db (Cout) or null.
 int pv_c1_convpool_bwd(const float* g, const float* y, const unsigned char* code, const float* x, int B, int H, int W, int Cout,
                        int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s) {
-  if (!pv_c1_convpool_supported(1, Cout, 2, act, H, W)) return PV_EINVAL;
+  if (!pv_c1_convpool_supported(1, Cout, 2, act, H, W) || W > 3000) return PV_EINVAL;
   if (ws_bytes < pv_c1_convpool_ws(B, H, W, Cout)) return PV_EWS;
-  const int ns = c1p_splits(B, H / 2);
+  const int ns = c1p_splits(B, H / 2, W), lpw = c1p_lpw(W);
   int CP = 1;
   while (CP < Cout) CP *= 2;
   float* part = reinterpret_cast<float*>(ws);
   float* part_b = db ? part + (int64_t)ns * Cout * 9 : nullptr;
-  C1PoolBwd p{g, y, code, x, part, part_b, B, H, W, Cout, act, H / 2, W / 2, CP, ns};
-  hipLaunchKernelGGL(pv_c1_convpool_bwd_kernel, dim3(ns), dim3(256), 0, s, p);
+  C1PoolBwd p{g, y, code, x, part, part_b, B, H, W, Cout, act, H / 2, W / 2, CP, ns, lpw};
+  hipLaunchKernelGGL(pv_c1_convpool_bwd_kernel, dim3(ns), dim3(256), (size_t)lpw * 16 * (W + 2), s, p);
   PV_LAUNCH_CHECK();
   const int64_t nw = (int64_t)Cout * 9;
   const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
