@@ -39,7 +39,8 @@ int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr);
 // all of a step's weight tilings in one launch (per 16 entries).  kind 0: pv_conv3_direct f32, 1: its bf16 two-piece form,
-// 2 / 3: pv_conv3_sp with 2 / 3 pieces; dst sized by pv_conv_wt_bytes
+// 2 / 3: pv_conv3_sp with 2 / 3 pieces, 4: a conv head's Linear weight re-indexed channels-last (Co = out, Ci = C,
+// KK = spatial size); dst sized by pv_conv_wt_bytes
 struct PvWprepEntry { const float* w; char* dst; int Co, Ci, KK, flip, kind; int pad_; int64_t start, total; };
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd);
 int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s);
@@ -55,6 +56,16 @@ int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, cons
                        unsigned char* code, hipStream_t s);
 int pv_c1_convpool_bwd(const float* g, const float* y, const unsigned char* code, const float* x, int B, int H, int W, int Cout,
                        int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s);
+// the Linear head over a channels-last feature map without transposes (pv_convhead.hip); wt: the weight re-indexed to
+// [out][s*C + c] (pv_conv_wprep_table kind 4: Co = out, Ci = C, KK = S)
+bool pv_convhead_supported(int64_t F, int out);
+int64_t pv_convhead_ws(int B, int64_t F, int out);
+int pv_convhead_fwd(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
+                    int64_t ws_bytes, hipStream_t s);
+int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act, float* g, int B, int64_t F, int out,
+                    hipStream_t s);
+int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, void* ws,
+                      int64_t ws_bytes, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

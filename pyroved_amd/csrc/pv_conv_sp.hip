@@ -133,6 +133,12 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
     const PvWprepEntry E = t.e[k];
     const int64_t e = idx - E.start;
     const int Co = E.Co, Ci = E.Ci, KK = E.KK, flip = E.flip;
+    if (E.kind == 4) {                                // conv head: dst[j][s*C + c] = w[j][c*S + s]  (Co = out, Ci = C, KK = S)
+      const int64_t F = (int64_t)Ci * KK, j = e / F, f = e - j * F;
+      const int sp = (int)(f / Ci), c = (int)(f - (int64_t)sp * Ci);
+      reinterpret_cast<float*>(E.dst)[e] = E.w[j * F + (int64_t)c * KK + sp];
+      continue;
+    }
     if (E.kind >= 2) {
       if (E.kind == 3) sp_wprep_elem<3>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
       else sp_wprep_elem<2>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
@@ -157,12 +163,14 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
 }
 
 static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
+  if (kind == 4) return (int64_t)Co * Ci * KK;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   const int KC = kind == 0 ? 16 : 32;
   return (int64_t)((N + 63) / 64) * (C / KC) * KK * 64 * KC;
 }
 
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd) {
+  if (kind == 4) return -1;                          // (sized by the caller: out * F floats)
   if (kind >= 2) return pv_conv3_sp_wt_bytes(Ci, Co);
   return pv_conv3_direct_wt_floats(Ci, Co, nd) * (int64_t)sizeof(float);
 }

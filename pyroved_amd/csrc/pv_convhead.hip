@@ -1,0 +1,191 @@
+// pv_convhead.hip — the fully connected head on top of a convolutional feature extractor (nets/conv.py:
+// features2latent = flatten (C, spatial) + nn.Linear) without the layout changes.  Activations are channels-last here, the
+// Linear's weight is indexed channels-first (f = c*S + s): instead of transposing the feature map (33 MB at C5's size)
+// before the forward GEMM and transposing its gradient back, the WEIGHT (out x F, out <= 16) is re-indexed once per step
+// (pv_conv_wprep_table kind 4: wt[j][s*C + c] = w[j][c*S + s]) and three streaming kernels do the rest:
+//   forward   head[b][j] = bias[j] + sum_f a[b][f] wt[j][f]                         reads a once
+//   backward  g[b][f]    = act'(y[b][f]) * sum_j dhead[b][j] wt[j][f]               reads y, writes g (the producing
+//                          convolution's activation backward folded in)
+//   wgrad     dw[j][c*S + s] = sum_b dhead[b][j] a[b][s*C + c],  db[j] = sum_b dhead[b][j]
+#include "pv_common.h"
+#include "pv_conv.h"
+
+#define CH_MAXOUT 16
+
+// workgroup (b, seg): the dot products of sample b over segment seg of f -> part[b][seg][j]
+template <int OUT>
+__global__ __launch_bounds__(256) void pv_convhead_fwd_kernel(const float* __restrict__ a, const float* __restrict__ wt,
+                                                              float* __restrict__ part, int64_t F, int out, int nseg) {
+  __shared__ float sm[4][CH_MAXOUT];
+  const int b = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
+  const int64_t F4 = F / 4, i_lo = F4 * seg / nseg, i_hi = F4 * (seg + 1) / nseg;
+  const f32x4* ab = reinterpret_cast<const f32x4*>(a + (int64_t)b * F);
+  float acc[OUT];
+#pragma unroll
+  for (int j = 0; j < OUT; ++j) acc[j] = 0.0f;
+  for (int64_t i = i_lo + tid; i < i_hi; i += 256) {
+    const f32x4 v = ab[i];
+#pragma unroll
+    for (int j = 0; j < OUT; ++j)
+      if (j < out) {
+        const f32x4 w = reinterpret_cast<const f32x4*>(wt + (int64_t)j * F)[i];
+        acc[j] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < OUT; ++j) {
+    float v = acc[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & 63) == 0) sm[tid >> 6][j] = v;
+  }
+  __syncthreads();
+  if (tid < out) part[((int64_t)b * nseg + seg) * out + tid] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+}
+
+// head[b][j] = bias[j] + sum_seg part[b][seg][j] (segment order)
+__global__ void pv_convhead_fwd_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                              float* __restrict__ head, int B, int out, int nseg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * out) return;
+  const int b = e / out, j = e - b * out;
+  float v = bias ? bias[j] : 0.0f;
+  for (int k = 0; k < nseg; ++k) v += part[((int64_t)b * nseg + k) * out + j];
+  head[e] = v;
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void pv_convhead_bwd_kernel(const float* __restrict__ dhead, const float* __restrict__ wt,
+                                                              const float* __restrict__ y, int act, float* __restrict__ g,
+                                                              int B, int64_t F, int out) {
+  const int64_t F4 = F / 4, total = (int64_t)B * F4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / F4, i = e - b * F4;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < OUT; ++j)
+      if (j < out) v += dhead[b * out + j] * reinterpret_cast<const f32x4*>(wt + (int64_t)j * F)[i];
+    if (act != PV_ACT_NONE) {
+      const f32x4 yy = reinterpret_cast<const f32x4*>(y)[e];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= pv_act_grad(yy[k], 0.0f, act);
+    }
+    reinterpret_cast<f32x4*>(g)[e] = v;
+  }
+}
+
+// partial[split][j][f] (channels-last f) over the samples of the split
+template <int OUT>
+__global__ __launch_bounds__(256) void pv_convhead_wgrad_kernel(const float* __restrict__ dhead, const float* __restrict__ a,
+                                                                float* __restrict__ part, int B, int64_t F, int out, int nsplit) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // float4 index along f
+  const int split = blockIdx.y;
+  const int b_lo = (int)((int64_t)B * split / nsplit), b_hi = (int)((int64_t)B * (split + 1) / nsplit);
+  if (i >= F / 4) return;
+  f32x4 acc[OUT];
+#pragma unroll
+  for (int j = 0; j < OUT; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int b = b_lo; b < b_hi; ++b) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(a + (int64_t)b * F)[i];
+#pragma unroll
+    for (int j = 0; j < OUT; ++j)
+      if (j < out) acc[j] += dhead[(int64_t)b * out + j] * v;
+  }
+#pragma unroll
+  for (int j = 0; j < OUT; ++j)
+    if (j < out) reinterpret_cast<f32x4*>(part + ((int64_t)split * out + j) * F)[i] = acc[j];
+}
+
+// dw[j][c*S + s] = sum_split part[split][j][s*C + c] (split order) through a 32 x 32 LDS tile, so that both the reads
+// (along c) and the writes (along s) are coalesced; the last block row also does db[j] = sum_b dhead[b][j] (sample order)
+__global__ __launch_bounds__(256) void pv_convhead_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int out, int S,
+                                                                       int C, float* __restrict__ dw, const float* __restrict__ dhead,
+                                                                       int B, float* __restrict__ db) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
+  const int tcs = (C + 31) / 32, tss = (S + 31) / 32;
+  const int64_t F = (int64_t)S * C, ntiles = (int64_t)out * tss * tcs;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tc = (int)(t % tcs), ts = (int)((t / tcs) % tss);
+    const int64_t j = t / ((int64_t)tcs * tss);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = ts * 32 + ty + 8 * r, c = tc * 32 + tx;
+      float v = 0.0f;
+      if (s < S && c < C)
+        for (int k = 0; k < nsplit; ++k) v += part[((int64_t)k * out + j) * F + (int64_t)s * C + c];
+      tile[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = tc * 32 + ty + 8 * r, s = ts * 32 + tx;
+      if (s < S && c < C) dw[j * F + (int64_t)c * S + s] = tile[tx][ty + 8 * r];
+    }
+  }
+  if (blockIdx.x == 0 && db && (int)threadIdx.x < out) {
+    float v = 0.0f;
+    for (int b = 0; b < B; ++b) v += dhead[(int64_t)b * out + threadIdx.x];
+    db[threadIdx.x] = v;
+  }
+}
+
+bool pv_convhead_supported(int64_t F, int out) { return out >= 1 && out <= CH_MAXOUT && F >= 4 && F % 4 == 0; }
+
+static int ch_splits(int B) { const int n = B / 16; return n > 16 ? 16 : (n < 1 ? 1 : n); }      // >= 16 samples per split
+static int ch_segs(int B, int64_t F) {               // forward: ~1024 workgroups, at least 1024 floats per segment
+  int64_t n = (1024 + B - 1) / B, cap = F / 1024;
+  if (n > cap) n = cap;
+  return (int)(n < 1 ? 1 : (n > 16 ? 16 : n));
+}
+int64_t pv_convhead_ws(int B, int64_t F, int out) {
+  const int64_t wg = (int64_t)ch_splits(B) * out * F, fw = (int64_t)B * ch_segs(B, F) * out;
+  return (wg > fw ? wg : fw) * (int64_t)sizeof(float) + 256;
+}
+
+#define CH_DISPATCH(KERNEL, GRID, ...)                                                                       \
+  do {                                                                                                       \
+    if (out <= 4) hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, s, __VA_ARGS__);                         \
+    else if (out <= 8) hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(256), 0, s, __VA_ARGS__);                    \
+    else hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(256), 0, s, __VA_ARGS__);                                 \
+    PV_LAUNCH_CHECK();                                                                                       \
+  } while (0)
+
+int pv_convhead_fwd(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
+                    int64_t ws_bytes, hipStream_t s) {
+  if (!pv_convhead_supported(F, out)) return PV_EINVAL;
+  if (ws_bytes < pv_convhead_ws(B, F, out)) return PV_EWS;
+  const int nseg = ch_segs(B, F);
+  float* part = reinterpret_cast<float*>(ws);
+  CH_DISPATCH(pv_convhead_fwd_kernel, dim3((unsigned)B, (unsigned)nseg), a, wt, part, F, out, nseg);
+  hipLaunchKernelGGL(pv_convhead_fwd_finish_kernel, dim3((unsigned)((B * out + 255) / 256)), dim3(256), 0, s, part, bias, head, B,
+                     out, nseg);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act, float* g, int B, int64_t F, int out,
+                    hipStream_t s) {
+  if (!pv_convhead_supported(F, out) || act == PV_ACT_GELU) return PV_EINVAL;
+  int64_t nb = ((int64_t)B * (F / 4) + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  CH_DISPATCH(pv_convhead_bwd_kernel, dim3((unsigned)nb), dhead, wt, y, act, g, B, F, out);
+  return 0;
+}
+
+int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, void* ws,
+                      int64_t ws_bytes, hipStream_t s) {
+  const int64_t F = (int64_t)S * C;
+  if (!pv_convhead_supported(F, out)) return PV_EINVAL;
+  if (ws_bytes < pv_convhead_ws(B, F, out)) return PV_EWS;
+  const int ns = ch_splits(B);
+  float* part = reinterpret_cast<float*>(ws);
+  const dim3 grid((unsigned)((F / 4 + 255) / 256), (unsigned)ns);
+  CH_DISPATCH(pv_convhead_wgrad_kernel, grid, dhead, a, part, B, F, out, ns);
+  int64_t fb = (int64_t)out * ((S + 31) / 32) * ((C + 31) / 32);
+  if (fb > 4096) fb = 4096;
+  hipLaunchKernelGGL(pv_convhead_wgrad_finish_kernel, dim3((unsigned)fb), dim3(256), 0, s, part, ns, out, S, C, dw, dhead, B, db);
+  PV_LAUNCH_CHECK();
+  return 0;
+}

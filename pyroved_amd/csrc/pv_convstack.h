@@ -122,11 +122,19 @@ inline void wt_layout(const pv_op* ops, int n, int nd, int stack_id, int conv_bf
     }
 }
 
+// a conv head's weight entry for wt_prep (kind 4): w (out, C*S) -> dst (out, S*C)
+inline PvWprepEntry head_entry(const float* w, float* dst, int out, int C, int64_t S) {
+  PvWprepEntry E{};
+  E.w = w; E.dst = reinterpret_cast<char*>(dst); E.Co = out; E.Ci = C; E.KK = (int)S; E.flip = 0; E.kind = 4;
+  return E;
+}
+
 // one launch per 16 tilings: everything wt_layout placed for this stack (flip 1 entries only when with_dgrad)
 inline int wt_prep(const float* params, const pv_op* ops, int n, int nd, int stack_id, int conv_bf16, const WtPlan& w, char* base,
-                   bool with_dgrad, hipStream_t s) {
-  PvWprepEntry e[2 * PV_MAX_OPS];
+                   bool with_dgrad, hipStream_t s, const PvWprepEntry* extra = nullptr, int n_extra = 0) {
+  PvWprepEntry e[2 * PV_MAX_OPS + 4];
   int ne = 0;
+  for (int k = 0; k < n_extra && k < 4; ++k) e[ne++] = extra[k];     // (e.g. a conv head's re-indexed Linear weight)
   for (int i = 0; i < n; ++i)
     for (int flip = 0; flip < (with_dgrad ? 2 : 1); ++flip) {
       const int64_t off = w.off[2 * (stack_id * PV_MAX_OPS + i) + flip];
@@ -242,8 +250,8 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
 // dL/d(a[0]) (null when need_input_grad is false: the first op then skips its dgrad)
 inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n, int nd, int B, float* const* a,
                      const Shape* sh, float* g, float* const* gbuf, int& pp, bool need_input_grad, float** gout,
-                     const Scratch& sc, hipStream_t s, int stack_id = 0) {
-  bool g_is_pre = false;
+                     const Scratch& sc, hipStream_t s, int stack_id = 0, bool g_is_pre0 = false) {
+  bool g_is_pre = g_is_pre0;                           // g already carries the last op's activation derivative
   const bool c1pool = stack_id == 0 && sc.code && !need_input_grad && c1pool_fusable(ops, n, nd, sh[0]);
   for (int i = n - 1; i >= 0; --i) {
     if (c1pool && i == 1) {                            // g = dL/d(a[2]): the fused backward of ops 1 and 0

@@ -52,6 +52,7 @@ struct Layout {
   float* ccol; int64_t cF; float* cbn; int cbn_maxC;
   pvcs::WtPlan cwtp; char* cwt;                            // the step's tiled conv-encoder weights
   unsigned char* ccode;                                    // max-pool winners of the fused first block
+  float* chead_wt;                                         // the head's weight re-indexed channels-last (null: GEMM path)
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
@@ -102,7 +103,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
   const int n_enc = (L.enc_conv || L.enc_ext) ? 0 : p->n_enc;
   pvcs::Needs cnd;
-  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr;
+  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr; L.chead_wt = nullptr;
   if (L.enc_conv) {
     L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
     if ((int64_t)L.ces[0].H * L.ces[0].W == p->n_pix && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
@@ -111,6 +112,10 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       const pvcs::Shape& fe = L.ces[p->n_enc_ops];
       L.cF = (int64_t)fe.H * fe.W * fe.C;
       L.cfeat = c.take(B * L.cF);
+      if (pv_convhead_supported(L.cF, p->head.out_dim)) {
+        L.chead_wt = c.take((int64_t)p->head.out_dim * L.cF);
+        pvcs::upd(cnd.scratch, pv_convhead_ws((int)B, L.cF, p->head.out_dim));
+      }
       L.cg[0] = c.take(cnd.maxact); L.cg[1] = c.take(cnd.maxact);
       L.ccol = c.take(cnd.maxcol);
       pvcs::wt_layout(p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, false, L.cwtp);
@@ -313,9 +318,16 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
   sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // (both orientations: the backward of the same step reuses them)
   sc.code = L.ccode;
-  PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s));
+  const pvcs::Shape& fe0 = L.ces[p->n_enc_ops];
+  const bool hfused = pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
+  const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.chead_wt, p->head.out_dim, fe0.C, (int64_t)fe0.H * fe0.W);
+  PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s, &he,
+                       hfused ? 1 : 0));
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
   const pvcs::Shape& fe = L.ces[p->n_enc_ops];
+  if (hfused)      // (the weight is re-indexed channels-last, not the feature map: pv_convhead.hip)
+    return pv_convhead_fwd(L.cea[p->n_enc_ops], L.chead_wt, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr, L.head,
+                           (int)B, L.cF, p->head.out_dim, L.scratch, L.scratch_bytes, s);
   PV_TRY(pv_nsc_to_ncs(L.cea[p->n_enc_ops], L.cfeat, B, fe.C, (int64_t)fe.H * fe.W, s));
   return linear_fwd(L.cfeat, L.cF, p->params + p->head.w_off, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr,
                     L.head, nullptr, p->head.out_dim, B, L.cF, p->head.out_dim, PV_ACT_NONE, L.scratch, L.scratch_bytes, s);
@@ -423,12 +435,23 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
   }
   if (L.enc_conv) {
     // head (features2latent.fc_latent) backward, then the op sequence in reverse; the other small wgrads ride along
-    PV_TRY(linear_wgrad(L.dhead, hd.out_dim, L.cfeat, L.cF, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B, L.cF,
-                        hd.out_dim, ws, wsb, s));
-    PV_TRY(linear_dgrad(L.dhead, hd.out_dim, p->params + hd.w_off, L.cg[0], L.cF, nullptr, nullptr, 0, PV_ACT_NONE, B,
-                        L.cF, hd.out_dim, ws, wsb, s));
     const pvcs::Shape& fe = L.ces[p->n_enc_ops];
-    PV_TRY(pv_ncs_to_nsc(L.cg[0], L.cg[1], B, fe.C, (int64_t)fe.H * fe.W, s));
+    const pv_op& last = p->enc_ops[p->n_enc_ops - 1];
+    bool g_is_pre = false;
+    if (pv_convhead_supported(L.cF, hd.out_dim) && L.chead_wt) {
+      // dL/d(features) straight in channels-last order into cg[1], the last convolution's activation derivative folded in
+      g_is_pre = last.kind == PV_OP_CONV && last.act != PV_ACT_GELU;
+      PV_TRY(pv_convhead_wgrad(L.dhead, L.cea[p->n_enc_ops], G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, (int)B,
+                               fe.H * fe.W, fe.C, hd.out_dim, ws, wsb, s));
+      PV_TRY(pv_convhead_bwd(L.dhead, L.chead_wt, L.cea[p->n_enc_ops], g_is_pre ? last.act : PV_ACT_NONE, L.cg[1], (int)B, L.cF,
+                             hd.out_dim, s));
+    } else {
+      PV_TRY(linear_wgrad(L.dhead, hd.out_dim, L.cfeat, L.cF, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B, L.cF,
+                          hd.out_dim, ws, wsb, s));
+      PV_TRY(linear_dgrad(L.dhead, hd.out_dim, p->params + hd.w_off, L.cg[0], L.cF, nullptr, nullptr, 0, PV_ACT_NONE, B,
+                          L.cF, hd.out_dim, ws, wsb, s));
+      PV_TRY(pv_ncs_to_nsc(L.cg[0], L.cg[1], B, fe.C, (int64_t)fe.H * fe.W, s));
+    }
     float* a[PV_MAX_OPS + 1];
     a[0] = const_cast<float*>(p->x);
     for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
@@ -437,7 +460,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     sc.code = L.ccode;
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
-                           nullptr, sc, s));
+                           nullptr, sc, s, 0, g_is_pre));
     if (fin) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
     for (int i = 0; i < n_extra; i += 4) PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s));
     return 0;

@@ -32,6 +32,7 @@ struct VLayout {
   float* g[2];                                         // gradient ping-pong (largest activation)
   pvcs::Scratch sc;                                    // im2col / dcol scratch + GEMM split-K scratch
   pvcs::WtPlan wtp; char* wt;                          // the step's tiled conv weights (both stacks, both orientations)
+  float* head_wt;                                      // features2latent's weight re-indexed channels-last (null: GEMM path)
   int64_t F;                                           // flattened feature size C*S of the encoder output
   int64_t total;
 };
@@ -62,6 +63,8 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   const Shape& fe = L.es[p->n_enc_ops];
   L.F = (int64_t)fe.H * fe.W * fe.C;
   if (p->head.in_dim != L.F) return false;
+  L.head_wt = pv_convhead_supported(L.F, 2 * p->z_dim) ? c.take(2 * z * L.F) : nullptr;
+  if (L.head_wt || !base) pvcs::upd(nd.scratch, pv_convhead_ws((int)B, L.F, 2 * p->z_dim));
   L.feat = c.take(B * L.F);
   L.head = c.take(B * 2 * z); L.dhead = c.take(B * 2 * z);
   L.z = c.take(B * z); L.z_scale = c.take(B * z); L.dzc = c.take(B * z);
@@ -101,7 +104,12 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
 
 // tile the conv weights the coming launches need: stack 0 / 1 / both, with or without the input-gradient orientation
 int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_dgrad, hipStream_t s) {
-  if (enc) PV_TRY(pvcs::wt_prep(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, L.wtp, L.wt, with_dgrad, s));
+  if (enc) {
+    const Shape& fe = L.es[p->n_enc_ops];
+    const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.head_wt, 2 * p->z_dim, fe.C, (int64_t)fe.H * fe.W);
+    PV_TRY(pvcs::wt_prep(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, L.wtp, L.wt, with_dgrad, s, &he,
+                         L.head_wt ? 1 : 0));
+  }
   if (dec) PV_TRY(pvcs::wt_prep(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, s));
   return 0;
 }
@@ -115,10 +123,15 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
   L.ea[0] = const_cast<float*>(x);
   PV_TRY(pvcs::stack_fwd(p->params, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, L.sc, s));
   const Shape& fe = L.es[p->n_enc_ops];
-  // torch flattens (C, spatial): features2latent sees channels-first order
-  PV_TRY(pv_nsc_to_ncs(L.ea[p->n_enc_ops], L.feat, B, fe.C, (int64_t)fe.H * fe.W, s));
-  PV_TRY(linear_fwd(L.feat, L.F, p->params + p->head.w_off, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr,
-                    L.head, nullptr, 2 * p->z_dim, B, L.F, 2 * p->z_dim, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
+  // torch flattens (C, spatial): features2latent sees channels-first order — the weight is re-indexed, not the features
+  if (L.head_wt) {
+    PV_TRY(pv_convhead_fwd(L.ea[p->n_enc_ops], L.head_wt, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr, L.head,
+                           (int)B, L.F, 2 * p->z_dim, L.sc.ws, L.sc.ws_bytes, s));
+  } else {
+    PV_TRY(pv_nsc_to_ncs(L.ea[p->n_enc_ops], L.feat, B, fe.C, (int64_t)fe.H * fe.W, s));
+    PV_TRY(linear_fwd(L.feat, L.F, p->params + p->head.w_off, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr,
+                      L.head, nullptr, 2 * p->z_dim, B, L.F, 2 * p->z_dim, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
+  }
   PvHead h{};
   h.head = L.head; h.eps = with_kl ? p->eps : L.z_scale; h.z = L.z; h.z_scale = L.z_scale;
   h.z_loc_out = z_loc_out; h.z_scale_out = z_scale_out;
@@ -188,19 +201,33 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   hb.dzc = L.dzc; hb.ldzc = z; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps; hb.head = L.head; hb.dhead = L.dhead;
   hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = 0; hb.beta = p->beta;
   PV_TRY(pv_head_bwd(hb, s));
-  PV_TRY(linear_wgrad(L.dhead, 2 * z, L.feat, L.F, p->grads + p->head.w_off,
-                      p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, B, L.F, 2 * z, L.sc.ws, L.sc.ws_bytes, s));
-  float* dfeat = L.g[pp];
-  PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + p->head.w_off, dfeat, L.F, nullptr, nullptr, 0, PV_ACT_NONE, B, L.F,
-                      2 * z, L.sc.ws, L.sc.ws_bytes, s));
-  pp ^= 1;
   const Shape& fe = L.es[p->n_enc_ops];
-  g = L.g[pp];
-  PV_TRY(pv_ncs_to_nsc(dfeat, g, B, fe.C, (int64_t)fe.H * fe.W, s));
-  pp ^= 1;
+  const pv_op& last = p->enc[p->n_enc_ops - 1];
+  bool g_is_pre = false;
+  if (L.head_wt) {
+    // dL/d(features) straight in channels-last order, with the last convolution's activation derivative folded in
+    const bool fold = last.kind == PV_OP_CONV && last.act != PV_ACT_GELU;
+    PV_TRY(pv_convhead_wgrad(L.dhead, L.ea[p->n_enc_ops], p->grads + p->head.w_off,
+                             p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, (int)B, fe.H * fe.W, fe.C, (int)(2 * z),
+                             L.sc.ws, L.sc.ws_bytes, s));
+    g = L.g[pp];
+    PV_TRY(pv_convhead_bwd(L.dhead, L.head_wt, L.ea[p->n_enc_ops], fold ? last.act : PV_ACT_NONE, g, (int)B, L.F, (int)(2 * z), s));
+    pp ^= 1;
+    g_is_pre = fold;
+  } else {
+    PV_TRY(linear_wgrad(L.dhead, 2 * z, L.feat, L.F, p->grads + p->head.w_off,
+                        p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, B, L.F, 2 * z, L.sc.ws, L.sc.ws_bytes, s));
+    float* dfeat = L.g[pp];
+    PV_TRY(linear_dgrad(L.dhead, 2 * z, p->params + p->head.w_off, dfeat, L.F, nullptr, nullptr, 0, PV_ACT_NONE, B, L.F,
+                        2 * z, L.sc.ws, L.sc.ws_bytes, s));
+    pp ^= 1;
+    g = L.g[pp];
+    PV_TRY(pv_ncs_to_nsc(dfeat, g, B, fe.C, (int64_t)fe.H * fe.W, s));
+    pp ^= 1;
+  }
   // ---- encoder ops in reverse (no input gradient for the first one) ----
   return pvcs::stack_bwd(p->params, p->grads, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, g, L.g, pp, false,
-                         nullptr, L.sc, s);
+                         nullptr, L.sc, s, 0, g_is_pre);
 }
 
 extern "C" int pv_ved_encode(const pv_ved_plan* p, float* z_loc, float* z_scale, void* stream) {
