@@ -189,3 +189,30 @@ int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, 
   PV_LAUNCH_CHECK();
   return 0;
 }
+
+// test hooks (tests/test_gpu_conv_kernels.py): the fused first block and the conv head on caller-provided tensors
+extern "C" int pv_debug_c1_convpool(int bwd, const float* x, int B, int H, int W, const float* w, const float* bias, int Cout,
+                                    int act, float* y, unsigned char* code, const float* g, float* dw, float* db, void* ws,
+                                    long long ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!bwd) return pv_c1_convpool_fwd(x, B, H, W, w, bias, Cout, act, y, code, s);
+  return pv_c1_convpool_bwd(g, y, code, x, B, H, W, Cout, act, dw, db, ws, ws_bytes, s);
+}
+extern "C" long long pv_debug_c1_convpool_ws(int B, int H, int W, int Cout) { return pv_c1_convpool_ws(B, H, W, Cout); }
+
+extern "C" long long pv_debug_convhead_ws(int B, long long F, int out) { return pv_convhead_ws(B, F, out); }
+// what 0: wt = re-indexed w; 1: head = forward(a); 2: g = backward(dhead, y = a, act); 3: dw, db = wgrad(dhead, a)
+extern "C" int pv_debug_convhead(int what, const float* w, float* wt, const float* bias, const float* a, float* head,
+                                 const float* dhead, float* g, float* dw, float* db, int B, int S, int C, int out, int act, void* ws,
+                                 long long ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t F = (int64_t)S * C;
+  if (what == 0) {
+    PvWprepEntry e{};
+    e.w = w; e.dst = reinterpret_cast<char*>(wt); e.Co = out; e.Ci = C; e.KK = S; e.kind = 4;
+    return pv_conv_wprep_table(&e, 1, s);
+  }
+  if (what == 1) return pv_convhead_fwd(a, wt, bias, head, B, F, out, ws, ws_bytes, s);
+  if (what == 2) return pv_convhead_bwd(dhead, wt, a, act, g, B, F, out, s);
+  return pv_convhead_wgrad(dhead, a, dw, db, B, S, C, out, ws, ws_bytes, s);
+}
