@@ -570,67 +570,85 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy)
     b_off[dy] = (q + dy) * RP + (r >> 2) * PP + (r & 3) * 8 + wci * (NCIB * 32);
+  // staging: a thread's fp32 pieces of a tile — 4 of the dY tile (pixel n, channels 4 c4 .. +3), PK of the 10x10 halo window
+  // of the input (CIW channels) — are fetched into registers, split into the NS planes and written to LDS.  With 32-channel
+  // workgroups (PRE) the NEXT tile's pieces are fetched under the current tile's MFMAs.
+  constexpr int PPT = CIW / 4;                       // float4 pieces per patch pixel
+  constexpr int PK = (100 * PPT + 255) / 256;
+  constexpr bool PRE = NCIB == 1;
+  f32x4 vd[4], vp[PK];
+  // per-thread constants of its pieces: position in the tile / halo window, LDS offset (the same for every tile)
+  int dn_y[4], dn_x[4], d_lds[4], pp_r[PK], pp_c[PK], p_lds[PK];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = tid + 256 * k, n = e >> 4, c4 = e & 15;
+    dn_y[k] = n >> 3; dn_x[k] = n & 7;
+    d_lds[k] = (n >> 3) * SW_DYL + (n & 7) * SW_DYP + c4 * 8;
+  }
+#pragma unroll
+  for (int k = 0; k < PK; ++k) {
+    const int e = tid + 256 * k, pix = e / PPT, f = e - pix * PPT;
+    const int row = pix / 10, col = pix - row * 10;
+    pp_r[k] = e < 100 * PPT ? row : 1 << 20;         // (pieces past the window: never in the image)
+    pp_c[k] = col;
+    p_lds[k] = row * RP + col * PP + f * 8;
+  }
+  const int dco = cot * 64 + 4 * (tid & 15), pcf = cit * CIW + 4 * (tid % PPT);
+  const bool dvec = dco + 3 < p.Cout && (p.Cout & 3) == 0;
+  // the tile to fetch next, advanced incrementally (no divisions in the loop)
+  int ftx, fty, fb;
+  {
+    int t = (int)t_lo;
+    ftx = t % p.tiles_x; t /= p.tiles_x;
+    fty = t % p.tiles_y; fb = t / p.tiles_y;
+  }
+  auto fetch = [&]() {
+    const int y0 = fty * 8, x0 = ftx * 8;
+    const float* dy_b = p.dy + (int64_t)fb * p.H * p.W * p.Cout + dco;
+    const float* in_b = p.in + (int64_t)fb * p.H * p.W * p.Cin + pcf;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = y0 + dn_y[k], x = x0 + dn_x[k];
+      vd[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (y < p.H && x < p.W) {
+        const float* src = dy_b + ((int64_t)y * p.W + x) * p.Cout;
+        if (dvec) vd[k] = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (dco + i < p.Cout) vd[k][i] = src[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+      const int y = y0 - 1 + pp_r[k], x = x0 - 1 + pp_c[k];
+      vp[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W) vp[k] = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin);
+    }
+    if (++ftx == p.tiles_x) { ftx = 0; if (++fty == p.tiles_y) { fty = 0; ++fb; } }
+  };
+  if (PRE && t_lo < t_hi) fetch();
   for (int64_t tt = t_lo; tt < t_hi; ++tt) {
-    int t = (int)tt;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
-    const int y0 = ty * 8, x0 = tx * 8;
-    __syncthreads();
-    {                                                // dY tile: pixel n, channels 4*c4 .. +3 -> NS planes
-      f32x4 v[4];
+    __syncthreads();                                 // the previous tile's fragment reads are done
+    if (!PRE) fetch();
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = tid + 256 * k, n = e >> 4, c4 = e & 15;
-        const int y = y0 + (n >> 3), x = x0 + (n & 7);
-        const int co = cot * 64 + 4 * c4;
-        v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (y < p.H && x < p.W) {
-          const float* src = p.dy + (((int64_t)b * p.H + y) * p.W + x) * p.Cout + co;
-          if (co + 3 < p.Cout && (p.Cout & 3) == 0) v[k] = *reinterpret_cast<const f32x4*>(src);
-          else {
+    for (int k = 0; k < 4; ++k) {
+      u32x2 pl[NS];
+      sp_split4<NS>(vd[k], pl);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (co + i < p.Cout) v[k][i] = src[i];
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = tid + 256 * k, n = e >> 4, c4 = e & 15;
-        u32x2 pl[NS];
-        sp_split4<NS>(v[k], pl);
-        const int o = (n >> 3) * SW_DYL + (n & 7) * SW_DYP + c4 * 8;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(dyl + j * SW_DYPLANE + o) = pl[j];
-      }
+      for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(dyl + j * SW_DYPLANE + d_lds[k]) = pl[j];
     }
-    {                                                // patch: pixel (row, col) of the 10x10 halo window, CIW channels
-      constexpr int PPT = CIW / 4;                   // float4 pieces per pixel
-      constexpr int PK = (100 * PPT + 255) / 256;
-      const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin + cit * CIW;
-      f32x4 v[PK];
 #pragma unroll
-      for (int k = 0; k < PK; ++k) {
-        const int e = tid + 256 * k, pix = e / PPT, f = e - pix * PPT;
-        const int row = pix / 10, col = pix - row * 10;
-        const int y = y0 - 1 + row, x = x0 - 1 + col;
-        v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (e < 100 * PPT && y >= 0 && y < p.H && x >= 0 && x < p.W)
-          v[k] = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + 4 * f);
-      }
+    for (int k = 0; k < PK; ++k) {
+      u32x2 pl[NS];
+      sp_split4<NS>(vp[k], pl);
+      if (pp_r[k] < (1 << 20)) {
 #pragma unroll
-      for (int k = 0; k < PK; ++k) {
-        const int e = tid + 256 * k, pix = e / PPT, f = e - pix * PPT;
-        const int row = pix / 10, col = pix - row * 10;
-        u32x2 pl[NS];
-        sp_split4<NS>(v[k], pl);
-        const int o = row * RP + col * PP + f * 8;
-        if (e < 100 * PPT) {
-#pragma unroll
-          for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(patch + j * PPLANE + o) = pl[j];
-        }
+        for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(patch + j * PPLANE + p_lds[k]) = pl[j];
       }
     }
     __syncthreads();
+    if (PRE && tt + 1 < t_hi) fetch();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                 // 32 pixels: lane group q <-> tile line 4 ks + q, k slot i <-> x = i
       sbf8 a[2][NS];
