@@ -327,14 +327,20 @@ def measure(args, name, cfg, fused, ctx):
            "loss_per_image_last_step": losses[-1].item() / (B * world)}
     step_tf = out["value"] / world * cfg["flops_per_image"] / 1e12
     if ved:
+        # both precisions run the 2-D k3 convolutions on v_mfma_f32_16x16x32_bf16 with split operands (pv_conv_sp.hip):
+        # three exact bf16 pieces and six products per multiply-add (fp32-class) or two rounded pieces and three products
         bf = fused == 3
-        peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
-        out.update(dtype="bf16x3" if bf else "f32", path="conv-bf16x3" if bf else "conv-f32",
-                   arith=("bf16 split-precision MFMA in the k3 convolutions (fp32 accumulate)" if bf
-                          else "fp32 (f32-input MFMA)"),
+        prods = 3 if bf else 6
+        peak = MFMA_BF16_PEAK_TFLOPS
+        out.update(dtype="bf16x3" if bf else "bf16x6", path="conv-bf16x3" if bf else "conv-bf16x6",
+                   arith=("2-D k3 convolutions on the bf16 MFMA, operands split into two rounded bf16 pieces, three products "
+                          "(fp32 accumulate); fp32 elsewhere" if bf else
+                          "2-D k3 convolutions on the bf16 MFMA, operands split EXACTLY into three bf16 pieces, six products "
+                          "(fp32 accumulate): fp32-class; 1-D convolutions on the f32-input MFMA; fp32 elsewhere"),
                    roofline={"bound": "mfma", "scope": "step", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s",
-                             "frac": step_tf / peak, "traffic": None,
-                             "kernel": "whole step (direct conv fwd/dgrad/wgrad kernels dominate; see profiles/)",
+                             "frac": step_tf / peak, "traffic": None, "mfma_products_per_mac": prods,
+                             "frac_of_split_operand_peak": step_tf * prods / peak,
+                             "kernel": "whole step (pv_conv3_sp_kernel / pv_conv3_sp_wgrad_kernel dominate; see profiles/)",
                              "kernel_ms": out["ms_per_step"], "flops_per_launch": cfg["flops_per_image"] * B})
         return out
     mode = fused if eng.uses_fused(B) else 0
