@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 10
+#define PV_ABI_VERSION 11
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -353,6 +353,31 @@ int pv_ved_encode(const pv_ved_plan* plan, float* z_loc, float* z_scale, void* s
 
 /* convDecoderNet.forward (nets/conv.py:95-102): loc (B, out_ch, *out_dim) for z (B, z_dim). */
 int pv_ved_decode(const pv_ved_plan* plan, const float* z, float* loc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * A stand-alone convolutional stack — nets/conv.py:150-262 FeatureExtractor.forward / Upsampler.forward outside a
+ * model — as one forward and one backward call on the same op executor the VED / conv-encoder steps use.
+ * Tensors are in the reference's (torch) layout: x (B, in_ch, *in_dim), out (B, C', *dims').  The forward keeps
+ * every activation in the workspace; the backward must get the SAME plan / workspace, untouched in between. */
+typedef struct pv_convnet_plan {
+  int32_t batch, ndim;                 /* ndim 1 or 2                                                          */
+  int32_t in_ch, in_dim[2];
+  int32_t n_ops;
+  int32_t bn_eval;                     /* batch norm on the running statistics (module.eval())                 */
+  int32_t conv_bf16;                   /* 0: fp32-class, 1: mixed precision in the 2-D k3 convolutions         */
+  int32_t need_dx;                     /* the backward will be asked for dL/dx (set at forward time too)       */
+  pv_op   ops[PV_MAX_OPS];
+  const float* params;                 /* flat buffer the ops' offsets refer to (running statistics included)  */
+  float*  grads;                       /* same layout (backward only)                                          */
+  void*   ws; int64_t ws_bytes;
+} pv_convnet_plan;
+
+int64_t pv_convnet_workspace_bytes(const pv_convnet_plan* plan);
+/* out_shape[0] = channels, [1..ndim] = spatial dims of the stack's output */
+int pv_convnet_out_shape(const pv_convnet_plan* plan, int32_t* out_shape);
+int pv_convnet_forward(const pv_convnet_plan* plan, const float* x, float* out, void* stream);
+/* dout shaped like the forward's out; dx (may be null unless need_dx) shaped like x; parameter gradients in plan->grads */
+int pv_convnet_backward(const pv_convnet_plan* plan, const float* x, const float* dout, float* dx, void* stream);
 
 /* ===================================================================================================
  * Semi-supervised models (models/ssivae.py ssiVAE, models/ss_reg_ivae.py ss_reg_iVAE) trained by

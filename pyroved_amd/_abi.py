@@ -13,7 +13,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 10
+PV_ABI_VERSION = 11
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -91,6 +91,16 @@ class pv_ved_plan(C.Structure):
     ]
 
 
+class pv_convnet_plan(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("ndim", C.c_int32), ("in_ch", C.c_int32), ("in_dim", C.c_int32 * 2),
+        ("n_ops", C.c_int32), ("bn_eval", C.c_int32), ("conv_bf16", C.c_int32), ("need_dx", C.c_int32),
+        ("ops", pv_op * PV_MAX_OPS),
+        ("params", C.c_void_p), ("grads", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+    ]
+
+
 MLP_OUT = {"linear": 0, "softmax": 1}
 SS_TASK = {"classification": 0, "regression": 1}
 
@@ -113,6 +123,10 @@ SIGNATURES = {
     "pv_ved_loss_and_grads": (C.c_int, [C.POINTER(pv_ved_plan), C.c_int, C.c_void_p]),
     "pv_ved_encode": (C.c_int, [C.POINTER(pv_ved_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pv_ved_decode": (C.c_int, [C.POINTER(pv_ved_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_convnet_workspace_bytes": (C.c_int64, [C.POINTER(pv_convnet_plan)]),
+    "pv_convnet_out_shape": (C.c_int, [C.POINTER(pv_convnet_plan), C.POINTER(C.c_int32)]),
+    "pv_convnet_forward": (C.c_int, [C.POINTER(pv_convnet_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_convnet_backward": (C.c_int, [C.POINTER(pv_convnet_plan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pv_ivae_uses_fused": (C.c_int, [C.POINTER(pv_ivae_plan)]),
     "pv_ivae_loss_and_grads": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
     "pv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -3,9 +3,10 @@ Convolutional encoder / decoder modules — host-side mirror of pyroved/nets/con
 
 Same class names, constructor signatures, sub-module names (hence `state_dict` keys) and parameter
 initialisation order as the reference, so checkpoints and seeds interchange.  The modules only *hold*
-parameters and describe the layer sequence: the arithmetic runs in HIP kernels through the C ABI
-(engine_ved.py walks `layer_program()` into a pv_ved_plan); `forward` on GPU tensors goes through the same
-library (no CPU path).
+parameters and describe the layer sequence: the arithmetic runs in HIP kernels through the C ABI (inside a
+model the owning engine walks the layer lists into its plan; a stand-alone FeatureExtractor / Upsampler called on
+a float32 CUDA tensor runs as one autograd Function over pv_convnet_forward / pv_convnet_backward, ops.conv_stack).
+3-D stacks and CPU tensors compose the torch modules, as the reference does.
 
 Scope of this build: 1-D and 2-D data, kernel 3 / stride 1 / padding 1 convolutions, 2x max-pooling,
 2x upsampling (nearest — the reference's own fallback for 1-D decoders, nets/conv.py:126-130 — or bilinear in 2-D),
@@ -75,6 +76,17 @@ def _conv_stack(ndim, input_channels, conv_filters, kernel_size, stride, padding
     return layers, ch_in
 
 
+def _stack_forward(stack, x: torch.Tensor) -> torch.Tensor:
+    """forward of a stand-alone FeatureExtractor / Upsampler (conv.py:195-213, 261-262).  A float32 CUDA input of a 1-D / 2-D
+    stack runs as ONE autograd Function over the library's conv-stack executor (ops.conv_stack: the kernels the VED and
+    conv-encoder steps use, differentiable in x and every parameter); 3-D data, CPU tensors and layer settings the
+    executor does not cover compose the torch modules as the reference does."""
+    from .. import ops
+    if ops.conv_stack_supported(stack, x):
+        return ops.conv_stack(stack, x)
+    return stack.layers(x)
+
+
 class FeatureExtractor(nn.Sequential):
     """Convolutional feature extractor (pyroved/nets/conv.py:150-213)."""
     def __init__(self, ndim: int, input_channels: int = 1, conv_filters: List[int] = None,
@@ -94,6 +106,9 @@ class FeatureExtractor(nn.Sequential):
                                 activation, tail)
         self.layers = nn.Sequential(*layers)
         self.ndim, self.activation, self.batchnorm = ndim, activation, batchnorm
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _stack_forward(self, x)
 
 
 class Upsampler(nn.Sequential):
@@ -115,6 +130,9 @@ class Upsampler(nn.Sequential):
         layers.append(get_conv(ndim)(ch, output_channels, 1, 1, 0))
         self.layers = nn.Sequential(*layers)
         self.ndim, self.activation, self.batchnorm = ndim, activation, batchnorm
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _stack_forward(self, x)
 
 
 class features_to_latent(nn.Module):

@@ -85,3 +85,114 @@ def linear_act(x: torch.Tensor, weight: torch.Tensor, bias, act: str = None) -> 
     b = None if bias is None else bias.contiguous()
     y = _LinearAct.apply(x2, w, b, act)
     return y.reshape(*lead, weight.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A convolutional stack (nets.conv.FeatureExtractor / Upsampler used OUTSIDE a model: the reference's
+# nets/conv.py:150-262 forward) as one autograd Function over pv_convnet_forward / pv_convnet_backward — the same op
+# executor and kernels the VED and conv-encoder steps run (csrc/pv_convstack.h).
+
+def _stack_tensors(ops_list):
+    """The stack's parameter tensors (and batch-norm running statistics) in plan order, with their keys."""
+    out = []
+    for kind, mod, _, key in ops_list:
+        if kind == "conv":
+            out.append((key + ".weight", mod.weight, True))
+            if mod.bias is not None:
+                out.append((key + ".bias", mod.bias, True))
+        elif kind == "batchnorm":
+            out.append((key + ".weight", mod.weight, True))
+            out.append((key + ".bias", mod.bias, True))
+            out.append((key + ".running_mean", mod.running_mean, False))
+            out.append((key + ".running_var", mod.running_var, False))
+    return out
+
+
+def conv_stack_supported(stack, x: torch.Tensor) -> bool:
+    """CUDA fp32 input of a 1-D / 2-D stack whose layers the op executor covers (kernel 3 / 1, stride 1, 2x pooling,
+    2x nearest / bilinear upsampling, the reference's batch norm) — anything else stays on the modules' own forward."""
+    from ._convplan import conv_ops, UnsupportedModel
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and stack.ndim in (1, 2)
+            and x.dim() == stack.ndim + 2 and x.shape[0] > 0):
+        return False
+    try:
+        conv_ops(stack.layers, stack.activation, "L")
+    except UnsupportedModel:
+        return False
+    return True
+
+
+class _ConvStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stack, *tensors):
+        import ctypes as C
+        from ._convplan import conv_ops, fill_ops, bn_modules
+        ops_list = conv_ops(stack.layers, stack.activation, "L")
+        named = _stack_tensors(ops_list)
+        assert len(named) == len(tensors)
+        layout, off = {}, 0
+        for (key, t, _), _t in zip(named, tensors):
+            layout[key] = off
+            off += (t.numel() + 63) // 64 * 64                       # (16-byte aligned pieces for the vector loads)
+        flat = torch.zeros(max(off, 1), device=x.device, dtype=torch.float32)
+        for (key, t, _), tt_ in zip(named, tensors):
+            flat[layout[key]:layout[key] + t.numel()].copy_(tt_.detach().reshape(-1))
+        p = _abi.pv_convnet_plan()
+        p.batch, p.ndim, p.in_ch = x.shape[0], stack.ndim, x.shape[1]
+        for i, d in enumerate(x.shape[2:]):
+            p.in_dim[i] = d
+        p.n_ops = fill_ops(p.ops, ops_list, layout)
+        p.bn_eval = int(not stack.training)
+        p.conv_bf16 = 0
+        p.need_dx = int(x.requires_grad)
+        L = _abi.lib()
+        with _abi.device_of(x.device):
+            need = L.pv_convnet_workspace_bytes(C.byref(p))
+            if need < 0:
+                raise _abi.PvError("pyroved_amd: unsupported conv stack (pv_convnet_workspace_bytes -> %d)" % need)
+            shp = (C.c_int32 * 3)()
+            _abi.check(L.pv_convnet_out_shape(C.byref(p), shp), "pv_convnet_out_shape")
+            ws = torch.empty(int(need), device=x.device, dtype=torch.uint8)
+            xc = x.detach().contiguous()
+            out = torch.empty((x.shape[0], shp[0]) + tuple(shp[1:1 + stack.ndim]), device=x.device, dtype=torch.float32)
+            p.params, p.ws, p.ws_bytes = flat.data_ptr(), ws.data_ptr(), ws.numel()
+            _abi.check(L.pv_convnet_forward(C.byref(p), _abi.ptr(xc), _abi.ptr(out), _abi.current_stream()), "pv_convnet_forward")
+        bns = bn_modules(ops_list)
+        if bns and stack.training:                                   # the kernels updated the running statistics in `flat`
+            with torch.no_grad():
+                for (key, t, is_param) in named:
+                    if not is_param:
+                        t.copy_(flat[layout[key]:layout[key] + t.numel()].view_as(t))
+                for b_ in bns:
+                    b_.num_batches_tracked += 1
+        ctx.plan, ctx.named, ctx.layout = p, named, layout
+        ctx.keep = (xc, flat, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes as C
+        p = ctx.plan
+        xc, flat, ws = ctx.keep
+        grads = torch.zeros_like(flat)
+        dx = torch.empty_like(xc) if (ctx.needs_input_grad[0] and p.need_dx) else None
+        p.grads = grads.data_ptr()
+        dout = dout.contiguous()
+        with _abi.device_of(xc.device):
+            _abi.check(_abi.lib().pv_convnet_backward(C.byref(p), _abi.ptr(xc), _abi.ptr(dout), _abi.ptr(dx), _abi.current_stream()),
+                       "pv_convnet_backward")
+        outs = []
+        for k, (key, t, is_param) in enumerate(ctx.named):
+            if is_param and ctx.needs_input_grad[2 + k]:
+                o = ctx.layout[key]
+                outs.append(grads[o:o + t.numel()].view_as(t).clone())
+            else:
+                outs.append(None)
+        return (dx, None) + tuple(outs)
+
+
+def conv_stack(stack, x: torch.Tensor) -> torch.Tensor:
+    """stack.layers applied to x (B, C, *dims) on the GPU through the library, differentiable in x and the parameters."""
+    from ._convplan import conv_ops
+    named = _stack_tensors(conv_ops(stack.layers, stack.activation, "L"))
+    return _ConvStack.apply(x, stack, *[t for _, t, _ in named])

@@ -180,3 +180,55 @@ def test_conv_head_without_transposes(gpu_device, B, S, Cc, out, act):
     assert rel_l2(gout, dfeat * act_grad_of_output(act, a.double())) < 2e-6
     assert rel_l2(dw, dhead.double().t() @ feat) < 2e-6
     assert rel_l2(db, dhead.double().sum(0)) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stand-alone nets.conv stacks (FeatureExtractor / Upsampler outside a model: the reference's nets/conv.py:150-262 forward)
+# run on the library's conv-stack executor as one autograd Function (ops.conv_stack); reference = the same modules'
+# torch composition in float64 on the CPU.
+STACK_CASES = [
+    ("fe2d_default", dict(kind="fe", ndim=2, in_ch=1, filters=None, bn=False, act="lrelu"), (3, 1, 32, 32), False),
+    ("fe2d_default_dx", dict(kind="fe", ndim=2, in_ch=1, filters=None, bn=False, act="lrelu"), (2, 1, 16, 16), True),
+    ("fe2d_rgb_tanh", dict(kind="fe", ndim=2, in_ch=3, filters=[(8,), (16, 16)], bn=False, act="tanh"), (2, 3, 12, 20), True),
+    ("fe1d", dict(kind="fe", ndim=1, in_ch=2, filters=[(16,), (32, 32)], bn=False, act="lrelu"), (4, 2, 40), True),
+    ("fe2d_bn", dict(kind="fe", ndim=2, in_ch=1, filters=[(8,), (16,)], bn=True, act="lrelu"), (5, 1, 8, 8), False),
+    ("up1d", dict(kind="up", ndim=1, in_ch=32, filters=[(32, 32), (16,)], bn=False, act="lrelu", out_ch=1), (3, 32, 8), True),
+    ("up2d_bilinear", dict(kind="up", ndim=2, in_ch=16, filters=[(16,), (8,)], bn=False, act="tanh", out_ch=2), (2, 16, 4, 4), True),
+]
+
+
+@pytest.mark.parametrize("name,spec,shape,need_dx", STACK_CASES, ids=[c[0] for c in STACK_CASES])
+def test_standalone_conv_stacks_run_on_the_library(gpu_device, name, spec, shape, need_dx):
+    import copy
+    import warnings
+    from pyroved_amd.nets.conv import FeatureExtractor, Upsampler
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(3)
+    if spec["kind"] == "fe":
+        net = FeatureExtractor(spec["ndim"], spec["in_ch"], spec["filters"], batchnorm=spec["bn"], activation=spec["act"])
+    else:
+        net = Upsampler(spec["ndim"], spec["in_ch"], spec["filters"], spec["out_ch"], batchnorm=spec["bn"],
+                        activation=spec["act"], upsampling_mode="bilinear" if spec["ndim"] == 2 else "nearest")
+    ref = copy.deepcopy(net).double()
+    net = net.cuda()
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
+    xg = x.cuda().requires_grad_(need_dx)
+    out = net(xg)
+    assert "ConvStack" in type(out.grad_fn).__name__                 # the library path, not the modules' torch forward
+    xr = x.double().requires_grad_(need_dx)
+    want = ref.layers(xr)
+    assert out.shape == want.shape
+    assert rel_l2(out, want) < 5e-6
+    gout = torch.randn(*want.shape, generator=torch.Generator().manual_seed(2))
+    out.backward(gout.cuda())
+    want.backward(gout.double())
+    for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_l2(p1.grad, p2.grad) < 2e-5, n1
+    if need_dx:
+        assert rel_l2(xg.grad, xr.grad) < 2e-5
+    if spec["bn"]:                                                    # running statistics written back to the modules
+        for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
+            if b1.dtype.is_floating_point:
+                assert rel_l2(b1, b2) < 1e-5, n1
+            else:
+                assert int(b1) == int(b2), n1
