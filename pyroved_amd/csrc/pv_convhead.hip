@@ -77,10 +77,16 @@ __global__ __launch_bounds__(256) void pv_convhead_bwd_kernel(const float* __res
 // partial[split][j][f] (channels-last f) over the samples of the split
 template <int OUT>
 __global__ __launch_bounds__(256) void pv_convhead_wgrad_kernel(const float* __restrict__ dhead, const float* __restrict__ a,
-                                                                float* __restrict__ part, int B, int64_t F, int out, int nsplit) {
+                                                                float* __restrict__ part, float* __restrict__ part_b, int B,
+                                                                int64_t F, int out, int nsplit) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // float4 index along f
   const int split = blockIdx.y;
   const int b_lo = (int)((int64_t)B * split / nsplit), b_hi = (int)((int64_t)B * (split + 1) / nsplit);
+  if (blockIdx.x == 0 && part_b && (int)threadIdx.x < out) {           // db partial of this split (sample order)
+    float v = 0.0f;
+    for (int b = b_lo; b < b_hi; ++b) v += dhead[(int64_t)b * out + threadIdx.x];
+    part_b[(int64_t)split * out + threadIdx.x] = v;
+  }
   if (i >= F / 4) return;
   f32x4 acc[OUT];
 #pragma unroll
@@ -96,40 +102,9 @@ __global__ __launch_bounds__(256) void pv_convhead_wgrad_kernel(const float* __r
     if (j < out) reinterpret_cast<f32x4*>(part + ((int64_t)split * out + j) * F)[i] = acc[j];
 }
 
-// dw[j][c*S + s] = sum_split part[split][j][s*C + c] (split order) through a 32 x 32 LDS tile, so that both the reads
-// (along c) and the writes (along s) are coalesced; the last block row also does db[j] = sum_b dhead[b][j] (sample order)
-__global__ __launch_bounds__(256) void pv_convhead_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int out, int S,
-                                                                       int C, float* __restrict__ dw, const float* __restrict__ dhead,
-                                                                       int B, float* __restrict__ db) {
-  __shared__ float tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
-  const int tcs = (C + 31) / 32, tss = (S + 31) / 32;
-  const int64_t F = (int64_t)S * C, ntiles = (int64_t)out * tss * tcs;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int tc = (int)(t % tcs), ts = (int)((t / tcs) % tss);
-    const int64_t j = t / ((int64_t)tcs * tss);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int s = ts * 32 + ty + 8 * r, c = tc * 32 + tx;
-      float v = 0.0f;
-      if (s < S && c < C)
-        for (int k = 0; k < nsplit; ++k) v += part[((int64_t)k * out + j) * F + (int64_t)s * C + c];
-      tile[ty + 8 * r][tx] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = tc * 32 + ty + 8 * r, s = ts * 32 + tx;
-      if (s < S && c < C) dw[j * F + (int64_t)c * S + s] = tile[tx][ty + 8 * r];
-    }
-  }
-  if (blockIdx.x == 0 && db && (int)threadIdx.x < out) {
-    float v = 0.0f;
-    for (int b = 0; b < B; ++b) v += dhead[(int64_t)b * out + threadIdx.x];
-    db[threadIdx.x] = v;
-  }
-}
+int pv_wgrad_finish_blocks(int64_t nw, int nb);
+extern __global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
+                                                    const float* __restrict__ part_b, int nb, float* __restrict__ out_b);
 
 bool pv_convhead_supported(int64_t F, int out) { return out >= 1 && out <= CH_MAXOUT && F >= 4 && F % 4 == 0; }
 
@@ -140,7 +115,8 @@ static int ch_segs(int B, int64_t F) {               // forward: ~1024 workgroup
   return (int)(n < 1 ? 1 : (n > 16 ? 16 : n));
 }
 int64_t pv_convhead_ws(int B, int64_t F, int out) {
-  const int64_t wg = (int64_t)ch_splits(B) * out * F, fw = (int64_t)B * ch_segs(B, F) * out;
+  // weight gradient: per-split partials (+ bias partials), then their sum in channels-last order before the transposition
+  const int64_t wg = (int64_t)ch_splits(B) * out * (F + 1) + (int64_t)out * F, fw = (int64_t)B * ch_segs(B, F) * out;
   return (wg > fw ? wg : fw) * (int64_t)sizeof(float) + 256;
 }
 
@@ -181,13 +157,16 @@ int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, 
   if (ws_bytes < pv_convhead_ws(B, F, out)) return PV_EWS;
   const int ns = ch_splits(B);
   float* part = reinterpret_cast<float*>(ws);
+  float* part_b = part + (int64_t)ns * out * F;
+  float* sum = part_b + (int64_t)ns * out;           // [out][S][C]
   const dim3 grid((unsigned)((F / 4 + 255) / 256), (unsigned)ns);
-  CH_DISPATCH(pv_convhead_wgrad_kernel, grid, dhead, a, part, B, F, out, ns);
-  int64_t fb = (int64_t)out * ((S + 31) / 32) * ((C + 31) / 32);
-  if (fb > 4096) fb = 4096;
-  hipLaunchKernelGGL(pv_convhead_wgrad_finish_kernel, dim3((unsigned)fb), dim3(256), 0, s, part, ns, out, S, C, dw, dhead, B, db);
+  CH_DISPATCH(pv_convhead_wgrad_kernel, grid, dhead, a, part, db ? part_b : nullptr, B, F, out, ns);
+  // partials summed in split order (channels-last), then [out][S][C] -> the Linear's [out][C*S] by the tiled transpose
+  const int64_t nw = (int64_t)out * F;
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(pv_wgrad_finish_blocks(nw, db ? out : 0)), dim3(256), 0, s, part, ns, nw, sum,
+                     db ? part_b : nullptr, out, db);
   PV_LAUNCH_CHECK();
-  return 0;
+  return pv_nsc_to_ncs(sum, dw, out, C, S, s);
 }
 
 // test hooks (tests/test_gpu_conv_kernels.py): the fused first block and the conv head on caller-provided tensors
