@@ -72,25 +72,49 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
     const int n = wm * 32 + pb * 16 + r;
     pidx[pb] = p.nd == 2 ? (n >> 3) * PW + (n & 7) : n;
   }
+  // staging through registers, one stage ahead: the next chunk's patch pieces (<= 2 per thread) and the next tap group's
+  // weights (3 per thread) are in flight while the current stage's MFMAs run — these layers are small (a 1-D decoder
+  // layer is 0.4 GFLOP) and their time is the serial chain of stages, not FLOPs
+  constexpr int PKD = 2;                              // ceil(100 * 4 / 256) (2-D), ceil(66 * 4 / 256) (1-D)
+  int pg[PKD], pl_[PKD];                              // element offset of the piece in the image (-1: zero), LDS float offset
+#pragma unroll
+  for (int k = 0; k < PKD; ++k) {
+    const int e = tid + 256 * k, pix = e >> 2, f4 = e & 3;
+    const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
+    const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
+    pl_[k] = e < NPIX * 4 ? pix * CD_KC + 4 * f4 : -1;
+    pg[k] = (e < NPIX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (y * p.W + x) * p.Cin + 4 * f4 : -1;
+  }
+  f32x4 pv[PKD], wv[3];
+  const int ngrp = KK / TG;                           // weight stages per chunk
+#define CD_FETCH_P(CH)                                                                                               \
+  _Pragma("unroll") for (int k = 0; k < PKD; ++k) {                                                                  \
+    pv[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                                                                           \
+    if (pg[k] >= 0) pv[k] = *reinterpret_cast<const f32x4*>(in_b + pg[k] + (CH) * CD_KC);                            \
+  }
+#define CD_FETCH_W(STAGE)                                                                                            \
+  {                                                                                                                  \
+    const f32x4* src_ = reinterpret_cast<const f32x4*>(p.wt + ((int64_t)cot * nch * KK + (int64_t)(STAGE) * TG) * CD_TN * CD_KC); \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) wv[k] = src_[tid + 256 * k];                                       \
+  }
+  CD_FETCH_P(0);
+  CD_FETCH_W(0);
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();                                 // the previous chunk's reads are done
-    for (int e = tid; e < NPIX * 4; e += 256) {
-      const int pix = e >> 2, f4 = e & 3;
-      const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
-      const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-        v = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + ch * CD_KC + 4 * f4);
-      *reinterpret_cast<f32x4*>(patch + pix * CD_KC + 4 * f4) = v;
-    }
-    for (int tg = 0; tg < KK; tg += TG) {
-    if (tg > 0) __syncthreads();                     // the previous tap group's reads of the weights are done
-    {
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.wt + (((int64_t)cot * nch + ch) * KK + tg) * CD_TN * CD_KC);
-      f32x4* dst = reinterpret_cast<f32x4*>(wl);
-      for (int e = tid; e < TG * CD_TN * CD_KC / 4; e += 256) dst[e] = src[e];
-    }
+#pragma unroll
+    for (int k = 0; k < PKD; ++k)
+      if (pl_[k] >= 0) *reinterpret_cast<f32x4*>(patch + pl_[k]) = pv[k];
+    for (int g = 0; g < ngrp; ++g) {
+    const int tg = g * TG;
+    if (g > 0) __syncthreads();                      // the previous tap group's reads of the weights are done
+#pragma unroll
+    for (int k = 0; k < 3; ++k) reinterpret_cast<f32x4*>(wl)[tid + 256 * k] = wv[k];
     __syncthreads();
+    {
+      const int stage = ch * ngrp + g;
+      if (stage + 1 < nch * ngrp) CD_FETCH_W(stage + 1);
+      if (g + 1 == ngrp && ch + 1 < nch) CD_FETCH_P(ch + 1);
+    }
 #pragma unroll
     for (int tt = 0; tt < TG; ++tt) {
       const int tap = tg + tt;
