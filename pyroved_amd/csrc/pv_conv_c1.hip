@@ -115,7 +115,7 @@ struct C1PoolBwd {
 
 // A workgroup takes lpw consecutive pooled lines: the 4 input lines under each (with a zero halo) are staged in LDS in
 // one go, then thread (channel, pixel group) walks the pooled pixels: g / y / code are one coalesced load across the
-// channel lanes, the 4x4 input window comes out of LDS (the same address for every channel lane).
+// channel lanes, the 3x3 input window under the winning position comes out of LDS at per-lane addresses.
 __global__ __launch_bounds__(256) void pv_c1_convpool_bwd_kernel(C1PoolBwd p) {
   extern __shared__ float xs[];                       // [lpw][4][W + 2], column index = image column + 1
   __shared__ float sm[256][10];
@@ -146,18 +146,11 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_bwd_kernel(C1PoolBwd p) {
       const int64_t o = base + (int64_t)px * p.C;
       const float dv = msk * p.g[o] * pv_act_grad(p.y[o], 0.0f, p.act);
       const int k = p.code[o];
-      float xw[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xw[r][c] = xl[r * WS + 2 * px + c];
+      // the 3x3 input window under the WINNING position (k >> 1, k & 1) of this pooled value: per-lane LDS addresses
+      const float* xp = xl + (k >> 1) * WS + 2 * px + (k & 1);
       accb += dv;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const float dk = k == kk ? dv : 0.0f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] += dk * xw[(kk >> 1) + t / 3][(kk & 1) + t % 3];
-      }
+      for (int t = 0; t < 9; ++t) acc[t] += dv * xp[(t / 3) * WS + t % 3];
     }
   }
 #pragma unroll
