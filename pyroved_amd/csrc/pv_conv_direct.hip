@@ -555,32 +555,63 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_bf16_kernel(ConvD p) {
     const int n = wm * 32 + pb * 16 + r;
     pidx[pb] = p.nd == 2 ? (n >> 3) * PW + (n & 7) : n;
   }
+  // staging through registers one stage ahead, as in pv_conv3_direct_kernel: the next chunk's patch pieces (<= 4 per
+  // thread) and the next tap group's weights (3 + 3 16-byte pieces) are in flight under the current stage's MFMAs
+  constexpr int PKB = 4;
+  int pg[PKB], pls[PKB];
+#pragma unroll
+  for (int k = 0; k < PKB; ++k) {
+    const int e = tid + 256 * k, pix = e >> 3, f4 = e & 7;
+    const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
+    const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
+    pls[k] = e < NPIX * 8 ? pix * CB_KC + 4 * f4 : -1;
+    pg[k] = (e < NPIX * 8 && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (y * p.W + x) * p.Cin + 4 * f4 : -1;
+  }
+  f32x4 pv[PKB];
+  int4 wvh0, wvh1, wvh2, wvl0, wvl1, wvl2;         // (an indexed register array here ends up in scratch)
+  const int ngrp = KK / TG;
+#define CB_FETCH_P(CH)                                                                                               \
+  _Pragma("unroll") for (int k = 0; k < PKB; ++k) {                                                                  \
+    pv[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                                                                           \
+    if (pg[k] >= 0) pv[k] = *reinterpret_cast<const f32x4*>(in_b + pg[k] + (CH) * CB_KC);                            \
+  }
+#define CB_FETCH_W(STAGE)                                                                                            \
+  {                                                                                                                  \
+    const int64_t src0_ = ((int64_t)cot * nch * KK + (int64_t)(STAGE) * TG) * CD_TN * CB_KC;                         \
+    const int4* sh_ = reinterpret_cast<const int4*>(wt + src0_);                                                     \
+    const int4* sl_ = reinterpret_cast<const int4*>(wt + wtot + src0_);                                              \
+    wvh0 = sh_[tid]; wvh1 = sh_[tid + 256]; wvh2 = sh_[tid + 512];                                                   \
+    wvl0 = sl_[tid]; wvl1 = sl_[tid + 256]; wvl2 = sl_[tid + 512];                                                   \
+  }
+  CB_FETCH_P(0);
+  CB_FETCH_W(0);
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();                                 // the previous chunk's reads of the patch are done
-    for (int e = tid; e < NPIX * 8; e += 256) {      // patch: pixel, channels 4*f4 .. 4*f4+3 -> (hi, lo)
-      const int pix = e >> 3, f4 = e & 7;
-      const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
-      const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-        v = *reinterpret_cast<const f32x4*>(in_b + ((int64_t)y * p.W + x) * p.Cin + ch * CB_KC + 4 * f4);
+#pragma unroll
+    for (int k = 0; k < PKB; ++k) {                  // patch: pixel, channels 4*f4 .. 4*f4+3 -> (hi, lo)
       cbf4 h4, l4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const __bf16 hh = (__bf16)v[i]; h4[i] = hh; l4[i] = (__bf16)(v[i] - (float)hh); }
-      *reinterpret_cast<cbf4*>(ph + pix * CB_KC + 4 * f4) = h4;
-      *reinterpret_cast<cbf4*>(pl + pix * CB_KC + 4 * f4) = l4;
+      for (int i = 0; i < 4; ++i) { const __bf16 hh = (__bf16)pv[k][i]; h4[i] = hh; l4[i] = (__bf16)(pv[k][i] - (float)hh); }
+      if (pls[k] >= 0) {
+        *reinterpret_cast<cbf4*>(ph + pls[k]) = h4;
+        *reinterpret_cast<cbf4*>(pl + pls[k]) = l4;
+      }
     }
-    for (int tg = 0; tg < KK; tg += TG) {
-      if (tg > 0) __syncthreads();                   // the previous tap group's reads of the weights are done
+    for (int g = 0; g < ngrp; ++g) {
+      const int tg = g * TG;
+      if (g > 0) __syncthreads();                    // the previous tap group's reads of the weights are done
       {
-        const int64_t src0 = (((int64_t)cot * nch + ch) * KK + tg) * CD_TN * CB_KC;
-        const int4* sh = reinterpret_cast<const int4*>(wt + src0);
-        const int4* sl = reinterpret_cast<const int4*>(wt + wtot + src0);
-        int4* dh = reinterpret_cast<int4*>(wh);
-        int4* dl = reinterpret_cast<int4*>(wl);
-        for (int e = tid; e < TG * CD_TN * CB_KC / 8; e += 256) { dh[e] = sh[e]; dl[e] = sl[e]; }
+        int4* dh_ = reinterpret_cast<int4*>(wh) + tid;
+        int4* dl_ = reinterpret_cast<int4*>(wl) + tid;
+        dh_[0] = wvh0; dh_[256] = wvh1; dh_[512] = wvh2;
+        dl_[0] = wvl0; dl_[256] = wvl1; dl_[512] = wvl2;
       }
       __syncthreads();
+      {
+        const int stage = ch * ngrp + g;
+        if (stage + 1 < nch * ngrp) CB_FETCH_W(stage + 1);
+        if (g + 1 == ngrp && ch + 1 < nch) CB_FETCH_P(ch + 1);
+      }
 #pragma unroll
       for (int tt = 0; tt < TG; ++tt) {
         const int tap = tg + tt;
