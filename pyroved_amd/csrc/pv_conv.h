@@ -8,7 +8,9 @@ int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int
 int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s,
                     int eg_act = 0);
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s);
-int pv_upsample2_bwd(const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s);
+// eg_y / eg_act: optionally din *= act'(eg_y) (eg_y = the upsampled tensor, shaped like din)
+int pv_upsample2_bwd(const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s, const float* eg_y = nullptr,
+                     int eg_act = 0);
 int pv_ncs_to_nsc(const float* in, float* out, int64_t B, int C, int64_t S, hipStream_t s);
 int pv_nsc_to_ncs(const float* in, float* out, int64_t B, int C, int64_t S, hipStream_t s);
 int pv_act_bwd(float* dy, const float* y, int64_t n, int act, hipStream_t s);

@@ -117,8 +117,9 @@ __global__ void pv_upsample2_fwd_kernel(const float* __restrict__ in, float* __r
 }
 
 // din[b][y][x][c] = sum of the 2 (1-D) / 4 (2-D) output positions it was copied to
+// (eg_act != NONE: times act'(eg_y[e]), eg_y = the upsampled tensor = the producing convolution's output)
 __global__ void pv_upsample2_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
-                                        int C, int nd) {
+                                        int C, int nd, const float* __restrict__ eg_y, int eg_act) {
   const int Ho = 2 * H, Wo = nd == 2 ? 2 * W : 1;
   const int64_t total = (int64_t)B * H * W * C;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -130,6 +131,7 @@ __global__ void pv_upsample2_bwd_kernel(const float* __restrict__ dout, float* _
     for (int dy = 0; dy < 2; ++dy)
       for (int dx = 0; dx < (nd == 2 ? 2 : 1); ++dx)
         v += dout[((b * Ho + 2 * y + dy) * Wo + (nd == 2 ? 2 * x + dx : 0)) * C + c];
+    if (eg_y) v *= pv_act_grad(eg_y[e], 0.0f, eg_act);
     din[e] = v;
   }
 }
@@ -257,8 +259,10 @@ int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s) {
   CONV_LAUNCH(pv_upsample2_fwd_kernel, (int64_t)B * 2 * H * (nd == 2 ? 2 * W : 1) * C, in, out, B, H, W, C, nd);
 }
-int pv_upsample2_bwd(const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s) {
-  CONV_LAUNCH(pv_upsample2_bwd_kernel, (int64_t)B * H * W * C, dout, din, B, H, W, C, nd);
+int pv_upsample2_bwd(const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s, const float* eg_y,
+                     int eg_act) {
+  if (eg_act == PV_ACT_NONE || eg_act == PV_ACT_GELU) eg_y = nullptr;
+  CONV_LAUNCH(pv_upsample2_bwd_kernel, (int64_t)B * H * W * C, dout, din, B, H, W, C, nd, eg_y, eg_act);
 }
 static int ncs_nsc(const float* in, float* out, int64_t B, int C, int64_t S, int to_nsc, hipStream_t s) {
   const int64_t tiles = B * ((C + 31) / 32) * ((S + 31) / 32);

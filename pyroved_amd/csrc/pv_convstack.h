@@ -229,7 +229,8 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     return pv_maxpool2_bwd(in, g, gin, B, si.H, si.W, si.C, nd, s, fuse_act);
   }
   if (o.kind == PV_OP_UPSAMPLE2_BILINEAR) return pv_upsample2_bil_bwd(g, gin, B, si.H, si.W, si.C, s);
-  return pv_upsample2_bwd(g, gin, B, si.H, si.W, si.C, nd, s);
+  if (fused && fuse_act != PV_ACT_NONE) *fused = true;         // the producing convolution's activation backward rides along
+  return pv_upsample2_bwd(g, gin, B, si.H, si.W, si.C, nd, s, in, fuse_act);
 }
 
 // whole stack forward: a[0] given, a[1..n] written
