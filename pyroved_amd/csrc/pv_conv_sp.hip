@@ -43,7 +43,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 struct ConvSp {
   const float* in; const char* wt; const float* bias; float* out;
   const float* eg_y; int eg_act;      // optional: out *= act'(eg_y) elementwise (the producing layer's activation backward)
-  int B, H, W, Cin, Cout, act, tiles_x, tiles_y;
+  int B, H, W, Cin, Cout, act, tiles_x, tiles_y, halves;
 };
 
 // (hi16(b) << 16) | hi16(a): two truncated bf16 out of two fp32 bit patterns
@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
   const int y0 = ty * SP_T, x0 = tx * SP_T;
-  const int cot = blockIdx.y;
+  // p.halves == 2 (NCB = 2 only): a workgroup takes 32 of a 64-channel tile's output channels — twice the workgroups for
+  // launches that would otherwise be a single round of workgroups all in the same phase
+  const int cot = p.halves == 2 ? blockIdx.y >> 1 : blockIdx.y;
+  const int hco = p.halves == 2 ? 32 * (blockIdx.y & 1) : 0;          // first output channel of this workgroup within the tile
   const int nch = p.Cin / SP_KC;
   const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin;
   f32x4 acc[NCB][4];                                  // NCB: 16-channel blocks per workgroup (2 when Cout <= 32)
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
           for (int k = 0; k < NS; ++k)
-            a[cb][k] = *reinterpret_cast<const sbf8*>(wl + (tt * NS + k) * SP_WPLANE + cb * 1024 + aoff);
+            a[cb][k] = *reinterpret_cast<const sbf8*>(wl + (tt * NS + k) * SP_WPLANE + hco * 64 + cb * 1024 + aoff);
         // B fragments one pixel block ahead of the MFMAs that use them
         const int tofs = (dy * SP_PW + dx) * 64;
         sbf8 bcur[NS], bnxt[NS];
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
   if (p.bias) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      const int co = cot * SP_TN + cb * 16 + 4 * q;
+      const int co = cot * SP_TN + hco + cb * 16 + 4 * q;
       f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
       if (vec && co + 3 < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
       else {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb) {
-        const int co = cot * SP_TN + cb * 16 + 4 * q;
+        const int co = cot * SP_TN + hco + cb * 16 + 4 * q;
         gy[cb][pb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (ok[pb]) {
           if (vec && co + 3 < p.Cout) gy[cb][pb] = *reinterpret_cast<const f32x4*>(p.eg_y + ro[pb] + co);
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
     float* orow = p.out + ro[pb];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      const int co = cot * SP_TN + cb * 16 + 4 * q;
+      const int co = cot * SP_TN + hco + cb * 16 + 4 * q;
       if (vec && co + 3 < p.Cout) *reinterpret_cast<f32x4*>(orow + co) = acc[cb][pb];
       else {
 #pragma unroll
@@ -443,9 +446,15 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
   constexpr int TG = NS == 3 ? 1 : 3;
   static const int lds_pad = getenv("PV_SP_LDS_PAD") ? atoi(getenv("PV_SP_LDS_PAD")) : 0;   // (occupancy experiments)
   const size_t lds = (size_t)NS * SP_PPLANE + (size_t)TG * NS * SP_WPLANE + lds_pad;
-  const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)nt);
-  if (p.Cout <= 32) hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 2>), grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 4>), grid, dim3(256), lds, s, p);
+  const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.B * nt;
+  // fewer workgroups than CUs: 32-channel halves fill the chip (measured: 51 -> 37 us on 128 workgroups); with more, the
+  // doubled patch staging costs more than the extra round returns (PV_SP_HALVES overrides the limit)
+  static const int split_lim = getenv("PV_SP_HALVES") ? atoi(getenv("PV_SP_HALVES")) : 255;
+  ConvSp q = p;
+  q.halves = (p.Cout > 32 && wgs <= split_lim) ? 2 : 1;
+  const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(nt * q.halves));
+  if (p.Cout <= 32 || q.halves == 2) hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 2>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 4>), grid, dim3(256), lds, s, q);
   PV_LAUNCH_CHECK();
   return 0;
 }
