@@ -725,7 +725,8 @@ static int sw_splits(int B, int H, int W, int C, int Cout, int nsp) {
   const int64_t T = (int64_t)B * ((W + 7) / 8) * ((H + 7) / 8);
   const int ciw = (nsp == 2 && C % 64 == 0) ? 64 : 32;           // input channels per workgroup (three planes: 32, for the LDS)
   const int64_t owners = (int64_t)(C / ciw) * ((Cout + 63) / 64);
-  int64_t ns = (512 + owners - 1) / owners;                      // two workgroups per CU in all
+  static const int wg_target = getenv("PV_SW_WGS") ? atoi(getenv("PV_SW_WGS")) : 512;
+  int64_t ns = (wg_target + owners - 1) / owners;                // two workgroups per CU in all
   if (ns > T) ns = T;
   return (int)(ns < 1 ? 1 : ns);
 }
