@@ -37,11 +37,14 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
 // 2-D kernel-3 convolution on the bf16 matrix cores with exactly split operands (pv_conv_sp.hip): ns = 3 fp32-class
 // (six products), ns = 2 mixed precision (three); C % 32 == 0.  wt_scratch: pv_conv3_sp_wt_bytes bytes
 bool pv_conv3_sp_supported(int C, int Cout, int nd, int act);
+// the fp32-class form of the forward / input-gradient kernel: 4 = fp16 two-piece with exact scaling (default), 3 = bf16
+// three-piece (PV_SP_X6=1)
+int pv_conv3_sp_fp32_mode();
 int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr);
 // all of a step's weight tilings in one launch (per 16 entries).  kind 0: pv_conv3_direct f32, 1: its bf16 two-piece form,
-// 2 / 3: pv_conv3_sp with 2 / 3 pieces, 4: a conv head's Linear weight re-indexed channels-last (Co = out, Ci = C,
+// 2 / 3: pv_conv3_sp with 2 / 3 bf16 pieces, 5: its fp16 two-piece form (ns = 4), 4: a conv head's Linear weight re-indexed channels-last (Co = out, Ci = C,
 // KK = spatial size); dst sized by pv_conv_wt_bytes
 struct PvWprepEntry { const float* w; char* dst; int Co, Ci, KK, flip, kind; int pad_; int64_t start, total; };
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd);

@@ -24,6 +24,8 @@
 
 typedef __bf16 sbf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 shf8 __attribute__((ext_vector_type(8)));
+typedef __fp16 shp2 __attribute__((ext_vector_type(2)));
 #ifndef SP_EXP
 #define SP_EXP 0                 // timing experiments (wrong results): 1 no MFMAs, 2 no weight re-staging, 4 no patch re-staging
 #endif
@@ -39,6 +41,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define SP_NPIX (SP_PW * SP_PW)
 #define SP_PPLANE (SP_NPIX * 64) // bytes per patch plane
 #define SP_WPLANE (SP_TN * 64)   // bytes per weight plane of one tap
+
+// fp16 two-piece mode (F16): pieces are fp16 (11 + 11 significant bits: three products give ~2^-22 per multiply-add, fp32-class at
+// the MFMA cost of the mixed mode).  fp16's narrow exponent is handled by exact power-of-two scaling: the weights are tiled
+// times SP_F16_WSCALE, each 32-channel chunk of a tile's patch times 2^E with its maximum brought to [2^13, 2^14) — E never more
+// than 30 above the smallest E of the tile so far, so the accumulator (rescaled by 2^(E - E_prev) between chunks) cannot
+// overflow; a chunk that needs a larger E than that is 2^30 below what is already summed and its precision is moot.
+#define SP_F16_WSCALE 64.0f
+#define SP_F16_WSHIFT 6
 
 struct ConvSp {
   const float* in; const char* wt; const float* bias; float* out;
@@ -77,6 +87,36 @@ template <int NS> __device__ __forceinline__ void sp_split4(const f32x4& v, u32x
   }
 }
 
+// four fp32 (times the exact scale sc) -> two planes of four fp16: a0 = rtz(v sc), a1 = rtz(v sc - a0)
+__device__ __forceinline__ void sp_split4_f16(const f32x4& v, float sc, u32x2 (&pl)[2]) {
+  const f32x4 t = v * sc;
+  const shp2 h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]), h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
+  const shp2 l01 = __builtin_amdgcn_cvt_pkrtz(t[0] - (float)h01[0], t[1] - (float)h01[1]);
+  const shp2 l23 = __builtin_amdgcn_cvt_pkrtz(t[2] - (float)h23[0], t[3] - (float)h23[1]);
+  pl[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+  pl[1] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+}
+__device__ __forceinline__ void sp_split1_f16(float v, unsigned short (&pl)[2]) {
+  const float t = v * SP_F16_WSCALE;
+  const _Float16 h = (_Float16)t;
+  const _Float16 l = (_Float16)(t - (float)h);
+  pl[0] = __builtin_bit_cast(unsigned short, h);
+  pl[1] = __builtin_bit_cast(unsigned short, l);
+}
+template <bool F16> __device__ __forceinline__ f32x4 sp_mma(const sbf8& a, const sbf8& b, const f32x4& c) {
+#if SP_EXP & 1
+  return c;
+#else
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(shf8, a), __builtin_bit_cast(shf8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ float sp_pow2(int k) {          // 2^k, k clamped to the normal range
+  k = k < -126 ? -126 : (k > 127 ? 127 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
+}
+
 template <int NS> __device__ __forceinline__ void sp_split1(float v, unsigned short (&pl)[NS]) {
   if constexpr (NS == 3) {
     const float r1 = v - sp_trunc(v), r2 = r1 - sp_trunc(r1);
@@ -95,7 +135,7 @@ template <int NS> __device__ __forceinline__ void sp_split1(float v, unsigned sh
 //   flip == 0 (forward):  Wl[n = co][c = ci][t] = w[co][ci][t]                (N = Co, C = Ci)
 //   flip == 1 (dgrad):    Wl[n = ci][c = co][t] = w[co][ci][8 - t]            (N = Ci, C = Co)
 // laid out [n tile][chunk][t][plane][64 rows][32 channels, 16-byte slots swizzled], rows n >= N zero
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void sp_wprep_elem(const float* __restrict__ w, unsigned short* __restrict__ wt, int Co, int Ci, int flip,
                                               int64_t e) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
@@ -107,7 +147,8 @@ __device__ __forceinline__ void sp_wprep_elem(const float* __restrict__ w, unsig
     float v = 0.0f;
     if (n < N) v = flip ? w[((int64_t)c * Ci + n) * 9 + (8 - t)] : w[((int64_t)n * Ci + c) * 9 + t];
     unsigned short pl[NS];
-    sp_split1<NS>(v, pl);
+    if constexpr (F16) sp_split1_f16(v, pl);
+    else sp_split1<NS>(v, pl);
     const int scl = ((((cl >> 3) ^ (2 * ((nl >> 3) & 1)))) << 3) | (cl & 7);
     const int64_t base = (((int64_t)tile * nch + ch) * 9 + t) * NS;
 #pragma unroll
@@ -115,12 +156,12 @@ __device__ __forceinline__ void sp_wprep_elem(const float* __restrict__ w, unsig
   }
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ void pv_conv3_sp_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt, int Co, int Ci, int flip) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   const int64_t total = (int64_t)((N + SP_TN - 1) / SP_TN) * (C / SP_KC) * 9 * SP_TN * SP_KC;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
-    sp_wprep_elem<NS>(w, wt, Co, Ci, flip, e);
+    sp_wprep_elem<NS, F16>(w, wt, Co, Ci, flip, e);
 }
 
 // ---- every weight tiling of a step in one launch: entry k covers element indices [start, start + total) ----------------
@@ -137,6 +178,10 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
       const int64_t F = (int64_t)Ci * KK, j = e / F, f = e - j * F;
       const int sp = (int)(f / Ci), c = (int)(f - (int64_t)sp * Ci);
       reinterpret_cast<float*>(E.dst)[e] = E.w[j * F + (int64_t)c * KK + sp];
+      continue;
+    }
+    if (E.kind == 5) {                                // fp16 two-piece tiling (weights times SP_F16_WSCALE)
+      sp_wprep_elem<2, true>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
       continue;
     }
     if (E.kind >= 2) {
@@ -164,6 +209,7 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
 
 static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
   if (kind == 4) return (int64_t)Co * Ci * KK;
+  if (kind == 5) KK = 9;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   const int KC = kind == 0 ? 16 : 32;
   return (int64_t)((N + 63) / 64) * (C / KC) * KK * 64 * KC;
@@ -197,9 +243,11 @@ int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s) {
   return 0;
 }
 
-template <int NS, int NCB>
+template <int NS, int NCB, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
+  static_assert(!F16 || NS == 2, "the fp16 mode has two pieces");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float smax[2][4];                        // F16: the waves' patch maxima of the chunk being staged
   constexpr int TG = NS == 3 ? 1 : 3;                 // taps per weight stage
   constexpr int NG = 9 / TG;
   constexpr int WREGS = TG * NS;                      // 16-byte pieces of a weight stage per thread
@@ -267,14 +315,47 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
     if (goff[k] >= 0) pre[k] = *reinterpret_cast<const f32x4*>(in_b + goff[k]);
   }
   SP_W_FETCH(0);
+  int E_cur = 0, E_min = 1 << 20;                     // F16: the patch scale 2^E of the current chunk, the smallest so far
+  auto wave_max = [&](int slot) {                     // max |pre| of this wave -> smax[slot][wave]
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PK; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(pre[k][i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) smax[slot][wave] = m;
+  };
+  if constexpr (F16) wave_max(0);
   for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();                                  // the previous chunk's fragment reads are done
+    __syncthreads();                                  // the previous chunk's fragment reads are done (F16: smax is in)
+    float psc = 1.0f;
+    if constexpr (F16) {
+      const float m = fmaxf(fmaxf(smax[ch & 1][0], smax[ch & 1][1]), fmaxf(smax[ch & 1][2], smax[ch & 1][3]));
+      const int e = (int)((__float_as_uint(m) >> 23) & 255);
+      int E = E_cur;                                  // a (near-)zero chunk keeps the scale and does not count for E_min
+      if (e >= 20) {
+        E = 140 - e;                                  // max -> [2^13, 2^14)
+        if (E_min != (1 << 20) && E > E_min + 30) E = E_min + 30;
+        if (E < E_min) E_min = E;
+      }
+      if (ch > 0 && E != E_cur) {
+        const float ratio = sp_pow2(E - E_cur);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) acc[cb][pb] *= ratio;
+      }
+      E_cur = E;
+      psc = sp_pow2(E);
+    }
 #pragma unroll
     for (int k = 0; k < ((SP_EXP & 4) && ch > 0 ? 0 : PK); ++k) {
       const int e = tid + 256 * k, pix = e >> 3, f4 = e & 7;
       const int py = pix / SP_PW;
       u32x2 pl[NS];
-      sp_split4<NS>(pre[k], pl);
+      if constexpr (F16) sp_split4_f16(pre[k], psc, pl);
+      else sp_split4<NS>(pre[k], pl);
       const int o = pix * 64 + (((f4 >> 1) ^ (2 * (py & 1))) * 16) + (f4 & 1) * 8;
       if (k + 1 < PK || e < SP_NPIX * 8) {
 #pragma unroll
@@ -316,18 +397,18 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
           // products in ascending magnitude; the NCB accumulators of a product are independent
           if constexpr (NS == 3) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = SP_MFMA(a[cb][1], bcur[1], acc[cb][pb]);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][1], bcur[1], acc[cb][pb]);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = SP_MFMA(a[cb][2], bcur[0], acc[cb][pb]);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][2], bcur[0], acc[cb][pb]);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = SP_MFMA(a[cb][0], bcur[2], acc[cb][pb]);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[2], acc[cb][pb]);
           }
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = SP_MFMA(a[cb][1], bcur[0], acc[cb][pb]);
+          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][1], bcur[0], acc[cb][pb]);
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = SP_MFMA(a[cb][0], bcur[1], acc[cb][pb]);
+          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[1], acc[cb][pb]);
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = SP_MFMA(a[cb][0], bcur[0], acc[cb][pb]);
+          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[0], acc[cb][pb]);
 #pragma unroll
           for (int k = 0; k < NS; ++k) bcur[k] = bnxt[k];
         }
@@ -338,6 +419,16 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
         __syncthreads();
       }
     }
+    if constexpr (F16) {
+      if (ch + 1 < nch) wave_max((ch + 1) & 1);       // (the next chunk's values arrived under the MFMAs)
+    }
+  }
+  if constexpr (F16) {                                // back to true units
+    const float inv = sp_pow2(-(E_cur + SP_F16_WSHIFT));
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) acc[cb][pb] *= inv;
   }
   // C/D layout: lane (column = pixel r, q), reg i -> output channel 16*cb + 4q + i.  The activation is uniform: one
   // switch around tight loops over the 16*NCB values (a switch per value costs more than the convolution's MFMAs)
@@ -423,6 +514,11 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
   }
 }
 
+int pv_conv3_sp_fp32_mode() {
+  static const int mode = (getenv("PV_SP_X6") && atoi(getenv("PV_SP_X6"))) ? 3 : 4;
+  return mode;
+}
+
 bool pv_conv3_sp_supported(int C, int Cout, int nd, int act) {
   return nd == 2 && C >= SP_KC && C % SP_KC == 0 && Cout >= 8 && act != PV_ACT_GELU;
 }
@@ -433,14 +529,14 @@ int64_t pv_conv3_sp_wt_bytes(int C, int Cout) {
   return ((n + SP_TN - 1) / SP_TN) * SP_TN * n * 9 * 3 * 2 + 256;
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int flip, char* wt, int nt, int64_t total,
                            hipStream_t s) {
   if (wt) {
     int pb = (int)((total + 255) / 256);
     if (pb > 2048) pb = 2048;
-    hipLaunchKernelGGL(pv_conv3_sp_wprep_kernel<NS>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wt), Co, Ci,
-                       flip);
+    hipLaunchKernelGGL((pv_conv3_sp_wprep_kernel<NS, F16>), dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wt), Co,
+                       Ci, flip);
     PV_LAUNCH_CHECK();
   }
   constexpr int TG = NS == 3 ? 1 : 3;
@@ -453,8 +549,8 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
   ConvSp q = p;
   q.halves = (p.Cout > 32 && wgs <= split_lim) ? 2 : 1;
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(nt * q.halves));
-  if (p.Cout <= 32 || q.halves == 2) hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 2>), grid, dim3(256), lds, s, q);
-  else hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 4>), grid, dim3(256), lds, s, q);
+  if (p.Cout <= 32 || q.halves == 2) hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 2, F16>), grid, dim3(256), lds, s, q);
+  else hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 4, F16>), grid, dim3(256), lds, s, q);
   PV_LAUNCH_CHECK();
   return 0;
 }
@@ -465,7 +561,7 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
-  if (!pv_conv3_sp_supported(C, N, 2, act) || (ns != 2 && ns != 3)) return PV_EINVAL;
+  if (!pv_conv3_sp_supported(C, N, 2, act) || (ns != 2 && ns != 3 && ns != 4)) return PV_EINVAL;   // 4: fp16 two-piece
   const int nt = (N + SP_TN - 1) / SP_TN;
   const int64_t total = (int64_t)nt * (C / SP_KC) * 9 * SP_TN * SP_KC;
   ConvSp p{};
@@ -474,6 +570,7 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
   p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = N; p.act = act;
   p.tiles_x = (W + SP_T - 1) / SP_T; p.tiles_y = (H + SP_T - 1) / SP_T;
   char* prep = wt_ready ? nullptr : reinterpret_cast<char*>(wt_scratch);    // null: tiled already (pv_conv_wprep_table)
+  if (ns == 4) return conv3_sp_launch<2, true>(p, w, Co, Ci, flip, prep, nt, total, s);
   return ns == 3 ? conv3_sp_launch<3>(p, w, Co, Ci, flip, prep, nt, total, s) : conv3_sp_launch<2>(p, w, Co, Ci, flip, prep, nt, total, s);
 }
 

@@ -106,7 +106,7 @@ inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
 inline int wt_kind(const pv_op& o, int nd, int flip, int conv_bf16) {
   if (o.kind != PV_OP_CONV || o.ksize != 3) return -1;
   const int C = flip ? o.cout : o.cin, N = flip ? o.cin : o.cout, act = flip ? PV_ACT_NONE : o.act;
-  if (pv_conv3_sp_supported(C, N, nd, act)) return conv_bf16 ? 2 : 3;
+  if (pv_conv3_sp_supported(C, N, nd, act)) return conv_bf16 ? 2 : (pv_conv3_sp_fp32_mode() == 4 ? 5 : 3);
   if (pv_conv3_direct_supported(C, N, nd, act)) return (conv_bf16 && C % 32 == 0) ? 1 : 0;
   return -1;
 }
@@ -161,7 +161,7 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
     if (o.ksize == 3) {
       if (pv_conv3_sp_supported(o.cin, o.cout, nd, o.act))      // 2-D, Cin % 32 == 0: exactly split operands on the bf16 cores
         return pv_conv3_sp(in, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr, 0,
-                           sc.conv_bf16 ? 2 : 3, wt_ready(sc, slot, 0));
+                           sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), wt_ready(sc, slot, 0));
       if (pv_conv3_direct_supported(o.cin, o.cout, nd, o.act))
         return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr,
                                0, sc.conv_bf16, wt_ready(sc, slot, 0));
@@ -208,7 +208,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         return pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act,
-                           sc.conv_bf16 ? 2 : 3, wt_ready(sc, slot, 1));
+                           sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), wt_ready(sc, slot, 1));
       }
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;

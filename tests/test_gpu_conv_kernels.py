@@ -232,3 +232,24 @@ def test_standalone_conv_stacks_run_on_the_library(gpu_device, name, spec, shape
                 assert rel_l2(b1, b2) < 1e-5, n1
             else:
                 assert int(b1) == int(b2), n1
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 3e4])
+@pytest.mark.parametrize("B,H,W,Ci,Co,act", CONV_CASES[:4])
+def test_fp16_two_piece_conv_is_fp32_class_at_any_magnitude(gpu_device, scale, B, H, W, Ci, Co, act):
+    """mode 4: fp16 pieces with exact power-of-two scaling per 32-channel chunk of a tile's patch — inputs of size 1, 1e-6
+    (gradient-like) and 3e4, with one channel block 1e-9 of the rest and one exactly zero."""
+    g = torch.Generator().manual_seed(B * 1000 + H * 31 + Co)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).cuda()
+    x = torch.randn(B, H, W, Ci, generator=g) * scale
+    x[..., :8] *= 1e-9
+    if Ci >= 64:
+        x[..., 32:64] = 0.0
+    x = x.cuda()
+    n = max(Co, Ci)
+    scratch = torch.empty(((n + 63) // 64) * 64 * n * 9 * 6 + 4096, dtype=torch.uint8, device="cuda")
+    out = torch.full((B, H, W, Co), float("nan"), device="cuda")
+    rc = lib().pv_debug_conv3(4, ptr(x), B, H, W, 2, ptr(w), Co, Ci, 0, P(0), ptr(out), 0, ptr(scratch), P(0), 0, stream())
+    assert rc == 0
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
+    assert rel_l2(out, ref) < 2e-6
