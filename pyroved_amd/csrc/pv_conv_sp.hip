@@ -648,9 +648,15 @@ template <int NCIB> struct SwGeo {
   static constexpr int PLANE = 10 * RP + 2 * PP;     // (+ the two never-used pixels a line window reads past the halo)
 };
 
-template <int NS, int NCIB>
+// F16: fp16 two-piece operands (see pv_conv3_sp_kernel) — each staged dY tile and patch tile is scaled by its own exact power
+// of two (maximum to [2^13, 2^14)); the accumulators live in units of 2^(E_dy + E_patch) (the bias sums in 2^E_dy) and are
+// rescaled when a tile changes them; neither exponent may exceed the smallest so far by more than 30 (overflow guard —
+// a tile that would need more is 2^30 below what is already summed).
+template <int NS, int NCIB, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
+  static_assert(!F16 || (NS == 2 && NCIB == 1), "the fp16 mode: two pieces, 32-channel workgroups (next-tile prefetch)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float smx[2][2][4];                     // F16: [tile parity][dY | patch][wave] maxima of the tile being staged
   constexpr int PP = SwGeo<NCIB>::PP, RP = SwGeo<NCIB>::RP, PPLANE = SwGeo<NCIB>::PLANE;
   char* dyl = smem;                                  // [NS] planes
   char* patch = smem + NS * SW_DYPLANE;              // [NS] planes
@@ -668,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
 #pragma unroll
       for (int c = 0; c < NCIB; ++c) acc[t][a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   accb[0] = accb[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  const sbf8 ones = sw_frag(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  const unsigned one2 = F16 ? 0x3c003c00u : 0x3f803f80u;                  // 1.0 twice, fp16 / bf16
+  const sbf8 ones = sw_frag(one2, one2, one2, one2);
   const bool want_b = p.part_b && cit == 0 && wci == 0;
   // transposing-read addresses: lane r points at pixel (+ r>>2), channels 4 (r&3) .. +3 of the 16-channel block
   const int a_off = q * SW_DYL + (r >> 2) * SW_DYP + (r & 3) * 8 + wco * 64;
@@ -734,20 +741,69 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
     if (++ftx == p.tiles_x) { ftx = 0; if (++fty == p.tiles_y) { fty = 0; ++fb; } }
   };
   if (PRE && t_lo < t_hi) fetch();
+  int Ed = 0, Ep = 0, Ed_min = 1 << 20, Et_min = 1 << 20;           // F16: current exponents, smallest so far (dY, dY + patch)
+  auto wave_max = [&](int slot) {                    // this wave's max |dY piece| and |patch piece| of the fetched tile
+    float md = 0.0f, mp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) md = fmaxf(md, fabsf(vd[k][i]));
+#pragma unroll
+    for (int k = 0; k < PK; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mp = fmaxf(mp, fabsf(vp[k][i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { md = fmaxf(md, __shfl_xor(md, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
+    if (lane == 0) { smx[slot][0][wave] = md; smx[slot][1][wave] = mp; }
+  };
+  if constexpr (F16) { if (t_lo < t_hi) wave_max(0); }
+  int par = 0;
   for (int64_t tt = t_lo; tt < t_hi; ++tt) {
-    __syncthreads();                                 // the previous tile's fragment reads are done
+    __syncthreads();                                 // the previous tile's fragment reads are done (F16: smx is in)
     if (!PRE) fetch();
+    float scd = 1.0f, scp = 1.0f;
+    if constexpr (F16) {
+      const float md = fmaxf(fmaxf(smx[par][0][0], smx[par][0][1]), fmaxf(smx[par][0][2], smx[par][0][3]));
+      const float mp = fmaxf(fmaxf(smx[par][1][0], smx[par][1][1]), fmaxf(smx[par][1][2], smx[par][1][3]));
+      const int ed = (int)((__float_as_uint(md) >> 23) & 255), ep = (int)((__float_as_uint(mp) >> 23) & 255);
+      int nEd = Ed, nEp = Ep;                        // a (near-)zero tile keeps the scales and contributes nothing
+      if (ed >= 20 && ep >= 20) {
+        nEd = 140 - ed; nEp = 140 - ep;              // maxima -> [2^13, 2^14)
+        if (Ed_min != (1 << 20) && nEd > Ed_min + 30) nEd = Ed_min + 30;
+        if (nEd < Ed_min) Ed_min = nEd;
+        if (Et_min != (1 << 20) && nEd + nEp > Et_min + 30) nEp = Et_min + 30 - nEd;
+        if (nEd + nEp < Et_min) Et_min = nEd + nEp;
+      }
+      if (nEd + nEp != Ed + Ep) {
+        const float ratio = sp_pow2(nEd + nEp - Ed - Ep);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < NCIB; ++c) acc[t][a][c] *= ratio;
+      }
+      if (nEd != Ed) {
+        const float ratio = sp_pow2(nEd - Ed);
+        accb[0] *= ratio; accb[1] *= ratio;
+      }
+      Ed = nEd; Ep = nEp;
+      scd = sp_pow2(Ed); scp = sp_pow2(Ep);
+      par ^= 1;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       u32x2 pl[NS];
-      sp_split4<NS>(vd[k], pl);
+      if constexpr (F16) sp_split4_f16(vd[k], scd, pl);
+      else sp_split4<NS>(vd[k], pl);
 #pragma unroll
       for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(dyl + j * SW_DYPLANE + d_lds[k]) = pl[j];
     }
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
       u32x2 pl[NS];
-      sp_split4<NS>(vp[k], pl);
+      if constexpr (F16) sp_split4_f16(vp[k], scp, pl);
+      else sp_split4<NS>(vp[k], pl);
       if (pp_r[k] < (1 << 20)) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(patch + j * PPLANE + p_lds[k]) = pl[j];
@@ -770,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
 #pragma unroll
         for (int cob = 0; cob < 2; ++cob)
 #pragma unroll
-          for (int j = 0; j < NS; ++j) accb[cob] = SP_MFMA(a[cob][j], ones, accb[cob]);
+          for (int j = 0; j < NS; ++j) accb[cob] = sp_mma<F16>(a[cob][j], ones, accb[cob]);
       }
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
@@ -789,12 +845,25 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
           }
 #define SW_PROD(KA, KB)                                                                                                 \
   _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) _Pragma("unroll") for (int cob = 0; cob < 2; ++cob)                   \
-      acc[3 * dy + dx][cob][cib] = SP_MFMA(a[cob][KA], bb[dx][KB], acc[3 * dy + dx][cob][cib]);
+      acc[3 * dy + dx][cob][cib] = sp_mma<F16>(a[cob][KA], bb[dx][KB], acc[3 * dy + dx][cob][cib]);
           if constexpr (NS == 3) { SW_PROD(1, 1) SW_PROD(2, 0) SW_PROD(0, 2) }
           SW_PROD(1, 0) SW_PROD(0, 1) SW_PROD(0, 0)
         }
       }
     }
+    if constexpr (F16) {
+      if (tt + 1 < t_hi) wave_max(par);              // (the next tile's pieces arrived under the MFMAs)
+    }
+  }
+  if constexpr (F16) {                               // back to true units
+    const float inv = sp_pow2(-(Ed + Ep)), invb = sp_pow2(-Ed);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < NCIB; ++c) acc[t][a][c] *= inv;
+    accb[0] *= invb; accb[1] *= invb;
   }
   // C/D layout: lane (column = ci r, q), reg i -> output channel 16*cob + 4q + i of the wave's 32
 #pragma unroll
@@ -838,7 +907,7 @@ int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout) {
 
 int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,
                       int64_t ws_bytes, hipStream_t s, int ns) {
-  if (!pv_conv3_sp_wgrad_supported(C, Cout, 2) || (ns != 2 && ns != 3)) return PV_EINVAL;
+  if (!pv_conv3_sp_wgrad_supported(C, Cout, 2) || (ns != 2 && ns != 3 && ns != 4)) return PV_EINVAL;   // 4: fp16 two-piece
   if (ws_bytes < pv_conv3_sp_wgrad_ws(B, H, W, C, Cout)) return PV_EWS;
   ConvWgSp p{};
   p.dy = dy; p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = Cout;
@@ -849,8 +918,10 @@ int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int
   p.part_b = db ? p.part + (int64_t)p.nsplit * nw : nullptr;
   const bool wide = ns == 2 && C % 64 == 0;
   const dim3 grid((unsigned)p.nsplit, (unsigned)(wide ? C / 64 : C / 32), (unsigned)((Cout + 63) / 64));
-  const size_t lds = (size_t)ns * (SW_DYPLANE + (wide ? SwGeo<2>::PLANE : SwGeo<1>::PLANE));
-  if (ns == 3) {
+  const size_t lds = (size_t)(ns == 4 ? 2 : ns) * (SW_DYPLANE + (wide ? SwGeo<2>::PLANE : SwGeo<1>::PLANE));
+  if (ns == 4) {
+    hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1, true>), grid, dim3(256), lds, s, p);
+  } else if (ns == 3) {
     hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<3, 1>), grid, dim3(256), lds, s, p);
   } else {
     if (wide) hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 2>), grid, dim3(256), lds, s, p);

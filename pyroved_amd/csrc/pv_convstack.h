@@ -194,7 +194,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     if (o.ksize == 3) {
       if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s,
-                                 sc.conv_bf16 ? 2 : 3));
+                                 sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode()));
       else if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_wgrad_direct_bf16(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
       else if (pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))

@@ -253,3 +253,29 @@ def test_fp16_two_piece_conv_is_fp32_class_at_any_magnitude(gpu_device, scale, B
     assert rc == 0
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
     assert rel_l2(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("sx,sdy", [(1.0, 1.0), (1.0, 1e-7), (3e3, 1e-4)])
+@pytest.mark.parametrize("B,H,W,Ci,Co,act", CONV_CASES[:5])
+def test_fp16_two_piece_weight_gradient_is_fp32_class_at_any_magnitude(gpu_device, sx, sdy, B, H, W, Ci, Co, act):
+    """mode 4 of the weight gradient: every staged dY tile and patch tile carries its own exact power-of-two scale; inputs
+    and gradients of very different sizes, one image all zero, one image 1e6 times the others."""
+    g = torch.Generator().manual_seed(11 + B * 1000 + H * 31 + Co)
+    x = torch.randn(B, H, W, Ci, generator=g) * sx
+    dy = torch.randn(B, H, W, Co, generator=g) * sdy
+    if B > 1:
+        dy[0] = 0.0
+        x[-1] *= 1e6
+    x, dy = x.cuda(), dy.cuda()
+    dw = torch.full((Co, Ci, 3, 3), float("nan"), device="cuda")
+    db = torch.full((Co,), float("nan"), device="cuda")
+    nb = lib().pv_debug_conv3_wgrad_ws(4, B, H, W, Ci, Co, 2)
+    ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device="cuda")
+    rc = lib().pv_debug_conv3_wgrad(4, ptr(dy), ptr(x), B, H, W, Ci, 2, ptr(dw), ptr(db), Co, ptr(ws), C.c_longlong(ws.numel()),
+                                    stream())
+    assert rc == 0
+    wd = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = F.conv2d(x.permute(0, 3, 1, 2).double(), wd, None, padding=1)
+    (gw,) = torch.autograd.grad(y, wd, dy.permute(0, 3, 1, 2).double())
+    assert rel_l2(dw, gw) < 2e-6
+    assert rel_l2(db, dy.double().sum((0, 1, 2))) < 2e-6
