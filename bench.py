@@ -327,16 +327,18 @@ def measure(args, name, cfg, fused, ctx):
            "loss_per_image_last_step": losses[-1].item() / (B * world)}
     step_tf = out["value"] / world * cfg["flops_per_image"] / 1e12
     if ved:
-        # both precisions run the 2-D k3 convolutions on v_mfma_f32_16x16x32_bf16 with split operands (pv_conv_sp.hip):
-        # three exact bf16 pieces and six products per multiply-add (fp32-class) or two rounded pieces and three products
+        # both precisions run the 2-D k3 convolutions on the 16x16x32 matrix-core instructions with split operands
+        # (pv_conv_sp.hip), three products per multiply-add: fp32-class = two fp16 pieces with exact power-of-two scaling per
+        # staged tile (~2^-22 per product), mixed = two rounded bf16 pieces (~2^-17)
         bf = fused == 3
-        prods = 3 if bf else 6
-        peak = MFMA_BF16_PEAK_TFLOPS
-        out.update(dtype="bf16x3" if bf else "bf16x6", path="conv-bf16x3" if bf else "conv-bf16x6",
+        prods = 3
+        peak = MFMA_BF16_PEAK_TFLOPS                    # (the f16 16x16x32 MFMA has the same dense peak)
+        out.update(dtype="bf16x3" if bf else "f16x3", path="conv-bf16x3" if bf else "conv-f16x3",
                    arith=("2-D k3 convolutions on the bf16 MFMA, operands split into two rounded bf16 pieces, three products "
                           "(fp32 accumulate); fp32 elsewhere" if bf else
-                          "2-D k3 convolutions on the bf16 MFMA, operands split EXACTLY into three bf16 pieces, six products "
-                          "(fp32 accumulate): fp32-class; 1-D convolutions on the f32-input MFMA; fp32 elsewhere"),
+                          "2-D k3 convolutions on the f16 MFMA, operands split into two fp16 pieces with exact power-of-two scaling "
+                          "per staged tile, three products (fp32 accumulate): fp32-class (3e-7 relative l2 vs float64); 1-D "
+                          "convolutions on the f32-input MFMA; fp32 elsewhere"),
                    roofline={"bound": "mfma", "scope": "step", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s",
                              "frac": step_tf / peak, "traffic": None, "mfma_products_per_mac": prods,
                              "frac_of_split_operand_peak": step_tf * prods / peak,
