@@ -340,8 +340,19 @@ __global__ __launch_bounds__(256) void pv_conv3_wgrad_finish_kernel(const float*
     const int64_t e = (isb ? blk - nblk : blk) * og + o, lim = isb ? nb : n;
     const float* src = isb ? part_b : part;
     float v = 0.0f;
-    if (e < lim)
-      for (int s = sl; s < nsplit; s += nsl) v += src[(int64_t)s * lim + e];
+    if (e < lim) {
+      // four independent chains (a fixed order all the same) keep several loads in flight per thread
+      float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+      int s = sl;
+      for (; s + 3 * nsl < nsplit; s += 4 * nsl) {
+        v0 += src[(int64_t)s * lim + e];
+        v1 += src[(int64_t)(s + nsl) * lim + e];
+        v2 += src[(int64_t)(s + 2 * nsl) * lim + e];
+        v3 += src[(int64_t)(s + 3 * nsl) * lim + e];
+      }
+      for (; s < nsplit; s += nsl) v0 += src[(int64_t)s * lim + e];
+      v = (v0 + v1) + (v2 + v3);
+    }
     sm[sl * og + o] = v;
     __syncthreads();
     if (sl == 0 && e < lim) {
