@@ -44,7 +44,7 @@ int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr);
 // all of a step's weight tilings in one launch (per 16 entries).  kind 0: pv_conv3_direct f32, 1: its bf16 two-piece form,
-// 2 / 3: pv_conv3_sp with 2 / 3 bf16 pieces, 5: its fp16 two-piece form (ns = 4), 4: a conv head's Linear weight re-indexed channels-last (Co = out, Ci = C,
+// 6: that kernel's fp16 two-piece form, 2 / 3: pv_conv3_sp with 2 / 3 bf16 pieces, 5: its fp16 two-piece form (ns = 4), 4: a conv head's Linear weight re-indexed channels-last (Co = out, Ci = C,
 // KK = spatial size); dst sized by pv_conv_wt_bytes
 struct PvWprepEntry { const float* w; char* dst; int Co, Ci, KK, flip, kind; int pad_; int64_t start, total; };
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd);

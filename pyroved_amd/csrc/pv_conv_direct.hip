@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
 }
 
 // (bf16 split-precision forms: defined at the end of this file)
-__global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Co, int Ci, int KK, int flip);
-__global__ void pv_conv3_direct_bf16_kernel(ConvD p);
+template <bool F16> __global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Co, int Ci, int KK, int flip);
+template <bool F16> __global__ void pv_conv3_direct_bf16_kernel(ConvD p);
 
 bool pv_conv3_direct_supported(int C, int Cout, int nd, int act) {
   return C >= CD_KC && C % CD_KC == 0 && Cout >= 8 && (nd == 1 || nd == 2) && act != PV_ACT_GELU;
@@ -199,9 +199,12 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
   if (wt_ready) {                                    // tiled once per step by pv_conv_wprep_table
     wt_scratch = const_cast<float*>(reinterpret_cast<const float*>(wt_ready));
   } else {
-    if (bf16)      // (the hi + lo bf16 arrays take the same bytes as the fp32 tiling)
-      hipLaunchKernelGGL(pv_conv3_wprep_bf16_kernel, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wt_scratch), Co, Ci,
-                         KK, flip);
+    if (bf16 && use_bf16 == 2)   // (the hi + lo 16-bit arrays take the same bytes as the fp32 tiling)
+      hipLaunchKernelGGL(pv_conv3_wprep_bf16_kernel<true>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wt_scratch), Co,
+                         Ci, KK, flip);
+    else if (bf16)
+      hipLaunchKernelGGL(pv_conv3_wprep_bf16_kernel<false>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wt_scratch), Co,
+                         Ci, KK, flip);
     else
       hipLaunchKernelGGL(pv_conv3_wprep_kernel, dim3(pb), dim3(256), 0, s, w, wt_scratch, Co, Ci, KK, flip);
     PV_LAUNCH_CHECK();
@@ -215,7 +218,9 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
   const int npix = nd == 2 ? 100 : CD_PIX + 2;
   if (bf16) {
     const size_t ldsb = (size_t)(2 * 3 * CD_TN * 32 + 2 * npix * 32) * 2;
-    hipLaunchKernelGGL(pv_conv3_direct_bf16_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt), dim3(256), ldsb, s, p);
+    const dim3 gridb((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt);
+    if (use_bf16 == 2) hipLaunchKernelGGL(pv_conv3_direct_bf16_kernel<true>, gridb, dim3(256), ldsb, s, p);
+    else hipLaunchKernelGGL(pv_conv3_direct_bf16_kernel<false>, gridb, dim3(256), ldsb, s, p);
     PV_LAUNCH_CHECK();
     return 0;
   }
@@ -520,6 +525,22 @@ typedef __bf16 cbf4 __attribute__((ext_vector_type(4)));
 #define CB_KC 32
 #define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// F16 (the fp32-class form of these kernels): two fp16 pieces of the value times 2^6, each staged patch chunk scaled by its own
+// exact power of two — the scheme of pv_conv_sp.hip (see there), for the 1-D layers and the 2-D ones that kernel does not take
+typedef _Float16 chf8 __attribute__((ext_vector_type(8)));
+typedef __fp16 chp2 __attribute__((ext_vector_type(2)));
+#define CB_WSHIFT 6
+template <bool F16> __device__ __forceinline__ f32x4 cb_mma(const cbf8& a, const cbf8& b, const f32x4& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(chf8, a), __builtin_bit_cast(chf8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float cb_pow2(int k) {
+  k = k < -126 ? -126 : (k > 127 ? 127 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
+}
+
+template <bool F16>
 __global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Co, int Ci, int KK, int flip) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   const int nt = (N + CD_TN - 1) / CD_TN, nch = C / CB_KC;
@@ -530,14 +551,23 @@ __global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* 
     const int n = tile * CD_TN + nl, c = ch * CB_KC + cl;
     float v = 0.0f;
     if (n < N) v = flip ? w[((int64_t)c * Ci + n) * KK + (KK - 1 - t)] : w[((int64_t)n * Ci + c) * KK + t];
-    const __bf16 hi = (__bf16)v;
-    wt[e] = hi;
-    wt[total + e] = (__bf16)(v - (float)hi);
+    if constexpr (F16) {
+      const float t = v * (float)(1 << CB_WSHIFT);
+      const _Float16 hi = (_Float16)t;
+      reinterpret_cast<_Float16*>(wt)[e] = hi;
+      reinterpret_cast<_Float16*>(wt)[total + e] = (_Float16)(t - (float)hi);
+    } else {
+      const __bf16 hi = (__bf16)v;
+      wt[e] = hi;
+      wt[total + e] = (__bf16)(v - (float)hi);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void pv_conv3_direct_bf16_kernel(ConvD p) {
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
   extern __shared__ __attribute__((aligned(16))) char smb_[];
+  __shared__ float smax[2][4];                        // F16: the waves' patch maxima of the chunk being staged
   const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : CD_PIX + 2, NPIX = PH * PW;
   const int TG = 3;                                  // taps per weight stage: one kernel row (2-D) / all three (1-D)
   __bf16* wh = reinterpret_cast<__bf16*>(smb_);                       // [TG][64][32]
@@ -596,13 +626,57 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_bf16_kernel(ConvD p) {
   }
   CB_FETCH_P(0);
   CB_FETCH_W(0);
+  int E_cur = 0, E_min = 1 << 20;                     // F16: the patch scale 2^E of the current chunk, the smallest so far
+  auto wave_max = [&](int slot) {
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PKB; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(pv[k][i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) smax[slot][wave] = m;
+    __threadfence_block();                            // (the write must have landed before the next barrier lets the others read:
+                                                      //  hipcc 7.2 emits no s_waitcnt lgkmcnt between this store and the loop's s_barrier)
+  };
+  if constexpr (F16) wave_max(0);
   for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();                                 // the previous chunk's reads of the patch are done
+    __syncthreads();                                 // the previous chunk's reads of the patch are done (F16: smax is in)
+    float psc = 1.0f;
+    if constexpr (F16) {
+      const float m = fmaxf(fmaxf(smax[ch & 1][0], smax[ch & 1][1]), fmaxf(smax[ch & 1][2], smax[ch & 1][3]));
+      const int e = (int)((__float_as_uint(m) >> 23) & 255);
+      int E = E_cur;                                  // a (near-)zero chunk keeps the scale
+      if (e >= 20) {
+        E = 140 - e;                                  // max -> [2^13, 2^14)
+        if (E_min != (1 << 20) && E > E_min + 30) E = E_min + 30;
+        if (E < E_min) E_min = E;
+      }
+      if (ch > 0 && E != E_cur) {
+        const float ratio = cb_pow2(E - E_cur);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] *= ratio;
+      }
+      E_cur = E;
+      psc = cb_pow2(E);
+    }
 #pragma unroll
     for (int k = 0; k < PKB; ++k) {                  // patch: pixel, channels 4*f4 .. 4*f4+3 -> (hi, lo)
       cbf4 h4, l4;
+      if constexpr (F16) {
+        const f32x4 t = pv[k] * psc;
+        const chp2 h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]), h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
+        const chp2 l01 = __builtin_amdgcn_cvt_pkrtz(t[0] - (float)h01[0], t[1] - (float)h01[1]);
+        const chp2 l23 = __builtin_amdgcn_cvt_pkrtz(t[2] - (float)h23[0], t[3] - (float)h23[1]);
+        typedef unsigned int cu2 __attribute__((ext_vector_type(2)));
+        h4 = __builtin_bit_cast(cbf4, cu2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)});
+        l4 = __builtin_bit_cast(cbf4, cu2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)});
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const __bf16 hh = (__bf16)pv[k][i]; h4[i] = hh; l4[i] = (__bf16)(pv[k][i] - (float)hh); }
+        for (int i = 0; i < 4; ++i) { const __bf16 hh = (__bf16)pv[k][i]; h4[i] = hh; l4[i] = (__bf16)(pv[k][i] - (float)hh); }
+      }
       if (pls[k] >= 0) {
         *reinterpret_cast<cbf4*>(ph + pls[k]) = h4;
         *reinterpret_cast<cbf4*>(pl + pls[k]) = l4;
@@ -643,17 +717,27 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_bf16_kernel(ConvD p) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA32B(ah[cb], bh[pb], acc[cb][pb]);
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = cb_mma<F16>(ah[cb], bh[pb], acc[cb][pb]);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA32B(ah[cb], bl[pb], acc[cb][pb]);
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = cb_mma<F16>(ah[cb], bl[pb], acc[cb][pb]);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = MFMA32B(al[cb], bh[pb], acc[cb][pb]);
+          for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = cb_mma<F16>(al[cb], bh[pb], acc[cb][pb]);
       }
     }
+    if constexpr (F16) {
+      if (ch + 1 < nch) wave_max((ch + 1) & 1);       // (the next chunk's values arrived under the MFMAs)
+    }
+  }
+  if constexpr (F16) {
+    const float inv = cb_pow2(-(E_cur + CB_WSHIFT));
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) acc[cb][pb] *= inv;
   }
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {

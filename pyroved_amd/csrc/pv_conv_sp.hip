@@ -184,21 +184,27 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
       sp_wprep_elem<2, true>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
       continue;
     }
-    if (E.kind >= 2) {
+    if (E.kind >= 2 && E.kind != 6) {
       if (E.kind == 3) sp_wprep_elem<3>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
       else sp_wprep_elem<2>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
       continue;
     }
     // pv_conv_direct.hip's tilings: [n tile][chunk][tap][64][KC], KC = 16 fp32 (kind 0) / 32 bf16 hi + lo arrays (kind 1)
     const int N = flip ? Ci : Co, C = flip ? Co : Ci;
-    const int KC = E.kind == 1 ? 32 : 16, nch = C / KC;
+    const int KC = E.kind == 0 ? 16 : 32, nch = C / KC;                 // kind 6: as 1, fp16 pieces of the value times 2^6
     const int cl = (int)(e % KC), nl = (int)((e / KC) % 64), tp = (int)((e / (KC * 64)) % KK);
     const int ch = (int)((e / ((int64_t)KC * 64 * KK)) % nch), tile = (int)(e / ((int64_t)KC * 64 * KK * nch));
     const int n = tile * 64 + nl, c = ch * KC + cl;
     float v = 0.0f;
     if (n < N) v = flip ? E.w[((int64_t)c * Ci + n) * KK + (KK - 1 - tp)] : E.w[((int64_t)n * Ci + c) * KK + tp];
     if (E.kind == 0) reinterpret_cast<float*>(E.dst)[e] = v;
-    else {
+    else if (E.kind == 6) {
+      const float tv = v * SP_F16_WSCALE;
+      const _Float16 hi = (_Float16)tv;
+      _Float16* d = reinterpret_cast<_Float16*>(E.dst);
+      d[e] = hi;
+      d[E.total + e] = (_Float16)(tv - (float)hi);
+    } else {
       const __bf16 hi = (__bf16)v;
       __bf16* d = reinterpret_cast<__bf16*>(E.dst);
       d[e] = hi;
@@ -217,7 +223,7 @@ static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
 
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd) {
   if (kind == 4) return -1;                          // (sized by the caller: out * F floats)
-  if (kind >= 2) return pv_conv3_sp_wt_bytes(Ci, Co);
+  if (kind >= 2 && kind != 6) return pv_conv3_sp_wt_bytes(Ci, Co);
   return pv_conv3_direct_wt_floats(Ci, Co, nd) * (int64_t)sizeof(float);
 }
 
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) smax[slot][wave] = m;
+    __threadfence_block();                            // (landed before the next barrier: see pv_conv3_direct_bf16_kernel)
   };
   if constexpr (F16) wave_max(0);
   for (int ch = 0; ch < nch; ++ch) {
@@ -575,11 +582,14 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
 }
 
 // test / measurement hook: one convolution call on caller-provided device tensors.
-// mode 0: f32-input MFMA direct kernel, 1: its bf16 two-piece form, 2 / 3: this file's kernels with 2 / 3 pieces
+// mode 0: f32-input MFMA direct kernel, 1: its bf16 two-piece form, 5: its fp16 two-piece form, 2 / 3: this file's kernels with
+// 2 / 3 bf16 pieces, 4: with two fp16 pieces
 extern "C" int pv_debug_conv3(int mode, const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip,
                               const float* bias, float* out, int act, void* wt_scratch, const float* eg_y, int eg_act,
                               void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (mode == 5)      // the round-1 tile kernel (1-D and 2-D) on fp16 two-piece operands
+    return pv_conv3_direct(in, B, H, W, nd, w, Co, Ci, flip, bias, out, act, reinterpret_cast<float*>(wt_scratch), s, eg_y, eg_act, 2);
   if (mode >= 2) return nd == 2 ? pv_conv3_sp(in, B, H, W, w, Co, Ci, flip, bias, out, act, wt_scratch, s, eg_y, eg_act, mode)
                                 : PV_EINVAL;
   return pv_conv3_direct(in, B, H, W, nd, w, Co, Ci, flip, bias, out, act, reinterpret_cast<float*>(wt_scratch), s, eg_y, eg_act,
@@ -755,6 +765,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { md = fmaxf(md, __shfl_xor(md, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
     if (lane == 0) { smx[slot][0][wave] = md; smx[slot][1][wave] = mp; }
+    __threadfence_block();                           // (landed before the next barrier: see pv_conv3_direct_bf16_kernel)
   };
   if constexpr (F16) { if (t_lo < t_hi) wave_max(0); }
   int par = 0;

@@ -102,12 +102,16 @@ inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
   return sc.wt + sc.wtp->off[2 * slot + flip];
 }
 
+// pv_conv3_direct's precision argument: 1 two bf16 pieces (mixed), 2 two fp16 pieces with exact scaling (fp32-class), 0 the
+// f32-input MFMA (PV_SP_X6=1, or fewer than 32 input channels)
+inline int direct_mode(const Scratch& sc) { return sc.conv_bf16 ? 1 : (pv_conv3_sp_fp32_mode() == 4 ? 2 : 0); }
+
 // which tiling (pv_conv_wprep_table kind) a kernel-3 convolution uses in an orientation; -1: none (GEMM fallback, k1)
 inline int wt_kind(const pv_op& o, int nd, int flip, int conv_bf16) {
   if (o.kind != PV_OP_CONV || o.ksize != 3) return -1;
   const int C = flip ? o.cout : o.cin, N = flip ? o.cin : o.cout, act = flip ? PV_ACT_NONE : o.act;
   if (pv_conv3_sp_supported(C, N, nd, act)) return conv_bf16 ? 2 : (pv_conv3_sp_fp32_mode() == 4 ? 5 : 3);
-  if (pv_conv3_direct_supported(C, N, nd, act)) return (conv_bf16 && C % 32 == 0) ? 1 : 0;
+  if (pv_conv3_direct_supported(C, N, nd, act)) return C % 32 == 0 ? (conv_bf16 ? 1 : (pv_conv3_sp_fp32_mode() == 4 ? 6 : 0)) : 0;
   return -1;
 }
 
@@ -164,7 +168,7 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
                            sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), wt_ready(sc, slot, 0));
       if (pv_conv3_direct_supported(o.cin, o.cout, nd, o.act))
         return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr,
-                               0, sc.conv_bf16, wt_ready(sc, slot, 0));
+                               0, direct_mode(sc), wt_ready(sc, slot, 0));
       return conv3_fwd(in, B, si.H, si.W, si.C, nd, params + o.w_off, bias, out, o.cout, o.act, sc.ws, sc.ws_bytes, s);
     }
     return linear_fwd(in, K, params + o.w_off, bias, out, nullptr, o.cout, rows, K, o.cout, o.act, sc.ws, sc.ws_bytes, s);
@@ -213,7 +217,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s,
-                               in, fuse_act, sc.conv_bf16, wt_ready(sc, slot, 1));
+                               in, fuse_act, direct_mode(sc), wt_ready(sc, slot, 1));
       }
       PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
       return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);

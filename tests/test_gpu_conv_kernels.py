@@ -279,3 +279,27 @@ def test_fp16_two_piece_weight_gradient_is_fp32_class_at_any_magnitude(gpu_devic
     (gw,) = torch.autograd.grad(y, wd, dy.permute(0, 3, 1, 2).double())
     assert rel_l2(dw, gw) < 2e-6
     assert rel_l2(db, dy.double().sum((0, 1, 2))) < 2e-6
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 3e4])
+@pytest.mark.parametrize("B,dims,Ci,Co", [(3, (40,), 32, 64), (2, (16,), 128, 128), (4, (64,), 64, 32), (2, (12, 20), 64, 40)])
+def test_fp16_two_piece_tile_kernel_1d_and_2d(gpu_device, scale, B, dims, Ci, Co):
+    """mode 5: the round-1 tile kernel (the 1-D decoder layers of VED run on it) with fp16 two-piece operands."""
+    nd = len(dims)
+    g = torch.Generator().manual_seed(B + Ci + Co + dims[0])
+    w = torch.randn(Co, Ci, *([3] * nd), generator=g) / (3 * Ci ** 0.5)
+    x = torch.randn(B, Ci, *dims, generator=g) * scale
+    x[:, :8] *= 1e-9
+    bias = torch.randn(Co, generator=g) * 0.1 * scale
+    H, W = (dims[0], 1) if nd == 1 else dims
+    xcl = (x.permute(0, 2, 1) if nd == 1 else x.permute(0, 2, 3, 1)).contiguous().cuda()
+    n = max(Co, Ci)
+    scratch = torch.empty(((n + 63) // 64) * 64 * n * 9 * 6 + 4096, dtype=torch.uint8, device="cuda")
+    out = torch.full((B, H, W, Co), float("nan"), device="cuda")
+    wc, bc = w.cuda(), bias.cuda()
+    rc = lib().pv_debug_conv3(5, ptr(xcl), B, H, W, nd, ptr(wc), Co, Ci, 0, ptr(bc), ptr(out), 0, ptr(scratch), P(0), 0, stream())
+    assert rc == 0
+    conv = F.conv1d if nd == 1 else F.conv2d
+    ref = conv(x.double(), w.double(), bias.double(), padding=1)
+    ref = (ref.permute(0, 2, 1) if nd == 1 else ref.permute(0, 2, 3, 1)).reshape(B, H, W, Co)
+    assert rel_l2(out, ref) < 2e-6
