@@ -3,6 +3,17 @@
 #pragma once
 #include "pv_common.h"
 
+// The split-order reductions that finish the weight gradients of a step, recorded while the backward runs and done by ONE
+// launch at its end (pv_wgrad_finish_all) instead of one launch per layer.  A deferring weight gradient takes its partials'
+// workspace from the list's region (it must survive until then); a null / full list means "finish now".
+struct PvFinishEntry { const float* part; float* out; const float* part_b; float* out_b; int64_t n; int nsplit, nb, blk0, nblk; };
+struct PvFinishList { PvFinishEntry e[16]; int n; char* base; int64_t off, cap; };
+// ws / ws_bytes for a weight gradient needing `need` bytes: a slice of the list's region (returns true: deferred) or the caller's
+bool pv_wgrad_ws(PvFinishList* list, int64_t need, void*& ws, int64_t& ws_bytes);
+int pv_wgrad_finish(PvFinishList* list, const float* part, int nsplit, int64_t n, float* out, const float* part_b, int nb,
+                    float* out_b, hipStream_t s);
+int pv_wgrad_finish_all(PvFinishList* list, hipStream_t s);
+
 int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s);
 // eg_act != NONE: din *= act'(in) (in = the pooled tensor = the producing conv's post-activation output)
 int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int nd, hipStream_t s,
@@ -21,16 +32,16 @@ int64_t pv_conv3_direct_wt_floats(int C, int Cout, int nd);
 bool pv_conv3_wgrad_direct_supported(int C, int Cout, int nd);
 int64_t pv_conv3_wgrad_direct_ws(int B, int H, int W, int C, int Cout, int nd);
 int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db, int Cout,
-                          void* ws, int64_t ws_bytes, hipStream_t s);
+                          void* ws, int64_t ws_bytes, hipStream_t s, PvFinishList* defer = nullptr);
 // one input channel (first encoder layer): a streaming reduction instead of a GEMM (pv_conv_direct.hip)
 bool pv_conv3_wgrad_c1_supported(int C, int Cout, int nd);
 int64_t pv_conv3_wgrad_c1_ws(int B, int H, int W, int C, int Cout, int nd);
 int pv_conv3_wgrad_c1(const float* dy, const float* in, int B, int H, int W, int nd, float* dw, float* db, int Cout, void* ws,
-                      int64_t ws_bytes, hipStream_t s);
+                      int64_t ws_bytes, hipStream_t s, PvFinishList* defer = nullptr);
 // eg_y / eg_act: optionally out *= act'(eg_y) (eg_y shaped like out): the producing layer's activation backward fused
 // into the input-gradient form
 int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db,
-                               int Cout, void* ws, int64_t ws_bytes, hipStream_t s);     // C % 32 == 0 (mixed precision)
+                               int Cout, void* ws, int64_t ws_bytes, hipStream_t s, PvFinishList* defer = nullptr);     // C % 32 == 0 (mixed precision)
 int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip, const float* bias,
                     float* out, int act, float* wt_scratch, hipStream_t s, const float* eg_y = nullptr, int eg_act = 0,
                     int use_bf16 = 0, const void* wt_ready = nullptr);
@@ -52,7 +63,7 @@ int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s);
 bool pv_conv3_sp_wgrad_supported(int C, int Cout, int nd);
 int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout);
 int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,
-                      int64_t ws_bytes, hipStream_t s, int ns);
+                      int64_t ws_bytes, hipStream_t s, int ns, PvFinishList* defer = nullptr);
 // first encoder block (conv k3 from one channel + activation + 2x max-pool) fused (pv_conv_c1.hip); code: one byte per
 // pooled value
 bool pv_c1_convpool_supported(int Cin, int Cout, int nd, int act, int H, int W);
@@ -60,7 +71,7 @@ int64_t pv_c1_convpool_ws(int B, int H, int W, int Cout);
 int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, const float* bias, int Cout, int act, float* out,
                        unsigned char* code, hipStream_t s);
 int pv_c1_convpool_bwd(const float* g, const float* y, const unsigned char* code, const float* x, int B, int H, int W, int Cout,
-                       int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s);
+                       int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s, PvFinishList* defer = nullptr);
 // the Linear head over a channels-last feature map without transposes (pv_convhead.hip); wt: the weight re-indexed to
 // [out][s*C + c] (pv_conv_wprep_table kind 4: Co = out, Ci = C, KK = S)
 bool pv_convhead_supported(int64_t F, int out);

@@ -185,8 +185,9 @@ int64_t pv_c1_convpool_ws(int B, int H, int W, int Cout) {
 
 // g: dL/d(pooled output), y: the pooled output, code: from the forward.  dw (Cout, 1, 3, 3), db (Cout) or null.
 int pv_c1_convpool_bwd(const float* g, const float* y, const unsigned char* code, const float* x, int B, int H, int W, int Cout,
-                       int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s) {
+                       int act, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t s, PvFinishList* defer) {
   if (!pv_c1_convpool_supported(1, Cout, 2, act, H, W) || W > 3000) return PV_EINVAL;
+  if (!pv_wgrad_ws(defer, pv_c1_convpool_ws(B, H, W, Cout), ws, ws_bytes)) defer = nullptr;
   if (ws_bytes < pv_c1_convpool_ws(B, H, W, Cout)) return PV_EWS;
   const int ns = c1p_splits(B, H / 2, W), lpw = c1p_lpw(W);
   int CP = 1;
@@ -196,9 +197,5 @@ int pv_c1_convpool_bwd(const float* g, const float* y, const unsigned char* code
   C1PoolBwd p{g, y, code, x, part, part_b, B, H, W, Cout, act, H / 2, W / 2, CP, ns, lpw};
   hipLaunchKernelGGL(pv_c1_convpool_bwd_kernel, dim3(ns), dim3(256), (size_t)lpw * 16 * (W + 2), s, p);
   PV_LAUNCH_CHECK();
-  const int64_t nw = (int64_t)Cout * 9;
-  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
-  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, part, ns, nw, dw, part_b, Cout, db);
-  PV_LAUNCH_CHECK();
-  return 0;
+  return pv_wgrad_finish(defer, part, ns, (int64_t)Cout * 9, dw, part_b, Cout, db, s);
 }

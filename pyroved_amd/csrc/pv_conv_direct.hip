@@ -331,48 +331,103 @@ __global__ __launch_bounds__(256) void pv_conv3_wgrad_direct_kernel(ConvWg p) {
 // out[e] = sum_s part[s][e] (and out_b likewise), in a fixed order: a workgroup takes 32 outputs x 8 split slices
 // (slice k sums splits k, k+8, ... ; the slices then meet in LDS in slice order) — hundreds of splits are a chain of
 // dependent-latency loads otherwise
+__device__ __forceinline__ void wgrad_finish_block(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
+                                                   const float* __restrict__ part_b, int nb, float* __restrict__ out_b,
+                                                   int64_t blk, float* sm) {
+  // few outputs (a first layer's 9 * Cout): 8 outputs x 32 slices per workgroup, otherwise 32 x 8 (pv_wgrad_finish_blocks)
+  const int og = n + (part_b ? nb : 0) <= 2048 ? 8 : 32, nsl = 256 / og;
+  const int o = threadIdx.x % og, sl = threadIdx.x / og;
+  const int64_t nblk = (n + og - 1) / og;
+  const bool isb = blk >= nblk;
+  const int64_t e = (isb ? blk - nblk : blk) * og + o, lim = isb ? nb : n;
+  const float* src = isb ? part_b : part;
+  float v = 0.0f;
+  if (e < lim) {
+    // four independent chains (a fixed order all the same) keep several loads in flight per thread
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    int s = sl;
+    for (; s + 3 * nsl < nsplit; s += 4 * nsl) {
+      v0 += src[(int64_t)s * lim + e];
+      v1 += src[(int64_t)(s + nsl) * lim + e];
+      v2 += src[(int64_t)(s + 2 * nsl) * lim + e];
+      v3 += src[(int64_t)(s + 3 * nsl) * lim + e];
+    }
+    for (; s < nsplit; s += nsl) v0 += src[(int64_t)s * lim + e];
+    v = (v0 + v1) + (v2 + v3);
+  }
+  sm[sl * og + o] = v;
+  __syncthreads();
+  if (sl == 0 && e < lim) {
+    float t = 0.0f;
+    for (int k = 0; k < nsl; ++k) t += sm[k * og + o];
+    (isb ? out_b : out)[e] = t;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n,
                                                                      float* __restrict__ out, const float* __restrict__ part_b,
                                                                      int nb, float* __restrict__ out_b) {
   __shared__ float sm[256];
-  // few outputs (a first layer's 9 * Cout): 8 outputs x 32 slices per workgroup, otherwise 32 x 8 — the launcher sizes
-  // the grid to match (pv_wgrad_finish_blocks)
-  const int og = n + (part_b ? nb : 0) <= 2048 ? 8 : 32, nsl = 256 / og;
-  const int o = threadIdx.x % og, sl = threadIdx.x / og;
-  const int64_t nblk = (n + og - 1) / og;
-  for (int64_t blk = blockIdx.x; blk < nblk + (part_b ? (nb + og - 1) / og : 0); blk += gridDim.x) {
-    const bool isb = blk >= nblk;
-    const int64_t e = (isb ? blk - nblk : blk) * og + o, lim = isb ? nb : n;
-    const float* src = isb ? part_b : part;
-    float v = 0.0f;
-    if (e < lim) {
-      // four independent chains (a fixed order all the same) keep several loads in flight per thread
-      float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-      int s = sl;
-      for (; s + 3 * nsl < nsplit; s += 4 * nsl) {
-        v0 += src[(int64_t)s * lim + e];
-        v1 += src[(int64_t)(s + nsl) * lim + e];
-        v2 += src[(int64_t)(s + 2 * nsl) * lim + e];
-        v3 += src[(int64_t)(s + 3 * nsl) * lim + e];
-      }
-      for (; s < nsplit; s += nsl) v0 += src[(int64_t)s * lim + e];
-      v = (v0 + v1) + (v2 + v3);
-    }
-    sm[sl * og + o] = v;
-    __syncthreads();
-    if (sl == 0 && e < lim) {
-      float t = 0.0f;
-      for (int k = 0; k < nsl; ++k) t += sm[k * og + o];
-      (isb ? out_b : out)[e] = t;
-    }
-    __syncthreads();
-  }
+  const int og = n + (part_b ? nb : 0) <= 2048 ? 8 : 32;
+  const int64_t total = (n + og - 1) / og + (part_b ? (nb + og - 1) / og : 0);
+  for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) wgrad_finish_block(part, nsplit, n, out, part_b, nb, out_b, blk, sm);
+}
+
+// every recorded reduction of a step in one launch: workgroup b serves entry k with blk0[k] <= b < blk0[k] + nblk[k]
+struct FinTab { PvFinishEntry e[16]; int n; };
+__global__ __launch_bounds__(256) void pv_wgrad_finish_table_kernel(FinTab t) {
+  __shared__ float sm[256];
+  int k = 0;
+  while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].blk0) ++k;
+  const PvFinishEntry E = t.e[k];
+  wgrad_finish_block(E.part, E.nsplit, E.n, E.out, E.part_b, E.nb, E.out_b, (int64_t)blockIdx.x - E.blk0, sm);
 }
 
 int pv_wgrad_finish_blocks(int64_t nw, int nb) {
   const int og = nw + nb <= 2048 ? 8 : 32;
   int64_t fb = (nw + og - 1) / og + (nb ? (nb + og - 1) / og : 0);
   return (int)(fb > 4096 ? 4096 : fb);
+}
+
+bool pv_wgrad_ws(PvFinishList* list, int64_t need, void*& ws, int64_t& ws_bytes) {
+  if (!list || !list->base || list->n >= 16 || list->off + need > list->cap) return false;
+  ws = list->base + list->off;
+  ws_bytes = need;
+  list->off += pv_align_up(need, 256);
+  return true;
+}
+
+int pv_wgrad_finish(PvFinishList* list, const float* part, int nsplit, int64_t n, float* out, const float* part_b, int nb,
+                    float* out_b, hipStream_t s) {
+  if (!part_b || !out_b) { part_b = nullptr; out_b = nullptr; nb = 0; }
+  if (list && list->n < 16) {
+    const int og = n + nb <= 2048 ? 8 : 32;
+    PvFinishEntry& E = list->e[list->n];
+    E.part = part; E.out = out; E.part_b = part_b; E.out_b = out_b; E.n = n; E.nsplit = nsplit; E.nb = nb;
+    E.nblk = (int)((n + og - 1) / og + (nb ? (nb + og - 1) / og : 0));
+    E.blk0 = list->n ? list->e[list->n - 1].blk0 + list->e[list->n - 1].nblk : 0;
+    ++list->n;
+    return 0;
+  }
+  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(pv_wgrad_finish_blocks(n, nb)), dim3(256), 0, s, part, nsplit, n, out, part_b,
+                     nb, out_b);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+int pv_wgrad_finish_all(PvFinishList* list, hipStream_t s) {
+  if (!list || list->n == 0) return 0;
+  FinTab t{};
+  t.n = list->n;
+  for (int k = 0; k < list->n; ++k) t.e[k] = list->e[k];
+  const int total = list->e[list->n - 1].blk0 + list->e[list->n - 1].nblk;
+  list->n = 0;
+  list->off = 0;
+  if (total < 1) return 0;
+  hipLaunchKernelGGL(pv_wgrad_finish_table_kernel, dim3((unsigned)total), dim3(256), 0, s, t);
+  PV_LAUNCH_CHECK();
+  return 0;
 }
 
 static int wgd_splits(int B, int H, int W, int C, int Cout, int nd) {
@@ -396,8 +451,9 @@ int64_t pv_conv3_wgrad_direct_ws(int B, int H, int W, int C, int Cout, int nd) {
 }
 
 int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db, int Cout,
-                          void* ws, int64_t ws_bytes, hipStream_t s) {
+                          void* ws, int64_t ws_bytes, hipStream_t s, PvFinishList* defer) {
   if (!pv_conv3_wgrad_direct_supported(C, Cout, nd)) return PV_EINVAL;
+  if (!pv_wgrad_ws(defer, pv_conv3_wgrad_direct_ws(B, H, W, C, Cout, nd), ws, ws_bytes)) defer = nullptr;
   if (ws_bytes < pv_conv3_wgrad_direct_ws(B, H, W, C, Cout, nd)) return PV_EWS;
   const int KK = nd == 2 ? 9 : 3;
   ConvWg p{};
@@ -413,10 +469,7 @@ int pv_conv3_wgrad_direct(const float* dy, const float* in, int B, int H, int W,
   hipLaunchKernelGGL(pv_conv3_wgrad_direct_kernel, dim3((unsigned)p.nsplit, (unsigned)(C / CD_KC), (unsigned)((Cout + CD_TN - 1) / CD_TN)),
                      dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
-  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
-  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
-  PV_LAUNCH_CHECK();
-  return 0;
+  return pv_wgrad_finish(defer, p.part, p.nsplit, nw, dw, p.part_b, Cout, db, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -494,8 +547,9 @@ int64_t pv_conv3_wgrad_c1_ws(int B, int H, int W, int C, int Cout, int nd) {
   return (int64_t)c1_splits(B, H, W, nd) * ((int64_t)Cout * (nd == 2 ? 9 : 3) + Cout) * (int64_t)sizeof(float) + 256;
 }
 int pv_conv3_wgrad_c1(const float* dy, const float* in, int B, int H, int W, int nd, float* dw, float* db, int Cout, void* ws,
-                      int64_t ws_bytes, hipStream_t s) {
+                      int64_t ws_bytes, hipStream_t s, PvFinishList* defer) {
   if (!pv_conv3_wgrad_c1_supported(1, Cout, nd)) return PV_EINVAL;
+  if (!pv_wgrad_ws(defer, pv_conv3_wgrad_c1_ws(B, H, W, 1, Cout, nd), ws, ws_bytes)) defer = nullptr;
   if (ws_bytes < pv_conv3_wgrad_c1_ws(B, H, W, 1, Cout, nd)) return PV_EWS;
   const int KK = nd == 2 ? 9 : 3, ns = c1_splits(B, H, W, nd);
   int CP = 1;
@@ -505,10 +559,7 @@ int pv_conv3_wgrad_c1(const float* dy, const float* in, int B, int H, int W, int
   hipLaunchKernelGGL(pv_conv3_wgrad_c1_kernel, dim3(ns), dim3(256), 0, s, dy, in, B, H, W, Cout, nd, CP, ns, part, part_b);
   PV_LAUNCH_CHECK();
   const int64_t nw = (int64_t)Cout * KK;
-  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
-  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, part, ns, nw, dw, part_b, Cout, db);
-  PV_LAUNCH_CHECK();
-  return 0;
+  return pv_wgrad_finish(defer, part, ns, nw, dw, part_b, Cout, db, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -879,8 +930,9 @@ __global__ __launch_bounds__(256) void pv_conv3_wgrad_bf16_kernel(ConvWg p) {
 }
 
 int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, int W, int C, int nd, float* dw, float* db,
-                               int Cout, void* ws, int64_t ws_bytes, hipStream_t s) {
+                               int Cout, void* ws, int64_t ws_bytes, hipStream_t s, PvFinishList* defer) {
   if (!pv_conv3_wgrad_direct_supported(C, Cout, nd) || C % CB_KC != 0) return PV_EINVAL;
+  if (!pv_wgrad_ws(defer, pv_conv3_wgrad_direct_ws(B, H, W, C, Cout, nd), ws, ws_bytes)) defer = nullptr;
   if (ws_bytes < pv_conv3_wgrad_direct_ws(B, H, W, C, Cout, nd)) return PV_EWS;
   const int KK = nd == 2 ? 9 : 3;
   ConvWg p{};
@@ -896,8 +948,5 @@ int pv_conv3_wgrad_direct_bf16(const float* dy, const float* in, int B, int H, i
   hipLaunchKernelGGL(pv_conv3_wgrad_bf16_kernel, dim3((unsigned)p.nsplit, (unsigned)(C / CB_KC), (unsigned)((Cout + CD_TN - 1) / CD_TN)),
                      dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
-  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
-  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
-  PV_LAUNCH_CHECK();
-  return 0;
+  return pv_wgrad_finish(defer, p.part, p.nsplit, nw, dw, p.part_b, Cout, db, s);
 }

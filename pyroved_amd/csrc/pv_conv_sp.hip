@@ -917,8 +917,9 @@ int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout) {
 }
 
 int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,
-                      int64_t ws_bytes, hipStream_t s, int ns) {
+                      int64_t ws_bytes, hipStream_t s, int ns, PvFinishList* defer) {
   if (!pv_conv3_sp_wgrad_supported(C, Cout, 2) || (ns != 2 && ns != 3 && ns != 4)) return PV_EINVAL;   // 4: fp16 two-piece
+  if (!pv_wgrad_ws(defer, pv_conv3_sp_wgrad_ws(B, H, W, C, Cout), ws, ws_bytes)) defer = nullptr;
   if (ws_bytes < pv_conv3_sp_wgrad_ws(B, H, W, C, Cout)) return PV_EWS;
   ConvWgSp p{};
   p.dy = dy; p.in = in; p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = Cout;
@@ -939,8 +940,5 @@ int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int
     else hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1>), grid, dim3(256), lds, s, p);
   }
   PV_LAUNCH_CHECK();
-  const int fb = pv_wgrad_finish_blocks(nw, db ? Cout : 0);
-  hipLaunchKernelGGL(pv_conv3_wgrad_finish_kernel, dim3(fb), dim3(256), 0, s, p.part, p.nsplit, nw, dw, p.part_b, Cout, db);
-  PV_LAUNCH_CHECK();
-  return 0;
+  return pv_wgrad_finish(defer, p.part, p.nsplit, nw, dw, p.part_b, Cout, db, s);
 }

@@ -14,6 +14,7 @@ struct NLayout {
   float* a[PV_MAX_OPS + 1];
   float* x_nsc; float* out_nsc; float* g[2];
   pvcs::Scratch sc; pvcs::WtPlan wtp; char* wt;
+  char* fin_ws; int64_t fin_bytes;
   int64_t total;
 };
 
@@ -49,6 +50,9 @@ bool ncarve(const pv_convnet_plan* p, char* base, NLayout& L) {
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
   L.sc.ws = base ? (void*)(base + c.off) : nullptr;
   c.off += L.sc.ws_bytes;
+  L.fin_bytes = pv_align_up(nd.wg_sum, 256);
+  L.fin_ws = base ? base + c.off : nullptr;
+  c.off += L.fin_bytes;
   L.sc.wt = L.wt; L.sc.wtp = &L.wtp;
   L.total = c.off;
   return true;
@@ -101,8 +105,12 @@ extern "C" int pv_convnet_backward(const pv_convnet_plan* p, const float* x, con
   pp ^= 1;
   PV_TRY(pvcs::wt_prep(p->params, p->ops, p->n_ops, p->ndim, 0, p->conv_bf16, L.wtp, L.wt, true, s));
   float* gout = nullptr;
+  PvFinishList fin{};
+  fin.base = L.fin_ws; fin.cap = L.fin_bytes;
+  L.sc.fin = &fin;
   PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->ops, p->n_ops, p->ndim, (int)B, L.a, L.sh, g, L.g, pp, dx != nullptr, &gout,
                          L.sc, s));
+  PV_TRY(pv_wgrad_finish_all(&fin, s));
   if (dx) PV_TRY(pv_nsc_to_ncs(gout, dx, B, p->in_ch, (int64_t)s0.H * s0.W, s));
   return 0;
 }

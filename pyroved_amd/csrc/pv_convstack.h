@@ -36,7 +36,8 @@ inline bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
 inline int kk_of(const pv_op& o, int nd) { return o.ksize == 3 ? (nd == 2 ? 9 : 3) : 1; }
 
 // scratch the stack's GEMMs and im2col need for B samples: running maxima
-struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0, code_bytes = 0; int bn_maxC = 0; };
+struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0, code_bytes = 0, wg_sum = 0; int bn_maxC = 0; };   // wg_sum: all the
+                                                   // kernel-3 weight gradients' partials at once (their finishes are deferred)
 #define PVCS_BN_SLOTS (2 * PV_MAX_OPS)        // per-op statistics slots: stack 0 (encoder) and stack 1 (decoder)
 inline int64_t bn_floats(const Needs& n) { return (int64_t)PVCS_BN_SLOTS * 4 * n.bn_maxC; }
 inline void upd(int64_t& m, int64_t v) { if (v > m) m = v; }
@@ -54,6 +55,7 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
   if (c1pool_fusable(ops, n, nd, s[0])) {
     upd(nd_.code_bytes, B * (s[0].H / 2) * (s[0].W / 2) * ops[0].cout);
     upd(nd_.scratch, pv_c1_convpool_ws((int)B, s[0].H, s[0].W, ops[0].cout));
+    nd_.wg_sum += pv_align_up(pv_c1_convpool_ws((int)B, s[0].H, s[0].W, ops[0].cout), 256);
   }
   for (int i = 0; i < n; ++i) {
     if (!op_shape(ops[i], nd, s[i], s[i + 1])) return false;
@@ -74,6 +76,12 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
       if (ops[i].ksize == 3) upd(nd_.scratch, pv_conv3_wgrad_direct_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
       if (ops[i].ksize == 3 && nd == 2) upd(nd_.scratch, pv_conv3_sp_wgrad_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout));
       if (ops[i].ksize == 3) upd(nd_.scratch, pv_conv3_wgrad_c1_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
+      if (ops[i].ksize == 3) {                                       // whichever weight-gradient kernel takes this layer
+        int64_t w = pv_conv3_wgrad_direct_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd);
+        upd(w, pv_conv3_wgrad_c1_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
+        if (nd == 2) upd(w, pv_conv3_sp_wgrad_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout));
+        nd_.wg_sum += pv_align_up(w, 256);
+      }
       upd(nd_.scratch, gemm_ws_need(rows, K, N));                    // dgrad, kernel 1
       upd(nd_.scratch, gemm_ws_need(rows, ops[i].cin, N * kk_of(ops[i], nd)));   // dgrad, kernel 3
     }
@@ -96,6 +104,7 @@ struct Scratch {
   int conv_bf16 = 0;                                         // kernel-3 convolutions on the bf16 matrix cores (x3)
   const char* wt = nullptr; const WtPlan* wtp = nullptr;     // the step's tiled weights (null: tile per call into col)
   unsigned char* code = nullptr;                             // winners of the fused first block's max-pool (stack 0 only)
+  PvFinishList* fin = nullptr;                               // weight-gradient finishes deferred to pv_wgrad_finish_all
 };
 inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
   if (!sc.wt || !sc.wtp || sc.wtp->off[2 * slot + flip] < 0) return nullptr;
@@ -198,13 +207,13 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     if (o.ksize == 3) {
       if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s,
-                                 sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode()));
+                                 sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), sc.fin));
       else if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
-        PV_TRY(pv_conv3_wgrad_direct_bf16(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
+        PV_TRY(pv_conv3_wgrad_direct_bf16(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, sc.fin));
       else if (pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
-        PV_TRY(pv_conv3_wgrad_direct(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
+        PV_TRY(pv_conv3_wgrad_direct(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, sc.fin));
       else if (pv_conv3_wgrad_c1_supported(si.C, o.cout, nd))
-        PV_TRY(pv_conv3_wgrad_c1(g, in, B, si.H, si.W, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
+        PV_TRY(pv_conv3_wgrad_c1(g, in, B, si.H, si.W, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, sc.fin));
       else
         PV_TRY(conv3_wgrad(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s));
       if (!gin) return 0;
@@ -261,7 +270,7 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
   for (int i = n - 1; i >= 0; --i) {
     if (c1pool && i == 1) {                            // g = dL/d(a[2]): the fused backward of ops 1 and 0
       PV_TRY(pv_c1_convpool_bwd(g, a[2], sc.code, a[0], B, sh[0].H, sh[0].W, ops[0].cout, ops[0].act, grads + ops[0].w_off,
-                                ops[0].b_off >= 0 ? grads + ops[0].b_off : nullptr, sc.ws, sc.ws_bytes, s));
+                                ops[0].b_off >= 0 ? grads + ops[0].b_off : nullptr, sc.ws, sc.ws_bytes, s, sc.fin));
       g = nullptr;
       break;
     }

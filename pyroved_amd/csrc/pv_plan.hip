@@ -53,6 +53,7 @@ struct Layout {
   pvcs::WtPlan cwtp; char* cwt;                            // the step's tiled conv-encoder weights
   unsigned char* ccode;                                    // max-pool winners of the fused first block
   float* chead_wt;                                         // the head's weight re-indexed channels-last (null: GEMM path)
+  char* cfin_ws; int64_t cfin_bytes;                       // the conv encoder's weight-gradient partials until the one finish launch
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
   int64_t rows;                            // decoder rows: B*N (spatial) or B (vanilla)
   int nchunk, rows_per_chunk;
@@ -103,7 +104,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
   const int n_enc = (L.enc_conv || L.enc_ext) ? 0 : p->n_enc;
   pvcs::Needs cnd;
-  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr; L.chead_wt = nullptr;
+  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr; L.chead_wt = nullptr; L.cfin_ws = nullptr; L.cfin_bytes = 0;
   if (L.enc_conv) {
     L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
     if ((int64_t)L.ces[0].H * L.ces[0].W == p->n_pix && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
@@ -233,6 +234,11 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.scratch_bytes = pv_align_up(scratch, 256);
   L.scratch = base ? (void*)(base + c.off) : nullptr;
   c.off += L.scratch_bytes;
+  if (L.enc_conv && L.cF >= 0) {
+    L.cfin_bytes = pv_align_up(cnd.wg_sum, 256);
+    L.cfin_ws = base ? base + c.off : nullptr;
+    c.off += L.cfin_bytes;
+  }
   L.total = c.off;
 }
 
@@ -458,9 +464,13 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
     sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // tiled by this step's conv_encoder_fwd
     sc.code = L.ccode;
+    PvFinishList wfin{};                              // the weight gradients' reductions: one launch after the stack
+    wfin.base = L.cfin_ws; wfin.cap = L.cfin_bytes;
+    sc.fin = &wfin;
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
                            nullptr, sc, s, 0, g_is_pre));
+    PV_TRY(pv_wgrad_finish_all(&wfin, s));
     if (fin) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
     for (int i = 0; i < n_extra; i += 4) PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s));
     return 0;

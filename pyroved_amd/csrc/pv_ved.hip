@@ -33,6 +33,7 @@ struct VLayout {
   pvcs::Scratch sc;                                    // im2col / dcol scratch + GEMM split-K scratch
   pvcs::WtPlan wtp; char* wt;                          // the step's tiled conv weights (both stacks, both orientations)
   float* head_wt;                                      // features2latent's weight re-indexed channels-last (null: GEMM path)
+  char* fin_ws; int64_t fin_bytes;                     // every weight gradient's partials until the one finish launch
   int64_t F;                                           // flattened feature size C*S of the encoder output
   int64_t total;
 };
@@ -97,6 +98,9 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
   L.sc.ws = base ? (void*)(base + c.off) : nullptr;
   c.off += L.sc.ws_bytes;
+  L.fin_bytes = pv_align_up(nd.wg_sum, 256);
+  L.fin_ws = base ? base + c.off : nullptr;
+  c.off += L.fin_bytes;
   L.total = c.off;
   L.sc.wt = L.wt; L.sc.wtp = &L.wtp;
   return true;
@@ -184,6 +188,9 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, nullptr, 0, p->beta, s));
   if (!want_grads) return 0;
 
+  PvFinishList fin{};                                  // the conv stacks' weight-gradient reductions: one launch at the end
+  fin.base = L.fin_ws; fin.cap = L.fin_bytes;
+  L.sc.fin = &fin;
   // ---- backward: decoder ops in reverse ----
   float* g = nullptr;                                  // (dlda = dL/d(output of the last op), loss = -ELBO)
   int pp = 0;
@@ -226,8 +233,9 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
     pp ^= 1;
   }
   // ---- encoder ops in reverse (no input gradient for the first one) ----
-  return pvcs::stack_bwd(p->params, p->grads, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, g, L.g, pp, false,
-                         nullptr, L.sc, s, 0, g_is_pre);
+  PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, g, L.g, pp, false,
+                         nullptr, L.sc, s, 0, g_is_pre));
+  return pv_wgrad_finish_all(&fin, s);
 }
 
 extern "C" int pv_ved_encode(const pv_ved_plan* p, float* z_loc, float* z_scale, void* stream) {
