@@ -53,7 +53,12 @@ bool pv_conv3_sp_supported(int C, int Cout, int nd, int act);
 int pv_conv3_sp_fp32_mode();
 int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
-                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr);
+                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr,
+                float* pool_out = nullptr, unsigned char* pool_code = nullptr);
+// pool_out / pool_code (forward form, even H and W): the 2x max-pool of the output (B, H/2, W/2, Co) and one byte per pooled value
+// (which of the 2x2 positions won) are written INSTEAD of the full-resolution output; pv_maxpool2_bwd_code is its backward
+int pv_maxpool2_bwd_code(const float* g, const float* y_pooled, const unsigned char* code, float* din, int B, int Hp, int Wp, int C,
+                         int eg_act, hipStream_t s);
 // all of a step's weight tilings in one launch (per 16 entries).  kind 0: pv_conv3_direct f32, 1: its bf16 two-piece form,
 // 6: that kernel's fp16 two-piece form, 2 / 3: pv_conv3_sp with 2 / 3 bf16 pieces, 5: its fp16 two-piece form (ns = 4), 4: a conv head's Linear weight re-indexed channels-last (Co = out, Ci = C,
 // KK = spatial size); dst sized by pv_conv_wt_bytes

@@ -102,6 +102,34 @@ __global__ void pv_maxpool2_bwd4_kernel(const float* __restrict__ in, const floa
   }
 }
 
+// backward of a max-pool whose forward kept only the pooled values and the winners (pv_conv3_sp with pool_out): din (B, 2 Hp,
+// 2 Wp, C) = g * act'(y_pooled) at the winning position of each window, zero elsewhere; one thread per (window, 4 channels)
+__global__ void pv_maxpool2_bwd_code_kernel(const float* __restrict__ g, const float* __restrict__ yp, const unsigned char* __restrict__ code,
+                                            float* __restrict__ din, int B, int Hp, int Wp, int C, int eg_act) {
+  const int C4 = C / 4, W = 2 * Wp;
+  const int64_t total = (int64_t)B * Hp * Wp * C4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % C4);
+    const int64_t w = e / C4;
+    const int ox = (int)(w % Wp), oy = (int)((w / Wp) % Hp);
+    const int64_t b = w / ((int64_t)Wp * Hp);
+    f32x4 v = *reinterpret_cast<const f32x4*>(g + w * C + 4 * c4);
+    if (eg_act != PV_ACT_NONE) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(yp + w * C + 4 * c4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= pv_act_grad(y[i], 0.0f, eg_act);
+    }
+    const unsigned cd = *reinterpret_cast<const unsigned*>(code + w * C + 4 * c4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = ((cd >> (8 * i)) & 3u) == (unsigned)k ? v[i] : 0.0f;
+      *reinterpret_cast<f32x4*>(din + (((b * 2 * Hp + 2 * oy + (k >> 1)) * W) + 2 * ox + (k & 1)) * C + 4 * c4) = o;
+    }
+  }
+}
+
 // out[b][y][x][c] = in[b][y/2][x/2][c]
 __global__ void pv_upsample2_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
                                         int nd) {
@@ -255,6 +283,11 @@ int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H
     CONV_LAUNCH(pv_maxpool2_bwd4_kernel, (int64_t)B * (H / 2) * (nd == 2 ? W / 2 : 1) * (C / 4), in, dout, din, B, H, W, C, nd,
                 eg_act);
   CONV_LAUNCH(pv_maxpool2_bwd_kernel, (int64_t)B * H * W * C, in, dout, din, B, H, W, C, nd, eg_act);
+}
+int pv_maxpool2_bwd_code(const float* g, const float* y_pooled, const unsigned char* code, float* din, int B, int Hp, int Wp, int C,
+                         int eg_act, hipStream_t s) {
+  if (C % 4 != 0 || eg_act == PV_ACT_GELU) return PV_EINVAL;
+  CONV_LAUNCH(pv_maxpool2_bwd_code_kernel, (int64_t)B * Hp * Wp * (C / 4), g, y_pooled, code, din, B, Hp, Wp, C, eg_act);
 }
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s) {
   CONV_LAUNCH(pv_upsample2_fwd_kernel, (int64_t)B * 2 * H * (nd == 2 ? 2 * W : 1) * C, in, out, B, H, W, C, nd);

@@ -54,6 +54,7 @@ struct ConvSp {
   const float* in; const char* wt; const float* bias; float* out;
   const float* eg_y; int eg_act;      // optional: out *= act'(eg_y) elementwise (the producing layer's activation backward)
   int B, H, W, Cin, Cout, act, tiles_x, tiles_y, halves;
+  float* pool_out; unsigned char* pool_code;   // != null: write maxpool2(out) (B, H/2, W/2, Cout) and its winners instead of out
 };
 
 // (hi16(b) << 16) | hi16(a): two truncated bf16 out of two fp32 bit patterns
@@ -479,6 +480,52 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
     ok[pb] = y < p.H && x < p.W;
     ro[pb] = (((int64_t)b * p.H + y) * p.W + x) * p.Cout;
   }
+  if (p.pool_out) {
+    // 2x max-pool fused (H, W even): a pixel block pb is the two image lines of one pooled line; the window of pooled pixel
+    // (pb, j) is lanes r = 2j, 2j + 1, 2j + 8, 2j + 9 of each 16-lane group — partners by DPP (quad xor 1, row rotate 8).
+    // Strict > in scan order: the first maximum wins, like torch; the winner's index goes to pool_code.
+    const bool writer = (r & 9) == 0;                 // r in {0, 2, 4, 6}
+    const int ppy = (y0 >> 1) + 4 * wy, ppx = (x0 >> 1) + 4 * wx + (r >> 1);
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      const bool okp = ppy + pb < Hp && ppx < Wp;
+      const int64_t po = (((int64_t)b * Hp + ppy + pb) * Wp + ppx) * p.Cout;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int co = cot * SP_TN + hco + cb * 16 + 4 * q;
+        f32x4 m;
+        unsigned code = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v00 = acc[cb][pb][i];
+          const int b00 = __float_as_int(v00);
+          const float v01 = __int_as_float(__builtin_amdgcn_update_dpp(0, b00, 0xB1, 0xF, 0xF, false));     // lane r ^ 1
+          const int b10 = __builtin_amdgcn_update_dpp(0, b00, 0x128, 0xF, 0xF, false);                       // lane (r + 8) % 16
+          const float v10 = __int_as_float(b10);
+          const float v11 = __int_as_float(__builtin_amdgcn_update_dpp(0, b10, 0xB1, 0xF, 0xF, false));
+          float mi = v00;
+          unsigned bi = 0;
+          if (v01 > mi) { mi = v01; bi = 1; }
+          if (v10 > mi) { mi = v10; bi = 2; }
+          if (v11 > mi) { mi = v11; bi = 3; }
+          m[i] = mi;
+          code |= bi << (8 * i);
+        }
+        if (writer && okp) {
+          if (vec && co + 3 < p.Cout) {
+            *reinterpret_cast<f32x4*>(p.pool_out + po + co) = m;
+            *reinterpret_cast<unsigned*>(p.pool_code + po + co) = code;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (co + i < p.Cout) { p.pool_out[po + co + i] = m[i]; p.pool_code[po + co + i] = (unsigned char)(code >> (8 * i)); }
+          }
+        }
+      }
+    }
+    return;
+  }
   if (p.eg_y) {                                       // out *= act'(eg_y): the producing layer's activation backward
     f32x4 gy[NCB][4];
 #pragma unroll
@@ -566,7 +613,8 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
 // flip == 1: out[.., Ci] = conv of in[.., Co] with the flipped / role-swapped weights (the input gradient).
 // ns = 3: fp32-class (six products); ns = 2: mixed precision (three products).  wt_scratch: pv_conv3_sp_wt_bytes bytes.
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
-                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready) {
+                int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready, float* pool_out,
+                unsigned char* pool_code) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   if (!pv_conv3_sp_supported(C, N, 2, act) || (ns != 2 && ns != 3 && ns != 4)) return PV_EINVAL;   // 4: fp16 two-piece
   const int nt = (N + SP_TN - 1) / SP_TN;
@@ -576,6 +624,10 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
   p.eg_y = (eg_y && eg_act != PV_ACT_NONE) ? eg_y : nullptr; p.eg_act = eg_act;
   p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = N; p.act = act;
   p.tiles_x = (W + SP_T - 1) / SP_T; p.tiles_y = (H + SP_T - 1) / SP_T;
+  if (pool_out) {                                    // fused 2x max-pool: forward form, even image sides
+    if (flip || !pool_code || (H & 1) || (W & 1) || p.eg_y) return PV_EINVAL;
+    p.pool_out = pool_out; p.pool_code = pool_code;
+  }
   char* prep = wt_ready ? nullptr : reinterpret_cast<char*>(wt_scratch);    // null: tiled already (pv_conv_wprep_table)
   if (ns == 4) return conv3_sp_launch<2, true>(p, w, Co, Ci, flip, prep, nt, total, s);
   return ns == 3 ? conv3_sp_launch<3>(p, w, Co, Ci, flip, prep, nt, total, s) : conv3_sp_launch<2>(p, w, Co, Ci, flip, prep, nt, total, s);
@@ -941,4 +993,13 @@ int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int
   }
   PV_LAUNCH_CHECK();
   return pv_wgrad_finish(defer, p.part, p.nsplit, nw, dw, p.part_b, Cout, db, s);
+}
+
+// test hook: convolution + activation + fused 2x max-pool (pooled values and winner bytes), and the pooling's backward
+extern "C" int pv_debug_conv3_pool(int mode, const float* in, int B, int H, int W, const float* w, int Co, int Ci, const float* bias,
+                                   int act, float* pooled, unsigned char* code, void* wt_scratch, const float* g, float* din,
+                                   void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!g) return pv_conv3_sp(in, B, H, W, w, Co, Ci, 0, bias, pooled, act, wt_scratch, s, nullptr, 0, mode, nullptr, pooled, code);
+  return pv_maxpool2_bwd_code(g, pooled, code, din, B, H / 2, W / 2, Co, act, s);
 }

@@ -47,6 +47,7 @@ bool ncarve(const pv_convnet_plan* p, char* base, NLayout& L) {
   L.wt = reinterpret_cast<char*>(c.take((L.wtp.bytes + 3) / 4));
   // (the fused first block has no input gradient: only when the caller will not ask for dL/dx)
   L.sc.code = (nd.code_bytes && !p->need_dx) ? reinterpret_cast<unsigned char*>(c.take((nd.code_bytes + 3) / 4)) : nullptr;
+  L.sc.code2 = nd.code2_bytes ? reinterpret_cast<unsigned char*>(c.take((nd.code2_bytes + 3) / 4)) : nullptr;
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
   L.sc.ws = base ? (void*)(base + c.off) : nullptr;
   c.off += L.sc.ws_bytes;

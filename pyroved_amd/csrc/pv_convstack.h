@@ -36,7 +36,7 @@ inline bool op_shape(const pv_op& o, int nd, const Shape& in, Shape& out) {
 inline int kk_of(const pv_op& o, int nd) { return o.ksize == 3 ? (nd == 2 ? 9 : 3) : 1; }
 
 // scratch the stack's GEMMs and im2col need for B samples: running maxima
-struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0, code_bytes = 0, wg_sum = 0; int bn_maxC = 0; };   // wg_sum: all the
+struct Needs { int64_t maxact = 0, maxcol = 0, scratch = 0, code_bytes = 0, code2_bytes = 0, wg_sum = 0; int bn_maxC = 0; };   // wg_sum: all the
                                                    // kernel-3 weight gradients' partials at once (their finishes are deferred)
 #define PVCS_BN_SLOTS (2 * PV_MAX_OPS)        // per-op statistics slots: stack 0 (encoder) and stack 1 (decoder)
 inline int64_t bn_floats(const Needs& n) { return (int64_t)PVCS_BN_SLOTS * 4 * n.bn_maxC; }
@@ -47,6 +47,21 @@ inline void upd(int64_t& m, int64_t v) { if (v > m) m = v; }
 inline bool c1pool_fusable(const pv_op* ops, int n, int nd, const Shape& s0) {
   return n >= 2 && ops[0].kind == PV_OP_CONV && ops[0].ksize == 3 && ops[1].kind == PV_OP_MAXPOOL2 && s0.C == 1 &&
          pv_c1_convpool_supported(ops[0].cin, ops[0].cout, nd, ops[0].act, s0.H, s0.W);
+}
+
+// a 2-D kernel-3 convolution the split-operand kernel takes, followed by the 2x max-pool, on even image sides: the pooling
+// runs in the convolution's epilogue (pooled values + one winner byte each; the full-resolution activation is never
+// written) and its backward from those bytes (pv_maxpool2_bwd_code), the convolution's activation derivative folded in
+inline bool convpool_fusable(const pv_op* ops, int n, int nd, int i, const Shape& si) {
+  return nd == 2 && i >= 1 && i + 1 < n && ops[i].kind == PV_OP_CONV && ops[i].ksize == 3 && ops[i + 1].kind == PV_OP_MAXPOOL2 &&
+         (si.H & 1) == 0 && (si.W & 1) == 0 && (ops[i].cout & 3) == 0 && ops[i].act != PV_ACT_GELU &&
+         pv_conv3_sp_supported(ops[i].cin, ops[i].cout, nd, ops[i].act) && !getenv("PV_NO_CONVPOOL");
+}
+inline int64_t code2_off(const pv_op* ops, int n, int nd, int B, const Shape* sh, int upto) {   // winner bytes before op `upto`
+  int64_t off = 0;
+  for (int i = 1; i < upto; ++i)
+    if (convpool_fusable(ops, n, nd, i, sh[i])) off += pv_align_up((int64_t)B * (sh[i].H / 2) * (sh[i].W / 2) * ops[i].cout, 256);
+  return off;
 }
 
 // shapes s[0..n] from s[0]; accumulates workspace needs; false on an inconsistent sequence
@@ -60,6 +75,7 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
   for (int i = 0; i < n; ++i) {
     if (!op_shape(ops[i], nd, s[i], s[i + 1])) return false;
     upd(nd_.maxact, s[i + 1].elems(B));
+    if (convpool_fusable(ops, n, nd, i, s[i])) upd(nd_.code2_bytes, code2_off(ops, n, nd, (int)B, s, i + 1));
     if (ops[i].kind == PV_OP_BATCHNORM) {
       if (ops[i].cin > nd_.bn_maxC) nd_.bn_maxC = ops[i].cin;
       upd(nd_.scratch, pv_bn_ws(B * s[i].H * s[i].W, ops[i].cin));
@@ -105,6 +121,7 @@ struct Scratch {
   const char* wt = nullptr; const WtPlan* wtp = nullptr;     // the step's tiled weights (null: tile per call into col)
   unsigned char* code = nullptr;                             // winners of the fused first block's max-pool (stack 0 only)
   PvFinishList* fin = nullptr;                               // weight-gradient finishes deferred to pv_wgrad_finish_all
+  unsigned char* code2 = nullptr;                            // winners of the convolution + max-pool pairs fused further up (stack 0)
 };
 inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
   if (!sc.wt || !sc.wtp || sc.wtp->off[2 * slot + flip] < 0) return nullptr;
@@ -255,8 +272,17 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
                               ops[0].cout, ops[0].act, a[2], sc.code, s));
     i0 = 2;
   }
-  for (int i = i0; i < n; ++i)
+  for (int i = i0; i < n; ++i) {
+    if (stack_id == 0 && sc.code2 && convpool_fusable(ops, n, nd, i, sh[i])) {      // a[i + 1] is never written
+      const pv_op& o = ops[i];
+      PV_TRY(pv_conv3_sp(a[i], B, sh[i].H, sh[i].W, params + o.w_off, o.cout, o.cin, 0, o.b_off >= 0 ? params + o.b_off : nullptr,
+                         a[i + 1], o.act, sc.col, s, nullptr, 0, sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(),
+                         wt_ready(sc, stack_id * PV_MAX_OPS + i, 0), a[i + 2], sc.code2 + code2_off(ops, n, nd, B, sh, i)));
+      ++i;
+      continue;
+    }
     PV_TRY(op_fwd(params, ops[i], nd, B, a[i], sh[i], a[i + 1], sc, stack_id * PV_MAX_OPS + i, s));
+  }
   return 0;
 }
 
@@ -273,6 +299,15 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
                                 ops[0].b_off >= 0 ? grads + ops[0].b_off : nullptr, sc.ws, sc.ws_bytes, s, sc.fin));
       g = nullptr;
       break;
+    }
+    if (stack_id == 0 && sc.code2 && i >= 2 && convpool_fusable(ops, n, nd, i - 1, sh[i - 1])) {
+      // the max-pool of a fused pair: g = dL/d(a[i + 1]) -> dL/d(pre-activation of the convolution below) from the winner bytes
+      float* gin2 = gbuf[pp];
+      PV_TRY(pv_maxpool2_bwd_code(g, a[i + 1], sc.code2 + code2_off(ops, n, nd, B, sh, i - 1), gin2, B, sh[i + 1].H, sh[i + 1].W,
+                                  sh[i + 1].C, ops[i - 1].act, s));
+      g_is_pre = true;
+      g = gin2; pp ^= 1;
+      continue;
     }
     float* gin = (i > 0 || need_input_grad) ? gbuf[pp] : nullptr;
     // the layer below is a convolution with an activation: let this op's backward apply act'(a[i]) to gin

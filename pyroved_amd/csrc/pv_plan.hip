@@ -52,6 +52,7 @@ struct Layout {
   float* ccol; int64_t cF; float* cbn; int cbn_maxC;
   pvcs::WtPlan cwtp; char* cwt;                            // the step's tiled conv-encoder weights
   unsigned char* ccode;                                    // max-pool winners of the fused first block
+  unsigned char* ccode2;                                   // ... of the convolution + max-pool pairs further up
   float* chead_wt;                                         // the head's weight re-indexed channels-last (null: GEMM path)
   char* cfin_ws; int64_t cfin_bytes;                       // the conv encoder's weight-gradient partials until the one finish launch
   void* scratch; int64_t scratch_bytes;    // split-K partials / colsum partials (used by one call at a time)
@@ -104,7 +105,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
   const int n_enc = (L.enc_conv || L.enc_ext) ? 0 : p->n_enc;
   pvcs::Needs cnd;
-  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr; L.chead_wt = nullptr; L.cfin_ws = nullptr; L.cfin_bytes = 0;
+  L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr; L.ccode2 = nullptr; L.chead_wt = nullptr; L.cfin_ws = nullptr; L.cfin_bytes = 0;
   if (L.enc_conv) {
     L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
     if ((int64_t)L.ces[0].H * L.ces[0].W == p->n_pix && pvcs::stack_shapes(p->enc_ops, p->n_enc_ops, p->enc_ndim, B, L.ces, cnd)) {
@@ -122,6 +123,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       pvcs::wt_layout(p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, false, L.cwtp);
       L.cwt = reinterpret_cast<char*>(c.take((L.cwtp.bytes + 3) / 4));
       L.ccode = cnd.code_bytes ? reinterpret_cast<unsigned char*>(c.take((cnd.code_bytes + 3) / 4)) : nullptr;
+      L.ccode2 = cnd.code2_bytes ? reinterpret_cast<unsigned char*>(c.take((cnd.code2_bytes + 3) / 4)) : nullptr;
       L.cbn = c.take(pvcs::bn_floats(cnd)); L.cbn_maxC = cnd.bn_maxC;
     } else {
       L.cF = -1;                                   // inconsistent op sequence: rejected by the entry points
@@ -323,7 +325,7 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
   pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
   sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // (both orientations: the backward of the same step reuses them)
-  sc.code = L.ccode;
+  sc.code = L.ccode; sc.code2 = L.ccode2;
   const pvcs::Shape& fe0 = L.ces[p->n_enc_ops];
   const bool hfused = pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.chead_wt, p->head.out_dim, fe0.C, (int64_t)fe0.H * fe0.W);
@@ -463,7 +465,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
     pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
     sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // tiled by this step's conv_encoder_fwd
-    sc.code = L.ccode;
+    sc.code = L.ccode; sc.code2 = L.ccode2;
     PvFinishList wfin{};                              // the weight gradients' reductions: one launch after the stack
     wfin.base = L.cfin_ws; wfin.cap = L.cfin_bytes;
     sc.fin = &wfin;

@@ -58,6 +58,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   // ---- encoder ----
   L.es[0] = Shape{p->in_dim[0], p->ndim_in == 2 ? p->in_dim[1] : 1, p->in_ch};
   if (!pvcs::stack_shapes(p->enc, p->n_enc_ops, p->ndim_in, B, L.es, nd)) return false;
+  const int64_t enc_code2 = nd.code2_bytes;           // (the encoder's fused convolution + max-pool pairs; stack 0 only)
   L.x_nsc = p->in_ch > 1 ? c.take(L.es[0].elems(B)) : nullptr;
   L.ea[0] = nullptr;                                   // = x (or x_nsc), set by the caller
   for (int i = 0; i < p->n_enc_ops; ++i) L.ea[i + 1] = c.take(L.es[i + 1].elems(B));
@@ -93,6 +94,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   pvcs::wt_layout(p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, true, L.wtp);
   L.wt = reinterpret_cast<char*>(c.take((L.wtp.bytes + 3) / 4));
   L.sc.code = nd.code_bytes ? reinterpret_cast<unsigned char*>(c.take((nd.code_bytes + 3) / 4)) : nullptr;
+  L.sc.code2 = enc_code2 ? reinterpret_cast<unsigned char*>(c.take((enc_code2 + 3) / 4)) : nullptr;
   L.sc.bn = c.take(pvcs::bn_floats(nd)); L.sc.bn_maxC = nd.bn_maxC; L.sc.bn_eval = p->bn_eval;
   L.sc.conv_bf16 = p->conv_bf16;
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);

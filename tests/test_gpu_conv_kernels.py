@@ -321,3 +321,36 @@ def test_fp16_kernels_are_bit_reproducible(gpu_device, mode, nd, B, H, W, Ci, Co
             first = out.clone()
         else:
             assert torch.equal(first, out)
+
+
+@pytest.mark.parametrize("mode", [4, 3, 2])
+@pytest.mark.parametrize("B,H,W,Ci,Co,act", [(3, 16, 16, 32, 64, "lrelu"), (2, 12, 20, 64, 40, "tanh"), (1, 6, 34, 32, 8, "relu"),
+                                             (2, 32, 32, 64, 128, "none"), (5, 4, 4, 128, 72, "softplus")])
+def test_convolution_with_fused_max_pool(gpu_device, mode, B, H, W, Ci, Co, act):
+    """The 2x max-pool in the convolution's epilogue (pooled values + one winner byte each, no full-resolution output) and its
+    backward from the bytes: dL/d(pre-activation) = g * act'(pooled) at the winner, zero elsewhere."""
+    g = torch.Generator().manual_seed(B + H + Co)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).cuda()
+    bias = (torch.randn(Co, generator=g) * 0.1).cuda()
+    x = torch.randn(B, H, W, Ci, generator=g).cuda()
+    n = max(Co, Ci)
+    scratch = torch.empty(((n + 63) // 64) * 64 * n * 9 * 6 + 4096, dtype=torch.uint8, device="cuda")
+    pooled = torch.full((B, H // 2, W // 2, Co), float("nan"), device="cuda")
+    code = torch.full((B, H // 2, W // 2, Co), 255, dtype=torch.uint8, device="cuda")
+    L = lib()
+    rc = L.pv_debug_conv3_pool(mode, ptr(x), B, H, W, ptr(w), Co, Ci, ptr(bias), ACTS[act], ptr(pooled), ptr(code), ptr(scratch), P(0),
+                               P(0), stream())
+    assert rc == 0
+    pre = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1).requires_grad_(True)
+    y = act_fn(act, pre)
+    ref = F.max_pool2d(y, 2)
+    tol = 2e-6 if mode != 2 else 2e-5
+    assert rel_l2(pooled, ref.permute(0, 2, 3, 1)) < tol
+    assert int(code.max()) <= 3
+    gp = torch.randn(B, H // 2, W // 2, Co, generator=g).cuda()
+    din = torch.full((B, H, W, Co), float("nan"), device="cuda")
+    rc = L.pv_debug_conv3_pool(mode, P(0), B, H, W, P(0), Co, Ci, P(0), ACTS[act], ptr(pooled), ptr(code), P(0), ptr(gp), ptr(din), stream())
+    assert rc == 0
+    (gpre,) = torch.autograd.grad(ref, pre, gp.permute(0, 3, 1, 2).double())
+    # (ties between fp32 and fp64 winners are measure-zero for random inputs; compare as tensors)
+    assert rel_l2(din, gpre.permute(0, 2, 3, 1)) < max(tol, 1e-5)
