@@ -2,6 +2,7 @@
 _convplan.py — reads a nets/conv.py layer stack (FeatureExtractor.layers / Upsampler.layers) into the op sequence
 (pv_op[]) of the C ABI.  Shared by engine_ved.VEDEngine and engine.IVAEEngine (convolutional encoder).
 """
+import os
 from typing import Optional
 
 import torch.nn as nn
@@ -48,8 +49,12 @@ def conv_ops(layers: nn.Sequential, activation, prefix: Optional[str] = None):
         elif isinstance(mod, UpsampleBlock):
             if mod.scale_factor != 2 or mod.mode not in ("nearest", "bilinear"):
                 raise UnsupportedModel("upsampling must be 2x nearest or bilinear")
-            ops.append(("upsample2" if mod.mode == "nearest" else "upsample2_bilinear", None, None, None))
-            ops.append(("conv", mod.conv, None, None if prefix is None else "%s.%d.conv" % (prefix, pos)))
+            # interpolate, then the 1-by-1 convolution (conv.py:141-147) == the 1-by-1 convolution, then interpolate: both are
+            # linear, act on different axes, and the interpolation weights sum to one (so the bias commutes too).  The plan
+            # runs the convolution FIRST — on a quarter (2-D) / half (1-D) of the pixels, forward and backward.
+            pair = [("conv", mod.conv, None, None if prefix is None else "%s.%d.conv" % (prefix, pos)),
+                    ("upsample2" if mod.mode == "nearest" else "upsample2_bilinear", None, None, None)]
+            ops.extend(pair[::-1] if os.environ.get("PV_UPSAMPLE_FIRST") else pair)      # (the reference's order, for A/B runs)
         else:
             raise UnsupportedModel("unsupported layer %s in a conv stack" % type(mod).__name__)
         i += 1

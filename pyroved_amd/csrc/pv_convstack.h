@@ -250,8 +250,10 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     }
     PV_TRY(linear_wgrad(g, o.cout, in, K, grads + o.w_off, db, rows, K, o.cout, sc.ws, sc.ws_bytes, s));
     if (!gin) return 0;
-    return linear_dgrad(g, o.cout, params + o.w_off, gin, K, nullptr, nullptr, 0, PV_ACT_NONE, rows, K, o.cout, sc.ws,
-                        sc.ws_bytes, s);
+    // (the producing convolution's activation derivative rides in this GEMM's epilogue: act'(in), in = that layer's output)
+    if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+    return linear_dgrad(g, o.cout, params + o.w_off, gin, K, fuse_act != PV_ACT_NONE ? in : nullptr, nullptr, K, fuse_act, rows, K,
+                        o.cout, sc.ws, sc.ws_bytes, s);
   }
   if (!gin) return 0;
   if (o.kind == PV_OP_MAXPOOL2) {
