@@ -87,6 +87,11 @@ int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act
                     hipStream_t s);
 int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, void* ws,
                       int64_t ws_bytes, hipStream_t s);
+// latent_to_features (Linear z -> C*S, viewed channels-first) producing / consuming channels-last maps directly; wt: kind 7 of
+// pv_conv_wprep_table (Co = z_dim, Ci = C, KK = S): wt[k][s*C + c] = w[c*S + s][k].  The input gradient is pv_convhead_fwd(g, wt).
+bool pv_l2f_supported(int64_t F, int zd, int C);
+int pv_l2f_fwd(const float* z, const float* wt, const float* bias, float* a, int B, int S, int C, int zd, hipStream_t s);
+int pv_l2f_wgrad(const float* g, const float* z, float* dw, float* db, int B, int S, int C, int zd, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

@@ -175,6 +175,12 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
     const PvWprepEntry E = t.e[k];
     const int64_t e = idx - E.start;
     const int Co = E.Co, Ci = E.Ci, KK = E.KK, flip = E.flip;
+    if (E.kind == 7) {                                // latent2features: dst[k][s*C + c] = w[c*S + s][k]  (Co = z_dim, Ci = C, KK = S)
+      const int64_t F = (int64_t)Ci * KK, k = e / F, f = e - k * F;
+      const int sp = (int)(f / Ci), c = (int)(f - (int64_t)sp * Ci);
+      reinterpret_cast<float*>(E.dst)[e] = E.w[((int64_t)c * KK + sp) * Co + k];
+      continue;
+    }
     if (E.kind == 4) {                                // conv head: dst[j][s*C + c] = w[j][c*S + s]  (Co = out, Ci = C, KK = S)
       const int64_t F = (int64_t)Ci * KK, j = e / F, f = e - j * F;
       const int sp = (int)(f / Ci), c = (int)(f - (int64_t)sp * Ci);
@@ -215,7 +221,7 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
 }
 
 static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
-  if (kind == 4) return (int64_t)Co * Ci * KK;
+  if (kind == 4 || kind == 7) return (int64_t)Co * Ci * KK;
   if (kind == 5) KK = 9;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   const int KC = kind == 0 ? 16 : 32;
@@ -223,7 +229,7 @@ static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
 }
 
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd) {
-  if (kind == 4) return -1;                          // (sized by the caller: out * F floats)
+  if (kind == 4 || kind == 7) return -1;             // (sized by the caller: out * F floats)
   if (kind >= 2 && kind != 6) return pv_conv3_sp_wt_bytes(Ci, Co);
   return pv_conv3_direct_wt_floats(Ci, Co, nd) * (int64_t)sizeof(float);
 }

@@ -195,3 +195,112 @@ extern "C" int pv_debug_convhead(int what, const float* w, float* wt, const floa
   if (what == 2) return pv_convhead_bwd(dhead, wt, a, act, g, B, F, out, s);
   return pv_convhead_wgrad(dhead, a, dw, db, B, S, C, out, ws, ws_bytes, s);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The mirror image at the decoder's entry — nets/conv.py latent_to_features: Linear(z_dim -> C0*S0) + view(C0, *dims) — with
+// the same idea: the feature map it produces (and the gradient it receives) are channels-last, the Linear's weight
+// W[f = c*S + s][k] is re-indexed once per step (pv_conv_wprep_table kind 7: wt[k][s*C + c] = W[c*S + s][k]; zd <= 16):
+//   forward   a[b][f'] = bias[f(f')] + sum_k z[b][k] wt[k][f']          (elementwise over the feature map)
+//   wgrad     dw[f][k] = sum_b g[b][f'] z[b][k],  db[f] = sum_b g[b][f']  (32 features x 8 sample slices per workgroup, slices meet in
+//             LDS in slice order)
+//   dgrad     dz[b][k] = sum_f' g[b][f'] wt[k][f']  = pv_convhead_fwd(a = g, wt, no bias)
+// instead of three GEMMs with a contraction or an output of 2 and two transposes.
+template <int ZD>
+__global__ __launch_bounds__(256) void pv_l2f_fwd_kernel(const float* __restrict__ z, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, float* __restrict__ a, int B, int S, int C,
+                                                         int zd) {
+  const int64_t F = (int64_t)S * C, F4 = F / 4, total = (int64_t)B * F4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / F4, i = e - b * F4;
+    const int s = (int)((4 * i) / C), c = (int)(4 * i - (int64_t)s * C);
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = bias[(int64_t)(c + j) * S + s];
+    }
+#pragma unroll
+    for (int k = 0; k < ZD; ++k)
+      if (k < zd) v += z[b * zd + k] * reinterpret_cast<const f32x4*>(wt + (int64_t)k * F)[i];
+    reinterpret_cast<f32x4*>(a)[e] = v;
+  }
+}
+
+template <int ZD>
+__global__ __launch_bounds__(256) void pv_l2f_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                           float* __restrict__ dw, float* __restrict__ db, int B, int S, int C,
+                                                           int zd) {
+  __shared__ float sm[8][32][ZD + 1];
+  const int fl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t F = (int64_t)S * C, fp = (int64_t)blockIdx.x * 32 + fl;       // channels-last feature index
+  float acc[ZD + 1];
+#pragma unroll
+  for (int k = 0; k <= ZD; ++k) acc[k] = 0.0f;
+  if (fp < F)
+    for (int b0 = sl; b0 < B; b0 += 64) {             // eight samples of the slice at a time: their loads go out together
+      float gv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = b0 + 8 * j < B ? g[(int64_t)(b0 + 8 * j) * F + fp] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int b = b0 + 8 * j < B ? b0 + 8 * j : 0;   // (gv = 0 beyond the batch)
+        acc[ZD] += gv[j];
+#pragma unroll
+        for (int k = 0; k < ZD; ++k)
+          if (k < zd) acc[k] += gv[j] * z[(int64_t)b * zd + k];
+      }
+    }
+#pragma unroll
+  for (int k = 0; k <= ZD; ++k) sm[sl][fl][k] = acc[k];
+  __syncthreads();
+  if (sl == 0 && fp < F) {
+    const int s = (int)(fp / C), c = (int)(fp - (int64_t)s * C);
+    const int64_t f = (int64_t)c * S + s;                                      // the Linear's row
+#pragma unroll
+    for (int k = 0; k <= ZD; ++k) {
+      float t = 0.0f;
+      for (int q = 0; q < 8; ++q) t += sm[q][fl][k];
+      if (k == ZD) { if (db) db[f] = t; }
+      else if (k < zd) dw[f * zd + k] = t;
+    }
+  }
+}
+
+bool pv_l2f_supported(int64_t F, int zd, int C) { return zd >= 1 && zd <= CH_MAXOUT && F >= 4 && C % 4 == 0; }
+
+#define L2F_DISPATCH(KERNEL, GRID, ...)                                                                      \
+  do {                                                                                                       \
+    if (zd <= 2) hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, s, __VA_ARGS__);                          \
+    else if (zd <= 4) hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, s, __VA_ARGS__);                     \
+    else if (zd <= 8) hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(256), 0, s, __VA_ARGS__);                     \
+    else hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(256), 0, s, __VA_ARGS__);                                 \
+    PV_LAUNCH_CHECK();                                                                                       \
+  } while (0)
+
+int pv_l2f_fwd(const float* z, const float* wt, const float* bias, float* a, int B, int S, int C, int zd, hipStream_t s) {
+  if (!pv_l2f_supported((int64_t)S * C, zd, C)) return PV_EINVAL;
+  int64_t nb = ((int64_t)B * S * C / 4 + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  L2F_DISPATCH(pv_l2f_fwd_kernel, dim3((unsigned)nb), z, wt, bias, a, B, S, C, zd);
+  return 0;
+}
+
+int pv_l2f_wgrad(const float* g, const float* z, float* dw, float* db, int B, int S, int C, int zd, hipStream_t s) {
+  if (!pv_l2f_supported((int64_t)S * C, zd, C)) return PV_EINVAL;
+  const int64_t F = (int64_t)S * C;
+  L2F_DISPATCH(pv_l2f_wgrad_kernel, dim3((unsigned)((F + 31) / 32)), g, z, dw, db, B, S, C, zd);
+  return 0;
+}
+
+// test hook: what 0: wt = re-indexed w (kind 7); 1: a = forward(z); 2: dw, db = wgrad(g, z); 3: dz = dgrad(g)
+extern "C" int pv_debug_l2f(int what, const float* w, float* wt, const float* bias, const float* z, float* a, const float* g,
+                            float* dw, float* db, float* dz, int B, int S, int C, int zd, void* ws, long long ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (what == 0) {
+    PvWprepEntry e{};
+    e.w = w; e.dst = reinterpret_cast<char*>(wt); e.Co = zd; e.Ci = C; e.KK = S; e.kind = 7;
+    return pv_conv_wprep_table(&e, 1, s);
+  }
+  if (what == 1) return pv_l2f_fwd(z, wt, bias, a, B, S, C, zd, s);
+  if (what == 2) return pv_l2f_wgrad(g, z, dw, db, B, S, C, zd, s);
+  return pv_convhead_fwd(g, wt, nullptr, dz, B, (int64_t)S * C, zd, ws, ws_bytes, s);
+}

@@ -34,6 +34,7 @@ struct VLayout {
   pvcs::WtPlan wtp; char* wt;                          // the step's tiled conv weights (both stacks, both orientations)
   float* head_wt;                                      // features2latent's weight re-indexed channels-last (null: GEMM path)
   char* fin_ws; int64_t fin_bytes;                     // every weight gradient's partials until the one finish launch
+  float* l2f_wt;                                       // latent2features' weight re-indexed channels-last (null: GEMM path)
   int64_t F;                                           // flattened feature size C*S of the encoder output
   int64_t total;
 };
@@ -78,6 +79,8 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   if (p->l2f.out_dim != F0) return false;
   if (!pvcs::stack_shapes(p->dec, p->n_dec_ops, p->ndim_out, B, L.ds, nd)) return false;
   L.f0 = c.take(B * F0); L.df0 = c.take(B * F0);
+  L.l2f_wt = pv_l2f_supported(F0, (int)z, L.ds[0].C) ? c.take(z * F0) : nullptr;
+  if (L.l2f_wt || !base) pvcs::upd(nd.scratch, pv_convhead_ws((int)B, F0, (int)z));     // (its input gradient = pv_convhead_fwd)
   L.da[0] = c.take(B * F0);
   pvcs::upd(nd.scratch, gemm_ws_need(B, F0, z)); pvcs::upd(nd.scratch, gemm_ws_need(F0, z, B));
   pvcs::upd(nd.scratch, gemm_ws_need(B, z, F0));
@@ -116,7 +119,12 @@ int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_
     PV_TRY(pvcs::wt_prep(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, L.wtp, L.wt, with_dgrad, s, &he,
                          L.head_wt ? 1 : 0));
   }
-  if (dec) PV_TRY(pvcs::wt_prep(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, s));
+  if (dec) {
+    PvWprepEntry le = pvcs::head_entry(p->params + p->l2f.w_off, L.l2f_wt, p->z_dim, L.ds[0].C, (int64_t)L.ds[0].H * L.ds[0].W);
+    le.kind = 7;                                       // wt[k][s*C + c] = w[c*S + s][k]
+    PV_TRY(pvcs::wt_prep(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, s, &le,
+                         L.l2f_wt ? 1 : 0));
+  }
   return 0;
 }
 
@@ -151,9 +159,14 @@ int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_
   const int64_t B = p->batch;
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
-  PV_TRY(linear_fwd(z, p->z_dim, p->params + p->l2f.w_off, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr,
-                    L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
-  PV_TRY(pv_ncs_to_nsc(L.f0, L.da[0], B, d0.C, (int64_t)d0.H * d0.W, s));       // view(-1, C0, *dims) -> channels-last
+  if (L.l2f_wt) {                                      // Linear + view(-1, C0, *dims), written channels-last directly
+    PV_TRY(pv_l2f_fwd(z, L.l2f_wt, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr, L.da[0], (int)B, d0.H * d0.W, d0.C,
+                      p->z_dim, s));
+  } else {
+    PV_TRY(linear_fwd(z, p->z_dim, p->params + p->l2f.w_off, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr,
+                      L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
+    PV_TRY(pv_ncs_to_nsc(L.f0, L.da[0], B, d0.C, (int64_t)d0.H * d0.W, s));     // view(-1, C0, *dims) -> channels-last
+  }
   return pvcs::stack_fwd(p->params, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.sc, s, 1);
 }
 
@@ -200,11 +213,17 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
                          &g, L.sc, s, 1));
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
-  PV_TRY(pv_nsc_to_ncs(g, L.df0, B, d0.C, (int64_t)d0.H * d0.W, s));
-  PV_TRY(linear_wgrad(L.df0, F0, L.z, z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, B,
-                      z, F0, L.sc.ws, L.sc.ws_bytes, s));
-  PV_TRY(linear_dgrad(L.df0, F0, p->params + p->l2f.w_off, L.dzc, z, nullptr, nullptr, 0, PV_ACT_NONE, B, z, F0,
-                      L.sc.ws, L.sc.ws_bytes, s));
+  if (L.l2f_wt) {                                      // straight from the channels-last gradient
+    PV_TRY(pv_l2f_wgrad(g, L.z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, (int)B,
+                        d0.H * d0.W, d0.C, (int)z, s));
+    PV_TRY(pv_convhead_fwd(g, L.l2f_wt, nullptr, L.dzc, (int)B, F0, (int)z, L.sc.ws, L.sc.ws_bytes, s));
+  } else {
+    PV_TRY(pv_nsc_to_ncs(g, L.df0, B, d0.C, (int64_t)d0.H * d0.W, s));
+    PV_TRY(linear_wgrad(L.df0, F0, L.z, z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, B,
+                        z, F0, L.sc.ws, L.sc.ws_bytes, s));
+    PV_TRY(linear_dgrad(L.df0, F0, p->params + p->l2f.w_off, L.dzc, z, nullptr, nullptr, 0, PV_ACT_NONE, B, z, F0,
+                        L.sc.ws, L.sc.ws_bytes, s));
+  }
   // ---- reparameterised sample + sampled KL -> head ----
   PvHeadBwd hb{};
   hb.dzc = L.dzc; hb.ldzc = z; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps; hb.head = L.head; hb.dhead = L.dhead;

@@ -354,3 +354,32 @@ def test_convolution_with_fused_max_pool(gpu_device, mode, B, H, W, Ci, Co, act)
     (gpre,) = torch.autograd.grad(ref, pre, gp.permute(0, 3, 1, 2).double())
     # (ties between fp32 and fp64 winners are measure-zero for random inputs; compare as tensors)
     assert rel_l2(din, gpre.permute(0, 2, 3, 1)) < max(tol, 1e-5)
+
+
+@pytest.mark.parametrize("B,S,Cc,zd", [(5, 16, 32, 2), (3, 9, 20, 5), (37, 16, 128, 2), (2, 4, 8, 16), (70, 64, 64, 7)])
+def test_latent_to_features_without_transposes(gpu_device, B, S, Cc, zd):
+    """latent2features: Linear(z_dim -> C*S) + view(C, S) producing the channels-last map a[b][s][c] directly, its weight / bias
+    gradients and the latent gradient from a channels-last gradient map."""
+    g = torch.Generator().manual_seed(B + S + zd)
+    Fdim = S * Cc
+    w = (torch.randn(Fdim, zd, generator=g) / zd ** 0.5).cuda()
+    bias = torch.randn(Fdim, generator=g).cuda()
+    z = torch.randn(B, zd, generator=g).cuda()
+    gmap = torch.randn(B, S, Cc, generator=g).cuda()
+    L = lib()
+    ws = torch.empty(int(L.pv_debug_convhead_ws(B, C.c_longlong(Fdim), zd)), dtype=torch.uint8, device="cuda")
+    wt = torch.empty(zd, Fdim, device="cuda")
+    a = torch.full((B, S, Cc), float("nan"), device="cuda")
+    dw = torch.full((Fdim, zd), float("nan"), device="cuda")
+    db = torch.full((Fdim,), float("nan"), device="cuda")
+    dz = torch.full((B, zd), float("nan"), device="cuda")
+    for what in range(4):
+        rc = L.pv_debug_l2f(what, ptr(w), ptr(wt), ptr(bias), ptr(z), ptr(a), ptr(gmap), ptr(dw), ptr(db), ptr(dz), B, S, Cc, zd,
+                            ptr(ws), C.c_longlong(ws.numel()), stream())
+        assert rc == 0
+    f0 = z.double() @ w.double().t() + bias.double()                          # (B, C*S), channels-first flatten
+    assert rel_l2(a, f0.reshape(B, Cc, S).permute(0, 2, 1)) < 2e-6
+    gf = gmap.double().permute(0, 2, 1).reshape(B, Fdim)
+    assert rel_l2(dw, gf.t() @ z.double()) < 2e-6
+    assert rel_l2(db, gf.sum(0)) < 2e-6
+    assert rel_l2(dz, gf @ w.double()) < 2e-6
