@@ -9,6 +9,7 @@
 //   wgrad     dw[j][c*S + s] = sum_b dhead[b][j] a[b][s*C + c],  db[j] = sum_b dhead[b][j]
 #include "pv_common.h"
 #include "pv_conv.h"
+#include <stdlib.h>
 
 #define CH_MAXOUT 16
 
@@ -114,10 +115,13 @@ static int ch_segs(int B, int64_t F) {               // forward: ~1024 workgroup
   if (n > cap) n = cap;
   return (int)(n < 1 ? 1 : (n > 16 ? 16 : n));
 }
+static int chm_segs(int B, int64_t F);
 int64_t pv_convhead_ws(int B, int64_t F, int out) {
   // weight gradient: per-split partials (+ bias partials), then their sum in channels-last order before the transposition
   const int64_t wg = (int64_t)ch_splits(B) * out * (F + 1) + (int64_t)out * F, fw = (int64_t)B * ch_segs(B, F) * out;
-  return (wg > fw ? wg : fw) * (int64_t)sizeof(float) + 256;
+  const int64_t fm = (int64_t)B * chm_segs(B, F) * out;                 // the MFMA forward's partials
+  const int64_t m = wg > fw ? wg : fw;
+  return (m > fm ? m : fm) * (int64_t)sizeof(float) + 256;
 }
 
 #define CH_DISPATCH(KERNEL, GRID, ...)                                                                       \
@@ -128,9 +132,17 @@ int64_t pv_convhead_ws(int B, int64_t F, int out) {
     PV_LAUNCH_CHECK();                                                                                       \
   } while (0)
 
+int64_t pv_convhead_mfma_ws(int B, int64_t F, int out);
+int pv_convhead_fwd_mfma(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
+                         int64_t ws_bytes, hipStream_t s);
+int pv_convhead_wgrad_mfma(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, hipStream_t s);
+static bool ch_use_mfma() { static const bool on = !(getenv("PV_CONVHEAD_STREAM") && atoi(getenv("PV_CONVHEAD_STREAM"))); return on; }
+
 int pv_convhead_fwd(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
                     int64_t ws_bytes, hipStream_t s) {
   if (!pv_convhead_supported(F, out)) return PV_EINVAL;
+  if (ch_use_mfma() && F % 16 == 0 && ws_bytes >= pv_convhead_mfma_ws(B, F, out))
+    return pv_convhead_fwd_mfma(a, wt, bias, head, B, F, out, ws, ws_bytes, s);
   if (ws_bytes < pv_convhead_ws(B, F, out)) return PV_EWS;
   const int nseg = ch_segs(B, F);
   float* part = reinterpret_cast<float*>(ws);
@@ -154,6 +166,7 @@ int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, 
                       int64_t ws_bytes, hipStream_t s) {
   const int64_t F = (int64_t)S * C;
   if (!pv_convhead_supported(F, out)) return PV_EINVAL;
+  if (ch_use_mfma()) return pv_convhead_wgrad_mfma(dhead, a, dw, db, B, S, C, out, s);
   if (ws_bytes < pv_convhead_ws(B, F, out)) return PV_EWS;
   const int ns = ch_splits(B);
   float* part = reinterpret_cast<float*>(ws);
@@ -303,4 +316,126 @@ extern "C" int pv_debug_l2f(int what, const float* w, float* wt, const float* bi
   if (what == 1) return pv_l2f_fwd(z, wt, bias, a, B, S, C, zd, s);
   if (what == 2) return pv_l2f_wgrad(g, z, dw, db, B, S, C, zd, s);
   return pv_convhead_fwd(g, wt, nullptr, dz, B, (int64_t)S * C, zd, ws, ws_bytes, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The conv head's forward and weight gradient as skinny GEMMs on the f32-input matrix cores (out <= 16 rows): the streaming
+// kernels above re-read the out x F weight once per sample segment (12x the feature-map traffic at out = 12) and their
+// weight gradient needs per-split partials, a finish and a transpose.  v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain.
+//   D[j][col] layout: lane (col = r, q), register i -> row j = 4 q + i.
+#define CH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// forward: workgroup (16-sample group, segment of f); wave w takes a quarter of the segment in steps of 16 features: one float4
+// of the re-indexed weight (row j = r) and one of the feature map (sample r) per lane feed four MFMAs (k = 4 q + s).
+__global__ __launch_bounds__(256) void pv_convhead_fwd_mfma_kernel(const float* __restrict__ a, const float* __restrict__ wt,
+                                                                   float* __restrict__ part, int B, int64_t F, int out, int nseg) {
+  __shared__ f32x4 red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int grp = blockIdx.x, seg = blockIdx.y;
+  const int64_t steps = F / 16, s_lo = steps * seg / nseg, s_hi = steps * (seg + 1) / nseg;
+  const int64_t w_lo = s_lo + (s_hi - s_lo) * wave / 4, w_hi = s_lo + (s_hi - s_lo) * (wave + 1) / 4;
+  const int b = grp * 16 + r;
+  const bool bok = b < B, jok = r < out;
+  const f32x4* ap = reinterpret_cast<const f32x4*>(a + (int64_t)(bok ? b : 0) * F) + q;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(wt + (int64_t)(jok ? r : 0) * F) + q;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc = zero;
+#pragma unroll 4
+  for (int64_t st = w_lo; st < w_hi; ++st) {
+    const f32x4 av = bok ? ap[st * 4] : zero;
+    const f32x4 wv = jok ? wp[st * 4] : zero;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = CH_MFMA(wv[s], av[s], acc);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (bok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * q + i < out) part[((int64_t)b * nseg + seg) * out + 4 * q + i] = t[i];
+    }
+  }
+}
+
+// weight gradient: a wave owns 64 channels-last features x all out rows and contracts over the samples, four at a time: one
+// float4 of the feature map (sample b0 + q, features 4 r .. 4 r + 3) and one value of dhead (sample b0 + q, row r) per lane feed
+// four MFMAs, one per feature of the float4.  Results go straight to the Linear's layout dw[j][c*S + s]; no partials.
+__global__ __launch_bounds__(256) void pv_convhead_wgrad_mfma_kernel(const float* __restrict__ dhead, const float* __restrict__ a,
+                                                                     float* __restrict__ dw, float* __restrict__ db, int B, int S,
+                                                                     int C, int out) {
+  // a workgroup owns 64 features; its four waves take a quarter of the samples each and meet in LDS in wave order
+  __shared__ f32x4 red[3][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int64_t F = (int64_t)S * C, f0 = (int64_t)blockIdx.x * 64;
+  if (blockIdx.x == gridDim.x - 1 && db && wave == 3) {  // db[j] = sum_b dhead[b][j]: lanes stride the samples, then a fixed tree
+    for (int j = 0; j < out; ++j) {
+      float v = 0.0f;
+      for (int b = lane; b < B; b += 64) v += dhead[(int64_t)b * out + j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) db[j] = v;
+    }
+  }
+  const bool fok = f0 + 4 * r + 3 < F, jok = r < out;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc[4] = {zero, zero, zero, zero};
+  const int nb4 = (B + 3) / 4, s_lo = nb4 * wave / 4, s_hi = nb4 * (wave + 1) / 4;
+#pragma unroll 4
+  for (int st = s_lo; st < s_hi; ++st) {
+    const int b = 4 * st + q;
+    const bool bok = b < B;
+    const f32x4 av = (bok && fok) ? *reinterpret_cast<const f32x4*>(a + (int64_t)b * F + f0 + 4 * r) : zero;
+    const float dv = (bok && jok) ? dhead[(int64_t)b * out + r] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = CH_MFMA(dv, av[s], acc[s]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) red[wave - 1][s][lane] = acc[s];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const f32x4 t = (acc[s] + red[0][s][lane]) + (red[1][s][lane] + red[2][s][lane]);
+    const int64_t fp = f0 + 4 * r + s;                 // channels-last feature of column r of accumulator s
+    if (fp >= F) continue;
+    const int sp = (int)(fp / C), c = (int)(fp - (int64_t)sp * C);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (4 * q + i < out) dw[(int64_t)(4 * q + i) * F + (int64_t)c * S + sp] = t[i];
+  }
+}
+
+static int chm_segs(int B, int64_t F) {              // forward: ~512 workgroups of (16 samples) x (segment of >= 64 features)
+  const int64_t groups = (B + 15) / 16;
+  int64_t n = (512 + groups - 1) / groups, cap = F / 64;
+  if (n > cap) n = cap;
+  return (int)(n < 1 ? 1 : (n > 32 ? 32 : n));       // (the finish sums the segments serially per output)
+}
+int64_t pv_convhead_mfma_ws(int B, int64_t F, int out) { return (int64_t)B * chm_segs(B, F) * out * (int64_t)sizeof(float) + 256; }
+
+int pv_convhead_fwd_mfma(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
+                         int64_t ws_bytes, hipStream_t s) {
+  if (!pv_convhead_supported(F, out) || F % 16 != 0) return PV_EINVAL;
+  if (ws_bytes < pv_convhead_mfma_ws(B, F, out)) return PV_EWS;
+  const int nseg = chm_segs(B, F);
+  float* part = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(pv_convhead_fwd_mfma_kernel, dim3((unsigned)((B + 15) / 16), (unsigned)nseg), dim3(256), 0, s, a, wt, part, B, F,
+                     out, nseg);
+  PV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pv_convhead_fwd_finish_kernel, dim3((unsigned)((B * out + 255) / 256)), dim3(256), 0, s, part, bias, head, B,
+                     out, nseg);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+int pv_convhead_wgrad_mfma(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, hipStream_t s) {
+  const int64_t F = (int64_t)S * C;
+  if (!pv_convhead_supported(F, out)) return PV_EINVAL;
+  hipLaunchKernelGGL(pv_convhead_wgrad_mfma_kernel, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, s, dhead, a, dw, db, B, S, C, out);
+  PV_LAUNCH_CHECK();
+  return 0;
 }
