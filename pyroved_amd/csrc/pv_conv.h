@@ -92,6 +92,8 @@ int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, 
 bool pv_l2f_supported(int64_t F, int zd, int C);
 int pv_l2f_fwd(const float* z, const float* wt, const float* bias, float* a, int B, int S, int C, int zd, hipStream_t s);
 int pv_l2f_wgrad(const float* g, const float* z, float* dw, float* db, int B, int S, int C, int zd, hipStream_t s);
+// y (B, N) = x (B, K; row stride ldx) w(N, K)^T for K <= 16
+int pv_smallk_linear(const float* x, int64_t ldx, const float* w, float* y, int64_t B, int K, int N, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int pv_upsample2_bil_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t s);
 // nn.BatchNormNd over channels-last rows x[R][C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + eps) (kept for backward)

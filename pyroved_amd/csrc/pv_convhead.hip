@@ -439,3 +439,25 @@ int pv_convhead_wgrad_mfma(const float* dhead, const float* a, float* dw, float*
   PV_LAUNCH_CHECK();
   return 0;
 }
+
+// y[b][j] = sum_k x[b*ldx + k] * w[j*K + k]  (K <= 16, no bias): a Linear with a contraction this short is not a GEMM —
+// fc_latent (content latents -> 128) of the spatial decoder when the encoder is not the compact fc one
+__global__ void pv_smallk_linear_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, float* __restrict__ y,
+                                        int64_t B, int K, int N) {
+  const int64_t total = B * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / N;
+    const int j = (int)(e - b * N);
+    float v = 0.0f;
+    for (int k = 0; k < K; ++k) v = fmaf(x[b * ldx + k], w[(int64_t)j * K + k], v);
+    y[e] = v;
+  }
+}
+int pv_smallk_linear(const float* x, int64_t ldx, const float* w, float* y, int64_t B, int K, int N, hipStream_t s) {
+  if (K < 1 || K > 16 || B < 1 || N < 1) return PV_EINVAL;
+  int64_t nb = (B * N + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(pv_smallk_linear_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, ldx, w, y, B, K, N);
+  PV_LAUNCH_CHECK();
+  return 0;
+}

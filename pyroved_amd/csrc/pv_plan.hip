@@ -10,6 +10,7 @@
 #include "pv_sdec_fused.h"
 #include "pv_linear.h"
 #include "pv_convstack.h"
+#include "pv_conv.h"
 
 namespace {
 
@@ -665,9 +666,11 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
       if (e != hipSuccess) return (int)e;
     }
   }
-  if (!L.enc_compact)
-    PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
-                      L.scratch, L.scratch_bytes, s));
+  if (!L.enc_compact) {
+    if (lat_in <= 16) PV_TRY(pv_smallk_linear(zin, ldz, p->params + p->fc_latent.w_off, L.hz, B, (int)lat_in, (int)H, s));
+    else PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
+                           L.scratch, L.scratch_bytes, s));
+  }
   if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
   if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s));
   else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
