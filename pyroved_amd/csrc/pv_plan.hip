@@ -502,7 +502,17 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
   }
   PvGemm probs[PV_MAX_LAYERS + 4];
   int np = 0;
-  for (int i = 0; i < n_extra; ++i) probs[np++] = extra[i];
+  for (int i = 0; i < n_extra; ++i) {
+    // a long contraction over a few output tiles (jiVAE's fc_latent: K*B decoder samples onto 128 x lat_in) would sit on
+    // a handful of workgroups in the one-tile-per-workgroup launch: split-K GEMM instead, finished before that launch
+    // so that its fused Adam guests see the final gradient
+    const PvGemm& e = extra[i];
+    const int64_t tiles = (int64_t)((e.M + 15) / 16) * ((e.N + 15) / 16);
+    const int sp = pv_gemm_pick_splits(e.M, e.N, e.K);
+    if (e.K > 1024 && tiles < 128 && sp > 1 &&
+        (int64_t)sp * e.M * (e.N + 1) * (int64_t)sizeof(float) <= wsb) PV_TRY(pv_gemm(e, sp, ws, wsb, s));
+    else probs[np++] = e;
+  }
   probs[np++] = wgrad_problem(L.dhead, hd.out_dim, elast, hd.in_dim, G + hd.w_off,
                               hd.b_off >= 0 ? G + hd.b_off : nullptr, B, hd.in_dim, hd.out_dim);
   const float* xin = p->c_dim > 0 ? L.xin : p->x;
