@@ -92,6 +92,13 @@ int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, 
 bool pv_l2f_supported(int64_t F, int zd, int C);
 int pv_l2f_fwd(const float* z, const float* wt, const float* bias, float* a, int B, int S, int C, int zd, hipStream_t s);
 int pv_l2f_wgrad(const float* g, const float* z, float* dw, float* db, int B, int S, int C, int zd, hipStream_t s);
+// kernel-1 convolutions over channels-last maps (pv_conv_k1.hip): operands straight from L2 into f32 MFMAs, no LDS stages
+int pv_k1_fwd(const float* in, int64_t rows, int Ci, const float* w, const float* bias, float* out, int Co, int act, hipStream_t s);
+int pv_k1_dgrad(const float* g, int64_t rows, int Co, const float* w, float* gin, int Ci, const float* eg_y, int eg_act,
+                hipStream_t s);
+int64_t pv_k1_wgrad_ws(int64_t rows, int Ci, int Co);
+int pv_k1_wgrad(const float* g, const float* in, int64_t rows, int Ci, int Co, float* dw, float* db, void* ws, int64_t ws_bytes,
+                hipStream_t s, PvFinishList* defer = nullptr);
 // y (B, N) = x (B, K; row stride ldx) w(N, K)^T for K <= 16
 int pv_smallk_linear(const float* x, int64_t ldx, const float* w, float* y, int64_t B, int K, int N, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -1,0 +1,299 @@
+// pv_conv_k1.hip — kernel-1 convolutions (nets/conv.py: UpsampleBlock's conv, the decoder's output layer) over
+// channels-last maps: a Linear over the pixels, out[p][n] = act(sum_k in[p][k] w[n][k] + b[n]), with a SHORT contraction
+// (32 ... 128 channels) and a few thousand pixels.  The LDS-tiled GEMM (pv_gemm.hip) runs such a problem as ~100
+// workgroups that each walk K in 32-wide stages behind barriers: one global-memory round trip per stage, 8-22 us per
+// launch for 10-70 MFLOP.  Here every operand of a wave's tile is requested at once and goes from L2 straight into
+// the registers of v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate): one memory latency per launch, no LDS, no barrier.
+//   forward / input gradient: a wave owns 16 pixels x 64 outputs; the weights are the MFMA's A operand (m = output), the
+//     pixels its B operand (n = pixel), so a lane ends up with four CONSECUTIVE outputs of one pixel (16-byte stores).
+//     The input gradient is the same kernel on the transposed weight (strided loads; the matrix is L2-resident) with the
+//     producing layer's activation derivative in the epilogue.
+//   weight gradient: dW[n][k] = sum_p g[p][n] in[p][k]: one 16 x 16 output tile and one chunk of the pixels per workgroup,
+//     its four waves take 64-pixel register batches, partial tiles meet in LDS and go to the step's deferred-reduction
+//     table (pv_conv.h: PvFinishList) — no launch of its own for the split-order sum.
+#include "pv_common.h"
+#include "pv_conv.h"
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define K1_KC 128                    // contraction chunk held in registers
+
+struct K1Fwd {
+  const float* in; const float* w; const float* bias; float* out; const float* eg_y;
+  int64_t rows;
+  int K, N, ld_in, ld_out, w_ns, w_ks, act, eg_act, ngroups, w_bytes;
+};
+
+// The vector form: K % 16 == 0, N % 4 == 0, 16-byte aligned pixel rows.  NJ 16-wide contraction groups per register chunk
+// (K % (16 NJ) == 0), NB 16-output blocks per wave; every load and MFMA is unconditional (outputs past N read a clamped
+// weight row and are not stored).  WV: the weight's contraction index has unit stride (forward form, 16-byte loads);
+// otherwise (input-gradient form, the transposed matrix) dword buffer loads: uniform base + 32-bit lane offset.
+template <bool WV, int NJ, int NB>
+__global__ __launch_bounds__(256) void pv_k1_fwd_kernel(K1Fwd a) {
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t rb = unit / a.ngroups;
+  const int ng = (int)(unit - rb * a.ngroups);
+  if (rb * 16 >= a.rows) return;                                   // (no barrier in this kernel)
+  const int64_t row = rb * 16 + r;
+  const bool rok = row < a.rows;
+  const float* ip = a.in + (rok ? row : 0) * a.ld_in + 4 * q;
+  const int n0 = 16 * NB * ng;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const float* wp[NB];
+  int wo[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int n = n0 + 16 * b + r, nc = n < a.N ? n : 0;
+    wp[b] = a.w + (int64_t)nc * a.w_ns + 4 * q;
+    wo[b] = 4 * (nc * a.w_ns + 4 * q * a.w_ks);
+  }
+  f32x4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int kc = 0; kc < a.K; kc += 16 * NJ) {
+    f32x4 x[NJ], w[NB][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) x[j] = *reinterpret_cast<const f32x4*>(ip + kc + 16 * j);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (WV) {
+          w[b][j] = *reinterpret_cast<const f32x4*>(wp[b] + kc + 16 * j);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            w[b][j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wo[b], 4 * (kc + 16 * j + i) * a.w_ks, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = MFMA4(w[b][j][i], x[j][i], acc[b]);
+      }
+    }
+  }
+  // C layout: lane (pixel r, q), register i <-> output n0 + 16 b + 4 q + i
+  if (!rok) return;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int n = n0 + 16 * b + 4 * q;
+    if (n >= a.N) continue;
+    f32x4 v = acc[b];
+    if (a.bias) v = v + *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.act != PV_ACT_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = pv_act_fwd(v[i], a.act);
+    }
+    if (a.eg_y) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(a.eg_y + row * a.ld_out + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= pv_act_grad(y[i], 0.0f, a.eg_act);
+    }
+    *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + n) = v;
+  }
+}
+
+// any K, N, alignment: scalar loads at clamped addresses, 16 pixels x 16 outputs per wave
+__global__ __launch_bounds__(256) void pv_k1_gen_kernel(K1Fwd a) {
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t rb = unit / a.ngroups;
+  const int ng = (int)(unit - rb * a.ngroups);
+  if (rb * 16 >= a.rows) return;
+  const int64_t row = rb * 16 + r;
+  const bool rok = row < a.rows;
+  const float* ip = a.in + (rok ? row : 0) * a.ld_in;
+  const int n = 16 * ng + r;
+  const float* wp = a.w + (int64_t)(n < a.N ? n : 0) * a.w_ns;
+  f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int k0 = 0; k0 < a.K; k0 += 16) {
+    float x[4], w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + 4 * q + i, kk = k < a.K ? k : a.K - 1;
+      const float xv = ip[kk], wv = wp[(int64_t)kk * a.w_ks];
+      x[i] = k < a.K ? xv : 0.0f;
+      w[i] = k < a.K ? wv : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = MFMA4(w[i], x[i], acc);
+  }
+  if (!rok) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int no = 16 * ng + 4 * q + i;
+    if (no >= a.N) break;
+    float t = acc[i] + (a.bias ? a.bias[no] : 0.0f);
+    t = pv_act_fwd(t, a.act);
+    if (a.eg_y) t *= pv_act_grad(a.eg_y[row * a.ld_out + no], 0.0f, a.eg_act);
+    a.out[row * a.ld_out + no] = t;
+  }
+}
+
+static inline bool k1_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <bool WV, int NJ>
+static void k1_launch_nb(const K1Fwd& a, int nb, unsigned grid, hipStream_t s) {
+  if (nb == 4) hipLaunchKernelGGL((pv_k1_fwd_kernel<WV, NJ, 4>), dim3(grid), dim3(256), 0, s, a);
+  else if (nb == 2) hipLaunchKernelGGL((pv_k1_fwd_kernel<WV, NJ, 2>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((pv_k1_fwd_kernel<WV, NJ, 1>), dim3(grid), dim3(256), 0, s, a);
+}
+template <bool WV>
+static void k1_launch_nj(const K1Fwd& a, int nb, unsigned grid, hipStream_t s) {
+  if (a.K % 128 == 0) k1_launch_nb<WV, 8>(a, nb, grid, s);
+  else if (a.K % 64 == 0) k1_launch_nb<WV, 4>(a, nb, grid, s);
+  else if (a.K % 32 == 0) k1_launch_nb<WV, 2>(a, nb, grid, s);
+  else k1_launch_nb<WV, 1>(a, nb, grid, s);
+}
+
+static int k1_launch(K1Fwd a, int64_t w_elems, hipStream_t s) {
+  if (a.rows <= 0 || a.N <= 0) return 0;
+  if (a.K < 1) return PV_EINVAL;
+  const bool xv = a.K % 16 == 0 && a.N % 4 == 0 && a.ld_in % 4 == 0 && a.ld_out % 4 == 0 && k1_al16(a.in) && k1_al16(a.out) &&
+                  (!a.bias || k1_al16(a.bias)) && (!a.eg_y || k1_al16(a.eg_y)) && w_elems < (1 << 28);
+  const bool wv = a.w_ks == 1 && a.w_ns % 4 == 0 && k1_al16(a.w);
+  a.w_bytes = (int)(w_elems * 4);
+  if (!xv) {
+    a.ngroups = (a.N + 15) / 16;
+    const int64_t units = ((a.rows + 15) / 16) * a.ngroups;
+    hipLaunchKernelGGL(pv_k1_gen_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a);
+  } else {
+    const int nb = a.N > 32 ? 4 : a.N > 16 ? 2 : 1;
+    a.ngroups = (a.N + 16 * nb - 1) / (16 * nb);
+    const int64_t units = ((a.rows + 15) / 16) * a.ngroups;
+    const unsigned grid = (unsigned)((units + 3) / 4);
+    if (wv) k1_launch_nj<true>(a, nb, grid, s);
+    else k1_launch_nj<false>(a, nb, grid, s);
+  }
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// out (rows, Co) = act(in (rows, Ci) w (Co, Ci)^T + bias)
+int pv_k1_fwd(const float* in, int64_t rows, int Ci, const float* w, const float* bias, float* out, int Co, int act,
+              hipStream_t s) {
+  K1Fwd a{};
+  a.in = in; a.w = w; a.bias = bias; a.out = out; a.rows = rows; a.K = Ci; a.N = Co; a.ld_in = Ci; a.ld_out = Co;
+  a.w_ns = Ci; a.w_ks = 1; a.act = act;
+  return k1_launch(a, (int64_t)Co * Ci, s);
+}
+
+// gin (rows, Ci) = (g (rows, Co) w (Co, Ci)) * act'(eg_y), eg_y shaped like gin (null: no factor)
+int pv_k1_dgrad(const float* g, int64_t rows, int Co, const float* w, float* gin, int Ci, const float* eg_y, int eg_act,
+                hipStream_t s) {
+  K1Fwd a{};
+  a.in = g; a.w = w; a.out = gin; a.rows = rows; a.K = Co; a.N = Ci; a.ld_in = Co; a.ld_out = Ci;
+  a.w_ns = 1; a.w_ks = Ci; a.act = PV_ACT_NONE;
+  if (eg_y && eg_act != PV_ACT_NONE) { a.eg_y = eg_y; a.eg_act = eg_act; }
+  return k1_launch(a, (int64_t)Co * Ci, s);
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------
+struct K1Wg {
+  const float* g; const float* in; float* part; float* part_b;
+  int64_t rows, chunk;
+  int Ci, Co, mtiles, ntiles, nsplit;
+};
+
+#define K1_WB 64                     // pixels per register batch of a wave
+
+__global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
+  __shared__ float part[4][16][17];
+  __shared__ float rpart[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = a.mtiles * a.ntiles;
+  const int sp = blockIdx.x / tiles, t = blockIdx.x - sp * tiles;
+  const int mb = t / a.ntiles, nb = t - mb * a.ntiles;
+  // A lane (m = output channel 16 mb + r, pixel slot q), B lane (n = input channel 16 nb + r, pixel slot q)
+  const int m = 16 * mb + r, n = 16 * nb + r;
+  const bool mok = m < a.Co, nok = n < a.Ci;
+  const float* gp = a.g + (mok ? m : 0);
+  const float* xp = a.in + (nok ? n : 0);
+  const int64_t p0 = (int64_t)sp * a.chunk, p1 = p0 + a.chunk < a.rows ? p0 + a.chunk : a.rows;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float rs = 0.0f;
+  for (int64_t b0 = p0 + (int64_t)K1_WB * wave; b0 < p1; b0 += 4 * K1_WB) {
+    float gv[K1_WB / 4], xv[K1_WB / 4];
+#pragma unroll
+    for (int s = 0; s < K1_WB / 4; ++s) {
+      const int64_t p = b0 + 4 * s + q;
+      const int64_t pc = p < p1 ? p : p1 - 1;
+      const float x = gp[pc * a.Co], y = xp[pc * a.Ci];
+      gv[s] = (p < p1 && mok) ? x : 0.0f;
+      xv[s] = (p < p1 && nok) ? y : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < K1_WB / 4; ++s) {
+      acc[s & 3] = MFMA4(gv[s], xv[s], acc[s & 3]);
+      rs += gv[s];
+    }
+  }
+  const f32x4 c = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  // C layout: lane (n = r, q), register i <-> m = 4 q + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[wave][4 * q + i][r] = c[i];
+  rs += __shfl_xor(rs, 16, 64);
+  rs += __shfl_xor(rs, 32, 64);
+  if (q == 0) rpart[wave][r] = rs;
+  __syncthreads();
+  const int mm = tid >> 4, nn = tid & 15, mo = 16 * mb + mm, no = 16 * nb + nn;
+  if (mo < a.Co && no < a.Ci)
+    a.part[(int64_t)sp * a.Co * a.Ci + (int64_t)mo * a.Ci + no] =
+        (part[0][mm][nn] + part[1][mm][nn]) + (part[2][mm][nn] + part[3][mm][nn]);
+  if (a.part_b && nb == 0 && tid < 16 && 16 * mb + tid < a.Co)
+    a.part_b[(int64_t)sp * a.Co + 16 * mb + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
+}
+
+static int k1_wg_splits(int64_t rows, int Ci, int Co) {
+  const int64_t tiles = (int64_t)((Co + 15) / 16) * ((Ci + 15) / 16);
+  int64_t ns = (rows + 4 * K1_WB - 1) / (4 * K1_WB);          // one register batch per wave
+  const int64_t cap = (1024 + tiles - 1) / tiles;              // ~4 workgroups per CU in all
+  if (ns > cap) ns = cap;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+int64_t pv_k1_wgrad_ws(int64_t rows, int Ci, int Co) {
+  return (int64_t)k1_wg_splits(rows, Ci, Co) * ((int64_t)Co * Ci + Co) * (int64_t)sizeof(float);
+}
+
+// dw (Co, Ci) = g (rows, Co)^T in (rows, Ci); db (Co) = column sums of g (null: none)
+int pv_k1_wgrad(const float* g, const float* in, int64_t rows, int Ci, int Co, float* dw, float* db, void* ws, int64_t ws_bytes,
+                hipStream_t s, PvFinishList* defer) {
+  if (rows < 1 || Ci < 1 || Co < 1) return PV_EINVAL;
+  const int64_t need = pv_k1_wgrad_ws(rows, Ci, Co);
+  const bool deferred = pv_wgrad_ws(defer, need, ws, ws_bytes);
+  if (!ws || ws_bytes < need) return PV_EWS;
+  K1Wg a{};
+  a.g = g; a.in = in; a.rows = rows; a.Ci = Ci; a.Co = Co;
+  a.mtiles = (Co + 15) / 16; a.ntiles = (Ci + 15) / 16;
+  a.nsplit = k1_wg_splits(rows, Ci, Co);
+  a.chunk = (rows + a.nsplit - 1) / a.nsplit;
+  a.chunk = (a.chunk + 3) / 4 * 4;
+  a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
+  a.part = (float*)ws;
+  a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci : nullptr;
+  hipLaunchKernelGGL(pv_k1_wgrad_kernel, dim3((unsigned)(a.mtiles * a.ntiles * a.nsplit)), dim3(256), 0, s, a);
+  PV_LAUNCH_CHECK();
+  return pv_wgrad_finish(deferred ? defer : nullptr, a.part, a.nsplit, (int64_t)Co * Ci, dw, a.part_b, Co, db, s);
+}
+
+// ---- test hooks (tests/test_gpu_conv_kernels.py) --------------------------------------------------------------------
+extern "C" int pv_debug_k1(int what, const float* a0, const float* a1, const float* a2, float* o0, float* o1, long long rows,
+                           int Ci, int Co, int act, const float* eg_y, void* ws, long long ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (what == 0) return pv_k1_fwd(a0, rows, Ci, a1, a2, o0, Co, act, s);                      // in, w, bias -> out
+  if (what == 1) return pv_k1_dgrad(a0, rows, Co, a1, o0, Ci, eg_y, act, s);                  // g, w -> gin
+  if (what == 2) return pv_k1_wgrad(a0, a1, rows, Ci, Co, o0, o1, ws, ws_bytes, s, nullptr);  // g, in -> dw, db
+  return PV_EINVAL;
+}
+extern "C" long long pv_debug_k1_ws(long long rows, int Ci, int Co) { return pv_k1_wgrad_ws(rows, Ci, Co); }

@@ -97,6 +97,9 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
         upd(w, pv_conv3_wgrad_c1_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
         if (nd == 2) upd(w, pv_conv3_sp_wgrad_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout));
         nd_.wg_sum += pv_align_up(w, 256);
+      } else {
+        upd(nd_.scratch, pv_k1_wgrad_ws(rows, ops[i].cin, ops[i].cout));
+        nd_.wg_sum += pv_align_up(pv_k1_wgrad_ws(rows, ops[i].cin, ops[i].cout), 256);
       }
       upd(nd_.scratch, gemm_ws_need(rows, K, N));                    // dgrad, kernel 1
       upd(nd_.scratch, gemm_ws_need(rows, ops[i].cin, N * kk_of(ops[i], nd)));   // dgrad, kernel 3
@@ -178,6 +181,13 @@ inline int wt_prep(const float* params, const pv_op* ops, int n, int nd, int sta
 inline float* bn_slot(const Scratch& sc, int slot) { return sc.bn + (int64_t)slot * 4 * sc.bn_maxC; }
 
 // one op forward: in (shape si) -> out
+// kernel-1 convolutions on the lean register-fed kernels of pv_conv_k1.hip (PV_NO_K1=1: the LDS-tiled GEMMs, for A/B timing)
+inline bool k1_lean() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PV_NO_K1"); v = (e && atoi(e) != 0) ? 0 : 1; }
+  return v == 1;
+}
+
 inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const float* in, const Shape& si, float* out,
                   const Scratch& sc, int slot, hipStream_t s) {
   if (o.kind == PV_OP_BATCHNORM) {
@@ -197,6 +207,7 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
                                0, direct_mode(sc), wt_ready(sc, slot, 0));
       return conv3_fwd(in, B, si.H, si.W, si.C, nd, params + o.w_off, bias, out, o.cout, o.act, sc.ws, sc.ws_bytes, s);
     }
+    if (k1_lean()) return pv_k1_fwd(in, rows, o.cin, params + o.w_off, bias, out, o.cout, o.act, s);
     return linear_fwd(in, K, params + o.w_off, bias, out, nullptr, o.cout, rows, K, o.cout, o.act, sc.ws, sc.ws_bytes, s);
   }
   if (o.kind == PV_OP_MAXPOOL2) return pv_maxpool2_fwd(in, out, B, si.H, si.W, si.C, nd, s);
@@ -248,10 +259,12 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
       return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);
     }
-    PV_TRY(linear_wgrad(g, o.cout, in, K, grads + o.w_off, db, rows, K, o.cout, sc.ws, sc.ws_bytes, s));
+    if (k1_lean()) PV_TRY(pv_k1_wgrad(g, in, rows, o.cin, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin));
+    else PV_TRY(linear_wgrad(g, o.cout, in, K, grads + o.w_off, db, rows, K, o.cout, sc.ws, sc.ws_bytes, s));
     if (!gin) return 0;
     // (the producing convolution's activation derivative rides in this GEMM's epilogue: act'(in), in = that layer's output)
     if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+    if (k1_lean()) return pv_k1_dgrad(g, rows, o.cout, params + o.w_off, gin, o.cin, fuse_act != PV_ACT_NONE ? in : nullptr, fuse_act, s);
     return linear_dgrad(g, o.cout, params + o.w_off, gin, K, fuse_act != PV_ACT_NONE ? in : nullptr, nullptr, K, fuse_act, rows, K,
                         o.cout, sc.ws, sc.ws_bytes, s);
   }

@@ -383,3 +383,37 @@ def test_latent_to_features_without_transposes(gpu_device, B, S, Cc, zd):
     assert rel_l2(dw, gf.t() @ z.double()) < 2e-6
     assert rel_l2(db, gf.sum(0)) < 2e-6
     assert rel_l2(dz, gf @ w.double()) < 2e-6
+
+
+K1_CASES = [  # (rows, Cin, Cout, act): the 1-D decoder's shapes of BASELINE config 5 and ragged / unaligned ones
+    (4096, 128, 128, "none"), (8192, 64, 64, "lrelu"), (16384, 32, 32, "tanh"), (32768, 32, 1, "none"), (50, 48, 20, "relu"),
+    (33, 7, 5, "sigmoid"), (1000, 256, 96, "softplus"), (17, 16, 4, "lrelu"), (70000, 1, 3, "none")]
+
+
+@pytest.mark.parametrize("rows,Ci,Co,act", K1_CASES)
+def test_kernel1_convolution_family(gpu_device, rows, Ci, Co, act):
+    """pv_conv_k1.hip: the kernel-1 convolution (a Linear over the pixels of a channels-last map) forward, input gradient
+    (with the producing layer's activation derivative folded in) and weight / bias gradient, against float64."""
+    g = torch.Generator().manual_seed(rows + Ci + Co)
+    x = torch.randn(rows, Ci, generator=g).cuda()
+    w = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda()
+    bias = torch.randn(Co, generator=g).cuda()
+    gy = torch.randn(rows, Co, generator=g).cuda()
+    yprev = act_fn(act, torch.randn(rows, Ci, generator=g)).cuda()        # the producing layer's output (for act')
+    L = lib()
+    L.pv_debug_k1_ws.restype = C.c_longlong
+    ws = torch.empty(max(int(L.pv_debug_k1_ws(C.c_longlong(rows), Ci, Co)), 256), dtype=torch.uint8, device="cuda")
+    out = torch.full((rows, Co), float("nan"), device="cuda")
+    gin = torch.full((rows, Ci), float("nan"), device="cuda")
+    dw = torch.full((Co, Ci), float("nan"), device="cuda")
+    db = torch.full((Co,), float("nan"), device="cuda")
+    args = (C.c_longlong(rows), Ci, Co)
+    tail = (ptr(ws), C.c_longlong(ws.numel()), stream())
+    assert L.pv_debug_k1(0, ptr(x), ptr(w), ptr(bias), ptr(out), P(0), *args, ACTS[act], P(0), *tail) == 0
+    assert L.pv_debug_k1(1, ptr(gy), ptr(w), P(0), ptr(gin), P(0), *args, ACTS[act], ptr(yprev), *tail) == 0
+    assert L.pv_debug_k1(2, ptr(gy), ptr(x), P(0), ptr(dw), ptr(db), *args, 0, P(0), *tail) == 0
+    ref = act_fn(act, x.double() @ w.double().t() + bias.double())
+    assert rel_l2(out, ref) < 2e-6
+    assert rel_l2(gin, (gy.double() @ w.double()) * act_grad_of_output(act, yprev.double())) < 2e-6
+    assert rel_l2(dw, gy.double().t() @ x.double()) < 2e-6
+    assert rel_l2(db, gy.double().sum(0)) < 2e-6
