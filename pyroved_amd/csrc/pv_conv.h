@@ -93,12 +93,15 @@ bool pv_l2f_supported(int64_t F, int zd, int C);
 int pv_l2f_fwd(const float* z, const float* wt, const float* bias, float* a, int B, int S, int C, int zd, hipStream_t s);
 int pv_l2f_wgrad(const float* g, const float* z, float* dw, float* db, int B, int S, int C, int zd, hipStream_t s);
 // kernel-1 convolutions over channels-last maps (pv_conv_k1.hip): operands straight from L2 into f32 MFMAs, no LDS stages
-int pv_k1_fwd(const float* in, int64_t rows, int Ci, const float* w, const float* bias, float* out, int Co, int act, hipStream_t s);
+// up = 1: the 1-D nearest 2x upsample that follows the convolution fused (forward: every output row stored twice; backward:
+// g has 2 rows rows and g[p] stands for g[2p] + g[2p + 1])
+int pv_k1_fwd(const float* in, int64_t rows, int Ci, const float* w, const float* bias, float* out, int Co, int act, hipStream_t s,
+              int up = 0);
 int pv_k1_dgrad(const float* g, int64_t rows, int Co, const float* w, float* gin, int Ci, const float* eg_y, int eg_act,
-                hipStream_t s);
+                hipStream_t s, int up = 0);
 int64_t pv_k1_wgrad_ws(int64_t rows, int Ci, int Co);
 int pv_k1_wgrad(const float* g, const float* in, int64_t rows, int Ci, int Co, float* dw, float* db, void* ws, int64_t ws_bytes,
-                hipStream_t s, PvFinishList* defer = nullptr);
+                hipStream_t s, PvFinishList* defer = nullptr, int up = 0);
 // y (B, N) = x (B, K; row stride ldx) w(N, K)^T for K <= 16
 int pv_smallk_linear(const float* x, int64_t ldx, const float* w, float* y, int64_t B, int K, int N, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -21,6 +21,8 @@ struct K1Fwd {
   const float* in; const float* w; const float* bias; float* out; const float* eg_y;
   int64_t rows;
   int K, N, ld_in, ld_out, w_ns, w_ks, act, eg_act, ngroups, w_bytes;
+  int up_out, up_in;      // 1-D nearest 2x upsample fused: every output row stored twice (rows 2p, 2p + 1) / the input row is the sum of
+                          // rows 2p and 2p + 1 (the upsample's backward)
 };
 
 // The vector form: K % 16 == 0, N % 4 == 0, 16-byte aligned pixel rows.  NJ 16-wide contraction groups per register chunk
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void pv_k1_fwd_kernel(K1Fwd a) {
   if (rb * 16 >= a.rows) return;                                   // (no barrier in this kernel)
   const int64_t row = rb * 16 + r;
   const bool rok = row < a.rows;
-  const float* ip = a.in + (rok ? row : 0) * a.ld_in + 4 * q;
+  const float* ip = a.in + (rok ? row : 0) * (a.up_in ? 2 : 1) * a.ld_in + 4 * q;
   const int n0 = 16 * NB * ng;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
   const float* wp[NB];
@@ -55,6 +57,10 @@ __global__ __launch_bounds__(256) void pv_k1_fwd_kernel(K1Fwd a) {
     f32x4 x[NJ], w[NB][NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) x[j] = *reinterpret_cast<const f32x4*>(ip + kc + 16 * j);
+    if (a.up_in) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) x[j] = x[j] + *reinterpret_cast<const f32x4*>(ip + a.ld_in + kc + 16 * j);
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -94,7 +100,12 @@ __global__ __launch_bounds__(256) void pv_k1_fwd_kernel(K1Fwd a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] *= pv_act_grad(y[i], 0.0f, a.eg_act);
     }
-    *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + n) = v;
+    if (a.up_out) {
+      *reinterpret_cast<f32x4*>(a.out + 2 * row * a.ld_out + n) = v;
+      *reinterpret_cast<f32x4*>(a.out + (2 * row + 1) * a.ld_out + n) = v;
+    } else {
+      *reinterpret_cast<f32x4*>(a.out + row * a.ld_out + n) = v;
+    }
   }
 }
 
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(256) void pv_k1_gen_kernel(K1Fwd a) {
   if (rb * 16 >= a.rows) return;
   const int64_t row = rb * 16 + r;
   const bool rok = row < a.rows;
-  const float* ip = a.in + (rok ? row : 0) * a.ld_in;
+  const float* ip = a.in + (rok ? row : 0) * (a.up_in ? 2 : 1) * a.ld_in;
   const int n = 16 * ng + r;
   const float* wp = a.w + (int64_t)(n < a.N ? n : 0) * a.w_ns;
   f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(256) void pv_k1_gen_kernel(K1Fwd a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + 4 * q + i, kk = k < a.K ? k : a.K - 1;
-      const float xv = ip[kk], wv = wp[(int64_t)kk * a.w_ks];
+      const float xv = ip[kk] + (a.up_in ? ip[a.ld_in + kk] : 0.0f), wv = wp[(int64_t)kk * a.w_ks];
       x[i] = k < a.K ? xv : 0.0f;
       w[i] = k < a.K ? wv : 0.0f;
     }
@@ -132,7 +143,8 @@ __global__ __launch_bounds__(256) void pv_k1_gen_kernel(K1Fwd a) {
     float t = acc[i] + (a.bias ? a.bias[no] : 0.0f);
     t = pv_act_fwd(t, a.act);
     if (a.eg_y) t *= pv_act_grad(a.eg_y[row * a.ld_out + no], 0.0f, a.eg_act);
-    a.out[row * a.ld_out + no] = t;
+    if (a.up_out) { a.out[2 * row * a.ld_out + no] = t; a.out[(2 * row + 1) * a.ld_out + no] = t; }
+    else a.out[row * a.ld_out + no] = t;
   }
 }
 
@@ -175,21 +187,22 @@ static int k1_launch(K1Fwd a, int64_t w_elems, hipStream_t s) {
   return 0;
 }
 
-// out (rows, Co) = act(in (rows, Ci) w (Co, Ci)^T + bias)
+// out (rows, Co) = act(in (rows, Ci) w (Co, Ci)^T + bias); up: out has 2 rows rows, row p written to 2p and 2p + 1
 int pv_k1_fwd(const float* in, int64_t rows, int Ci, const float* w, const float* bias, float* out, int Co, int act,
-              hipStream_t s) {
+              hipStream_t s, int up) {
   K1Fwd a{};
   a.in = in; a.w = w; a.bias = bias; a.out = out; a.rows = rows; a.K = Ci; a.N = Co; a.ld_in = Ci; a.ld_out = Co;
-  a.w_ns = Ci; a.w_ks = 1; a.act = act;
+  a.w_ns = Ci; a.w_ks = 1; a.act = act; a.up_out = up;
   return k1_launch(a, (int64_t)Co * Ci, s);
 }
 
-// gin (rows, Ci) = (g (rows, Co) w (Co, Ci)) * act'(eg_y), eg_y shaped like gin (null: no factor)
+// gin (rows, Ci) = (g (rows, Co) w (Co, Ci)) * act'(eg_y), eg_y shaped like gin (null: no factor); up: g has 2 rows rows and
+// g[p] stands for g[2p] + g[2p + 1]
 int pv_k1_dgrad(const float* g, int64_t rows, int Co, const float* w, float* gin, int Ci, const float* eg_y, int eg_act,
-                hipStream_t s) {
+                hipStream_t s, int up) {
   K1Fwd a{};
   a.in = g; a.w = w; a.out = gin; a.rows = rows; a.K = Co; a.N = Ci; a.ld_in = Co; a.ld_out = Ci;
-  a.w_ns = 1; a.w_ks = Ci; a.act = PV_ACT_NONE;
+  a.w_ns = 1; a.w_ks = Ci; a.act = PV_ACT_NONE; a.up_in = up;
   if (eg_y && eg_act != PV_ACT_NONE) { a.eg_y = eg_y; a.eg_act = eg_act; }
   return k1_launch(a, (int64_t)Co * Ci, s);
 }
@@ -198,7 +211,7 @@ int pv_k1_dgrad(const float* g, int64_t rows, int Co, const float* w, float* gin
 struct K1Wg {
   const float* g; const float* in; float* part; float* part_b;
   int64_t rows, chunk;
-  int Ci, Co, mtiles, ntiles, nsplit;
+  int Ci, Co, mtiles, ntiles, nsplit, up;
 };
 
 #define K1_WB 64                     // pixels per register batch of a wave
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
     for (int s = 0; s < K1_WB / 4; ++s) {
       const int64_t p = b0 + 4 * s + q;
       const int64_t pc = p < p1 ? p : p1 - 1;
-      const float x = gp[pc * a.Co], y = xp[pc * a.Ci];
+      const float x = a.up ? gp[2 * pc * a.Co] + gp[(2 * pc + 1) * a.Co] : gp[pc * a.Co], y = xp[pc * a.Ci];
       gv[s] = (p < p1 && mok) ? x : 0.0f;
       xv[s] = (p < p1 && nok) ? y : 0.0f;
     }
@@ -268,13 +281,13 @@ int64_t pv_k1_wgrad_ws(int64_t rows, int Ci, int Co) {
 
 // dw (Co, Ci) = g (rows, Co)^T in (rows, Ci); db (Co) = column sums of g (null: none)
 int pv_k1_wgrad(const float* g, const float* in, int64_t rows, int Ci, int Co, float* dw, float* db, void* ws, int64_t ws_bytes,
-                hipStream_t s, PvFinishList* defer) {
+                hipStream_t s, PvFinishList* defer, int up) {
   if (rows < 1 || Ci < 1 || Co < 1) return PV_EINVAL;
   const int64_t need = pv_k1_wgrad_ws(rows, Ci, Co);
   const bool deferred = pv_wgrad_ws(defer, need, ws, ws_bytes);
   if (!ws || ws_bytes < need) return PV_EWS;
   K1Wg a{};
-  a.g = g; a.in = in; a.rows = rows; a.Ci = Ci; a.Co = Co;
+  a.g = g; a.in = in; a.rows = rows; a.Ci = Ci; a.Co = Co; a.up = up;
   a.mtiles = (Co + 15) / 16; a.ntiles = (Ci + 15) / 16;
   a.nsplit = k1_wg_splits(rows, Ci, Co);
   a.chunk = (rows + a.nsplit - 1) / a.nsplit;
@@ -291,9 +304,11 @@ int pv_k1_wgrad(const float* g, const float* in, int64_t rows, int Ci, int Co, f
 extern "C" int pv_debug_k1(int what, const float* a0, const float* a1, const float* a2, float* o0, float* o1, long long rows,
                            int Ci, int Co, int act, const float* eg_y, void* ws, long long ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (what == 0) return pv_k1_fwd(a0, rows, Ci, a1, a2, o0, Co, act, s);                      // in, w, bias -> out
-  if (what == 1) return pv_k1_dgrad(a0, rows, Co, a1, o0, Ci, eg_y, act, s);                  // g, w -> gin
-  if (what == 2) return pv_k1_wgrad(a0, a1, rows, Ci, Co, o0, o1, ws, ws_bytes, s, nullptr);  // g, in -> dw, db
+  const int up = what >> 2;                                                                       // (+4: the fused-upsample forms)
+  what &= 3;
+  if (what == 0) return pv_k1_fwd(a0, rows, Ci, a1, a2, o0, Co, act, s, up);                      // in, w, bias -> out
+  if (what == 1) return pv_k1_dgrad(a0, rows, Co, a1, o0, Ci, eg_y, act, s, up);                  // g, w -> gin
+  if (what == 2) return pv_k1_wgrad(a0, a1, rows, Ci, Co, o0, o1, ws, ws_bytes, s, nullptr, up);  // g, in -> dw, db
   return PV_EINVAL;
 }
 extern "C" long long pv_debug_k1_ws(long long rows, int Ci, int Co) { return pv_k1_wgrad_ws(rows, Ci, Co); }

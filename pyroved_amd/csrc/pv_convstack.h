@@ -188,6 +188,16 @@ inline bool k1_lean() {
   return v == 1;
 }
 
+// a kernel-1 convolution without activation followed by the 1-D nearest upsample (UpsampleBlock with the convolution first):
+// one launch each way — the forward stores every row twice, the backward kernels read the sum of the two rows
+// (PV_NO_K1UP=1: separate upsample launches)
+inline bool k1up_fusable(const pv_op* ops, int n, int nd, int i) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PV_NO_K1UP"); v = (e && atoi(e) != 0) ? 0 : 1; }
+  return v == 1 && k1_lean() && nd == 1 && i >= 0 && i + 1 < n && ops[i].kind == PV_OP_CONV && ops[i].ksize == 1 &&
+         ops[i].act == PV_ACT_NONE && ops[i + 1].kind == PV_OP_UPSAMPLE2;
+}
+
 inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const float* in, const Shape& si, float* out,
                   const Scratch& sc, int slot, hipStream_t s) {
   if (o.kind == PV_OP_BATCHNORM) {
@@ -222,7 +232,7 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
 // *fused = true when done) instead of a separate elementwise pass in the producer's backward
 inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int B, const float* in, const Shape& si,
                   const float* out, float* g, float* gin, const Scratch& sc, int slot, hipStream_t s, bool g_is_pre = false,
-                  int fuse_act = PV_ACT_NONE, bool* fused = nullptr) {
+                  int fuse_act = PV_ACT_NONE, bool* fused = nullptr, int g_up = 0) {
   if (fused) *fused = false;
   if (fuse_act == PV_ACT_GELU) fuse_act = PV_ACT_NONE;
   if (o.kind == PV_OP_BATCHNORM)
@@ -259,12 +269,13 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       PV_TRY(pv_conv_wflip(params + o.w_off, sc.col, o.cout, o.cin, kk_of(o, nd), s));
       return conv3_fwd(g, B, si.H, si.W, o.cout, nd, sc.col, nullptr, gin, o.cin, PV_ACT_NONE, sc.ws, sc.ws_bytes, s);
     }
-    if (k1_lean()) PV_TRY(pv_k1_wgrad(g, in, rows, o.cin, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin));
+    if (g_up && !k1_lean()) return PV_EINVAL;
+    if (k1_lean()) PV_TRY(pv_k1_wgrad(g, in, rows, o.cin, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin, g_up));
     else PV_TRY(linear_wgrad(g, o.cout, in, K, grads + o.w_off, db, rows, K, o.cout, sc.ws, sc.ws_bytes, s));
     if (!gin) return 0;
     // (the producing convolution's activation derivative rides in this GEMM's epilogue: act'(in), in = that layer's output)
     if (fused && fuse_act != PV_ACT_NONE) *fused = true;
-    if (k1_lean()) return pv_k1_dgrad(g, rows, o.cout, params + o.w_off, gin, o.cin, fuse_act != PV_ACT_NONE ? in : nullptr, fuse_act, s);
+    if (k1_lean()) return pv_k1_dgrad(g, rows, o.cout, params + o.w_off, gin, o.cin, fuse_act != PV_ACT_NONE ? in : nullptr, fuse_act, s, g_up);
     return linear_dgrad(g, o.cout, params + o.w_off, gin, K, fuse_act != PV_ACT_NONE ? in : nullptr, nullptr, K, fuse_act, rows, K,
                         o.cout, sc.ws, sc.ws_bytes, s);
   }
@@ -296,6 +307,13 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
       ++i;
       continue;
     }
+    if (k1up_fusable(ops, n, nd, i)) {                                               // a[i + 1] is never written
+      const pv_op& o = ops[i];
+      PV_TRY(pv_k1_fwd(a[i], (int64_t)B * sh[i].H * sh[i].W, o.cin, params + o.w_off, o.b_off >= 0 ? params + o.b_off : nullptr,
+                       a[i + 2], o.cout, PV_ACT_NONE, s, 1));
+      ++i;
+      continue;
+    }
     PV_TRY(op_fwd(params, ops[i], nd, B, a[i], sh[i], a[i + 1], sc, stack_id * PV_MAX_OPS + i, s));
   }
   return 0;
@@ -324,12 +342,14 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
       g = gin2; pp ^= 1;
       continue;
     }
+    if (k1up_fusable(ops, n, nd, i - 1)) continue;     // the upsample of a fused pair: its backward rides in the convolution's
+    const int g_up = k1up_fusable(ops, n, nd, i) ? 1 : 0;
     float* gin = (i > 0 || need_input_grad) ? gbuf[pp] : nullptr;
     // the layer below is a convolution with an activation: let this op's backward apply act'(a[i]) to gin
     const int fuse_act = (i > 0 && gin && ops[i - 1].kind == PV_OP_CONV) ? ops[i - 1].act : PV_ACT_NONE;
     bool fused = false;
     PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, sc, stack_id * PV_MAX_OPS + i, s, g_is_pre,
-                  fuse_act, &fused));
+                  fuse_act, &fused, g_up));
     g_is_pre = fused;
     g = gin; pp ^= 1;
   }

@@ -417,3 +417,33 @@ def test_kernel1_convolution_family(gpu_device, rows, Ci, Co, act):
     assert rel_l2(gin, (gy.double() @ w.double()) * act_grad_of_output(act, yprev.double())) < 2e-6
     assert rel_l2(dw, gy.double().t() @ x.double()) < 2e-6
     assert rel_l2(db, gy.double().sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("rows,Ci,Co,act", [(4096, 128, 128, "lrelu"), (1024, 64, 64, "tanh"), (37, 24, 10, "relu"), (500, 32, 32, "none")])
+def test_kernel1_convolution_with_fused_upsample(gpu_device, rows, Ci, Co, act):
+    """the 1-D nearest 2x upsample that follows an UpsampleBlock's convolution, fused: forward rows stored twice, backward
+    kernels reading g[2p] + g[2p + 1]."""
+    g = torch.Generator().manual_seed(rows + Ci + Co + 1)
+    x = torch.randn(rows, Ci, generator=g).cuda()
+    w = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda()
+    bias = torch.randn(Co, generator=g).cuda()
+    gup = torch.randn(2 * rows, Co, generator=g).cuda()
+    yprev = act_fn(act, torch.randn(rows, Ci, generator=g)).cuda()
+    L = lib()
+    L.pv_debug_k1_ws.restype = C.c_longlong
+    ws = torch.empty(max(int(L.pv_debug_k1_ws(C.c_longlong(rows), Ci, Co)), 256), dtype=torch.uint8, device="cuda")
+    out = torch.full((2 * rows, Co), float("nan"), device="cuda")
+    gin = torch.full((rows, Ci), float("nan"), device="cuda")
+    dw = torch.full((Co, Ci), float("nan"), device="cuda")
+    db = torch.full((Co,), float("nan"), device="cuda")
+    args = (C.c_longlong(rows), Ci, Co)
+    tail = (ptr(ws), C.c_longlong(ws.numel()), stream())
+    assert L.pv_debug_k1(4, ptr(x), ptr(w), ptr(bias), ptr(out), P(0), *args, 0, P(0), *tail) == 0
+    assert L.pv_debug_k1(5, ptr(gup), ptr(w), P(0), ptr(gin), P(0), *args, ACTS[act], ptr(yprev), *tail) == 0
+    assert L.pv_debug_k1(6, ptr(gup), ptr(x), P(0), ptr(dw), ptr(db), *args, 0, P(0), *tail) == 0
+    ref = (x.double() @ w.double().t() + bias.double()).repeat_interleave(2, dim=0)
+    assert rel_l2(out, ref) < 2e-6
+    gy = gup.double().reshape(rows, 2, Co).sum(1)
+    assert rel_l2(gin, (gy @ w.double()) * act_grad_of_output(act, yprev.double())) < 2e-6
+    assert rel_l2(dw, gy.t() @ x.double()) < 2e-6
+    assert rel_l2(db, gy.sum(0)) < 2e-6
