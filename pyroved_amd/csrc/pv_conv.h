@@ -102,6 +102,10 @@ int pv_k1_dgrad(const float* g, int64_t rows, int Co, const float* w, float* gin
 int64_t pv_k1_wgrad_ws(int64_t rows, int Ci, int Co);
 int pv_k1_wgrad(const float* g, const float* in, int64_t rows, int Ci, int Co, float* dw, float* db, void* ws, int64_t ws_bytes,
                 hipStream_t s, PvFinishList* defer = nullptr, int up = 0);
+// kernel-3 1-D convolution weight gradient on the same register-fed kernel (dw (Co, Ci, 3))
+int64_t pv_conv3_1d_wgrad_lean_ws(int B, int L, int Ci, int Co);
+int pv_conv3_1d_wgrad_lean(const float* g, const float* in, int B, int L, int Ci, int Co, float* dw, float* db, void* ws,
+                           int64_t ws_bytes, hipStream_t s, PvFinishList* defer = nullptr);
 // y (B, N) = x (B, K; row stride ldx) w(N, K)^T for K <= 16
 int pv_smallk_linear(const float* x, int64_t ldx, const float* w, float* y, int64_t B, int K, int N, hipStream_t s);
 int pv_upsample2_bil_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -212,6 +212,8 @@ struct K1Wg {
   const float* g; const float* in; float* part; float* part_b;
   int64_t rows, chunk;
   int Ci, Co, mtiles, ntiles, nsplit, up;
+  int taps, L;            // taps = 3: the kernel-3 1-D convolution's weight gradient, dW[m][n][t] = sum_p g[p][m] in[p + t - 1][n] within
+                          // a sample of L positions (zero padding); taps = 1: kernel 1
 };
 
 #define K1_WB 64                     // pixels per register batch of a wave
@@ -222,7 +224,8 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = a.mtiles * a.ntiles;
-  const int sp = blockIdx.x / tiles, t = blockIdx.x - sp * tiles;
+  const int sp = blockIdx.x / (tiles * a.taps), tt = blockIdx.x - sp * tiles * a.taps;
+  const int tap = tt / tiles, t = tt - tap * tiles;
   const int mb = t / a.ntiles, nb = t - mb * a.ntiles;
   // A lane (m = output channel 16 mb + r, pixel slot q), B lane (n = input channel 16 nb + r, pixel slot q)
   const int m = 16 * mb + r, n = 16 * nb + r;
@@ -230,6 +233,8 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
   const float* gp = a.g + (mok ? m : 0);
   const float* xp = a.in + (nok ? n : 0);
   const int64_t p0 = (int64_t)sp * a.chunk, p1 = p0 + a.chunk < a.rows ? p0 + a.chunk : a.rows;
+  const int sh = a.taps == 3 ? tap - 1 : 0;                  // input position = output position + sh
+  const bool pow2 = (a.L & (a.L - 1)) == 0;
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -240,9 +245,16 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
     for (int s = 0; s < K1_WB / 4; ++s) {
       const int64_t p = b0 + 4 * s + q;
       const int64_t pc = p < p1 ? p : p1 - 1;
-      const float x = a.up ? gp[2 * pc * a.Co] + gp[(2 * pc + 1) * a.Co] : gp[pc * a.Co], y = xp[pc * a.Ci];
+      bool xok = p < p1 && nok;
+      int64_t px = pc;
+      if (sh != 0) {
+        const int l = pow2 ? (int)(pc & (a.L - 1)) : (int)(pc % a.L);
+        xok = xok && l + sh >= 0 && l + sh < a.L;
+        px = pc + sh < 0 ? 0 : pc + sh >= a.rows ? a.rows - 1 : pc + sh;
+      }
+      const float x = a.up ? gp[2 * pc * a.Co] + gp[(2 * pc + 1) * a.Co] : gp[pc * a.Co], y = xp[px * a.Ci];
       gv[s] = (p < p1 && mok) ? x : 0.0f;
-      xv[s] = (p < p1 && nok) ? y : 0.0f;
+      xv[s] = xok ? y : 0.0f;
     }
 #pragma unroll
     for (int s = 0; s < K1_WB / 4; ++s) {
@@ -260,14 +272,14 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
   __syncthreads();
   const int mm = tid >> 4, nn = tid & 15, mo = 16 * mb + mm, no = 16 * nb + nn;
   if (mo < a.Co && no < a.Ci)
-    a.part[(int64_t)sp * a.Co * a.Ci + (int64_t)mo * a.Ci + no] =
+    a.part[((int64_t)sp * a.Co * a.Ci + (int64_t)mo * a.Ci + no) * a.taps + tap] =
         (part[0][mm][nn] + part[1][mm][nn]) + (part[2][mm][nn] + part[3][mm][nn]);
-  if (a.part_b && nb == 0 && tid < 16 && 16 * mb + tid < a.Co)
+  if (a.part_b && nb == 0 && tap == 0 && tid < 16 && 16 * mb + tid < a.Co)
     a.part_b[(int64_t)sp * a.Co + 16 * mb + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
 }
 
-static int k1_wg_splits(int64_t rows, int Ci, int Co) {
-  const int64_t tiles = (int64_t)((Co + 15) / 16) * ((Ci + 15) / 16);
+static int k1_wg_splits(int64_t rows, int Ci, int Co, int taps) {
+  const int64_t tiles = (int64_t)((Co + 15) / 16) * ((Ci + 15) / 16) * taps;
   int64_t ns = (rows + 4 * K1_WB - 1) / (4 * K1_WB);          // one register batch per wave
   const int64_t cap = (1024 + tiles - 1) / tiles;              // ~4 workgroups per CU in all
   if (ns > cap) ns = cap;
@@ -275,29 +287,43 @@ static int k1_wg_splits(int64_t rows, int Ci, int Co) {
   return (int)ns;
 }
 
-int64_t pv_k1_wgrad_ws(int64_t rows, int Ci, int Co) {
-  return (int64_t)k1_wg_splits(rows, Ci, Co) * ((int64_t)Co * Ci + Co) * (int64_t)sizeof(float);
+static int64_t k1_wg_ws(int64_t rows, int Ci, int Co, int taps) {
+  return (int64_t)k1_wg_splits(rows, Ci, Co, taps) * ((int64_t)Co * Ci * taps + Co) * (int64_t)sizeof(float);
+}
+int64_t pv_k1_wgrad_ws(int64_t rows, int Ci, int Co) { return k1_wg_ws(rows, Ci, Co, 1); }
+int64_t pv_conv3_1d_wgrad_lean_ws(int B, int L, int Ci, int Co) { return k1_wg_ws((int64_t)B * L, Ci, Co, 3); }
+
+static int k1_wgrad_launch(const float* g, const float* in, int64_t rows, int L, int taps, int Ci, int Co, float* dw, float* db,
+                           void* ws, int64_t ws_bytes, hipStream_t s, PvFinishList* defer, int up) {
+  if (rows < 1 || Ci < 1 || Co < 1 || L < 1) return PV_EINVAL;
+  const int64_t need = k1_wg_ws(rows, Ci, Co, taps);
+  const bool deferred = pv_wgrad_ws(defer, need, ws, ws_bytes);
+  if (!ws || ws_bytes < need) return PV_EWS;
+  K1Wg a{};
+  a.g = g; a.in = in; a.rows = rows; a.Ci = Ci; a.Co = Co; a.up = up; a.taps = taps; a.L = L;
+  a.mtiles = (Co + 15) / 16; a.ntiles = (Ci + 15) / 16;
+  a.nsplit = k1_wg_splits(rows, Ci, Co, taps);
+  a.chunk = (rows + a.nsplit - 1) / a.nsplit;
+  a.chunk = (a.chunk + 3) / 4 * 4;
+  a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
+  a.part = (float*)ws;
+  a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
+  hipLaunchKernelGGL(pv_k1_wgrad_kernel, dim3((unsigned)(a.mtiles * a.ntiles * taps * a.nsplit)), dim3(256), 0, s, a);
+  PV_LAUNCH_CHECK();
+  return pv_wgrad_finish(deferred ? defer : nullptr, a.part, a.nsplit, (int64_t)Co * Ci * taps, dw, a.part_b, Co, db, s);
 }
 
 // dw (Co, Ci) = g (rows, Co)^T in (rows, Ci); db (Co) = column sums of g (null: none)
 int pv_k1_wgrad(const float* g, const float* in, int64_t rows, int Ci, int Co, float* dw, float* db, void* ws, int64_t ws_bytes,
                 hipStream_t s, PvFinishList* defer, int up) {
-  if (rows < 1 || Ci < 1 || Co < 1) return PV_EINVAL;
-  const int64_t need = pv_k1_wgrad_ws(rows, Ci, Co);
-  const bool deferred = pv_wgrad_ws(defer, need, ws, ws_bytes);
-  if (!ws || ws_bytes < need) return PV_EWS;
-  K1Wg a{};
-  a.g = g; a.in = in; a.rows = rows; a.Ci = Ci; a.Co = Co; a.up = up;
-  a.mtiles = (Co + 15) / 16; a.ntiles = (Ci + 15) / 16;
-  a.nsplit = k1_wg_splits(rows, Ci, Co);
-  a.chunk = (rows + a.nsplit - 1) / a.nsplit;
-  a.chunk = (a.chunk + 3) / 4 * 4;
-  a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
-  a.part = (float*)ws;
-  a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci : nullptr;
-  hipLaunchKernelGGL(pv_k1_wgrad_kernel, dim3((unsigned)(a.mtiles * a.ntiles * a.nsplit)), dim3(256), 0, s, a);
-  PV_LAUNCH_CHECK();
-  return pv_wgrad_finish(deferred ? defer : nullptr, a.part, a.nsplit, (int64_t)Co * Ci, dw, a.part_b, Co, db, s);
+  return k1_wgrad_launch(g, in, rows, 1, 1, Ci, Co, dw, db, ws, ws_bytes, s, defer, up);
+}
+
+// the kernel-3, padding-1 1-D convolution's weight gradient on the same kernel (three shifted, boundary-masked problems):
+// dw (Co, Ci, 3), g (B, L, Co), in (B, L, Ci)
+int pv_conv3_1d_wgrad_lean(const float* g, const float* in, int B, int L, int Ci, int Co, float* dw, float* db, void* ws,
+                           int64_t ws_bytes, hipStream_t s, PvFinishList* defer) {
+  return k1_wgrad_launch(g, in, (int64_t)B * L, L, 3, Ci, Co, dw, db, ws, ws_bytes, s, defer, 0);
 }
 
 // ---- test hooks (tests/test_gpu_conv_kernels.py) --------------------------------------------------------------------
@@ -309,6 +335,8 @@ extern "C" int pv_debug_k1(int what, const float* a0, const float* a1, const flo
   if (what == 0) return pv_k1_fwd(a0, rows, Ci, a1, a2, o0, Co, act, s, up);                      // in, w, bias -> out
   if (what == 1) return pv_k1_dgrad(a0, rows, Co, a1, o0, Ci, eg_y, act, s, up);                  // g, w -> gin
   if (what == 2) return pv_k1_wgrad(a0, a1, rows, Ci, Co, o0, o1, ws, ws_bytes, s, nullptr, up);  // g, in -> dw, db
+  if (what == 3)                                                                                  // kernel 3, 1-D: act = L
+    return pv_conv3_1d_wgrad_lean(a0, a1, (int)(rows / act), act, Ci, Co, o0, o1, ws, ws_bytes, s, nullptr);
   return PV_EINVAL;
 }
-extern "C" long long pv_debug_k1_ws(long long rows, int Ci, int Co) { return pv_k1_wgrad_ws(rows, Ci, Co); }
+extern "C" long long pv_debug_k1_ws(long long rows, int Ci, int Co) { return k1_wg_ws(rows, Ci, Co, 3); }

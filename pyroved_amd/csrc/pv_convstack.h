@@ -96,6 +96,8 @@ inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, N
         int64_t w = pv_conv3_wgrad_direct_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd);
         upd(w, pv_conv3_wgrad_c1_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout, nd));
         if (nd == 2) upd(w, pv_conv3_sp_wgrad_ws((int)B, s[i].H, s[i].W, ops[i].cin, ops[i].cout));
+        if (nd == 1) upd(w, pv_conv3_1d_wgrad_lean_ws((int)B, s[i].H, ops[i].cin, ops[i].cout));
+        upd(nd_.scratch, w);
         nd_.wg_sum += pv_align_up(w, 256);
       } else {
         upd(nd_.scratch, pv_k1_wgrad_ws(rows, ops[i].cin, ops[i].cout));
@@ -188,6 +190,13 @@ inline bool k1_lean() {
   return v == 1;
 }
 
+// kernel-3 1-D weight gradients on the kernel-1 family's register-fed kernel (PV_NO_K3LEAN=1: the LDS-tiled direct kernels)
+inline bool k3_lean_1d(int nd) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PV_NO_K3LEAN"); v = (e && atoi(e) != 0) ? 0 : 1; }
+  return v == 1 && nd == 1 && k1_lean();
+}
+
 // a kernel-1 convolution without activation followed by the 1-D nearest upsample (UpsampleBlock with the convolution first):
 // one launch each way — the forward stores every row twice, the backward kernels read the sum of the two rows
 // (PV_NO_K1UP=1: separate upsample launches)
@@ -246,6 +255,8 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s,
                                  sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), sc.fin));
+      else if (k3_lean_1d(nd) && !sc.conv_bf16)          // (the mixed-precision leg's bf16 kernel is the faster one there)
+        PV_TRY(pv_conv3_1d_wgrad_lean(g, in, B, si.H, si.C, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin));
       else if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_wgrad_direct_bf16(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, sc.fin));
       else if (pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))

@@ -447,3 +447,25 @@ def test_kernel1_convolution_with_fused_upsample(gpu_device, rows, Ci, Co, act):
     assert rel_l2(gin, (gy @ w.double()) * act_grad_of_output(act, yprev.double())) < 2e-6
     assert rel_l2(dw, gy.t() @ x.double()) < 2e-6
     assert rel_l2(db, gy.sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ln,Ci,Co", [(256, 16, 128, 128), (64, 32, 64, 64), (5, 24, 20, 12), (3, 7, 32, 8), (2, 1, 16, 16), (9, 128, 32, 1)])
+def test_kernel3_1d_weight_gradient_on_the_register_fed_kernel(gpu_device, B, Ln, Ci, Co):
+    """the kernel-3, padding-1 Conv1d weight gradient as three shifted, boundary-masked kernel-1 problems, against float64."""
+    g = torch.Generator().manual_seed(B + Ln + Ci + Co)
+    x = torch.randn(B, Ln, Ci, generator=g).cuda()
+    gy = torch.randn(B, Ln, Co, generator=g).cuda()
+    L = lib()
+    L.pv_debug_k1_ws.restype = C.c_longlong
+    rows = B * Ln
+    ws = torch.empty(max(int(L.pv_debug_k1_ws(C.c_longlong(rows), Ci, Co)), 256), dtype=torch.uint8, device="cuda")
+    dw = torch.full((Co, Ci, 3), float("nan"), device="cuda")
+    db = torch.full((Co,), float("nan"), device="cuda")
+    assert L.pv_debug_k1(3, ptr(gy), ptr(x), P(0), ptr(dw), ptr(db), C.c_longlong(rows), Ci, Co, Ln, P(0), ptr(ws),
+                         C.c_longlong(ws.numel()), stream()) == 0
+    xd = x.double().permute(0, 2, 1)
+    wd = torch.zeros(Co, Ci, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = F.conv1d(xd, wd, None, padding=1)
+    (gw,) = torch.autograd.grad(y, wd, gy.double().permute(0, 2, 1))
+    assert rel_l2(dw, gw) < 2e-6
+    assert rel_l2(db, gy.double().sum((0, 1))) < 2e-6
