@@ -166,7 +166,8 @@ __global__ void pv_conv3_sp_wprep_kernel(const float* __restrict__ w, unsigned s
 }
 
 // ---- every weight tiling of a step in one launch: entry k covers element indices [start, start + total) ----------------
-struct WprepTab { PvWprepEntry e[16]; int n; int64_t total; };
+#define WPREP_CAP 32
+struct WprepTab { PvWprepEntry e[WPREP_CAP]; int n; int64_t total; };
 
 __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < t.total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -236,9 +237,9 @@ int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd) {
 
 // fills start / total of the entries and launches (16 entries per launch)
 int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s) {
-  for (int lo = 0; lo < n; lo += 16) {
+  for (int lo = 0; lo < n; lo += WPREP_CAP) {
     WprepTab t{};
-    t.n = n - lo < 16 ? n - lo : 16;
+    t.n = n - lo < WPREP_CAP ? n - lo : WPREP_CAP;
     int64_t acc = 0;
     for (int k = 0; k < t.n; ++k) {
       e[lo + k].total = wprep_elems(e[lo + k].kind, e[lo + k].Co, e[lo + k].Ci, e[lo + k].KK, e[lo + k].flip);

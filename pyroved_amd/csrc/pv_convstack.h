@@ -165,10 +165,9 @@ inline PvWprepEntry head_entry(const float* w, float* dst, int out, int C, int64
 }
 
 // one launch per 16 tilings: everything wt_layout placed for this stack (flip 1 entries only when with_dgrad)
-inline int wt_prep(const float* params, const pv_op* ops, int n, int nd, int stack_id, int conv_bf16, const WtPlan& w, char* base,
-                   bool with_dgrad, hipStream_t s, const PvWprepEntry* extra = nullptr, int n_extra = 0) {
-  PvWprepEntry e[2 * PV_MAX_OPS + 4];
-  int ne = 0;
+// (wt_entries: append a stack's entries to e[]; wt_prep: one stack, one launch)
+inline void wt_entries(const float* params, const pv_op* ops, int n, int nd, int stack_id, int conv_bf16, const WtPlan& w, char* base,
+                       bool with_dgrad, PvWprepEntry* e, int& ne, const PvWprepEntry* extra = nullptr, int n_extra = 0) {
   for (int k = 0; k < n_extra && k < 4; ++k) e[ne++] = extra[k];     // (e.g. a conv head's re-indexed Linear weight)
   for (int i = 0; i < n; ++i)
     for (int flip = 0; flip < (with_dgrad ? 2 : 1); ++flip) {
@@ -178,6 +177,12 @@ inline int wt_prep(const float* params, const pv_op* ops, int n, int nd, int sta
       E.w = params + ops[i].w_off; E.dst = base + off; E.Co = ops[i].cout; E.Ci = ops[i].cin; E.KK = kk_of(ops[i], nd);
       E.flip = flip; E.kind = wt_kind(ops[i], nd, flip, conv_bf16); E.pad_ = 0; E.start = E.total = 0;
     }
+}
+inline int wt_prep(const float* params, const pv_op* ops, int n, int nd, int stack_id, int conv_bf16, const WtPlan& w, char* base,
+                   bool with_dgrad, hipStream_t s, const PvWprepEntry* extra = nullptr, int n_extra = 0) {
+  PvWprepEntry e[2 * PV_MAX_OPS + 4];
+  int ne = 0;
+  wt_entries(params, ops, n, nd, stack_id, conv_bf16, w, base, with_dgrad, e, ne, extra, n_extra);
   return ne ? pv_conv_wprep_table(e, ne, s) : 0;
 }
 inline float* bn_slot(const Scratch& sc, int slot) { return sc.bn + (int64_t)slot * 4 * sc.bn_maxC; }

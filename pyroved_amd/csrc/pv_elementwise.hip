@@ -1020,33 +1020,63 @@ extern "C" int pv_adam_step(float* params, float* grads, float* m, float* v, int
 
 // ---------------------------------------------------------------------------------------------
 // elementwise likelihood for the vanilla fcDecoderNet path (fc.py:143-152): a[M] logits -> loc, ll, dL/da
+__device__ __forceinline__ void pv_lik_one(float av, float xv, int lik, int sigmoid_out, float sig, float& ll, float& d, float& lv) {
+  if (lik == PV_LIK_BERNOULLI) {
+    const float pr = 1.0f / (1.0f + expf(-av));
+    const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
+    const float lg = logf(pc) - log1pf(-pc);
+    ll = -(fmaxf(lg, 0.0f) - lg * xv + log1pf(expf(-fabsf(lg))));
+    const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
+    d = (1.0f / (1.0f + expf(-lg)) - xv) * mask;
+    lv = pr;
+  } else if (lik == PV_LIK_CBERNOULLI) {
+    pv_cbern(av, xv, ll, d, lv);
+  } else {
+    const float pr = sigmoid_out ? 1.0f / (1.0f + expf(-av)) : av;
+    const float df = xv - pr;
+    ll = -(df * df) / (2.0f * sig * sig) - logf(sig) - LOG_SQRT_2PI;
+    d = -df / (sig * sig) * (sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+    lv = pr;
+  }
+}
+
 __global__ void pv_lik_elem_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t M, int lik,
                                    int sigmoid_out, float sig, float* __restrict__ loc, float* __restrict__ llrow,
                                    float* __restrict__ dlda) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M; e += (int64_t)gridDim.x * blockDim.x) {
-    const float av = a[e], xv = x[e];
     float ll, d, lv;
-    if (lik == PV_LIK_BERNOULLI) {
-      const float pr = 1.0f / (1.0f + expf(-av));
-      const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
-      const float lg = logf(pc) - log1pf(-pc);
-      ll = -(fmaxf(lg, 0.0f) - lg * xv + log1pf(expf(-fabsf(lg))));
-      const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
-      d = (1.0f / (1.0f + expf(-lg)) - xv) * mask;
-      lv = pr;
-    } else if (lik == PV_LIK_CBERNOULLI) {
-      pv_cbern(av, xv, ll, d, lv);
-    } else {
-      const float pr = sigmoid_out ? 1.0f / (1.0f + expf(-av)) : av;
-      const float df = xv - pr;
-      ll = -(df * df) / (2.0f * sig * sig) - logf(sig) - LOG_SQRT_2PI;
-      d = -df / (sig * sig) * (sigmoid_out ? pr * (1.0f - pr) : 1.0f);
-      lv = pr;
-    }
+    pv_lik_one(a[e], x[e], lik, sigmoid_out, sig, ll, d, lv);
     if (loc) loc[e] = lv;
     if (llrow) llrow[e] = ll;
     if (dlda) dlda[e] = d;
   }
+}
+
+// the same per element plus the per-sample sum (pv_segsum's order: thread t adds elements t, t + 256, ...): one workgroup
+// per sample, ll_b[b] = sum over the sample's `per` elements — pv_lik_elem + pv_segsum in one launch, bit-identical
+__global__ __launch_bounds__(256) void pv_lik_rows_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t per,
+                                                          int lik, int sigmoid_out, float sig, float* __restrict__ loc,
+                                                          float* __restrict__ dlda, float* __restrict__ llb) {
+  __shared__ float sm[4];
+  const int64_t base = (int64_t)blockIdx.x * per;
+  float acc = 0.0f;
+  for (int64_t n = threadIdx.x; n < per; n += 256) {
+    float ll, d, lv;
+    pv_lik_one(a[base + n], x[base + n], lik, sigmoid_out, sig, ll, d, lv);
+    if (loc) loc[base + n] = lv;
+    if (dlda) dlda[base + n] = d;
+    acc += ll;
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) llb[blockIdx.x] = acc;
+}
+
+int pv_lik_rows(const float* a, const float* x, int64_t B, int64_t per, int lik, int sigmoid_out, float sig, float* loc,
+                float* dlda, float* llb, hipStream_t s) {
+  if (B < 1) return 0;
+  hipLaunchKernelGGL(pv_lik_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, a, x, per, lik, sigmoid_out, sig, loc, dlda, llb);
+  PV_LAUNCH_CHECK();
+  return 0;
 }
 
 int pv_lik_elem(const float* a, const float* x, int64_t M, int lik, int sigmoid_out, float sig, float* loc,

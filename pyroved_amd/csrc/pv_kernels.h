@@ -150,6 +150,9 @@ struct PvFusedOffsets;
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
                          hipStream_t s);
 
+// pv_lik_elem + pv_segsum in one launch (one workgroup per sample; same summation order)
+int pv_lik_rows(const float* a, const float* x, int64_t B, int64_t per, int lik, int sigmoid_out, float sig, float* loc,
+                float* dlda, float* llb, hipStream_t s);
 int pv_lik_elem(const float* a, const float* x, int64_t M, int lik, int sigmoid_out, float sig, float* loc,
                 float* llrow, float* dlda, hipStream_t s);
 

@@ -113,19 +113,21 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
 
 // tile the conv weights the coming launches need: stack 0 / 1 / both, with or without the input-gradient orientation
 int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_dgrad, hipStream_t s) {
+  PvWprepEntry e[4 * PV_MAX_OPS + 8];                  // both stacks' tilings: one launch
+  int ne = 0;
   if (enc) {
     const Shape& fe = L.es[p->n_enc_ops];
     const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.head_wt, 2 * p->z_dim, fe.C, (int64_t)fe.H * fe.W);
-    PV_TRY(pvcs::wt_prep(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, L.wtp, L.wt, with_dgrad, s, &he,
-                         L.head_wt ? 1 : 0));
+    pvcs::wt_entries(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, L.wtp, L.wt, with_dgrad, e, ne, &he,
+                     L.head_wt ? 1 : 0);
   }
   if (dec) {
     PvWprepEntry le = pvcs::head_entry(p->params + p->l2f.w_off, L.l2f_wt, p->z_dim, L.ds[0].C, (int64_t)L.ds[0].H * L.ds[0].W);
     le.kind = 7;                                       // wt[k][s*C + c] = w[c*S + s][k]
-    PV_TRY(pvcs::wt_prep(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, s, &le,
-                         L.l2f_wt ? 1 : 0));
+    pvcs::wt_entries(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, e, ne, &le,
+                     L.l2f_wt ? 1 : 0);
   }
-  return 0;
+  return ne ? pv_conv_wprep_table(e, ne, s) : 0;
 }
 
 // encoder forward up to (head, z, z_scale[, KL scalars]); eps == null: inference (z = unused)
@@ -196,10 +198,16 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   const float* y = p->y;
   if (p->out_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->y, L.y_nsc, B, p->out_ch, S, s)); y = L.y_nsc; }
   float* loc = p->loc ? (p->out_ch > 1 ? L.loc_nsc : p->loc) : nullptr;
-  PV_TRY(pv_lik_elem(L.da[p->n_dec_ops], y, OUT, p->lik, p->sigmoid_out, p->decoder_sig, loc, L.llrow,
-                     want_grads ? L.dlda : nullptr, s));
-  if (p->loc && p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, p->loc, B, p->out_ch, S, s));
-  PV_TRY(pv_segsum(L.llrow, B, per, L.llb, s));
+  if (B >= 64 || per <= 4096) {                        // one workgroup per sample: element terms and their sum in one launch
+    PV_TRY(pv_lik_rows(L.da[p->n_dec_ops], y, B, per, p->lik, p->sigmoid_out, p->decoder_sig, loc, want_grads ? L.dlda : nullptr,
+                       L.llb, s));
+    if (p->loc && p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, p->loc, B, p->out_ch, S, s));
+  } else {
+    PV_TRY(pv_lik_elem(L.da[p->n_dec_ops], y, OUT, p->lik, p->sigmoid_out, p->decoder_sig, loc, L.llrow,
+                       want_grads ? L.dlda : nullptr, s));
+    if (p->loc && p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, p->loc, B, p->out_ch, S, s));
+    PV_TRY(pv_segsum(L.llrow, B, per, L.llb, s));
+  }
   PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, nullptr, 0, p->beta, s));
   if (!want_grads) return 0;
 
