@@ -56,6 +56,32 @@ __device__ __forceinline__ float pv_act_grad(float y, float pre, int act) {
   }
 }
 
+// Epilogue helpers.  pv_act_fwd / pv_act_grad inlined per VALUE put every activation's code (tanhf, erff, log1pf ...) behind a
+// run-time switch at each of a lane's 16 outputs: ~500 instructions and ~36 branches per value, 6-8 k of a GEMM kernel's 9 k
+// instructions.  pv_act_lin: the piecewise-linear activations (none / relu / lrelu) as v > 0 ? v : slope v, branch-free;
+// pv_act_pair_slow: ONE out-of-line copy per translation unit of the full switch, act(v) * act_aux'(y, pr).
+__device__ __forceinline__ bool pv_act_is_lin(int act) { return act == PV_ACT_NONE || act == PV_ACT_RELU || act == PV_ACT_LRELU; }
+__device__ __forceinline__ float pv_act_slope(int act) { return act == PV_ACT_NONE ? 1.0f : act == PV_ACT_RELU ? 0.0f : 0.01f; }
+static __device__ __noinline__ float pv_act_pair_slow(float v, int act, bool has_aux, float y, float pr, int act_aux) {
+  v = pv_act_fwd(v, act);
+  if (has_aux) v *= pv_act_grad(y, pr, act_aux);
+  return v;
+}
+
+// pv_act_fwd2 / pv_act_grad2: the same functions with the cheap cases inline and the transcendental ones behind one
+// out-of-line copy (a call costs less than the inlined switch's branches, and the kernel's code shrinks several-fold)
+static __device__ __noinline__ float pv_act_fwd_slow(float x, int act) { return pv_act_fwd(x, act); }
+static __device__ __noinline__ float pv_act_grad_slow(float y, float pre, int act) { return pv_act_grad(y, pre, act); }
+__device__ __forceinline__ float pv_act_fwd2(float x, int act) {
+  if (pv_act_is_lin(act)) return x > 0.0f ? x : x * pv_act_slope(act);
+  return pv_act_fwd_slow(x, act);
+}
+__device__ __forceinline__ float pv_act_grad2(float y, float pre, int act) {
+  if (act == PV_ACT_SOFTPLUS || act == PV_ACT_GELU) return pv_act_grad_slow(y, pre, act);
+  const float lin = y > 0.0f ? 1.0f : pv_act_slope(act);
+  return act == PV_ACT_TANH ? 1.0f - y * y : act == PV_ACT_SIGMOID ? y * (1.0f - y) : lin;
+}
+
 // torch.distributions.ContinuousBernoulli(probs = sigmoid(a)).log_prob(x) (utils/prob.py:27) and d(-log_prob)/da.
 //   probs -> clamp_probs; logits = log(p) - log1p(-p); log_prob = -BCEWithLogits(logits, x) + log C(p), with
 //   log C(p) = log|log1p(-p) - log p| - log|1 - 2p| outside (0.499, 0.501] and its Taylor expansion

@@ -25,7 +25,38 @@ struct ConvD {
   const float* in; const float* wt; const float* bias; float* out;
   const float* eg_y; int eg_act;      // optional: out *= act'(eg_y) elementwise (the producing layer's activation backward)
   int B, H, W, Cin, Cout, nd, act, KK, tiles_x, tiles_y;
+  int simple; float slope, gslope;    // piecewise-linear activations (none / relu / lrelu, both ways): one branch-free epilogue path
+  int spt;                            // 1-D, bf16 / fp16 kernel: samples per 64-position tile (short signals share a tile, each with its own halo rows)
 };
+
+// epilogue of the tile kernels: four consecutive output channels co .. co + 3 of one pixel (orow = its output row).
+// Piecewise-linear activations (none / relu / lrelu, forward and derivative) take an inline branch-free path; everything
+// else goes through ONE out-of-line copy of the activation switch (inlined per value it was ~6 k of a kernel's 7.8 k
+// instructions, 36 branches per value on the executed path).
+__device__ __noinline__ void cd_store4_generic(const float* bias, const float* eg_y, float* orow, int co, int Cout, int act, int eg_act,
+                                               f32x4 v) {
+  for (int i = 0; i < 4; ++i)
+    if (co + i < Cout) {
+      float t = pv_act_fwd(v[i] + (bias ? bias[co + i] : 0.0f), act);
+      if (eg_y) t *= pv_act_grad(eg_y[co + i], 0.0f, eg_act);
+      orow[co + i] = t;
+    }
+}
+__device__ __forceinline__ void cd_store4(const ConvD& p, float* orow, int co, f32x4 v) {
+  if (p.simple && co + 3 < p.Cout && (p.Cout & 3) == 0) {
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : v[i] * p.slope;
+    if (p.eg_y) {
+      const f32x4 yy = *reinterpret_cast<const f32x4*>(p.eg_y + (orow - p.out) + co);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= yy[i] > 0.0f ? 1.0f : p.gslope;
+    }
+    *reinterpret_cast<f32x4*>(orow + co) = v;
+  } else {
+    cd_store4_generic(p.bias, p.eg_y ? p.eg_y + (orow - p.out) : nullptr, orow, co, p.Cout, p.act, p.eg_act, v);
+  }
+}
 
 // raw torch weight w[Co][Ci][KK] -> tiled logical matrix Wl[n][c][t]:
 //   flip == 0 (forward):  Wl[n = co][c = ci][t] = w[co][ci][t]                (N = Co, C = Ci)
@@ -145,33 +176,14 @@ __global__ __launch_bounds__(256) void pv_conv3_direct_kernel(ConvD p) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int co = cot * CD_TN + wn * 32 + cb * 16 + 4 * q;
-      if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
-        f32x4 v = acc[cb][pb];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = pv_act_fwd(v[i], p.act);
-        if (p.eg_y) {
-          const f32x4 yy = *reinterpret_cast<const f32x4*>(p.eg_y + (orow - p.out) + co);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] *= pv_act_grad(yy[i], 0.0f, p.eg_act);
-        }
-        *reinterpret_cast<f32x4*>(orow + co) = v;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (co + i < p.Cout) {
-            float v = pv_act_fwd(acc[cb][pb][i] + (p.bias ? p.bias[co + i] : 0.0f), p.act);
-            if (p.eg_y) v *= pv_act_grad(p.eg_y[(orow - p.out) + co + i], 0.0f, p.eg_act);
-            orow[co + i] = v;
-          }
-      }
+      cd_store4(p, orow, co, acc[cb][pb]);
     }
   }
 }
 
 // (bf16 split-precision forms: defined at the end of this file)
 template <bool F16> __global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int Co, int Ci, int KK, int flip);
-template <bool F16> __global__ void pv_conv3_direct_bf16_kernel(ConvD p);
+template <bool F16, int NCH> __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p);
 
 bool pv_conv3_direct_supported(int C, int Cout, int nd, int act) {
   return C >= CD_KC && C % CD_KC == 0 && Cout >= 8 && (nd == 1 || nd == 2) && act != PV_ACT_GELU;
@@ -215,12 +227,40 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
   p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = N; p.nd = nd; p.act = act; p.KK = KK;
   p.tiles_x = nd == 2 ? (W + 7) / 8 : 1;
   p.tiles_y = nd == 2 ? (H + 7) / 8 : (H + CD_PIX - 1) / CD_PIX;
+  {
+    auto lin = [](int a_) { return a_ == PV_ACT_NONE || a_ == PV_ACT_RELU || a_ == PV_ACT_LRELU; };
+    auto slope = [](int a_) { return a_ == PV_ACT_NONE ? 1.0f : a_ == PV_ACT_RELU ? 0.0f : 0.01f; };
+    const int eg = p.eg_y ? p.eg_act : PV_ACT_NONE;
+    p.simple = lin(p.act) && lin(eg);
+    p.slope = slope(p.act); p.gslope = slope(eg);
+  }
   const int npix = nd == 2 ? 100 : CD_PIX + 2;
   if (bf16) {
-    const size_t ldsb = (size_t)(2 * 3 * CD_TN * 32 + 2 * npix * 32) * 2;
-    const dim3 gridb((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt);
-    if (use_bf16 == 2) hipLaunchKernelGGL(pv_conv3_direct_bf16_kernel<true>, gridb, dim3(256), ldsb, s, p);
-    else hipLaunchKernelGGL(pv_conv3_direct_bf16_kernel<false>, gridb, dim3(256), ldsb, s, p);
+    // 1-D signals of <= 32 positions: floor(64 / H) samples per tile (at most 8: the patch then has <= 80 rows) — only when
+    // one sample per tile would be more than two rounds of workgroups: a workgroup's time is its chain of K-loop stages
+    // whatever the tile holds, so below that the emptier tiles cost nothing and packing only removes parallelism
+    // (measured on VED C5, batch 256: +10 us per step with packing).  PV_PACK1D=0 / 1: never / always.
+    static int pack_env = -2;
+    if (pack_env == -2) { const char* e_ = getenv("PV_PACK1D"); pack_env = e_ ? (atoi(e_) != 0 ? 1 : 0) : -1; }
+    p.spt = 1;
+    if (nd == 1 && H >= 8 && H <= CD_PIX / 2 && (pack_env == 1 || (pack_env == -1 && (int64_t)B * nt > 1024))) p.spt = CD_PIX / H;
+    const int npb = p.spt > 1 ? p.spt * (H + 2) : npix;
+    const size_t ldsb = (size_t)(2 * 3 * CD_TN * 32 + 2 * npb * 32) * 2;
+    const dim3 gridb((unsigned)(p.spt > 1 ? (B + p.spt - 1) / p.spt : p.tiles_x * p.tiles_y * B), (unsigned)nt);
+    // PV_RES1D=1: the all-chunks-in-flight form (NCH > 0).  Off by default: measured +10 us per VED C5 step against the
+    // streaming form once the epilogue's code bloat was gone — the stages were never memory-latency chains
+    static int res_env = -1;
+    if (res_env < 0) { const char* e_ = getenv("PV_RES1D"); res_env = (e_ && atoi(e_) != 0) ? 1 : 0; }
+    const int nchr = (res_env && nd == 1 && C / 32 <= 4) ? C / 32 : 0;
+#define CB_LAUNCH(F, N) hipLaunchKernelGGL((pv_conv3_direct_bf16_kernel<F, N>), gridb, dim3(256), ldsb, s, p)
+    if (use_bf16 == 2) {
+      if (nchr == 4) CB_LAUNCH(true, 4); else if (nchr == 3) CB_LAUNCH(true, 3); else if (nchr == 2) CB_LAUNCH(true, 2);
+      else if (nchr == 1) CB_LAUNCH(true, 1); else CB_LAUNCH(true, 0);
+    } else {
+      if (nchr == 4) CB_LAUNCH(false, 4); else if (nchr == 3) CB_LAUNCH(false, 3); else if (nchr == 2) CB_LAUNCH(false, 2);
+      else if (nchr == 1) CB_LAUNCH(false, 1); else CB_LAUNCH(false, 0);
+    }
+#undef CB_LAUNCH
     PV_LAUNCH_CHECK();
     return 0;
   }
@@ -615,11 +655,17 @@ __global__ void pv_conv3_wprep_bf16_kernel(const float* __restrict__ w, __bf16* 
   }
 }
 
-template <bool F16>
+// NCH > 0 (1-D layers with 32 NCH input channels; experiment, PV_RES1D=1): EVERY chunk's patch pieces and weights are
+// requested before the first stage (registers: 4 + 6 16-byte pieces per chunk and thread) instead of one stage ahead.
+// Measured slower than the streaming form (see the launcher).
+template <bool F16, int NCH>
 __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
   extern __shared__ __attribute__((aligned(16))) char smb_[];
   __shared__ float smax[2][4];                        // F16: the waves' patch maxima of the chunk being staged
-  const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : CD_PIX + 2, NPIX = PH * PW;
+  // 1-D with p.spt > 1: the tile holds spt whole samples of H <= 32 positions; sample s of the tile owns patch rows
+  // s (H + 2) ... s (H + 2) + H + 1 (its own zero halo), output pixel n = s H + l reads patch row s (H + 2) + l + tap
+  const int SPT = p.nd == 2 ? 1 : p.spt, SEG = p.H + 2;
+  const int KK = p.KK, PW = p.nd == 2 ? 10 : 1, PH = p.nd == 2 ? 10 : (SPT > 1 ? SPT * SEG : CD_PIX + 2), NPIX = PH * PW;
   const int TG = 3;                                  // taps per weight stage: one kernel row (2-D) / all three (1-D)
   __bf16* wh = reinterpret_cast<__bf16*>(smb_);                       // [TG][64][32]
   __bf16* wl = wh + TG * CD_TN * CB_KC;
@@ -629,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
   const int wm = wave & 1, wn = wave >> 1;
   int t = blockIdx.x;
   const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+  const int ty = t % p.tiles_y; const int b = (t / p.tiles_y) * SPT;    // (first sample of the tile)
   const int y0 = ty * (p.nd == 2 ? 8 : CD_PIX), x0 = tx * 8;
   const int cot = blockIdx.y;
   const int nch = p.Cin / CB_KC;
@@ -645,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {
     const int n = wm * 32 + pb * 16 + r;
-    pidx[pb] = p.nd == 2 ? (n >> 3) * PW + (n & 7) : n;
+    pidx[pb] = p.nd == 2 ? (n >> 3) * PW + (n & 7) : (SPT > 1 ? (n < SPT * p.H ? n + 2 * (n / p.H) : 0) : n);
   }
   // staging through registers one stage ahead, as in pv_conv3_direct_kernel: the next chunk's patch pieces (<= 4 per
   // thread) and the next tap group's weights (3 + 3 16-byte pieces) are in flight under the current stage's MFMAs
@@ -655,9 +701,10 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
   for (int k = 0; k < PKB; ++k) {
     const int e = tid + 256 * k, pix = e >> 3, f4 = e & 7;
     const int py = p.nd == 2 ? pix / PW : pix, px = p.nd == 2 ? pix - py * PW : 0;
-    const int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0;
+    int y = y0 - 1 + py, x = p.nd == 2 ? x0 - 1 + px : 0, sb = 0;
+    if (SPT > 1) { sb = pix / SEG; y = pix - sb * SEG - 1; }
     pls[k] = e < NPIX * 8 ? pix * CB_KC + 4 * f4 : -1;
-    pg[k] = (e < NPIX * 8 && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (y * p.W + x) * p.Cin + 4 * f4 : -1;
+    pg[k] = (e < NPIX * 8 && b + sb < p.B && y >= 0 && y < p.H && x >= 0 && x < p.W) ? ((sb * p.H + y) * p.W + x) * p.Cin + 4 * f4 : -1;
   }
   f32x4 pv[PKB];
   int4 wvh0, wvh1, wvh2, wvl0, wvl1, wvl2;         // (an indexed register array here ends up in scratch)
@@ -677,6 +724,24 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
   }
   CB_FETCH_P(0);
   CB_FETCH_W(0);
+  constexpr int NA = NCH > 1 ? NCH - 1 : 1;
+  f32x4 pva[NA][PKB];
+  int4 wva[NA][6];
+  if constexpr (NCH > 1) {                             // chunks 1 .. NCH-1 (ngrp == 1 here: a stage is a chunk)
+#pragma unroll
+    for (int c = 1; c < NCH; ++c) {
+#pragma unroll
+      for (int k = 0; k < PKB; ++k) {
+        pva[c - 1][k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (pg[k] >= 0) pva[c - 1][k] = *reinterpret_cast<const f32x4*>(in_b + pg[k] + c * CB_KC);
+      }
+      const int64_t src0_ = ((int64_t)cot * nch * KK + (int64_t)c * TG) * CD_TN * CB_KC;
+      const int4* sh_ = reinterpret_cast<const int4*>(wt + src0_);
+      const int4* sl_ = reinterpret_cast<const int4*>(wt + wtot + src0_);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { wva[c - 1][j] = sh_[tid + 256 * j]; wva[c - 1][3 + j] = sl_[tid + 256 * j]; }
+    }
+  }
   int E_cur = 0, E_min = 1 << 20;                     // F16: the patch scale 2^E of the current chunk, the smallest so far
   auto wave_max = [&](int slot) {
     float m = 0.0f;
@@ -691,7 +756,8 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
                                                       //  hipcc 7.2 emits no s_waitcnt lgkmcnt between this store and the loop's s_barrier)
   };
   if constexpr (F16) wave_max(0);
-  for (int ch = 0; ch < nch; ++ch) {
+#pragma unroll(NCH > 0 ? NCH : 1)
+  for (int ch = 0; ch < (NCH > 0 ? NCH : nch); ++ch) {
     __syncthreads();                                 // the previous chunk's reads of the patch are done (F16: smax is in)
     float psc = 1.0f;
     if constexpr (F16) {
@@ -743,7 +809,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
         dl_[0] = wvl0; dl_[256] = wvl1; dl_[512] = wvl2;
       }
       __syncthreads();
-      {
+      if constexpr (NCH == 0) {
         const int stage = ch * ngrp + g;
         if (stage + 1 < nch * ngrp) CB_FETCH_W(stage + 1);
         if (g + 1 == ngrp && ch + 1 < nch) CB_FETCH_P(ch + 1);
@@ -779,8 +845,16 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
           for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = cb_mma<F16>(al[cb], bh[pb], acc[cb][pb]);
       }
     }
+    if constexpr (NCH > 1) {
+      if (ch + 1 < NCH) {                              // (unrolled: static indices)
+#pragma unroll
+        for (int k = 0; k < PKB; ++k) pv[k] = pva[ch < NA ? ch : 0][k];
+        const int c_ = ch < NA ? ch : 0;
+        wvh0 = wva[c_][0]; wvh1 = wva[c_][1]; wvh2 = wva[c_][2]; wvl0 = wva[c_][3]; wvl1 = wva[c_][4]; wvl2 = wva[c_][5];
+      }
+    }
     if constexpr (F16) {
-      if (ch + 1 < nch) wave_max((ch + 1) & 1);       // (the next chunk's values arrived under the MFMAs)
+      if (ch + 1 < (NCH > 0 ? NCH : nch)) wave_max((ch + 1) & 1);       // (the next chunk's values arrived under the MFMAs)
     }
   }
   if constexpr (F16) {
@@ -794,18 +868,12 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
   for (int pb = 0; pb < 2; ++pb) {
     const int n = wm * 32 + pb * 16 + r;
     const int y = p.nd == 2 ? y0 + (n >> 3) : y0 + n, x = p.nd == 2 ? x0 + (n & 7) : 0;
-    if (y >= p.H || x >= p.W) continue;
+    if (SPT > 1 ? (n >= SPT * p.H || b + n / p.H >= p.B) : (y >= p.H || x >= p.W)) continue;   // (packed: y runs over the tile's samples)
     float* orow = p.out + (((int64_t)b * p.H + y) * p.W + x) * p.Cout;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int co = cot * CD_TN + wn * 32 + cb * 16 + 4 * q;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (co + i < p.Cout) {
-          float v = pv_act_fwd(acc[cb][pb][i] + (p.bias ? p.bias[co + i] : 0.0f), p.act);
-          if (p.eg_y) v *= pv_act_grad(p.eg_y[(orow - p.out) + co + i], 0.0f, p.eg_act);
-          orow[co + i] = v;
-        }
+      cd_store4(p, orow, co, acc[cb][pb]);
     }
   }
 }

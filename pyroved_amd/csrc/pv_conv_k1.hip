@@ -21,9 +21,26 @@ struct K1Fwd {
   const float* in; const float* w; const float* bias; float* out; const float* eg_y;
   int64_t rows;
   int K, N, ld_in, ld_out, w_ns, w_ks, act, eg_act, ngroups, w_bytes;
+  int simple; float slope, gslope;   // piecewise-linear activations (none / relu / lrelu, both ways): v > 0 ? v : slope v, one
+                                     // branch-free path instead of a per-value switch over every activation's code
   int up_out, up_in;      // 1-D nearest 2x upsample fused: every output row stored twice (rows 2p, 2p + 1) / the input row is the sum of
                           // rows 2p and 2p + 1 (the upsample's backward)
 };
+
+// any activation / derivative: ONE out-of-line copy of the switch (inlined per value it was 6.5 k of a kernel's 6.8 k instructions)
+__device__ __noinline__ f32x4 k1_act_generic(f32x4 v, const float* eg_y, int act, int eg_act) {
+  for (int i = 0; i < 4; ++i) {
+    v[i] = pv_act_fwd(v[i], act);
+    if (eg_y) v[i] *= pv_act_grad(eg_y[i], 0.0f, eg_act);
+  }
+  return v;
+}
+
+__device__ __noinline__ float k1_act_one(float t, const float* eg_y, int act, int eg_act) {
+  t = pv_act_fwd(t, act);
+  if (eg_y) t *= pv_act_grad(eg_y[0], 0.0f, eg_act);
+  return t;
+}
 
 // The vector form: K % 16 == 0, N % 4 == 0, 16-byte aligned pixel rows.  NJ 16-wide contraction groups per register chunk
 // (K % (16 NJ) == 0), NB 16-output blocks per wave; every load and MFMA is unconditional (outputs past N read a clamped
@@ -91,14 +108,16 @@ __global__ __launch_bounds__(256) void pv_k1_fwd_kernel(K1Fwd a) {
     if (n >= a.N) continue;
     f32x4 v = acc[b];
     if (a.bias) v = v + *reinterpret_cast<const f32x4*>(a.bias + n);
-    if (a.act != PV_ACT_NONE) {
+    if (a.simple) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = pv_act_fwd(v[i], a.act);
-    }
-    if (a.eg_y) {
-      const f32x4 y = *reinterpret_cast<const f32x4*>(a.eg_y + row * a.ld_out + n);
+      for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : v[i] * a.slope;
+      if (a.eg_y) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(a.eg_y + row * a.ld_out + n);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= pv_act_grad(y[i], 0.0f, a.eg_act);
+        for (int i = 0; i < 4; ++i) v[i] *= y[i] > 0.0f ? 1.0f : a.gslope;
+      }
+    } else {
+      v = k1_act_generic(v, a.eg_y ? a.eg_y + row * a.ld_out + n : nullptr, a.act, a.eg_act);
     }
     if (a.up_out) {
       *reinterpret_cast<f32x4*>(a.out + 2 * row * a.ld_out + n) = v;
@@ -141,8 +160,12 @@ __global__ __launch_bounds__(256) void pv_k1_gen_kernel(K1Fwd a) {
     const int no = 16 * ng + 4 * q + i;
     if (no >= a.N) break;
     float t = acc[i] + (a.bias ? a.bias[no] : 0.0f);
-    t = pv_act_fwd(t, a.act);
-    if (a.eg_y) t *= pv_act_grad(a.eg_y[row * a.ld_out + no], 0.0f, a.eg_act);
+    if (a.simple) {
+      t = t > 0.0f ? t : t * a.slope;
+      if (a.eg_y) t *= a.eg_y[row * a.ld_out + no] > 0.0f ? 1.0f : a.gslope;
+    } else {
+      t = k1_act_one(t, a.eg_y ? a.eg_y + row * a.ld_out + no : nullptr, a.act, a.eg_act);
+    }
     if (a.up_out) { a.out[2 * row * a.ld_out + no] = t; a.out[(2 * row + 1) * a.ld_out + no] = t; }
     else a.out[row * a.ld_out + no] = t;
   }
@@ -171,6 +194,11 @@ static int k1_launch(K1Fwd a, int64_t w_elems, hipStream_t s) {
                   (!a.bias || k1_al16(a.bias)) && (!a.eg_y || k1_al16(a.eg_y)) && w_elems < (1 << 28);
   const bool wv = a.w_ks == 1 && a.w_ns % 4 == 0 && k1_al16(a.w);
   a.w_bytes = (int)(w_elems * 4);
+  auto lin = [](int act) { return act == PV_ACT_NONE || act == PV_ACT_RELU || act == PV_ACT_LRELU; };
+  auto slope = [](int act) { return act == PV_ACT_NONE ? 1.0f : act == PV_ACT_RELU ? 0.0f : 0.01f; };
+  const int eg = a.eg_y ? a.eg_act : PV_ACT_NONE;
+  a.simple = lin(a.act) && lin(eg);
+  a.slope = slope(a.act); a.gslope = slope(eg);
   if (!xv) {
     a.ngroups = (a.N + 15) / 16;
     const int64_t units = ((a.rows + 15) / 16) * a.ngroups;

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void pv_out_lik_kernel(PvOutLik p) {
       for (int jj = 0; jj < OL_MAXJ; ++jj) {
         const int j = lane + 64 * jj;
         if (j < H) {
-          dr[j] = dlda * wo[jj] * pv_act_grad(hv[jj], pr_ ? pr_[j] : 0.0f, p.act_last);
+          dr[j] = dlda * wo[jj] * pv_act_grad2(hv[jj], pr_ ? pr_[j] : 0.0f, p.act_last);
           acc[jj] += dlda * hv[jj];
         }
       }
@@ -894,7 +894,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
       } else {
         for (int o = 0; o < hd.out_dim; ++o) v += sh_dh[o] * Wh[(int64_t)o * hd.in_dim + k];
       }
-      v *= pv_act_grad((chain && k == t) ? pf_act1 : p.enc_act[ne - 1][(int64_t)b * ll_.out_dim + k], 0.0f, ll_.act);
+      v *= pv_act_grad2((chain && k == t) ? pf_act1 : p.enc_act[ne - 1][(int64_t)b * ll_.out_dim + k], 0.0f, ll_.act);
       p.enc_dp[ne - 1][(int64_t)b * ll_.out_dim + k] = v;
       sh_e[cur][k] = v;
     }
@@ -929,7 +929,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     if (half == 0 && k < l.in_dim) {
       float y = sh_p[0][k] + sh_p[1][k];
       const float hv = pre ? pf_act0 : p.enc_act[li - 1][(int64_t)b * lp.out_dim + k];
-      y *= pv_act_grad(hv, 0.0f, lp.act);
+      y *= pv_act_grad2(hv, 0.0f, lp.act);
       p.enc_dp[li - 1][(int64_t)b * lp.out_dim + k] = y;
       sh_e[cur ^ 1][k] = y;
     }

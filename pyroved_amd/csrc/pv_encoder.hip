@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
     if (jo < l.out_dim && row < e.B) {
       float v = (part[0][rr][jj] + part[1][rr][jj]) + (part[2][rr][jj] + part[3][rr][jj]);
       v += l.b_off >= 0 ? e.params[l.b_off + jo] : 0.0f;
-      e.eact[0][(int64_t)row * l.out_dim + jo] = pv_act_fwd(v, l.act);
+      e.eact[0][(int64_t)row * l.out_dim + jo] = pv_act_fwd2(v, l.act);
     }
   }
 }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
       // C/D layout: lane (col r, q), reg i -> output j = 16*ob + 4*q + i of row r
       f32x4 y;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[i] = pv_act_fwd(acc[i] + bv[i], l.act);
+      for (int i = 0; i < 4; ++i) y[i] = pv_act_fwd2(acc[i] + bv[i], l.act);
       *reinterpret_cast<f32x4*>(&act[cur ^ 1][r][16 * ob + 4 * q]) = y;
       if (rok) *reinterpret_cast<f32x4*>(e.eact[li] + (int64_t)(row0 + r) * l.out_dim + 16 * ob + 4 * q) = y;
     }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
 #pragma unroll
         for (int o = 0; o < 16; ++o) v += dv[o] * (fastk ? whp[o] : (o < hd.out_dim ? Wh[(int64_t)o * hd.in_dim + k] : 0.0f));
         for (int o = 16; o < hd.out_dim; ++o) v += dh[o] * Wh[(int64_t)o * hd.in_dim + k];
-        v *= pv_act_grad(hv, 0.0f, ll.act);
+        v *= pv_act_grad2(hv, 0.0f, ll.act);
         e.edp[ne - 1][(int64_t)row * ll.out_dim + k] = v;
       }
       buf[cur][rr][k] = v;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_dgrad_kernel(PvEncDgrad e) 
       if (row < e.B) {
         const f32x4 h = pre ? h0 : *reinterpret_cast<const f32x4*>(e.eact[li - 1] + (int64_t)row * lp.out_dim + 16 * kb + 4 * q);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = acc[i] * pv_act_grad(h[i], 0.0f, lp.act);
+        for (int i = 0; i < 4; ++i) y[i] = acc[i] * pv_act_grad2(h[i], 0.0f, lp.act);
         *reinterpret_cast<f32x4*>(e.edp[li - 1] + (int64_t)row * lp.out_dim + 16 * kb + 4 * q) = y;
       }
       *reinterpret_cast<f32x4*>(&buf[cur ^ 1][r][16 * kb + 4 * q]) = y;

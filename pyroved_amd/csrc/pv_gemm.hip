@@ -171,6 +171,8 @@ __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], floa
   const int n = n0 + wn * 32 + (lane & 31);
   if (n >= g.N) return;
   const float bias = (g.bias && !p.part) ? g.bias[n] : 0.0f;
+  const bool simple = pv_act_is_lin(g.act) && (!g.aux || pv_act_is_lin(g.act_aux));      // (pv_common.h: epilogue helpers)
+  const float slope = pv_act_slope(g.act), gslope = pv_act_slope(g.act_aux);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -181,12 +183,9 @@ __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], floa
     } else {
       v += bias;
       if (g.pre) g.pre[(int64_t)m * g.ldc + n] = v;
-      v = pv_act_fwd(v, g.act);
-      if (g.aux) {
-        const float y = g.aux[(int64_t)m * g.ldaux + n];
-        const float pr = g.auxpre ? g.auxpre[(int64_t)m * g.ldaux + n] : 0.0f;
-        v *= pv_act_grad(y, pr, g.act_aux);
-      }
+      const float y = g.aux ? g.aux[(int64_t)m * g.ldaux + n] : 0.0f;
+      if (simple) v = (v > 0.0f ? v : v * slope) * (g.aux ? (y > 0.0f ? 1.0f : gslope) : 1.0f);
+      else v = pv_act_pair_slow(v, g.act, g.aux != nullptr, y, g.auxpre ? g.auxpre[(int64_t)m * g.ldaux + n] : 0.0f, g.act_aux);
       g.C[(int64_t)m * g.ldc + n] = v;
     }
   }

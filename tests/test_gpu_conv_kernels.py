@@ -282,7 +282,10 @@ def test_fp16_two_piece_weight_gradient_is_fp32_class_at_any_magnitude(gpu_devic
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e-6, 3e4])
-@pytest.mark.parametrize("B,dims,Ci,Co", [(3, (40,), 32, 64), (2, (16,), 128, 128), (4, (64,), 64, 32), (2, (12, 20), 64, 40)])
+@pytest.mark.parametrize("B,dims,Ci,Co", [(3, (40,), 32, 64), (2, (16,), 128, 128), (4, (64,), 64, 32), (2, (12, 20), 64, 40),
+                                         (9, (16,), 64, 64), (5, (24,), 32, 40), (17, (8,), 32, 32), (3, (32,), 64, 128), (7, (11,), 32, 16),
+                                         # more than 1024 one-sample tiles: several short signals share a 64-position tile
+                                         (1100, (16,), 32, 32), (1030, (24,), 32, 40), (1500, (8,), 32, 16), (1027, (11,), 32, 64)])
 def test_fp16_two_piece_tile_kernel_1d_and_2d(gpu_device, scale, B, dims, Ci, Co):
     """mode 5: the round-1 tile kernel (the 1-D decoder layers of VED run on it) with fp16 two-piece operands."""
     nd = len(dims)
