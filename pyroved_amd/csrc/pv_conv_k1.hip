@@ -4,7 +4,7 @@
 // workgroups that each walk K in 32-wide stages behind barriers: one global-memory round trip per stage, 8-22 us per
 // launch for 10-70 MFLOP.  Here every operand of a wave's tile is requested at once and goes from L2 straight into
 // the registers of v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate): one memory latency per launch, no LDS, no barrier.
-//   forward / input gradient: a wave owns 16 pixels x 64 outputs; the weights are the MFMA's A operand (m = output), the
+//   forward / input gradient: a wave owns 16 pixels x 32 outputs; the weights are the MFMA's A operand (m = output), the
 //     pixels its B operand (n = pixel), so a lane ends up with four CONSECUTIVE outputs of one pixel (16-byte stores).
 //     The input gradient is the same kernel on the transposed weight (strided loads; the matrix is L2-resident) with the
 //     producing layer's activation derivative in the epilogue.
@@ -13,6 +13,7 @@
 //     table (pv_conv.h: PvFinishList) — no launch of its own for the split-order sum.
 #include "pv_common.h"
 #include "pv_conv.h"
+#include <stdlib.h>
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define K1_KC 128                    // contraction chunk held in registers
@@ -204,7 +205,10 @@ static int k1_launch(K1Fwd a, int64_t w_elems, hipStream_t s) {
     const int64_t units = ((a.rows + 15) / 16) * a.ngroups;
     hipLaunchKernelGGL(pv_k1_gen_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a);
   } else {
-    const int nb = a.N > 32 ? 4 : a.N > 16 ? 2 : 1;
+    static int nb_env = -1;                            // PV_K1_NB=1|2|4: 16-output blocks per wave (experiments)
+    if (nb_env < 0) { const char* e_ = getenv("PV_K1_NB"); nb_env = e_ ? atoi(e_) : 0; }
+    int nb = a.N > 16 ? 2 : 1;                         // (measured on VED C5: 2 blocks per wave -9 us per step against 4 — more waves)
+    if (nb_env == 1 || nb_env == 2 || nb_env == 4) nb = (a.N > 16 * (nb_env / 2)) ? nb_env : nb;
     a.ngroups = (a.N + 16 * nb - 1) / (16 * nb);
     const int64_t units = ((a.rows + 15) / 16) * a.ngroups;
     const unsigned grid = (unsigned)((units + 3) / 4);
