@@ -313,7 +313,10 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
 static int k1_wg_splits(int64_t rows, int Ci, int Co, int taps) {
   const int64_t tiles = (int64_t)((Co + 15) / 16) * ((Ci + 15) / 16) * taps;
   int64_t ns = (rows + 4 * K1_WB - 1) / (4 * K1_WB);          // one register batch per wave
-  const int64_t cap = (1024 + tiles - 1) / tiles;              // ~4 workgroups per CU in all
+  static int cap_env = -1;                                     // PV_K1_WCAP=n: workgroup target of the weight gradient (experiments)
+  if (cap_env < 0) { const char* e_ = getenv("PV_K1_WCAP"); cap_env = e_ ? atoi(e_) : 0; }
+  const int64_t target = cap_env > 0 ? cap_env : (taps == 3 ? 4096 : 1024);    // (measured on VED C5: 4096 for the three-tap form -7 us)
+  const int64_t cap = (target + tiles - 1) / tiles;            // ~4 workgroups per CU in all
   if (ns > cap) ns = cap;
   if (ns < 1) ns = 1;
   return (int)ns;
