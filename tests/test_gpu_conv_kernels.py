@@ -194,6 +194,12 @@ STACK_CASES = [
     ("fe2d_bn", dict(kind="fe", ndim=2, in_ch=1, filters=[(8,), (16,)], bn=True, act="lrelu"), (5, 1, 8, 8), False),
     ("up1d", dict(kind="up", ndim=1, in_ch=32, filters=[(32, 32), (16,)], bn=False, act="lrelu", out_ch=1), (3, 32, 8), True),
     ("up2d_bilinear", dict(kind="up", ndim=2, in_ch=16, filters=[(16,), (8,)], bn=False, act="tanh", out_ch=2), (2, 16, 4, 4), True),
+    # kernel-1 family with a transcendental activation derivative in the input-gradient epilogue, ragged channel counts
+    # (scalar path of the kernel-1 kernels), batch norm between the blocks, and the 2-D nearest upsample (not fused)
+    ("up1d_tanh", dict(kind="up", ndim=1, in_ch=32, filters=[(32, 32), (16, 16)], bn=False, act="tanh", out_ch=1), (5, 32, 8), True),
+    ("up1d_ragged_softplus", dict(kind="up", ndim=1, in_ch=12, filters=[(20,), (6,)], bn=False, act="softplus", out_ch=3), (3, 12, 9), True),
+    ("up1d_bn", dict(kind="up", ndim=1, in_ch=16, filters=[(16,), (8,)], bn=True, act="lrelu", out_ch=1), (6, 16, 8), True),
+    ("up2d_nearest", dict(kind="up", ndim=2, in_ch=16, filters=[(16,), (8,)], bn=False, act="lrelu", out_ch=1, mode="nearest"), (2, 16, 4, 6), True),
 ]
 
 
@@ -208,7 +214,7 @@ def test_standalone_conv_stacks_run_on_the_library(gpu_device, name, spec, shape
         net = FeatureExtractor(spec["ndim"], spec["in_ch"], spec["filters"], batchnorm=spec["bn"], activation=spec["act"])
     else:
         net = Upsampler(spec["ndim"], spec["in_ch"], spec["filters"], spec["out_ch"], batchnorm=spec["bn"],
-                        activation=spec["act"], upsampling_mode="bilinear" if spec["ndim"] == 2 else "nearest")
+                        activation=spec["act"], upsampling_mode=spec.get("mode", "bilinear" if spec["ndim"] == 2 else "nearest"))
     ref = copy.deepcopy(net).double()
     net = net.cuda()
     x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
