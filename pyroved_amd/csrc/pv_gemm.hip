@@ -13,6 +13,7 @@
 // described by (row stride, col stride) so NT (forward), NN (dgrad) and TN (wgrad) share the kernel.
 // fp32 MFMA == an fmaf chain bit-for-bit, so results are exact-fp32-class (no TF32 on gfx950).
 #include "pv_common.h"
+#include <stdlib.h>
 
 #define GT 64      // tile edge
 #define GK 16      // k per stage
@@ -276,6 +277,15 @@ int pv_gemm_pick_splits(int M, int N, int K) {
   // aim for >= ~512 workgroups (2 per CU) when the contraction is long enough to split; a split costs a
   // second (finish) launch, ~6 us on the stream, so short contractions are never split
   const int64_t tiles = (int64_t)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+  static const int few_env = getenv("PV_GEMM_NO_FEWSPLIT") && atoi(getenv("PV_GEMM_NO_FEWSPLIT")) ? 0 : 1;
+  if (few_env && tiles < 64 && K >= 256 && K <= 1024) {
+    // a handful of tiles over a medium contraction (a 256 x 787 -> 128 encoder layer: 8 workgroups walking 25 stages, 24 us):
+    // at least 128 of k per split, ~128 workgroups in all — the walk shrinks to 4-5 stages, the finish launch costs ~4 us
+    int64_t s = (128 + tiles - 1) / tiles;
+    const int64_t maxs = K / 128;
+    if (s > maxs) s = maxs;
+    return (int)(s < 1 ? 1 : s);
+  }
   if (tiles >= 512 || K <= 1024) return 1;
   int64_t s = (512 + tiles - 1) / tiles;
   const int64_t maxs = (K + 4 * GK - 1) / (4 * GK);     // at least 64 of k per split
@@ -298,7 +308,7 @@ int pv_gemm(const PvGemm& g, int splits, void* ws, int64_t ws_bytes, hipStream_t
   p.part_rs = nullptr;
   if (splits > 1) {
     const int64_t need = (int64_t)splits * g.M * (g.N + (g.rowsumA ? 1 : 0)) * (int64_t)sizeof(float);
-    if (!ws || ws_bytes < need) return PV_EWS;
+    if (!ws || ws_bytes < need) return PV_EWS;        // (callers size their scratch with gemm_ws_need = the same pick_splits)
     p.part = (float*)ws;
     if (g.rowsumA) p.part_rs = p.part + (int64_t)splits * g.M * g.N;
   }
