@@ -173,6 +173,7 @@ __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], floa
   if (n >= g.N) return;
   const float bias = (g.bias && !p.part) ? g.bias[n] : 0.0f;
   const bool simple = pv_act_is_lin(g.act) && (!g.aux || pv_act_is_lin(g.act_aux));      // (pv_common.h: epilogue helpers)
+  const bool lin_f = g.act == PV_ACT_NONE && g.aux != nullptr;                            // input-gradient form: only act_aux' to apply
   const float slope = pv_act_slope(g.act), gslope = pv_act_slope(g.act_aux);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -186,6 +187,7 @@ __device__ __forceinline__ void gemm_tile(const GemmK& p, float (*As)[GLD], floa
       if (g.pre) g.pre[(int64_t)m * g.ldc + n] = v;
       const float y = g.aux ? g.aux[(int64_t)m * g.ldaux + n] : 0.0f;
       if (simple) v = (v > 0.0f ? v : v * slope) * (g.aux ? (y > 0.0f ? 1.0f : gslope) : 1.0f);
+      else if (lin_f) v *= pv_act_grad2(y, g.auxpre ? g.auxpre[(int64_t)m * g.ldaux + n] : 0.0f, g.act_aux);   // (tanh' / sigmoid' inline)
       else v = pv_act_pair_slow(v, g.act, g.aux != nullptr, y, g.auxpre ? g.auxpre[(int64_t)m * g.ldaux + n] : 0.0f, g.act_aux);
       g.C[(int64_t)m * g.ldc + n] = v;
     }
