@@ -9,6 +9,7 @@
 // output) and that byte, and accumulates dW / db straight from the input image.
 #include "pv_common.h"
 #include "pv_conv.h"
+#include <stdlib.h>
 
 struct C1Pool {
   const float* x; const float* w; const float* bias; float* out; unsigned char* code;
@@ -24,8 +25,10 @@ template <int ACT> __device__ __forceinline__ float c1_act(float v) {
   return v;
 }
 
-// one thread per (pooled pixel, 4 channels): the 4x4 input window, 4 convolution outputs x 4 channels
-template <int ACT>
+// one thread per (pooled pixel, 4 CV channels): the 4x4 input window, 4 convolution outputs x 4 CV channels.  CV = 2 (channel
+// counts that are multiples of 8): the window loads and their bounds arithmetic — a third of the thread's instructions — serve
+// twice the outputs
+template <int ACT, int CV>
 __global__ __launch_bounds__(256) void pv_c1_convpool_fwd_kernel(C1Pool p) {
   __shared__ __attribute__((aligned(16))) float wl[10 * 64];          // [tap 0..8 | bias][C]
   for (int i = threadIdx.x; i < 10 * p.C; i += 256) {
@@ -33,11 +36,11 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_fwd_kernel(C1Pool p) {
     wl[t * p.C + c] = t < 9 ? p.w[c * 9 + t] : (p.bias ? p.bias[c] : 0.0f);
   }
   __syncthreads();
-  const int C4 = p.C / 4;
-  const int64_t total = (int64_t)p.B * p.Hp * p.Wp * C4;
+  const int CG = p.C / (4 * CV);
+  const int64_t total = (int64_t)p.B * p.Hp * p.Wp * CG;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int c4 = (int)(e % C4);
-    const int64_t w_ = e / C4;
+    const int cg = (int)(e % CG);
+    const int64_t w_ = e / CG;
     const int px = (int)(w_ % p.Wp), py = (int)((w_ / p.Wp) % p.Hp);
     const int64_t b = w_ / ((int64_t)p.Wp * p.Hp);
     const float* xb = p.x + b * p.H * p.W;
@@ -49,31 +52,35 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_fwd_kernel(C1Pool p) {
         const int y = 2 * py - 1 + r, x = 2 * px - 1 + c;
         xw[r][c] = (y >= 0 && y < p.H && x >= 0 && x < p.W) ? xb[y * p.W + x] : 0.0f;
       }
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * p.C + 4 * c4);
-    f32x4 v[4] = {bv, bv, bv, bv};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + t * p.C + 4 * c4);
-      const int ty = t / 3, tx = t - 3 * ty;
+    for (int h = 0; h < CV; ++h) {
+      const int c0 = 4 * (CV * cg + h);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * p.C + c0);
+      f32x4 v[4] = {bv, bv, bv, bv};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] += wv * xw[(k >> 1) + ty][(k & 1) + tx];
-    }
-    f32x4 m;
-    unsigned best = 0;
+      for (int t = 0; t < 9; ++t) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + t * p.C + c0);
+        const int ty = t / 3, tx = t - 3 * ty;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float mi = c1_act<ACT>(v[0][i]);
-      unsigned bi = 0;
-#pragma unroll
-      for (int k = 1; k < 4; ++k) {
-        const float a = c1_act<ACT>(v[k][i]);
-        if (a > mi) { mi = a; bi = k; }
+        for (int k = 0; k < 4; ++k) v[k] += wv * xw[(k >> 1) + ty][(k & 1) + tx];
       }
-      m[i] = mi;
-      best |= bi << (8 * i);
+      f32x4 m;
+      unsigned best = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float mi = c1_act<ACT>(v[0][i]);
+        unsigned bi = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const float a = c1_act<ACT>(v[k][i]);
+          if (a > mi) { mi = a; bi = k; }
+        }
+        m[i] = mi;
+        best |= bi << (8 * i);
+      }
+      *reinterpret_cast<f32x4*>(p.out + w_ * p.C + c0) = m;
+      *reinterpret_cast<unsigned*>(p.code + w_ * p.C + c0) = best;
     }
-    *reinterpret_cast<f32x4*>(p.out + w_ * p.C + 4 * c4) = m;
-    *reinterpret_cast<unsigned*>(p.code + w_ * p.C + 4 * c4) = best;
   }
 }
 
@@ -85,19 +92,25 @@ int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, cons
                        unsigned char* code, hipStream_t s) {
   if (!pv_c1_convpool_supported(1, Cout, 2, act, H, W)) return PV_EINVAL;
   C1Pool p{x, w, bias, out, code, B, H, W, Cout, act, H / 2, W / 2};
-  const int64_t total = (int64_t)B * p.Hp * p.Wp * (Cout / 4);
+  static const int cv_env = getenv("PV_C1_CV") ? atoi(getenv("PV_C1_CV")) : 2;            // PV_C1_CV=1|2|4: float4 channel groups per thread (A/B timing)
+  const int cv = (cv_env == 4 && Cout % 16 == 0) ? 4 : (cv_env >= 2 && Cout % 8 == 0) ? 2 : 1;
+  const int64_t total = (int64_t)B * p.Hp * p.Wp * (Cout / (4 * cv));
   int64_t nb = (total + 255) / 256;
   if (nb > 16384) nb = 16384;
   if (nb < 1) return 0;
   const dim3 grid((unsigned)nb);
+#define C1_LAUNCH(A) { if (cv == 4) hipLaunchKernelGGL((pv_c1_convpool_fwd_kernel<A, 4>), grid, dim3(256), 0, s, p); \
+                       else if (cv == 2) hipLaunchKernelGGL((pv_c1_convpool_fwd_kernel<A, 2>), grid, dim3(256), 0, s, p); \
+                       else hipLaunchKernelGGL((pv_c1_convpool_fwd_kernel<A, 1>), grid, dim3(256), 0, s, p); }
   switch (act) {
-    case PV_ACT_TANH: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_TANH>, grid, dim3(256), 0, s, p); break;
-    case PV_ACT_RELU: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_RELU>, grid, dim3(256), 0, s, p); break;
-    case PV_ACT_LRELU: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_LRELU>, grid, dim3(256), 0, s, p); break;
-    case PV_ACT_SOFTPLUS: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_SOFTPLUS>, grid, dim3(256), 0, s, p); break;
-    case PV_ACT_SIGMOID: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_SIGMOID>, grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL(pv_c1_convpool_fwd_kernel<PV_ACT_NONE>, grid, dim3(256), 0, s, p); break;
+    case PV_ACT_TANH: C1_LAUNCH(PV_ACT_TANH); break;
+    case PV_ACT_RELU: C1_LAUNCH(PV_ACT_RELU); break;
+    case PV_ACT_LRELU: C1_LAUNCH(PV_ACT_LRELU); break;
+    case PV_ACT_SOFTPLUS: C1_LAUNCH(PV_ACT_SOFTPLUS); break;
+    case PV_ACT_SIGMOID: C1_LAUNCH(PV_ACT_SIGMOID); break;
+    default: C1_LAUNCH(PV_ACT_NONE); break;
   }
+#undef C1_LAUNCH
   PV_LAUNCH_CHECK();
   return 0;
 }
