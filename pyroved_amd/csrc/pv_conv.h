@@ -7,7 +7,21 @@
 // launch at its end (pv_wgrad_finish_all) instead of one launch per layer.  A deferring weight gradient takes its partials'
 // workspace from the list's region (it must survive until then); a null / full list means "finish now".
 struct PvFinishEntry { const float* part; float* out; const float* part_b; float* out_b; int64_t n; int nsplit, nb, blk0, nblk; };
-struct PvFinishList { PvFinishEntry e[16]; int n; char* base; int64_t off, cap; };
+// a register-fed weight-gradient problem (pv_conv_k1.hip) and a batch of them recorded for one launch (pv_k1_wgrad_flush)
+struct PvK1Wg {
+  const float* g; const float* in; float* part; float* part_b;
+  int64_t rows, chunk;
+  int Ci, Co, mtiles, ntiles, nsplit, up;
+  int taps, L;            // taps = 3: the kernel-3 1-D convolution's weight gradient, dW[m][n][t] = sum_p g[p][m] in[p + t - 1][n] within
+                          // a sample of L positions (zero padding); taps = 1: kernel 1
+  int nblk;               // workgroups of the problem
+};
+#define PV_K1_BATCH 12
+struct PvK1Batch { PvK1Wg e[PV_K1_BATCH]; int n; };
+int pv_k1_wgrad_flush(PvK1Batch* b, hipStream_t s);
+// k1b != null: register-fed weight gradients whose partials live in the list are RECORDED there instead of launched — their g
+// and input buffers must stay untouched until pv_k1_wgrad_flush (before pv_wgrad_finish_all)
+struct PvFinishList { PvFinishEntry e[16]; int n; char* base; int64_t off, cap; PvK1Batch* k1b; };
 // ws / ws_bytes for a weight gradient needing `need` bytes: a slice of the list's region (returns true: deferred) or the caller's
 bool pv_wgrad_ws(PvFinishList* list, int64_t need, void*& ws, int64_t& ws_bytes);
 int pv_wgrad_finish(PvFinishList* list, const float* part, int nsplit, int64_t n, float* out, const float* part_b, int nb,

@@ -240,23 +240,15 @@ int pv_k1_dgrad(const float* g, int64_t rows, int Co, const float* w, float* gin
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------
-struct K1Wg {
-  const float* g; const float* in; float* part; float* part_b;
-  int64_t rows, chunk;
-  int Ci, Co, mtiles, ntiles, nsplit, up;
-  int taps, L;            // taps = 3: the kernel-3 1-D convolution's weight gradient, dW[m][n][t] = sum_p g[p][m] in[p + t - 1][n] within
-                          // a sample of L positions (zero padding); taps = 1: kernel 1
-};
+typedef PvK1Wg K1Wg;                 // (pv_conv.h: the batch of deferred problems holds them)
 
 #define K1_WB 64                     // pixels per register batch of a wave
 
-__global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
-  __shared__ float part[4][16][17];
-  __shared__ float rpart[4][16];
+__device__ __forceinline__ void k1_wgrad_body(const K1Wg& a, int blk, float (*part)[16][17], float (*rpart)[16]) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = a.mtiles * a.ntiles;
-  const int sp = blockIdx.x / (tiles * a.taps), tt = blockIdx.x - sp * tiles * a.taps;
+  const int sp = blk / (tiles * a.taps), tt = blk - sp * tiles * a.taps;
   const int tap = tt / tiles, t = tt - tap * tiles;
   const int mb = t / a.ntiles, nb = t - mb * a.ntiles;
   // A lane (m = output channel 16 mb + r, pixel slot q), B lane (n = input channel 16 nb + r, pixel slot q)
@@ -310,6 +302,24 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
     a.part_b[(int64_t)sp * a.Co + 16 * mb + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
 }
 
+__global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
+  __shared__ float part[4][16][17];
+  __shared__ float rpart[4][16];
+  k1_wgrad_body(a, blockIdx.x, part, rpart);
+}
+
+// every recorded weight gradient of a stack's backward in ONE launch (PvK1Batch): workgroup b serves problem k with
+// blk0[k] <= b < blk0[k + 1].  The problems are independent (each reads its own layer's g and input, which the stack keeps
+// alive until the flush), so a dozen 8-23 us launches — each with its own cold start — become one that fills the GPU.
+struct K1Tab { K1Wg e[PV_K1_BATCH]; int blk0[PV_K1_BATCH + 1]; int n; };
+__global__ __launch_bounds__(256) void pv_k1_wgrad_table_kernel(K1Tab t) {
+  __shared__ float part[4][16][17];
+  __shared__ float rpart[4][16];
+  int k = 0;
+  while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  k1_wgrad_body(t.e[k], (int)blockIdx.x - t.blk0[k], part, rpart);
+}
+
 static int k1_wg_splits(int64_t rows, int Ci, int Co, int taps) {
   const int64_t tiles = (int64_t)((Co + 15) / 16) * ((Ci + 15) / 16) * taps;
   int64_t ns = (rows + 4 * K1_WB - 1) / (4 * K1_WB);          // one register batch per wave
@@ -343,9 +353,28 @@ static int k1_wgrad_launch(const float* g, const float* in, int64_t rows, int L,
   a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
   a.part = (float*)ws;
   a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
-  hipLaunchKernelGGL(pv_k1_wgrad_kernel, dim3((unsigned)(a.mtiles * a.ntiles * taps * a.nsplit)), dim3(256), 0, s, a);
-  PV_LAUNCH_CHECK();
+  a.nblk = a.mtiles * a.ntiles * taps * a.nsplit;
+  if (deferred && defer->k1b && defer->k1b->n < PV_K1_BATCH) {          // recorded: launched by pv_k1_wgrad_flush
+    defer->k1b->e[defer->k1b->n++] = a;
+  } else {
+    hipLaunchKernelGGL(pv_k1_wgrad_kernel, dim3((unsigned)a.nblk), dim3(256), 0, s, a);
+    PV_LAUNCH_CHECK();
+  }
   return pv_wgrad_finish(deferred ? defer : nullptr, a.part, a.nsplit, (int64_t)Co * Ci * taps, dw, a.part_b, Co, db, s);
+}
+
+int pv_k1_wgrad_flush(PvK1Batch* b, hipStream_t s) {
+  if (!b || b->n == 0) return 0;
+  K1Tab t{};
+  t.n = b->n;
+  int tot = 0;
+  for (int k = 0; k < b->n; ++k) { t.e[k] = b->e[k]; t.blk0[k] = tot; tot += b->e[k].nblk; }
+  t.blk0[b->n] = tot;
+  b->n = 0;
+  if (tot < 1) return 0;
+  hipLaunchKernelGGL(pv_k1_wgrad_table_kernel, dim3((unsigned)tot), dim3(256), 0, s, t);
+  PV_LAUNCH_CHECK();
+  return 0;
 }
 
 // dw (Co, Ci) = g (rows, Co)^T in (rows, Ci); db (Co) = column sums of g (null: none)

@@ -202,6 +202,14 @@ inline bool k3_lean_1d(int nd) {
   return v == 1 && nd == 1 && k1_lean();
 }
 
+// mixed-precision leg: the register-fed (exact fp32) form too when the weight gradients are batched into one launch
+// (PV_K3LEAN_MIXED=0: keep the bf16 tile kernel there)
+inline bool k3_lean_mixed(const Scratch& sc) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PV_K3LEAN_MIXED"); v = (e && atoi(e) == 0) ? 0 : 1; }
+  return v == 1 && sc.fin && sc.fin->k1b;
+}
+
 // a kernel-1 convolution without activation followed by the 1-D nearest upsample (UpsampleBlock with the convolution first):
 // one launch each way — the forward stores every row twice, the backward kernels read the sum of the two rows
 // (PV_NO_K1UP=1: separate upsample launches)
@@ -260,7 +268,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s,
                                  sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), sc.fin));
-      else if (k3_lean_1d(nd) && !sc.conv_bf16)          // (the mixed-precision leg's bf16 kernel is the faster one there)
+      else if (k3_lean_1d(nd) && (!sc.conv_bf16 || k3_lean_mixed(sc)))   // (launch by launch the mixed leg's bf16 kernel is faster)
         PV_TRY(pv_conv3_1d_wgrad_lean(g, in, B, si.H, si.C, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin));
       else if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_wgrad_direct_bf16(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, sc.fin));
@@ -339,7 +347,9 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
 // dL/d(a[0]) (null when need_input_grad is false: the first op then skips its dgrad)
 inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n, int nd, int B, float* const* a,
                      const Shape* sh, float* g, float* const* gbuf, int& pp, bool need_input_grad, float** gout,
-                     const Scratch& sc, hipStream_t s, int stack_id = 0, bool g_is_pre0 = false) {
+                     const Scratch& sc, hipStream_t s, int stack_id = 0, bool g_is_pre0 = false, float* const* gown = nullptr) {
+  // gown != null: op i writes dL/d(a[i]) into its OWN buffer gown[i] instead of the ping-pong pair — every layer's gradient
+  // then survives the whole backward, which is what recorded (batched) weight gradients need (PvFinishList::k1b)
   bool g_is_pre = g_is_pre0;                           // g already carries the last op's activation derivative
   const bool c1pool = stack_id == 0 && sc.code && !need_input_grad && c1pool_fusable(ops, n, nd, sh[0]);
   for (int i = n - 1; i >= 0; --i) {
@@ -360,7 +370,7 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
     }
     if (k1up_fusable(ops, n, nd, i - 1)) continue;     // the upsample of a fused pair: its backward rides in the convolution's
     const int g_up = k1up_fusable(ops, n, nd, i) ? 1 : 0;
-    float* gin = (i > 0 || need_input_grad) ? gbuf[pp] : nullptr;
+    float* gin = (i > 0 || need_input_grad) ? (gown ? gown[i] : gbuf[pp]) : nullptr;
     // the layer below is a convolution with an activation: let this op's backward apply act'(a[i]) to gin
     const int fuse_act = (i > 0 && gin && ops[i - 1].kind == PV_OP_CONV) ? ops[i - 1].act : PV_ACT_NONE;
     bool fused = false;

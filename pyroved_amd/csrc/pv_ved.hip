@@ -8,6 +8,7 @@
 #include "pv_common.h"
 #include "pv_kernels.h"
 #include "pv_convstack.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,6 +31,7 @@ struct VLayout {
   float* f0; float* df0;
   float* llrow; float* dlda; float* llb;
   float* g[2];                                         // gradient ping-pong (largest activation)
+  float* dg[PV_MAX_OPS + 1];                           // the decoder's per-op gradients dL/d(da[i]) (kept for the batched weight gradients)
   pvcs::Scratch sc;                                    // im2col / dcol scratch + GEMM split-K scratch
   pvcs::WtPlan wtp; char* wt;                          // the step's tiled conv weights (both stacks, both orientations)
   float* head_wt;                                      // features2latent's weight re-indexed channels-last (null: GEMM path)
@@ -92,6 +94,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   L.loc_nsc = p->out_ch > 1 ? c.take(OUT) : nullptr;
   L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B);
   L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
+  for (int i = 0; i <= p->n_dec_ops; ++i) L.dg[i] = c.take(L.ds[i].elems(B));
   L.sc.col = c.take(nd.maxcol);
   pvcs::wt_layout(p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, false, L.wtp);
   pvcs::wt_layout(p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, true, L.wtp);
@@ -217,8 +220,15 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   // ---- backward: decoder ops in reverse ----
   float* g = nullptr;                                  // (dlda = dL/d(output of the last op), loss = -ELBO)
   int pp = 0;
+  // the decoder's register-fed weight gradients (kernel-1 family, Conv1d kernel 3) are recorded and run as ONE launch after
+  // the input-gradient chain: every layer keeps its own gradient buffer (L.dg) until then.  PV_NO_K1BATCH=1: one launch each.
+  static const int k1b_env = getenv("PV_NO_K1BATCH") && atoi(getenv("PV_NO_K1BATCH")) ? 0 : 1;
+  PvK1Batch k1b{};
+  if (k1b_env) fin.k1b = &k1b;
   PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.g, pp, true,
-                         &g, L.sc, s, 1));
+                         &g, L.sc, s, 1, false, k1b_env ? L.dg : nullptr));
+  PV_TRY(pv_k1_wgrad_flush(&k1b, s));
+  fin.k1b = nullptr;
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
   if (L.l2f_wt) {                                      // straight from the channels-last gradient
