@@ -308,16 +308,119 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_kernel(K1Wg a) {
   k1_wgrad_body(a, blockIdx.x, part, rpart);
 }
 
+// The batched launch is a THROUGHPUT kernel (~20 k workgroups, load-bound at one operand load per MFMA), where the lean
+// tile's virtue — many short workgroups — buys nothing: 2 x 2 output blocks per workgroup with all TAPS of a Conv1d in it
+// (g loaded once, the input at the three shifted positions) is a third of the loads per MFMA.  (As a launch of its own this
+// form measured 20 us per step SLOWER: a quarter of the workgroups.)  Same partial layout as the lean form.
+template <int TAPS>
+__device__ __forceinline__ void k1_wgrad_fat_body(const K1Wg& a, int blk, float* lds) {
+  constexpr int WB = TAPS == 3 ? 32 : 64;            // pixels per register batch of a wave
+  float (*part)[TAPS * 32][33] = reinterpret_cast<float (*)[TAPS * 32][33]>(lds);
+  float (*rpart)[32] = reinterpret_cast<float (*)[32]>(lds + 4 * TAPS * 32 * 33);
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = a.mtiles * a.ntiles;
+  const int sp = blk / tiles, t = blk - sp * tiles;
+  const int mb = t / a.ntiles, nb = t - mb * a.ntiles;
+  bool mok[2], nok[2];
+  const float* gp[2];
+  const float* xp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = 16 * (2 * mb + i) + r; mok[i] = m < a.Co; gp[i] = a.g + (mok[i] ? m : 0);
+    const int n = 16 * (2 * nb + i) + r; nok[i] = n < a.Ci; xp[i] = a.in + (nok[i] ? n : 0);
+  }
+  const int64_t p0 = (int64_t)sp * a.chunk, p1 = p0 + a.chunk < a.rows ? p0 + a.chunk : a.rows;
+  const bool pow2 = (a.L & (a.L - 1)) == 0;
+  f32x4 acc[TAPS][2][2];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[tp][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float rs[2] = {0.0f, 0.0f};
+  for (int64_t b0 = p0 + (int64_t)WB * wave; b0 < p1; b0 += 4 * WB) {
+    float gv[2][WB / 4], xv[TAPS][2][WB / 4];
+#pragma unroll
+    for (int s = 0; s < WB / 4; ++s) {
+      const int64_t p = b0 + 4 * s + q;
+      const bool pok = p < p1;
+      const int64_t pc = pok ? p : p1 - 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float x = a.up ? gp[i][2 * pc * a.Co] + gp[i][(2 * pc + 1) * a.Co] : gp[i][pc * a.Co];
+        gv[i][s] = (pok && mok[i]) ? x : 0.0f;
+      }
+      if (TAPS == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const float y = xp[j][pc * a.Ci]; xv[0][j][s] = (pok && nok[j]) ? y : 0.0f; }
+      } else {
+        const int l = pow2 ? (int)(pc & (a.L - 1)) : (int)(pc % a.L);
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {          // input position = output position + tp - 1, inside the sample
+          const int sh = tp - 1;
+          const bool ok = pok && l + sh >= 0 && l + sh < a.L;
+          const int64_t px = pc + sh < 0 ? 0 : pc + sh >= a.rows ? a.rows - 1 : pc + sh;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) { const float y = xp[j][px * a.Ci]; xv[tp][j][s] = (ok && nok[j]) ? y : 0.0f; }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < WB / 4; ++s) {
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[tp][i][j] = MFMA4(gv[i][s], xv[tp][j][s], acc[tp][i][j]);
+      rs[0] += gv[0][s]; rs[1] += gv[1][s];
+    }
+  }
+  // C layout: lane (n = r, q), register e <-> m = 4 q + e
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[wave][(tp * 2 + i) * 16 + 4 * q + e][16 * j + r] = acc[tp][i][j][e];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float v = rs[i];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (q == 0) rpart[wave][16 * i + r] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < TAPS * 32 * 32; e += 256) {
+    const int nn = e & 31, row = e >> 5, mm = row & 31, tp = row >> 5;
+    const int mo = 32 * mb + mm, no = 32 * nb + nn;
+    if (mo < a.Co && no < a.Ci)
+      a.part[((int64_t)sp * a.Co * a.Ci + (int64_t)mo * a.Ci + no) * TAPS + tp] =
+          (part[0][row][nn] + part[1][row][nn]) + (part[2][row][nn] + part[3][row][nn]);
+  }
+  if (a.part_b && nb == 0 && tid < 32 && 32 * mb + tid < a.Co)
+    a.part_b[(int64_t)sp * a.Co + 32 * mb + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
+}
+
 // every recorded weight gradient of a stack's backward in ONE launch (PvK1Batch): workgroup b serves problem k with
 // blk0[k] <= b < blk0[k + 1].  The problems are independent (each reads its own layer's g and input, which the stack keeps
 // alive until the flush), so a dozen 8-23 us launches — each with its own cold start — become one that fills the GPU.
 struct K1Tab { K1Wg e[PV_K1_BATCH]; int blk0[PV_K1_BATCH + 1]; int n; };
 __global__ __launch_bounds__(256) void pv_k1_wgrad_table_kernel(K1Tab t) {
-  __shared__ float part[4][16][17];
-  __shared__ float rpart[4][16];
+  __shared__ float lds[4 * 3 * 32 * 33 + 4 * 32];     // the fat three-tap form's partial tiles (50.7 KB); the others use a part of it
   int k = 0;
   while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
-  k1_wgrad_body(t.e[k], (int)blockIdx.x - t.blk0[k], part, rpart);
+  const int blk = (int)blockIdx.x - t.blk0[k];
+  if (t.e[k].fat) {
+    if (t.e[k].taps == 3) k1_wgrad_fat_body<3>(t.e[k], blk, lds);
+    else k1_wgrad_fat_body<1>(t.e[k], blk, lds);
+  } else {
+    k1_wgrad_body(t.e[k], blk, reinterpret_cast<float (*)[16][17]>(lds), reinterpret_cast<float (*)[16]>(lds + 4 * 16 * 17));
+  }
 }
 
 static int k1_wg_splits(int64_t rows, int Ci, int Co, int taps) {
@@ -355,6 +458,21 @@ static int k1_wgrad_launch(const float* g, const float* in, int64_t rows, int L,
   a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
   a.nblk = a.mtiles * a.ntiles * taps * a.nsplit;
   if (deferred && defer->k1b && defer->k1b->n < PV_K1_BATCH) {          // recorded: launched by pv_k1_wgrad_flush
+    static const int fat_env = getenv("PV_K1_NOFAT") && atoi(getenv("PV_K1_NOFAT")) ? 0 : 1;
+    if (fat_env && Ci > 16 && Co > 16) {                                // the throughput form (never more splits: ws is sized for the lean one)
+      const int wb = taps == 3 ? 32 : 64;
+      static const int fatb = getenv("PV_K1_FATB") ? atoi(getenv("PV_K1_FATB")) : 2;   // register batches per wave (experiments)
+      const int nbw = fatb >= 1 && fatb <= 16 ? fatb : 2;
+      int64_t ns = (rows + 4 * nbw * wb - 1) / (4 * nbw * wb);          // two register batches per wave
+      if (ns > a.nsplit) ns = a.nsplit;
+      if (ns < 1) ns = 1;
+      a.fat = 1;
+      a.mtiles = (Co + 31) / 32; a.ntiles = (Ci + 31) / 32;
+      a.chunk = ((rows + ns - 1) / ns + 3) / 4 * 4;
+      a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
+      a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
+      a.nblk = a.mtiles * a.ntiles * a.nsplit;
+    }
     defer->k1b->e[defer->k1b->n++] = a;
   } else {
     hipLaunchKernelGGL(pv_k1_wgrad_kernel, dim3((unsigned)a.nblk), dim3(256), 0, s, a);
@@ -402,5 +520,19 @@ extern "C" int pv_debug_k1(int what, const float* a0, const float* a1, const flo
   if (what == 3)                                                                                  // kernel 3, 1-D: act = L
     return pv_conv3_1d_wgrad_lean(a0, a1, (int)(rows / act), act, Ci, Co, o0, o1, ws, ws_bytes, s, nullptr);
   return PV_EINVAL;
+}
+// the batched form: a kernel-1 and a kernel-3 (1-D, samples of L positions) weight gradient of the same (g, in) recorded in one
+// PvK1Batch, one table launch, one reduction launch
+extern "C" int pv_debug_k1_batch(const float* g, const float* in, long long rows, int L, int Ci, int Co, float* dw1, float* db1,
+                                 float* dw3, float* db3, void* ws, long long ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PvFinishList fin{};
+  PvK1Batch kb{};
+  fin.base = (char*)ws; fin.cap = ws_bytes; fin.k1b = &kb;
+  PV_TRY(pv_k1_wgrad(g, in, rows, Ci, Co, dw1, db1, nullptr, 0, s, &fin, 0));
+  PV_TRY(pv_conv3_1d_wgrad_lean(g, in, (int)(rows / L), L, Ci, Co, dw3, db3, nullptr, 0, s, &fin));
+  if (kb.n != 2) return PV_EINVAL;                   // (both must have been recorded)
+  PV_TRY(pv_k1_wgrad_flush(&kb, s));
+  return pv_wgrad_finish_all(&fin, s);
 }
 extern "C" long long pv_debug_k1_ws(long long rows, int Ci, int Co) { return k1_wg_ws(rows, Ci, Co, 3); }

@@ -478,3 +478,30 @@ def test_kernel3_1d_weight_gradient_on_the_register_fed_kernel(gpu_device, B, Ln
     (gw,) = torch.autograd.grad(y, wd, gy.double().permute(0, 2, 1))
     assert rel_l2(dw, gw) < 2e-6
     assert rel_l2(db, gy.double().sum((0, 1))) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ln,Ci,Co", [(256, 16, 128, 128), (64, 32, 64, 32), (5, 24, 20, 40), (3, 7, 32, 8), (9, 128, 32, 64), (4, 10, 48, 17)])
+def test_batched_weight_gradients_one_launch(gpu_device, B, Ln, Ci, Co):
+    """PvK1Batch: a kernel-1 and a Conv1d kernel-3 weight gradient recorded and run by ONE table-driven launch (the 32 x 32 tile
+    form with all taps in the workgroup when both channel counts exceed 16), then one reduction launch; against float64."""
+    g = torch.Generator().manual_seed(B + Ln + Ci + Co + 7)
+    x = torch.randn(B, Ln, Ci, generator=g).cuda()
+    gy = torch.randn(B, Ln, Co, generator=g).cuda()
+    L = lib()
+    L.pv_debug_k1_ws.restype = C.c_longlong
+    rows = B * Ln
+    ws = torch.empty(2 * int(L.pv_debug_k1_ws(C.c_longlong(rows), Ci, Co)) + 4096, dtype=torch.uint8, device="cuda")
+    dw1 = torch.full((Co, Ci), float("nan"), device="cuda")
+    db1 = torch.full((Co,), float("nan"), device="cuda")
+    dw3 = torch.full((Co, Ci, 3), float("nan"), device="cuda")
+    db3 = torch.full((Co,), float("nan"), device="cuda")
+    assert L.pv_debug_k1_batch(ptr(gy), ptr(x), C.c_longlong(rows), Ln, Ci, Co, ptr(dw1), ptr(db1), ptr(dw3), ptr(db3), ptr(ws),
+                               C.c_longlong(ws.numel()), stream()) == 0
+    g2, x2 = gy.double().reshape(rows, Co), x.double().reshape(rows, Ci)
+    assert rel_l2(dw1, g2.t() @ x2) < 2e-6
+    assert rel_l2(db1, g2.sum(0)) < 2e-6
+    wd = torch.zeros(Co, Ci, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = F.conv1d(x.double().permute(0, 2, 1), wd, None, padding=1)
+    (gw,) = torch.autograd.grad(y, wd, gy.double().permute(0, 2, 1))
+    assert rel_l2(dw3, gw) < 2e-6
+    assert rel_l2(db3, g2.sum(0)) < 2e-6
