@@ -67,6 +67,10 @@ bool pv_conv3_sp_supported(int C, int Cout, int nd, int act);
 // three-piece (PV_SP_X6=1)
 int pv_conv3_sp_fp32_mode();
 int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
+// a layer's weight gradient + input gradient as ONE launch: between begin and flush the fp16-mode pv_conv3_sp_wgrad (with a
+// deferring finish list) and pv_conv3_sp calls record their kernel instead of launching it; flush launches what was recorded
+void pv_conv3_sp_pair_begin();
+int pv_conv3_sp_pair_flush(hipStream_t s);
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr,
                 float* pool_out = nullptr, unsigned char* pool_code = nullptr);

@@ -258,9 +258,8 @@ int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s) {
 }
 
 template <int NS, int NCB, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
+__device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, const int bid_y, char* smem) {
   static_assert(!F16 || NS == 2, "the fp16 mode has two pieces");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float smax[2][4];                        // F16: the waves' patch maxima of the chunk being staged
   constexpr int TG = NS == 3 ? 1 : 3;                 // taps per weight stage
   constexpr int NG = 9 / TG;
@@ -269,14 +268,14 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
   char* wl = smem + NS * SP_PPLANE;                   // [TG][NS][64][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int wy = wave >> 1, wx = wave & 1;
-  int t = blockIdx.x;
+  int t = bid_x;
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
   const int y0 = ty * SP_T, x0 = tx * SP_T;
   // p.halves == 2 (NCB = 2 only): a workgroup takes 32 of a 64-channel tile's output channels — twice the workgroups for
   // launches that would otherwise be a single round of workgroups all in the same phase
-  const int cot = p.halves == 2 ? blockIdx.y >> 1 : blockIdx.y;
-  const int hco = p.halves == 2 ? 32 * (blockIdx.y & 1) : 0;          // first output channel of this workgroup within the tile
+  const int cot = p.halves == 2 ? bid_y >> 1 : bid_y;
+  const int hco = p.halves == 2 ? 32 * (bid_y & 1) : 0;          // first output channel of this workgroup within the tile
   const int nch = p.Cin / SP_KC;
   const float* in_b = p.in + (int64_t)b * p.H * p.W * p.Cin;
   f32x4 acc[NCB][4];                                  // NCB: 16-channel blocks per workgroup (2 when Cout <= 32)
@@ -575,6 +574,12 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
   }
 }
 
+template <int NS, int NCB, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  sp_conv_body<NS, NCB, F16>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
 int pv_conv3_sp_fp32_mode() {
   static const int mode = (getenv("PV_SP_X6") && atoi(getenv("PV_SP_X6"))) ? 3 : 4;
   return mode;
@@ -590,6 +595,7 @@ int64_t pv_conv3_sp_wt_bytes(int C, int Cout) {
   return ((n + SP_TN - 1) / SP_TN) * SP_TN * n * 9 * 3 * 2 + 256;
 }
 
+bool sp_pair_capture_fwd(const ConvSp& q, int ncb, dim3 grid, size_t lds);
 template <int NS, bool F16 = false>
 static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int flip, char* wt, int nt, int64_t total,
                            hipStream_t s) {
@@ -610,6 +616,9 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
   ConvSp q = p;
   q.halves = (p.Cout > 32 && wgs <= split_lim) ? 2 : 1;
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(nt * q.halves));
+  if constexpr (F16) {
+    if (sp_pair_capture_fwd(q, (p.Cout <= 32 || q.halves == 2) ? 2 : 4, grid, lds)) return 0;      // (launched by pv_conv3_sp_pair_flush)
+  }
   if (p.Cout <= 32 || q.halves == 2) hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 2, F16>), grid, dim3(256), lds, s, q);
   else hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 4, F16>), grid, dim3(256), lds, s, q);
   PV_LAUNCH_CHECK();
@@ -722,16 +731,15 @@ template <int NCIB> struct SwGeo {
 // rescaled when a tile changes them; neither exponent may exceed the smallest so far by more than 30 (overflow guard —
 // a tile that would need more is 2^30 below what is already summed).
 template <int NS, int NCIB, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
+__device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x, const int bid_y, const int bid_z, char* smem) {
   static_assert(!F16 || (NS == 2 && NCIB == 1), "the fp16 mode: two pieces, 32-channel workgroups (next-tile prefetch)");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float smx[2][2][4];                     // F16: [tile parity][dY | patch][wave] maxima of the tile being staged
   constexpr int PP = SwGeo<NCIB>::PP, RP = SwGeo<NCIB>::RP, PPLANE = SwGeo<NCIB>::PLANE;
   char* dyl = smem;                                  // [NS] planes
   char* patch = smem + NS * SW_DYPLANE;              // [NS] planes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int wco = wave & 1, wci = wave >> 1;
-  const int split = blockIdx.x, cit = blockIdx.y, cot = blockIdx.z;
+  const int split = bid_x, cit = bid_y, cot = bid_z;
   constexpr int CIW = 32 * NCIB;                     // input channels per workgroup
   const int64_t T = (int64_t)p.B * p.tiles_y * p.tiles_x;
   const int64_t t_lo = T * split / p.nsplit, t_hi = T * (split + 1) / p.nsplit;
@@ -953,6 +961,77 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
     }
 }
 
+template <int NS, int NCIB, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void pv_conv3_sp_wgrad_kernel(ConvWgSp p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  sp_wgrad_body<NS, NCIB, F16>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+
+// A layer's input gradient and weight gradient in ONE launch (fp16 two-piece forms): they are independent (both read dY),
+// each is memory phase + MFMA phase in sequence with every workgroup of a launch in the same phase — interleaved on the
+// same CUs (even workgroups: input gradient, odd: weight gradient, two resident per CU) one's MFMAs cover the other's
+// fetches and stores.  Two streams gave -6...-19 % in isolation but lost it to their event barriers; one launch has none.
+struct SpPairIdx { int nA, gAx, nB, gBx, gBy; };
+template <int NCB>
+__global__ __launch_bounds__(256, 2) void pv_conv3_sp_pair_kernel(ConvSp pa, ConvWgSp pb, SpPairIdx ix) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = (int)blockIdx.x, m = ix.nA < ix.nB ? ix.nA : ix.nB;
+  bool isA; int idx;
+  if (b < 2 * m) { isA = (b & 1) == 0; idx = b >> 1; }
+  else { isA = ix.nA > ix.nB; idx = b - m; }
+  if (isA) sp_conv_body<2, NCB, true>(pa, idx % ix.gAx, idx / ix.gAx, smem);
+  else sp_wgrad_body<2, 1, true>(pb, idx % ix.gBx, (idx / ix.gBx) % ix.gBy, idx / (ix.gBx * ix.gBy), smem);
+}
+
+// capture of the two launches of a pair (pv_conv3_sp_pair_begin ... pv_conv3_sp_pair_flush, same host thread)
+struct SpPairCap {
+  bool on = false, haveA = false, haveB = false;
+  ConvSp a; int ncb = 0; dim3 gridA; size_t ldsA = 0;
+  ConvWgSp b; dim3 gridB; size_t ldsB = 0;
+};
+static thread_local SpPairCap g_pair;
+
+bool sp_pair_capture_fwd(const ConvSp& q, int ncb, dim3 grid, size_t lds) {
+  if (!g_pair.on || g_pair.haveA || q.pool_out) return false;
+  g_pair.a = q; g_pair.ncb = ncb; g_pair.gridA = grid; g_pair.ldsA = lds; g_pair.haveA = true;
+  return true;
+}
+void pv_conv3_sp_pair_begin() {
+  static const int on = getenv("PV_NO_SPPAIR") && atoi(getenv("PV_NO_SPPAIR")) ? 0 : 1;
+  g_pair = SpPairCap{};
+  g_pair.on = on != 0;
+}
+int pv_conv3_sp_pair_flush(hipStream_t s) {
+  SpPairCap c = g_pair;
+  g_pair = SpPairCap{};
+  // only while the two together are well under two rounds of workgroups (768: conv-encoder iVAE at batch 128 -12 us per step);
+  // beyond that each launch fills the chip on its own and interleaving costs (VED at batch 256, every layer paired: +30 us).
+  // PV_SPPAIR_MAX overrides.
+  static const int64_t pair_max = getenv("PV_SPPAIR_MAX") ? atoll(getenv("PV_SPPAIR_MAX")) : 768;
+  const int64_t nab = (int64_t)c.gridA.x * c.gridA.y + (int64_t)c.gridB.x * c.gridB.y * c.gridB.z;
+  if (c.haveA && c.haveB && nab > pair_max) {
+    hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1, true>), c.gridB, dim3(256), c.ldsB, s, c.b);
+    PV_LAUNCH_CHECK();
+    c.haveB = false;
+  }
+  if (c.haveA && c.haveB) {
+    SpPairIdx ix{(int)(c.gridA.x * c.gridA.y), (int)c.gridA.x, (int)(c.gridB.x * c.gridB.y * c.gridB.z), (int)c.gridB.x, (int)c.gridB.y};
+    const size_t lds = c.ldsA > c.ldsB ? c.ldsA : c.ldsB;
+    const dim3 grid((unsigned)(ix.nA + ix.nB));
+    if (c.ncb == 2) hipLaunchKernelGGL((pv_conv3_sp_pair_kernel<2>), grid, dim3(256), lds, s, c.a, c.b, ix);
+    else hipLaunchKernelGGL((pv_conv3_sp_pair_kernel<4>), grid, dim3(256), lds, s, c.a, c.b, ix);
+    PV_LAUNCH_CHECK();
+  } else if (c.haveA) {
+    if (c.ncb == 2) hipLaunchKernelGGL((pv_conv3_sp_kernel<2, 2, true>), c.gridA, dim3(256), c.ldsA, s, c.a);
+    else hipLaunchKernelGGL((pv_conv3_sp_kernel<2, 4, true>), c.gridA, dim3(256), c.ldsA, s, c.a);
+    PV_LAUNCH_CHECK();
+  } else if (c.haveB) {
+    hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1, true>), c.gridB, dim3(256), c.ldsB, s, c.b);
+    PV_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 int pv_wgrad_finish_blocks(int64_t nw, int nb);
 extern __global__ void pv_conv3_wgrad_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
                                                     const float* __restrict__ part_b, int nb, float* __restrict__ out_b);
@@ -990,7 +1069,9 @@ int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int
   const bool wide = ns == 2 && C % 64 == 0;
   const dim3 grid((unsigned)p.nsplit, (unsigned)(wide ? C / 64 : C / 32), (unsigned)((Cout + 63) / 64));
   const size_t lds = (size_t)(ns == 4 ? 2 : ns) * (SW_DYPLANE + (wide ? SwGeo<2>::PLANE : SwGeo<1>::PLANE));
-  if (ns == 4) {
+  if (ns == 4 && defer && g_pair.on && !g_pair.haveB) {          // (deferred reduction: the kernel may run later, in the pair launch)
+    g_pair.b = p; g_pair.gridB = grid; g_pair.ldsB = lds; g_pair.haveB = true;
+  } else if (ns == 4) {
     hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1, true>), grid, dim3(256), lds, s, p);
   } else if (ns == 3) {
     hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<3, 1>), grid, dim3(256), lds, s, p);

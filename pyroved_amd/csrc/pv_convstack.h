@@ -265,6 +265,19 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     if (!g_is_pre) PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));         // g = dL/d(pre-activation)
     float* db = o.b_off >= 0 ? grads + o.b_off : nullptr;
     if (o.ksize == 3) {
+      const bool pair = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) && gin && sc.fin && !sc.conv_bf16 && pv_conv3_sp_fp32_mode() == 4 &&
+                        pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE);
+      if (pair) {                                       // weight gradient + input gradient: one launch (pv_conv_sp.hip)
+        pv_conv3_sp_pair_begin();
+        int rc = pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, 4, sc.fin);
+        if (rc == 0) {
+          if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+          rc = pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act, 4,
+                           wt_ready(sc, slot, 1));
+        }
+        const int rc2 = pv_conv3_sp_pair_flush(s);
+        return rc ? rc : rc2;
+      }
       if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s,
                                  sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), sc.fin));
