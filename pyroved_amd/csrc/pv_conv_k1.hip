@@ -340,30 +340,49 @@ __device__ __forceinline__ void k1_wgrad_fat_body(const K1Wg& a, int blk, float*
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[tp][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float rs[2] = {0.0f, 0.0f};
+  // Operands by buffer loads: a 32-bit lane offset per operand and batch plus the (uniform) step within the batch —
+  // no 64-bit address arithmetic and no selects per load (the lean form spends ~100 VALU instructions per 12 MFMAs on
+  // them).  Rows past the tensor read 0 (buffer bounds; the chunk is a whole number of workgroup batches, so a batch never
+  // straddles the next chunk), channels past Co / Ci read a valid channel whose outputs are never stored.
+  const int gm = a.up ? 2 : 1;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)(a.rows * gm * a.Co * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)(a.rows * a.Ci * 4), 0x00020000);
+  int mc[2], nc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { mc[i] = mok[i] ? 16 * (2 * mb + i) + r : 0; nc[i] = nok[i] ? 16 * (2 * nb + i) + r : 0; }
   for (int64_t b0 = p0 + (int64_t)WB * wave; b0 < p1; b0 += 4 * WB) {
     float gv[2][WB / 4], xv[TAPS][2][WB / 4];
+    const int pb = (int)b0 + q;                        // this lane's first pixel of the batch
+    int go[2], xo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { go[i] = 4 * (pb * gm * a.Co + mc[i]); xo[i] = 4 * (pb * a.Ci + nc[i]); }
+    const int l0 = pow2 ? (pb & (a.L - 1)) : pb % a.L;
 #pragma unroll
     for (int s = 0; s < WB / 4; ++s) {
-      const int64_t p = b0 + 4 * s + q;
-      const bool pok = p < p1;
-      const int64_t pc = pok ? p : p1 - 1;
+      const int so_g = 16 * s * gm * a.Co, so_x = 16 * s * a.Ci;      // (uniform: 4 pixels x 4 bytes per step)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float x = a.up ? gp[i][2 * pc * a.Co] + gp[i][(2 * pc + 1) * a.Co] : gp[i][pc * a.Co];
-        gv[i][s] = (pok && mok[i]) ? x : 0.0f;
+        // (the step goes into the LANE offset: the scalar offset is not part of the buffer's range check, and a lane offset
+        //  that is negative before the step is added would read 0 for a pixel that exists)
+        float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, go[i] + so_g, 0, 0));
+        if (a.up) x += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, go[i] + so_g + 4 * a.Co, 0, 0));
+        gv[i][s] = x;
       }
       if (TAPS == 1) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const float y = xp[j][pc * a.Ci]; xv[0][j][s] = (pok && nok[j]) ? y : 0.0f; }
+        for (int j = 0; j < 2; ++j) xv[0][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo[j] + so_x, 0, 0));
       } else {
-        const int l = pow2 ? (int)(pc & (a.L - 1)) : (int)(pc % a.L);
+        int l = l0 + 4 * s;
+        l = pow2 ? (l & (a.L - 1)) : l % a.L;
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) {          // input position = output position + tp - 1, inside the sample
           const int sh = tp - 1;
-          const bool ok = pok && l + sh >= 0 && l + sh < a.L;
-          const int64_t px = pc + sh < 0 ? 0 : pc + sh >= a.rows ? a.rows - 1 : pc + sh;
+          const bool ok = l + sh >= 0 && l + sh < a.L;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) { const float y = xp[j][px * a.Ci]; xv[tp][j][s] = (ok && nok[j]) ? y : 0.0f; }
+          for (int j = 0; j < 2; ++j) {
+            const float y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo[j] + so_x + 4 * sh * a.Ci, 0, 0));
+            xv[tp][j][s] = ok ? y : 0.0f;
+          }
         }
       }
     }
@@ -459,7 +478,7 @@ static int k1_wgrad_launch(const float* g, const float* in, int64_t rows, int L,
   a.nblk = a.mtiles * a.ntiles * taps * a.nsplit;
   if (deferred && defer->k1b && defer->k1b->n < PV_K1_BATCH) {          // recorded: launched by pv_k1_wgrad_flush
     static const int fat_env = getenv("PV_K1_NOFAT") && atoi(getenv("PV_K1_NOFAT")) ? 0 : 1;
-    if (fat_env && Ci > 16 && Co > 16) {                                // the throughput form (never more splits: ws is sized for the lean one)
+    if (fat_env && Ci > 16 && Co > 16 && rows * 2 * (int64_t)(Co > Ci ? Co : Ci) * 4 < (int64_t)1 << 31) {                                // the throughput form (never more splits: ws is sized for the lean one)
       const int wb = taps == 3 ? 32 : 64;
       static const int fatb = getenv("PV_K1_FATB") ? atoi(getenv("PV_K1_FATB")) : 2;   // register batches per wave (experiments)
       const int nbw = fatb >= 1 && fatb <= 16 ? fatb : 2;
@@ -468,7 +487,7 @@ static int k1_wgrad_launch(const float* g, const float* in, int64_t rows, int L,
       if (ns < 1) ns = 1;
       a.fat = 1;
       a.mtiles = (Co + 31) / 32; a.ntiles = (Ci + 31) / 32;
-      a.chunk = ((rows + ns - 1) / ns + 3) / 4 * 4;
+      a.chunk = ((rows + ns - 1) / ns + 4 * wb - 1) / (4 * wb) * (4 * wb);   // whole workgroup batches (the body relies on it)
       a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
       a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
       a.nblk = a.mtiles * a.ntiles * a.nsplit;

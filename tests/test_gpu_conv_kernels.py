@@ -480,7 +480,8 @@ def test_kernel3_1d_weight_gradient_on_the_register_fed_kernel(gpu_device, B, Ln
     assert rel_l2(db, gy.double().sum((0, 1))) < 2e-6
 
 
-@pytest.mark.parametrize("B,Ln,Ci,Co", [(256, 16, 128, 128), (64, 32, 64, 32), (5, 24, 20, 40), (3, 7, 32, 8), (9, 128, 32, 64), (4, 10, 48, 17)])
+@pytest.mark.parametrize("B,Ln,Ci,Co", [(256, 16, 128, 128), (64, 32, 64, 32), (5, 24, 20, 40), (3, 7, 32, 8), (9, 128, 32, 64), (4, 10, 48, 17),
+                                        (1, 16, 32, 32), (8, 16, 32, 32), (2, 300, 24, 24)])   # (small tensors: the first pixels' left tap weighs most)
 def test_batched_weight_gradients_one_launch(gpu_device, B, Ln, Ci, Co):
     """PvK1Batch: a kernel-1 and a Conv1d kernel-3 weight gradient recorded and run by ONE table-driven launch (the 32 x 32 tile
     form with all taps in the workgroup when both channel counts exceed 16), then one reduction launch; against float64."""
