@@ -61,7 +61,7 @@ struct Layout {
   int nchunk, rows_per_chunk;
   // fused persistent decoder path
   bool fused; int f_grid, f_kmax;
-  float* f_part; float* f_part_hz; float* f_rowtp; float* f_wimg;
+  float* f_part; float* f_part_hz; float* f_rowtp; float* f_wimg; float* f_park;
   int64_t total;
 };
 
@@ -150,7 +150,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   int64_t maxd = 0;
   L.fused = p->fused && pv_sdec_fused_supported(p) && !(K > 0 && !L.enc_compact);   // (jiVAE + generic encoder: layered)
   L.f_grid = L.f_kmax = 0;
-  L.f_part = L.f_part_hz = L.f_rowtp = L.f_wimg = nullptr;
+  L.f_part = L.f_part_hz = L.f_rowtp = L.f_wimg = L.f_park = nullptr;
   for (int i = 0; i < p->n_dec; ++i) {
     L.dact[i] = L.fused ? nullptr : c.take(R * p->dec[i].out_dim);
     L.dpre_[i] = (!L.fused && p->dec[i].act == PV_ACT_GELU) ? c.take(R * p->dec[i].out_dim) : nullptr;
@@ -172,6 +172,8 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       L.f_part_hz = c.take(S * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);
       L.f_wimg = c.take(FB_WIMG_BYTES / (int64_t)sizeof(float));
+      const int64_t park = (p->fused == 2 && !inference_only) ? pv_sdec_fused_bf16_park_bytes(true, units, L.f_grid) : 0;
+      L.f_park = park ? c.take(park / (int64_t)sizeof(float)) : nullptr;
       upd(pv_colsum_ws(B, (int)H0));
     }
     L.logits = nullptr;
@@ -658,7 +660,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.W2 = p->params + p->dec[1].w_off; f.b2 = p->params + p->dec[1].b_off;
   f.wo = p->params + p->out.w_off; f.bo = p->params + p->out.b_off;
   f.llrow = L.llrow; f.loc = p->loc; f.rowtp = L.f_rowtp; f.part_hz = L.f_part_hz; f.part = L.f_part;
-  f.wimg = L.f_wimg;
+  f.wimg = L.f_wimg; f.park = L.f_park;
   f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)S; f.lik = p->lik;
   f.sw = K > 0 ? L.sw : p->row_w; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;

@@ -29,6 +29,7 @@ struct PvFused {
   const float* sw;       // per-sample weight of dL/dlogit (jiVAE: alpha[b][k] of sample (k, b)); null: 1
   int64_t x_units;       // > 0: the observations repeat every x_units units (jiVAE: B*N/16; x is (B, N)); 0: x is (M)
   void* wimg;            // bf16x3 kernel only: FB_WIMG_BYTES of pre-split weight images (pv_sdec_fused_bf16_prep)
+  void* park;            // 8-wave split-precision kernel only: pv_sdec_fused_w8x3_park_bytes(grid) of per-wave parking slots
   int64_t M;             // rows
   int64_t units;         // M / FD_UNIT
   int N, cd, B, lik, sigmoid_out, kmax;
@@ -56,6 +57,11 @@ struct PvFbPrep;
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3);
 int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s);
 int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
+// the 8-wave split-precision kernel (pv_sdec_fused_w8x3.hip; images pre-scaled by 2 log2(e) like the plain 8-wave kernel's)
+int pv_sdec_fused_w8x3_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
+int64_t pv_sdec_fused_w8x3_park_bytes(int grid);
+// bytes of PvFused::park the launch of (x3, units) needs (0: the kernel that will run has no parking slots)
+int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid);
 // waves per workgroup that publish a dL/d(hz) slot (sizes part_hz)
 int pv_sdec_fused_bf16_waves(bool x3, int64_t units);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer

@@ -847,24 +847,32 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
 
 // the plain-bf16 path runs the 8-wave kernel (pv_sdec_fused_w8.hip) when a workgroup gets at least ~6 of the 8 units a
 // tile takes (batch >= ~32 at 28x28; below that most of a 128-row tile would idle and the 4-wave / 64-row kernel here
-// is faster: 26 vs 30 us at batch 16).  PV_W8=0 / 1 in the environment forces one of them (A/B runs).
-static int fb_w8_mode = -1;            // -1: not read yet; 0 / 1: forced; 2: by problem size
-// test / A-B hook: 0 or 1 forces the 4-wave or the 8-wave plain-bf16 kernel, 2 restores the choice by size
-extern "C" void pv_debug_force_w8(int mode) { fb_w8_mode = mode; }
-static bool fb_use_w8(int64_t units) {
-  int& v = fb_w8_mode;
-  if (v < 0) { const char* e = getenv("PV_W8"); v = e ? (atoi(e) == 0 ? 0 : 1) : 2; }
-  if (v != 2) return v != 0 && units * FD_UNIT < (int64_t)1 << 31;
-  return units >= 6 * (int64_t)pv_sdec_fused_grid(units) && units * FD_UNIT < (int64_t)1 << 31;
+// is faster: 26 vs 30 us at batch 16); the split-precision path likewise runs pv_sdec_fused_w8x3.hip (round 3).
+// PV_W8=0 / 1 and PV_W8X3=0 / 1 in the environment force one of them (A/B runs).
+static int fb_w8_mode[2] = {-1, -1};   // [plain, x3]  -1: not read yet; 0 / 1: forced; 2: by problem size
+// test / A-B hooks: 0 or 1 forces the 4-wave or the 8-wave kernel, 2 restores the choice by size
+extern "C" void pv_debug_force_w8(int mode) { fb_w8_mode[0] = mode; }
+extern "C" void pv_debug_force_w8x3(int mode) { fb_w8_mode[1] = mode; }
+static bool fb_use_w8(int64_t units, bool x3 = false) {
+  int& v = fb_w8_mode[x3 ? 1 : 0];
+  // (the 8-wave split-precision kernel measured SLOWER than the 4-wave one — 271 vs 188 us at batch 256, r03 — and is
+  //  opt-in: PV_W8X3=1 or the test hook; see pv_sdec_fused_w8x3.hip)
+  if (v < 0) { const char* e = getenv(x3 ? "PV_W8X3" : "PV_W8"); v = e ? (atoi(e) == 0 ? 0 : 1) : (x3 ? 0 : 2); }
+  const int64_t row_cap = (int64_t)1 << 30;                  // (the 8-wave kernels address rows by 32-bit BYTE offsets)
+  if (v != 2) return v != 0 && units * FD_UNIT < row_cap;
+  return units >= 6 * (int64_t)pv_sdec_fused_grid(units) && units * FD_UNIT < row_cap;
 }
-int pv_sdec_fused_bf16_waves(bool x3, int64_t units) { return (!x3 && fb_use_w8(units)) ? 8 : FB_WAVES; }
+int pv_sdec_fused_bf16_waves(bool x3, int64_t units) { return fb_use_w8(units, x3) ? 8 : FB_WAVES; }
+int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid) {
+  return (x3 && fb_use_w8(units, true)) ? pv_sdec_fused_w8x3_park_bytes(grid) : 0;
+}
 
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   static_assert(FB_WIMG_BYTES == 4 * IMG_BYTES, "pv_sdec_fused.h and the LDS image layout disagree");
   PvFbPrep p{};
   p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz;
   p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
-  p.scale = (!x3 && fb_use_w8(f.units)) ? 2.8853900817779268f : 0.0f;
+  p.scale = fb_use_w8(f.units, x3) ? 2.8853900817779268f : 0.0f;
   return p;
 }
 
@@ -880,7 +888,7 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
 }
 
 int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s) {
-  if (!x3 && fb_use_w8(f_in.units)) return pv_sdec_fused_w8_launch(f_in, grid, grads, s);
+  if (fb_use_w8(f_in.units, x3)) return x3 ? pv_sdec_fused_w8x3_launch(f_in, grid, grads, s) : pv_sdec_fused_w8_launch(f_in, grid, grads, s);
   PvFused f = f_in;
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }

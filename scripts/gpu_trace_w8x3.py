@@ -1,0 +1,34 @@
+"""Phase timing of the 8-wave split-precision decoder kernel (a -DX3_TRACE build: scripts/mkvariant_file.sh x3trace
+pv_sdec_fused_w8x3.hip -DX3_TRACE; PV_LIB_PATH=pyroved_amd/variants/lib_x3trace.so python scripts/gpu_trace_w8x3.py):
+cycles per phase, workgroup 0, waves 0 / 7."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pyroved_amd as pv
+from pyroved_amd import _abi
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+eng = model.engine(fused=2)
+x = torch.rand(B, 28, 28, generator=torch.Generator().manual_seed(0)).cuda()
+eps = torch.randn(B, model.z_dim).cuda()
+for _ in range(3):
+    eng.loss_and_grads(x, eps)
+torch.cuda.synchronize()
+lib = C.CDLL(_abi.LIB_PATH)
+buf = (C.c_longlong * 512)()
+print("rc", lib.pv_debug_read_trace_w8x3(buf, 512))
+names = ["start", "coord layer", "fwd L1+tanh+park", "bar0 (W2 landed)", "fwd L2+logit+lik", "dwo colsum+dpre2",
+         "bar+stageA+bar", "consume2 A", "(stage+consume2 B)+bar", "reload W1+dgrad2", "bar (W1 landed)", "dgrad1 (+unpark)",
+         "rowlocal+colsum dpre0", "bar+stageA+bar", "consume1 A", "(stage+consume1 B)+bar"]
+for w, base in ((0, 0), (7, 256)):
+    for t in range(8):
+        st = [buf[base + t * 32 + k] for k in range(16)]
+        if not st[0]:
+            continue
+        out, prev = [], st[0]
+        for k in range(1, 16):
+            if st[k]:
+                out.append("%s=%d" % (names[k], st[k] - prev)); prev = st[k]
+        print("wave", w, "tile", t, "total", prev - st[0], " | ".join(out))
+    nxt = [buf[base + t * 32] for t in range(8) if buf[base + t * 32]]
+    print("wave", w, "tile starts (delta):", [b - a for a, b in zip(nxt, nxt[1:])])

@@ -1675,6 +1675,52 @@ def test_w8_kernel_on_small_and_odd_cases(gpu_device, force_w8, name):
         model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
 
 
+@pytest.fixture()
+def force_w8x3():
+    lib = C.CDLL(_abi.LIB_PATH)
+    lib.pv_debug_force_w8x3(1)
+    try:
+        yield
+    finally:
+        lib.pv_debug_force_w8x3(0)
+
+
+@pytest.mark.parametrize("name", sorted(W8_SMALL) + ["ivae_28x28_r_b128", "ivae_28x28_rt_b256"])
+def test_w8x3_kernel_forced_vs_golden_and_oracle(gpu_device, force_w8x3, name):
+    """The 8-wave SPLIT-PRECISION decoder kernel (round 3: pv_sdec_fused_w8x3.hip, the default fused=2 path once a
+    workgroup has >= 6 units) forced on the small / odd fixtures — partial tiles with most waves idle and half tiles never
+    staged, 1-D data, ragged rows, non-unit KL scale, randn and saturated inputs — and on the two full-size fixtures,
+    at the fp32-class bars: ELBO terms 2e-5 vs the reference's recorded numbers, every gradient 1e-4 vs the oracle."""
+    gold = load_golden(name)
+    meta = meta_of(gold)
+    if meta["batch"] > 64:
+        torch.set_num_threads(8)
+    model, cfg, eng = build(meta, 2)
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    x = make_x(meta["xkind"], meta["batch"], meta["data_dim"])
+    for k in range(meta["steps"]):
+        pre = "s%d" % k
+        eps = torch.from_numpy(gold[pre + ".eps"])
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"])
+        s = eng.scalars.cpu().numpy()
+        np.testing.assert_allclose(s[0], float(gold[pre + ".loss"]), rtol=RTOL_ELBO, err_msg="loss")
+        np.testing.assert_allclose(s[1], float(gold[pre + ".term.model.obs"]), rtol=RTOL_ELBO)
+        o.step(x, eps, meta["beta"])
+        for key in o.p:
+            err = rel_l2(eng.grad_of(key), o.last_grads[key])
+            assert err < RTOL_GRAD, "step %d grad %s: rel l2 error %.3e vs oracle" % (k, key, err)
+        # bit-reproducible (fixed-order reductions), and the forward-only launch (evaluate) agrees
+        g0 = {key: eng.grad_of(key).clone() for key in o.p}
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"])
+        for key in o.p:
+            assert torch.equal(g0[key], eng.grad_of(key)), key
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"], want_grads=False)
+        np.testing.assert_allclose(eng.scalars[0].item(), s[0], rtol=1e-6)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"])
+        eng.adam_step()
+        model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
+
+
 @pytest.mark.parametrize("vname", ["gauss_rts", "gauss_nosig_r", "cbern_16x16_r", "cdim3_rt", "1d32_t_cdim2", "rect_12x20_rts", "priors_rts"])
 def test_w8_kernel_model_variants(gpu_device, force_w8, vname):
     """Likelihoods, class conditioning, custom priors, 1-D + c_dim and rectangular data on the forced 8-wave kernel vs the
