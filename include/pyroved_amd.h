@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 11
+#define PV_ABI_VERSION 12
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -202,6 +202,14 @@ typedef struct pv_ivae_plan {
 
 /* Library / ABI version (PV_ABI_VERSION). */
 int pv_version(void);
+
+/* (v12) Process-wide numeric range switch of the 2-D kernel-3 convolution kernels (conv encoder of an iVAE, VED).  Their
+ * default fp32-class form carries the weights as two fp16 pieces of w * 64 (exact power-of-two scaling of the activations,
+ * none of the weights), valid for 1e-6 < max|w| < 1023; on = 1 selects the three-piece bf16 kernels, which have no range
+ * limit and the same accuracy at ~1.5x the matrix time.  The Python engines call it when a weight leaves the safe range
+ * (checked at bind time and every 64 steps; Adam moves a weight by at most lr per step).  No reference counterpart: the
+ * reference's nn.Conv2d is plain fp32 (nets/conv.py:24-60). */
+void pv_conv_set_wide_weights(int on);
 
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
  * layer widths).  Returns < 0 on an unsupported plan. */

@@ -45,6 +45,11 @@ def conv_ops(layers: nn.Sequential, activation, prefix: Optional[str] = None):
                     raise UnsupportedModel("batch-norm layers must be the reference's nn.BatchNormNd(channels) defaults")
                 ops.append(("batchnorm", b_, None, None if prefix is None else "%s.%d" % (prefix, i)))
         elif isinstance(mod, (nn.MaxPool1d, nn.MaxPool2d)):
+            def _all(v, want):
+                return all(int(u) == want for u in (v if isinstance(v, (tuple, list)) else (v,)))
+            if not (_all(mod.kernel_size, 2) and _all(mod.stride if mod.stride is not None else mod.kernel_size, 2)
+                    and _all(mod.padding, 0) and _all(mod.dilation, 1) and not mod.ceil_mode and not mod.return_indices):
+                raise UnsupportedModel("max pooling must be the reference's 2x window, stride 2, no padding")
             ops.append(("maxpool2", None, None, None))
         elif isinstance(mod, UpsampleBlock):
             if mod.scale_factor != 2 or mod.mode not in ("nearest", "bilinear"):

@@ -867,11 +867,10 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
 
 extern "C" int pv_version(void) { return PV_ABI_VERSION; }
 
-// the plan pv_ivae_decode works on: layered layout; jiVAE.decode(z, y) (jivae.py:255-267) is one decoder row block
+// the plan pv_ivae_decode works on; jiVAE.decode(z, y) (jivae.py:255-267) is one decoder row block
 // per given (z, one-hot class) pair — the class vector is a conditioning input there, not an enumeration axis
 static pv_ivae_plan decode_plan(const pv_ivae_plan* plan) {
   pv_ivae_plan lay = *plan;
-  lay.fused = 0;
   if (lay.discrete_dim > 0) {
     lay.c_dim += lay.discrete_dim;
     lay.head.out_dim -= lay.discrete_dim;
@@ -881,6 +880,59 @@ static pv_ivae_plan decode_plan(const pv_ivae_plan* plan) {
 }
 
 static pv_ivae_plan guide_plan(const pv_ivae_plan* plan);
+
+// ---- forward-only decode on the fused spatial-decoder kernel (models/base.py:145-171) ----
+// decode(z, angle, shift, scale) of an invariant model whose decoder the fused kernel is specialised for: the per-sample
+// transform is the uniform (angle, scale, shift), hz = fc_latent(z), and the persistent kernel runs its forward half only
+// and writes `loc` — no (B N) x 128 activation is materialised (the layered path needs 3 of them: 63 GB at B = 32768).
+// Always at fp32-class precision (fused = 1: f32 matrix instructions; otherwise bf16 split precision), whatever the
+// training precision: reconstructions are what parity is judged on.
+struct DecodeLayout { float* tp; float* hz; float* wimg; float* xdummy; void* scratch; int64_t scratch_bytes, total; };
+static bool decode_fused(const pv_ivae_plan* lay) { return lay->fused && lay->coord_dim > 0 && pv_sdec_fused_supported(lay); }
+static void carve_decode(const pv_ivae_plan* lay, char* base, DecodeLayout& D) {
+  Carver c{base, 0};
+  const int64_t B = lay->batch, H0 = lay->fc_coord.out_dim, lat_in = plan_lat_in(lay);
+  D.tp = c.take(B * 8);
+  D.hz = c.take(B * H0);
+  D.wimg = c.take(FB_WIMG_BYTES / (int64_t)sizeof(float));
+  D.xdummy = c.take(FD_UNIT);
+  D.scratch_bytes = pv_align_up(lat_in > 16 ? gemm_ws_need(B, H0, lat_in) : 0, 256);
+  D.scratch = base ? (void*)(base + c.off) : nullptr;
+  c.off += D.scratch_bytes;
+  D.total = c.off;
+}
+static int decode_fused_run(const pv_ivae_plan* lay, const float* z, float angle, float shift_x, float shift_y, float scale,
+                            float* loc, hipStream_t s) {
+  DecodeLayout D;
+  carve_decode(lay, (char*)lay->ws, D);
+  if (lay->ws_bytes < D.total) return PV_EWS;
+  const int64_t B = lay->batch, N = lay->n_pix, lat_in = plan_lat_in(lay);
+  const int H = FD_H;
+  if (lay->fc_latent.in_dim != lat_in) return PV_EINVAL;
+  PV_TRY(pv_fill_tp(D.tp, (int)B, angle, scale, shift_x, shift_y, s));
+  if (lat_in <= 16) PV_TRY(pv_smallk_linear(z, lat_in, lay->params + lay->fc_latent.w_off, D.hz, B, (int)lat_in, H, s));
+  else PV_TRY(linear_fwd(z, lat_in, lay->params + lay->fc_latent.w_off, nullptr, D.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
+                         D.scratch, D.scratch_bytes, s));
+  hipError_t e = hipMemsetAsync(D.xdummy, 0, FD_UNIT * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  PvFused f{};
+  f.x = D.xdummy; f.x_units = 1;                       // (no observations: every unit reads the same 16 zeros)
+  f.grid = lay->grid; f.tp = D.tp; f.hz = D.hz;
+  f.Wc = lay->params + lay->fc_coord.w_off; f.bc = lay->params + lay->fc_coord.b_off;
+  f.W1 = lay->params + lay->dec[0].w_off; f.b1 = lay->params + lay->dec[0].b_off;
+  f.W2 = lay->params + lay->dec[1].w_off; f.b2 = lay->params + lay->dec[1].b_off;
+  f.wo = lay->params + lay->out.w_off; f.bo = lay->params + lay->out.b_off;
+  f.llrow = nullptr; f.loc = loc; f.wimg = D.wimg;
+  f.M = B * N; f.units = f.M / FD_UNIT; f.N = (int)N; f.cd = lay->coord_dim; f.B = (int)B;
+  f.lik = PV_LIK_GAUSSIAN; f.sigmoid_out = lay->sigmoid_out; f.sig = 1.0f;      // loc = sigmoid(a) or a
+  const int grid = pv_sdec_fused_grid(f.units);
+  if (lay->fused == 1) return pv_sdec_fused_launch(f, grid, false, s);
+  const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, false, true);
+  f.hz_scale = 0.0f;                                   // hz is written unscaled here; the 8-wave kernels scale it themselves
+  (void)prep;
+  PV_TRY(pv_sdec_fused_bf16_prep(f, false, true, s));
+  return pv_sdec_fused_bf16_launch(f, grid, false, true, s);
+}
 
 // what: PV_WS_ALL = enough for every entry point at this batch; PV_WS_STEP / _ENCODE / _DECODE = for that call alone
 // (the training step's fused layout is far smaller than the layered one pv_ivae_decode uses at the same batch)
@@ -908,8 +960,14 @@ extern "C" int64_t pv_ivae_workspace_bytes_for(const pv_ivae_plan* plan, int wha
   }
   if (what == PV_WS_ALL || what == PV_WS_DECODE) {
     pv_ivae_plan q = decode_plan(plan);
-    carve(&q, nullptr, L, true);
-    if (L.total > total) total = L.total;
+    if (decode_fused(&q)) {
+      DecodeLayout D;
+      carve_decode(&q, nullptr, D);
+      if (D.total > total) total = D.total;
+    } else {
+      carve(&q, nullptr, L, true);
+      if (L.total > total) total = L.total;
+    }
   }
   return total;
 }
@@ -930,6 +988,9 @@ extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, 
   carve(plan, (char*)plan->ws, L);
   if (plan->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
+  // the sampled-class objective (Trace_ELBO on a drawn class) exists for the vanilla decoder only — the reference's own model
+  // cannot run it with invariances (models/jivae.py:181-189) — and only the layer-by-layer path implements it
+  if (plan->class_onehot && (L.fused || plan->coord_dim > 0)) return PV_EINVAL;
   if (L.fused) return loss_and_grads_fused(plan, L, want_grads, s);
   return loss_and_grads_layered(plan, L, want_grads, s);
 }
@@ -1036,6 +1097,8 @@ extern "C" int pv_ivae_decode(const pv_ivae_plan* plan, const float* z, float an
   if (plan->coord_dim > 0 && !plan->grid) return PV_EINVAL;
   pv_ivae_plan lay = decode_plan(plan);
   plan = &lay;
+  if (decode_fused(plan)) return decode_fused_run(plan, z, angle, shift_x, shift_y, scale, loc, (hipStream_t)stream);
+  lay.fused = 0;
   Layout L;
   carve(plan, (char*)plan->ws, L, true);
   if (plan->ws_bytes < L.total) return PV_EWS;

@@ -21,7 +21,7 @@ struct PvFused {
   const float *W1, *b1;  // decoder.fc_layers.0 (H, H), (H)
   const float *W2, *b2;  // decoder.fc_layers.2
   const float *wo, *bo;  // decoder.out (1, H), (1)
-  float* llrow;          // (M) log-likelihood per row
+  float* llrow;          // (M) log-likelihood per row (null: not wanted — forward-only decode)
   float* loc;            // (M) decoder output or null
   float* rowtp;          // (4, M) per-row d(phi), d(scale), d(tx), d(ty)
   float* part_hz;        // (B * kmax, H) partial sums of dL/d(hz), zero-filled by the caller

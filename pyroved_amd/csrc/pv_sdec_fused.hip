@@ -326,7 +326,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void pv_sdec_fused_kernel(PvFused f)
       }
       if (f.sw) dlda *= f.sw[row / f.N];          // (jiVAE) weight of the row's sample
       if (q == 0) {
-        f.llrow[row] = ll;
+        if (f.llrow) f.llrow[row] = ll;
         if (f.loc) f.loc[row] = locv;
       }
       if (GRADS) {

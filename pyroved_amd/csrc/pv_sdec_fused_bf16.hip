@@ -677,7 +677,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       FB_STAMP(18);
       dlda *= act ? swv : 0.0f;
       if (q == 0 && act) {
-        f.llrow[row] = ll;
+        if (f.llrow) f.llrow[row] = ll;
         if (f.loc) f.loc[row] = locv;
       }
       xv_next = x_of(pos_nx);                   // lands long before the next LDS-DMA issue point drains loads

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
       dlda *= act ? swv : 0.0f;
       if (q == 0) {
         if (act) {
-          f.llrow[row] = ll;
+          if (f.llrow) f.llrow[row] = ll;
           if (f.loc) f.loc[row] = locv;
         }
         if (GRADS) { dbo += dlda; inf_dl[r] = dlda; }

@@ -526,6 +526,7 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   x3_wait_vm0();                                        // (the observation load above: nothing compiler-visible in flight)
   fetch_unit_inputs(pos_cur);
   const X3Addr wad0 = x3_addr(r, q);
+  (void)wad0;
   int tile_no = -1;
   for (int ut = u_lo; ut < u_hi; ut += X3_WAVES) {
     ++tile_no;
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
       dlda *= act ? swv : 0.0f;
       if (q == 0) {
         if (act) {
-          *reinterpret_cast<float*>(reinterpret_cast<char*>(f.llrow) + rowb) = ll;
+          if (f.llrow) *reinterpret_cast<float*>(reinterpret_cast<char*>(f.llrow) + rowb) = ll;
           if (f.loc) *reinterpret_cast<float*>(reinterpret_cast<char*>(f.loc) + rowb) = locv;
         }
         if (GRADS) { dbo += dlda; inf_dl[r] = dlda; }

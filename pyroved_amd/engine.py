@@ -150,6 +150,7 @@ class IVAEEngine:
     def bind(self):
         """(Re)builds the flat buffers from the model's current parameters and re-points the
         parameters at them.  Called at construction and whenever the parameters were moved."""
+        self._conv_slices = None                # (re-derived, and the weight-range check runs at the next step)
         items = self._param_order()
         n_par = len(items)
         items = items + self._stat_buffers()
@@ -251,6 +252,38 @@ class IVAEEngine:
             if p is None or p.data_ptr() != v.data_ptr() or p.shape != v.shape:
                 return False
         return True
+
+    # ---- numeric range of the fp16-piece convolution kernels (include/pyroved_amd.h: pv_conv_set_wide_weights) ----
+    _CONV_W_HI, _CONV_W_LO, _CONV_W_EVERY = 500.0, 2.0 ** -16, 64
+
+    def _conv3_weight_slices(self):
+        """(offset, numel) in the flat buffer of every kernel-3 convolution weight the model's conv stacks hold."""
+        out = []
+        for key, par in self._views.items():
+            if key.endswith(".weight") and par.dim() >= 3 and par.shape[-1] == 3:
+                out.append((self._layout[key], par.numel()))
+        return out
+
+    def _check_conv_weight_range(self, force: bool = False):
+        """Every _CONV_W_EVERY-th step (and at bind time): if a kernel-3 convolution weight left the range the fp16-piece
+        kernels are exact in, switch the process to the unbounded three-piece bf16 kernels.  One scalar read-back per 64
+        steps; Adam moves a weight by at most lr per step, so the margin to fp16's limit (1023) cannot be crossed between
+        two checks."""
+        if getattr(self, "_conv_slices", None) is None:
+            self._conv_slices = self._conv3_weight_slices()
+            self._conv_tick = 0
+        if not self._conv_slices or getattr(IVAEEngine, "_wide_weights", False):
+            return
+        self._conv_tick += 1
+        if not force and self._conv_tick % self._CONV_W_EVERY != 1:
+            return
+        mx = float(torch.stack([self.flat[o:o + n].abs().max() for o, n in self._conv_slices]).max())
+        if mx >= self._CONV_W_HI or 0.0 < mx < self._CONV_W_LO or mx != mx:
+            import warnings
+            warnings.warn("pyroved_amd: a convolution weight reached |w| = %.3g, outside the range of the fp16-piece "
+                          "kernels; switching this process to the three-piece bf16 convolution kernels" % mx)
+            _abi.lib().pv_conv_set_wide_weights(1)
+            IVAEEngine._wide_weights = True
 
     def ensure_bound(self):
         if not self._bound():
@@ -390,6 +423,8 @@ class IVAEEngine:
         class_onehot (B, discrete_dim): jiVAE WITHOUT enumeration — the class the guide drew for every sample
         (pv_ivae_plan.class_onehot; the trainer's default enumerate_parallel=False)."""
         self.ensure_bound()
+        if self.conv_enc:
+            self._check_conv_weight_range()
         if step and (self.ext_enc or self.ext_dec or getattr(self, "ext_y", False) or not want_grads):
             raise ValueError("step=True needs every parameter in the library (no user-defined modules) and want_grads")
         if self.ext_dec:

@@ -113,6 +113,7 @@ class VEDEngine(IVAEEngine):
         """Enqueues Trace_ELBO.loss_and_grads(VED.model, VED.guide) on the current stream: x (B, C, *input_dim),
         target y (B, C', *output_dim), eps (B, z_dim)."""
         self.ensure_bound()
+        self._check_conv_weight_range()
         if y is None:
             raise ValueError("VED needs the target y")
         b = x.shape[0]

@@ -112,11 +112,13 @@ class baseVAE(nn.Module):
                 z_encoded.append(torch.cat(encoded, -1).cpu())
             return torch.cat(z_encoded)
         eng = self.engine()
+        # results stay on the device until the loader is exhausted: ONE device -> host copy per call instead of a
+        # synchronising .cpu() per batch (the reference's loop, base.py:137-142, pays one per batch)
         for data in loader:
-            x = data[0].to(eng.device, torch.float32)
-            y = data[1].to(eng.device, torch.float32) if len(data) > 1 else None
-            z_encoded.append(torch.cat(eng.encode(x, y), -1).cpu())     # (z_loc, z_scale[, class probabilities])
-        return torch.cat(z_encoded)
+            x = data[0].to(eng.device, torch.float32, non_blocking=True)
+            y = data[1].to(eng.device, torch.float32, non_blocking=True) if len(data) > 1 else None
+            z_encoded.append(torch.cat(eng.encode(x, y), -1))           # (z_loc, z_scale[, class probabilities])
+        return torch.cat(z_encoded).cpu()
 
     def _decode(self, z_new: torch.Tensor, device: str = None, **kwargs: int) -> torch.Tensor:
         """Decodes latent coordinates batch-by-batch (base.py:145-171).  kwargs: batch_size,
@@ -150,10 +152,9 @@ class baseVAE(nn.Module):
             shift = (t[0], t[1] if len(t) > 1 else t[0])
             scale = float(kwargs.get("scale", 1.0))
         x_decoded = []
-        for (z,) in loader:
-            loc = eng.decode(z.to(eng.device, torch.float32), angle, shift, scale)
-            x_decoded.append(loc.cpu())
-        return torch.cat(x_decoded)
+        for (z,) in loader:                    # decoded batches stay on the device; one copy at the end (see _encode)
+            x_decoded.append(eng.decode(z.to(eng.device, torch.float32, non_blocking=True), angle, shift, scale))
+        return torch.cat(x_decoded).cpu()
 
     def set_encoder(self, encoder_net: Type[torch.nn.Module]) -> None:
         """Sets a user-defined encoder neural network."""

@@ -116,17 +116,42 @@ def conv_stack_supported(stack, x: torch.Tensor) -> bool:
             and x.dim() == stack.ndim + 2 and x.shape[0] > 0):
         return False
     try:
-        conv_ops(stack.layers, stack.activation, "L")
+        ops_list = conv_ops(stack.layers, stack.activation, "L")
     except UnsupportedModel:
         return False
-    return True
+    first = next((m for kind, m, _, _ in ops_list if kind == "conv"), None)
+    if first is None or x.shape[1] != first.in_channels:
+        return False                                   # (the modules' own forward raises torch's shape error)
+    return _stack_plan(stack, x, ops_list)[1] >= 0     # geometry the executor rejects: the torch modules run instead
+
+
+def _stack_plan(stack, x, ops_list, layout=None):
+    """(plan, workspace bytes or a negative library code) of the stack on input x; offsets from `layout` when given."""
+    import ctypes as C
+    from ._convplan import fill_ops
+    if layout is None:
+        layout, off = {}, 0
+        for key, t, _ in _stack_tensors(ops_list):
+            layout[key] = off
+            off += (t.numel() + 63) // 64 * 64
+    p = _abi.pv_convnet_plan()
+    p.batch, p.ndim, p.in_ch = x.shape[0], stack.ndim, x.shape[1]
+    for i, d in enumerate(x.shape[2:]):
+        p.in_dim[i] = d
+    p.n_ops = fill_ops(p.ops, ops_list, layout)
+    p.bn_eval = int(not stack.training)
+    p.conv_bf16 = 0
+    p.need_dx = int(x.requires_grad)
+    with _abi.device_of(x.device):
+        need = int(_abi.lib().pv_convnet_workspace_bytes(C.byref(p)))
+    return p, need
 
 
 class _ConvStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stack, *tensors):
         import ctypes as C
-        from ._convplan import conv_ops, fill_ops, bn_modules
+        from ._convplan import conv_ops, bn_modules
         ops_list = conv_ops(stack.layers, stack.activation, "L")
         named = _stack_tensors(ops_list)
         assert len(named) == len(tensors)
@@ -137,17 +162,9 @@ class _ConvStack(torch.autograd.Function):
         flat = torch.zeros(max(off, 1), device=x.device, dtype=torch.float32)
         for (key, t, _), tt_ in zip(named, tensors):
             flat[layout[key]:layout[key] + t.numel()].copy_(tt_.detach().reshape(-1))
-        p = _abi.pv_convnet_plan()
-        p.batch, p.ndim, p.in_ch = x.shape[0], stack.ndim, x.shape[1]
-        for i, d in enumerate(x.shape[2:]):
-            p.in_dim[i] = d
-        p.n_ops = fill_ops(p.ops, ops_list, layout)
-        p.bn_eval = int(not stack.training)
-        p.conv_bf16 = 0
-        p.need_dx = int(x.requires_grad)
+        p, need = _stack_plan(stack, x, ops_list, layout)
         L = _abi.lib()
         with _abi.device_of(x.device):
-            need = L.pv_convnet_workspace_bytes(C.byref(p))
             if need < 0:
                 raise _abi.PvError("pyroved_amd: unsupported conv stack (pv_convnet_workspace_bytes -> %d)" % need)
             shp = (C.c_int32 * 3)()
@@ -166,14 +183,17 @@ class _ConvStack(torch.autograd.Function):
                 for b_ in bns:
                     b_.num_batches_tracked += 1
         ctx.plan, ctx.named, ctx.layout = p, named, layout
-        ctx.keep = (xc, flat, ws)
+        ctx.save_for_backward(xc, flat)         # (version-checked: an in-place edit of either before backward raises)
+        ctx.ws = ws
         return out
 
     @staticmethod
     def backward(ctx, dout):
         import ctypes as C
         p = ctx.plan
-        xc, flat, ws = ctx.keep
+        xc, flat = ctx.saved_tensors
+        ws = ctx.ws
+        p.params, p.ws, p.ws_bytes = flat.data_ptr(), ws.data_ptr(), ws.numel()
         grads = torch.zeros_like(flat)
         dx = torch.empty_like(xc) if (ctx.needs_input_grad[0] and p.need_dx) else None
         p.grads = grads.data_ptr()

@@ -77,6 +77,10 @@ class SVItrainer:
             raise ValueError("enumerate_parallel=True needs a model with a discrete latent (models.jiVAE)")
         self.model = model
         self.svi = None
+        # (attributes every route leaves behind, so that code probing a trainer never meets a missing one)
+        self.engine, self.group, self._hist, self._feed_cache = None, kwargs.get("process_group", None), None, None
+        self.loss_history = {"training_loss": [], "test_loss": []}
+        self.current_epoch = 0
         pyro_objects = (optimizer is not None and not isinstance(optimizer, dict)) or \
                        (loss is not None and loss != "Trace_ELBO")
         if pyro_objects:
@@ -91,6 +95,13 @@ class SVItrainer:
                 raise TypeError("optimizer / loss objects are Pyro objects and need pyro-ppl, which is not installed; "
                                 "pass None or a dict of Adam arguments (the default Trace_ELBO objective runs in the "
                                 "HIP library)") from e
+            # this route is plain single-process Pyro: nothing synchronises replicas and the HIP precision modes do not apply
+            if pvdist.world(self.group)[1] > 1:
+                raise ValueError("Pyro optimizer / loss objects cannot be combined with data-parallel training: replicas "
+                                 "would train unsynchronised (pass optimizer=None or a dict of Adam arguments)")
+            bad = [k for k in ("precision", "fused", "rng", "device_feed", "mirror_evaluate_update") if k in kwargs]
+            if bad:
+                raise ValueError("%s only apply to the HIP training path, not to Pyro optimizer / loss objects" % bad)
             pyro.clear_param_store()
             opt = optimizer if optimizer is not None and not isinstance(optimizer, dict) else \
                 poptim.Adam({"lr": kwargs.get("lr", 1e-3), **(optimizer or {})})
@@ -168,7 +179,11 @@ class SVItrainer:
         extra = {}
         if self._sampled_class:
             # the guide's second draw (after eps): y_b ~ OneHotCategorical(alpha_b), alpha = the encoder's class
-            # probabilities for the GLOBAL batch (every rank computes them, so every rank draws the same classes)
+            # probabilities for the GLOBAL batch (every rank computes them, so every rank draws the same classes).
+            # Cost of this mode, by design: one extra encoder pass and — with rng="cpu", the default — one host sync per
+            # step (alpha.cpu()), because the class must come out of the global CPU generator right after eps for the
+            # trainer to reproduce the reference's stream (fixtures jsivae_*); the device feed is off for the same reason.
+            # rng="device" draws on the GPU without the sync (a different stream, like the reference on a CUDA device).
             xg = x.to(dev, torch.float32)
             alpha = eng.encode(xg)[2]
             if self.rng == "cpu":

@@ -1675,6 +1675,127 @@ def test_w8_kernel_on_small_and_odd_cases(gpu_device, force_w8, name):
         model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
 
 
+@pytest.mark.parametrize("fused", [1, 2, 3])
+@pytest.mark.parametrize("case", ["28x28_rt", "12x20_rts_gauss", "1d32_t", "jivae_8x8_r"])
+def test_fused_forward_only_decode(gpu_device, case, fused):
+    """decode() runs the fused persistent decoder kernel forward-only (no (B N) x 128 activations; SURVEY 8f rank 1,
+    reference models/base.py:145-171) — against the layer-by-layer kernels and the oracle's decode, with angle / shift /
+    scale, at fp32-class precision whatever the training precision (fused = 3 decodes in split precision too), and its
+    workspace stays small at a batch where the layered path would need tens of GB."""
+    g = torch.Generator().manual_seed(5)
+    kw, y = {}, None
+    if case == "28x28_rt":
+        dd, inv = (28, 28), ["r", "t"]
+    elif case == "12x20_rts_gauss":
+        dd, inv, kw = (12, 20), ["r", "t", "s"], dict(sampler_d="gaussian", sigmoid_d=False)
+    elif case == "1d32_t":
+        dd, inv = (32,), ["t"]
+    else:
+        dd, inv = (8, 8), ["r"]
+    if case.startswith("jivae"):
+        model = pv.models.jiVAE(dd, 2, 3, inv, seed=2, device="cuda")
+        ref = pv.models.jiVAE(dd, 2, 3, inv, seed=2, device="cuda")
+        y = torch.zeros(37, 3)
+        y[torch.arange(37), torch.randint(0, 3, (37,), generator=g)] = 1.0
+    else:
+        model = pv.models.iVAE(dd, 2, inv, seed=2, device="cuda", **kw)
+        ref = pv.models.iVAE(dd, 2, inv, seed=2, device="cuda", **kw)
+    eng = model.engine(fused=fused)
+    ref.engine(fused=0)
+    z = torch.randn(37, 2, generator=g)
+    tkw = {}
+    if "r" in inv:
+        tkw["angle"] = torch.tensor(0.4)
+    if "t" in inv:
+        tkw["shift"] = torch.tensor([0.1, -0.2][:len(dd)])
+    if "s" in inv:
+        tkw["scale"] = torch.tensor(1.2)
+    for k in ({}, tkw):
+        a = model.decode(z, y, **k) if y is not None else model.decode(z, **k)
+        b = ref.decode(z, y, **k) if y is not None else ref.decode(z, **k)
+        assert a.shape == (37, *dd) and not a.is_cuda
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=2e-6)
+    # several loader batches (batch_size 16): same values, one host copy
+    a = model.decode(z, y, batch_size=16) if y is not None else model.decode(z, batch_size=16)
+    np.testing.assert_allclose(a.numpy(), (ref.decode(z, y) if y is not None else ref.decode(z)).numpy(), rtol=1e-4, atol=2e-6)
+    if case == "28x28_rt":
+        p = eng._plan(32768, what=3)
+        need = _abi.lib().pv_ivae_workspace_bytes_for(C.byref(p), 3)
+        assert 0 < need < (1 << 26), need            # 64 MB (the layered decode of 32768 latents: 63 GB)
+        zz = torch.randn(4096, 2, generator=g)
+        big = model.decode(zz, batch_size=4096)
+        small = ref.decode(zz[:64])
+        np.testing.assert_allclose(big[:64].numpy(), small.numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_conv_weight_range_switches_kernels(gpu_device):
+    """ The default fp32-class 2-D convolution kernels carry the weights as fp16 pieces of w * 64 — exact only
+    for max|w| < 1023.  A VED whose encoder weights are blown up beyond that: the engine notices at its first step, switches
+    the process to the three-piece bf16 kernels (no range limit) with a warning, and the step matches the oracle at the
+    usual bars instead of returning inf / NaN."""
+    from pyroved_amd.engine import IVAEEngine
+    lib = _abi.lib()
+    model = pv.models.VED((32, 32), (32,), latent_dim=2, seed=1, device="cuda")
+    cfg = orc.VedConfig(input_dim=(32, 32), output_dim=(32,), latent_dim=2, hidden_dim_e=None, hidden_dim_d=None,
+                        activation="lrelu")
+    with torch.no_grad():
+        w = model.encoder_z.feature_extractor.layers[5].weight          # the 64 -> 64 kernel-3 convolution (split-operand kernel)
+        assert w.dim() == 4 and w.shape[1] % 32 == 0
+        w.mul_(2000.0 / w.abs().max())                                   # max|w| = 2000: fp16(w * 64) would be inf
+        model.encoder_z.feature_extractor.layers[0].weight.mul_(1e-3)    # (keeps the activations in a sane range)
+    eng = model.engine()
+    o = orc.VedOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg, dtype=torch.float64)
+    g = torch.Generator().manual_seed(3)
+    x, y, eps = torch.rand(6, 1, 32, 32, generator=g), torch.rand(6, 1, 32, generator=g), torch.randn(6, 2, generator=g)
+    try:
+        with pytest.warns(UserWarning, match="three-piece bf16"):
+            eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+        assert IVAEEngine._wide_weights
+        s = eng.scalars.cpu().numpy()
+        loss_ref = o.step(x, y, eps, 1.0)
+        assert np.isfinite(s).all()
+        np.testing.assert_allclose(s[0], loss_ref, rtol=1e-4)
+        for key in o.p:
+            # (a network with weights of 2000 next to weights of 1e-3 is ill-conditioned by construction: fp32 arithmetic
+            #  itself is ~1e-3 off the float64 oracle in the first layers; what is checked is "finite and right", not 1e-4)
+            err = rel_l2(eng.grad_of(key), o.last_grads[key].float())
+            assert err < 1e-2, "grad %s: rel l2 error %.3e vs the float64 oracle" % (key, err)
+    finally:
+        lib.pv_conv_set_wide_weights(0)
+        IVAEEngine._wide_weights = False
+
+
+def test_class_onehot_rejected_where_undefined(gpu_device):
+    """ The sampled-class objective exists for the vanilla decoder only; a direct engine call with class_onehot
+    on a jiVAE WITH invariances (fused or layered path) is refused instead of silently running the enumerated objective."""
+    for fused in (0, 2):
+        model = pv.models.jiVAE((8, 8), 2, 3, ["r"], seed=1, device="cuda")
+        eng = model.engine(fused=fused)
+        x, eps = torch.rand(5, 8, 8).cuda(), torch.randn(5, model.z_dim).cuda()
+        y = torch.zeros(5, 3, device="cuda")
+        y[:, 0] = 1.0
+        with pytest.raises(_abi.PvError):
+            eng.loss_and_grads(x, eps, class_onehot=y)
+        eng.loss_and_grads(x, eps)                                       # the enumerated objective still runs
+
+
+def test_conv_stack_with_other_pooling_falls_back_to_torch(gpu_device):
+    """ A stand-alone conv stack whose pooling is not the reference's 2x / stride-2 window is NOT handed to the
+    library (which would assume 2x pooling): the torch modules run it; the reference's own geometry still takes the library."""
+    from pyroved_amd import ops
+    fe = pv.nets.FeatureExtractor(2, 1, [(16,), (32,)]).cuda()
+    x = torch.rand(3, 1, 16, 16, device="cuda")
+    assert ops.conv_stack_supported(fe, x)
+    want = fe(x)
+    pools = [i for i, m in enumerate(fe.layers) if isinstance(m, torch.nn.MaxPool2d)]
+    assert pools
+    fe.layers[pools[0]] = torch.nn.MaxPool2d(3, stride=2, padding=1)
+    assert not ops.conv_stack_supported(fe, x)
+    got = fe(x)                                                          # torch composition
+    assert got.shape[0] == 3 and torch.isfinite(got).all() and want.shape[0] == 3
+    assert not ops.conv_stack_supported(pv.nets.FeatureExtractor(2, 1, [(16,), (32,)]).cuda(), torch.rand(3, 2, 16, 16, device="cuda"))
+
+
 @pytest.fixture()
 def force_w8x3():
     lib = C.CDLL(_abi.LIB_PATH)

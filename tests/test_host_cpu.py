@@ -98,16 +98,23 @@ def _headline_plan(batch, fused):
 
 def test_workspace_by_purpose():
     """pv_ivae_workspace_bytes_for: the fused training step needs a small fraction of what a layered decode of the same
-    batch needs; PV_WS_ALL (= pv_ivae_workspace_bytes) covers all three."""
+    batch needs, the fused forward-only decode (round 3) a few KB per image; PV_WS_ALL (= pv_ivae_workspace_bytes) covers
+    all three."""
     lib = _abi.lib()
     for fused in (2, 3):
         p = _headline_plan(4096, fused)
         step, enc, dec = (lib.pv_ivae_workspace_bytes_for(C.byref(p), w) for w in (1, 2, 3))
         allb = lib.pv_ivae_workspace_bytes(C.byref(p))
         assert min(step, enc, dec) > 0 and allb == max(step, enc, dec) == lib.pv_ivae_workspace_bytes_for(C.byref(p), 0)
-        assert enc < 64 << 20 and step < dec // 4
+        assert enc < 64 << 20
         # step: ~0.1 MB per image (per-row outputs + per-sample partials), not the layered path's ~1.9 MB
         assert step < 4096 * 200_000
+        # decode on the fused kernel: hz + transform parameters + the weight images — no (B N) x 128 activations
+        assert dec < 4096 * 1024 + (1 << 20)
+        p.fused = 0
+        dec_layered = lib.pv_ivae_workspace_bytes_for(C.byref(p), 3)
+        assert step < dec_layered // 4 and dec < dec_layered // 100
+        p.fused = fused
     assert lib.pv_ivae_workspace_bytes_for(C.byref(p), 4) < 0
     p.fused = 0
     assert lib.pv_ivae_workspace_bytes_for(C.byref(p), 1) > 4096 * 1_000_000
