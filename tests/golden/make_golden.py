@@ -568,6 +568,15 @@ if __name__ == "__main__":
         _rs = globals()["_run_steps_real"]
         _rs("ivaeconv_64x64_rts_b4", (64, 64), ["r", "t", "s"], batch=4, steps=2,
             model_kw={"conv_encoder": [(32,), (64, 64), (128, 128)]})
+    if only is None or "midsize" in only:
+        # (round 3) mid-size pins between the toy fixtures and the BASELINE sizes — one SVI step each through the
+        # reference's own modules and trainer: C3's model at batch 64 (0.5 M decoder rows: several workgroup ranges per
+        # sample, K-fold slot arithmetic), C4's at batch 16, C5's at batch 16 (multi-round conv launches, split-K seams)
+        _rs = globals()["_run_steps_real"]
+        run_jsteps("jivae_28x28_r_k10_b64", (28, 28), ["r"], 10, batch=64, steps=1)
+        _rs("ivaeconv_64x64_rts_b16", (64, 64), ["r", "t", "s"], batch=16, steps=1,
+            model_kw={"conv_encoder": [(32,), (64, 64), (128, 128)]})
+        run_ved_steps("ved_64x64_to_128_b16", (64, 64), (128,), batch=16, steps=1)
     # constructor variants of models/ivae.py:122-163 and the likelihoods of utils/prob.py:25-29: every branch the
     # HIP-vs-oracle "variants" tests exercise gets a reference-generated pin
     if only is None or "variants" in only:

@@ -1218,6 +1218,25 @@ def _props(eng, call, n_samples, sl):
     return s_full.cpu().numpy()
 
 
+def _grads_vs_oracle(eng, ref_grads, tol_of, what, abs_bound=None):
+    """Every parameter tensor's gradient against the oracle's backward on the same inputs: relative L2 below tol_of(key)
+    (None: judged on the absolute scale abs_bound).  Returns the worst (error, key) for the assertion messages."""
+    worst = (0.0, None)
+    for key, gref in ref_grads.items():
+        if gref is None:
+            continue
+        g = eng.grad_of(key)
+        tol = tol_of(key)
+        if tol is None:
+            assert (g.cpu() - gref).abs().max().item() < abs_bound, "%s: %s" % (what, key)
+            continue
+        err = rel_l2(g, gref)
+        assert err < tol, "%s: grad %s rel l2 error %.3e (bar %.1e) vs the oracle's backward" % (what, key, err, tol)
+        if err / tol > worst[0]:
+            worst = (err / tol, key)
+    return worst
+
+
 @pytest.mark.parametrize("fused", [2, 3])
 def test_full_size_c3_jivae(gpu_device, fused):
     """BASELINE config 3 at its own size: jiVAE K=10, 28x28 ['r'], batch 512 -> 4.0 M decoder rows (unit partition,
@@ -1234,9 +1253,16 @@ def test_full_size_c3_jivae(gpu_device, fused):
     xg, eg = x.cuda(), eps.cuda()
     s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 5e-6)
     cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, discrete_dim=k_)
-    with torch.no_grad():
-        out = orc.jelbo({k: v.cpu() for k, v in model.state_dict().items()}, cfg, x, eps)
+    # (round 3) the oracle's BACKWARD at this size too (4.0 M decoder rows under autograd: ~12 GB, tens of seconds on 8
+    # threads): every gradient tensor, not only the scalars — a size-dependent but deterministic and additive gradient bug
+    # (split-K seams, slot arithmetic of the per-sample partial sums) would pass the properties above
+    o = orc.SVIOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg)
+    out = o.loss_and_grads(x, eps)
     np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
+    eng.loss_and_grads(xg, eg)
+    ref = {k: v.grad for k, v in o.p.items()}
+    tol = (lambda key: 3e-2) if fused == 3 else jivae_grad_tol
+    _grads_vs_oracle(eng, ref, tol, "C3 jiVAE K=10 B=512 fused=%d" % fused, abs_bound=1e-6 * b * 784 * (3e4 if fused == 3 else 1))
 
 
 @pytest.mark.parametrize("fused", [0, 2, 3])
@@ -1255,8 +1281,19 @@ def test_full_size_c4_conv_encoder(gpu_device, fused):
     xg, eg = x.cuda(), eps.cuda()
     s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 5e-6)
     cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, conv_encoder=hid)
-    with torch.no_grad():
-        out = orc.elbo({k: v.cpu() for k, v in model.state_dict().items()}, cfg, x, eps)
+    # (round 3) backward at size too.  At 0.5 M decoder rows / 0.5 M conv pixels per layer the fp32 CPU oracle is itself
+    # 1e-4 .. 2e-4 off float64 on the encoder tensors (sums of ~1e6 cancelling terms): the float64 oracle is the truth here,
+    # and a tensor's bar is 1e-4 or twice what the reference's own precision (the fp32 oracle) achieves, whichever is larger
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    o = orc.SVIOracle(sd, cfg)
+    out = o.loss_and_grads(x, eps)
+    o64 = orc.SVIOracle(sd, cfg, dtype=torch.float64)
+    o64.loss_and_grads(x, eps)
+    ref = {k: v.grad for k, v in o64.p.items()}
+    e32 = {k: rel_l2(o.p[k].grad, ref[k]) for k in ref}
+    eng.loss_and_grads(xg, eg)
+    tol = (lambda key: 3e-2) if fused == 3 else (lambda key: max(RTOL_GRAD, 2 * e32[key]))
+    _grads_vs_oracle(eng, {k: v.float() for k, v in ref.items()}, tol, "C4 conv-encoder iVAE 64x64 B=128 fused=%d" % fused)
     np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
     np.testing.assert_allclose(s[1], out["ll"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
     np.testing.assert_allclose(s[2], out["logpz"].item(), rtol=1e-4)
@@ -1279,10 +1316,20 @@ def test_full_size_c5_ved(gpu_device, prec):
     xg, yg, eg = x.cuda(), y.cuda(), eps.cuda()
     s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi], 1.0, yg[lo:hi]), b, 2e-5)
     cfg = orc.VedConfig(input_dim=(64, 64), output_dim=(128,), latent_dim=2)
-    with torch.no_grad():
-        out = orc.ved_elbo({k: v.cpu() for k, v in model.state_dict().items()}, cfg, x, y, eps)
-    np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if prec == "bf16" else RTOL_ELBO)
-
+    # (round 3) backward at size too, against the float64 oracle (see test_full_size_c4_conv_encoder)
+    gr = {}
+    for dt in (torch.float32, torch.float64):
+        p_ = {k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in model.state_dict().items()}
+        out = orc.ved_elbo(p_, cfg, x.to(dt), y.to(dt), eps.to(dt))
+        out["loss"].backward()
+        gr[dt] = {k: v.grad for k, v in p_.items()}
+        if dt == torch.float32:
+            np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if prec == "bf16" else RTOL_ELBO)
+    ref = gr[torch.float64]
+    e32 = {k: rel_l2(gr[torch.float32][k], ref[k]) for k in ref}
+    eng.loss_and_grads(xg, eg, 1.0, yg)
+    tol = (lambda key: 3e-2) if prec == "bf16" else (lambda key: max(RTOL_GRAD, 2 * e32[key]))
+    _grads_vs_oracle(eng, {k: v.float() for k, v in ref.items()}, tol, "C5 VED 64x64->128 B=256 %s" % prec)
 
 BF16_CASES = ["ivae_28x28_rt_b256", "ivae_28x28_r_b128", "ivae_28x28_r_b32_blobs", "ivae_8x8_rts_b6", "ivae_8x8_r_b6",
               "ivae_1d16_t_b5", "ivae_8x8_rts_b6_randn", "ivae_8x8_rt_b6_beta4"]
