@@ -23,6 +23,14 @@ The timed region is EXACTLY --steps steps bracketed by barrier + synchronize, ma
 --repeats times inside the invocation (default 5) and `ms_per_step` / `value` are the MEDIAN region (all regions in
 `ms_per_step_all`), so a 20-step run is not one 3 ms sample.
 
+Round 3: timed regions are repeated until two successive ones agree to 1 % (the box is still warming up for the first few:
+`regions_discarded` says how many were dropped, cap 40), THEN --repeats regions are measured; `roofline.kernel` is the name
+rocprofv3 prints for the kernel the library dispatches (asked from the library), `roofline.traffic` comes from the committed
+PMC pass of the same config (profiles/traffic.json); the conv-encoder / VED configs carry `roofline_conv` = the heaviest
+kernel-3 convolution launch, event-timed inside the step; the default N = 1 run adds `C4fc` (fc encoder), a `trainer` leg
+(SVItrainer.step over a CPU DataLoader: what a user of the reference API calls) and an `inference` leg (encode + decode);
+N > 1 runs report `allreduce_ms` and both scalings (`value` = weak, `strong` = the config's batch sharded).
+
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline     the dominant kernel (the fused decoder kernel) against the dense MFMA peak of the instruction it
                runs on, its duration measured with HIP events recorded on the launch stream inside the timed
@@ -62,19 +70,20 @@ CONFIGS = {
                desc="jiVAE discrete_dim=10 latent_dim=2 invariances=['r'] 28x28 bernoulli, exact enumeration"),
     "C4": dict(kind="ivae_conv", data_dim=(64, 64), inv=["r", "t", "s"], batch=128, flops_per_image=1.50e9, dec_passes=1,
                ring=4, desc="iVAE 64x64 invariances=['r','t','s'] + set_encoder(convEncoderNet default stack)"),
+    "C4fc": dict(kind="ivae", data_dim=(64, 64), inv=["r", "t", "s"], batch=128, flops_per_image=8.18e8, dec_passes=1, ring=4,
+                 desc="iVAE 64x64 invariances=['r','t','s'] latent_dim=2 bernoulli, fc encoder (SURVEY 8d: C4's other reading)"),
     "C5": dict(kind="ved", data_dim=(64, 64), out_dim=(128,), batch=256, flops_per_image=7.09e8, dec_passes=0, ring=2,
                desc="VED im2spec 64x64 image -> 128-point spectrum, default conv stacks"),
 }
-# HBM bytes per launch of the dominant kernel, from rocprofv3 PMC passes of earlier builds (FETCH_SIZE doubled per the
-# guide's gfx950 correction + WRITE_SIZE), C2 at batch 256.  NOT collected by this run: `traffic_source` says where from.
-TRAFFIC = {("C2", 2): (2 * 1331 * 1024 + 37943 * 1024, "profiles/r01j_pmc_fused_bf16_and_bf16x3.txt"),
-           ("C2", 3): (2 * 994 * 1024 + 37925 * 1024, "profiles/r01j_pmc_fused_bf16_and_bf16x3.txt")}
-_traffic_file = os.path.join(ROOT, "profiles", "traffic.json")     # refreshed by scripts/gpu_pmc.sh when it is run
+# HBM bytes per launch of a config's dominant kernel, from the committed rocprofv3 PMC passes (scripts/gpu_prof_r3.sh writes
+# profiles/traffic.json: FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, separate passes).  NOT collected by
+# this run: `traffic_source` says where from.  Keys "<config>:<mode>" (decoder kernel) and "<config>:<mode>:conv".
+TRAFFIC = {}
+_traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
 if os.path.exists(_traffic_file):
     try:
         for k_, v_ in json.load(open(_traffic_file)).items():
-            c_, f_ = k_.split(":")
-            TRAFFIC[(c_, int(f_))] = (int(v_["bytes"]), v_["source"])
+            TRAFFIC[k_] = (int(v_["bytes"]), v_["source"])
     except Exception:
         pass
 
@@ -203,6 +212,15 @@ def cpu_baseline(name, cfg, budget_s=12.0):
         el1 = time.perf_counter() - t1
         if el1 > 4.0 or n1 >= 20:
             break
+    # ... and every physical core (SURVEY 8d asked for this figure by name; on a 128-core host it is slower than 32 threads)
+    torch.set_num_threads(n_phys)
+    t2, n2 = time.perf_counter(), 0
+    while True:
+        one()
+        n2 += 1
+        el2 = time.perf_counter() - t2
+        if el2 > 3.0 or n2 >= 10:
+            break
     torch.set_num_threads(best_n)
     return dict(value=n * B / el, unit="images/s", cores=best_n, kind="port",
                 sample="%d SVI steps of batch %d (%.1f s) of the same %s workload (%s), eager torch CPU oracle "
@@ -211,13 +229,34 @@ def cpu_baseline(name, cfg, budget_s=12.0):
                 ms_per_step=1e3 * el / n, cpu_model=model_name, physical_cores=n_phys, logical_cpus=n_logical,
                 thread_probe_ms={str(k): 1e3 * v for k, v in probes.items()},
                 one_thread={"value": n1 * B / el1, "unit": "images/s", "cores": 1, "ms_per_step": 1e3 * el1 / n1,
-                            "sample": "%d steps (%.1f s)" % (n1, el1)}), loss0 / B
+                            "sample": "%d steps (%.1f s)" % (n1, el1)},
+                all_physical_cores={"value": n2 * B / el2, "unit": "images/s", "cores": n_phys, "ms_per_step": 1e3 * el2 / n2,
+                                    "sample": "%d steps (%.1f s)" % (n2, el2)}), loss0 / B
 
 
 # --------------------------------------------------------------------------------------------- the timed run
+MAX_REGIONS = 40                 # cap on warm-up regions + measured regions of one leg
+CONVERGED = 0.01                 # two successive regions within 1 %: the box has stopped warming up
+
+
+class TorchEvents:
+    """torch events on the current stream around the collective (N > 1), every EV_EVERY-th step."""
+    def __init__(self):
+        self.pairs = []
+
+    def pair(self):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.append((a, b))
+        return a, b
+
+    def elapsed_ms(self):
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
 def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B):
-    """warm-up + --repeats timed regions of --steps steps on one decoder path.
-    -> (list of region seconds (max over ranks), kernel ms samples, per-step losses (cpu), engine, model)"""
+    """warm-up, regions of --steps steps until two successive ones agree to 1 %, then --repeats measured regions, on one
+    decoder path.  -> dict(regions (max over ranks, seconds), discarded, kernel ms, conv-kernel ms + flops, all-reduce ms,
+    per-step losses (cpu), engine, model)"""
     model = make_model(pv, cfg, dev)
     eng = model.engine(fused=fused)
     if world > 1:
@@ -229,38 +268,50 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B):
     data = make_data(cfg, ring_n * world * B, gen)
     data = [t.view(ring_n, world, B, *t.shape[1:])[:, rank].contiguous().to(dev) for t in data]
     R = max(1, args.repeats)
-    total_steps = args.warmup + R * args.steps
+    n_eps = args.warmup + 2 * args.steps               # noise ring (the first warmup + steps draws are the seeded stream)
     torch.manual_seed(1)
-    eps_all = torch.empty(total_steps, world, B, model.z_dim).normal_()[:, rank].contiguous().to(dev)
+    eps_all = torch.empty(n_eps, world, B, model.z_dim).normal_()[:, rank].contiguous().to(dev)
     n_ev = (args.steps + EV_EVERY - 1) // EV_EVERY
-    events = HipEvents(n_ev * R)
-    hist = torch.zeros(total_steps, 4, device=dev)
+    events = HipEvents(n_ev)                            # re-recorded every region: the last measured region's samples are read
+    conv = cfg["kind"] in ("ved", "ivae_conv")
+    cevents = HipEvents(n_ev) if conv else None
+    cflops = C.c_double(0.0)
+    arev = TorchEvents()
+    hist = torch.zeros(n_eps, 4, device=dev)
     ved = cfg["kind"] == "ved"
     one_call = world == 1 and not args.two_call and getattr(eng, "supports_step", False)
 
-    def step(i, ev=None):
+    def step(i, ev=None, cev=None, ar=None):
         eng.events = ev if ev is not None else (None, None)
+        eng.conv_events = (cev[0], cev[1], cflops) if cev is not None else None
+        k = i % n_eps
         x = data[0][i % ring_n]
+        if ar is not None:
+            ar = arev.pair()
         if ved:
-            eng.loss_and_grads(x, eps_all[i], 1.0, data[1][i % ring_n], scalars_out=hist[i] if world == 1 else None)
+            eng.loss_and_grads(x, eps_all[k], 1.0, data[1][i % ring_n], scalars_out=hist[k] if world == 1 else None)
             if world > 1:
+                if ar: ar[0].record()
                 pvdist.allreduce_sum_(eng.grad)
-                hist[i].copy_(eng.scalars)
+                if ar: ar[1].record()
+                hist[k].copy_(eng.scalars)
             eng.adam_step()
         elif world > 1:
-            eng.loss_and_grads(x, eps_all[i])
+            eng.loss_and_grads(x, eps_all[k])
+            if ar: ar[0].record()
             pvdist.allreduce_sum_(eng.grad)           # gradients + the 4 loss scalars in one collective
+            if ar: ar[1].record()
             if hasattr(eng, "adam_step_hist"):
-                eng.adam_step_hist(hist[i])           # Adam + the history write in one launch
+                eng.adam_step_hist(hist[k])           # Adam + the history write in one launch; no host sync anywhere
             else:
-                hist[i].copy_(eng.scalars)
+                hist[k].copy_(eng.scalars)
                 eng.adam_step()
         elif one_call:
             # single process: SVI.step as ONE library call (pv_ivae_step: ELBO + gradients + Adam; bit-identical to
             # the two calls, tests/test_gpu_parity.py)
-            eng.loss_and_grads(x, eps_all[i], scalars_out=hist[i], step=True)
+            eng.loss_and_grads(x, eps_all[k], scalars_out=hist[k], step=True)
         else:
-            eng.loss_and_grads(x, eps_all[i], scalars_out=hist[i])
+            eng.loss_and_grads(x, eps_all[k], scalars_out=hist[k])
             eng.adam_step()
 
     # one untimed, state-free pass first (gradients only, no optimizer update, no collective on real data): module
@@ -273,89 +324,152 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B):
         pvdist.allreduce_sum_(torch.zeros_like(eng.grad))
     for i in range(args.warmup):
         step(i)
-    regions = []
-    for r in range(R):
-        base = args.warmup + r * args.steps
+    torch.cuda.synchronize()
+    losses_head = hist[:, 0].cpu().clone()             # (steps 0 .. warmup-1 of the seeded stream; later slots are reused)
+
+    def region(base):
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(base + i, events.pairs[r * n_ev + i // EV_EVERY] if i % EV_EVERY == 0 else None)
+            sample = i % EV_EVERY == 0
+            j = i // EV_EVERY
+            step(base + i, events.pairs[j] if sample else None, cevents.pairs[j] if (sample and conv) else None,
+                 True if (sample and world > 1) else None)
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         if world > 1:
             td.all_reduce(t, op=td.ReduceOp.MAX)
-        regions.append(t.item())
-    kms = events.elapsed_ms() if not ved else []
-    return regions, kms, hist[:, 0].cpu(), eng, model
+        return t.item()
+
+    all_regions, base = [], args.warmup
+    first = region(base)
+    losses_first = hist[:, 0].cpu().clone()            # slot `warmup` = the first timed step
+    all_regions.append(first)
+    base += args.steps
+    # warm-up regions: until two successive ones agree (decided on the max-over-ranks time, identical on every rank)
+    while len(all_regions) < MAX_REGIONS - R:
+        r = region(base)
+        base += args.steps
+        all_regions.append(r)
+        if abs(all_regions[-1] - all_regions[-2]) <= CONVERGED * all_regions[-1]:
+            break
+    discarded = len(all_regions) - 1                   # the last converged region is the first measured one
+    regions = [all_regions[-1]]
+    arev.pairs.clear()
+    for _ in range(R - 1):
+        regions.append(region(base))
+        base += args.steps
+    torch.cuda.synchronize()
+    return dict(regions=regions, discarded=discarded, all_regions=all_regions + regions[1:],
+                kms=events.elapsed_ms() if not ved else [], cms=cevents.elapsed_ms() if conv else [],
+                conv_flops=cflops.value, ar_ms=arev.elapsed_ms(), losses_head=losses_head, losses_first=losses_first,
+                last_loss=hist[(base - 1) % n_eps, 0].item(), eng=eng, model=model)
+
+
+def _kernel_name(fused, units, grads=1, lik=0):
+    """The name rocprofv3 prints for the decoder kernel the library dispatches (a debug export of the library)."""
+    from pyroved_amd import _abi
+    lib = C.CDLL(_abi.LIB_PATH)
+    lib.pv_debug_decoder_kernel_name.restype = C.c_char_p
+    lib.pv_debug_decoder_kernel_name.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
+    return lib.pv_debug_decoder_kernel_name(fused, units, grads, lik).decode()
 
 
 def _paths(cfg, mode, B, n_pix):
-    """(kernel name, flops per launch, peak TF, dtype label, arithmetic description) of the dominant kernel."""
-    dec_fl = DEC_FLOP_PER_PIXEL * n_pix * max(cfg["dec_passes"], 1) * B
+    """(kernel name, flops per launch, peak TF, dtype label, arithmetic description) of the dominant decoder kernel."""
+    passes = max(cfg["dec_passes"], 1)
+    dec_fl = DEC_FLOP_PER_PIXEL * n_pix * passes * B
+    units = B * n_pix * passes // 16
     if mode == 2:
-        return ("pv_sdec_fused_bf16_kernel (decoder fwd+bwd, all layers, bf16x3 split precision)", dec_fl,
-                MFMA_BF16_PEAK_TFLOPS, "bf16x3", "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)")
+        return (_kernel_name(2, units), dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16x3",
+                "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)")
     if mode == 3:
-        return ("pv_sdec_fused_bf16_kernel<X3=false> (decoder fwd+bwd, all layers, plain bf16 operands)", dec_fl,
-                MFMA_BF16_PEAK_TFLOPS, "bf16", "bf16 MFMA operands for the hidden-layer contractions (fp32 accumulate; fp32 elsewhere)")
+        return (_kernel_name(3, units), dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16",
+                "bf16 MFMA operands for the hidden-layer contractions (fp32 accumulate; fp32 elsewhere)")
     if mode == 1:
-        return ("pv_sdec_fused_kernel (decoder fwd+bwd, all layers, f32-input MFMA)", dec_fl, MFMA_F32_PEAK_TFLOPS,
-                "f32", "fp32 (f32-input MFMA)")
-    return ("pv_gemm_kernel<NT> (decoder hidden layer fwd, M=B*N, K=N=128)", 2.0 * B * n_pix * 128 * 128 * max(cfg["dec_passes"], 1),
+        return (_kernel_name(1, units), dec_fl, MFMA_F32_PEAK_TFLOPS, "f32", "fp32 (f32-input MFMA)")
+    return ("pv_gemm_kernel<NT> (decoder hidden layer fwd, M=B*N, K=N=128)", 2.0 * B * n_pix * 128 * 128 * passes,
             MFMA_F32_PEAK_TFLOPS, "f32", "fp32 (f32-input MFMA)")
+
+
+def _traffic(key, B, cfg):
+    tr = TRAFFIC.get(key) if B == cfg["batch"] else None
+    return (tr[0] if tr else None,
+            (tr[1] + " (committed rocprofv3 --pmc pass of this config, not collected by this run)") if tr else None)
 
 
 def measure(args, name, cfg, fused, ctx):
     """One decoder path of one config -> dict of numbers."""
     pv, pvdist, td, dev, rank, world, B = ctx
-    regions, kms, losses, eng, model = _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B)
+    r = _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B)
+    regions, eng = r["regions"], r["eng"]
     med = statistics.median(regions)
     n_pix = 1
     for d in cfg["data_dim"]:
         n_pix *= d
     ved = cfg["kind"] == "ved"
     out = {"regions_s": regions, "median_s": med, "ms_per_step": 1e3 * med / args.steps,
-           "ms_per_step_all": [1e3 * r / args.steps for r in regions],
+           "ms_per_step_all": [1e3 * v / args.steps for v in regions],
+           "regions_discarded": r["discarded"],
+           "ms_per_step_warming": [1e3 * v / args.steps for v in r["all_regions"][:r["discarded"]]],
            "value": args.steps * B * world / med,
-           "loss_per_image_step0": losses[0].item() / (B * world),
-           "loss_per_image_first_timed_step": losses[args.warmup].item() / (B * world),
-           "loss_per_image_last_step": losses[-1].item() / (B * world)}
+           "loss_per_image_step0": r["losses_head"][0].item() / (B * world) if args.warmup > 0 else r["losses_first"][0].item() / (B * world),
+           "loss_per_image_first_timed_step": r["losses_first"][args.warmup].item() / (B * world),
+           "loss_per_image_last_step": r["last_loss"] / (B * world)}
+    if world > 1 and r["ar_ms"]:
+        out["allreduce_ms"] = sum(r["ar_ms"]) / len(r["ar_ms"])
+        out["allreduce_ms_samples"] = len(r["ar_ms"])
     step_tf = out["value"] / world * cfg["flops_per_image"] / 1e12
+    out["step_algorithmic_tflops"] = step_tf
+    conv_roof = None
+    if r["cms"] and r["conv_flops"] > 0:
+        # the heaviest kernel-3 convolution launch of the encoder's forward (64 -> 64 channels at 32x32 in the default stack,
+        # max-pool in its epilogue), event-timed inside the step: split operands, three matrix instructions per multiply-add
+        c_avg = sum(r["cms"]) / len(r["cms"])
+        c_tf = r["conv_flops"] / (c_avg * 1e-3) / 1e12
+        bf = fused == 3
+        tb, ts = _traffic("%s:%d:conv" % (name, fused), B, cfg)
+        conv_roof = {"bound": "mfma", "achieved": c_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": c_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": tb, "traffic_source": ts,
+                     "kernel": "void pv_conv3_sp_kernel<2, 4, %s>(ConvSp)" % ("false" if bf else "true"),
+                     "what": "heaviest kernel-3 convolution of the encoder forward (most multiply-adds), with its max-pool "
+                             "epilogue; operands split in two %s pieces, 3 products per multiply-add"
+                             % ("rounded bf16" if bf else "fp16 (exact power-of-two scaling)"),
+                     "kernel_ms": c_avg, "kernel_ms_samples": len(r["cms"]), "flops_per_launch": r["conv_flops"],
+                     "mfma_products_per_mac": 3, "frac_of_split_operand_peak": 3 * c_tf / MFMA_BF16_PEAK_TFLOPS}
     if ved:
         # both precisions run the 2-D k3 convolutions on the 16x16x32 matrix-core instructions with split operands
         # (pv_conv_sp.hip), three products per multiply-add: fp32-class = two fp16 pieces with exact power-of-two scaling per
         # staged tile (~2^-22 per product), mixed = two rounded bf16 pieces (~2^-17)
         bf = fused == 3
-        prods = 3
-        peak = MFMA_BF16_PEAK_TFLOPS                    # (the f16 16x16x32 MFMA has the same dense peak)
         out.update(dtype="bf16x3" if bf else "f16x3", path="conv-bf16x3" if bf else "conv-f16x3",
                    arith=("2-D k3 convolutions on the bf16 MFMA, operands split into two rounded bf16 pieces, three products "
                           "(fp32 accumulate); fp32 elsewhere" if bf else
                           "2-D k3 convolutions on the f16 MFMA, operands split into two fp16 pieces with exact power-of-two scaling "
                           "per staged tile, three products (fp32 accumulate): fp32-class (3e-7 relative l2 vs float64); 1-D "
-                          "convolutions on the f32-input MFMA; fp32 elsewhere"),
-                   roofline={"bound": "mfma", "scope": "step", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s",
-                             "frac": step_tf / peak, "traffic": None, "mfma_products_per_mac": prods,
-                             "frac_of_split_operand_peak": step_tf * prods / peak,
-                             "kernel": "whole step (pv_conv3_sp_kernel / pv_conv3_sp_wgrad_kernel dominate; see profiles/)",
-                             "kernel_ms": out["ms_per_step"], "flops_per_launch": cfg["flops_per_image"] * B})
+                          "convolutions on the f32-input MFMA; fp32 elsewhere"))
+        out["roofline"] = conv_roof if conv_roof else {"bound": "mfma", "achieved": 0.0, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                       "unit": "TFLOP/s", "frac": 0.0, "traffic": None, "kernel": "n/a"}
+        out["roofline_step"] = {"bound": "mfma", "scope": "step", "achieved": step_tf, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": step_tf / MFMA_BF16_PEAK_TFLOPS,
+                                "flops_per_step": cfg["flops_per_image"] * B}
         return out
     mode = fused if eng.uses_fused(B) else 0
     kname, fl, peak, dtype, arith = _paths(cfg, mode, B, n_pix)
+    kms = r["kms"]
     k_avg = sum(kms) / max(len(kms), 1)
     achieved = fl / (k_avg * 1e-3) / 1e12 if k_avg > 0 else 0.0
-    tr = TRAFFIC.get((name, mode)) if B == cfg["batch"] else None
+    tb, ts = _traffic("%s:%d" % (name, mode), B, cfg)
     out.update(dtype=dtype, arith=arith, path={0: "layered", 1: "fused-f32", 2: "fused-bf16x3", 3: "fused-bf16"}[mode],
                roofline={"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": tr[0] if tr else None,
-                         "traffic_source": (tr[1] + " (earlier rocprofv3 --pmc run, not collected by this run)") if tr else None,
-                         "kernel": kname, "kernel_ms": k_avg, "kernel_ms_samples": len(kms), "flops_per_launch": fl},
-               step_algorithmic_tflops=step_tf)
+                         "traffic": tb, "traffic_source": ts,
+                         "kernel": kname, "kernel_ms": k_avg, "kernel_ms_samples": len(kms), "flops_per_launch": fl})
+    if conv_roof:
+        out["roofline_conv"] = conv_roof
     return out
 
 
@@ -364,18 +478,79 @@ def sub_config(name, args):
     cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(args.sub_steps), "--warmup", "10",
            "--repeats", "3", "--no-cpu-baseline", "--no-configs"]
     try:
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         rec = {"config": name, "workload": d["config"]["workload"], "n_gpus": 1, "dtype": d["dtype"],
-               "ms_per_step": d["ms_per_step"], "ms_per_step_all": d["ms_per_step_all"], "value": d["value"],
+               "ms_per_step": d["ms_per_step"], "ms_per_step_all": d["ms_per_step_all"],
+               "regions_discarded": d.get("regions_discarded"), "value": d["value"],
                "unit": d["unit"], "roofline": d["roofline"], "step_algorithmic_tflops": d.get("step_algorithmic_tflops"),
                "loss_per_image_step0": d["elbo"]["loss_per_image_step0"]}
-        if "fp32_class" in d:
-            rec["fp32_class"] = d["fp32_class"]
+        for k in ("roofline_conv", "roofline_step", "fp32_class"):
+            if k in d:
+                rec[k] = d[k]
         return rec
     except Exception as e:       # a failed side measurement must not take the headline line down
         return {"config": name, "error": repr(e)[:300]}
+
+
+def trainer_leg(pv, dev):
+    """What a user of the reference API calls: SVItrainer.step(train_loader) with a CPU DataLoader handed over
+    (trainers/svi.py:139-162), images/s INCLUDING the feed — 61 440 images of the headline model, batch 256, one warm-up
+    epoch (uploads the dataset, builds the engine), then 3 timed epochs; both precisions."""
+    n, B, epochs = 61440, 256, 3
+    x = torch.rand(n, 28, 28, generator=torch.Generator().manual_seed(0))
+    out = {"images": n, "batch": B, "epochs": epochs, "unit": "images/s",
+           "what": "SVItrainer.step(init_dataloader(x, batch_size=256)) on iVAE 28x28 ['r','t']: shuffling DataLoader's order "
+                   "and the CPU generator's noise stream reproduced, dataset resident on the device after the first epoch"}
+    for precision in ("bf16", "fp32"):
+        model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device=dev)
+        loader = pv.utils.init_dataloader(x, batch_size=B)
+        tr = pv.trainers.SVItrainer(model, seed=1, precision=precision)
+        tr.step(loader)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            tr.step(loader)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[precision] = {"value": n * epochs / dt, "ms_per_step": 1e3 * dt / (epochs * (n // B)),
+                          "loss_per_image_last_epoch": tr.loss_history["training_loss"][-1]}
+        del tr, model
+    return out
+
+
+def inference_leg(pv, dev):
+    """encode() and decode() of the headline model through the reference API (models/base.py:121-171): 65 536 samples in
+    loader batches of 4096, results on the CPU as the API returns them (one device -> host copy per call), and the kernels'
+    own rate (inputs and outputs on the device).  decode runs the fused decoder kernel forward-only at fp32-class
+    precision (split-precision MFMA); encode the fc encoder's GEMM kernels."""
+    n, bs = 65536, 4096
+    model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device=dev)
+    x = torch.rand(n, 28, 28, generator=torch.Generator().manual_seed(0))
+    z = torch.randn(n, 2, generator=torch.Generator().manual_seed(1))
+    model.encode(x[:bs], batch_size=bs); model.decode(z[:bs], batch_size=bs)           # warm-up
+    out = {"samples": n, "batch_size": bs, "unit": "images/s"}
+    for what, fn in (("encode_api", lambda: model.encode(x, batch_size=bs)), ("decode_api", lambda: model.decode(z, batch_size=bs))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        out[what] = n / (time.perf_counter() - t0)
+    eng = model.engine()
+    xg, zg = x[:32768].to(dev), z[:32768].to(dev)
+    for what, fn in (("encode_device", lambda: eng.encode(xg)), ("decode_device", lambda: eng.decode(zg))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        out[what] = 5 * 32768 / (time.perf_counter() - t0)
+    from pyroved_amd import _abi
+    out["decode_workspace_bytes_b32768"] = int(_abi.lib().pv_ivae_workspace_bytes_for(C.byref(eng._plan(32768, what=3)), 3))
+    out["decode_kernel"] = _kernel_name(2, 32768 * 784 // 16, grads=0)
+    return out
 
 
 def main():
@@ -385,6 +560,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-legs", action="store_true", help="skip the trainer / inference legs of the default N=1 run")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's batch is the GLOBAL batch, sharded")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "3")),
                     help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3 (fp32-class), 3 fused plain bf16")
@@ -433,6 +609,11 @@ def main():
     alt = None
     if args.fused == 3 and not args.no_alt:
         alt = measure(args, name, cfg, 2, ctx)      # the same workload on the fp32-class path
+    strong = None
+    if world > 1 and not args.strong and b_cfg % world == 0 and not args.no_alt:
+        # N > 1: the other scaling too — the config's batch as the GLOBAL batch, sharded (at batch 256 / 28x28 this is
+        # latency-bound by design: 32 images per GPU at N = 8; DESIGN.md section 6 has the expected curve)
+        strong = measure(args, name, cfg, args.fused, (pv, pvdist, td, dev, rank, world, b_cfg // world))
     if rank == 0:
         out = {
             "metric": "images/sec (SVI step)", "value": main_leg["value"], "unit": "images/s", "n_gpus": world,
@@ -443,28 +624,59 @@ def main():
                                    % (name, cfg["desc"], B, B * world, main_leg["arith"], "allreduce+" if world > 1 else ""),
                        "parallelism": "dp%d" % world, "path": main_leg["path"], "baseline_config": name},
             "repeats": len(main_leg["regions_s"]), "ms_per_step_all": main_leg["ms_per_step_all"],
+            "regions_discarded": main_leg["regions_discarded"], "ms_per_step_warming": main_leg["ms_per_step_warming"],
             "ms_per_step_spread": (max(main_leg["ms_per_step_all"]) - min(main_leg["ms_per_step_all"])),
             "roofline": main_leg["roofline"],
             "step_algorithmic_tflops": main_leg.get("step_algorithmic_tflops"),
             "elbo": {k: main_leg[k] for k in ("loss_per_image_first_timed_step", "loss_per_image_last_step",
                                               "loss_per_image_step0")},
         }
+        for k in ("roofline_conv", "roofline_step", "allreduce_ms", "allreduce_ms_samples"):
+            if k in main_leg:
+                out[k] = main_leg[k]
         if alt is not None:
             out["fp32_class"] = {"path": alt["path"], "dtype": alt["dtype"], "value": alt["value"], "unit": "images/s",
                                  "ms_per_step": alt["ms_per_step"], "ms_per_step_all": alt["ms_per_step_all"],
-                                 "kernel_ms": alt["roofline"]["kernel_ms"], "roofline_frac": alt["roofline"]["frac"],
+                                 "regions_discarded": alt["regions_discarded"],
+                                 "kernel": alt["roofline"].get("kernel"),
+                                 "kernel_ms": alt["roofline"].get("kernel_ms"), "roofline_frac": alt["roofline"]["frac"],
+                                 "roofline_traffic": alt["roofline"].get("traffic"),
                                  "loss_per_image_step0": alt["loss_per_image_step0"]}
+            if "roofline_conv" in alt:
+                out["fp32_class"]["roofline_conv"] = alt["roofline_conv"]
+            if "allreduce_ms" in alt:
+                out["fp32_class"]["allreduce_ms"] = alt["allreduce_ms"]
+        if strong is not None:
+            out["strong"] = {"scaling": "strong", "global_batch": b_cfg, "batch_per_gpu": b_cfg // world,
+                             "value": strong["value"], "unit": "images/s", "ms_per_step": strong["ms_per_step"],
+                             "ms_per_step_all": strong["ms_per_step_all"], "allreduce_ms": strong.get("allreduce_ms"),
+                             "kernel_ms": strong["roofline"].get("kernel_ms"),
+                             "note": "latency-bound by design at this size (launch chain + one all-reduce per step vs a few "
+                                     "microseconds of decoder work per GPU): weak scaling is the curve that can reach the "
+                                     ">= 6x target"}
         if world == 1 and not args.no_cpu_baseline:
             cb, loss0 = cpu_baseline(name, cfg)
             out["cpu_baseline"] = cb
             out["elbo"]["oracle_loss_per_image_step0"] = loss0
             if B == cfg["batch"]:
                 out["elbo"]["rel_err_step0"] = abs(out["elbo"]["loss_per_image_step0"] - loss0) / abs(loss0)
-        if world == 1 and name == "C2" and not args.no_configs and not args.strong and args.batch is None:
-            # release this process's device memory first, then one short process per side config
+        default_run = world == 1 and name == "C2" and not args.strong and args.batch is None
+        if default_run and not args.no_legs:
             del main_leg, alt
             torch.cuda.empty_cache()
-            out["configs"] = [sub_config(c, args) for c in ("C1", "C3", "C4", "C5")]
+            try:
+                out["trainer"] = trainer_leg(pv, dev)
+            except Exception as e:
+                out["trainer"] = {"error": repr(e)[:300]}
+            try:
+                out["inference"] = inference_leg(pv, dev)
+            except Exception as e:
+                out["inference"] = {"error": repr(e)[:300]}
+        if default_run and not args.no_configs:
+            # release this process's device memory first, then one short process per side config
+            main_leg = alt = None
+            torch.cuda.empty_cache()
+            out["configs"] = [sub_config(c, args) for c in ("C1", "C3", "C4", "C4fc", "C5")]
         print(json.dumps(out))
     if world > 1:
         td.destroy_process_group()

@@ -198,6 +198,13 @@ typedef struct pv_ivae_plan {
    *   cannot broadcast its K-times repeated z against the drawn class (models/jivae.py:181-189) — PV_EINVAL.
    *   The caller draws y from `alpha` of pv_ivae_encode on the same x (the guide's order: eps first, then y). ---- */
   const float* class_onehot;
+  /* ---- measurement (v12): hipEvent_t pair recorded on `stream` around the HEAVIEST kernel-3 convolution launch of the
+   *   convolutional encoder's forward (most multiply-adds; NULL: no recording), and — out — that launch's algorithmic
+   *   FLOPs 2 B H W Cin Cout 9 written to *conv_ev_flops when it is not NULL (host memory, written before the call returns).
+   *   bench.py's roofline for the conv-encoder config; nothing in the reference corresponds. ---- */
+  void*   conv_ev_start;
+  void*   conv_ev_stop;
+  double* conv_ev_flops;
 } pv_ivae_plan;
 
 /* Library / ABI version (PV_ABI_VERSION). */
@@ -346,6 +353,9 @@ typedef struct pv_ved_plan {
   float*       z_loc;     /* out (B, z_dim), may be NULL                                                */
   float*       z_scale;
   float*       loc;       /* out (B, out_ch, *out_dim) decoder output, may be NULL                      */
+  void*        conv_ev_start;  /* (v12) measurement: as in pv_ivae_plan, for the encoder stack's heaviest k3 convolution */
+  void*        conv_ev_stop;
+  double*      conv_ev_flops;
 } pv_ved_plan;
 
 /* Workspace bytes for pv_ved_* calls with this plan; < 0: unsupported plan. */

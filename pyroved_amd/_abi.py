@@ -69,6 +69,7 @@ class pv_ivae_plan(C.Structure):
         ("adam_step", C.c_int32), ("_pad2", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
         ("class_onehot", C.c_void_p),
+        ("conv_ev_start", C.c_void_p), ("conv_ev_stop", C.c_void_p), ("conv_ev_flops", C.c_void_p),
     ]
 
 
@@ -88,6 +89,7 @@ class pv_ved_plan(C.Structure):
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scalars", C.c_void_p), ("z_loc", C.c_void_p), ("z_scale", C.c_void_p), ("loc", C.c_void_p),
+        ("conv_ev_start", C.c_void_p), ("conv_ev_stop", C.c_void_p), ("conv_ev_flops", C.c_void_p),
     ]
 
 

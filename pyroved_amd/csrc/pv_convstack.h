@@ -127,7 +127,22 @@ struct Scratch {
   unsigned char* code = nullptr;                             // winners of the fused first block's max-pool (stack 0 only)
   PvFinishList* fin = nullptr;                               // weight-gradient finishes deferred to pv_wgrad_finish_all
   unsigned char* code2 = nullptr;                            // winners of the convolution + max-pool pairs fused further up (stack 0)
+  void* ev_start = nullptr; void* ev_stop = nullptr;         // measurement: events around op `ev_op` of stack 0's forward
+  int ev_op = -1;
 };
+// the stack's heaviest split-operand kernel-3 convolution (most multiply-adds) and its algorithmic FLOPs; -1: none
+inline int heaviest_conv(const pv_op* ops, int n, int nd, int B, const Shape* sh, double* flops) {
+  int best = -1;
+  double bf = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const pv_op& o = ops[i];
+    if (o.kind != PV_OP_CONV || o.ksize != 3 || !pv_conv3_sp_supported(o.cin, o.cout, nd, o.act)) continue;
+    const double fl = 2.0 * B * sh[i].H * sh[i].W * (double)o.cin * o.cout * kk_of(o, nd);
+    if (fl > bf) { bf = fl; best = i; }
+  }
+  if (flops) *flops = bf;
+  return best;
+}
 inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
   if (!sc.wt || !sc.wtp || sc.wtp->off[2 * slot + flip] < 0) return nullptr;
   return sc.wt + sc.wtp->off[2 * slot + flip];
@@ -336,6 +351,12 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
     i0 = 2;
   }
   for (int i = i0; i < n; ++i) {
+    const bool timed = stack_id == 0 && i == sc.ev_op && sc.ev_start && sc.ev_stop;
+    struct EvGuard {                     // start event now, stop event when the op's launches are enqueued
+      bool on; void* stop; hipStream_t s;
+      ~EvGuard() { if (on) (void)hipEventRecord((hipEvent_t)stop, s); }
+    } evg{timed, sc.ev_stop, s};
+    if (timed) (void)hipEventRecord((hipEvent_t)sc.ev_start, s);
     if (stack_id == 0 && sc.code2 && convpool_fusable(ops, n, nd, i, sh[i])) {      // a[i + 1] is never written
       const pv_op& o = ops[i];
       PV_TRY(pv_conv3_sp(a[i], B, sh[i].H, sh[i].W, params + o.w_off, o.cout, o.cin, 0, o.b_off >= 0 ? params + o.b_off : nullptr,

@@ -329,6 +329,12 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
   sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // (both orientations: the backward of the same step reuses them)
   sc.code = L.ccode; sc.code2 = L.ccode2;
+  if (p->conv_ev_start && p->conv_ev_stop) {
+    double fl = 0.0;
+    sc.ev_op = pvcs::heaviest_conv(p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)p->batch, L.ces, &fl);
+    sc.ev_start = p->conv_ev_start; sc.ev_stop = p->conv_ev_stop;
+    if (p->conv_ev_flops) *p->conv_ev_flops = fl;
+  }
   const pvcs::Shape& fe0 = L.ces[p->n_enc_ops];
   const bool hfused = pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.chead_wt, p->head.out_dim, fe0.C, (int64_t)fe0.H * fe0.W);

@@ -140,7 +140,14 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
   const float* x = p->x;
   if (p->in_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->x, L.x_nsc, B, p->in_ch, (int64_t)s0.H * s0.W, s)); x = L.x_nsc; }
   L.ea[0] = const_cast<float*>(x);
+  if (p->conv_ev_start && p->conv_ev_stop) {          // measurement: events around the heaviest kernel-3 convolution
+    double fl = 0.0;
+    L.sc.ev_op = pvcs::heaviest_conv(p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.es, &fl);
+    L.sc.ev_start = p->conv_ev_start; L.sc.ev_stop = p->conv_ev_stop;
+    if (p->conv_ev_flops) *p->conv_ev_flops = fl;
+  }
   PV_TRY(pvcs::stack_fwd(p->params, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, L.sc, s));
+  L.sc.ev_op = -1;
   const Shape& fe = L.es[p->n_enc_ops];
   // torch flattens (C, spatial): features2latent sees channels-first order — the weight is re-indexed, not the features
   if (L.head_wt) {

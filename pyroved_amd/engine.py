@@ -389,6 +389,8 @@ class IVAEEngine:
         p.ext_z = p.ext_dz = p.ext_ll = None
         p.class_onehot = None
         p.ev_start, p.ev_stop = self.events
+        ce = getattr(self, "conv_events", None)          # (start, stop, ctypes double for the launch's FLOPs) or None
+        p.conv_ev_start, p.conv_ev_stop, p.conv_ev_flops = (ce[0], ce[1], C.addressof(ce[2])) if ce else (None, None, None)
         need = _abi.lib().pv_ivae_workspace_bytes_for(C.byref(p), what)
         if need < 0:
             raise _abi.PvError("pyroved_amd: unsupported plan (pv_ivae_workspace_bytes_for -> %d)" % need)

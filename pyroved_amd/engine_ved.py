@@ -90,6 +90,8 @@ class VEDEngine(IVAEEngine):
         p.bn_eval = int(not self.model.training)
         p.conv_bf16 = int(self.fused == 3)           # SVItrainer(precision="bf16")
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
+        ce = getattr(self, "conv_events", None)          # (start, stop, ctypes double for the launch's FLOPs) or None
+        p.conv_ev_start, p.conv_ev_stop, p.conv_ev_flops = (ce[0], ce[1], C.addressof(ce[2])) if ce else (None, None, None)
         need = _abi.lib().pv_ved_workspace_bytes(C.byref(p))
         if need < 0:
             raise _abi.PvError("pyroved_amd: unsupported VED plan (pv_ved_workspace_bytes -> %d)" % need)
