@@ -58,7 +58,7 @@ PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3);
 int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s);
 int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
 // the 8-wave split-precision kernel (pv_sdec_fused_w8x3.hip; images pre-scaled by 2 log2(e) like the plain 8-wave kernel's)
-int pv_sdec_fused_w8x3_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
+int pv_sdec_fused_w8x3_launch(const PvFused& f, int grid, bool grads, hipStream_t s, int waves);   // waves: 8 or 4
 int64_t pv_sdec_fused_w8x3_park_bytes(int grid);
 // bytes of PvFused::park the launch of (x3, units) needs (0: the kernel that will run has no parking slots)
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid);

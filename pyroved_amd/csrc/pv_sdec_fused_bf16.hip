@@ -846,30 +846,42 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_trace), n * sizeof(long long));
 }
 
-// the plain-bf16 path runs the 8-wave kernel (pv_sdec_fused_w8.hip) when a workgroup gets at least ~6 of the 8 units a
-// tile takes (batch >= ~32 at 28x28; below that most of a 128-row tile would idle and the 4-wave / 64-row kernel here
-// is faster: 26 vs 30 us at batch 16); the split-precision path likewise runs pv_sdec_fused_w8x3.hip (round 3).
-// PV_W8=0 / 1 and PV_W8X3=0 / 1 in the environment force one of them (A/B runs).
-static int fb_w8_mode[2] = {-1, -1};   // [plain, x3]  -1: not read yet; 0 / 1: forced; 2: by problem size
-// test / A-B hooks: 0 or 1 forces the 4-wave or the 8-wave kernel, 2 restores the choice by size
+// Kernel choice.  Plain bf16 (fused = 3): the 8-wave kernel (pv_sdec_fused_w8.hip) when a workgroup gets at least ~6 of the
+// 8 units a tile takes (batch >= ~32 at 28x28; below that most of a 128-row tile would idle and the 4-wave / 64-row kernel
+// here is faster: 26 vs 30 us at batch 16).  Split precision (fused = 2): training launches run this file's 4-wave kernel;
+// forward-only launches of enough units (decode, evaluate) the 8-wave build of pv_sdec_fused_w8x3.hip (round 3: 6.3 vs 5.0 M
+// decoded images/s).  That source's training builds — 8 waves: 245 us, 4 waves: 188 us at batch 256, against 190 us here —
+// stay selectable for A/B runs and are parity-tested (tests/test_gpu_parity.py: force_w8x3).
+// Environment (A/B runs): PV_W8=0 / 1 forces the plain kernel; PV_X3_KERNEL=old | 4 | 8 the split-precision one.
+static int fb_w8_mode[2] = {-1, -1};   // [plain, x3]  -1: not read yet; 2: by problem size; plain: 0 / 1 forced; x3: 0 old, 4, 8
+// test / A-B hooks
 extern "C" void pv_debug_force_w8(int mode) { fb_w8_mode[0] = mode; }
-extern "C" void pv_debug_force_w8x3(int mode) { fb_w8_mode[1] = mode; }
-static bool fb_use_w8(int64_t units, bool x3 = false, bool grads = true) {
-  int& v = fb_w8_mode[x3 ? 1 : 0];
-  // The 8-wave split-precision kernel: its TRAINING form measured slower than the 4-wave one (271 vs 188 us at batch 256,
-  // r03: same instruction count per wave, issue costs of the two waves of a SIMD add, plus its spills and 12 barriers per
-  // tile) and is opt-in (PV_W8X3=1 or the test hook); its FORWARD-ONLY form (decode, evaluate: 136 registers, no overlay,
-  // no barriers in the tile loop) is the faster one — 6.3 vs 5.0 M decoded images/s — and is chosen by size like the
-  // plain-bf16 kernel.
-  if (v < 0) { const char* e = getenv(x3 ? "PV_W8X3" : "PV_W8"); v = e ? (atoi(e) == 0 ? 0 : 1) : 2; }
-  const int64_t row_cap = (int64_t)1 << 30;                  // (the 8-wave kernels address rows by 32-bit BYTE offsets)
-  if (v != 2) return v != 0 && units * FD_UNIT < row_cap;
-  if (x3 && grads) return false;
-  return units >= 6 * (int64_t)pv_sdec_fused_grid(units) && units * FD_UNIT < row_cap;
+extern "C" void pv_debug_force_w8x3(int mode) { fb_w8_mode[1] = mode == 1 ? 8 : mode; }   // 1: the 8-wave form (round-3 tests), 4, 0 old, 2 default
+static const int64_t fb_row_cap = (int64_t)1 << 30;          // (the pv_sdec_fused_w8*.hip kernels address rows by 32-bit BYTE offsets)
+static bool fb_use_w8(int64_t units) {
+  int& v = fb_w8_mode[0];
+  if (v < 0) { const char* e = getenv("PV_W8"); v = e ? (atoi(e) == 0 ? 0 : 1) : 2; }
+  if (v != 2) return v != 0 && units * FD_UNIT < fb_row_cap;
+  return units >= 6 * (int64_t)pv_sdec_fused_grid(units) && units * FD_UNIT < fb_row_cap;
 }
-int pv_sdec_fused_bf16_waves(bool x3, int64_t units) { return fb_use_w8(units, x3, true) ? 8 : FB_WAVES; }
+// split precision: 0 = this file's 4-wave kernel, 4 / 8 = pv_sdec_fused_w8x3.hip with that many waves
+static int fb_x3_kind(int64_t units, bool grads) {
+  int& v = fb_w8_mode[1];
+  if (v < 0) {
+    const char* e = getenv("PV_X3_KERNEL");
+    v = !e ? 2 : (e[0] == 'o' ? 0 : (atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : 2)));
+  }
+  if (units * FD_UNIT >= fb_row_cap) return 0;
+  if (v != 2) return v;
+  // training: this file's kernel.  The new source's 4-wave build measures the same (187.9 vs 189.7 us at batch 256 with every
+  // offload and the epilogues folded into the consuming k-loops: profiles/r03_decoder_schedule_experiments.txt) — not worth a
+  // switch of the two-rounds-tested default; its 8-wave build is slower (245 us).  Forward-only: the 8-wave build by size.
+  if (grads) return 0;
+  return units >= 6 * (int64_t)pv_sdec_fused_grid(units) ? 8 : 0;
+}
+int pv_sdec_fused_bf16_waves(bool x3, int64_t units) { return (x3 ? fb_x3_kind(units, true) == 8 : fb_use_w8(units)) ? 8 : FB_WAVES; }
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid) {
-  return (x3 && fb_use_w8(units, true, true)) ? pv_sdec_fused_w8x3_park_bytes(grid) : 0;
+  return (x3 && fb_x3_kind(units, true) == 8) ? pv_sdec_fused_w8x3_park_bytes(grid) : 0;
 }
 
 // measurement hook (not in include/): the kernel a decoder launch of (fused mode, units, grads, likelihood) dispatches, spelled
@@ -879,8 +891,8 @@ extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, in
   static thread_local char buf[128];
   const char* g = grads ? "true" : "false";
   if (fused == 1) snprintf(buf, sizeof buf, "void pv_sdec_fused_kernel<%s>(PvFused)", g);
-  else if (fused == 2 && fb_use_w8(units, true, grads != 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d>(PvFused)", g, lik);
-  else if (fused == 3 && fb_use_w8(units, false, grads != 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d>(PvFused)", g, lik);
+  else if (fused == 2 && fb_x3_kind(units, grads != 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d, %d>(PvFused)", g, lik, fb_x3_kind(units, grads != 0));
+  else if (fused == 3 && fb_use_w8(units)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d>(PvFused)", g, lik);
   else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %s>(PvFused)", g, lik, fused == 2 ? "true" : "false");
   else snprintf(buf, sizeof buf, "pv_gemm_kernel (layer-by-layer path)");
   return buf;
@@ -891,7 +903,7 @@ PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   PvFbPrep p{};
   p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz;
   p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
-  p.scale = fb_use_w8(f.units, x3, grads) ? 2.8853900817779268f : 0.0f;
+  p.scale = (x3 ? fb_x3_kind(f.units, grads) != 0 : fb_use_w8(f.units)) ? 2.8853900817779268f : 0.0f;
   return p;
 }
 
@@ -907,7 +919,12 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
 }
 
 int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s) {
-  if (fb_use_w8(f_in.units, x3, grads)) return x3 ? pv_sdec_fused_w8x3_launch(f_in, grid, grads, s) : pv_sdec_fused_w8_launch(f_in, grid, grads, s);
+  if (x3) {
+    const int kind = fb_x3_kind(f_in.units, grads);
+    if (kind) return pv_sdec_fused_w8x3_launch(f_in, grid, grads, s, kind);
+  } else if (fb_use_w8(f_in.units)) {
+    return pv_sdec_fused_w8_launch(f_in, grid, grads, s);
+  }
   PvFused f = f_in;
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }

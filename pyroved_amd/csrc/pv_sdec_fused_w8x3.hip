@@ -20,6 +20,14 @@
 //     8-instruction transfers per tile — and takes them back under the dgrad of layer 1.
 //   * saved activations are hi + lo, so 1 - h^2 is formed at fp32 precision; the column sums contract hi and lo pieces
 //     (t_hi x [1 | x0h | x1h | dlh | dll | x0l | x1l] + t_lo x [1 | x0h | x1h | dlh]).
+// NW (waves per workgroup) is a template parameter (round 3, second step):
+//   NW = 8: the form described above.  Its forward-only launches (decode, evaluate) are the fastest (136 registers, two
+//           waves per SIMD hide every latency); its training launches lose to the register limit (256: spills, parking,
+//           dgrad in halves) and to 12 barriers per tile — 271 us at batch 256 against the old 4-wave kernel's 188.
+//   NW = 4: the same source with one wave per SIMD and the 512-register budget: a tile is 64 rows = ONE staged exchange
+//           per layer (5 barriers per tile), a wave owns a 64 x 64 block of dW1 / dW2, h0 stays in registers, nothing
+//           spills.  This is the training kernel of the fp32-class path: every VALU->MFMA move of the plain-bf16 8-wave
+//           kernel (coordinate layer, column sums, row-local input gradient, multiply-free tanh) without its register bill.
 // Layout, row -> lane mapping, weight images, staging swizzles and the per-workgroup gradient record are those of
 // pv_sdec_fused_bf16.hip / pv_sdec_fused_w8.hip (pv_fb_layout.h), so the rest of the step is unchanged.
 #include "pv_sdec_fused.h"
@@ -31,7 +39,7 @@ typedef short short8_ __attribute__((ext_vector_type(8)));
 typedef unsigned uint4_ __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4_ lds_short4;
 
-#define X3_WAVES 8
+#define X3_WAVES 8                         // the LDS map is laid out for the 8-wave form (NW = 4 leaves slots unused)
 #define X3_ROWS (X3_WAVES * FD_UNIT)       // 128 rows per tile
 #define X3_HALF 64                         // rows per staged half
 #define X3_THREADS (64 * X3_WAVES)
@@ -102,8 +110,9 @@ __device__ __forceinline__ float x3_sum_q(float v) {
   return v;
 }
 // one layer's hi + lo images (64 KB) from their global copy: 8 one-KB pieces per wave
+template <int NW>
 __device__ __forceinline__ void x3_reload(const char* __restrict__ gimg, unsigned lds_dst, int wave, int lane) {
-  constexpr int PIECES = 2 * IMG_BYTES / (X3_WAVES * 1024);
+  constexpr int PIECES = 2 * IMG_BYTES / (NW * 1024);
 #pragma unroll
   for (int c = 0; c < PIECES; ++c) {
     const int off = (wave * PIECES + c) * 1024;
@@ -122,22 +131,29 @@ __device__ __forceinline__ X3Addr x3_addr(int r, int q) {
   return a;
 }
 
-#ifndef X3_FW_DBL
-#define X3_FW_DBL 1                 // forward layers: operands of the next group prefetched
+#ifndef X3_PF4
+#define X3_PF4 2                    // operand prefetch distance (groups of 6 MFMAs) of the layer loops with 4 waves: one wave
+#endif                              // per SIMD has nobody else to cover the LDS latency, and 512 registers to spend on it
+#ifndef X3_FOLD
+#define X3_FOLD 1                   // 4 waves: a layer's elementwise epilogue issued inside the consuming layer's k-loop
 #endif
 #ifndef X3_WAD_LOCAL
 #define X3_WAD_LOCAL 1              // 1: weight-read lane offsets recomputed per layer call instead of living in 10 registers
 #endif
-// forward layer of the wave's unit: out = bias + W in, all pre-scaled by C; three products per block
+// forward layer of the wave's unit: out = bias + W in, all pre-scaled by C; three products per block.
+// PF: operand prefetch distance in groups (0: loaded where they are used)
+// epi(g): independent elementwise work issued with group g's matrix instructions (see x3_tanh_split_chunk)
+struct X3NoEpi { __device__ __forceinline__ void operator()(int) const {} };
+template <int PF, class Epi = X3NoEpi>
 __device__ __forceinline__ void x3_layer_fwd(const __bf16* __restrict__ Wh, const float* __restrict__ bs,
                                              const bf16x4 (&ih)[8], const bf16x4 (&il)[8], f32x4 (&out)[8],
-                                             const X3Addr& ad, int q) {
+                                             const X3Addr& ad, int q, Epi epi = Epi()) {
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
   const __bf16* ah = Wh + ad.fb;
   const __bf16* al = ah + W_IMG;
   const int (&xm)[4] = ad.fx;
-  bf16x8 wh[1 + X3_FW_DBL][2], wl[1 + X3_FW_DBL][2];
+  bf16x8 wh[PF + 1][2], wl[PF + 1][2];
   auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
     const int m = g >> 2, op = (g & 3) * 2;
 #pragma unroll
@@ -147,13 +163,13 @@ __device__ __forceinline__ void x3_layer_fwd(const __bf16* __restrict__ Wh, cons
       l[o] = *reinterpret_cast<const bf16x8*>(al + off);
     }
   };
-  if (X3_FW_DBL) load(0, wh[0], wl[0]);
+#pragma unroll
+  for (int g = 0; g < PF; ++g) load(g, wh[g], wl[g]);
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int m = g >> 2, op = (g & 3) * 2;
-    const int cur = X3_FW_DBL ? (g & 1) : 0;
-    if (X3_FW_DBL) { if (g + 1 < 16) load(g + 1, wh[(g + 1) & X3_FW_DBL], wl[(g + 1) & X3_FW_DBL]); }
-    else load(g, wh[0], wl[0]);
+    const int cur = g % (PF + 1);
+    if (g + PF < 16) load(g + PF, wh[(g + PF) % (PF + 1)], wl[(g + PF) % (PF + 1)]);
     X3_FENCE();
     const bf16x8 bh = x3_cat(ih[2 * m], ih[2 * m + 1]), bl = x3_cat(il[2 * m], il[2 * m + 1]);
 #pragma unroll
@@ -162,6 +178,7 @@ __device__ __forceinline__ void x3_layer_fwd(const __bf16* __restrict__ Wh, cons
     for (int o = 0; o < 2; ++o) out[op + o] = MFMA32(wh[cur][o], bl, out[op + o]);
 #pragma unroll
     for (int o = 0; o < 2; ++o) out[op + o] = MFMA32(wl[cur][o], bh, out[op + o]);
+    epi(g);
     X3_FENCE();
   }
 }
@@ -169,9 +186,8 @@ __device__ __forceinline__ void x3_layer_fwd(const __bf16* __restrict__ Wh, cons
 // dgrad of the wave's unit, output blocks 4*hf .. 4*hf+3: out[k] = sum_j (C W)[j][k] dp[j]; A = W^T via the transposing
 // LDS read.  In two halves because the epilogue of a half (1 - h^2, split) ends the life of that half of the saved
 // activation before the other half's accumulators exist: 16 registers less at the kernel's tightest point.
-#ifndef X3_DG_DBL
-#define X3_DG_DBL 0                 // 1: operands of the next group prefetched (16 more registers)
-#endif
+// PF: operand prefetch distance in groups (0 with 8 waves: the 256-register limit)
+template <int PF>
 __device__ __forceinline__ void x3_layer_dgrad_half(const __bf16* __restrict__ Wh, const bf16x4 (&ih)[8],
                                                     const bf16x4 (&il)[8], f32x4 (&out)[4], int hf, const X3Addr& ad) {
 #pragma unroll
@@ -179,7 +195,7 @@ __device__ __forceinline__ void x3_layer_dgrad_half(const __bf16* __restrict__ W
   const __bf16* ah = Wh + ad.db;
   const __bf16* al = ah + W_IMG;
   const int (&xk)[4] = ad.dx;
-  bf16x8 wh[1 + X3_DG_DBL][2], wl[1 + X3_DG_DBL][2];
+  bf16x8 wh[PF + 1][2], wl[PF + 1][2];
   auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
     const int m = g >> 1, kp = 4 * hf + (g & 1) * 2;
 #pragma unroll
@@ -189,13 +205,13 @@ __device__ __forceinline__ void x3_layer_dgrad_half(const __bf16* __restrict__ W
       l[o] = x3_cat(x3_tr(al + off), x3_tr(al + off + 16 * LDB));
     }
   };
-  if (X3_DG_DBL) load(0, wh[0], wl[0]);
+#pragma unroll
+  for (int g = 0; g < PF; ++g) load(g, wh[g], wl[g]);
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int m = g >> 1, kq = (g & 1) * 2;
-    const int cur = X3_DG_DBL ? (g & 1) : 0;
-    if (X3_DG_DBL) { if (g + 1 < 8) load(g + 1, wh[(g + 1) & X3_DG_DBL], wl[(g + 1) & X3_DG_DBL]); }
-    else load(g, wh[0], wl[0]);
+    const int cur = g % (PF + 1);
+    if (g + PF < 8) load(g + PF, wh[(g + PF) % (PF + 1)], wl[(g + PF) % (PF + 1)]);
     X3_FENCE();
     const bf16x8 bh = x3_cat(ih[2 * m], ih[2 * m + 1]), bl = x3_cat(il[2 * m], il[2 * m + 1]);
 #pragma unroll
@@ -206,6 +222,71 @@ __device__ __forceinline__ void x3_layer_dgrad_half(const __bf16* __restrict__ W
     for (int o = 0; o < 2; ++o) out[kq + o] = MFMA32(wl[cur][o], bh, out[kq + o]);
     X3_FENCE();
   }
+}
+
+// dgrad of the wave's unit, all 8 output blocks (the 4-wave form: registers are no concern), with an epilogue functor
+template <int PF, class Epi = X3NoEpi>
+__device__ __forceinline__ void x3_layer_dgrad(const __bf16* __restrict__ Wh, const bf16x4 (&ih)[8], const bf16x4 (&il)[8],
+                                               f32x4 (&out)[8], const X3Addr& ad, Epi epi = Epi()) {
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) out[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const __bf16* ah = Wh + ad.db;
+  const __bf16* al = ah + W_IMG;
+  const int (&xk)[4] = ad.dx;
+  bf16x8 wh[PF + 1][2], wl[PF + 1][2];
+  auto load = [&](int g, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
+    const int m = g >> 2, kp = (g & 3) * 2;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int off = 32 * m * LDB + xk[(kp + o) >> 1] + 4 * ((kp + o) & 1);
+      h[o] = x3_cat(x3_tr(ah + off), x3_tr(ah + off + 16 * LDB));
+      l[o] = x3_cat(x3_tr(al + off), x3_tr(al + off + 16 * LDB));
+    }
+  };
+#pragma unroll
+  for (int g = 0; g < PF; ++g) load(g, wh[g], wl[g]);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int m = g >> 2, kp = (g & 3) * 2;
+    const int cur = g % (PF + 1);
+    if (g + PF < 16) load(g + PF, wh[(g + PF) % (PF + 1)], wl[(g + PF) % (PF + 1)]);
+    X3_FENCE();
+    const bf16x8 bh = x3_cat(ih[2 * m], ih[2 * m + 1]), bl = x3_cat(il[2 * m], il[2 * m + 1]);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) out[kp + o] = MFMA32(wh[cur][o], bh, out[kp + o]);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) out[kp + o] = MFMA32(wh[cur][o], bl, out[kp + o]);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) out[kp + o] = MFMA32(wl[cur][o], bh, out[kp + o]);
+    epi(g);
+    X3_FENCE();
+  }
+}
+
+// Elementwise epilogues in CHUNKS of two values (chunk c of 16: block c >> 1, elements 2 (c & 1), 2 (c & 1) + 1), to be
+// issued between the matrix instructions of the CONSUMING layer's k-loop (4-wave form): one wave per SIMD pays 6.5 cycles
+// per VALU instruction in a pure elementwise phase but ~4 beside MFMAs, which themselves hide ~8 cycles of it each
+// (scripts/ubench/mfma_overlap2.hip).  k-block m of the consumer needs blocks 2m, 2m+1 = chunks 4m .. 4m+3.
+__device__ __forceinline__ void x3_split2(float t0, float t1, bf16x4& h, bf16x4& l, int e0) {
+  const __bf16 h0 = (__bf16)t0, h1 = (__bf16)t1;
+  h[e0] = h0; h[e0 + 1] = h1;
+  l[e0] = (__bf16)(t0 - (float)h0); l[e0 + 1] = (__bf16)(t1 - (float)h1);
+}
+// tanh given C*x, then (hi, lo)
+__device__ __forceinline__ void x3_tanh_split_chunk(const f32x4 (&v)[8], bf16x4 (&h)[8], bf16x4 (&l)[8], int c) {
+  const int jb = c >> 1, e0 = 2 * (c & 1);
+  float t0 = __builtin_amdgcn_exp2f(v[jb][e0]), t1 = __builtin_amdgcn_exp2f(v[jb][e0 + 1]);
+  t0 = __builtin_amdgcn_rcpf(t0 + 1.0f); t1 = __builtin_amdgcn_rcpf(t1 + 1.0f);
+  t0 = 1.0f - 2.0f * t0; t1 = 1.0f - 2.0f * t1;
+  x3_split2(t0, t1, h[jb], l[jb], e0);
+}
+// d * (1 - (hh + hl)^2), then (hi, lo)
+__device__ __forceinline__ void x3_dtanh_split_chunk(const f32x4 (&d)[8], const bf16x4 (&hh)[8], const bf16x4 (&hl)[8],
+                                                     bf16x4 (&oh)[8], bf16x4 (&ol)[8], int c) {
+  const int jb = c >> 1, e0 = 2 * (c & 1);
+  const float a0 = (float)hh[jb][e0] + (float)hl[jb][e0], a1 = (float)hh[jb][e0 + 1] + (float)hl[jb][e0 + 1];
+  const float t0 = d[jb][e0] * (1.0f - a0 * a0), t1 = d[jb][e0 + 1] * (1.0f - a1 * a1);
+  x3_split2(t0, t1, oh[jb], ol[jb], e0);
 }
 
 // tanh of x given C*x, in place, written as stages (pv_sdec_fused_w8.hip)
@@ -311,12 +392,17 @@ __device__ __forceinline__ void x3_stage_store(__bf16* __restrict__ sh, const bf
 // lane offset of the transposing read of staged rows R0 + 4q .. 4q+3 (R0 a multiple of 16), columns 16*blk ..
 __device__ __forceinline__ int x3_stage_toff(int r, int q) { return (4 * q + (r >> 2)) * LDS2 + 4 * ((r & 3) ^ q); }
 
-// wgrad over one staged half (64 rows = up to 2 k-steps).  Region: [dpre hi | dpre lo | h hi | h lo], 64 x LDS2 each.
-// Wave (jp = wave >> 1, kh = wave & 1) owns the 32 x 64 block dW[32jp .. +31][64kh .. +63] and the bias sums of rows
-// 32jp + 16kh .. +15 (an MFMA against ones):
+// wgrad over one staged exchange (64 rows = up to 2 k-steps).  Region: [dpre hi | dpre lo | h hi | h lo], 64 x LDS2 each.
+// Wave (jp = wave >> 1, kh = wave & 1) owns the (16 SB) x 64 block dW[16 SB jp .. ][64kh .. +63] (SB = 16 / NW: 32 rows
+// with 8 waves, 64 with 4) and the bias sums of its 16 NB rows 16 SB jp + 16 NB kh .. (NB = 8 / NW; an MFMA against ones):
 //   dW[j][k] += sum_rows dpre[row][j] h[row][k]  (dh hh + dh hl + dl hh);   db[j] += sum_rows dpre[row][j]
-__device__ __forceinline__ void x3_wgrad_consume(const __bf16* st, f32x4 (&accW)[2][4], f32x4& accB, int wave, int r, int q,
-                                                 int ksteps) {
+// The wave holds its SB row blocks ROTATED by NB kh — accW[s] is row block (s + NB kh) mod SB — so that its bias blocks are
+// always operands 0 .. NB-1: a wave-uniform choice between REGISTER operands (kh ? a[NB + t] : a[t]) made hipcc put the
+// operand arrays in scratch memory and index them there (14 scratch transfers per k-step: 8.7 k cycles per exchange).
+template <int NW>
+__device__ __forceinline__ void x3_wgrad_consume(const __bf16* st, f32x4 (&accW)[16 / NW][4], f32x4 (&accB)[8 / NW], int wave,
+                                                 int r, int q, int ksteps) {
+  constexpr int SB = 16 / NW, NB = 8 / NW;
   const __bf16* sah = st;
   const __bf16* sal = st + X3_ARR;
   const __bf16* sbh = st + 2 * X3_ARR;
@@ -328,10 +414,10 @@ __device__ __forceinline__ void x3_wgrad_consume(const __bf16* st, f32x4 (&accW)
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
   for (int ks = 0; ks < ksteps; ++ks) {
     const int koff = toff + 32 * ks * LDS2;
-    bf16x8 ah[2], al[2];
+    bf16x8 ah[SB], al[SB];
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
-      const int off = koff + 32 * jp + 16 * s_;
+    for (int s_ = 0; s_ < SB; ++s_) {
+      const int off = koff + 16 * SB * jp + 16 * ((s_ + NB * kh) & (SB - 1));
       ah[s_] = x3_cat(x3_tr(sah + off), x3_tr(sah + off + 16 * LDS2));
       al[s_] = x3_cat(x3_tr(sal + off), x3_tr(sal + off + 16 * LDS2));
     }
@@ -343,18 +429,21 @@ __device__ __forceinline__ void x3_wgrad_consume(const __bf16* st, f32x4 (&accW)
     };
     load(0, bh[0], bl[0]);
     X3_FENCE();
-    accB = MFMA32(kh ? ah[1] : ah[0], ones, accB);
-    accB = MFMA32(kh ? al[1] : al[0], ones, accB);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      accB[t] = MFMA32(ah[t], ones, accB[t]);
+      accB[t] = MFMA32(al[t], ones, accB[t]);
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       if (o + 1 < 4) load(o + 1, bh[(o + 1) & 1], bl[(o + 1) & 1]);
       X3_FENCE();
 #pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) accW[s_][o] = MFMA32(ah[s_], bh[o & 1], accW[s_][o]);
+      for (int s_ = 0; s_ < SB; ++s_) accW[s_][o] = MFMA32(ah[s_], bh[o & 1], accW[s_][o]);
 #pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) accW[s_][o] = MFMA32(ah[s_], bl[o & 1], accW[s_][o]);
+      for (int s_ = 0; s_ < SB; ++s_) accW[s_][o] = MFMA32(ah[s_], bl[o & 1], accW[s_][o]);
 #pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) accW[s_][o] = MFMA32(al[s_], bh[o & 1], accW[s_][o]);
+      for (int s_ = 0; s_ < SB; ++s_) accW[s_][o] = MFMA32(al[s_], bh[o & 1], accW[s_][o]);
       X3_FENCE();
     }
   }
@@ -386,7 +475,7 @@ __device__ __forceinline__ void x3_colsum_mfma(__bf16* __restrict__ sc, const bf
 __device__ long long x3_trace[512];
 #define X3_STAMP(k)                                                                              \
   do {                                                                                           \
-    if (g == 0 && lane == 0 && (wave == 0 || wave == 7) && tile_no < 8)                          \
+    if (g == 0 && lane == 0 && (wave == 0 || wave == NW - 1) && tile_no < 8)                          \
       x3_trace[(wave ? 256 : 0) + tile_no * 32 + (k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
 extern "C" int pv_debug_read_trace_w8x3(long long* out, int n) {
@@ -398,8 +487,10 @@ extern "C" int pv_debug_read_trace_w8x3(long long* out, int n) {
 #endif
 
 // LIK: the likelihood is a compile-time choice
-template <bool GRADS, int LIK>
-__global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
+template <bool GRADS, int LIK, int NW>
+__global__ __launch_bounds__(64 * NW) void pv_sdec_w8x3_kernel(PvFused f) {
+  constexpr int SB = 16 / NW, NB = 8 / NW;           // 16-row blocks of dW / of the bias sums a wave owns
+  constexpr int NH = NW / 4;                         // staged exchanges per layer and tile (64 rows each)
   extern __shared__ __attribute__((aligned(16))) char smb[];
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -415,8 +506,8 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   const char* gimg = reinterpret_cast<const char*>(f.wimg);
 
   // ---- prologue: weight images by LDS-DMA (prepared set: W1h W1l W2h W2l), vectors and tables ----
-  x3_reload(gimg, lds0 + XO_R1, wave, lane);
-  x3_reload(gimg + 2 * IMG_BYTES, lds0 + XO_R2, wave, lane);
+  x3_reload<NW>(gimg, lds0 + XO_R1, wave, lane);
+  x3_reload<NW>(gimg + 2 * IMG_BYTES, lds0 + XO_R2, wave, lane);
   if (tid < FD_H) {
     vec[tid] = f.wo[tid];
     vec[FD_H + tid] = X3_C * f.b1[tid];
@@ -425,17 +516,19 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   {
     // coordinate layer A operands (v_mfma_f32_16x16x16_bf16: lane (m, kq) holds A[m][4kq .. 4kq+3]), k slots:
     //   kq 0: [wh0 wh0 wl0 0] x [xh0 xl0 xh0 0]   kq 1: the same for coordinate 1   kq 2: [bch bcl 0 0] x [1 1 0 0]
-    const int jb = tid >> 6, m = lane & 15, kq = lane >> 4, j = 16 * jb + m;
-    float v = 0.0f;
-    if (kq == 0) v = X3_C * f.Wc[j * f.cd];
-    else if (kq == 1) v = f.cd == 2 ? X3_C * f.Wc[j * 2 + 1] : 0.0f;
-    else if (kq == 2) v = X3_C * f.bc[j];
-    __bf16 hi, lo;
-    fb_split(v, hi, lo);
-    bf16x4 a = x3_zero4();
-    if (kq < 2) { a[0] = hi; a[1] = hi; a[2] = lo; }
-    else if (kq == 2) { a[0] = hi; a[1] = lo; }
-    reinterpret_cast<bf16x4*>(smb + XO_ATAB)[tid] = a;
+    for (int jb = tid >> 6; jb < 8; jb += NW) {
+      const int m = lane & 15, kq = lane >> 4, j = 16 * jb + m;
+      float v = 0.0f;
+      if (kq == 0) v = X3_C * f.Wc[j * f.cd];
+      else if (kq == 1) v = f.cd == 2 ? X3_C * f.Wc[j * 2 + 1] : 0.0f;
+      else if (kq == 2) v = X3_C * f.bc[j];
+      __bf16 hi, lo;
+      fb_split(v, hi, lo);
+      bf16x4 a = x3_zero4();
+      if (kq < 2) { a[0] = hi; a[1] = hi; a[2] = lo; }
+      else if (kq == 2) { a[0] = hi; a[1] = lo; }
+      reinterpret_cast<bf16x4*>(smb + XO_ATAB)[64 * jb + lane] = a;
+    }
   }
   if (tid < 256) {
     // row-local dgrad A operands (16x16x32: lane (m, kq) holds A[m][k], k = the 8 logical columns a lane feeds as B:
@@ -460,11 +553,15 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
 
   // persistent accumulators: the wave's 32 x 64 blocks of dW1 (x C) and dW2, the bias sums, and the wave-local column
   // sums D[j][n]: n = 0 dL/d(hz) | 1, 5 dWc0 (hi, lo) | 2, 6 dWc1 | 3, 4 d(wo)   (n 0,1,2,5,6 carry C^2)
-  f32x4 accW1[2][4], accW2[2][4], accS[8], accB1 = {0, 0, 0, 0}, accB2 = {0, 0, 0, 0};
+  f32x4 accW1[SB][4], accW2[SB][4], accS[8], accB1[NB], accB2[NB];
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb) {
-    accW1[kb >> 2][kb & 3] = f32x4{0, 0, 0, 0}; accW2[kb >> 2][kb & 3] = f32x4{0, 0, 0, 0}; accS[kb] = f32x4{0, 0, 0, 0};
-  }
+  for (int kb = 0; kb < 8; ++kb) accS[kb] = f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int s_ = 0; s_ < SB; ++s_)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { accW1[s_][o] = f32x4{0, 0, 0, 0}; accW2[s_][o] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+  for (int t = 0; t < NB; ++t) { accB1[t] = f32x4{0, 0, 0, 0}; accB2[t] = f32x4{0, 0, 0, 0}; }
   float dbo = 0.0f;
   int cur_b = -1;                                    // the sample whose dL/d(hz) this WAVE is accumulating
   const int upb = f.N / FD_UNIT;
@@ -472,7 +569,7 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   // the wave's parking slot for h0 (hi/lo), rewritten every tile
   // (uniform base + 32-bit lane offset everywhere a lane touches global memory: one address register instead of a 64-bit
   //  pair per access point — per-lane pointers hoisted out of the tile loop were what the first build spilled)
-  char* const park_base = reinterpret_cast<char*>(f.park) + ((int64_t)g * X3_WAVES + wave) * X3_PARK_BYTES_PER_WAVE;
+  char* const park_base = reinterpret_cast<char*>(f.park) + ((int64_t)g * NW + wave) * X3_PARK_BYTES_PER_WAVE;   // (NW = 8 only)
   auto park_at = [&](int jb) -> uint4_* {
     return reinterpret_cast<uint4_*>(park_base + (unsigned)((lane0 | x3_opaque0()) * 16 + 1024 * jb));
   };
@@ -480,7 +577,7 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   auto flush_hz = [&](int b) {
     const int64_t ub = (int64_t)b * upb;
     const int gfirst = (int)(((ub + 1) * G + f.units - 1) / f.units) - 1;
-    float* dst = f.part_hz + ((int64_t)b * f.kmax + (g - gfirst) * X3_WAVES + wave) * FD_H + 4 * q;
+    float* dst = f.part_hz + ((int64_t)b * f.kmax + (g - gfirst) * NW + wave) * FD_H + 4 * q;
     if (r == 0) {
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<f32x4*>(dst + 16 * jb) = accS[jb] * X3_RC2;
@@ -528,13 +625,13 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   const X3Addr wad0 = x3_addr(r, q);
   (void)wad0;
   int tile_no = -1;
-  for (int ut = u_lo; ut < u_hi; ut += X3_WAVES) {
+  for (int ut = u_lo; ut < u_hi; ut += NW) {
     ++tile_no;
     (void)tile_no;
     asm volatile("; X3_TILE_BEGIN");
     X3_STAMP(0);
-    const int nact = (u_hi - ut) < X3_WAVES ? (u_hi - ut) : X3_WAVES;
-    if (ut + X3_WAVES + wave < u_hi) advance(pos_nx, X3_WAVES);
+    const int nact = (u_hi - ut) < NW ? (u_hi - ut) : NW;
+    if (ut + NW + wave < u_hi) advance(pos_nx, NW);
     else pos_nx = pos_lo;
     int opq = 0;
     asm volatile("" : "+v"(opq));
@@ -573,7 +670,7 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
     float* inf_x1 = info + X3_ROWS + 16 * wave;
     float* inf_dl = info + 2 * X3_ROWS + 16 * wave;
 
-    f32x4 tC[8];
+    f32x4 tC[8], tD[8];                        // (tD: the 4-wave form keeps a layer's pre-activations while the next layer consumes them)
     bf16x4 h0h[8], h0l[8], h1h[8], h1l[8], pAh[8], pAl[8];
     float dlda = 0.0f;
     {
@@ -605,16 +702,27 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) tC[jb] = x3_mfma16(aop[jb], bx, tC[jb]);
       X3_FENCE();
-      x3_tanh8(tC);
-      x3_split8(tC, h0h, h0l);
+      if (NW == 4 && X3_FOLD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x3_tanh_split_chunk(tC, h0h, h0l, c);      // (k-block 0; the rest rides in layer 1's loop)
+      } else {
+        x3_tanh8(tC);
+        x3_split8(tC, h0h, h0l);
+      }
     }
     asm volatile("; X3_P1_coord_done");
     X3_STAMP(1);
     fetch_unit_inputs(pos_nx);                 // the slots were consumed by the coordinate layer above
-    if (GRADS && tile_no > 0) x3_reload(gimg + 2 * IMG_BYTES, lds0 + XO_R2, wave, lane);   // W2 was the previous tile's staging area
+    if (GRADS && tile_no > 0) x3_reload<NW>(gimg + 2 * IMG_BYTES, lds0 + XO_R2, wave, lane);   // W2 was the previous tile's staging area
     {
-      x3_layer_fwd(W1h, b1s, h0h, h0l, tC, wad, q);
-      if (GRADS) {
+      if (NW == 4 && X3_FOLD) {
+        x3_layer_fwd<X3_PF4>(W1h, b1s, h0h, h0l, tD, wad, q, [&](int g_) { if (g_ < 12) x3_tanh_split_chunk(tC, h0h, h0l, 4 + g_); });
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x3_tanh_split_chunk(tD, h1h, h1l, c);
+      } else {
+        x3_layer_fwd<(NW == 4 ? X3_PF4 : 1)>(W1h, b1s, h0h, h0l, tC, wad, q);
+      }
+      if (GRADS && NW == 8) {
         // park h0 (needed again at the end of the tile only)
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
@@ -623,8 +731,10 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
           *park_at(jb) = uint4_{a[0], a[1], b[0], b[1]};
         }
       }
-      x3_tanh8(tC);
-      x3_split8(tC, h1h, h1l);                                     // feeds layer 2 and its wgrad
+      if (!(NW == 4 && X3_FOLD)) {
+        x3_tanh8(tC);
+        x3_split8(tC, h1h, h1l);                                   // feeds layer 2 and its wgrad
+      }
     }
     asm volatile("; X3_P2_l1_done");
     X3_STAMP(2);
@@ -634,7 +744,10 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
     }
     X3_STAMP(3);
     {
-      x3_layer_fwd(W2h, b2s, h1h, h1l, tC, wad, q);
+      if (NW == 4 && X3_FOLD)
+        x3_layer_fwd<X3_PF4>(W2h, b2s, h1h, h1l, tC, wad, q, [&](int g_) { if (g_ < 12) x3_tanh_split_chunk(tD, h1h, h1l, 4 + g_); });
+      else
+        x3_layer_fwd<(NW == 4 ? X3_PF4 : 1)>(W2h, b2s, h1h, h1l, tC, wad, q);
       // ---- h2, output layer + likelihood (fp32); tC <- g = wo (1 - h2^2), pA <- split(h2) ----
       x3_tanh8(tC);                                                // tC = h2
       if (GRADS) x3_split8(tC, pAh, pAl);
@@ -681,8 +794,8 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
     asm volatile("; X3_P3_fwd_done");
     X3_STAMP(4);
     if (!GRADS) continue;
-    const int ksA = nact >= 3 ? 2 : 1;                           // k-steps of the first staged half (units 0..3)
-    const int ksB = nact <= 4 ? 0 : (nact >= 7 ? 2 : 1);         // ... of the second (units 4..7)
+    // k-steps (32 rows) of staged exchange h: units 4h .. 4h+3 of the tile
+    auto ks_of = [&](int h) { const int n = nact - 4 * h; return n <= 0 ? 0 : (n >= 3 ? 2 : 1); };
     {
       // ---- d(wo) += sum_rows dlda h2 : wave-local MFMAs through the wave's own scratch rows of region ST2;
       // B = dlda of rows 4q..4q+3 in columns 3 (hi) and 4 (lo) for h2_hi, column 3 (hi) for h2_lo
@@ -705,41 +818,56 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
     }
     asm volatile("; X3_P4_dwo_done");
     X3_STAMP(5);
-    // ---- wgrad of layer 2: (dpre2, h1), 64 rows at a time ----
-    __syncthreads();                                              // every wave's column sums are out of the region
-    if (wave < 4) {
-      x3_stage_store(st2, pAh, 16 * wave + r, q);
-      x3_stage_store(st2 + X3_ARR, pAl, 16 * wave + r, q);
-      x3_stage_store(st2 + 2 * X3_ARR, h1h, 16 * wave + r, q);
-      x3_stage_store(st2 + 3 * X3_ARR, h1l, 16 * wave + r, q);
-    }
-    __syncthreads();
-    X3_STAMP(6);
-    x3_wgrad_consume(st2, accW2, accB2, wave, r, q, ksA);
-    X3_STAMP(7);
-    if (ksB > 0) {
-      __syncthreads();
-      if (wave >= 4) {
-        x3_stage_store(st2, pAh, 16 * (wave - 4) + r, q);
-        x3_stage_store(st2 + X3_ARR, pAl, 16 * (wave - 4) + r, q);
-        x3_stage_store(st2 + 2 * X3_ARR, h1h, 16 * (wave - 4) + r, q);
-        x3_stage_store(st2 + 3 * X3_ARR, h1l, 16 * (wave - 4) + r, q);
+    // ---- wgrad of layer 2: (dpre2, h1), 64 rows per staged exchange ----
+    // (8 waves: waves 4-7's column-sum scratch rows are rows waves 0-3 stage into; 4 waves: a wave's scratch rows are its
+    //  own staging rows in arrays 0 and 2, so its own lgkmcnt wait above is all the ordering it needs)
+    if (NW == 8) __syncthreads();                                 // every wave's column sums are out of the region
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      if (ks_of(h) == 0) break;                                   // (workgroup-uniform)
+      if (h > 0) __syncthreads();
+      if ((wave >> 2) == h) {
+        x3_stage_store(st2, pAh, 16 * (wave & 3) + r, q);
+        x3_stage_store(st2 + X3_ARR, pAl, 16 * (wave & 3) + r, q);
+        x3_stage_store(st2 + 2 * X3_ARR, h1h, 16 * (wave & 3) + r, q);
+        x3_stage_store(st2 + 3 * X3_ARR, h1l, 16 * (wave & 3) + r, q);
       }
       __syncthreads();
-      x3_wgrad_consume(st2, accW2, accB2, wave, r, q, ksB);
+      X3_STAMP(6 + h);
+      x3_wgrad_consume<NW>(st2, accW2, accB2, wave, r, q, ks_of(h));
     }
     __syncthreads();                                              // region ST2 consumed everywhere
     asm volatile("; X3_P6_cons2");
     X3_STAMP(8);
     x3_wait_vm0();                                                // (nothing compiler-visible may be in flight)
-    x3_reload(gimg, lds0 + XO_R1, wave, lane);                    // W1 comes back under the dgrad of layer 2
+    x3_reload<NW>(gimg, lds0 + XO_R1, wave, lane);                // W1 comes back under the dgrad of layer 2
     bf16x4 p0h[8], p0l[8], d1h[8], d1l[8];
+    if (NW == 4 && X3_FOLD) {
+      // 4 waves: dgrad of layer 2 in one piece; its epilogue C dpre1 = (C dL/dh1)(1 - h1^2) -> (hi, lo) rides in the k-loop
+      // of the dgrad of layer 1, which consumes it block by block
+      x3_layer_dgrad<X3_PF4>(W2h, pAh, pAl, tC, wad);              // tC = C dL/dh1
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x3_dtanh_split_chunk(tC, h1h, h1l, d1h, d1l, c);
+      asm volatile("; X3_P7_dgrad2");
+      X3_STAMP(9);
+      x3_wait_vm0();
+      __syncthreads();      // W1 landed everywhere; every wave is past its reads of W2 (region ST1 is free)
+      X3_STAMP(10);
+      x3_layer_dgrad<X3_PF4>(W1h, d1h, d1l, tD, wad, [&](int g_) { if (g_ < 12) x3_dtanh_split_chunk(tC, h1h, h1l, d1h, d1l, 4 + g_); });
+      f32x4 t4[4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) t4[jb] = tD[4 * hf + jb];
+        x3_dtanh_split4(t4, h0h + 4 * hf, h0l + 4 * hf, p0h + 4 * hf, p0l + 4 * hf);   // C^2 dpre0
+      }
+    } else {
     {
       // C dpre1 = (C dL/dh1) (1 - h1^2), split: feeds the dgrad and the wgrad of layer 1
       f32x4 t4[4];
-      x3_layer_dgrad_half(W2h, pAh, pAl, t4, 0, wad);
+      x3_layer_dgrad_half<(NW == 4 ? X3_PF4 : 0)>(W2h, pAh, pAl, t4, 0, wad);
       x3_dtanh_split4(t4, h1h, h1l, d1h, d1l);
-      x3_layer_dgrad_half(W2h, pAh, pAl, t4, 1, wad);
+      x3_layer_dgrad_half<(NW == 4 ? X3_PF4 : 0)>(W2h, pAh, pAl, t4, 1, wad);
       x3_dtanh_split4(t4, h1h + 4, h1l + 4, d1h + 4, d1l + 4);
     }
     asm volatile("; X3_P7_dgrad2");
@@ -748,28 +876,37 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
     __syncthreads();        // W1 landed everywhere; every wave is past its reads of W2 (region ST1 is free)
     X3_STAMP(10);
     {
-      // h0 comes back from its parking slot half by half, each under a half of the dgrad of layer 1
+      // NW = 8: h0 comes back from its parking slot half by half, each under a half of the dgrad of layer 1
       typedef unsigned uint2_ __attribute__((ext_vector_type(2)));
       uint4_ pk[4];
       f32x4 t4[4];
+      if (NW == 8) {
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) pk[jb] = *park_at(jb);
-      x3_layer_dgrad_half(W1h, d1h, d1l, t4, 0, wad);              // C^2 dL/dh0
+        for (int jb = 0; jb < 4; ++jb) pk[jb] = *park_at(jb);
+      }
+      x3_layer_dgrad_half<(NW == 4 ? X3_PF4 : 0)>(W1h, d1h, d1l, t4, 0, wad);              // C^2 dL/dh0
+      if (NW == 8) {
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        h0h[jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][0], pk[jb][1]});
-        h0l[jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][2], pk[jb][3]});
+        for (int jb = 0; jb < 4; ++jb) {
+          h0h[jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][0], pk[jb][1]});
+          h0l[jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][2], pk[jb][3]});
+        }
       }
       x3_dtanh_split4(t4, h0h, h0l, p0h, p0l);                     // C^2 dpre0
+      if (NW == 8) {
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) pk[jb] = *park_at(4 + jb);
-      x3_layer_dgrad_half(W1h, d1h, d1l, t4, 1, wad);
+        for (int jb = 0; jb < 4; ++jb) pk[jb] = *park_at(4 + jb);
+      }
+      x3_layer_dgrad_half<(NW == 4 ? X3_PF4 : 0)>(W1h, d1h, d1l, t4, 1, wad);
+      if (NW == 8) {
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        h0h[4 + jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][0], pk[jb][1]});
-        h0l[4 + jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][2], pk[jb][3]});
+        for (int jb = 0; jb < 4; ++jb) {
+          h0h[4 + jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][0], pk[jb][1]});
+          h0l[4 + jb] = __builtin_bit_cast(bf16x4, uint2_{pk[jb][2], pk[jb][3]});
+        }
       }
       x3_dtanh_split4(t4, h0h + 4, h0l + 4, p0h + 4, p0l + 4);
+    }
     }
     asm volatile("; X3_P8_dgrad1");
     X3_STAMP(11);
@@ -816,28 +953,21 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
     }
     asm volatile("; X3_P12_rowlocal");
     X3_STAMP(12);
-    // ---- wgrad of layer 1: (C dpre1, h0), 64 rows at a time ----
-    __syncthreads();
-    if (wave < 4) {
-      x3_stage_store(st1, d1h, 16 * wave + r, q);
-      x3_stage_store(st1 + X3_ARR, d1l, 16 * wave + r, q);
-      x3_stage_store(st1 + 2 * X3_ARR, h0h, 16 * wave + r, q);
-      x3_stage_store(st1 + 3 * X3_ARR, h0l, 16 * wave + r, q);
-    }
-    __syncthreads();
-    X3_STAMP(13);
-    x3_wgrad_consume(st1, accW1, accB1, wave, r, q, ksA);
-    X3_STAMP(14);
-    if (ksB > 0) {
-      __syncthreads();
-      if (wave >= 4) {
-        x3_stage_store(st1, d1h, 16 * (wave - 4) + r, q);
-        x3_stage_store(st1 + X3_ARR, d1l, 16 * (wave - 4) + r, q);
-        x3_stage_store(st1 + 2 * X3_ARR, h0h, 16 * (wave - 4) + r, q);
-        x3_stage_store(st1 + 3 * X3_ARR, h0l, 16 * (wave - 4) + r, q);
+    // ---- wgrad of layer 1: (C dpre1, h0), 64 rows per staged exchange ----
+    if (NW == 8) __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      if (ks_of(h) == 0) break;
+      if (h > 0) __syncthreads();
+      if ((wave >> 2) == h) {
+        x3_stage_store(st1, d1h, 16 * (wave & 3) + r, q);
+        x3_stage_store(st1 + X3_ARR, d1l, 16 * (wave & 3) + r, q);
+        x3_stage_store(st1 + 2 * X3_ARR, h0h, 16 * (wave & 3) + r, q);
+        x3_stage_store(st1 + 3 * X3_ARR, h0l, 16 * (wave & 3) + r, q);
       }
       __syncthreads();
-      x3_wgrad_consume(st1, accW1, accB1, wave, r, q, ksB);
+      X3_STAMP(13 + h);
+      x3_wgrad_consume<NW>(st1, accW1, accB1, wave, r, q, ks_of(h));
     }
     __syncthreads();                      // region ST1 consumed everywhere (the next tile's W2 reload lands there)
     asm volatile("; X3_P13_cons1");
@@ -851,22 +981,25 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   {
     const int jp = wave >> 1, kh = wave & 1;
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_)
+    for (int s_ = 0; s_ < SB; ++s_)
 #pragma unroll
       for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16s + 4q + i][64kh + 16o + r]
-          const int e = (32 * jp + 16 * s_ + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
+          // C/D layout: lane (col = r, q), reg i -> dW[16 SB jp + 16 blk + 4q + i][64kh + 16o + r], blk = (s + NB kh) mod SB
+          const int e = (16 * SB * jp + 16 * ((s_ + NB * kh) & (SB - 1)) + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
           rec[e] = accW1[s_][o][i] * X3_RC;
           rec[FD_H * FD_H + e] = accW2[s_][o][i];
         }
     if (r == 0) {
-      const int j0 = 32 * jp + 16 * kh;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rec[2 * FD_H * FD_H + j0 + 4 * q + i] = accB1[i] * X3_RC;
-        rec[2 * FD_H * FD_H + FD_H + j0 + 4 * q + i] = accB2[i];
+      for (int t = 0; t < NB; ++t) {
+        const int j0 = 16 * SB * jp + 16 * (NB * kh + t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rec[2 * FD_H * FD_H + j0 + 4 * q + i] = accB1[t][i] * X3_RC;
+          rec[2 * FD_H * FD_H + FD_H + j0 + 4 * q + i] = accB2[t][i];
+        }
       }
     }
   }
@@ -886,7 +1019,7 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
     const float* scr = reinterpret_cast<const float*>(smb + XO_R1);
     float vo = 0.0f, v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
-    for (int w = 0; w < X3_WAVES; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float* s_ = scr + (w * 16) * FD_H + tid;
       v0 += s_[1 * FD_H] + s_[5 * FD_H];
       v1 += s_[2 * FD_H] + s_[6 * FD_H];
@@ -898,20 +1031,23 @@ __global__ __launch_bounds__(X3_THREADS) void pv_sdec_w8x3_kernel(PvFused f) {
   }
   if (tid == 0) {
     float v = 0.0f;
-    for (int w = 0; w < X3_WAVES; ++w) v += red[w];
+    for (int w = 0; w < NW; ++w) v += red[w];
     rec[2 * FD_H * FD_H + 5 * FD_H] = v;
   }
 }
 
-int64_t pv_sdec_fused_w8x3_park_bytes(int grid) { return (int64_t)grid * X3_WAVES * X3_PARK_BYTES_PER_WAVE; }
+int64_t pv_sdec_fused_w8x3_park_bytes(int grid) { return (int64_t)grid * 8 * X3_PARK_BYTES_PER_WAVE; }
 
-int pv_sdec_fused_w8x3_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {
+// waves: 8 or 4 (the template's NW)
+int pv_sdec_fused_w8x3_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s, int waves) {
   PvFused f = f_in;
   f.ablate = 0;
-  if (grads && !f.park) return PV_EINVAL;
+  if (waves != 4 && waves != 8) return PV_EINVAL;
+  if (grads && waves == 8 && !f.park) return PV_EINVAL;
   const size_t lds = X3_LDS_BYTES;
   const void* fn = nullptr;
-#define X3_PICK(G, L) fn = reinterpret_cast<const void*>(&pv_sdec_w8x3_kernel<G, L>)
+#define X3_PICK(G, L) fn = waves == 8 ? reinterpret_cast<const void*>(&pv_sdec_w8x3_kernel<G, L, 8>) \
+                                      : reinterpret_cast<const void*>(&pv_sdec_w8x3_kernel<G, L, 4>)
   if (grads) {
     if (f.lik == PV_LIK_BERNOULLI) X3_PICK(true, PV_LIK_BERNOULLI);
     else if (f.lik == PV_LIK_GAUSSIAN) X3_PICK(true, PV_LIK_GAUSSIAN);
@@ -922,15 +1058,15 @@ int pv_sdec_fused_w8x3_launch(const PvFused& f_in, int grid, bool grads, hipStre
     else X3_PICK(false, PV_LIK_CBERNOULLI);
   }
 #undef X3_PICK
-  static const void* configured[6] = {};
-  const int slot = (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
+  static const void* configured[12] = {};
+  const int slot = (waves == 8 ? 6 : 0) + (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
   if (configured[slot] != fn) {                     // (idempotent: a race between host threads only repeats the call)
     hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e1 != hipSuccess) return (int)e1;
     configured[slot] = fn;
   }
   void* args[] = {&f};
-  hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(X3_THREADS), args, lds, s);
+  hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(64 * waves), args, lds, s);
   if (e2 != hipSuccess) return (int)e2;
   PV_LAUNCH_CHECK();
   return 0;

@@ -20,7 +20,7 @@ print("rc", lib.pv_debug_read_trace_w8x3(buf, 512))
 names = ["start", "coord layer", "fwd L1+tanh+park", "bar0 (W2 landed)", "fwd L2+logit+lik", "dwo colsum+dpre2",
          "bar+stageA+bar", "consume2 A", "(stage+consume2 B)+bar", "reload W1+dgrad2", "bar (W1 landed)", "dgrad1 (+unpark)",
          "rowlocal+colsum dpre0", "bar+stageA+bar", "consume1 A", "(stage+consume1 B)+bar"]
-for w, base in ((0, 0), (7, 256)):
+for w, base in ((0, 0), (3, 256)):
     for t in range(8):
         st = [buf[base + t * 32 + k] for k in range(16)]
         if not st[0]:

@@ -1848,10 +1848,12 @@ def test_conv_stack_with_other_pooling_falls_back_to_torch(gpu_device):
     assert not ops.conv_stack_supported(pv.nets.FeatureExtractor(2, 1, [(16,), (32,)]).cuda(), torch.rand(3, 2, 16, 16, device="cuda"))
 
 
-@pytest.fixture()
-def force_w8x3():
+@pytest.fixture(params=[8, 4, 0], ids=["w8x3", "w4x3", "old4"])
+def force_w8x3(request):
+    """Forces one split-precision decoder kernel for every launch (training and forward-only): pv_sdec_fused_w8x3.hip with
+    8 or 4 waves, or (0) the round-1/2 kernel of pv_sdec_fused_bf16.hip; by default the choice depends on launch kind and size."""
     lib = C.CDLL(_abi.LIB_PATH)
-    lib.pv_debug_force_w8x3(1)
+    lib.pv_debug_force_w8x3(request.param)
     try:
         yield
     finally:
