@@ -1,4 +1,4 @@
-"""Phase timing of the 8-wave plain-bf16 decoder kernel (a -DW8_TRACE build: scripts/mkvariant_w8.sh trace -DW8_TRACE;
+"""Phase timing of the 8-wave plain-bf16 decoder kernel (a -DW8_TRACE build: scripts/mkvariant_file.sh trace pv_sdec_fused_w8.hip -DW8_TRACE;
 PV_LIB_PATH=pyroved_amd/variants/lib_trace.so python scripts/gpu_trace_w8.py): cycles per phase, workgroup 0, waves 0 / 7."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,0 +1,64 @@
+"""HBM traffic per launch of a bench config's dominant kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate
+runs of the same command, as MI355X_MICROARCH.md prescribes; rocprofv3 reports KiB; FETCH_SIZE doubled — gfx950 reports half of
+a wide streaming read).  Usage: pmc_traffic.py <label e.g. C5:2> <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <source>
+Decoder kernel (name contains pv_sdec_): mean over its launches -> key "<label>".  Heaviest convolution (pv_conv3_sp_kernel):
+launches of a step are matched by their position in the step (a step = the launches between two Adam launches); position 1 = the
+second split-operand convolution of the encoder's forward = the one bench.py event-times (64 -> 64 channels at 32x32 with the
+max-pool epilogue in the default stack; pvcs::heaviest_conv) -> key "<label>:conv"."""
+import collections, csv, json, os, sys
+
+label, f_csv, w_csv, out_json, source = sys.argv[1:6]
+
+
+def load(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    return rows
+
+
+def per_kernel(rows, pred):
+    return [float(r["Counter_Value"]) for r in rows if pred(r["Kernel_Name"])]
+
+
+def steps_of(rows):
+    """lists of rows per step (split at Adam-carrying launches)"""
+    out, cur = [], []
+    for r in rows:
+        cur.append(r)
+        n = r["Kernel_Name"]
+        if "pv_adam" in n or "pv_wgrad_small" in n:
+            out.append(cur); cur = []
+    return out[2:] if len(out) > 4 else out          # (drop the first steps: warm-up / allocation effects)
+
+
+F, W = load(f_csv, "FETCH_SIZE"), load(w_csv, "WRITE_SIZE")
+res = {}
+dec = lambda n: "pv_sdec_" in n and "reduce" not in n
+fd, wd = per_kernel(F, dec), per_kernel(W, dec)
+if fd and wd:
+    f, w = sum(fd) / len(fd), sum(wd) / len(wd)
+    res[label] = {"bytes": int((2 * f + w) * 1024), "source": source, "fetch_kib": round(f, 1), "write_kib": round(w, 1),
+                  "launches": len(fd)}
+conv = lambda n: "pv_conv3_sp_kernel" in n
+if any(conv(r["Kernel_Name"]) for r in F):
+    def positions(rows):
+        acc = collections.defaultdict(list)
+        for st in steps_of(rows):
+            k = 0
+            for r in st:
+                if conv(r["Kernel_Name"]):
+                    acc[(k, int(r.get("Grid_Size", 0)))].append(float(r["Counter_Value"]))
+                    k += 1
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+    pf, pw = positions(F), positions(W)
+    keys = [k for k in pf if k in pw]
+    if keys:
+        gmax = max(k[1] for k in keys)
+        best = (1, gmax) if (1, gmax) in keys else max((k for k in keys if k[1] == gmax), key=lambda k: 2 * pf[k] + pw[k])
+        res[label + ":conv"] = {"bytes": int((2 * pf[best] + pw[best]) * 1024), "source": source,
+                                "fetch_kib": round(pf[best], 1), "write_kib": round(pw[best], 1),
+                                "position_in_step": best[0], "grid": best[1]}
+old = json.load(open(out_json)) if os.path.exists(out_json) else {}
+old.update(res)
+json.dump(old, open(out_json, "w"), indent=1)
+print(label, res)
