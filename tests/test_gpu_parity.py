@@ -333,7 +333,10 @@ VARIANT_GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G
 def test_model_variants_vs_golden(gpu_device, name, fused):
     """The same constructor variants / likelihoods against fixtures produced by the REFERENCE's own code
     (tests/golden/make_golden.py variants; models/ivae.py:122-163, utils/prob.py:25-29): loss and the three ELBO terms,
-    z, every gradient and every parameter after Adam for each recorded step, then encode / decode."""
+    z, every gradient and every parameter after Adam for each recorded step, then encode / decode.
+    ContinuousBernoulli variants (ivaevar_cbern_*): ONE recorded step only — the reference's own fp32 gradients carry ~1e-3
+    of cancellation noise there, so Adam trajectories cannot be re-joined from digests; the likelihood itself is pinned
+    against float64 in test_continuous_bernoulli_normaliser_vs_float64."""
     from conftest import variant_of, variant_inputs
     gold = load_golden(name)
     meta, kw, cfg_kw = variant_of(gold)
@@ -1778,6 +1781,39 @@ def test_fused_forward_only_decode(gpu_device, case, fused):
         big = model.decode(zz, batch_size=4096)
         small = ref.decode(zz[:64])
         np.testing.assert_allclose(big[:64].numpy(), small.numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_continuous_bernoulli_normaliser_vs_float64(gpu_device, fused):
+    """ ContinuousBernoulli's log-normaliser log C(p) = log(2 atanh(1 - 2p) / (1 - 2p)) and its derivative
+    cancel catastrophically at p -> 1/2 — where every pixel of a fresh model sits; the kernels use series in (1 - 2p)^2 there
+    (pv_common.h: pv_cbern).  Pinned DIRECTLY against float64: a decoder whose output weights are zero emits the same logit
+    a = out.bias for every pixel; sweep a through 0, the series / closed-form switch (|1 - 2p| = 0.3 at a = 0.619) and the
+    saturated tails, and compare sum log p(x | z) and d loss / d out.bias with torch.distributions in float64
+    (utils/prob.py:27: ContinuousBernoulli(probs=sigmoid(a)))."""
+    inv = ["r"] if fused else None
+    model = pv.models.iVAE((8, 8), 2, inv, seed=1, device="cuda", sampler_d="continuous_bernoulli")
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(9, 8, 8, generator=g)
+    eps = torch.randn(9, model.z_dim, generator=g)
+    # (|a| <= 4: further out fp32's resolution of 1 - p, not the normaliser, sets the error — in the reference's fp32 too)
+    for a in (0.0, 1e-6, -1e-4, 3e-3, -2e-2, 0.3, -0.6, 0.619, 0.63, -1.5, 2.5, -4.0, 4.0):
+        with torch.no_grad():
+            model.decoder.out.weight.zero_()
+            model.decoder.out.bias.fill_(a)
+        eng = model.engine(fused=fused)
+        eng.loss_and_grads(x.cuda(), eps.cuda())
+        s = eng.scalars.cpu().numpy()
+        ad = torch.full((9, 64), a, dtype=torch.float64, requires_grad=True)
+        d = torch.distributions.ContinuousBernoulli(probs=torch.sigmoid(ad), validate_args=False)
+        ll = d.log_prob(x.reshape(9, 64).double()).sum()
+        (-ll).backward()
+        # (a pixel's log-probability is -BCE + log C: two O(0.69) fp32 numbers that nearly cancel around p = 1/2, so one
+        #  fp32 ulp of either — 6e-8 — is the floor per pixel: 576 pixels -> 7e-5 absolute)
+        np.testing.assert_allclose(s[1], ll.item(), rtol=2e-6 if abs(a) < 1 else 2e-5, atol=576 * 1.2e-7, err_msg="sum log p(x|z) at logit %g" % a)
+        gb = eng.grad_of("decoder.out.bias").cpu().double().sum().item()
+        ref = ad.grad.sum().item()
+        assert abs(gb - ref) <= 2e-5 * max(1.0, abs(ref)) + 2e-4, "d loss / d out.bias at logit %g: %.8g vs %.8g" % (a, gb, ref)
 
 
 def test_conv_weight_range_switches_kernels(gpu_device):
