@@ -1,5 +1,5 @@
 """
-_pyro_programs.py — `model()` / `guide()` of iVAE, jiVAE and VED as real Pyro programs, for users who have pyro-ppl
+_pyro_programs.py — `model()` / `guide()` of iVAE, jiVAE, VED and (round 3) the two semi-supervised models as real Pyro programs, for users who have pyro-ppl
 ("an optional `import pyro` path").  Pyro is NOT a dependency of this build and nothing on the HIP training
 path imports this module's `pyro`: `trainers.SVItrainer` runs the same objectives in the library's fused kernels.  The
 programs exist so that a Pyro user can hand `model.model` / `model.guide` to `pyro.infer.SVI`, `poutine.trace`, custom
@@ -8,7 +8,7 @@ networks then run as differentiable operators over the library's HIP GEMMs (`pyr
 transform and the likelihood in PyTorch on the device.
 
 Site names, plates, scales and tensor shapes follow the reference's programs (models/ivae.py:165-221,
-models/jivae.py:152-220, models/ved.py:122-163) so that traces are interchangeable.  Checked on the GPU under the test
+models/jivae.py:152-220, models/ved.py:122-163, models/ssivae.py:153-248, models/ss_reg_ivae.py:156-246) so that traces are interchangeable.  Checked on the GPU under the test
 suite's stand-in `pyro` (tests/golden/_minipyro.py) against the fused HIP objective (tests/test_gpu_pyro_programs.py).
 """
 import torch
@@ -160,3 +160,79 @@ def ved_model(m, x=None, y=None, **kwargs):
             z = pyro.sample("z", dist.Normal(x.new_zeros(b, m.z_dim), x.new_ones(b, m.z_dim)).to_event(1))
         loc = m.decoder(z)
         pyro.sample("obs", _likelihood(m, dist, loc.flatten(1)).to_event(1), obs=y.flatten(1))
+
+
+# ------------------------------------------------------------------------------------------------ ssiVAE / ss_reg_iVAE
+def _ss_label_prior(m, dist, xs):
+    """p(y): uniform over the classes (ssivae.py:183-185) or N(0, reg_sig) (ss_reg_ivae.py:183-186)."""
+    b = xs.shape[0]
+    if hasattr(m, "num_classes"):
+        return dist.OneHotCategorical(xs.new_ones(b, m.num_classes) / m.num_classes)
+    return dist.Normal(xs.new_zeros(b, m.reg_dim), m.reg_sig).to_event(1)
+
+
+def _ss_label_guide(m, dist, out):
+    """q(y|x) from the label network's output: OneHotCategorical(alpha) / N(c, reg_sig)."""
+    if hasattr(m, "num_classes"):
+        return dist.OneHotCategorical(out)
+    return dist.Normal(out, m.reg_sig).to_event(1)
+
+
+def ss_model(m, xs, ys=None, **kwargs):
+    """p(x|z,y) p(y) p(z) (models/ssivae.py:153-190, models/ss_reg_ivae.py:156-193).  With the label enumerated in parallel
+    by the guide (classification, unlabeled batch) ys is (K, B, K) and the decoder runs on K * B rows."""
+    pyro, dist = _pyro()
+    pyro.module("ss_vae", m)
+    beta = kwargs.get("scale_factor", 1.)
+    b = xs.shape[0]
+    with pyro.plate("data"):
+        with pyro.poutine.scale(scale=beta):
+            zs = pyro.sample("z", dist.Normal(xs.new_zeros(b, m.z_dim), xs.new_ones(b, m.z_dim)).to_event(1))
+        ys = pyro.sample("y", _ss_label_prior(m, dist, xs), obs=ys)
+        c = ys.shape[-1]
+        lead = ys.shape[:-1]                               # (B,) or, enumerated, (K, B)
+        yr = ys.reshape(-1, c)
+        zr = zs.reshape(-1, zs.shape[-1])                  # (enumerated: the guide's z is (K, B, z) — split_latent's view(-1, z))
+        if zr.shape[0] != yr.shape[0]:
+            zr = zr.repeat(yr.shape[0] // zr.shape[0], 1)
+        if m.coord > 0:
+            xc, zc = _transformed_grid(m, zr)
+            loc = m.decoder(xc, [zc, yr])
+        else:
+            loc = m.decoder([zr, yr])
+        loc = loc.reshape(*lead, -1)
+        pyro.sample("x", _likelihood(m, dist, loc).to_event(1), obs=xs.flatten(1))
+
+
+def ss_guide(m, xs, ys=None, **kwargs):
+    """q(z|y,x) q(y|x) (models/ssivae.py:192-211, models/ss_reg_ivae.py:195-212)."""
+    pyro, dist = _pyro()
+    beta = kwargs.get("scale_factor", 1.)
+    with pyro.plate("data"):
+        if ys is None:
+            ys = pyro.sample("y", _ss_label_guide(m, dist, m.encoder_y(xs)))
+        if ys.dim() > 2:                                   # enumerated label (K, B, K): the z-encoder sees K * B rows
+            k = ys.shape[0]
+            loc, scale = m.encoder_z([xs.flatten(1).repeat(k, 1), ys.reshape(-1, ys.shape[-1])])
+            loc, scale = loc.reshape(k, xs.shape[0], -1), scale.reshape(k, xs.shape[0], -1)
+        else:
+            loc, scale = m.encoder_z([xs.flatten(1), ys])
+        with pyro.poutine.scale(scale=beta):
+            pyro.sample("z", dist.Normal(loc, scale).to_event(1))
+
+
+def ss_model_aux(m, xs, ys=None, **kwargs):
+    """The auxiliary (supervised) objective (models/ssivae.py:215-228, models/ss_reg_ivae.py:226-240)."""
+    pyro, dist = _pyro()
+    pyro.module("ss_vae", m)
+    with pyro.plate("data"):
+        mult = kwargs.get("aux_loss_multiplier", 20)
+        if ys is not None:
+            out = m.encoder_y(xs)
+            with pyro.poutine.scale(scale=mult):
+                pyro.sample("y_aux", _ss_label_guide(m, dist, out), obs=ys)
+
+
+def ss_guide_aux(m, xs, ys=None, **kwargs):
+    """Dummy guide of the auxiliary objective (models/ssivae.py:230-234)."""
+    return None

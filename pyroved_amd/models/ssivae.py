@@ -5,8 +5,8 @@ regression).  Same constructor signatures, sub-module names (encoder_z, encoder_
 parameter initialisation order and inference API (classifier / regressor, encode, decode, manifold2d,
 manifold_traversal, set_classifier / set_regressor).
 
-`model` / `guide` / `model_aux` / `guide_aux` are Pyro programs in the reference; the objectives they define are evaluated
-by the HIP library through trainers.auxSVItrainer (engine_ss.SSEngine).
+`model` / `guide` / `model_aux` / `guide_aux` are Pyro programs in the reference and (for users with pyro-ppl) here;
+trainers.auxSVItrainer evaluates the objectives they define in the HIP library (engine_ss.SSEngine).
 """
 from typing import Optional, Tuple, Union, Type, List
 
@@ -46,11 +46,24 @@ class _ssBase(baseVAE):
             self._engine.configure(**kw)      # an engine made earlier (encode, a previous trainer) takes the new settings
         return self._engine
 
+    # model / guide / model_aux / guide_aux: real Pyro programs for users who have pyro-ppl (models/_pyro_programs.py; same
+    # sites, plates and scales as models/ssivae.py:153-234 and models/ss_reg_ivae.py:156-246); auxSVItrainer never goes
+    # through them — it evaluates the same objectives in the HIP library (engine_ss.SSEngine)
     def model(self, xs, ys=None, **kwargs):
-        raise NotImplementedError("model() is a Pyro program in the reference; this build evaluates the same objective in "
-                                  "HIP kernels — train with trainers.auxSVItrainer")
+        from ._pyro_programs import ss_model
+        return ss_model(self, xs, ys, **kwargs)
 
-    guide = model_aux = guide_aux = model
+    def guide(self, xs, ys=None, **kwargs):
+        from ._pyro_programs import ss_guide
+        return ss_guide(self, xs, ys, **kwargs)
+
+    def model_aux(self, xs, ys=None, **kwargs):
+        from ._pyro_programs import ss_model_aux
+        return ss_model_aux(self, xs, ys, **kwargs)
+
+    def guide_aux(self, xs, ys=None, **kwargs):
+        from ._pyro_programs import ss_guide_aux
+        return ss_guide_aux(self, xs, ys, **kwargs)
 
     def split_latent(self, zs: torch.Tensor) -> Tuple[torch.Tensor]:
         """Split a latent variable into the transformation parts and the content (ssivae.py:203-213)."""

@@ -133,6 +133,79 @@ def test_trainer_with_pyro_objects_runs_the_pyro_route(gpu_device, minipyro):
     np.testing.assert_allclose(hist[0], hist[1], rtol=1e-4)
 
 
+@pytest.mark.parametrize("task,inv", [("classification", ["r", "t"]), ("classification", None), ("regression", ["t", "s"])])
+def test_semisupervised_programs_match_the_hip_objectives(gpu_device, minipyro, task, inv):
+    """(round 3) model / guide / model_aux / guide_aux of ssiVAE and ss_reg_iVAE as Pyro programs (reference:
+    models/ssivae.py:153-234, models/ss_reg_ivae.py:156-246) against the three objectives auxSVItrainer evaluates in the
+    HIP library (engine_ss.SSEngine): the labeled ELBO step, the unlabeled ELBO step (classification: the guide's label
+    enumerated in parallel under TraceEnum_ELBO; regression: a reparameterised label) and the auxiliary supervised loss —
+    loss and every parameter gradient, on the noise the programs drew."""
+    b, dim, data_dim = 5, 3, (8, 8)
+    if task == "classification":
+        model = pv.models.ssiVAE(data_dim, 2, dim, inv, seed=2, device="cuda")
+        ys = torch.zeros(b, dim, device="cuda")
+        ys[torch.arange(b), torch.arange(b) % dim] = 1.0
+    else:
+        model = pv.models.ss_reg_iVAE(data_dim, 2, dim, inv, seed=2, device="cuda")
+        ys = torch.rand(b, dim, generator=torch.Generator().manual_seed(5)).cuda()
+    x = make_x("rand", b, data_dim).cuda()
+    eng = model.engine()
+
+    def pyro_grads():
+        g = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+        for p_ in model.parameters():
+            p_.grad = None
+        return g
+
+    def check(grads, what, tol=3e-4):
+        for n, gref in grads.items():
+            if gref.abs().max() == 0:
+                assert eng.grad_of(n).abs().max().item() == 0, "%s: %s" % (what, n)
+            else:
+                assert rel_l2(eng.grad_of(n), gref) < tol, "%s: %s" % (what, n)
+
+    # (1) labeled batch: Trace_ELBO(model, guide)(xs, ys)
+    torch.manual_seed(3)
+    loss, _ = minipyro.Trace_ELBO().loss_and_grads(model.model, model.guide, x, ys, scale_factor=1.5)
+    eps = guide_eps(minipyro.tap(), "z")
+    grads = pyro_grads()
+    eng.grad.zero_()
+    got = eng.elbo_loss_and_grads(x, eps, ys, beta=1.5)
+    np.testing.assert_allclose(got.item(), loss.item(), rtol=2e-5)
+    check(grads, "labeled ELBO")
+    # (2) unlabeled batch
+    torch.manual_seed(4)
+    if task == "classification":
+        elbo = minipyro.TraceEnum_ELBO(max_plate_nesting=1)
+        loss, _ = elbo.loss_and_grads(model.model, minipyro.config_enumerate(model.guide, "parallel", expand=True), x)
+        tap = minipyro.tap()
+        assert tap["sites"]["guide.y"].shape == (dim, b, dim)
+        eps = guide_eps(tap, "z")                                     # (K, B, z)
+        grads = pyro_grads()
+        eng.grad.zero_()
+        got = eng.elbo_loss_and_grads(x, eps)
+        tol = 5e-3                                                    # (class-probability gradients: differences of per-class ELBOs)
+    else:
+        loss, _ = minipyro.Trace_ELBO().loss_and_grads(model.model, model.guide, x)
+        tap = minipyro.tap()
+        fy = tap["guide_fns"]["y"].base_dist
+        eps_y = ((tap["sites"]["guide.y"] - fy.loc.detach()) / fy.scale).contiguous()
+        eps = guide_eps(tap, "z")
+        grads = pyro_grads()
+        eng.grad.zero_()
+        got = eng.elbo_loss_and_grads(x, eps, None, eps_y)
+        tol = 3e-4
+    np.testing.assert_allclose(got.item(), loss.item(), rtol=2e-5)
+    check(grads, "unlabeled ELBO", tol)
+    # (3) auxiliary loss
+    loss, _ = minipyro.Trace_ELBO().loss_and_grads(model.model_aux, model.guide_aux, x, ys, aux_loss_multiplier=7.0)
+    grads = pyro_grads()
+    eng.grad.zero_()
+    got = eng.aux_loss_and_grads(x, ys, 7.0)
+    np.testing.assert_allclose(got.item(), loss.item(), rtol=2e-5)
+    check(grads, "auxiliary loss")
+
+
 def test_programs_need_pyro(gpu_device):
     if "pyro" in sys.modules:
         pytest.skip("a pyro module is importable here")
