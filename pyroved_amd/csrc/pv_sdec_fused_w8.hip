@@ -253,7 +253,9 @@ __device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16*
     bf16x8 a[2], b[4];
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
-      const int off = koff + 32 * jp + 16 * s_;
+      // (the wave holds its two row blocks ROTATED by kh — a[s] / accW[s] are row block s ^ kh — so that its bias block is
+      //  always operand 0: no wave-uniform select between register operands, 8 v_cndmask per k-step)
+      const int off = koff + 32 * jp + 16 * (s_ ^ kh);
       a[s_] = w8_cat(w8_tr(sa + off), w8_tr(sa + off + 16 * LDS2));
     }
 #pragma unroll
@@ -262,7 +264,7 @@ __device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16*
       b[o] = w8_cat(w8_tr(sb + off), w8_tr(sb + off + 16 * LDS2));
     }
     W8_FENCE();
-    accB = MFMA32(kh ? a[1] : a[0], ones, accB);
+    accB = MFMA32(a[0], ones, accB);
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -686,8 +688,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
       for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16s + 4q + i][64kh + 16o + r]
-          const int e = (32 * jp + 16 * s_ + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
+          // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16 (s ^ kh) + 4q + i][64kh + 16o + r]  (w8_wgrad_consume's rotation)
+          const int e = (32 * jp + 16 * (s_ ^ kh) + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
           rec[e] = accW1[s_][o][i] * W8_RC;
           rec[FD_H * FD_H + e] = accW2[s_][o][i];
         }
