@@ -933,10 +933,8 @@ static int decode_fused_run(const pv_ivae_plan* lay, const float* z, float angle
   f.lik = PV_LIK_GAUSSIAN; f.sigmoid_out = lay->sigmoid_out; f.sig = 1.0f;      // loc = sigmoid(a) or a
   const int grid = pv_sdec_fused_grid(f.units);
   if (lay->fused == 1) return pv_sdec_fused_launch(f, grid, false, s);
-  const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, false, true);
   f.hz_scale = 0.0f;                                   // hz is written unscaled here; the 8-wave kernels scale it themselves
-  (void)prep;
-  PV_TRY(pv_sdec_fused_bf16_prep(f, false, true, s));
+  PV_TRY(pv_sdec_fused_bf16_prep(f, false, true, s));  // weight images (pre-scaled or not: the launch below makes the same choice)
   return pv_sdec_fused_bf16_launch(f, grid, false, true, s);
 }
 
