@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 12
+#define PV_ABI_VERSION 13
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -217,6 +217,15 @@ int pv_version(void);
  * (checked at bind time and every 64 steps; Adam moves a weight by at most lr per step).  No reference counterpart: the
  * reference's nn.Conv2d is plain fp32 (nets/conv.py:24-60). */
 void pv_conv_set_wide_weights(int on);
+
+/* (v13) Steps of models with a convolutional encoder (VED, iVAE + convEncoderNet) enqueue the weight gradients of the
+ * encoder's kernel-3 convolutions, the decoder's batched weight gradients and their split-order reductions on a second,
+ * low-priority stream the library creates per device; the input-gradient chain stays on the caller's stream, which
+ * waits for the side stream before the entry point's last launches (nothing is left running that the caller's stream
+ * does not wait for; results are bit-identical either way).  on = 0 keeps everything on the caller's stream — e.g. while
+ * the caller captures its stream into a graph it does not want forked; on = 1 restores the default (also: PV_NO_SIDE=1 in
+ * the environment).  No reference counterpart: the reference runs every op on torch's current stream. */
+void pv_set_side_stream(int on);
 
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
  * layer widths).  Returns < 0 on an unsupported plan. */

@@ -13,7 +13,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 12
+PV_ABI_VERSION = 13
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -120,6 +120,7 @@ class pv_mlp_plan(C.Structure):
 SIGNATURES = {
     "pv_version": (C.c_int, []),
     "pv_conv_set_wide_weights": (None, [C.c_int]),
+    "pv_set_side_stream": (None, [C.c_int]),
     "pv_ivae_workspace_bytes": (C.c_int64, [C.POINTER(pv_ivae_plan)]),
     "pv_ivae_workspace_bytes_for": (C.c_int64, [C.POINTER(pv_ivae_plan), C.c_int]),
     "pv_ved_workspace_bytes": (C.c_int64, [C.POINTER(pv_ved_plan)]),

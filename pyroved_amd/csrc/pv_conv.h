@@ -22,12 +22,20 @@ struct PvK1Batch { PvK1Wg e[PV_K1_BATCH]; int n; };
 int pv_k1_wgrad_flush(PvK1Batch* b, hipStream_t s);
 // k1b != null: register-fed weight gradients whose partials live in the list are RECORDED there instead of launched — their g
 // and input buffers must stay untouched until pv_k1_wgrad_flush (before pv_wgrad_finish_all)
-struct PvFinishList { PvFinishEntry e[16]; int n; char* base; int64_t off, cap; PvK1Batch* k1b; };
+// st[k]: the stream entry k's partials are written on (two-stream steps, pv_side.h)
+struct PvFinishList { PvFinishEntry e[16]; int n; char* base; int64_t off, cap; PvK1Batch* k1b; hipStream_t st[16]; };
 // ws / ws_bytes for a weight gradient needing `need` bytes: a slice of the list's region (returns true: deferred) or the caller's
 bool pv_wgrad_ws(PvFinishList* list, int64_t need, void*& ws, int64_t& ws_bytes);
+// would pv_wgrad_ws(list, need, ...) defer?
+inline bool pv_wgrad_defers(const PvFinishList* list, int64_t need) {
+  return list && list->base && list->n < 16 && list->off + need <= list->cap;
+}
 int pv_wgrad_finish(PvFinishList* list, const float* part, int nsplit, int64_t n, float* out, const float* part_b, int nb,
                     float* out_b, hipStream_t s);
 int pv_wgrad_finish_all(PvFinishList* list, hipStream_t s);
+// the reductions recorded so far as one launch on `s` (which first waits for every other stream that writes their partials);
+// the list stays open — later entries keep taking fresh slices of its region — and pv_wgrad_finish_all closes it
+int pv_wgrad_finish_flush(PvFinishList* list, hipStream_t s);
 
 int pv_maxpool2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s);
 // eg_act != NONE: din *= act'(in) (in = the pooled tensor = the producing conv's post-activation output)

@@ -8,6 +8,7 @@
 //   ncs <-> nsc          ((B, C, S) <-> (B, S, C) transposes at the torch-layout boundaries)
 //   act_bwd              (dY *= act'(Y) in place)
 #include "pv_common.h"
+#include "pv_side.h"
 #include "pv_conv.h"
 
 #define CONV_THREADS 256
@@ -287,7 +288,11 @@ int pv_maxpool2_bwd(const float* in, const float* dout, float* din, int B, int H
 int pv_maxpool2_bwd_code(const float* g, const float* y_pooled, const unsigned char* code, float* din, int B, int Hp, int Wp, int C,
                          int eg_act, hipStream_t s) {
   if (C % 4 != 0 || eg_act == PV_ACT_GELU) return PV_EINVAL;
-  CONV_LAUNCH(pv_maxpool2_bwd_code_kernel, (int64_t)B * Hp * Wp * (C / 4), g, y_pooled, code, din, B, Hp, Wp, C, eg_act);
+  const int64_t n = (int64_t)B * Hp * Wp * (C / 4);
+  // (a side-stream weight gradient may wait for this launch: it carries the fork event when one is armed)
+  if (n > 0) PV_LAUNCH_FORK(pv_maxpool2_bwd_code_kernel, dim3(conv_blocks(n)), dim3(CONV_THREADS), 0, s, g, y_pooled, code, din, B, Hp, Wp, C, eg_act);
+  PV_LAUNCH_CHECK();
+  return 0;
 }
 int pv_upsample2_fwd(const float* in, float* out, int B, int H, int W, int C, int nd, hipStream_t s) {
   CONV_LAUNCH(pv_upsample2_fwd_kernel, (int64_t)B * 2 * H * (nd == 2 ? 2 * W : 1) * C, in, out, B, H, W, C, nd);

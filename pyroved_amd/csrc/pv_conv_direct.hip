@@ -13,6 +13,7 @@
 // The weights come pre-tiled ([co tile][chunk][tap][64][16], zero-padded) from pv_conv3_wprep, which also does the
 // flip / role swap of the dgrad form, so staging them is a straight 16-byte copy.
 #include "pv_common.h"
+#include "pv_side.h"
 #include "pv_conv.h"
 #include <stdlib.h>
 
@@ -252,7 +253,7 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
     static int res_env = -1;
     if (res_env < 0) { const char* e_ = getenv("PV_RES1D"); res_env = (e_ && atoi(e_) != 0) ? 1 : 0; }
     const int nchr = (res_env && nd == 1 && C / 32 <= 4) ? C / 32 : 0;
-#define CB_LAUNCH(F, N) hipLaunchKernelGGL((pv_conv3_direct_bf16_kernel<F, N>), gridb, dim3(256), ldsb, s, p)
+#define CB_LAUNCH(F, N) PV_LAUNCH_FORK((pv_conv3_direct_bf16_kernel<F, N>), gridb, dim3(256), ldsb, s, p)   /* (carries an armed fork event: pv_side.h) */
     if (use_bf16 == 2) {
       if (nchr == 4) CB_LAUNCH(true, 4); else if (nchr == 3) CB_LAUNCH(true, 3); else if (nchr == 2) CB_LAUNCH(true, 2);
       else if (nchr == 1) CB_LAUNCH(true, 1); else CB_LAUNCH(true, 0);
@@ -265,7 +266,7 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
     return 0;
   }
   const size_t lds = (size_t)(3 * CD_TN * CD_KC + npix * CD_KC) * sizeof(float);
-  hipLaunchKernelGGL(pv_conv3_direct_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt), dim3(256), lds, s, p);
+  PV_LAUNCH_FORK(pv_conv3_direct_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)nt), dim3(256), lds, s, p);
   PV_LAUNCH_CHECK();
   return 0;
 }
@@ -447,6 +448,7 @@ int pv_wgrad_finish(PvFinishList* list, const float* part, int nsplit, int64_t n
     E.part = part; E.out = out; E.part_b = part_b; E.out_b = out_b; E.n = n; E.nsplit = nsplit; E.nb = nb;
     E.nblk = (int)((n + og - 1) / og + (nb ? (nb + og - 1) / og : 0));
     E.blk0 = list->n ? list->e[list->n - 1].blk0 + list->e[list->n - 1].nblk : 0;
+    list->st[list->n] = s;
     ++list->n;
     return 0;
   }
@@ -456,18 +458,35 @@ int pv_wgrad_finish(PvFinishList* list, const float* part, int nsplit, int64_t n
   return 0;
 }
 
-int pv_wgrad_finish_all(PvFinishList* list, hipStream_t s) {
+static int wgrad_finish_launch(PvFinishList* list, hipStream_t s) {
   if (!list || list->n == 0) return 0;
   FinTab t{};
   t.n = list->n;
   for (int k = 0; k < list->n; ++k) t.e[k] = list->e[k];
   const int total = list->e[list->n - 1].blk0 + list->e[list->n - 1].nblk;
   list->n = 0;
-  list->off = 0;
   if (total < 1) return 0;
-  hipLaunchKernelGGL(pv_wgrad_finish_table_kernel, dim3((unsigned)total), dim3(256), 0, s, t);
+  PV_LAUNCH_FORK(pv_wgrad_finish_table_kernel, dim3((unsigned)total), dim3(256), 0, s, t);   // (carries an armed join event: pv_side.h)
   PV_LAUNCH_CHECK();
   return 0;
+}
+
+int pv_wgrad_finish_all(PvFinishList* list, hipStream_t s) {
+  if (!list) return 0;
+  PV_TRY(wgrad_finish_launch(list, s));
+  list->off = 0;
+  return 0;
+}
+
+int pv_wgrad_finish_flush(PvFinishList* list, hipStream_t s) {
+  if (!list || list->n == 0) return 0;
+  for (int k = 0; k < list->n; ++k) {                 // one wait per other stream
+    if (list->st[k] == s) continue;
+    bool seen = false;
+    for (int j = 0; j < k; ++j) seen = seen || list->st[j] == list->st[k];
+    if (!seen) PV_TRY(pv_stream_after(s, list->st[k]));
+  }
+  return wgrad_finish_launch(list, s);
 }
 
 static int wgd_splits(int B, int H, int W, int C, int Cout, int nd) {

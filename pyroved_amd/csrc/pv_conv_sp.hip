@@ -19,6 +19,7 @@
 // {q^1: r in 4-11} (MI355X_MICROARCH.md, LDS), so the 16-byte slot of a row is XORed with 2*(bit 3 of the fragment row) —
 // for the patch that is the parity of the patch line — which makes every fragment read conflict-free.
 #include "pv_common.h"
+#include "pv_side.h"
 #include "pv_conv.h"
 #include <stdlib.h>
 
@@ -624,8 +625,9 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
   if constexpr (F16) {
     if (sp_pair_capture_fwd(q, (p.Cout <= 32 || q.halves == 2) ? 2 : 4, grid, lds)) return 0;      // (launched by pv_conv3_sp_pair_flush)
   }
-  if (p.Cout <= 32 || q.halves == 2) hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 2, F16>), grid, dim3(256), lds, s, q);
-  else hipLaunchKernelGGL((pv_conv3_sp_kernel<NS, 4, F16>), grid, dim3(256), lds, s, q);
+  // (PV_LAUNCH_FORK: an input gradient whose result a side-stream weight gradient waits for carries the fork event)
+  if (p.Cout <= 32 || q.halves == 2) PV_LAUNCH_FORK((pv_conv3_sp_kernel<NS, 2, F16>), grid, dim3(256), lds, s, q);
+  else PV_LAUNCH_FORK((pv_conv3_sp_kernel<NS, 4, F16>), grid, dim3(256), lds, s, q);
   PV_LAUNCH_CHECK();
   return 0;
 }

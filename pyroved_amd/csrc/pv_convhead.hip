@@ -8,6 +8,7 @@
 //                          convolution's activation backward folded in)
 //   wgrad     dw[j][c*S + s] = sum_b dhead[b][j] a[b][s*C + c],  db[j] = sum_b dhead[b][j]
 #include "pv_common.h"
+#include "pv_side.h"
 #include "pv_conv.h"
 #include <stdlib.h>
 
@@ -158,7 +159,11 @@ int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act
   if (!pv_convhead_supported(F, out) || act == PV_ACT_GELU) return PV_EINVAL;
   int64_t nb = ((int64_t)B * (F / 4) + 255) / 256;
   if (nb > 16384) nb = 16384;
-  CH_DISPATCH(pv_convhead_bwd_kernel, dim3((unsigned)nb), dhead, wt, y, act, g, B, F, out);
+  // (the encoder's last weight gradient waits for this launch on the side stream: it carries the fork event when one is armed)
+  if (out <= 4) PV_LAUNCH_FORK(pv_convhead_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+  else if (out <= 8) PV_LAUNCH_FORK(pv_convhead_bwd_kernel<8>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+  else PV_LAUNCH_FORK(pv_convhead_bwd_kernel<16>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+  PV_LAUNCH_CHECK();
   return 0;
 }
 

@@ -7,6 +7,7 @@
 #include "pv_common.h"
 #include "pv_linear.h"
 #include "pv_conv.h"
+#include "pv_side.h"
 
 namespace pvcs {
 
@@ -129,7 +130,25 @@ struct Scratch {
   unsigned char* code2 = nullptr;                            // winners of the convolution + max-pool pairs fused further up (stack 0)
   void* ev_start = nullptr; void* ev_stop = nullptr;         // measurement: events around op `ev_op` of stack 0's forward
   int ev_op = -1;
+  // two-stream steps (pv_side.h).  side != null: the split-operand weight gradients of stack_bwd are enqueued there (each
+  // after the launches on the main stream that produce its g; the CALLER joins before the finish) — needs per-op gradient
+  // buffers (stack_bwd's gown), since nothing on the main stream waits for them.  wt_join != null && *wt_join: the step's
+  // weight tilings are still running on `side`; stack_fwd joins before the first op that reads them.
+  hipStream_t side = nullptr;
+  bool* wt_join = nullptr;
+  bool fork_after = false;       // stack_bwd: the stack's LAST input-gradient launch carries a fork event (the caller calls pv_fork_to)
+  bool* side_joined = nullptr;   // stack_bwd sets it when it has joined the side stream itself (after its flush of the reductions)
 };
+inline int join_tilings(const Scratch& sc, hipStream_t s) {
+  if (sc.wt_join && *sc.wt_join) { *sc.wt_join = false; return pv_stream_after(s, sc.side); }
+  return 0;
+}
+// a layer's weight + input gradient in one launch (pv_conv3_sp_pair) although a side stream is there (PV_SIDE_PAIR=1, A/B)
+inline bool side_keeps_pairs() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PV_SIDE_PAIR"); v = (e && atoi(e) != 0) ? 1 : 0; }
+  return v == 1;
+}
 // the stack's heaviest split-operand kernel-3 convolution (most multiply-adds) and its algorithmic FLOPs; -1: none
 inline int heaviest_conv(const pv_op* ops, int n, int nd, int B, const Shape* sh, double* flops) {
   int best = -1;
@@ -280,8 +299,12 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     if (!g_is_pre) PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));         // g = dL/d(pre-activation)
     float* db = o.b_off >= 0 ? grads + o.b_off : nullptr;
     if (o.ksize == 3) {
+      // the split-operand weight gradient goes to the side stream when its partials land in the finish list (never in sc.ws,
+      // which the main stream keeps using)
+      const bool on_side = sc.side && pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) &&
+                           pv_wgrad_defers(sc.fin, pv_conv3_sp_wgrad_ws(B, si.H, si.W, si.C, o.cout));
       const bool pair = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) && gin && sc.fin && !sc.conv_bf16 && pv_conv3_sp_fp32_mode() == 4 &&
-                        pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE);
+                        pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE) && (!on_side || side_keeps_pairs());
       if (pair) {                                       // weight gradient + input gradient: one launch (pv_conv_sp.hip)
         pv_conv3_sp_pair_begin();
         int rc = pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, 4, sc.fin);
@@ -293,9 +316,11 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
         const int rc2 = pv_conv3_sp_pair_flush(s);
         return rc ? rc : rc2;
       }
-      if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd))
-        PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s,
+      if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd)) {
+        if (on_side) PV_TRY(pv_fork_to(sc.side, s));                // g is complete: its producer's stop event, or a record on s
+        PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, on_side ? sc.side : s,
                                  sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), sc.fin));
+      }
       else if (k3_lean_1d(nd) && (!sc.conv_bf16 || k3_lean_mixed(sc)))   // (launch by launch the mixed leg's bf16 kernel is faster)
         PV_TRY(pv_conv3_1d_wgrad_lean(g, in, B, si.H, si.C, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin));
       else if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
@@ -310,6 +335,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       // dX = conv3(dpre; taps flipped, channel roles swapped) — same spatial size, C = cout -> cin
       if (pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+        if (sc.side) pv_fork_arm();                        // the layer below may fork its weight gradient off this launch
         return pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act,
                            sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), wt_ready(sc, slot, 1));
       }
@@ -350,6 +376,7 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
                               ops[0].cout, ops[0].act, a[2], sc.code, s));
     i0 = 2;
   }
+  PV_TRY(join_tilings(sc, s));                         // (the fused first block reads the raw weights)
   for (int i = i0; i < n; ++i) {
     const bool timed = stack_id == 0 && i == sc.ev_op && sc.ev_start && sc.ev_stop;
     struct EvGuard {                     // start event now, stop event when the op's launches are enqueued
@@ -385,17 +412,31 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
   // gown != null: op i writes dL/d(a[i]) into its OWN buffer gown[i] instead of the ping-pong pair — every layer's gradient
   // then survives the whole backward, which is what recorded (batched) weight gradients need (PvFinishList::k1b)
   bool g_is_pre = g_is_pre0;                           // g already carries the last op's activation derivative
+  Scratch scl = sc;
+  if (!gown) scl.side = nullptr;                       // (ping-pong buffers are rewritten while a side-stream reader could be behind)
   const bool c1pool = stack_id == 0 && sc.code && !need_input_grad && c1pool_fusable(ops, n, nd, sh[0]);
   for (int i = n - 1; i >= 0; --i) {
+    // an armed fork event is the stop event of the launch that produced g: only a kernel-3 convolution that takes g as it
+    // is (no activation pass in between) may hand it to its side-stream weight gradient
+    if (!(scl.side && ops[i].kind == PV_OP_CONV && ops[i].ksize == 3 && g_is_pre)) pv_fork_disarm();
     if (c1pool && i == 1) {                            // g = dL/d(a[2]): the fused backward of ops 1 and 0
+      // two streams: every weight gradient recorded so far is reduced on the side stream, next to this launch
+      // (the main stream then waits for that launch's stop event: the join without a marker packet on the side stream)
+      const bool flushed = scl.side && sc.fin && sc.fin->n > 0;
+      if (flushed) { pv_fork_arm(); PV_TRY(pv_wgrad_finish_flush(sc.fin, scl.side)); }
       PV_TRY(pv_c1_convpool_bwd(g, a[2], sc.code, a[0], B, sh[0].H, sh[0].W, ops[0].cout, ops[0].act, grads + ops[0].w_off,
                                 ops[0].b_off >= 0 ? grads + ops[0].b_off : nullptr, sc.ws, sc.ws_bytes, s, sc.fin));
+      if (flushed) {
+        PV_TRY(pv_fork_to(s, scl.side));
+        if (sc.side_joined) *sc.side_joined = true;
+      }
       g = nullptr;
       break;
     }
     if (stack_id == 0 && sc.code2 && i >= 2 && convpool_fusable(ops, n, nd, i - 1, sh[i - 1])) {
       // the max-pool of a fused pair: g = dL/d(a[i + 1]) -> dL/d(pre-activation of the convolution below) from the winner bytes
-      float* gin2 = gbuf[pp];
+      float* gin2 = gown ? gown[i] : gbuf[pp];
+      if (scl.side) pv_fork_arm();
       PV_TRY(pv_maxpool2_bwd_code(g, a[i + 1], sc.code2 + code2_off(ops, n, nd, B, sh, i - 1), gin2, B, sh[i + 1].H, sh[i + 1].W,
                                   sh[i + 1].C, ops[i - 1].act, s));
       g_is_pre = true;
@@ -408,11 +449,13 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
     // the layer below is a convolution with an activation: let this op's backward apply act'(a[i]) to gin
     const int fuse_act = (i > 0 && gin && ops[i - 1].kind == PV_OP_CONV) ? ops[i - 1].act : PV_ACT_NONE;
     bool fused = false;
-    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, sc, stack_id * PV_MAX_OPS + i, s, g_is_pre,
+    if (i == 0 && sc.fork_after && gin) pv_fork_arm();
+    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, scl, stack_id * PV_MAX_OPS + i, s, g_is_pre,
                   fuse_act, &fused, g_up));
     g_is_pre = fused;
     g = gin; pp ^= 1;
   }
+  if (!sc.fork_after) pv_fork_disarm();
   if (gout) *gout = g;
   return 0;
 }

@@ -10,6 +10,7 @@
 #include "pv_sdec_fused.h"
 #include "pv_linear.h"
 #include "pv_convstack.h"
+#include "pv_side.h"
 #include "pv_conv.h"
 
 namespace {
@@ -50,6 +51,7 @@ struct Layout {
   // convolutional encoder (plan->n_enc_ops > 0): activation shapes / buffers, flattened features, gradient ping-pong
   bool enc_ext;                            // external encoder: (z_loc, z_scale) given, gradients handed back
   bool enc_conv; pvcs::Shape ces[PV_MAX_OPS + 1]; float* cea[PV_MAX_OPS + 1]; float* cfeat; float* cg[2];
+  float* ceg[PV_MAX_OPS + 1];                              // per-op gradients dL/d(cea[i]) (the weight gradients run on the side stream)
   float* ccol; int64_t cF; float* cbn; int cbn_maxC;
   pvcs::WtPlan cwtp; char* cwt;                            // the step's tiled conv-encoder weights
   unsigned char* ccode;                                    // max-pool winners of the fused first block
@@ -106,6 +108,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.enc_conv = !L.enc_ext && p->n_enc_ops > 0;
   const int n_enc = (L.enc_conv || L.enc_ext) ? 0 : p->n_enc;
   pvcs::Needs cnd;
+  for (auto& e : L.ceg) e = nullptr;
   L.cfeat = L.cg[0] = L.cg[1] = L.ccol = L.cbn = nullptr; L.cF = 0; L.cbn_maxC = 0; L.cwt = nullptr; L.ccode = nullptr; L.ccode2 = nullptr; L.chead_wt = nullptr; L.cfin_ws = nullptr; L.cfin_bytes = 0;
   if (L.enc_conv) {
     L.ces[0] = pvcs::Shape{p->enc_in_dim[0], p->enc_ndim == 2 ? p->enc_in_dim[1] : 1, 1};
@@ -120,6 +123,10 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
         pvcs::upd(cnd.scratch, pv_convhead_ws((int)B, L.cF, p->head.out_dim));
       }
       L.cg[0] = c.take(cnd.maxact); L.cg[1] = c.take(cnd.maxact);
+      if (!inference_only) {
+        const bool c1 = pvcs::c1pool_fusable(p->enc_ops, p->n_enc_ops, p->enc_ndim, L.ces[0]);   // (its backward never writes dL/d(cea[1]))
+        for (int i = 1; i < p->n_enc_ops; ++i) L.ceg[i] = (i == 1 && c1) ? nullptr : c.take(L.ces[i].elems(B));
+      }
       L.ccol = c.take(cnd.maxcol);
       pvcs::wt_layout(p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, false, L.cwtp);
       L.cwt = reinterpret_cast<char*>(c.take((L.cwtp.bytes + 3) / 4));
@@ -338,9 +345,22 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   const pvcs::Shape& fe0 = L.ces[p->n_enc_ops];
   const bool hfused = pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.chead_wt, p->head.out_dim, fe0.C, (int64_t)fe0.H * fe0.W);
-  PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s, &he,
-                       hfused ? 1 : 0));
+  // the weight tilings next to the fused first block (raw weights) on the side stream; stack_fwd joins before its first tiled op
+  hipStream_t side = pv_side_stream();
+  bool wt_join = false;
+  static const int wprep_side = getenv("PV_SIDE_WPREP") && atoi(getenv("PV_SIDE_WPREP")) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
+  if (wprep_side && side && sc.code && pvcs::c1pool_fusable(p->enc_ops, p->n_enc_ops, p->enc_ndim, L.ces[0])) {
+    PV_TRY(pv_stream_after(side, s));
+    PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, side, &he,
+                         hfused ? 1 : 0));
+    wt_join = true;
+    sc.side = side; sc.wt_join = &wt_join;
+  } else {
+    PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s, &he,
+                         hfused ? 1 : 0));
+  }
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
+  if (wt_join) { wt_join = false; PV_TRY(pv_stream_after(s, side)); }
   const pvcs::Shape& fe = L.ces[p->n_enc_ops];
   if (hfused)      // (the weight is re-indexed channels-last, not the feature map: pv_convhead.hip)
     return pv_convhead_fwd(L.cea[p->n_enc_ops], L.chead_wt, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr, L.head,
@@ -460,6 +480,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
       g_is_pre = last.kind == PV_OP_CONV && last.act != PV_ACT_GELU;
       PV_TRY(pv_convhead_wgrad(L.dhead, L.cea[p->n_enc_ops], G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, (int)B,
                                fe.H * fe.W, fe.C, hd.out_dim, ws, wsb, s));
+      if (pv_side_stream()) pv_fork_arm();             // (the last convolution's weight gradient forks off this launch)
       PV_TRY(pv_convhead_bwd(L.dhead, L.chead_wt, L.cea[p->n_enc_ops], g_is_pre ? last.act : PV_ACT_NONE, L.cg[1], (int)B, L.cF,
                              hd.out_dim, s));
     } else {
@@ -479,8 +500,14 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     wfin.base = L.cfin_ws; wfin.cap = L.cfin_bytes;
     sc.fin = &wfin;
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
+    // kernel-3 weight gradients on the side stream, the input-gradient chain on s (every op's gradient in its own buffer);
+    // joined before the finish
+    hipStream_t side = pv_side_stream();
+    bool joined = false;
+    sc.side = side; sc.side_joined = &joined;
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
-                           nullptr, sc, s, 0, g_is_pre));
+                           nullptr, sc, s, 0, g_is_pre, side ? L.ceg : nullptr));
+    if (side && !joined) PV_TRY(pv_stream_after(s, side));
     PV_TRY(pv_wgrad_finish_all(&wfin, s));
     if (fin) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
     for (int i = 0; i < n_extra; i += 4) PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s));

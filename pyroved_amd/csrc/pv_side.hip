@@ -1,0 +1,111 @@
+// pv_side.hip — the library's second HIP stream (one per device) for work that is off a step's dependent chain: the
+// convolutional encoders' weight gradients, their split-order reductions, the step's weight tilings.  A step forks work
+// onto it with pv_stream_after(side, main) and joins with pv_stream_after(main, side) before anything that depends on
+// it (and always before the entry point returns: nothing is left running on the side stream that the caller's stream
+// does not wait for).  Events come from a small ring per device; the stream has the lowest priority the device offers,
+// so the dependent chain on the caller's stream wins the dispatcher when both have workgroups pending.
+#include "pv_common.h"
+#include "pv_side.h"
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kMaxDev = 16, kEvents = 64;
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[kEvents] = {};
+  int next = 0;
+  bool tried = false;
+};
+Side g_side[kMaxDev];
+std::mutex g_mu;
+
+std::atomic<int> g_on{-1};                            // -1: not decided yet (environment), 0 / 1
+bool side_enabled() {
+  int v = g_on.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("PV_NO_SIDE");
+    v = (e && atoi(e) != 0) ? 0 : 1;
+    int expect = -1;
+    g_on.compare_exchange_strong(expect, v);
+    v = g_on.load();
+  }
+  return v == 1;
+}
+
+Side* side_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  Side& S = g_side[dev];
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!S.tried) {
+    S.tried = true;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    for (int i = 0; i < kEvents; ++i)
+      if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int k = 0; k < i; ++k) (void)hipEventDestroy(S.ev[k]);
+        (void)hipStreamDestroy(st);
+        return nullptr;
+      }
+    S.stream = st;
+  }
+  return S.stream ? &S : nullptr;
+}
+
+}  // namespace
+
+extern "C" void pv_set_side_stream(int on) { g_on.store(on ? 1 : 0); }
+
+hipStream_t pv_side_stream() {
+  if (!side_enabled()) return nullptr;
+  Side* S = side_of_current_device();
+  return S ? S->stream : nullptr;
+}
+
+namespace {
+thread_local hipEvent_t t_armed = nullptr;
+thread_local bool t_taken = false;
+hipEvent_t next_event(Side* S) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t e = S->ev[S->next];
+  S->next = (S->next + 1) % kEvents;
+  return e;
+}
+}  // namespace
+
+void pv_fork_arm() {
+  Side* S = side_of_current_device();
+  t_armed = S ? next_event(S) : nullptr;
+  t_taken = false;
+}
+void pv_fork_disarm() { t_armed = nullptr; t_taken = false; }
+hipEvent_t pv_fork_take() {
+  if (!t_armed || t_taken) return nullptr;
+  t_taken = true;
+  return t_armed;
+}
+int pv_fork_to(hipStream_t side, hipStream_t main) {
+  if (t_armed && t_taken) {
+    const hipError_t rc = hipStreamWaitEvent(side, t_armed, 0);
+    pv_fork_disarm();
+    return rc == hipSuccess ? 0 : (int)rc;
+  }
+  pv_fork_disarm();
+  return pv_stream_after(side, main);
+}
+
+int pv_stream_after(hipStream_t waiter, hipStream_t signaller) {
+  if (waiter == signaller) return 0;
+  Side* S = side_of_current_device();
+  if (!S) return PV_EINVAL;
+  hipEvent_t e = next_event(S);
+  hipError_t rc = hipEventRecord(e, signaller);
+  if (rc == hipSuccess) rc = hipStreamWaitEvent(waiter, e, 0);
+  return rc == hipSuccess ? 0 : (int)rc;
+}

@@ -8,6 +8,7 @@
 #include "pv_common.h"
 #include "pv_kernels.h"
 #include "pv_convstack.h"
+#include "pv_side.h"
 #include <stdlib.h>
 
 namespace {
@@ -32,6 +33,7 @@ struct VLayout {
   float* llrow; float* dlda; float* llb;
   float* g[2];                                         // gradient ping-pong (largest activation)
   float* dg[PV_MAX_OPS + 1];                           // the decoder's per-op gradients dL/d(da[i]) (kept for the batched weight gradients)
+  float* eg[PV_MAX_OPS + 1];                           // the encoder's per-op gradients dL/d(ea[i]) (their weight gradients run on the side stream)
   pvcs::Scratch sc;                                    // im2col / dcol scratch + GEMM split-K scratch
   pvcs::WtPlan wtp; char* wt;                          // the step's tiled conv weights (both stacks, both orientations)
   float* head_wt;                                      // features2latent's weight re-indexed channels-last (null: GEMM path)
@@ -95,6 +97,11 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B);
   L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
   for (int i = 0; i <= p->n_dec_ops; ++i) L.dg[i] = c.take(L.ds[i].elems(B));
+  {
+    const bool c1 = pvcs::c1pool_fusable(p->enc, p->n_enc_ops, p->ndim_in, L.es[0]);     // (its backward never writes dL/d(ea[1]))
+    L.eg[0] = nullptr;
+    for (int i = 1; i <= p->n_enc_ops; ++i) L.eg[i] = (i == 1 && c1) || i == p->n_enc_ops ? nullptr : c.take(L.es[i].elems(B));
+  }
   L.sc.col = c.take(nd.maxcol);
   pvcs::wt_layout(p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, false, L.wtp);
   pvcs::wt_layout(p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, true, L.wtp);
@@ -199,8 +206,22 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (p->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = p->batch, z = p->z_dim;
-  PV_TRY(ved_wt_prep(p, L, true, true, want_grads != 0, s));
+  // The step's weight tilings run on the side stream next to the fused first block (which reads the raw weights); the
+  // encoder's stack joins before its first tiled convolution.
+  hipStream_t side = pv_side_stream();
+  bool wt_join = false;
+  static const int wprep_side = getenv("PV_SIDE_WPREP") && atoi(getenv("PV_SIDE_WPREP")) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
+  if (wprep_side && side && pvcs::c1pool_fusable(p->enc, p->n_enc_ops, p->ndim_in, L.es[0]) && L.sc.code) {
+    PV_TRY(pv_stream_after(side, s));                  // (the previous step's Adam wrote the weights on s)
+    PV_TRY(ved_wt_prep(p, L, true, true, want_grads != 0, side));
+    wt_join = true;
+    L.sc.side = side; L.sc.wt_join = &wt_join;
+  } else {
+    PV_TRY(ved_wt_prep(p, L, true, true, want_grads != 0, s));
+  }
   PV_TRY(ved_encoder_fwd(p, L, p->z_loc, p->z_scale, true, s));
+  if (wt_join) { wt_join = false; PV_TRY(pv_stream_after(s, side)); }    // (a stack that never joined)
+  L.sc.wt_join = nullptr; L.sc.side = nullptr;
   PV_TRY(ved_decoder_fwd(p, L, L.z, s));
   // ---- likelihood of the target (ved.py:141-145) ----
   const Shape& od = L.ds[p->n_dec_ops];
@@ -232,15 +253,26 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   static const int k1b_env = getenv("PV_NO_K1BATCH") && atoi(getenv("PV_NO_K1BATCH")) ? 0 : 1;
   PvK1Batch k1b{};
   if (k1b_env) fin.k1b = &k1b;
+  hipStream_t side2 = k1b_env ? pv_side_stream() : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
+  L.sc.fork_after = side2 != nullptr;
   PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.g, pp, true,
                          &g, L.sc, s, 1, false, k1b_env ? L.dg : nullptr));
-  PV_TRY(pv_k1_wgrad_flush(&k1b, s));
+  L.sc.fork_after = false;
+  // The recorded decoder weight gradients and everything else off the dependent chain from here on (latent_to_features'
+  // weight gradient, the encoder's kernel-3 weight gradients) go to the side stream; the chain — latent gradient, head,
+  // the encoder's input gradients — stays on s.  Joined before the finish.
+  const bool two = side2 != nullptr;
+  side = side2;
+  hipStream_t sw = two ? side : s;
+  if (two) PV_TRY(pv_fork_to(side, s));                // after the chain's last launch (its stop event when it took one)
+  PV_TRY(pv_k1_wgrad_flush(&k1b, sw));
   fin.k1b = nullptr;
+  for (int k = 0; k < fin.n; ++k) fin.st[k] = sw;      // (recorded on s, written by the launch above)
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
   if (L.l2f_wt) {                                      // straight from the channels-last gradient
     PV_TRY(pv_l2f_wgrad(g, L.z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, (int)B,
-                        d0.H * d0.W, d0.C, (int)z, s));
+                        d0.H * d0.W, d0.C, (int)z, sw));
     PV_TRY(pv_convhead_fwd(g, L.l2f_wt, nullptr, L.dzc, (int)B, F0, (int)z, L.sc.ws, L.sc.ws_bytes, s));
   } else {
     PV_TRY(pv_nsc_to_ncs(g, L.df0, B, d0.C, (int64_t)d0.H * d0.W, s));
@@ -264,6 +296,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
                              p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, (int)B, fe.H * fe.W, fe.C, (int)(2 * z),
                              L.sc.ws, L.sc.ws_bytes, s));
     g = L.g[pp];
+    if (two) pv_fork_arm();                            // (the last convolution's weight gradient forks off this launch)
     PV_TRY(pv_convhead_bwd(L.dhead, L.head_wt, L.ea[p->n_enc_ops], fold ? last.act : PV_ACT_NONE, g, (int)B, L.F, (int)(2 * z), s));
     pp ^= 1;
     g_is_pre = fold;
@@ -279,8 +312,12 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
     pp ^= 1;
   }
   // ---- encoder ops in reverse (no input gradient for the first one) ----
+  bool joined = false;
+  L.sc.side = two ? side : nullptr; L.sc.side_joined = &joined;
   PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->enc, p->n_enc_ops, p->ndim_in, (int)B, L.ea, L.es, g, L.g, pp, false,
-                         nullptr, L.sc, s, 0, g_is_pre));
+                         nullptr, L.sc, s, 0, g_is_pre, two ? L.eg : nullptr));
+  L.sc.side = nullptr; L.sc.side_joined = nullptr;
+  if (two && !joined) PV_TRY(pv_stream_after(s, side));
   return pv_wgrad_finish_all(&fin, s);
 }
 

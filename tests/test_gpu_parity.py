@@ -1853,6 +1853,52 @@ def test_conv_weight_range_switches_kernels(gpu_device):
         IVAEEngine._wide_weights = False
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
+    """Steps of models with a convolutional encoder put the encoder's kernel-3 weight gradients, the decoder's batched
+    weight gradients and their reductions on the library's side stream (pv_side.hip; include/pyroved_amd.h
+    pv_set_side_stream).  Same kernels, same summation order: loss, every gradient and the parameters after three Adam
+    steps are BIT-identical with the side stream off — for VED (models/ved.py:122-163) and for an iVAE with
+    convEncoderNet (nets/conv.py:24-102), at a batch where every layer takes the split-operand kernels."""
+    lib = _abi.lib()
+    fused = 3 if precision == "bf16" else 2
+    g = torch.Generator().manual_seed(5)
+    xv, yv, ev = torch.rand(48, 1, 64, 64, generator=g), torch.rand(48, 1, 128, generator=g), torch.randn(48, 2, generator=g)
+    xi, ei = torch.rand(24, 64, 64, generator=g), torch.randn(24, 6, generator=g)
+
+    def run(side):
+        lib.pv_set_side_stream(side)
+        out = []
+        ved = pv.models.VED((64, 64), (128,), latent_dim=2, seed=1, device="cuda")
+        eng = ved.engine(fused=fused)
+        for _ in range(3):
+            eng.loss_and_grads(xv.cuda(), ev.cuda(), 1.0, yv.cuda())
+            out.append(eng.scalars.clone())
+            out.append(eng.grad.clone())
+            eng.adam_step()
+        out.append(eng.flat.clone())
+        iv = pv.models.iVAE((64, 64), 2, ["r", "t", "s"], seed=1, device="cuda")
+        iv.set_encoder(pv.nets.convEncoderNet((64, 64), latent_dim=6))
+        eng = iv.engine(fused=fused)
+        for _ in range(3):
+            eng.loss_and_grads(xi.cuda(), ei.cuda())
+            out.append(eng.scalars.clone())
+            out.append(eng.grad.clone())
+            eng.adam_step()
+        out.append(eng.flat.clone())
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        one, two = run(0), run(1)
+    finally:
+        lib.pv_set_side_stream(1)
+    assert len(one) == len(two)
+    for k, (a, b) in enumerate(zip(one, two)):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), "tensor %d differs between the one-stream and the two-stream step" % k
+
+
 def test_class_onehot_rejected_where_undefined(gpu_device):
     """ The sampled-class objective exists for the vanilla decoder only; a direct engine call with class_onehot
     on a jiVAE WITH invariances (fused or layered path) is refused instead of silently running the enumerated objective."""
