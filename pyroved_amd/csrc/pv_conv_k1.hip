@@ -12,6 +12,7 @@
 //     its four waves take 64-pixel register batches, partial tiles meet in LDS and go to the step's deferred-reduction
 //     table (pv_conv.h: PvFinishList) — no launch of its own for the split-order sum.
 #include "pv_common.h"
+#include "pv_side.h"
 #include "pv_conv.h"
 #include <stdlib.h>
 
@@ -176,9 +177,11 @@ static inline bool k1_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <bool WV, int NJ>
 static void k1_launch_nb(const K1Fwd& a, int nb, unsigned grid, hipStream_t s) {
-  if (nb == 4) hipLaunchKernelGGL((pv_k1_fwd_kernel<WV, NJ, 4>), dim3(grid), dim3(256), 0, s, a);
-  else if (nb == 2) hipLaunchKernelGGL((pv_k1_fwd_kernel<WV, NJ, 2>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((pv_k1_fwd_kernel<WV, NJ, 1>), dim3(grid), dim3(256), 0, s, a);
+  // (PV_LAUNCH_FORK: an input-gradient launch carries the fork event when the recorded weight gradients are about to be
+  //  flushed onto the side stream — pv_side.h)
+  if (nb == 4) PV_LAUNCH_FORK((pv_k1_fwd_kernel<WV, NJ, 4>), dim3(grid), dim3(256), 0, s, a);
+  else if (nb == 2) PV_LAUNCH_FORK((pv_k1_fwd_kernel<WV, NJ, 2>), dim3(grid), dim3(256), 0, s, a);
+  else PV_LAUNCH_FORK((pv_k1_fwd_kernel<WV, NJ, 1>), dim3(grid), dim3(256), 0, s, a);
 }
 template <bool WV>
 static void k1_launch_nj(const K1Fwd& a, int nb, unsigned grid, hipStream_t s) {
@@ -203,7 +206,7 @@ static int k1_launch(K1Fwd a, int64_t w_elems, hipStream_t s) {
   if (!xv) {
     a.ngroups = (a.N + 15) / 16;
     const int64_t units = ((a.rows + 15) / 16) * a.ngroups;
-    hipLaunchKernelGGL(pv_k1_gen_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a);
+    PV_LAUNCH_FORK(pv_k1_gen_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a);
   } else {
     static int nb_env = -1;                            // PV_K1_NB=1|2|4: 16-output blocks per wave (experiments)
     if (nb_env < 0) { const char* e_ = getenv("PV_K1_NB"); nb_env = e_ ? atoi(e_) : 0; }

@@ -143,6 +143,16 @@ inline int join_tilings(const Scratch& sc, hipStream_t s) {
   if (sc.wt_join && *sc.wt_join) { *sc.wt_join = false; return pv_stream_after(s, sc.side); }
   return 0;
 }
+// recorded (batched) weight gradients are flushed onto the side stream every k1_chunk() problems, next to the rest of the
+// input-gradient chain (PV_K1_CHUNK=n; 0: one launch after the chain)
+inline int k1_chunk() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PV_K1_CHUNK"); v = e ? atoi(e) : 5; if (v < 0) v = 0; }
+  return v;
+}
+inline bool k1_flush_due(const Scratch& sc) {
+  return sc.side && sc.fin && sc.fin->k1b && k1_chunk() > 0 && sc.fin->k1b->n >= k1_chunk();
+}
 // a layer's weight + input gradient in one launch (pv_conv3_sp_pair) although a side stream is there (PV_SIDE_PAIR=1, A/B)
 inline bool side_keeps_pairs() {
   static int v = -1;
@@ -341,6 +351,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       }
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+        if (k1_flush_due(sc)) pv_fork_arm();               // stack_bwd forks the recorded weight gradients off this launch
         return pv_conv3_direct(g, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s,
                                in, fuse_act, direct_mode(sc), wt_ready(sc, slot, 1));
       }
@@ -353,6 +364,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     if (!gin) return 0;
     // (the producing convolution's activation derivative rides in this GEMM's epilogue: act'(in), in = that layer's output)
     if (fused && fuse_act != PV_ACT_NONE) *fused = true;
+    if (k1_lean() && k1_flush_due(sc)) pv_fork_arm();
     if (k1_lean()) return pv_k1_dgrad(g, rows, o.cout, params + o.w_off, gin, o.cin, fuse_act != PV_ACT_NONE ? in : nullptr, fuse_act, s, g_up);
     return linear_dgrad(g, o.cout, params + o.w_off, gin, K, fuse_act != PV_ACT_NONE ? in : nullptr, nullptr, K, fuse_act, rows, K,
                         o.cout, sc.ws, sc.ws_bytes, s);
@@ -454,6 +466,11 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
                   fuse_act, &fused, g_up));
     g_is_pre = fused;
     g = gin; pp ^= 1;
+    if (i > 0 && k1_flush_due(scl)) {                  // (the last chunk is the caller's: it knows what else follows the chain)
+      PV_TRY(pv_fork_to(scl.side, s));
+      PV_TRY(pv_k1_wgrad_flush(sc.fin->k1b, scl.side));
+      for (int k = 0; k < sc.fin->n; ++k) sc.fin->st[k] = scl.side;   // (whatever s wrote before the fork is complete for the side stream too)
+    }
   }
   if (!sc.fork_after) pv_fork_disarm();
   if (gout) *gout = g;

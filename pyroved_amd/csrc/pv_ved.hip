@@ -255,9 +255,10 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (k1b_env) fin.k1b = &k1b;
   hipStream_t side2 = k1b_env ? pv_side_stream() : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
   L.sc.fork_after = side2 != nullptr;
+  L.sc.side = side2;                                   // (chunks of the recorded weight gradients run next to the chain)
   PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.g, pp, true,
                          &g, L.sc, s, 1, false, k1b_env ? L.dg : nullptr));
-  L.sc.fork_after = false;
+  L.sc.fork_after = false; L.sc.side = nullptr;
   // The recorded decoder weight gradients and everything else off the dependent chain from here on (latent_to_features'
   // weight gradient, the encoder's kernel-3 weight gradients) go to the side stream; the chain — latent gradient, head,
   // the encoder's input gradients — stays on s.  Joined before the finish.
