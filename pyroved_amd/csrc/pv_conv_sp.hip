@@ -177,6 +177,26 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
     const PvWprepEntry E = t.e[k];
     const int64_t e = idx - E.start;
     const int Co = E.Co, Ci = E.Ci, KK = E.KK, flip = E.flip;
+    if (E.kind == 8) {                                // pv_dec1d.hip; flip: taps reversed, channel roles swapped
+      const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+      int c, n, tp;
+      bool pad = false;
+      if ((C & 15) == 0) {                            // MFMA fragment order: [16-row block][chunk = tap * C/16 + t][lane 16 q + r][4]
+        const int kc = C >> 4, nck = KK * kc;         //   = (row 16 ob + r, column 16 t + 4 q + i): a wave's operand load is 1 KB contiguous;
+        const int G = nck >= 12 ? 8 : 4;              //   chunks padded to groups of 4 / 8 with zeros (pv_dec1d.hip d1_group)
+        const int nckp = (nck + G - 1) / G * G;
+        const int i = (int)(e & 3), lane = (int)((e >> 2) & 63), ch = (int)((e >> 8) % nckp), ob = (int)((e >> 8) / nckp);
+        pad = ch >= nck;
+        tp = pad ? 0 : ch / kc;
+        n = 16 * ob + (lane & 15); c = pad ? 0 : 16 * (ch - tp * kc) + 4 * (lane >> 4) + i;
+      } else {                                        // a contraction narrower than 16 (plain loops): dst[tap][n][c]
+        c = (int)(e % C); n = (int)((e / C) % N); tp = (int)(e / ((int64_t)C * N));
+      }
+      float v = 0.0f;
+      if (n < N && !pad) v = flip ? E.w[((int64_t)c * Ci + n) * KK + (KK - 1 - tp)] : E.w[((int64_t)n * Ci + c) * KK + tp];
+      reinterpret_cast<float*>(E.dst)[e] = v;
+      continue;
+    }
     if (E.kind == 7) {                                // latent2features: dst[k][s*C + c] = w[c*S + s][k]  (Co = z_dim, Ci = C, KK = S)
       const int64_t F = (int64_t)Ci * KK, k = e / F, f = e - k * F;
       const int sp = (int)(f / Ci), c = (int)(f - (int64_t)sp * Ci);
@@ -223,6 +243,11 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
 }
 
 static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
+  if (kind == 8) {                                   // (rows padded to 16 in fragment order)
+    const int N = flip ? Ci : Co, C = flip ? Co : Ci;
+    const int nck = KK * (C >> 4), G = nck >= 12 ? 8 : 4;
+    return (C & 15) == 0 ? (int64_t)((N + 15) / 16) * ((nck + G - 1) / G * G) * 256 : (int64_t)N * C * KK;
+  }
   if (kind == 4 || kind == 7) return (int64_t)Co * Ci * KK;
   if (kind == 5) KK = 9;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
@@ -231,7 +256,7 @@ static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
 }
 
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd) {
-  if (kind == 4 || kind == 7) return -1;             // (sized by the caller: out * F floats)
+  if (kind == 4 || kind == 7 || kind == 8) return -1;   // (sized by the caller)
   if (kind >= 2 && kind != 6) return pv_conv3_sp_wt_bytes(Ci, Co);
   return pv_conv3_direct_wt_floats(Ci, Co, nd) * (int64_t)sizeof(float);
 }

@@ -477,4 +477,20 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
   return 0;
 }
 
+// the weight gradients of a stack whose input gradients are already there (pv_dec1d_bwd): op i reads g = the gradient buffer of
+// the op above it (gown[i + 1]; gown[i + 2] un-summed when the nearest upsample after a kernel-1 convolution rides along;
+// g_out for the last op), every one of them dL/d(pre-activation) already
+inline int stack_wgrads(const float* params, float* grads, const pv_op* ops, int n, int nd, int B, float* const* a, const Shape* sh,
+                        float* g_out, float* const* gown, const Scratch& sc, hipStream_t s, int stack_id) {
+  for (int i = n - 1; i >= 0; --i) {
+    if (ops[i].kind != PV_OP_CONV) continue;
+    const int g_up = k1up_fusable(ops, n, nd, i) ? 1 : 0;
+    const int j = i + 1 + g_up;
+    float* g = j >= n ? g_out : gown[j];
+    PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, nullptr, sc, stack_id * PV_MAX_OPS + i, s, true,
+                  PV_ACT_NONE, nullptr, g_up));
+  }
+  return 0;
+}
+
 }  // namespace pvcs

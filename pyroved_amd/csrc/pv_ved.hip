@@ -9,6 +9,7 @@
 #include "pv_kernels.h"
 #include "pv_convstack.h"
 #include "pv_side.h"
+#include "pv_dec1d.h"
 #include <stdlib.h>
 
 namespace {
@@ -39,6 +40,7 @@ struct VLayout {
   float* head_wt;                                      // features2latent's weight re-indexed channels-last (null: GEMM path)
   char* fin_ws; int64_t fin_bytes;                     // every weight gradient's partials until the one finish launch
   float* l2f_wt;                                       // latent2features' weight re-indexed channels-last (null: GEMM path)
+  float* d1_wt;                                        // the 1-D decoder's weights tiled for its fused launches (pv_dec1d.hip; null: not that shape)
   int64_t F;                                           // flattened feature size C*S of the encoder output
   int64_t total;
 };
@@ -86,6 +88,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   L.l2f_wt = pv_l2f_supported(F0, (int)z, L.ds[0].C) ? c.take(z * F0) : nullptr;
   if (L.l2f_wt || !base) pvcs::upd(nd.scratch, pv_convhead_ws((int)B, F0, (int)z));     // (its input gradient = pv_convhead_fwd)
   L.da[0] = c.take(B * F0);
+  L.d1_wt = pv_dec1d_supported(p->dec, p->n_dec_ops, p->ndim_out, L.ds[0].H, L.ds[0].C) ? c.take(pv_dec1d_wt_floats(p->dec, p->n_dec_ops)) : nullptr;
   pvcs::upd(nd.scratch, gemm_ws_need(B, F0, z)); pvcs::upd(nd.scratch, gemm_ws_need(F0, z, B));
   pvcs::upd(nd.scratch, gemm_ws_need(B, z, F0));
   for (int i = 0; i < p->n_dec_ops; ++i) L.da[i + 1] = c.take(L.ds[i + 1].elems(B));
@@ -121,6 +124,15 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   return true;
 }
 
+// the decoder as one forward / one input-gradient launch: a 1-D stack pv_dec1d.hip takes, its kernel-1 + upsample pairs fused
+// the way the recorded weight gradients expect
+bool dec1d_active(const pv_ved_plan* p, const VLayout& L) {
+  if (!L.d1_wt || !pv_dec1d_enabled() || !pvcs::k1_lean() || !pvcs::k3_lean_1d(p->ndim_out)) return false;
+  for (int i = 0; i + 1 < p->n_dec_ops; ++i)
+    if (p->dec[i + 1].kind == PV_OP_UPSAMPLE2 && !pvcs::k1up_fusable(p->dec, p->n_dec_ops, p->ndim_out, i)) return false;
+  return true;
+}
+
 // tile the conv weights the coming launches need: stack 0 / 1 / both, with or without the input-gradient orientation
 int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_dgrad, hipStream_t s) {
   PvWprepEntry e[4 * PV_MAX_OPS + 8];                  // both stacks' tilings: one launch
@@ -134,8 +146,13 @@ int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_
   if (dec) {
     PvWprepEntry le = pvcs::head_entry(p->params + p->l2f.w_off, L.l2f_wt, p->z_dim, L.ds[0].C, (int64_t)L.ds[0].H * L.ds[0].W);
     le.kind = 7;                                       // wt[k][s*C + c] = w[c*S + s][k]
-    pvcs::wt_entries(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, e, ne, &le,
-                     L.l2f_wt ? 1 : 0);
+    if (dec1d_active(p, L)) {                          // (its own tilings instead of the layer kernels')
+      if (L.l2f_wt) e[ne++] = le;
+      pv_dec1d_wt_entries(p->params, p->dec, p->n_dec_ops, L.d1_wt, e, ne);
+    } else {
+      pvcs::wt_entries(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, e, ne, &le,
+                       L.l2f_wt ? 1 : 0);
+    }
   }
   return ne ? pv_conv_wprep_table(e, ne, s) : 0;
 }
@@ -186,6 +203,7 @@ int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_
                       L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
     PV_TRY(pv_ncs_to_nsc(L.f0, L.da[0], B, d0.C, (int64_t)d0.H * d0.W, s));     // view(-1, C0, *dims) -> channels-last
   }
+  if (dec1d_active(p, L)) return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s);
   return pvcs::stack_fwd(p->params, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.sc, s, 1);
 }
 
@@ -254,11 +272,19 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   PvK1Batch k1b{};
   if (k1b_env) fin.k1b = &k1b;
   hipStream_t side2 = k1b_env ? pv_side_stream() : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
-  L.sc.fork_after = side2 != nullptr;
-  L.sc.side = side2;                                   // (chunks of the recorded weight gradients run next to the chain)
-  PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.g, pp, true,
-                         &g, L.sc, s, 1, false, k1b_env ? L.dg : nullptr));
-  L.sc.fork_after = false; L.sc.side = nullptr;
+  if (k1b_env && dec1d_active(p, L)) {
+    // every input gradient of the decoder in one launch (the fork event rides on it), then the weight gradients are recorded
+    if (side2) pv_fork_arm();
+    PV_TRY(pv_dec1d_bwd(p->dec, p->n_dec_ops, L.d1_wt, (int)B, L.ds[0].H, L.ds[0].C, L.da, L.dlda, L.dg, s));
+    PV_TRY(pvcs::stack_wgrads(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.dg, L.sc, s, 1));
+    g = L.dg[0];
+  } else {
+    L.sc.fork_after = side2 != nullptr;
+    L.sc.side = side2;                                 // (chunks of the recorded weight gradients run next to the chain)
+    PV_TRY(pvcs::stack_bwd(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.g, pp, true,
+                           &g, L.sc, s, 1, false, k1b_env ? L.dg : nullptr));
+    L.sc.fork_after = false; L.sc.side = nullptr;
+  }
   // The recorded decoder weight gradients and everything else off the dependent chain from here on (latent_to_features'
   // weight gradient, the encoder's kernel-3 weight gradients) go to the side stream; the chain — latent gradient, head,
   // the encoder's input gradients — stays on s.  Joined before the finish.

@@ -1899,6 +1899,42 @@ def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
         assert torch.equal(a, b), "tensor %d differs between the one-stream and the two-stream step" % k
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_1d_decoder_matches_layer_launches(gpu_device, precision):
+    """VED's Conv1d decoder (nets/conv.py:190-262: kernel-3 blocks, UpsampleBlocks, the kernel-1 output layer) runs as one
+    forward and one input-gradient launch (csrc/pv_dec1d.hip).  Against the layer-by-layer launches it replaces
+    (pv_debug_dec1d(0)): ELBO, reconstruction and every gradient agree to fp32 rounding — for the default im2spec shape, a
+    shorter spectrum with another activation, and two output channels."""
+    import ctypes as C
+    dbg = C.CDLL(_abi.LIB_PATH)
+    fused = 3 if precision == "bf16" else 2
+    g = torch.Generator().manual_seed(11)
+    cases = [((64, 64), (128,), 1, "lrelu", 20), ((32, 32), (64,), 1, "tanh", 7), ((32, 32), (32,), 2, "relu", 5)]
+    try:
+        for in_dim, out_dim, och, act, b in cases:
+            x = torch.rand(b, 1, *in_dim, generator=g)
+            y = torch.rand(b, och, *out_dim, generator=g)
+            eps = torch.randn(b, 2, generator=g)
+            res = []
+            for on in (0, 1):
+                dbg.pv_debug_dec1d(on)
+                m = pv.models.VED(in_dim, out_dim, input_channels=1, output_channels=och, latent_dim=2, activation=act,
+                                  seed=1, device="cuda")
+                eng = m.engine(fused=fused)
+                eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+                zc = torch.randn(b, 2, generator=torch.Generator().manual_seed(3))
+                res.append((eng.scalars.clone(), eng.grad.clone(), m.decode(zc)))
+            (s0, g0, d0), (s1, g1, d1) = res
+            assert torch.isfinite(g1).all()
+            np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6)
+            err = rel_l2(g1, g0)
+            # (mixed precision: the layer launches run the kernel-3 convolutions on two bf16 pieces, the fused launch in exact fp32)
+            assert err < (2e-4 if precision == "bf16" else 2e-6), "%s -> %s: gradients differ by %.2e" % (in_dim, out_dim, err)
+            assert torch.allclose(d1, d0, rtol=1e-5, atol=1e-6)
+    finally:
+        dbg.pv_debug_dec1d(-1)
+
+
 def test_class_onehot_rejected_where_undefined(gpu_device):
     """ The sampled-class objective exists for the vanilla decoder only; a direct engine call with class_onehot
     on a jiVAE WITH invariances (fused or layered path) is refused instead of silently running the enumerated objective."""
