@@ -118,6 +118,29 @@ __device__ __forceinline__ void pv_cbern(float a, float x, float& ll, float& dld
   pr_out = pr;
 }
 
+// one element of the observation likelihood (fc.py:143-152, prob.py:15-30): a = the decoder's output before the output
+// non-linearity, x = the target -> log p(x | a), dL/da of the NEGATIVE ELBO's likelihood term, loc (torch.finfo(float32).eps clamp as clamp_probs)
+__device__ __forceinline__ void pv_lik_one(float av, float xv, int lik, int sigmoid_out, float sig, float& ll, float& d, float& lv) {
+  if (lik == PV_LIK_BERNOULLI) {
+    const float pr = 1.0f / (1.0f + expf(-av));
+    const float pc = fminf(fmaxf(pr, 1.1920928955078125e-07f), 1.0f - 1.1920928955078125e-07f);
+    const float lg = logf(pc) - log1pf(-pc);
+    ll = -(fmaxf(lg, 0.0f) - lg * xv + log1pf(expf(-fabsf(lg))));
+    const float mask = (pr >= 1.1920928955078125e-07f && pr <= 1.0f - 1.1920928955078125e-07f) ? 1.0f : 0.0f;
+    d = (1.0f / (1.0f + expf(-lg)) - xv) * mask;
+    lv = pr;
+  } else if (lik == PV_LIK_CBERNOULLI) {
+    pv_cbern(av, xv, ll, d, lv);
+  } else {
+    const float pr = sigmoid_out ? 1.0f / (1.0f + expf(-av)) : av;
+    const float df = xv - pr;
+    ll = -(df * df) / (2.0f * sig * sig) - logf(sig) - 0.91893853320467274178f;
+    d = -df / (sig * sig) * (sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+    lv = pr;
+  }
+}
+
+
 __device__ __forceinline__ float pv_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

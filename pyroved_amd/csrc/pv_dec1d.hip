@@ -46,6 +46,13 @@ struct D1Args {
   int n, B;
   const float* in;       // forward: a[0] (B, L0, C0); backward: dL/d(a[n]) (B, Ln, Cn)
   int L0, C0;
+  // latent_to_features in the same launch (zd > 0).  Forward: a[0] = bias + z wt is computed here and written to a0_out;
+  // backward: dz[b][k] = <dL/d(a[0])[b], wt[k]> from the last step's result
+  const float* z; const float* l2f_wt; const float* l2f_b; float* a0_out; float* dz;
+  int zd;
+  // forward: the observation likelihood of the last step's result (y != null)
+  const float* y; float* loc; float* dlda; float* llb;
+  int lik, sigmoid_out; float sig;
 };
 
 __device__ __forceinline__ int d1_pitch(int C) { return C + 4; }
@@ -276,7 +283,25 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
       float* dst = lds + A.op[0].li;
       const int P = d1_pitch(A.C0);
       const float* src = A.in + (int64_t)b * A.L0 * A.C0;
-      if ((A.C0 & 3) == 0) {
+      if (!BWD && A.zd > 0) {                          // latent_to_features: the input is computed, not read (C0 % 16 == 0)
+        const int c4n = A.C0 >> 2;
+        const int64_t F = (int64_t)A.L0 * A.C0;
+        float zv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) zv[k] = k < A.zd ? A.z[(int64_t)b * A.zd + k] : 0.0f;
+        for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
+          const int l = e / c4n, c = 4 * (e - l * c4n);
+          f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (A.l2f_b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = A.l2f_b[(int64_t)(c + j) * A.L0 + l];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k < A.zd) v += zv[k] * *reinterpret_cast<const f32x4*>(A.l2f_wt + (int64_t)k * F + (int64_t)l * A.C0 + c);
+          *reinterpret_cast<f32x4*>(&dst[(l + 1) * P + c]) = v;
+        }
+      } else if ((A.C0 & 3) == 0) {
         const int c4n = A.C0 >> 2;
         for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
           const int l = e / c4n, c4 = e - l * c4n;
@@ -314,6 +339,70 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
           const int l = e / o.N, c = e - l * o.N;
           dst[e] = src[(l + 1) * Po + c];
         }
+      }
+    }
+    if (!BWD && A.y) {                                 // log p(y | output): elements over threads, waves and then 8 partials in order
+      const D1Op& o = A.op[A.n - 1];
+      const int Lout = o.up ? 2 * o.L : o.L, Po = d1_pitch(o.N), per = Lout * o.N;
+      const float* src = lds + o.lo;
+      float acc = 0.0f;
+      for (int e = tid; e < per; e += D1_THREADS) {
+        const int l = e / o.N, c = e - l * o.N;
+        float ll, d, lv;
+        pv_lik_one(src[(l + 1) * Po + c], A.y[(int64_t)b * per + e], A.lik, A.sigmoid_out, A.sig, ll, d, lv);
+        if (A.loc) A.loc[(int64_t)b * per + e] = lv;
+        if (A.dlda) A.dlda[(int64_t)b * per + e] = d;
+        acc += ll;
+      }
+      acc = pv_wave_sum(acc);
+      float* red = lds + o.lt;                         // (the row-pair scratch: unused by the forward)
+      if (lane == 0) red[wave] = acc;
+      pv_lds_barrier();
+      if (tid == 0) {
+        float v = 0.0f;
+        for (int w = 0; w < D1_WAVES; ++w) v += red[w];
+        A.llb[b] = v;
+      }
+    }
+    if (!BWD && A.zd > 0) {                            // the computed input goes out too (the first layer's weight gradient reads it)
+      const int P = d1_pitch(A.C0), c4n = A.C0 >> 2;
+      const float* src = lds + A.op[0].li;
+      float* dst = A.a0_out + (int64_t)b * A.L0 * A.C0;
+      for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
+        const int l = e / c4n, c4 = e - l * c4n;
+        *reinterpret_cast<f32x4*>(dst + (int64_t)l * A.C0 + 4 * c4) = *reinterpret_cast<const f32x4*>(&src[(l + 1) * P + 4 * c4]);
+      }
+    }
+    if (BWD && A.zd > 0) {                             // dz[b][k] = <g0, wt[k]>: threads over elements, waves and then 8 partials in order
+      const D1Op& o = A.op[A.n - 1];
+      const int Po = d1_pitch(o.N), c4n = o.N >> 2;
+      const float* g0 = lds + o.lo;
+      const int64_t F = (int64_t)o.L * o.N;
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+      for (int e = tid; e < o.L * c4n; e += D1_THREADS) {
+        const int l = e / c4n, c = 4 * (e - l * c4n);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&g0[(l + 1) * Po + c]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < A.zd) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(A.l2f_wt + (int64_t)k * F + (int64_t)l * o.N + c);
+            acc[k] += (g[0] * w[0] + g[1] * w[1]) + (g[2] * w[2] + g[3] * w[3]);
+          }
+      }
+      pv_lds_barrier();                                // (the row-pair scratch is free: every step is done)
+      float* red = lds + o.lt;                         // [8 waves][8]
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = pv_wave_sum(acc[k]);
+        if (lane == 0) red[wave * 8 + k] = v;
+      }
+      pv_lds_barrier();
+      if (tid < A.zd) {
+        float v = 0.0f;
+        for (int w = 0; w < D1_WAVES; ++w) v += red[w * 8 + tid];
+        A.dz[(int64_t)b * A.zd + tid] = v;
       }
     }
     D1_STAMP(2 + A.n + 1);
@@ -425,6 +514,7 @@ static int64_t lay_out(D1Args& A, bool bwd) {
     prev = d.lo;
     if (bwd && d.up && d1_rows_floats(d.L, d.K) > tmax) tmax = d1_rows_floats(d.L, d.K);
   }
+  if (tmax < 64) tmax = 64;                            // (also the 8 x 8 partials of the latent gradient)
   const int lt = (int)off;                             // one shared buffer for the row-pair sums
   off += (tmax + 3) / 4 * 4;
   for (int j = 0; j < A.n; ++j) A.op[j].lt = lt;
@@ -485,16 +575,29 @@ static int launch(D1Args& A, hipStream_t s) {
   return 0;
 }
 
-int pv_dec1d_fwd(const float* params, const pv_op* ops, int n, const float* wt, int B, int L0, int C0, float* const* a, hipStream_t s) {
+int pv_dec1d_fwd(const float* params, const pv_op* ops, int n, const float* wt, int B, int L0, int C0, float* const* a, hipStream_t s,
+                 const PvD1L2f* l2f, const PvD1Lik* lk) {
   D1Args A;
   if (!build(A, false, params, ops, n, wt, B, L0, C0, a, nullptr, nullptr)) return PV_EINVAL;
+  if (lk) {
+    if (!lk->y || !lk->llb) return PV_EINVAL;
+    A.y = lk->y; A.loc = lk->loc; A.dlda = lk->dlda; A.llb = lk->llb; A.lik = lk->lik; A.sigmoid_out = lk->sigmoid_out; A.sig = lk->sig;
+  }
+  if (l2f) {
+    if (!pv_dec1d_l2f_ok(l2f->zd) || !l2f->z || !l2f->wt) return PV_EINVAL;
+    A.z = l2f->z; A.l2f_wt = l2f->wt; A.l2f_b = l2f->bias; A.a0_out = a[0]; A.zd = l2f->zd;
+  }
   return launch<false>(A, s);
 }
 
 // g_out = dL/d(a[n]) (B, Ln, Cn); gown[i] <- dL/d(a[i]) for every conv op i (with act'(a[i]) of a producing convolution applied)
 int pv_dec1d_bwd(const pv_op* ops, int n, const float* wt, int B, int L0, int C0, float* const* a, const float* g_out,
-                 float* const* gown, hipStream_t s) {
+                 float* const* gown, hipStream_t s, const PvD1L2f* l2f) {
   D1Args A;
   if (!build(A, true, nullptr, ops, n, wt, B, L0, C0, a, g_out, gown)) return PV_EINVAL;
+  if (l2f) {
+    if (!pv_dec1d_l2f_ok(l2f->zd) || !l2f->wt || !l2f->dz || (A.op[A.n - 1].N & 3) != 0) return PV_EINVAL;
+    A.l2f_wt = l2f->wt; A.dz = l2f->dz; A.zd = l2f->zd;
+  }
   return launch<true>(A, s);
 }

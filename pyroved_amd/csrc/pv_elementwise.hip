@@ -1020,26 +1020,6 @@ extern "C" int pv_adam_step(float* params, float* grads, float* m, float* v, int
 
 // ---------------------------------------------------------------------------------------------
 // elementwise likelihood for the vanilla fcDecoderNet path (fc.py:143-152): a[M] logits -> loc, ll, dL/da
-__device__ __forceinline__ void pv_lik_one(float av, float xv, int lik, int sigmoid_out, float sig, float& ll, float& d, float& lv) {
-  if (lik == PV_LIK_BERNOULLI) {
-    const float pr = 1.0f / (1.0f + expf(-av));
-    const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
-    const float lg = logf(pc) - log1pf(-pc);
-    ll = -(fmaxf(lg, 0.0f) - lg * xv + log1pf(expf(-fabsf(lg))));
-    const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
-    d = (1.0f / (1.0f + expf(-lg)) - xv) * mask;
-    lv = pr;
-  } else if (lik == PV_LIK_CBERNOULLI) {
-    pv_cbern(av, xv, ll, d, lv);
-  } else {
-    const float pr = sigmoid_out ? 1.0f / (1.0f + expf(-av)) : av;
-    const float df = xv - pr;
-    ll = -(df * df) / (2.0f * sig * sig) - logf(sig) - LOG_SQRT_2PI;
-    d = -df / (sig * sig) * (sigmoid_out ? pr * (1.0f - pr) : 1.0f);
-    lv = pr;
-  }
-}
-
 __global__ void pv_lik_elem_kernel(const float* __restrict__ a, const float* __restrict__ x, int64_t M, int lik,
                                    int sigmoid_out, float sig, float* __restrict__ loc, float* __restrict__ llrow,
                                    float* __restrict__ dlda) {

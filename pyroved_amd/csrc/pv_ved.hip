@@ -191,10 +191,15 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
 }
 
 // decoder forward from z (B, z_dim) to the logits / pre-sigmoid output in L.da[n_dec_ops]
-int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_t s) {
+int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_t s, const PvD1Lik* lk = nullptr, bool* lik_done = nullptr) {
   const int64_t B = p->batch;
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
+  if (L.l2f_wt && dec1d_active(p, L) && pv_dec1d_l2f_ok(p->z_dim)) {       // the Linear rides in the decoder's launch
+    const PvD1L2f lf{z, L.l2f_wt, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr, nullptr, p->z_dim};
+    if (lik_done) *lik_done = lk != nullptr;
+    return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s, &lf, lk);
+  }
   if (L.l2f_wt) {                                      // Linear + view(-1, C0, *dims), written channels-last directly
     PV_TRY(pv_l2f_fwd(z, L.l2f_wt, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr, L.da[0], (int)B, d0.H * d0.W, d0.C,
                       p->z_dim, s));
@@ -203,7 +208,10 @@ int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_
                       L.f0, nullptr, F0, B, p->z_dim, F0, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
     PV_TRY(pv_ncs_to_nsc(L.f0, L.da[0], B, d0.C, (int64_t)d0.H * d0.W, s));     // view(-1, C0, *dims) -> channels-last
   }
-  if (dec1d_active(p, L)) return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s);
+  if (dec1d_active(p, L)) {
+    if (lik_done) *lik_done = lk != nullptr;
+    return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s, nullptr, lk);
+  }
   return pvcs::stack_fwd(p->params, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.sc, s, 1);
 }
 
@@ -240,14 +248,18 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   PV_TRY(ved_encoder_fwd(p, L, p->z_loc, p->z_scale, true, s));
   if (wt_join) { wt_join = false; PV_TRY(pv_stream_after(s, side)); }    // (a stack that never joined)
   L.sc.wt_join = nullptr; L.sc.side = nullptr;
-  PV_TRY(ved_decoder_fwd(p, L, L.z, s));
-  // ---- likelihood of the target (ved.py:141-145) ----
+  // ---- decoder + likelihood of the target (ved.py:141-145); one output channel: the likelihood rides in the decoder's launch ----
   const Shape& od = L.ds[p->n_dec_ops];
   const int64_t OUT = od.elems(B), per = OUT / B, S = (int64_t)od.H * od.W;
+  const PvD1Lik lk{p->y, p->loc, want_grads ? L.dlda : nullptr, L.llb, p->lik, p->sigmoid_out, p->decoder_sig};
+  bool lik_done = false;
+  PV_TRY(ved_decoder_fwd(p, L, L.z, s, p->out_ch == 1 ? &lk : nullptr, &lik_done));
   const float* y = p->y;
-  if (p->out_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->y, L.y_nsc, B, p->out_ch, S, s)); y = L.y_nsc; }
+  if (!lik_done && p->out_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->y, L.y_nsc, B, p->out_ch, S, s)); y = L.y_nsc; }
   float* loc = p->loc ? (p->out_ch > 1 ? L.loc_nsc : p->loc) : nullptr;
-  if (B >= 64 || per <= 4096) {                        // one workgroup per sample: element terms and their sum in one launch
+  if (lik_done) {
+    // (nothing to launch)
+  } else if (B >= 64 || per <= 4096) {                 // one workgroup per sample: element terms and their sum in one launch
     PV_TRY(pv_lik_rows(L.da[p->n_dec_ops], y, B, per, p->lik, p->sigmoid_out, p->decoder_sig, loc, want_grads ? L.dlda : nullptr,
                        L.llb, s));
     if (p->loc && p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, p->loc, B, p->out_ch, S, s));
@@ -272,10 +284,13 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   PvK1Batch k1b{};
   if (k1b_env) fin.k1b = &k1b;
   hipStream_t side2 = k1b_env ? pv_side_stream() : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
+  bool dz_done = false;
   if (k1b_env && dec1d_active(p, L)) {
     // every input gradient of the decoder in one launch (the fork event rides on it), then the weight gradients are recorded
     if (side2) pv_fork_arm();
-    PV_TRY(pv_dec1d_bwd(p->dec, p->n_dec_ops, L.d1_wt, (int)B, L.ds[0].H, L.ds[0].C, L.da, L.dlda, L.dg, s));
+    dz_done = L.l2f_wt && pv_dec1d_l2f_ok(p->z_dim);   // the latent gradient rides in the same launch
+    const PvD1L2f lf{nullptr, L.l2f_wt, nullptr, L.dzc, p->z_dim};
+    PV_TRY(pv_dec1d_bwd(p->dec, p->n_dec_ops, L.d1_wt, (int)B, L.ds[0].H, L.ds[0].C, L.da, L.dlda, L.dg, s, dz_done ? &lf : nullptr));
     PV_TRY(pvcs::stack_wgrads(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.dg, L.sc, s, 1));
     g = L.dg[0];
   } else {
@@ -300,7 +315,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (L.l2f_wt) {                                      // straight from the channels-last gradient
     PV_TRY(pv_l2f_wgrad(g, L.z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, (int)B,
                         d0.H * d0.W, d0.C, (int)z, sw));
-    PV_TRY(pv_convhead_fwd(g, L.l2f_wt, nullptr, L.dzc, (int)B, F0, (int)z, L.sc.ws, L.sc.ws_bytes, s));
+    if (!dz_done) PV_TRY(pv_convhead_fwd(g, L.l2f_wt, nullptr, L.dzc, (int)B, F0, (int)z, L.sc.ws, L.sc.ws_bytes, s));
   } else {
     PV_TRY(pv_nsc_to_ncs(g, L.df0, B, d0.C, (int64_t)d0.H * d0.W, s));
     PV_TRY(linear_wgrad(L.df0, F0, L.z, z, p->grads + p->l2f.w_off, p->l2f.b_off >= 0 ? p->grads + p->l2f.b_off : nullptr, B,
