@@ -504,10 +504,13 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     // joined before the finish
     hipStream_t side = pv_side_stream();
     bool joined = false;
+    PvSideJoin sj;                                    // joins the side stream on an early return
+    sj.fork(s, side);
     sc.side = side; sc.side_joined = &joined;
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
                            nullptr, sc, s, 0, g_is_pre, side ? L.ceg : nullptr));
     if (side && !joined) PV_TRY(pv_stream_after(s, side));
+    sj.joined();
     PV_TRY(pv_wgrad_finish_all(&wfin, s));
     if (fin) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
     for (int i = 0; i < n_extra; i += 4) PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s));

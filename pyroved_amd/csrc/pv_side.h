@@ -23,3 +23,16 @@ int pv_fork_to(hipStream_t side, hipStream_t main);
     if (fe__) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, nullptr, fe__, 0, __VA_ARGS__);     \
     else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                               \
   } while (0)
+
+// An entry point that forks work onto the side stream holds one of these: if it returns early (an error) after a fork, the
+// caller's stream still waits for the side stream — nothing is left running on memory the caller may release.
+struct PvSideJoin {
+  hipStream_t main = nullptr, side = nullptr;
+  bool forked = false;
+  void fork(hipStream_t m, hipStream_t sd) { main = m; side = sd; forked = sd != nullptr; }
+  void joined() { forked = false; }
+  ~PvSideJoin() {
+    if (forked) (void)pv_stream_after(main, side);
+    pv_fork_disarm();
+  }
+};

@@ -232,6 +232,8 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (p->ws_bytes < L.total) return PV_EWS;
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = p->batch, z = p->z_dim;
+  pv_fork_disarm();                                    // (no fork state of an earlier, failed call)
+  PvSideJoin sj;                                       // joins the side stream on every return path
   // The step's weight tilings run on the side stream next to the fused first block (which reads the raw weights); the
   // encoder's stack joins before its first tiled convolution.
   hipStream_t side = pv_side_stream();
@@ -305,6 +307,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   // the encoder's input gradients — stays on s.  Joined before the finish.
   const bool two = side2 != nullptr;
   side = side2;
+  if (two) sj.fork(s, side);
   hipStream_t sw = two ? side : s;
   if (two) PV_TRY(pv_fork_to(side, s));                // after the chain's last launch (its stop event when it took one)
   PV_TRY(pv_k1_wgrad_flush(&k1b, sw));
@@ -360,6 +363,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
                          nullptr, L.sc, s, 0, g_is_pre, two ? L.eg : nullptr));
   L.sc.side = nullptr; L.sc.side_joined = nullptr;
   if (two && !joined) PV_TRY(pv_stream_after(s, side));
+  sj.joined();
   return pv_wgrad_finish_all(&fin, s);
 }
 
