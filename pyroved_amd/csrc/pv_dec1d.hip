@@ -4,12 +4,14 @@
 //
 // Such a stack is a chain of ten tiny GEMMs per sample (a layer is 16-128 positions x 32-128 channels: 0.4 GFLOP at batch
 // 256), each 5-12 us as a launch of its own — launch, cold start and drain, not arithmetic.  Here a workgroup (8 waves)
-// carries ONE sample through the whole chain: the activations (at most 4096 floats) ping-pong between two LDS buffers with
-// zero halo rows, a wave owns 16 output channels x 16 positions at a time, the weights stream from L2 straight into the A
-// operand of v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: an exact fp32 FMA chain, like the kernel-1 family they
-// replace) from a layout tiled once per step by pv_conv_wprep_table (kind 8: [tap][output][contraction], the input-gradient
-// form with taps flipped and channel roles swapped).  Every layer's output / gradient is also written to global memory in
-// the layouts the step's other kernels use: the weight gradients (pv_conv_k1.hip's recorded batch) read them.
+// carries ONE sample through the whole chain: every activation of the sample (a few thousand floats per layer, zero halo rows
+// for the kernel-3 padding) stays in LDS until the end, a wave owns 16 output channels x 16 positions at a time, the weights
+// stream from L2 straight into the A operand of v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: an exact fp32 FMA chain,
+// like the kernel-1 family they replace) from a layout written once per step by pv_conv_wprep_table in MFMA fragment order
+// (kind 8; the input-gradient form with taps flipped and channel roles swapped).  Every layer's output / gradient goes to
+// global memory in one burst at the end, in the layouts the step's other kernels use: the weight gradients
+// (pv_conv_k1.hip's recorded batch) read them.  latent_to_features (the Linear in front of the stack) and the observation
+// likelihood behind it can ride in the same launches.
 //
 // Conventions as in pv_convstack.h: op i maps a[i] -> a[i+1]; an UpsampleBlock arrives as CONV k1 (no activation) followed
 // by UPSAMPLE2 (the convolution first: both linear, half the positions) and is one step here (rows stored twice forward,
