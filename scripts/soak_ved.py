@@ -1,0 +1,52 @@
+"""Randomised VED configurations (1-D outputs: the fused Conv1d decoder where its shape rules allow, the layer launches
+elsewhere) against the CPU oracle: ELBO 1e-4, every gradient tensor rel-L2 1e-4 (float64 oracle).
+    python scripts/soak_ved.py [n_cases] [seed]"""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pyroved_amd as pv
+from oracle import svi_oracle as orc
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n_cases):
+    in_side = rng.choice([16, 32])
+    out_len = rng.choice([16, 32, 48, 64, 128])
+    och = rng.choice([1, 1, 2])
+    act = rng.choice(["lrelu", "relu", "tanh", "softplus"])
+    hd = rng.choice([None, [(64, 64), (32,)], [(128,), (64,), (32,)], [(48, 48), (16,)], [(32, 32), (24,)]])
+    sampler = rng.choice(["bernoulli", "gaussian", "continuous_bernoulli"])
+    latent = rng.choice([2, 3, 9])
+    b = rng.choice([1, 3, 17])
+    nblocks = len(hd) if hd else 3
+    if out_len % (2 ** nblocks) != 0:
+        continue
+    cfg = orc.VedConfig(input_dim=(in_side, in_side), output_dim=(out_len,), output_channels=och, latent_dim=latent,
+                        hidden_dim_e=[(32,), (64, 64)], hidden_dim_d=hd, activation=act, sampler=sampler)
+    try:
+        m = pv.models.VED((in_side, in_side), (out_len,), output_channels=och, latent_dim=latent, hidden_dim_e=[(32,), (64, 64)],
+                          hidden_dim_d=hd, activation=act, sampler_d=sampler, seed=case + 1, device="cuda")
+    except Exception as e:
+        print("case %d: constructor refused (%s)" % (case, e)); continue
+    o = orc.VedOracle({k: v.cpu() for k, v in m.state_dict().items()}, cfg, dtype=torch.float64)
+    g = torch.Generator().manual_seed(case)
+    x, y, eps = torch.rand(b, 1, in_side, in_side, generator=g), torch.rand(b, och, out_len, generator=g), torch.randn(b, latent, generator=g)
+    eng = m.engine()
+    try:
+        eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+    except Exception as e:
+        print("case %2d REFUSED: in %d out %d x%d act %s hd %s %s z %d b %d: %s" % (case, in_side, out_len, och, act, hd, sampler, latent, b, e), flush=True)
+        bad += 1
+        continue
+    loss, ref = eng.scalars[0].item(), o.step(x, y, eps, 1.0)
+    worst, wk = 0.0, ""
+    for k in o.p:
+        gk, rk = eng.grad_of(k).cpu().double(), o.last_grads[k].double()
+        e = ((gk - rk).norm() / rk.norm().clamp_min(1e-30)).item()
+        if e > worst: worst, wk = e, k
+    ok = abs(loss - ref) <= 1e-4 * abs(ref) and worst < 1e-4
+    bad += 0 if ok else 1
+    print("case %2d %s: in %d out %d x%d act %s hd %s %s z %d b %d: loss %.6g (oracle %.6g) worst grad %.1e (%s)"
+          % (case, "ok " if ok else "BAD", in_side, out_len, och, act, hd, sampler, latent, b, loss, ref, worst, wk), flush=True)
+print("%d bad" % bad)
