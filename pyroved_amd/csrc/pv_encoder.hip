@@ -13,6 +13,9 @@
 // anything else takes the generic GEMM path of pv_plan.hip.
 #include "pv_common.h"
 #include "pv_kernels.h"
+#include <atomic>
+#include <random>
+#include <stdlib.h>
 
 #define EN_ROWS 16
 #define EN_LD 132
@@ -81,18 +84,20 @@ __device__ __forceinline__ f32x4 en_load_bias(const float* bias, int out_dim, in
 // first encoder layer: eact[0] = act(x W0^T + b0), one workgroup per (16 rows x 16 outputs), K split over 4 waves
 #define L1_WAVES 4
 #define L1_STEPS 4             // k16-steps per register batch
-__global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
-  __shared__ float part[L1_WAVES][EN_ROWS][17];
+// bx / by: output block / row block (by >= rb: guest workgroups, ny row blocks in all); the first 64 * L1_WAVES threads of the
+// workgroup take part (NW = 4 or 8 waves split K).  Returns true when this workgroup wrote a tile of eact[0] (the merged launch then signals it).
+template <bool COHERENT, int NW>
+__device__ __forceinline__ bool enc_l1_body(const PvEncFwd& e, int bx, int by, int nx, int ny, float (*part)[EN_ROWS][17]) {
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
-  if ((int)blockIdx.y >= rb) {                     // guest work: the decoder kernel's weight images (pv_fb_layout.h)
-    const int64_t blk = (int64_t)(blockIdx.y - rb) * gridDim.x + blockIdx.x;
-    pv_fb_prep(e.prep, blk * (64 * L1_WAVES) + tid, (int64_t)(gridDim.y - rb) * gridDim.x * (64 * L1_WAVES));
-    return;
+  if (by >= rb) {                                  // guest work: the decoder kernel's weight images (pv_fb_layout.h)
+    const int64_t blk = (int64_t)(by - rb) * nx + bx;
+    pv_fb_prep(e.prep, blk * (64 * NW) + tid, (int64_t)(ny - rb) * nx * (64 * NW));
+    return false;
   }
   const pv_layer l = e.enc[0];
-  const int ob = blockIdx.x, row0 = blockIdx.y * EN_ROWS, K = l.in_dim;
+  const int ob = bx, row0 = by * EN_ROWS, K = l.in_dim;
   const int rowc = min(row0 + r, e.B - 1);
   const int j = 16 * ob + r;
   const bool jok = j < l.out_dim;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
   auto load = [&](int k0, f32x4 (&av)[L1_STEPS], f32x4 (&bv)[L1_STEPS]) {
 #pragma unroll
     for (int s = 0; s < L1_STEPS; ++s) {
-      const int k = k0 + 16 * L1_WAVES * s;
+      const int k = k0 + 16 * NW * s;
       const int kc = k < K ? k : 0;
       av[s] = *reinterpret_cast<const f32x4*>(wrow + kc);
       bv[s] = *reinterpret_cast<const f32x4*>(xrow + kc);
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i & 1] = MFMA(av[s][i], bv[s][i], acc[i & 1]);
   };
-  const int KB = 16 * L1_WAVES * L1_STEPS;         // k's per batch over the whole workgroup
+  const int KB = 16 * NW * L1_STEPS;         // k's per batch over the whole workgroup
   load(16 * wave, a[0], b[0]);
   for (int k0 = 16 * wave; k0 < K; k0 += 2 * KB) {
     const bool more1 = k0 + KB < K, more2 = k0 + 2 * KB < K;
@@ -133,18 +138,29 @@ __global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
   pv_lds_barrier();
   {
     const int rr = tid >> 4, jj = tid & 15, jo = 16 * ob + jj, row = row0 + rr;
-    if (jo < l.out_dim && row < e.B) {
+    if (tid < 256 && jo < l.out_dim && row < e.B) {
       float v = (part[0][rr][jj] + part[1][rr][jj]) + (part[2][rr][jj] + part[3][rr][jj]);
+      if (NW == 8) v += (part[4][rr][jj] + part[5][rr][jj]) + (part[6][rr][jj] + part[7][rr][jj]);
       v += l.b_off >= 0 ? e.params[l.b_off + jo] : 0.0f;
-      e.eact[0][(int64_t)row * l.out_dim + jo] = pv_act_fwd2(v, l.act);
+      const float y = pv_act_fwd2(v, l.act);
+      // COHERENT (the merged launch): a device-scope store — written through to where another XCD's workgroup of the SAME
+      // launch can read it (a plain store may sit dirty in this XCD's L2 until the kernel ends)
+      if (COHERENT) __hip_atomic_store(e.eact[0] + (int64_t)row * l.out_dim + jo, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else e.eact[0][(int64_t)row * l.out_dim + jo] = y;
     }
   }
+  return true;
+}
+
+__global__ __launch_bounds__(64 * L1_WAVES) void pv_enc_l1_kernel(PvEncFwd e) {
+  __shared__ float part[L1_WAVES][EN_ROWS][17];
+  enc_l1_body<false, L1_WAVES>(e, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, part);
 }
 
 
 #ifdef EN_TRACE
 __device__ long long en_trace[64];
-#define EN_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) en_trace[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define EN_STAMP(k) do { if (rbk == 0 && threadIdx.x == 0) en_trace[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
 extern "C" int pv_debug_read_enc_trace(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(en_trace), (n > 64 ? 64 : n) * sizeof(long long));
 }
@@ -152,20 +168,21 @@ extern "C" int pv_debug_read_enc_trace(long long* out, int n) {
 #define EN_STAMP(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
-  __shared__ __attribute__((aligned(16))) float act[2][EN_ROWS][EN_LD];
-  __shared__ float sm[8];
+// rbk: the workgroup's row block.  MERGED: the first layer runs in the SAME launch (pv_enc_kernel): everything that does not
+// depend on it is requested first, then the workgroup waits for its row block's tiles (flags == e.gen), then reads them.
+template <bool MERGED>
+__device__ __forceinline__ void enc_fwd_body(const PvEncFwd& e, int rbk, float (*act)[EN_ROWS][EN_LD], float* sm) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
-  const int row0 = blockIdx.x * EN_ROWS;
+  const int row0 = rbk * EN_ROWS;
   const bool rok = row0 + r < e.B;
   int cur = 0;
   EN_STAMP(0);
   // ---- the first layer's output (pv_enc_l1_kernel): requested before anything else — loads return in order, and the
-  // first barrier waits only for this one ----
+  // first barrier waits only for this one (merged launch: after the wait below) ----
   const int w0_ = e.enc[0].out_dim;
   const bool l0ok = tid < EN_ROWS * (w0_ / 4);                       // (w0 <= 128: one float4 per thread)
   f32x4 l0v = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (l0ok) {
+  if (!MERGED && l0ok) {
     const int rr = tid / (w0_ / 4), c4 = tid % (w0_ / 4);
     l0v = *reinterpret_cast<const f32x4*>(e.eact[0] + (int64_t)min(row0 + rr, e.B - 1) * w0_ + 4 * c4);
   }
@@ -195,6 +212,27 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
   float eps_pf = 0.0f;                               // thread t < 16*z_dim handles (row t / z, column t % z)
   if (tid < EN_ROWS * e.z_dim && row0 + tid / e.z_dim < e.B)
     eps_pf = e.eps[(int64_t)(row0 + tid / e.z_dim) * e.z_dim + tid % e.z_dim];
+  if (MERGED) {
+    // wait for the first layer's tiles of this row block: lane j of wave 0 polls flag j (bounded: a launch that loses its
+    // producers must not hang the device; the step's parity tests would show it)
+    const int cb = (w0_ + 15) >> 4;
+    if (tid < cb) {
+      const unsigned* f = e.flags + (int64_t)rbk * cb + tid;
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e.gen) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    if (l0ok) {                                                       // device-scope loads: past this XCD's (possibly stale) L2 lines
+      const int rr = tid / (w0_ / 4), c4 = tid % (w0_ / 4);
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(e.eact[0] + (int64_t)min(row0 + rr, e.B - 1) * w0_ + 4 * c4);
+      const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l0v[0] = __uint_as_float((unsigned)lo); l0v[1] = __uint_as_float((unsigned)(lo >> 32));
+      l0v[2] = __uint_as_float((unsigned)hi); l0v[3] = __uint_as_float((unsigned)(hi >> 32));
+    }
+  }
   // ---- the first layer's output (pv_enc_l1_kernel) into LDS; rows past the batch repeat the last one ----
   {
     if (l0ok) *reinterpret_cast<f32x4*>(&act[0][tid / (w0_ / 4)][4 * (tid % (w0_ / 4))]) = l0v;
@@ -294,8 +332,8 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
     lqd = en_block_sum(lqd, sm);
   }
   if (tid == 0) {
-    e.kl_part[2 * blockIdx.x] = e.beta * lp + e.beta_disc * lpd;
-    e.kl_part[2 * blockIdx.x + 1] = e.beta * lq + e.beta_disc * lqd;
+    e.kl_part[2 * rbk] = e.beta * lp + e.beta_disc * lpd;
+    e.kl_part[2 * rbk + 1] = e.beta * lq + e.beta_disc * lqd;
   }
   pv_lds_barrier();
   EN_STAMP(5);
@@ -352,6 +390,38 @@ __global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
   }
 }
 
+__global__ __launch_bounds__(EN_THREADS) void pv_enc_fwd_kernel(PvEncFwd e) {
+  __shared__ __attribute__((aligned(16))) float act[2][EN_ROWS][EN_LD];
+  __shared__ float sm[8];
+  enc_fwd_body<false>(e, (int)blockIdx.x, act, sm);
+}
+
+// Both in ONE launch: workgroups [0, n1) are the first layer's tiles (and its guests), in row-block-major order; workgroups
+// n1 + k carry row block k through the rest.  The second kind starts at once — its weights, biases and noise are requested
+// while the first layer is still running, which hides the ~5 us every launch spends before its first operand is usable —
+// and waits for its 8 producers through per-tile flags: a producer publishes e.gen (a value no earlier call used) after a
+// device-scope release of its tile, the consumer polls with acquire loads.  Workgroups are dispatched in index order, so
+// every producer is running or done before a consumer occupies a slot: no deadlock at any batch size.
+__global__ __launch_bounds__(EN_THREADS) void pv_enc_kernel(PvEncFwd e, int nx, int ny) {
+  __shared__ __attribute__((aligned(16))) float act[2][EN_ROWS][EN_LD];
+  __shared__ float sm[8];
+  const int n1 = nx * ny, id = (int)blockIdx.x;
+  if (id < n1) {
+    if (threadIdx.x >= 64 * L1_WAVES) return;                        // (four waves split K; all eight measured no faster)
+    float (*part)[EN_ROWS][17] = reinterpret_cast<float (*)[EN_ROWS][17]>(&act[0][0][0]);
+    const int bx = id % nx, by = id / nx;
+    if (enc_l1_body<true, L1_WAVES>(e, bx, by, nx, ny, part)) {
+      // every thread's (write-through) store of the tile has been acknowledged, then the flag: no cache-wide write-back
+      // (a release fence here cost more than the launch it saves: 24 vs 21 us for the pair)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pv_lds_barrier();
+      if (threadIdx.x == 0) __hip_atomic_store(e.flags + (int64_t)by * nx + bx, e.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  enc_fwd_body<true>(e, id - n1, act, sm);
+}
+
 bool pv_enc_compact_supported(const pv_ivae_plan* p) {
   if (p->n_enc < 1) return false;
   int in = p->n_pix + p->c_dim;
@@ -367,6 +437,17 @@ bool pv_enc_compact_supported(const pv_ivae_plan* p) {
   return true;
 }
 
+// a flag value no earlier call of this process used (and, with a random start, none a previous process is likely to have left
+// in recycled device memory): producers publish it, consumers wait for it — no zero-initialised state anywhere
+static unsigned enc_next_gen() {
+  static std::atomic<unsigned> g{[] {
+    std::random_device rd;
+    return (unsigned)rd() | 1u;
+  }()};
+  unsigned v = g.fetch_add(1u);
+  return v;
+}
+
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
   const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
   const int cb = (e.enc[0].out_dim + 15) / 16;
@@ -375,6 +456,14 @@ int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
     const int64_t work = e.prep.nzero4 > 128 * 32 ? e.prep.nzero4 : 128 * 32;
     extra = (int)((work + (int64_t)cb * 64 * L1_WAVES - 1) / ((int64_t)cb * 64 * L1_WAVES));
     if (extra > 16) extra = 16;
+  }
+  static const int two = getenv("PV_ENC_TWO") && atoi(getenv("PV_ENC_TWO")) ? 1 : 0;     // (A/B: the two launches)
+  if (e.flags && !two) {
+    PvEncFwd m = e;
+    m.gen = enc_next_gen();
+    hipLaunchKernelGGL(pv_enc_kernel, dim3((unsigned)(cb * (rb + extra) + rb)), dim3(EN_THREADS), 0, s, m, cb, rb + extra);
+    PV_LAUNCH_CHECK();
+    return 0;
   }
   hipLaunchKernelGGL(pv_enc_l1_kernel, dim3(cb, rb + extra), dim3(64 * L1_WAVES), 0, s, e);
   PV_LAUNCH_CHECK();

@@ -208,6 +208,7 @@ struct PvEncFwd {
   int K; float* alpha; float* sw;
   const float* w;                   // (B) per-sample weights of the KL partial sums (plan->row_w) or null
   PvFbPrep prep;                    // hosted in the first-layer launch when prep.img is set (bf16x3 decoder path)
+  unsigned* flags; unsigned gen;    // != null: one launch for both kernels; (row blocks x 8) words of scratch, any content (pv_encoder.hip)
 };
 bool pv_enc_compact_supported(const pv_ivae_plan* p);
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s);

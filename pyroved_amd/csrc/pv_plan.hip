@@ -40,6 +40,7 @@ struct Layout {
   float* head; float* dhead; float* z; float* z_scale; float* tp; float* zy;
   float* edp[PV_MAX_LAYERS];               // dL/d(pre-activation) of every encoder hidden layer
   bool enc_compact; float* kl_part; int kl_blocks;   // compact encoder kernels (pv_encoder.hip)
+  unsigned* enc_flags;                               // ... their merged launch's tile flags (8 per row block; any content)
   // decoder
   float* hz; float* h0; float* dact[PV_MAX_LAYERS]; float* dpre_[PV_MAX_LAYERS];
   float* logits; float* llrow; float* llb; float* dbuf[2];
@@ -154,6 +155,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.enc_compact = !L.enc_conv && !L.enc_ext && pv_enc_compact_supported(p);
   L.kl_blocks = (int)((B + 15) / 16);
   L.kl_part = c.take(2 * L.kl_blocks);
+  L.enc_flags = reinterpret_cast<unsigned*>(c.take(8 * L.kl_blocks));     // (the merged encoder launch's tile flags)
   int64_t maxd = 0;
   L.fused = p->fused && pv_sdec_fused_supported(p) && !(K > 0 && !L.enc_compact);   // (jiVAE + generic encoder: layered)
   L.f_grid = L.f_kmax = 0;
@@ -646,6 +648,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     e.w = p->row_w;
     if (p->coord_dim > 0) { e.hz = L.hz; e.Wz = p->params + p->fc_latent.w_off; e.H0 = p->fc_coord.out_dim; }
     e.hz_scale = hz_scale;
+    e.flags = L.enc_flags;
     e.B = p->batch; e.z_dim = p->z_dim; e.c_dim = p->c_dim; e.coord_dim = p->coord_dim;
     e.has_r = p->has_r; e.has_t = p->has_t; e.has_s = p->has_s;
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;

@@ -1,0 +1,18 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pyroved_amd as pv
+from pyroved_amd import _abi
+model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+eng = model.engine(fused=3)
+x = torch.rand(256, 28, 28, generator=torch.Generator().manual_seed(0)).cuda()
+eps = torch.randn(256, model.z_dim).cuda()
+for _ in range(5):
+    eng.loss_and_grads(x, eps)
+torch.cuda.synchronize()
+lib = C.CDLL(_abi.LIB_PATH)
+buf = (C.c_longlong * 64)()
+print("rc", lib.pv_debug_read_enc_trace(buf, 64))
+t = [buf[i] for i in range(7)]
+names = ["l0 load + prefetch requests + LDS", "hidden layer 1", "head", "z / KL terms", "block sums", "split latent", "?"]
+print([(names[i], t[i + 1] - t[i]) for i in range(6)], "total", t[6] - t[0])

@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # a step starts at each enc_fwd kernel; take the 3rd-from-last complete step
-starts = [i for i, n in enumerate(names) if "enc_l1" in n]
+starts = [i for i, n in enumerate(names) if "enc_l1" in n or "pv_enc_kernel" in n]
 a, b = starts[-3], starts[-2]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = None
 tot_k = 0
