@@ -13,6 +13,7 @@
 // anything else takes the generic GEMM path of pv_plan.hip.
 #include "pv_common.h"
 #include "pv_kernels.h"
+#include "pv_side.h"
 #include <atomic>
 #include <random>
 #include <stdlib.h>
@@ -458,7 +459,7 @@ int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
     if (extra > 16) extra = 16;
   }
   static const int two = getenv("PV_ENC_TWO") && atoi(getenv("PV_ENC_TWO")) ? 1 : 0;     // (A/B: the two launches)
-  if (e.flags && !two) {
+  if (e.flags && !two && !pv_stream_capturing(s)) {    // (a captured launch would replay its generation value: two launches then)
     PvEncFwd m = e;
     m.gen = enc_next_gen();
     hipLaunchKernelGGL(pv_enc_kernel, dim3((unsigned)(cb * (rb + extra) + rb)), dim3(EN_THREADS), 0, s, m, cb, rb + extra);

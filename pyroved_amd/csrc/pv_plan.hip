@@ -348,7 +348,7 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   const bool hfused = pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.chead_wt, p->head.out_dim, fe0.C, (int64_t)fe0.H * fe0.W);
   // the weight tilings next to the fused first block (raw weights) on the side stream; stack_fwd joins before its first tiled op
-  hipStream_t side = pv_side_stream();
+  hipStream_t side = pv_side_stream_for(s);
   bool wt_join = false;
   static const int wprep_side = getenv("PV_SIDE_WPREP") && atoi(getenv("PV_SIDE_WPREP")) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
   if (wprep_side && side && sc.code && pvcs::c1pool_fusable(p->enc_ops, p->n_enc_ops, p->enc_ndim, L.ces[0])) {
@@ -482,7 +482,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
       g_is_pre = last.kind == PV_OP_CONV && last.act != PV_ACT_GELU;
       PV_TRY(pv_convhead_wgrad(L.dhead, L.cea[p->n_enc_ops], G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, (int)B,
                                fe.H * fe.W, fe.C, hd.out_dim, ws, wsb, s));
-      if (pv_side_stream()) pv_fork_arm();             // (the last convolution's weight gradient forks off this launch)
+      if (pv_side_stream_for(s)) pv_fork_arm();             // (the last convolution's weight gradient forks off this launch)
       PV_TRY(pv_convhead_bwd(L.dhead, L.chead_wt, L.cea[p->n_enc_ops], g_is_pre ? last.act : PV_ACT_NONE, L.cg[1], (int)B, L.cF,
                              hd.out_dim, s));
     } else {
@@ -504,7 +504,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     // kernel-3 weight gradients on the side stream, the input-gradient chain on s (every op's gradient in its own buffer);
     // joined before the finish
-    hipStream_t side = pv_side_stream();
+    hipStream_t side = pv_side_stream_for(s);
     bool joined = false;
     PvSideJoin sj;                                    // joins the side stream on an early return
     sj.fork(s, side);

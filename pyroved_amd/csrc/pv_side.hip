@@ -62,6 +62,12 @@ Side* side_of_current_device() {
 
 extern "C" void pv_set_side_stream(int on) { g_on.store(on ? 1 : 0); }
 
+bool pv_stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+
 hipStream_t pv_side_stream() {
   if (!side_enabled()) return nullptr;
   Side* S = side_of_current_device();
