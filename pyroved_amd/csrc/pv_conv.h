@@ -91,7 +91,9 @@ int pv_maxpool2_bwd_code(const float* g, const float* y_pooled, const unsigned c
 // KK = spatial size); dst sized by pv_conv_wt_bytes
 struct PvWprepEntry { const float* w; char* dst; int Co, Ci, KK, flip, kind; int pad_; int64_t start, total; };
 int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd);
-int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s);
+struct PvFbPrep;
+// fb != null: the spatial decoder's bf16 weight images (pv_fb_layout.h) are written by extra workgroups of the (first) launch
+int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s, const PvFbPrep* fb = nullptr);
 bool pv_conv3_sp_wgrad_supported(int C, int Cout, int nd);
 int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout);
 int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,

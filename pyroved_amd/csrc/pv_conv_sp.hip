@@ -21,6 +21,7 @@
 #include "pv_common.h"
 #include "pv_side.h"
 #include "pv_conv.h"
+#include "pv_fb_layout.h"
 #include <stdlib.h>
 
 typedef __bf16 sbf8 __attribute__((ext_vector_type(8)));
@@ -168,10 +169,18 @@ __global__ void pv_conv3_sp_wprep_kernel(const float* __restrict__ w, unsigned s
 
 // ---- every weight tiling of a step in one launch: entry k covers element indices [start, start + total) ----------------
 #define WPREP_CAP 32
-struct WprepTab { PvWprepEntry e[WPREP_CAP]; int n; int64_t total; };
+struct WprepTab { PvWprepEntry e[WPREP_CAP]; int n; int64_t total; PvFbPrep fb; int fb_blocks; };
 
 __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < t.total; idx += (int64_t)gridDim.x * blockDim.x) {
+  if (t.fb_blocks > 0) {                              // the last fb_blocks workgroups: the spatial decoder's weight images
+    const int first = (int)gridDim.x - t.fb_blocks;
+    if ((int)blockIdx.x >= first) {
+      pv_fb_prep(t.fb, (int64_t)((int)blockIdx.x - first) * blockDim.x + threadIdx.x, (int64_t)t.fb_blocks * blockDim.x);
+      return;
+    }
+  }
+  const int nb = (int)gridDim.x - t.fb_blocks;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < t.total; idx += (int64_t)nb * blockDim.x) {
     int k = 0;
     while (k + 1 < t.n && idx >= t.e[k + 1].start) ++k;
     const PvWprepEntry E = t.e[k];
@@ -262,9 +271,23 @@ int64_t pv_conv_wt_bytes(int kind, int Co, int Ci, int nd) {
 }
 
 // fills start / total of the entries and launches (16 entries per launch)
-int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s) {
+int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s, const PvFbPrep* fb) {
+  if (n <= 0 && fb) {                                 // nothing to tile: the images alone
+    WprepTab t{};
+    t.fb = *fb;
+    const int64_t work = fb->nzero4 > 128 * 32 ? fb->nzero4 : 128 * 32;
+    t.fb_blocks = (int)((work + 255) / 256 > 256 ? 256 : (work + 255) / 256);
+    hipLaunchKernelGGL(pv_conv_wprep_table_kernel, dim3(t.fb_blocks), dim3(256), 0, s, t);
+    PV_LAUNCH_CHECK();
+    return 0;
+  }
   for (int lo = 0; lo < n; lo += WPREP_CAP) {
     WprepTab t{};
+    if (fb && lo == 0) {
+      t.fb = *fb;
+      const int64_t work = fb->nzero4 > 128 * 32 ? fb->nzero4 : 128 * 32;
+      t.fb_blocks = (int)((work + 255) / 256 > 256 ? 256 : (work + 255) / 256);
+    }
     t.n = n - lo < WPREP_CAP ? n - lo : WPREP_CAP;
     int64_t acc = 0;
     for (int k = 0; k < t.n; ++k) {
@@ -276,8 +299,9 @@ int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s) {
     t.total = acc;
     int pb = (int)((acc + 255) / 256);
     if (pb > 4096) pb = 4096;
-    if (pb < 1) continue;
-    hipLaunchKernelGGL(pv_conv_wprep_table_kernel, dim3(pb), dim3(256), 0, s, t);
+    if (pb < 1 && t.fb_blocks == 0) continue;
+    if (pb < 1) pb = 1;
+    hipLaunchKernelGGL(pv_conv_wprep_table_kernel, dim3(pb + t.fb_blocks), dim3(256), 0, s, t);
     PV_LAUNCH_CHECK();
   }
   return 0;

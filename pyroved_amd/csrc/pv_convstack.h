@@ -7,6 +7,7 @@
 #include "pv_common.h"
 #include "pv_linear.h"
 #include "pv_conv.h"
+#include "pv_fb_layout.h"
 #include "pv_side.h"
 
 namespace pvcs {
@@ -223,11 +224,11 @@ inline void wt_entries(const float* params, const pv_op* ops, int n, int nd, int
     }
 }
 inline int wt_prep(const float* params, const pv_op* ops, int n, int nd, int stack_id, int conv_bf16, const WtPlan& w, char* base,
-                   bool with_dgrad, hipStream_t s, const PvWprepEntry* extra = nullptr, int n_extra = 0) {
+                   bool with_dgrad, hipStream_t s, const PvWprepEntry* extra = nullptr, int n_extra = 0, const PvFbPrep* fb = nullptr) {
   PvWprepEntry e[2 * PV_MAX_OPS + 4];
   int ne = 0;
   wt_entries(params, ops, n, nd, stack_id, conv_bf16, w, base, with_dgrad, e, ne, extra, n_extra);
-  return ne ? pv_conv_wprep_table(e, ne, s) : 0;
+  return (ne || fb) ? pv_conv_wprep_table(e, ne, s, fb) : 0;
 }
 inline float* bn_slot(const Scratch& sc, int slot) { return sc.bn + (int64_t)slot * 4 * sc.bn_maxC; }
 

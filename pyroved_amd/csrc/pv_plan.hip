@@ -329,7 +329,8 @@ int conv3_wgrad(const float* dpre, const float* in, int B, int H, int W_, int C,
 namespace {
 
 // convolutional encoder: x viewed as (B, 1, *enc_in_dim) -> op sequence -> flatten (C, spatial) -> L.head
-int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
+// prep != null: the spatial decoder's weight images are written by the same tiling launch (pv_conv_wprep_table)
+int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr) {
   const int64_t B = p->batch;
   if (L.cF < 0 || p->head.in_dim != L.cF) return PV_EINVAL;
   float* a[PV_MAX_OPS + 1];
@@ -354,12 +355,12 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   if (wprep_side && side && sc.code && pvcs::c1pool_fusable(p->enc_ops, p->n_enc_ops, p->enc_ndim, L.ces[0])) {
     PV_TRY(pv_stream_after(side, s));
     PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, side, &he,
-                         hfused ? 1 : 0));
+                         hfused ? 1 : 0, prep));
     wt_join = true;
     sc.side = side; sc.wt_join = &wt_join;
   } else {
     PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s, &he,
-                         hfused ? 1 : 0));
+                         hfused ? 1 : 0, prep));
   }
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
   if (wt_join) { wt_join = false; PV_TRY(pv_stream_after(s, side)); }
@@ -372,8 +373,8 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
                     L.head, nullptr, p->head.out_dim, B, L.cF, p->head.out_dim, PV_ACT_NONE, L.scratch, L.scratch_bytes, s);
 }
 
-int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
-  if (L.enc_conv) return conv_encoder_fwd(p, L, s);
+int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr) {
+  if (L.enc_conv) return conv_encoder_fwd(p, L, s, prep);
   const int64_t B = p->batch;
   const float* in = p->x;
   int64_t ldin = p->n_pix;
@@ -654,8 +655,8 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;
     return pv_enc_fwd(e, s);
   }
-  if (prep) return PV_EINVAL;                     // (stand-alone preparation on this path)
-  if (!L.enc_ext) PV_TRY(encoder_fwd(p, L, s));
+  if (prep && !L.enc_conv) return PV_EINVAL;      // (stand-alone preparation on this path)
+  if (!L.enc_ext) PV_TRY(encoder_fwd(p, L, s, prep));
   PvHead h{};
   h.head = L.enc_ext ? p->ext_head : L.head; h.scale_direct = L.enc_ext ? 1 : 0; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
   h.z_loc_out = p->z_loc; h.z_scale_out = p->z_scale;
@@ -709,9 +710,14 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     f.hz_scale = prep.scale;                          // the compact encoder's last launch writes scale * hz directly
     PV_TRY(guide_fwd(p, L, s, &prep, f.hz_scale));
   } else {
-    PV_TRY(guide_fwd(p, L, s));
-    if (p->fused >= 2) {
+    // conv encoder: the decoder's weight images ride in its weight-tiling launch; generic encoders: a launch of their own
+    const bool prep_in_enc = p->fused >= 2 && L.enc_conv;
+    const PvFbPrep prep = p->fused >= 2 ? pv_sdec_fused_bf16_prep_args(f, want_grads != 0, p->fused == 2) : PvFbPrep{};
+    PV_TRY(guide_fwd(p, L, s, prep_in_enc ? &prep : nullptr));
+    if (p->fused >= 2 && !prep_in_enc) {
       PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, p->fused == 2, s));
+    } else if (p->fused >= 2) {
+      // (done)
     } else if (want_grads) {
       hipError_t e = hipMemsetAsync(L.f_part_hz, 0, (size_t)(S * L.f_kmax * H) * sizeof(float), s);
       if (e != hipSuccess) return (int)e;
