@@ -177,6 +177,7 @@ __device__ __forceinline__ void enc_fwd_body(const PvEncFwd& e, int rbk, float (
   const int row0 = rbk * EN_ROWS;
   const bool rok = row0 + r < e.B;
   int cur = 0;
+  bool timed_out = false;
   EN_STAMP(0);
   // ---- the first layer's output (pv_enc_l1_kernel): requested before anything else — loads return in order, and the
   // first barrier waits only for this one (merged launch: after the wait below) ----
@@ -214,17 +215,19 @@ __device__ __forceinline__ void enc_fwd_body(const PvEncFwd& e, int rbk, float (
   if (tid < EN_ROWS * e.z_dim && row0 + tid / e.z_dim < e.B)
     eps_pf = e.eps[(int64_t)(row0 + tid / e.z_dim) * e.z_dim + tid % e.z_dim];
   if (MERGED) {
-    // wait for the first layer's tiles of this row block: lane j of wave 0 polls flag j (bounded: a launch that loses its
-    // producers must not hang the device; the step's parity tests would show it)
+    // wait for the first layer's tiles of this row block: lane j of wave 0 polls flag j.  Bounded (seconds): a launch that
+    // loses its producers must not hang the device — it poisons the row block's KL partial sums instead (the loss turns NaN)
     const int cb = (w0_ + 15) >> 4;
+    int late = 0;
     if (tid < cb) {
       const unsigned* f = e.flags + (int64_t)rbk * cb + tid;
+      late = 1;
       for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e.gen) break;
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e.gen) { late = 0; break; }
         __builtin_amdgcn_s_sleep(2);
       }
     }
-    __syncthreads();
+    timed_out = __syncthreads_or(late) != 0;
     if (l0ok) {                                                       // device-scope loads: past this XCD's (possibly stale) L2 lines
       const int rr = tid / (w0_ / 4), c4 = tid % (w0_ / 4);
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(e.eact[0] + (int64_t)min(row0 + rr, e.B - 1) * w0_ + 4 * c4);
@@ -333,8 +336,9 @@ __device__ __forceinline__ void enc_fwd_body(const PvEncFwd& e, int rbk, float (
     lqd = en_block_sum(lqd, sm);
   }
   if (tid == 0) {
-    e.kl_part[2 * rbk] = e.beta * lp + e.beta_disc * lpd;
-    e.kl_part[2 * rbk + 1] = e.beta * lq + e.beta_disc * lqd;
+    const float poison = timed_out ? __int_as_float(0x7fc00000) : 0.0f;
+    e.kl_part[2 * rbk] = e.beta * lp + e.beta_disc * lpd + poison;
+    e.kl_part[2 * rbk + 1] = e.beta * lq + e.beta_disc * lqd + poison;
   }
   pv_lds_barrier();
   EN_STAMP(5);
