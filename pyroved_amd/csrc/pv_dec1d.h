@@ -16,14 +16,20 @@ void pv_dec1d_wt_entries(const float* params, const pv_op* ops, int n, float* wt
 // a[0][b][l][c] = bias[c * L0 + l] + sum_k z[b][k] wt[k][l * C0 + c] is computed while the sample is staged (and written to
 // a[0]); backward dz[b][k] = sum_{l,c} dL/d(a[0])[b][l][c] wt[k][l * C0 + c].  wt: pv_conv_wprep_table kind 7.  zd <= 8.
 struct PvD1L2f { const float* z; const float* wt; const float* bias; float* dz; int zd; };
+// the reparameterised sample and the head's backward in the same launches (ved.py:147-163 guide / model's latent site; a
+// standard-normal prior, no per-sample weights): forward z = mu + softplus(s) eps from head (B, ldh) = [mu | s | ...], written
+// to z / z_scale (and the optional copies), kl_part[2b], kl_part[2b+1] = beta * (log p(z_b), log q(z_b | x_b)); backward
+// dhead (B, ldh) from the latent gradient of the same launch.  Needs PvD1L2f in the same call (z is produced / dz consumed here).
+struct PvD1Head { const float* head; const float* eps; float* z; float* z_scale; float* z_loc_out; float* z_scale_out; float* kl_part;
+                  float* dhead; int ldh; float beta; };
 inline bool pv_dec1d_l2f_ok(int zd) { return zd >= 1 && zd <= 8; }
 // the observation likelihood of the stack's output (fc.py:143-152 through pv_lik_one; one output channel) in the forward launch:
 // y (B, per) the target, loc / dlda (B, per) optional, llb[b] = the sample's log-likelihood
 struct PvD1Lik { const float* y; float* loc; float* dlda; float* llb; int lik, sigmoid_out; float sig; };
 // a[1..n] written (the tensor between a fused kernel-1 convolution and its upsample never is); l2f != null: a[0] too, from z
 int pv_dec1d_fwd(const float* params, const pv_op* ops, int n, const float* wt, int B, int L0, int C0, float* const* a, hipStream_t s,
-                 const PvD1L2f* l2f = nullptr, const PvD1Lik* lk = nullptr);
+                 const PvD1L2f* l2f = nullptr, const PvD1Lik* lk = nullptr, const PvD1Head* hd = nullptr);
 // gown[i] <- dL/d(a[i]) for every convolution i, the producing convolution's activation derivative applied; g_out = dL/d(a[n]);
 // l2f != null: l2f->dz too
 int pv_dec1d_bwd(const pv_op* ops, int n, const float* wt, int B, int L0, int C0, float* const* a, const float* g_out,
-                 float* const* gown, hipStream_t s, const PvD1L2f* l2f = nullptr);
+                 float* const* gown, hipStream_t s, const PvD1L2f* l2f = nullptr, const PvD1Head* hd = nullptr);

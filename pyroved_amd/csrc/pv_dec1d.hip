@@ -52,6 +52,9 @@ struct D1Args {
   // backward: dz[b][k] = <dL/d(a[0])[b], wt[k]> from the last step's result
   const float* z; const float* l2f_wt; const float* l2f_b; float* a0_out; float* dz;
   int zd;
+  // the head in the same launches (h_head != null): forward z from [mu | softplus input] and eps, backward dhead
+  const float* h_head; const float* h_eps; float* h_z; float* h_zs; float* h_zlo; float* h_zso; float* h_kl; float* h_dhead;
+  int h_ldh; float h_beta;
   // forward: the observation likelihood of the last step's result (y != null)
   const float* y; float* loc; float* dlda; float* llb;
   int lik, sigmoid_out; float sig;
@@ -289,8 +292,30 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
         const int c4n = A.C0 >> 2;
         const int64_t F = (int64_t)A.L0 * A.C0;
         float zv[8];
+        if (A.h_head) {                                // the reparameterised sample is drawn here (every thread: zd <= 8 values)
+          float lp = 0.0f, lq = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) zv[k] = k < A.zd ? A.z[(int64_t)b * A.zd + k] : 0.0f;
+          for (int k = 0; k < 8; ++k) {
+            zv[k] = 0.0f;
+            if (k < A.zd) {
+              const float mu = A.h_head[(int64_t)b * A.h_ldh + k], sp = A.h_head[(int64_t)b * A.h_ldh + A.zd + k];
+              const float sig = pv_softplus(sp), ep = A.h_eps[(int64_t)b * A.zd + k];
+              const float zz = mu + sig * ep, d = zz - mu;
+              zv[k] = zz;
+              lq += -(d * d) / (2.0f * (sig * sig)) - logf(sig) - 0.91893853320467274178f;      // torch Normal.log_prob
+              lp += -(zz * zz) / 2.0f - 0.91893853320467274178f;
+              if (tid == 0) {
+                A.h_z[(int64_t)b * A.zd + k] = zz; A.h_zs[(int64_t)b * A.zd + k] = sig;
+                if (A.h_zlo) A.h_zlo[(int64_t)b * A.zd + k] = mu;
+                if (A.h_zso) A.h_zso[(int64_t)b * A.zd + k] = sig;
+              }
+            }
+          }
+          if (tid == 0) { A.h_kl[2 * b] = A.h_beta * lp; A.h_kl[2 * b + 1] = A.h_beta * lq; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) zv[k] = k < A.zd ? A.z[(int64_t)b * A.zd + k] : 0.0f;
+        }
         for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
           const int l = e / c4n, c = 4 * (e - l * c4n);
           f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -405,6 +430,16 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
         float v = 0.0f;
         for (int w = 0; w < D1_WAVES; ++w) v += red[w * 8 + tid];
         A.dz[(int64_t)b * A.zd + tid] = v;
+        if (A.h_head) {                                // head backward (pv_head_bwd_elem, no coordinates / weights)
+          const int64_t e = (int64_t)b * A.zd + tid;
+          const float zz = A.h_z[e], sig = A.h_zs[e], ep = A.h_eps[e];
+          const float sp = A.h_head[(int64_t)b * A.h_ldh + A.zd + tid];
+          const float g = v + A.h_beta * zz;           // d(-ll - beta log p(z)) / dz
+          const float dsig = g * ep - A.h_beta / sig;  // + beta d(log q) / d(sigma) (total derivative)
+          const float sgm = sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp));
+          A.h_dhead[(int64_t)b * A.h_ldh + tid] = g;
+          A.h_dhead[(int64_t)b * A.h_ldh + A.zd + tid] = dsig * sgm;
+        }
       }
     }
     D1_STAMP(2 + A.n + 1);
@@ -578,15 +613,20 @@ static int launch(D1Args& A, hipStream_t s) {
 }
 
 int pv_dec1d_fwd(const float* params, const pv_op* ops, int n, const float* wt, int B, int L0, int C0, float* const* a, hipStream_t s,
-                 const PvD1L2f* l2f, const PvD1Lik* lk) {
+                 const PvD1L2f* l2f, const PvD1Lik* lk, const PvD1Head* hd) {
   D1Args A;
   if (!build(A, false, params, ops, n, wt, B, L0, C0, a, nullptr, nullptr)) return PV_EINVAL;
+  if (hd) {
+    if (!l2f || !hd->head || !hd->eps || !hd->z || !hd->z_scale || !hd->kl_part) return PV_EINVAL;
+    A.h_head = hd->head; A.h_eps = hd->eps; A.h_z = hd->z; A.h_zs = hd->z_scale; A.h_zlo = hd->z_loc_out; A.h_zso = hd->z_scale_out;
+    A.h_kl = hd->kl_part; A.h_ldh = hd->ldh; A.h_beta = hd->beta;
+  }
   if (lk) {
     if (!lk->y || !lk->llb) return PV_EINVAL;
     A.y = lk->y; A.loc = lk->loc; A.dlda = lk->dlda; A.llb = lk->llb; A.lik = lk->lik; A.sigmoid_out = lk->sigmoid_out; A.sig = lk->sig;
   }
   if (l2f) {
-    if (!pv_dec1d_l2f_ok(l2f->zd) || !l2f->z || !l2f->wt) return PV_EINVAL;
+    if (!pv_dec1d_l2f_ok(l2f->zd) || (!l2f->z && !hd) || !l2f->wt) return PV_EINVAL;
     A.z = l2f->z; A.l2f_wt = l2f->wt; A.l2f_b = l2f->bias; A.a0_out = a[0]; A.zd = l2f->zd;
   }
   return launch<false>(A, s);
@@ -594,9 +634,14 @@ int pv_dec1d_fwd(const float* params, const pv_op* ops, int n, const float* wt, 
 
 // g_out = dL/d(a[n]) (B, Ln, Cn); gown[i] <- dL/d(a[i]) for every conv op i (with act'(a[i]) of a producing convolution applied)
 int pv_dec1d_bwd(const pv_op* ops, int n, const float* wt, int B, int L0, int C0, float* const* a, const float* g_out,
-                 float* const* gown, hipStream_t s, const PvD1L2f* l2f) {
+                 float* const* gown, hipStream_t s, const PvD1L2f* l2f, const PvD1Head* hd) {
   D1Args A;
   if (!build(A, true, nullptr, ops, n, wt, B, L0, C0, a, g_out, gown)) return PV_EINVAL;
+  if (hd) {
+    if (!l2f || !hd->head || !hd->eps || !hd->z || !hd->z_scale || !hd->dhead) return PV_EINVAL;
+    A.h_head = hd->head; A.h_eps = hd->eps; A.h_z = hd->z; A.h_zs = hd->z_scale; A.h_dhead = hd->dhead; A.h_ldh = hd->ldh;
+    A.h_beta = hd->beta;
+  }
   if (l2f) {
     if (!pv_dec1d_l2f_ok(l2f->zd) || !l2f->wt || !l2f->dz || (A.op[A.n - 1].N & 3) != 0) return PV_EINVAL;
     A.l2f_wt = l2f->wt; A.dz = l2f->dz; A.zd = l2f->zd;

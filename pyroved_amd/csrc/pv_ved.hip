@@ -31,7 +31,7 @@ struct VLayout {
   float* x_nsc; float* y_nsc; float* loc_nsc;
   float* feat; float* head; float* dhead; float* z; float* z_scale; float* dzc;
   float* f0; float* df0;
-  float* llrow; float* dlda; float* llb;
+  float* llrow; float* dlda; float* llb; float* kl_part;          // kl_part (2 B): per-sample KL terms when the head rides in the decoder's launch
   float* g[2];                                         // gradient ping-pong (largest activation)
   float* dg[PV_MAX_OPS + 1];                           // the decoder's per-op gradients dL/d(da[i]) (kept for the batched weight gradients)
   float* eg[PV_MAX_OPS + 1];                           // the encoder's per-op gradients dL/d(ea[i]) (their weight gradients run on the side stream)
@@ -97,7 +97,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   const int64_t OUT = od.elems(B);
   L.y_nsc = p->out_ch > 1 ? c.take(OUT) : nullptr;
   L.loc_nsc = p->out_ch > 1 ? c.take(OUT) : nullptr;
-  L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B);
+  L.llrow = c.take(OUT); L.dlda = c.take(OUT); L.llb = c.take(B); L.kl_part = c.take(2 * B);
   L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
   for (int i = 0; i <= p->n_dec_ops; ++i) L.dg[i] = c.take(L.ds[i].elems(B));
   {
@@ -131,6 +131,11 @@ bool dec1d_active(const pv_ved_plan* p, const VLayout& L) {
   for (int i = 0; i + 1 < p->n_dec_ops; ++i)
     if (p->dec[i + 1].kind == PV_OP_UPSAMPLE2 && !pvcs::k1up_fusable(p->dec, p->n_dec_ops, p->ndim_out, i)) return false;
   return true;
+}
+
+// the head (reparameterised sample, its KL terms, its backward) in the decoder's launches: with latent_to_features there
+bool head_folded(const pv_ved_plan* p, const VLayout& L) {
+  return dec1d_active(p, L) && L.l2f_wt && pv_dec1d_l2f_ok(p->z_dim) && !getenv("PV_NO_HEADFOLD");
 }
 
 // tile the conv weights the coming launches need: stack 0 / 1 / both, with or without the input-gradient orientation
@@ -182,6 +187,7 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
     PV_TRY(linear_fwd(L.feat, L.F, p->params + p->head.w_off, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr,
                       L.head, nullptr, 2 * p->z_dim, B, L.F, 2 * p->z_dim, PV_ACT_NONE, L.sc.ws, L.sc.ws_bytes, s));
   }
+  if (with_kl && head_folded(p, L)) return 0;          // (z is drawn in the decoder's launch: ved_decoder_fwd)
   PvHead h{};
   h.head = L.head; h.eps = with_kl ? p->eps : L.z_scale; h.z = L.z; h.z_scale = L.z_scale;
   h.z_loc_out = z_loc_out; h.z_scale_out = z_scale_out;
@@ -191,14 +197,17 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
 }
 
 // decoder forward from z (B, z_dim) to the logits / pre-sigmoid output in L.da[n_dec_ops]
-int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_t s, const PvD1Lik* lk = nullptr, bool* lik_done = nullptr) {
+int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_t s, const PvD1Lik* lk = nullptr, bool* lik_done = nullptr,
+                    bool with_head = false) {
   const int64_t B = p->batch;
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
   if (L.l2f_wt && dec1d_active(p, L) && pv_dec1d_l2f_ok(p->z_dim)) {       // the Linear rides in the decoder's launch
     const PvD1L2f lf{z, L.l2f_wt, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr, nullptr, p->z_dim};
+    const PvD1Head hd{L.head, p->eps, L.z, L.z_scale, p->z_loc, p->z_scale, L.kl_part, nullptr, 2 * p->z_dim, p->beta};
     if (lik_done) *lik_done = lk != nullptr;
-    return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s, &lf, lk);
+    return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s, &lf, lk,
+                        with_head && head_folded(p, L) ? &hd : nullptr);
   }
   if (L.l2f_wt) {                                      // Linear + view(-1, C0, *dims), written channels-last directly
     PV_TRY(pv_l2f_fwd(z, L.l2f_wt, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr, L.da[0], (int)B, d0.H * d0.W, d0.C,
@@ -255,7 +264,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   const int64_t OUT = od.elems(B), per = OUT / B, S = (int64_t)od.H * od.W;
   const PvD1Lik lk{p->y, p->loc, want_grads ? L.dlda : nullptr, L.llb, p->lik, p->sigmoid_out, p->decoder_sig};
   bool lik_done = false;
-  PV_TRY(ved_decoder_fwd(p, L, L.z, s, p->out_ch == 1 ? &lk : nullptr, &lik_done));
+  PV_TRY(ved_decoder_fwd(p, L, L.z, s, p->out_ch == 1 ? &lk : nullptr, &lik_done, true));
   const float* y = p->y;
   if (!lik_done && p->out_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->y, L.y_nsc, B, p->out_ch, S, s)); y = L.y_nsc; }
   float* loc = p->loc ? (p->out_ch > 1 ? L.loc_nsc : p->loc) : nullptr;
@@ -271,7 +280,8 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
     if (p->loc && p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, p->loc, B, p->out_ch, S, s));
     PV_TRY(pv_segsum(L.llrow, B, per, L.llb, s));
   }
-  PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, nullptr, 0, p->beta, s));
+  if (head_folded(p, L)) PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, (int)B, 1.0f /* partials come scaled */, s));
+  else PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, nullptr, 0, p->beta, s));
   if (!want_grads) return 0;
 
   PvFinishList fin{};                                  // the conv stacks' weight-gradient reductions: one launch at the end
@@ -286,13 +296,16 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   PvK1Batch k1b{};
   if (k1b_env) fin.k1b = &k1b;
   hipStream_t side2 = k1b_env ? pv_side_stream_for(s) : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
-  bool dz_done = false;
+  bool dz_done = false, head_done = false;
   if (k1b_env && dec1d_active(p, L)) {
     // every input gradient of the decoder in one launch (the fork event rides on it), then the weight gradients are recorded
     if (side2) pv_fork_arm();
     dz_done = L.l2f_wt && pv_dec1d_l2f_ok(p->z_dim);   // the latent gradient rides in the same launch
     const PvD1L2f lf{nullptr, L.l2f_wt, nullptr, L.dzc, p->z_dim};
-    PV_TRY(pv_dec1d_bwd(p->dec, p->n_dec_ops, L.d1_wt, (int)B, L.ds[0].H, L.ds[0].C, L.da, L.dlda, L.dg, s, dz_done ? &lf : nullptr));
+    head_done = dz_done && head_folded(p, L);          // ... and the head's backward
+    const PvD1Head hd{L.head, p->eps, L.z, L.z_scale, nullptr, nullptr, nullptr, L.dhead, 2 * p->z_dim, p->beta};
+    PV_TRY(pv_dec1d_bwd(p->dec, p->n_dec_ops, L.d1_wt, (int)B, L.ds[0].H, L.ds[0].C, L.da, L.dlda, L.dg, s, dz_done ? &lf : nullptr,
+                        head_done ? &hd : nullptr));
     PV_TRY(pvcs::stack_wgrads(p->params, p->grads, p->dec, p->n_dec_ops, p->ndim_out, (int)B, L.da, L.ds, L.dlda, L.dg, L.sc, s, 1));
     g = L.dg[0];
   } else {
@@ -330,7 +343,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   PvHeadBwd hb{};
   hb.dzc = L.dzc; hb.ldzc = z; hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps; hb.head = L.head; hb.dhead = L.dhead;
   hb.B = (int)B; hb.z_dim = (int)z; hb.coord_dim = 0; hb.beta = p->beta;
-  PV_TRY(pv_head_bwd(hb, s));
+  if (!head_done) PV_TRY(pv_head_bwd(hb, s));
   const Shape& fe = L.es[p->n_enc_ops];
   const pv_op& last = p->enc[p->n_enc_ops - 1];
   bool g_is_pre = false;
