@@ -112,6 +112,10 @@ bool pv_convhead_supported(int64_t F, int out);
 int64_t pv_convhead_ws(int B, int64_t F, int out);
 int pv_convhead_fwd(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
                     int64_t ws_bytes, hipStream_t s);
+// the forward without its finish launch: *part (B, *nseg, out) partial sums in ws, to be added in segment order on top of the bias
+// by the consumer (pv_dec1d.hip, per sample); PV_EINVAL when the matrix-core form does not apply
+int pv_convhead_fwd_partials(const float* a, const float* wt, int B, int64_t F, int out, void* ws, int64_t ws_bytes, hipStream_t s,
+                             const float** part, int* nseg);
 int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act, float* g, int B, int64_t F, int out,
                     hipStream_t s);
 int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, void* ws,

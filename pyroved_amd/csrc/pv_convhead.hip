@@ -437,6 +437,19 @@ int pv_convhead_fwd_mfma(const float* a, const float* wt, const float* bias, flo
   return 0;
 }
 
+// the matrix-core forward WITHOUT its finish launch: *part (B, *nseg, out) partial sums in ws; the consumer adds them in segment
+// order on top of the bias (pv_dec1d.hip does, per sample).  PV_EINVAL when that form does not apply.
+int pv_convhead_fwd_partials(const float* a, const float* wt, int B, int64_t F, int out, void* ws, int64_t ws_bytes, hipStream_t s,
+                             const float** part, int* nseg) {
+  if (!pv_convhead_supported(F, out) || !ch_use_mfma() || F % 16 != 0 || ws_bytes < pv_convhead_mfma_ws(B, F, out)) return PV_EINVAL;
+  const int ns = chm_segs(B, F);
+  float* pt = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(pv_convhead_fwd_mfma_kernel, dim3((unsigned)((B + 15) / 16), (unsigned)ns), dim3(256), 0, s, a, wt, pt, B, F, out, ns);
+  PV_LAUNCH_CHECK();
+  *part = pt; *nseg = ns;
+  return 0;
+}
+
 int pv_convhead_wgrad_mfma(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, hipStream_t s) {
   const int64_t F = (int64_t)S * C;
   if (!pv_convhead_supported(F, out)) return PV_EINVAL;

@@ -20,8 +20,11 @@ struct PvD1L2f { const float* z; const float* wt; const float* bias; float* dz; 
 // standard-normal prior, no per-sample weights): forward z = mu + softplus(s) eps from head (B, ldh) = [mu | s | ...], written
 // to z / z_scale (and the optional copies), kl_part[2b], kl_part[2b+1] = beta * (log p(z_b), log q(z_b | x_b)); backward
 // dhead (B, ldh) from the latent gradient of the same launch.  Needs PvD1L2f in the same call (z is produced / dz consumed here).
+// part != null (forward): head itself is produced here, head[b][j] = bias[j] + sum_seg part[b][seg][j] (pv_convhead_fwd_partials),
+// and written to head_out (B, ldh)
 struct PvD1Head { const float* head; const float* eps; float* z; float* z_scale; float* z_loc_out; float* z_scale_out; float* kl_part;
-                  float* dhead; int ldh; float beta; };
+                  float* dhead; int ldh; float beta;
+                  const float* part = nullptr; const float* bias = nullptr; float* head_out = nullptr; int nseg = 0; };
 inline bool pv_dec1d_l2f_ok(int zd) { return zd >= 1 && zd <= 8; }
 // the observation likelihood of the stack's output (fc.py:143-152 through pv_lik_one; one output channel) in the forward launch:
 // y (B, per) the target, loc / dlda (B, per) optional, llb[b] = the sample's log-likelihood

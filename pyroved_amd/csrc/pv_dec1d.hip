@@ -55,6 +55,7 @@ struct D1Args {
   // the head in the same launches (h_head != null): forward z from [mu | softplus input] and eps, backward dhead
   const float* h_head; const float* h_eps; float* h_z; float* h_zs; float* h_zlo; float* h_zso; float* h_kl; float* h_dhead;
   int h_ldh; float h_beta;
+  const float* h_part; const float* h_bias; float* h_hout; int h_nseg;     // forward: head from its partial sums (pv_convhead_fwd_partials)
   // forward: the observation likelihood of the last step's result (y != null)
   const float* y; float* loc; float* dlda; float* llb;
   int lik, sigmoid_out; float sig;
@@ -298,7 +299,15 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
           for (int k = 0; k < 8; ++k) {
             zv[k] = 0.0f;
             if (k < A.zd) {
-              const float mu = A.h_head[(int64_t)b * A.h_ldh + k], sp = A.h_head[(int64_t)b * A.h_ldh + A.zd + k];
+              float mu, sp;
+              if (A.h_part) {                          // the conv head's finish: bias + partial sums in segment order
+                mu = A.h_bias ? A.h_bias[k] : 0.0f; sp = A.h_bias ? A.h_bias[A.zd + k] : 0.0f;
+                const float* pt = A.h_part + (int64_t)b * A.h_nseg * A.h_ldh;
+                for (int sg = 0; sg < A.h_nseg; ++sg) { mu += pt[sg * A.h_ldh + k]; sp += pt[sg * A.h_ldh + A.zd + k]; }
+                if (tid == 0) { A.h_hout[(int64_t)b * A.h_ldh + k] = mu; A.h_hout[(int64_t)b * A.h_ldh + A.zd + k] = sp; }
+              } else {
+                mu = A.h_head[(int64_t)b * A.h_ldh + k]; sp = A.h_head[(int64_t)b * A.h_ldh + A.zd + k];
+              }
               const float sig = pv_softplus(sp), ep = A.h_eps[(int64_t)b * A.zd + k];
               const float zz = mu + sig * ep, d = zz - mu;
               zv[k] = zz;
@@ -620,6 +629,10 @@ int pv_dec1d_fwd(const float* params, const pv_op* ops, int n, const float* wt, 
     if (!l2f || !hd->head || !hd->eps || !hd->z || !hd->z_scale || !hd->kl_part) return PV_EINVAL;
     A.h_head = hd->head; A.h_eps = hd->eps; A.h_z = hd->z; A.h_zs = hd->z_scale; A.h_zlo = hd->z_loc_out; A.h_zso = hd->z_scale_out;
     A.h_kl = hd->kl_part; A.h_ldh = hd->ldh; A.h_beta = hd->beta;
+    if (hd->part) {
+      if (!hd->head_out || hd->nseg < 1 || hd->ldh != 2 * l2f->zd) return PV_EINVAL;
+      A.h_part = hd->part; A.h_bias = hd->bias; A.h_hout = hd->head_out; A.h_nseg = hd->nseg;
+    }
   }
   if (lk) {
     if (!lk->y || !lk->llb) return PV_EINVAL;

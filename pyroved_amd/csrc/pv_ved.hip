@@ -31,6 +31,7 @@ struct VLayout {
   float* x_nsc; float* y_nsc; float* loc_nsc;
   float* feat; float* head; float* dhead; float* z; float* z_scale; float* dzc;
   float* f0; float* df0;
+  const float* head_part = nullptr; int head_nseg = 0;            // the conv head's partial sums when its finish rides in the decoder's launch
   float* llrow; float* dlda; float* llb; float* kl_part;          // kl_part (2 B): per-sample KL terms when the head rides in the decoder's launch
   float* g[2];                                         // gradient ping-pong (largest activation)
   float* dg[PV_MAX_OPS + 1];                           // the decoder's per-op gradients dL/d(da[i]) (kept for the batched weight gradients)
@@ -179,7 +180,12 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
   L.sc.ev_op = -1;
   const Shape& fe = L.es[p->n_enc_ops];
   // torch flattens (C, spatial): features2latent sees channels-first order — the weight is re-indexed, not the features
-  if (L.head_wt) {
+  L.head_part = nullptr;
+  if (L.head_wt && with_kl && head_folded(p, L) && !getenv("PV_NO_HEADPART") &&
+      pv_convhead_fwd_partials(L.ea[p->n_enc_ops], L.head_wt, (int)B, L.F, 2 * p->z_dim, L.sc.ws, L.sc.ws_bytes, s, &L.head_part,
+                               &L.head_nseg) == 0) {
+    // (the partial sums meet in the decoder's launch, which writes L.head)
+  } else if (L.head_wt) {
     PV_TRY(pv_convhead_fwd(L.ea[p->n_enc_ops], L.head_wt, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr, L.head,
                            (int)B, L.F, 2 * p->z_dim, L.sc.ws, L.sc.ws_bytes, s));
   } else {
@@ -204,7 +210,8 @@ int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
   if (L.l2f_wt && dec1d_active(p, L) && pv_dec1d_l2f_ok(p->z_dim)) {       // the Linear rides in the decoder's launch
     const PvD1L2f lf{z, L.l2f_wt, p->l2f.b_off >= 0 ? p->params + p->l2f.b_off : nullptr, nullptr, p->z_dim};
-    const PvD1Head hd{L.head, p->eps, L.z, L.z_scale, p->z_loc, p->z_scale, L.kl_part, nullptr, 2 * p->z_dim, p->beta};
+    PvD1Head hd{L.head, p->eps, L.z, L.z_scale, p->z_loc, p->z_scale, L.kl_part, nullptr, 2 * p->z_dim, p->beta};
+    if (L.head_part) { hd.part = L.head_part; hd.bias = p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr; hd.head_out = L.head; hd.nseg = L.head_nseg; }
     if (lik_done) *lik_done = lk != nullptr;
     return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s, &lf, lk,
                         with_head && head_folded(p, L) ? &hd : nullptr);
