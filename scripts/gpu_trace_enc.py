@@ -1,3 +1,5 @@
+"""Phase stamps of the encoder launch (library built with -DEN_TRACE: pv_encoder.hip): cycles per phase of the first row block's
+workgroup; PV_ENC_TWO=1 for the two-launch form."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
