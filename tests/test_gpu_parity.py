@@ -1935,6 +1935,33 @@ def test_fused_1d_decoder_matches_layer_launches(gpu_device, precision):
         dbg.pv_debug_dec1d(-1)
 
 
+def test_fused_1d_decoder_more_samples_than_workgroups(gpu_device):
+    """The fused Conv1d decoder launches at most 2048 workgroups; beyond that a workgroup carries several samples one after
+    the other through the same LDS buffers (csrc/pv_dec1d.hip: the grid-stride loop and its closing barrier).  A batch of
+    2100 against the layer launches (pv_debug_dec1d(0)): loss terms, every gradient, decode."""
+    import ctypes as C
+    dbg = C.CDLL(_abi.LIB_PATH)
+    g = torch.Generator().manual_seed(13)
+    b = 2100
+    x, y, eps = torch.rand(b, 1, 16, 16, generator=g), torch.rand(b, 1, 16, generator=g), torch.randn(b, 2, generator=g)
+    res = []
+    try:
+        for on in (0, 1):
+            dbg.pv_debug_dec1d(on)
+            m = pv.models.VED((16, 16), (16,), latent_dim=2, hidden_dim_e=[(32,), (64, 64)], hidden_dim_d=[(64, 64), (32,)],
+                              seed=1, device="cuda")
+            eng = m.engine()
+            eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+            res.append((eng.scalars.clone(), eng.grad.clone(), m.decode(torch.randn(b, 2, generator=torch.Generator().manual_seed(3)))))
+    finally:
+        dbg.pv_debug_dec1d(-1)
+    (s0, g0, d0), (s1, g1, d1) = res
+    assert torch.isfinite(g1).all()
+    np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=3e-6)
+    assert rel_l2(g1, g0) < 3e-6
+    assert torch.allclose(d1, d0, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("family", ["ivae", "ved"])
 def test_steps_replay_from_a_captured_graph(gpu_device, family):
     """A step captured into a graph (torch.cuda.graph on the stream the library launches on) replays correctly: under
