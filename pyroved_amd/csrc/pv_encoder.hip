@@ -453,6 +453,9 @@ static unsigned enc_next_gen() {
   return v;
 }
 
+static int g_enc_two = -1;                            // test hook: 1 two launches, 0 one launch, -1 the environment's choice
+extern "C" void pv_debug_enc_two(int two) { g_enc_two = two < 0 ? -1 : (two ? 1 : 0); }
+
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
   const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
   const int cb = (e.enc[0].out_dim + 15) / 16;
@@ -462,7 +465,8 @@ int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
     extra = (int)((work + (int64_t)cb * 64 * L1_WAVES - 1) / ((int64_t)cb * 64 * L1_WAVES));
     if (extra > 16) extra = 16;
   }
-  static const int two = getenv("PV_ENC_TWO") && atoi(getenv("PV_ENC_TWO")) ? 1 : 0;     // (A/B: the two launches)
+  static const int two_env = getenv("PV_ENC_TWO") && atoi(getenv("PV_ENC_TWO")) ? 1 : 0;     // (A/B: the two launches)
+  const int two = g_enc_two >= 0 ? g_enc_two : two_env;
   if (e.flags && !two && !pv_stream_capturing(s)) {    // (a captured launch would replay its generation value: two launches then)
     PvEncFwd m = e;
     m.gen = enc_next_gen();

@@ -1935,6 +1935,33 @@ def test_fused_1d_decoder_matches_layer_launches(gpu_device, precision):
         dbg.pv_debug_dec1d(-1)
 
 
+def test_one_launch_encoder_at_large_batch(gpu_device):
+    """The compact encoder's one-launch form (csrc/pv_encoder.hip pv_enc_kernel: first-layer tiles and the rest of the encoder in
+    one grid, hand-off through per-tile flags) at a batch whose grid (4 600 workgroups) does not fit the device at once: the
+    consumers are dispatched after every producer, so it must neither hang nor read a tile early.  Bit-identical to the
+    two-launch form (pv_debug_enc_two): encode and one training step, iVAE 28x28 (fcEncoderNet, nets/fc.py:51-61)."""
+    import ctypes as C
+    dbg = C.CDLL(_abi.LIB_PATH)
+    g = torch.Generator().manual_seed(17)
+    b = 8200                                            # (not a multiple of 16: the last row block is partial)
+    x, eps = torch.rand(b, 28, 28, generator=g).cuda(), torch.randn(b, 5, generator=g).cuda()
+    res = []
+    try:
+        for two in (1, 0):
+            dbg.pv_debug_enc_two(two)
+            m = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+            eng = m.engine(fused=3)
+            zl, zs = m.encode(x)
+            eng.loss_and_grads(x, eps)
+            torch.cuda.synchronize()
+            res.append((torch.as_tensor(zl).clone(), torch.as_tensor(zs).clone(), eng.scalars.clone(), eng.grad.clone()))
+    finally:
+        dbg.pv_debug_enc_two(-1)
+    for a, c in zip(*res):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, c)
+
+
 def test_fused_1d_decoder_more_samples_than_workgroups(gpu_device):
     """The fused Conv1d decoder launches at most 2048 workgroups; beyond that a workgroup carries several samples one after
     the other through the same LDS buffers (csrc/pv_dec1d.hip: the grid-stride loop and its closing barrier).  A batch of
