@@ -12,7 +12,7 @@ from abc import abstractmethod
 import torch
 import torch.nn as nn
 
-from ..utils import init_dataloader, generate_grid
+from ..utils import iter_batches, generate_grid
 
 tt = torch.tensor
 
@@ -113,7 +113,7 @@ class baseVAE(nn.Module):
     def _encode(self, *input_args, device: str = None, **kwargs: int) -> torch.Tensor:
         """Encodes data batch-by-batch with the trained encoder (base.py:121-143);
         returns cat([z_loc, z_scale], -1) on the CPU."""
-        loader = init_dataloader(*input_args, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
+        loader = iter_batches(*input_args, batch_size=kwargs.get("batch_size", 100))
         z_encoded = []
         if not self._engine_ready():
             # a bare baseVAE with only set_encoder() called (the reference's own tests use it so): the network's
@@ -137,7 +137,7 @@ class baseVAE(nn.Module):
     def _decode(self, z_new: torch.Tensor, device: str = None, **kwargs: int) -> torch.Tensor:
         """Decodes latent coordinates batch-by-batch (base.py:145-171).  kwargs: batch_size,
         and for invariant models angle / shift / scale of the coordinate grid."""
-        loader = init_dataloader(z_new, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
+        loader = iter_batches(z_new, batch_size=kwargs.get("batch_size", 100))
         if not self._engine_ready():
             # bare baseVAE with only set_decoder() called: transform the grid once, then the decoder's own forward
             from ..utils import transform_coordinates

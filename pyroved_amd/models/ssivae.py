@@ -15,7 +15,7 @@ import torch
 from .base import baseVAE
 from .ivae import _plot_manifold
 from ..nets import fcDecoderNet, fcEncoderNet, sDecoderNet, fcClassifierNet, fcRegressorNet
-from ..utils import (get_sampler, set_deterministic_mode, to_onehot, init_dataloader, generate_latent_grid,
+from ..utils import (get_sampler, set_deterministic_mode, to_onehot, iter_batches, generate_latent_grid,
                      generate_latent_grid_traversal)
 
 tt = torch.tensor
@@ -75,7 +75,7 @@ class _ssBase(baseVAE):
 
     def _label_net_batches(self, x_new: torch.Tensor, **kwargs: int) -> torch.Tensor:
         eng = self.engine()
-        loader = init_dataloader(x_new, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
+        loader = iter_batches(x_new, batch_size=kwargs.get("batch_size", 100))
         out = []
         for (x_i,) in loader:
             with torch.no_grad():

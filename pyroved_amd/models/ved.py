@@ -13,7 +13,7 @@ import torch
 
 from .base import baseVAE
 from ..nets.conv import convEncoderNet, convDecoderNet
-from ..utils import get_sampler, init_dataloader, set_deterministic_mode
+from ..utils import get_sampler, iter_batches, set_deterministic_mode
 
 
 class VED(baseVAE):
@@ -97,7 +97,7 @@ class VED(baseVAE):
     def predict(self, x_new: torch.Tensor, **kwargs: int) -> torch.Tensor:
         """Forward prediction (encode -> 30 samples -> decode): mean and standard deviation (models/ved.py:198-216)."""
         eng = self.engine()
-        loader = init_dataloader(x_new, shuffle=False, **{k: v for k, v in kwargs.items() if k == "batch_size"})
+        loader = iter_batches(x_new, batch_size=kwargs.get("batch_size", 100))
         mus, sds = [], []
         for (x_i,) in loader:
             z_mu, z_sig = eng.encode(x_i.to(eng.device, torch.float32))

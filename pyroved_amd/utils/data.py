@@ -5,7 +5,7 @@ Behaviour contract kept from the reference (it defines the data order parity dep
 a `torch.Generator(device)` handed to the loader only when `device=` is passed.  SVItrainer recognises loaders
 built here (plain TensorDataset + standard samplers) and feeds them from device memory (trainers/svi.py).
 """
-from typing import Tuple
+from typing import Iterator, Tuple
 
 import torch
 from torch.utils.data import DataLoader, RandomSampler, TensorDataset
@@ -23,6 +23,18 @@ def init_dataloader(*args: torch.Tensor, random_sampler: bool = False, shuffle: 
     else:
         opts["shuffle"] = shuffle
     return DataLoader(ds, **opts)
+
+
+def iter_batches(*args: torch.Tensor, batch_size: int = 100) -> Iterator[Tuple[torch.Tensor, ...]]:
+    """The batches `init_dataloader(*args, shuffle=False, batch_size=...)` yields — same boundaries, same order, the last
+    one partial — as views of the callers' tensors.  The inference loops (encode / decode / predict / classifier) walk
+    their input in order, where a DataLoader over a TensorDataset indexes and collates SAMPLE BY SAMPLE on the host
+    (0.3-1.5 s per 65 536 images of 28x28, ~50x the kernels' time)."""
+    n = args[0].shape[0]
+    if any(a.shape[0] != n for a in args):
+        raise ValueError("Size mismatch between tensors")          # (TensorDataset's assertion)
+    for lo in range(0, n, batch_size):
+        yield tuple(a[lo:lo + batch_size] for a in args)
 
 
 def init_ssvae_dataloaders(data_unsup: torch.Tensor, data_sup: Tuple[torch.Tensor], data_val: Tuple[torch.Tensor],

@@ -389,6 +389,22 @@ def test_device_feed_falls_back_on_custom_loaders():
     assert tr._feed_cache is None and len(tr.loss_history["training_loss"]) == 1
 
 
+def test_inference_batches_equal_a_nonshuffling_loader():
+    """encode / decode / predict walk their input with utils.iter_batches instead of a DataLoader (which indexes and collates
+    sample by sample): same batch boundaries, order and contents as init_dataloader(..., shuffle=False) (base.py:129,154)."""
+    from pyroved_amd.utils import init_dataloader, iter_batches
+    x, y = torch.rand(1037, 5, 3), torch.rand(1037, 2)
+    for bs in (100, 1, 64, 1037, 2000):
+        a = list(init_dataloader(x, y, shuffle=False, batch_size=bs))
+        b = list(iter_batches(x, y, batch_size=bs))
+        assert len(a) == len(b)
+        for p_, q_ in zip(a, b):
+            assert torch.equal(p_[0], q_[0]) and torch.equal(p_[1], q_[1])
+    assert len(list(iter_batches(x))) == 11                         # the reference's default batch size of 100
+    with pytest.raises(ValueError):
+        list(iter_batches(x, y[:5]))
+
+
 def test_shard_bounds_cover_batch():
     for n in (0, 1, 5, 7, 256, 257):
         for w in (1, 2, 3, 8):
