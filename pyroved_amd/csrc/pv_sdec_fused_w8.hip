@@ -103,6 +103,15 @@ __device__ __forceinline__ float w8_sum_q(float v) {
   return v;
 }
 
+// timing ablations (profiling builds only, results are WRONG; profiles/r03e_w8_ablations.txt): -DW8_ABL=1 the forward loops
+// read every second weight group from LDS and use it twice, 2 the same in the dgrad loops, 4 the wgrad consume reads every
+// second k-step, 8 no dW1 / dW2 record stores
+#ifndef W8_ABL
+#define W8_ABL 0
+#endif
+#define W8_ABL_LOADS(bit, g) (!(W8_ABL & (bit)) || (((g) & 1) == 0))
+#define W8_ABL_BUF(bit, g) ((W8_ABL & (bit)) ? (((g) >> 1) & 1) : ((g) & 1))
+
 // forward layer of the wave's unit: out = bias + W in, both pre-scaled by C (C * pre-activation on return)
 // lane offsets (elements) of the weight reads, computed once per kernel and kept in registers (10 of them):
 //   forward: row 16*ob + r, logical chunk 4m + q -> physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])   (pv_fb_layout.h)
@@ -133,11 +142,11 @@ __device__ __forceinline__ void w8_layer_fwd(const __bf16* __restrict__ Wh, cons
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int m = g >> 2, op = (g & 3) * 2;
-    if (g + 1 < 16) load(g + 1, wh[(g + 1) & 1]);
+    if (g + 1 < 16 && W8_ABL_LOADS(1, g + 1)) load(g + 1, wh[W8_ABL_BUF(1, g + 1)]);
     W8_FENCE();
     const bf16x8 bh = w8_cat(ih[2 * m], ih[2 * m + 1]);
 #pragma unroll
-    for (int o = 0; o < 2; ++o) out[op + o] = MFMA32(wh[g & 1][o], bh, out[op + o]);
+    for (int o = 0; o < 2; ++o) out[op + o] = MFMA32(wh[W8_ABL_BUF(1, g)][o], bh, out[op + o]);
     W8_FENCE();
   }
 }
@@ -162,11 +171,11 @@ __device__ __forceinline__ void w8_layer_dgrad(const __bf16* __restrict__ Wh, co
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int m = g >> 2, kp = (g & 3) * 2;
-    if (g + 1 < 16) load(g + 1, wh[(g + 1) & 1]);
+    if (g + 1 < 16 && W8_ABL_LOADS(2, g + 1)) load(g + 1, wh[W8_ABL_BUF(2, g + 1)]);
     W8_FENCE();
     const bf16x8 bh = w8_cat(ih[2 * m], ih[2 * m + 1]);
 #pragma unroll
-    for (int o = 0; o < 2; ++o) out[kp + o] = MFMA32(wh[g & 1][o], bh, out[kp + o]);
+    for (int o = 0; o < 2; ++o) out[kp + o] = MFMA32(wh[W8_ABL_BUF(2, g)][o], bh, out[kp + o]);
     W8_FENCE();
   }
 }
@@ -248,9 +257,17 @@ __device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16*
   const short one = 0x3f80;                           // bf16 1.0
   const short8_ ones_s = {one, one, one, one, one, one, one, one};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+#if W8_ABL & 4
+  bf16x8 a[2], b[4];
+#endif
   for (int ks = 0; ks < ksteps; ++ks) {
     const int koff = toff + 32 * ks * LDS2;
+#if W8_ABL & 4
+    if ((ks & 1) == 0) {
+#else
     bf16x8 a[2], b[4];
+    {
+#endif
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
       // (the wave holds its two row blocks ROTATED by kh — a[s] / accW[s] are row block s ^ kh — so that its bias block is
@@ -262,6 +279,7 @@ __device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16*
     for (int o = 0; o < 4; ++o) {
       const int off = koff + 64 * kh + 16 * o;
       b[o] = w8_cat(w8_tr(sb + off), w8_tr(sb + off + 16 * LDS2));
+    }
     }
     W8_FENCE();
     accB = MFMA32(a[0], ones, accB);
@@ -690,8 +708,12 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
         for (int i = 0; i < 4; ++i) {
           // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16 (s ^ kh) + 4q + i][64kh + 16o + r]  (w8_wgrad_consume's rotation)
           const int e = (32 * jp + 16 * (s_ ^ kh) + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
+#if W8_ABL & 8
+          if (accW1[s_][o][i] == 1.2345e30f) rec[e] = accW2[s_][o][i];      // (timing ablation: no record stores)
+#else
           rec[e] = accW1[s_][o][i] * W8_RC;
           rec[FD_H * FD_H + e] = accW2[s_][o][i];
+#endif
         }
     if (r == 0) {
       const int j0 = 32 * jp + 16 * kh;

@@ -16,15 +16,18 @@ torch.cuda.synchronize()
 lib = C.CDLL(_abi.LIB_PATH)
 buf = (C.c_longlong * 512)()
 print("rc", lib.pv_debug_read_trace_w8(buf, 512))
-names = ["start", "coord layer", "fwd L1+tanh", "fwd L2+logit+lik", "dwo colsum+dpre2", "stage1+bar1", "consume wgrad2",
-         "dgrad2+dtanh", "dgrad1+dtanh", "bar2", "stage2+bar3", "consume wgrad1", "rowlocal(+flush)", "bar4", "colsum dpre0"]
+# stamps in program order (index 12 — the row-local coordinate backward — sits between barrier 2 and the round-2 staging)
+order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 10, 11, 13]
+names = {1: "coord layer", 2: "fwd L1+tanh", 3: "fwd L2+logit+lik", 4: "dwo colsum+dpre2", 5: "stage1+bar1", 6: "consume wgrad2",
+         7: "dgrad2+dtanh", 8: "dgrad1+dtanh", 9: "bar2", 12: "rowlocal+colsum dpre0(+flush)", 10: "stage2+bar3", 11: "consume wgrad1",
+         13: "bar4"}
 for w, base in ((0, 0), (7, 256)):
     for t in range(8):
         st = [buf[base + t * 16 + k] for k in range(15)]
         if not st[0]:
             continue
         out, prev = [], st[0]
-        for k in range(1, 15):
+        for k in order[1:]:
             if st[k]:
                 out.append("%s=%d" % (names[k], st[k] - prev)); prev = st[k]
         print("wave", w, "tile", t, "total", prev - st[0], " ".join(out))
