@@ -102,10 +102,13 @@ class VED(baseVAE):
         for (x_i,) in loader:
             z_mu, z_sig = eng.encode(x_i.to(eng.device, torch.float32))
             z_mu, z_sig = z_mu.cpu(), z_sig.cpu()
+            # the 30 draws come from the CPU generator as in the reference; they are decoded in ONE call (rows are
+            # independent) and reduced on the device: one host copy per batch instead of 30 decode + .cpu() round trips
             z_samples = torch.distributions.Normal(z_mu, z_sig).rsample(sample_shape=(30,))
-            y = torch.cat([eng.decode(z.to(eng.device))[None].cpu() for z in z_samples])
-            mus.append(y.mean(0))
-            sds.append(y.std(0))
+            y = eng.decode(z_samples.reshape(-1, z_samples.shape[-1]).to(eng.device))
+            y = y.reshape(30, z_mu.shape[0], *y.shape[1:])
+            mus.append(y.mean(0).cpu())
+            sds.append(y.std(0).cpu())
         return torch.cat(mus), torch.cat(sds)
 
     def manifold2d(self, d: int, plot: bool = True, **kwargs: Union[str, int]) -> torch.Tensor:

@@ -33,6 +33,10 @@ def iter_batches(*args: torch.Tensor, batch_size: int = 100) -> Iterator[Tuple[t
     n = args[0].shape[0]
     if any(a.shape[0] != n for a in args):
         raise ValueError("Size mismatch between tensors")          # (TensorDataset's assertion)
+    # iter(DataLoader) draws its base seed from the global CPU generator even when nothing is shuffled; an encode /
+    # classifier call between two epochs therefore moves the stream the NEXT epoch's permutation and noise come from
+    # (the reference trainers' recorded histories include that draw): consume exactly the same value here
+    torch.empty((), dtype=torch.int64).random_()
     for lo in range(0, n, batch_size):
         yield tuple(a[lo:lo + batch_size] for a in args)
 

@@ -401,6 +401,10 @@ def test_inference_batches_equal_a_nonshuffling_loader():
         for p_, q_ in zip(a, b):
             assert torch.equal(p_[0], q_[0]) and torch.equal(p_[1], q_[1])
     assert len(list(iter_batches(x))) == 11                         # the reference's default batch size of 100
+    # ... and the global CPU generator ends in the same state (iter(DataLoader) draws a base seed even without shuffling)
+    torch.manual_seed(5); list(init_dataloader(x, shuffle=False, batch_size=64)); a = torch.get_rng_state()
+    torch.manual_seed(5); list(iter_batches(x, batch_size=64)); b = torch.get_rng_state()
+    assert torch.equal(a, b)
     with pytest.raises(ValueError):
         list(iter_batches(x, y[:5]))
 
