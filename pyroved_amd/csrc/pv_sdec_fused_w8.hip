@@ -318,8 +318,18 @@ extern "C" int pv_debug_read_trace_w8(long long* out, int n) {
   if (n > 512) n = 512;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w8_trace), n * sizeof(long long));
 }
+// ... and of the launch around the tile loop: 0 kernel entry, 1 prologue done, 2 tile loop done, 3 record written (shader
+// cycles at [128 + k], the constant 100 MHz counter at [136 + k]: their ratio is the clock the launch ran at)
+#define W8_STAMP_K(k)                                                                             \
+  do {                                                                                           \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) {                 \
+      w8_trace[128 + (k)] = (long long)__builtin_readcyclecounter();                             \
+      w8_trace[136 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();                         \
+    }                                                                                            \
+  } while (0)
 #else
 #define W8_STAMP(k) do { } while (0)
+#define W8_STAMP_K(k) do { } while (0)
 #endif
 
 // LIK: the likelihood is a compile-time choice
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   float* info = reinterpret_cast<float*>(smb + WO_INFO);
   float* red = reinterpret_cast<float*>(smb + WO_RED);
   const char* gimg = reinterpret_cast<const char*>(f.wimg);
+  W8_STAMP_K(0);
 
   // ---- prologue: weight images by LDS-DMA (W1 at image 0, W2 at image 2 of the prepared set), vectors and tables ----
   {
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   }
   w8_wait_vm0();
   __syncthreads();
+  W8_STAMP_K(1);
   const float bo = f.bo[0];
 
   // persistent accumulators: the wave's slice (rows 16*wave .. +15) of dW1 (x C) and dW2, the bias sums, and the
@@ -695,6 +707,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     asm volatile("; W8_TILE_END");
   }
   if (!GRADS) return;
+  W8_STAMP_K(2);
 
   if (cur_b >= 0) flush_hz(cur_b);
   // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
@@ -755,6 +768,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     for (int w = 0; w < W8_WAVES; ++w) v += red[w];
     rec[2 * FD_H * FD_H + 5 * FD_H] = v;
   }
+  W8_STAMP_K(3);
 }
 
 int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {

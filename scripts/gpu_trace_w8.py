@@ -33,3 +33,9 @@ for w, base in ((0, 0), (7, 256)):
         print("wave", w, "tile", t, "total", prev - st[0], " ".join(out))
     nxt = [buf[base + t * 16] for t in range(8) if buf[base + t * 16]]
     print("wave", w, "tile starts (delta):", [b - a for a, b in zip(nxt, nxt[1:])])
+k = [buf[128 + i] for i in range(4)]
+if k[0]:
+    print("launch (workgroup 0, wave 0): prologue %d, tile loop %d, epilogue (flush, record, column sums) %d cycles" % (k[1] - k[0], k[2] - k[1], k[3] - k[2]))
+    rt = [buf[136 + i] for i in range(4)]
+    us = (rt[3] - rt[0]) / 100.0
+    print("  entry -> record written: %d cycles in %.2f us of the constant 100 MHz counter = %.3f GHz" % (k[3] - k[0], us, (k[3] - k[0]) / us / 1e3))
