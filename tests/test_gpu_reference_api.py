@@ -99,6 +99,28 @@ def test_ved_decode_predict_encode_manifold(input_dim, output_dim):
     assert model.manifold2d(4, plot=True).squeeze().shape == (16, *output_dim)
 
 
+def test_ved_predict_matches_its_definition():
+    """VED.predict (models/ved.py:198-216): mean and standard deviation over 30 decoded draws z ~ N(z_mu, z_sig) per input.
+    The 30 draws of a batch are decoded in ONE call; the same draws (same seed: predict's only generator use is the loop's
+    base seed and one rsample per batch) decoded one by one give the same numbers."""
+    model = models.VED((16, 16), (24,), seed=3)
+    x = torch.randn(5, 1, 16, 16, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(11)
+    mu, sd = model.predict(x, batch_size=3)
+    eng = model.engine()
+    torch.manual_seed(11)
+    torch.empty((), dtype=torch.int64).random_()
+    ref_mu, ref_sd = [], []
+    for lo in (0, 3):
+        z_mu, z_sig = eng.encode(x[lo:lo + 3].to(eng.device, torch.float32))
+        zs = torch.distributions.Normal(z_mu.cpu(), z_sig.cpu()).rsample(sample_shape=(30,))
+        y = torch.stack([eng.decode(z.to(eng.device)).cpu() for z in zs])
+        ref_mu.append(y.mean(0)); ref_sd.append(y.std(0))
+    assert mu.shape[0] == 5 and sd.shape == mu.shape and (sd >= 0).all()
+    np.testing.assert_allclose(mu.numpy(), torch.cat(ref_mu).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sd.numpy(), torch.cat(ref_sd).numpy(), rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("invariances", [None, ['r'], ['s'], ['r', 't', 's']])
 def test_conditional_ivae_decode(invariances):
     model = models.iVAE((8, 8), c_dim=3, invariances=invariances)
