@@ -401,6 +401,19 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   __syncthreads();
   W8_STAMP_K(1);
   const float bo = f.bo[0];
+  // The kernel arguments arrive as 16-dword scalar tuples; what the tile loop needs of them again lives in scalar values of
+  // its own (made opaque here), so that a register-pressure spill saves and restores two lanes, not the argument tuple's
+  // sixteen — 36 + 21 v_readlane per tile came from fetching llrow / loc / rowtp back that way.
+  typedef __attribute__((address_space(1))) float gfloat;         // (explicitly global: an opaque pointer would be stored through flat_*)
+  unsigned long long u_llrow, u_loc, u_rowtp, u_part_hz;
+  int64_t a_M;
+  // (real copies: an in-place "+s" keeps the value inside the tuple's registers, and the tuple is still spilled as a whole)
+  asm volatile("s_mov_b64 %0, %5\n\ts_mov_b64 %1, %6\n\ts_mov_b64 %2, %7\n\ts_mov_b64 %3, %8\n\ts_mov_b64 %4, %9"
+               : "=&s"(u_llrow), "=&s"(u_loc), "=&s"(u_rowtp), "=&s"(u_part_hz), "=&s"(a_M)
+               : "s"((unsigned long long)f.llrow), "s"((unsigned long long)f.loc), "s"((unsigned long long)f.rowtp),
+                 "s"((unsigned long long)f.part_hz), "s"(f.M));
+  gfloat* a_llrow = (gfloat*)u_llrow; gfloat* a_loc = (gfloat*)u_loc; gfloat* a_rowtp = (gfloat*)u_rowtp;
+  gfloat* a_part_hz = (gfloat*)u_part_hz;
 
   // persistent accumulators: the wave's slice (rows 16*wave .. +15) of dW1 (x C) and dW2, the bias sums, and the
   // wave-local column sums D[j][n]: n = 0 dL/d(hz) | 1, 5 dWc0 (hi, lo) | 2, 6 dWc1 | 3, 4 d(wo)   (n 0,1,2,5,6 carry C^2)
@@ -418,10 +431,10 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     // the wave's rows of sample b end: publish its partial dL/d(hz[b]) (column 0 of accS: lanes r == 0) in its own slot
     const int64_t ub = (int64_t)b * upb;
     const int gfirst = (int)(((ub + 1) * G + f.units - 1) / f.units) - 1;
-    float* dst = f.part_hz + ((int64_t)b * f.kmax + (g - gfirst) * W8_WAVES + wave) * FD_H + 4 * q;
+    gfloat* dst = a_part_hz + ((int64_t)b * f.kmax + (g - gfirst) * W8_WAVES + wave) * FD_H + 4 * q;
     if (r == 0) {
 #pragma unroll
-      for (int jb = 0; jb < 8; ++jb) *reinterpret_cast<f32x4*>(dst + 16 * jb) = accS[jb] * W8_RC2;
+      for (int jb = 0; jb < 8; ++jb) *(__attribute__((address_space(1))) f32x4*)(dst + 16 * jb) = accS[jb] * W8_RC2;
     }
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb)
@@ -596,8 +609,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
       dlda *= act ? swv : 0.0f;
       if (q == 0) {
         if (act) {
-          if (f.llrow) f.llrow[row] = ll;
-          if (f.loc) f.loc[row] = locv;
+          if (a_llrow) a_llrow[row] = ll;
+          if (a_loc) a_loc[row] = locv;
         }
         if (GRADS) { dbo += dlda; inf_dl[r] = dlda; }
       }
@@ -662,10 +675,10 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
       for (int mm = 0; mm < 4; ++mm) dd = MFMA32(ttab[64 * mm], w8_cat(p0[2 * mm], p0[2 * mm + 1]), dd);
       if (q == 0 && act) {
         const float d0 = (dd[0] + dd[1]) * W8_RC2, d1 = (dd[2] + dd[3]) * W8_RC2;
-        f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
-        f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
-        f.rowtp[2 * f.M + row] = d0;
-        f.rowtp[3 * f.M + row] = d1;
+        a_rowtp[row] = sc * (d1 * u0c - d0 * u1c);
+        a_rowtp[a_M + row] = d0 * u0c + d1 * u1c;
+        a_rowtp[2 * a_M + row] = d0;
+        a_rowtp[3 * a_M + row] = d1;
       }
       if (act && bu != cur_b) {
         if (cur_b >= 0) flush_hz(cur_b);
