@@ -212,7 +212,11 @@ __device__ __forceinline__ f32x4 w8_f32_of(const bf16x4& h) {
   f[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
   return f;
 }
-// d *= 1 - h^2 with h saved as bf16, four blocks at a time
+// d *= h^2 - 1 = -(1 - h^2) with h saved as bf16, four blocks at a time.  The SIGN is deliberate: `1 - t t` costs a v_xor per value
+// in front of the packed fma (its operand negation is not used by the compiler: 64 instructions per tile), `t t - 1` is the
+// packed fma alone.  Everything downstream is linear, so after layer 2's call the kernel carries -C dpre1 (the wgrad of layer 1
+// accumulates -dW1 / -db1: undone with the un-scaling where the record is written), and layer 1's call flips the sign back
+// (C^2 dpre0 as before).  Negation commutes with every rounding on the way: bit-identical results.
 __device__ __forceinline__ void w8_mul_dtanh(f32x4 (&d)[8], const bf16x4 (&hb)[8]) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -221,7 +225,7 @@ __device__ __forceinline__ void w8_mul_dtanh(f32x4 (&d)[8], const bf16x4 (&hb)[8
     for (int jb = 0; jb < 4; ++jb) t[jb] = w8_f32_of(hb[4 * half + jb]);
     W8_FENCE();
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) t[jb] = 1.0f - t[jb] * t[jb];
+    for (int jb = 0; jb < 4; ++jb) t[jb] = t[jb] * t[jb] - 1.0f;
     W8_FENCE();
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) d[4 * half + jb] = d[4 * half + jb] * t[jb];
@@ -250,6 +254,10 @@ __device__ __forceinline__ int w8_stage_toff(int r, int q) { return (4 * q + (r 
 // (2 A operands x 4 B operands per 32 staged rows: 12 transposing reads per 8 MFMAs; a 16 x 128 slice per wave needs
 // 18) and the bias sums of rows 32jp + 16kh .. +15 (an MFMA against ones):
 //   dW[j][k] += sum_rows dpre[row][j] h[row][k];   db[j] += sum_rows dpre[row][j]
+__device__ __forceinline__ bf16x4 w8_tr_at(unsigned lds_byte_addr) {
+  const short4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(size_t)lds_byte_addr);
+  return __builtin_bit_cast(bf16x4, v);
+}
 __device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16* sb, f32x4 (&accW)[2][4], f32x4& accB,
                                                  int wave, int r, int q, int ksteps) {
   const int toff = w8_stage_toff(r | w8_opaque0(), q);
@@ -257,29 +265,30 @@ __device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16*
   const short one = 0x3f80;                           // bf16 1.0
   const short8_ ones_s = {one, one, one, one, one, one, one, one};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+  // Three LDS byte addresses carry everything that is not a compile-time constant (the arrays' bases — beyond the 16-bit
+  // offset field of a ds_read — the lane's transposing-read offset, the wave's block); made opaque so that the twelve reads
+  // of a k-step are base + immediate instead of a v_add_u32 each (21 address instructions per k-step before).
+  // (the wave holds its two row blocks ROTATED by kh — a[s] / accW[s] are row block s ^ kh — so that its bias block is always
+  //  operand 0: no wave-uniform select between register operands, 8 v_cndmask per k-step)
+  unsigned la0 = (unsigned)(size_t)sa + 2u * (unsigned)(toff + 32 * jp + 16 * kh);
+  unsigned la1 = (unsigned)(size_t)sa + 2u * (unsigned)(toff + 32 * jp + 16 * (1 ^ kh));
+  unsigned lb = (unsigned)(size_t)sb + 2u * (unsigned)(toff + 64 * kh);
+  asm volatile("" : "+v"(la0), "+v"(la1), "+v"(lb));
+  constexpr unsigned ROW16 = 2u * 16 * LDS2;         // bytes of 16 staged rows
 #if W8_ABL & 4
   bf16x8 a[2], b[4];
 #endif
   for (int ks = 0; ks < ksteps; ++ks) {
-    const int koff = toff + 32 * ks * LDS2;
 #if W8_ABL & 4
     if ((ks & 1) == 0) {
 #else
     bf16x8 a[2], b[4];
     {
 #endif
+    a[0] = w8_cat(w8_tr_at(la0), w8_tr_at(la0 + ROW16));
+    a[1] = w8_cat(w8_tr_at(la1), w8_tr_at(la1 + ROW16));
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
-      // (the wave holds its two row blocks ROTATED by kh — a[s] / accW[s] are row block s ^ kh — so that its bias block is
-      //  always operand 0: no wave-uniform select between register operands, 8 v_cndmask per k-step)
-      const int off = koff + 32 * jp + 16 * (s_ ^ kh);
-      a[s_] = w8_cat(w8_tr(sa + off), w8_tr(sa + off + 16 * LDS2));
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int off = koff + 64 * kh + 16 * o;
-      b[o] = w8_cat(w8_tr(sb + off), w8_tr(sb + off + 16 * LDS2));
-    }
+    for (int o = 0; o < 4; ++o) b[o] = w8_cat(w8_tr_at(lb + 32u * o), w8_tr_at(lb + 32u * o + ROW16));
     }
     W8_FENCE();
     accB = MFMA32(a[0], ones, accB);
@@ -288,6 +297,7 @@ __device__ __forceinline__ void w8_wgrad_consume(const __bf16* sa, const __bf16*
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) accW[s_][o] = MFMA32(a[s_], b[o], accW[s_][o]);
     W8_FENCE();
+    la0 += 2 * ROW16; la1 += 2 * ROW16; lb += 2 * ROW16;
   }
 }
 
@@ -653,12 +663,12 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     bf16x4 p0[8];
     {
       w8_layer_dgrad(W2h, pA, tC, wad);                            // tC = C dL/dh1
-      w8_mul_dtanh(tC, h1b);                                      // C dpre1
+      w8_mul_dtanh(tC, h1b);                                      // -C dpre1 (see w8_mul_dtanh)
       w8_cvt8(tC, pA);                                            // feeds the dgrad and the wgrad of layer 1
       asm volatile("; W8_P7_dgrad2");
     W8_STAMP(7);
-      w8_layer_dgrad(W1h, pA, tC, wad);                            // tC = C^2 dL/dh0
-      w8_mul_dtanh(tC, h0b);                                      // C^2 dpre0
+      w8_layer_dgrad(W1h, pA, tC, wad);                            // tC = -C^2 dL/dh0
+      w8_mul_dtanh(tC, h0b);                                      // C^2 dpre0 (the sign is back)
       w8_cvt8(tC, p0);
     }
     asm volatile("; W8_P8_dgrad1");
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
 #if W8_ABL & 8
           if (accW1[s_][o][i] == 1.2345e30f) rec[e] = accW2[s_][o][i];      // (timing ablation: no record stores)
 #else
-          rec[e] = accW1[s_][o][i] * W8_RC;
+          rec[e] = accW1[s_][o][i] * -W8_RC;                        // (accW1 / accB1 hold -C dW1 / -C db1)
           rec[FD_H * FD_H + e] = accW2[s_][o][i];
 #endif
         }
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
       const int j0 = 32 * jp + 16 * kh;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        rec[2 * FD_H * FD_H + j0 + 4 * q + i] = accB1[i] * W8_RC;
+        rec[2 * FD_H * FD_H + j0 + 4 * q + i] = accB1[i] * -W8_RC;
         rec[2 * FD_H * FD_H + FD_H + j0 + 4 * q + i] = accB2[i];
       }
     }
