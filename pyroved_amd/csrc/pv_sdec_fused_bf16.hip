@@ -307,30 +307,35 @@ __device__ __forceinline__ int fb_stage_toff(int r, int q) { return (4 * q + (r 
 template <bool X3>
 __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)[2][8], f32x4 (&accB)[2], int wave,
                                                  int r, int q, int ksteps) {
-  const __bf16* sah = st;
-  const __bf16* sal = st + ST_ARR;
-  const __bf16* sbh = st + FbLds<X3>::NARR * ST_ARR;
-  const __bf16* sbl = sbh + ST_ARR;
   const int toff = fb_stage_toff(r | fb_opaque0(), q);
   const short one = 0x3f80;                           // bf16 1.0
   const short8_ ones_s = {one, one, one, one, one, one, one, one};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+  // two LDS byte addresses (the dpre arrays' and the activation arrays') carry everything that is not a compile-time
+  // constant; opaque, so that every read of a k-step is base + immediate — one staging area lies beyond the 16-bit offset
+  // field of a ds_read and cost a v_add_u32 per read (pv_sdec_fused_w8.hip: w8_wgrad_consume)
+  unsigned la = (unsigned)(size_t)st + 2u * (unsigned)(toff + 32 * wave);
+  unsigned lb = (unsigned)(size_t)st + 2u * (unsigned)(FbLds<X3>::NARR * ST_ARR + toff);
+  asm volatile("" : "+v"(la), "+v"(lb));
+  constexpr unsigned ROW16 = 2u * 16 * LDS2, ARR = 2u * ST_ARR;
+  auto tr_at = [](unsigned addr) {
+    const short4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(size_t)addr);
+    return __builtin_bit_cast(bf16x4, v);
+  };
   for (int ks = 0; ks < ksteps; ++ks) {
-    const int koff = toff + 32 * ks * LDS2;
     bf16x8 a_h[2], a_l[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int off = koff + 16 * (2 * wave + s);
-      a_h[s] = fb_cat(fb_tr(sah + off), fb_tr(sah + off + 16 * LDS2));
-      if (X3) a_l[s] = fb_cat(fb_tr(sal + off), fb_tr(sal + off + 16 * LDS2));
+      a_h[s] = fb_cat(tr_at(la + 32u * s), tr_at(la + 32u * s + ROW16));
+      if (X3) a_l[s] = fb_cat(tr_at(la + ARR + 32u * s), tr_at(la + ARR + 32u * s + ROW16));
     }
     bf16x8 bh[2][2], bl[2][2];
     auto load = [&](int kp, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
 #pragma unroll
       for (int o = 0; o < 2; ++o) {
-        const int off = koff + 16 * (kp + o);
-        h[o] = fb_cat(fb_tr(sbh + off), fb_tr(sbh + off + 16 * LDS2));
-        if (X3) l[o] = fb_cat(fb_tr(sbl + off), fb_tr(sbl + off + 16 * LDS2));
+        const unsigned off = 32u * (unsigned)(kp + o);
+        h[o] = fb_cat(tr_at(lb + off), tr_at(lb + off + ROW16));
+        if (X3) l[o] = fb_cat(tr_at(lb + ARR + off), tr_at(lb + ARR + off + ROW16));
       }
     };
     load(0, bh[0], bl[0]);
@@ -362,6 +367,7 @@ __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)
       }
       FB_FENCE();
     }
+    la += 2 * ROW16; lb += 2 * ROW16;
   }
 }
 
