@@ -786,6 +786,9 @@ template <int NCIB> struct SwGeo {
 // of two (maximum to [2^13, 2^14)); the accumulators live in units of 2^(E_dy + E_patch) (the bias sums in 2^E_dy) and are
 // rescaled when a tile changes them; neither exponent may exceed the smallest so far by more than 30 (overflow guard —
 // a tile that would need more is 2^30 below what is already summed).
+#ifndef SW_BUF
+#define SW_BUF 1
+#endif
 template <int NS, int NCIB, bool F16 = false>
 __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x, const int bid_y, const int bid_z, char* smem) {
   static_assert(!F16 || (NS == 2 && NCIB == 1), "the fp16 mode: two pieces, 32-channel workgroups (next-tile prefetch)");
@@ -848,7 +851,35 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
     ftx = t % p.tiles_x; t /= p.tiles_x;
     fty = t % p.tiles_y; fb = t / p.tiles_y;
   }
-  auto fetch = [&]() {
+  // Buffer-load form of the fetch (SW_BUF): one descriptor per tensor, a 32-bit byte offset per piece, pieces outside the image
+  // pointed past the descriptor's range (they read 0) — no exec-mask branch, zero fill and 64-bit address chain per piece (the
+  // loop issued ~330 VALU and ~210 SALU next to its 116 MFMA).  Tensors under 2 GiB and whole 64-channel dY blocks only.
+  const bool use_buf = SW_BUF && (p.Cout & 63) == 0 && (int64_t)p.B * p.H * p.W * p.Cout < (1ll << 29) &&
+                       (int64_t)p.B * p.H * p.W * p.Cin < (1ll << 29);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0,
+                                         use_buf ? (int)((int64_t)p.B * p.H * p.W * p.Cout * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0,
+                                         use_buf ? (int)((int64_t)p.B * p.H * p.W * p.Cin * 4) : 0, 0x00020000);
+  auto fetch_buf = [&]() {
+    const int y0 = fty * 8, x0 = ftx * 8;
+    const unsigned img = (unsigned)fb * (unsigned)(p.H * p.W);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned y = (unsigned)(y0 + dn_y[k]), x = (unsigned)(x0 + dn_x[k]);
+      const unsigned off = ((img + y * (unsigned)p.W + x) * (unsigned)p.Cout + (unsigned)dco) * 4u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(drs, (y < (unsigned)p.H && x < (unsigned)p.W) ? off : 0x80000000u, 0, 0);
+      vd[k] = __builtin_bit_cast(f32x4, v);
+    }
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+      const unsigned y = (unsigned)(y0 - 1 + pp_r[k]), x = (unsigned)(x0 - 1 + pp_c[k]);     // (negative: wraps past H / W)
+      const unsigned off = ((img + y * (unsigned)p.W + x) * (unsigned)p.Cin + (unsigned)pcf) * 4u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(irs, (y < (unsigned)p.H && x < (unsigned)p.W) ? off : 0x80000000u, 0, 0);
+      vp[k] = __builtin_bit_cast(f32x4, v);
+    }
+    if (++ftx == p.tiles_x) { ftx = 0; if (++fty == p.tiles_y) { fty = 0; ++fb; } }
+  };
+  auto fetch_ptr = [&]() {
     const int y0 = fty * 8, x0 = ftx * 8;
     const float* dy_b = p.dy + (int64_t)fb * p.H * p.W * p.Cout + dco;
     const float* in_b = p.in + (int64_t)fb * p.H * p.W * p.Cin + pcf;
@@ -873,6 +904,7 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
     }
     if (++ftx == p.tiles_x) { ftx = 0; if (++fty == p.tiles_y) { fty = 0; ++fb; } }
   };
+  auto fetch = [&]() { if (use_buf) fetch_buf(); else fetch_ptr(); };
   if (PRE && t_lo < t_hi) fetch();
   int Ed = 0, Ep = 0, Ed_min = 1 << 20, Et_min = 1 << 20;           // F16: current exponents, smallest so far (dY, dY + patch)
   auto wave_max = [&](int slot) {                    // this wave's max |dY piece| and |patch piece| of the fetched tile
