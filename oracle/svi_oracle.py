@@ -706,7 +706,8 @@ class SSOracle:
             shape = (b, cfg.z_dim)
         return torch.empty(shape).normal_(), eps_y
 
-    def compute_loss(self, x, ys=None, eps=None, eps_y=None, beta=1.0, mult=20.0):
+    def compute_loss(self, x, ys=None, eps=None, eps_y=None, beta=1.0, mult=20.0, after_elbo=None):
+        """after_elbo (tests): called with the parameter dict between the ELBO step's Adam update and the auxiliary step."""
         x = x.to(self.dtype)
         if eps is None:
             eps, eps_y = self.draw(x.shape[0], ys is None)
@@ -714,6 +715,8 @@ class SSOracle:
                       None if eps_y is None else eps_y.to(self.dtype), beta, self.reg_sig, self.grid)
         self.last = out
         l1 = self._svi_step(out["loss"], "elbo")
+        if after_elbo is not None:
+            after_elbo(self.p)
         aux = ss_aux_loss(self.p, self.cfg, self.task, x, ys.to(self.dtype), mult, self.reg_sig) if ys is not None else 0.0
         l2 = self._svi_step(aux, "aux")
         return l1, l2

@@ -34,33 +34,91 @@ __device__ __forceinline__ int fb_swz(int R) { return 4 * (R & 3) + fb_sl((R >> 
 // element index of (row R, permuted column pc) in an image
 __device__ __forceinline__ int fb_wel(int R, int pc) { return R * LDB + 8 * ((pc >> 3) ^ fb_swz(R)) + (pc & 7); }
 
-// once per step: the hidden layers' weights as bf16 hi / lo images (W1h W1l W2h W2l) and the zero fill of the
-// dL/d(hz) partial-sum slots.  Thread t of T cooperating threads (any launch shape).
+// once per step: the hidden layers' weights as two-piece images (W1h W1l W2h W2l) and the zero fill of the
+// dL/d(hz) partial-sum slots.  Thread t of T cooperating threads (any launch shape made of WHOLE waves).
+//   mode 0: bf16 hi / lo pieces of scale * W (rounded split, ~2^-17 relative);
+//   mode 1: fp16 hi / lo pieces of s * W with s the power of two that brings max |W| into [1, 2) — fp16's narrow exponent
+//           then costs nothing: hi + lo = s W to 2^-22 of an element, to 2^-25 of the largest for elements whose lo piece is
+//           subnormal — and the three scales {s1, s2, s_o (of the output layer's weights)} written after the images
+//           (FB_SCALE_OFF): pv_sdec_fused_bf16.hip's fp16 modes.
+#define FB_SCALE_OFF (4 * IMG_BYTES)   // byte offset of the fp32 scales {s1, s2, s_o, 0} behind the four images
 struct PvFbPrep {
   const float* W1; const float* W2;   // (128, 128) fp32, nn.Linear layout
-  void* img;                          // 4 * IMG_BYTES
+  void* img;                          // 4 * IMG_BYTES (+ 16 bytes of scales in mode 1)
   float* zero; int64_t nzero4;        // float4s to clear (0: none)
-  float scale;                        // images hold scale * W (0: unscaled) — pv_sdec_fused_w8.hip's 2 log2(e)
+  float scale;                        // mode 0: images hold scale * W (0: unscaled) — pv_sdec_fused_w8.hip's 2 log2(e)
+  int mode;                           // 0: bf16 pieces, 1: normalised fp16 pieces
+  const float* wo;                    // mode 1: decoder.out weights (128), for s_o
 };
+// max |v| over n4 float4s, by one wave (every lane returns it); loads in independent batches of 16 per lane — a loop of
+// single dependent loads paid an L2 round trip per iteration: +23 us on the launch that hosts the preparation
+__device__ __forceinline__ float pv_fb_wave_absmax(const float* __restrict__ v, int n4, int lane) {
+  float m = 0.0f;
+  const f32x4* p = reinterpret_cast<const f32x4*>(v);
+  for (int b0 = 0; b0 < n4; b0 += 64 * 16) {
+    f32x4 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = b0 + 64 * k + lane;
+      x[k] = i < n4 ? p[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(x[k][0]), fabsf(x[k][1])), fmaxf(fabsf(x[k][2]), fabsf(x[k][3]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+// the power of two s with s * m in [1, 2) (1 for m = 0 or a non-finite m; exponent clamped to +-60)
+__device__ __forceinline__ float pv_fb_norm_scale(float m) {
+  if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f;
+  int e = __builtin_amdgcn_frexp_expf(m);               // m = f * 2^e, f in [0.5, 1)
+  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  return __uint_as_float((unsigned)(127 + 1 - e) << 23);
+}
+__device__ __forceinline__ void fb_split_f16(float x, unsigned short& hi, unsigned short& lo) {
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
 __device__ __forceinline__ void pv_fb_prep(const PvFbPrep& p, int64_t t, int64_t T) {
   __bf16* img = reinterpret_cast<__bf16*>(p.img);
+  float s1 = p.scale != 0.0f ? p.scale : 1.0f, s2 = s1;
+  if (p.mode == 1) {
+    // every wave finds the three maxima for itself (192 KB of L2-resident reads per wave: no cross-wave step, any launch shape)
+    const int lane = (int)(t & 63);
+    s1 = pv_fb_norm_scale(pv_fb_wave_absmax(p.W1, 128 * 32, lane));
+    s2 = pv_fb_norm_scale(pv_fb_wave_absmax(p.W2, 128 * 32, lane));
+    if ((t >> 6) == 0) {                                 // (wave-uniform: the first wave, all of its lanes)
+      const float so = pv_fb_norm_scale(pv_fb_wave_absmax(p.wo, 32, lane));
+      if (lane == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.img) + FB_SCALE_OFF) = f32x4{s1, s2, so, 0.0f};
+    }
+  }
   for (int64_t idx = t; idx < 128 * 32; idx += T) {
     const int row = (int)(idx >> 5), c4 = (int)(idx & 31);
-    const float sc = p.scale != 0.0f ? p.scale : 1.0f;
-    const f32x4 w1 = reinterpret_cast<const f32x4*>(p.W1)[idx] * sc;
-    const f32x4 w2 = reinterpret_cast<const f32x4*>(p.W2)[idx] * sc;
-    bf16x4 h1, l1, h2, l2;
+    const f32x4 w1 = reinterpret_cast<const f32x4*>(p.W1)[idx] * s1;
+    const f32x4 w2 = reinterpret_cast<const f32x4*>(p.W2)[idx] * s2;
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    us4 h1, l1, h2, l2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __bf16 a, b;
-      fb_split(w1[i], a, b); h1[i] = a; l1[i] = b;
-      fb_split(w2[i], a, b); h2[i] = a; l2[i] = b;
+      unsigned short a, b;
+      if (p.mode == 1) {
+        fb_split_f16(w1[i], a, b); h1[i] = a; l1[i] = b;
+        fb_split_f16(w2[i], a, b); h2[i] = a; l2[i] = b;
+      } else {
+        __bf16 x, y;
+        fb_split(w1[i], x, y); h1[i] = __builtin_bit_cast(unsigned short, x); l1[i] = __builtin_bit_cast(unsigned short, y);
+        fb_split(w2[i], x, y); h2[i] = __builtin_bit_cast(unsigned short, x); l2[i] = __builtin_bit_cast(unsigned short, y);
+      }
     }
     const int e = fb_wel(row, fb_pcol(4 * c4));
-    *reinterpret_cast<bf16x4*>(img + e) = h1;
-    *reinterpret_cast<bf16x4*>(img + W_IMG + e) = l1;
-    *reinterpret_cast<bf16x4*>(img + 2 * W_IMG + e) = h2;
-    *reinterpret_cast<bf16x4*>(img + 3 * W_IMG + e) = l2;
+    *reinterpret_cast<us4*>(img + e) = h1;
+    *reinterpret_cast<us4*>(img + W_IMG + e) = l1;
+    *reinterpret_cast<us4*>(img + 2 * W_IMG + e) = h2;
+    *reinterpret_cast<us4*>(img + 3 * W_IMG + e) = l2;
   }
   for (int64_t idx = t; idx < p.nzero4; idx += T) reinterpret_cast<f32x4*>(p.zero)[idx] = f32x4{0, 0, 0, 0};
 }

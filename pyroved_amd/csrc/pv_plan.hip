@@ -704,6 +704,14 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)S; f.lik = p->lik;
   f.sw = K > 0 ? L.sw : p->row_w; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
   f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
+  // fp16 builds of the fp32-class kernel: where the per-row exponent of dL/dlogit is centred (|dL/dlogit| <= 1 for the Bernoulli
+  // likelihoods; ~ residual / sig^2 for the Gaussian): exact powers of two either way, only the representable RANGE moves
+  f.dl_exp = 4;
+  if (p->lik == PV_LIK_GAUSSIAN && p->decoder_sig > 0.0f) {
+    int e2 = 0;
+    (void)frexpf(p->decoder_sig * p->decoder_sig, &e2);      // sig^2 = m 2^e2, m in [0.5, 1)
+    f.dl_exp = e2 < -40 ? -40 : (e2 > 40 ? 40 : e2);
+  }
   // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
   if (p->fused >= 2 && L.enc_compact) {
     const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0, p->fused == 2);

@@ -9,7 +9,7 @@
 // [dW1 HxH | dW2 HxH | db1 H | db2 H | dWc0 H | dWc1 H | dwo H | dbo (1, padded to H) | 8 spare slots x H]
 // (the spare slots are summed into dwo by the reduction when it is called with dwo_slots = 1; both kernels now
 //  sum their d(wo) in LDS and leave the slots unused)
-#define FB_WIMG_BYTES (4 * FD_H * FD_H * 2)    // bf16x3 kernel: global copy of its four LDS weight images
+#define FB_WIMG_BYTES (4 * FD_H * FD_H * 2 + 256)   // split-precision kernels: global copy of the four LDS weight images (+ the fp16 modes' scales)
 
 struct PvFused {
   const float* x;        // (M) observations, M = B*N rows (b, n)
@@ -36,6 +36,8 @@ struct PvFused {
   int ablate;            // profiling only (env PV_FD_ABLATE): 1 skip wgrad exchanges, 2 skip coord-layer exchange,
                          // 4 skip dgrad, 8 skip d(wo) reduction  -> wrong gradients, used to price the phases
   float sig;
+  int dl_exp;            // fp16 modes (pv_sdec_fused_bf16.hip): exponent bias of the per-row dL/dlogit factor folded into the
+                         // staged activations: 2^dl_exp * |dL/dlogit| should sit around 1 .. 2^8 (Bernoulli 4; Gaussian: -log2(1 / sig^2))
 };
 
 // true when the plan's architecture is the one the fused kernel is specialised for
