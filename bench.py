@@ -385,7 +385,19 @@ def _paths(cfg, mode, B, n_pix):
     dec_fl = DEC_FLOP_PER_PIXEL * n_pix * passes * B
     units = B * n_pix * passes // 16
     if mode == 2:
-        return (_kernel_name(2, units), dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16x3",
+        kn = _kernel_name(2, units)
+        # round 4: training launches of the fp32-class path run an fp16 build from 16 384 rows up (last template argument of
+        # pv_sdec_fused_bf16_kernel: 8 = H231, 2 = H221, 1 = the bf16 three-product kernel; pv_sdec_fused_bf16.hip)
+        prec = kn.split(",")[-1].split(">")[0].strip() if "pv_sdec_fused_bf16_kernel" in kn else "1"
+        if prec == "8":
+            return (kn, dec_fl, MFMA_BF16_PEAK_TFLOPS, "f16w2",
+                    "f16 MFMA: weights as two exact power-of-two-scaled fp16 pieces, activations one piece (forward 2 products, "
+                    "dgrad 3 with dL/dpre split, wgrad 1; fp32 accumulate; fp32 elsewhere): every gradient within 1e-4 of the oracle")
+        if prec == "2":
+            return (kn, dec_fl, MFMA_BF16_PEAK_TFLOPS, "f16w2",
+                    "f16 MFMA: weights as two exact power-of-two-scaled fp16 pieces, activations and dL/dpre one piece (forward 2 "
+                    "products, dgrad 2, wgrad 1; fp32 accumulate; fp32 elsewhere); selected from 2 M decoder rows up")
+        return (kn, dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16x3",
                 "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)")
     if mode == 3:
         return (_kernel_name(3, units), dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16",
@@ -464,7 +476,7 @@ def measure(args, name, cfg, fused, ctx):
     k_avg = sum(kms) / max(len(kms), 1)
     achieved = fl / (k_avg * 1e-3) / 1e12 if k_avg > 0 else 0.0
     tb, ts = _traffic("%s:%d" % (name, mode), B, cfg)
-    out.update(dtype=dtype, arith=arith, path={0: "layered", 1: "fused-f32", 2: "fused-bf16x3", 3: "fused-bf16"}[mode],
+    out.update(dtype=dtype, arith=arith, path={0: "layered", 1: "fused-f32", 2: "fused-" + dtype, 3: "fused-bf16"}[mode],
                roofline={"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": tb, "traffic_source": ts,
                          "kernel": kname, "kernel_ms": k_avg, "kernel_ms_samples": len(kms), "flops_per_launch": fl})
@@ -677,7 +689,36 @@ def main():
             main_leg = alt = None
             torch.cuda.empty_cache()
             out["configs"] = [sub_config(c, args) for c in ("C1", "C3", "C4", "C4fc", "C5")]
-        print(json.dumps(out))
+        # the side legs' headline scalars at the FRONT of the line (the driver's record keeps the known keys and the last 2 000
+        # characters) and once more as a short line on stderr, which ends the captured output
+        summ = {}
+        if "fp32_class" in out:
+            summ.update(fp32_class_ms=round(out["fp32_class"]["ms_per_step"], 5), fp32_class_images_s=round(out["fp32_class"]["value"]),
+                        fp32_class_kernel_ms=out["fp32_class"].get("kernel_ms"), fp32_class_frac=out["fp32_class"].get("roofline_frac"))
+        tr, inf = out.get("trainer") or {}, out.get("inference") or {}
+        if isinstance(tr.get("bf16"), dict):
+            summ["trainer_images_s"] = round(tr["bf16"]["value"])
+        if isinstance(tr.get("fp32"), dict):
+            summ["trainer_fp32_class_images_s"] = round(tr["fp32"]["value"])
+        for k_src, k_dst in (("decode_device", "decode_images_s"), ("encode_device", "encode_images_s"),
+                             ("decode_api", "decode_api_images_s"), ("encode_api", "encode_api_images_s")):
+            if isinstance(inf.get(k_src), (int, float)):
+                summ[k_dst] = round(inf[k_src])
+        for c in out.get("configs") or []:
+            if isinstance(c, dict) and "ms_per_step" in c and "config" in c:
+                summ["%s_ms" % str(c["config"]).lower()] = round(c["ms_per_step"], 4)
+                if isinstance(c.get("fp32_class"), dict) and "ms_per_step" in c["fp32_class"]:
+                    summ["%s_fp32_class_ms" % str(c["config"]).lower()] = round(c["fp32_class"]["ms_per_step"], 4)
+        front = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data")
+        ordered = {k: out[k] for k in front}
+        ordered["summary"] = summ
+        ordered.update({k: v for k, v in out.items() if k not in front})
+        print(json.dumps(ordered))
+        sys.stdout.flush()
+        print("BENCH-SUMMARY " + json.dumps({"value": round(out["value"]), "ms_per_step": round(out["ms_per_step"], 5),
+                                             "kernel_ms": out["roofline"].get("kernel_ms"), "frac": out["roofline"].get("frac"),
+                                             **summ}), file=sys.stderr)
     if world > 1:
         td.destroy_process_group()
 

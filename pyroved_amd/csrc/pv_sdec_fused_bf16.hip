@@ -986,17 +986,22 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
 // forward-only launches of enough units (decode, evaluate) the 8-wave build of pv_sdec_fused_w8x3.hip (round 3: 6.3 vs 5.0 M
 // decoded images/s).  That source's training builds — 8 waves: 245 us, 4 waves: 188 us at batch 256, against 190 us here —
 // stay selectable for A/B runs and are parity-tested (tests/test_gpu_parity.py: force_w8x3).
-// Round 4: training launches of the fp32-class path run this file's fp16 build with two-piece weights and one-piece
-// activations (FB_P_H221, kind 21) once the problem has FB_H221_MIN_UNITS units — the independent rounding errors of the
-// one-piece operands average out over the rows a gradient sums (error table: profiles/r04_fb_prec_table.txt); smaller problems
-// keep the bf16 three-product kernel (kind 0).
+// Round 4: training launches of the fp32-class path run this file's fp16 builds — weights as two exact scaled pieces,
+// activations one piece — once the rows a gradient sums are enough for the one-piece operands' independent rounding errors to
+// average out (error table: profiles/r04a_fb_prec_table.txt, bars: every gradient tensor 1e-4 vs the oracle):
+//   >= FB_H231_MIN_UNITS units (16 384 rows):   H231 (kind 28: dL/dpre split in both dgrads; worst tensor 1.6e-5 at C2)
+//   >= FB_H221_MIN_UNITS units (2 M rows):      H221 (kind 21: one piece everywhere; 6e-5 at C2's 2e5 rows, ~1 / sqrt(rows))
+// smaller problems keep the bf16 three-product kernel (kind 0).
 // Environment (A/B runs): PV_W8=0 / 1 forces the plain kernel; PV_X3_KERNEL=old | 4 | 8 | h221 | h223 | h321 | h333 the split-precision one.
 static int fb_w8_mode[2] = {-1, -1};   // [plain, x3]  -1: not read yet; 2: by problem size; plain: 0 / 1 forced; x3: 0 old, 4, 8, 21, 23, 31, 33
 // test / A-B hooks
 extern "C" void pv_debug_force_w8(int mode) { fb_w8_mode[0] = mode; }
 extern "C" void pv_debug_force_w8x3(int mode) { fb_w8_mode[1] = mode == 1 ? 8 : mode; }   // 1: the 8-wave form (round-3 tests), 4, 0 old, 2 default, 21 / 23 / 31 / 33 the fp16 builds
+#ifndef FB_H231_MIN_UNITS
+#define FB_H231_MIN_UNITS 1024         // 16 384 rows
+#endif
 #ifndef FB_H221_MIN_UNITS
-#define FB_H221_MIN_UNITS 1024         // 16 384 rows
+#define FB_H221_MIN_UNITS 131072       // 2 097 152 rows
 #endif
 #ifndef FB_EXPERIMENTS
 #define FB_EXPERIMENTS 1               // the error table's other corners (H223 / H321 / H333; Bernoulli training launches only)
@@ -1020,7 +1025,8 @@ static int fb_x3_kind(int64_t units, bool grads) {
   if (v > 8) return grads ? v : (units * FD_UNIT < fb_row_cap && units >= 6 * (int64_t)pv_sdec_fused_grid(units) ? 8 : 0);
   if (units * FD_UNIT >= fb_row_cap) return 0;
   if (v != 2) return v;
-  if (grads && units >= FB_H221_MIN_UNITS) return 28;
+  if (grads && units >= FB_H221_MIN_UNITS) return 21;
+  if (grads && units >= FB_H231_MIN_UNITS) return 28;
   // training: this file's kernel.  The new source's 4-wave build measures the same (187.9 vs 189.7 us at batch 256 with every
   // offload and the epilogues folded into the consuming k-loops: profiles/r03_decoder_schedule_experiments.txt) — not worth a
   // switch of the two-rounds-tested default; its 8-wave build is slower (245 us).  Forward-only: the 8-wave build by size.
