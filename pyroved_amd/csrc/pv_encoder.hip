@@ -169,6 +169,13 @@ extern "C" int pv_debug_read_enc_trace(long long* out, int n) {
 #define EN_STAMP(k) do { } while (0)
 #endif
 
+__device__ unsigned en_late_total;          // consumers of the merged launch that computed their own first-layer tiles
+extern "C" long long pv_debug_enc_late_count() {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(en_late_total), sizeof v) != hipSuccess) return -1;
+  return (long long)v;
+}
+
 // rbk: the workgroup's row block.  MERGED: the first layer runs in the SAME launch (pv_enc_kernel): everything that does not
 // depend on it is requested first, then the workgroup waits for its row block's tiles (flags == e.gen), then reads them.
 template <bool MERGED>
@@ -177,7 +184,6 @@ __device__ __forceinline__ void enc_fwd_body(const PvEncFwd& e, int rbk, float (
   const int row0 = rbk * EN_ROWS;
   const bool rok = row0 + r < e.B;
   int cur = 0;
-  bool timed_out = false;
   EN_STAMP(0);
   // ---- the first layer's output (pv_enc_l1_kernel): requested before anything else — loads return in order, and the
   // first barrier waits only for this one (merged launch: after the wait below) ----
@@ -215,19 +221,39 @@ __device__ __forceinline__ void enc_fwd_body(const PvEncFwd& e, int rbk, float (
   if (tid < EN_ROWS * e.z_dim && row0 + tid / e.z_dim < e.B)
     eps_pf = e.eps[(int64_t)(row0 + tid / e.z_dim) * e.z_dim + tid % e.z_dim];
   if (MERGED) {
-    // wait for the first layer's tiles of this row block: lane j of wave 0 polls flag j.  Bounded (seconds): a launch that
-    // loses its producers must not hang the device — it poisons the row block's KL partial sums instead (the loss turns NaN)
+    // wait for the first layer's tiles of this row block: lane j of wave 0 polls flag j, a bounded number of times
+    // (e.spin_limit polls of ~0.5 us).  HIP promises nothing about dispatch order: a consumer whose producers have not
+    // published by then (not dispatched yet behind a full chip, a competing stream, a second rank on the GPU) computes its
+    // row block's tiles ITSELF — the same arithmetic in the same order, so the same bits, whoever gets there first — and the
+    // launch completes under any placement and any order (round 4; rounds 1-3 spun for seconds and then returned a NaN loss).
+    // en_late_total counts the fallbacks (observability, tests: pv_debug_enc_late_count).
     const int cb = (w0_ + 15) >> 4;
     int late = 0;
     if (tid < cb) {
       const unsigned* f = e.flags + (int64_t)rbk * cb + tid;
       late = 1;
-      for (int spin = 0; spin < (1 << 22); ++spin) {
+      for (int spin = 0; spin < e.spin_limit; ++spin) {
         if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e.gen) { late = 0; break; }
         __builtin_amdgcn_s_sleep(2);
       }
     }
-    timed_out = __syncthreads_or(late) != 0;
+    if (__syncthreads_or(late) != 0) {                                // (workgroup-uniform)
+      // (the producers' own K split — L1_WAVES waves — for the same summation order; the other waves pair the barrier inside)
+      float (*part4)[EN_ROWS][17] = reinterpret_cast<float (*)[EN_ROWS][17]>(&act[0][0][0]);
+      for (int bx = 0; bx < cb; ++bx) {
+        if (tid < 64 * L1_WAVES) enc_l1_body<true, L1_WAVES>(e, bx, rbk, cb, (e.B + EN_ROWS - 1) / EN_ROWS, part4);
+        else pv_lds_barrier();
+        pv_lds_barrier();                                              // `part4` is free again
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every thread's write-through stores acknowledged
+      pv_lds_barrier();
+      if (tid == 0) atomicAdd(&en_late_total, 1u);
+    }
+    // Hand-off protocol (cdna_hip_programming.md guideline 16, form R1): the producers' tile stores are agent-scope
+    // (write-through, sc1) stores, every storing thread drains them (s_waitcnt vmcnt(0)) before the workgroup barrier that
+    // precedes ONE lane's relaxed agent-scope flag store; here ONE relaxed poll per flag, a barrier, then agent-scope (sc1)
+    // loads, which bypass this CU's L1 and this XCD's possibly stale L2 lines — the guide's "sc1 loads may replace the
+    // acquire only when the producer stored sc1".
     if (l0ok) {                                                       // device-scope loads: past this XCD's (possibly stale) L2 lines
       const int rr = tid / (w0_ / 4), c4 = tid % (w0_ / 4);
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(e.eact[0] + (int64_t)min(row0 + rr, e.B - 1) * w0_ + 4 * c4);
@@ -336,9 +362,8 @@ __device__ __forceinline__ void enc_fwd_body(const PvEncFwd& e, int rbk, float (
     lqd = en_block_sum(lqd, sm);
   }
   if (tid == 0) {
-    const float poison = timed_out ? __int_as_float(0x7fc00000) : 0.0f;
-    e.kl_part[2 * rbk] = e.beta * lp + e.beta_disc * lpd + poison;
-    e.kl_part[2 * rbk + 1] = e.beta * lq + e.beta_disc * lqd + poison;
+    e.kl_part[2 * rbk] = e.beta * lp + e.beta_disc * lpd;
+    e.kl_part[2 * rbk + 1] = e.beta * lq + e.beta_disc * lqd;
   }
   pv_lds_barrier();
   EN_STAMP(5);
@@ -455,6 +480,10 @@ static unsigned enc_next_gen() {
 
 static int g_enc_two = -1;                            // test hook: 1 two launches, 0 one launch, -1 the environment's choice
 extern "C" void pv_debug_enc_two(int two) { g_enc_two = two < 0 ? -1 : (two ? 1 : 0); }
+// polls before a consumer computes its tiles itself.  256 x ~0.5 us is 10-20x what the producers need on an idle GPU; the
+// fallback is exact, so a short limit only costs redundant work.  Test hook: 0 forces every consumer onto the fallback.
+static int g_enc_spin = 256;
+extern "C" void pv_debug_enc_spin_limit(int polls) { g_enc_spin = polls < 0 ? 256 : polls; }
 
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
   const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
@@ -470,6 +499,7 @@ int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
   if (e.flags && !two && !pv_stream_capturing(s)) {    // (a captured launch would replay its generation value: two launches then)
     PvEncFwd m = e;
     m.gen = enc_next_gen();
+    m.spin_limit = g_enc_spin;
     hipLaunchKernelGGL(pv_enc_kernel, dim3((unsigned)(cb * (rb + extra) + rb)), dim3(EN_THREADS), 0, s, m, cb, rb + extra);
     PV_LAUNCH_CHECK();
     return 0;

@@ -209,6 +209,7 @@ struct PvEncFwd {
   const float* w;                   // (B) per-sample weights of the KL partial sums (plan->row_w) or null
   PvFbPrep prep;                    // hosted in the first-layer launch when prep.img is set (bf16x3 decoder path)
   unsigned* flags; unsigned gen;    // != null: one launch for both kernels; (row blocks x 8) words of scratch, any content (pv_encoder.hip)
+  int spin_limit;                   // merged launch: polls of a tile flag before the consumer computes the tile itself
 };
 bool pv_enc_compact_supported(const pv_ivae_plan* p);
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s);

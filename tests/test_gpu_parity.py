@@ -1971,6 +1971,45 @@ def test_one_launch_encoder_at_large_batch(gpu_device):
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("b", [256, 8200])
+def test_one_launch_encoder_fallback_is_exact(gpu_device, b):
+    """HIP promises no dispatch order, so the one-launch encoder's consumers must not depend on their producers ever
+    arriving: after a bounded number of polls a consumer computes its row block's first-layer tiles itself, with the
+    producers' own K split (csrc/pv_encoder.hip enc_fwd_body).  pv_debug_enc_spin_limit(0) sends EVERY consumer down that
+    path: encode, loss, every gradient and the parameters after a one-call step must be bit-identical to the normal run and
+    to the two-launch form, and the fallback counter must show the path was taken."""
+    import ctypes as C
+    dbg = C.CDLL(_abi.LIB_PATH)
+    dbg.pv_debug_enc_late_count.restype = C.c_longlong
+    g = torch.Generator().manual_seed(23)
+    x, eps = torch.rand(b, 28, 28, generator=g).cuda(), torch.randn(b, 5, generator=g).cuda()
+    res, late = [], []
+    try:
+        for two, spin in ((1, -1), (0, -1), (0, 0)):
+            dbg.pv_debug_enc_two(two)
+            dbg.pv_debug_enc_spin_limit(spin)
+            torch.cuda.synchronize()
+            before = dbg.pv_debug_enc_late_count()
+            m = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+            eng = m.engine(fused=3)
+            zl, zs = m.encode(x)
+            eng.loss_and_grads(x, eps)
+            torch.cuda.synchronize()
+            rec = [torch.as_tensor(zl).clone(), torch.as_tensor(zs).clone(), eng.scalars.clone(), eng.grad.clone()]
+            eng.loss_and_grads(x, eps, step=True)
+            torch.cuda.synchronize()
+            rec.append(torch.cat([p.detach().flatten() for p in m.parameters()]).clone())
+            res.append(rec)
+            late.append(dbg.pv_debug_enc_late_count() - before)
+    finally:
+        dbg.pv_debug_enc_two(-1)
+        dbg.pv_debug_enc_spin_limit(-1)
+    assert late[0] == 0 and late[2] >= 2 * ((b + 15) // 16), late        # every consumer of both training launches fell back
+    for a, c, d in zip(*res):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, c) and torch.equal(a, d)
+
+
 def test_fused_1d_decoder_more_samples_than_workgroups(gpu_device):
     """The fused Conv1d decoder launches at most 2048 workgroups; beyond that a workgroup carries several samples one after
     the other through the same LDS buffers (csrc/pv_dec1d.hip: the grid-stride loop and its closing barrier).  A batch of
