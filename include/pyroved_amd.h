@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 13
+#define PV_ABI_VERSION 14
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -180,11 +180,13 @@ typedef struct pv_ivae_plan {
   const float* ext_dz;
   const float* ext_ll;
   int32_t      ext_decoder;
-  int32_t      _pad4;
+  int32_t      conv_wide; /* (v14) convolutional encoder, fp32-class modes: a kernel-3 weight lies outside the range the two-piece
+                             fp16 kernels are exact in (|w| < ~1000, not all < ~1e-6): three bf16 pieces instead (no range limit).
+                             A fact of THIS model's weights — rounds 2-3 had a process-wide setter                              */
   /* ---- Adam (torch.optim.Adam defaults via pyro.optim.Adam, svi.py:79-81) ---- */
   float   lr, adam_beta1, adam_beta2, adam_eps;
   int32_t adam_step;      /* 1-based step count of THIS update                            */
-  int32_t _pad2;
+  int32_t flags;          /* (v14) PV_PLAN_* bits below                                   */
   /* ---- optional instrumentation ---- */
   void*   ev_start;       /* hipEvent_t recorded on `stream` right before the dominant decoder  */
   void*   ev_stop;        /* kernel's launch and right after it (NULL: no recording)            */
@@ -210,21 +212,26 @@ typedef struct pv_ivae_plan {
 /* Library / ABI version (PV_ABI_VERSION). */
 int pv_version(void);
 
-/* (v12) Process-wide numeric range switch of the 2-D kernel-3 convolution kernels (conv encoder of an iVAE, VED).  Their
- * default fp32-class form carries the weights as two fp16 pieces of w * 64 (exact power-of-two scaling of the activations,
- * none of the weights), valid for 1e-6 < max|w| < 1023; on = 1 selects the three-piece bf16 kernels, which have no range
- * limit and the same accuracy at ~1.5x the matrix time.  The Python engines call it when a weight leaves the safe range
- * (checked at bind time and every 64 steps; Adam moves a weight by at most lr per step).  No reference counterpart: the
- * reference's nn.Conv2d is plain fp32 (nets/conv.py:24-60). */
+/* (v14) Per-plan switches that rounds 2-3 kept in process-wide setters (`flags` of pv_ivae_plan / pv_ved_plan):
+ *   PV_PLAN_ENC_TWO_LAUNCH  the compact fc encoder as two launches (first layer, then the rest) instead of one grid whose
+ *                           second half waits on per-tile flags — e.g. for a caller that wants no in-launch hand-off;
+ *   PV_PLAN_NO_SIDE_STREAM  steps with a convolutional encoder (VED, iVAE + convEncoderNet) keep every launch on the caller's
+ *                           stream.  By default the weight gradients of the encoder's kernel-3 convolutions, the decoder's
+ *                           batched weight gradients and their split-order reductions run on a second, low-priority stream the
+ *                           library creates per device; the caller's stream waits for it before the entry point's last
+ *                           launches (nothing is left running that the caller's stream does not wait for; bit-identical
+ *                           either way).  Also PV_NO_SIDE=1 in the environment, and never while the stream is captured.
+ * The numeric range of the convolution kernels is pv_ivae_plan.conv_wide / conv_bf16 == 2 of pv_ved_plan and
+ * pv_convnet_plan: the default fp32-class form carries kernel-3 weights as two fp16 pieces of w * 64, valid for
+ * 1e-6 < max|w| < 1023; the wide form uses three bf16 pieces (no range limit, same accuracy, ~1.5x the matrix time).  The
+ * Python engines set it when a weight of THEIR model leaves the safe range (checked at bind time, on the first inference call
+ * after a bind, and every 64 steps; Adam moves a weight by at most lr per step).
+ * No reference counterpart: the reference's nn.Conv2d is plain fp32 on torch's current stream (nets/conv.py:24-60). */
+#define PV_PLAN_ENC_TWO_LAUNCH 1
+#define PV_PLAN_NO_SIDE_STREAM 2
+/* (v12 / v13, deprecated since v14: no effect — the switches are plan fields now; kept for one version so that existing
+ * bindings load) */
 void pv_conv_set_wide_weights(int on);
-
-/* (v13) Steps of models with a convolutional encoder (VED, iVAE + convEncoderNet) enqueue the weight gradients of the
- * encoder's kernel-3 convolutions, the decoder's batched weight gradients and their split-order reductions on a second,
- * low-priority stream the library creates per device; the input-gradient chain stays on the caller's stream, which
- * waits for the side stream before the entry point's last launches (nothing is left running that the caller's stream
- * does not wait for; results are bit-identical either way).  on = 0 keeps everything on the caller's stream — e.g. while
- * the caller captures its stream into a graph it does not want forked; on = 1 restores the default (also: PV_NO_SIDE=1 in
- * the environment).  No reference counterpart: the reference runs every op on torch's current stream. */
 void pv_set_side_stream(int on);
 
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
@@ -342,12 +349,13 @@ typedef struct pv_ved_plan {
   int32_t dec_c0, dec_dim0[2];
   int32_t bn_eval;                 /* batch-norm layers use their running statistics (module.eval(): VED.encode / decode /
                                       manifold2d switch to it and nothing switches back, models/ved.py:178,193,230)  */
-  int32_t conv_bf16;               /* mixed precision: kernel-3 convolutions with a multiple of 32 input channels run
-                                      forward and input gradient on the bf16 matrix cores in split precision (hi + lo,
-                                      3 products: ~2^-16 per product — gradients that are sums with heavy cancellation
-                                      lose digits, measured 7e-3 on the first layer's weights); 0: f32-input MFMA.
-                                      (pv_ivae_plan's convolutional encoder: selected by fused == 3)                */
-  int32_t _pad;
+  int32_t conv_bf16;               /* precision of the kernel-3 convolutions with a multiple of 32 input channels (matrix
+                                      cores, split operands): 0 fp32-class — two fp16 pieces with exact power-of-two scaling,
+                                      3 products (3e-7 vs float64); 1 mixed — two rounded bf16 pieces, 3 products (~2^-16 per
+                                      product: gradients that are sums with heavy cancellation lose digits, measured 7e-3 on
+                                      the first layer's weights); 2 (v14) fp32-class for weights outside fp16's range — three
+                                      bf16 pieces.  (pv_ivae_plan's convolutional encoder: fused == 3 selects 1, conv_wide 2) */
+  int32_t flags;                   /* (v14) PV_PLAN_NO_SIDE_STREAM                                                          */
   float*       params;
   float*       grads;
   float*       adam_m;
@@ -391,7 +399,7 @@ typedef struct pv_convnet_plan {
   int32_t in_ch, in_dim[2];
   int32_t n_ops;
   int32_t bn_eval;                     /* batch norm on the running statistics (module.eval())                 */
-  int32_t conv_bf16;                   /* 0: fp32-class, 1: mixed precision in the 2-D k3 convolutions         */
+  int32_t conv_bf16;                   /* 0: fp32-class, 1: mixed precision in the 2-D k3 convolutions, 2: fp32-class wide (as pv_ved_plan) */
   int32_t need_dx;                     /* the backward will be asked for dL/dx (set at forward time too)       */
   pv_op   ops[PV_MAX_OPS];
   const float* params;                 /* flat buffer the ops' offsets refer to (running statistics included)  */

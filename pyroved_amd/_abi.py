@@ -13,7 +13,8 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 13
+PV_ABI_VERSION = 14
+PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM = 1, 2     # pv_ivae_plan.flags / pv_ved_plan.flags
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -64,9 +65,9 @@ class pv_ivae_plan(C.Structure):
         ("ext_encoder", C.c_int32), ("bn_eval", C.c_int32),
         ("row_w", C.c_void_p), ("row_elbo", C.c_void_p), ("dy", C.c_void_p),
         ("ext_z", C.c_void_p), ("ext_dz", C.c_void_p), ("ext_ll", C.c_void_p),
-        ("ext_decoder", C.c_int32), ("_pad4", C.c_int32),
+        ("ext_decoder", C.c_int32), ("conv_wide", C.c_int32),
         ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
-        ("adam_step", C.c_int32), ("_pad2", C.c_int32),
+        ("adam_step", C.c_int32), ("flags", C.c_int32),
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
         ("class_onehot", C.c_void_p),
         ("conv_ev_start", C.c_void_p), ("conv_ev_stop", C.c_void_p), ("conv_ev_flops", C.c_void_p),
@@ -83,7 +84,7 @@ class pv_ved_plan(C.Structure):
         ("enc", pv_op * PV_MAX_OPS), ("dec", pv_op * PV_MAX_OPS),
         ("head", pv_layer), ("l2f", pv_layer),
         ("dec_c0", C.c_int32), ("dec_dim0", C.c_int32 * 2), ("bn_eval", C.c_int32),
-        ("conv_bf16", C.c_int32), ("_pad", C.c_int32),
+        ("conv_bf16", C.c_int32), ("flags", C.c_int32),
         ("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
         ("n_params", C.c_int64),
         ("x", C.c_void_p), ("y", C.c_void_p), ("eps", C.c_void_p),

@@ -631,13 +631,13 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
 }
 
 // 4: two fp16 pieces with exact power-of-two scaling (default; needs |w| * 64 inside fp16's range, i.e. |w| < ~1023 and not
-// all below ~1e-6), 3: three bf16 pieces (no range limit; PV_SP_X6=1 or pv_conv_set_wide_weights(1), which the host side
-// calls when a kernel-3 convolution weight leaves the safe range: engine.py _check_conv_weight_range)
-static int sp_mode_override = 0;
-extern "C" void pv_conv_set_wide_weights(int on) { sp_mode_override = on ? 3 : 0; }
+// all below ~1e-6), 3: three bf16 pieces (no range limit).  The process-wide default is 4 (PV_SP_X6=1 in the environment: 3);
+// a plan whose weights leave the safe range asks for 3 itself (ABI v14: pv_ivae_plan.conv_wide, conv_bf16 == 2 of the other
+// plans; pv_convstack.h sp_fp32_mode) — the setter of v12 / v13 is a no-op kept for one version
+extern "C" void pv_conv_set_wide_weights(int) {}
 int pv_conv3_sp_fp32_mode() {
   static const int mode = (getenv("PV_SP_X6") && atoi(getenv("PV_SP_X6"))) ? 3 : 4;
-  return sp_mode_override ? sp_mode_override : mode;
+  return mode;
 }
 
 bool pv_conv3_sp_supported(int C, int Cout, int nd, int act) {

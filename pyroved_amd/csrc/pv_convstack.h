@@ -124,7 +124,9 @@ struct WtPlan {
 struct Scratch {
   float* col /* flipped-weight scratch (maxcol floats) */; void* ws; int64_t ws_bytes;
   float* bn = nullptr; int bn_maxC = 0; int bn_eval = 0;     // batch-norm statistics slots (bn_floats), mode
-  int conv_bf16 = 0;                                         // kernel-3 convolutions on the bf16 matrix cores (x3)
+  int conv_bf16 = 0;                                         // conv mode of the plan (pv_*_plan.conv_bf16): 0 fp32-class (two fp16 pieces,
+                                                             // exact scaling), 1 mixed (two rounded bf16 pieces), 2 fp32-class for weights
+                                                             // outside fp16's range (three bf16 pieces); see conv_mixed / sp_mode below
   const char* wt = nullptr; const WtPlan* wtp = nullptr;     // the step's tiled weights (null: tile per call into col)
   unsigned char* code = nullptr;                             // winners of the fused first block's max-pool (stack 0 only)
   PvFinishList* fin = nullptr;                               // weight-gradient finishes deferred to pv_wgrad_finish_all
@@ -180,14 +182,20 @@ inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
 
 // pv_conv3_direct's precision argument: 1 two bf16 pieces (mixed), 2 two fp16 pieces with exact scaling (fp32-class), 0 the
 // f32-input MFMA (PV_SP_X6=1, or fewer than 32 input channels)
-inline int direct_mode(const Scratch& sc) { return sc.conv_bf16 ? 1 : (pv_conv3_sp_fp32_mode() == 4 ? 2 : 0); }
+// the conv mode is a PLAN fact (ABI v14; rounds 2-3 kept the wide-weights switch in a process-wide setter):
+inline bool conv_mixed(int cm) { return cm == 1; }
+// the split-operand kernels' piece count for fp32-class work: 4 = two fp16 pieces, 3 = three bf16 pieces
+inline int sp_fp32_mode(int cm) { return cm == 2 ? 3 : pv_conv3_sp_fp32_mode(); }
+// ... and the `mode` argument of pv_conv3_sp / _wgrad / _pair / pv_conv3_direct's callers: 2 mixed, else the fp32-class one
+inline int sp_mode(int cm) { return conv_mixed(cm) ? 2 : sp_fp32_mode(cm); }
+inline int direct_mode(const Scratch& sc) { return conv_mixed(sc.conv_bf16) ? 1 : (sp_fp32_mode(sc.conv_bf16) == 4 ? 2 : 0); }
 
 // which tiling (pv_conv_wprep_table kind) a kernel-3 convolution uses in an orientation; -1: none (GEMM fallback, k1)
 inline int wt_kind(const pv_op& o, int nd, int flip, int conv_bf16) {
   if (o.kind != PV_OP_CONV || o.ksize != 3) return -1;
   const int C = flip ? o.cout : o.cin, N = flip ? o.cin : o.cout, act = flip ? PV_ACT_NONE : o.act;
-  if (pv_conv3_sp_supported(C, N, nd, act)) return conv_bf16 ? 2 : (pv_conv3_sp_fp32_mode() == 4 ? 5 : 3);
-  if (pv_conv3_direct_supported(C, N, nd, act)) return C % 32 == 0 ? (conv_bf16 ? 1 : (pv_conv3_sp_fp32_mode() == 4 ? 6 : 0)) : 0;
+  if (pv_conv3_sp_supported(C, N, nd, act)) return conv_mixed(conv_bf16) ? 2 : (sp_fp32_mode(conv_bf16) == 4 ? 5 : 3);
+  if (pv_conv3_direct_supported(C, N, nd, act)) return C % 32 == 0 ? (conv_mixed(conv_bf16) ? 1 : (sp_fp32_mode(conv_bf16) == 4 ? 6 : 0)) : 0;
   return -1;
 }
 
@@ -278,7 +286,7 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
     if (o.ksize == 3) {
       if (pv_conv3_sp_supported(o.cin, o.cout, nd, o.act))      // 2-D, Cin % 32 == 0: exactly split operands on the bf16 cores
         return pv_conv3_sp(in, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr, 0,
-                           sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), wt_ready(sc, slot, 0));
+                           sp_mode(sc.conv_bf16), wt_ready(sc, slot, 0));
       if (pv_conv3_direct_supported(o.cin, o.cout, nd, o.act))
         return pv_conv3_direct(in, B, si.H, si.W, nd, params + o.w_off, o.cout, o.cin, 0, bias, out, o.act, sc.col, s, nullptr,
                                0, direct_mode(sc), wt_ready(sc, slot, 0));
@@ -314,7 +322,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       // which the main stream keeps using)
       const bool on_side = sc.side && pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) &&
                            pv_wgrad_defers(sc.fin, pv_conv3_sp_wgrad_ws(B, si.H, si.W, si.C, o.cout));
-      const bool pair = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) && gin && sc.fin && !sc.conv_bf16 && pv_conv3_sp_fp32_mode() == 4 &&
+      const bool pair = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) && gin && sc.fin && !conv_mixed(sc.conv_bf16) && sp_fp32_mode(sc.conv_bf16) == 4 &&
                         pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE) && (!on_side || side_keeps_pairs());
       if (pair) {                                       // weight gradient + input gradient: one launch (pv_conv_sp.hip)
         pv_conv3_sp_pair_begin();
@@ -330,11 +338,11 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd)) {
         if (on_side) PV_TRY(pv_fork_to(sc.side, s));                // g is complete: its producer's stop event, or a record on s
         PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, on_side ? sc.side : s,
-                                 sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), sc.fin));
+                                 sp_mode(sc.conv_bf16), sc.fin));
       }
-      else if (k3_lean_1d(nd) && (!sc.conv_bf16 || k3_lean_mixed(sc)))   // (launch by launch the mixed leg's bf16 kernel is faster)
+      else if (k3_lean_1d(nd) && (!conv_mixed(sc.conv_bf16) || k3_lean_mixed(sc)))   // (launch by launch the mixed leg's bf16 kernel is faster)
         PV_TRY(pv_conv3_1d_wgrad_lean(g, in, B, si.H, si.C, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin));
-      else if (sc.conv_bf16 && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
+      else if (conv_mixed(sc.conv_bf16) && si.C % 32 == 0 && pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_wgrad_direct_bf16(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, sc.fin));
       else if (pv_conv3_wgrad_direct_supported(si.C, o.cout, nd))
         PV_TRY(pv_conv3_wgrad_direct(g, in, B, si.H, si.W, si.C, nd, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, sc.fin));
@@ -348,7 +356,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         if (sc.side) pv_fork_arm();                        // the layer below may fork its weight gradient off this launch
         return pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act,
-                           sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(), wt_ready(sc, slot, 1));
+                           sp_mode(sc.conv_bf16), wt_ready(sc, slot, 1));
       }
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
@@ -400,7 +408,7 @@ inline int stack_fwd(const float* params, const pv_op* ops, int n, int nd, int B
     if (stack_id == 0 && sc.code2 && convpool_fusable(ops, n, nd, i, sh[i])) {      // a[i + 1] is never written
       const pv_op& o = ops[i];
       PV_TRY(pv_conv3_sp(a[i], B, sh[i].H, sh[i].W, params + o.w_off, o.cout, o.cin, 0, o.b_off >= 0 ? params + o.b_off : nullptr,
-                         a[i + 1], o.act, sc.col, s, nullptr, 0, sc.conv_bf16 ? 2 : pv_conv3_sp_fp32_mode(),
+                         a[i + 1], o.act, sc.col, s, nullptr, 0, sp_mode(sc.conv_bf16),
                          wt_ready(sc, stack_id * PV_MAX_OPS + i, 0), a[i + 2], sc.code2 + code2_off(ops, n, nd, B, sh, i)));
       ++i;
       continue;

@@ -70,6 +70,8 @@ struct Layout {
 
 // jiVAE (discrete_dim = K > 0): K decoder samples per input, ordered [k][b]; head = [mu | softplus input | class logits]
 static inline int64_t plan_K(const pv_ivae_plan* p) { return p->discrete_dim > 0 ? p->discrete_dim : 0; }
+// conv mode of the convolutional encoder (pv_convstack.h: 0 fp32-class fp16 pieces, 1 mixed, 2 fp32-class three bf16 pieces)
+static inline int plan_conv_mode(const pv_ivae_plan* p) { return p->fused == 3 ? 1 : (p->conv_wide ? 2 : 0); }
 static inline int64_t plan_S(const pv_ivae_plan* p) { return (plan_K(p) > 0 ? plan_K(p) : 1) * (int64_t)p->batch; }
 static inline int64_t plan_head_w(const pv_ivae_plan* p) { return 2 * (int64_t)p->z_dim + plan_K(p); }
 static inline int64_t plan_lat_in(const pv_ivae_plan* p) {
@@ -129,7 +131,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
         for (int i = 1; i < p->n_enc_ops; ++i) L.ceg[i] = (i == 1 && c1) ? nullptr : c.take(L.ces[i].elems(B));
       }
       L.ccol = c.take(cnd.maxcol);
-      pvcs::wt_layout(p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, false, L.cwtp);
+      pvcs::wt_layout(p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, plan_conv_mode(p), false, L.cwtp);
       L.cwt = reinterpret_cast<char*>(c.take((L.cwtp.bytes + 3) / 4));
       L.ccode = cnd.code_bytes ? reinterpret_cast<unsigned char*>(c.take((cnd.code_bytes + 3) / 4)) : nullptr;
       L.ccode2 = cnd.code2_bytes ? reinterpret_cast<unsigned char*>(c.take((cnd.code2_bytes + 3) / 4)) : nullptr;
@@ -336,7 +338,7 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, cons
   float* a[PV_MAX_OPS + 1];
   a[0] = const_cast<float*>(p->x);                  // one input channel: (B, 1, H, W) is already channels-last
   for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-  pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
+  pvcs::Scratch sc{L.ccol, L.scratch, L.scratch_bytes, L.cbn, L.cbn_maxC, p->bn_eval, plan_conv_mode(p)};
   sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // (both orientations: the backward of the same step reuses them)
   sc.code = L.ccode; sc.code2 = L.ccode2;
   if (p->conv_ev_start && p->conv_ev_stop) {
@@ -349,17 +351,17 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, cons
   const bool hfused = pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.chead_wt, p->head.out_dim, fe0.C, (int64_t)fe0.H * fe0.W);
   // the weight tilings next to the fused first block (raw weights) on the side stream; stack_fwd joins before its first tiled op
-  hipStream_t side = pv_side_stream_for(s);
+  hipStream_t side = pv_side_stream_for(s, p->flags);
   bool wt_join = false;
   static const int wprep_side = getenv("PV_SIDE_WPREP") && atoi(getenv("PV_SIDE_WPREP")) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
   if (wprep_side && side && sc.code && pvcs::c1pool_fusable(p->enc_ops, p->n_enc_ops, p->enc_ndim, L.ces[0])) {
     PV_TRY(pv_stream_after(side, s));
-    PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, side, &he,
+    PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, plan_conv_mode(p), L.cwtp, L.cwt, true, side, &he,
                          hfused ? 1 : 0, prep));
     wt_join = true;
     sc.side = side; sc.wt_join = &wt_join;
   } else {
-    PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, p->fused == 3, L.cwtp, L.cwt, true, s, &he,
+    PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, plan_conv_mode(p), L.cwtp, L.cwt, true, s, &he,
                          hfused ? 1 : 0, prep));
   }
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
@@ -483,7 +485,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
       g_is_pre = last.kind == PV_OP_CONV && last.act != PV_ACT_GELU;
       PV_TRY(pv_convhead_wgrad(L.dhead, L.cea[p->n_enc_ops], G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, (int)B,
                                fe.H * fe.W, fe.C, hd.out_dim, ws, wsb, s));
-      if (pv_side_stream_for(s)) pv_fork_arm();             // (the last convolution's weight gradient forks off this launch)
+      if (pv_side_stream_for(s, p->flags)) pv_fork_arm();             // (the last convolution's weight gradient forks off this launch)
       PV_TRY(pv_convhead_bwd(L.dhead, L.chead_wt, L.cea[p->n_enc_ops], g_is_pre ? last.act : PV_ACT_NONE, L.cg[1], (int)B, L.cF,
                              hd.out_dim, s));
     } else {
@@ -496,7 +498,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     float* a[PV_MAX_OPS + 1];
     a[0] = const_cast<float*>(p->x);
     for (int i = 1; i <= p->n_enc_ops; ++i) a[i] = L.cea[i];
-    pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, p->fused == 3};
+    pvcs::Scratch sc{L.ccol, ws, wsb, L.cbn, L.cbn_maxC, p->bn_eval, plan_conv_mode(p)};
     sc.wt = L.cwt; sc.wtp = &L.cwtp;                  // tiled by this step's conv_encoder_fwd
     sc.code = L.ccode; sc.code2 = L.ccode2;
     PvFinishList wfin{};                              // the weight gradients' reductions: one launch after the stack
@@ -505,7 +507,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     // kernel-3 weight gradients on the side stream, the input-gradient chain on s (every op's gradient in its own buffer);
     // joined before the finish
-    hipStream_t side = pv_side_stream_for(s);
+    hipStream_t side = pv_side_stream_for(s, p->flags);
     bool joined = false;
     PvSideJoin sj;                                    // joins the side stream on an early return
     sj.fork(s, side);
@@ -649,7 +651,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     e.w = p->row_w;
     if (p->coord_dim > 0) { e.hz = L.hz; e.Wz = p->params + p->fc_latent.w_off; e.H0 = p->fc_coord.out_dim; }
     e.hz_scale = hz_scale;
-    e.flags = L.enc_flags;
+    e.flags = (p->flags & PV_PLAN_ENC_TWO_LAUNCH) ? nullptr : L.enc_flags;
     e.B = p->batch; e.z_dim = p->z_dim; e.c_dim = p->c_dim; e.coord_dim = p->coord_dim;
     e.has_r = p->has_r; e.has_t = p->has_t; e.has_s = p->has_s;
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;

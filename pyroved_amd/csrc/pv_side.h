@@ -8,7 +8,9 @@ hipStream_t pv_side_stream();
 // are not replayable: the entry points fall back to their one-stream, one-kernel-per-stage forms under capture.)
 bool pv_stream_capturing(hipStream_t s);
 // pv_side_stream() unless `s` is being captured
-inline hipStream_t pv_side_stream_for(hipStream_t s) { return pv_stream_capturing(s) ? nullptr : pv_side_stream(); }
+inline hipStream_t pv_side_stream_for(hipStream_t s, int plan_flags = 0) {
+  return ((plan_flags & 2 /* PV_PLAN_NO_SIDE_STREAM */) || pv_stream_capturing(s)) ? nullptr : pv_side_stream();
+}
 // everything enqueued on `signaller` so far happens before whatever is enqueued on `waiter` from now on
 // (an event record on `signaller`: a marker packet that costs that stream ~5 us, scripts/ubench/event_cost.hip)
 int pv_stream_after(hipStream_t waiter, hipStream_t signaller);

@@ -22,17 +22,10 @@ struct Side {
 Side g_side[kMaxDev];
 std::mutex g_mu;
 
-std::atomic<int> g_on{-1};                            // -1: not decided yet (environment), 0 / 1
+// the environment's choice, read once (PV_NO_SIDE=1: never); per plan: PV_PLAN_NO_SIDE_STREAM (pv_side_stream_for)
 bool side_enabled() {
-  int v = g_on.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("PV_NO_SIDE");
-    v = (e && atoi(e) != 0) ? 0 : 1;
-    int expect = -1;
-    g_on.compare_exchange_strong(expect, v);
-    v = g_on.load();
-  }
-  return v == 1;
+  static const bool on = [] { const char* e = getenv("PV_NO_SIDE"); return !(e && atoi(e) != 0); }();
+  return on;
 }
 
 Side* side_of_current_device() {
@@ -60,7 +53,7 @@ Side* side_of_current_device() {
 
 }  // namespace
 
-extern "C" void pv_set_side_stream(int on) { g_on.store(on ? 1 : 0); }
+extern "C" void pv_set_side_stream(int) {}            // (v13's process-wide switch: a plan flag since v14; no-op kept for one version)
 
 bool pv_stream_capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

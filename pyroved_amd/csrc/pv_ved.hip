@@ -252,7 +252,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   PvSideJoin sj;                                       // joins the side stream on every return path
   // The step's weight tilings run on the side stream next to the fused first block (which reads the raw weights); the
   // encoder's stack joins before its first tiled convolution.
-  hipStream_t side = pv_side_stream_for(s);
+  hipStream_t side = pv_side_stream_for(s, p->flags);
   bool wt_join = false;
   static const int wprep_side = getenv("PV_SIDE_WPREP") && atoi(getenv("PV_SIDE_WPREP")) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
   if (wprep_side && side && pvcs::c1pool_fusable(p->enc, p->n_enc_ops, p->ndim_in, L.es[0]) && L.sc.code) {
@@ -302,7 +302,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   static const int k1b_env = getenv("PV_NO_K1BATCH") && atoi(getenv("PV_NO_K1BATCH")) ? 0 : 1;
   PvK1Batch k1b{};
   if (k1b_env) fin.k1b = &k1b;
-  hipStream_t side2 = k1b_env ? pv_side_stream_for(s) : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
+  hipStream_t side2 = k1b_env ? pv_side_stream_for(s, p->flags) : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
   bool dz_done = false, head_done = false;
   if (k1b_env && dec1d_active(p, L)) {
     // every input gradient of the decoder in one launch (the fork event rides on it), then the weight gradients are recorded

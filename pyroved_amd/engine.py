@@ -150,7 +150,8 @@ class IVAEEngine:
     def bind(self):
         """(Re)builds the flat buffers from the model's current parameters and re-points the
         parameters at them.  Called at construction and whenever the parameters were moved."""
-        self._conv_slices = None                # (re-derived, and the weight-range check runs at the next step)
+        self._conv_slices = None                # (re-derived, and the weight-range check runs at the next call)
+        self.wide_weights = False               # this model's kernel-3 weights fit the fp16-piece kernels until a check says otherwise
         items = self._param_order()
         n_par = len(items)
         items = items + self._stat_buffers()
@@ -253,7 +254,7 @@ class IVAEEngine:
                 return False
         return True
 
-    # ---- numeric range of the fp16-piece convolution kernels (include/pyroved_amd.h: pv_conv_set_wide_weights) ----
+    # ---- numeric range of the fp16-piece convolution kernels (include/pyroved_amd.h: pv_ivae_plan.conv_wide) ----
     _CONV_W_HI, _CONV_W_LO, _CONV_W_EVERY = 500.0, 2.0 ** -16, 64
 
     def _conv3_weight_slices(self):
@@ -265,25 +266,34 @@ class IVAEEngine:
         return out
 
     def _check_conv_weight_range(self, force: bool = False):
-        """Every _CONV_W_EVERY-th step (and at bind time): if a kernel-3 convolution weight left the range the fp16-piece
-        kernels are exact in, switch the process to the unbounded three-piece bf16 kernels.  One scalar read-back per 64
-        steps; Adam moves a weight by at most lr per step, so the margin to fp16's limit (1023) cannot be crossed between
-        two checks."""
+        """At the first call after a bind (training step, encode or decode alike) and every _CONV_W_EVERY-th call: if a
+        kernel-3 convolution weight of THIS model left the range the fp16-piece kernels are exact in, its plans ask for the
+        unbounded three-piece bf16 kernels from then on (plan field, ABI v14; other models in the process are unaffected).
+        One scalar read-back per 64 calls; Adam moves a weight by at most lr per step, so the margin to fp16's limit (1023)
+        cannot be crossed between two checks.  The read-back synchronises: while the current stream is being captured the
+        check is skipped (captured steps are never range-checked — check before capturing)."""
         if getattr(self, "_conv_slices", None) is None:
             self._conv_slices = self._conv3_weight_slices()
             self._conv_tick = 0
-        if not self._conv_slices or getattr(IVAEEngine, "_wide_weights", False):
+        if not self._conv_slices or self.wide_weights:
             return
         self._conv_tick += 1
         if not force and self._conv_tick % self._CONV_W_EVERY != 1:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            self._conv_tick -= 1                # (the next uncaptured call checks)
             return
         mx = float(torch.stack([self.flat[o:o + n].abs().max() for o, n in self._conv_slices]).max())
         if mx >= self._CONV_W_HI or 0.0 < mx < self._CONV_W_LO or mx != mx:
             import warnings
             warnings.warn("pyroved_amd: a convolution weight reached |w| = %.3g, outside the range of the fp16-piece "
-                          "kernels; switching this process to the three-piece bf16 convolution kernels" % mx)
-            _abi.lib().pv_conv_set_wide_weights(1)
-            IVAEEngine._wide_weights = True
+                          "kernels; this model switches to the three-piece bf16 convolution kernels" % mx)
+            self.wide_weights = True
+
+    def _plan_flags(self) -> int:
+        """pv_ivae_plan.flags / pv_ved_plan.flags from the engine's switches (ABI v14; process-wide setters before)."""
+        return ((_abi.PV_PLAN_ENC_TWO_LAUNCH if getattr(self, "enc_two_launch", False) else 0) |
+                (0 if getattr(self, "side_stream", True) else _abi.PV_PLAN_NO_SIDE_STREAM))
 
     def ensure_bound(self):
         if not self._bound():
@@ -384,6 +394,8 @@ class IVAEEngine:
             b0 = b1 = float(beta)
         p.beta, p.beta_disc = b0, b1
         p.bn_eval = int(not self.model.training)
+        p.conv_wide = int(self.wide_weights)
+        p.flags = self._plan_flags()
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = p.ext_head = p.ext_dhead = None
         p.row_w = p.row_elbo = p.dy = None
         p.ext_z = p.ext_dz = p.ext_ll = None
@@ -636,6 +648,8 @@ class IVAEEngine:
             with torch.no_grad():
                 z_loc, z_scale = self.model.encoder_z(x)
             return z_loc.to(torch.float32), z_scale.to(torch.float32)
+        if self.conv_enc:
+            self._check_conv_weight_range()
         b = x.shape[0]
         p = self._plan(b, what=2)
         x = self._prep(x, "x", (b, p.n_pix))

@@ -88,7 +88,9 @@ class VEDEngine(IVAEEngine):
         p.batch = batch
         p.beta = float(beta)
         p.bn_eval = int(not self.model.training)
-        p.conv_bf16 = int(self.fused == 3)           # SVItrainer(precision="bf16")
+        # SVItrainer(precision="bf16"): mixed; otherwise fp32-class, in the three-piece form once a weight left fp16's range
+        p.conv_bf16 = 1 if self.fused == 3 else (2 if self.wide_weights else 0)
+        p.flags = self._plan_flags()
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
         ce = getattr(self, "conv_events", None)          # (start, stop, ctypes double for the launch's FLOPs) or None
         p.conv_ev_start, p.conv_ev_stop, p.conv_ev_flops = (ce[0], ce[1], C.addressof(ce[2])) if ce else (None, None, None)
@@ -143,6 +145,7 @@ class VEDEngine(IVAEEngine):
     @_abi.on_device
     def encode(self, x, y=None):
         self.ensure_bound()
+        self._check_conv_weight_range()
         b = x.shape[0]
         p = self._plan(b)
         x = self._prep(x, "x", self._in_shape(b))
@@ -158,6 +161,7 @@ class VEDEngine(IVAEEngine):
     @_abi.on_device
     def decode(self, z, *unused, **unused_kw):
         self.ensure_bound()
+        self._check_conv_weight_range()
         b = z.shape[0]
         p = self._plan(b)
         z = self._prep(z, "z", (b, p.z_dim))

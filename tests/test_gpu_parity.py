@@ -1828,10 +1828,11 @@ def test_continuous_bernoulli_normaliser_vs_float64(gpu_device, fused):
 def test_conv_weight_range_switches_kernels(gpu_device):
     """ The default fp32-class 2-D convolution kernels carry the weights as fp16 pieces of w * 64 — exact only
     for max|w| < 1023.  A VED whose encoder weights are blown up beyond that: the engine notices at its first step, switches
-    the process to the three-piece bf16 kernels (no range limit) with a warning, and the step matches the oracle at the
-    usual bars instead of returning inf / NaN."""
-    from pyroved_amd.engine import IVAEEngine
-    lib = _abi.lib()
+    THIS model's plans to the three-piece bf16 kernels (no range limit; ABI v14: pv_ved_plan.conv_bf16 = 2) with a warning,
+    and the step matches the oracle at the usual bars instead of returning inf / NaN — while a second model in the same
+    process, with ordinary weights, keeps the fp16-piece kernels (round 3's process-wide switch moved both)."""
+    other = pv.models.VED((32, 32), (32,), latent_dim=2, seed=2, device="cuda")
+    eng_other = other.engine()
     model = pv.models.VED((32, 32), (32,), latent_dim=2, seed=1, device="cuda")
     cfg = orc.VedConfig(input_dim=(32, 32), output_dim=(32,), latent_dim=2, hidden_dim_e=None, hidden_dim_d=None,
                         activation="lrelu")
@@ -1844,10 +1845,13 @@ def test_conv_weight_range_switches_kernels(gpu_device):
     o = orc.VedOracle({k: v.cpu() for k, v in model.state_dict().items()}, cfg, dtype=torch.float64)
     g = torch.Generator().manual_seed(3)
     x, y, eps = torch.rand(6, 1, 32, 32, generator=g), torch.rand(6, 1, 32, generator=g), torch.randn(6, 2, generator=g)
-    try:
+    if True:
         with pytest.warns(UserWarning, match="three-piece bf16"):
             eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
-        assert IVAEEngine._wide_weights
+        assert eng.wide_weights and eng._static.conv_bf16 == 2
+        eng_other.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+        assert not eng_other.wide_weights and eng_other._static.conv_bf16 == 0      # per plan: the other model is untouched
+        assert np.isfinite(eng_other.scalars.cpu().numpy()).all()
         s = eng.scalars.cpu().numpy()
         loss_ref = o.step(x, y, eps, 1.0)
         assert np.isfinite(s).all()
@@ -1857,16 +1861,19 @@ def test_conv_weight_range_switches_kernels(gpu_device):
             #  itself is ~1e-3 off the float64 oracle in the first layers; what is checked is "finite and right", not 1e-4)
             err = rel_l2(eng.grad_of(key), o.last_grads[key].float())
             assert err < 1e-2, "grad %s: rel l2 error %.3e vs the float64 oracle" % (key, err)
-    finally:
-        lib.pv_conv_set_wide_weights(0)
-        IVAEEngine._wide_weights = False
+        # encode() on freshly bound out-of-range weights is checked too (the check ran only in training steps)
+        eng2 = model.engine()
+        eng2.bind()
+        with pytest.warns(UserWarning, match="three-piece bf16"):
+            zl, _ = eng2.encode(x.cuda())
+        assert eng2.wide_weights and torch.isfinite(zl).all()
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
     """Steps of models with a convolutional encoder put the encoder's kernel-3 weight gradients, the decoder's batched
     weight gradients and their reductions on the library's side stream (pv_side.hip; include/pyroved_amd.h
-    pv_set_side_stream).  Same kernels, same summation order: loss, every gradient and the parameters after three Adam
+    PV_PLAN_NO_SIDE_STREAM, a plan flag since ABI v14).  Same kernels, same summation order: loss, every gradient and the parameters after three Adam
     steps are BIT-identical with the side stream off — for VED (models/ved.py:122-163) and for an iVAE with
     convEncoderNet (nets/conv.py:24-102), at a batch where every layer takes the split-operand kernels."""
     lib = _abi.lib()
@@ -1876,10 +1883,10 @@ def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
     xi, ei = torch.rand(24, 64, 64, generator=g), torch.randn(24, 6, generator=g)
 
     def run(side):
-        lib.pv_set_side_stream(side)
         out = []
         ved = pv.models.VED((64, 64), (128,), latent_dim=2, seed=1, device="cuda")
         eng = ved.engine(fused=fused)
+        eng.side_stream = bool(side)
         for _ in range(3):
             eng.loss_and_grads(xv.cuda(), ev.cuda(), 1.0, yv.cuda())
             out.append(eng.scalars.clone())
@@ -1889,6 +1896,7 @@ def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
         iv = pv.models.iVAE((64, 64), 2, ["r", "t", "s"], seed=1, device="cuda")
         iv.set_encoder(pv.nets.convEncoderNet((64, 64), latent_dim=6))
         eng = iv.engine(fused=fused)
+        eng.side_stream = bool(side)
         for _ in range(3):
             eng.loss_and_grads(xi.cuda(), ei.cuda())
             out.append(eng.scalars.clone())
@@ -1898,10 +1906,7 @@ def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
         torch.cuda.synchronize()
         return out
 
-    try:
-        one, two = run(0), run(1)
-    finally:
-        lib.pv_set_side_stream(1)
+    one, two = run(0), run(1)
     assert len(one) == len(two)
     for k, (a, b) in enumerate(zip(one, two)):
         assert torch.isfinite(a).all()
@@ -1948,24 +1953,19 @@ def test_one_launch_encoder_at_large_batch(gpu_device):
     """The compact encoder's one-launch form (csrc/pv_encoder.hip pv_enc_kernel: first-layer tiles and the rest of the encoder in
     one grid, hand-off through per-tile flags) at a batch whose grid (4 600 workgroups) does not fit the device at once: the
     consumers are dispatched after every producer, so it must neither hang nor read a tile early.  Bit-identical to the
-    two-launch form (pv_debug_enc_two): encode and one training step, iVAE 28x28 (fcEncoderNet, nets/fc.py:51-61)."""
-    import ctypes as C
-    dbg = C.CDLL(_abi.LIB_PATH)
+    two-launch form (the plan flag PV_PLAN_ENC_TWO_LAUNCH): encode and one training step, iVAE 28x28 (fcEncoderNet, nets/fc.py:51-61)."""
     g = torch.Generator().manual_seed(17)
     b = 8200                                            # (not a multiple of 16: the last row block is partial)
     x, eps = torch.rand(b, 28, 28, generator=g).cuda(), torch.randn(b, 5, generator=g).cuda()
     res = []
-    try:
-        for two in (1, 0):
-            dbg.pv_debug_enc_two(two)
-            m = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
-            eng = m.engine(fused=3)
-            zl, zs = m.encode(x)
-            eng.loss_and_grads(x, eps)
-            torch.cuda.synchronize()
-            res.append((torch.as_tensor(zl).clone(), torch.as_tensor(zs).clone(), eng.scalars.clone(), eng.grad.clone()))
-    finally:
-        dbg.pv_debug_enc_two(-1)
+    for two in (1, 0):
+        m = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+        eng = m.engine(fused=3)
+        eng.enc_two_launch = bool(two)                   # pv_ivae_plan.flags: PV_PLAN_ENC_TWO_LAUNCH (ABI v14)
+        zl, zs = m.encode(x)
+        eng.loss_and_grads(x, eps)
+        torch.cuda.synchronize()
+        res.append((torch.as_tensor(zl).clone(), torch.as_tensor(zs).clone(), eng.scalars.clone(), eng.grad.clone()))
     for a, c in zip(*res):
         assert torch.isfinite(a).all()
         assert torch.equal(a, c)
