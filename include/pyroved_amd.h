@@ -354,7 +354,10 @@ typedef struct pv_ved_plan {
                                       3 products (3e-7 vs float64); 1 mixed — two rounded bf16 pieces, 3 products (~2^-16 per
                                       product: gradients that are sums with heavy cancellation lose digits, measured 7e-3 on
                                       the first layer's weights); 2 (v14) fp32-class for weights outside fp16's range — three
-                                      bf16 pieces.  (pv_ivae_plan's convolutional encoder: fused == 3 selects 1, conv_wide 2) */
+                                      bf16 pieces; 3 (v14) throughput — ONE fp16 piece per operand (power-of-two scaled per
+                                      staged tile), one product: a third of the matrix instructions, no split arithmetic;
+                                      gradients to ~1e-2, the ELBO to 1e-4 (SVItrainer(precision="bf16")).
+                                      (pv_ivae_plan's convolutional encoder: fused == 3 selects 3, conv_wide 2)             */
   int32_t flags;                   /* (v14) PV_PLAN_NO_SIDE_STREAM                                                          */
   float*       params;
   float*       grads;
@@ -399,7 +402,7 @@ typedef struct pv_convnet_plan {
   int32_t in_ch, in_dim[2];
   int32_t n_ops;
   int32_t bn_eval;                     /* batch norm on the running statistics (module.eval())                 */
-  int32_t conv_bf16;                   /* 0: fp32-class, 1: mixed precision in the 2-D k3 convolutions, 2: fp32-class wide (as pv_ved_plan) */
+  int32_t conv_bf16;                   /* 0: fp32-class, 1: mixed, 2: fp32-class wide, 3: one fp16 piece (as pv_ved_plan) */
   int32_t need_dx;                     /* the backward will be asked for dL/dx (set at forward time too)       */
   pv_op   ops[PV_MAX_OPS];
   const float* params;                 /* flat buffer the ops' offsets refer to (running statistics included)  */

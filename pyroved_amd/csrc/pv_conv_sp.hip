@@ -99,6 +99,14 @@ __device__ __forceinline__ void sp_split4_f16(const f32x4& v, float sc, u32x2 (&
   pl[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
   pl[1] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
 }
+// one-piece forms (round 4, the throughput precision: ONE fp16 piece per operand, one product): round to nearest
+typedef _Float16 shf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sp_split4_f16(const f32x4& v, float sc, u32x2 (&pl)[1]) {
+  pl[0] = __builtin_bit_cast(u32x2, __builtin_convertvector(v * sc, shf4));
+}
+__device__ __forceinline__ void sp_split1_f16(float v, unsigned short (&pl)[1]) {
+  pl[0] = __builtin_bit_cast(unsigned short, (_Float16)(v * SP_F16_WSCALE));
+}
 __device__ __forceinline__ void sp_split1_f16(float v, unsigned short (&pl)[2]) {
   const float t = v * SP_F16_WSCALE;
   const _Float16 h = (_Float16)t;
@@ -222,6 +230,10 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
       sp_wprep_elem<2, true>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
       continue;
     }
+    if (E.kind == 9) {                                // fp16 one-piece tiling (the throughput precision)
+      sp_wprep_elem<1, true>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
+      continue;
+    }
     if (E.kind >= 2 && E.kind != 6) {
       if (E.kind == 3) sp_wprep_elem<3>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
       else sp_wprep_elem<2>(E.w, reinterpret_cast<unsigned short*>(E.dst), Co, Ci, flip, e);
@@ -258,7 +270,7 @@ static int64_t wprep_elems(int kind, int Co, int Ci, int KK, int flip) {
     return (C & 15) == 0 ? (int64_t)((N + 15) / 16) * ((nck + G - 1) / G * G) * 256 : (int64_t)N * C * KK;
   }
   if (kind == 4 || kind == 7) return (int64_t)Co * Ci * KK;
-  if (kind == 5) KK = 9;
+  if (kind == 5 || kind == 9) KK = 9;
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   const int KC = kind == 0 ? 16 : 32;
   return (int64_t)((N + 63) / 64) * (C / KC) * KK * 64 * KC;
@@ -309,7 +321,7 @@ int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s, const PvFbPrep* f
 
 template <int NS, int NCB, bool F16 = false>
 __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, const int bid_y, char* smem) {
-  static_assert(!F16 || NS == 2, "the fp16 mode has two pieces");
+  static_assert(F16 ? (NS == 2 || NS == 1) : NS >= 2, "the fp16 modes have two pieces (fp32-class) or one (throughput)");
   __shared__ float smax[2][4];                        // F16: the waves' patch maxima of the chunk being staged
   constexpr int TG = NS == 3 ? 1 : 3;                 // taps per weight stage
   constexpr int NG = 9 / TG;
@@ -467,10 +479,12 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[2], acc[cb][pb]);
           }
+          if constexpr (NS >= 2) {
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][1], bcur[0], acc[cb][pb]);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][1], bcur[0], acc[cb][pb]);
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[1], acc[cb][pb]);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[1], acc[cb][pb]);
+          }
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[0], acc[cb][pb]);
 #pragma unroll
@@ -661,7 +675,7 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
                        Ci, flip);
     PV_LAUNCH_CHECK();
   }
-  constexpr int TG = NS == 3 ? 1 : 3;
+  constexpr int TG = NS == 3 ? 1 : (NS == 1 ? 3 : 3);
   static const int lds_pad = getenv("PV_SP_LDS_PAD") ? atoi(getenv("PV_SP_LDS_PAD")) : 0;   // (occupancy experiments)
   const size_t lds = (size_t)NS * SP_PPLANE + (size_t)TG * NS * SP_WPLANE + lds_pad;
   const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.B * nt;
@@ -671,7 +685,7 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
   ConvSp q = p;
   q.halves = (p.Cout > 32 && wgs <= split_lim) ? 2 : 1;
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(nt * q.halves));
-  if constexpr (F16) {
+  if constexpr (F16 && NS == 2) {
     if (sp_pair_capture_fwd(q, (p.Cout <= 32 || q.halves == 2) ? 2 : 4, grid, lds)) return 0;      // (launched by pv_conv3_sp_pair_flush)
   }
   // (PV_LAUNCH_FORK: an input gradient whose result a side-stream weight gradient waits for carries the fork event)
@@ -688,7 +702,7 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready, float* pool_out,
                 unsigned char* pool_code) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
-  if (!pv_conv3_sp_supported(C, N, 2, act) || (ns != 2 && ns != 3 && ns != 4)) return PV_EINVAL;   // 4: fp16 two-piece
+  if (!pv_conv3_sp_supported(C, N, 2, act) || ns < 1 || ns > 4) return PV_EINVAL;   // 4: fp16 two-piece, 1: fp16 one-piece
   const int nt = (N + SP_TN - 1) / SP_TN;
   const int64_t total = (int64_t)nt * (C / SP_KC) * 9 * SP_TN * SP_KC;
   ConvSp p{};
@@ -702,19 +716,21 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
   }
   char* prep = wt_ready ? nullptr : reinterpret_cast<char*>(wt_scratch);    // null: tiled already (pv_conv_wprep_table)
   if (ns == 4) return conv3_sp_launch<2, true>(p, w, Co, Ci, flip, prep, nt, total, s);
+  if (ns == 1) return conv3_sp_launch<1, true>(p, w, Co, Ci, flip, prep, nt, total, s);
   return ns == 3 ? conv3_sp_launch<3>(p, w, Co, Ci, flip, prep, nt, total, s) : conv3_sp_launch<2>(p, w, Co, Ci, flip, prep, nt, total, s);
 }
 
 // test / measurement hook: one convolution call on caller-provided device tensors.
 // mode 0: f32-input MFMA direct kernel, 1: its bf16 two-piece form, 5: its fp16 two-piece form, 2 / 3: this file's kernels with
-// 2 / 3 bf16 pieces, 4: with two fp16 pieces
+// 2 / 3 bf16 pieces, 4: with two fp16 pieces, 7: with one fp16 piece
 extern "C" int pv_debug_conv3(int mode, const float* in, int B, int H, int W, int nd, const float* w, int Co, int Ci, int flip,
                               const float* bias, float* out, int act, void* wt_scratch, const float* eg_y, int eg_act,
                               void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (mode == 5)      // the round-1 tile kernel (1-D and 2-D) on fp16 two-piece operands
     return pv_conv3_direct(in, B, H, W, nd, w, Co, Ci, flip, bias, out, act, reinterpret_cast<float*>(wt_scratch), s, eg_y, eg_act, 2);
-  if (mode >= 2) return nd == 2 ? pv_conv3_sp(in, B, H, W, w, Co, Ci, flip, bias, out, act, wt_scratch, s, eg_y, eg_act, mode)
+  if (mode == 7) mode = 1 + 16;                      // (7: this file's kernels with ONE fp16 piece)
+  if (mode >= 2) return nd == 2 ? pv_conv3_sp(in, B, H, W, w, Co, Ci, flip, bias, out, act, wt_scratch, s, eg_y, eg_act, mode & 15)
                                 : PV_EINVAL;
   return pv_conv3_direct(in, B, H, W, nd, w, Co, Ci, flip, bias, out, act, reinterpret_cast<float*>(wt_scratch), s, eg_y, eg_act,
                          mode);
@@ -730,7 +746,7 @@ extern "C" int pv_debug_conv3_wgrad(int mode, const float* dy, const float* in, 
   hipStream_t s = (hipStream_t)stream;
   if (mode == 1) return pv_conv3_wgrad_direct_bf16(dy, in, B, H, W, C, nd, dw, db, Cout, ws, ws_bytes, s);
   if (mode == 0) return pv_conv3_wgrad_direct(dy, in, B, H, W, C, nd, dw, db, Cout, ws, ws_bytes, s);
-  return nd == 2 ? pv_conv3_sp_wgrad(dy, in, B, H, W, C, dw, db, Cout, ws, ws_bytes, s, mode) : PV_EINVAL;
+  return nd == 2 ? pv_conv3_sp_wgrad(dy, in, B, H, W, C, dw, db, Cout, ws, ws_bytes, s, mode == 7 ? 1 : mode) : PV_EINVAL;
 }
 
 // resident workgroups per CU the runtime predicts for the forward kernel (ns pieces, 4 channel blocks) at lds bytes
@@ -791,7 +807,7 @@ template <int NCIB> struct SwGeo {
 #endif
 template <int NS, int NCIB, bool F16 = false>
 __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x, const int bid_y, const int bid_z, char* smem) {
-  static_assert(!F16 || (NS == 2 && NCIB == 1), "the fp16 mode: two pieces, 32-channel workgroups (next-tile prefetch)");
+  static_assert(F16 ? ((NS == 2 || NS == 1) && NCIB == 1) : NS >= 2, "the fp16 modes: two pieces or one, 32-channel workgroups (next-tile prefetch)");
   __shared__ float smx[2][2][4];                     // F16: [tile parity][dY | patch][wave] maxima of the tile being staged
   constexpr int PP = SwGeo<NCIB>::PP, RP = SwGeo<NCIB>::RP, PPLANE = SwGeo<NCIB>::PLANE;
   char* dyl = smem;                                  // [NS] planes
@@ -1013,7 +1029,8 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
   _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) _Pragma("unroll") for (int cob = 0; cob < 2; ++cob)                   \
       acc[3 * dy + dx][cob][cib] = sp_mma<F16>(a[cob][KA], bb[dx][KB], acc[3 * dy + dx][cob][cib]);
           if constexpr (NS == 3) { SW_PROD(1, 1) SW_PROD(2, 0) SW_PROD(0, 2) }
-          SW_PROD(1, 0) SW_PROD(0, 1) SW_PROD(0, 0)
+          if constexpr (NS >= 2) { SW_PROD(1, 0) SW_PROD(0, 1) }
+          SW_PROD(0, 0)
         }
       }
     }
@@ -1144,7 +1161,7 @@ int64_t pv_conv3_sp_wgrad_ws(int B, int H, int W, int C, int Cout) {
 
 int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int C, float* dw, float* db, int Cout, void* ws,
                       int64_t ws_bytes, hipStream_t s, int ns, PvFinishList* defer) {
-  if (!pv_conv3_sp_wgrad_supported(C, Cout, 2) || (ns != 2 && ns != 3 && ns != 4)) return PV_EINVAL;   // 4: fp16 two-piece
+  if (!pv_conv3_sp_wgrad_supported(C, Cout, 2) || ns < 1 || ns > 4) return PV_EINVAL;   // 4: fp16 two-piece, 1: fp16 one-piece
   if (!pv_wgrad_ws(defer, pv_conv3_sp_wgrad_ws(B, H, W, C, Cout), ws, ws_bytes)) defer = nullptr;
   if (ws_bytes < pv_conv3_sp_wgrad_ws(B, H, W, C, Cout)) return PV_EWS;
   ConvWgSp p{};
@@ -1156,11 +1173,13 @@ int pv_conv3_sp_wgrad(const float* dy, const float* in, int B, int H, int W, int
   p.part_b = db ? p.part + (int64_t)p.nsplit * nw : nullptr;
   const bool wide = ns == 2 && C % 64 == 0;
   const dim3 grid((unsigned)p.nsplit, (unsigned)(wide ? C / 64 : C / 32), (unsigned)((Cout + 63) / 64));
-  const size_t lds = (size_t)(ns == 4 ? 2 : ns) * (SW_DYPLANE + (wide ? SwGeo<2>::PLANE : SwGeo<1>::PLANE));
+  const size_t lds = (size_t)(ns == 4 ? 2 : ns) * (SW_DYPLANE + (wide ? SwGeo<2>::PLANE : SwGeo<1>::PLANE)) + (ns == 1 ? 0 : 0);
   if (ns == 4 && defer && g_pair.on && !g_pair.haveB) {          // (deferred reduction: the kernel may run later, in the pair launch)
     g_pair.b = p; g_pair.gridB = grid; g_pair.ldsB = lds; g_pair.haveB = true;
   } else if (ns == 4) {
     hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1, true>), grid, dim3(256), lds, s, p);
+  } else if (ns == 1) {
+    hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<1, 1, true>), grid, dim3(256), lds, s, p);
   } else if (ns == 3) {
     hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<3, 1>), grid, dim3(256), lds, s, p);
   } else {

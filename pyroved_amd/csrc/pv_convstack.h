@@ -125,8 +125,9 @@ struct Scratch {
   float* col /* flipped-weight scratch (maxcol floats) */; void* ws; int64_t ws_bytes;
   float* bn = nullptr; int bn_maxC = 0; int bn_eval = 0;     // batch-norm statistics slots (bn_floats), mode
   int conv_bf16 = 0;                                         // conv mode of the plan (pv_*_plan.conv_bf16): 0 fp32-class (two fp16 pieces,
-                                                             // exact scaling), 1 mixed (two rounded bf16 pieces), 2 fp32-class for weights
-                                                             // outside fp16's range (three bf16 pieces); see conv_mixed / sp_mode below
+                                                             // exact scaling), 1 mixed (two rounded bf16 pieces, 3 products), 2 fp32-class
+                                                             // for weights outside fp16's range (three bf16 pieces), 3 throughput (ONE
+                                                             // fp16 piece, one product); see conv_mixed / sp_mode below
   const char* wt = nullptr; const WtPlan* wtp = nullptr;     // the step's tiled weights (null: tile per call into col)
   unsigned char* code = nullptr;                             // winners of the fused first block's max-pool (stack 0 only)
   PvFinishList* fin = nullptr;                               // weight-gradient finishes deferred to pv_wgrad_finish_all
@@ -183,18 +184,18 @@ inline const void* wt_ready(const Scratch& sc, int slot, int flip) {
 // pv_conv3_direct's precision argument: 1 two bf16 pieces (mixed), 2 two fp16 pieces with exact scaling (fp32-class), 0 the
 // f32-input MFMA (PV_SP_X6=1, or fewer than 32 input channels)
 // the conv mode is a PLAN fact (ABI v14; rounds 2-3 kept the wide-weights switch in a process-wide setter):
-inline bool conv_mixed(int cm) { return cm == 1; }
+inline bool conv_mixed(int cm) { return cm == 1 || cm == 3; }   // (3: the kernels without a one-piece form run their mixed one)
 // the split-operand kernels' piece count for fp32-class work: 4 = two fp16 pieces, 3 = three bf16 pieces
 inline int sp_fp32_mode(int cm) { return cm == 2 ? 3 : pv_conv3_sp_fp32_mode(); }
 // ... and the `mode` argument of pv_conv3_sp / _wgrad / _pair / pv_conv3_direct's callers: 2 mixed, else the fp32-class one
-inline int sp_mode(int cm) { return conv_mixed(cm) ? 2 : sp_fp32_mode(cm); }
+inline int sp_mode(int cm) { return cm == 3 ? 1 : (cm == 1 ? 2 : sp_fp32_mode(cm)); }
 inline int direct_mode(const Scratch& sc) { return conv_mixed(sc.conv_bf16) ? 1 : (sp_fp32_mode(sc.conv_bf16) == 4 ? 2 : 0); }
 
 // which tiling (pv_conv_wprep_table kind) a kernel-3 convolution uses in an orientation; -1: none (GEMM fallback, k1)
 inline int wt_kind(const pv_op& o, int nd, int flip, int conv_bf16) {
   if (o.kind != PV_OP_CONV || o.ksize != 3) return -1;
   const int C = flip ? o.cout : o.cin, N = flip ? o.cin : o.cout, act = flip ? PV_ACT_NONE : o.act;
-  if (pv_conv3_sp_supported(C, N, nd, act)) return conv_mixed(conv_bf16) ? 2 : (sp_fp32_mode(conv_bf16) == 4 ? 5 : 3);
+  if (pv_conv3_sp_supported(C, N, nd, act)) return conv_bf16 == 3 ? 9 : (conv_bf16 == 1 ? 2 : (sp_fp32_mode(conv_bf16) == 4 ? 5 : 3));
   if (pv_conv3_direct_supported(C, N, nd, act)) return C % 32 == 0 ? (conv_mixed(conv_bf16) ? 1 : (sp_fp32_mode(conv_bf16) == 4 ? 6 : 0)) : 0;
   return -1;
 }

@@ -70,8 +70,9 @@ struct Layout {
 
 // jiVAE (discrete_dim = K > 0): K decoder samples per input, ordered [k][b]; head = [mu | softplus input | class logits]
 static inline int64_t plan_K(const pv_ivae_plan* p) { return p->discrete_dim > 0 ? p->discrete_dim : 0; }
-// conv mode of the convolutional encoder (pv_convstack.h: 0 fp32-class fp16 pieces, 1 mixed, 2 fp32-class three bf16 pieces)
-static inline int plan_conv_mode(const pv_ivae_plan* p) { return p->fused == 3 ? 1 : (p->conv_wide ? 2 : 0); }
+// conv mode of the convolutional encoder (pv_convstack.h: 0 fp32-class fp16 pieces, 1 mixed, 2 fp32-class three bf16 pieces,
+// 3 one fp16 piece)
+static inline int plan_conv_mode(const pv_ivae_plan* p) { return p->fused == 3 ? 3 : (p->conv_wide ? 2 : 0); }   // fused == 3: the throughput precision
 static inline int64_t plan_S(const pv_ivae_plan* p) { return (plan_K(p) > 0 ? plan_K(p) : 1) * (int64_t)p->batch; }
 static inline int64_t plan_head_w(const pv_ivae_plan* p) { return 2 * (int64_t)p->z_dim + plan_K(p); }
 static inline int64_t plan_lat_in(const pv_ivae_plan* p) {

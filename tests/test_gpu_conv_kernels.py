@@ -69,7 +69,9 @@ CONV_CASES = [  # (B, H, W, Cin, Cout, act)
     (2, 8, 8, 96, 72, "softplus"), (5, 4, 4, 128, 128, "sigmoid"), (1, 33, 17, 32, 32, "lrelu")]
 
 
-@pytest.mark.parametrize("mode,tol", [(3, 2e-6), (2, 2e-5)])
+# mode 7 (round 4): ONE fp16 piece per operand, one product — the throughput precision: per-element relative error 2^-12 on
+# both operands, ~3e-4 on a 288..1152-term dot product of random data
+@pytest.mark.parametrize("mode,tol", [(3, 2e-6), (2, 2e-5), (7, 6e-4)])
 @pytest.mark.parametrize("B,H,W,Ci,Co,act", CONV_CASES)
 def test_split_operand_conv_forward_and_input_gradient(gpu_device, mode, tol, B, H, W, Ci, Co, act):
     g = torch.Generator().manual_seed(B * 1000 + H * 31 + Co)
@@ -99,7 +101,7 @@ def test_split_operand_conv_forward_and_input_gradient(gpu_device, mode, tol, B,
     assert rel_l2(din, refd) < tol
 
 
-@pytest.mark.parametrize("mode,tol", [(3, 2e-6), (2, 2e-5)])
+@pytest.mark.parametrize("mode,tol", [(3, 2e-6), (2, 2e-5), (7, 6e-4)])
 @pytest.mark.parametrize("B,H,W,Ci,Co,act", CONV_CASES)
 def test_split_operand_conv_weight_gradient(gpu_device, mode, tol, B, H, W, Ci, Co, act):
     g = torch.Generator().manual_seed(7 + B * 1000 + H * 31 + Co)
