@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 artefact run on the GPU box (from the repo root): bench line, rocprofv3 kernel stats of the same command, step
+# Round-4 artefact run on the GPU box (from the repo root): bench line, rocprofv3 kernel stats of the same command, step
 # timelines (C2 bf16 / fp32-class, C4, C5), SQ counters of the headline decoder kernels, and FETCH_SIZE / WRITE_SIZE passes of
-# every config's dominant kernel(s) -> traffic.json (scripts/pmc_traffic.py).  Usage: bash scripts/gpu_prof_r3.sh <tag>
-TAG=${1:-r03}
+# every config's dominant kernel(s) -> traffic.json (scripts/pmc_traffic.py).  Usage: bash scripts/gpu_prof_r4.sh <tag>
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -42,13 +42,13 @@ PY
 done
 echo "== HBM traffic per launch, every config (FETCH_SIZE and WRITE_SIZE in separate passes)"
 rm -f $OUT/traffic.json
-for spec in "C2 3" "C2 2" "C1 3" "C3 3" "C4 3" "C4 2" "C4fc 3" "C5 2" "C5 3"; do
+for spec in "C2 3" "C2 2" "C1 3" "C1 2" "C3 3" "C3 2" "C4 3" "C4 2" "C4fc 3" "C4fc 2" "C5 2" "C5 3"; do
   set -- $spec; c=$1; m=$2
   for ctr in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rm -rf /tmp/tr_${TAG}_${c}_${m}_$ctr && timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE $ctr --output-format csv -d /tmp/tr_${TAG}_${c}_${m}_$ctr -o pmc -- python $R/bench.py --config $c --fused $m --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-configs --no-alt --no-legs > /dev/null 2>&1)
   done
   ff=$(find /tmp/tr_${TAG}_${c}_${m}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
   fw=$(find /tmp/tr_${TAG}_${c}_${m}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-  [ -n "$ff" ] && [ -n "$fw" ] && python scripts/pmc_traffic.py "$c:$m" "$ff" "$fw" $OUT/traffic.json "profiles/${TAG}_traffic.json (scripts/gpu_prof_r3.sh)" | tee -a $OUT/traffic.log
+  [ -n "$ff" ] && [ -n "$fw" ] && python scripts/pmc_traffic.py "$c:$m" "$ff" "$fw" $OUT/traffic.json "profiles/${TAG}_traffic.json (scripts/gpu_prof_r4.sh)" | tee -a $OUT/traffic.log
 done
 ls $OUT
