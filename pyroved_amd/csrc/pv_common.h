@@ -13,6 +13,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (e__ != hipSuccess) return (int)e__;    \
   } while (0)
 
+// ---- roctx ranges around the ABI entry points (tracing).  The marker library is NOT a link dependency: the
+// two symbols are looked up once — in what the process already holds (a profiler's preload, an application that links roctx),
+// else by dlopen of librocprofiler-sdk-roctx.so / libroctx64.so when PV_ROCTX=1 — and a missing library costs one branch per
+// call.  rocprofv3 --marker-trace then cuts a trainer epoch by step and phase (pv_ivae_step, pv_ved_loss_and_grads, ...).
+void pv_range_push(const char* name);   // pv_side.hip
+void pv_range_pop();
+struct PvRange {
+  explicit PvRange(const char* name) { pv_range_push(name); }
+  ~PvRange() { pv_range_pop(); }
+  PvRange(const PvRange&) = delete;
+  PvRange& operator=(const PvRange&) = delete;
+};
+#define PV_RANGE(name) PvRange pv_range_guard__(name)
+
 #define PV_TRY(expr)                           \
   do {                                         \
     int r__ = (expr);                          \

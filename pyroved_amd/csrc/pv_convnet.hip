@@ -76,6 +76,7 @@ extern "C" int pv_convnet_out_shape(const pv_convnet_plan* p, int32_t* out_shape
 }
 
 extern "C" int pv_convnet_forward(const pv_convnet_plan* p, const float* x, float* out, void* stream) {
+  PV_RANGE("pv_convnet_forward");
   NLayout L;
   if (!p || !p->params || !p->ws || !x || !out || !ncarve(p, (char*)p->ws, L)) return PV_EINVAL;
   if (p->ws_bytes < L.total) return PV_EWS;
@@ -91,6 +92,7 @@ extern "C" int pv_convnet_forward(const pv_convnet_plan* p, const float* x, floa
 }
 
 extern "C" int pv_convnet_backward(const pv_convnet_plan* p, const float* x, const float* dout, float* dx, void* stream) {
+  PV_RANGE("pv_convnet_backward");
   NLayout L;
   if (!p || !p->params || !p->grads || !p->ws || !x || !dout || !ncarve(p, (char*)p->ws, L)) return PV_EINVAL;
   if (p->ws_bytes < L.total) return PV_EWS;

@@ -989,6 +989,7 @@ __global__ void pv_adam_hist_kernel(float* __restrict__ p, float* __restrict__ g
 extern "C" int pv_adam_step_hist(float* params, float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                                  float beta2, float eps, int32_t step, const float* scalars_src, float* scalars_dst,
                                  int32_t n_scalars, void* stream) {
+  PV_RANGE("pv_adam_step_hist");
   if (step < 1 || n < 0 || n_scalars < 0 || n_scalars > 256 || (n_scalars > 0 && (!scalars_src || !scalars_dst)))
     return PV_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -1004,6 +1005,7 @@ extern "C" int pv_adam_step_hist(float* params, float* grads, float* m, float* v
 
 extern "C" int pv_adam_step(float* params, float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, int32_t step, void* stream) {
+  PV_RANGE("pv_adam_step");
   if (n <= 0) return 0;
   if (step < 1) return PV_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);

@@ -1033,6 +1033,7 @@ extern "C" int pv_ivae_uses_fused(const pv_ivae_plan* plan) {
 }
 
 extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* stream) {
+  PV_RANGE("pv_ivae_loss_and_grads");
   if (plan && plan->ext_decoder) return PV_EINVAL;      // (pv_ivae_guide / pv_ivae_guide_backward)
   if (!valid_plan(plan) || !plan->params || !plan->x || !plan->eps || !plan->scalars || !plan->ws) return PV_EINVAL;
   if (want_grads && !plan->grads) return PV_EINVAL;
@@ -1063,6 +1064,7 @@ static pv_ivae_plan guide_plan(const pv_ivae_plan* plan) {
 }
 
 extern "C" int pv_ivae_guide(const pv_ivae_plan* plan, void* stream) {
+  PV_RANGE("pv_ivae_guide");
   if (!plan || !plan->ext_decoder || plan->discrete_dim > 0 || plan->row_w || plan->row_elbo || plan->dy) return PV_EINVAL;
   const pv_ivae_plan q = guide_plan(plan);
   if (!valid_plan(&q) || !q.params || !q.x || !q.eps || !q.scalars || !q.ws || !q.ext_z) return PV_EINVAL;
@@ -1077,6 +1079,7 @@ extern "C" int pv_ivae_guide(const pv_ivae_plan* plan, void* stream) {
 }
 
 extern "C" int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, void* stream) {
+  PV_RANGE("pv_ivae_guide_backward");
   if (!plan || !plan->ext_decoder || plan->discrete_dim > 0) return PV_EINVAL;
   const pv_ivae_plan q = guide_plan(plan);
   if (!valid_plan(&q) || !q.params || !q.eps || !q.scalars || !q.ws || !q.ext_ll) return PV_EINVAL;
@@ -1096,6 +1099,7 @@ extern "C" int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, 
 // gradient launch (pv_wgrad.hip: every element is updated by whoever finalises its gradient; bit-identical to
 // pv_ivae_loss_and_grads + pv_adam_step, one launch fewer); everywhere else it is exactly that pair of calls.
 extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
+  PV_RANGE("pv_ivae_step");
   if (plan && !plan->ext_decoder && valid_plan(plan) && plan->params && plan->x && plan->eps && plan->scalars && plan->ws &&
       plan->grads && plan->adam_m && plan->adam_v && plan->adam_step >= 1 && plan->n_params > 0 &&
       !(plan->coord_dim > 0 && !plan->grid) && !plan->ext_encoder &&
@@ -1123,6 +1127,7 @@ extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
 }
 
 extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream) {
+  PV_RANGE("pv_ivae_encode");
   if (!plan) return PV_EINVAL;
   pv_ivae_plan lay = plan->ext_decoder ? guide_plan(plan) : *plan;
   if (!valid_plan(&lay) || plan->ext_encoder || !plan->params || !plan->x || !plan->ws || !z_loc || !z_scale) return PV_EINVAL;
@@ -1147,6 +1152,7 @@ extern "C" int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_s
 
 extern "C" int pv_ivae_decode(const pv_ivae_plan* plan, const float* z, float angle, float shift_x, float shift_y,
                               float scale, float* loc, void* stream) {
+  PV_RANGE("pv_ivae_decode");
   if (!valid_plan(plan) || !plan->params || !plan->ws || !z || !loc) return PV_EINVAL;
   if (plan->coord_dim > 0 && !plan->grid) return PV_EINVAL;
   pv_ivae_plan lay = decode_plan(plan);

@@ -99,6 +99,43 @@ int pv_fork_to(hipStream_t side, hipStream_t main) {
   return pv_stream_after(side, main);
 }
 
+// ---- roctx ranges (pv_common.h: PV_RANGE) ----
+#include <dlfcn.h>
+namespace {
+typedef int (*RangePushFn)(const char*);
+typedef int (*RangePopFn)();
+RangePushFn g_push = nullptr;
+RangePopFn g_pop = nullptr;
+std::atomic<int> g_roctx{-1};                         // -1: not resolved yet, 0: absent, 1: present
+void resolve_roctx() {
+  void* push = dlsym(RTLD_DEFAULT, "roctxRangePushA");
+  void* pop = dlsym(RTLD_DEFAULT, "roctxRangePop");
+  const char* want = getenv("PV_ROCTX");
+  if ((!push || !pop) && want && atoi(want) != 0) {
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+      if (!h) continue;
+      push = dlsym(h, "roctxRangePushA");
+      pop = dlsym(h, "roctxRangePop");
+      if (push && pop) break;
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (push && pop) { g_push = (RangePushFn)push; g_pop = (RangePopFn)pop; g_roctx.store(1); }
+  else g_roctx.store(0);
+}
+}  // namespace
+void pv_range_push(const char* name) {
+  int st = g_roctx.load(std::memory_order_acquire);
+  if (st < 0) { resolve_roctx(); st = g_roctx.load(std::memory_order_acquire); }
+  if (st == 1) (void)g_push(name);
+}
+void pv_range_pop() {
+  if (g_roctx.load(std::memory_order_acquire) == 1) (void)g_pop();
+}
+// test hook: 1 when the marker library was found (after the first range)
+extern "C" int pv_debug_roctx_state() { pv_range_push("pv_debug_roctx_state"); pv_range_pop(); return g_roctx.load(); }
+
 int pv_stream_after(hipStream_t waiter, hipStream_t signaller) {
   if (waiter == signaller) return 0;
   Side* S = side_of_current_device();

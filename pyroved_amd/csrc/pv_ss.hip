@@ -173,6 +173,7 @@ extern "C" int64_t pv_mlp_workspace_bytes(const pv_mlp_plan* plan) {
 }
 
 extern "C" int pv_mlp_forward(const pv_mlp_plan* plan, float* out, void* stream) {
+  PV_RANGE("pv_mlp_forward");
   if (!mlp_valid(plan) || !plan->params || !plan->x || !plan->ws || !out) return PV_EINVAL;
   MlpLayout L;
   mlp_carve(plan, (char*)plan->ws, L);
@@ -197,6 +198,7 @@ extern "C" int pv_mlp_forward(const pv_mlp_plan* plan, float* out, void* stream)
 }
 
 extern "C" int pv_mlp_backward(const pv_mlp_plan* plan, const float* out, const float* dout, void* stream) {
+  PV_RANGE("pv_mlp_backward");
   if (!mlp_valid(plan) || !plan->params || !plan->grads || !plan->x || !plan->ws || !dout) return PV_EINVAL;
   if (plan->out_kind == PV_MLP_SOFTMAX && !out) return PV_EINVAL;
   MlpLayout L;

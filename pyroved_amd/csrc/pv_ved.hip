@@ -241,6 +241,7 @@ extern "C" int64_t pv_ved_workspace_bytes(const pv_ved_plan* plan) {
 }
 
 extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void* stream) {
+  PV_RANGE("pv_ved_loss_and_grads");
   if (!valid_ved(p) || !p->params || !p->x || !p->y || !p->eps || !p->scalars || !p->ws) return PV_EINVAL;
   if (want_grads && !p->grads) return PV_EINVAL;
   VLayout L;
@@ -388,6 +389,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
 }
 
 extern "C" int pv_ved_encode(const pv_ved_plan* p, float* z_loc, float* z_scale, void* stream) {
+  PV_RANGE("pv_ved_encode");
   if (!valid_ved(p) || !p->params || !p->x || !p->ws || !z_loc || !z_scale) return PV_EINVAL;
   VLayout L;
   if (!vcarve(p, (char*)p->ws, L)) return PV_EINVAL;
@@ -397,6 +399,7 @@ extern "C" int pv_ved_encode(const pv_ved_plan* p, float* z_loc, float* z_scale,
 }
 
 extern "C" int pv_ved_decode(const pv_ved_plan* p, const float* z, float* loc, void* stream) {
+  PV_RANGE("pv_ved_decode");
   if (!valid_ved(p) || !p->params || !p->ws || !z || !loc) return PV_EINVAL;
   VLayout L;
   if (!vcarve(p, (char*)p->ws, L)) return PV_EINVAL;

@@ -534,3 +534,21 @@ def test_aux_trainer_data_parallel_world2_gloo(name):
         np.testing.assert_allclose(te, gold["epochs.test"], rtol=1e-3, atol=1e-6)
     for key in res[0][3]:
         assert np.array_equal(res[0][3][key], res[1][3][key]), key
+
+
+def test_roctx_ranges_resolve_without_a_link_dependency():
+    """The ABI entry points carry roctx ranges (csrc/pv_common.h PV_RANGE) whose two symbols are looked up at run time: the
+    library must load where no marker library exists (nothing in its NEEDED list names one) and find the markers when asked
+    to (PV_ROCTX=1) — checked in a fresh process, the lookup being once per process."""
+    import subprocess
+    import sys
+    from pyroved_amd import _abi
+    needed = subprocess.run(["readelf", "-d", _abi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "roctx" not in needed.lower()
+    code = ("import ctypes as C, os; os.environ['PV_ROCTX'] = '%s'; "
+            "print(C.CDLL(%r).pv_debug_roctx_state())" % ("%s", _abi.LIB_PATH))
+    have = any(os.path.exists(os.path.join("/opt/rocm/lib", n)) for n in ("librocprofiler-sdk-roctx.so", "libroctx64.so"))
+    off = subprocess.run([sys.executable, "-c", code % "0"], capture_output=True, text=True)
+    assert off.returncode == 0 and off.stdout.strip() == "0", off.stderr
+    on = subprocess.run([sys.executable, "-c", code % "1"], capture_output=True, text=True)
+    assert on.returncode == 0 and on.stdout.strip() == ("1" if have else "0"), on.stderr
