@@ -626,6 +626,14 @@ def main():
         # N > 1: the other scaling too — the config's batch as the GLOBAL batch, sharded (at batch 256 / 28x28 this is
         # latency-bound by design: 32 images per GPU at N = 8; DESIGN.md section 6 has the expected curve)
         strong = measure(args, name, cfg, args.fused, (pv, pvdist, td, dev, rank, world, b_cfg // world))
+    c5w = None
+    if world > 1 and name == "C2" and not args.strong and args.batch is None and not args.no_alt:
+        # N > 1: the conv config too (weak scaling, 256 images per GPU) — its 0.75 ms step hides the all-reduce's latency far
+        # better than C2's 0.12 ms, so it is the config whose curve can reach the >= 6x target
+        try:
+            c5w = measure(args, "C5", CONFIGS["C5"], args.fused, (pv, pvdist, td, dev, rank, world, CONFIGS["C5"]["batch"]))
+        except Exception as e:                   # (must not take the headline line down)
+            c5w = {"error": repr(e)[:300]}
     if rank == 0:
         out = {
             "metric": "images/sec (SVI step)", "value": main_leg["value"], "unit": "images/s", "n_gpus": world,
@@ -666,6 +674,16 @@ def main():
                              "note": "latency-bound by design at this size (launch chain + one all-reduce per step vs a few "
                                      "microseconds of decoder work per GPU): weak scaling is the curve that can reach the "
                                      ">= 6x target"}
+        if c5w is not None:
+            out["c5_weak"] = c5w if "error" in c5w else {
+                "config": "C5", "scaling": "weak", "batch_per_gpu": CONFIGS["C5"]["batch"], "value": c5w["value"],
+                "unit": "images/s", "ms_per_step": c5w["ms_per_step"], "ms_per_step_all": c5w["ms_per_step_all"],
+                "allreduce_ms": c5w.get("allreduce_ms"), "dtype": c5w["dtype"]}
+        if world > 1:
+            # what DESIGN.md section 6 expects on 8 GPUs of one node (no hardware run before round 4): the driver computes the
+            # measured x from its own per-N runs; these are the predictions to hold them against
+            out["expected_x8"] = {"c2_weak": "5.3-6.0 (one all-reduce of 0.6 MB per 0.13 ms step: latency-bound on xGMI)",
+                                  "c5_weak": "~7.4 (2.8 MB per 0.75-0.9 ms step)", "c2_strong": "1.3-1.6 (latency-bound by design)"}
         if world == 1 and not args.no_cpu_baseline:
             cb, loss0 = cpu_baseline(name, cfg)
             out["cpu_baseline"] = cb
