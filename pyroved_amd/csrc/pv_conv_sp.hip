@@ -183,7 +183,8 @@ __global__ void pv_conv_wprep_table_kernel(WprepTab t) {
   if (t.fb_blocks > 0) {                              // the last fb_blocks workgroups: the spatial decoder's weight images
     const int first = (int)gridDim.x - t.fb_blocks;
     if ((int)blockIdx.x >= first) {
-      pv_fb_prep(t.fb, (int64_t)((int)blockIdx.x - first) * blockDim.x + threadIdx.x, (int64_t)t.fb_blocks * blockDim.x);
+      pv_fb_prep(t.fb, (int64_t)((int)blockIdx.x - first) * blockDim.x + threadIdx.x, (int64_t)t.fb_blocks * blockDim.x,
+                 (int)(blockDim.x >> 6), (int)(threadIdx.x >> 6));
       return;
     }
   }

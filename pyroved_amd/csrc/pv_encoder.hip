@@ -94,7 +94,7 @@ __device__ __forceinline__ bool enc_l1_body(const PvEncFwd& e, int bx, int by, i
   const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
   if (by >= rb) {                                  // guest work: the decoder kernel's weight images (pv_fb_layout.h)
     const int64_t blk = (int64_t)(by - rb) * nx + bx;
-    pv_fb_prep(e.prep, blk * (64 * NW) + tid, (int64_t)(ny - rb) * nx * (64 * NW));
+    pv_fb_prep(e.prep, blk * (64 * NW) + tid, (int64_t)(ny - rb) * nx * (64 * NW), NW, wave);
     return false;
   }
   const pv_layer l = e.enc[0];

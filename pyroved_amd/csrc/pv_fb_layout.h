@@ -35,32 +35,33 @@ __device__ __forceinline__ int fb_swz(int R) { return 4 * (R & 3) + fb_sl((R >> 
 __device__ __forceinline__ int fb_wel(int R, int pc) { return R * LDB + 8 * ((pc >> 3) ^ fb_swz(R)) + (pc & 7); }
 
 // once per step: the hidden layers' weights as two-piece images (W1h W1l W2h W2l) and the zero fill of the
-// dL/d(hz) partial-sum slots.  Thread t of T cooperating threads (any launch shape made of WHOLE waves).
+// dL/d(hz) partial-sum slots.  Thread t of T cooperating threads (any launch shape made of whole workgroups of <= 8 waves).
 //   mode 0: bf16 hi / lo pieces of scale * W (rounded split, ~2^-17 relative);
 //   mode 1: fp16 hi / lo pieces of s * W with s the power of two that brings max |W| into [1, 2) — fp16's narrow exponent
 //           then costs nothing: hi + lo = s W to 2^-22 of an element, to 2^-25 of the largest for elements whose lo piece is
 //           subnormal — and the three scales {s1, s2, s_o (of the output layer's weights)} written after the images
-//           (FB_SCALE_OFF): pv_sdec_fused_bf16.hip's fp16 modes.
+//           (FB_SCALE_OFF): pv_sdec_fused_bf16.hip's fp16 modes;
+//   mode 2: as 1 for the images of C s W, C = 2 log2(e), with s = 1 while max |C W| lies in [2^-6, 2^10): pv_sdec_fused_w8h.hip.
 #define FB_SCALE_OFF (4 * IMG_BYTES)   // byte offset of the fp32 scales {s1, s2, s_o, 0} behind the four images
 struct PvFbPrep {
   const float* W1; const float* W2;   // (128, 128) fp32, nn.Linear layout
   void* img;                          // 4 * IMG_BYTES (+ 16 bytes of scales in mode 1)
   float* zero; int64_t nzero4;        // float4s to clear (0: none)
   float scale;                        // mode 0: images hold scale * W (0: unscaled) — pv_sdec_fused_w8.hip's 2 log2(e)
-  int mode;                           // 0: bf16 pieces, 1: normalised fp16 pieces
+  int mode;                           // 0: bf16 pieces, 1: normalised fp16 pieces, 2: fp16 pieces of C s W
   const float* wo;                    // mode 1: decoder.out weights (128), for s_o
 };
-// max |v| over n4 float4s, by one wave (every lane returns it); loads in independent batches of 16 per lane — a loop of
-// single dependent loads paid an L2 round trip per iteration: +23 us on the launch that hosts the preparation
-__device__ __forceinline__ float pv_fb_wave_absmax(const float* __restrict__ v, int n4, int lane) {
+// max |v| over float4s [lo4, hi4) of v, by one wave (every lane returns it); loads in independent batches of 16 per lane — a
+// loop of single dependent loads paid an L2 round trip per iteration: +23 us on the launch that hosts the preparation
+__device__ __forceinline__ float pv_fb_wave_absmax(const float* __restrict__ v, int lo4, int hi4, int lane) {
   float m = 0.0f;
   const f32x4* p = reinterpret_cast<const f32x4*>(v);
-  for (int b0 = 0; b0 < n4; b0 += 64 * 16) {
+  for (int b0 = lo4; b0 < hi4; b0 += 64 * 16) {
     f32x4 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int i = b0 + 64 * k + lane;
-      x[k] = i < n4 ? p[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      x[k] = i < hi4 ? p[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k)
@@ -83,29 +84,48 @@ __device__ __forceinline__ void fb_split_f16(float x, unsigned short& hi, unsign
   hi = __builtin_bit_cast(unsigned short, h);
   lo = __builtin_bit_cast(unsigned short, l);
 }
-__device__ __forceinline__ void pv_fb_prep(const PvFbPrep& p, int64_t t, int64_t T) {
+// nw: the waves of the calling workgroup that take part (ALL of its live waves: mode 1 has a workgroup barrier), wv: this one
+__device__ __forceinline__ void pv_fb_prep(const PvFbPrep& p, int64_t t, int64_t T, int nw, int wv) {
   __bf16* img = reinterpret_cast<__bf16*>(p.img);
   float s1 = p.scale != 0.0f ? p.scale : 1.0f, s2 = s1;
-  if (p.mode == 1) {
-    // every wave finds the three maxima for itself (192 KB of L2-resident reads per wave: no cross-wave step, any launch shape)
+  if (p.mode >= 1) {
+    // every WORKGROUP finds the maxima for itself, its waves a share of the two matrices each (128 KB of L2-resident reads per
+    // workgroup, two rounds of loads per wave: the hosting launch must not wait for this), combined through LDS
+    __shared__ float fbmax[2][8];
     const int lane = (int)(t & 63);
-    s1 = pv_fb_norm_scale(pv_fb_wave_absmax(p.W1, 128 * 32, lane));
-    s2 = pv_fb_norm_scale(pv_fb_wave_absmax(p.W2, 128 * 32, lane));
-    if ((t >> 6) == 0) {                                 // (wave-uniform: the first wave, all of its lanes)
-      const float so = pv_fb_norm_scale(pv_fb_wave_absmax(p.wo, 32, lane));
+    const int per = (128 * 32 + nw - 1) / nw, lo4 = wv * per, hi4 = lo4 + per < 128 * 32 ? lo4 + per : 128 * 32;
+    const float m1 = pv_fb_wave_absmax(p.W1, lo4, hi4, lane), m2 = pv_fb_wave_absmax(p.W2, lo4, hi4, lane);
+    if (lane == 0) { fbmax[0][wv] = m1; fbmax[1][wv] = m2; }
+    __syncthreads();
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int w = 0; w < nw; ++w) { a1 = fmaxf(a1, fbmax[0][w]); a2 = fmaxf(a2, fbmax[1][w]); }
+    if (p.mode == 2) {
+      // images of C s W, C = 2 log2(e), with s = 1 wherever two fp16 pieces of C W are accurate as they stand (max |C W| in
+      // [2^-6, 2^10): 2^-19 of the largest element at worst) — the kernel's tanh then needs no multiply — else normalised
+      const float C_ = 2.8853900817779268f;
+      const float c1 = C_ * a1, c2 = C_ * a2;
+      s1 = (c1 >= 0.015625f && c1 < 1024.0f) ? 1.0f : pv_fb_norm_scale(c1);
+      s2 = (c2 >= 0.015625f && c2 < 1024.0f) ? 1.0f : pv_fb_norm_scale(c2);
+    } else {
+      s1 = pv_fb_norm_scale(a1);
+      s2 = pv_fb_norm_scale(a2);
+    }
+    if ((t >> 6) == 0) {                                 // (wave-uniform: the first wave of the first workgroup, all of its lanes)
+      const float so = pv_fb_norm_scale(pv_fb_wave_absmax(p.wo, 0, 32, lane));
       if (lane == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.img) + FB_SCALE_OFF) = f32x4{s1, s2, so, 0.0f};
     }
   }
+  const float g1 = p.mode == 2 ? 2.8853900817779268f * s1 : s1, g2 = p.mode == 2 ? 2.8853900817779268f * s2 : s2;
   for (int64_t idx = t; idx < 128 * 32; idx += T) {
     const int row = (int)(idx >> 5), c4 = (int)(idx & 31);
-    const f32x4 w1 = reinterpret_cast<const f32x4*>(p.W1)[idx] * s1;
-    const f32x4 w2 = reinterpret_cast<const f32x4*>(p.W2)[idx] * s2;
+    const f32x4 w1 = reinterpret_cast<const f32x4*>(p.W1)[idx] * g1;
+    const f32x4 w2 = reinterpret_cast<const f32x4*>(p.W2)[idx] * g2;
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
     us4 h1, l1, h2, l2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       unsigned short a, b;
-      if (p.mode == 1) {
+      if (p.mode >= 1) {
         fb_split_f16(w1[i], a, b); h1[i] = a; l1[i] = b;
         fb_split_f16(w2[i], a, b); h2[i] = a; l2[i] = b;
       } else {

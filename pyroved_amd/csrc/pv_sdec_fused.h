@@ -62,6 +62,8 @@ int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t 
 // the 8-wave split-precision kernel (pv_sdec_fused_w8x3.hip; images pre-scaled by 2 log2(e) like the plain 8-wave kernel's)
 int pv_sdec_fused_w8x3_launch(const PvFused& f, int grid, bool grads, hipStream_t s, int waves);   // waves: 8 or 4
 int64_t pv_sdec_fused_w8x3_park_bytes(int grid);
+// the 8-wave fp16 kernel of the fp32-class path (pv_sdec_fused_w8h.hip; training launches; prep mode 2); ds: dL/dpre split
+int pv_sdec_fused_w8h_launch(const PvFused& f, int grid, bool ds, hipStream_t s);
 // bytes of PvFused::park the launch of (x3, units) needs (0: the kernel that will run has no parking slots)
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid);
 // waves per workgroup that publish a dL/d(hz) slot (sizes part_hz)

@@ -535,7 +535,7 @@ __device__ long long fb_trace[256];
 // stand-alone form of the per-step preparation (pv_fb_layout.h); the SVI step runs it inside the encoder's
 // first-layer launch instead (pv_encoder.hip)
 __global__ __launch_bounds__(256) void pv_fb_prep_kernel(PvFbPrep p) {
-  pv_fb_prep(p, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+  pv_fb_prep(p, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256, 4, (int)(threadIdx.x >> 6));
 }
 
 // LIK: the likelihood is a compile-time choice (the rarely used ones must not cost the Bernoulli kernel registers)
@@ -1019,7 +1019,7 @@ static int fb_x3_kind(int64_t units, bool grads) {
   int& v = fb_w8_mode[1];
   if (v < 0) {
     const char* e = getenv("PV_X3_KERNEL");
-    v = !e ? 2 : (e[0] == 'o' ? 0 : (e[0] == 'h' ? (atoi(e + 1) == 221 ? 21 : atoi(e + 1) == 223 ? 23 : atoi(e + 1) == 321 ? 31 : atoi(e + 1) == 333 ? 33 : atoi(e + 1) == 231 ? 28 : 2)
+    v = !e ? 2 : (e[0] == 'w' ? (atoi(e + 1) == 231 ? 48 : 41) : e[0] == 'o' ? 0 : (e[0] == 'h' ? (atoi(e + 1) == 221 ? 21 : atoi(e + 1) == 223 ? 23 : atoi(e + 1) == 321 ? 31 : atoi(e + 1) == 333 ? 33 : atoi(e + 1) == 231 ? 28 : 2)
                                                  : (atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : 2))));
   }
   if (v > 8) return grads ? v : (units * FD_UNIT < fb_row_cap && units >= 6 * (int64_t)pv_sdec_fused_grid(units) ? 8 : 0);
@@ -1033,12 +1033,16 @@ static int fb_x3_kind(int64_t units, bool grads) {
   if (grads) return 0;
   return units >= 6 * (int64_t)pv_sdec_fused_grid(units) ? 8 : 0;
 }
-static bool fb_kind_here(int kind) { return kind == 0 || kind > 8; }   // kinds this file's 4-wave kernel serves
+static bool fb_kind_here(int kind) { return kind == 0 || (kind > 8 && kind < 40); }   // kinds this file's 4-wave kernel serves
+static bool fb_kind_w8h(int kind) { return kind == 41 || kind == 48; }   // pv_sdec_fused_w8h.hip: H221 / H231 arithmetic, 8 waves
 static int fb_kind_prec(int kind) {
   return kind == 21 ? FB_P_H221 : kind == 23 ? FB_P_H223 : kind == 31 ? FB_P_H321 : kind == 33 ? FB_P_H333
        : kind == 26 ? FB_P_H2A1 : kind == 27 ? FB_P_H2B1 : kind == 28 ? FB_P_H231 : FB_P_X3;
 }
-int pv_sdec_fused_bf16_waves(bool x3, int64_t units) { return (x3 ? fb_x3_kind(units, true) == 8 : fb_use_w8(units)) ? 8 : FB_WAVES; }
+int pv_sdec_fused_bf16_waves(bool x3, int64_t units) {
+  const int kind = x3 ? fb_x3_kind(units, true) : 0;
+  return (x3 ? (kind == 8 || fb_kind_w8h(kind)) : fb_use_w8(units)) ? 8 : FB_WAVES;
+}
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid) {
   return (x3 && fb_x3_kind(units, true) == 8) ? pv_sdec_fused_w8x3_park_bytes(grid) : 0;
 }
@@ -1050,6 +1054,7 @@ extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, in
   static thread_local char buf[128];
   const char* g = grads ? "true" : "false";
   if (fused == 1) snprintf(buf, sizeof buf, "void pv_sdec_fused_kernel<%s>(PvFused)", g);
+  else if (fused == 2 && fb_kind_w8h(fb_x3_kind(units, grads != 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8h_kernel<%d, %s>(PvFused)", lik, fb_x3_kind(units, grads != 0) == 48 ? "true" : "false");
   else if (fused == 2 && !fb_kind_here(fb_x3_kind(units, grads != 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d, %d>(PvFused)", g, lik, fb_x3_kind(units, grads != 0));
   else if (fused == 3 && fb_use_w8(units)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d>(PvFused)", g, lik);
   else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %d>(PvFused)", g, lik, fused == 2 ? fb_kind_prec(fb_x3_kind(units, grads != 0)) : FB_P_BF16);
@@ -1063,8 +1068,8 @@ PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz; p.wo = f.wo;
   p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
   const int kind = x3 ? fb_x3_kind(f.units, grads) : -1;
-  p.mode = kind > 8 ? 1 : 0;
-  p.scale = (x3 ? !fb_kind_here(kind) : fb_use_w8(f.units)) ? 2.8853900817779268f : 0.0f;
+  p.mode = fb_kind_w8h(kind) ? 2 : (kind > 8 ? 1 : 0);
+  p.scale = (x3 ? !fb_kind_here(kind) : fb_use_w8(f.units)) ? 2.8853900817779268f : 0.0f;     // (also what hz arrives multiplied by)
   return p;
 }
 
@@ -1083,6 +1088,7 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3
   int prec = FB_P_BF16;
   if (x3) {
     const int kind = fb_x3_kind(f_in.units, grads);
+    if (fb_kind_w8h(kind)) return grads ? pv_sdec_fused_w8h_launch(f_in, grid, kind == 48, s) : PV_EINVAL;
     if (!fb_kind_here(kind)) return pv_sdec_fused_w8x3_launch(f_in, grid, grads, s, kind);
     prec = fb_kind_prec(kind);
   } else if (fb_use_w8(f_in.units)) {

@@ -21,7 +21,9 @@ from oracle import svi_oracle as orc  # noqa: E402
 from conftest import jmeta_of, load_golden, make_x, meta_of  # noqa: E402
 
 torch.set_num_threads(16)
-KINDS = [(0, "bf16 {3,3,3}"), (21, "f16 {2,2,1}"), (23, "f16 {2,2,3}"), (31, "f16 {3,2,1}"), (26, "f16 {2,3|2,1}"), (27, "f16 {2,2|3,1}"), (28, "f16 {2,3,1}"), (33, "f16 {3,3,3}")]
+KINDS = [(int(k), n) for k, n in (kv.split(":") for kv in os.environ["PV_TABLE_KINDS"].split(","))] if os.environ.get("PV_TABLE_KINDS") else [
+    (0, "bf16 {3,3,3}"), (21, "f16 {2,2,1}"), (23, "f16 {2,2,3}"), (31, "f16 {3,2,1}"), (26, "f16 {2,3|2,1}"), (27, "f16 {2,2|3,1}"),
+    (28, "f16 {2,3,1}"), (33, "f16 {3,3,3}")]
 FIXTURES = sys.argv[1:] or ["ivae_28x28_r_b128", "ivae_28x28_rt_b256", "ivae_28x28_r_b32_blobs", "ivae_8x8_rts_b6",
                             "ivae_8x8_rts_b6_randn", "ivae_7x9_rts_b3", "ivae_1d16_t_b5"]
 lib = C.CDLL(_abi.LIB_PATH)

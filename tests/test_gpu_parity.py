@@ -2169,10 +2169,11 @@ def test_w8x3_kernel_forced_vs_golden_and_oracle(gpu_device, force_w8x3, name):
         model.load_state_dict({k_: v_.detach() for k_, v_ in o.p.items()})
 
 
-@pytest.fixture(params=[28, 21], ids=["h231", "h221"])
+@pytest.fixture(params=[28, 21, 41], ids=["h231", "h221", "w8h221"])
 def force_h2(request):
     """Forces one fp16 build of the fp32-class decoder kernel (round 4: pv_sdec_fused_bf16_kernel<.., FB_P_H231 / H221>) for every
-    training launch; by default H231 runs from 16 384 decoder rows up."""
+    training launch; by default H231 runs from 16 384 decoder rows up.  41: the H221 arithmetic in the 8-wave geometry
+    (pv_sdec_fused_w8h.hip — a measured negative, profiles/r04e_w8h_experiments.txt — selectable for A/B runs)."""
     lib = C.CDLL(_abi.LIB_PATH)
     lib.pv_debug_force_w8x3(request.param)
     try:
@@ -2187,7 +2188,7 @@ def h2_grad_tol(rows, kind):
     the fp32-class bar holds; forced on toy problems the bar follows 1 / sqrt(rows)."""
     if kind == 28 and rows >= 16384:
         return RTOL_GRAD
-    return max(RTOL_GRAD if kind == 28 else 2.5 * RTOL_GRAD, 0.03 / rows ** 0.5)
+    return max(RTOL_GRAD if kind == 28 else (2.5 if kind == 21 else 3.5) * RTOL_GRAD, 0.03 / rows ** 0.5)
 
 
 @pytest.mark.parametrize("name", sorted(W8_SMALL) + ["ivae_28x28_r_b128", "ivae_28x28_rt_b256"])
@@ -2304,7 +2305,7 @@ def test_h2_kernel_jivae_and_row_weights(gpu_device, force_h2):
         tol = jivae_grad_tol(key)
         if tol is None:
             continue
-        if force_h2 == 21:
+        if force_h2 != 28:
             tol = max(tol, 1e-3)
         err = rel_l2(eng.grad_of(key), o.last_grads[key])
         assert err < tol, "grad %s: rel l2 error %.3e" % (key, err)
