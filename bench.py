@@ -447,20 +447,24 @@ def measure(args, name, cfg, fused, ctx):
         tb, ts = _traffic("%s:%d:conv" % (name, fused), B, cfg)
         conv_roof = {"bound": "mfma", "achieved": c_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": c_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": tb, "traffic_source": ts,
-                     "kernel": "void pv_conv3_sp_kernel<2, 4, %s>(ConvSp)" % ("false" if bf else "true"),
+                     "kernel": "void pv_conv3_sp_kernel<%d, 4, true>(ConvSp)" % (1 if bf else 2),
                      "what": "heaviest kernel-3 convolution of the encoder forward (most multiply-adds), with its max-pool "
-                             "epilogue; operands split in two %s pieces, 3 products per multiply-add"
-                             % ("rounded bf16" if bf else "fp16 (exact power-of-two scaling)"),
+                             "epilogue; " + ("ONE fp16 piece per operand (power-of-two scaled per staged tile), one product per "
+                                             "multiply-add: the throughput precision" if bf else
+                                             "operands split in two fp16 pieces (exact power-of-two scaling), 3 products per "
+                                             "multiply-add"),
                      "kernel_ms": c_avg, "kernel_ms_samples": len(r["cms"]), "flops_per_launch": r["conv_flops"],
-                     "mfma_products_per_mac": 3, "frac_of_split_operand_peak": 3 * c_tf / MFMA_BF16_PEAK_TFLOPS}
+                     "mfma_products_per_mac": 1 if bf else 3,
+                     "frac_of_split_operand_peak": (1 if bf else 3) * c_tf / MFMA_BF16_PEAK_TFLOPS}
     if ved:
-        # both precisions run the 2-D k3 convolutions on the 16x16x32 matrix-core instructions with split operands
-        # (pv_conv_sp.hip), three products per multiply-add: fp32-class = two fp16 pieces with exact power-of-two scaling per
-        # staged tile (~2^-22 per product), mixed = two rounded bf16 pieces (~2^-17)
+        # both precisions run the 2-D k3 convolutions on the 16x16x32 f16 matrix-core instruction (pv_conv_sp.hip): fp32-class =
+        # two fp16 pieces with exact power-of-two scaling per staged tile, three products (~2^-22 per product); throughput
+        # (round 4; SVItrainer(precision="bf16")) = ONE fp16 piece per operand, one product
         bf = fused == 3
-        out.update(dtype="bf16x3" if bf else "f16x3", path="conv-bf16x3" if bf else "conv-f16x3",
-                   arith=("2-D k3 convolutions on the bf16 MFMA, operands split into two rounded bf16 pieces, three products "
-                          "(fp32 accumulate); fp32 elsewhere" if bf else
+        out.update(dtype="f16" if bf else "f16x3", path="conv-f16" if bf else "conv-f16x3",
+                   arith=("2-D k3 convolutions on the f16 MFMA with ONE fp16 piece per operand (power-of-two scaled per staged "
+                          "tile), one product per multiply-add (fp32 accumulate); 1-D convolutions on the f32-input MFMA; fp32 "
+                          "elsewhere" if bf else
                           "2-D k3 convolutions on the f16 MFMA, operands split into two fp16 pieces with exact power-of-two scaling "
                           "per staged tile, three products (fp32 accumulate): fp32-class (3e-7 relative l2 vs float64); 1-D "
                           "convolutions on the f32-input MFMA; fp32 elsewhere"))

@@ -27,6 +27,12 @@ struct PvRange {
 };
 #define PV_RANGE(name) PvRange pv_range_guard__(name)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for `fn`, once per (device, function): the attribute is per device, and a process
+// may drive several (a process-wide "configured" flag left the second device's launches failing).  0 or a hipError_t.
+int pv_set_dynamic_lds(const void* fn, int bytes);   // pv_side.hip
+// the current device's LDS per workgroup (bytes; 0 when unknown)
+int pv_device_lds_limit();
+
 #define PV_TRY(expr)                           \
   do {                                         \
     int r__ = (expr);                          \

@@ -501,6 +501,8 @@ static bool build(D1Args& A, bool bwd, const float* params, const pv_op* ops, in
 
 bool pv_dec1d_supported(const pv_op* ops, int n, int nd, int L0, int C0) {
   if (nd != 1 || n < 1) return false;
+  const int lim = pv_device_lds_limit();               // (gfx950: 160 KB; another device falls back to the layer launches)
+  if (lim > 0 && lim < D1_LDS_MAX) return false;
   D1Args A;
   for (int bwd = 0; bwd < 2; ++bwd) {                  // a sample's activations (either direction) fit the LDS
     if (!build(A, bwd != 0, nullptr, ops, n, nullptr, 1, L0, C0, nullptr, nullptr, nullptr)) return false;
@@ -609,12 +611,7 @@ static int launch(D1Args& A, hipStream_t s) {
   const int64_t lds = lay_out(A, BWD) * (int64_t)sizeof(float);
   if (lds > D1_LDS_MAX) return PV_EINVAL;
   const void* fn = reinterpret_cast<const void*>(&pv_dec1d_kernel<BWD>);
-  static int64_t configured = 0;                       // (idempotent: a race between host threads only repeats the call)
-  if (configured < lds) {
-    const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, D1_LDS_MAX);
-    if (e1 != hipSuccess) return (int)e1;
-    configured = D1_LDS_MAX;
-  }
+  PV_TRY(pv_set_dynamic_lds(fn, D1_LDS_MAX));           // (per device)
   if (BWD) PV_LAUNCH_FORK(pv_dec1d_kernel<BWD>, dim3(d1_grid(A.B)), dim3(D1_THREADS), (size_t)lds, s, A);   // (the recorded weight gradients fork off this launch)
   else hipLaunchKernelGGL(pv_dec1d_kernel<BWD>, dim3(d1_grid(A.B)), dim3(D1_THREADS), (size_t)lds, s, A);
   PV_LAUNCH_CHECK();

@@ -517,16 +517,8 @@ int pv_sdec_fused_launch(const PvFused& f_in, int grid, bool grads, hipStream_t 
   if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }
   f.ablate = ablate;
   const size_t lds = FD_LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_sdec_fused_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_sdec_fused_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
-    attr_set = true;
-  }
+  PV_TRY(pv_set_dynamic_lds(reinterpret_cast<const void*>(&pv_sdec_fused_kernel<true>), (int)lds));
+  PV_TRY(pv_set_dynamic_lds(reinterpret_cast<const void*>(&pv_sdec_fused_kernel<false>), (int)lds));
   if (grads)
     hipLaunchKernelGGL(pv_sdec_fused_kernel<true>, dim3(grid), dim3(FD_THREADS), lds, s, f);
   else

@@ -1136,15 +1136,7 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3
 #undef FB_PICK
 #undef FB_PICK_P
   // (per device: a process may drive several; idempotent: a race between host threads only repeats the call)
-  static const void* configured[16][9 * 6] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const int slot = prec * 6 + (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
-  if (dev < 0 || dev >= 16 || configured[dev][slot] != fn) {
-    hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess) return (int)e1;
-    if (dev >= 0 && dev < 16) configured[dev][slot] = fn;
-  }
+  PV_TRY(pv_set_dynamic_lds(fn, (int)lds));          // (per device and kernel)
   void* args[] = {&f};
   hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(FB_THREADS), args, lds, s);
   if (e2 != hipSuccess) return (int)e2;

@@ -810,13 +810,7 @@ int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream
     else W8_PICK(false, PV_LIK_CBERNOULLI);
   }
 #undef W8_PICK
-  static const void* configured[6] = {};
-  const int slot = (grads ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
-  if (configured[slot] != fn) {                     // (idempotent: a race between host threads only repeats the call)
-    hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess) return (int)e1;
-    configured[slot] = fn;
-  }
+  PV_TRY(pv_set_dynamic_lds(fn, (int)lds));          // (per device and kernel)
   void* args[] = {&f};
   hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(W8_THREADS), args, lds, s);
   if (e2 != hipSuccess) return (int)e2;

@@ -776,15 +776,7 @@ int pv_sdec_fused_w8h_launch(const PvFused& f_in, int grid, bool ds, hipStream_t
   else if (f.lik == PV_LIK_GAUSSIAN) H8_PICK(PV_LIK_GAUSSIAN);
   else H8_PICK(PV_LIK_CBERNOULLI);
 #undef H8_PICK
-  static const void* configured[16][6] = {};           // per device (a process may drive several)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const int slot = (ds ? 3 : 0) + (f.lik == PV_LIK_BERNOULLI ? 0 : f.lik == PV_LIK_GAUSSIAN ? 1 : 2);
-  if (dev < 0 || dev >= 16 || configured[dev][slot] != fn) {
-    hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess) return (int)e1;
-    if (dev >= 0 && dev < 16) configured[dev][slot] = fn;
-  }
+  PV_TRY(pv_set_dynamic_lds(fn, (int)lds));          // (per device and kernel)
   void* args[] = {&f};
   hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(H8_THREADS), args, lds, s);
   if (e2 != hipSuccess) return (int)e2;

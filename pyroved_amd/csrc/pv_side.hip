@@ -136,6 +136,43 @@ void pv_range_pop() {
 // test hook: 1 when the marker library was found (after the first range)
 extern "C" int pv_debug_roctx_state() { pv_range_push("pv_debug_roctx_state"); pv_range_pop(); return g_roctx.load(); }
 
+// ---- dynamic-LDS opt-in per (device, kernel) ----
+namespace {
+struct LdsKey { const void* fn; int bytes; };
+LdsKey g_lds[kMaxDev][64];
+int g_lds_n[kMaxDev] = {};
+int g_lds_limit[kMaxDev] = {};
+}  // namespace
+int pv_set_dynamic_lds(const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+    (void)hipGetLastError();
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < g_lds_n[dev]; ++i)
+      if (g_lds[dev][i].fn == fn && g_lds[dev][i].bytes >= bytes) return 0;
+  }
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < g_lds_n[dev]; ++i)
+    if (g_lds[dev][i].fn == fn) { g_lds[dev][i].bytes = bytes; return 0; }
+  if (g_lds_n[dev] < 64) g_lds[dev][g_lds_n[dev]++] = LdsKey{fn, bytes};
+  return 0;
+}
+int pv_device_lds_limit() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return 0; }
+  if (g_lds_limit[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+    g_lds_limit[dev] = v > 0 ? v : -1;
+  }
+  return g_lds_limit[dev] > 0 ? g_lds_limit[dev] : 0;
+}
+
 int pv_stream_after(hipStream_t waiter, hipStream_t signaller) {
   if (waiter == signaller) return 0;
   Side* S = side_of_current_device();

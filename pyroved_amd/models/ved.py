@@ -105,8 +105,13 @@ class VED(baseVAE):
             # the 30 draws come from the CPU generator as in the reference; they are decoded in ONE call (rows are
             # independent) and reduced on the device: one host copy per batch instead of 30 decode + .cpu() round trips
             z_samples = torch.distributions.Normal(z_mu, z_sig).rsample(sample_shape=(30,))
-            y = eng.decode(z_samples.reshape(-1, z_samples.shape[-1]).to(eng.device))
-            y = y.reshape(30, z_mu.shape[0], *y.shape[1:])
+            if self.training and getattr(eng, "_bn_dec", None):
+                # batch norm in train mode (the reference's predict never calls eval()): statistics are per decode CALL and
+                # the running estimates move once per call — draw by draw, as models/ved.py:208-213 does
+                y = torch.stack([eng.decode(z_samples[i].to(eng.device)) for i in range(30)])
+            else:
+                y = eng.decode(z_samples.reshape(-1, z_samples.shape[-1]).to(eng.device))
+                y = y.reshape(30, z_mu.shape[0], *y.shape[1:])
             mus.append(y.mean(0).cpu())
             sds.append(y.std(0).cpu())
         return torch.cat(mus), torch.cat(sds)
