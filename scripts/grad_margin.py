@@ -1,0 +1,129 @@
+"""Per-tensor gradient margins of the BASELINE configs at their own (per-GPU) sizes.
+
+For C3 (jiVAE K=10, batch 512), C4 (conv-encoder iVAE 64x64, batch 128) and C5 (VED 64x64 -> 128, batch 256), both precisions of
+the HIP path, one loss_and_grads from the seeded initial parameters: per gradient tensor
+    err  = rel-L2 of the HIP gradient vs the FLOAT64 oracle,
+    e32  = rel-L2 of the fp32 CPU oracle vs the float64 oracle (the noise of the bar's own reference),
+    bar  = what tests/test_gpu_parity.py::test_full_size_c3/c4/c5_* assert (fp32-class: max(1e-4, 2 e32), C3: jiVAE's per-tensor
+           bars; throughput precision: 3e-2),
+    margin = bar / err.
+The tests keep the asserts; this script makes the margins visible.   python scripts/grad_margin.py > profiles/r04f_grad_margin.txt
+(C3's float64 backward holds ~25 GB of activations and takes a few minutes of CPU time.)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import pyroved_amd as pv  # noqa: E402
+from oracle import svi_oracle as orc  # noqa: E402
+from conftest import jivae_grad_tol, make_x  # noqa: E402
+
+torch.set_num_threads(int(os.environ.get("PV_THREADS", "16")))
+which = sys.argv[1:] or ["C4", "C5", "C3"]
+
+
+def rel(a, b):
+    return ((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item()
+
+
+def table(title, grads_by_mode, g32, g64, bar_of):
+    print("== " + title)
+    modes = list(grads_by_mode)
+    print("%-44s %9s" % ("tensor", "e32") + "".join("  %10s %9s %8s" % ("err " + m, "bar", "margin") for m in modes))
+    worst = {m: 1e30 for m in modes}
+    for k in g64:
+        e32 = rel(g32[k], g64[k])
+        line = "%-44s %9.1e" % (k, e32)
+        for m in modes:
+            err = rel(grads_by_mode[m][k], g64[k])
+            bar = bar_of(m, k, e32)
+            if bar is None:
+                line += "  %10.1e %9s %8s" % (err, "(abs)", "-")
+                continue
+            line += "  %10.1e %9.1e %8.1f" % (err, bar, bar / max(err, 1e-300))
+            worst[m] = min(worst[m], bar / max(err, 1e-300))
+        print(line)
+    print("%-44s %9s" % ("smallest margin", "") + "".join("  %10s %9s %8.1f" % ("", "", worst[m]) for m in modes))
+    print()
+
+
+def oracle_grads(loss_fn, sd, dtype):
+    p = {k: v.detach().cpu().clone().to(dtype).requires_grad_(True) if v.is_floating_point() else v.detach().cpu().clone()
+         for k, v in sd.items()}
+    loss_fn(p, dtype).backward()
+    return {k: v.grad for k, v in p.items() if v.is_floating_point() and v.grad is not None}
+
+
+if "C4" in which:
+    data_dim, inv, b = (64, 64), ["r", "t", "s"], 128
+    hid = [(32,), (64, 64), (128, 128)]
+    x = make_x("rand", b, data_dim)
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, conv_encoder=hid)
+    got = {}
+    for fused, name in ((2, "fp32-class"), (3, "throughput")):
+        model = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+        model.set_encoder(pv.nets.convEncoderNet(data_dim, latent_dim=model.z_dim))
+        if fused == 2:
+            torch.manual_seed(1)
+            eps = torch.empty(b, model.z_dim).normal_()
+            sd = {k: v.cpu() for k, v in model.state_dict().items()}
+            o32 = orc.SVIOracle(sd, cfg)
+        eng = model.engine(fused=fused)
+        eng.loss_and_grads(x.cuda(), eps.cuda())
+        got[name] = {k: eng.grad_of(k).clone() for k in o32.p}
+    o32.loss_and_grads(x, eps)
+    o64 = orc.SVIOracle(sd, cfg, dtype=torch.float64)
+    o64.loss_and_grads(x, eps)
+    table("C4: iVAE 64x64 ['r','t','s'] + convEncoderNet, batch 128 (0.52 M decoder rows)", got,
+          {k: v.grad for k, v in o32.p.items()}, {k: v.grad for k, v in o64.p.items()},
+          lambda m, k, e32: 3e-2 if m == "throughput" else max(1e-4, 2 * e32))
+
+if "C5" in which:
+    b = 256
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(b, 1, 64, 64, generator=g)
+    y = torch.rand(b, 1, 128, generator=g)
+    cfg = orc.VedConfig(input_dim=(64, 64), output_dim=(128,), latent_dim=2)
+    got = {}
+    for fused, name in ((2, "fp32-class"), (3, "throughput")):
+        model = pv.models.VED((64, 64), (128,), seed=1, device="cuda")
+        if fused == 2:
+            torch.manual_seed(1)
+            eps = torch.empty(b, model.z_dim).normal_()
+            sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        eng = model.engine(fused=fused)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+        keys = [k for k, v in model.named_parameters()]
+        got[name] = {k: eng.grad_of(k).clone() for k in keys}
+    gr = {dt: oracle_grads(lambda p, dt: orc.ved_elbo(p, cfg, x.to(dt), y.to(dt), eps.to(dt))["loss"], sd, dt)
+          for dt in (torch.float32, torch.float64)}
+    g64 = {k: gr[torch.float64][k] for k in got["fp32-class"]}
+    table("C5: VED 64x64 -> 128, batch 256", got, gr[torch.float32], g64,
+          lambda m, k, e32: 3e-2 if m == "throughput" else max(1e-4, 2 * e32))
+
+if "C3" in which:
+    data_dim, inv, k_, b = (28, 28), ["r"], 10, 512
+    x = make_x("rand", b, data_dim)
+    cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, discrete_dim=k_)
+    got = {}
+    for fused, name in ((2, "fp32-class"), (3, "throughput")):
+        model = pv.models.jiVAE(data_dim, 2, k_, inv, seed=1, device="cuda")
+        if fused == 2:
+            torch.manual_seed(1)
+            eps = torch.empty(b, model.z_dim).normal_()
+            sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        eng = model.engine(fused=fused)
+        eng.loss_and_grads(x.cuda(), eps.cuda())
+        o32 = orc.SVIOracle(sd, cfg) if fused == 2 else o32
+        got[name] = {k: eng.grad_of(k).clone() for k in o32.p}
+    o32.loss_and_grads(x, eps)
+    g32 = {k: v.grad.clone() for k, v in o32.p.items()}
+    del o32
+    o64 = orc.SVIOracle(sd, cfg, dtype=torch.float64)
+    o64.loss_and_grads(x, eps)
+    table("C3: jiVAE K=10, 28x28 ['r'], batch 512 (4.0 M decoder rows; the fp32-class path runs the one-piece fp16 build here)",
+          got, g32, {k: v.grad for k, v in o64.p.items()},
+          lambda m, k, e32: 3e-2 if m == "throughput" else jivae_grad_tol(k))
