@@ -92,12 +92,14 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define FB_P_H2A1 6              // dgrad of layer 2 with dL/dpre2 split (3 products), the rest as H221
 #define FB_P_H2B1 7              // dgrad of layer 1 with dL/dpre1 split
 #define FB_P_H231 8              // both dgrads with split dL/dpre
+#define FB_P_H131 9              // H231 whose FORWARD contracts the weights' hi piece only (experiment: is the forward's second product needed?)
 template <int P> struct FbP {
   static constexpr bool F16 = P >= 2;                          // fp16 pieces, normalised weights, per-row exponent
   static constexpr int WP = P == FB_P_BF16 ? 1 : 2;            // weight pieces (LDS images per layer)
   static constexpr bool FWD_LO = P == FB_P_X3 || P == FB_P_H321 || P == FB_P_H333;   // forward also contracts the activation's lo piece
-  static constexpr bool DGR2_LO = P == FB_P_X3 || P == FB_P_H333 || P == FB_P_H2A1 || P == FB_P_H231;   // dgrad of layer 2 also contracts dL/dpre2's lo piece
-  static constexpr bool DGR1_LO = P == FB_P_X3 || P == FB_P_H333 || P == FB_P_H2B1 || P == FB_P_H231;   // dgrad of layer 1: dL/dpre1's
+  static constexpr bool DGR2_LO = P == FB_P_X3 || P == FB_P_H333 || P == FB_P_H2A1 || P == FB_P_H231 || P == FB_P_H131;   // dgrad of layer 2 also contracts dL/dpre2's lo piece
+  static constexpr bool DGR1_LO = P == FB_P_X3 || P == FB_P_H333 || P == FB_P_H2B1 || P == FB_P_H231 || P == FB_P_H131;   // dgrad of layer 1: dL/dpre1's
+  static constexpr bool FWD_WLO = WP == 2 && P != FB_P_H131;   // the forward contracts the weights' lo piece
   static constexpr bool WG3 = P == FB_P_X3 || P == FB_P_H223 || P == FB_P_H333;      // wgrad: both operands split, three products
   static constexpr bool HL = FWD_LO || WG3;                    // activations carry a lo piece
   static constexpr bool DL2 = DGR2_LO || WG3;                  // dL/dpre2 / dL/dpre1 carry a lo piece
@@ -204,7 +206,7 @@ template <int P>
 __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
                                              const float* __restrict__ bs, const bf16x4 (&ih)[8],
                                              const bf16x4 (&il)[8], f32x4 (&out)[8], int r, int q) {
-  constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::WP == 2, AL = FbP<P>::FWD_LO;
+  constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::FWD_WLO, AL = FbP<P>::FWD_LO;
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
   // row 16*ob + r, logical chunk 4m + q  ->  physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])
@@ -1037,7 +1039,7 @@ static bool fb_kind_here(int kind) { return kind == 0 || (kind > 8 && kind < 40)
 static bool fb_kind_w8h(int kind) { return kind == 41 || kind == 48; }   // pv_sdec_fused_w8h.hip: H221 / H231 arithmetic, 8 waves
 static int fb_kind_prec(int kind) {
   return kind == 21 ? FB_P_H221 : kind == 23 ? FB_P_H223 : kind == 31 ? FB_P_H321 : kind == 33 ? FB_P_H333
-       : kind == 26 ? FB_P_H2A1 : kind == 27 ? FB_P_H2B1 : kind == 28 ? FB_P_H231 : FB_P_X3;
+       : kind == 26 ? FB_P_H2A1 : kind == 27 ? FB_P_H2B1 : kind == 28 ? FB_P_H231 : kind == 29 ? FB_P_H131 : FB_P_X3;
 }
 int pv_sdec_fused_bf16_waves(bool x3, int64_t units) {
   const int kind = x3 ? fb_x3_kind(units, true) : 0;
@@ -1123,6 +1125,7 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3
       else if (prec == FB_P_H333) FB_PICK_P(true, PV_LIK_BERNOULLI, FB_P_H333);
       else if (prec == FB_P_H2A1) FB_PICK_P(true, PV_LIK_BERNOULLI, FB_P_H2A1);
       else if (prec == FB_P_H2B1) FB_PICK_P(true, PV_LIK_BERNOULLI, FB_P_H2B1);
+      else if (prec == FB_P_H131) FB_PICK_P(true, PV_LIK_BERNOULLI, FB_P_H131);
 #endif
     }
     else if (f.lik == PV_LIK_GAUSSIAN) FB_PICK_G(PV_LIK_GAUSSIAN);
