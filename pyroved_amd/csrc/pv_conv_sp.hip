@@ -29,7 +29,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 shf8 __attribute__((ext_vector_type(8)));
 typedef __fp16 shp2 __attribute__((ext_vector_type(2)));
 #ifndef SP_EXP
-#define SP_EXP 0                 // timing experiments (wrong results): 1 no MFMAs, 2 no weight re-staging, 4 no patch re-staging
+#define SP_EXP 0                 // timing experiments (wrong results): 1 no MFMAs, 2 no weight re-staging, 4 no patch re-staging, 8 no operand split
 #endif
 #if SP_EXP & 1
 #define SP_MFMA(a, b, c) (c)
@@ -92,6 +92,11 @@ template <int NS> __device__ __forceinline__ void sp_split4(const f32x4& v, u32x
 
 // four fp32 (times the exact scale sc) -> two planes of four fp16: a0 = rtz(v sc), a1 = rtz(v sc - a0)
 __device__ __forceinline__ void sp_split4_f16(const f32x4& v, float sc, u32x2 (&pl)[2]) {
+#if SP_EXP & 8                   // (timing: operands that arrive split — no VALU work)
+  pl[0] = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])};
+  pl[1] = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])};
+  return;
+#endif
   const f32x4 t = v * sc;
   const shp2 h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]), h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
   const shp2 l01 = __builtin_amdgcn_cvt_pkrtz(t[0] - (float)h01[0], t[1] - (float)h01[1]);
@@ -393,6 +398,7 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
   SP_W_FETCH(0);
   int E_cur = 0, E_min = 1 << 20;                     // F16: the patch scale 2^E of the current chunk, the smallest so far
   auto wave_max = [&](int slot) {                     // max |pre| of this wave -> smax[slot][wave]
+    if (SP_EXP & 8) return;
     float m = 0.0f;
 #pragma unroll
     for (int k = 0; k < PK; ++k)
@@ -806,6 +812,18 @@ template <int NCIB> struct SwGeo {
 #ifndef SW_BUF
 #define SW_BUF 1
 #endif
+// phase-timing trace (profiling builds only: -DSW_TRACE, scripts/gpu_trace_sw.py): shader-clock sums of the middle split's
+// first owner, thread 0
+#ifdef SW_TRACE
+__device__ long long sw_trace[16];
+#define SW_STAMP(k) do { if (tr_on) { const long long c_ = (long long)__builtin_readcyclecounter(); tr_sum[(k)] += c_ - tr_prev; tr_prev = c_; } } while (0)
+extern "C" int pv_debug_read_trace_sw(long long* out, int n) {
+  if (n > 16) n = 16;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_trace), n * sizeof(long long));
+}
+#else
+#define SW_STAMP(k) do { } while (0)
+#endif
 template <int NS, int NCIB, bool F16 = false>
 __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x, const int bid_y, const int bid_z, char* smem) {
   static_assert(F16 ? ((NS == 2 || NS == 1) && NCIB == 1) : NS >= 2, "the fp16 modes: two pieces or one, 32-channel workgroups (next-tile prefetch)");
@@ -925,6 +943,7 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
   if (PRE && t_lo < t_hi) fetch();
   int Ed = 0, Ep = 0, Ed_min = 1 << 20, Et_min = 1 << 20;           // F16: current exponents, smallest so far (dY, dY + patch)
   auto wave_max = [&](int slot) {                    // this wave's max |dY piece| and |patch piece| of the fetched tile
+    if (SP_EXP & 8) return;
     float md = 0.0f, mp = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -941,8 +960,14 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
   };
   if constexpr (F16) { if (t_lo < t_hi) wave_max(0); }
   int par = 0;
+#ifdef SW_TRACE
+  const bool tr_on = tid == 0 && split == p.nsplit / 2 && cit == 0 && cot == 0;
+  long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = (long long)__builtin_readcyclecounter();
+  const long long tr_t0 = tr_prev;
+#endif
   for (int64_t tt = t_lo; tt < t_hi; ++tt) {
     __syncthreads();                                 // the previous tile's fragment reads are done (F16: smx is in)
+    SW_STAMP(0);
     if (!PRE) fetch();
     float scd = 1.0f, scp = 1.0f;
     if constexpr (F16) {
@@ -992,8 +1017,11 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
         for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(patch + j * PPLANE + p_lds[k]) = pl[j];
       }
     }
+    SW_STAMP(1);
     __syncthreads();
+    SW_STAMP(2);
     if (PRE && tt + 1 < t_hi) fetch();
+    SW_STAMP(3);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                 // 32 pixels: lane group q <-> tile line 4 ks + q, k slot i <-> x = i
       sbf8 a[2][NS];
@@ -1035,10 +1063,19 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
         }
       }
     }
+    SW_STAMP(4);
     if constexpr (F16) {
       if (tt + 1 < t_hi) wave_max(par);              // (the next tile's pieces arrived under the MFMAs)
     }
+    SW_STAMP(5);
   }
+#ifdef SW_TRACE
+  if (tr_on) {
+    for (int k = 0; k < 6; ++k) sw_trace[k] = tr_sum[k];
+    sw_trace[6] = (long long)(t_hi - t_lo);
+    sw_trace[7] = (long long)__builtin_readcyclecounter() - tr_t0;
+  }
+#endif
   if constexpr (F16) {                               // back to true units
     const float inv = sp_pow2(-(Ed + Ep)), invb = sp_pow2(-Ed);
 #pragma unroll
