@@ -325,6 +325,17 @@ int pv_conv_wprep_table(PvWprepEntry* e, int n, hipStream_t s, const PvFbPrep* f
   return 0;
 }
 
+// phase-timing trace (profiling builds only: -DSP_TRACE, scripts/gpu_trace_sw.py fwd): shader-clock stamps of a middle workgroup
+#ifdef SP_TRACE
+__device__ long long sp_trace[16];
+#define SP_STAMP(k) do { if (tr_on) { const long long c_ = (long long)__builtin_readcyclecounter(); tr_sum[(k)] += c_ - tr_prev; tr_prev = c_; } } while (0)
+extern "C" int pv_debug_read_trace_sp(long long* out, int n) {
+  if (n > 16) n = 16;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_trace), n * sizeof(long long));
+}
+#else
+#define SP_STAMP(k) do { } while (0)
+#endif
 template <int NS, int NCB, bool F16 = false>
 __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, const int bid_y, char* smem) {
   static_assert(F16 ? (NS == 2 || NS == 1) : NS >= 2, "the fp16 modes have two pieces (fp32-class) or one (throughput)");
@@ -336,6 +347,11 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
   char* wl = smem + NS * SP_PPLANE;                   // [TG][NS][64][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int wy = wave >> 1, wx = wave & 1;
+#ifdef SP_TRACE
+  const bool tr_on = threadIdx.x == 0 && bid_x == (int)(gridDim.x / 2) && bid_y == 0;
+  long long tr_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = (long long)__builtin_readcyclecounter();
+  const long long tr_t0 = tr_prev;
+#endif
   int t = bid_x;
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
@@ -410,8 +426,10 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
     __threadfence_block();                            // (landed before the next barrier: see pv_conv3_direct_bf16_kernel)
   };
   if constexpr (F16) wave_max(0);
+  SP_STAMP(0);                                        // prologue: addresses, first patch + weight requests, wave max (= first data)
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();                                  // the previous chunk's fragment reads are done (F16: smax is in)
+    SP_STAMP(1);
     float psc = 1.0f;
     if constexpr (F16) {
       const float m = fmaxf(fmaxf(smax[ch & 1][0], smax[ch & 1][1]), fmaxf(smax[ch & 1][2], smax[ch & 1][3]));
@@ -446,7 +464,9 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
       }
     }
     SP_W_STORE();
+    SP_STAMP(2);
     __syncthreads();
+    SP_STAMP(3);
     if (ch + 1 < nch) {
 #pragma unroll
       for (int k = 0; k < PK; ++k)
@@ -504,9 +524,11 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
         __syncthreads();
       }
     }
+    SP_STAMP(4);
     if constexpr (F16) {
       if (ch + 1 < nch) wave_max((ch + 1) & 1);       // (the next chunk's values arrived under the MFMAs)
     }
+    SP_STAMP(5);
   }
   if constexpr (F16) {                                // back to true units
     const float inv = sp_pow2(-(E_cur + SP_F16_WSHIFT));
@@ -643,6 +665,14 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
       }
     }
   }
+#ifdef SP_TRACE
+  SP_STAMP(6);
+  if (tr_on) {
+    for (int k = 0; k < 7; ++k) sp_trace[k] = tr_sum[k];
+    sp_trace[7] = (long long)nch;
+    sp_trace[8] = (long long)__builtin_readcyclecounter() - tr_t0;
+  }
+#endif
 }
 
 template <int NS, int NCB, bool F16 = false>

@@ -947,8 +947,11 @@ __global__ __launch_bounds__(256) void pv_latent_bwd_reduce_kernel(PvLatentBwd p
                                                                    int G_, float* __restrict__ Gr, PvFusedOffsets o,
                                                                    int cd) {
   __shared__ f32x4 smr[4][64];
-  if ((int)blockIdx.x < PV_FUSED_REDUCE_BLOCKS) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, blockIdx.x, smr);
-  else pv_latent_bwd_block(p, blockIdx.x - PV_FUSED_REDUCE_BLOCKS);
+#ifndef LB_EXP
+#define LB_EXP 0                 // timing experiments (wrong results): 1 no record sums, 2 no latent backward
+#endif
+  if ((int)blockIdx.x < PV_FUSED_REDUCE_BLOCKS) { if (!(LB_EXP & 1)) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, blockIdx.x, smr); }
+  else if (!(LB_EXP & 2)) pv_latent_bwd_block(p, blockIdx.x - PV_FUSED_REDUCE_BLOCKS);
 }
 
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
