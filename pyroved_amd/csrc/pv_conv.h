@@ -118,6 +118,7 @@ int pv_convhead_fwd_partials(const float* a, const float* wt, int B, int64_t F, 
                              const float** part, int* nseg);
 int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act, float* g, int B, int64_t F, int out,
                     hipStream_t s);
+bool pv_convhead_wgrad_uses_ws();
 int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, void* ws,
                       int64_t ws_bytes, hipStream_t s);
 // latent_to_features (Linear z -> C*S, viewed channels-first) producing / consuming channels-last maps directly; wt: kind 7 of

@@ -167,6 +167,9 @@ int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act
   return 0;
 }
 
+// does pv_convhead_wgrad use the caller's workspace (the streaming form)?  Then it must stay on the stream that owns it.
+bool pv_convhead_wgrad_uses_ws() { return !ch_use_mfma(); }
+
 int pv_convhead_wgrad(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, void* ws,
                       int64_t ws_bytes, hipStream_t s) {
   const int64_t F = (int64_t)S * C;

@@ -612,8 +612,8 @@ static int launch(D1Args& A, hipStream_t s) {
   if (lds > D1_LDS_MAX) return PV_EINVAL;
   const void* fn = reinterpret_cast<const void*>(&pv_dec1d_kernel<BWD>);
   PV_TRY(pv_set_dynamic_lds(fn, D1_LDS_MAX));           // (per device)
-  if (BWD) PV_LAUNCH_FORK(pv_dec1d_kernel<BWD>, dim3(d1_grid(A.B)), dim3(D1_THREADS), (size_t)lds, s, A);   // (the recorded weight gradients fork off this launch)
-  else hipLaunchKernelGGL(pv_dec1d_kernel<BWD>, dim3(d1_grid(A.B)), dim3(D1_THREADS), (size_t)lds, s, A);
+  // (backward: the recorded weight gradients fork off this launch; forward: the step's loss scalars, when the caller armed an event)
+  PV_LAUNCH_FORK(pv_dec1d_kernel<BWD>, dim3(d1_grid(A.B)), dim3(D1_THREADS), (size_t)lds, s, A);
   PV_LAUNCH_CHECK();
   return 0;
 }

@@ -8,6 +8,7 @@
 // Reductions are tree/ordered (no float atomics): results are bit-reproducible run to run.
 #include "pv_common.h"
 #include "pv_kernels.h"
+#include "pv_side.h"
 #include "pv_sdec_fused.h"
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
@@ -79,7 +80,88 @@ __global__ __launch_bounds__(256) void pv_head_fwd_kernel(PvHead h) {
 }
 
 int pv_head_fwd(const PvHead& h, hipStream_t s) {
+  if (h.ch_part || h.hz || h.kl_part) return PV_EINVAL;   // (pv_head_fwd_blocks's fields)
   hipLaunchKernelGGL(pv_head_fwd_kernel, dim3(1), dim3(256), 0, s, h);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same per-sample work 16 samples per workgroup, with what stands before and after it on a conv encoder's path in the same
+// launch: the conv head's partial sums (pv_convhead_fwd_finish_kernel's order), then head_fwd, then fc_latent
+// (pv_smallk_linear_kernel's sum).  The KL sums leave as per-workgroup partials (kl_part), like the compact encoder's.
+#define HB_ROWS 16
+__global__ __launch_bounds__(256) void pv_head_fwd_blocks_kernel(PvHead h) {
+  __shared__ float sm[16];
+  const int b0 = (int)blockIdx.x * HB_ROWS, nb = min(HB_ROWS, h.B - b0), t = threadIdx.x;
+  const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
+  if (h.ch_part) {
+    for (int e = t; e < nb * h.ch_out; e += 256) {
+      const int b = b0 + e / h.ch_out, j = e % h.ch_out;
+      float v = h.ch_bias ? h.ch_bias[j] : 0.0f;
+      for (int k = 0; k < h.ch_nseg; ++k) v += h.ch_part[((int64_t)b * h.ch_nseg + k) * h.ch_out + j];
+      h.head_w[(int64_t)b * h.ch_out + j] = v;
+    }
+    __syncthreads();
+  }
+  float lp = 0.0f, lq = 0.0f;
+  for (int el = t; el < nb * h.z_dim; el += 256) {
+    const int b = b0 + el / h.z_dim, i = el % h.z_dim;
+    const int64_t e = (int64_t)b * h.z_dim + i;
+    const float mu = h.head[(int64_t)b * ldh + i];
+    const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
+    const float sig = h.scale_direct ? sp : pv_softplus(sp);
+    const float z = mu + sig * h.eps[e];
+    h.z[e] = z;
+    h.z_scale[e] = sig;
+    if (h.z_loc_out) h.z_loc_out[e] = mu;
+    if (h.z_scale_out) h.z_scale_out[e] = sig;
+    const float d = z - mu;
+    const float wb = h.w ? h.w[b] : 1.0f;
+    lq += wb * (-(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI);
+    lp += wb * (-(z * z) / 2.0f - LOG_SQRT_2PI);
+  }
+  lp = pv_block_sum(lp, sm);
+  lq = pv_block_sum(lq, sm);
+  if (t == 0) { h.kl_part[2 * blockIdx.x] = h.beta * lp; h.kl_part[2 * blockIdx.x + 1] = h.beta * lq; }
+  __syncthreads();
+  if (t < nb) {
+    const int b = b0 + t;
+    const float* zb = h.z + (int64_t)b * h.z_dim;
+    int idx = 0;
+    float c = 1.0f, s = 0.0f, sc = 1.0f, tx = 0.0f, ty = 0.0f;
+    if (h.coord_dim == 1) {
+      if (h.has_t) { tx = zb[0] * h.tp0; idx = 1; }
+    } else if (h.coord_dim == 2) {
+      if (h.has_r) { const float phi = zb[idx++]; c = cosf(phi); s = sinf(phi); }
+      if (h.has_t) { tx = zb[idx] * h.tp0; ty = zb[idx + 1] * h.tp1; idx += 2; }
+      if (h.has_s) { sc = 1.0f + h.sc_prior * zb[idx++]; }
+    }
+    if (h.tp) {
+      float* tpb = h.tp + (int64_t)b * 8;
+      tpb[0] = c; tpb[1] = s; tpb[2] = sc; tpb[3] = tx; tpb[4] = ty;
+    }
+    if (h.zy) {
+      const int L = h.z_dim - idx;
+      float* o = h.zy + (int64_t)b * (L + h.c_dim);
+      for (int i = 0; i < L; ++i) o[i] = zb[idx + i];
+      for (int i = 0; i < h.c_dim; ++i) o[L + i] = h.y[(int64_t)b * h.c_dim + i];
+    }
+  }
+  if (h.hz) {
+    __syncthreads();
+    for (int e = t; e < nb * h.H; e += 256) {
+      const int b = b0 + e / h.H, j = e % h.H;
+      float v = 0.0f;
+      for (int k = 0; k < h.lat_in; ++k) v = fmaf(h.zin[(int64_t)b * h.ldz + k], h.Wz[(int64_t)j * h.lat_in + k], v);
+      h.hz[(int64_t)b * h.H + j] = v;
+    }
+  }
+}
+
+int pv_head_fwd_blocks(const PvHead& h, hipStream_t s) {
+  if (!h.kl_part || h.B < 1 || (h.ch_part && (!h.head_w || h.ch_out != (h.ldh > 0 ? h.ldh : 2 * h.z_dim))) ||
+      (h.hz && (h.lat_in < 1 || h.lat_in > 16))) return PV_EINVAL;
+  hipLaunchKernelGGL(pv_head_fwd_blocks_kernel, dim3((unsigned)((h.B + HB_ROWS - 1) / HB_ROWS)), dim3(256), 0, s, h);
   PV_LAUNCH_CHECK();
   return 0;
 }
@@ -957,8 +1039,8 @@ __global__ __launch_bounds__(256) void pv_latent_bwd_reduce_kernel(PvLatentBwd p
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
                          hipStream_t s) {
   if (p.H > 512 || p.lat_in > 64 + (p.K > 0 ? p.K : 0) || p.hb.z_dim > 256 || p.K > 128) return PV_EINVAL;
-  hipLaunchKernelGGL(pv_latent_bwd_reduce_kernel, dim3(PV_FUSED_REDUCE_BLOCKS + p.hb.B), dim3(256), 0, s, p, part, grid,
-                     G, o, cd);
+  // (a conv encoder's head weight gradient forks off this launch onto the side stream: it carries the fork event when one is armed)
+  PV_LAUNCH_FORK(pv_latent_bwd_reduce_kernel, dim3(PV_FUSED_REDUCE_BLOCKS + p.hb.B), dim3(256), 0, s, p, part, grid, G, o, cd);
   PV_LAUNCH_CHECK();
   return 0;
 }

@@ -19,8 +19,16 @@ struct PvHead {
   int ldh;               // row stride of head (0: 2*z_dim)
   int scale_direct;      // 1: the second half of head IS z_scale (external encoder), not its softplus input
   const float* w;        // (B) per-sample weights of the KL sums (plan->row_w) or null
+  // pv_head_fwd_blocks only (a conv encoder's tail as ONE launch of ceil(B / 16) workgroups, 16 samples each):
+  //   ch_part != null: head[b][j] = ch_bias[j] + sum_seg ch_part[b][seg][j] first (pv_convhead_fwd_partials; ldh == ch_out), into head_w
+  //   hz != null: hz[b][j] = sum_k zin[b * ldz + k] Wz[j * lat_in + k] last (fc_latent of the spatial decoder, lat_in <= 16)
+  //   kl_part: (blocks, 2) partial sums of beta log p(z), beta log q(z|x) instead of scalars[2], [3] (pv_finish_scalars sums them)
+  const float* ch_part; const float* ch_bias; float* head_w; int ch_nseg, ch_out;
+  const float* zin; const float* Wz; float* hz; int64_t ldz; int lat_in, H;
+  float* kl_part;
 };
 int pv_head_fwd(const PvHead& h, hipStream_t s);
+int pv_head_fwd_blocks(const PvHead& h, hipStream_t s);
 int pv_fill_tp(float* tp, int B, float angle, float sc, float tx, float ty, hipStream_t s);
 int pv_concat(const float* a, int64_t lda, int na, const float* y, int64_t ldy, int nb, float* out, int64_t B,
               hipStream_t s);

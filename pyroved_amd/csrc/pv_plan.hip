@@ -333,7 +333,9 @@ namespace {
 
 // convolutional encoder: x viewed as (B, 1, *enc_in_dim) -> op sequence -> flatten (C, spatial) -> L.head
 // prep != null: the spatial decoder's weight images are written by the same tiling launch (pv_conv_wprep_table)
-int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr) {
+// hp != null: the caller's next launch (pv_head_fwd) sums the conv head's partial sums itself — *hp is filled when that form ran
+struct PvHeadPart { const float* part = nullptr; const float* bias = nullptr; int nseg = 0, out = 0; };
+int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr, PvHeadPart* hp = nullptr) {
   const int64_t B = p->batch;
   if (L.cF < 0 || p->head.in_dim != L.cF) return PV_EINVAL;
   float* a[PV_MAX_OPS + 1];
@@ -368,6 +370,15 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, cons
   PV_TRY(pvcs::stack_fwd(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, sc, s));
   if (wt_join) { wt_join = false; PV_TRY(pv_stream_after(s, side)); }
   const pvcs::Shape& fe = L.ces[p->n_enc_ops];
+  if (hfused && hp) {
+    const float* part = nullptr;
+    int nseg = 0;
+    if (pv_convhead_fwd_partials(L.cea[p->n_enc_ops], L.chead_wt, (int)B, L.cF, p->head.out_dim, L.scratch, L.scratch_bytes, s, &part,
+                                 &nseg) == 0) {
+      hp->part = part; hp->bias = p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr; hp->nseg = nseg; hp->out = p->head.out_dim;
+      return 0;
+    }
+  }
   if (hfused)      // (the weight is re-indexed channels-last, not the feature map: pv_convhead.hip)
     return pv_convhead_fwd(L.cea[p->n_enc_ops], L.chead_wt, p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr, L.head,
                            (int)B, L.cF, p->head.out_dim, L.scratch, L.scratch_bytes, s);
@@ -376,8 +387,8 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, cons
                     L.head, nullptr, p->head.out_dim, B, L.cF, p->head.out_dim, PV_ACT_NONE, L.scratch, L.scratch_bytes, s);
 }
 
-int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr) {
-  if (L.enc_conv) return conv_encoder_fwd(p, L, s, prep);
+int encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr, PvHeadPart* hp = nullptr) {
+  if (L.enc_conv) return conv_encoder_fwd(p, L, s, prep, hp);
   const int64_t B = p->batch;
   const float* in = p->x;
   int64_t ldin = p->n_pix;
@@ -464,7 +475,7 @@ typedef PvFinishArgs PvFinish;
 // in the weight-gradient launch
 int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, hipStream_t s,
                 const PvFinish* fin = nullptr, const PvAdamFuse* adam = nullptr, bool* adam_done = nullptr,
-                bool dgrad_done = false) {
+                bool dgrad_done = false, bool head_side = false) {
   const int64_t B = p->batch;
   float* G = p->grads;
   void* ws = L.scratch;
@@ -481,12 +492,19 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     const pvcs::Shape& fe = L.ces[p->n_enc_ops];
     const pv_op& last = p->enc_ops[p->n_enc_ops - 1];
     bool g_is_pre = false;
+    hipStream_t side = pv_side_stream_for(s, p->flags);
+    PvSideJoin sj;                                    // joins the side stream on an early return
     if (pv_convhead_supported(L.cF, hd.out_dim) && L.chead_wt) {
       // dL/d(features) straight in channels-last order into cg[1], the last convolution's activation derivative folded in
       g_is_pre = last.kind == PV_OP_CONV && last.act != PV_ACT_GELU;
+      // the head's weight gradient needs dhead only: on the side stream (forked off the launch that wrote dhead) next to the
+      // input gradient below
+      hipStream_t hs = s;
+      if (head_side && side) { PV_TRY(pv_fork_to(side, s)); sj.fork(s, side); hs = side; }
+      else pv_fork_disarm();
       PV_TRY(pv_convhead_wgrad(L.dhead, L.cea[p->n_enc_ops], G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, (int)B,
-                               fe.H * fe.W, fe.C, hd.out_dim, ws, wsb, s));
-      if (pv_side_stream_for(s, p->flags)) pv_fork_arm();             // (the last convolution's weight gradient forks off this launch)
+                               fe.H * fe.W, fe.C, hd.out_dim, ws, wsb, hs));
+      if (side) pv_fork_arm();                                        // (the last convolution's weight gradient forks off this launch)
       PV_TRY(pv_convhead_bwd(L.dhead, L.chead_wt, L.cea[p->n_enc_ops], g_is_pre ? last.act : PV_ACT_NONE, L.cg[1], (int)B, L.cF,
                              hd.out_dim, s));
     } else {
@@ -508,9 +526,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     int pp = 0;                                       // g = cg[1]; first free ping-pong buffer = cg[0]
     // kernel-3 weight gradients on the side stream, the input-gradient chain on s (every op's gradient in its own buffer);
     // joined before the finish
-    hipStream_t side = pv_side_stream_for(s, p->flags);
     bool joined = false;
-    PvSideJoin sj;                                    // joins the side stream on an early return
     sj.fork(s, side);
     sc.side = side; sc.side_joined = &joined;
     PV_TRY(pvcs::stack_bwd(p->params, G, p->enc_ops, p->n_enc_ops, p->enc_ndim, (int)B, a, L.ces, L.cg[1], L.cg, pp, false,
@@ -518,8 +534,9 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     if (side && !joined) PV_TRY(pv_stream_after(s, side));
     sj.joined();
     PV_TRY(pv_wgrad_finish_all(&wfin, s));
-    if (fin) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
-    for (int i = 0; i < n_extra; i += 4) PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s));
+    if (fin && n_extra < 1) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
+    for (int i = 0; i < n_extra; i += 4)             // (the loss scalars ride in the first of these launches)
+      PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s, nullptr, i == 0 ? fin : nullptr));
     return 0;
   }
   const float* elast = L.eact[ne - 1];
@@ -632,8 +649,11 @@ int latent_encoder_bwd(const pv_ivae_plan* p, const Layout& L, int64_t lat_in, i
 }
 
 // guide: encoder -> (z_loc, z_scale) -> z = z_loc + z_scale*eps, sampled-KL terms, transform parameters
+// hzr != null (not the compact encoder): fc_latent of the spatial decoder may ride in the head launch — hzr->done says whether it did
+// (kl: the KL sums of scalars[2], [3] left as partials in L.kl_part: pass them to pv_finish_scalars)
+struct PvHzReq { const float* zin; int64_t ldz; int lat_in, H; const float* Wz; float* hz; bool done, kl; };
 int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbPrep* prep = nullptr,
-              float hz_scale = 0.0f) {
+              float hz_scale = 0.0f, PvHzReq* hzr = nullptr) {
   if (L.enc_compact) {
     PvEncFwd e{};
     if (prep) e.prep = *prep;
@@ -659,8 +679,21 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     return pv_enc_fwd(e, s);
   }
   if (prep && !L.enc_conv) return PV_EINVAL;      // (stand-alone preparation on this path)
-  if (!L.enc_ext) PV_TRY(encoder_fwd(p, L, s, prep));
+  // a conv encoder in front of the spatial decoder (hzr): the conv head's partial sums, this head and fc_latent in ONE launch of
+  // ceil(B / 16) workgroups (PV_HEAD_MERGE=0: the four launches)
+  static const int ab_merge = getenv("PV_HEAD_MERGE") ? atoi(getenv("PV_HEAD_MERGE")) : 1;
+  const bool blocks = ab_merge && hzr && L.enc_conv && !L.enc_ext && plan_K(p) == 0 && p->head.out_dim == (int)plan_head_w(p);
+  PvHeadPart hp;
+  if (!L.enc_ext) PV_TRY(encoder_fwd(p, L, s, prep, blocks ? &hp : nullptr));
   PvHead h{};
+  if (hp.part) { h.ch_part = hp.part; h.ch_bias = hp.bias; h.ch_nseg = hp.nseg; h.ch_out = hp.out; h.head_w = L.head; }
+  if (blocks) {
+    h.kl_part = L.kl_part; hzr->kl = true;
+    if (hzr->lat_in <= 16) {
+      h.zin = hzr->zin; h.ldz = hzr->ldz; h.lat_in = hzr->lat_in; h.H = hzr->H; h.Wz = hzr->Wz; h.hz = hzr->hz;
+      hzr->done = true;
+    }
+  }
   h.head = L.enc_ext ? p->ext_head : L.head; h.scale_direct = L.enc_ext ? 1 : 0; h.eps = p->eps; h.y = p->y; h.z = L.z; h.z_scale = L.z_scale;
   h.z_loc_out = p->z_loc; h.z_scale_out = p->z_scale;
   h.tp = p->coord_dim > 0 ? L.tp : nullptr; h.zy = L.zy; h.scalars = p->scalars;
@@ -671,7 +704,8 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
   h.ldh = L.enc_ext ? 0 : (int)plan_head_w(p);
   const int64_t K = plan_K(p);
   if (K > 0) h.zy = nullptr;                      // (written per decoder sample below)
-  PV_TRY(pv_head_fwd(h, s));
+  if (blocks) PV_TRY(pv_head_fwd_blocks(h, s));
+  else PV_TRY(pv_head_fwd(h, s));
   if (K > 0) {
     const int coord = p->z_dim - p->latent_dim;
     const int n_content = p->coord_dim > 0 ? p->latent_dim : p->z_dim;
@@ -715,6 +749,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     (void)frexpf(p->decoder_sig * p->decoder_sig, &e2);      // sig^2 = m 2^e2, m in [0.5, 1)
     f.dl_exp = e2 < -40 ? -40 : (e2 > 40 ? 40 : e2);
   }
+  PvHzReq hzr{zin, ldz, (int)lat_in, H, p->params + p->fc_latent.w_off, L.hz, false, false};
   // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
   if (p->fused >= 2 && L.enc_compact) {
     const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0, p->fused == 2);
@@ -724,7 +759,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     // conv encoder: the decoder's weight images ride in its weight-tiling launch; generic encoders: a launch of their own
     const bool prep_in_enc = p->fused >= 2 && L.enc_conv;
     const PvFbPrep prep = p->fused >= 2 ? pv_sdec_fused_bf16_prep_args(f, want_grads != 0, p->fused == 2) : PvFbPrep{};
-    PV_TRY(guide_fwd(p, L, s, prep_in_enc ? &prep : nullptr));
+    PV_TRY(guide_fwd(p, L, s, prep_in_enc ? &prep : nullptr, 0.0f, &hzr));
     if (p->fused >= 2 && !prep_in_enc) {
       PV_TRY(pv_sdec_fused_bf16_prep(f, want_grads != 0, p->fused == 2, s));
     } else if (p->fused >= 2) {
@@ -734,7 +769,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
       if (e != hipSuccess) return (int)e;
     }
   }
-  if (!L.enc_compact) {
+  if (!L.enc_compact && !hzr.done) {
     if (lat_in <= 16) PV_TRY(pv_smallk_linear(zin, ldz, p->params + p->fc_latent.w_off, L.hz, B, (int)lat_in, (int)H, s));
     else PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
                            L.scratch, L.scratch_bytes, s));
@@ -753,7 +788,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   if (!want_grads) {
     PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
     PV_TRY(weigh_llb(p, L, s));
-    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
+    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
     return extra_outputs(p, L, nullptr, lat_in, s);
   }
   PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
@@ -781,14 +816,21 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     lb.enc_n = p->n_enc; lb.enc_params = p->params; lb.enc_head = p->head;
     for (int i = 0; i < p->n_enc; ++i) { lb.enc_l[i] = p->enc[i]; lb.enc_act[i] = L.eact[i]; lb.enc_dp[i] = L.edp[i]; }
   }
+  // conv encoder with a side stream: the head's weight gradient forks off this launch (encoder_bwd)
+  static const int ab_side = getenv("PV_HEAD_SIDE") ? atoi(getenv("PV_HEAD_SIDE")) : 1;
+  static const int ab_fin = getenv("PV_FIN_RIDE") ? atoi(getenv("PV_FIN_RIDE")) : 1;
+  const bool head_side = ab_side && L.enc_conv && !L.enc_ext && pv_side_stream_for(s, p->flags) && !pv_convhead_wgrad_uses_ws() &&
+                         pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
+  if (head_side) pv_fork_arm();
   PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s));
-  // the loss scalars ride in the encoder dgrad launch (compact encoder) or get their own
-  PvFinish fin{L.llb, (int)B, p->scalars, L.enc_compact ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* scaled */};
-  if (!L.enc_compact) PV_TRY(pv_finish_scalars(fin.llb, fin.B, fin.scalars, fin.kl_part, fin.n_part, fin.beta, s));
+  // the loss scalars ride in the encoder dgrad launch (compact encoder), in the last weight-gradient launch (conv encoder) or get their own
+  PvFinish fin{L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* scaled */};
+  const bool fin_rides = L.enc_compact || (ab_fin && L.enc_conv && !L.enc_ext);
+  if (!fin_rides) PV_TRY(pv_finish_scalars(fin.llb, fin.B, fin.scalars, fin.kl_part, fin.n_part, fin.beta, s));
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
   // (jiVAE: over the K*B decoder samples, zin = [z content | onehot(k)])
   const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
-  PV_TRY(encoder_bwd(p, L, &wz, 1, s, L.enc_compact ? &fin : nullptr, adam, adam_done, chain));
+  PV_TRY(encoder_bwd(p, L, &wz, 1, s, fin_rides ? &fin : nullptr, adam, adam_done, chain, head_side));
   return extra_outputs(p, L, L.dzc, lat_in, s);
 }
 

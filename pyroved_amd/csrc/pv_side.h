@@ -23,6 +23,7 @@ int pv_stream_after(hipStream_t waiter, hipStream_t signaller);
 void pv_fork_arm();
 void pv_fork_disarm();
 hipEvent_t pv_fork_take();
+bool pv_fork_taken();                                  // did a launch take the armed event?
 int pv_fork_to(hipStream_t side, hipStream_t main);
 #define PV_LAUNCH_FORK(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                            \
   do {                                                                                                    \

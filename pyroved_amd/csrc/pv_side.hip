@@ -89,6 +89,7 @@ hipEvent_t pv_fork_take() {
   t_taken = true;
   return t_armed;
 }
+bool pv_fork_taken() { return t_armed && t_taken; }
 int pv_fork_to(hipStream_t side, hipStream_t main) {
   if (t_armed && t_taken) {
     const hipError_t rc = hipStreamWaitEvent(side, t_armed, 0);

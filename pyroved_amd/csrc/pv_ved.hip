@@ -203,8 +203,9 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
 }
 
 // decoder forward from z (B, z_dim) to the logits / pre-sigmoid output in L.da[n_dec_ops]
+// arm_fork: the one-launch form carries a fork event (pv_fork_taken() tells the caller whether it ran)
 int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_t s, const PvD1Lik* lk = nullptr, bool* lik_done = nullptr,
-                    bool with_head = false) {
+                    bool with_head = false, bool arm_fork = false) {
   const int64_t B = p->batch;
   const Shape& d0 = L.ds[0];
   const int64_t F0 = (int64_t)d0.H * d0.W * d0.C;
@@ -213,6 +214,7 @@ int ved_decoder_fwd(const pv_ved_plan* p, VLayout& L, const float* z, hipStream_
     PvD1Head hd{L.head, p->eps, L.z, L.z_scale, p->z_loc, p->z_scale, L.kl_part, nullptr, 2 * p->z_dim, p->beta};
     if (L.head_part) { hd.part = L.head_part; hd.bias = p->head.b_off >= 0 ? p->params + p->head.b_off : nullptr; hd.head_out = L.head; hd.nseg = L.head_nseg; }
     if (lik_done) *lik_done = lk != nullptr;
+    if (arm_fork) pv_fork_arm();
     return pv_dec1d_fwd(p->params, p->dec, p->n_dec_ops, L.d1_wt, (int)B, d0.H, d0.C, L.da, s, &lf, lk,
                         with_head && head_folded(p, L) ? &hd : nullptr);
   }
@@ -272,7 +274,10 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   const int64_t OUT = od.elems(B), per = OUT / B, S = (int64_t)od.H * od.W;
   const PvD1Lik lk{p->y, p->loc, want_grads ? L.dlda : nullptr, L.llb, p->lik, p->sigmoid_out, p->decoder_sig};
   bool lik_done = false;
-  PV_TRY(ved_decoder_fwd(p, L, L.z, s, p->out_ch == 1 ? &lk : nullptr, &lik_done, true));
+  // a step with gradients and a side stream: the loss scalars are summed there, next to the backward's first launch
+  static const int fin_side_env = getenv("PV_FIN_SIDE") ? atoi(getenv("PV_FIN_SIDE")) : 1;
+  hipStream_t side_f = (want_grads && fin_side_env) ? pv_side_stream_for(s, p->flags) : nullptr;
+  PV_TRY(ved_decoder_fwd(p, L, L.z, s, p->out_ch == 1 ? &lk : nullptr, &lik_done, true, side_f != nullptr));
   const float* y = p->y;
   if (!lik_done && p->out_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->y, L.y_nsc, B, p->out_ch, S, s)); y = L.y_nsc; }
   float* loc = p->loc ? (p->out_ch > 1 ? L.loc_nsc : p->loc) : nullptr;
@@ -288,8 +293,11 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
     if (p->loc && p->out_ch > 1) PV_TRY(pv_nsc_to_ncs(L.loc_nsc, p->loc, B, p->out_ch, S, s));
     PV_TRY(pv_segsum(L.llrow, B, per, L.llb, s));
   }
-  if (head_folded(p, L)) PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, (int)B, 1.0f /* partials come scaled */, s));
-  else PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, nullptr, 0, p->beta, s));
+  hipStream_t sf = s;
+  if (side_f && lik_done && pv_fork_taken()) { PV_TRY(pv_fork_to(side_f, s)); sj.fork(s, side_f); sf = side_f; }
+  else pv_fork_disarm();
+  if (head_folded(p, L)) PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, (int)B, 1.0f /* partials come scaled */, sf));
+  else PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, nullptr, 0, p->beta, sf));
   if (!want_grads) return 0;
 
   PvFinishList fin{};                                  // the conv stacks' weight-gradient reductions: one launch at the end

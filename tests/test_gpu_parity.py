@@ -1919,6 +1919,52 @@ def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
         assert torch.equal(a, b), "tensor %d differs between the one-stream and the two-stream step" % k
 
 
+_CONV_TAIL_SCRIPT = r"""
+import sys, torch
+import pyroved_amd as pv
+g = torch.Generator().manual_seed(7)
+x, eps = torch.rand(40, 64, 64, generator=g), torch.randn(40, 6, generator=g)
+iv = pv.models.iVAE((64, 64), 2, ["r", "t", "s"], seed=1, device="cuda")
+iv.set_encoder(pv.nets.convEncoderNet((64, 64), latent_dim=6))
+eng = iv.engine(fused=int(sys.argv[1]))
+out = []
+for _ in range(2):
+    eng.loss_and_grads(x.cuda(), eps.cuda())
+    out += [eng.scalars.clone().cpu(), eng.grad[:eng.n_flat].clone().cpu()]      # (eng.grad ends with the four scalars)
+    eng.adam_step()
+out.append(eng.flat.clone().cpu())
+torch.save(out, sys.argv[2])
+"""
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_conv_encoder_tail_launches_match_the_separate_ones(gpu_device, precision, tmp_path):
+    """Round 4: in front of the spatial decoder a convEncoderNet's tail (nets/conv.py:77-102 features2latent, then ivae.py:170-196)
+    is ONE launch — the conv head's partial sums, reparameterised sample + KL partials + transform parameters, fc_latent
+    (pv_head_fwd_blocks) — its head weight gradient runs on the side stream next to the head's input gradient, and the loss scalars
+    ride in the last weight-gradient launch.  Against the separate launches (PV_HEAD_MERGE=0 PV_HEAD_SIDE=0 PV_FIN_RIDE=0, a
+    second process: the switches are read once): every gradient and the parameters after two Adam steps bit-identical, the loss
+    scalars to 1e-6 (the KL sums now meet as per-16-sample partials)."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fused = "3" if precision == "bf16" else "2"
+    outs = []
+    for k, extra in enumerate(({}, {"PV_HEAD_MERGE": "0", "PV_HEAD_SIDE": "0", "PV_FIN_RIDE": "0"})):
+        f = str(tmp_path / ("o%d.pt" % k))
+        r = subprocess.run([_sys.executable, "-c", _CONV_TAIL_SCRIPT, fused, f], env=dict(os.environ, **extra), cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    new, old = outs
+    assert len(new) == len(old) == 5
+    for k in (0, 2):                                   # scalars: loss, ll, beta logp, beta logq
+        assert torch.isfinite(new[k]).all()
+        assert torch.allclose(new[k][:4], old[k][:4], rtol=1e-6, atol=1e-4), (new[k][:4], old[k][:4])
+    for k in (1, 3, 4):
+        assert torch.equal(new[k], old[k]), "tensor %d differs" % k
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_fused_1d_decoder_matches_layer_launches(gpu_device, precision):
     """VED's Conv1d decoder (nets/conv.py:190-262: kernel-3 blocks, UpsampleBlocks, the kernel-1 output layer) runs as one
