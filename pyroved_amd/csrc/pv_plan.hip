@@ -535,8 +535,15 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     sj.joined();
     PV_TRY(pv_wgrad_finish_all(&wfin, s));
     if (fin && n_extra < 1) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
-    for (int i = 0; i < n_extra; i += 4)             // (the loss scalars ride in the first of these launches)
-      PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s, nullptr, i == 0 ? fin : nullptr));
+    // (the loss scalars ride in the first of these launches; every other gradient is final by now, so pv_ivae_step's Adam update
+    //  rides in the last one: its own outputs in its epilogue, the rest of the flat buffer by guest workgroups)
+    static const int ab_adam = getenv("PV_CONV_ADAM_RIDE") ? atoi(getenv("PV_CONV_ADAM_RIDE")) : 1;
+    for (int i = 0; i < n_extra; i += 4) {
+      const bool last = i + 4 >= n_extra;
+      const bool ride = last && adam && adam_done && ab_adam && B <= 4096;
+      PV_TRY(pv_wgrad_small(extra + i, n_extra - i < 4 ? n_extra - i : 4, s, ride ? adam : nullptr, i == 0 ? fin : nullptr));
+      if (ride) *adam_done = true;
+    }
     return 0;
   }
   const float* elast = L.eact[ne - 1];
@@ -1137,7 +1144,7 @@ extern "C" int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, 
   return latent_encoder_bwd(&q, L, q.z_dim, 4, 1, s);
 }
 
-// SVI.step in one call.  On the fused-decoder path with the compact encoder the Adam update rides in the last
+// SVI.step in one call.  On the fused-decoder path with the compact encoder or a conv encoder the Adam update rides in the last
 // gradient launch (pv_wgrad.hip: every element is updated by whoever finalises its gradient; bit-identical to
 // pv_ivae_loss_and_grads + pv_adam_step, one launch fewer); everywhere else it is exactly that pair of calls.
 extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
@@ -1151,7 +1158,7 @@ extern "C" int pv_ivae_step(const pv_ivae_plan* plan, void* stream) {
     Layout L;
     carve(plan, (char*)plan->ws, L);
     if (plan->ws_bytes < L.total) return PV_EWS;
-    if (L.fused && L.enc_compact) {
+    if (L.fused && (L.enc_compact || L.enc_conv)) {  // (conv encoder: in the launch of fc_latent's weight gradient, the step's last)
       const double bc1 = 1.0 - pow((double)plan->adam_beta1, (double)plan->adam_step);
       const double bc2 = 1.0 - pow((double)plan->adam_beta2, (double)plan->adam_step);
       const PvAdamFuse ad{plan->params, plan->grads, plan->adam_m, plan->adam_v, plan->n_params, plan->adam_beta1,

@@ -1621,7 +1621,8 @@ def test_one_call_step_is_bit_identical(gpu_device, kind):
     """loss_and_grads(step=True) (pv_ivae_step: on the fused path Adam rides in the last gradient launch, every element
     updated by the workgroup that finalises its gradient + guest workgroups for the rest) against loss_and_grads() +
     adam_step(): parameters, both Adam moments, the zeroed gradients and the loss scalars must be bit-identical over
-    several steps; paths that cannot fuse (layered decoder, conv encoder, long batches) fall back to the same pair."""
+    several steps; with a conv encoder (round 4) Adam rides in the launch of fc_latent's weight gradient, the step's last; paths
+    that cannot fuse (layered decoder, long batches) fall back to the same pair."""
     torch.manual_seed(3)
     b = 5000 if kind == "b5000" else 37
     def make():
