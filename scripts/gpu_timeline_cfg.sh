@@ -1,5 +1,6 @@
 #!/bin/bash
-# Kernel timeline of one SVI step of a bench config (a step = the kernels between two pv_adam launches), last leg run:
+# Kernel timeline of one SVI step of a bench config (a step = the kernels between two pv_adam launches, or two pv_wgrad_small launches
+# when Adam rides in that launch), last leg run:
 #   bash scripts/gpu_timeline_cfg.sh <tag> <C4|C5> [extra bench args]
 TAG=${1:-tlc}; CFG=${2:-C5}; shift; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
@@ -11,6 +12,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 ends = [i for i, n in enumerate(names) if "pv_adam" in n]
+if len(ends) < 3:                                     # (conv-encoder iVAE, round 4: Adam rides in the step's last weight-gradient launch)
+    ends = [i for i, n in enumerate(names) if "pv_wgrad_small" in n]
 a, b = ends[-3] + 1, ends[-2] + 1
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = None
 tot_k = 0
