@@ -22,6 +22,8 @@ for case in range(n_cases):
     nblocks = len(hd) if hd else 3
     if out_len % (2 ** nblocks) != 0:
         continue
+    if os.environ.get("SOAK_ONLY") and case != int(os.environ["SOAK_ONLY"]):
+        continue
     cfg = orc.VedConfig(input_dim=(in_side, in_side), output_dim=(out_len,), output_channels=och, latent_dim=latent,
                         hidden_dim_e=[(32,), (64, 64)], hidden_dim_d=hd, activation=act, sampler=sampler)
     try:
@@ -46,7 +48,23 @@ for case in range(n_cases):
         e = ((gk - rk).norm() / rk.norm().clamp_min(1e-30)).item()
         if e > worst: worst, wk = e, k
     ok = abs(loss - ref) <= 1e-4 * abs(ref) and worst < 1e-4
+    note = ""
+    if not ok and abs(loss - ref) <= 1e-4 * abs(ref) and act in ("relu", "lrelu"):
+        # a ReLU kink?  A pre-activation within rounding of zero takes the other branch in one arithmetic than in another: the
+        # gradient is then discontinuous in the inputs and no bar means anything.  Probe: the FLOAT64 oracle's own gradient of that
+        # tensor under input perturbations of 1e-5 relative (fp32 rounding error after a few layers) — if IT moves by more than the bar, the
+        # case sits on a kink and is not counted.
+        moved = 0.0
+        for t in range(12):
+            gp = torch.Generator().manual_seed(1000 + t)
+            o2 = orc.VedOracle({k: v.cpu() for k, v in m.state_dict().items()}, cfg, dtype=torch.float64)
+            o2.step(x.double() * (1 + 1e-5 * torch.randn(x.shape, generator=gp, dtype=torch.float64)), y,
+                    eps.double() * (1 + 1e-5 * torch.randn(eps.shape, generator=gp, dtype=torch.float64)), 1.0)
+            moved = max(moved, ((o2.last_grads[wk].double() - o.last_grads[wk].double()).norm() / o.last_grads[wk].double().norm().clamp_min(1e-30)).item())
+        note = "  [float64 oracle's own gradient of that tensor moves by %.1e under 1e-5 input perturbations]" % moved
+        ok = moved > 1e-4
+        if ok: note += " -> kink, not counted"
     bad += 0 if ok else 1
     print("case %2d %s: in %d out %d x%d act %s hd %s %s z %d b %d: loss %.6g (oracle %.6g) worst grad %.1e (%s)"
-          % (case, "ok " if ok else "BAD", in_side, out_len, och, act, hd, sampler, latent, b, loss, ref, worst, wk), flush=True)
+          % (case, "ok " if ok else "BAD", in_side, out_len, och, act, hd, sampler, latent, b, loss, ref, worst, wk) + note, flush=True)
 print("%d bad" % bad)
