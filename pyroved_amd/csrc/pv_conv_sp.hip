@@ -90,7 +90,15 @@ template <int NS> __device__ __forceinline__ void sp_split4(const f32x4& v, u32x
   }
 }
 
-// four fp32 (times the exact scale sc) -> two planes of four fp16: a0 = rtz(v sc), a1 = rtz(v sc - a0)
+// the second pieces of two values whose first pieces are the halves of h: fp16(t - h), one mixed-precision fma each (the f16 half of
+// h and the f32 t go in as they are, the result is rounded once into its half of the pair) — instead of cvt, sub, sub, cvt_pk
+__device__ __forceinline__ unsigned sp_lo_pair(unsigned h, float t0, float t1) {
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(t0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(t1));
+  return l;
+}
+// four fp32 (times the exact scale sc) -> two planes of four fp16: a0 = rtz(v sc), a1 = fp16(v sc - a0) (exact difference, one rounding)
 __device__ __forceinline__ void sp_split4_f16(const f32x4& v, float sc, u32x2 (&pl)[2]) {
 #if SP_EXP & 8                   // (timing: operands that arrive split — no VALU work)
   pl[0] = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])};
@@ -98,11 +106,10 @@ __device__ __forceinline__ void sp_split4_f16(const f32x4& v, float sc, u32x2 (&
   return;
 #endif
   const f32x4 t = v * sc;
-  const shp2 h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]), h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
-  const shp2 l01 = __builtin_amdgcn_cvt_pkrtz(t[0] - (float)h01[0], t[1] - (float)h01[1]);
-  const shp2 l23 = __builtin_amdgcn_cvt_pkrtz(t[2] - (float)h23[0], t[3] - (float)h23[1]);
-  pl[0] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-  pl[1] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+  const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t[0], t[1]));
+  const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t[2], t[3]));
+  pl[0] = u32x2{h01, h23};
+  pl[1] = u32x2{sp_lo_pair(h01, t[0], t[1]), sp_lo_pair(h23, t[2], t[3])};
 }
 // one-piece forms (round 4, the throughput precision: ONE fp16 piece per operand, one product): round to nearest
 typedef _Float16 shf4 __attribute__((ext_vector_type(4)));
@@ -925,6 +932,41 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
                                          use_buf ? (int)((int64_t)p.B * p.H * p.W * p.Cout * 4) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0,
                                          use_buf ? (int)((int64_t)p.B * p.H * p.W * p.Cin * 4) : 0, 0x00020000);
+  // Exact tilings (H and W multiples of 8: every BASELINE shape): a piece's byte offset is the tile's base (scalar) plus a
+  // per-thread constant, and a halo piece lies outside the image only when its tile touches that border — 5 class bits per piece
+  // (top / bottom / left / right / no such piece) against the tile's border mask: no multiplies and no coordinate compares per
+  // piece (they were 16 v_mul_lo / v_mad_u64 — quarter rate — and ~60 more VALU instructions per tile)
+  const bool exact = use_buf && (p.H & 7) == 0 && (p.W & 7) == 0;
+  int d_const[4], p_const[PK];
+  unsigned long long p_cls = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d_const[k] = ((dn_y[k] * p.W + dn_x[k]) * p.Cout + dco) * 4;
+#pragma unroll
+  for (int k = 0; k < PK; ++k) {
+    const int ry = pp_r[k] - 1, rx = pp_c[k] - 1;
+    p_const[k] = pp_r[k] < (1 << 20) ? ((ry * p.W + rx) * p.Cin + pcf) * 4 : 0;
+    const unsigned c = pp_r[k] < (1 << 20) ? ((ry < 0 ? 1u : 0u) | (ry > 7 ? 2u : 0u) | (rx < 0 ? 4u : 0u) | (rx > 7 ? 8u : 0u)) : 16u;
+    p_cls |= (unsigned long long)c << (5 * k);
+  }
+  static_assert(PK * 5 <= 64, "class bits of the patch pieces in one 64-bit word");
+  auto fetch_exact = [&]() {
+    const unsigned pix0 = ((unsigned)fb * (unsigned)p.H + (unsigned)(fty * 8)) * (unsigned)p.W + (unsigned)(ftx * 8);
+    const unsigned base_d = pix0 * (unsigned)p.Cout * 4u, base_p = pix0 * (unsigned)p.Cin * 4u;
+    const unsigned border = (fty == 0 ? 1u : 0u) | (fty == p.tiles_y - 1 ? 2u : 0u) | (ftx == 0 ? 4u : 0u) |
+                            (ftx == p.tiles_x - 1 ? 8u : 0u) | 16u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(drs, base_d + (unsigned)d_const[k], 0, 0);
+      vd[k] = __builtin_bit_cast(f32x4, v);
+    }
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+      const bool out = ((unsigned)(p_cls >> (5 * k)) & border) != 0;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(irs, out ? 0x80000000u : base_p + (unsigned)p_const[k], 0, 0);
+      vp[k] = __builtin_bit_cast(f32x4, v);
+    }
+    if (++ftx == p.tiles_x) { ftx = 0; if (++fty == p.tiles_y) { fty = 0; ++fb; } }
+  };
   auto fetch_buf = [&]() {
     const int y0 = fty * 8, x0 = ftx * 8;
     const unsigned img = (unsigned)fb * (unsigned)(p.H * p.W);
@@ -969,7 +1011,7 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
     }
     if (++ftx == p.tiles_x) { ftx = 0; if (++fty == p.tiles_y) { fty = 0; ++fb; } }
   };
-  auto fetch = [&]() { if (use_buf) fetch_buf(); else fetch_ptr(); };
+  auto fetch = [&]() { if (exact) fetch_exact(); else if (use_buf) fetch_buf(); else fetch_ptr(); };
   if (PRE && t_lo < t_hi) fetch();
   int Ed = 0, Ep = 0, Ed_min = 1 << 20, Et_min = 1 << 20;           // F16: current exponents, smallest so far (dY, dY + patch)
   auto wave_max = [&](int slot) {                    // this wave's max |dY piece| and |patch piece| of the fetched tile
@@ -1073,16 +1115,27 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
       for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
         for (int cib = 0; cib < NCIB; ++cib) {
-          // one 12-pixel line window per plane: dwords w0..w4 = pixels (0,1) .. (8,9) [(10,11) are never used]
           sbf8 bb[3][NS];
 #pragma unroll
           for (int j = 0; j < NS; ++j) {
             const char* bp = patch + j * PPLANE + b_off[dy] + ks * (4 * RP) + cib * 32;
-            const u32x2 w01 = sw_tr(bp), w23 = sw_tr(bp + 4 * PP), w45 = sw_tr(bp + 8 * PP);
-            bb[0][j] = sw_frag(w01[0], w01[1], w23[0], w23[1]);
-            bb[1][j] = sw_frag(__builtin_amdgcn_alignbit(w01[1], w01[0], 16), __builtin_amdgcn_alignbit(w23[0], w01[1], 16),
-                               __builtin_amdgcn_alignbit(w23[1], w23[0], 16), __builtin_amdgcn_alignbit(w45[0], w23[1], 16));
-            bb[2][j] = sw_frag(w01[1], w23[0], w23[1], w45[0]);
+            if constexpr (F16) {
+              // fp16 forms (round 4): the three taps of a kernel row are three windows of the line read straight from LDS — a
+              // transposing read starts at any pixel, and the pixel pitch keeps every start conflict-free — instead of one 12-pixel
+              // window shifted in registers (4 v_alignbit + ~10 v_mov per plane and kernel row: a third of this loop's VALU work)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const u32x2 lo = sw_tr(bp + dx * PP), hi = sw_tr(bp + dx * PP + 4 * PP);
+                bb[dx][j] = sw_frag(lo[0], lo[1], hi[0], hi[1]);
+              }
+            } else {
+              // one 12-pixel line window per plane: dwords w0..w4 = pixels (0,1) .. (8,9) [(10,11) are never used]
+              const u32x2 w01 = sw_tr(bp), w23 = sw_tr(bp + 4 * PP), w45 = sw_tr(bp + 8 * PP);
+              bb[0][j] = sw_frag(w01[0], w01[1], w23[0], w23[1]);
+              bb[1][j] = sw_frag(__builtin_amdgcn_alignbit(w01[1], w01[0], 16), __builtin_amdgcn_alignbit(w23[0], w01[1], 16),
+                                 __builtin_amdgcn_alignbit(w23[1], w23[0], 16), __builtin_amdgcn_alignbit(w45[0], w23[1], 16));
+              bb[2][j] = sw_frag(w01[1], w23[0], w23[1], w45[0]);
+            }
           }
 #define SW_PROD(KA, KB)                                                                                                 \
   _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) _Pragma("unroll") for (int cob = 0; cob < 2; ++cob)                   \
