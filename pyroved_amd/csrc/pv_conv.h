@@ -79,9 +79,10 @@ int64_t pv_conv3_sp_wt_bytes(int C, int Cout);
 // deferring finish list) and pv_conv3_sp calls record their kernel instead of launching it; flush launches what was recorded
 void pv_conv3_sp_pair_begin();
 int pv_conv3_sp_pair_flush(hipStream_t s);
+// up_code != null: out is (B, 2H, 2W, N) — the result un-pooled by the winner bytes up_code (B, H, W, N) of a fused conv + max-pool
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready = nullptr,
-                float* pool_out = nullptr, unsigned char* pool_code = nullptr);
+                float* pool_out = nullptr, unsigned char* pool_code = nullptr, const unsigned char* up_code = nullptr);
 // pool_out / pool_code (forward form, even H and W): the 2x max-pool of the output (B, H/2, W/2, Co) and one byte per pooled value
 // (which of the 2x2 positions won) are written INSTEAD of the full-resolution output; pv_maxpool2_bwd_code is its backward
 int pv_maxpool2_bwd_code(const float* g, const float* y_pooled, const unsigned char* code, float* din, int B, int Hp, int Wp, int C,

@@ -57,6 +57,10 @@ struct ConvSp {
   const float* eg_y; int eg_act;      // optional: out *= act'(eg_y) elementwise (the producing layer's activation backward)
   int B, H, W, Cin, Cout, act, tiles_x, tiles_y, halves;
   float* pool_out; unsigned char* pool_code;   // != null: write maxpool2(out) (B, H/2, W/2, Cout) and its winners instead of out
+  // != null (input gradients whose result is dL/d(a max-pooled activation); round 4): the 2x un-pooling rides in the epilogue — out is
+  // (B, 2H, 2W, Cout), a value (already times act'(eg_y), eg_y = the pooled activation) goes to its winner's position, zeros to the
+  // other three: pv_maxpool2_bwd_code's launch, its read of this tensor and the write of it are gone
+  const unsigned char* up_code;
 };
 
 // (hi16(b) << 16) | hi16(a): two truncated bf16 out of two fp32 bit patterns
@@ -632,6 +636,16 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
     }
     return;
   }
+  unsigned upc[NCB][4];                               // (un-pooling epilogue: the winner bytes, requested ahead of the arithmetic)
+  if (p.up_code) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+        const int co = cot * SP_TN + hco + cb * 16 + 4 * q;
+        upc[cb][pb] = (ok[pb] && co + 3 < p.Cout) ? *reinterpret_cast<const unsigned*>(p.up_code + ro[pb] + co) : 0u;
+      }
+  }
   if (p.eg_y) {                                       // out *= act'(eg_y): the producing layer's activation backward
     f32x4 gy[NCB][4];
 #pragma unroll
@@ -657,6 +671,29 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
       case PV_ACT_SIGMOID: SP_EACH_G(v *= yv * (1.0f - yv)); break;
       default: break;
     }
+  }
+  if (p.up_code) {                                    // (host: Cout % 4 == 0)
+    const int W2 = 2 * p.W;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      if (!ok[pb]) continue;
+      const int y = y0 + 8 * wy + 2 * pb + (r >> 3), x = x0 + 8 * wx + (r & 7);
+      float* o00 = p.out + (((int64_t)b * 2 * p.H + 2 * y) * W2 + 2 * x) * p.Cout;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int co = cot * SP_TN + hco + cb * 16 + 4 * q;
+        if (co + 3 >= p.Cout) continue;
+        const unsigned code = upc[cb][pb];
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = ((code >> (8 * i)) & 0xffu) == (unsigned)pos ? acc[cb][pb][i] : 0.0f;
+          *reinterpret_cast<f32x4*>(o00 + (int64_t)((pos >> 1) * W2 + (pos & 1)) * p.Cout + co) = v;
+        }
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
@@ -744,7 +781,7 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
 // ns = 3: fp32-class (six products); ns = 2: mixed precision (three products).  wt_scratch: pv_conv3_sp_wt_bytes bytes.
 int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, int Ci, int flip, const float* bias, float* out,
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready, float* pool_out,
-                unsigned char* pool_code) {
+                unsigned char* pool_code, const unsigned char* up_code) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
   if (!pv_conv3_sp_supported(C, N, 2, act) || ns < 1 || ns > 4) return PV_EINVAL;   // 4: fp16 two-piece, 1: fp16 one-piece
   const int nt = (N + SP_TN - 1) / SP_TN;
@@ -754,6 +791,10 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
   p.eg_y = (eg_y && eg_act != PV_ACT_NONE) ? eg_y : nullptr; p.eg_act = eg_act;
   p.B = B; p.H = H; p.W = W; p.Cin = C; p.Cout = N; p.act = act;
   p.tiles_x = (W + SP_T - 1) / SP_T; p.tiles_y = (H + SP_T - 1) / SP_T;
+  if (up_code) {                                     // fused 2x un-pooling (pv_conv_sp.hip ConvSp): whole float4 channel groups only
+    if (pool_out || (N & 3)) return PV_EINVAL;
+    p.up_code = up_code;
+  }
   if (pool_out) {                                    // fused 2x max-pool: forward form, even image sides
     if (flip || !pool_code || (H & 1) || (W & 1) || p.eg_y) return PV_EINVAL;
     p.pool_out = pool_out; p.pool_code = pool_code;

@@ -306,9 +306,22 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
 // g_is_pre: g already is dL/d(pre-activation) (the consumer's backward applied this layer's activation derivative);
 // fuse_act != NONE: the PRODUCER of `in` is a convolution with that activation — apply act'(in) to gin here (returns
 // *fused = true when done) instead of a separate elementwise pass in the producer's backward
+// does a kernel-3 convolution's backward run its input gradient on the split-operand kernel as a launch of its own (not the
+// weight + input gradient pair launch)?  That launch can carry the un-pooling epilogue.
+inline bool conv_bwd_sp_alone(const pv_op& o, int nd, int B, const Shape& si, const Scratch& sc) {
+  if (o.kind != PV_OP_CONV || o.ksize != 3 || !pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE)) return false;
+  const bool wg = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd);
+  const bool on_side = sc.side && wg && pv_wgrad_defers(sc.fin, pv_conv3_sp_wgrad_ws(B, si.H, si.W, si.C, o.cout));
+  const bool pair = wg && sc.fin && !conv_mixed(sc.conv_bf16) && sp_fp32_mode(sc.conv_bf16) == 4 && (!on_side || side_keeps_pairs());
+  return !pair;
+}
 inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int B, const float* in, const Shape& si,
                   const float* out, float* g, float* gin, const Scratch& sc, int slot, hipStream_t s, bool g_is_pre = false,
-                  int fuse_act = PV_ACT_NONE, bool* fused = nullptr, int g_up = 0) {
+                  int fuse_act = PV_ACT_NONE, bool* fused = nullptr, int g_up = 0, const unsigned char* up_code = nullptr,
+                  bool* unpooled = nullptr) {
+  // up_code != null (kernel-3 convolutions on the split-operand kernels, not in a pair launch): gin is the UN-POOLED input gradient
+  // (B, 2H, 2W, cin) — the max-pool below this op rides in the launch's epilogue; *unpooled tells the caller whether it did
+  if (unpooled) *unpooled = false;
   if (fused) *fused = false;
   if (fuse_act == PV_ACT_GELU) fuse_act = PV_ACT_NONE;
   if (o.kind == PV_OP_BATCHNORM)
@@ -356,8 +369,10 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
         if (sc.side) pv_fork_arm();                        // the layer below may fork its weight gradient off this launch
+        const bool up = up_code && unpooled && (o.cin & 3) == 0;
+        if (up) *unpooled = true;
         return pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act,
-                           sp_mode(sc.conv_bf16), wt_ready(sc, slot, 1));
+                           sp_mode(sc.conv_bf16), wt_ready(sc, slot, 1), nullptr, nullptr, up ? up_code : nullptr);
       }
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;
@@ -437,7 +452,16 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
   Scratch scl = sc;
   if (!gown) scl.side = nullptr;                       // (ping-pong buffers are rewritten while a side-stream reader could be behind)
   const bool c1pool = stack_id == 0 && sc.code && !need_input_grad && c1pool_fusable(ops, n, nd, sh[0]);
+  // the max-pool of a fused conv + pool pair un-pooled in the epilogue of the input-gradient launch ABOVE it (pv_conv_sp.hip up_code;
+  // PV_NO_UNPOOL_FUSE=1: pv_maxpool2_bwd_code's own launch).  Own gradient buffers only (gown: the side-stream form).
+  static const int unpool_fuse = getenv("PV_NO_UNPOOL_FUSE") && atoi(getenv("PV_NO_UNPOOL_FUSE")) ? 0 : 1;
+  int pool_done_at = -1;                               // index of a pool op whose backward the launch above has written
   for (int i = n - 1; i >= 0; --i) {
+    if (i == pool_done_at) {                           // g = dL/d(pre-activation of the convolution below), already un-pooled
+      g = gown[i];
+      g_is_pre = true;
+      continue;
+    }
     // an armed fork event is the stop event of the launch that produced g: only a kernel-3 convolution that takes g as it
     // is (no activation pass in between) may hand it to its side-stream weight gradient
     if (!(scl.side && ops[i].kind == PV_OP_CONV && ops[i].ksize == 3 && g_is_pre)) pv_fork_disarm();
@@ -469,11 +493,23 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
     const int g_up = k1up_fusable(ops, n, nd, i) ? 1 : 0;
     float* gin = (i > 0 || need_input_grad) ? (gown ? gown[i] : gbuf[pp]) : nullptr;
     // the layer below is a convolution with an activation: let this op's backward apply act'(a[i]) to gin
-    const int fuse_act = (i > 0 && gin && ops[i - 1].kind == PV_OP_CONV) ? ops[i - 1].act : PV_ACT_NONE;
-    bool fused = false;
+    int fuse_act = (i > 0 && gin && ops[i - 1].kind == PV_OP_CONV) ? ops[i - 1].act : PV_ACT_NONE;
+    // ... or the max-pool of a fused conv + pool pair: act'(the pooled activation a[i]) and the un-pooling ride along, the
+    // result is dL/d(pre-activation of the convolution below the pool) in the POOL's gradient buffer
+    const unsigned char* up_code = nullptr;
+    if (unpool_fuse && gown && scl.side && stack_id == 0 && sc.code2 && i >= 3 && ops[i].kind == PV_OP_CONV && ops[i].ksize == 3 &&
+        ops[i - 2].act != PV_ACT_GELU && (ops[i].cin & 3) == 0 && conv_bwd_sp_alone(ops[i], nd, B, sh[i], scl) &&
+        convpool_fusable(ops, n, nd, i - 2, sh[i - 2])) {
+      up_code = sc.code2 + code2_off(ops, n, nd, B, sh, i - 2);
+      fuse_act = ops[i - 2].act;
+      gin = gown[i - 1];
+    }
+    bool fused = false, unpooled = false;
     if (i == 0 && sc.fork_after && gin) pv_fork_arm();
     PV_TRY(op_bwd(params, grads, ops[i], nd, B, a[i], sh[i], a[i + 1], g, gin, scl, stack_id * PV_MAX_OPS + i, s, g_is_pre,
-                  fuse_act, &fused, g_up));
+                  fuse_act, &fused, g_up, up_code, &unpooled));
+    if (up_code && !unpooled) return PV_EINVAL;        // (the launch form was chosen above: it must have taken the epilogue)
+    if (unpooled) pool_done_at = i - 1;
     g_is_pre = fused;
     g = gin; pp ^= 1;
     if (i > 0 && k1_flush_due(scl)) {                  // (the last chunk is the caller's: it knows what else follows the chain)
