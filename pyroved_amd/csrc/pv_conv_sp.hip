@@ -853,7 +853,8 @@ extern "C" int pv_debug_conv3_sp_occupancy(int ns, int lds) {
 // 4 consecutive pixels of one channel).  A lane's 8 k values are 8 consecutive pixels of one line, so the three taps
 // dx = 0, 1, 2 of a kernel row are windows of ONE 12-pixel line read: dx = 0 and 2 are register sub-ranges, dx = 1 is
 // four v_alignbit — a third of the patch reads of a per-tap formulation, which is what lets two workgroups per CU run
-// under the LDS bandwidth.  Pixel rows are 160 bytes apart (64 channels + pad) with a per-line skew so that the two
+// under the LDS bandwidth.  (The fp16 forms, round 4, read the three windows separately after all: at their MFMA count the loop
+// was bound by VALU issue, not by the LDS, and the register shifts were a quarter of its VALU work.)  Pixel rows are 160 bytes apart (64 channels + pad) with a per-line skew so that the two
 // 16-lane halves of a transposing read (two adjacent lines) land on disjoint banks.
 // Per-split partial results are summed in split order by pv_conv3_wgrad_finish_kernel (no atomics).
 struct ConvWgSp {
