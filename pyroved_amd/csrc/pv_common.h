@@ -161,6 +161,17 @@ __device__ __forceinline__ void pv_lik_one(float av, float xv, int lik, int sigm
 }
 
 
+// v summed over the four 16-lane rows of the wave (lanes r, r + 16, r + 32, r + 48), result in every lane: gfx950's row / half swaps
+// (v_permlane16_swap, v_permlane32_swap: plain VALU) instead of two ds_bpermute round trips through the LDS pipeline.  The pairings
+// and the order of the two additions are those of `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`: the same bits.
+__device__ __forceinline__ float pv_sum_rows(float v) {
+  unsigned b = __float_as_uint(v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+  b = __float_as_uint(v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+}
 __device__ __forceinline__ float pv_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

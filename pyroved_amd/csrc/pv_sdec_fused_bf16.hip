@@ -472,9 +472,7 @@ __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)
 }
 
 __device__ __forceinline__ float fb_sum_q(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  return pv_sum_rows(v);                             // (pv_common.h: v_permlane16/32_swap, the bits of the two shfl_xor sums)
 }
 // Column sums over a unit's 16 rows of a C/D-layout tensor v (lane (r, q): row r, columns 16*jb + 4q + i), optionally
 // also weighted by two per-row scalars: wave-local transpose through LDS.  The wave writes its 16 x 128 fp32 tile

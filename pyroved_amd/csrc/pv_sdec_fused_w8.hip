@@ -98,9 +98,7 @@ __device__ __forceinline__ void w8_glds4(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void w8_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void w8_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); }
 __device__ __forceinline__ float w8_sum_q(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  return pv_sum_rows(v);                             // (pv_common.h: v_permlane16/32_swap, the bits of the two shfl_xor sums)
 }
 
 // timing ablations (profiling builds only, results are WRONG; profiles/r03e_w8_ablations.txt): -DW8_ABL=1 the forward loops
