@@ -172,9 +172,23 @@ __device__ __forceinline__ float pv_sum_rows(float v) {
   auto s32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
   return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
 }
+// the butterfly sum over the wave (v += v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: every lane ends with the total).  __shfl_xor compiles
+// to ds_bpermute — six dependent round trips through the LDS pipeline, ~700 cycles in the small latency-bound kernels that call this
+// several times in a row.  The same pairs in the same order (the same bits) without the LDS: the half / row swaps of gfx950 for
+// 32 and 16, DPP for the rest (row_ror:8 is lane ^ 8 inside a row of 16; lane ^ 4 is row_half_mirror followed by the quad reversal).
 __device__ __forceinline__ float pv_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  unsigned b = __float_as_uint(v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  v = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+  b = __float_as_uint(v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+#define PV_DPP_F(X, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), (CTRL), 0xF, 0xF, false))
+  v += PV_DPP_F(v, 0x128);                            // row_ror:8            lane ^ 8
+  { const float t = PV_DPP_F(v, 0x141); v += PV_DPP_F(t, 0x1B); }   // row_half_mirror, quad_perm [3,2,1,0]   lane ^ 4
+  v += PV_DPP_F(v, 0x4E);                             // quad_perm [2,3,0,1]  lane ^ 2
+  v += PV_DPP_F(v, 0xB1);                             // quad_perm [1,0,3,2]  lane ^ 1
+#undef PV_DPP_F
   return v;
 }
 
