@@ -172,6 +172,22 @@ __device__ __forceinline__ float pv_sum_rows(float v) {
   auto s32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
   return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
 }
+// max over the wave of a non-negative value, uniform result: four DPP steps inside each row of 16 lanes (quad xor 1, xor 2, half-row
+// mirror, row mirror), then the four rows' values through scalar registers — non-negative floats order like their bit patterns.
+// (__shfl_xor compiles to ds_bpermute: six dependent LDS round trips per value, ~700 cycles at the end of every tile.)
+__device__ __forceinline__ float pv_wave_max_nonneg(float v) {
+  int b = __float_as_int(v);
+#define PV_DPP_MAX(CTRL) b = __float_as_int(fmaxf(__int_as_float(b), __int_as_float(__builtin_amdgcn_update_dpp(b, b, (CTRL), 0xF, 0xF, false))))
+  PV_DPP_MAX(0xB1);                                   // quad_perm [1,0,3,2]
+  PV_DPP_MAX(0x4E);                                   // quad_perm [2,3,0,1]
+  PV_DPP_MAX(0x141);                                  // row_half_mirror
+  PV_DPP_MAX(0x140);                                  // row_mirror
+#undef PV_DPP_MAX
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane(b, 0), r1 = (unsigned)__builtin_amdgcn_readlane(b, 16);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane(b, 32), r3 = (unsigned)__builtin_amdgcn_readlane(b, 48);
+  const unsigned m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+  return __uint_as_float(m01 > m23 ? m01 : m23);
+}
 // the butterfly sum over the wave (v += v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: every lane ends with the total).  __shfl_xor compiles
 // to ds_bpermute — six dependent round trips through the LDS pipeline, ~700 cycles in the small latency-bound kernels that call this
 // several times in a row.  The same pairs in the same order (the same bits) without the LDS: the half / row swaps of gfx950 for

@@ -768,8 +768,7 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_direct_bf16_kernel(ConvD p) {
     for (int k = 0; k < PKB; ++k)
 #pragma unroll
       for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(pv[k][i]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m = pv_wave_max_nonneg(m);
     if (lane == 0) smax[slot][wave] = m;
     __threadfence_block();                            // (the write must have landed before the next barrier lets the others read:
                                                       //  hipcc 7.2 emits no s_waitcnt lgkmcnt between this store and the loop's s_barrier)

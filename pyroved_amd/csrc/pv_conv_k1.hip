@@ -293,8 +293,7 @@ __device__ __forceinline__ void k1_wgrad_body(const K1Wg& a, int blk, float (*pa
   // C layout: lane (n = r, q), register i <-> m = 4 q + i
 #pragma unroll
   for (int i = 0; i < 4; ++i) part[wave][4 * q + i][r] = c[i];
-  rs += __shfl_xor(rs, 16, 64);
-  rs += __shfl_xor(rs, 32, 64);
+  rs = pv_sum_rows(rs);
   if (q == 0) rpart[wave][r] = rs;
   __syncthreads();
   const int mm = tid >> 4, nn = tid & 15, mo = 16 * mb + mm, no = 16 * nb + nn;
@@ -412,8 +411,7 @@ __device__ __forceinline__ void k1_wgrad_fat_body(const K1Wg& a, int blk, float*
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float v = rs[i];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = pv_sum_rows(v);
     if (q == 0) rpart[wave][16 * i + r] = v;
   }
   __syncthreads();

@@ -139,22 +139,6 @@ template <bool F16> __device__ __forceinline__ f32x4 sp_mma(const sbf8& a, const
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
 }
-// max over the wave of a non-negative value, uniform result: four DPP steps inside each row of 16 lanes (quad xor 1, xor 2, half-row
-// mirror, row mirror), then the four rows' values through scalar registers — non-negative floats order like their bit patterns.
-// (__shfl_xor compiles to ds_bpermute: six dependent LDS round trips per value, ~700 cycles at the end of every tile.)
-__device__ __forceinline__ float sp_wave_max_nonneg(float v) {
-  int b = __float_as_int(v);
-#define SP_DPP_MAX(CTRL) b = __float_as_int(fmaxf(__int_as_float(b), __int_as_float(__builtin_amdgcn_update_dpp(b, b, (CTRL), 0xF, 0xF, false))))
-  SP_DPP_MAX(0xB1);                                   // quad_perm [1,0,3,2]
-  SP_DPP_MAX(0x4E);                                   // quad_perm [2,3,0,1]
-  SP_DPP_MAX(0x141);                                  // row_half_mirror
-  SP_DPP_MAX(0x140);                                  // row_mirror
-#undef SP_DPP_MAX
-  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane(b, 0), r1 = (unsigned)__builtin_amdgcn_readlane(b, 16);
-  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane(b, 32), r3 = (unsigned)__builtin_amdgcn_readlane(b, 48);
-  const unsigned m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
-  return __uint_as_float(m01 > m23 ? m01 : m23);
-}
 __device__ __forceinline__ float sp_pow2(int k) {          // 2^k, k clamped to the normal range
   k = k < -126 ? -126 : (k > 127 ? 127 : k);
   return __uint_as_float((unsigned)(k + 127) << 23);
@@ -447,7 +431,7 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
     for (int k = 0; k < PK; ++k)
 #pragma unroll
       for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(pre[k][i]));
-    m = sp_wave_max_nonneg(m);
+    m = pv_wave_max_nonneg(m);
     if (lane == 0) smax[slot][wave] = m;
     __threadfence_block();                            // (landed before the next barrier: see pv_conv3_direct_bf16_kernel)
   };
@@ -1082,7 +1066,7 @@ __device__ __forceinline__ void sp_wgrad_body(const ConvWgSp& p, const int bid_x
     for (int k = 0; k < PK; ++k)
 #pragma unroll
       for (int i = 0; i < 4; ++i) mp = fmaxf(mp, fabsf(vp[k][i]));
-    md = sp_wave_max_nonneg(md); mp = sp_wave_max_nonneg(mp);
+    md = pv_wave_max_nonneg(md); mp = pv_wave_max_nonneg(mp);
     if (lane == 0) { smx[slot][0][wave] = md; smx[slot][1][wave] = mp; }
     __threadfence_block();                           // (landed before the next barrier: see pv_conv3_direct_bf16_kernel)
   };

@@ -37,8 +37,7 @@ __global__ __launch_bounds__(256) void pv_convhead_fwd_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < OUT; ++j) {
     float v = acc[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = pv_wave_sum(v);
     if ((tid & 63) == 0) sm[tid >> 6][j] = v;
   }
   __syncthreads();
@@ -381,8 +380,7 @@ __global__ __launch_bounds__(256) void pv_convhead_wgrad_mfma_kernel(const float
     for (int j = 0; j < out; ++j) {
       float v = 0.0f;
       for (int b = lane; b < B; b += 64) v += dhead[(int64_t)b * out + j];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      v = pv_wave_sum(v);
       if (lane == 0) db[j] = v;
     }
   }

@@ -67,9 +67,7 @@ __device__ __forceinline__ float pv_fb_wave_absmax(const float* __restrict__ v, 
     for (int k = 0; k < 16; ++k)
       m = fmaxf(m, fmaxf(fmaxf(fabsf(x[k][0]), fabsf(x[k][1])), fmaxf(fabsf(x[k][2]), fabsf(x[k][3]))));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  return m;
+  return pv_wave_max_nonneg(m);
 }
 // the power of two s with s * m in [1, 2) (1 for m = 0 or a non-finite m; exponent clamped to +-60)
 __device__ __forceinline__ float pv_fb_norm_scale(float m) {

@@ -98,8 +98,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void pv_wgrad_small_kernel(PvWgradSm
   // C/D layout: lane (n = r, q), reg i -> m = 16*mb + 4q + i
 #pragma unroll
   for (int i = 0; i < 4; ++i) part[wave][4 * q + i][r] = c[i];
-  rs += __shfl_xor(rs, 16, 64);
-  rs += __shfl_xor(rs, 32, 64);
+  rs = pv_sum_rows(rs);
   if (q == 0) rpart[wave][r] = rs;
   __syncthreads();
   {
