@@ -815,6 +815,14 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   __shared__ __attribute__((aligned(16))) float sh_e[2][128];        // encoder dgrad chain (layer widths <= 128)
   __shared__ float sh_p[2][128];
   const int t = threadIdx.x;
+  // The plan struct sits in the kernarg segment and the compiler fetches its fields where they are first used: five or six DEPENDENT
+  // scalar-load round trips (~700 cycles each, cold scalar cache) before the first row load was issued.  Asking for everything the
+  // first phase and the chain's requests need in ONE place makes them one batch of s_loads behind one wait.
+  // (the rest of the struct — one field per 64-byte line is enough — rides in the same batch: later fetches then hit the scalar cache)
+  asm volatile("" :: "s"(p.llrow), "s"(p.rowtp), "s"(p.part_hz), "s"(p.M), "s"(p.N), "s"(p.kmax), "s"(p.H), "s"(p.K), "s"(p.hb.B),
+               "s"(p.fwd_only), "s"(p.enc_n), "s"(p.enc_params), "s"(p.lat_in), "s"(p.dhz), "s"(p.hb.z), "s"(p.hb.dhead),
+               "s"(p.alpha), "s"(p.enc_l[0].w_off), "s"(p.enc_l[2].w_off), "s"(p.enc_head.w_off), "s"(p.enc_act[0]),
+               "s"(p.enc_act[4]), "s"(p.enc_dp[0]), "s"(p.enc_dp[4]));
   const int K = p.K > 0 ? p.K : 1, Bq = p.hb.B;
   // Operands of the encoder chain that depend on nothing computed here (its last layer's weight column, the head's, the
   // saved activations) are requested EARLY — right after the first pass's row loads have been issued (loads return in
