@@ -837,18 +837,20 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     const pv_layer l = p.enc_l[p.enc_n - 1], lp = p.enc_l[p.enc_n - 2], hd = p.enc_head;
     const int jh = l.out_dim >> 1, j0 = chalf * jh;      // widths are multiples of 16 (pv_enc_compact_supported)
     if (ck < l.in_dim) {
-      const float* wc = p.enc_params + l.w_off + ck;
+      // (rows past the half are never used — the contraction below stops at jh, a multiple of 8 — so their loads are CLAMPED to the
+      //  last row instead of guarded: a guard per load compiled into 64 scalar branches, ~2.5 k cycles of this launch's critical path)
+      const float* wc = p.enc_params + l.w_off + ck + (int64_t)j0 * l.in_dim;
 #pragma unroll
       for (int u = 0; u < 16; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wv4[u][i] = (4 * u + i < jh) ? wc[(int64_t)(j0 + 4 * u + i) * l.in_dim] : 0.0f;
+        for (int i = 0; i < 4; ++i) wv4[u][i] = wc[(4 * u + i < jh ? 4 * u + i : jh - 1) * l.in_dim];
       if (chalf == 0) pf_act0 = p.enc_act[p.enc_n - 2][(int64_t)b * lp.out_dim + ck];
     }
     if (t < l.out_dim) {
       pf_act1 = p.enc_act[p.enc_n - 1][(int64_t)b * l.out_dim + t];
       const float* Wh = p.enc_params + hd.w_off + t;
 #pragma unroll
-      for (int o = 0; o < 16; ++o) whd[o] = o < hd.out_dim ? Wh[(int64_t)o * hd.in_dim] : 0.0f;
+      for (int o = 0; o < 16; ++o) whd[o] = Wh[(o < hd.out_dim ? o : hd.out_dim - 1) * hd.in_dim];   // (clamped: used below only for o < out_dim)
     }
   };
   float tp_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -859,9 +861,13 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     const int64_t r0 = s * p.N;
     float a[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     {
-      // four rows per thread and array in flight at once (784 rows = 3.06 per thread)
+      // four rows per thread and array in flight at once.  The rows come in chunks of 1024 (thread t: rows t + 256 u of a chunk); every
+      // chunk but the last is whole, the LAST one (the only one at 784 rows) is predicated and its loads are all issued — with the
+      // chain's operand requests behind them — before anything is added: a thread with all four rows in range used to wait for them in
+      // the loop above before the rest were even requested (~1.9 k cycles on the wave the block reduction waits for).  Same sums.
       int n = t;
-      for (; n + 768 < p.N; n += 1024) {
+      const int n_last = ((p.N - 1) >> 10) << 10;       // first row of the last chunk
+      for (; n < n_last; n += 1024) {
         float v[4][5];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -874,22 +880,21 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
 #pragma unroll
           for (int c = 0; c < 5; ++c) a[c] += v[u][c];
       }
-      float v[3][5];
+      float v[4][5];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const bool ok = n + 256 * u < p.N;
         v[u][0] = ok ? p.llrow[r0 + n + 256 * u] : 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[u][1 + c] = (ok && !p.fwd_only) ? p.rowtp[(int64_t)c * p.M + r0 + n + 256 * u] : 0.0f;
       }
+      LB_STAMP(8);
       if (k == 0 && chain) prefetch_chain();           // (behind the row loads in the memory pipeline)
+      LB_STAMP(9);
 #pragma unroll
-      for (int u = 0; u < 3; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int c = 0; c < 5; ++c) a[c] += v[u][c];
-      if (n + 768 < p.N) {                               // (not reached: the loop above leaves at most 3 strides)
-        for (n += 768; n < p.N; n += 256) a[0] += p.llrow[r0 + n];
-      }
     }
     LB_STAMP(7);
     // the five row sums in ONE block reduction (fixed order: wave sums, then waves 0..3)

@@ -20,3 +20,5 @@ prev = buf[0]
 for k in range(1, 7):
     print("%-28s %7d cycles" % (names[k], buf[k] - prev)); prev = buf[k]
 print("total", buf[6] - buf[0], " | row loads landed + summed per thread at", buf[7] - buf[0])
+if buf[8]:
+    print("   first phase: row loads issued at", buf[8] - buf[0], "| the chain's operand requests issued at", buf[9] - buf[0])
