@@ -38,11 +38,29 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_fwd_kernel(C1Pool p) {
   __syncthreads();
   const int CG = p.C / (4 * CV);
   const int64_t total = (int64_t)p.B * p.Hp * p.Wp * CG;
+  // element -> (image, pooled line, pooled pixel, channel group): five 64-bit divisions by run-time values cost more than the
+  // convolution of the element; below 2^31 elements they are 32-bit, and shifts where the divisor is a power of two (uniform branches)
+  const bool small = total < (1ll << 31);
+  const int shCG = (CG & (CG - 1)) == 0 ? 31 - __clz(CG) : -1, shW = (p.Wp & (p.Wp - 1)) == 0 ? 31 - __clz(p.Wp) : -1;
+  const int shH = (p.Hp & (p.Hp - 1)) == 0 ? 31 - __clz(p.Hp) : -1;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(e % CG);
-    const int64_t w_ = e / CG;
-    const int px = (int)(w_ % p.Wp), py = (int)((w_ / p.Wp) % p.Hp);
-    const int64_t b = w_ / ((int64_t)p.Wp * p.Hp);
+    int cg, px, py;
+    int64_t w_, b;
+    if (small) {
+      const unsigned u = (unsigned)e;
+      const unsigned w32 = shCG >= 0 ? u >> shCG : u / (unsigned)CG;
+      cg = (int)(u - w32 * (unsigned)CG);
+      const unsigned l32 = shW >= 0 ? w32 >> shW : w32 / (unsigned)p.Wp;
+      px = (int)(w32 - l32 * (unsigned)p.Wp);
+      const unsigned b32 = shH >= 0 ? l32 >> shH : l32 / (unsigned)p.Hp;
+      py = (int)(l32 - b32 * (unsigned)p.Hp);
+      w_ = w32; b = b32;
+    } else {
+      cg = (int)(e % CG);
+      w_ = e / CG;
+      px = (int)(w_ % p.Wp); py = (int)((w_ / p.Wp) % p.Hp);
+      b = w_ / ((int64_t)p.Wp * p.Hp);
+    }
     const float* xb = p.x + b * p.H * p.W;
     float xw[4][4];
 #pragma unroll
@@ -137,12 +155,18 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_bwd_kernel(C1PoolBwd p) {
   const int64_t l_lo = (int64_t)blockIdx.x * p.lpw;
   const int nl = (int)(lines - l_lo < p.lpw ? lines - l_lo : p.lpw);
   const int WS = p.W + 2;
-  for (int i = tid; i < nl * 4 * WS; i += 256) {
-    const int li = i / (4 * WS), r = (i / WS) & 3, c = i % WS - 1;
+  // (staged a row of W + 2 per wave and pass: the row's image / line are wave-uniform, no division per element)
+  for (int row = tid >> 6; row < nl * 4; row += 4) {
+    const int li = row >> 2, r = row & 3;
     const int64_t l = l_lo + li;
     const int py = (int)(l % p.Hp), y = 2 * py - 1 + r;
     const int64_t b = l / p.Hp;
-    xs[i] = (y >= 0 && y < p.H && c >= 0 && c < p.W) ? p.x[(b * p.H + y) * p.W + c] : 0.0f;
+    const bool yok = y >= 0 && y < p.H;
+    const float* xrow = p.x + (b * p.H + (yok ? y : 0)) * p.W;
+    for (int cc = tid & 63; cc < WS; cc += 64) {
+      const int c = cc - 1;
+      xs[row * WS + cc] = (yok && c >= 0 && c < p.W) ? xrow[c] : 0.0f;
+    }
   }
   __syncthreads();
   float acc[9], accb = 0.0f;
