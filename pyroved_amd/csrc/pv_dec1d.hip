@@ -159,12 +159,16 @@ __device__ __forceinline__ f32x4 d1_ev(const D1Op& o, int b, int ob, int lb, int
   return ev;
 }
 
+// element index -> row: the divisors (channel counts, a quarter of them) are powers of two in every stock decoder — a shift behind a
+// uniform branch instead of a 30-instruction division in front of every element of every layer's staging / epilogue loops
+__device__ __forceinline__ int d1_div(int e, int n) { return (n & (n - 1)) == 0 ? e >> (31 - __clz(n)) : e / n; }
+
 // contraction narrower than 16 (the output layer's input gradient: K = output channels of the whole stack): plain FMAs
 template <bool BWD>
 __device__ __forceinline__ void d1_small_k(const D1Op& o, const float* __restrict__ in, float* __restrict__ outb, const float* y) {
   const int Pi = d1_pitch(o.K), Po = d1_pitch(o.N);
   for (int e = threadIdx.x; e < o.L * o.N; e += D1_THREADS) {
-    const int l = e / o.N, n = e - l * o.N;
+    const int l = d1_div(e, o.N), n = e - l * o.N;
     float v = 0.0f;
     for (int tap = 0; tap < o.taps; ++tap)
       for (int k = 0; k < o.K; ++k)
@@ -199,7 +203,7 @@ __device__ __forceinline__ void d1_step(const D1Args& A, int i, int b, float* ld
     const float* gi = lds + o.li;
     float* go = lds + o.lt;
     for (int e = tid; e < o.L * o.K; e += D1_THREADS) {
-      const int l = e / o.K, c = e - l * o.K;
+      const int l = d1_div(e, o.K), c = e - l * o.K;
       go[(l + 1) * P + c] = gi[(2 * l + 1) * P + c] + gi[(2 * l + 2) * P + c];
     }
     d1_zero_halo(go, o.L, o.K);
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
           for (int k = 0; k < 8; ++k) zv[k] = k < A.zd ? A.z[(int64_t)b * A.zd + k] : 0.0f;
         }
         for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
-          const int l = e / c4n, c = 4 * (e - l * c4n);
+          const int l = d1_div(e, c4n), c = 4 * (e - l * c4n);
           f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
           if (A.l2f_b) {
 #pragma unroll
@@ -340,12 +344,12 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
       } else if ((A.C0 & 3) == 0) {
         const int c4n = A.C0 >> 2;
         for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
-          const int l = e / c4n, c4 = e - l * c4n;
+          const int l = d1_div(e, c4n), c4 = e - l * c4n;
           *reinterpret_cast<f32x4*>(&dst[(l + 1) * P + 4 * c4]) = *reinterpret_cast<const f32x4*>(src + (int64_t)l * A.C0 + 4 * c4);
         }
       } else {
         for (int e = tid; e < A.L0 * A.C0; e += D1_THREADS) {
-          const int l = e / A.C0, c = e - l * A.C0;
+          const int l = d1_div(e, A.C0), c = e - l * A.C0;
           dst[(l + 1) * P + c] = src[e];
         }
       }
@@ -367,12 +371,12 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
       if ((o.N & 3) == 0) {
         const int c4n = o.N >> 2;
         for (int e = tid; e < Lout * c4n; e += D1_THREADS) {
-          const int l = e / c4n, c4 = e - l * c4n;
+          const int l = d1_div(e, c4n), c4 = e - l * c4n;
           *reinterpret_cast<f32x4*>(dst + (int64_t)l * o.N + 4 * c4) = *reinterpret_cast<const f32x4*>(&src[(l + 1) * Po + 4 * c4]);
         }
       } else {
         for (int e = tid; e < Lout * o.N; e += D1_THREADS) {
-          const int l = e / o.N, c = e - l * o.N;
+          const int l = d1_div(e, o.N), c = e - l * o.N;
           dst[e] = src[(l + 1) * Po + c];
         }
       }
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
       const float* src = lds + o.lo;
       float acc = 0.0f;
       for (int e = tid; e < per; e += D1_THREADS) {
-        const int l = e / o.N, c = e - l * o.N;
+        const int l = d1_div(e, o.N), c = e - l * o.N;
         float ll, d, lv;
         pv_lik_one(src[(l + 1) * Po + c], A.y[(int64_t)b * per + e], A.lik, A.sigmoid_out, A.sig, ll, d, lv);
         if (A.loc) A.loc[(int64_t)b * per + e] = lv;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
       const float* src = lds + A.op[0].li;
       float* dst = A.a0_out + (int64_t)b * A.L0 * A.C0;
       for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
-        const int l = e / c4n, c4 = e - l * c4n;
+        const int l = d1_div(e, c4n), c4 = e - l * c4n;
         *reinterpret_cast<f32x4*>(dst + (int64_t)l * A.C0 + 4 * c4) = *reinterpret_cast<const f32x4*>(&src[(l + 1) * P + 4 * c4]);
       }
     }
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
       for (int e = tid; e < o.L * c4n; e += D1_THREADS) {
-        const int l = e / c4n, c = 4 * (e - l * c4n);
+        const int l = d1_div(e, c4n), c = 4 * (e - l * c4n);
         const f32x4 g = *reinterpret_cast<const f32x4*>(&g0[(l + 1) * Po + c]);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
