@@ -81,10 +81,19 @@ __device__ __forceinline__ f32x4 en_load_bias(const float* bias, int out_dim, in
   return b;
 }
 
+#ifdef EN_TRACE
+__device__ long long en_trace_p[16];
+#define ENP_STAMP(k) do { if (COHERENT && bx == 0 && by == 0 && threadIdx.x == 0) en_trace_p[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+extern "C" int pv_debug_read_enc_trace_p(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(en_trace_p), 16 * sizeof(long long)); }
+#else
+#define ENP_STAMP(k) do { } while (0)
+#endif
 // ---------------------------------------------------------------------------------------------
 // first encoder layer: eact[0] = act(x W0^T + b0), one workgroup per (16 rows x 16 outputs), K split over 4 waves
 #define L1_WAVES 4
-#define L1_STEPS 4             // k16-steps per register batch
+#ifndef L1_STEPS
+#define L1_STEPS 7             // k16-steps per register batch: at K = 784 a wave's 13 steps are two batches, both requested at once
+#endif                         // (4: three to four batches, two in flight — one more memory round trip per tile; same sums)
 // bx / by: output block / row block (by >= rb: guest workgroups, ny row blocks in all); the first 64 * L1_WAVES threads of the
 // workgroup take part (NW = 4 or 8 waves split K).  Returns true when this workgroup wrote a tile of eact[0] (the merged launch then signals it).
 template <bool COHERENT, int NW>
@@ -97,6 +106,7 @@ __device__ __forceinline__ bool enc_l1_body(const PvEncFwd& e, int bx, int by, i
     pv_fb_prep(e.prep, blk * (64 * NW) + tid, (int64_t)(ny - rb) * nx * (64 * NW), NW, wave);
     return false;
   }
+  ENP_STAMP(0);
   const pv_layer l = e.enc[0];
   const int ob = bx, row0 = by * EN_ROWS, K = l.in_dim;
   const int rowc = min(row0 + r, e.B - 1);
@@ -125,6 +135,7 @@ __device__ __forceinline__ bool enc_l1_body(const PvEncFwd& e, int bx, int by, i
   };
   const int KB = 16 * NW * L1_STEPS;         // k's per batch over the whole workgroup
   load(16 * wave, a[0], b[0]);
+  ENP_STAMP(1);
   for (int k0 = 16 * wave; k0 < K; k0 += 2 * KB) {
     const bool more1 = k0 + KB < K, more2 = k0 + 2 * KB < K;
     if (more1) load(k0 + KB, a[1], b[1]);
@@ -132,6 +143,7 @@ __device__ __forceinline__ bool enc_l1_body(const PvEncFwd& e, int bx, int by, i
     if (more2) load(k0 + 2 * KB, a[0], b[0]);
     if (more1) consume(a[1], b[1]);
   }
+  ENP_STAMP(2);
   const f32x4 c = acc[0] + acc[1];
   // C/D layout: lane (batch row r, q), reg i -> output 16*ob + 4q + i
 #pragma unroll
@@ -150,6 +162,7 @@ __device__ __forceinline__ bool enc_l1_body(const PvEncFwd& e, int bx, int by, i
       else e.eact[0][(int64_t)row * l.out_dim + jo] = y;
     }
   }
+  ENP_STAMP(3);
   return true;
 }
 

@@ -18,3 +18,8 @@ print("rc", lib.pv_debug_read_enc_trace(buf, 64))
 t = [buf[i] for i in range(7)]
 names = ["l0 load + prefetch requests + LDS", "hidden layer 1", "head", "z / KL terms", "block sums", "split latent", "?"]
 print([(names[i], t[i + 1] - t[i]) for i in range(6)], "total", t[6] - t[0])
+
+bp = (C.c_longlong * 16)()
+if hasattr(lib, "pv_debug_read_enc_trace_p") and lib.pv_debug_read_enc_trace_p(bp) == 0 and bp[0]:
+    print("producer tile (0, 0): first requests issued %d | K loop done %d | tile stored %d (cycles from its start); consumer row block 0 started %d cycles %s that producer"
+          % (bp[1] - bp[0], bp[2] - bp[0], bp[3] - bp[0], abs(buf[0] - bp[0]), "after" if buf[0] >= bp[0] else "before"))
