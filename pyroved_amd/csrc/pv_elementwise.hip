@@ -915,14 +915,27 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     for (int c = 0; c < 4; ++c) tp_acc[c] += a[1 + c];
     for (int j = t; j < p.H; j += 256) {
       // ascending slot order (fixed); four independent chains keep the loads in flight
+      // (the same four chains in the same order — slot kk < (kmax & ~3) to chain kk & 3, the rest to chain 0 — but 16 slots requested
+      //  at once, past-the-end ones clamped and added as zeros: the rolled loops waited for memory once per group of four and once per
+      //  leftover slot — three dependent round trips at the usual nine slots, ~2.4 k cycles of this launch's critical path)
       const float* ph = p.part_hz + (s * p.kmax) * p.H + j;
       float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-      int kk = 0;
-      for (; kk + 3 < p.kmax; kk += 4) {
-        v0 += ph[(int64_t)kk * p.H]; v1 += ph[(int64_t)(kk + 1) * p.H];
-        v2 += ph[(int64_t)(kk + 2) * p.H]; v3 += ph[(int64_t)(kk + 3) * p.H];
+      const int k4 = p.kmax & ~3;
+      for (int kk0 = 0; kk0 < p.kmax; kk0 += 16) {
+        float w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = ph[(int64_t)(kk0 + u < p.kmax ? kk0 + u : p.kmax - 1) * p.H];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int kk = kk0 + u;
+          const float x = kk < p.kmax ? w[u] : 0.0f;
+          const bool tail = kk >= k4;
+          if ((u & 3) == 0) v0 += x;
+          else if ((u & 3) == 1) { v1 += tail ? 0.0f : x; v0 += tail ? x : 0.0f; }
+          else if ((u & 3) == 2) { v2 += tail ? 0.0f : x; v0 += tail ? x : 0.0f; }
+          else { v3 += tail ? 0.0f : x; v0 += tail ? x : 0.0f; }
+        }
       }
-      for (; kk < p.kmax; ++kk) v0 += ph[(int64_t)kk * p.H];
       const float v = (v0 + v1) + (v2 + v3);
       p.dhz[s * p.H + j] = v;
       sh_dhz[j] += v;                                  // the same thread owns j in every pass
