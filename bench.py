@@ -502,7 +502,7 @@ def sub_config(name, args):
                "regions_discarded": d.get("regions_discarded"), "value": d["value"],
                "unit": d["unit"], "roofline": d["roofline"], "step_algorithmic_tflops": d.get("step_algorithmic_tflops"),
                "loss_per_image_step0": d["elbo"]["loss_per_image_step0"]}
-        for k in ("roofline_conv", "roofline_step", "fp32_class"):
+        for k in ("roofline_conv", "roofline_step", "fp32_class", "throughput_precision"):
             if k in d:
                 rec[k] = d[k]
         return rec
@@ -578,8 +578,10 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--no-legs", action="store_true", help="skip the trainer / inference legs of the default N=1 run")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's batch is the GLOBAL batch, sharded")
-    ap.add_argument("--fused", type=int, default=int(os.environ.get("PV_BENCH_FUSED", "3")),
-                    help="0 layered, 1 fused f32 MFMA, 2 fused bf16x3 (fp32-class), 3 fused plain bf16")
+    ap.add_argument("--fused", type=int, default=None,
+                    help="lead path: 0 layered, 1 fused f32 MFMA, 2 fp32-class (every gradient to 1e-4: the reference's precision), "
+                         "3 throughput precision (bf16 / one fp16 piece).  Default: 3 for C2 (BASELINE configs[1] names bf16), "
+                         "2 for every other config (BASELINE names no dtype there and the reference is fp32 end to end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the fp32-class path)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of C1, C3, C4, C5")
@@ -621,10 +623,15 @@ def main():
         B = b_cfg
     ctx = (pv, pvdist, td, dev, rank, world, B)
 
+    if args.fused is None:
+        args.fused = int(os.environ.get("PV_BENCH_FUSED", "3" if name == "C2" else "2"))
     main_leg = measure(args, name, cfg, args.fused, ctx)
     alt = None
-    if args.fused == 3 and not args.no_alt:
-        alt = measure(args, name, cfg, 2, ctx)      # the same workload on the fp32-class path
+    if args.fused in (2, 3) and not args.no_alt:
+        alt = measure(args, name, cfg, 5 - args.fused, ctx)      # the same workload on the other precision
+    # which leg is the fp32-class one (the reference's precision: what C1 / C3 / C4 / C5 lead with) and which the throughput one
+    fp32_leg = main_leg if args.fused == 2 else (alt if args.fused == 3 else None)
+    alt_key = "fp32_class" if args.fused == 3 else "throughput_precision"
     strong = None
     if world > 1 and not args.strong and b_cfg % world == 0 and not args.no_alt:
         # N > 1: the other scaling too — the config's batch as the GLOBAL batch, sharded (at batch 256 / 28x28 this is
@@ -635,7 +642,7 @@ def main():
         # N > 1: the conv config too (weak scaling, 256 images per GPU) — its 0.75 ms step hides the all-reduce's latency far
         # better than C2's 0.12 ms, so it is the config whose curve can reach the >= 6x target
         try:
-            c5w = measure(args, "C5", CONFIGS["C5"], args.fused, (pv, pvdist, td, dev, rank, world, CONFIGS["C5"]["batch"]))
+            c5w = measure(args, "C5", CONFIGS["C5"], 2, (pv, pvdist, td, dev, rank, world, CONFIGS["C5"]["batch"]))
         except Exception as e:                   # (must not take the headline line down)
             c5w = {"error": repr(e)[:300]}
     if rank == 0:
@@ -658,8 +665,16 @@ def main():
         for k in ("roofline_conv", "roofline_step", "allreduce_ms", "allreduce_ms_samples"):
             if k in main_leg:
                 out[k] = main_leg[k]
+        # driver-visible scalars inside `roofline` (a key the driver's record keeps): the step-level fraction of the lead leg and
+        # the fp32-class leg's step time / kernel fraction / step fraction, whichever leg that is
+        out["roofline"] = dict(out["roofline"])
+        out["roofline"]["step_frac"] = main_leg["step_algorithmic_tflops"] / MFMA_BF16_PEAK_TFLOPS
+        if fp32_leg is not None:
+            out["roofline"]["fp32_class_ms"] = fp32_leg["ms_per_step"]
+            out["roofline"]["fp32_class_frac"] = fp32_leg["roofline"]["frac"]
+            out["roofline"]["fp32_class_step_frac"] = fp32_leg["step_algorithmic_tflops"] / MFMA_BF16_PEAK_TFLOPS
         if alt is not None:
-            out["fp32_class"] = {"path": alt["path"], "dtype": alt["dtype"], "value": alt["value"], "unit": "images/s",
+            out[alt_key] = {"path": alt["path"], "dtype": alt["dtype"], "value": alt["value"], "unit": "images/s",
                                  "ms_per_step": alt["ms_per_step"], "ms_per_step_all": alt["ms_per_step_all"],
                                  "regions_discarded": alt["regions_discarded"],
                                  "kernel": alt["roofline"].get("kernel"),
@@ -667,9 +682,9 @@ def main():
                                  "roofline_traffic": alt["roofline"].get("traffic"),
                                  "loss_per_image_step0": alt["loss_per_image_step0"]}
             if "roofline_conv" in alt:
-                out["fp32_class"]["roofline_conv"] = alt["roofline_conv"]
+                out[alt_key]["roofline_conv"] = alt["roofline_conv"]
             if "allreduce_ms" in alt:
-                out["fp32_class"]["allreduce_ms"] = alt["allreduce_ms"]
+                out[alt_key]["allreduce_ms"] = alt["allreduce_ms"]
         if strong is not None:
             out["strong"] = {"scaling": "strong", "global_batch": b_cfg, "batch_per_gpu": b_cfg // world,
                              "value": strong["value"], "unit": "images/s", "ms_per_step": strong["ms_per_step"],
@@ -717,6 +732,10 @@ def main():
         if "fp32_class" in out:
             summ.update(fp32_class_ms=round(out["fp32_class"]["ms_per_step"], 5), fp32_class_images_s=round(out["fp32_class"]["value"]),
                         fp32_class_kernel_ms=out["fp32_class"].get("kernel_ms"), fp32_class_frac=out["fp32_class"].get("roofline_frac"))
+        elif fp32_leg is not None:
+            summ.update(fp32_class_ms=round(fp32_leg["ms_per_step"], 5), fp32_class_images_s=round(fp32_leg["value"]),
+                        fp32_class_kernel_ms=fp32_leg["roofline"].get("kernel_ms"), fp32_class_frac=fp32_leg["roofline"]["frac"])
+        summ["step_frac"] = round(out["roofline"]["step_frac"], 4)
         tr, inf = out.get("trainer") or {}, out.get("inference") or {}
         if isinstance(tr.get("bf16"), dict):
             summ["trainer_images_s"] = round(tr["bf16"]["value"])
@@ -728,9 +747,10 @@ def main():
                 summ[k_dst] = round(inf[k_src])
         for c in out.get("configs") or []:
             if isinstance(c, dict) and "ms_per_step" in c and "config" in c:
+                # (side configs lead with the fp32-class leg: `<config>_ms` IS the reference-precision step)
                 summ["%s_ms" % str(c["config"]).lower()] = round(c["ms_per_step"], 4)
-                if isinstance(c.get("fp32_class"), dict) and "ms_per_step" in c["fp32_class"]:
-                    summ["%s_fp32_class_ms" % str(c["config"]).lower()] = round(c["fp32_class"]["ms_per_step"], 4)
+                if isinstance(c.get("throughput_precision"), dict) and "ms_per_step" in c["throughput_precision"]:
+                    summ["%s_throughput_ms" % str(c["config"]).lower()] = round(c["throughput_precision"]["ms_per_step"], 4)
         front = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data")
         ordered = {k: out[k] for k in front}

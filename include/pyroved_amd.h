@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 14
+#define PV_ABI_VERSION 15
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
@@ -207,12 +207,27 @@ typedef struct pv_ivae_plan {
   void*   conv_ev_start;
   void*   conv_ev_stop;
   double* conv_ev_flops;
+  /* ---- (v15) which build of the fused decoder kernel runs: 0 = the library's choice by problem size (what every caller
+   *   wants).  Non-zero values exist for parity tests and A/B timing of the other builds on the same inputs — a PLAN field:
+   *   rounds 3-4 had process-wide debug setters.  fused == 3: 1 the 4-wave kernel, 2 the 8-wave kernel
+   *   (pv_sdec_fused_w8.hip).  fused == 2: 1 the bf16 three-product kernel, 21 / 28 the fp16 builds H221 / H231
+   *   (pv_sdec_fused_bf16.hip); forward-only launches ignore 21 / 28.  Further values name dropped variants that only
+   *   the experiments build of the library contains (csrc/Makefile `experiments`); elsewhere they are PV_EINVAL. ---- */
+  int32_t dec_kernel;
+  int32_t reserved0;
 } pv_ivae_plan;
 
 /* Library / ABI version (PV_ABI_VERSION). */
 int pv_version(void);
+/* (v15) 1 when the library is the -DPV_EXPERIMENTS build (csrc/Makefile `experiments`: environment A/B switches and the
+ * dropped kernel variants compiled in), 0 for the shipped one (no environment switch besides PV_ROCTX). */
+int pv_experiments_build(void);
 
-/* (v14) Per-plan switches that rounds 2-3 kept in process-wide setters (`flags` of pv_ivae_plan / pv_ved_plan):
+/* (v14) Per-plan switches that rounds 2-3 kept in process-wide setters (`flags` of pv_ivae_plan / pv_ved_plan /
+ * pv_convnet_plan).  (v15) The library reads NO environment variable besides PV_ROCTX (roctx ranges) and keeps no mutable
+ * process-wide switch: the v12 / v13 setters pv_conv_set_wide_weights / pv_set_side_stream are REMOVED (a binding that still
+ * looks them up fails at load instead of silently doing nothing), the test hooks of rounds 3-4 are the plan fields below and
+ * pv_ivae_plan.dec_kernel.
  *   PV_PLAN_ENC_TWO_LAUNCH  the compact fc encoder as two launches (first layer, then the rest) instead of one grid whose
  *                           second half waits on per-tile flags — e.g. for a caller that wants no in-launch hand-off;
  *   PV_PLAN_NO_SIDE_STREAM  steps with a convolutional encoder (VED, iVAE + convEncoderNet) keep every launch on the caller's
@@ -220,7 +235,7 @@ int pv_version(void);
  *                           batched weight gradients and their split-order reductions run on a second, low-priority stream the
  *                           library creates per device; the caller's stream waits for it before the entry point's last
  *                           launches (nothing is left running that the caller's stream does not wait for; bit-identical
- *                           either way).  Also PV_NO_SIDE=1 in the environment, and never while the stream is captured.
+ *                           either way).  Never while the stream is captured.
  * The numeric range of the convolution kernels is pv_ivae_plan.conv_wide / conv_bf16 == 2 of pv_ved_plan and
  * pv_convnet_plan: the default fp32-class form carries kernel-3 weights as two fp16 pieces of w * 64, valid for
  * 1e-6 < max|w| < 1023; the wide form uses three bf16 pieces (no range limit, same accuracy, ~1.5x the matrix time).  The
@@ -229,10 +244,13 @@ int pv_version(void);
  * No reference counterpart: the reference's nn.Conv2d is plain fp32 on torch's current stream (nets/conv.py:24-60). */
 #define PV_PLAN_ENC_TWO_LAUNCH 1
 #define PV_PLAN_NO_SIDE_STREAM 2
-/* (v12 / v13, deprecated since v14: no effect — the switches are plan fields now; kept for one version so that existing
- * bindings load) */
-void pv_conv_set_wide_weights(int on);
-void pv_set_side_stream(int on);
+/* (v15) PV_PLAN_ENC_NO_WAIT: the one-launch encoder's consumers do not poll the producers' flags at all and compute their
+ *   first-layer tiles themselves (the bounded-poll fallback taken at once: bit-identical results, redundant work) — the
+ *   parity test of that path, and a caller that wants no cross-workgroup hand-off but one launch.
+ * PV_PLAN_NO_DEC1D (pv_ved_plan): the Conv1d decoder runs layer by layer instead of as one forward and one
+ *   input-gradient launch (csrc/pv_dec1d.hip) — the launches that form replaced, kept as its parity reference. */
+#define PV_PLAN_ENC_NO_WAIT    4
+#define PV_PLAN_NO_DEC1D       8
 
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
  * layer widths).  Returns < 0 on an unsupported plan. */
@@ -404,6 +422,7 @@ typedef struct pv_convnet_plan {
   int32_t bn_eval;                     /* batch norm on the running statistics (module.eval())                 */
   int32_t conv_bf16;                   /* 0: fp32-class, 1: mixed, 2: fp32-class wide, 3: one fp16 piece (as pv_ved_plan) */
   int32_t need_dx;                     /* the backward will be asked for dL/dx (set at forward time too)       */
+  int32_t flags;                       /* (v15) PV_PLAN_NO_SIDE_STREAM: every launch on the caller's stream    */
   pv_op   ops[PV_MAX_OPS];
   const float* params;                 /* flat buffer the ops' offsets refer to (running statistics included)  */
   float*  grads;                       /* same layout (backward only)                                          */

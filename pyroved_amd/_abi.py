@@ -13,8 +13,9 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 14
-PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM = 1, 2     # pv_ivae_plan.flags / pv_ved_plan.flags
+PV_ABI_VERSION = 15
+# pv_ivae_plan.flags / pv_ved_plan.flags / pv_convnet_plan.flags
+PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM, PV_PLAN_ENC_NO_WAIT, PV_PLAN_NO_DEC1D = 1, 2, 4, 8
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -22,7 +23,10 @@ ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2, "lrelu": 3, "softplus": 4, "gel
 LIK = {"bernoulli": 0, "gaussian": 1, "continuous_bernoulli": 2}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PV_LIB_PATH") or os.path.join(_HERE, "libpyroved_amd.so")   # override: kernel experiments only
+# PV_LIB_PATH: the experiments build (csrc/Makefile `experiments`: libpyroved_amd_exp.so) or a profiling build; the shipped
+# library itself reads no environment variable besides PV_ROCTX
+LIB_PATH = os.environ.get("PV_LIB_PATH") or os.path.join(_HERE, "libpyroved_amd.so")
+EXP_LIB_PATH = os.path.join(_HERE, "libpyroved_amd_exp.so")
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -71,6 +75,7 @@ class pv_ivae_plan(C.Structure):
         ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
         ("class_onehot", C.c_void_p),
         ("conv_ev_start", C.c_void_p), ("conv_ev_stop", C.c_void_p), ("conv_ev_flops", C.c_void_p),
+        ("dec_kernel", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -98,6 +103,7 @@ class pv_convnet_plan(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("ndim", C.c_int32), ("in_ch", C.c_int32), ("in_dim", C.c_int32 * 2),
         ("n_ops", C.c_int32), ("bn_eval", C.c_int32), ("conv_bf16", C.c_int32), ("need_dx", C.c_int32),
+        ("flags", C.c_int32),
         ("ops", pv_op * PV_MAX_OPS),
         ("params", C.c_void_p), ("grads", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
@@ -120,8 +126,7 @@ class pv_mlp_plan(C.Structure):
 # name -> (restype, argtypes); must list every function include/pyroved_amd.h declares
 SIGNATURES = {
     "pv_version": (C.c_int, []),
-    "pv_conv_set_wide_weights": (None, [C.c_int]),
-    "pv_set_side_stream": (None, [C.c_int]),
+    "pv_experiments_build": (C.c_int, []),
     "pv_ivae_workspace_bytes": (C.c_int64, [C.POINTER(pv_ivae_plan)]),
     "pv_ivae_workspace_bytes_for": (C.c_int64, [C.POINTER(pv_ivae_plan), C.c_int]),
     "pv_ved_workspace_bytes": (C.c_int64, [C.POINTER(pv_ved_plan)]),

@@ -33,6 +33,21 @@ int pv_set_dynamic_lds(const void* fn, int bytes);   // pv_side.hip
 // the current device's LDS per workgroup (bytes; 0 when unknown)
 int pv_device_lds_limit();
 
+// ---- experiment switches.  The shipped library has NO environment switches besides PV_ROCTX (pv_side.hip) and no mutable
+// process-wide state: every A/B knob of the kernel experiments (NOTES.md) is pv_exp_int(name, default), which is the
+// compile-time constant `default` here and reads the environment only in the -DPV_EXPERIMENTS build
+// (`make experiments` -> libpyroved_amd_exp.so, loaded through PV_LIB_PATH by scripts/ and by the tests of dropped variants).
+#ifdef PV_EXPERIMENTS
+#include <stdlib.h>
+static inline const char* pv_exp_str(const char* name) { return getenv(name); }
+static inline int pv_exp_int(const char* name, int dflt) { const char* e = pv_exp_str(name); return e ? atoi(e) : dflt; }
+static inline long long pv_exp_ll(const char* name, long long dflt) { const char* e = pv_exp_str(name); return e ? atoll(e) : dflt; }
+#else
+static inline constexpr const char* pv_exp_str(const char*) { return nullptr; }
+static inline constexpr int pv_exp_int(const char*, int dflt) { return dflt; }
+static inline constexpr long long pv_exp_ll(const char*, long long dflt) { return dflt; }
+#endif
+
 #define PV_TRY(expr)                           \
   do {                                         \
     int r__ = (expr);                          \

@@ -110,7 +110,7 @@ int pv_c1_convpool_fwd(const float* x, int B, int H, int W, const float* w, cons
                        unsigned char* code, hipStream_t s) {
   if (!pv_c1_convpool_supported(1, Cout, 2, act, H, W)) return PV_EINVAL;
   C1Pool p{x, w, bias, out, code, B, H, W, Cout, act, H / 2, W / 2};
-  static const int cv_env = getenv("PV_C1_CV") ? atoi(getenv("PV_C1_CV")) : 2;            // PV_C1_CV=1|2|4: float4 channel groups per thread (A/B timing)
+  static const int cv_env = pv_exp_int("PV_C1_CV", 2);            // PV_C1_CV=1|2|4: float4 channel groups per thread (A/B timing)
   const int cv = (cv_env == 4 && Cout % 16 == 0) ? 4 : (cv_env >= 2 && Cout % 8 == 0) ? 2 : 1;
   const int64_t total = (int64_t)B * p.Hp * p.Wp * (Cout / (4 * cv));
   int64_t nb = (total + 255) / 256;

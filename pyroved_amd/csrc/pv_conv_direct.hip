@@ -241,8 +241,8 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
     // one sample per tile would be more than two rounds of workgroups: a workgroup's time is its chain of K-loop stages
     // whatever the tile holds, so below that the emptier tiles cost nothing and packing only removes parallelism
     // (measured on VED C5, batch 256: +10 us per step with packing).  PV_PACK1D=0 / 1: never / always.
-    static int pack_env = -2;
-    if (pack_env == -2) { const char* e_ = getenv("PV_PACK1D"); pack_env = e_ ? (atoi(e_) != 0 ? 1 : 0) : -1; }
+    static const int pack_raw = pv_exp_int("PV_PACK1D", -1);
+    const int pack_env = pack_raw < 0 ? -1 : (pack_raw != 0 ? 1 : 0);
     p.spt = 1;
     if (nd == 1 && H >= 8 && H <= CD_PIX / 2 && (pack_env == 1 || (pack_env == -1 && (int64_t)B * nt > 1024))) p.spt = CD_PIX / H;
     const int npb = p.spt > 1 ? p.spt * (H + 2) : npix;
@@ -250,8 +250,7 @@ int pv_conv3_direct(const float* in, int B, int H, int W, int nd, const float* w
     const dim3 gridb((unsigned)(p.spt > 1 ? (B + p.spt - 1) / p.spt : p.tiles_x * p.tiles_y * B), (unsigned)nt);
     // PV_RES1D=1: the all-chunks-in-flight form (NCH > 0).  Off by default: measured +10 us per VED C5 step against the
     // streaming form once the epilogue's code bloat was gone — the stages were never memory-latency chains
-    static int res_env = -1;
-    if (res_env < 0) { const char* e_ = getenv("PV_RES1D"); res_env = (e_ && atoi(e_) != 0) ? 1 : 0; }
+    static const int res_env = pv_exp_int("PV_RES1D", 0) != 0 ? 1 : 0;
     const int nchr = (res_env && nd == 1 && C / 32 <= 4) ? C / 32 : 0;
 #define CB_LAUNCH(F, N) PV_LAUNCH_FORK((pv_conv3_direct_bf16_kernel<F, N>), gridb, dim3(256), ldsb, s, p)   /* (carries an armed fork event: pv_side.h) */
     if (use_bf16 == 2) {

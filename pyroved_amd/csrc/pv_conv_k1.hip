@@ -208,8 +208,7 @@ static int k1_launch(K1Fwd a, int64_t w_elems, hipStream_t s) {
     const int64_t units = ((a.rows + 15) / 16) * a.ngroups;
     PV_LAUNCH_FORK(pv_k1_gen_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a);
   } else {
-    static int nb_env = -1;                            // PV_K1_NB=1|2|4: 16-output blocks per wave (experiments)
-    if (nb_env < 0) { const char* e_ = getenv("PV_K1_NB"); nb_env = e_ ? atoi(e_) : 0; }
+    static const int nb_env = pv_exp_int("PV_K1_NB", 0);   // PV_K1_NB=1|2|4: 16-output blocks per wave (experiments build)
     int nb = a.N > 16 ? 2 : 1;                         // (measured on VED C5: 2 blocks per wave -9 us per step against 4 — more waves)
     if (nb_env == 1 || nb_env == 2 || nb_env == 4) nb = (a.N > 16 * (nb_env / 2)) ? nb_env : nb;
     a.ngroups = (a.N + 16 * nb - 1) / (16 * nb);
@@ -446,8 +445,7 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_table_kernel(K1Tab t) {
 static int k1_wg_splits(int64_t rows, int Ci, int Co, int taps) {
   const int64_t tiles = (int64_t)((Co + 15) / 16) * ((Ci + 15) / 16) * taps;
   int64_t ns = (rows + 4 * K1_WB - 1) / (4 * K1_WB);          // one register batch per wave
-  static int cap_env = -1;                                     // PV_K1_WCAP=n: workgroup target of the weight gradient (experiments)
-  if (cap_env < 0) { const char* e_ = getenv("PV_K1_WCAP"); cap_env = e_ ? atoi(e_) : 0; }
+  static const int cap_env = pv_exp_int("PV_K1_WCAP", 0);      // PV_K1_WCAP=n: workgroup target of the weight gradient (experiments build)
   const int64_t target = cap_env > 0 ? cap_env : (taps == 3 ? 4096 : 1024);    // (measured on VED C5: 4096 for the three-tap form -7 us)
   const int64_t cap = (target + tiles - 1) / tiles;            // ~4 workgroups per CU in all
   if (ns > cap) ns = cap;
@@ -478,10 +476,10 @@ static int k1_wgrad_launch(const float* g, const float* in, int64_t rows, int L,
   a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
   a.nblk = a.mtiles * a.ntiles * taps * a.nsplit;
   if (deferred && defer->k1b && defer->k1b->n < PV_K1_BATCH) {          // recorded: launched by pv_k1_wgrad_flush
-    static const int fat_env = getenv("PV_K1_NOFAT") && atoi(getenv("PV_K1_NOFAT")) ? 0 : 1;
+    static const int fat_env = pv_exp_int("PV_K1_NOFAT", 0) ? 0 : 1;
     if (fat_env && Ci > 16 && Co > 16 && rows * 2 * (int64_t)(Co > Ci ? Co : Ci) * 4 < (int64_t)1 << 31) {                                // the throughput form (never more splits: ws is sized for the lean one)
       const int wb = taps == 3 ? 32 : 64;
-      static const int fatb = getenv("PV_K1_FATB") ? atoi(getenv("PV_K1_FATB")) : 2;   // register batches per wave (experiments)
+      static const int fatb = pv_exp_int("PV_K1_FATB", 2);   // register batches per wave (experiments)
       const int nbw = fatb >= 1 && fatb <= 16 ? fatb : 2;
       int64_t ns = (rows + 4 * nbw * wb - 1) / (4 * nbw * wb);          // two register batches per wave
       if (ns > a.nsplit) ns = a.nsplit;

@@ -727,10 +727,9 @@ __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
 // 4: two fp16 pieces with exact power-of-two scaling (default; needs |w| * 64 inside fp16's range, i.e. |w| < ~1023 and not
 // all below ~1e-6), 3: three bf16 pieces (no range limit).  The process-wide default is 4 (PV_SP_X6=1 in the environment: 3);
 // a plan whose weights leave the safe range asks for 3 itself (ABI v14: pv_ivae_plan.conv_wide, conv_bf16 == 2 of the other
-// plans; pv_convstack.h sp_fp32_mode) — the setter of v12 / v13 is a no-op kept for one version
-extern "C" void pv_conv_set_wide_weights(int) {}
+// plans; pv_convstack.h sp_fp32_mode); the v12 / v13 setter is gone since v15
 int pv_conv3_sp_fp32_mode() {
-  static const int mode = (getenv("PV_SP_X6") && atoi(getenv("PV_SP_X6"))) ? 3 : 4;
+  static const int mode = pv_exp_int("PV_SP_X6", 0) ? 3 : 4;
   return mode;
 }
 
@@ -756,12 +755,12 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
     PV_LAUNCH_CHECK();
   }
   constexpr int TG = NS == 3 ? 1 : (NS == 1 ? 3 : 3);
-  static const int lds_pad = getenv("PV_SP_LDS_PAD") ? atoi(getenv("PV_SP_LDS_PAD")) : 0;   // (occupancy experiments)
+  static const int lds_pad = pv_exp_int("PV_SP_LDS_PAD", 0);   // (occupancy experiments)
   const size_t lds = (size_t)NS * SP_PPLANE + (size_t)TG * NS * SP_WPLANE + lds_pad;
   const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.B * nt;
   // fewer workgroups than CUs: 32-channel halves fill the chip (measured: 51 -> 37 us on 128 workgroups); with more, the
   // doubled patch staging costs more than the extra round returns (PV_SP_HALVES overrides the limit)
-  static const int split_lim = getenv("PV_SP_HALVES") ? atoi(getenv("PV_SP_HALVES")) : 255;
+  static const int split_lim = pv_exp_int("PV_SP_HALVES", 255);
   ConvSp q = p;
   q.halves = (p.Cout > 32 && wgs <= split_lim) ? 2 : 1;
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(nt * q.halves));
@@ -1263,7 +1262,7 @@ bool sp_pair_capture_fwd(const ConvSp& q, int ncb, dim3 grid, size_t lds) {
   return true;
 }
 void pv_conv3_sp_pair_begin() {
-  static const int on = getenv("PV_NO_SPPAIR") && atoi(getenv("PV_NO_SPPAIR")) ? 0 : 1;
+  static const int on = pv_exp_int("PV_NO_SPPAIR", 0) ? 0 : 1;
   g_pair = SpPairCap{};
   g_pair.on = on != 0;
 }
@@ -1273,7 +1272,7 @@ int pv_conv3_sp_pair_flush(hipStream_t s) {
   // only while the two together are well under two rounds of workgroups (768: conv-encoder iVAE at batch 128 -12 us per step);
   // beyond that each launch fills the chip on its own and interleaving costs (VED at batch 256, every layer paired: +30 us).
   // PV_SPPAIR_MAX overrides.
-  static const int64_t pair_max = getenv("PV_SPPAIR_MAX") ? atoll(getenv("PV_SPPAIR_MAX")) : 768;
+  static const int64_t pair_max = pv_exp_ll("PV_SPPAIR_MAX", 768);
   const int64_t nab = (int64_t)c.gridA.x * c.gridA.y + (int64_t)c.gridB.x * c.gridB.y * c.gridB.z;
   if (c.haveA && c.haveB && nab > pair_max) {
     hipLaunchKernelGGL((pv_conv3_sp_wgrad_kernel<2, 1, true>), c.gridB, dim3(256), c.ldsB, s, c.b);
@@ -1306,7 +1305,7 @@ static int sw_splits(int B, int H, int W, int C, int Cout, int nsp) {
   const int64_t T = (int64_t)B * ((W + 7) / 8) * ((H + 7) / 8);
   const int ciw = (nsp == 2 && C % 64 == 0) ? 64 : 32;           // input channels per workgroup (three planes: 32, for the LDS)
   const int64_t owners = (int64_t)(C / ciw) * ((Cout + 63) / 64);
-  static const int wg_target = getenv("PV_SW_WGS") ? atoi(getenv("PV_SW_WGS")) : 512;
+  static const int wg_target = pv_exp_int("PV_SW_WGS", 512);
   int64_t ns = (wg_target + owners - 1) / owners;                // two workgroups per CU in all
   if (ns > T) ns = T;
   return (int)(ns < 1 ? 1 : ns);

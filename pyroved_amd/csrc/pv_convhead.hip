@@ -136,7 +136,7 @@ int64_t pv_convhead_mfma_ws(int B, int64_t F, int out);
 int pv_convhead_fwd_mfma(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
                          int64_t ws_bytes, hipStream_t s);
 int pv_convhead_wgrad_mfma(const float* dhead, const float* a, float* dw, float* db, int B, int S, int C, int out, hipStream_t s);
-static bool ch_use_mfma() { static const bool on = !(getenv("PV_CONVHEAD_STREAM") && atoi(getenv("PV_CONVHEAD_STREAM"))); return on; }
+static bool ch_use_mfma() { static const bool on = !pv_exp_int("PV_CONVHEAD_STREAM", 0); return on; }
 
 int pv_convhead_fwd(const float* a, const float* wt, const float* bias, float* head, int B, int64_t F, int out, void* ws,
                     int64_t ws_bytes, hipStream_t s) {

@@ -57,7 +57,7 @@ inline bool c1pool_fusable(const pv_op* ops, int n, int nd, const Shape& s0) {
 inline bool convpool_fusable(const pv_op* ops, int n, int nd, int i, const Shape& si) {
   return nd == 2 && i >= 1 && i + 1 < n && ops[i].kind == PV_OP_CONV && ops[i].ksize == 3 && ops[i + 1].kind == PV_OP_MAXPOOL2 &&
          (si.H & 1) == 0 && (si.W & 1) == 0 && (ops[i].cout & 3) == 0 && ops[i].act != PV_ACT_GELU &&
-         pv_conv3_sp_supported(ops[i].cin, ops[i].cout, nd, ops[i].act) && !getenv("PV_NO_CONVPOOL");
+         pv_conv3_sp_supported(ops[i].cin, ops[i].cout, nd, ops[i].act) && !pv_exp_str("PV_NO_CONVPOOL");
 }
 inline int64_t code2_off(const pv_op* ops, int n, int nd, int B, const Shape* sh, int upto) {   // winner bytes before op `upto`
   int64_t off = 0;
@@ -150,8 +150,7 @@ inline int join_tilings(const Scratch& sc, hipStream_t s) {
 // recorded (batched) weight gradients are flushed onto the side stream every k1_chunk() problems, next to the rest of the
 // input-gradient chain (PV_K1_CHUNK=n; 0: one launch after the chain)
 inline int k1_chunk() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PV_K1_CHUNK"); v = e ? atoi(e) : 5; if (v < 0) v = 0; }
+  static const int v = pv_exp_int("PV_K1_CHUNK", 5) < 0 ? 0 : pv_exp_int("PV_K1_CHUNK", 5);
   return v;
 }
 inline bool k1_flush_due(const Scratch& sc) {
@@ -159,8 +158,7 @@ inline bool k1_flush_due(const Scratch& sc) {
 }
 // a layer's weight + input gradient in one launch (pv_conv3_sp_pair) although a side stream is there (PV_SIDE_PAIR=1, A/B)
 inline bool side_keeps_pairs() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PV_SIDE_PAIR"); v = (e && atoi(e) != 0) ? 1 : 0; }
+  static const int v = pv_exp_int("PV_SIDE_PAIR", 0) != 0 ? 1 : 0;
   return v == 1;
 }
 // the stack's heaviest split-operand kernel-3 convolution (most multiply-adds) and its algorithmic FLOPs; -1: none
@@ -244,23 +242,20 @@ inline float* bn_slot(const Scratch& sc, int slot) { return sc.bn + (int64_t)slo
 // one op forward: in (shape si) -> out
 // kernel-1 convolutions on the lean register-fed kernels of pv_conv_k1.hip (PV_NO_K1=1: the LDS-tiled GEMMs, for A/B timing)
 inline bool k1_lean() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PV_NO_K1"); v = (e && atoi(e) != 0) ? 0 : 1; }
+  static const int v = pv_exp_int("PV_NO_K1", 0) != 0 ? 0 : 1;
   return v == 1;
 }
 
 // kernel-3 1-D weight gradients on the kernel-1 family's register-fed kernel (PV_NO_K3LEAN=1: the LDS-tiled direct kernels)
 inline bool k3_lean_1d(int nd) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PV_NO_K3LEAN"); v = (e && atoi(e) != 0) ? 0 : 1; }
+  static const int v = pv_exp_int("PV_NO_K3LEAN", 0) != 0 ? 0 : 1;
   return v == 1 && nd == 1 && k1_lean();
 }
 
 // mixed-precision leg: the register-fed (exact fp32) form too when the weight gradients are batched into one launch
 // (PV_K3LEAN_MIXED=0: keep the bf16 tile kernel there)
 inline bool k3_lean_mixed(const Scratch& sc) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PV_K3LEAN_MIXED"); v = (e && atoi(e) == 0) ? 0 : 1; }
+  static const int v = pv_exp_int("PV_K3LEAN_MIXED", 1) == 0 ? 0 : 1;
   return v == 1 && sc.fin && sc.fin->k1b;
 }
 
@@ -268,8 +263,7 @@ inline bool k3_lean_mixed(const Scratch& sc) {
 // one launch each way — the forward stores every row twice, the backward kernels read the sum of the two rows
 // (PV_NO_K1UP=1: separate upsample launches)
 inline bool k1up_fusable(const pv_op* ops, int n, int nd, int i) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PV_NO_K1UP"); v = (e && atoi(e) != 0) ? 0 : 1; }
+  static const int v = pv_exp_int("PV_NO_K1UP", 0) != 0 ? 0 : 1;
   return v == 1 && k1_lean() && nd == 1 && i >= 0 && i + 1 < n && ops[i].kind == PV_OP_CONV && ops[i].ksize == 1 &&
          ops[i].act == PV_ACT_NONE && ops[i + 1].kind == PV_OP_UPSAMPLE2;
 }
@@ -454,7 +448,7 @@ inline int stack_bwd(const float* params, float* grads, const pv_op* ops, int n,
   const bool c1pool = stack_id == 0 && sc.code && !need_input_grad && c1pool_fusable(ops, n, nd, sh[0]);
   // the max-pool of a fused conv + pool pair un-pooled in the epilogue of the input-gradient launch ABOVE it (pv_conv_sp.hip up_code;
   // PV_NO_UNPOOL_FUSE=1: pv_maxpool2_bwd_code's own launch).  Own gradient buffers only (gown: the side-stream form).
-  static const int unpool_fuse = getenv("PV_NO_UNPOOL_FUSE") && atoi(getenv("PV_NO_UNPOOL_FUSE")) ? 0 : 1;
+  static const int unpool_fuse = pv_exp_int("PV_NO_UNPOOL_FUSE", 0) ? 0 : 1;
   int pool_done_at = -1;                               // index of a pool op whose backward the launch above has written
   for (int i = n - 1; i >= 0; --i) {
     if (i == pool_done_at) {                           // g = dL/d(pre-activation of the convolution below), already un-pooled

@@ -7,7 +7,7 @@
 // multiples of 16 (the last layer's output may be narrower), activations other than GELU, an UPSAMPLE2 only after a kernel-1
 // convolution without activation, lengths that are multiples of 16, every activation of a sample within the LDS buffers
 bool pv_dec1d_supported(const pv_op* ops, int n, int nd, int L0, int C0);
-// the run-time switch (PV_NO_DEC1D=1, pv_debug_dec1d): off = the layer-by-layer launches
+// the experiments build's switch (PV_NO_DEC1D=1; per plan: PV_PLAN_NO_DEC1D): off = the layer-by-layer launches
 bool pv_dec1d_enabled();
 // the stack's weights tiled for both launches (pv_conv_wprep_table kind 8): size and table entries
 int64_t pv_dec1d_wt_floats(const pv_op* ops, int n);

@@ -460,10 +460,9 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
   }
 }
 
-int g_dec1d_on = -1;                                   // -1: environment (PV_NO_DEC1D=1 turns it off)
-bool dec1d_on() {
-  if (g_dec1d_on < 0) { const char* e = getenv("PV_NO_DEC1D"); g_dec1d_on = (e && atoi(e) != 0) ? 0 : 1; }
-  return g_dec1d_on == 1;
+bool dec1d_on() {                                      // (per plan: PV_PLAN_NO_DEC1D; PV_NO_DEC1D=1 in the experiments build)
+  static const bool on = !pv_exp_int("PV_NO_DEC1D", 0);
+  return on;
 }
 
 bool lin_act(int act) { return act == PV_ACT_NONE || act == PV_ACT_RELU || act == PV_ACT_LRELU || act == PV_ACT_TANH ||
@@ -494,8 +493,6 @@ int steps_of(const pv_op* ops, int n, int L0, int C0, Step* st) {
 }
 
 }  // namespace
-
-extern "C" void pv_debug_dec1d(int on) { g_dec1d_on = on < 0 ? -1 : (on ? 1 : 0); }
 
 bool pv_dec1d_enabled() { return dec1d_on(); }
 

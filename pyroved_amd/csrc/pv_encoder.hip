@@ -491,12 +491,9 @@ static unsigned enc_next_gen() {
   return v;
 }
 
-static int g_enc_two = -1;                            // test hook: 1 two launches, 0 one launch, -1 the environment's choice
-extern "C" void pv_debug_enc_two(int two) { g_enc_two = two < 0 ? -1 : (two ? 1 : 0); }
-// polls before a consumer computes its tiles itself.  256 x ~0.5 us is 10-20x what the producers need on an idle GPU; the
-// fallback is exact, so a short limit only costs redundant work.  Test hook: 0 forces every consumer onto the fallback.
-static int g_enc_spin = 256;
-extern "C" void pv_debug_enc_spin_limit(int polls) { g_enc_spin = polls < 0 ? 256 : polls; }
+// Polls before a consumer computes its tiles itself (PvEncFwd::spin_limit, from the plan): 256 x ~0.5 us is 10-20x what the
+// producers need on an idle GPU; the fallback is exact, so a short limit only costs redundant work.  PV_PLAN_ENC_NO_WAIT makes
+// it 0: every consumer takes the fallback (the parity test of that path).  No process-wide state (ABI v15).
 
 int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
   const int rb = (e.B + EN_ROWS - 1) / EN_ROWS;
@@ -507,12 +504,11 @@ int pv_enc_fwd(const PvEncFwd& e, hipStream_t s) {
     extra = (int)((work + (int64_t)cb * 64 * L1_WAVES - 1) / ((int64_t)cb * 64 * L1_WAVES));
     if (extra > 16) extra = 16;
   }
-  static const int two_env = getenv("PV_ENC_TWO") && atoi(getenv("PV_ENC_TWO")) ? 1 : 0;     // (A/B: the two launches)
-  const int two = g_enc_two >= 0 ? g_enc_two : two_env;
+  static const int two = pv_exp_int("PV_ENC_TWO", 0) ? 1 : 0;     // (A/B in the experiments build; per plan: PV_PLAN_ENC_TWO_LAUNCH)
   if (e.flags && !two && !pv_stream_capturing(s)) {    // (a captured launch would replay its generation value: two launches then)
     PvEncFwd m = e;
     m.gen = enc_next_gen();
-    m.spin_limit = g_enc_spin;
+    if (m.spin_limit < 0) m.spin_limit = 256;
     hipLaunchKernelGGL(pv_enc_kernel, dim3((unsigned)(cb * (rb + extra) + rb)), dim3(EN_THREADS), 0, s, m, cb, rb + extra);
     PV_LAUNCH_CHECK();
     return 0;

@@ -279,7 +279,7 @@ int pv_gemm_pick_splits(int M, int N, int K) {
   // aim for >= ~512 workgroups (2 per CU) when the contraction is long enough to split; a split costs a
   // second (finish) launch, ~6 us on the stream, so short contractions are never split
   const int64_t tiles = (int64_t)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
-  static const int few_env = getenv("PV_GEMM_NO_FEWSPLIT") && atoi(getenv("PV_GEMM_NO_FEWSPLIT")) ? 0 : 1;
+  static const int few_env = pv_exp_int("PV_GEMM_NO_FEWSPLIT", 0) ? 0 : 1;
   if (few_env && tiles < 64 && K >= 256 && K <= 1024) {
     // a handful of tiles over a medium contraction (a 256 x 787 -> 128 encoder layer: 8 workgroups walking 25 stages, 24 us):
     // at least 128 of k per split, ~128 workgroups in all — the walk shrinks to 4-5 stages, the finish launch costs ~4 us

@@ -71,8 +71,11 @@ struct Layout {
 // jiVAE (discrete_dim = K > 0): K decoder samples per input, ordered [k][b]; head = [mu | softplus input | class logits]
 static inline int64_t plan_K(const pv_ivae_plan* p) { return p->discrete_dim > 0 ? p->discrete_dim : 0; }
 // conv mode of the convolutional encoder (pv_convstack.h: 0 fp32-class fp16 pieces, 1 mixed, 2 fp32-class three bf16 pieces,
-// 3 one fp16 piece)
-static inline int plan_conv_mode(const pv_ivae_plan* p) { return p->fused == 3 ? 3 : (p->conv_wide ? 2 : 0); }   // fused == 3: the throughput precision
+// 3 one fp16 piece).  fused == 3 is the throughput precision; conv_wide (a weight left fp16's range) selects the range-free
+// bf16 forms of either precision
+static inline int plan_conv_mode(const pv_ivae_plan* p) {
+  return p->fused == 3 ? (p->conv_wide ? 1 : 3) : (p->conv_wide ? 2 : 0);
+}
 static inline int64_t plan_S(const pv_ivae_plan* p) { return (plan_K(p) > 0 ? plan_K(p) : 1) * (int64_t)p->batch; }
 static inline int64_t plan_head_w(const pv_ivae_plan* p) { return 2 * (int64_t)p->z_dim + plan_K(p); }
 static inline int64_t plan_lat_in(const pv_ivae_plan* p) {
@@ -95,6 +98,7 @@ bool valid_plan(const pv_ivae_plan* p) {
   if (p->lik != PV_LIK_GAUSSIAN && !p->sigmoid_out) return false;   // probs outside (0,1): unsupported
   if (p->coord_dim > 0 && p->out.out_dim != 1) return false;
   if (p->coord_dim == 0 && p->out.out_dim != p->n_pix) return false;
+  if (p->dec_kernel != 0 && !pv_sdec_fused_sel_valid(p->fused, p->dec_kernel)) return false;
   return true;
 }
 
@@ -179,12 +183,12 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       const int64_t units = R / FD_UNIT;
       L.f_grid = pv_sdec_fused_grid(units);
       L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
-      if (p->fused >= 2) L.f_kmax *= pv_sdec_fused_bf16_waves(p->fused == 2, units);   // the bf16 kernels publish dL/d(hz) per wave
+      if (p->fused >= 2) L.f_kmax *= pv_sdec_fused_bf16_waves(p->fused == 2, units, p->dec_kernel);   // the bf16 kernels publish dL/d(hz) per wave
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
       L.f_part_hz = c.take(S * L.f_kmax * H0);
       L.f_rowtp = c.take(4 * R);
       L.f_wimg = c.take(FB_WIMG_BYTES / (int64_t)sizeof(float));
-      const int64_t park = (p->fused == 2 && !inference_only) ? pv_sdec_fused_bf16_park_bytes(true, units, L.f_grid) : 0;
+      const int64_t park = (p->fused == 2 && !inference_only) ? pv_sdec_fused_bf16_park_bytes(true, units, L.f_grid, p->dec_kernel) : 0;
       L.f_park = park ? c.take(park / (int64_t)sizeof(float)) : nullptr;
       upd(pv_colsum_ws(B, (int)H0));
     }
@@ -356,7 +360,7 @@ int conv_encoder_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, cons
   // the weight tilings next to the fused first block (raw weights) on the side stream; stack_fwd joins before its first tiled op
   hipStream_t side = pv_side_stream_for(s, p->flags);
   bool wt_join = false;
-  static const int wprep_side = getenv("PV_SIDE_WPREP") && atoi(getenv("PV_SIDE_WPREP")) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
+  static const int wprep_side = pv_exp_int("PV_SIDE_WPREP", 0) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
   if (wprep_side && side && sc.code && pvcs::c1pool_fusable(p->enc_ops, p->n_enc_ops, p->enc_ndim, L.ces[0])) {
     PV_TRY(pv_stream_after(side, s));
     PV_TRY(pvcs::wt_prep(p->params, p->enc_ops, p->n_enc_ops, p->enc_ndim, 0, plan_conv_mode(p), L.cwtp, L.cwt, true, side, &he,
@@ -537,7 +541,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
     if (fin && n_extra < 1) PV_TRY(pv_finish_scalars(fin->llb, fin->B, fin->scalars, fin->kl_part, fin->n_part, fin->beta, s));
     // (the loss scalars ride in the first of these launches; every other gradient is final by now, so pv_ivae_step's Adam update
     //  rides in the last one: its own outputs in its epilogue, the rest of the flat buffer by guest workgroups)
-    static const int ab_adam = getenv("PV_CONV_ADAM_RIDE") ? atoi(getenv("PV_CONV_ADAM_RIDE")) : 1;
+    static const int ab_adam = pv_exp_int("PV_CONV_ADAM_RIDE", 1);
     for (int i = 0; i < n_extra; i += 4) {
       const bool last = i + 4 >= n_extra;
       const bool ride = last && adam && adam_done && ab_adam && B <= 4096;
@@ -680,6 +684,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
     if (p->coord_dim > 0) { e.hz = L.hz; e.Wz = p->params + p->fc_latent.w_off; e.H0 = p->fc_coord.out_dim; }
     e.hz_scale = hz_scale;
     e.flags = (p->flags & PV_PLAN_ENC_TWO_LAUNCH) ? nullptr : L.enc_flags;
+    e.spin_limit = (p->flags & PV_PLAN_ENC_NO_WAIT) ? 0 : 256;
     e.B = p->batch; e.z_dim = p->z_dim; e.c_dim = p->c_dim; e.coord_dim = p->coord_dim;
     e.has_r = p->has_r; e.has_t = p->has_t; e.has_s = p->has_s;
     e.tp0 = p->t_prior[0]; e.tp1 = p->t_prior[1]; e.sc_prior = p->sc_prior;
@@ -688,7 +693,7 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
   if (prep && !L.enc_conv) return PV_EINVAL;      // (stand-alone preparation on this path)
   // a conv encoder in front of the spatial decoder (hzr): the conv head's partial sums, this head and fc_latent in ONE launch of
   // ceil(B / 16) workgroups (PV_HEAD_MERGE=0: the four launches)
-  static const int ab_merge = getenv("PV_HEAD_MERGE") ? atoi(getenv("PV_HEAD_MERGE")) : 1;
+  static const int ab_merge = pv_exp_int("PV_HEAD_MERGE", 1);
   const bool blocks = ab_merge && hzr && L.enc_conv && !L.enc_ext && plan_K(p) == 0 && p->head.out_dim == (int)plan_head_w(p);
   PvHeadPart hp;
   if (!L.enc_ext) PV_TRY(encoder_fwd(p, L, s, prep, blocks ? &hp : nullptr));
@@ -747,7 +752,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.wimg = L.f_wimg; f.park = L.f_park;
   f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)S; f.lik = p->lik;
   f.sw = K > 0 ? L.sw : p->row_w; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
-  f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig;
+  f.sigmoid_out = p->sigmoid_out; f.kmax = L.f_kmax; f.sig = p->decoder_sig; f.sel = p->dec_kernel;
   // fp16 builds of the fp32-class kernel: where the per-row exponent of dL/dlogit is centred (|dL/dlogit| <= 1 for the Bernoulli
   // likelihoods; ~ residual / sig^2 for the Gaussian): exact powers of two either way, only the representable RANGE moves
   f.dl_exp = 4;
@@ -816,16 +821,15 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   lb.K = (int)K; lb.alpha = L.alpha; lb.beta_disc = p->beta_disc;
   hb.w = p->row_w; lb.row_ll = p->row_elbo ? L.row_ll : nullptr; lb.dzc_out = p->dy ? L.dzc : nullptr;
   // compact encoder: every sample's dgrad chain runs in its latent_bwd workgroup (one dependent launch less)
-  static int chain_env = -1;          // PV_CHAIN=0: keep pv_enc_dgrad as its own launch (A/B timing)
-  if (chain_env < 0) { const char* e_ = getenv("PV_CHAIN"); chain_env = (e_ && atoi(e_) == 0) ? 0 : 1; }
+  static const int chain_env = pv_exp_int("PV_CHAIN", 1) ? 1 : 0;          // PV_CHAIN=0: keep pv_enc_dgrad as its own launch (A/B timing, experiments build)
   const bool chain = chain_env && L.enc_compact && !L.enc_ext && 2 * z + K <= 256;
   if (chain) {
     lb.enc_n = p->n_enc; lb.enc_params = p->params; lb.enc_head = p->head;
     for (int i = 0; i < p->n_enc; ++i) { lb.enc_l[i] = p->enc[i]; lb.enc_act[i] = L.eact[i]; lb.enc_dp[i] = L.edp[i]; }
   }
   // conv encoder with a side stream: the head's weight gradient forks off this launch (encoder_bwd)
-  static const int ab_side = getenv("PV_HEAD_SIDE") ? atoi(getenv("PV_HEAD_SIDE")) : 1;
-  static const int ab_fin = getenv("PV_FIN_RIDE") ? atoi(getenv("PV_FIN_RIDE")) : 1;
+  static const int ab_side = pv_exp_int("PV_HEAD_SIDE", 1);
+  static const int ab_fin = pv_exp_int("PV_FIN_RIDE", 1);
   const bool head_side = ab_side && L.enc_conv && !L.enc_ext && pv_side_stream_for(s, p->flags) && !pv_convhead_wgrad_uses_ws() &&
                          pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   if (head_side) pv_fork_arm();
@@ -971,6 +975,13 @@ int loss_and_grads_layered(const pv_ivae_plan* p, const Layout& L, int want_grad
 }  // namespace
 
 extern "C" int pv_version(void) { return PV_ABI_VERSION; }
+extern "C" int pv_experiments_build(void) {
+#ifdef PV_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // the plan pv_ivae_decode works on; jiVAE.decode(z, y) (jivae.py:255-267) is one decoder row block
 // per given (z, one-hot class) pair — the class vector is a conditioning input there, not an enumeration axis
@@ -1030,6 +1041,7 @@ static int decode_fused_run(const pv_ivae_plan* lay, const float* z, float angle
   f.llrow = nullptr; f.loc = loc; f.wimg = D.wimg;
   f.M = B * N; f.units = f.M / FD_UNIT; f.N = (int)N; f.cd = lay->coord_dim; f.B = (int)B;
   f.lik = PV_LIK_GAUSSIAN; f.sigmoid_out = lay->sigmoid_out; f.sig = 1.0f;      // loc = sigmoid(a) or a
+  f.sel = lay->dec_kernel;
   const int grid = pv_sdec_fused_grid(f.units);
   if (lay->fused == 1) return pv_sdec_fused_launch(f, grid, false, s);
   f.hz_scale = 0.0f;                                   // hz is written unscaled here; the 8-wave kernels scale it themselves

@@ -36,6 +36,7 @@ struct PvFused {
   int ablate;            // profiling only (env PV_FD_ABLATE): 1 skip wgrad exchanges, 2 skip coord-layer exchange,
                          // 4 skip dgrad, 8 skip d(wo) reduction  -> wrong gradients, used to price the phases
   float sig;
+  int sel;               // pv_ivae_plan.dec_kernel: which build of the decoder kernel runs (0: by problem size; pv_sdec_fused_bf16.hip)
   int dl_exp;            // fp16 modes (pv_sdec_fused_bf16.hip): exponent bias of the per-row dL/dlogit factor folded into the
                          // staged activations: 2^dl_exp * |dL/dlogit| should sit around 1 .. 2^8 (Bernoulli 4; Gaussian: -log2(1 / sig^2))
 };
@@ -65,9 +66,11 @@ int64_t pv_sdec_fused_w8x3_park_bytes(int grid);
 // the 8-wave fp16 kernel of the fp32-class path (pv_sdec_fused_w8h.hip; training launches; prep mode 2); ds: dL/dpre split
 int pv_sdec_fused_w8h_launch(const PvFused& f, int grid, bool ds, hipStream_t s);
 // bytes of PvFused::park the launch of (x3, units) needs (0: the kernel that will run has no parking slots)
-int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid);
+int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel);
 // waves per workgroup that publish a dL/d(hz) slot (sizes part_hz)
-int pv_sdec_fused_bf16_waves(bool x3, int64_t units);
+int pv_sdec_fused_bf16_waves(bool x3, int64_t units, int sel);
+// whether `sel` (pv_ivae_plan.dec_kernel) names a decoder-kernel build this library contains for the fused mode
+bool pv_sdec_fused_sel_valid(int fused, int sel);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
 struct PvFusedOffsets { int64_t W1, b1, W2, b2, Wc, wo, bo; };
 int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int dwo_slots,

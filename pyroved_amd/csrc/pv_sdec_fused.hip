@@ -513,8 +513,7 @@ int pv_sdec_fused_kmax(int n_pix, int64_t units, int grid) {
 
 int pv_sdec_fused_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {
   PvFused f = f_in;
-  static int ablate = -1;
-  if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }
+  static const int ablate = pv_exp_int("PV_FD_ABLATE", 0);
   f.ablate = ablate;
   const size_t lds = FD_LDS_FLOATS * sizeof(float);
   PV_TRY(pv_set_dynamic_lds(reinterpret_cast<const void*>(&pv_sdec_fused_kernel<true>), (int)lds));

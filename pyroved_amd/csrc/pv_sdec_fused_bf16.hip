@@ -1003,11 +1003,11 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
 //   >= FB_H231_MIN_UNITS units (16 384 rows):   H231 (kind 28: dL/dpre split in both dgrads; worst tensor 1.6e-5 at C2)
 //   >= FB_H221_MIN_UNITS units (2 M rows):      H221 (kind 21: one piece everywhere; 6e-5 at C2's 2e5 rows, ~1 / sqrt(rows))
 // smaller problems keep the bf16 three-product kernel (kind 0).
-// Environment (A/B runs): PV_W8=0 / 1 forces the plain kernel; PV_X3_KERNEL=old | 4 | 8 | h221 | h223 | h321 | h333 the split-precision one.
-static int fb_w8_mode[2] = {-1, -1};   // [plain, x3]  -1: not read yet; 2: by problem size; plain: 0 / 1 forced; x3: 0 old, 4, 8, 21, 23, 31, 33
-// test / A-B hooks
-extern "C" void pv_debug_force_w8(int mode) { fb_w8_mode[0] = mode; }
-extern "C" void pv_debug_force_w8x3(int mode) { fb_w8_mode[1] = mode == 1 ? 8 : mode; }   // 1: the 8-wave form (round-3 tests), 4, 0 old, 2 default, 21 / 23 / 31 / 33 the fp16 builds
+// Which build runs is a function of (fused mode, units, launch kind) and of pv_ivae_plan.dec_kernel (`sel`, 0 = by size: ABI v15,
+// a PLAN field — no process-wide state).  sel, plain (fused 3): 1 the 4-wave kernel, 2 the 8-wave kernel.  sel, split precision
+// (fused 2): 1 the bf16 three-product kernel (kind 0), 21 / 28 the fp16 builds; the experiments build (-DPV_EXPERIMENTS) also
+// knows 4 / 8 (pv_sdec_fused_w8x3.hip's training forms), 23 / 31 / 33 / 26 / 27 / 29 (the error table's other corners), 41 / 48
+// (pv_sdec_fused_w8h.hip) and, with sel == 0, the environment: PV_W8=0 / 1, PV_X3_KERNEL=old | 4 | 8 | h221 | h223 | ... | w221 | w231.
 #ifndef FB_H231_MIN_UNITS
 #define FB_H231_MIN_UNITS 1024         // 16 384 rows
 #endif
@@ -1015,24 +1015,50 @@ extern "C" void pv_debug_force_w8x3(int mode) { fb_w8_mode[1] = mode == 1 ? 8 : 
 #define FB_H221_MIN_UNITS 131072       // 2 097 152 rows
 #endif
 #ifndef FB_EXPERIMENTS
+#ifdef PV_EXPERIMENTS
 #define FB_EXPERIMENTS 1               // the error table's other corners (H223 / H321 / H333; Bernoulli training launches only)
+#else
+#define FB_EXPERIMENTS 0
+#endif
 #endif
 static const int64_t fb_row_cap = (int64_t)1 << 30;          // (the pv_sdec_fused_w8*.hip kernels address rows by 32-bit BYTE offsets)
-static bool fb_use_w8(int64_t units) {
-  int& v = fb_w8_mode[0];
-  if (v < 0) { const char* e = getenv("PV_W8"); v = e ? (atoi(e) == 0 ? 0 : 1) : 2; }
+#ifdef PV_EXPERIMENTS
+static int fb_env_plain() {
+  static const int v = [] { const char* e = pv_exp_str("PV_W8"); return e ? (atoi(e) == 0 ? 0 : 1) : 2; }();
+  return v;
+}
+static int fb_env_x3() {
+  static const int v = [] {
+    const char* e = pv_exp_str("PV_X3_KERNEL");
+    return !e ? 2 : (e[0] == 'w' ? (atoi(e + 1) == 231 ? 48 : 41) : e[0] == 'o' ? 0 : (e[0] == 'h' ? (atoi(e + 1) == 221 ? 21 : atoi(e + 1) == 223 ? 23 : atoi(e + 1) == 321 ? 31 : atoi(e + 1) == 333 ? 33 : atoi(e + 1) == 231 ? 28 : 2)
+                                                    : (atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : 2))));
+  }();
+  return v;
+}
+#else
+static constexpr int fb_env_plain() { return 2; }
+static constexpr int fb_env_x3() { return 2; }
+#endif
+bool pv_sdec_fused_sel_valid(int fused, int sel) {
+  if (sel == 0) return true;
+  if (fused == 3) return sel == 1 || sel == 2;
+  if (fused != 2) return false;
+  if (sel == 1 || sel == 21 || sel == 28) return true;
+#ifdef PV_EXPERIMENTS
+  return sel == 4 || sel == 8 || sel == 23 || sel == 31 || sel == 33 || sel == 26 || sel == 27 || sel == 29 || sel == 41 || sel == 48;
+#else
+  return false;
+#endif
+}
+static bool fb_use_w8(int64_t units, int sel) {
+  const int v = sel == 1 ? 0 : (sel == 2 ? 1 : fb_env_plain());          // 0 / 1 forced, 2 by problem size
   if (v != 2) return v != 0 && units * FD_UNIT < fb_row_cap;
   return units >= 6 * (int64_t)pv_sdec_fused_grid(units) && units * FD_UNIT < fb_row_cap;
 }
 // split precision: 0 = this file's 4-wave bf16 kernel, 21 (23 / 31 / 33) = its fp16 builds, 4 / 8 = pv_sdec_fused_w8x3.hip with
 // that many waves
-static int fb_x3_kind(int64_t units, bool grads) {
-  int& v = fb_w8_mode[1];
-  if (v < 0) {
-    const char* e = getenv("PV_X3_KERNEL");
-    v = !e ? 2 : (e[0] == 'w' ? (atoi(e + 1) == 231 ? 48 : 41) : e[0] == 'o' ? 0 : (e[0] == 'h' ? (atoi(e + 1) == 221 ? 21 : atoi(e + 1) == 223 ? 23 : atoi(e + 1) == 321 ? 31 : atoi(e + 1) == 333 ? 33 : atoi(e + 1) == 231 ? 28 : 2)
-                                                 : (atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : 2))));
-  }
+static int fb_x3_kind(int64_t units, bool grads, int sel) {
+  const int v = sel == 0 ? fb_env_x3() : (sel == 1 ? 0 : sel);
   if (v > 8) return grads ? v : (units * FD_UNIT < fb_row_cap && units >= 6 * (int64_t)pv_sdec_fused_grid(units) ? 8 : 0);
   if (units * FD_UNIT >= fb_row_cap) return 0;
   if (v != 2) return v;
@@ -1050,12 +1076,17 @@ static int fb_kind_prec(int kind) {
   return kind == 21 ? FB_P_H221 : kind == 23 ? FB_P_H223 : kind == 31 ? FB_P_H321 : kind == 33 ? FB_P_H333
        : kind == 26 ? FB_P_H2A1 : kind == 27 ? FB_P_H2B1 : kind == 28 ? FB_P_H231 : kind == 29 ? FB_P_H131 : FB_P_X3;
 }
-int pv_sdec_fused_bf16_waves(bool x3, int64_t units) {
-  const int kind = x3 ? fb_x3_kind(units, true) : 0;
-  return (x3 ? (kind == 8 || fb_kind_w8h(kind)) : fb_use_w8(units)) ? 8 : FB_WAVES;
+int pv_sdec_fused_bf16_waves(bool x3, int64_t units, int sel) {
+  const int kind = x3 ? fb_x3_kind(units, true, sel) : 0;
+  return (x3 ? (kind == 8 || fb_kind_w8h(kind)) : fb_use_w8(units, sel)) ? 8 : FB_WAVES;
 }
-int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid) {
-  return (x3 && fb_x3_kind(units, true) == 8) ? pv_sdec_fused_w8x3_park_bytes(grid) : 0;
+int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel) {
+#ifdef PV_EXPERIMENTS
+  return (x3 && fb_x3_kind(units, true, sel) == 8) ? pv_sdec_fused_w8x3_park_bytes(grid) : 0;
+#else
+  (void)x3; (void)units; (void)grid; (void)sel;
+  return 0;                                             // (parking slots: the 8-wave split-precision TRAINING form only)
+#endif
 }
 
 // measurement hook (not in include/): the kernel a decoder launch of (fused mode, units, grads, likelihood) dispatches, spelled
@@ -1065,10 +1096,10 @@ extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, in
   static thread_local char buf[128];
   const char* g = grads ? "true" : "false";
   if (fused == 1) snprintf(buf, sizeof buf, "void pv_sdec_fused_kernel<%s>(PvFused)", g);
-  else if (fused == 2 && fb_kind_w8h(fb_x3_kind(units, grads != 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8h_kernel<%d, %s>(PvFused)", lik, fb_x3_kind(units, grads != 0) == 48 ? "true" : "false");
-  else if (fused == 2 && !fb_kind_here(fb_x3_kind(units, grads != 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d, %d>(PvFused)", g, lik, fb_x3_kind(units, grads != 0));
-  else if (fused == 3 && fb_use_w8(units)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d>(PvFused)", g, lik);
-  else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %d>(PvFused)", g, lik, fused == 2 ? fb_kind_prec(fb_x3_kind(units, grads != 0)) : FB_P_BF16);
+  else if (fused == 2 && fb_kind_w8h(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8h_kernel<%d, %s>(PvFused)", lik, fb_x3_kind(units, grads != 0, 0) == 48 ? "true" : "false");
+  else if (fused == 2 && !fb_kind_here(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d, %d>(PvFused)", g, lik, fb_x3_kind(units, grads != 0, 0));
+  else if (fused == 3 && fb_use_w8(units, 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d>(PvFused)", g, lik);
+  else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %d>(PvFused)", g, lik, fused == 2 ? fb_kind_prec(fb_x3_kind(units, grads != 0, 0)) : FB_P_BF16);
   else snprintf(buf, sizeof buf, "pv_gemm_kernel (layer-by-layer path)");
   return buf;
 }
@@ -1078,9 +1109,9 @@ PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   PvFbPrep p{};
   p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz; p.wo = f.wo;
   p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
-  const int kind = x3 ? fb_x3_kind(f.units, grads) : -1;
+  const int kind = x3 ? fb_x3_kind(f.units, grads, f.sel) : -1;
   p.mode = fb_kind_w8h(kind) ? 2 : (kind > 8 ? 1 : 0);
-  p.scale = (x3 ? !fb_kind_here(kind) : fb_use_w8(f.units)) ? 2.8853900817779268f : 0.0f;     // (also what hz arrives multiplied by)
+  p.scale = (x3 ? !fb_kind_here(kind) : fb_use_w8(f.units, f.sel)) ? 2.8853900817779268f : 0.0f;     // (also what hz arrives multiplied by)
   return p;
 }
 
@@ -1098,16 +1129,19 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
 int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s) {
   int prec = FB_P_BF16;
   if (x3) {
-    const int kind = fb_x3_kind(f_in.units, grads);
+    const int kind = fb_x3_kind(f_in.units, grads, f_in.sel);
+#ifdef PV_EXPERIMENTS
     if (fb_kind_w8h(kind)) return grads ? pv_sdec_fused_w8h_launch(f_in, grid, kind == 48, s) : PV_EINVAL;
+#else
+    if (fb_kind_w8h(kind) || (grads && !fb_kind_here(kind))) return PV_EINVAL;   // (dropped variants: the experiments build)
+#endif
     if (!fb_kind_here(kind)) return pv_sdec_fused_w8x3_launch(f_in, grid, grads, s, kind);
     prec = fb_kind_prec(kind);
-  } else if (fb_use_w8(f_in.units)) {
+  } else if (fb_use_w8(f_in.units, f_in.sel)) {
     return pv_sdec_fused_w8_launch(f_in, grid, grads, s);
   }
   PvFused f = f_in;
-  static int ablate = -1;
-  if (ablate < 0) { const char* e = getenv("PV_FD_ABLATE"); ablate = e ? atoi(e) : 0; }
+  static const int ablate = pv_exp_int("PV_FD_ABLATE", 0);
   f.ablate = ablate;
   const size_t lds = FB_LDS_BYTES;
   const void* fn = nullptr;

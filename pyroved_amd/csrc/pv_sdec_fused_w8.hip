@@ -53,6 +53,12 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define WO_CTP (WO_CHZ + W8_WAVES * FD_H * 4)
 #define WO_CGR (WO_CTP + W8_WAVES * 256)
 #define W8_LDS_BYTES (WO_CGR + W8_WAVES * 256)
+// column-parallel tail (a workgroup's last tile when it holds ONE unit): the exchange buffers live in the rows of staging B
+// that a one-k-step consume never reads (rows 32 ..): six 4 KB piece buffers [wave][lane] of bf16x4 + the partial logits
+#define WO_TX (WO_SB + 2 * 32 * LDS2)
+#define W8_TX_BYTES (W8_WAVES * 64 * 8)
+#define WO_TLOG (WO_TX + 6 * W8_TX_BYTES)
+static_assert(WO_TLOG + W8_WAVES * 16 * 4 <= WO_SB + W8_ARR_BYTES, "tail exchange buffers fit behind the staged rows");
 static_assert(W8_LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(2 * IMG_BYTES % (W8_WAVES * 1024) == 0, "image load: whole 1 KB LDS-DMA pieces per wave");
 
@@ -106,6 +112,9 @@ __device__ __forceinline__ float w8_sum_q(float v) {
 // second k-step, 8 no dW1 / dW2 record stores
 #ifndef W8_ABL
 #define W8_ABL 0
+#endif
+#ifndef W8_TAIL
+#define W8_TAIL 1                    // 0: the seventh tile row-parallel as in rounds 2-4 (A/B builds)
 #endif
 #define W8_ABL_LOADS(bit, g) (!(W8_ABL & (bit)) || (((g) & 1) == 0))
 #define W8_ABL_BUF(bit, g) ((W8_ABL & (bit)) ? (((g) >> 1) & 1) : ((g) & 1))
@@ -340,6 +349,62 @@ extern "C" int pv_debug_read_trace_w8(long long* out, int n) {
 #define W8_STAMP_K(k) do { } while (0)
 #endif
 
+// ---- column-parallel tail helpers --------------------------------------------------------------------------------------
+// At batch 256 a workgroup owns 49 units: six full 8-wave tiles and ONE unit more.  Row-parallel, that seventh tile costs a
+// whole tile's dependent chain (20.9 k of the launch's 178 k cycles: profiles/r03e_w8_ablations.txt) for one wave's work.
+// Here the eight waves share the unit instead: wave w computes the 16-column block w of every layer (4 MFMAs where the
+// row-parallel wave issues 32, 4 tanh per lane instead of 32) and the waves exchange their bf16x4 pieces through LDS — after
+// an exchange every wave holds the unit's whole activation row set in exactly the registers (ih[8]) the row-parallel form
+// keeps, so weight-gradient staging, the wave-local column sums and the row-local coordinate backward are the row-parallel
+// code run by ONE wave each.
+__device__ __forceinline__ void w8_xchg_put(char* smb, int k, const bf16x4& mine, int wave, int lane) {
+  reinterpret_cast<bf16x4*>(smb + WO_TX + k * W8_TX_BYTES)[wave * 64 + lane] = mine;
+}
+__device__ __forceinline__ void w8_xchg_get(const char* smb, int k, bf16x4 (&all)[8], int lane) {
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) all[jb] = reinterpret_cast<const bf16x4*>(smb + WO_TX + k * W8_TX_BYTES)[jb * 64 + lane];
+}
+// block `wave` of a forward layer: C * pre-activation of outputs 16 wave + 4q .. +3 for row r
+__device__ __forceinline__ f32x4 w8_tail_fwd(const __bf16* __restrict__ Wh, const float* __restrict__ bs, const bf16x4 (&ih)[8],
+                                             const W8Addr& ad, int wave, int q) {
+  f32x4 out = *reinterpret_cast<const f32x4*>(bs + 16 * wave + 4 * q);
+  const __bf16* ah = Wh + ad.fb + 16 * wave * LDB;
+  bf16x8 wh[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) wh[m] = *reinterpret_cast<const bf16x8*>(ah + ad.fx[m]);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) out = MFMA32(wh[m], w8_cat(ih[2 * m], ih[2 * m + 1]), out);
+  return out;
+}
+// block `wave` of a dgrad layer: out[k = 16 wave + 4q .. +3] = sum_j (C W)[j][k] dp[j]
+__device__ __forceinline__ f32x4 w8_tail_dgrad(const __bf16* __restrict__ Wh, const bf16x4 (&ih)[8], const W8Addr& ad, int wave,
+                                               int r) {
+  f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+  const __bf16* ah = Wh + ad.db + 32 * ((wave >> 1) ^ (r >> 2)) + 4 * (wave & 1);
+  bf16x8 wh[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) wh[m] = w8_cat(w8_tr(ah + 32 * m * LDB), w8_tr(ah + 32 * m * LDB + 16 * LDB));
+#pragma unroll
+  for (int m = 0; m < 4; ++m) out = MFMA32(wh[m], w8_cat(ih[2 * m], ih[2 * m + 1]), out);
+  return out;
+}
+__device__ __forceinline__ f32x4 w8_tanh4(f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = w8_tanhc(v[i]);
+  return v;
+}
+__device__ __forceinline__ bf16x4 w8_cvt4(const f32x4& v) {
+  bf16x4 h;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) h[i] = (__bf16)v[i];
+  return h;
+}
+// d * (h^2 - 1) for one block (w8_mul_dtanh's sign convention)
+__device__ __forceinline__ f32x4 w8_mul_dtanh4(const f32x4& d, const bf16x4& hb) {
+  const f32x4 t = w8_f32_of(hb);
+  return d * (t * t - 1.0f);
+}
+
 // LIK: the likelihood is a compile-time choice
 template <bool GRADS, int LIK>
 __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
@@ -465,8 +530,12 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     while (p_.loc >= upb) { p_.loc -= upb; ++p_.b; }
     if (xun > 0) { while (p_.xu >= xun) p_.xu -= xun; }
   };
-  const Pos pos_lo = pos_of(u_lo);                      // what an out-of-range wave fetches instead (valid, unused)
-  Pos pos_cur = pos_of(u_lo + wave < u_hi ? u_lo + wave : u_lo);
+  // a range of 8 n + 1 units ends with a column-parallel tail (below): the row-parallel tiles cover [u_lo, u_end), and what a
+  // wave without a further unit prefetches is the tail unit's inputs (every wave takes part in the tail)
+  const bool has_tail = W8_TAIL && ((u_hi - u_lo) & (W8_WAVES - 1)) == 1;
+  const int u_end = has_tail ? u_hi - 1 : u_hi;
+  const Pos pos_lo = pos_of(has_tail ? u_end : u_lo);   // what an out-of-range wave fetches instead (valid; unused without a tail)
+  Pos pos_cur = pos_of(u_lo + wave < u_end ? u_lo + wave : (has_tail ? u_end : u_lo));
   Pos pos_nx = pos_cur;
   float sw_next = 1.0f;
   auto x_of = [&](const Pos& p_) -> float {
@@ -487,14 +556,14 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   fetch_unit_inputs(pos_cur);
   const W8Addr wad = w8_addr(r, q);
   int tile_no = -1;
-  for (int ut = u_lo; ut < u_hi; ut += W8_WAVES) {
+  for (int ut = u_lo; ut < u_end; ut += W8_WAVES) {
     ++tile_no;
     (void)tile_no;                      // (used by the -DW8_TRACE stamps only)
     asm volatile("; W8_TILE_BEGIN");
     W8_STAMP(0);
-    const int nact = (u_hi - ut) < W8_WAVES ? (u_hi - ut) : W8_WAVES;
+    const int nact = (u_end - ut) < W8_WAVES ? (u_end - ut) : W8_WAVES;
     // the unit this wave fetches for the NEXT tile
-    if (ut + W8_WAVES + wave < u_hi) advance(pos_nx, W8_WAVES);
+    if (ut + W8_WAVES + wave < u_end) advance(pos_nx, W8_WAVES);
     else pos_nx = pos_lo;
     int opq = 0;
     asm volatile("" : "+v"(opq));       // a zero the compiler cannot see through, OR-ed into the lane id: every lane-dependent
@@ -726,6 +795,204 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
     W8_STAMP(13);
     W8_STAMP(14);
     asm volatile("; W8_TILE_END");
+  }
+
+  if (has_tail) {
+    // ================= column-parallel tail: ONE unit, eight waves (helpers above the kernel) =================
+    asm volatile("; W8_TAIL_BEGIN");
+    const int lane = lane0, r = lane & 15, q = lane >> 4;
+    const float* wos = vec;
+    const float* b1s = vec + FD_H;
+    const float* b2s = vec + 2 * FD_H;
+    const int unit = u_end, bu = pos_cur.b;            // (every wave's prefetch slots hold the tail unit's inputs: pos_lo)
+    const int64_t row = (int64_t)unit * FD_UNIT + r;
+    float x0, x1, u0c, u1c, sc;
+    w8_wait_vm0();
+    {
+      const float* t = ctp;
+      const float* gr = cgr;
+      if (f.cd == 2) {
+        const float gx = gr[2 * r], gy = gr[2 * r + 1];
+        u0c = gx * t[0] - gy * t[1];
+        u1c = gx * t[1] + gy * t[0];
+        sc = t[2];
+        x0 = u0c * sc + t[3];
+        x1 = u1c * sc + t[4];
+      } else {
+        u0c = gr[r]; u1c = 0.0f; sc = 1.0f;
+        x0 = u0c + t[3]; x1 = 0.0f;
+      }
+    }
+    const float xv = xv_next, swv = sw_next;
+    float* inf_x0 = info + 16 * wave;
+    float* inf_x1 = info + W8_ROWS + 16 * wave;
+    float* inf_dl = info + 2 * W8_ROWS + 16 * wave;
+    bf16x4 h0b[8], h1b[8], own0, own1;
+    {
+      // ---- coordinate layer, block `wave` ----
+      bf16x4 bx = w8_zero4();
+      {
+        const float v = q == 0 ? x0 : x1;
+        __bf16 vh, vl;
+        fb_split(v, vh, vl);
+        const __bf16 one = (__bf16)1.0f;
+        if (q < 2) { bx[0] = vh; bx[1] = vl; bx[2] = vh; }
+        else if (q == 2) { bx[0] = one; bx[1] = one; }
+      }
+      f32x4 t0 = *reinterpret_cast<const f32x4*>(chz + 16 * wave + 4 * q);
+      if (f.hz_scale == 0.0f) t0 = t0 * W8_C;
+      const bf16x4 aop = (reinterpret_cast<const bf16x4*>(smb + WO_ATAB) + lane)[64 * wave];
+      if (GRADS && q == 0) { inf_x0[r] = x0; inf_x1[r] = x1; }
+      t0 = w8_mfma16(aop, bx, t0);
+      own0 = w8_cvt4(w8_tanh4(t0));
+      w8_xchg_put(smb, 0, own0, wave, lane);
+    }
+    __syncthreads();                                               // exchange 0: h0
+    w8_xchg_get(smb, 0, h0b, lane);
+    own1 = w8_cvt4(w8_tanh4(w8_tail_fwd(W1h, b1s, h0b, wad, wave, q)));
+    w8_xchg_put(smb, 1, own1, wave, lane);
+    __syncthreads();                                               // exchange 1: h1
+    w8_xchg_get(smb, 1, h1b, lane);
+    f32x4 gq;                                                      // wo (1 - h2^2), block `wave`
+    float dlda = 0.0f;
+    {
+      const f32x4 t2 = w8_tanh4(w8_tail_fwd(W2h, b2s, h1b, wad, wave, q));
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * wave + 4 * q);
+      const f32x4 pw = t2 * wv;
+      const float part = w8_sum_q((pw[0] + pw[1]) + (pw[2] + pw[3]));
+      if (GRADS) {
+        w8_xchg_put(smb, 2, w8_cvt4(t2), wave, lane);               // (h2: read back by the wave that sums d(wo))
+        gq = wv - wv * (t2 * t2);
+      }
+      float* tlog = reinterpret_cast<float*>(smb + WO_TLOG);
+      if (q == 0) tlog[16 * wave + r] = part;
+      __syncthreads();                                             // exchange 2: h2 pieces + partial logits
+      float a = bo;
+      {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < W8_WAVES; ++w) sacc += tlog[16 * w + r];
+        a += sacc;
+      }
+      float ll, locv;
+      if (LIK == PV_LIK_BERNOULLI) {
+        const float pr = w8_rcp(1.0f + w8_exp(-a));
+        const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
+        const float lg = w8_log(pc) - w8_log(1.0f - pc);
+        ll = -(fmaxf(lg, 0.0f) - lg * xv + w8_log(1.0f + w8_exp(-fabsf(lg))));
+        const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
+        dlda = (w8_rcp(1.0f + w8_exp(-lg)) - xv) * mask;
+        locv = pr;
+      } else if (LIK == PV_LIK_CBERNOULLI) {
+        pv_cbern(a, xv, ll, dlda, locv);
+      } else {
+        const float pr = f.sigmoid_out ? w8_rcp(1.0f + w8_exp(-a)) : a;
+        const float d = xv - pr;
+        ll = -(d * d) / (2.0f * f.sig * f.sig) - w8_log(f.sig) - LOG_SQRT_2PI;
+        dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+        locv = pr;
+      }
+      dlda *= swv;
+      if (q == 0) {
+        if (wave == 0) {
+          if (a_llrow) a_llrow[row] = ll;
+          if (a_loc) a_loc[row] = locv;
+          if (GRADS) dbo += dlda;
+        }
+        if (GRADS) inf_dl[r] = dlda;
+      }
+    }
+    if (GRADS) {
+      bf16x4 pA[8];
+      // ---- dpre2 = dlda wo (1 - h2^2), block `wave` -> every wave ----
+      w8_xchg_put(smb, 3, w8_cvt4(gq * dlda), wave, lane);
+      __syncthreads();                                             // exchange 3: dpre2
+      w8_xchg_get(smb, 3, pA, lane);
+      if (wave == 0) {                                             // rows 0 .. 15 of the weight-gradient staging
+        w8_stage_store(sA, pA, r, q);
+        w8_stage_store(sB, h1b, r, q);
+      } else if (wave == 1) {                                      // rows 16 .. 31: zero gradient rows (one k-step is 32 rows)
+        bf16x4 z8[8];
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) z8[jb] = w8_zero4();
+        w8_stage_store(sA, z8, 16 + r, q);
+        w8_stage_store(sB, h1b, 16 + r, q);
+      } else if (wave == 3) {
+        // d(wo) += sum_rows dlda h2 in this wave's own rows of staging A (rows 48 .. 63: unused by the tail's staging)
+        bf16x4 h2b[8];
+        w8_xchg_get(smb, 2, h2b, lane);
+        w8_wait_lgkm0();
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(inf_dl + 4 * q);
+        bf16x4 bw = w8_zero4();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __bf16 hi, lo;
+          fb_split(d4[i], hi, lo);
+          bw[i] = r == 3 ? hi : (r == 4 ? lo : (__bf16)0.0f);
+        }
+        w8_colsum_mfma(sA, h2b, bw, accS, wave, r, q);
+      }
+      // ---- dgrad of layer 2, block `wave` ----
+      const f32x4 d1 = w8_mul_dtanh4(w8_tail_dgrad(W2h, pA, wad, wave, r), own1);      // -C dpre1
+      w8_xchg_put(smb, 4, w8_cvt4(d1), wave, lane);
+      __syncthreads();                                             // exchange 4: dpre1 (+ the staged rows of round 1)
+      w8_xchg_get(smb, 4, pA, lane);
+      w8_wgrad_consume(sA, sB, accW2, accB2, wave, r, q, 1);
+      // ---- dgrad of layer 1, block `wave` ----
+      const f32x4 d0 = w8_mul_dtanh4(w8_tail_dgrad(W1h, pA, wad, wave, r), own0);      // C^2 dpre0
+      w8_xchg_put(smb, 5, w8_cvt4(d0), wave, lane);
+      __syncthreads();                                             // exchange 5: dpre0; round 1 consumed everywhere
+      if (wave == 0) {
+        w8_stage_store(sA, pA, r, q);
+        w8_stage_store(sB, h0b, r, q);
+      } else if (wave == 1) {
+        bf16x4 z8[8];
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) z8[jb] = w8_zero4();
+        w8_stage_store(sA, z8, 16 + r, q);
+        w8_stage_store(sB, h0b, 16 + r, q);
+      } else if (wave == 2) {
+        // coordinate layer backward, row-local part
+        bf16x4 p0[8];
+        w8_xchg_get(smb, 5, p0, lane);
+        f32x4 dd = {0.0f, 0.0f, 0.0f, 0.0f};
+        const bf16x8* ttab = reinterpret_cast<const bf16x8*>(smb + WO_TTAB) + lane;
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) dd = MFMA32(ttab[64 * mm], w8_cat(p0[2 * mm], p0[2 * mm + 1]), dd);
+        if (q == 0) {
+          const float d0_ = (dd[0] + dd[1]) * W8_RC2, d1_ = (dd[2] + dd[3]) * W8_RC2;
+          a_rowtp[row] = sc * (d1_ * u0c - d0_ * u1c);
+          a_rowtp[a_M + row] = d0_ * u0c + d1_ * u1c;
+          a_rowtp[2 * a_M + row] = d0_;
+          a_rowtp[3 * a_M + row] = d1_;
+        }
+      } else if (wave == 3) {
+        // dL/d(hz[b]) = sum_rows dpre0, dWc_k = sum_rows dpre0 x'_k in this wave's own rows of staging A
+        bf16x4 p0[8];
+        w8_xchg_get(smb, 5, p0, lane);
+        if (bu != cur_b) {
+          if (cur_b >= 0) flush_hz(cur_b);
+          cur_b = bu;
+        }
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(inf_x0 + 4 * q);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(inf_x1 + 4 * q);
+        bf16x4 bc_ = w8_zero4();
+        const bool use1 = r == 2 || r == 6, lo_col = r >= 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __bf16 hi, lo;
+          fb_split(use1 ? a1[i] : a0[i], hi, lo);
+          __bf16 v = lo_col ? lo : hi;
+          if (r == 0) v = (__bf16)1.0f;
+          if (r == 3 || r == 4 || r > 6) v = (__bf16)0.0f;
+          bc_[i] = v;
+        }
+        w8_colsum_mfma(sA, p0, bc_, accS, wave, r, q);
+      }
+      __syncthreads();                                             // round 2 staged
+      w8_wgrad_consume(sA, sB, accW1, accB1, wave, r, q, 1);
+    }
+    asm volatile("; W8_TAIL_END");
   }
   if (!GRADS) return;
   W8_STAMP_K(2);

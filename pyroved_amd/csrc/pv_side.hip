@@ -22,9 +22,9 @@ struct Side {
 Side g_side[kMaxDev];
 std::mutex g_mu;
 
-// the environment's choice, read once (PV_NO_SIDE=1: never); per plan: PV_PLAN_NO_SIDE_STREAM (pv_side_stream_for)
+// per plan: PV_PLAN_NO_SIDE_STREAM (pv_side_stream_for); PV_NO_SIDE=1 in the experiments build
 bool side_enabled() {
-  static const bool on = [] { const char* e = getenv("PV_NO_SIDE"); return !(e && atoi(e) != 0); }();
+  static const bool on = !pv_exp_int("PV_NO_SIDE", 0);
   return on;
 }
 
@@ -52,8 +52,6 @@ Side* side_of_current_device() {
 }
 
 }  // namespace
-
-extern "C" void pv_set_side_stream(int) {}            // (v13's process-wide switch: a plan flag since v14; no-op kept for one version)
 
 bool pv_stream_capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

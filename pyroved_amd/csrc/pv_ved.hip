@@ -128,7 +128,7 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
 // the decoder as one forward / one input-gradient launch: a 1-D stack pv_dec1d.hip takes, its kernel-1 + upsample pairs fused
 // the way the recorded weight gradients expect
 bool dec1d_active(const pv_ved_plan* p, const VLayout& L) {
-  if (!L.d1_wt || !pv_dec1d_enabled() || !pvcs::k1_lean() || !pvcs::k3_lean_1d(p->ndim_out)) return false;
+  if (!L.d1_wt || (p->flags & PV_PLAN_NO_DEC1D) || !pv_dec1d_enabled() || !pvcs::k1_lean() || !pvcs::k3_lean_1d(p->ndim_out)) return false;
   for (int i = 0; i + 1 < p->n_dec_ops; ++i)
     if (p->dec[i + 1].kind == PV_OP_UPSAMPLE2 && !pvcs::k1up_fusable(p->dec, p->n_dec_ops, p->ndim_out, i)) return false;
   return true;
@@ -136,7 +136,7 @@ bool dec1d_active(const pv_ved_plan* p, const VLayout& L) {
 
 // the head (reparameterised sample, its KL terms, its backward) in the decoder's launches: with latent_to_features there
 bool head_folded(const pv_ved_plan* p, const VLayout& L) {
-  return dec1d_active(p, L) && L.l2f_wt && pv_dec1d_l2f_ok(p->z_dim) && !getenv("PV_NO_HEADFOLD");
+  return dec1d_active(p, L) && L.l2f_wt && pv_dec1d_l2f_ok(p->z_dim) && !pv_exp_str("PV_NO_HEADFOLD");
 }
 
 // tile the conv weights the coming launches need: stack 0 / 1 / both, with or without the input-gradient orientation
@@ -181,7 +181,7 @@ int ved_encoder_fwd(const pv_ved_plan* p, VLayout& L, float* z_loc_out, float* z
   const Shape& fe = L.es[p->n_enc_ops];
   // torch flattens (C, spatial): features2latent sees channels-first order — the weight is re-indexed, not the features
   L.head_part = nullptr;
-  if (L.head_wt && with_kl && head_folded(p, L) && !getenv("PV_NO_HEADPART") &&
+  if (L.head_wt && with_kl && head_folded(p, L) && !pv_exp_str("PV_NO_HEADPART") &&
       pv_convhead_fwd_partials(L.ea[p->n_enc_ops], L.head_wt, (int)B, L.F, 2 * p->z_dim, L.sc.ws, L.sc.ws_bytes, s, &L.head_part,
                                &L.head_nseg) == 0) {
     // (the partial sums meet in the decoder's launch, which writes L.head)
@@ -257,7 +257,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   // encoder's stack joins before its first tiled convolution.
   hipStream_t side = pv_side_stream_for(s, p->flags);
   bool wt_join = false;
-  static const int wprep_side = getenv("PV_SIDE_WPREP") && atoi(getenv("PV_SIDE_WPREP")) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
+  static const int wprep_side = pv_exp_int("PV_SIDE_WPREP", 0) ? 1 : 0;   // (measured: the join costs more than the overlap returns)
   if (wprep_side && side && pvcs::c1pool_fusable(p->enc, p->n_enc_ops, p->ndim_in, L.es[0]) && L.sc.code) {
     PV_TRY(pv_stream_after(side, s));                  // (the previous step's Adam wrote the weights on s)
     PV_TRY(ved_wt_prep(p, L, true, true, want_grads != 0, side));
@@ -275,8 +275,8 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   const PvD1Lik lk{p->y, p->loc, want_grads ? L.dlda : nullptr, L.llb, p->lik, p->sigmoid_out, p->decoder_sig};
   bool lik_done = false;
   // a step with gradients and a side stream: the loss scalars are summed there, next to the backward's first launch
-  static const int fin_side_env = getenv("PV_FIN_SIDE") ? atoi(getenv("PV_FIN_SIDE")) : 1;
-  hipStream_t side_f = (want_grads && fin_side_env) ? pv_side_stream_for(s, p->flags) : nullptr;
+  static const int fin_side_env = pv_exp_int("PV_FIN_SIDE", 1);
+  hipStream_t side_f = (want_grads != 0 && fin_side_env != 0) ? pv_side_stream_for(s, p->flags) : nullptr;
   PV_TRY(ved_decoder_fwd(p, L, L.z, s, p->out_ch == 1 ? &lk : nullptr, &lik_done, true, side_f != nullptr));
   const float* y = p->y;
   if (!lik_done && p->out_ch > 1) { PV_TRY(pv_ncs_to_nsc(p->y, L.y_nsc, B, p->out_ch, S, s)); y = L.y_nsc; }
@@ -308,7 +308,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   int pp = 0;
   // the decoder's register-fed weight gradients (kernel-1 family, Conv1d kernel 3) are recorded and run as ONE launch after
   // the input-gradient chain: every layer keeps its own gradient buffer (L.dg) until then.  PV_NO_K1BATCH=1: one launch each.
-  static const int k1b_env = getenv("PV_NO_K1BATCH") && atoi(getenv("PV_NO_K1BATCH")) ? 0 : 1;
+  static const int k1b_env = pv_exp_int("PV_NO_K1BATCH", 0) ? 0 : 1;
   PvK1Batch k1b{};
   if (k1b_env) fin.k1b = &k1b;
   hipStream_t side2 = k1b_env ? pv_side_stream_for(s, p->flags) : nullptr;      // (k1b_env: every decoder gradient has its own buffer)
@@ -392,6 +392,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
                          nullptr, L.sc, s, 0, g_is_pre, two ? L.eg : nullptr));
   L.sc.side = nullptr; L.sc.side_joined = nullptr;
   if (two && !joined) PV_TRY(pv_stream_after(s, side));
+  else if (!two && sf != s) PV_TRY(pv_stream_after(s, sf));   // (no second fork: the loss scalars alone ran on the side stream)
   sj.joined();
   return pv_wgrad_finish_all(&fin, s);
 }

@@ -38,7 +38,13 @@ class IVAEEngine:
     to the HIP library."""
     supports_scalars_out = True      # loss_and_grads can write the 4 loss scalars to a caller-given device slot
     supports_step = True             # loss_and_grads(step=True) = SVI.step in one library call
-
+    # per-plan switches (ABI v14 / v15 plan fields; the library keeps no process-wide switch).  Set on an engine — or, in tests,
+    # on the class — before the next call:
+    dec_kernel = 0                   # pv_ivae_plan.dec_kernel: 0 = the library picks the decoder-kernel build by problem size
+    enc_two_launch = False           # PV_PLAN_ENC_TWO_LAUNCH
+    enc_no_wait = False              # PV_PLAN_ENC_NO_WAIT: the one-launch encoder's consumers compute their tiles themselves
+    side_stream = True               # PV_PLAN_NO_SIDE_STREAM when False
+    dec1d = True                     # PV_PLAN_NO_DEC1D when False (VED's Conv1d decoder layer by layer)
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: int = 2):
         self.model = model
@@ -287,13 +293,16 @@ class IVAEEngine:
         if mx >= self._CONV_W_HI or 0.0 < mx < self._CONV_W_LO or mx != mx:
             import warnings
             warnings.warn("pyroved_amd: a convolution weight reached |w| = %.3g, outside the range of the fp16-piece "
-                          "kernels; this model switches to the three-piece bf16 convolution kernels" % mx)
+                          "kernels; this model switches to the range-free bf16-piece convolution kernels (three pieces at "
+                          "fp32-class precision, the two-piece mixed form at the throughput precision)" % mx)
             self.wide_weights = True
 
     def _plan_flags(self) -> int:
         """pv_ivae_plan.flags / pv_ved_plan.flags from the engine's switches (ABI v14; process-wide setters before)."""
         return ((_abi.PV_PLAN_ENC_TWO_LAUNCH if getattr(self, "enc_two_launch", False) else 0) |
-                (0 if getattr(self, "side_stream", True) else _abi.PV_PLAN_NO_SIDE_STREAM))
+                (0 if getattr(self, "side_stream", True) else _abi.PV_PLAN_NO_SIDE_STREAM) |
+                (_abi.PV_PLAN_ENC_NO_WAIT if getattr(self, "enc_no_wait", False) else 0) |
+                (0 if getattr(self, "dec1d", True) else _abi.PV_PLAN_NO_DEC1D))
 
     def ensure_bound(self):
         if not self._bound():
@@ -396,6 +405,7 @@ class IVAEEngine:
         p.bn_eval = int(not self.model.training)
         p.conv_wide = int(self.wide_weights)
         p.flags = self._plan_flags()
+        p.dec_kernel = int(getattr(self, "dec_kernel", 0))     # 0: the library picks the decoder-kernel build by size (ABI v15)
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = p.alpha = p.ext_head = p.ext_dhead = None
         p.row_w = p.row_elbo = p.dy = None
         p.ext_z = p.ext_dz = p.ext_ll = None

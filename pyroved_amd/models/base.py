@@ -17,39 +17,63 @@ from ..utils import iter_batches, generate_grid
 tt = torch.tensor
 
 
-def _to_host(t: torch.Tensor) -> torch.Tensor:
-    """Device -> host copy of a result tensor: large results go through page-locked memory (torch's caching host allocator
-    keeps the block for the next call), 2-3x the rate of a pageable `.cpu()`; the tensor returned is an ordinary CPU tensor."""
+def _to_host(t: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """Device -> host copy of a result tensor into `out` (an ordinary pageable CPU tensor of t's shape; allocated when None).
+    Large results go through a page-locked STAGING buffer (torch's caching host allocator keeps the block for the next chunk
+    or call), 2-3x the rate of a pageable `.cpu()`; what is returned is never pinned."""
+    if out is None:
+        out = torch.empty(t.shape, dtype=t.dtype, device="cpu")
     if not t.is_cuda or t.numel() * t.element_size() < (1 << 22):
-        return t.cpu()
+        out.copy_(t)
+        return out
     try:
-        out = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+        stage = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
     except RuntimeError:
-        return t.cpu()
-    out.copy_(t, non_blocking=True)
+        out.copy_(t)
+        return out
+    stage.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
+    out.copy_(stage)
     return out
 
 
 _FLUSH_BYTES = 1 << 28     # results kept on the device between two device -> host copies of _encode / _decode (256 MB)
 
 
-def _gather_batches(batches) -> torch.Tensor:
-    """cat() of per-batch device results on the host with BOUNDED device residency: the batches are kept on the device and
-    copied out in chunks of ~_FLUSH_BYTES (one synchronising copy per chunk, not per batch as the reference's loop pays, and
-    not one for the whole result either — 1e6 decoded 64x64 images are 16 GB: ADVICE r3)."""
-    out, pend, nbytes = [], [], 0
+def _gather_batches(batches, total_rows: int = None) -> torch.Tensor:
+    """cat() of per-batch device results on the host with BOUNDED residency on both sides: the batches are kept on the device
+    and copied out in chunks of ~_FLUSH_BYTES (one synchronising copy per chunk, not per batch as the reference's loop pays,
+    and not one for the whole result either — 1e6 decoded 64x64 images are 16 GB: ADVICE r3), each chunk through ONE page-locked
+    staging block into its slice of the pageable result, which is allocated once when `total_rows` is known (no
+    second copy of the result, nothing pinned is returned)."""
+    result, filled, parts = None, 0, []
+
+    def flush(pend):
+        nonlocal result, filled
+        t = torch.cat(pend) if len(pend) > 1 else pend[0]
+        if total_rows is not None and result is None:
+            result = torch.empty((total_rows,) + tuple(t.shape[1:]), dtype=t.dtype, device="cpu")
+        if result is not None and filled + t.shape[0] <= result.shape[0]:
+            _to_host(t, result[filled:filled + t.shape[0]])
+            filled += t.shape[0]
+        else:                                         # (row count unknown or exceeded: fall back to parts + cat)
+            parts.append(_to_host(t))
+
+    pend, nbytes = [], 0
     for t in batches:
         pend.append(t)
         nbytes += t.numel() * t.element_size()
         if nbytes >= _FLUSH_BYTES:
-            out.append(_to_host(torch.cat(pend) if len(pend) > 1 else pend[0]))
+            flush(pend)
             pend, nbytes = [], 0
     if pend:
-        out.append(_to_host(torch.cat(pend) if len(pend) > 1 else pend[0]))
-    if not out:
+        flush(pend)
+    if result is not None:
+        head = result if filled == result.shape[0] else result[:filled]
+        return head if not parts else torch.cat([head] + parts)
+    if not parts:
         return torch.empty(0)
-    return out[0] if len(out) == 1 else torch.cat(out)
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
 
 
 class baseVAE(nn.Module):
@@ -154,7 +178,7 @@ class baseVAE(nn.Module):
                 x = data[0].to(eng.device, torch.float32, non_blocking=True)
                 y = data[1].to(eng.device, torch.float32, non_blocking=True) if len(data) > 1 else None
                 yield torch.cat(eng.encode(x, y), -1)                    # (z_loc, z_scale[, class probabilities])
-        return _gather_batches(run())
+        return _gather_batches(run(), total_rows=int(input_args[0].shape[0]))
 
     def _decode(self, z_new: torch.Tensor, device: str = None, **kwargs: int) -> torch.Tensor:
         """Decodes latent coordinates batch-by-batch (base.py:145-171).  kwargs: batch_size,
@@ -188,8 +212,8 @@ class baseVAE(nn.Module):
             shift = (t[0], t[1] if len(t) > 1 else t[0])
             scale = float(kwargs.get("scale", 1.0))
         # decoded batches stay on the device between copies (see _encode)
-        return _gather_batches(eng.decode(z.to(eng.device, torch.float32, non_blocking=True), angle, shift, scale)
-                               for (z,) in loader)
+        return _gather_batches((eng.decode(z.to(eng.device, torch.float32, non_blocking=True), angle, shift, scale)
+                                for (z,) in loader), total_rows=int(z_new.shape[0]))
 
     def set_encoder(self, encoder_net: Type[torch.nn.Module]) -> None:
         """Sets a user-defined encoder neural network."""

@@ -12,7 +12,8 @@ cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=2, invariances=meta["inva
 lib = C.CDLL(_abi.LIB_PATH)
 res = {}
 for mode in (0, 1):
-    lib.pv_debug_force_w8(mode)
+    from pyroved_amd.engine import IVAEEngine
+    IVAEEngine.dec_kernel = 2 if mode else 1             # pv_ivae_plan.dec_kernel: the 8-wave / the 4-wave plain-bf16 kernel
     model = pv.models.iVAE(meta["data_dim"], 2, meta["invariances"], seed=1, device="cuda")
     eng = model.engine(fused=3)
     if mode == 0:

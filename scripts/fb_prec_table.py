@@ -27,6 +27,7 @@ KINDS = [(int(k), n) for k, n in (kv.split(":") for kv in os.environ["PV_TABLE_K
 FIXTURES = sys.argv[1:] or ["ivae_28x28_r_b128", "ivae_28x28_rt_b256", "ivae_28x28_r_b32_blobs", "ivae_8x8_rts_b6",
                             "ivae_8x8_rts_b6_randn", "ivae_7x9_rts_b3", "ivae_1d16_t_b5"]
 lib = C.CDLL(_abi.LIB_PATH)
+from pyroved_amd.engine import IVAEEngine  # noqa: E402  (the other precision corners need PV_LIB_PATH=<the experiments build>)
 
 
 def rel(a, b):
@@ -46,7 +47,7 @@ for name in FIXTURES:
         cfg = orc.Config(data_dim=meta["data_dim"], latent_dim=meta["latent_dim"], invariances=meta["invariances"])
     res, o64, o32 = {}, None, None
     for kind, _ in KINDS:
-        lib.pv_debug_force_w8x3(kind)
+        IVAEEngine.dec_kernel = kind if kind else 1      # pv_ivae_plan.dec_kernel (1: the bf16 three-product kernel)
         if jiv:
             model = pv.models.jiVAE(meta["data_dim"], meta["latent_dim"], meta["discrete_dim"], meta["invariances"], seed=1,
                                     device="cuda")
@@ -61,7 +62,7 @@ for name in FIXTURES:
             o32.step(x, eps, meta["beta"])
         eng.loss_and_grads(x.cuda(), eps.cuda(), meta["beta"])
         res[kind] = (eng.scalars[0].item(), {k: rel(eng.grad_of(k).cpu(), o64.last_grads[k]) for k in o64.p})
-    lib.pv_debug_force_w8x3(2)
+    IVAEEngine.dec_kernel = 0
     l64 = o64.last["loss"].item()
     rows = meta["batch"] * int(torch.tensor(meta["data_dim"]).prod()) * (meta["discrete_dim"] if jiv else 1)
     print("== %s  (%d decoder rows)   float64 ELBO %.6f" % (name, rows, l64))
@@ -84,7 +85,7 @@ x = make_x(meta["xkind"], meta["batch"], meta["data_dim"]).cuda()
 eps = torch.from_numpy(gold["s0.eps"]).cuda()
 print("== loss_and_grads at batch 256 (28x28, ['r','t']), ms per call, median of 5 x 100 calls")
 for kind, label in KINDS:
-    lib.pv_debug_force_w8x3(kind)
+    IVAEEngine.dec_kernel = kind if kind else 1
     model = pv.models.iVAE(meta["data_dim"], 2, meta["invariances"], seed=1, device="cuda")
     eng = model.engine(fused=2)
     for _ in range(20):
@@ -101,4 +102,4 @@ for kind, label in KINDS:
         ts.append(a.elapsed_time(b) / 100)
     ts.sort()
     print("%-14s %.4f" % (label, ts[2]))
-lib.pv_debug_force_w8x3(2)
+IVAEEngine.dec_kernel = 0

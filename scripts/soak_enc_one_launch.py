@@ -28,8 +28,8 @@ for i in range(steps):
     eps = torch.randn(b, m.z_dim, generator=g, device="cuda")
     out = []
     for two in (0, 1):
-        dbg.pv_debug_enc_two(two)
-        dbg.pv_debug_enc_spin_limit(0 if (contend and two == 0 and i % 8 == 7) else -1)
+        eng.enc_two_launch = bool(two)                   # plan flags (ABI v14 / v15)
+        eng.enc_no_wait = bool(contend and two == 0 and i % 8 == 7)
         if contend:
             with torch.cuda.stream(side):
                 a = big[i % 3]
@@ -43,8 +43,6 @@ for i in range(steps):
             print("step %d differs: %s vs %s" % (i, out[0][0].tolist(), out[1][0].tolist()))
     if i % 64 == 0:
         eng.adam_step()                                  # (let the weights move)
-dbg.pv_debug_enc_two(-1)
-dbg.pv_debug_enc_spin_limit(-1)
 torch.cuda.synchronize()
 print("%d steps at batch %d%s: %d mismatches, %d consumer fallbacks" % (steps, b, " under contention" if contend else "", bad,
                                                                        dbg.pv_debug_enc_late_count() - late0))
