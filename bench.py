@@ -253,12 +253,14 @@ class TorchEvents:
         return [a.elapsed_time(b) for a, b in self.pairs]
 
 
-def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B):
+def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
     """warm-up, regions of --steps steps until two successive ones agree to 1 %, then --repeats measured regions, on one
     decoder path.  -> dict(regions (max over ranks, seconds), discarded, kernel ms, conv-kernel ms + flops, all-reduce ms,
     per-step losses (cpu), engine, model)"""
     model = make_model(pv, cfg, dev)
     eng = model.engine(fused=fused)
+    for k_, v_ in (attrs or {}).items():           # per-plan switches of the engine (e.g. enc_fold=False: the guide as its own launch)
+        setattr(eng, k_, v_)
     if world > 1:
         pvdist.sync_replicas(eng)
     ring_n = cfg["ring"]
@@ -370,16 +372,20 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B):
                 last_loss=hist[(base - 1) % n_eps, 0].item(), eng=eng, model=model)
 
 
-def _kernel_name(fused, units, grads=1, lik=0):
+def _kernel_name(fused, units, grads=1, lik=0, fold=False):
     """The name rocprofv3 prints for the decoder kernel the library dispatches (a debug export of the library)."""
     from pyroved_amd import _abi
     lib = C.CDLL(_abi.LIB_PATH)
+    if fold:
+        lib.pv_debug_decoder_kernel_name_fold.restype = C.c_char_p
+        lib.pv_debug_decoder_kernel_name_fold.argtypes = [C.c_int, C.c_int]
+        return lib.pv_debug_decoder_kernel_name_fold(grads, lik).decode()
     lib.pv_debug_decoder_kernel_name.restype = C.c_char_p
     lib.pv_debug_decoder_kernel_name.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
     return lib.pv_debug_decoder_kernel_name(fused, units, grads, lik).decode()
 
 
-def _paths(cfg, mode, B, n_pix):
+def _paths(cfg, mode, B, n_pix, fold=False):
     """(kernel name, flops per launch, peak TF, dtype label, arithmetic description) of the dominant decoder kernel."""
     passes = max(cfg["dec_passes"], 1)
     dec_fl = DEC_FLOP_PER_PIXEL * n_pix * passes * B
@@ -400,8 +406,9 @@ def _paths(cfg, mode, B, n_pix):
         return (kn, dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16x3",
                 "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)")
     if mode == 3:
-        return (_kernel_name(3, units), dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16",
-                "bf16 MFMA operands for the hidden-layer contractions (fp32 accumulate; fp32 elsewhere)")
+        return (_kernel_name(3, units, fold=fold), dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16",
+                "bf16 MFMA operands for the hidden-layer contractions (fp32 accumulate; fp32 elsewhere)"
+                + ("; the guide (fc encoder, sample, split) runs in the decoder launch's prologue in fp32" if fold else ""))
     if mode == 1:
         return (_kernel_name(1, units), dec_fl, MFMA_F32_PEAK_TFLOPS, "f32", "fp32 (f32-input MFMA)")
     return ("pv_gemm_kernel<NT> (decoder hidden layer fwd, M=B*N, K=N=128)", 2.0 * B * n_pix * 128 * 128 * passes,
@@ -414,10 +421,10 @@ def _traffic(key, B, cfg):
             (tr[1] + " (committed rocprofv3 --pmc pass of this config, not collected by this run)") if tr else None)
 
 
-def measure(args, name, cfg, fused, ctx):
+def measure(args, name, cfg, fused, ctx, attrs=None):
     """One decoder path of one config -> dict of numbers."""
     pv, pvdist, td, dev, rank, world, B = ctx
-    r = _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B)
+    r = _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs)
     regions, eng = r["regions"], r["eng"]
     med = statistics.median(regions)
     n_pix = 1
@@ -475,7 +482,15 @@ def measure(args, name, cfg, fused, ctx):
                                 "flops_per_step": cfg["flops_per_image"] * B}
         return out
     mode = fused if eng.uses_fused(B) else 0
-    kname, fl, peak, dtype, arith = _paths(cfg, mode, B, n_pix)
+    fold = False
+    if mode == 3 and hasattr(eng, "_plan"):
+        try:
+            from pyroved_amd import _abi
+            fold = bool(_abi.lib().pv_ivae_guide_folds(C.byref(eng._plan(B))))
+        except Exception:
+            fold = False
+    kname, fl, peak, dtype, arith = _paths(cfg, mode, B, n_pix, fold)
+    out["guide_folded"] = fold
     kms = r["kms"]
     k_avg = sum(kms) / max(len(kms), 1)
     achieved = fl / (k_avg * 1e-3) / 1e12 if k_avg > 0 else 0.0
@@ -629,6 +644,11 @@ def main():
     alt = None
     if args.fused in (2, 3) and not args.no_alt:
         alt = measure(args, name, cfg, 5 - args.fused, ctx)      # the same workload on the other precision
+    unfolded = None
+    if main_leg.get("guide_folded") and not args.no_alt:
+        # the decoder launch hosts the guide: its duration is no longer the decoder's alone.
+        # The same workload with the guide as its own launch gives the decoder-only kernel time / fraction next to it
+        unfolded = measure(args, name, cfg, args.fused, ctx, attrs={"enc_fold": False})
     # which leg is the fp32-class one (the reference's precision: what C1 / C3 / C4 / C5 lead with) and which the throughput one
     fp32_leg = main_leg if args.fused == 2 else (alt if args.fused == 3 else None)
     alt_key = "fp32_class" if args.fused == 3 else "throughput_precision"
@@ -669,6 +689,15 @@ def main():
         # the fp32-class leg's step time / kernel fraction / step fraction, whichever leg that is
         out["roofline"] = dict(out["roofline"])
         out["roofline"]["step_frac"] = main_leg["step_algorithmic_tflops"] / MFMA_BF16_PEAK_TFLOPS
+        if unfolded is not None:
+            out["roofline"]["note"] = ("this launch also runs the guide (fc encoder, sample, split, fc_latent: fp32 matrix-vector "
+                                       "products, no matrix-core work); decoder_only_* = the same workload with the guide in its "
+                                       "own launch (PV_PLAN_NO_ENC_FOLD)")
+            out["roofline"]["decoder_only_kernel"] = unfolded["roofline"].get("kernel")
+            out["roofline"]["decoder_only_kernel_ms"] = unfolded["roofline"].get("kernel_ms")
+            out["roofline"]["decoder_only_frac"] = unfolded["roofline"].get("frac")
+            out["unfolded"] = {"ms_per_step": unfolded["ms_per_step"], "value": unfolded["value"], "unit": "images/s",
+                               "launches": "pv_enc_kernel, pv_sdec_w8_kernel, pv_latent_bwd_reduce_kernel, pv_wgrad_small_kernel"}
         if fp32_leg is not None:
             out["roofline"]["fp32_class_ms"] = fp32_leg["ms_per_step"]
             out["roofline"]["fp32_class_frac"] = fp32_leg["roofline"]["frac"]

@@ -248,9 +248,14 @@ int pv_experiments_build(void);
  *   first-layer tiles themselves (the bounded-poll fallback taken at once: bit-identical results, redundant work) — the
  *   parity test of that path, and a caller that wants no cross-workgroup hand-off but one launch.
  * PV_PLAN_NO_DEC1D (pv_ved_plan): the Conv1d decoder runs layer by layer instead of as one forward and one
- *   input-gradient launch (csrc/pv_dec1d.hip) — the launches that form replaced, kept as its parity reference. */
+ *   input-gradient launch (csrc/pv_dec1d.hip) — the launches that form replaced, kept as its parity reference.
+ * PV_PLAN_NO_ENC_FOLD: keep the guide (fc encoder, sample, split, fc_latent) in its own launch even where the decoder launch could
+ *   host it (round 5: at fused == 3, a batch that is a multiple of the decoder grid — one image per workgroup at batch 256 on 256
+ *   CUs — every workgroup runs its images' guide in the decoder launch's prologue).  Results agree to fp32 rounding (another
+ *   summation order in the encoder's matrix-vector products), not bit for bit. */
 #define PV_PLAN_ENC_NO_WAIT    4
 #define PV_PLAN_NO_DEC1D       8
+#define PV_PLAN_NO_ENC_FOLD    16
 
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
  * layer widths).  Returns < 0 on an unsupported plan. */
@@ -267,6 +272,11 @@ int64_t pv_ivae_workspace_bytes_for(const pv_ivae_plan* plan, int what);
  * kernel, 0 if it will take the layer-by-layer path (plan->fused == 0 or an architecture the
  * fused kernel is not specialised for). */
 int pv_ivae_uses_fused(const pv_ivae_plan* plan);
+
+/* (v15) 1 if pv_ivae_loss_and_grads / pv_ivae_step will run this plan's guide (fc encoder, reparameterised sample, split,
+ * fc_latent) INSIDE the decoder launch instead of as a launch of its own (see PV_PLAN_NO_ENC_FOLD), 0 otherwise (also while the
+ * stream is being captured). */
+int pv_ivae_guide_folds(const pv_ivae_plan* plan);
 
 /* Trace_ELBO.loss_and_grads for iVAE.guide + iVAE.model (models/ivae.py:165-221,
  * pyro's Trace_ELBO with one particle): writes plan->scalars and, when

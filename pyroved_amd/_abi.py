@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime li
 
 PV_ABI_VERSION = 15
 # pv_ivae_plan.flags / pv_ved_plan.flags / pv_convnet_plan.flags
-PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM, PV_PLAN_ENC_NO_WAIT, PV_PLAN_NO_DEC1D = 1, 2, 4, 8
+PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM, PV_PLAN_ENC_NO_WAIT, PV_PLAN_NO_DEC1D, PV_PLAN_NO_ENC_FOLD = 1, 2, 4, 8, 16
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)
@@ -138,6 +138,7 @@ SIGNATURES = {
     "pv_convnet_forward": (C.c_int, [C.POINTER(pv_convnet_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pv_convnet_backward": (C.c_int, [C.POINTER(pv_convnet_plan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pv_ivae_uses_fused": (C.c_int, [C.POINTER(pv_ivae_plan)]),
+    "pv_ivae_guide_folds": (C.c_int, [C.POINTER(pv_ivae_plan)]),
     "pv_ivae_loss_and_grads": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
     "pv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),

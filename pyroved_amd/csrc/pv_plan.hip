@@ -161,7 +161,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   for (int i = 0; i < n_enc; ++i) L.edp[i] = c.take(B * p->enc[i].out_dim);
   L.enc_compact = !L.enc_conv && !L.enc_ext && pv_enc_compact_supported(p);
   L.kl_blocks = (int)((B + 15) / 16);
-  L.kl_part = c.take(2 * L.kl_blocks);
+  L.kl_part = c.take(2 * (B > L.kl_blocks ? B : L.kl_blocks));   // (per 16-row block — or per sample when the guide rides in the decoder launch)
   L.enc_flags = reinterpret_cast<unsigned*>(c.take(8 * L.kl_blocks));     // (the merged encoder launch's tile flags)
   int64_t maxd = 0;
   L.fused = p->fused && pv_sdec_fused_supported(p) && !(K > 0 && !L.enc_compact);   // (jiVAE + generic encoder: layered)
@@ -728,6 +728,17 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
   return 0;
 }
 
+// the plan-side conditions of the folded guide (PvEncFold): plain-bf16 fused decoder, the plain two-hidden-layer fc encoder, no
+// conditioning vector / discrete latent / per-sample weights; the launch-side ones are pv_sdec_fused_fold_ok's
+static bool plan_guide_may_fold(const pv_ivae_plan* p, const Layout& L) {
+  const int64_t z = p->z_dim;
+  return p->fused == 3 && L.fused && L.enc_compact && !L.enc_ext && !(p->flags & PV_PLAN_NO_ENC_FOLD) && plan_K(p) == 0 &&
+         p->c_dim == 0 && !p->row_w && !p->row_elbo && !p->dy && p->n_enc == 2 && p->enc[0].in_dim == p->n_pix &&
+         p->enc[0].out_dim <= FD_H && p->enc[1].out_dim <= FD_H && p->head.out_dim == 2 * z && z <= 16 && plan_lat_in(p) <= 16 &&
+         p->enc[0].w_off % 4 == 0 && p->enc[1].w_off % 4 == 0 && p->head.w_off % 4 == 0 && p->enc[1].in_dim % 4 == 0 &&
+         p->head.in_dim % 4 == 0 && p->coord_dim > 0;
+}
+
 // loss_and_grads with the fused persistent spatial-decoder kernel (pv_sdec_fused.hip)
 int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads, hipStream_t s,
                          const PvAdamFuse* adam = nullptr, bool* adam_done = nullptr) {
@@ -762,8 +773,31 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     f.dl_exp = e2 < -40 ? -40 : (e2 > 40 ? 40 : e2);
   }
   PvHzReq hzr{zin, ldz, (int)lat_in, H, p->params + p->fc_latent.w_off, L.hz, false, false};
-  // bf16x3 kernel: its weight images + the zero fill of part_hz ride in the encoder's first launch
-  if (p->fused >= 2 && L.enc_compact) {
+  // ---- the guide folded into the decoder launch (pv_sdec_fused.h PvEncFold): the plain-bf16 8-wave kernel, a workgroup's units a
+  // whole number of images, the plain fc encoder of two hidden layers — BASELINE's headline config is exactly this.  No encoder
+  // launch, no weight-image copy, no hand-off: the step is decoder launch -> latent backward + record sums -> small weight gradients.
+  PvEncFold ef{};
+  bool fold = false;
+  if (plan_guide_may_fold(p, L) && !pv_stream_capturing(s)) {
+    f.hz_scale = 2.8853900817779268f;
+    fold = pv_sdec_fused_fold_ok(f, L.f_grid, p->fused == 2);
+    if (fold) {
+      ef.params = p->params; ef.enc0 = p->enc[0]; ef.enc1 = p->enc[1]; ef.head = p->head;
+      ef.x = p->x; ef.ldx = N; ef.eps = p->eps;
+      ef.eact0 = L.eact[0]; ef.eact1 = L.eact[1]; ef.head_out = L.head;
+      ef.z = L.z; ef.z_scale = L.z_scale; ef.z_loc_out = p->z_loc; ef.z_scale_out = p->z_scale;
+      ef.tp = L.tp; ef.kl_part = L.kl_part; ef.hz = L.hz; ef.Wz = p->params + p->fc_latent.w_off;
+      ef.lat_in = (int)lat_in; ef.z_dim = (int)z; ef.coord_dim = p->coord_dim;
+      ef.has_r = p->has_r; ef.has_t = p->has_t; ef.has_s = p->has_s;
+      ef.tp0 = p->t_prior[0]; ef.tp1 = p->t_prior[1]; ef.sc_prior = p->sc_prior; ef.beta = p->beta;
+    } else {
+      f.hz_scale = 0.0f;
+    }
+  }
+  const int kl_n = fold ? (int)B : L.kl_blocks;      // KL partial sums in L.kl_part: per sample when folded, else per 16-row block
+  if (fold) {
+    // (nothing to launch before the decoder kernel)
+  } else if (p->fused >= 2 && L.enc_compact) {
     const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0, p->fused == 2);
     f.hz_scale = prep.scale;                          // the compact encoder's last launch writes scale * hz directly
     PV_TRY(guide_fwd(p, L, s, &prep, f.hz_scale));
@@ -785,23 +819,6 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     if (lat_in <= 16) PV_TRY(pv_smallk_linear(zin, ldz, p->params + p->fc_latent.w_off, L.hz, B, (int)lat_in, (int)H, s));
     else PV_TRY(linear_fwd(zin, ldz, p->params + p->fc_latent.w_off, nullptr, L.hz, nullptr, H, B, lat_in, H, PV_ACT_NONE,
                            L.scratch, L.scratch_bytes, s));
-  }
-  if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
-  if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s));
-  else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
-  if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_stop, s);
-  if (!want_grads && K > 0) {                        // llb[b] = sum_k alpha_bk ll_kb
-    PvLatentBwd lf{};
-    lf.llrow = L.llrow; lf.llb = L.llb; lf.M = R; lf.N = (int)N; lf.H = 0; lf.K = (int)K; lf.alpha = L.alpha;
-    lf.hb.B = (int)B; lf.fwd_only = 1;
-    PV_TRY(pv_latent_bwd(lf, s));
-    return pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, L.kl_blocks, 1.0f, s);
-  }
-  if (!want_grads) {
-    PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
-    PV_TRY(weigh_llb(p, L, s));
-    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* partials come scaled */, s));
-    return extra_outputs(p, L, nullptr, lat_in, s);
   }
   PvFusedOffsets o{p->dec[0].w_off, p->dec[0].b_off, p->dec[1].w_off, p->dec[1].b_off,
                    p->fc_coord.w_off, p->out.w_off, p->out.b_off};
@@ -827,6 +844,23 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     lb.enc_n = p->n_enc; lb.enc_params = p->params; lb.enc_head = p->head;
     for (int i = 0; i < p->n_enc; ++i) { lb.enc_l[i] = p->enc[i]; lb.enc_act[i] = L.eact[i]; lb.enc_dp[i] = L.edp[i]; }
   }
+  if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
+  if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s, fold ? &ef : nullptr));
+  else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
+  if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_stop, s);
+  if (!want_grads && K > 0) {                        // llb[b] = sum_k alpha_bk ll_kb
+    PvLatentBwd lf{};
+    lf.llrow = L.llrow; lf.llb = L.llb; lf.M = R; lf.N = (int)N; lf.H = 0; lf.K = (int)K; lf.alpha = L.alpha;
+    lf.hb.B = (int)B; lf.fwd_only = 1;
+    PV_TRY(pv_latent_bwd(lf, s));
+    return pv_finish_scalars(L.llb, (int)B, p->scalars, L.kl_part, L.kl_blocks, 1.0f, s);
+  }
+  if (!want_grads) {
+    PV_TRY(pv_segsum(L.llrow, B, N, L.llb, s));
+    PV_TRY(weigh_llb(p, L, s));
+    PV_TRY(pv_finish_scalars(L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, kl_n, 1.0f /* partials come scaled */, s));
+    return extra_outputs(p, L, nullptr, lat_in, s);
+  }
   // conv encoder with a side stream: the head's weight gradient forks off this launch (encoder_bwd)
   static const int ab_side = pv_exp_int("PV_HEAD_SIDE", 1);
   static const int ab_fin = pv_exp_int("PV_FIN_RIDE", 1);
@@ -835,7 +869,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   if (head_side) pv_fork_arm();
   PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s));
   // the loss scalars ride in the encoder dgrad launch (compact encoder), in the last weight-gradient launch (conv encoder) or get their own
-  PvFinish fin{L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, L.kl_blocks, 1.0f /* scaled */};
+  PvFinish fin{L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, kl_n, 1.0f /* scaled */};
   const bool fin_rides = L.enc_compact || (ab_fin && L.enc_conv && !L.enc_ext);
   if (!fin_rides) PV_TRY(pv_finish_scalars(fin.llb, fin.B, fin.scalars, fin.kl_part, fin.n_part, fin.beta, s));
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
@@ -1091,6 +1125,16 @@ extern "C" int64_t pv_ivae_workspace_bytes(const pv_ivae_plan* plan) { return pv
 
 extern "C" int pv_ivae_uses_fused(const pv_ivae_plan* plan) {
   return valid_plan(plan) && plan->fused && pv_sdec_fused_supported(plan) ? 1 : 0;
+}
+
+extern "C" int pv_ivae_guide_folds(const pv_ivae_plan* plan) {
+  if (!valid_plan(plan) || !plan->fused || !pv_sdec_fused_supported(plan)) return 0;
+  Layout L;
+  carve(plan, nullptr, L);                             // (offsets only: nothing is dereferenced)
+  if (!L.fused || !plan_guide_may_fold(plan, L)) return 0;
+  PvFused f{};
+  f.M = L.rows; f.units = L.rows / FD_UNIT; f.N = plan->n_pix; f.B = (int)plan_S(plan); f.sel = plan->dec_kernel;
+  return pv_sdec_fused_fold_ok(f, L.f_grid, false) ? 1 : 0;
 }
 
 extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* stream) {

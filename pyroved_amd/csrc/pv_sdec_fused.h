@@ -41,6 +41,34 @@ struct PvFused {
                          // staged activations: 2^dl_exp * |dL/dlogit| should sit around 1 .. 2^8 (Bernoulli 4; Gaussian: -log2(1 / sig^2))
 };
 
+// ---- the guide folded into the decoder launch (round 5; pv_sdec_fused_w8.hip) -------------------------------------------------
+// When a workgroup's unit range is a whole number of images (batch a multiple of the grid: BASELINE's batch 256 on 256 CUs is one
+// image per workgroup) the workgroup can run its images' guide ITSELF in the launch's prologue — fcEncoderNet.forward (nets/fc.py:
+// 51-61) as fp32 matrix-vector products straight from the L2-resident weights, the reparameterised sample and its sampled-KL terms
+// (models/ivae.py:204-221), _split_latent (models/base.py:97-119) and fc_latent(z) — and convert the decoder's two hidden weight
+// matrices into its own LDS images: the encoder launch (18.7 us of dependent latency for 51 MFLOP), its hand-off protocol and the
+// global weight-image copy all disappear from the step.  Everything the backward launches read is written exactly where the
+// encoder launch would have put it.
+struct PvEncFold {
+  const float* params;
+  pv_layer enc0, enc1, head;       // two hidden layers (widths 128) + the merged [mu | softplus input] head
+  const float* x; int64_t ldx;     // (B, ldx) observations (the encoder's input: x.view(B, N))
+  const float* eps;                // (B, z_dim)
+  float* eact0; float* eact1;      // hidden activations (B, 128)
+  float* head_out;                 // (B, 2 z_dim)
+  float* z; float* z_scale; float* z_loc_out; float* z_scale_out;
+  float* tp;                       // (B, 8) cos, sin, scale, tx, ty
+  float* kl_part;                  // (B, 2): beta * log p(z_b), beta * log q(z_b | x_b)
+  float* hz; const float* Wz;      // (B, 128) fc_latent(z content) * C ; fc_latent.weight (128, lat_in)
+  int lat_in, z_dim, coord_dim, has_r, has_t, has_s;
+  float tp0, tp1, sc_prior, beta;
+  int img_per_wg;                  // images per workgroup (B / grid): 1
+};
+// whether the launch of (f, grads) can host the guide of `p`'s encoder (the caller checks the encoder's architecture)
+bool pv_sdec_fused_w8_fold_ok(const PvFused& f, int grid);
+// ... and whether the launcher will pick that kernel for (f, x3) at all
+bool pv_sdec_fused_fold_ok(const PvFused& f, int grid, bool x3);
+
 // true when the plan's architecture is the one the fused kernel is specialised for
 bool pv_sdec_fused_supported(const pv_ivae_plan* p);
 // workgroups the kernel runs with (<= number of CUs, <= units)
@@ -58,8 +86,8 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
 // ... or, as arguments for a kernel that hosts the preparation (pv_fb_layout.h: pv_fb_prep)
 struct PvFbPrep;
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3);
-int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s);
-int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s);
+int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s, const PvEncFold* fold = nullptr);
+int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s, const PvEncFold* fold = nullptr);
 // the 8-wave split-precision kernel (pv_sdec_fused_w8x3.hip; images pre-scaled by 2 log2(e) like the plain 8-wave kernel's)
 int pv_sdec_fused_w8x3_launch(const PvFused& f, int grid, bool grads, hipStream_t s, int waves);   // waves: 8 or 4
 int64_t pv_sdec_fused_w8x3_park_bytes(int grid);

@@ -1092,13 +1092,18 @@ int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel)
 // measurement hook (not in include/): the kernel a decoder launch of (fused mode, units, grads, likelihood) dispatches, spelled
 // the way rocprofv3 prints it — bench.py puts it in `roofline.kernel` so that the line can be matched against
 // profiles/*_kernel_stats.csv by name
+extern "C" const char* pv_debug_decoder_kernel_name_fold(int grads, int lik) {      // (the launch that hosts the guide: pv_ivae_guide_folds)
+  static thread_local char buf[128];
+  snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d, true>(PvFused, PvEncFold)", grads ? "true" : "false", lik);
+  return buf;
+}
 extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, int grads, int lik) {
   static thread_local char buf[128];
   const char* g = grads ? "true" : "false";
   if (fused == 1) snprintf(buf, sizeof buf, "void pv_sdec_fused_kernel<%s>(PvFused)", g);
   else if (fused == 2 && fb_kind_w8h(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8h_kernel<%d, %s>(PvFused)", lik, fb_x3_kind(units, grads != 0, 0) == 48 ? "true" : "false");
   else if (fused == 2 && !fb_kind_here(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d, %d>(PvFused)", g, lik, fb_x3_kind(units, grads != 0, 0));
-  else if (fused == 3 && fb_use_w8(units, 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d>(PvFused)", g, lik);
+  else if (fused == 3 && fb_use_w8(units, 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d, false>(PvFused, PvEncFold)", g, lik);
   else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %d>(PvFused)", g, lik, fused == 2 ? fb_kind_prec(fb_x3_kind(units, grads != 0, 0)) : FB_P_BF16);
   else snprintf(buf, sizeof buf, "pv_gemm_kernel (layer-by-layer path)");
   return buf;
@@ -1126,7 +1131,12 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
   return 0;
 }
 
-int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s) {
+bool pv_sdec_fused_fold_ok(const PvFused& f, int grid, bool x3) {
+  return !x3 && fb_use_w8(f.units, f.sel) && pv_sdec_fused_w8_fold_ok(f, grid);
+}
+
+int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s, const PvEncFold* fold) {
+  if (fold && (x3 || !fb_use_w8(f_in.units, f_in.sel))) return PV_EINVAL;      // (the folded guide lives in the 8-wave plain-bf16 kernel)
   int prec = FB_P_BF16;
   if (x3) {
     const int kind = fb_x3_kind(f_in.units, grads, f_in.sel);
@@ -1138,7 +1148,7 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3
     if (!fb_kind_here(kind)) return pv_sdec_fused_w8x3_launch(f_in, grid, grads, s, kind);
     prec = fb_kind_prec(kind);
   } else if (fb_use_w8(f_in.units, f_in.sel)) {
-    return pv_sdec_fused_w8_launch(f_in, grid, grads, s);
+    return pv_sdec_fused_w8_launch(f_in, grid, grads, s, fold);
   }
   PvFused f = f_in;
   static const int ablate = pv_exp_int("PV_FD_ABLATE", 0);

@@ -405,9 +405,81 @@ __device__ __forceinline__ f32x4 w8_mul_dtanh4(const f32x4& d, const bf16x4& hb)
   return d * (t * t - 1.0f);
 }
 
-// LIK: the likelihood is a compile-time choice
-template <bool GRADS, int LIK>
-__global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
+// ---- the guide in the prologue (PvEncFold, pv_sdec_fused.h) ------------------------------------------------------------------
+// LDS scratch of the folded guide: the staging arrays, which the tile loop has not touched yet
+#define WF_H1 WO_SA                                 // hidden activations, 128 floats each
+#define WF_H2 (WF_H1 + 512)
+#define WF_HD (WF_H2 + 512)                         // head pre-activations (<= 64), then z (<= 32) at +256
+#define WF_P (WF_HD + 512)                          // per wave: 64 lanes x 17 partial sums
+#define WF_P_WAVE (64 * 17 * 4)
+static_assert(WF_P + W8_WAVES * WF_P_WAVE <= WO_VEC, "guide scratch fits in the staging arrays");
+// rows j0 .. j0 + 15 (clamped to nrows - 1) of y = W x for ONE wave: W row-major (nrows, K) fp32 in global memory (L2-resident:
+// every workgroup reads the same matrix), K % 4 == 0, K <= 1024, x anywhere (global: the image itself — no staging, no barrier
+// in front of the first layer).  Lane l takes the float4 columns l, l + 64, ... of every row (coalesced 1 KB per row and
+// instruction, all of a pass's 34 loads independent), the 64 x 16 partial sums are transposed through LDS (P: 64 x 17 floats
+// of this wave) and each lane returns y[j0 + (lane & 15)] — plain fp32 fused multiply-adds in a fixed order.
+__device__ __forceinline__ f32x4 w8_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float w8_dot4(const f32x4& w, const f32x4& x, float acc) {
+  return fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc))));
+}
+__device__ __forceinline__ float w8_gemv16(const float* __restrict__ W, int K, int nrows, int j0, const float* __restrict__ x,
+                                           float* __restrict__ P, int lane) {
+  const int K4 = K >> 2;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  for (int c0 = 0; c0 < K4; c0 += 128) {            // two column groups per pass
+    const int ka = c0 + lane, kb = c0 + 64 + lane;
+    const bool oka = ka < K4, okb = kb < K4;
+    f32x4 xa = w8_ld4(x + 4 * (oka ? ka : 0)), xb = w8_ld4(x + 4 * (okb ? kb : 0));
+    f32x4 wa[16], wb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = j0 + i < nrows ? j0 + i : nrows - 1;
+      const float* wr = W + (int64_t)row * K;
+      wa[i] = w8_ld4(wr + 4 * (oka ? ka : 0));
+      wb[i] = w8_ld4(wr + 4 * (okb ? kb : 0));
+    }
+    if (!oka) xa = f32x4{0.0f, 0.0f, 0.0f, 0.0f};    // (a column that does not exist contributes w * 0)
+    if (!okb) xb = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = w8_dot4(wb[i], xb, w8_dot4(wa[i], xa, acc[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) P[lane * 17 + i] = acc[i];
+  const int r = lane & 15, q = lane >> 4;
+  float v = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v += P[(16 * q + i) * 17 + r];
+  return pv_sum_rows(v);
+}
+// the same for K <= 128 (the hidden layers and the head: x in LDS): TWO rows per load instruction — lanes 0-31 take row
+// j0 + 2i, lanes 32-63 row j0 + 2i + 1 — so 8 loads cover the 16 rows with every lane busy
+__device__ __forceinline__ float w8_gemv16_k128(const float* __restrict__ W, int K, int nrows, int j0, const float* __restrict__ xs,
+                                                float* __restrict__ P, int lane) {
+  const int K4 = K >> 2, c = lane & 31, half = lane >> 5;
+  const bool ok = c < K4;
+  f32x4 xv = w8_ld4(xs + 4 * (ok ? c : 0));
+  f32x4 wv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = j0 + 2 * i + half < nrows ? j0 + 2 * i + half : nrows - 1;
+    wv[i] = w8_ld4(W + (int64_t)row * K + 4 * (ok ? c : 0));
+  }
+  if (!ok) xv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) P[lane * 9 + i] = w8_dot4(wv[i], xv, 0.0f);
+  // lane (r, q): row j0 + r = j0 + 2 (r >> 1) + (r & 1): the 32 lanes of half r & 1, eight of them per q
+  const int r = lane & 15, q = lane >> 4;
+  float v = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v += P[(32 * (r & 1) + 8 * q + t) * 9 + (r >> 1)];
+  return pv_sum_rows(v);
+}
+
+// LIK: the likelihood is a compile-time choice.  FOLD: the workgroup runs its images' guide itself (PvEncFold e; else unused)
+template <bool GRADS, int LIK, bool FOLD>
+__global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEncFold e) {
   extern __shared__ __attribute__((aligned(16))) char smb[];
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,13 +496,23 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   W8_STAMP_K(0);
 
   // ---- prologue: weight images by LDS-DMA (W1 at image 0, W2 at image 2 of the prepared set), vectors and tables ----
-  {
+  f32x4 w1v[8], w2v[8];                               // (FOLD: the fp32 weights in flight while the guide runs)
+  if (!FOLD) {
     constexpr int PIECES = IMG_BYTES / (W8_WAVES * 1024);
 #pragma unroll
     for (int c = 0; c < PIECES; ++c) {
       const int off = (wave * PIECES + c) * 1024;
       w8_glds16(gimg + off + lane * 16, lds0 + WO_W1 + off);
       w8_glds16(gimg + 2 * IMG_BYTES + off + lane * 16, lds0 + WO_W2 + off);
+    }
+  } else {
+    // FOLD: the images straight from the fp32 weights (pv_fb_layout.h pv_fb_prep, mode 0: bf16(C w), permuted columns,
+    // swizzled chunks) — 8 float4 of each matrix per thread; and this workgroup's dL/d(hz) slots cleared
+    if (GRADS) {
+      const int64_t b0 = (int64_t)g * e.img_per_wg;
+      f32x4* zp = reinterpret_cast<f32x4*>(f.part_hz + b0 * f.kmax * FD_H);
+      const int n4 = e.img_per_wg * f.kmax * (FD_H / 4);
+      for (int i = tid; i < n4; i += W8_THREADS) zp[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
   }
   if (tid < FD_H) {
@@ -469,6 +551,143 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
       a[e] = m >= 4 ? (__bf16)0.0f : ((m & 1) ? lo : hi);
     }
     reinterpret_cast<bf16x8*>(smb + WO_TTAB)[tid] = a;
+  }
+  if (FOLD) {
+    // ---- the guide of this workgroup's images (nets/fc.py:51-61, models/ivae.py:204-221, models/base.py:97-119) ----
+    // (barriers here are LDS-only: the global stores of this phase are read back after the closing __syncthreads alone)
+    float* h1s = reinterpret_cast<float*>(smb + WF_H1);
+    float* h2s = reinterpret_cast<float*>(smb + WF_H2);
+    float* hds = reinterpret_cast<float*>(smb + WF_HD);
+    float* zs = hds + 64;
+    float* P = reinterpret_cast<float*>(smb + WF_P + wave * WF_P_WAVE);
+    const int N = (int)e.ldx, zd = e.z_dim;
+    const int r_ = lane & 15, q_ = lane >> 4;
+    {
+      const int64_t b = g;                                         // one image per workgroup (pv_sdec_fused_w8_fold_ok)
+      // small operands of the later phases, requested up front (each would otherwise head its phase with an L2 / HBM round trip)
+      const int jw = 16 * wave + r_;
+      const float pb1 = (e.enc1.b_off >= 0 && jw < e.enc1.out_dim) ? e.params[e.enc1.b_off + jw] : 0.0f;
+      const float pbh = (e.head.b_off >= 0 && jw < e.head.out_dim) ? e.params[e.head.b_off + jw] : 0.0f;
+      const float pep = (wave == 0 && lane < zd) ? e.eps[b * zd + lane] : 0.0f;
+      float pwz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (tid < FD_H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pwz[i] = i < e.lat_in ? e.Wz[(int64_t)tid * e.lat_in + i] : 0.0f;
+      }
+      {
+        // (every workgroup reads the same 400 KB matrix at the same time: which wave takes which 16 rows rotates with the
+        //  workgroup index, so that the chip's requests spread over the L2 channels instead of marching through them in step)
+        const int jr = 16 * ((wave + g) & (W8_WAVES - 1));
+        const float v = w8_gemv16(e.params + e.enc0.w_off, N, e.enc0.out_dim, jr, e.x + b * e.ldx, P, lane);
+        const int j = jr + r_;
+        if (q_ == 0 && j < e.enc0.out_dim) {
+          const float y = pv_act_fwd2(v + (e.enc0.b_off >= 0 ? e.params[e.enc0.b_off + j] : 0.0f), e.enc0.act);
+          h1s[j] = y;
+          e.eact0[b * e.enc0.out_dim + j] = y;
+        }
+      }
+      W8_STAMP_K(4);
+      {
+        // the decoder's fp32 hidden weights, requested now (the first layer's 34 operand registers per lane are free again)
+        // and converted into the LDS images after the guide: 8 float4 of each matrix per thread
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = tid + W8_THREADS * u;
+          w1v[u] = reinterpret_cast<const f32x4*>(f.W1)[idx];
+          w2v[u] = reinterpret_cast<const f32x4*>(f.W2)[idx];
+        }
+      }
+      pv_lds_barrier();
+      {
+        const float v = w8_gemv16_k128(e.params + e.enc1.w_off, e.enc1.in_dim, e.enc1.out_dim, 16 * wave, h1s, P, lane);
+        const int j = 16 * wave + r_;
+        if (q_ == 0 && j < e.enc1.out_dim) {
+          const float y = pv_act_fwd2(v + pb1, e.enc1.act);
+          h2s[j] = y;
+          e.eact1[b * e.enc1.out_dim + j] = y;
+        }
+      }
+      W8_STAMP_K(5);
+      pv_lds_barrier();
+      if (16 * wave < e.head.out_dim) {                            // [mu | softplus input]: 16 rows per wave
+        const float v = w8_gemv16_k128(e.params + e.head.w_off, e.head.in_dim, e.head.out_dim, 16 * wave, h2s, P, lane);
+        const int j = 16 * wave + r_;
+        if (q_ == 0 && j < e.head.out_dim) {
+          const float y = v + pbh;
+          hds[j] = y;
+          e.head_out[b * e.head.out_dim + j] = y;
+        }
+      }
+      W8_STAMP_K(6);
+      pv_lds_barrier();
+      if (wave == 0) {
+        // z = mu + softplus(s) eps and the sampled-KL terms (torch Normal.log_prob), one lane per latent coordinate
+        float lp = 0.0f, lq = 0.0f;
+        if (lane < zd) {
+          const float mu = hds[lane], sig = pv_softplus(hds[zd + lane]);
+          const float ep = pep;
+          const float z = mu + sig * ep;
+          e.z[b * zd + lane] = z;
+          e.z_scale[b * zd + lane] = sig;
+          if (e.z_loc_out) e.z_loc_out[b * zd + lane] = mu;
+          if (e.z_scale_out) e.z_scale_out[b * zd + lane] = sig;
+          const float d = z - mu;
+          lq = -(d * d) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI;
+          lp = -(z * z) / 2.0f - LOG_SQRT_2PI;
+          zs[lane] = z;
+        }
+        lp = pv_wave_sum(lp);
+        lq = pv_wave_sum(lq);
+        if (lane == 0) {
+          e.kl_part[2 * b] = e.beta * lp;
+          e.kl_part[2 * b + 1] = e.beta * lq;
+          // _split_latent -> the transform parameters (models/base.py:97-119; the t / s priors of models/ivae.py:187-191)
+          const float* zb = zs;
+          int idx = 0;
+          float c = 1.0f, sn = 0.0f, sc = 1.0f, tx = 0.0f, ty = 0.0f;
+          if (e.coord_dim == 1) {
+            if (e.has_t) { tx = zb[0] * e.tp0; idx = 1; }
+          } else if (e.coord_dim == 2) {
+            if (e.has_r) { const float phi = zb[idx++]; c = cosf(phi); sn = sinf(phi); }
+            if (e.has_t) { tx = zb[idx] * e.tp0; ty = zb[idx + 1] * e.tp1; idx += 2; }
+            if (e.has_s) { sc = 1.0f + e.sc_prior * zb[idx++]; }
+          }
+          float* t = e.tp + b * 8;
+          t[0] = c; t[1] = sn; t[2] = sc; t[3] = tx; t[4] = ty;
+        }
+      }
+      pv_lds_barrier();
+      if (tid < FD_H) {
+        // hz = C fc_latent(z content) (nets/fc.py:217,230: no bias)
+        int coord = 0;
+        if (e.coord_dim == 1) coord = e.has_t ? 1 : 0;
+        else if (e.coord_dim == 2) coord = e.has_r + 2 * e.has_t + e.has_s;
+        const float* wz = e.Wz + (int64_t)tid * e.lat_in;
+        float v = 0.0f;
+        for (int i = 0; i < e.lat_in; ++i) v += zs[coord + i] * (i < 4 ? pwz[i] : wz[i]);
+        e.hz[b * FD_H + tid] = v * W8_C;
+      }
+      W8_STAMP_K(7);
+    }
+  }
+  if (FOLD) {
+    // ... and the decoder's weight images from the fp32 values requested before the guide
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    __bf16* i1 = reinterpret_cast<__bf16*>(smb + WO_W1);
+    __bf16* i2 = reinterpret_cast<__bf16*>(smb + WO_W2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + W8_THREADS * u, row = idx >> 5, c4 = idx & 31;
+      us4 h1, h2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        h1[i] = __builtin_bit_cast(unsigned short, (__bf16)(w1v[u][i] * W8_C));
+        h2[i] = __builtin_bit_cast(unsigned short, (__bf16)(w2v[u][i] * W8_C));
+      }
+      const int el = fb_wel(row, fb_pcol(4 * c4));
+      *reinterpret_cast<us4*>(i1 + el) = h1;
+      *reinterpret_cast<us4*>(i2 + el) = h2;
+    }
   }
   w8_wait_vm0();
   __syncthreads();
@@ -1059,12 +1278,27 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f) {
   W8_STAMP_K(3);
 }
 
-int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s) {
+// the guide can ride in this launch when every workgroup's unit range is exactly one image (batch == grid: BASELINE's batch
+// 256 on 256 CUs; with more images per workgroup their guides would run one after the other in front of the tile loop)
+bool pv_sdec_fused_w8_fold_ok(const PvFused& f, int grid) {
+  if (f.N % FD_UNIT != 0 || f.N > 1024 || f.N % 4 != 0 || grid < 1 || f.B % grid != 0 || f.x_units != 0) return false;
+  const int ipw = f.B / grid;
+  return ipw == 1 && f.units == (int64_t)f.B * (f.N / FD_UNIT);      // ONE image per workgroup: batch == grid
+}
+
+int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s, const PvEncFold* fold) {
   PvFused f = f_in;
   f.ablate = 0;
   const size_t lds = W8_LDS_BYTES;
   const void* fn = nullptr;
-#define W8_PICK(G, L) fn = reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L>)
+  PvEncFold e{};
+  if (fold) {
+    if (!pv_sdec_fused_w8_fold_ok(f, grid)) return PV_EINVAL;
+    e = *fold;
+    e.img_per_wg = f.B / grid;
+  }
+#define W8_PICK(G, L) fn = fold ? reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, true>) \
+                                : reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, false>)
   if (grads) {
     if (f.lik == PV_LIK_BERNOULLI) W8_PICK(true, PV_LIK_BERNOULLI);
     else if (f.lik == PV_LIK_GAUSSIAN) W8_PICK(true, PV_LIK_GAUSSIAN);
@@ -1076,7 +1310,7 @@ int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream
   }
 #undef W8_PICK
   PV_TRY(pv_set_dynamic_lds(fn, (int)lds));          // (per device and kernel)
-  void* args[] = {&f};
+  void* args[] = {&f, &e};
   hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(W8_THREADS), args, lds, s);
   if (e2 != hipSuccess) return (int)e2;
   PV_LAUNCH_CHECK();

@@ -8,6 +8,7 @@ from pyroved_amd import _abi
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
 eng = model.engine(fused=3)
+eng.enc_fold = os.environ.get('PV_TRACE_FOLD', '1') != '0'
 x = torch.rand(B, 28, 28, generator=torch.Generator().manual_seed(0)).cuda()
 eps = torch.randn(B, model.z_dim).cuda()
 for _ in range(3):
@@ -33,6 +34,10 @@ for w, base in ((0, 0), (7, 256)):
         print("wave", w, "tile", t, "total", prev - st[0], " ".join(out))
     nxt = [buf[base + t * 16] for t in range(8) if buf[base + t * 16]]
     print("wave", w, "tile starts (delta):", [b - a for a, b in zip(nxt, nxt[1:])])
+if buf[128 + 4]:
+    kk = [buf[128 + i] for i in (0, 4, 5, 6, 7, 1)]
+    print("folded guide (workgroup 0, wave 0): entry -> layer 0 %d, layer 1 %d, head %d, sample + split + fc_latent %d, images + barrier %d cycles"
+          % tuple(b - a for a, b in zip(kk, kk[1:])))
 k = [buf[128 + i] for i in range(4)]
 if k[0]:
     print("launch (workgroup 0, wave 0): prologue %d, tile loop %d, epilogue (flush, record, column sums) %d cycles" % (k[1] - k[0], k[2] - k[1], k[3] - k[2]))

@@ -1203,7 +1203,11 @@ def test_full_size_properties(gpu_device, cfgname, fused):
     eng.loss_and_grads(x[h:], eps[h:])
     g1, s1 = eng.grad[:eng.n_flat].clone(), eng.scalars.clone()
     np.testing.assert_allclose((s0 + s1).cpu().numpy(), s_full.cpu().numpy(), rtol=2e-6)
-    assert rel_l2(g0 + g1, g_full) < 2e-6
+    # (round 5: at batch == grid the full batch's guide rides in the decoder launch — fp32 matrix-vector products in another
+    #  summation order than the encoder launch the half batches take; under bf16 decoder operands a last-bit change of z moves
+    #  roundings: measured 2.9e-6 there, 2e-6 everywhere else)
+    folds = fused == 3 and bool(_abi.lib().pv_ivae_guide_folds(C.byref(eng._plan(b))))
+    assert rel_l2(g0 + g1, g_full) < (6e-6 if folds else 2e-6)
     assert torch.isfinite(g_full).all()
 
 
@@ -2084,6 +2088,63 @@ def test_fused_1d_decoder_matches_layer_launches(gpu_device, precision):
         pass
 
 
+@pytest.mark.parametrize("case", ["rt_b256", "r_b512", "rts_b256_16x16", "t1d_b256"])
+def test_guide_folded_into_the_decoder_launch(gpu_device, case):
+    """Round 5: where a decoder workgroup's rows are a whole number of images (batch a multiple of the grid: BASELINE's batch
+    256 on 256 CUs) the plain-bf16 fused step runs the guide — fcEncoderNet.forward (nets/fc.py:51-61), the reparameterised sample
+    and its KL terms (models/ivae.py:204-221), _split_latent (models/base.py:97-119), fc_latent — in the decoder launch's prologue
+    (csrc/pv_sdec_fused_w8.hip, PvEncFold) as exact fp32 matrix-vector products.  Against the separate encoder launch
+    (PV_PLAN_NO_ENC_FOLD) the encoder's outputs agree to fp32 rounding, the loss to 1e-5, every gradient to the mode's bars vs the
+    ORACLE on both paths; the folded step is bit-reproducible and its one-call form (pv_ivae_step) bit-identical to the two calls."""
+    torch.set_num_threads(8)
+    data_dim, inv, b = {"rt_b256": ((28, 28), ["r", "t"], 256), "r_b512": ((28, 28), ["r"], 512),
+                        "rts_b256_16x16": ((16, 16), ["r", "t", "s"], 256), "t1d_b256": ((64,), ["t"], 256)}[case]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(b, *data_dim, generator=g)
+    res = {}
+    for fold in (True, False):
+        m = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+        eng = m.engine(fused=3)
+        eng.enc_fold = fold
+        eps = torch.randn(b, m.z_dim, generator=torch.Generator().manual_seed(5))
+        p = eng._plan(b)
+        folds = bool(_abi.lib().pv_ivae_guide_folds(C.byref(p)))
+        n_units = b * int(np.prod(data_dim)) // 16
+        expect = fold and b == cus and n_units >= 6 * cus
+        assert folds == expect, (case, fold, folds, expect)
+        eng.loss_and_grads(x.cuda(), eps.cuda())
+        torch.cuda.synchronize()
+        rec = dict(scalars=eng.scalars.clone(), grad=eng.grad.clone(), folds=folds)
+        eng.loss_and_grads(x.cuda(), eps.cuda())
+        assert torch.equal(rec["grad"], eng.grad) and torch.equal(rec["scalars"], eng.scalars)      # bit-reproducible
+        eng.loss_and_grads(x.cuda(), eps.cuda(), want_grads=False)
+        np.testing.assert_allclose(eng.scalars.cpu().numpy(), rec["scalars"].cpu().numpy(), rtol=2e-6)
+        cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv)
+        o = orc.SVIOracle({k: v.cpu() for k, v in m.state_dict().items()}, cfg)
+        ref = o.step(x, eps)
+        np.testing.assert_allclose(rec["scalars"][0].item(), ref, rtol=1e-4)
+        for key in o.p:
+            lo = eng._layout[key]
+            err = rel_l2(rec["grad"][lo:lo + o.p[key].numel()].view_as(o.p[key]), o.last_grads[key])
+            assert err < 3e-2, "%s fold=%s grad %s: rel l2 error %.3e vs oracle" % (case, fold, key, err)
+        # the one-call step on the same state: parameters bit-identical to loss_and_grads + adam_step
+        m2 = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+        e2 = m2.engine(fused=3); e2.enc_fold = fold
+        e2.loss_and_grads(x.cuda(), eps.cuda()); e2.adam_step()
+        m3 = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+        e3 = m3.engine(fused=3); e3.enc_fold = fold
+        e3.loss_and_grads(x.cuda(), eps.cuda(), step=True)
+        torch.cuda.synchronize()
+        assert torch.equal(e2.flat, e3.flat)
+        rec["z"] = m.encode(x)                          # (pv_ivae_encode: the encoder kernels — the same weights either way)
+        res[fold] = rec
+    a, c = res[True], res[False]
+    np.testing.assert_allclose(a["scalars"].cpu().numpy(), c["scalars"].cpu().numpy(), rtol=1e-5)
+    if a["folds"]:
+        assert rel_l2(a["grad"][:eng.n_flat], c["grad"][:eng.n_flat]) < 2e-2       # (bf16 operands: a last-bit change of z moves roundings)
+
+
 def test_one_launch_encoder_at_large_batch(gpu_device):
     """The compact encoder's one-launch form (csrc/pv_encoder.hip pv_enc_kernel: first-layer tiles and the rest of the encoder in
     one grid, hand-off through per-tile flags) at a batch whose grid (4 600 workgroups) does not fit the device at once: the
@@ -2127,6 +2188,7 @@ def test_one_launch_encoder_fallback_is_exact(gpu_device, b):
             eng = m.engine(fused=3)
             eng.enc_two_launch = bool(two)               # pv_ivae_plan.flags: PV_PLAN_ENC_TWO_LAUNCH
             eng.enc_no_wait = spin == 0                  # ... PV_PLAN_ENC_NO_WAIT (ABI v15; a process-wide debug setter before)
+            eng.enc_fold = False                         # (round 5: at batch 256 the guide would ride in the decoder launch)
             zl, zs = m.encode(x)
             eng.loss_and_grads(x, eps)
             torch.cuda.synchronize()
