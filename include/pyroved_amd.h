@@ -274,8 +274,7 @@ int64_t pv_ivae_workspace_bytes_for(const pv_ivae_plan* plan, int what);
 int pv_ivae_uses_fused(const pv_ivae_plan* plan);
 
 /* (v15) 1 if pv_ivae_loss_and_grads / pv_ivae_step will run this plan's guide (fc encoder, reparameterised sample, split,
- * fc_latent) INSIDE the decoder launch instead of as a launch of its own (see PV_PLAN_NO_ENC_FOLD), 0 otherwise (also while the
- * stream is being captured). */
+ * fc_latent) INSIDE the decoder launch instead of as a launch of its own (see PV_PLAN_NO_ENC_FOLD), 0 otherwise. */
 int pv_ivae_guide_folds(const pv_ivae_plan* plan);
 
 /* Trace_ELBO.loss_and_grads for iVAE.guide + iVAE.model (models/ivae.py:165-221,

@@ -778,7 +778,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // launch, no weight-image copy, no hand-off: the step is decoder launch -> latent backward + record sums -> small weight gradients.
   PvEncFold ef{};
   bool fold = false;
-  if (plan_guide_may_fold(p, L) && !pv_stream_capturing(s)) {
+  if (plan_guide_may_fold(p, L)) {       // (no cross-workgroup hand-off in it: fine under stream capture too)
     f.hz_scale = 2.8853900817779268f;
     fold = pv_sdec_fused_fold_ok(f, L.f_grid, p->fused == 2);
     if (fold) {

@@ -414,24 +414,27 @@ __device__ __forceinline__ f32x4 w8_mul_dtanh4(const f32x4& d, const bf16x4& hb)
 #define WF_P_WAVE (64 * 17 * 4)
 static_assert(WF_P + W8_WAVES * WF_P_WAVE <= WO_VEC, "guide scratch fits in the staging arrays");
 // rows j0 .. j0 + 15 (clamped to nrows - 1) of y = W x for ONE wave: W row-major (nrows, K) fp32 in global memory (L2-resident:
-// every workgroup reads the same matrix), K % 4 == 0, K <= 1024, x anywhere (global: the image itself — no staging, no barrier
-// in front of the first layer).  Lane l takes the float4 columns l, l + 64, ... of every row (coalesced 1 KB per row and
+// every workgroup reads the same matrix), K % 4 == 0, K <= 1024, x in registers (the image itself, requested at kernel entry:
+// it comes from HBM, the weights from L2 — no staging, no barrier in front of the first layer).  Lane l takes the float4 columns l, l + 64, ... of every row (coalesced 1 KB per row and
 // instruction, all of a pass's 34 loads independent), the 64 x 16 partial sums are transposed through LDS (P: 64 x 17 floats
 // of this wave) and each lane returns y[j0 + (lane & 15)] — plain fp32 fused multiply-adds in a fixed order.
 __device__ __forceinline__ f32x4 w8_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ float w8_dot4(const f32x4& w, const f32x4& x, float acc) {
   return fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc))));
 }
-__device__ __forceinline__ float w8_gemv16(const float* __restrict__ W, int K, int nrows, int j0, const float* __restrict__ x,
-                                           float* __restrict__ P, int lane) {
+template <class HOOK>
+__device__ __forceinline__ float w8_gemv16(const float* __restrict__ W, int K, int nrows, int j0, const f32x4 (&xr)[4],
+                                           float* __restrict__ P, int lane, HOOK after_last_loads) {
   const int K4 = K >> 2;
+  const int npass = (K4 + 127) >> 7;
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  for (int c0 = 0; c0 < K4; c0 += 128) {            // two column groups per pass
+  for (int pi = 0; pi < npass; ++pi) {              // two column groups per pass
+    const int pj = pi, c0 = pj << 7;
     const int ka = c0 + lane, kb = c0 + 64 + lane;
     const bool oka = ka < K4, okb = kb < K4;
-    f32x4 xa = w8_ld4(x + 4 * (oka ? ka : 0)), xb = w8_ld4(x + 4 * (okb ? kb : 0));
+    f32x4 xa = pj == 0 ? xr[0] : xr[2], xb = pj == 0 ? xr[1] : xr[3];     // (x: requested at kernel entry, column groups l + 64 c)
     f32x4 wa[16], wb[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -440,6 +443,7 @@ __device__ __forceinline__ float w8_gemv16(const float* __restrict__ W, int K, i
       wa[i] = w8_ld4(wr + 4 * (oka ? ka : 0));
       wb[i] = w8_ld4(wr + 4 * (okb ? kb : 0));
     }
+    if (pi == npass - 1) after_last_loads();
     if (!oka) xa = f32x4{0.0f, 0.0f, 0.0f, 0.0f};    // (a column that does not exist contributes w * 0)
     if (!okb) xb = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -455,17 +459,21 @@ __device__ __forceinline__ float w8_gemv16(const float* __restrict__ W, int K, i
 }
 // the same for K <= 128 (the hidden layers and the head: x in LDS): TWO rows per load instruction — lanes 0-31 take row
 // j0 + 2i, lanes 32-63 row j0 + 2i + 1 — so 8 loads cover the 16 rows with every lane busy
-__device__ __forceinline__ float w8_gemv16_k128(const float* __restrict__ W, int K, int nrows, int j0, const float* __restrict__ xs,
-                                                float* __restrict__ P, int lane) {
+// (the weights are requested by w8_gemv16_k128_load long before x exists — behind the first layer's loads in the memory queue —
+//  so that the later layers start with their operands in registers instead of an L2 round trip each)
+__device__ __forceinline__ void w8_gemv16_k128_load(const float* __restrict__ W, int K, int nrows, int j0, int lane, f32x4 (&wv)[8]) {
   const int K4 = K >> 2, c = lane & 31, half = lane >> 5;
   const bool ok = c < K4;
-  f32x4 xv = w8_ld4(xs + 4 * (ok ? c : 0));
-  f32x4 wv[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = j0 + 2 * i + half < nrows ? j0 + 2 * i + half : nrows - 1;
     wv[i] = w8_ld4(W + (int64_t)row * K + 4 * (ok ? c : 0));
   }
+}
+__device__ __forceinline__ float w8_gemv16_k128(const f32x4 (&wv)[8], int K, const float* __restrict__ xs, float* __restrict__ P, int lane) {
+  const int K4 = K >> 2, c = lane & 31;
+  const bool ok = c < K4;
+  f32x4 xv = w8_ld4(xs + 4 * (ok ? c : 0));
   if (!ok) xv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < 8; ++i) P[lane * 9 + i] = w8_dot4(wv[i], xv, 0.0f);
@@ -494,6 +502,16 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   float* red = reinterpret_cast<float*>(smb + WO_RED);
   const char* gimg = reinterpret_cast<const char*>(f.wimg);
   W8_STAMP_K(0);
+  f32x4 xr[4];                                        // FOLD: the workgroup's image, float4 columns lane + 64 c (c < 4)
+  if (FOLD) {
+    const int K4 = (int)(e.ldx >> 2);
+    const float* xg = e.x + (int64_t)g * e.ldx;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k4 = lane + 64 * c;
+      xr[c] = *reinterpret_cast<const f32x4*>(xg + 4 * (k4 < K4 ? k4 : 0));
+    }
+  }
 
   // ---- prologue: weight images by LDS-DMA (W1 at image 0, W2 at image 2 of the prepared set), vectors and tables ----
   f32x4 w1v[8], w2v[8];                               // (FOLD: the fp32 weights in flight while the guide runs)
@@ -515,43 +533,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       for (int i = tid; i < n4; i += W8_THREADS) zp[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
   }
-  if (tid < FD_H) {
-    vec[tid] = f.wo[tid];
-    vec[FD_H + tid] = W8_C * f.b1[tid];
-    vec[2 * FD_H + tid] = W8_C * f.b2[tid];
-  }
-  {
-    // coordinate layer A operands (v_mfma_f32_16x16x16_bf16: lane (m, kq) holds A[m][4kq .. 4kq+3]), k slots:
-    //   kq 0: [wh0 wh0 wl0 0] x [xh0 xl0 xh0 0]   kq 1: the same for coordinate 1   kq 2: [bch bcl 0 0] x [1 1 0 0]
-    const int jb = tid >> 6, m = lane & 15, kq = lane >> 4, j = 16 * jb + m;
-    float v = 0.0f;
-    if (kq == 0) v = W8_C * f.Wc[j * f.cd];
-    else if (kq == 1) v = f.cd == 2 ? W8_C * f.Wc[j * 2 + 1] : 0.0f;
-    else if (kq == 2) v = W8_C * f.bc[j];
-    __bf16 hi, lo;
-    fb_split(v, hi, lo);
-    bf16x4 a = w8_zero4();
-    if (kq < 2) { a[0] = hi; a[1] = hi; a[2] = lo; }
-    else if (kq == 2) { a[0] = hi; a[1] = lo; }
-    reinterpret_cast<bf16x4*>(smb + WO_ATAB)[tid] = a;
-  }
-  if (tid < 256) {
-    // row-local dgrad A operands (16x16x32: lane (m, kq) holds A[m][k], k = the 8 logical columns a lane feeds as B:
-    // 32mm + 4kq + e (e < 4), 32mm + 16 + 4kq + (e - 4)); rows m: 0 Wc0 hi, 1 Wc0 lo, 2 Wc1 hi, 3 Wc1 lo, others 0
-    const int mm = tid >> 6, m = lane & 15, kq = lane >> 4;
-    bf16x8 a;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = 32 * mm + 4 * kq + (e < 4 ? e : 16 + e - 4);
-      float w = 0.0f;
-      if (m < 2) w = f.Wc[j * f.cd];
-      else if (m < 4 && f.cd == 2) w = f.Wc[j * 2 + 1];
-      __bf16 hi, lo;
-      fb_split(w, hi, lo);
-      a[e] = m >= 4 ? (__bf16)0.0f : ((m & 1) ? lo : hi);
-    }
-    reinterpret_cast<bf16x8*>(smb + WO_TTAB)[tid] = a;
-  }
+  // (FOLD: the guide first — its operand requests head the memory queue; the vectors and tables below need nothing from it)
   if (FOLD) {
     // ---- the guide of this workgroup's images (nets/fc.py:51-61, models/ivae.py:204-221, models/base.py:97-119) ----
     // (barriers here are LDS-only: the global stores of this phase are read back after the closing __syncthreads alone)
@@ -569,6 +551,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       const float pb1 = (e.enc1.b_off >= 0 && jw < e.enc1.out_dim) ? e.params[e.enc1.b_off + jw] : 0.0f;
       const float pbh = (e.head.b_off >= 0 && jw < e.head.out_dim) ? e.params[e.head.b_off + jw] : 0.0f;
       const float pep = (wave == 0 && lane < zd) ? e.eps[b * zd + lane] : 0.0f;
+      f32x4 wl1[8], wlh[8];
       float pwz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (tid < FD_H) {
 #pragma unroll
@@ -578,7 +561,12 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
         // (every workgroup reads the same 400 KB matrix at the same time: which wave takes which 16 rows rotates with the
         //  workgroup index, so that the chip's requests spread over the L2 channels instead of marching through them in step)
         const int jr = 16 * ((wave + g) & (W8_WAVES - 1));
-        const float v = w8_gemv16(e.params + e.enc0.w_off, N, e.enc0.out_dim, jr, e.x + b * e.ldx, P, lane);
+        const float v = w8_gemv16(e.params + e.enc0.w_off, N, e.enc0.out_dim, jr, xr, P, lane,
+                                  [&]() {     // (issued behind the first pass's loads)
+                                    w8_gemv16_k128_load(e.params + e.enc1.w_off, e.enc1.in_dim, e.enc1.out_dim, 16 * wave, lane, wl1);
+                                  });
+        if (16 * wave < e.head.out_dim)     // (the head's, once the first layer's operand registers are free: under layer 1)
+          w8_gemv16_k128_load(e.params + e.head.w_off, e.head.in_dim, e.head.out_dim, 16 * wave, lane, wlh);
         const int j = jr + r_;
         if (q_ == 0 && j < e.enc0.out_dim) {
           const float y = pv_act_fwd2(v + (e.enc0.b_off >= 0 ? e.params[e.enc0.b_off + j] : 0.0f), e.enc0.act);
@@ -599,7 +587,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       }
       pv_lds_barrier();
       {
-        const float v = w8_gemv16_k128(e.params + e.enc1.w_off, e.enc1.in_dim, e.enc1.out_dim, 16 * wave, h1s, P, lane);
+        const float v = w8_gemv16_k128(wl1, e.enc1.in_dim, h1s, P, lane);
         const int j = 16 * wave + r_;
         if (q_ == 0 && j < e.enc1.out_dim) {
           const float y = pv_act_fwd2(v + pb1, e.enc1.act);
@@ -610,7 +598,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       W8_STAMP_K(5);
       pv_lds_barrier();
       if (16 * wave < e.head.out_dim) {                            // [mu | softplus input]: 16 rows per wave
-        const float v = w8_gemv16_k128(e.params + e.head.w_off, e.head.in_dim, e.head.out_dim, 16 * wave, h2s, P, lane);
+        const float v = w8_gemv16_k128(wlh, e.head.in_dim, h2s, P, lane);
         const int j = 16 * wave + r_;
         if (q_ == 0 && j < e.head.out_dim) {
           const float y = v + pbh;
@@ -669,6 +657,43 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       }
       W8_STAMP_K(7);
     }
+  }
+  if (tid < FD_H) {
+    vec[tid] = f.wo[tid];
+    vec[FD_H + tid] = W8_C * f.b1[tid];
+    vec[2 * FD_H + tid] = W8_C * f.b2[tid];
+  }
+  {
+    // coordinate layer A operands (v_mfma_f32_16x16x16_bf16: lane (m, kq) holds A[m][4kq .. 4kq+3]), k slots:
+    //   kq 0: [wh0 wh0 wl0 0] x [xh0 xl0 xh0 0]   kq 1: the same for coordinate 1   kq 2: [bch bcl 0 0] x [1 1 0 0]
+    const int jb = tid >> 6, m = lane & 15, kq = lane >> 4, j = 16 * jb + m;
+    float v = 0.0f;
+    if (kq == 0) v = W8_C * f.Wc[j * f.cd];
+    else if (kq == 1) v = f.cd == 2 ? W8_C * f.Wc[j * 2 + 1] : 0.0f;
+    else if (kq == 2) v = W8_C * f.bc[j];
+    __bf16 hi, lo;
+    fb_split(v, hi, lo);
+    bf16x4 a = w8_zero4();
+    if (kq < 2) { a[0] = hi; a[1] = hi; a[2] = lo; }
+    else if (kq == 2) { a[0] = hi; a[1] = lo; }
+    reinterpret_cast<bf16x4*>(smb + WO_ATAB)[tid] = a;
+  }
+  if (tid < 256) {
+    // row-local dgrad A operands (16x16x32: lane (m, kq) holds A[m][k], k = the 8 logical columns a lane feeds as B:
+    // 32mm + 4kq + e (e < 4), 32mm + 16 + 4kq + (e - 4)); rows m: 0 Wc0 hi, 1 Wc0 lo, 2 Wc1 hi, 3 Wc1 lo, others 0
+    const int mm = tid >> 6, m = lane & 15, kq = lane >> 4;
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = 32 * mm + 4 * kq + (e < 4 ? e : 16 + e - 4);
+      float w = 0.0f;
+      if (m < 2) w = f.Wc[j * f.cd];
+      else if (m < 4 && f.cd == 2) w = f.Wc[j * 2 + 1];
+      __bf16 hi, lo;
+      fb_split(w, hi, lo);
+      a[e] = m >= 4 ? (__bf16)0.0f : ((m & 1) ? lo : hi);
+    }
+    reinterpret_cast<bf16x8*>(smb + WO_TTAB)[tid] = a;
   }
   if (FOLD) {
     // ... and the decoder's weight images from the fp32 values requested before the guide
