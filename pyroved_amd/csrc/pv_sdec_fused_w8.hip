@@ -424,33 +424,53 @@ __device__ __forceinline__ float w8_dot4(const f32x4& w, const f32x4& x, float a
 }
 template <class HOOK>
 __device__ __forceinline__ float w8_gemv16(const float* __restrict__ W, int K, int nrows, int j0, const f32x4 (&xr)[4],
-                                           float* __restrict__ P, int lane, HOOK after_last_loads) {
+                                           const f32x4& xpk, float* __restrict__ P, int lane, HOOK after_last_loads) {
+  // The memory pipeline of a CU takes one 16-byte-per-lane load instruction per 16 cycles whatever it hits: the layer is bound
+  // by its count of load instructions.  Column groups of 64 float4 that do not exist are skipped (wave-uniform), and a last
+  // group of <= 4 columns (28 x 28: 196 = 3 * 64 + 4) is ONE instruction for all 16 rows — lane l takes row l >> 2, column
+  // l & 3 of the group — instead of sixteen that serve four lanes each: 49 instructions per wave instead of 64.
   const int K4 = K >> 2;
-  const int npass = (K4 + 127) >> 7;
+  const int ng = (K4 + 63) >> 6;                      // column groups (<= 4)
+  const int rem = K4 - 64 * (ng - 1);                 // columns of the last group
+  const bool packed = ng >= 2 && rem <= 4;
+  const int ngn = packed ? ng - 1 : ng;               // groups read the plain way
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  for (int pi = 0; pi < npass; ++pi) {              // two column groups per pass
-    const int pj = pi, c0 = pj << 7;
-    const int ka = c0 + lane, kb = c0 + 64 + lane;
-    const bool oka = ka < K4, okb = kb < K4;
-    f32x4 xa = pj == 0 ? xr[0] : xr[2], xb = pj == 0 ? xr[1] : xr[3];     // (x: requested at kernel entry, column groups l + 64 c)
-    f32x4 wa[16], wb[16];
+  float pk = 0.0f;
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {                    // two column groups per pass
+    if (2 * pi >= ngn) break;
+    const int ka = 128 * pi + lane, kb = ka + 64;
+    const bool hasb = 2 * pi + 1 < ngn;               // (wave-uniform)
+    const bool oka = ka < K4, okb = hasb && kb < K4;
+    f32x4 xa = xr[2 * pi], xb = xr[2 * pi + 1];
+    f32x4 wa[16], wb[16], wp = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = j0 + i < nrows ? j0 + i : nrows - 1;
       const float* wr = W + (int64_t)row * K;
       wa[i] = w8_ld4(wr + 4 * (oka ? ka : 0));
-      wb[i] = w8_ld4(wr + 4 * (okb ? kb : 0));
+      if (hasb) wb[i] = w8_ld4(wr + 4 * (okb ? kb : 0));
     }
-    if (pi == npass - 1) after_last_loads();
+    const bool last = 2 * pi + 2 >= ngn;
+    if (last && packed) {
+      const int row = j0 + (lane >> 2) < nrows ? j0 + (lane >> 2) : nrows - 1;
+      wp = w8_ld4(W + (int64_t)row * K + 4 * (64 * (ng - 1) + ((lane & 3) < rem ? (lane & 3) : 0)));
+    }
+    if (last) after_last_loads();
     if (!oka) xa = f32x4{0.0f, 0.0f, 0.0f, 0.0f};    // (a column that does not exist contributes w * 0)
     if (!okb) xb = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = w8_dot4(wb[i], xb, w8_dot4(wa[i], xa, acc[i]));
+    for (int i = 0; i < 16; ++i) {
+      acc[i] = w8_dot4(wa[i], xa, acc[i]);
+      if (hasb) acc[i] = w8_dot4(wb[i], xb, acc[i]);
+    }
+    if (last && packed && (lane & 3) < rem) pk = w8_dot4(wp, xpk, 0.0f);
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) P[lane * 17 + i] = acc[i];
+  if (packed) P[lane * 17 + (lane >> 2)] += pk;       // (the packed group's product belongs to row lane >> 2)
   const int r = lane & 15, q = lane >> 4;
   float v = 0.0f;
 #pragma unroll
@@ -502,7 +522,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   float* red = reinterpret_cast<float*>(smb + WO_RED);
   const char* gimg = reinterpret_cast<const char*>(f.wimg);
   W8_STAMP_K(0);
-  f32x4 xr[4];                                        // FOLD: the workgroup's image, float4 columns lane + 64 c (c < 4)
+  f32x4 xr[4], xpk;                                   // FOLD: the workgroup's image, float4 columns lane + 64 c (c < 4); w8_gemv16's packed group
   if (FOLD) {
     const int K4 = (int)(e.ldx >> 2);
     const float* xg = e.x + (int64_t)g * e.ldx;
@@ -510,6 +530,29 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
     for (int c = 0; c < 4; ++c) {
       const int k4 = lane + 64 * c;
       xr[c] = *reinterpret_cast<const f32x4*>(xg + 4 * (k4 < K4 ? k4 : 0));
+    }
+    const int kp = 64 * (((K4 + 63) >> 6) - 1) + (lane & 3);
+    xpk = *reinterpret_cast<const f32x4*>(xg + 4 * (kp < K4 ? kp : 0));
+  }
+  // FOLD: the operands of the vectors and tables below, requested here (they are written after the guide: their round trips
+  // would otherwise follow it)
+  float pt_v[3] = {0.0f, 0.0f, 0.0f}, pt_a = 0.0f, pt_t[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (FOLD) {
+    if (tid < FD_H) { pt_v[0] = f.wo[tid]; pt_v[1] = f.b1[tid]; pt_v[2] = f.b2[tid]; }
+    {
+      const int jb = tid >> 6, m = lane & 15, kq = lane >> 4, j = 16 * jb + m;
+      if (kq == 0) pt_a = f.Wc[j * f.cd];
+      else if (kq == 1) pt_a = f.cd == 2 ? f.Wc[j * 2 + 1] : 0.0f;
+      else if (kq == 2) pt_a = f.bc[j];
+    }
+    if (tid < 256) {
+      const int mm = tid >> 6, m = lane & 15, kq = lane >> 4;
+#pragma unroll
+      for (int e_ = 0; e_ < 8; ++e_) {
+        const int j = 32 * mm + 4 * kq + (e_ < 4 ? e_ : 16 + e_ - 4);
+        if (m < 2) pt_t[e_] = f.Wc[j * f.cd];
+        else if (m < 4 && f.cd == 2) pt_t[e_] = f.Wc[j * 2 + 1];
+      }
     }
   }
 
@@ -561,7 +604,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
         // (every workgroup reads the same 400 KB matrix at the same time: which wave takes which 16 rows rotates with the
         //  workgroup index, so that the chip's requests spread over the L2 channels instead of marching through them in step)
         const int jr = 16 * ((wave + g) & (W8_WAVES - 1));
-        const float v = w8_gemv16(e.params + e.enc0.w_off, N, e.enc0.out_dim, jr, xr, P, lane,
+        const float v = w8_gemv16(e.params + e.enc0.w_off, N, e.enc0.out_dim, jr, xr, xpk, P, lane,
                                   [&]() {     // (issued behind the first pass's loads)
                                     w8_gemv16_k128_load(e.params + e.enc1.w_off, e.enc1.in_dim, e.enc1.out_dim, 16 * wave, lane, wl1);
                                   });
@@ -659,16 +702,17 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
     }
   }
   if (tid < FD_H) {
-    vec[tid] = f.wo[tid];
-    vec[FD_H + tid] = W8_C * f.b1[tid];
-    vec[2 * FD_H + tid] = W8_C * f.b2[tid];
+    vec[tid] = FOLD ? pt_v[0] : f.wo[tid];
+    vec[FD_H + tid] = W8_C * (FOLD ? pt_v[1] : f.b1[tid]);
+    vec[2 * FD_H + tid] = W8_C * (FOLD ? pt_v[2] : f.b2[tid]);
   }
   {
     // coordinate layer A operands (v_mfma_f32_16x16x16_bf16: lane (m, kq) holds A[m][4kq .. 4kq+3]), k slots:
     //   kq 0: [wh0 wh0 wl0 0] x [xh0 xl0 xh0 0]   kq 1: the same for coordinate 1   kq 2: [bch bcl 0 0] x [1 1 0 0]
     const int jb = tid >> 6, m = lane & 15, kq = lane >> 4, j = 16 * jb + m;
     float v = 0.0f;
-    if (kq == 0) v = W8_C * f.Wc[j * f.cd];
+    if (FOLD) v = W8_C * pt_a;
+    else if (kq == 0) v = W8_C * f.Wc[j * f.cd];
     else if (kq == 1) v = f.cd == 2 ? W8_C * f.Wc[j * 2 + 1] : 0.0f;
     else if (kq == 2) v = W8_C * f.bc[j];
     __bf16 hi, lo;
@@ -687,7 +731,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
     for (int e = 0; e < 8; ++e) {
       const int j = 32 * mm + 4 * kq + (e < 4 ? e : 16 + e - 4);
       float w = 0.0f;
-      if (m < 2) w = f.Wc[j * f.cd];
+      if (FOLD) w = pt_t[e];
+      else if (m < 2) w = f.Wc[j * f.cd];
       else if (m < 4 && f.cd == 2) w = f.Wc[j * 2 + 1];
       __bf16 hi, lo;
       fb_split(w, hi, lo);
