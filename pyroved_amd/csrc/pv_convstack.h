@@ -302,12 +302,23 @@ inline int op_fwd(const float* params, const pv_op& o, int nd, int B, const floa
 // *fused = true when done) instead of a separate elementwise pass in the producer's backward
 // does a kernel-3 convolution's backward run its input gradient on the split-operand kernel as a launch of its own (not the
 // weight + input gradient pair launch)?  That launch can carry the un-pooling epilogue.
+// (ONE place decides the launch form of a kernel-3 convolution's backward — stack_bwd plans the un-pooling epilogue with it, op_bwd
+//  launches by it: ADVICE r4, the two used to carry hand-copied predicates)
+struct ConvBwdForm { bool on_side, pair; };
+inline ConvBwdForm conv_bwd_form(const pv_op& o, int nd, int B, const Shape& si, const Scratch& sc, bool want_gin) {
+  const bool wg = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd);
+  ConvBwdForm f;
+  // the split-operand weight gradient goes to the side stream when its partials land in the finish list (never in sc.ws,
+  // which the main stream keeps using)
+  f.on_side = sc.side && wg && pv_wgrad_defers(sc.fin, pv_conv3_sp_wgrad_ws(B, si.H, si.W, si.C, o.cout));
+  // weight gradient + input gradient in one launch (pv_conv_sp.hip)
+  f.pair = wg && want_gin && sc.fin && !conv_mixed(sc.conv_bf16) && sp_fp32_mode(sc.conv_bf16) == 4 &&
+           pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE) && (!f.on_side || side_keeps_pairs());
+  return f;
+}
 inline bool conv_bwd_sp_alone(const pv_op& o, int nd, int B, const Shape& si, const Scratch& sc) {
   if (o.kind != PV_OP_CONV || o.ksize != 3 || !pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE)) return false;
-  const bool wg = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd);
-  const bool on_side = sc.side && wg && pv_wgrad_defers(sc.fin, pv_conv3_sp_wgrad_ws(B, si.H, si.W, si.C, o.cout));
-  const bool pair = wg && sc.fin && !conv_mixed(sc.conv_bf16) && sp_fp32_mode(sc.conv_bf16) == 4 && (!on_side || side_keeps_pairs());
-  return !pair;
+  return !conv_bwd_form(o, nd, B, si, sc, true).pair;
 }
 inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int B, const float* in, const Shape& si,
                   const float* out, float* g, float* gin, const Scratch& sc, int slot, hipStream_t s, bool g_is_pre = false,
@@ -326,12 +337,8 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
     if (!g_is_pre) PV_TRY(pv_act_bwd(g, out, rows * o.cout, o.act, s));         // g = dL/d(pre-activation)
     float* db = o.b_off >= 0 ? grads + o.b_off : nullptr;
     if (o.ksize == 3) {
-      // the split-operand weight gradient goes to the side stream when its partials land in the finish list (never in sc.ws,
-      // which the main stream keeps using)
-      const bool on_side = sc.side && pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) &&
-                           pv_wgrad_defers(sc.fin, pv_conv3_sp_wgrad_ws(B, si.H, si.W, si.C, o.cout));
-      const bool pair = pv_conv3_sp_wgrad_supported(si.C, o.cout, nd) && gin && sc.fin && !conv_mixed(sc.conv_bf16) && sp_fp32_mode(sc.conv_bf16) == 4 &&
-                        pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE) && (!on_side || side_keeps_pairs());
+      const ConvBwdForm form = conv_bwd_form(o, nd, B, si, sc, gin != nullptr);
+      const bool on_side = form.on_side, pair = form.pair;
       if (pair) {                                       // weight gradient + input gradient: one launch (pv_conv_sp.hip)
         pv_conv3_sp_pair_begin();
         int rc = pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, s, 4, sc.fin);
