@@ -1307,6 +1307,11 @@ static int sw_splits(int B, int H, int W, int C, int Cout, int nsp) {
   const int64_t owners = (int64_t)(C / ciw) * ((Cout + 63) / 64);
   static const int wg_target = pv_exp_int("PV_SW_WGS", 512);
   int64_t ns = (wg_target + owners - 1) / owners;                // two workgroups per CU in all
+  // ... but never fewer than 12 tiles per split: below that a split's fixed costs (its partial-sum block of the finish launch,
+  // its prologue) outweigh the parallelism (round 5, `gpurun_out/r05ab3`: conv-encoder iVAE at batch 128 0.836 -> 0.826 ms
+  // fp32-class, 0.562 -> 0.545 at the throughput precision; VED at batch 256 — 8+ tiles per split already — unchanged)
+  static const int min_tiles = pv_exp_int("PV_SW_MINTILES", 12);
+  if (min_tiles > 1 && ns > (T + min_tiles - 1) / min_tiles) ns = (T + min_tiles - 1) / min_tiles;
   if (ns > T) ns = T;
   return (int)(ns < 1 ? 1 : ns);
 }

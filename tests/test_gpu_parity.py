@@ -2231,7 +2231,7 @@ def test_fused_1d_decoder_more_samples_than_workgroups(gpu_device):
     assert torch.allclose(d1, d0, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("family", ["ivae", "ved"])
+@pytest.mark.parametrize("family", ["ivae", "ved", "ivae_folded_guide"])
 def test_steps_replay_from_a_captured_graph(gpu_device, family):
     """A step captured into a graph (torch.cuda.graph on the stream the library launches on) replays correctly: under
     capture the library keeps to forms that can be replayed — the encoder as its two launches (the one-launch form hands its
@@ -2245,6 +2245,17 @@ def test_steps_replay_from_a_captured_graph(gpu_device, family):
         es = [torch.randn(32, model.z_dim, generator=g).cuda() for _ in range(3)]
         call = lambda x, e, y: eng.loss_and_grads(x, e)
         ys = [None] * 3
+    elif family == "ivae_folded_guide":
+        # (round 5) batch == decoder grid at the throughput precision: the decoder launch hosts the guide — no cross-workgroup
+        # hand-off in it, so the SAME form runs under capture
+        nb = torch.cuda.get_device_properties(0).multi_processor_count
+        model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+        eng = model.engine(fused=3)
+        xs = [torch.rand(nb, 28, 28, generator=g).cuda() for _ in range(3)]
+        es = [torch.randn(nb, model.z_dim, generator=g).cuda() for _ in range(3)]
+        call = lambda x, e, y: eng.loss_and_grads(x, e)
+        ys = [None] * 3
+        assert _abi.lib().pv_ivae_guide_folds(C.byref(eng._plan(nb))) == 1
     else:
         model = pv.models.VED((32, 32), (32,), latent_dim=2, seed=1, device="cuda")
         eng = model.engine()
