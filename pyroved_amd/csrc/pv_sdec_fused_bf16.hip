@@ -770,22 +770,27 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_tanh8(tC, c2);                                          // tC = h2
       FB_STAMP(17);
       // ---- output layer + likelihood (fp32) ----
-      float part = 0.0f;
+      // (four independent accumulation chains: one chain of 32 dependent multiply-adds is ~250 cycles of pure latency for the
+      //  single wave of a SIMD)
+      f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * jb + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part += tC[jb][i] * wv[i];
+        part4 = part4 + tC[jb] * wv;
       }
-      const float a = fb_sum_q(part) + bo;
+      const float a = fb_sum_q((part4[0] + part4[1]) + (part4[2] + part4[3])) + bo;
       float ll, locv;
       if (LIK == PV_LIK_BERNOULLI) {
         const float pr = fb_rcp(1.0f + fb_exp(-a));
         const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
-        const float lg = fb_log(pc) - fb_log(1.0f - pc);
-        ll = -(fmaxf(lg, 0.0f) - lg * xv + fb_log(1.0f + fb_exp(-fabsf(lg))));
+        // -BCEWithLogits(lg, x) with lg = logit(pc) (torch: probs_to_logits, then binary_cross_entropy_with_logits), written with
+        // the identities 1 + exp(-|lg|) = 1 / max(pc, 1 - pc) and sigmoid(lg) = pc: the two logarithms lg is made of serve the
+        // softplus term too, and the row's dependent chain is exp -> rcp -> 2 log instead of seven transcendentals (round 5)
+        const float lpc = fb_log(pc), l1pc = fb_log(1.0f - pc);
+        const float lg = lpc - l1pc;
+        ll = -(fmaxf(lg, 0.0f) - lg * xv - fmaxf(lpc, l1pc));
         const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
-        dlda = (fb_rcp(1.0f + fb_exp(-lg)) - xv) * mask;
+        dlda = (pc - xv) * mask;
         locv = pr;
       } else if (LIK == PV_LIK_CBERNOULLI) {
         pv_cbern(a, xv, ll, dlda, locv);
@@ -898,16 +903,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     FB_STAMP(21);
     // ---- coordinate layer backward (fp32): row-local part ----
     {
-      float d0 = 0.0f, d1 = 0.0f;
+      f32x4 d04 = {0.0f, 0.0f, 0.0f, 0.0f}, d14 = {0.0f, 0.0f, 0.0f, 0.0f};      // (independent chains, as the logit's)
 #pragma unroll
       for (int jb = 0; jb < 8; ++jb) {
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc0 + 16 * jb + 4 * q);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc1 + 16 * jb + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { d0 += tC[jb][i] * w0[i]; d1 += tC[jb][i] * w1[i]; }
+        d04 = d04 + tC[jb] * w0;
+        d14 = d14 + tC[jb] * w1;
       }
-      d0 = fb_sum_q(d0);
-      d1 = fb_sum_q(d1);
+      float d0 = fb_sum_q((d04[0] + d04[1]) + (d04[2] + d04[3]));
+      float d1 = fb_sum_q((d14[0] + d14[1]) + (d14[2] + d14[3]));
       if (F16) { d0 *= frow; d1 *= frow; }
       if (q == 0 && act) {
         f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);

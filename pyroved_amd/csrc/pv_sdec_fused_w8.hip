@@ -958,10 +958,14 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       if (LIK == PV_LIK_BERNOULLI) {
         const float pr = w8_rcp(1.0f + w8_exp(-a));
         const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
-        const float lg = w8_log(pc) - w8_log(1.0f - pc);
-        ll = -(fmaxf(lg, 0.0f) - lg * xv + w8_log(1.0f + w8_exp(-fabsf(lg))));
+        // -BCEWithLogits(lg, x) with lg = logit(pc) (torch: probs_to_logits, then binary_cross_entropy_with_logits), written with
+        // the identities 1 + exp(-|lg|) = 1 / max(pc, 1 - pc) and sigmoid(lg) = pc: the two logarithms lg is made of serve the
+        // softplus term too, and the row's dependent chain is exp -> rcp -> 2 log instead of seven transcendentals (round 5)
+        const float lpc = w8_log(pc), l1pc = w8_log(1.0f - pc);
+        const float lg = lpc - l1pc;
+        ll = -(fmaxf(lg, 0.0f) - lg * xv - fmaxf(lpc, l1pc));
         const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
-        dlda = (w8_rcp(1.0f + w8_exp(-lg)) - xv) * mask;
+        dlda = (pc - xv) * mask;
         locv = pr;
       } else if (LIK == PV_LIK_CBERNOULLI) {
         pv_cbern(a, xv, ll, dlda, locv);
@@ -1167,10 +1171,14 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       if (LIK == PV_LIK_BERNOULLI) {
         const float pr = w8_rcp(1.0f + w8_exp(-a));
         const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
-        const float lg = w8_log(pc) - w8_log(1.0f - pc);
-        ll = -(fmaxf(lg, 0.0f) - lg * xv + w8_log(1.0f + w8_exp(-fabsf(lg))));
+        // -BCEWithLogits(lg, x) with lg = logit(pc) (torch: probs_to_logits, then binary_cross_entropy_with_logits), written with
+        // the identities 1 + exp(-|lg|) = 1 / max(pc, 1 - pc) and sigmoid(lg) = pc: the two logarithms lg is made of serve the
+        // softplus term too, and the row's dependent chain is exp -> rcp -> 2 log instead of seven transcendentals (round 5)
+        const float lpc = w8_log(pc), l1pc = w8_log(1.0f - pc);
+        const float lg = lpc - l1pc;
+        ll = -(fmaxf(lg, 0.0f) - lg * xv - fmaxf(lpc, l1pc));
         const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
-        dlda = (w8_rcp(1.0f + w8_exp(-lg)) - xv) * mask;
+        dlda = (pc - xv) * mask;
         locv = pr;
       } else if (LIK == PV_LIK_CBERNOULLI) {
         pv_cbern(a, xv, ll, dlda, locv);
