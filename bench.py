@@ -261,6 +261,8 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
     eng = model.engine(fused=fused)
     for k_, v_ in (attrs or {}).items():           # per-plan switches of the engine (e.g. enc_fold=False: the guide as its own launch)
         setattr(eng, k_, v_)
+    if os.environ.get("PV_BENCH_CONV_X3") == "1":  # (A/B: the fp32-class convolutions with both operands split, rounds 2-4's form)
+        eng.conv_x3 = True
     if world > 1:
         pvdist.sync_replicas(eng)
     ring_n = cfg["ring"]
@@ -475,9 +477,11 @@ def measure(args, name, cfg, fused, ctx, attrs=None):
                    arith=("2-D k3 convolutions on the f16 MFMA with ONE fp16 piece per operand (power-of-two scaled per staged "
                           "tile), one product per multiply-add (fp32 accumulate); 1-D convolutions on the f32-input MFMA; fp32 "
                           "elsewhere" if bf else
-                          "2-D k3 convolutions on the f16 MFMA, operands split into two fp16 pieces with exact power-of-two scaling "
-                          "per staged tile, three products (fp32 accumulate): fp32-class (3e-7 relative l2 vs float64); 1-D "
-                          "convolutions on the f32-input MFMA; fp32 elsewhere"))
+                          "2-D k3 convolutions on the f16 MFMA, operands as fp16 pieces with exact power-of-two scaling per staged "
+                          "tile: FORWARD both operands two pieces, three products (3e-7 relative l2 vs float64: its outputs pick "
+                          "max-pool winners); BACKWARD weights two pieces against dL/dy as one (input gradient, two products), one "
+                          "piece per operand in the weight gradient — every gradient within the fp32 reference's own distance from "
+                          "float64 (fp32 accumulate); 1-D convolutions on the f32-input MFMA; fp32 elsewhere"))
         out["roofline"] = conv_roof if conv_roof else {"bound": "mfma", "achieved": 0.0, "peak": MFMA_BF16_PEAK_TFLOPS,
                                                        "unit": "TFLOP/s", "frac": 0.0, "traffic": None, "kernel": "n/a"}
         out["roofline_step"] = {"bound": "mfma", "scope": "step", "achieved": step_tf, "peak": MFMA_BF16_PEAK_TFLOPS,

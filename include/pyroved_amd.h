@@ -256,6 +256,13 @@ int pv_experiments_build(void);
 #define PV_PLAN_ENC_NO_WAIT    4
 #define PV_PLAN_NO_DEC1D       8
 #define PV_PLAN_NO_ENC_FOLD    16
+/* (v15) PV_PLAN_CONV_X3 (pv_ivae_plan with a convolutional encoder; pv_ved_plan / pv_convnet_plan say it as conv_bf16 == 0): the
+ *   fp32-class kernel-3 convolutions with BOTH operands as two fp16 pieces and three products per multiply-add in EVERY direction
+ *   (rounds 2-4's form, 3e-7 per convolution vs float64).  Default since round 5 (conv_bf16 == 4): the FORWARD unchanged (its outputs
+ *   decide max-pool winners and leaky-ReLU signs), the BACKWARD cheaper: input gradients with dL/dy as ONE fp16 piece scaled per
+ *   staged tile against the two-piece weights (two products), weight gradients with one piece per operand (one product) — rounding
+ *   errors that are independent from element to element and average out of the sums a gradient is. */
+#define PV_PLAN_CONV_X3        64
 
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,
  * layer widths).  Returns < 0 on an unsupported plan. */
@@ -382,7 +389,9 @@ typedef struct pv_ved_plan {
                                       product: gradients that are sums with heavy cancellation lose digits, measured 7e-3 on
                                       the first layer's weights); 2 (v14) fp32-class for weights outside fp16's range — three
                                       bf16 pieces; 3 (v14) throughput — ONE fp16 piece per operand (power-of-two scaled per
-                                      staged tile), one product: a third of the matrix instructions, no split arithmetic;
+                                      staged tile), one product: a third of the matrix instructions, no split arithmetic; 4 (v15)
+                                      fp32-class with the cheaper backward — forward as 0, input gradient 2 products (dL/dy one fp16
+                                      piece), weight gradient 1 (see PV_PLAN_CONV_X3);
                                       gradients to ~1e-2, the ELBO to 1e-4 (SVItrainer(precision="bf16")).
                                       (pv_ivae_plan's convolutional encoder: fused == 3 selects 3, conv_wide 2)             */
   int32_t flags;                   /* (v14) PV_PLAN_NO_SIDE_STREAM                                                          */
@@ -429,7 +438,7 @@ typedef struct pv_convnet_plan {
   int32_t in_ch, in_dim[2];
   int32_t n_ops;
   int32_t bn_eval;                     /* batch norm on the running statistics (module.eval())                 */
-  int32_t conv_bf16;                   /* 0: fp32-class, 1: mixed, 2: fp32-class wide, 3: one fp16 piece (as pv_ved_plan) */
+  int32_t conv_bf16;                   /* 0: fp32-class x3, 1: mixed, 2: fp32-class wide, 3: one fp16 piece, 4: fp32-class, cheaper backward (as pv_ved_plan) */
   int32_t need_dx;                     /* the backward will be asked for dL/dx (set at forward time too)       */
   int32_t flags;                       /* (v15) PV_PLAN_NO_SIDE_STREAM: every launch on the caller's stream    */
   pv_op   ops[PV_MAX_OPS];

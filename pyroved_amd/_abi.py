@@ -16,6 +16,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime li
 PV_ABI_VERSION = 15
 # pv_ivae_plan.flags / pv_ved_plan.flags / pv_convnet_plan.flags
 PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM, PV_PLAN_ENC_NO_WAIT, PV_PLAN_NO_DEC1D, PV_PLAN_NO_ENC_FOLD = 1, 2, 4, 8, 16
+PV_PLAN_CONV_X3 = 64
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)

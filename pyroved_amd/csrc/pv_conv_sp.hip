@@ -347,15 +347,21 @@ extern "C" int pv_debug_read_trace_sp(long long* out, int n) {
 #else
 #define SP_STAMP(k) do { } while (0)
 #endif
-template <int NS, int NCB, bool F16 = false>
+// NSA: pieces of the PATCH (the activations, or dL/d(output) in the input-gradient form); NS: pieces of the weights.  NSA == NS
+// except in the round-5 form <2, .., true, 1>: the weights keep their two exact fp16 pieces, the patch is ONE fp16 piece
+// (round to nearest, power-of-two scaled per staged chunk) — two products instead of three.  A weight's rounding error is
+// systematic (the same perturbation at every pixel of every sample), an activation's is independent from element to element
+// and averages out of every sum the step forms: the argument of the decoder kernel's fp16 builds (pv_sdec_fused_bf16.hip).
+template <int NS, int NCB, bool F16 = false, int NSA = NS>
 __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, const int bid_y, char* smem) {
   static_assert(F16 ? (NS == 2 || NS == 1) : NS >= 2, "the fp16 modes have two pieces (fp32-class) or one (throughput)");
+  static_assert(NSA == NS || (F16 && NS == 2 && NSA == 1), "patch pieces");
   __shared__ float smax[2][4];                        // F16: the waves' patch maxima of the chunk being staged
   constexpr int TG = NS == 3 ? 1 : 3;                 // taps per weight stage
   constexpr int NG = 9 / TG;
   constexpr int WREGS = TG * NS;                      // 16-byte pieces of a weight stage per thread
-  char* patch = smem;                                 // [NS][324][64 B]
-  char* wl = smem + NS * SP_PPLANE;                   // [TG][NS][64][64 B]
+  char* patch = smem;                                 // [NSA][324][64 B]
+  char* wl = smem + NSA * SP_PPLANE;                  // [TG][NS][64][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int wy = wave >> 1, wx = wave & 1;
 #ifdef SP_TRACE
@@ -464,13 +470,13 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
     for (int k = 0; k < ((SP_EXP & 4) && ch > 0 ? 0 : PK); ++k) {
       const int e = tid + 256 * k, pix = e >> 3, f4 = e & 7;
       const int py = pix / SP_PW;
-      u32x2 pl[NS];
+      u32x2 pl[NSA];
       if constexpr (F16) sp_split4_f16(pre[k], psc, pl);
       else sp_split4<NS>(pre[k], pl);
       const int o = pix * 64 + (((f4 >> 1) ^ (2 * (py & 1))) * 16) + (f4 & 1) * 8;
       if (k + 1 < PK || e < SP_NPIX * 8) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x2*>(patch + j * SP_PPLANE + o) = pl[j];
+        for (int j = 0; j < NSA; ++j) *reinterpret_cast<u32x2*>(patch + j * SP_PPLANE + o) = pl[j];
       }
     }
     SP_W_STORE();
@@ -497,14 +503,14 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
             a[cb][k] = *reinterpret_cast<const sbf8*>(wl + (tt * NS + k) * SP_WPLANE + hco * 64 + cb * 1024 + aoff);
         // B fragments one pixel block ahead of the MFMAs that use them
         const int tofs = (dy * SP_PW + dx) * 64;
-        sbf8 bcur[NS], bnxt[NS];
+        sbf8 bcur[NSA], bnxt[NSA];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) bcur[k] = *reinterpret_cast<const sbf8*>(patch + k * SP_PPLANE + boff[0][dy & 1] + tofs);
+        for (int k = 0; k < NSA; ++k) bcur[k] = *reinterpret_cast<const sbf8*>(patch + k * SP_PPLANE + boff[0][dy & 1] + tofs);
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
           if (pb + 1 < 4) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k)
+            for (int k = 0; k < NSA; ++k)
               bnxt[k] = *reinterpret_cast<const sbf8*>(patch + k * SP_PPLANE + boff[pb + 1 < 4 ? pb + 1 : 3][dy & 1] + tofs);
           }
           // products in ascending magnitude; the NCB accumulators of a product are independent
@@ -519,13 +525,15 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
           if constexpr (NS >= 2) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][1], bcur[0], acc[cb][pb]);
+            if constexpr (NSA >= 2) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[1], acc[cb][pb]);
+              for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[1], acc[cb][pb]);
+            }
           }
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) acc[cb][pb] = sp_mma<F16>(a[cb][0], bcur[0], acc[cb][pb]);
 #pragma unroll
-          for (int k = 0; k < NS; ++k) bcur[k] = bnxt[k];
+          for (int k = 0; k < NSA; ++k) bcur[k] = bnxt[k];
         }
       }
       if (g + 1 < NG && !(SP_EXP & 2)) {
@@ -718,10 +726,10 @@ __device__ __forceinline__ void sp_conv_body(const ConvSp& p, const int bid_x, c
 #endif
 }
 
-template <int NS, int NCB, bool F16 = false>
+template <int NS, int NCB, bool F16 = false, int NSA = NS>
 __global__ __launch_bounds__(256, 2) void pv_conv3_sp_kernel(ConvSp p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  sp_conv_body<NS, NCB, F16>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+  sp_conv_body<NS, NCB, F16, NSA>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 
 // 4: two fp16 pieces with exact power-of-two scaling (default; needs |w| * 64 inside fp16's range, i.e. |w| < ~1023 and not
@@ -744,7 +752,7 @@ int64_t pv_conv3_sp_wt_bytes(int C, int Cout) {
 }
 
 bool sp_pair_capture_fwd(const ConvSp& q, int ncb, dim3 grid, size_t lds);
-template <int NS, bool F16 = false>
+template <int NS, bool F16 = false, int NSA = NS>
 static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int flip, char* wt, int nt, int64_t total,
                            hipStream_t s) {
   if (wt) {
@@ -756,7 +764,7 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
   }
   constexpr int TG = NS == 3 ? 1 : (NS == 1 ? 3 : 3);
   static const int lds_pad = pv_exp_int("PV_SP_LDS_PAD", 0);   // (occupancy experiments)
-  const size_t lds = (size_t)NS * SP_PPLANE + (size_t)TG * NS * SP_WPLANE + lds_pad;
+  const size_t lds = (size_t)NSA * SP_PPLANE + (size_t)TG * NS * SP_WPLANE + lds_pad;
   const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.B * nt;
   // fewer workgroups than CUs: 32-channel halves fill the chip (measured: 51 -> 37 us on 128 workgroups); with more, the
   // doubled patch staging costs more than the extra round returns (PV_SP_HALVES overrides the limit)
@@ -764,12 +772,12 @@ static int conv3_sp_launch(const ConvSp& p, const float* w, int Co, int Ci, int 
   ConvSp q = p;
   q.halves = (p.Cout > 32 && wgs <= split_lim) ? 2 : 1;
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(nt * q.halves));
-  if constexpr (F16 && NS == 2) {
+  if constexpr (F16 && NS == 2 && NSA == 2) {
     if (sp_pair_capture_fwd(q, (p.Cout <= 32 || q.halves == 2) ? 2 : 4, grid, lds)) return 0;      // (launched by pv_conv3_sp_pair_flush)
   }
   // (PV_LAUNCH_FORK: an input gradient whose result a side-stream weight gradient waits for carries the fork event)
-  if (p.Cout <= 32 || q.halves == 2) PV_LAUNCH_FORK((pv_conv3_sp_kernel<NS, 2, F16>), grid, dim3(256), lds, s, q);
-  else PV_LAUNCH_FORK((pv_conv3_sp_kernel<NS, 4, F16>), grid, dim3(256), lds, s, q);
+  if (p.Cout <= 32 || q.halves == 2) PV_LAUNCH_FORK((pv_conv3_sp_kernel<NS, 2, F16, NSA>), grid, dim3(256), lds, s, q);
+  else PV_LAUNCH_FORK((pv_conv3_sp_kernel<NS, 4, F16, NSA>), grid, dim3(256), lds, s, q);
   PV_LAUNCH_CHECK();
   return 0;
 }
@@ -781,7 +789,7 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
                 int act, void* wt_scratch, hipStream_t s, const float* eg_y, int eg_act, int ns, const void* wt_ready, float* pool_out,
                 unsigned char* pool_code, const unsigned char* up_code) {
   const int N = flip ? Ci : Co, C = flip ? Co : Ci;
-  if (!pv_conv3_sp_supported(C, N, 2, act) || ns < 1 || ns > 4) return PV_EINVAL;   // 4: fp16 two-piece, 1: fp16 one-piece
+  if (!pv_conv3_sp_supported(C, N, 2, act) || ns < 1 || ns > 5) return PV_EINVAL;   // 4: fp16 two-piece, 1: fp16 one-piece, 5: fp16 weights two / patch one
   const int nt = (N + SP_TN - 1) / SP_TN;
   const int64_t total = (int64_t)nt * (C / SP_KC) * 9 * SP_TN * SP_KC;
   ConvSp p{};
@@ -799,6 +807,7 @@ int pv_conv3_sp(const float* in, int B, int H, int W, const float* w, int Co, in
   }
   char* prep = wt_ready ? nullptr : reinterpret_cast<char*>(wt_scratch);    // null: tiled already (pv_conv_wprep_table)
   if (ns == 4) return conv3_sp_launch<2, true>(p, w, Co, Ci, flip, prep, nt, total, s);
+  if (ns == 5) return conv3_sp_launch<2, true, 1>(p, w, Co, Ci, flip, prep, nt, total, s);
   if (ns == 1) return conv3_sp_launch<1, true>(p, w, Co, Ci, flip, prep, nt, total, s);
   return ns == 3 ? conv3_sp_launch<3>(p, w, Co, Ci, flip, prep, nt, total, s) : conv3_sp_launch<2>(p, w, Co, Ci, flip, prep, nt, total, s);
 }
@@ -813,6 +822,7 @@ extern "C" int pv_debug_conv3(int mode, const float* in, int B, int H, int W, in
   if (mode == 5)      // the round-1 tile kernel (1-D and 2-D) on fp16 two-piece operands
     return pv_conv3_direct(in, B, H, W, nd, w, Co, Ci, flip, bias, out, act, reinterpret_cast<float*>(wt_scratch), s, eg_y, eg_act, 2);
   if (mode == 7) mode = 1 + 16;                      // (7: this file's kernels with ONE fp16 piece)
+  if (mode == 8) mode = 5 + 16;                      // (8: weights two fp16 pieces, patch one)
   if (mode >= 2) return nd == 2 ? pv_conv3_sp(in, B, H, W, w, Co, Ci, flip, bias, out, act, wt_scratch, s, eg_y, eg_act, mode & 15)
                                 : PV_EINVAL;
   return pv_conv3_direct(in, B, H, W, nd, w, Co, Ci, flip, bias, out, act, reinterpret_cast<float*>(wt_scratch), s, eg_y, eg_act,

@@ -127,7 +127,11 @@ struct Scratch {
   int conv_bf16 = 0;                                         // conv mode of the plan (pv_*_plan.conv_bf16): 0 fp32-class (two fp16 pieces,
                                                              // exact scaling), 1 mixed (two rounded bf16 pieces, 3 products), 2 fp32-class
                                                              // for weights outside fp16's range (three bf16 pieces), 3 throughput (ONE
-                                                             // fp16 piece, one product); see conv_mixed / sp_mode below
+                                                             // fp16 piece, one product), 4 fp32-class with a cheaper BACKWARD (round 5:
+                                                             // forward as 0 — three products: its outputs pick max-pool winners and
+                                                             // leaky-ReLU signs, a coarser forward flips them by the thousand —; input
+                                                             // gradient with dL/dy as ONE fp16 piece, two products; weight gradient one
+                                                             // piece per operand, one product); see conv_mixed / sp_mode below
   const char* wt = nullptr; const WtPlan* wtp = nullptr;     // the step's tiled weights (null: tile per call into col)
   unsigned char* code = nullptr;                             // winners of the fused first block's max-pool (stack 0 only)
   PvFinishList* fin = nullptr;                               // weight-gradient finishes deferred to pv_wgrad_finish_all
@@ -187,7 +191,31 @@ inline bool conv_mixed(int cm) { return cm == 1 || cm == 3; }   // (3: the kerne
 inline int sp_fp32_mode(int cm) { return cm == 2 ? 3 : pv_conv3_sp_fp32_mode(); }
 // ... and the `mode` argument of pv_conv3_sp / _wgrad / _pair / pv_conv3_direct's callers: 2 mixed, else the fp32-class one
 inline int sp_mode(int cm) { return cm == 3 ? 1 : (cm == 1 ? 2 : sp_fp32_mode(cm)); }
+// ... of the INPUT gradient (mode 4: the weights two fp16 pieces, dL/dy one: two products) and of the split-operand WEIGHT
+// gradient (mode 4: one piece per operand — its sums run over every pixel of every sample)
+// (the input gradient with ONE piece per operand too — one product — was measured: the weights' rounding is systematic, the
+//  conv-stack gradients land AT the bar instead of 1.3 - 3.7x inside it: gpurun_out/r05r; not adopted)
+inline int sp_dg_mode(int cm) { return cm == 4 ? 5 : sp_mode(cm); }
+inline int sp_wg_mode(int cm) { return cm == 4 ? 1 : sp_mode(cm); }
 inline int direct_mode(const Scratch& sc) { return conv_mixed(sc.conv_bf16) ? 1 : (sp_fp32_mode(sc.conv_bf16) == 4 ? 2 : 0); }
+
+// Mode 4's one-piece backward operands carry independent rounding errors of 2^-12 that average out of the sums a gradient is:
+// it is taken only where EVERY split-operand kernel-3 convolution of the stack sums at least PV_CONV_W1_MIN_PIXELS pixels
+// (batch x height x width at that layer) — the rule of the decoder kernel's fp16 builds (pv_sdec_fused_bf16.hip: 16 384 rows);
+// smaller problems keep mode 0 (three products everywhere).
+#define PV_CONV_W1_MIN_PIXELS 16384
+inline int conv_mode_for(int cm, const pv_op* ops, int n, int nd, int64_t B, int in_c, const int* in_dim) {
+  if (cm != 4) return cm;
+  Shape s{in_dim[0], nd == 2 ? in_dim[1] : 1, in_c}, t;
+  for (int i = 0; i < n; ++i) {
+    if (ops[i].kind == PV_OP_CONV && ops[i].ksize == 3 && pv_conv3_sp_supported(ops[i].cin, ops[i].cout, nd, ops[i].act) &&
+        B * s.H * s.W < PV_CONV_W1_MIN_PIXELS)
+      return 0;
+    if (!op_shape(ops[i], nd, s, t)) return 0;
+    s = t;
+  }
+  return 4;
+}
 
 // which tiling (pv_conv_wprep_table kind) a kernel-3 convolution uses in an orientation; -1: none (GEMM fallback, k1)
 inline int wt_kind(const pv_op& o, int nd, int flip, int conv_bf16) {
@@ -312,7 +340,7 @@ inline ConvBwdForm conv_bwd_form(const pv_op& o, int nd, int B, const Shape& si,
   // which the main stream keeps using)
   f.on_side = sc.side && wg && pv_wgrad_defers(sc.fin, pv_conv3_sp_wgrad_ws(B, si.H, si.W, si.C, o.cout));
   // weight gradient + input gradient in one launch (pv_conv_sp.hip)
-  f.pair = wg && want_gin && sc.fin && !conv_mixed(sc.conv_bf16) && sp_fp32_mode(sc.conv_bf16) == 4 &&
+  f.pair = wg && want_gin && sc.fin && !conv_mixed(sc.conv_bf16) && sc.conv_bf16 != 4 && sp_fp32_mode(sc.conv_bf16) == 4 &&
            pv_conv3_sp_supported(o.cout, o.cin, nd, PV_ACT_NONE) && (!f.on_side || side_keeps_pairs());
   return f;
 }
@@ -353,7 +381,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
       if (pv_conv3_sp_wgrad_supported(si.C, o.cout, nd)) {
         if (on_side) PV_TRY(pv_fork_to(sc.side, s));                // g is complete: its producer's stop event, or a record on s
         PV_TRY(pv_conv3_sp_wgrad(g, in, B, si.H, si.W, si.C, grads + o.w_off, db, o.cout, sc.ws, sc.ws_bytes, on_side ? sc.side : s,
-                                 sp_mode(sc.conv_bf16), sc.fin));
+                                 sp_wg_mode(sc.conv_bf16), sc.fin));
       }
       else if (k3_lean_1d(nd) && (!conv_mixed(sc.conv_bf16) || k3_lean_mixed(sc)))   // (launch by launch the mixed leg's bf16 kernel is faster)
         PV_TRY(pv_conv3_1d_wgrad_lean(g, in, B, si.H, si.C, o.cout, grads + o.w_off, db, sc.ws, sc.ws_bytes, s, sc.fin));
@@ -373,7 +401,7 @@ inline int op_bwd(const float* params, float* grads, const pv_op& o, int nd, int
         const bool up = up_code && unpooled && (o.cin & 3) == 0;
         if (up) *unpooled = true;
         return pv_conv3_sp(g, B, si.H, si.W, params + o.w_off, o.cout, o.cin, 1, nullptr, gin, PV_ACT_NONE, sc.col, s, in, fuse_act,
-                           sp_mode(sc.conv_bf16), wt_ready(sc, slot, 1), nullptr, nullptr, up ? up_code : nullptr);
+                           sp_dg_mode(sc.conv_bf16), wt_ready(sc, slot, 1), nullptr, nullptr, up ? up_code : nullptr);
       }
       if (pv_conv3_direct_supported(o.cout, o.cin, nd, PV_ACT_NONE)) {
         if (fused && fuse_act != PV_ACT_NONE) *fused = true;

@@ -74,7 +74,11 @@ static inline int64_t plan_K(const pv_ivae_plan* p) { return p->discrete_dim > 0
 // 3 one fp16 piece).  fused == 3 is the throughput precision; conv_wide (a weight left fp16's range) selects the range-free
 // bf16 forms of either precision
 static inline int plan_conv_mode(const pv_ivae_plan* p) {
-  return p->fused == 3 ? (p->conv_wide ? 1 : 3) : (p->conv_wide ? 2 : 0);
+  if (p->fused == 3) return p->conv_wide ? 1 : 3;
+  if (p->conv_wide) return 2;
+  if (p->flags & PV_PLAN_CONV_X3) return 0;
+  // round 5: the cheaper backward (pv_convstack.h mode 4) where the stack's gradient sums are long enough
+  return pvcs::conv_mode_for(4, p->enc_ops, p->n_enc_ops, p->enc_ndim, p->batch, 1, p->enc_in_dim);
 }
 static inline int64_t plan_S(const pv_ivae_plan* p) { return (plan_K(p) > 0 ? plan_K(p) : 1) * (int64_t)p->batch; }
 static inline int64_t plan_head_w(const pv_ivae_plan* p) { return 2 * (int64_t)p->z_dim + plan_K(p); }

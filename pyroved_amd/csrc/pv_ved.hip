@@ -59,6 +59,12 @@ bool valid_ved(const pv_ved_plan* p) {
 }
 
 // shapes + workspace carving; false on an inconsistent plan
+// the conv mode this call runs with: the plan's, except that mode 4 (the cheaper backward) needs gradient sums long enough for
+// its one-piece operands' rounding to average out — decided on the ENCODER stack (the 2-D convolutions; pv_convstack.h)
+static int ved_conv_mode(const pv_ved_plan* p) {
+  return pvcs::conv_mode_for(p->conv_bf16, p->enc, p->n_enc_ops, p->ndim_in, p->batch, p->in_ch, p->in_dim);
+}
+
 bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
   VCarver c{base, 0};
   const int64_t B = p->batch, z = p->z_dim;
@@ -107,13 +113,13 @@ bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {
     for (int i = 1; i <= p->n_enc_ops; ++i) L.eg[i] = (i == 1 && c1) || i == p->n_enc_ops ? nullptr : c.take(L.es[i].elems(B));
   }
   L.sc.col = c.take(nd.maxcol);
-  pvcs::wt_layout(p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, false, L.wtp);
-  pvcs::wt_layout(p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, true, L.wtp);
+  pvcs::wt_layout(p->enc, p->n_enc_ops, p->ndim_in, 0, ved_conv_mode(p), false, L.wtp);
+  pvcs::wt_layout(p->dec, p->n_dec_ops, p->ndim_out, 1, ved_conv_mode(p), true, L.wtp);
   L.wt = reinterpret_cast<char*>(c.take((L.wtp.bytes + 3) / 4));
   L.sc.code = nd.code_bytes ? reinterpret_cast<unsigned char*>(c.take((nd.code_bytes + 3) / 4)) : nullptr;
   L.sc.code2 = enc_code2 ? reinterpret_cast<unsigned char*>(c.take((enc_code2 + 3) / 4)) : nullptr;
   L.sc.bn = c.take(pvcs::bn_floats(nd)); L.sc.bn_maxC = nd.bn_maxC; L.sc.bn_eval = p->bn_eval;
-  L.sc.conv_bf16 = p->conv_bf16;
+  L.sc.conv_bf16 = ved_conv_mode(p);
   L.sc.ws_bytes = pv_align_up(nd.scratch, 256);
   L.sc.ws = base ? (void*)(base + c.off) : nullptr;
   c.off += L.sc.ws_bytes;
@@ -146,7 +152,7 @@ int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_
   if (enc) {
     const Shape& fe = L.es[p->n_enc_ops];
     const PvWprepEntry he = pvcs::head_entry(p->params + p->head.w_off, L.head_wt, 2 * p->z_dim, fe.C, (int64_t)fe.H * fe.W);
-    pvcs::wt_entries(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, p->conv_bf16, L.wtp, L.wt, with_dgrad, e, ne, &he,
+    pvcs::wt_entries(p->params, p->enc, p->n_enc_ops, p->ndim_in, 0, ved_conv_mode(p), L.wtp, L.wt, with_dgrad, e, ne, &he,
                      L.head_wt ? 1 : 0);
   }
   if (dec) {
@@ -156,7 +162,7 @@ int ved_wt_prep(const pv_ved_plan* p, VLayout& L, bool enc, bool dec, bool with_
       if (L.l2f_wt) e[ne++] = le;
       pv_dec1d_wt_entries(p->params, p->dec, p->n_dec_ops, L.d1_wt, e, ne);
     } else {
-      pvcs::wt_entries(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, p->conv_bf16, L.wtp, L.wt, with_dgrad, e, ne, &le,
+      pvcs::wt_entries(p->params, p->dec, p->n_dec_ops, p->ndim_out, 1, ved_conv_mode(p), L.wtp, L.wt, with_dgrad, e, ne, &le,
                        L.l2f_wt ? 1 : 0);
     }
   }

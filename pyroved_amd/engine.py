@@ -45,6 +45,7 @@ class IVAEEngine:
     enc_no_wait = False              # PV_PLAN_ENC_NO_WAIT: the one-launch encoder's consumers compute their tiles themselves
     side_stream = True               # PV_PLAN_NO_SIDE_STREAM when False
     dec1d = True                     # PV_PLAN_NO_DEC1D when False (VED's Conv1d decoder layer by layer)
+    conv_x3 = False                  # PV_PLAN_CONV_X3 / conv_bf16 = 0: fp32-class kernel-3 convolutions with both operands as two fp16 pieces
     enc_fold = True                  # PV_PLAN_NO_ENC_FOLD when False (the guide as its own launch even where the decoder launch could host it)
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, fused: int = 2):
@@ -304,7 +305,8 @@ class IVAEEngine:
                 (0 if getattr(self, "side_stream", True) else _abi.PV_PLAN_NO_SIDE_STREAM) |
                 (_abi.PV_PLAN_ENC_NO_WAIT if getattr(self, "enc_no_wait", False) else 0) |
                 (0 if getattr(self, "dec1d", True) else _abi.PV_PLAN_NO_DEC1D) |
-                (0 if getattr(self, "enc_fold", True) else _abi.PV_PLAN_NO_ENC_FOLD))
+                (0 if getattr(self, "enc_fold", True) else _abi.PV_PLAN_NO_ENC_FOLD) |
+                (_abi.PV_PLAN_CONV_X3 if getattr(self, "conv_x3", False) else 0))
 
     def ensure_bound(self):
         if not self._bound():

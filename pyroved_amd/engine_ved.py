@@ -91,7 +91,9 @@ class VEDEngine(IVAEEngine):
         # SVItrainer(precision="bf16"): the throughput precision (one fp16 piece per operand of the 2-D kernel-3 convolutions, one
         # matrix product); otherwise fp32-class.  Once a weight left fp16's range (engine._check_conv_weight_range) the throughput
         # precision falls back to the range-free two-piece bf16 "mixed" kernels and fp32-class to the three-piece bf16 form
-        p.conv_bf16 = ((1 if self.wide_weights else 3) if self.fused == 3 else (2 if self.wide_weights else 0))
+        # (round 5: fp32-class = "f16w2" — weights two fp16 pieces, activations one — unless conv_x3 asks for both operands split)
+        p.conv_bf16 = ((1 if self.wide_weights else 3) if self.fused == 3 else
+                       (2 if self.wide_weights else (0 if self.conv_x3 else 4)))
         p.flags = self._plan_flags()
         p.x = p.y = p.eps = p.z_loc = p.z_scale = p.loc = None
         ce = getattr(self, "conv_events", None)          # (start, stop, ctypes double for the launch's FLOPs) or None

@@ -71,7 +71,10 @@ CONV_CASES = [  # (B, H, W, Cin, Cout, act)
 
 # mode 7 (round 4): ONE fp16 piece per operand, one product — the throughput precision: per-element relative error 2^-12 on
 # both operands, ~3e-4 on a 288..1152-term dot product of random data
-@pytest.mark.parametrize("mode,tol", [(3, 2e-6), (2, 2e-5), (7, 6e-4)])
+# mode 8 (round 5, "f16w2"): the weights two exact fp16 pieces, the patch ONE piece (round to nearest), two products: what is left is
+# the patch's rounding alone — 2^-12 per element, independent from element to element: ~2e-4 on a dot product of random data, and
+# it averages out of everything a training step sums (the full-size gradient tests hold the mode to the fp32-class bars)
+@pytest.mark.parametrize("mode,tol", [(3, 2e-6), (2, 2e-5), (7, 6e-4), (8, 3e-4)])
 @pytest.mark.parametrize("B,H,W,Ci,Co,act", CONV_CASES)
 def test_split_operand_conv_forward_and_input_gradient(gpu_device, mode, tol, B, H, W, Ci, Co, act):
     g = torch.Generator().manual_seed(B * 1000 + H * 31 + Co)

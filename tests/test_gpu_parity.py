@@ -1294,7 +1294,7 @@ def full_size_tol(key, e32):
     return max(floor, 2 * e32[key])
 
 
-@pytest.mark.parametrize("fused,draw", [(0, "seed0"), (2, "seed0"), (2, "seed7"), (2, "blobs"), (3, "seed0")])
+@pytest.mark.parametrize("fused,draw", [(0, "seed0"), (2, "seed0"), (2, "seed7"), (2, "blobs"), (20, "seed0"), (3, "seed0")])
 def test_full_size_c4_conv_encoder(gpu_device, fused, draw):
     """BASELINE config 4 at its own shape and per-GPU batch: iVAE 64x64 ['r','t','s'] + set_encoder(convEncoderNet)
     with the default stack (nets/conv.py:24-64), batch 128 — properties + the ELBO terms vs the oracle."""
@@ -1304,7 +1304,12 @@ def test_full_size_c4_conv_encoder(gpu_device, fused, draw):
     xkind, xseed, eseed = FULL_SIZE_DRAWS[draw]
     model = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
     model.set_encoder(pv.nets.convEncoderNet(data_dim, latent_dim=model.z_dim))
+    # fused 20: the fp32-class path with the convolutions' BACKWARD at three products too (rounds 2-4's form, PV_PLAN_CONV_X3);
+    # the default since round 5 keeps three products in the forward only (input gradient two, weight gradient one)
+    conv_x3 = fused == 20
+    fused = 2 if conv_x3 else fused
     eng = model.engine(fused=fused)
+    eng.conv_x3 = conv_x3
     x = make_x(xkind, b, data_dim, seed=xseed)
     torch.manual_seed(eseed)
     eps = torch.empty(b, model.z_dim).normal_()
@@ -1330,7 +1335,7 @@ def test_full_size_c4_conv_encoder(gpu_device, fused, draw):
     np.testing.assert_allclose(s[3], out["logqz"].item(), rtol=1e-4)
 
 
-@pytest.mark.parametrize("prec,draw", [("fp32", "seed0"), ("fp32", "seed7"), ("fp32", "blobs"), ("bf16", "seed0")])
+@pytest.mark.parametrize("prec,draw", [("fp32", "seed0"), ("fp32", "seed7"), ("fp32", "blobs"), ("fp32x3", "seed0"), ("bf16", "seed0")])
 def test_full_size_c5_ved(gpu_device, prec, draw):
     """BASELINE config 5 at its per-GPU size: VED 64x64 -> 128-point spectrum, batch 256 — properties + ELBO terms
     vs the oracle (three draws at the fp32-class precision: FULL_SIZE_DRAWS)."""
@@ -1339,6 +1344,7 @@ def test_full_size_c5_ved(gpu_device, prec, draw):
     xkind, xseed, eseed = FULL_SIZE_DRAWS[draw]
     model = pv.models.VED((64, 64), (128,), seed=1, device="cuda")
     eng = model.engine(fused=3 if prec == "bf16" else 2)
+    eng.conv_x3 = prec == "fp32x3"       # (the convolutions' backward at three products too: rounds 2-4's fp32-class form)
     g = torch.Generator().manual_seed(xseed)
     x = torch.rand(b, 1, 64, 64, generator=g)
     if xkind == "blobs":
@@ -1891,7 +1897,7 @@ def test_conv_weight_range_switches_kernels(gpu_device):
             eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
         assert eng.wide_weights and eng._static.conv_bf16 == 2
         eng_other.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
-        assert not eng_other.wide_weights and eng_other._static.conv_bf16 == 0      # per plan: the other model is untouched
+        assert not eng_other.wide_weights and eng_other._static.conv_bf16 == 4      # per plan: the other model is untouched (4: the default fp32-class mode)
         assert np.isfinite(eng_other.scalars.cpu().numpy()).all()
         s = eng.scalars.cpu().numpy()
         loss_ref = o.step(x, y, eps, 1.0)
