@@ -404,7 +404,7 @@ def _paths(cfg, mode, B, n_pix, fold=False):
         if prec == "2":
             return (kn, dec_fl, MFMA_BF16_PEAK_TFLOPS, "f16w2",
                     "f16 MFMA: weights as two exact power-of-two-scaled fp16 pieces, activations and dL/dpre one piece (forward 2 "
-                    "products, dgrad 2, wgrad 1; fp32 accumulate; fp32 elsewhere); selected from 2 M decoder rows up")
+                    "products, dgrad 2, wgrad 1; fp32 accumulate; fp32 elsewhere); selected from 524 288 decoder rows up")
         return (kn, dec_fl, MFMA_BF16_PEAK_TFLOPS, "bf16x3",
                 "bf16 split-precision MFMA (hi+lo, 3 products, fp32 accumulate; fp32 elsewhere)")
     if mode == 3:

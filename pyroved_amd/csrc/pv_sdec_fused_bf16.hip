@@ -1006,7 +1006,10 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
 // activations one piece — once the rows a gradient sums are enough for the one-piece operands' independent rounding errors to
 // average out (error table: profiles/r04a_fb_prec_table.txt, bars: every gradient tensor 1e-4 vs the oracle):
 //   >= FB_H231_MIN_UNITS units (16 384 rows):   H231 (kind 28: dL/dpre split in both dgrads; worst tensor 1.6e-5 at C2)
-//   >= FB_H221_MIN_UNITS units (2 M rows):      H221 (kind 21: one piece everywhere; 6e-5 at C2's 2e5 rows, ~1 / sqrt(rows))
+//   >= FB_H221_MIN_UNITS units (524 288 rows):  H221 (kind 21: one piece everywhere; 6e-5 at C2's 2e5 rows, ~1 / sqrt(rows):
+//                                               round 5 moved the gate from 2 M rows to where the model predicts <= 4e-5 and three
+//                                               draws of the 64x64 config measure 4.3e-5 ... 5.1e-5 on the worst tensor —
+//                                               profiles/r05u_grad_margin_h221_*.txt — C4's decoder launch 357 -> 327 us)
 // smaller problems keep the bf16 three-product kernel (kind 0).
 // Which build runs is a function of (fused mode, units, launch kind) and of pv_ivae_plan.dec_kernel (`sel`, 0 = by size: ABI v15,
 // a PLAN field — no process-wide state).  sel, plain (fused 3): 1 the 4-wave kernel, 2 the 8-wave kernel.  sel, split precision
@@ -1017,7 +1020,7 @@ extern "C" int pv_debug_read_trace(long long* out, int n) {
 #define FB_H231_MIN_UNITS 1024         // 16 384 rows
 #endif
 #ifndef FB_H221_MIN_UNITS
-#define FB_H221_MIN_UNITS 131072       // 2 097 152 rows
+#define FB_H221_MIN_UNITS 32768        // 524 288 rows (round 5; rounds 4: 131072 = 2 097 152 rows)
 #endif
 #ifndef FB_EXPERIMENTS
 #ifdef PV_EXPERIMENTS

@@ -1314,7 +1314,9 @@ def test_full_size_c4_conv_encoder(gpu_device, fused, draw):
     torch.manual_seed(eseed)
     eps = torch.empty(b, model.z_dim).normal_()
     xg, eg = x.cuda(), eps.cuda()
-    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 5e-6)
+    # (shard additivity: the half batches are 262 k decoder rows — the H231 build of the fp32-class kernel — the full batch 524 k,
+    #  from which the one-piece-activation H221 build runs since round 5: two roundings of the same sums, 8e-6 apart)
+    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 2e-5 if fused == 2 else 5e-6)
     cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, conv_encoder=hid)
     # (round 3) backward at size too.  At 0.5 M decoder rows / 0.5 M conv pixels per layer the fp32 CPU oracle is itself
     # 1e-4 .. 2e-4 off float64 on the encoder tensors (sums of ~1e6 cancelling terms): the float64 oracle is the truth here,
