@@ -175,16 +175,24 @@ __global__ __launch_bounds__(256) void pv_c1_convpool_bwd_kernel(C1PoolBwd p) {
   const bool cok = co < p.C;
   const int coc = cok ? co : p.C - 1;
   const float msk = cok ? 1.0f : 0.0f;
-  for (int li = 0; li < nl; ++li) {
-    const float* xl = xs + li * 4 * WS;
-    const int64_t base = (l_lo + li) * p.Wp * p.C + coc;
-#pragma unroll 4
-    for (int px = rg; px < p.Wp; px += RG) {
-      const int64_t o = base + (int64_t)px * p.C;
-      const float dv = msk * p.g[o] * pv_act_grad(p.y[o], 0.0f, p.act);
-      const int k = p.code[o];
+  // (round 5: a pixel column of ALL the workgroup's lines per pass — the 3 x 8 global loads of a pass are independent and in
+  //  flight together; line by line the kernel waited for memory once per line: 42 -> ? us at batch 128)
+  for (int px = rg; px < p.Wp; px += RG) {
+    float gv[8], yv[8];
+    int kv[8];
+#pragma unroll
+    for (int li = 0; li < 8; ++li) {
+      const int lc = li < nl ? li : nl - 1;
+      const int64_t o = ((l_lo + lc) * p.Wp + px) * p.C + coc;
+      gv[li] = p.g[o]; yv[li] = p.y[o]; kv[li] = p.code[o];
+    }
+#pragma unroll
+    for (int li = 0; li < 8; ++li) {
+      if (li >= nl) break;
+      const float dv = msk * gv[li] * pv_act_grad(yv[li], 0.0f, p.act);
+      const int k = kv[li];
       // the 3x3 input window under the WINNING position (k >> 1, k & 1) of this pooled value: per-lane LDS addresses
-      const float* xp = xl + (k >> 1) * WS + 2 * px + (k & 1);
+      const float* xp = xs + li * 4 * WS + (k >> 1) * WS + 2 * px + (k & 1);
       accb += dv;
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[t] += dv * xp[(t / 3) * WS + t % 3];
