@@ -229,6 +229,9 @@ def require_device(t, what):
 def current_stream():
     """The current HIP stream of the CURRENT device: library calls are made under `on_device` / `device_of`, which make
     the tensors' device current first (kernels launched on device A's stream against device B's pointers fault)."""
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # (the handle without a torch.cuda.Stream object around it)
+    if raw is not None:
+        return C.c_void_p(raw(torch._C._cuda_getDevice()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

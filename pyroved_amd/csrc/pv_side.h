@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 // the side stream of the calling thread's current device; null: disabled (PV_NO_SIDE=1) or not available
 hipStream_t pv_side_stream();
+hipStream_t pv_side_stream2();                         // a second one (same priority); null when pv_side_stream() is
 // is `s` being captured into a graph?  (Forks with stop events and launches that hand data over through per-call flag values
 // are not replayable: the entry points fall back to their one-stream, one-kernel-per-stage forms under capture.)
 bool pv_stream_capturing(hipStream_t s);
@@ -24,7 +25,7 @@ void pv_fork_arm();
 void pv_fork_disarm();
 hipEvent_t pv_fork_take();
 bool pv_fork_taken();                                  // did a launch take the armed event?
-int pv_fork_to(hipStream_t side, hipStream_t main);
+int pv_fork_to(hipStream_t side, hipStream_t main, hipStream_t side_b = nullptr);   // side_b: a second waiter on the same event
 #define PV_LAUNCH_FORK(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                            \
   do {                                                                                                    \
     hipEvent_t fe__ = pv_fork_take();                                                                     \

@@ -14,7 +14,7 @@ namespace {
 
 constexpr int kMaxDev = 16, kEvents = 64;
 struct Side {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;
   hipEvent_t ev[kEvents] = {};
   int next = 0;
   bool tried = false;
@@ -47,6 +47,8 @@ Side* side_of_current_device() {
         return nullptr;
       }
     S.stream = st;
+    // a second one of the same priority (two independent families of side work; null when the device refuses)
+    if (hipStreamCreateWithPriority(&S.stream2, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); S.stream2 = nullptr; }
   }
   return S.stream ? &S : nullptr;
 }
@@ -63,6 +65,12 @@ hipStream_t pv_side_stream() {
   if (!side_enabled()) return nullptr;
   Side* S = side_of_current_device();
   return S ? S->stream : nullptr;
+}
+
+hipStream_t pv_side_stream2() {
+  if (!side_enabled()) return nullptr;
+  Side* S = side_of_current_device();
+  return S ? S->stream2 : nullptr;
 }
 
 namespace {
@@ -88,13 +96,24 @@ hipEvent_t pv_fork_take() {
   return t_armed;
 }
 bool pv_fork_taken() { return t_armed && t_taken; }
-int pv_fork_to(hipStream_t side, hipStream_t main) {
+int pv_fork_to(hipStream_t side, hipStream_t main, hipStream_t side_b) {
   if (t_armed && t_taken) {
-    const hipError_t rc = hipStreamWaitEvent(side, t_armed, 0);
+    hipError_t rc = hipStreamWaitEvent(side, t_armed, 0);
+    if (rc == hipSuccess && side_b && side_b != side) rc = hipStreamWaitEvent(side_b, t_armed, 0);
     pv_fork_disarm();
     return rc == hipSuccess ? 0 : (int)rc;
   }
   pv_fork_disarm();
+  if (side_b && side_b != side) {                     // one marker for both
+    if (side == main && side_b == main) return 0;
+    Side* S = side_of_current_device();
+    if (!S) return PV_EINVAL;
+    hipEvent_t e = next_event(S);
+    hipError_t rc = hipEventRecord(e, main);
+    if (rc == hipSuccess && side != main) rc = hipStreamWaitEvent(side, e, 0);
+    if (rc == hipSuccess && side_b != main) rc = hipStreamWaitEvent(side_b, e, 0);
+    return rc == hipSuccess ? 0 : (int)rc;
+  }
   return pv_stream_after(side, main);
 }
 

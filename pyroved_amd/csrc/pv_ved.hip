@@ -343,8 +343,14 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   const bool two = side2 != nullptr;
   side = side2;
   if (two) sj.fork(s, side);
-  hipStream_t sw = two ? side : s;
-  if (two) PV_TRY(pv_fork_to(side, s));                // after the chain's last launch (its stop event when it took one)
+  // the decoder's recorded weight gradients on a stream of their own: the encoder's kernel-3 weight gradients then start as
+  // soon as their dL/dy exists instead of queueing behind them (round 5, `gpurun_out/r05y`: VED at batch 256 0.806-0.812 ->
+  // 0.792 ms; PV_K1_STREAM3=0 in the experiments build: both families on the one side stream)
+  static const int k1_own_env = pv_exp_int("PV_K1_STREAM3", 1);
+  hipStream_t side3 = (two && k1_own_env) ? pv_side_stream2() : nullptr;
+  struct Join3 { hipStream_t m, s3; ~Join3() { if (s3) (void)pv_stream_after(m, s3); } } j3{s, side3};
+  hipStream_t sw = two ? (side3 ? side3 : side) : s;
+  if (two) PV_TRY(pv_fork_to(side, s, side3));         // after the chain's last launch (its stop event when it took one)
   PV_TRY(pv_k1_wgrad_flush(&k1b, sw));
   fin.k1b = nullptr;
   for (int k = 0; k < fin.n; ++k) fin.st[k] = sw;      // (recorded on s, written by the launch above)
@@ -400,6 +406,7 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (two && !joined) PV_TRY(pv_stream_after(s, side));
   else if (!two && sf != s) PV_TRY(pv_stream_after(s, sf));   // (no second fork: the loss scalars alone ran on the side stream)
   sj.joined();
+  if (side3) { PV_TRY(pv_stream_after(s, side3)); j3.s3 = nullptr; }
   return pv_wgrad_finish_all(&fin, s);
 }
 

@@ -1966,6 +1966,45 @@ def test_conv_weight_range_throughput_precision(gpu_device):
     np.testing.assert_allclose(e2.scalars[0].item(), o2.loss_and_grads(xx, ee)["loss"].item(), rtol=1e-3)
 
 
+def test_engine_notices_moved_and_replaced_parameters(gpu_device):
+    """Every call asks whether the model's parameters still live in the engine's flat buffer (engine.IVAEEngine._bound; the
+    reference re-registers the modules with pyro.module at every model()/guide() call, models/ivae.py:145,171).  The
+    per-call check is a snapshot walk (round 5: nn.Module.named_parameters() was a third of a 0.1 ms step's host time): it
+    has to see a tensor whose storage moved, a replaced nn.Parameter, a swapped submodule and an added parameter — and
+    the step after each must use the NEW values (compared with a fresh model holding them)."""
+    def fresh(state):
+        m = pv.models.iVAE((16, 16), latent_dim=2, invariances=["r"], hidden_dim_e=[64, 64], hidden_dim_d=[64, 64], seed=0, device="cuda")
+        m.load_state_dict(state)
+        return m
+    g = torch.Generator().manual_seed(5)
+    x, eps = torch.rand(32, 256, generator=g).cuda(), torch.randn(32, 3, generator=g).cuda()
+    model = pv.models.iVAE((16, 16), latent_dim=2, invariances=["r"], hidden_dim_e=[64, 64], hidden_dim_d=[64, 64], seed=0, device="cuda")
+    eng = model.engine()
+    eng.loss_and_grads(x, eps)
+    assert eng._bound() and eng._snap is not None          # the fast path is armed
+    lin = next(m for m in model.decoder.modules() if isinstance(m, torch.nn.Linear) and m.bias is not None)
+
+    def check(what):
+        assert not eng._bound(), what + ": not noticed"
+        eng.loss_and_grads(x, eps)
+        assert eng._bound()
+        ref = fresh({k: v.detach().clone() for k, v in model.state_dict().items()}).engine()
+        ref.loss_and_grads(x, eps)
+        assert torch.equal(eng.scalars, ref.scalars), what
+        assert torch.equal(eng.grad[:eng.n_flat], ref.grad[:ref.n_flat]), what
+
+    with torch.no_grad():                                  # 1. the storage moved (what .to() / .half().float() do)
+        lin.weight.data = lin.weight.data.clone() * 1.25
+    check("moved storage")
+    lin.bias = torch.nn.Parameter(torch.full_like(lin.bias, 0.01))          # 2. a replaced nn.Parameter
+    check("replaced parameter")
+    owner = next(m for m in model.modules() if any(c is lin for c in m.children()))
+    name = next(n for n, c in owner.named_children() if c is lin)
+    new_lin = torch.nn.Linear(lin.in_features, lin.out_features).cuda()     # 3. a swapped submodule
+    setattr(owner, name, new_lin)
+    check("swapped submodule")
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_two_stream_conv_steps_are_bit_identical(gpu_device, precision):
     """Steps of models with a convolutional encoder put the encoder's kernel-3 weight gradients, the decoder's batched
