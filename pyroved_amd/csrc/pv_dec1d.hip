@@ -189,6 +189,8 @@ extern "C" int pv_debug_read_d1_trace(long long* out) { return (int)hipMemcpyFro
 #else
 #define D1_STAMP(k) do { } while (0)
 #endif
+// finer stamps inside two chosen steps (1: a 128 -> 128 kernel-3 step, 8: a 32 -> 32 kernel-1 step): slots 32 + 8 s + j
+#define D1_FINE(j) do { if (i == 1) D1_STAMP(32 + (j)); else if (i == 8) D1_STAMP(40 + (j)); } while (0)
 
 // One step of a sample.  BWD = false: out = act(conv(in) + bias), rows stored twice for a fused upsample; BWD = true:
 // out = conv^T(g) * act'(y) (the incoming gradient summed over row pairs first for a fused upsample).  pre: group 0 of the
@@ -213,7 +215,9 @@ __device__ __forceinline__ void d1_step(const D1Args& A, int i, int b, float* ld
   float* ob_ = lds + o.lo;
   const int up = BWD ? 0 : o.up;
   const int Lout = up ? 2 * o.L : o.L, Po = d1_pitch(o.N);
+  D1_FINE(0);
   d1_zero_halo(ob_, Lout, o.N);
+  D1_FINE(1);
   if (!d1_mfma_step(o)) {
     d1_small_k<BWD>(o, in, ob_, BWD && o.e ? o.e + (int64_t)b * o.L * o.N : nullptr);
   } else {
@@ -226,7 +230,12 @@ __device__ __forceinline__ void d1_step(const D1Args& A, int i, int b, float* ld
       const float* wl = d1_wl(o, ob, lane);
       if (tile != wave) { d1_ldg_op(o, wl, pre); pev = d1_ev<BWD>(o, b, ob, lb, r, q); }   // (a further tile of the step: on demand)
       const f32x4 ev = pev;
+      D1_FINE(2);
       const f32x4 acc = o.G == 8 ? d1_mma<8>(o, in, lb, r, q, wl, pre) : d1_mma<4>(o, in, lb, r, q, wl, pre);
+#ifdef D1_TRACE
+      asm volatile("s_nop 0" :: "v"(acc[0]));
+#endif
+      D1_FINE(3);
       f32x4 v;
       if (vec && pv_act_is_lin(o.act)) {               // the common case branch-free: y > 0 ? y : slope y, derivative 1 or slope
         const float slope = pv_act_slope(o.act);
@@ -263,6 +272,7 @@ __device__ __forceinline__ void d1_step(const D1Args& A, int i, int b, float* ld
       }
     }
   }
+  D1_FINE(4);
   if (!last && d1_mfma_step(A.op[i + 1]) && wave < d1_tiles(A.op[i + 1])) {      // the next step's first requests, before the barrier
     const D1Op& nx = A.op[i + 1];
     int ob, lb;
@@ -270,7 +280,9 @@ __device__ __forceinline__ void d1_step(const D1Args& A, int i, int b, float* ld
     d1_ldg_op(nx, d1_wl(nx, ob, lane), pre);
     pev = d1_ev<BWD>(nx, b, ob, lb, r, q);
   }
+  D1_FINE(5);
   pv_lds_barrier();
+  D1_FINE(6);
 }
 
 // BWD = false: A.in = a[0], op[j] = stack op j.  BWD = true: A.in = dL/d(a[n]); op[j] = the stack's steps in reverse, K = that
@@ -289,6 +301,7 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
       d1_ldg_op(A.op[0], d1_wl(A.op[0], ob, lane), pre);
       pev = d1_ev<BWD>(A.op[0], b, ob, lb, lane & 15, lane >> 4);
     }
+    D1_STAMP(48);
     {                                                  // the sample's input -> LDS rows 1 .. L0 (any width)
       float* dst = lds + A.op[0].li;
       const int P = d1_pitch(A.C0);
@@ -297,48 +310,89 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
         const int c4n = A.C0 >> 2;
         const int64_t F = (int64_t)A.L0 * A.C0;
         float zv[8];
-        if (A.h_head) {                                // the reparameterised sample is drawn here (every thread: zd <= 8 values)
-          float lp = 0.0f, lq = 0.0f;
+        // requested now, used after the head's finish and the sample: this thread's first latent_to_features element (bias and
+        // up to four weight rows) — its round trip runs under the finish's instead of after it
+        const int c4n0 = A.C0 >> 2;
+        const bool pref = A.zd <= 4 && tid < A.L0 * c4n0;
+        f32x4 pw[4], pb4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (pref) {
+          const int l = d1_div(tid, c4n0), c = 4 * (tid - l * c4n0);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            zv[k] = 0.0f;
-            if (k < A.zd) {
-              float mu, sp;
-              if (A.h_part) {                          // the conv head's finish: bias + partial sums in segment order
-                mu = A.h_bias ? A.h_bias[k] : 0.0f; sp = A.h_bias ? A.h_bias[A.zd + k] : 0.0f;
-                const float* pt = A.h_part + (int64_t)b * A.h_nseg * A.h_ldh;
-                for (int sg = 0; sg < A.h_nseg; ++sg) { mu += pt[sg * A.h_ldh + k]; sp += pt[sg * A.h_ldh + A.zd + k]; }
-                if (tid == 0) { A.h_hout[(int64_t)b * A.h_ldh + k] = mu; A.h_hout[(int64_t)b * A.h_ldh + A.zd + k] = sp; }
-              } else {
-                mu = A.h_head[(int64_t)b * A.h_ldh + k]; sp = A.h_head[(int64_t)b * A.h_ldh + A.zd + k];
-              }
-              const float sig = pv_softplus(sp), ep = A.h_eps[(int64_t)b * A.zd + k];
-              const float zz = mu + sig * ep, d = zz - mu;
-              zv[k] = zz;
-              lq += -(d * d) / (2.0f * (sig * sig)) - logf(sig) - 0.91893853320467274178f;      // torch Normal.log_prob
-              lp += -(zz * zz) / 2.0f - 0.91893853320467274178f;
-              if (tid == 0) {
-                A.h_z[(int64_t)b * A.zd + k] = zz; A.h_zs[(int64_t)b * A.zd + k] = sig;
-                if (A.h_zlo) A.h_zlo[(int64_t)b * A.zd + k] = mu;
-                if (A.h_zso) A.h_zso[(int64_t)b * A.zd + k] = sig;
-              }
-            }
+          for (int k = 0; k < 4; ++k)
+            if (k < A.zd) pw[k] = *reinterpret_cast<const f32x4*>(A.l2f_wt + (int64_t)k * ((int64_t)A.L0 * A.C0) + (int64_t)l * A.C0 + c);
+          if (A.l2f_b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pb4[j] = A.l2f_b[(int64_t)(c + j) * A.L0 + l];
           }
-          if (tid == 0) { A.h_kl[2 * b] = A.h_beta * lp; A.h_kl[2 * b + 1] = A.h_beta * lq; }
+        }
+        const float* hfin = nullptr;                   // the conv head's finish: bias + partial sums in segment order
+        if (A.h_head && A.h_part) {
+          // one partial sum per thread into LDS (the first step's output rows: free until the staging barrier), then thread j adds
+          // output j's in segment order — one memory round trip instead of h_nseg dependent ones in every thread (round 5: this
+          // stage 26.7 k -> 17.4 k cycles of the launch's 120 k; the same chain, the same bits)
+          float* hs = lds + A.op[0].lo;
+          const int np = A.h_nseg * A.h_ldh;           // (<= D1_THREADS: pv_dec1d_fwd checks)
+          if (tid < np) hs[tid] = A.h_part[(int64_t)b * np + tid];
+          pv_lds_barrier();
+          if (tid < A.h_ldh) {
+            float v = A.h_bias ? A.h_bias[tid] : 0.0f;
+            for (int sg = 0; sg < A.h_nseg; ++sg) v += hs[sg * A.h_ldh + tid];
+            hs[np + tid] = v;
+            A.h_hout[(int64_t)b * A.h_ldh + tid] = v;
+          }
+          pv_lds_barrier();
+          hfin = hs + np;
+        }
+        D1_STAMP(49);
+        if (A.h_head) {
+          // the reparameterised sample: component k by thread k (one copy of the softplus / log chain in the code — the launch runs
+          // it once, cold: eight predicated copies cost more in instruction fetch than in arithmetic), the two log-density sums
+          // by thread 0 in component order, every thread reads z back from LDS
+          float* hz = lds + A.op[0].lo + D1_THREADS + 16;          // [0, 8): z, [8, 16): log q terms, [16, 24): log p terms
+          if (tid < A.zd) {
+            const int k = tid;
+            float mu, sp;
+            if (hfin) { mu = hfin[k]; sp = hfin[A.zd + k]; }
+            else { mu = A.h_head[(int64_t)b * A.h_ldh + k]; sp = A.h_head[(int64_t)b * A.h_ldh + A.zd + k]; }
+            const float sig = pv_softplus(sp), ep = A.h_eps[(int64_t)b * A.zd + k];
+            const float zz = mu + sig * ep, d = zz - mu;
+            hz[k] = zz;
+            hz[8 + k] = -(d * d) / (2.0f * (sig * sig)) - logf(sig) - 0.91893853320467274178f;      // torch Normal.log_prob
+            hz[16 + k] = -(zz * zz) / 2.0f - 0.91893853320467274178f;
+            A.h_z[(int64_t)b * A.zd + k] = zz; A.h_zs[(int64_t)b * A.zd + k] = sig;
+            if (A.h_zlo) A.h_zlo[(int64_t)b * A.zd + k] = mu;
+            if (A.h_zso) A.h_zso[(int64_t)b * A.zd + k] = sig;
+          }
+          pv_lds_barrier();
+          if (tid == 0) {
+            float lp = 0.0f, lq = 0.0f;
+            for (int k = 0; k < A.zd; ++k) { lq += hz[8 + k]; lp += hz[16 + k]; }
+            A.h_kl[2 * b] = A.h_beta * lp; A.h_kl[2 * b + 1] = A.h_beta * lq;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float t = hz[k < A.zd ? k : 0]; zv[k] = k < A.zd ? t : 0.0f; }
         } else {
 #pragma unroll
           for (int k = 0; k < 8; ++k) zv[k] = k < A.zd ? A.z[(int64_t)b * A.zd + k] : 0.0f;
         }
+        D1_STAMP(50);
         for (int e = tid; e < A.L0 * c4n; e += D1_THREADS) {
           const int l = d1_div(e, c4n), c = 4 * (e - l * c4n);
           f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (A.l2f_b) {
+          if (pref && e == tid) {                      // (the requested element: the same chain from registers)
+            v = pb4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = A.l2f_b[(int64_t)(c + j) * A.L0 + l];
+            for (int k = 0; k < 4; ++k)
+              if (k < A.zd) v += zv[k] * pw[k];
+          } else {
+            if (A.l2f_b) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = A.l2f_b[(int64_t)(c + j) * A.L0 + l];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (k < A.zd) v += zv[k] * *reinterpret_cast<const f32x4*>(A.l2f_wt + (int64_t)k * F + (int64_t)l * A.C0 + c);
           }
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (k < A.zd) v += zv[k] * *reinterpret_cast<const f32x4*>(A.l2f_wt + (int64_t)k * F + (int64_t)l * A.C0 + c);
           *reinterpret_cast<f32x4*>(&dst[(l + 1) * P + c]) = v;
         }
       } else if ((A.C0 & 3) == 0) {
@@ -353,6 +407,7 @@ __global__ __launch_bounds__(D1_THREADS) void pv_dec1d_kernel(D1Args A) {
           dst[(l + 1) * P + c] = src[e];
         }
       }
+      D1_STAMP(51);
       d1_zero_halo(dst, A.L0, A.C0);
     }
     pv_lds_barrier();
@@ -567,6 +622,8 @@ static int64_t lay_out(D1Args& A, bool bwd) {
   const int lt = (int)off;                             // one shared buffer for the row-pair sums
   off += (tmax + 3) / 4 * 4;
   for (int j = 0; j < A.n; ++j) A.op[j].lt = lt;
+  // (forward staging scratch from the first step's output rows on: D1_THREADS partial sums, 16 head outputs, 24 sample terms)
+  if (!bwd && A.n > 0 && off < A.op[0].lo + D1_THREADS + 48) off = A.op[0].lo + D1_THREADS + 48;
   return off;
 }
 
@@ -629,6 +686,7 @@ int pv_dec1d_fwd(const float* params, const pv_op* ops, int n, const float* wt, 
     A.h_kl = hd->kl_part; A.h_ldh = hd->ldh; A.h_beta = hd->beta;
     if (hd->part) {
       if (!hd->head_out || hd->nseg < 1 || hd->ldh != 2 * l2f->zd) return PV_EINVAL;
+      if ((int64_t)hd->nseg * hd->ldh > D1_THREADS) return PV_EINVAL;    // (one partial sum per thread of the staging pass)
       A.h_part = hd->part; A.h_bias = hd->bias; A.h_hout = hd->head_out; A.h_nseg = hd->nseg;
     }
   }

@@ -18,3 +18,11 @@ assert lib.pv_debug_read_d1_trace(buf) == 0
 for k, name in ((0, "forward"), (1, "backward")):
     t = [buf[64 * k + i] for i in range(14)]
     print(name, "cycles per stage (stage 0 = operand request + staging):", [t[i + 1] - t[i] for i in range(11) if t[i + 1] > t[i]], "total", max(t) - t[0])
+for k, name in ((0, "forward"), (1, "backward")):
+    for s_, what in ((32, "step 1"), (40, "step 8")):
+        t = [buf[64 * k + s_ + j] for j in range(7)]
+        if min(t) > 0:
+            print(name, what, "entry->halo %d  ->mma start %d  mma %d  epilogue %d  next requests %d  barrier %d" % tuple(t[j + 1] - t[j] for j in range(6)))
+t = [buf[0], buf[48], buf[49], buf[50], buf[51], buf[1]]
+if min(t) > 0:
+    print("forward stage 0: first requests %d  head finish %d  sample + KL %d  latent_to_features %d  halo + barrier %d" % tuple(t[j + 1] - t[j] for j in range(5)))
