@@ -15,7 +15,9 @@ struct PvK1Wg {
   int taps, L;            // taps = 3: the kernel-3 1-D convolution's weight gradient, dW[m][n][t] = sum_p g[p][m] in[p + t - 1][n] within
                           // a sample of L positions (zero padding); taps = 1: kernel 1
   int nblk;               // workgroups of the problem
-  int fat;                // batched launches: 32 x 32 output tiles with all taps in the workgroup (mtiles / ntiles count those)
+  int fat;                // batched launches: 1 = 32 x 32 output tiles with all taps in the workgroup (mtiles / ntiles count those);
+                          // 2 = the wide form: (16 mj) x (16 nj) tiles fed by mj- / nj-float vector loads (round 5)
+  int mj, nj;
 };
 #define PV_K1_BATCH 12
 struct PvK1Batch { PvK1Wg e[PV_K1_BATCH]; int n; };

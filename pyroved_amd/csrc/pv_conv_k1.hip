@@ -425,6 +425,116 @@ __device__ __forceinline__ void k1_wgrad_fat_body(const K1Wg& a, int blk, float*
     a.part_b[(int64_t)sp * a.Co + 32 * mb + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
 }
 
+// The WIDE form (round 5).  The fat form feeds every MFMA with two 4-byte loads per lane: its ~2 M load instructions per launch
+// (each a 256-byte request) are what the launch takes its 100+ us for, and what it takes from the kernels it runs next to (VED at
+// batch 256 without this launch: 0.772 -> 0.728 ms).  An fp32 MFMA wants ONE value per lane and operand, but nothing says WHICH
+// 16 channels an MFMA's rows are: a lane loads MJ (NJ) consecutive channels of its pixel in one 8- / 16-byte load and component
+// j feeds MFMA j, whose row r is channel MJ r + j — a (16 MJ) x (16 NJ) tile per wave and tap from one g load and TAPS input
+// loads per four pixels: 4 load instructions per 24 MFMAs (three taps, 64 x 32) where the fat form issued 16.  Same split / partial
+// layout, the four waves' tiles summed through LDS tap by tap.
+template <int N> struct K1Vec;
+template <> struct K1Vec<2> { typedef float T __attribute__((ext_vector_type(2))); typedef unsigned U __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t rs, int off) { return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0)); } };
+template <> struct K1Vec<4> { typedef float T __attribute__((ext_vector_type(4))); typedef unsigned U __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t rs, int off) { return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0)); } };
+template <int TAPS, int MJ, int NJ> struct K1Wide {
+  static constexpr int WB = TAPS == 3 ? (NJ == 4 ? 16 : 32) : 64;    // pixels per register batch of a wave
+  static constexpr int MT = 16 * MJ, NT = 16 * NJ;
+};
+template <int TAPS, int MJ, int NJ>
+__device__ __forceinline__ void k1_wgrad_wide_body(const K1Wg& a, int blk, float* lds) {
+  typedef K1Wide<TAPS, MJ, NJ> W;
+  constexpr int WB = W::WB, MT = W::MT, NT = W::NT;
+  typedef typename K1Vec<MJ>::T vm;
+  typedef typename K1Vec<NJ>::T vn;
+  float (*part)[MT][NT + 1] = reinterpret_cast<float (*)[MT][NT + 1]>(lds);
+  float (*rpart)[MT] = reinterpret_cast<float (*)[MT]>(lds + 4 * MT * (NT + 1));
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = a.mtiles * a.ntiles;
+  const int sp = blk / tiles, t = blk - sp * tiles;
+  const int mb = t / a.ntiles, nb = t - mb * a.ntiles;
+  const int m0 = MT * mb, n0 = NT * nb;               // (Co / Ci are whole tiles: k1_wgrad_launch picks the form)
+  const int64_t p0 = (int64_t)sp * a.chunk, p1 = p0 + a.chunk < a.rows ? p0 + a.chunk : a.rows;
+  const bool pow2 = (a.L & (a.L - 1)) == 0;
+  f32x4 acc[TAPS][MJ][NJ];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) acc[tp][j][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  vm rs = {};
+  const int gm = a.up ? 2 : 1;
+  // (rows past the tensor read 0 through the buffers' bounds, as in the fat form)
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)(a.rows * gm * a.Co * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)(a.rows * a.Ci * 4), 0x00020000);
+  for (int64_t b0 = p0 + (int64_t)WB * wave; b0 < p1; b0 += 4 * WB) {
+    vm gv[WB / 4];
+    vn xv[TAPS][WB / 4];
+    const int pb = (int)b0 + q;                        // this lane's first pixel of the batch
+    const int go = 4 * (pb * gm * a.Co + m0 + MJ * r), xo = 4 * (pb * a.Ci + n0 + NJ * r);
+    const int l0 = pow2 ? (pb & (a.L - 1)) : pb % a.L;
+#pragma unroll
+    for (int s = 0; s < WB / 4; ++s) {
+      const int so_g = 16 * s * gm * a.Co, so_x = 16 * s * a.Ci;      // (uniform: 4 pixels x 4 bytes per step)
+      vm x = K1Vec<MJ>::ld(grs, go + so_g);
+      if (a.up) x += K1Vec<MJ>::ld(grs, go + so_g + 4 * a.Co);
+      gv[s] = x;
+      if (TAPS == 1) {
+        xv[0][s] = K1Vec<NJ>::ld(xrs, xo + so_x);
+      } else {
+        int l = l0 + 4 * s;
+        l = pow2 ? (l & (a.L - 1)) : l % a.L;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {            // input position = output position + tp - 1, inside the sample
+          const int sh = tp - 1;
+          const bool ok = l + sh >= 0 && l + sh < a.L;
+          const vn y = K1Vec<NJ>::ld(xrs, xo + so_x + 4 * sh * a.Ci);
+#pragma unroll
+          for (int i = 0; i < NJ; ++i) xv[tp][s][i] = ok ? y[i] : 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < WB / 4; ++s) {
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+          for (int i = 0; i < NJ; ++i) acc[tp][j][i] = MFMA4(gv[s][j], xv[tp][s][i], acc[tp][j][i]);
+      rs += gv[s];
+    }
+  }
+  // C layout: lane (column r, q), register e <-> row 4 q + e; row rr of MFMA j is channel MJ rr + j, column r of MFMA i channel NJ r + i
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) {
+    if (tp) __syncthreads();                           // (the previous tap's sums are read)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+#pragma unroll
+      for (int i = 0; i < NJ; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[wave][MJ * (4 * q + e) + j][NJ * r + i] = acc[tp][j][i][e];
+    if (tp == 0) {
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        const float v = pv_sum_rows(rs[j]);
+        if (q == 0) rpart[wave][MJ * r + j] = v;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < MT * NT; e += 256) {
+      const int nn = e % NT, mm = e / NT;
+      a.part[((int64_t)sp * a.Co * a.Ci + (int64_t)(m0 + mm) * a.Ci + n0 + nn) * TAPS + tp] =
+          (part[0][mm][nn] + part[1][mm][nn]) + (part[2][mm][nn] + part[3][mm][nn]);
+    }
+  }
+  if (a.part_b && nb == 0 && tid < MT)
+    a.part_b[(int64_t)sp * a.Co + m0 + tid] = (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]);
+}
+
 // every recorded weight gradient of a stack's backward in ONE launch (PvK1Batch): workgroup b serves problem k with
 // blk0[k] <= b < blk0[k + 1].  The problems are independent (each reads its own layer's g and input, which the stack keeps
 // alive until the flush), so a dozen 8-23 us launches — each with its own cold start — become one that fills the GPU.
@@ -434,7 +544,15 @@ __global__ __launch_bounds__(256) void pv_k1_wgrad_table_kernel(K1Tab t) {
   int k = 0;
   while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
   const int blk = (int)blockIdx.x - t.blk0[k];
-  if (t.e[k].fat) {
+  if (t.e[k].fat == 2) {
+    const int key = t.e[k].taps * 100 + t.e[k].mj * 10 + t.e[k].nj;
+    if (key == 342) k1_wgrad_wide_body<3, 4, 2>(t.e[k], blk, lds);
+    else if (key == 324) k1_wgrad_wide_body<3, 2, 4>(t.e[k], blk, lds);
+    else if (key == 322) k1_wgrad_wide_body<3, 2, 2>(t.e[k], blk, lds);
+    else if (key == 142) k1_wgrad_wide_body<1, 4, 2>(t.e[k], blk, lds);
+    else if (key == 124) k1_wgrad_wide_body<1, 2, 4>(t.e[k], blk, lds);
+    else k1_wgrad_wide_body<1, 2, 2>(t.e[k], blk, lds);
+  } else if (t.e[k].fat) {
     if (t.e[k].taps == 3) k1_wgrad_fat_body<3>(t.e[k], blk, lds);
     else k1_wgrad_fat_body<1>(t.e[k], blk, lds);
   } else {
@@ -490,6 +608,26 @@ static int k1_wgrad_launch(const float* g, const float* in, int64_t rows, int L,
       a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
       a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
       a.nblk = a.mtiles * a.ntiles * a.nsplit;
+      // the wide form where the channel counts are whole tiles of it (PV_K1_NOWIDE=1 in the experiments build: the fat form)
+      static const int wide_env = pv_exp_int("PV_K1_NOWIDE", 0) ? 0 : 1;
+      int mj = 0, nj = 0;
+      if (Co % 64 == 0 && Ci % 32 == 0) { mj = 4; nj = 2; }
+      else if (Co % 32 == 0 && Ci % 64 == 0) { mj = 2; nj = 4; }
+      else if (Co % 32 == 0 && Ci % 32 == 0) { mj = 2; nj = 2; }
+      if (wide_env && mj && (taps == 1 || taps == 3)) {
+        const int wbw = taps == 3 ? (nj == 4 ? 16 : 32) : 64;          // (K1Wide::WB)
+        static const int wideb = pv_exp_int("PV_K1_WIDEB", 1);          // register batches per wave
+        const int nbq = wideb >= 1 && wideb <= 16 ? wideb : 1;
+        int64_t nsw = (rows + 4 * nbq * wbw - 1) / (4 * nbq * wbw);
+        if (nsw > k1_wg_splits(rows, Ci, Co, taps)) nsw = k1_wg_splits(rows, Ci, Co, taps);   // (ws is sized for the lean form's count)
+        if (nsw < 1) nsw = 1;
+        a.fat = 2; a.mj = mj; a.nj = nj;
+        a.mtiles = Co / (16 * mj); a.ntiles = Ci / (16 * nj);
+        a.chunk = ((rows + nsw - 1) / nsw + 4 * wbw - 1) / (4 * wbw) * (4 * wbw);
+        a.nsplit = (int)((rows + a.chunk - 1) / a.chunk);
+        a.part_b = db ? a.part + (int64_t)a.nsplit * Co * Ci * taps : nullptr;
+        a.nblk = a.mtiles * a.ntiles * a.nsplit;
+      }
     }
     defer->k1b->e[defer->k1b->n++] = a;
   } else {
@@ -508,6 +646,7 @@ int pv_k1_wgrad_flush(PvK1Batch* b, hipStream_t s) {
   t.blk0[b->n] = tot;
   b->n = 0;
   if (tot < 1) return 0;
+  if (pv_exp_int("PV_K1_SKIP", 0)) return 0;          // (experiments build: what would the step cost without this launch?  wrong gradients)
   hipLaunchKernelGGL(pv_k1_wgrad_table_kernel, dim3((unsigned)tot), dim3(256), 0, s, t);
   PV_LAUNCH_CHECK();
   return 0;

@@ -1316,7 +1316,11 @@ static int sw_splits(int B, int H, int W, int C, int Cout, int nsp) {
   const int ciw = (nsp == 2 && C % 64 == 0) ? 64 : 32;           // input channels per workgroup (three planes: 32, for the LDS)
   const int64_t owners = (int64_t)(C / ciw) * ((Cout + 63) / 64);
   static const int wg_target = pv_exp_int("PV_SW_WGS", 512);
-  int64_t ns = (wg_target + owners - 1) / owners;                // two workgroups per CU in all
+  // the one-piece form (conv mode 4's weight gradient) runs NEXT TO the input-gradient chain on the side stream: 320 workgroups
+  // leave that chain more of the chip and write 5/8 of the partials (round 5, `gpurun_out/r05al`, `r05am`, two boxes: VED at batch
+  // 256 0.7755 -> 0.7589 ms, conv-encoder iVAE at batch 128 0.7611 -> 0.7508; 256 / 288 / 352 / 384 / 448 in between or worse)
+  static const int wg_target1 = pv_exp_int("PV_SW_WGS1", 320);
+  int64_t ns = ((nsp == 1 ? wg_target1 : wg_target) + owners - 1) / owners;   // (512: two workgroups per CU in all)
   // ... but never fewer than 12 tiles per split: below that a split's fixed costs (its partial-sum block of the finish launch,
   // its prologue) outweigh the parallelism (round 5, `gpurun_out/r05ab3`: conv-encoder iVAE at batch 128 0.836 -> 0.826 ms
   // fp32-class, 0.562 -> 0.545 at the throughput precision; VED at batch 256 — 8+ tiles per split already — unchanged)

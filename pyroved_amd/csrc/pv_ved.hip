@@ -378,9 +378,13 @@ extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void*
   if (L.head_wt) {
     // dL/d(features) straight in channels-last order, with the last convolution's activation derivative folded in
     const bool fold = last.kind == PV_OP_CONV && last.act != PV_ACT_GELU;
+    // the head's weight gradient needs dhead only: when the decoder's backward launch wrote it (the side streams already wait for
+    // that launch) it runs on the side stream next to the input gradient below instead of in front of it on the chain
+    static const int head_side_env = pv_exp_int("PV_VED_HEAD_SIDE", 1);
+    hipStream_t hs = (two && head_done && head_side_env && !pv_convhead_wgrad_uses_ws()) ? side : s;
     PV_TRY(pv_convhead_wgrad(L.dhead, L.ea[p->n_enc_ops], p->grads + p->head.w_off,
                              p->head.b_off >= 0 ? p->grads + p->head.b_off : nullptr, (int)B, fe.H * fe.W, fe.C, (int)(2 * z),
-                             L.sc.ws, L.sc.ws_bytes, s));
+                             L.sc.ws, L.sc.ws_bytes, hs));
     g = L.g[pp];
     if (two) pv_fork_arm();                            // (the last convolution's weight gradient forks off this launch)
     PV_TRY(pv_convhead_bwd(L.dhead, L.head_wt, L.ea[p->n_enc_ops], fold ? last.act : PV_ACT_NONE, g, (int)B, L.F, (int)(2 * z), s));
