@@ -512,6 +512,14 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
       else pv_fork_disarm();
       PV_TRY(pv_convhead_wgrad(L.dhead, L.cea[p->n_enc_ops], G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, (int)B,
                                fe.H * fe.W, fe.C, hd.out_dim, ws, wsb, hs));
+      // ... and so do the small weight gradients the caller hands over (fc_latent's: they need the latent-backward launch's
+      // results only) with the loss scalars riding: behind the head's on the side stream instead of at the very end of the step.
+      // The optimizer update is then a launch of its own after the last reduction (round 5: the closing launch 13.6 -> ~6 us).
+      static const int ab_early = pv_exp_int("PV_EXTRA_EARLY", 1);
+      if (ab_early && hs == side && side && n_extra > 0 && n_extra <= 4) {
+        PV_TRY(pv_wgrad_small(extra, n_extra, side, nullptr, fin));
+        n_extra = 0; fin = nullptr;
+      }
       if (side) pv_fork_arm();                                        // (the last convolution's weight gradient forks off this launch)
       PV_TRY(pv_convhead_bwd(L.dhead, L.chead_wt, L.cea[p->n_enc_ops], g_is_pre ? last.act : PV_ACT_NONE, L.cg[1], (int)B, L.cF,
                              hd.out_dim, s));
