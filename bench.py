@@ -87,7 +87,13 @@ if os.path.exists(_traffic_file):
     except Exception:
         pass
 
-EV_EVERY = 8
+EV_EVERY = 8                     # (N > 1: the all-reduce's torch events, every EV_EVERY-th step)
+EV_PER_REGION = 2                # decoder / conv launches carrying HIP events per timed region (a launch with events costs the stream
+                                 # ~11 us: profiles/r05ay_region_profile.txt); the measured regions' samples are pooled
+PREROLL_MS, PREROLL_MAX = 10.0, 100   # untimed steps enqueued right in front of every timed region's opening synchronisation: ~10 ms of
+                                 # them (at most 100; counted from the first region's step time, the same on every rank).  A 20-step
+                                 # region is 2 ms — after the idle gap between regions it ran at a colder GPU's clocks (decoder
+                                 # launch 87.8 vs 85.6 us, step 0.1091 vs 0.1049 ms); a training run is not 20 steps long
 
 
 class HipEvents:
@@ -275,10 +281,13 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
     n_eps = args.warmup + 2 * args.steps               # noise ring (the first warmup + steps draws are the seeded stream)
     torch.manual_seed(1)
     eps_all = torch.empty(n_eps, world, B, model.z_dim).normal_()[:, rank].contiguous().to(dev)
-    n_ev = (args.steps + EV_EVERY - 1) // EV_EVERY
-    events = HipEvents(n_ev)                            # re-recorded every region: the last measured region's samples are read
+    ev_every = max(1, (args.steps + EV_PER_REGION - 1) // EV_PER_REGION)
+    n_ev = (args.steps + ev_every - 1) // ev_every
+    events = HipEvents(n_ev * R)                        # one set per measured region (warm-up regions re-record set 0)
     conv = cfg["kind"] in ("ved", "ivae_conv")
-    cevents = HipEvents(n_ev) if conv else None
+    cevents = HipEvents(n_ev * R) if conv else None
+    preroll_env = os.environ.get("PV_BENCH_PREROLL")            # (experiments: a fixed count)
+    preroll_n = [int(preroll_env) if preroll_env is not None else 0]   # set after the first region (its step time is the estimate)
     cflops = C.c_double(0.0)
     arev = TorchEvents()
     hist = torch.zeros(n_eps, 4, device=dev)
@@ -331,16 +340,26 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
     torch.cuda.synchronize()
     losses_head = hist[:, 0].cpu().clone()             # (steps 0 .. warmup-1 of the seeded stream; later slots are reused)
 
-    def region(base):
+    first_after = {"t": None}                           # loss of the first step after the warm-up (= step 0 when --warmup 0)
+
+    def note_first(i):
+        if first_after["t"] is None:
+            first_after["t"] = hist[i % n_eps, 0].clone()
+
+    def region(base, slot=0):
+        for i in range(preroll_n[0]):                   # (untimed; the noise ring wraps, the optimizer state moves on)
+            step(base + i)
+            note_first(base + i)
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            sample = i % EV_EVERY == 0
-            j = i // EV_EVERY
+            sample = i % ev_every == 0
+            j = slot * n_ev + i // ev_every
             step(base + i, events.pairs[j] if sample else None, cevents.pairs[j] if (sample and conv) else None,
-                 True if (sample and world > 1) else None)
+                 True if (i % EV_EVERY == 0 and world > 1) else None)
+            note_first(base + i)
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
@@ -351,6 +370,8 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
 
     all_regions, base = [], args.warmup
     first = region(base)
+    if preroll_env is None:                             # (max over ranks already: the same count everywhere)
+        preroll_n[0] = max(0, min(PREROLL_MAX, int(PREROLL_MS * 1e-3 / max(first / args.steps, 1e-9) + 0.999)))
     losses_first = hist[:, 0].cpu().clone()            # slot `warmup` = the first timed step
     all_regions.append(first)
     base += args.steps
@@ -364,13 +385,14 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
     discarded = len(all_regions) - 1                   # the last converged region is the first measured one
     regions = [all_regions[-1]]
     arev.pairs.clear()
-    for _ in range(R - 1):
-        regions.append(region(base))
+    for k_ in range(R - 1):
+        regions.append(region(base, k_ + 1))
         base += args.steps
     torch.cuda.synchronize()
     return dict(regions=regions, discarded=discarded, all_regions=all_regions + regions[1:],
                 kms=events.elapsed_ms() if not ved else [], cms=cevents.elapsed_ms() if conv else [],
                 conv_flops=cflops.value, ar_ms=arev.elapsed_ms(), losses_head=losses_head, losses_first=losses_first,
+                first_after_warmup=first_after["t"].item(), preroll=preroll_n[0], ev_samples_per_region=n_ev,
                 last_loss=hist[(base - 1) % n_eps, 0].item(), eng=eng, model=model)
 
 
@@ -438,7 +460,8 @@ def measure(args, name, cfg, fused, ctx, attrs=None):
            "regions_discarded": r["discarded"],
            "ms_per_step_warming": [1e3 * v / args.steps for v in r["all_regions"][:r["discarded"]]],
            "value": args.steps * B * world / med,
-           "loss_per_image_step0": r["losses_head"][0].item() / (B * world) if args.warmup > 0 else r["losses_first"][0].item() / (B * world),
+           "loss_per_image_step0": (r["losses_head"][0].item() if args.warmup > 0 else r["first_after_warmup"]) / (B * world),
+           "preroll_steps": r["preroll"], "kernel_event_samples_per_region": r["ev_samples_per_region"],
            "loss_per_image_first_timed_step": r["losses_first"][args.warmup].item() / (B * world),
            "loss_per_image_last_step": r["last_loss"] / (B * world)}
     if world > 1 and r["ar_ms"]:
@@ -683,6 +706,13 @@ def main():
                        "parallelism": "dp%d" % world, "path": main_leg["path"], "baseline_config": name},
             "repeats": len(main_leg["regions_s"]), "ms_per_step_all": main_leg["ms_per_step_all"],
             "regions_discarded": main_leg["regions_discarded"], "ms_per_step_warming": main_leg["ms_per_step_warming"],
+            "timing": {"preroll_steps": main_leg["preroll_steps"],
+                       "kernel_event_samples_per_region": main_leg["kernel_event_samples_per_region"],
+                       "note": "every timed region (exactly --steps steps between two synchronisations) is preceded by "
+                               "preroll_steps untimed steps (~10 ms of them, at most 100; none before the first, discarded region) enqueued "
+                               "back to back: after the idle gap between regions a 2 ms region ran at a colder GPU's clocks (step 0.1091 vs 0.1049 ms, profiles/r05ay_*); launches "
+                               "carrying HIP events cost the stream ~11 us each, so two per region are sampled and the "
+                               "measured regions' samples pooled"},
             "ms_per_step_spread": (max(main_leg["ms_per_step_all"]) - min(main_leg["ms_per_step_all"])),
             "roofline": main_leg["roofline"],
             "step_algorithmic_tflops": main_leg.get("step_algorithmic_tflops"),
