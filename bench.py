@@ -88,8 +88,8 @@ if os.path.exists(_traffic_file):
         pass
 
 EV_EVERY = 8                     # (N > 1: the all-reduce's torch events, every EV_EVERY-th step)
-EV_PER_REGION = 2                # decoder / conv launches carrying HIP events per timed region (a launch with events costs the stream
-                                 # ~11 us: profiles/r05ay_region_profile.txt); the measured regions' samples are pooled
+EV_PER_REGION = 1                # decoder / conv launches carrying HIP events per timed region, taken mid-region (a launch with events
+                                 # costs the stream ~11 us: profiles/r05ay_bench_region_timing.txt); the measured regions' samples are pooled
 PREROLL_MS, PREROLL_MAX = 10.0, 100   # untimed steps enqueued right in front of every timed region's opening synchronisation: ~10 ms of
                                  # them (at most 100; counted from the first region's step time, the same on every rank).  A 20-step
                                  # region is 2 ms — after the idle gap between regions it ran at a colder GPU's clocks (decoder
@@ -281,8 +281,8 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
     n_eps = args.warmup + 2 * args.steps               # noise ring (the first warmup + steps draws are the seeded stream)
     torch.manual_seed(1)
     eps_all = torch.empty(n_eps, world, B, model.z_dim).normal_()[:, rank].contiguous().to(dev)
-    ev_every = max(1, (args.steps + EV_PER_REGION - 1) // EV_PER_REGION)
-    n_ev = (args.steps + ev_every - 1) // ev_every
+    n_ev = max(1, min(EV_PER_REGION, args.steps))
+    ev_at = {min(args.steps - 1, int((2 * j_ + 1) * args.steps / (2 * n_ev))): j_ for j_ in range(n_ev)}   # step index -> sample slot
     events = HipEvents(n_ev * R)                        # one set per measured region (warm-up regions re-record set 0)
     conv = cfg["kind"] in ("ved", "ivae_conv")
     cevents = HipEvents(n_ev * R) if conv else None
@@ -355,8 +355,8 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            sample = i % ev_every == 0
-            j = slot * n_ev + i // ev_every
+            sample = i in ev_at
+            j = slot * n_ev + ev_at.get(i, 0)
             step(base + i, events.pairs[j] if sample else None, cevents.pairs[j] if (sample and conv) else None,
                  True if (i % EV_EVERY == 0 and world > 1) else None)
             note_first(base + i)
@@ -711,8 +711,8 @@ def main():
                        "note": "every timed region (exactly --steps steps between two synchronisations) is preceded by "
                                "preroll_steps untimed steps (~10 ms of them, at most 100; none before the first, discarded region) enqueued "
                                "back to back: after the idle gap between regions a 2 ms region ran at a colder GPU's clocks (step 0.1091 vs 0.1049 ms, profiles/r05ay_*); launches "
-                               "carrying HIP events cost the stream ~11 us each, so two per region are sampled and the "
-                               "measured regions' samples pooled"},
+                               "carrying HIP events cost the stream ~11 us each, so one launch per region (mid-region) is sampled and "
+                               "the measured regions' samples pooled"},
             "ms_per_step_spread": (max(main_leg["ms_per_step_all"]) - min(main_leg["ms_per_step_all"])),
             "roofline": main_leg["roofline"],
             "step_algorithmic_tflops": main_leg.get("step_algorithmic_tflops"),
