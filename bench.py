@@ -767,8 +767,8 @@ def main():
         if world > 1:
             # what DESIGN.md section 6 expects on 8 GPUs of one node (no hardware run before round 4): the driver computes the
             # measured x from its own per-N runs; these are the predictions to hold them against
-            out["expected_x8"] = {"c2_weak": "5.3-6.0 (one all-reduce of 0.6 MB per 0.13 ms step: latency-bound on xGMI)",
-                                  "c5_weak": "~7.4 (2.8 MB per 0.75-0.9 ms step)", "c2_strong": "1.3-1.6 (latency-bound by design)"}
+            out["expected_x8"] = {"c2_weak": "5.1-5.8 (one all-reduce of 0.6 MB, ~30-50 us + hand-offs, per 0.104 ms step: latency-bound on xGMI)",
+                                  "c5_weak": "~7.4 (2.3 MB per 0.73-0.77 ms step)", "c2_strong": "1.3-1.6 (latency-bound by design)"}
         if world == 1 and not args.no_cpu_baseline:
             cb, loss0 = cpu_baseline(name, cfg)
             out["cpu_baseline"] = cb
