@@ -55,10 +55,15 @@ __global__ void pv_convhead_fwd_finish_kernel(const float* __restrict__ part, co
   head[e] = v;
 }
 
+// g[b][f] = (sum_j dhead[b][j] wt[j][f]) * act'(y[b][f]).  A thread owns one float4 column i of f and walks CH_NB samples: its OUT
+// weight float4 stay in registers (round 5: one sample per thread re-read the whole (out x F) matrix from L2 for every sample —
+// 50 MB at the conv-encoder iVAE's batch 128 — behind a 64-bit division per thread: 17-21 us for 8 MB of useful traffic)
+// (heads of <= 4 outputs keep the round-3 form below: at VED's batch 256 the faster kernel made the STEP 0.7-1.2 % slower on every
+//  A/B — the encoder's first weight gradient forks off this launch and then shares more of the input-gradient chain's time)
 template <int OUT>
-__global__ __launch_bounds__(256) void pv_convhead_bwd_kernel(const float* __restrict__ dhead, const float* __restrict__ wt,
-                                                              const float* __restrict__ y, int act, float* __restrict__ g,
-                                                              int B, int64_t F, int out) {
+__global__ __launch_bounds__(256) void pv_convhead_bwd1_kernel(const float* __restrict__ dhead, const float* __restrict__ wt,
+                                                               const float* __restrict__ y, int act, float* __restrict__ g,
+                                                               int B, int64_t F, int out) {
   const int64_t F4 = F / 4, total = (int64_t)B * F4;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t b = e / F4, i = e - b * F4;
@@ -72,6 +77,38 @@ __global__ __launch_bounds__(256) void pv_convhead_bwd_kernel(const float* __res
       for (int k = 0; k < 4; ++k) v[k] *= pv_act_grad(yy[k], 0.0f, act);
     }
     reinterpret_cast<f32x4*>(g)[e] = v;
+  }
+}
+template <int OUT, int CH_NB>
+__global__ __launch_bounds__(256) void pv_convhead_bwd_kernel(const float* __restrict__ dhead, const float* __restrict__ wt,
+                                                              const float* __restrict__ y, int act, float* __restrict__ g,
+                                                              int B, int64_t F, int out) {
+  const int64_t F4 = F / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= F4) return;
+  f32x4 w[OUT];
+#pragma unroll
+  for (int j = 0; j < OUT; ++j) w[j] = j < out ? reinterpret_cast<const f32x4*>(wt + (int64_t)j * F)[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int b0 = (int)blockIdx.y * CH_NB;
+  f32x4 yy[CH_NB];
+  if (act != PV_ACT_NONE) {
+#pragma unroll
+    for (int k = 0; k < CH_NB; ++k)
+      if (b0 + k < B) yy[k] = reinterpret_cast<const f32x4*>(y)[(int64_t)(b0 + k) * F4 + i];
+  }
+#pragma unroll
+  for (int k = 0; k < CH_NB; ++k) {
+    const int b = b0 + k;
+    if (b >= B) break;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < OUT; ++j)
+      if (j < out) v += dhead[(int64_t)b * out + j] * w[j];
+    if (act != PV_ACT_NONE) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] *= pv_act_grad(yy[k][c], 0.0f, act);
+    }
+    reinterpret_cast<f32x4*>(g)[(int64_t)b * F4 + i] = v;
   }
 }
 
@@ -156,12 +193,19 @@ int pv_convhead_fwd(const float* a, const float* wt, const float* bias, float* h
 int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act, float* g, int B, int64_t F, int out,
                     hipStream_t s) {
   if (!pv_convhead_supported(F, out) || act == PV_ACT_GELU) return PV_EINVAL;
-  int64_t nb = ((int64_t)B * (F / 4) + 255) / 256;
-  if (nb > 16384) nb = 16384;
   // (the encoder's last weight gradient waits for this launch on the side stream: it carries the fork event when one is armed)
-  if (out <= 4) PV_LAUNCH_FORK(pv_convhead_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
-  else if (out <= 8) PV_LAUNCH_FORK(pv_convhead_bwd_kernel<8>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
-  else PV_LAUNCH_FORK(pv_convhead_bwd_kernel<16>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+  if (out <= 4) {
+    int64_t nb = ((int64_t)B * (F / 4) + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    PV_LAUNCH_FORK(pv_convhead_bwd1_kernel<4>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+    PV_LAUNCH_CHECK();
+    return 0;
+  }
+  const int nbs = 4;                                   // samples per thread
+  const dim3 grid((unsigned)((F / 4 + 255) / 256), (unsigned)((B + nbs - 1) / nbs));
+  if (grid.y > 65535) return PV_EINVAL;
+  if (out <= 8) PV_LAUNCH_FORK((pv_convhead_bwd_kernel<8, 4>), grid, dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+  else PV_LAUNCH_FORK((pv_convhead_bwd_kernel<16, 4>), grid, dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
   PV_LAUNCH_CHECK();
   return 0;
 }
