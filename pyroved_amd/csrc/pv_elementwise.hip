@@ -90,27 +90,47 @@ int pv_head_fwd(const PvHead& h, hipStream_t s) {
 // launch: the conv head's partial sums (pv_convhead_fwd_finish_kernel's order), then head_fwd, then fc_latent
 // (pv_smallk_linear_kernel's sum).  The KL sums leave as per-workgroup partials (kl_part), like the compact encoder's.
 #define HB_ROWS 16
+// (round 5: the launch is a chain of dependent round trips — it ran 13 us for 128 samples.  The conv head's partial sums are requested
+//  eight at a time (the same additions in the same order), the noise before the head exists, and the head / z values a later
+//  phase of the same workgroup needs pass through LDS instead of being read back from global memory.)
 __global__ __launch_bounds__(256) void pv_head_fwd_blocks_kernel(PvHead h) {
   __shared__ float sm[16];
+  __shared__ float s_head[HB_ROWS * 64];            // [row][<= 64 head outputs] when the conv head is finished here (ch_out <= 64)
+  __shared__ float s_z[HB_ROWS * 32];               // [row][<= 32 latent coordinates]
   const int b0 = (int)blockIdx.x * HB_ROWS, nb = min(HB_ROWS, h.B - b0), t = threadIdx.x;
   const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
+  const bool lds_head = h.ch_part && h.ch_out <= 64 && h.head == h.head_w, lds_z = h.z_dim <= 32;
+  // the first sample element's noise: requested in front of the partial sums' round trips
+  float eps0 = 0.0f;
+  if (t < nb * h.z_dim) eps0 = h.eps[(int64_t)b0 * h.z_dim + t];
   if (h.ch_part) {
     for (int e = t; e < nb * h.ch_out; e += 256) {
-      const int b = b0 + e / h.ch_out, j = e % h.ch_out;
+      const int r = e / h.ch_out, b = b0 + r, j = e % h.ch_out;
       float v = h.ch_bias ? h.ch_bias[j] : 0.0f;
-      for (int k = 0; k < h.ch_nseg; ++k) v += h.ch_part[((int64_t)b * h.ch_nseg + k) * h.ch_out + j];
+      const float* pp = h.ch_part + (int64_t)b * h.ch_nseg * h.ch_out + j;
+      int k = 0;
+      for (; k + 8 <= h.ch_nseg; k += 8) {
+        float p8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p8[u] = pp[(int64_t)(k + u) * h.ch_out];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += p8[u];
+      }
+      for (; k < h.ch_nseg; ++k) v += pp[(int64_t)k * h.ch_out];
       h.head_w[(int64_t)b * h.ch_out + j] = v;
+      if (lds_head) s_head[r * 64 + j] = v;
     }
     __syncthreads();
   }
   float lp = 0.0f, lq = 0.0f;
   for (int el = t; el < nb * h.z_dim; el += 256) {
-    const int b = b0 + el / h.z_dim, i = el % h.z_dim;
+    const int r = el / h.z_dim, b = b0 + r, i = el % h.z_dim;
     const int64_t e = (int64_t)b * h.z_dim + i;
-    const float mu = h.head[(int64_t)b * ldh + i];
-    const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
+    const float mu = lds_head ? s_head[r * 64 + i] : h.head[(int64_t)b * ldh + i];
+    const float sp = lds_head ? s_head[r * 64 + h.z_dim + i] : h.head[(int64_t)b * ldh + h.z_dim + i];
     const float sig = h.scale_direct ? sp : pv_softplus(sp);
-    const float z = mu + sig * h.eps[e];
+    const float z = mu + sig * (el == t ? eps0 : h.eps[e]);
+    if (lds_z) s_z[r * 32 + i] = z;
     h.z[e] = z;
     h.z_scale[e] = sig;
     if (h.z_loc_out) h.z_loc_out[e] = mu;
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(256) void pv_head_fwd_blocks_kernel(PvHead h) {
   __syncthreads();
   if (t < nb) {
     const int b = b0 + t;
-    const float* zb = h.z + (int64_t)b * h.z_dim;
+    const float* zb = lds_z ? s_z + t * 32 : h.z + (int64_t)b * h.z_dim;
     int idx = 0;
     float c = 1.0f, s = 0.0f, sc = 1.0f, tx = 0.0f, ty = 0.0f;
     if (h.coord_dim == 1) {
@@ -149,10 +169,17 @@ __global__ __launch_bounds__(256) void pv_head_fwd_blocks_kernel(PvHead h) {
   }
   if (h.hz) {
     __syncthreads();
+    // (the decoder's latent input is a slice of z where no class vector is concatenated: from LDS then)
+    const int64_t zo = h.zin - h.z;
+    const bool z_lds = lds_z && zo >= 0 && zo + h.lat_in <= h.z_dim && h.ldz == h.z_dim;
     for (int e = t; e < nb * h.H; e += 256) {
-      const int b = b0 + e / h.H, j = e % h.H;
+      const int r = e / h.H, b = b0 + r, j = e % h.H;
       float v = 0.0f;
-      for (int k = 0; k < h.lat_in; ++k) v = fmaf(h.zin[(int64_t)b * h.ldz + k], h.Wz[(int64_t)j * h.lat_in + k], v);
+      if (z_lds) {
+        for (int k = 0; k < h.lat_in; ++k) v = fmaf(s_z[r * 32 + (int)zo + k], h.Wz[(int64_t)j * h.lat_in + k], v);
+      } else {
+        for (int k = 0; k < h.lat_in; ++k) v = fmaf(h.zin[(int64_t)b * h.ldz + k], h.Wz[(int64_t)j * h.lat_in + k], v);
+      }
       h.hz[(int64_t)b * h.H + j] = v;
     }
   }
