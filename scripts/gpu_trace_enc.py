@@ -5,10 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pyroved_amd as pv
 from pyroved_amd import _abi
-model = pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
-eng = model.engine(fused=3)
-x = torch.rand(256, 28, 28, generator=torch.Generator().manual_seed(0)).cuda()
-eps = torch.randn(256, model.z_dim).cuda()
+import sys as _s
+SH = (64, 64) if len(_s.argv) > 1 and _s.argv[1] == "c4fc" else (28, 28)
+BB = 128 if SH[0] == 64 else 256
+model = pv.models.iVAE(SH, 2, ["r", "t", "s"] if SH[0] == 64 else ["r", "t"], seed=1, device="cuda")
+eng = model.engine(fused=2 if SH[0] == 64 else 3)
+eng.enc_fold = False
+x = torch.rand(BB, SH[0], SH[1], generator=torch.Generator().manual_seed(0)).cuda()
+eps = torch.randn(BB, model.z_dim).cuda()
 for _ in range(5):
     eng.loss_and_grads(x, eps)
 torch.cuda.synchronize()
