@@ -212,7 +212,14 @@ int pv_convhead_bwd(const float* dhead, const float* wt, const float* y, int act
   }
   const int nbs = 4;                                   // samples per thread
   const dim3 grid((unsigned)((F / 4 + 255) / 256), (unsigned)((B + nbs - 1) / nbs));
-  if (grid.y > 65535) return PV_EINVAL;
+  if (grid.y > 65535) {                                // (a batch beyond the grid's second dimension: the one-sample-per-thread form)
+    int64_t nb = ((int64_t)B * (F / 4) + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    if (out <= 8) PV_LAUNCH_FORK(pv_convhead_bwd1_kernel<8>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+    else PV_LAUNCH_FORK(pv_convhead_bwd1_kernel<16>, dim3((unsigned)nb), dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
+    PV_LAUNCH_CHECK();
+    return 0;
+  }
   if (out <= 8) PV_LAUNCH_FORK((pv_convhead_bwd_kernel<8, 4>), grid, dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
   else PV_LAUNCH_FORK((pv_convhead_bwd_kernel<16, 4>), grid, dim3(256), 0, s, dhead, wt, y, act, g, B, F, out);
   PV_LAUNCH_CHECK();
