@@ -53,6 +53,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# test hook: PV_BENCH_FORCE_DIST=1 initialises the process group and takes the multi-rank code path (sync, collective, barriers,
+# max-over-ranks timing) at WORLD_SIZE 1 — on a one-GPU box it is the only way the nccl (= RCCL) backend ever executes this file
+FORCE_DIST = bool(os.environ.get("PV_BENCH_FORCE_DIST"))
+COLLECTIVE = {"want": os.environ.get("PV_BENCH_COLLECTIVE", "native"), "used": None}
 N_RING = 16                      # distinct resident minibatches (n = 16 * B) for the 28x28 configs
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* f32-in peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -269,8 +273,22 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
         setattr(eng, k_, v_)
     if os.environ.get("PV_BENCH_CONV_X3") == "1":  # (A/B: the fp32-class convolutions with both operands split, rounds 2-4's form)
         eng.conv_x3 = True
-    if world > 1:
+    multi = world > 1 or FORCE_DIST                 # (FORCE_DIST: the multi-rank code path at world size 1 — test hook)
+    comm = None
+    if multi:
         pvdist.sync_replicas(eng)
+        # the step's one collective: ncclAllReduce enqueued by the LIBRARY on the compute stream (pv_ivae_dp_step / pv_ved_dp_step,
+        # ABI v16) on an RCCL communicator of this process; PV_BENCH_COLLECTIVE=torch: torch.distributed.all_reduce (its own
+        # stream + two event hand-offs per step) — also what a gloo run (the one-GPU test hook) uses
+        if COLLECTIVE["want"] == "native" and pvdist.native_available():
+            try:
+                comm = pvdist.native_comm(dev)
+                COLLECTIVE["used"] = "rccl-native (%s)" % os.path.basename(comm.library)
+            except Exception as e:                   # (a measurement harness must still produce its line: say so in it)
+                COLLECTIVE["used"] = "torch.distributed (native communicator failed: %s)" % repr(e)[:200]
+                comm = None
+        else:
+            COLLECTIVE["used"] = "torch.distributed"
     ring_n = cfg["ring"]
     gen = torch.Generator().manual_seed(0)
     # synthetic data, resident in HBM before the timed region.  Weak scaling: every rank owns B samples of each of the
@@ -292,7 +310,13 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
     arev = TorchEvents()
     hist = torch.zeros(n_eps, 4, device=dev)
     ved = cfg["kind"] == "ved"
-    one_call = world == 1 and not args.two_call and getattr(eng, "supports_step", False)
+    one_call = not multi and not args.two_call and getattr(eng, "supports_step", False)
+
+    def reduce_(t):
+        if comm is not None:
+            comm.allreduce_sum_(t)
+        else:
+            pvdist.allreduce_sum_(t)
 
     def step(i, ev=None, cev=None, ar=None):
         eng.events = ev if ev is not None else (None, None)
@@ -301,24 +325,30 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
         x = data[0][i % ring_n]
         if ar is not None:
             ar = arev.pair()
-        if ved:
-            eng.loss_and_grads(x, eps_all[k], 1.0, data[1][i % ring_n], scalars_out=hist[k] if world == 1 else None)
-            if world > 1:
-                if ar: ar[0].record()
-                pvdist.allreduce_sum_(eng.grad)
-                if ar: ar[1].record()
-                hist[k].copy_(eng.scalars)
-            eng.adam_step()
-        elif world > 1:
-            eng.loss_and_grads(x, eps_all[k])
+        if multi and comm is not None and not ar:
+            # the data-parallel step as ONE library call: shard gradients -> ncclAllReduce([grads | 4 scalars]) -> Adam + history
+            if ved:
+                eng.loss_and_grads(x, eps_all[k], 1.0, data[1][i % ring_n], step=True, comm=comm, hist_out=hist[k])
+            else:
+                eng.loss_and_grads(x, eps_all[k], step=True, comm=comm, hist_out=hist[k])
+        elif multi:
+            # (torch.distributed's collective, or a sampled step of the native one: the same three enqueues on the same stream as
+            #  three calls, with events around the collective)
+            if ved:
+                eng.loss_and_grads(x, eps_all[k], 1.0, data[1][i % ring_n])
+            else:
+                eng.loss_and_grads(x, eps_all[k])
             if ar: ar[0].record()
-            pvdist.allreduce_sum_(eng.grad)           # gradients + the 4 loss scalars in one collective
+            reduce_(eng.grad)                         # gradients + the 4 loss scalars in one collective
             if ar: ar[1].record()
             if hasattr(eng, "adam_step_hist"):
                 eng.adam_step_hist(hist[k])           # Adam + the history write in one launch; no host sync anywhere
             else:
                 hist[k].copy_(eng.scalars)
                 eng.adam_step()
+        elif ved:
+            eng.loss_and_grads(x, eps_all[k], 1.0, data[1][i % ring_n], scalars_out=hist[k])
+            eng.adam_step()
         elif one_call:
             # single process: SVI.step as ONE library call (pv_ivae_step: ELBO + gradients + Adam; bit-identical to
             # the two calls, tests/test_gpu_parity.py)
@@ -333,8 +363,8 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
         eng.loss_and_grads(data[0][0], eps_all[0], 1.0, data[1][0])
     else:
         eng.loss_and_grads(data[0][0], eps_all[0])
-    if world > 1:
-        pvdist.allreduce_sum_(torch.zeros_like(eng.grad))
+    if multi:
+        reduce_(torch.zeros_like(eng.grad))
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -350,7 +380,7 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
         for i in range(preroll_n[0]):                   # (untimed; the noise ring wraps, the optimizer state moves on)
             step(base + i)
             note_first(base + i)
-        if world > 1:
+        if multi:
             td.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -358,13 +388,13 @@ def _run(args, cfg, fused, pv, pvdist, td, dev, rank, world, B, attrs=None):
             sample = i in ev_at
             j = slot * n_ev + ev_at.get(i, 0)
             step(base + i, events.pairs[j] if sample else None, cevents.pairs[j] if (sample and conv) else None,
-                 True if (i % EV_EVERY == 0 and world > 1) else None)
+                 True if (i % EV_EVERY == 0 and multi) else None)
             note_first(base + i)
-        if world > 1:
+        if multi:
             td.barrier()
         torch.cuda.synchronize()
         t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             td.all_reduce(t, op=td.ReduceOp.MAX)
         return t.item()
 
@@ -464,7 +494,8 @@ def measure(args, name, cfg, fused, ctx, attrs=None):
            "preroll_steps": r["preroll"], "kernel_event_samples_per_region": r["ev_samples_per_region"],
            "loss_per_image_first_timed_step": r["losses_first"][args.warmup].item() / (B * world),
            "loss_per_image_last_step": r["last_loss"] / (B * world)}
-    if world > 1 and r["ar_ms"]:
+    if (world > 1 or FORCE_DIST) and r["ar_ms"]:
+        out["collective"] = COLLECTIVE["used"]
         out["allreduce_ms"] = sum(r["ar_ms"]) / len(r["ar_ms"])
         out["allreduce_ms_samples"] = len(r["ar_ms"])
         # one bucket, issued after the step's last gradient launch and followed by Adam: nothing runs beside it on this rank,
@@ -648,7 +679,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as td
-    if world > 1:
+    if world > 1 or FORCE_DIST:
+        if FORCE_DIST:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             td.init_process_group("nccl", device_id=dev)
         else:
@@ -719,7 +753,7 @@ def main():
             "elbo": {k: main_leg[k] for k in ("loss_per_image_first_timed_step", "loss_per_image_last_step",
                                               "loss_per_image_step0")},
         }
-        for k in ("roofline_conv", "roofline_step", "allreduce_ms", "allreduce_ms_samples", "allreduce_exposed_ms"):
+        for k in ("roofline_conv", "roofline_step", "allreduce_ms", "allreduce_ms_samples", "allreduce_exposed_ms", "collective"):
             if k in main_leg:
                 out[k] = main_leg[k]
         # driver-visible scalars inside `roofline` (a key the driver's record keeps): the step-level fraction of the lead leg and
@@ -827,7 +861,7 @@ def main():
         print("BENCH-SUMMARY " + json.dumps({"value": round(out["value"]), "ms_per_step": round(out["ms_per_step"], 5),
                                              "kernel_ms": out["roofline"].get("kernel_ms"), "frac": out["roofline"].get("frac"),
                                              **summ}), file=sys.stderr)
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         td.destroy_process_group()
 
 

@@ -28,11 +28,12 @@
 extern "C" {
 #endif
 
-#define PV_ABI_VERSION 15
+#define PV_ABI_VERSION 16
 
 /* error codes (negative; positive values are hipError_t) */
 #define PV_EINVAL   (-1)   /* bad argument / unsupported configuration */
 #define PV_EWS      (-2)   /* workspace too small */
+#define PV_ECOLL    (-3)   /* (v16) the collective library (RCCL) could not be loaded or returned an error */
 
 /* activations: utils/nn.py:118-124 (get_activation) + the output sigmoid */
 enum pv_act {
@@ -316,6 +317,31 @@ int pv_ivae_guide_backward(const pv_ivae_plan* plan, int want_grads, void* strea
  * so plan->grads holds the zeroed gradients of pyro's zero_grads afterwards.  Needs adam_m / adam_v / adam_step. */
 int pv_ivae_step(const pv_ivae_plan* plan, void* stream);
 
+/* ---- (v16) the data-parallel step with its collective INSIDE the library --------------------------------------------------
+ * The reference has no distributed code.  What is sharded is trainers/svi.py:104-113 (`self.svi.step(x)` per
+ * minibatch): the loss is a SUM over the data plate (models/ivae.py:177,215), so every replica computes its contiguous slice of
+ * the global minibatch and the global gradient is ONE all-reduce(SUM) of [flat gradient | 4 loss scalars] (SURVEY section 8b,
+ * "Collective boundary": "a direct ncclAllReduce through the same C layer"; section 8e).
+ *
+ * RCCL is not a link dependency.  pv_dist_load(path) resolves ncclAllReduce & co. in the RCCL shared object the CALLER's process
+ * already holds (NULL / "": the loaded "librccl.so.1" / "librccl.so", else the default search path) — once per process; a second
+ * call naming another library is PV_EINVAL.  The communicator (ncclComm_t, created by the caller with ncclCommInitRank of that
+ * same library for the device of `stream`) is handed in as an opaque pointer; the library never creates, keeps or destroys one.
+ * Every entry point only ENQUEUES on `stream` (no second stream, no event, no host synchronisation): capturable in a hipGraph. */
+int pv_dist_load(const char* rccl_path);
+/* the path pv_dist_load resolved ("" before a successful load) */
+const char* pv_dist_library(void);
+/* rank / size of a communicator (ncclCommUserRank / ncclCommCount) — lets a caller check what it hands in */
+int pv_dist_comm_info(void* comm, int32_t* rank, int32_t* world);
+/* in-place fp32 SUM over the communicator's ranks of buf[0, n) (ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum)) on `stream` */
+int pv_dist_allreduce_sum(void* comm, float* buf, int64_t n, void* stream);
+/* SVI.step of one replica as ONE enqueue: pv_ivae_loss_and_grads on this rank's shard -> all-reduce(SUM) of
+ * plan->grads[0, n_params + 4) -> pv_adam_step_hist (Adam, zero_grads, the REDUCED loss scalars into hist_dst — 4 floats, may be
+ * NULL).  Needs plan->scalars == plan->grads + plan->n_params (the flat gradient buffer's trailing slots), the Adam fields as
+ * for pv_ivae_step, no external encoder / decoder.  Every replica must hold the same parameters and call it with the same
+ * adam_step; results equal the single-process step on the global minibatch up to the summation order of the shards' sums. */
+int pv_ivae_dp_step(const pv_ivae_plan* plan, void* comm, float* hist_dst, void* stream);
+
 /* baseVAE._encode inner call (models/base.py:131-135): encoder_z(x[,y]) ->
  * z_loc, z_scale (B, z_dim) each; jiVAE: also plan->alpha (B, discrete_dim) when not NULL. */
 int pv_ivae_encode(const pv_ivae_plan* plan, float* z_loc, float* z_scale, void* stream);
@@ -427,6 +453,10 @@ int pv_ved_encode(const pv_ved_plan* plan, float* z_loc, float* z_scale, void* s
 
 /* convDecoderNet.forward (nets/conv.py:95-102): loc (B, out_ch, *out_dim) for z (B, z_dim). */
 int pv_ved_decode(const pv_ved_plan* plan, const float* z, float* loc, void* stream);
+/* (v16) the data-parallel VED step as one enqueue (see pv_ivae_dp_step): pv_ved_loss_and_grads -> all-reduce(SUM) of
+ * plan->grads[0, n_params + 4) -> pv_adam_step_hist.  pv_ved_plan carries no optimizer fields: Adam's arrive as arguments. */
+int pv_ved_dp_step(const pv_ved_plan* plan, void* comm, float lr, float beta1, float beta2, float eps,
+                   int32_t adam_step, float* hist_dst, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * A stand-alone convolutional stack — nets/conv.py:150-262 FeatureExtractor.forward / Upsampler.forward outside a

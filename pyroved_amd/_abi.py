@@ -13,7 +13,7 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libamdhip64.so.7 the library binds to)
 
-PV_ABI_VERSION = 15
+PV_ABI_VERSION = 16
 # pv_ivae_plan.flags / pv_ved_plan.flags / pv_convnet_plan.flags
 PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM, PV_PLAN_ENC_NO_WAIT, PV_PLAN_NO_DEC1D, PV_PLAN_NO_ENC_FOLD = 1, 2, 4, 8, 16
 PV_PLAN_CONV_X3 = 64
@@ -147,6 +147,13 @@ SIGNATURES = {
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "pv_ivae_step": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p]),
+    "pv_dist_load": (C.c_int, [C.c_char_p]),
+    "pv_dist_library": (C.c_char_p, []),
+    "pv_dist_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pv_dist_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pv_ivae_dp_step": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pv_ved_dp_step": (C.c_int, [C.POINTER(pv_ved_plan), C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int32, C.c_void_p, C.c_void_p]),
     "pv_ivae_guide": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p]),
     "pv_ivae_guide_backward": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_int, C.c_void_p]),
     "pv_ivae_encode": (C.c_int, [C.POINTER(pv_ivae_plan), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -209,7 +216,7 @@ def lib():
 
 def check(code, what):
     if code != 0:
-        kind = "hipError_t" if code > 0 else {-1: "PV_EINVAL", -2: "PV_EWS"}.get(code, "PV error")
+        kind = "hipError_t" if code > 0 else {-1: "PV_EINVAL", -2: "PV_EWS", -3: "PV_ECOLL"}.get(code, "PV error")
         raise PvError("pyroved_amd: %s failed with %s (%d)" % (what, kind, code))
 
 

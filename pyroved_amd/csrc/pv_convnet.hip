@@ -27,8 +27,18 @@ struct NCarver {
   }
 };
 
+// the conv mode the stack runs with: the plan's, with mode 4 (the cheaper backward) size-gated exactly as in the iVAE and VED
+// plans (pv_convstack.h: conv_mode_for) — a direct ABI caller asking for 4 at a small batch gets the three-product backward
+static int net_conv_mode(const pv_convnet_plan* p) {
+  return pvcs::conv_mode_for(p->conv_bf16, p->ops, p->n_ops, p->ndim, p->batch, p->in_ch, p->in_dim);
+}
+
 bool ncarve(const pv_convnet_plan* p, char* base, NLayout& L) {
   if (!p || p->batch <= 0 || (p->ndim != 1 && p->ndim != 2) || p->in_ch < 1 || p->n_ops < 1 || p->n_ops > PV_MAX_OPS) return false;
+  // flags: only PV_PLAN_NO_SIDE_STREAM is defined for this plan, and it is what this entry point does anyway (every launch on
+  // the caller's stream); any other bit is a caller's mistake
+  if (p->flags & ~PV_PLAN_NO_SIDE_STREAM) return false;
+  const int cmode = net_conv_mode(p);
   NCarver c{base, 0};
   const int64_t B = p->batch;
   pvcs::Needs nd;
@@ -42,8 +52,8 @@ bool ncarve(const pv_convnet_plan* p, char* base, NLayout& L) {
   L.g[0] = c.take(nd.maxact); L.g[1] = c.take(nd.maxact);
   L.sc.col = c.take(nd.maxcol);
   L.sc.bn = c.take(pvcs::bn_floats(nd)); L.sc.bn_maxC = nd.bn_maxC; L.sc.bn_eval = p->bn_eval;
-  L.sc.conv_bf16 = p->conv_bf16;
-  pvcs::wt_layout(p->ops, p->n_ops, p->ndim, 0, p->conv_bf16, p->need_dx != 0, L.wtp);
+  L.sc.conv_bf16 = cmode;
+  pvcs::wt_layout(p->ops, p->n_ops, p->ndim, 0, cmode, p->need_dx != 0, L.wtp);
   L.wt = reinterpret_cast<char*>(c.take((L.wtp.bytes + 3) / 4));
   // (the fused first block has no input gradient: only when the caller will not ask for dL/dx)
   L.sc.code = (nd.code_bytes && !p->need_dx) ? reinterpret_cast<unsigned char*>(c.take((nd.code_bytes + 3) / 4)) : nullptr;
@@ -85,7 +95,7 @@ extern "C" int pv_convnet_forward(const pv_convnet_plan* p, const float* x, floa
   const Shape& s0 = L.sh[0];
   if (p->in_ch > 1) { PV_TRY(pv_ncs_to_nsc(x, L.x_nsc, B, p->in_ch, (int64_t)s0.H * s0.W, s)); x = L.x_nsc; }
   L.a[0] = const_cast<float*>(x);
-  PV_TRY(pvcs::wt_prep(p->params, p->ops, p->n_ops, p->ndim, 0, p->conv_bf16, L.wtp, L.wt, false, s));
+  PV_TRY(pvcs::wt_prep(p->params, p->ops, p->n_ops, p->ndim, 0, net_conv_mode(p), L.wtp, L.wt, false, s));
   PV_TRY(pvcs::stack_fwd(p->params, p->ops, p->n_ops, p->ndim, (int)B, L.a, L.sh, L.sc, s));
   const Shape& so = L.sh[p->n_ops];
   return pv_nsc_to_ncs(L.a[p->n_ops], out, B, so.C, (int64_t)so.H * so.W, s);
@@ -106,7 +116,7 @@ extern "C" int pv_convnet_backward(const pv_convnet_plan* p, const float* x, con
   float* g = L.g[pp];
   PV_TRY(pv_ncs_to_nsc(dout, g, B, so.C, (int64_t)so.H * so.W, s));
   pp ^= 1;
-  PV_TRY(pvcs::wt_prep(p->params, p->ops, p->n_ops, p->ndim, 0, p->conv_bf16, L.wtp, L.wt, true, s));
+  PV_TRY(pvcs::wt_prep(p->params, p->ops, p->n_ops, p->ndim, 0, net_conv_mode(p), L.wtp, L.wt, true, s));
   float* gout = nullptr;
   PvFinishList fin{};
   fin.base = L.fin_ws; fin.cap = L.fin_bytes;

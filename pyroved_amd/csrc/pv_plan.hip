@@ -748,7 +748,11 @@ static bool plan_guide_may_fold(const pv_ivae_plan* p, const Layout& L) {
          p->c_dim == 0 && !p->row_w && !p->row_elbo && !p->dy && p->n_enc == 2 && p->enc[0].in_dim == p->n_pix &&
          p->enc[0].out_dim <= FD_H && p->enc[1].out_dim <= FD_H && p->head.out_dim == 2 * z && z <= 16 && plan_lat_in(p) <= 16 &&
          p->enc[0].w_off % 4 == 0 && p->enc[1].w_off % 4 == 0 && p->head.w_off % 4 == 0 && p->enc[1].in_dim % 4 == 0 &&
-         p->head.in_dim % 4 == 0 && p->coord_dim > 0;
+         p->head.in_dim % 4 == 0 && p->coord_dim > 0 &&
+         // the folded prologue also reads the decoder's hidden matrices, the observations and the parameter base as float4
+         // (the Python engine aligns every offset; a raw C-ABI caller need not) — otherwise the guide keeps its launch
+         p->dec[0].w_off % 4 == 0 && p->dec[1].w_off % 4 == 0 && p->n_pix % 4 == 0 &&
+         ((uintptr_t)p->params & 15) == 0 && ((uintptr_t)p->x & 15) == 0;
 }
 
 // loss_and_grads with the fused persistent spatial-decoder kernel (pv_sdec_fused.hip)

@@ -60,9 +60,13 @@ bool valid_ved(const pv_ved_plan* p) {
 
 // shapes + workspace carving; false on an inconsistent plan
 // the conv mode this call runs with: the plan's, except that mode 4 (the cheaper backward) needs gradient sums long enough for
-// its one-piece operands' rounding to average out — decided on the ENCODER stack (the 2-D convolutions; pv_convstack.h)
+// its one-piece operands' rounding to average out — decided over BOTH stacks (the one mode drives the encoder's and the decoder's
+// convolutions: a 1-D encoder in front of a 2-D decoder — spec2im — has no encoder convolution that could trip the gate, and
+// the decoder's early 4x4 / 8x8 layers at a small batch are exactly the short sums the gate exists for)
 static int ved_conv_mode(const pv_ved_plan* p) {
-  return pvcs::conv_mode_for(p->conv_bf16, p->enc, p->n_enc_ops, p->ndim_in, p->batch, p->in_ch, p->in_dim);
+  const int enc = pvcs::conv_mode_for(p->conv_bf16, p->enc, p->n_enc_ops, p->ndim_in, p->batch, p->in_ch, p->in_dim);
+  if (enc != 4) return enc;
+  return pvcs::conv_mode_for(p->conv_bf16, p->dec, p->n_dec_ops, p->ndim_out, p->batch, p->dec_c0, p->dec_dim0);
 }
 
 bool vcarve(const pv_ved_plan* p, char* base, VLayout& L) {

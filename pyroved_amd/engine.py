@@ -36,6 +36,7 @@ def _linears(seq: nn.Sequential) -> List[nn.Linear]:
 class IVAEEngine:
     """Binds an iVAE-like model (encoder_z: fcEncoderNet, decoder: sDecoderNet | fcDecoderNet)
     to the HIP library."""
+    supports_dp_step = True          # loss_and_grads(step=True, comm=NativeComm): the data-parallel step as one library call
     supports_scalars_out = True      # loss_and_grads can write the 4 loss scalars to a caller-given device slot
     supports_step = True             # loss_and_grads(step=True) = SVI.step in one library call
     # per-plan switches (ABI v14 / v15 plan fields; the library keeps no process-wide switch).  Set on an engine — or, in tests,
@@ -485,7 +486,7 @@ class IVAEEngine:
                        scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None,
                        row_w: Optional[torch.Tensor] = None, row_elbo: Optional[torch.Tensor] = None,
                        dy: Optional[torch.Tensor] = None, step: bool = False,
-                       class_onehot: Optional[torch.Tensor] = None):
+                       class_onehot: Optional[torch.Tensor] = None, comm=None, hist_out: Optional[torch.Tensor] = None):
         """Enqueues Trace_ELBO.loss_and_grads on the current stream.  Results land in
         self.scalars (device, 4 floats) and self.grad[:n_flat]; nothing is synchronised.
         row_w (B): per-sample weights of the ELBO terms; row_elbo (B) / dy (B, c_dim): extra outputs
@@ -493,12 +494,17 @@ class IVAEEngine:
         step=True: the whole SVI.step — the Adam update follows in the same library call (pv_ivae_step; on the fused
         decoder path it rides in the last gradient launch), identical in effect to loss_and_grads() + adam_step().
         class_onehot (B, discrete_dim): jiVAE WITHOUT enumeration — the class the guide drew for every sample
-        (pv_ivae_plan.class_onehot; the trainer's default enumerate_parallel=False)."""
+        (pv_ivae_plan.class_onehot; the trainer's default enumerate_parallel=False).
+        step=True with comm (a dist.NativeComm): the DATA-PARALLEL step as one library call on this stream (pv_ivae_dp_step):
+        this rank's shard's loss and gradients -> ncclAllReduce(SUM) of [gradients | loss scalars] -> Adam, with the reduced
+        scalars written to hist_out (4 floats) in the optimizer's launch."""
         self.ensure_bound()
         if self.conv_enc:
             self._check_conv_weight_range()
         if step and (self.ext_enc or self.ext_dec or getattr(self, "ext_y", False) or not want_grads):
             raise ValueError("step=True needs every parameter in the library (no user-defined modules) and want_grads")
+        if comm is not None and (not step or scalars_out is not None):
+            raise ValueError("comm= goes with step=True and the engine's own scalars (no scalars_out)")
         if self.ext_dec:
             return self._loss_and_grads_ext_decoder(x, eps, beta, y, want_grads, scalars_out, z_out, loc_out)
         b = x.shape[0]
@@ -543,7 +549,13 @@ class IVAEEngine:
             if step:
                 p.lr, p.adam_beta1, p.adam_beta2, p.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
                 p.adam_step = self.adam_t + 1
-                _abi.check(_abi.lib().pv_ivae_step(C.byref(p), _abi.current_stream()), "pv_ivae_step")
+                if comm is not None:
+                    if hist_out is not None:
+                        _abi.require_device(hist_out, "hist_out")
+                    _abi.check(_abi.lib().pv_ivae_dp_step(C.byref(p), comm.handle, _abi.ptr(hist_out), _abi.current_stream()),
+                               "pv_ivae_dp_step")
+                else:
+                    _abi.check(_abi.lib().pv_ivae_step(C.byref(p), _abi.current_stream()), "pv_ivae_step")
                 self.adam_t += 1
             else:
                 _abi.check(_abi.lib().pv_ivae_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),

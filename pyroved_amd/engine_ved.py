@@ -117,9 +117,12 @@ class VEDEngine(IVAEEngine):
     # ------------------------------------------------------------------ calls
     @_abi.on_device
     def loss_and_grads(self, x, eps, beta: float = 1.0, y=None, want_grads: bool = True,
-                       scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None):
+                       scalars_out: Optional[torch.Tensor] = None, z_out=None, loc_out=None, step: bool = False, comm=None,
+                       hist_out: Optional[torch.Tensor] = None):
         """Enqueues Trace_ELBO.loss_and_grads(VED.model, VED.guide) on the current stream: x (B, C, *input_dim),
-        target y (B, C', *output_dim), eps (B, z_dim)."""
+        target y (B, C', *output_dim), eps (B, z_dim).
+        step=True with comm (a dist.NativeComm): the data-parallel SVI.step as one library call (pv_ved_dp_step): this shard's
+        gradients -> ncclAllReduce(SUM) of [gradients | loss scalars] -> Adam, the reduced scalars into hist_out."""
         self.ensure_bound()
         self._check_conv_weight_range()
         if y is None:
@@ -136,9 +139,19 @@ class VEDEngine(IVAEEngine):
             p.loc = loc_out.data_ptr()
         if scalars_out is not None:
             p.scalars = scalars_out.data_ptr()
+        if step and (comm is None or not want_grads or scalars_out is not None):
+            raise ValueError("step=True is the data-parallel step: it needs comm=, want_grads and the engine's own scalars")
         try:
-            _abi.check(_abi.lib().pv_ved_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),
-                       "pv_ved_loss_and_grads")
+            if step:
+                if hist_out is not None:
+                    _abi.require_device(hist_out, "hist_out")
+                _abi.check(_abi.lib().pv_ved_dp_step(C.byref(p), comm.handle, self.lr, self.betas[0], self.betas[1],
+                                                     self.adam_eps, self.adam_t + 1, _abi.ptr(hist_out),
+                                                     _abi.current_stream()), "pv_ved_dp_step")
+                self.adam_t += 1
+            else:
+                _abi.check(_abi.lib().pv_ved_loss_and_grads(C.byref(p), int(want_grads), _abi.current_stream()),
+                           "pv_ved_loss_and_grads")
         finally:
             p.scalars = self.scalars.data_ptr()
         if want_grads:

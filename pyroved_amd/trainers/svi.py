@@ -138,8 +138,18 @@ class SVItrainer:
         self.current_epoch = 0
         self._hist = None
         rank, world = pvdist.world(self.group)
+        # data parallel over the nccl (= RCCL) backend: the step's one collective is enqueued by the LIBRARY on the compute
+        # stream (dist.NativeComm, ABI v16 pv_ivae_dp_step / pv_ved_dp_step) — `collective="torch"` keeps torch.distributed's
+        # all_reduce (its own stream, two event hand-offs per step); gloo groups (CPU tests) always do.
+        self._comm = None
+        which = kwargs.get("collective", "native")
+        if which not in ("native", "torch"):
+            raise ValueError("collective must be 'native' or 'torch' (got %r)" % (which,))
         if world > 1:
             pvdist.sync_replicas(self.engine, self.group)
+            if (which == "native" and kwargs.get("engine") is None and pvdist.native_available(self.group)
+                    and getattr(self.engine, "supports_dp_step", False)):
+                self._comm = pvdist.native_comm(self.engine.device, self.group)
 
     # ------------------------------------------------------------------ one minibatch
     def _draw_eps(self, b: int) -> torch.Tensor:
@@ -200,6 +210,11 @@ class SVItrainer:
             if one_call:                              # loss, gradients and Adam in one library call (pv_ivae_step)
                 eng.loss_and_grads(xs, es, beta, ys, scalars_out=self._hist[i], step=True, **extra)
                 return
+            if (self._comm is not None and train and world > 1
+                    and not (getattr(eng, "ext_enc", False) or getattr(eng, "ext_dec", False) or getattr(eng, "ext_y", False))):
+                # the data-parallel SVI.step as ONE library call on this stream: shard gradients -> ncclAllReduce -> Adam + history
+                eng.loss_and_grads(xs, es, beta, ys, step=True, comm=self._comm, hist_out=self._hist[i], **extra)
+                return
             if direct:
                 eng.loss_and_grads(xs, es, beta, ys, want_grads=train, scalars_out=self._hist[i], **extra)
             else:
@@ -207,12 +222,13 @@ class SVItrainer:
         else:                                          # more ranks than samples: contribute zeros
             eng.grad.zero_()
         if world > 1:
+            reduce_ = self._comm.allreduce_sum_ if self._comm is not None else (lambda t_: pvdist.allreduce_sum_(t_, self.group))
             if not train:                              # only the scalars need reducing
-                pvdist.allreduce_sum_(eng.scalars, self.group)
+                reduce_(eng.scalars)
             else:
-                pvdist.allreduce_sum_(eng.grad, self.group)
+                reduce_(eng.grad)
                 for g_ in (eng.extra_grads() if hasattr(eng, "extra_grads") else []):
-                    pvdist.allreduce_sum_(g_, self.group)        # a user-defined encoder's gradients
+                    reduce_(g_)                        # a user-defined encoder's gradients
         step_opt = train or (self.mirror_evaluate_update and eng.grads_live)
         if step_opt and not direct and hasattr(eng, "adam_step_hist"):
             eng.adam_step_hist(self._hist[i])          # Adam + the reduced loss into the history, one launch

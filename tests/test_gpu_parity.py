@@ -645,6 +645,33 @@ def test_ved_steps_vs_golden_and_oracle(gpu_device, name):
     assert mu.shape == dec[:2].shape and sd.shape == mu.shape and torch.isfinite(mu).all()
 
 
+def test_ved_spec2im_small_batch_keeps_the_three_product_backward(gpu_device):
+    """conv mode 4 (the one-piece backward) is size-gated — it needs gradient sums of >= 16 384 pixels per
+    convolution — and the gate must look at BOTH stacks.  spec2im (a 1-D encoder in front of a 2-D decoder, default channel
+    counts) has no 2-D encoder convolution that could trip it, and at batch 4 the decoder's 4x4 / 8x8 / 16x16 layers sum a few
+    hundred pixels: the default plan must run the three-product backward there, i.e. give the SAME BITS as the plan that asks
+    for it (conv_x3), and hold the fp32-class gradient bar against the oracle."""
+    def run(conv_x3):
+        m = pv.models.VED((64,), (16, 16), latent_dim=2, seed=1, device="cuda")
+        eng = m.engine(fused=2)
+        eng.conv_x3 = conv_x3
+        g = torch.Generator().manual_seed(11)
+        x, y = torch.rand(4, 1, 64, generator=g), torch.rand(4, 1, 16, 16, generator=g)
+        eps = torch.randn(4, m.z_dim, generator=g)
+        eng.loss_and_grads(x.cuda(), eps.cuda(), 1.0, y.cuda())
+        torch.cuda.synchronize()
+        return m, eng, (x, y, eps)
+    m0, e0, (x, y, eps) = run(False)
+    m1, e1, _ = run(True)
+    assert torch.equal(e0.grad[:e0.n_flat + 4], e1.grad[:e1.n_flat + 4]), "small-batch spec2im took the one-piece backward"
+    cfg = orc.VedConfig(input_dim=(64,), output_dim=(16, 16), latent_dim=2)
+    o = orc.VedOracle({k: v.cpu() for k, v in m0.state_dict().items()}, cfg)
+    o.step(x, y, eps, 1.0)
+    for key in o.p:
+        err = rel_l2(e0.grad_of(key), o.last_grads[key])
+        assert err < RTOL_GRAD, "grad %s: rel l2 error %.3e vs oracle" % (key, err)
+
+
 def test_ved_bf16_mode_vs_oracle(gpu_device):
     """VED in the throughput precision (SVItrainer(precision="bf16") -> plan.conv_bf16 = 3, round 4: the 2-D kernel-3
     convolutions with a multiple of 32 input channels run forward, input gradient and weight gradient on the matrix cores

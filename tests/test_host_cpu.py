@@ -552,3 +552,30 @@ def test_roctx_ranges_resolve_without_a_link_dependency():
     assert off.returncode == 0 and off.stdout.strip() == "0", off.stderr
     on = subprocess.run([sys.executable, "-c", code % "1"], capture_output=True, text=True)
     assert on.returncode == 0 and on.stdout.strip() == ("1" if have else "0"), on.stderr
+
+
+def test_dist_layer_resolves_the_process_rccl_and_refuses_a_second_one():
+    """ABI v16: the collective lives in the library but RCCL is not a link dependency — pv_dist_load resolves ncclAllReduce & co. in
+    the RCCL shared object the process already holds (PyTorch's own), once; without a communicator every entry point is PV_EINVAL
+    (no compute call here: there is no GPU)."""
+    import ctypes as C
+    import subprocess
+    from pyroved_amd import dist as pvdist
+    path = pvdist._loaded_rccl_path()
+    assert path and "rccl" in os.path.basename(path)
+    lib = _abi.lib()
+    assert lib.pv_dist_load(path.encode()) == 0
+    assert lib.pv_dist_library().decode() == path
+    assert lib.pv_dist_load(path.encode()) == 0                       # idempotent
+    assert lib.pv_dist_load(b"/nonexistent/librccl.so") == -1         # a second library in one process: PV_EINVAL
+    assert lib.pv_dist_allreduce_sum(None, None, 4, None) == -1
+    assert lib.pv_ivae_dp_step(None, None, None, None) == -1
+    assert lib.pv_dist_comm_info(None, None, None) == -1
+    # libpyroved_amd.so itself must not link RCCL (a single-GPU user never loads it)
+    out = subprocess.run(["readelf", "-d", _abi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in out.lower()
+    # a path that does not load is an error of its own kind (fresh process: nothing resolved yet)
+    code = ("import sys; sys.path.insert(0, %r); from pyroved_amd import _abi; "
+            "print(_abi.lib().pv_dist_load(b'/nonexistent/librccl.so'))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.stdout.strip() == "-3", (r.stdout, r.stderr[-500:])      # PV_ECOLL
