@@ -56,7 +56,7 @@ def test_dp_step_world1_is_bit_identical_to_the_two_call_step(comm, kind):
         dims = (32, 32)
         def mk():
             m = pv.models.iVAE((32, 32), 2, ["r", "t", "s"], seed=1, device="cuda")
-            m.set_encoder(pv.nets.convEncoderNet((32, 32), latent_dim=m.z_dim, hidden_dim=(32, 64)))
+            m.set_encoder(pv.nets.convEncoderNet((32, 32), latent_dim=m.z_dim, hidden_dim=[(32,), (64, 64)]))
             return m
         b, fused = 16, 2
     else:
