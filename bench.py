@@ -533,9 +533,10 @@ def measure(args, name, cfg, fused, ctx, attrs=None):
                           "elsewhere" if bf else
                           "2-D k3 convolutions on the f16 MFMA, operands as fp16 pieces with exact power-of-two scaling per staged "
                           "tile: FORWARD both operands two pieces, three products (3e-7 relative l2 vs float64: its outputs pick "
-                          "max-pool winners); BACKWARD weights two pieces against dL/dy as one (input gradient, two products), one "
-                          "piece per operand in the weight gradient — every gradient within the fp32 reference's own distance from "
-                          "float64 (fp32 accumulate); 1-D convolutions on the f32-input MFMA; fp32 elsewhere"))
+                          "max-pool winners); INPUT GRADIENT the same three products (round 6: one-piece dL/dy accumulated down the "
+                          "chain to 1.6e-4 under equal forward decisions); WEIGHT GRADIENT one piece per operand, one product "
+                          "(5..8e-5 on its own tensor) — every gradient within 1e-4 of float64 under the HIP forward's own "
+                          "decisions, three draws (fp32 accumulate); 1-D convolutions on the f32-input MFMA; fp32 elsewhere"))
         out["roofline"] = conv_roof if conv_roof else {"bound": "mfma", "achieved": 0.0, "peak": MFMA_BF16_PEAK_TFLOPS,
                                                        "unit": "TFLOP/s", "frac": 0.0, "traffic": None, "kernel": "n/a"}
         out["roofline_step"] = {"bound": "mfma", "scope": "step", "achieved": step_tf, "peak": MFMA_BF16_PEAK_TFLOPS,

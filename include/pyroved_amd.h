@@ -260,9 +260,11 @@ int pv_experiments_build(void);
 /* (v15) PV_PLAN_CONV_X3 (pv_ivae_plan with a convolutional encoder; pv_ved_plan / pv_convnet_plan say it as conv_bf16 == 0): the
  *   fp32-class kernel-3 convolutions with BOTH operands as two fp16 pieces and three products per multiply-add in EVERY direction
  *   (rounds 2-4's form, 3e-7 per convolution vs float64).  Default since round 5 (conv_bf16 == 4): the FORWARD unchanged (its outputs
- *   decide max-pool winners and leaky-ReLU signs), the BACKWARD cheaper: input gradients with dL/dy as ONE fp16 piece scaled per
- *   staged tile against the two-piece weights (two products), weight gradients with one piece per operand (one product) — rounding
- *   errors that are independent from element to element and average out of the sums a gradient is. */
+ *   decide max-pool winners and leaky-ReLU signs), the INPUT GRADIENT unchanged too (v16: round 5 ran it with dL/dy as ONE fp16
+ *   piece, two products — an error that accumulates down the chain of input gradients to 1.6e-4 on the first layers' tensors under
+ *   equal forward decisions), the WEIGHT GRADIENT with one piece per operand (one product): a rounding error that is independent
+ *   from element to element, averages out of the sum over every pixel of every sample and stays in its own tensor (5 ... 8e-5;
+ *   DESIGN.md section 4.3). */
 #define PV_PLAN_CONV_X3        64
 
 /* Bytes of workspace pv_ivae_* calls need for this plan (depends on batch, n_pix,

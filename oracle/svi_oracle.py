@@ -67,6 +67,7 @@ class Config:
     conv_batchnorm: bool = False   # convEncoderNet(..., batchnorm=True); the running statistics travel in Config.bufs
     bufs: Optional[dict] = None    # batch-norm buffers of the conv encoder (set by SVIOracle), always training mode: the
                                    # reference's iVAE never calls eval() (models/base.py:121-143)
+    conv_decisions: Optional[object] = None     # test infrastructure (ConvDecisions): record / apply the conv encoder's sign and winner decisions
     custom_encoder: Optional[object] = None     # iVAE.set_encoder(user module): a callable x -> (z_loc, z_scale) in torch
     custom_decoder: Optional[object] = None     # iVAE.set_decoder(user module): (x_coord_prime, z) -> loc, or z -> loc (vanilla)
     custom_label_net: Optional[object] = None   # ssiVAE.set_classifier / ss_reg_iVAE.set_regressor(user module): x -> probabilities / means
@@ -393,22 +394,107 @@ def _bn(p: Params, bufs, pre: str, h, training: bool):
                         training, 0.1, 1e-5)
 
 
-def conv_encoder_forward(p: Params, cfg: VedConfig, x, bufs=None, training=True):
+class ConvDecisions:
+    """The data-dependent DECISIONS of a conv encoder's forward — leaky-ReLU signs and 2x2 max-pool winners — as test infrastructure
+    (VERDICT r5 item 3).  Two implementations of nets/conv.py:150-213 in different arithmetics decide a handful of near-ties
+    differently, and a flipped decision changes a gradient by far more than either arithmetic's rounding: to see ARITHMETIC error the
+    float64 oracle is run under another implementation's decisions, and the flips are counted as a quantity of their own.
+      record()            -> the forward fills `sign` / `win` with its own decisions (one entry per conv layer / pool, in order);
+      given decisions     -> the forward applies them instead of deciding: y = x where sign else 0.01 x; pooled = x[winner].
+    sign[i]: bool (B, C, H, W) after conv i — at the POOLED resolution when that conv's block ends in a max-pool whose input the
+    other implementation never stores (the sign of the window's winner; losers carry no gradient); win[j]: int64 (B, C, H/2, W/2)
+    with k = 2 dy + dx of the window's winner.  2-D stacks with activation 'lrelu' or 'relu', no batch norm."""
+
+    def __init__(self, sign=None, win=None, pool_of=None):
+        self.sign = [] if sign is None else sign
+        self.win = [] if win is None else win
+        self.recording = sign is None
+        self.pool_of = {} if pool_of is None else dict(pool_of)   # conv index -> index of the max-pool that follows it directly
+
+    @staticmethod
+    def pick(h, k):
+        """h (B, C, H, W), k (B, C, H/2, W/2) in 0..3 -> the window element 2 dy + dx = k (differentiable gather)."""
+        b, c, hh, ww = h.shape
+        win = h.reshape(b, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, c, hh // 2, ww // 2, 4)
+        return win.gather(-1, k.unsqueeze(-1)).squeeze(-1)
+
+    @staticmethod
+    def first_max(h):
+        """torch's max-pool winner (first maximum in scan order) of every 2x2 window as k = 2 dy + dx."""
+        b, c, hh, ww = h.shape
+        win = h.reshape(b, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, c, hh // 2, ww // 2, 4)
+        m = win.max(-1, keepdim=True).values
+        return (win == m).to(torch.int8).argmax(-1)      # argmax of a 0/1 tensor: the FIRST maximum
+
+    def flips(self, other):
+        """(differing signs, differing winners, signs compared, winners compared) against another decision set of the same net;
+        a sign recorded at full resolution is compared at the winners of `self` where `other` holds the pooled one."""
+        ds = dw = ns = nw = 0
+        j = 0
+        for i, (a, b) in enumerate(zip(self.sign, other.sign)):
+            if a.shape != b.shape:                    # one side knows this sign at the pooled resolution only: compare at ITS winners
+                pooled_first = a.shape[-1] < b.shape[-1]
+                full, pooled = (b, a) if pooled_first else (a, b)
+                owner = self if pooled_first else other
+                k = owner.win[(owner.pool_of or self.pool_of or other.pool_of)[i]]
+                full = self.pick(full.to(torch.int8), k).bool()
+                a, b = (pooled, full) if pooled_first else (full, pooled)
+            ds += int((a != b).sum()); ns += a.numel()
+        for a, b in zip(self.win, other.win):
+            dw += int((a != b).sum()); nw += a.numel()
+        return ds, dw, ns, nw
+
+
+def conv_encoder_forward(p: Params, cfg: VedConfig, x, bufs=None, training=True, decisions: "ConvDecisions" = None):
     """convEncoderNet.forward (nets/conv.py:24-64): FeatureExtractor (conv k3 s1 p1 + activation per filter, a 2x
-    max-pool after every block but the last; conv.py:150-213) -> flatten (C, spatial) -> Linear -> (mu, softplus)."""
+    max-pool after every block but the last; conv.py:150-213) -> flatten (C, spatial) -> Linear -> (mu, softplus).
+    decisions (test infrastructure, see ConvDecisions): record this forward's leaky-ReLU signs and max-pool winners, or apply
+    given ones instead of deciding."""
     act, nd = _ACT[cfg.activation], len(cfg.input_dim)
     h, idx = x, 0
     blocks = cfg.he
+    dec = decisions
+    if dec is not None:
+        assert nd == 2 and cfg.activation in ("lrelu", "relu") and not cfg.batchnorm, "ConvDecisions: 2-D lrelu / relu stacks"
+        slope = 0.01 if cfg.activation == "lrelu" else 0.0
+        li = pi = 0
     for bi, block in enumerate(blocks):
-        for _ in block:
+        pool_done = False
+        for ci, _ in enumerate(block):
             pre = "encoder_z.feature_extractor.layers.%d" % idx
-            h = act(_conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"], stride=1, padding=1))
+            h = _conv(nd)(h, p[pre + ".weight"], p[pre + ".bias"], stride=1, padding=1)
+            pooled_next = dec is not None and ci + 1 == len(block) and bi + 1 < len(blocks)
+            if dec is None:
+                h = act(h)
+            elif dec.recording:
+                dec.sign.append((h > 0).detach())
+                if pooled_next:
+                    k = ConvDecisions.first_max(h.detach())      # (the activation is monotone: the winner before = after it)
+                    dec.pool_of[li] = len(dec.win); dec.win.append(k)
+                h = act(h)
+                li += 1
+            else:
+                sg = dec.sign[li]
+                if pooled_next and sg.shape[-1] * 2 == h.shape[-1]:
+                    # the other implementation pooled in the convolution's epilogue: winner first, then the winner's sign
+                    h = ConvDecisions.pick(h, dec.win[pi])
+                    h = torch.where(sg, h, slope * h)
+                    pi += 1; li += 1; idx += 2         # conv, activation (the pool's own index is counted below)
+                    pool_done = True
+                    continue
+                h = torch.where(sg, h, slope * h)
+                li += 1
             idx += 2                                   # conv, activation
             if cfg.batchnorm:
                 h = _bn(p, bufs, "encoder_z.feature_extractor.layers.%d" % idx, h, training)
                 idx += 1
         if bi + 1 < len(blocks):
-            h = (F.max_pool1d if nd == 1 else F.max_pool2d)(h, 2, 2)
+            if pool_done:
+                pass
+            elif dec is not None and not dec.recording:
+                h = ConvDecisions.pick(h, dec.win[pi]); pi += 1
+            else:
+                h = (F.max_pool1d if nd == 1 else F.max_pool2d)(h, 2, 2)
             idx += 1
     enc = F.linear(h.reshape(h.shape[0], -1), p["encoder_z.features2latent.fc_latent.weight"],
                    p["encoder_z.features2latent.fc_latent.bias"])
@@ -443,11 +529,11 @@ def conv_decoder_forward(p: Params, cfg: VedConfig, z, bufs=None, training=True)
     return torch.sigmoid(h) if cfg.sigmoid_d else h
 
 
-def ved_elbo(p: Params, cfg: VedConfig, x, y, eps, beta=1.0, bufs=None, training=True):
+def ved_elbo(p: Params, cfg: VedConfig, x, y, eps, beta=1.0, bufs=None, training=True, decisions=None):
     """Trace_ELBO of VED.guide/model (models/ved.py:122-163): z = mu + sigma*eps,
     loss = -( sum_b log p(y_b | z_b) + beta*sum_b log N(z_b;0,1) - beta*sum_b log N(z_b;mu_b,sigma_b) )."""
     b = x.shape[0]
-    z_loc, z_scale = conv_encoder_forward(p, cfg, x, bufs, training)
+    z_loc, z_scale = conv_encoder_forward(p, cfg, x, bufs, training, decisions)
     z = z_loc + z_scale * eps
     logq = td.Normal(z_loc, z_scale).log_prob(z).sum(-1)
     logp = td.Normal(torch.zeros_like(z), torch.ones_like(z)).log_prob(z).sum(-1)
@@ -505,7 +591,7 @@ def _encode_any(p: Params, cfg: Config, x, y=None):
     if cfg.conv_encoder is not None:
         vc = VedConfig(input_dim=cfg.data_dim, output_dim=cfg.data_dim, latent_dim=cfg.z_dim,
                        hidden_dim_e=cfg.conv_encoder, activation=cfg.conv_activation, batchnorm=cfg.conv_batchnorm)
-        return conv_encoder_forward(p, vc, x.reshape(x.shape[0], 1, *cfg.data_dim), cfg.bufs, True)
+        return conv_encoder_forward(p, vc, x.reshape(x.shape[0], 1, *cfg.data_dim), cfg.bufs, True, cfg.conv_decisions)
     return encoder_forward(p, cfg, x, y)
 
 

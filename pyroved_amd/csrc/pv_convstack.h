@@ -66,6 +66,29 @@ inline int64_t code2_off(const pv_op* ops, int n, int nd, int B, const Shape* sh
   return off;
 }
 
+// test / measurement hook behind pv_debug_ivae_conv_trace / pv_debug_ved_conv_trace (not in include/): where a step leaves the
+// DECISIONS of the encoder stack's forward — the activations its backward reads (channels-last (B, H, W, C) fp32: the sign of a
+// leaky-ReLU / ReLU output is the sign of its input) and the max-pool winner bytes ((B, H/2, W/2, C); k = 2 dy + dx of the 2x2
+// window's first maximum in scan order).  6 int64 per op i = 0 .. n-1, describing the op's OUTPUT a[i + 1]:
+//   [0] byte offset of a[i + 1] from `base` (-1: never written — the convolution's max-pool runs in its epilogue),
+//   [1..3] H, W, C of a[i + 1],  [4] byte offset of the recorded winners when op i is a max-pool (-1: not recorded),  [5] op kind
+inline void conv_trace(const pv_op* ops, int n, int nd, int B, const Shape* sh, float* const* a, const unsigned char* code,
+                       const unsigned char* code2, const char* base, int64_t* out) {
+  const bool c1 = code && c1pool_fusable(ops, n, nd, sh[0]);
+  for (int i = 0; i < n; ++i) {
+    int64_t* o = out + 6 * i;
+    const bool fused_next = (i == 0 && c1) || (code2 && convpool_fusable(ops, n, nd, i, sh[i]));
+    o[0] = (fused_next || !a[i + 1]) ? -1 : (int64_t)(reinterpret_cast<const char*>(a[i + 1]) - base);
+    o[1] = sh[i + 1].H; o[2] = sh[i + 1].W; o[3] = sh[i + 1].C;
+    o[4] = -1; o[5] = ops[i].kind;
+    if (ops[i].kind == PV_OP_MAXPOOL2 && i >= 1) {
+      if (i == 1 && c1) o[4] = (int64_t)(reinterpret_cast<const char*>(code) - base);
+      else if (code2 && convpool_fusable(ops, n, nd, i - 1, sh[i - 1]))
+        o[4] = (int64_t)(reinterpret_cast<const char*>(code2 + code2_off(ops, n, nd, B, sh, i - 1)) - base);
+    }
+  }
+}
+
 // shapes s[0..n] from s[0]; accumulates workspace needs; false on an inconsistent sequence
 inline bool stack_shapes(const pv_op* ops, int n, int nd, int64_t B, Shape* s, Needs& nd_) {
   upd(nd_.maxact, s[0].elems(B));
@@ -191,12 +214,20 @@ inline bool conv_mixed(int cm) { return cm == 1 || cm == 3; }   // (3: the kerne
 inline int sp_fp32_mode(int cm) { return cm == 2 ? 3 : pv_conv3_sp_fp32_mode(); }
 // ... and the `mode` argument of pv_conv3_sp / _wgrad / _pair / pv_conv3_direct's callers: 2 mixed, else the fp32-class one
 inline int sp_mode(int cm) { return cm == 3 ? 1 : (cm == 1 ? 2 : sp_fp32_mode(cm)); }
-// ... of the INPUT gradient (mode 4: the weights two fp16 pieces, dL/dy one: two products) and of the split-operand WEIGHT
-// gradient (mode 4: one piece per operand — its sums run over every pixel of every sample)
-// (the input gradient with ONE piece per operand too — one product — was measured: the weights' rounding is systematic, the
-//  conv-stack gradients land AT the bar instead of 1.3 - 3.7x inside it: gpurun_out/r05r; not adopted)
-inline int sp_dg_mode(int cm) { return cm == 4 ? 5 : sp_mode(cm); }
-inline int sp_wg_mode(int cm) { return cm == 4 ? 1 : sp_mode(cm); }
+// ... of the INPUT gradient and of the split-operand WEIGHT gradient.  Mode 4, round 6: the input gradient keeps BOTH operands
+// split (three products, as mode 0) and only the weight gradient — whose sums run over every pixel of every sample and whose
+// error stays in its own tensor — takes one piece per operand.  Round 5 also ran the input gradient with dL/dy as ONE fp16 piece
+// (two products): under equal forward decisions (tests: masked_conv_check; profiles/r06a_conv_bwd_forms.txt) that form's error
+// ACCUMULATES down the chain of input gradients — 0.85 ... 1.65e-4 on the first layers' tensors on three draws, over the 1e-4
+// bar on three of six — where three products leave 0.6 ... 3.6e-5; the one-piece weight gradient adds 5 ... 7e-5 to its own
+// tensor only (worst 0.78 of the bar).  C5 +4.7 %, C4 +1.8 % against round 5's form; mode 0 (three products everywhere) another
+// +6.5 % / +4.2 %.
+// (the input gradient with ONE piece per operand too — one product — was measured in round 5: the weights' rounding is systematic,
+//  the conv-stack gradients land AT the end-to-end bar: gpurun_out/r05r; not adopted)
+// (experiments build: PV_CONV_DG / PV_CONV_WG override mode 4's two choices — 4 = both operands split, three products — for the
+//  error / time table of profiles/r06*_conv_bwd_forms.txt)
+inline int sp_dg_mode(int cm) { static const int e = pv_exp_int("PV_CONV_DG", 0); return (cm == 4 && e) ? e : sp_mode(cm); }
+inline int sp_wg_mode(int cm) { static const int e = pv_exp_int("PV_CONV_WG", 0); return cm == 4 ? (e ? e : 1) : sp_mode(cm); }
 inline int direct_mode(const Scratch& sc) { return conv_mixed(sc.conv_bf16) ? 1 : (sp_fp32_mode(sc.conv_bf16) == 4 ? 2 : 0); }
 
 // Mode 4's one-piece backward operands carry independent rounding errors of 2^-12 that average out of the sums a gradient is:

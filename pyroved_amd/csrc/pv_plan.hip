@@ -1153,6 +1153,19 @@ extern "C" int pv_ivae_guide_folds(const pv_ivae_plan* plan) {
   return pv_sdec_fused_fold_ok(f, L.f_grid, false) ? 1 : 0;
 }
 
+// test hook (not in include/; pv_convstack.h: conv_trace): offsets into plan->ws of the conv encoder's stored activations and
+// max-pool winners after a pv_ivae_loss_and_grads call — tests/test_gpu_parity.py compares gradients with the float64 oracle
+// under the HIP forward's own decisions and counts the decisions that differ
+extern "C" int pv_debug_ivae_conv_trace(const pv_ivae_plan* plan, int64_t* out) {
+  if (!valid_plan(plan) || !plan->ws || !out || plan->n_enc_ops <= 0) return PV_EINVAL;
+  Layout L;
+  carve(plan, (char*)plan->ws, L);
+  if (!L.enc_conv || L.cF < 0 || plan->ws_bytes < L.total) return PV_EINVAL;
+  pvcs::conv_trace(plan->enc_ops, plan->n_enc_ops, plan->enc_ndim, plan->batch, L.ces, L.cea, L.ccode, L.ccode2,
+                   (const char*)plan->ws, out);
+  return 0;
+}
+
 extern "C" int pv_ivae_loss_and_grads(const pv_ivae_plan* plan, int want_grads, void* stream) {
   PV_RANGE("pv_ivae_loss_and_grads");
   if (plan && plan->ext_decoder) return PV_EINVAL;      // (pv_ivae_guide / pv_ivae_guide_backward)

@@ -252,6 +252,15 @@ extern "C" int64_t pv_ved_workspace_bytes(const pv_ved_plan* plan) {
   return L.total;
 }
 
+// test hook (not in include/; pv_convstack.h: conv_trace): the encoder stack's stored activations and max-pool winners
+extern "C" int pv_debug_ved_conv_trace(const pv_ved_plan* p, int64_t* out) {
+  if (!valid_ved(p) || !p->ws || !out) return PV_EINVAL;
+  VLayout L;
+  if (!vcarve(p, (char*)p->ws, L) || p->ws_bytes < L.total) return PV_EINVAL;
+  pvcs::conv_trace(p->enc, p->n_enc_ops, p->ndim_in, p->batch, L.es, L.ea, L.sc.code, L.sc.code2, (const char*)p->ws, out);
+  return 0;
+}
+
 extern "C" int pv_ved_loss_and_grads(const pv_ved_plan* p, int want_grads, void* stream) {
   PV_RANGE("pv_ved_loss_and_grads");
   if (!valid_ved(p) || !p->params || !p->x || !p->y || !p->eps || !p->scalars || !p->ws) return PV_EINVAL;

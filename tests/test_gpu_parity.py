@@ -7,6 +7,7 @@ Tolerance: BASELINE.json's bar is 1e-4 relative in fp32 for the ELBO and reconst
 asserts below use 2e-5 .. 1e-4 as noted per quantity.
 """
 import ctypes as C
+import dataclasses
 import glob
 import os
 
@@ -19,6 +20,8 @@ from conftest import GOLDEN, load_golden, make_x, check_digest, meta_of, jmeta_o
 import pyroved_amd as pv
 from pyroved_amd import _abi
 from oracle import svi_oracle as orc
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -1321,6 +1324,85 @@ def full_size_tol(key, e32):
     return max(floor, 2 * e32[key])
 
 
+# ----  the conv bar that can see ARITHMETIC again: gradients under forced-equal decisions ----------------------
+# The 5e-4 floor above is the end-to-end check; it cannot tell a 4e-4 arithmetic regression from a decision flip.  So the float64
+# oracle is run a second time under the HIP forward's OWN decisions (oracle.ConvDecisions: the leaky-ReLU signs read off the
+# activations the step's backward uses, the max-pool winners read off its winner bytes — pv_debug_*_conv_trace, a test hook outside
+# include/): with equal decisions what is left between the two gradients is rounding, and every conv-stack tensor is held to
+# max(1e-4, 2 e32m) — e32m = the fp32 CPU oracle under the same decisions against the float64 one.  The decisions that differ are
+# counted as a quantity of their own: the HIP forward (three fp16 products per multiply-add, 3e-7 per convolution) must not flip
+# more of them against float64 than the reference precision itself does on the same draw (a small allowance for counting noise).
+def hip_conv_decisions(eng, batch, kind):
+    """oracle.ConvDecisions of the encoder stack as the HIP step that just ran decided them."""
+    import ctypes as C_
+    from pyroved_amd import _abi
+    fn = getattr(_abi.lib(), "pv_debug_%s_conv_trace" % kind)
+    fn.restype, fn.argtypes = C_.c_int, [C_.c_void_p, C_.POINTER(C_.c_int64)]
+    plan = eng._plan(batch)
+    n_ops = plan.n_enc_ops
+    ops = plan.enc_ops if kind == "ivae" else plan.enc
+    out = (C_.c_int64 * (6 * 32))()
+    assert fn(C_.byref(plan), out) == 0
+    torch.cuda.synchronize()
+    rows = [tuple(out[6 * i:6 * i + 6]) for i in range(n_ops)]
+
+    def act(i):                                   # op i's output, (B, C, H, W) on the host
+        off, h, w, c = rows[i][:4]
+        n = batch * h * w * c
+        return eng.ws[off:off + 4 * n].view(torch.float32).view(batch, h, w, c).permute(0, 3, 1, 2).cpu()
+    sign, win, pool_of = [], [], {}
+    li = 0
+    for i in range(n_ops):
+        kind_i = rows[i][5]
+        if kind_i == 1:                           # PV_OP_CONV
+            if rows[i][0] >= 0:
+                sign.append(act(i) > 0)
+            else:                                 # pooled in the convolution's epilogue: the winner's sign, from the pool's output
+                assert i + 1 < n_ops and rows[i + 1][5] == 2 and rows[i + 1][0] >= 0
+                sign.append(act(i + 1) > 0)
+            li += 1
+        elif kind_i == 2:                         # PV_OP_MAXPOOL2
+            off, h, w, c = rows[i][4], rows[i][1], rows[i][2], rows[i][3]
+            assert off >= 0, "max-pool %d keeps no winner bytes: not a stack the masked comparison covers" % i
+            n = batch * h * w * c
+            pool_of[li - 1] = len(win)
+            win.append(eng.ws[off:off + n].view(batch, h, w, c).permute(0, 3, 1, 2).cpu().long())
+            assert int(win[-1].max()) <= 3
+    return orc.ConvDecisions(sign=sign, win=win, pool_of=pool_of)
+
+
+def masked_conv_check(eng, kind, batch, grads_of, what, slack=None):
+    """grads_of(dtype, decisions) -> {key: gradient} of the oracle.  Asserts the conv-stack gradients under the HIP forward's
+    decisions and the flip counts; returns the numbers (also written to gpurun_out/ for profiles/)."""
+    hip = hip_conv_decisions(eng, batch, kind)
+    rec64, rec32 = orc.ConvDecisions(), orc.ConvDecisions()
+    grads_of(torch.float64, rec64, False)           # (forward only: what each arithmetic decides for itself)
+    grads_of(torch.float32, rec32, False)
+    f_hip, f_32 = rec64.flips(hip), rec64.flips(rec32)
+    ref = grads_of(torch.float64, orc.ConvDecisions(sign=hip.sign, win=hip.win, pool_of=hip.pool_of))
+    g32 = grads_of(torch.float32, orc.ConvDecisions(sign=hip.sign, win=hip.win, pool_of=hip.pool_of))
+    lines = ["%s: decisions that differ from the float64 oracle's — HIP forward: %d signs + %d winners; fp32 oracle: %d signs + %d winners"
+             " (of %d / %d)" % (what, f_hip[0], f_hip[1], f_32[0], f_32[1], f_hip[2], f_hip[3])]
+    worst, worst_key = 0.0, None
+    for key in ref:
+        if ".feature_extractor." not in key and "features2latent" not in key:
+            continue
+        e32m = rel_l2(g32[key], ref[key])
+        err = rel_l2(eng.grad_of(key), ref[key].float())
+        bar = max(RTOL_GRAD, 2 * e32m)
+        lines.append("  %-52s HIP %.2e   fp32 oracle %.2e   bar %.1e" % (key, err, e32m, bar))
+        if err / bar > worst:
+            worst, worst_key = err / bar, key
+    n_hip, n_32 = f_hip[0] + f_hip[1], f_32[0] + f_32[1]
+    lines.append("  worst err / bar %.2f" % worst)
+    os.makedirs(os.path.join(ROOT_DIR, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT_DIR, "gpurun_out", "grad_margin_masked.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
+    assert worst < 1.0, "%s (equal decisions): grad %s at %.2f of its bar\n%s" % (what, worst_key, worst, "\n".join(lines))
+    assert n_hip <= 2 * n_32 + 32, "%s: the HIP forward flips %d decisions against float64, the fp32 oracle %d" % (what, n_hip, n_32)
+    return n_hip, n_32, worst
+
+
 @pytest.mark.parametrize("fused,draw", [(0, "seed0"), (2, "seed0"), (2, "seed7"), (2, "blobs"), (20, "seed0"), (3, "seed0")])
 def test_full_size_c4_conv_encoder(gpu_device, fused, draw):
     """BASELINE config 4 at its own shape and per-GPU batch: iVAE 64x64 ['r','t','s'] + set_encoder(convEncoderNet)
@@ -1358,6 +1440,14 @@ def test_full_size_c4_conv_encoder(gpu_device, fused, draw):
     eng.loss_and_grads(xg, eg)
     tol = (lambda key: 3e-2) if fused == 3 else (lambda key: full_size_tol(key, e32))
     _grads_vs_oracle(eng, {k: v.float() for k, v in ref.items()}, tol, "C4 conv-encoder iVAE 64x64 B=128 fused=%d %s" % (fused, draw))
+    if fused == 2:
+        # ... and under the HIP forward's own decisions, where the bar is max(1e-4, 2 e32m) again (both backward forms)
+        def grads_of(dt, dec, grads=True):
+            o_ = orc.SVIOracle(sd, dataclasses.replace(cfg, conv_decisions=dec), dtype=dt)
+            with torch.set_grad_enabled(grads):
+                o_.loss_and_grads(x, eps)
+            return {k: v.grad for k, v in o_.p.items()}
+        masked_conv_check(eng, "ivae", b, grads_of, "C4 conv-encoder iVAE 64x64 B=128 %s %s" % ("x3-3-3" if conv_x3 else "x3-3-1", draw))
     np.testing.assert_allclose(s[0], out["loss"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
     np.testing.assert_allclose(s[1], out["ll"].item(), rtol=1e-4 if fused == 3 else RTOL_ELBO)
     np.testing.assert_allclose(s[2], out["logpz"].item(), rtol=1e-4)
@@ -1398,6 +1488,15 @@ def test_full_size_c5_ved(gpu_device, prec, draw):
     eng.loss_and_grads(xg, eg, 1.0, yg)
     tol = (lambda key: 3e-2) if prec == "bf16" else (lambda key: full_size_tol(key, e32))
     _grads_vs_oracle(eng, {k: v.float() for k, v in ref.items()}, tol, "C5 VED 64x64->128 B=256 %s %s" % (prec, draw))
+    if prec != "bf16":
+        def grads_of(dt, dec, grads=True):
+            p_ = {k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in model.state_dict().items()}
+            with torch.set_grad_enabled(grads):
+                out_ = orc.ved_elbo(p_, cfg, x.to(dt), y.to(dt), eps.to(dt), decisions=dec)
+            if grads:
+                out_["loss"].backward()
+            return {k: v.grad for k, v in p_.items()}
+        masked_conv_check(eng, "ved", b, grads_of, "C5 VED 64x64->128 B=256 %s %s" % (prec, draw))
 
 BF16_CASES = ["ivae_28x28_rt_b256", "ivae_28x28_r_b128", "ivae_28x28_r_b32_blobs", "ivae_8x8_rts_b6", "ivae_8x8_r_b6",
               "ivae_1d16_t_b5", "ivae_8x8_rts_b6_randn", "ivae_8x8_rt_b6_beta4"]

@@ -513,3 +513,49 @@ def test_ss_oracle_epochs_match_reference_trainer(name):
     for key in o.p:      # (after several Adam steps: noise-decided entries, see above)
         check_digest(o.p[key], gold, "final." + key, rtol=1e-4, atol=1.1e-3, what=name,
                      sum_slack=1e-2 * 5e-4 * o.p[key].numel() ** 0.5)
+
+
+def test_conv_decisions_replay_reproduces_the_forward_and_counts_flips():
+    """ConvDecisions (test infrastructure of the full-size conv parity tests): a float64 forward run under its OWN recorded
+    leaky-ReLU signs and max-pool winners reproduces loss and gradients; so does the form a HIP step hands over (the sign of a
+    conv + pool pair known at the pooled resolution only); the flip counter sees exactly the decisions that were changed."""
+    cfg = orc.VedConfig(input_dim=(16, 16), output_dim=(32,), latent_dim=2)
+    model = pv.models.VED((16, 16), (32,), seed=3, device="cpu")
+    g = torch.Generator().manual_seed(0)
+    x, y, eps = torch.rand(3, 1, 16, 16, generator=g), torch.rand(3, 1, 32, generator=g), torch.randn(3, 2, generator=g)
+
+    def run(decisions):
+        p_ = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.state_dict().items()}
+        out = orc.ved_elbo(p_, cfg, x.double(), y.double(), eps.double(), decisions=decisions)
+        out["loss"].backward()
+        return out["loss"].item(), {k: v.grad for k, v in p_.items()}
+    rec = orc.ConvDecisions()
+    loss0, g0 = run(rec)
+    assert len(rec.sign) == 5 and len(rec.win) == 2 and rec.flips(rec)[:2] == (0, 0)
+    loss_plain, g_plain = run(None)
+    assert loss_plain == loss0
+    # replay, full-resolution signs
+    loss1, g1 = run(orc.ConvDecisions(sign=rec.sign, win=rec.win))
+    np.testing.assert_allclose(loss1, loss0, rtol=1e-13)
+    for k in g0:
+        np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=1e-10, atol=1e-13)
+    # replay, the pooled pairs' signs at the pooled resolution (what a fused conv + pool epilogue leaves behind)
+    pooled_after = {0: 0, 2: 1}                        # conv index -> pool index (blocks (32,), (64, 64), (128, 128))
+    sign_p = [orc.ConvDecisions.pick(s_.to(torch.int8), rec.win[pooled_after[i]]).bool() if i in pooled_after else s_
+              for i, s_ in enumerate(rec.sign)]
+    hip_like = orc.ConvDecisions(sign=sign_p, win=rec.win)
+    loss2, g2 = run(hip_like)
+    np.testing.assert_allclose(loss2, loss0, rtol=1e-13)
+    for k in g0:
+        np.testing.assert_allclose(g2[k].numpy(), g0[k].numpy(), rtol=1e-10, atol=1e-13)
+    assert rec.flips(hip_like)[:2] == (0, 0)
+    # three flipped winners and two flipped signs are counted as such — and change the gradients
+    win_f = [w.clone() for w in rec.win]
+    win_f[1].view(-1)[:3] = (win_f[1].view(-1)[:3] + 1) % 4
+    sign_f = [s_.clone() for s_ in rec.sign]
+    sign_f[3].view(-1)[:2] = ~sign_f[3].view(-1)[:2]
+    flipped = orc.ConvDecisions(sign=sign_f, win=win_f)
+    ds, dw, ns, nw = rec.flips(flipped)
+    assert dw == 3 and 2 <= ds <= 5 and ns > 0 and nw == rec.win[0].numel() + rec.win[1].numel()
+    _, g3 = run(flipped)
+    assert max(float((g3[k] - g0[k]).norm() / g0[k].norm()) for k in g0 if "feature_extractor" in k) > 1e-6
