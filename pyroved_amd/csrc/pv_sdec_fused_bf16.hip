@@ -57,7 +57,8 @@ typedef __attribute__((address_space(3))) short4_ lds_short4;
 #define BO_CHZ (BO_RED + 256)              // next tile's per-unit inputs, fetched by LDS-DMA a tile ahead:
 #define BO_CTP (BO_CHZ + FB_WAVES * FD_H * 4)   //   hz[b] (128 floats), tp[b] (8 of 64 floats), grid rows (16*cd of 64)
 #define BO_CGR (BO_CTP + FB_WAVES * 256)
-#define FB_LDS_BYTES (BO_CGR + FB_WAVES * 256)
+#define BO_TAILV (BO_CGR + FB_WAVES * 256)  // column-parallel tail (H231 build): column-sum vectors [3][128] + per-wave row partials [2][4][16]
+#define FB_LDS_BYTES (BO_TAILV + 2048)
 #define FB_THREADS (64 * FB_WAVES)
 #ifndef FB_GB
 #define FB_GB 2                  // output blocks per operand group of the layer loops (8 / FB_GB groups per k-block)
@@ -524,6 +525,200 @@ __device__ __forceinline__ void fb_colsum(const f32x4 (&v)[8], float* __restrict
   }
 }
 
+// ---- column-parallel tail (round 6; the H231 build) --------------------------------------------------------------------------
+// At batch 256 a workgroup owns 49 units: twelve full 4-wave tiles and ONE unit more, which row-parallel costs a whole tile's
+// dependent chain (1/13 of the launch) for one wave's work.  Here the four waves SHARE that unit, as the 8-wave kernel's tail
+// does (pv_sdec_fused_w8.hip): wave w computes the column blocks 2w, 2w + 1 of every layer (a quarter of the matrix and of the
+// transcendental instructions) and the waves exchange their 16-bit pieces through LDS.  After an exchange every wave holds the
+// unit's whole row set in exactly the registers the row-parallel form keeps, so the weight-gradient staging is the row-parallel
+// code run by one wave (wave 0: the 16 rows; wave 1: 16 zero rows — a k-step contracts 32), with the same barriers, LDS overlay
+// and image reloads as a full tile.  What differs from the row-parallel arithmetic: sums over a row's 128 columns (the logit,
+// the row-local coordinate backward) are four per-wave partial sums added in wave order, and the wave-local column sums
+// (d(wo), dL/d(hz), dWc) are 16-lane butterflies — other summation orders of the same fp32 terms.
+#ifndef FB_TAIL
+#define FB_TAIL 1                // 0: the odd last unit row-parallel, as in rounds 1-5 (A/B builds)
+#endif
+// LDS of the tail: everything lives in the GAP between the two layers' images (never an image: no reload inside the tail) — one
+// 8 KB exchange buffer (halves alternate: h0 | h1, then dpre hi | lo), three COMPACT 16-row staging arrays (the tail's weight
+// gradient contracts its 16 rows with v_mfma_f32_16x16x16_f16: no zero rows, no 64-row arrays) and the unit's d(wo) sums; the
+// other column sums and the per-wave row partials sit behind the prefetch slots (BO_TAILV)
+template <int P> struct FbTailLds {
+  using LL = FbLds<P>;
+  static constexpr int G0 = 2 * IMG_BYTES;                                       // the gap (W1h | W1l | gap | W2l | W2h)
+  static constexpr int E = G0;                                                   // exchange buffer, 2 x 4 KB
+  static constexpr int ST_ROWS16 = 16 * LDS2 * 2;                                // bytes of a compact staging array
+  static constexpr int SD = E + 8192;                                            // dL/dpre hi, lo
+  static constexpr int SA = SD + 2 * ST_ROWS16;                                  // activations (scaled rows + their factor column)
+  static constexpr int WOV = SA + ST_ROWS16;                                     // d(wo) column sums [128]
+  static constexpr int V = BO_TAILV;                                             // dL/d(hz), dWc0, dWc1 [3][128]
+  static constexpr int RP = V + 3 * FD_H * 4;                                    // row partials [2][4][16] (the logit's first, then d0 | d1)
+  static_assert(LL::NST == 3 && LL::OV && LL::W1L + IMG_BYTES == G0 && LL::W2L == G0 + LL::GAP, "the tail's LDS map is written for the three-array overlay (H231)");
+  static_assert(WOV + FD_H * 4 <= G0 + LL::GAP, "exchange buffer + compact staging + d(wo) fit in the gap");
+  static_assert(FB_WAVES * 16 * 36 * 4 <= 2 * ST_ROWS16 && FB_WAVES * 16 * 36 * 4 <= IMG_BYTES, "fb_tail_colsum's transpose buffers");
+  static_assert(RP + 2 * 4 * 16 * 4 <= FB_LDS_BYTES && FB_LDS_BYTES <= 160 * 1024, "tail vectors");
+};
+__device__ __forceinline__ float fb_row16_sum(float v) {       // sum over the 16 lanes of a row (all lanes end with it)
+#define FB_DPP_F(X, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), (CTRL), 0xF, 0xF, false))
+  v += FB_DPP_F(v, 0x128);                            // row_ror:8            lane ^ 8
+  { const float t = FB_DPP_F(v, 0x141); v += FB_DPP_F(t, 0x1B); }   // lane ^ 4
+  v += FB_DPP_F(v, 0x4E);                             // lane ^ 2
+  v += FB_DPP_F(v, 0xB1);                             // lane ^ 1
+#undef FB_DPP_F
+  return v;
+}
+// Column sums over the unit's 16 rows of the wave's two blocks v (lane (r, q): row r, columns 32 wave + 16 o + 4q + i), weighted
+// per row by up to three weight vectors (w[k][row]; null: ones): a wave-local transpose through `tmp` (16 rows x 36 floats of
+// this wave's own) — lane l sums column 32 wave + (l & 31) over rows 8 (l >> 5) .. +7, the two halves meet by one half-wave swap.
+// A 16-lane DPP butterfly per value (the first cut of this tail) cost 6 dependent VALU per value: 2.4 k cycles for the 24 sums
+// of the coordinate layer against ~0.5 k this way.
+template <int NW>
+__device__ __forceinline__ void fb_tail_colsum(const f32x4 (&v)[2], float* __restrict__ tmp, const float* __restrict__ w0,
+                                               const float* __restrict__ w1, const float* __restrict__ w2, int lane, int r, int q,
+                                               float (&out)[3]) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o) *reinterpret_cast<f32x4*>(tmp + r * 36 + 16 * o + 4 * q) = v[o];
+  __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own stores have landed
+  const int col = lane & 31, r0 = 8 * (lane >> 5);
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float x = tmp[(r0 + k) * 36 + col];
+    s0 += w0 ? x * w0[r0 + k] : x;
+    if (NW >= 2) s1 += x * w1[r0 + k];
+    if (NW >= 3) s2 += x * w2[r0 + k];
+  }
+  auto meet = [](float a) {
+    const unsigned b = __float_as_uint(a);
+    auto sw = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  };
+  out[0] = meet(s0);
+  if (NW >= 2) out[1] = meet(s1);
+  if (NW >= 3) out[2] = meet(s2);
+}
+__device__ __forceinline__ void fb_xchg_put(char* smb, int off, const bf16x4 (&mine)[2], int wave, int lane) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o) reinterpret_cast<bf16x4*>(smb + off)[(2 * wave + o) * 64 + lane] = mine[o];
+}
+__device__ __forceinline__ void fb_xchg_get(const char* smb, int off, bf16x4 (&all)[8], int lane) {
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) all[jb] = reinterpret_cast<const bf16x4*>(smb + off)[jb * 64 + lane];
+}
+// blocks 2 wave, 2 wave + 1 of a forward layer (fb_layer_fwd's arithmetic for two of its eight output blocks)
+template <int P>
+__device__ __forceinline__ void fb_tail_fwd(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
+                                            const float* __restrict__ bs, const bf16x4 (&ih)[8], f32x4 (&out)[2], int wave,
+                                            int r, int q) {
+  constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::FWD_WLO;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) out[o] = *reinterpret_cast<const f32x4*>(bs + 16 * (2 * wave + o) + 4 * q);
+  const int lbase = r * LDB + 8 * (q ^ fb_sl(r >> 2)) + 32 * wave * LDB;
+  bf16x8 wh[4][2], wl[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int off = lbase + 16 * o * LDB + 32 * (m ^ (r & 3));
+      wh[m][o] = *reinterpret_cast<const bf16x8*>(Wh + off);
+      if (WL) wl[m][o] = *reinterpret_cast<const bf16x8*>(Wl + off);
+    }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) out[o] = fb_mma<F16>(wh[m][o], bh, out[o]);
+    if (WL) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o) out[o] = fb_mma<F16>(wl[m][o], bh, out[o]);
+    }
+  }
+}
+// blocks 2 wave, 2 wave + 1 of a dgrad layer (fb_layer_dgrad's arithmetic: h x dp_hi, h x dp_lo, l x dp_hi)
+template <int P, bool AL>
+__device__ __forceinline__ void fb_tail_dgrad(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl, const bf16x4 (&ih)[8],
+                                              const bf16x4 (&il)[8], f32x4 (&out)[2], int wave, int r, int q) {
+  constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::WP == 2;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) out[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // (kb = 2 wave + o: kb >> 1 = wave, kb & 1 = o)
+  const int toff = (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q)) + 32 * (wave ^ (r >> 2));
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    bf16x8 h[2], l[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int off = toff + 32 * m * LDB + 4 * o;
+      h[o] = fb_cat(fb_tr(Wh + off), fb_tr(Wh + off + 16 * LDB));
+      if (WL) l[o] = fb_cat(fb_tr(Wl + off), fb_tr(Wl + off + 16 * LDB));
+    }
+    const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) out[o] = fb_mma<F16>(h[o], bh, out[o]);
+    if (AL) {
+      const bf16x8 bl = fb_cat(il[2 * m], il[2 * m + 1]);
+#pragma unroll
+      for (int o = 0; o < 2; ++o) out[o] = fb_mma<F16>(h[o], bl, out[o]);
+    }
+    if (WL) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o) out[o] = fb_mma<F16>(l[o], bh, out[o]);
+    }
+  }
+}
+// the tail's weight gradient: dW[j][k] += sum over the unit's 16 rows of dpre[row][j] h[row][k] (+ the bias gradient against the
+// rows' factor column) from COMPACT staging arrays (dpre hi | dpre lo at sd, activations at sa; fb_stage_store's row layout) with
+// the 16-row matrix instruction — fb_wgrad_consume's arithmetic for one half k-step
+template <int P>
+__device__ __forceinline__ void fb_wgrad_consume16(const __bf16* sd, const __bf16* sa, f32x4 (&accW)[2][8], f32x4 (&accB)[2],
+                                                   int wave, int r, int q) {
+  static_assert(FbP<P>::F16 && FbP<P>::BIAS_LO && !FbP<P>::WG3, "H231");
+  const int toff = fb_stage_toff(r, q);
+  auto tr4 = [](const __bf16* p_) { return __builtin_bit_cast(half4_, fb_tr(p_)); };
+  half4_ a_h[2], a_l[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    a_h[s_] = tr4(sd + toff + 32 * wave + 16 * s_);
+    a_l[s_] = tr4(sd + 16 * LDS2 + toff + 32 * wave + 16 * s_);
+  }
+  const half4_ bias_b = tr4(sa + toff + 16 * 8);
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    accB[s_] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h[s_], bias_b, accB[s_], 0, 0, 0);
+    accB[s_] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_l[s_], bias_b, accB[s_], 0, 0, 0);
+  }
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    const half4_ b = tr4(sa + toff + 16 * kb);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) accW[s_][kb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h[s_], b, accW[s_][kb], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void fb_tanh2(f32x4 (&v)[2], float c) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[o][i] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[o][i] * c) + 1.0f);
+}
+// two blocks -> fp16 pieces (fb_presplit's arithmetic)
+template <bool LO>
+__device__ __forceinline__ void fb_presplit2(const f32x4 (&v)[2], bf16x4 (&h)[2], bf16x4 (&l)[2]) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const half4_ hh = __builtin_convertvector(v[o], half4_);
+    h[o] = __builtin_bit_cast(bf16x4, hh);
+    if (LO) {
+      typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+      const u32x2_ hu = __builtin_bit_cast(u32x2_, hh);
+      u32x2_ lu;
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lu[0]) : "v"(hu[0]), "v"(v[o][0]));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu[0]) : "v"(hu[0]), "v"(v[o][1]));
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lu[1]) : "v"(hu[1]), "v"(v[o][2]));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu[1]) : "v"(hu[1]), "v"(v[o][3]));
+      l[o] = __builtin_bit_cast(bf16x4, lu);
+    }
+  }
+}
+
 // phase-timing trace (profiling only, enabled by PV_FD_ABLATE bit 256): shader-clock stamps of workgroup 0 /
 // wave 0 for its first tiles; read back with pv_debug_read_trace()
 __device__ long long fb_trace[256];
@@ -538,9 +733,15 @@ __device__ long long fb_trace[256];
     if ((f.ablate & 256) && blockIdx.x == 0 && threadIdx.x == 0)                           \
       fb_trace[200 + (k)] = (long long)__builtin_readcyclecounter();                       \
   } while (0)
+#define FB_TSTAMP(k)                                                                       \
+  do {                                                                                     \
+    if ((f.ablate & 256) && blockIdx.x == 0 && threadIdx.x == 0)                           \
+      fb_trace[160 + (k)] = (long long)__builtin_readcyclecounter();                       \
+  } while (0)
 #else
 #define FB_STAMP(k) do { } while (0)     // (the stamps split basic blocks: compiled in only for scripts/gpu_trace.py)
 #define FB_KSTAMP(k) do { } while (0)
+#define FB_TSTAMP(k) do { } while (0)    // (the column-parallel tail's phases)
 #endif
 
 // stand-alone form of the per-step preparation (pv_fb_layout.h); the SVI step runs it inside the encoder's
@@ -654,8 +855,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     while (p_.loc >= upb) { p_.loc -= upb; ++p_.b; }
     if (f.x_units > 0) { while (p_.xu >= f.x_units) p_.xu -= f.x_units; }
   };
-  const Pos pos_lo = pos_of(u_lo);                      // what an out-of-range wave fetches instead (valid, unused)
-  Pos pos_cur = pos_of(u_lo + wave < u_hi ? u_lo + wave : u_lo);
+  // (H231 build) a range of 4 n + 1 units ends with a column-parallel tail (below): the row-parallel tiles cover [u_lo, u_end), and
+  // what a wave without a further unit prefetches is the TAIL unit's inputs (every wave takes part in the tail)
+  constexpr bool TAIL = FB_TAIL && GRADS && PREC == FB_P_H231;
+  const bool has_tail = TAIL && ((u_hi - u_lo) & (TILE_UNITS - 1)) == 1 && !(f.ablate & 512);   // (ablate: experiments build only)
+  const int64_t u_end = has_tail ? u_hi - 1 : u_hi;
+  const Pos pos_lo = pos_of(has_tail ? u_end : u_lo);   // what an out-of-range wave fetches instead (valid; unused without a tail)
+  Pos pos_cur = pos_of(u_lo + wave < u_end ? u_lo + wave : (has_tail ? u_end : u_lo));
   Pos pos_nx = pos_cur;
   // the wave's observations are fetched one tile ahead (an HBM miss, and loads retire in order: fetched in the
   // tile itself it would hold up the coordinate layer's own small loads)
@@ -681,10 +887,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   fetch_unit_inputs(pos_cur);
   int tile_no = -1;
   FB_KSTAMP(1);                                                          // prologue done
-  for (int64_t ut = u_lo; ut < u_hi; ut += TILE_UNITS) {
+  for (int64_t ut = u_lo; ut < u_end; ut += TILE_UNITS) {
     ++tile_no;
     FB_STAMP(0);
-    const int nact = (int)((u_hi - ut) < TILE_UNITS ? (u_hi - ut) : TILE_UNITS);
+    const int nact = (int)((u_end - ut) < TILE_UNITS ? (u_end - ut) : TILE_UNITS);
     if (ut + TILE_UNITS + wave < u_hi) advance(pos_nx, TILE_UNITS);     // the unit this wave fetches for the NEXT tile
     else pos_nx = pos_lo;
     int opq = 0;
@@ -924,6 +1130,230 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     FB_STAMP(22);
     if (OV) __syncthreads();   // the staging area is free again (the next tile's W2 reload lands here)
     FB_STAMP(13);
+  }
+  if constexpr (TAIL) {
+    if (has_tail) {
+      // ================= column-parallel tail: ONE unit, four waves (helpers above the kernel) =================
+      using TL = FbTailLds<PREC>;
+      ++tile_no;
+      const float* Wc0 = vec;
+      const float* Wc1 = vec + FD_H;
+      const float* bcs = vec + 2 * FD_H;
+      const float* wos = vec + 3 * FD_H;
+      const float* b1s = vec + 4 * FD_H;
+      const float* b2s = vec + 5 * FD_H;
+      const int bu = pos_cur.b;                          // (every wave's prefetch slots hold the tail unit's inputs)
+      const int64_t row = (int64_t)u_end * FD_UNIT + r;
+      float x0, x1, u0c, u1c, sc;
+      fb_wait_vm0();
+      if (f.cd == 2) {
+        const float gx = cgr[2 * r], gy = cgr[2 * r + 1];
+        u0c = gx * ctp[0] - gy * ctp[1];
+        u1c = gx * ctp[1] + gy * ctp[0];
+        sc = ctp[2];
+        x0 = u0c * sc + ctp[3];
+        x1 = u1c * sc + ctp[4];
+      } else {
+        u0c = cgr[r]; u1c = 0.0f; sc = 1.0f;
+        x0 = u0c + ctp[3]; x1 = 0.0f;
+      }
+      FB_TSTAMP(0);
+      const float xv = xv_next, swv = sw_next;
+      f32x4 h0o[2], h1o[2], h2o[2], t2[2];
+      bf16x4 oh[2], ol[2], pH0[8], pH1[8], pAh[8], pAl[8];
+      const bf16x4 z4 = __builtin_bit_cast(bf16x4, short4_{0, 0, 0, 0});
+      // ---- coordinate layer, own blocks ----
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const int j = 16 * (2 * wave + o) + 4 * q;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc0 + j);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc1 + j);
+        const f32x4 bc = *reinterpret_cast<const f32x4*>(bcs + j);
+        const f32x4 hz = *reinterpret_cast<const f32x4*>(chz + j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h0o[o][i] = w0[i] * x0 + w1[i] * x1 + bc[i] + hz[i];
+      }
+      fb_tanh2(h0o, FB_C);
+      fb_presplit2<false>(h0o, oh, ol);
+      fb_xchg_put(smb, TL::E, oh, wave, lane);
+      if (tile_no > 0) {                                  // W2's lo image was the previous tile's staging area
+        fb_wait_vm0();
+        fb_reload<LL::RL_BYTES>(gimg + LL::RL2_SRC, lds0 + LL::RL2_LDS, wave, lane);
+      }
+      FB_TSTAMP(1);
+      __syncthreads();                                                   // exchange 0: h0
+      FB_TSTAMP(2);
+      fb_xchg_get(smb, TL::E, pH0, lane);
+      fb_tail_fwd<PREC>(W1h, W1l, b1s, pH0, h1o, wave, r, q);
+      fb_tanh2(h1o, c1);
+      fb_presplit2<false>(h1o, oh, ol);
+      fb_xchg_put(smb, TL::E + 4096, oh, wave, lane);
+      FB_TSTAMP(3);
+      fb_wait_vm0();
+      FB_TSTAMP(4);
+      __syncthreads();                                                   // exchange 1: h1; W2 landed
+      FB_TSTAMP(5);
+      fb_xchg_get(smb, TL::E + 4096, pH1, lane);
+      fb_tail_fwd<PREC>(W2h, W2l, b2s, pH1, h2o, wave, r, q);
+      fb_tanh2(h2o, c2);
+      float* rp = reinterpret_cast<float*>(smb + TL::RP);
+      {
+        f32x4 p4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < 2; ++o) p4 = p4 + h2o[o] * *reinterpret_cast<const f32x4*>(wos + 16 * (2 * wave + o) + 4 * q);
+        const float part = fb_sum_q((p4[0] + p4[1]) + (p4[2] + p4[3]));
+        if (q == 0) rp[16 * wave + r] = part;
+      }
+      FB_TSTAMP(6);
+      __syncthreads();                                                   // exchange 2: the logit's per-wave partial sums
+      FB_TSTAMP(7);
+      const float a = ((rp[r] + rp[16 + r]) + (rp[32 + r] + rp[48 + r])) + bo;
+      float ll, locv, dlda;
+      if (LIK == PV_LIK_BERNOULLI) {
+        const float pr = fb_rcp(1.0f + fb_exp(-a));
+        const float pc = fminf(fmaxf(pr, BERN_EPS), 1.0f - BERN_EPS);
+        const float lpc = fb_log(pc), l1pc = fb_log(1.0f - pc);
+        const float lg = lpc - l1pc;
+        ll = -(fmaxf(lg, 0.0f) - lg * xv - fmaxf(lpc, l1pc));
+        const float mask = (pr >= BERN_EPS && pr <= 1.0f - BERN_EPS) ? 1.0f : 0.0f;
+        dlda = (pc - xv) * mask;
+        locv = pr;
+      } else if (LIK == PV_LIK_CBERNOULLI) {
+        pv_cbern(a, xv, ll, dlda, locv);
+      } else {
+        const float pr = f.sigmoid_out ? fb_rcp(1.0f + fb_exp(-a)) : a;
+        const float d = xv - pr;
+        ll = -(d * d) / (2.0f * f.sig * f.sig) - fb_log(f.sig) - LOG_SQRT_2PI;
+        dlda = -d / (f.sig * f.sig) * (f.sigmoid_out ? pr * (1.0f - pr) : 1.0f);
+        locv = pr;
+      }
+      dlda *= swv;
+      if (q == 0 && wave == 0) {
+        if (f.llrow) f.llrow[row] = ll;
+        if (f.loc) f.loc[row] = locv;
+        dbo += dlda;
+      }
+      // d(wo)[j] += sum_rows dlda h2[row][j], own blocks (transpose buffer: this wave's quarter of the not yet staged dpre arrays)
+      {
+        float* wov = reinterpret_cast<float*>(smb + TL::WOV);
+        f32x4 pv_[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) pv_[o] = dlda * h2o[o];
+        float cs[3];
+        fb_tail_colsum<1>(pv_, reinterpret_cast<float*>(smb + TL::SD) + wave * (16 * 36), nullptr, nullptr, nullptr, lane, r, q, cs);
+        if (lane < 32) wov[32 * wave + lane] = cs[0];
+      }
+      // dL/dlogit = m 2^e: the mantissa (times kappa s_o) goes down the dgrad chain, the exponent into the staged rows
+      const int ex = __builtin_amdgcn_frexp_expf(dlda);
+      const float dn = __builtin_amdgcn_frexp_mantf(dlda) * kso;
+      const _Float16 ph = (_Float16)__builtin_amdgcn_ldexpf(1.0f, ex + f.dl_exp);
+      const half4_ ph4 = half4_{ph, ph, ph, ph};
+      const float frow = __builtin_amdgcn_ldexpf(u0, ex);
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wos + 16 * (2 * wave + o) + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t2[o][i] = dn * wv[i] * (1.0f - h2o[o][i] * h2o[o][i]);     // dpre2
+      }
+      fb_presplit2<true>(t2, oh, ol);
+      fb_xchg_put(smb, TL::E, oh, wave, lane);
+      fb_xchg_put(smb, TL::E + 4096, ol, wave, lane);
+      FB_TSTAMP(8);
+      __syncthreads();                                                   // exchange 3: dpre2 (hi, lo)
+      FB_TSTAMP(9);
+      fb_xchg_get(smb, TL::E, pAh, lane);
+      fb_xchg_get(smb, TL::E + 4096, pAl, lane);
+      // ---- weight gradients: the unit's 16 rows, staged by wave 0 in compact arrays, contracted with the 16-row instruction ----
+      __bf16* tsd = reinterpret_cast<__bf16*>(smb + TL::SD);
+      __bf16* tsa = reinterpret_cast<__bf16*>(smb + TL::SA);
+      auto stage = [&](const bf16x4 (&dh)[8], const bf16x4 (&dl)[8], const bf16x4 (&hh)[8]) {
+        if (wave == 0) {
+          fb_stage_store<true, false>(tsd, tsd + 16 * LDS2, dh, dl, r, q);
+          fb_stage_store<false, true>(tsa, tsa, hh, dl, r, q, ph4);
+        }
+      };
+      stage(pAh, pAl, pH1);
+      FB_TSTAMP(10);
+      __syncthreads();
+      FB_TSTAMP(11);
+      fb_wgrad_consume16<PREC>(tsd, tsa, accW2, accB2, wave, r, q);
+      FB_TSTAMP(12);
+      // ---- dgrad of layer 2, own blocks ----
+      fb_tail_dgrad<PREC, PP::DGR2_LO>(W2h, W2l, pAh, pAl, t2, wave, r, q);
+#pragma unroll
+      for (int o = 0; o < 2; ++o) t2[o] = t2[o] * (1.0f - h1o[o] * h1o[o]);          // dpre1 (carried scales as in the tile loop)
+      fb_presplit2<true>(t2, oh, ol);
+      fb_xchg_put(smb, TL::E, oh, wave, lane);                          // (every wave read exchange 3 before the staging barrier)
+      fb_xchg_put(smb, TL::E + 4096, ol, wave, lane);
+      FB_TSTAMP(13);
+      __syncthreads();                                                   // exchange 4: dpre1; the staged rows are consumed
+      FB_TSTAMP(14);
+      fb_xchg_get(smb, TL::E, pAh, lane);
+      fb_xchg_get(smb, TL::E + 4096, pAl, lane);
+      // ---- dgrad of layer 1, own blocks ----
+      fb_tail_dgrad<PREC, PP::DGR1_LO>(W1h, W1l, pAh, pAl, t2, wave, r, q);
+#pragma unroll
+      for (int o = 0; o < 2; ++o) t2[o] = t2[o] * (1.0f - h0o[o] * h0o[o]);          // dpre0, normalised (frow restores the row)
+      FB_TSTAMP(15);
+      stage(pAh, pAl, pH0);
+      {
+        // coordinate layer: the column sums dL/d(hz), dWc0, dWc1 of the own blocks and the row-local partial sums
+        // (transpose buffer: W2's lo image — the tail is the last tile and every wave is past the dgrad of layer 2; the rows'
+        //  weights 2^e, 2^e x0, 2^e x1 in the wave's own slots of the tile loop's `info` rows)
+        float* vv = reinterpret_cast<float*>(smb + TL::V);
+        if (q == 0) {
+          info[16 * wave + r] = frow * x0; info[TILE_ROWS + 16 * wave + r] = frow * x1; info[2 * TILE_ROWS + 16 * wave + r] = frow;
+        }
+        float cs[3];
+        fb_tail_colsum<3>(t2, reinterpret_cast<float*>(smb + LL::W2L) + wave * (16 * 36), info + 2 * TILE_ROWS + 16 * wave,
+                          info + 16 * wave, info + TILE_ROWS + 16 * wave, lane, r, q, cs);
+        if (lane < 32) {
+          vv[32 * wave + lane] = cs[0];
+          vv[FD_H + 32 * wave + lane] = cs[1];
+          vv[2 * FD_H + 32 * wave + lane] = cs[2];
+        }
+        f32x4 d04 = {0.0f, 0.0f, 0.0f, 0.0f}, d14 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const int j = 16 * (2 * wave + o) + 4 * q;
+          d04 = d04 + t2[o] * *reinterpret_cast<const f32x4*>(Wc0 + j);
+          d14 = d14 + t2[o] * *reinterpret_cast<const f32x4*>(Wc1 + j);
+        }
+        const float d0 = fb_sum_q((d04[0] + d04[1]) + (d04[2] + d04[3]));
+        const float d1 = fb_sum_q((d14[0] + d14[1]) + (d14[2] + d14[3]));
+        if (q == 0) { rp[16 * wave + r] = d0; rp[64 + 16 * wave + r] = d1; }      // (the logit's partials were read before barrier 3)
+      }
+      FB_TSTAMP(16);
+      __syncthreads();
+      FB_TSTAMP(17);
+      fb_wgrad_consume16<PREC>(tsd, tsa, accW1, accB1, wave, r, q);
+      FB_TSTAMP(18);
+      if (wave == 0) {
+        const float* vv = reinterpret_cast<const float*>(smb + TL::V);
+        const float* wov = reinterpret_cast<const float*>(smb + TL::WOV);
+        if (bu != cur_b) {
+          if (cur_b >= 0) flush_hz(cur_b);
+          cur_b = bu;
+        }
+        const float2 a0 = *reinterpret_cast<const float2*>(vv + 2 * lane);
+        const float2 a1 = *reinterpret_cast<const float2*>(vv + FD_H + 2 * lane);
+        const float2 a2 = *reinterpret_cast<const float2*>(vv + 2 * FD_H + 2 * lane);
+        const float2 aw = *reinterpret_cast<const float2*>(wov + 2 * lane);
+        cs_hz.x += a0.x; cs_hz.y += a0.y;
+        cs_c0.x += a1.x; cs_c0.y += a1.y;
+        cs_c1.x += a2.x; cs_c1.y += a2.y;
+        cs_wo.x += aw.x; cs_wo.y += aw.y;
+        if (q == 0) {
+          const float* dp = rp;
+          const float d0 = ((dp[r] + dp[16 + r]) + (dp[32 + r] + dp[48 + r])) * frow;
+          const float d1 = ((dp[64 + r] + dp[80 + r]) + (dp[96 + r] + dp[112 + r])) * frow;
+          f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
+          f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
+          f.rowtp[2 * f.M + row] = d0;
+          f.rowtp[3 * f.M + row] = d1;
+        }
+      }
+    }
   }
   FB_KSTAMP(2);                                                          // last tile done
   if (!GRADS) return;
