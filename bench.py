@@ -827,6 +827,19 @@ def main():
             main_leg = alt = None
             torch.cuda.empty_cache()
             out["configs"] = [sub_config(c, args) for c in ("C1", "C3", "C4", "C4fc", "C5")]
+            #  the per-config headline scalars also INSIDE `roofline`, the one object the driver's record
+            # keeps whole: ms per step, the arithmetic the leg computes in, the dominant kernel's and the step's fraction of peak
+            rc = {}
+            for c in out["configs"]:
+                if isinstance(c, dict) and "ms_per_step" in c:
+                    rl = c.get("roofline") or {}
+                    rc[str(c["config"])] = {
+                        "ms_per_step": round(c["ms_per_step"], 5), "dtype": c.get("dtype"), "images_s": round(c["value"]),
+                        "kernel": rl.get("kernel"), "kernel_ms": rl.get("kernel_ms"), "frac": rl.get("frac"),
+                        "step_frac": (c.get("roofline_step") or {}).get("frac", rl.get("step_frac")),
+                        "conv_frac": (c.get("roofline_conv") or {}).get("frac"),
+                        "throughput_ms_per_step": (c.get("throughput_precision") or {}).get("ms_per_step")}
+            out["roofline"]["configs"] = rc
         # the side legs' headline scalars at the FRONT of the line (the driver's record keeps the known keys and the last 2 000
         # characters) and once more as a short line on stderr, which ends the captured output
         summ = {}

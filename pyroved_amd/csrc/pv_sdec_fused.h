@@ -97,6 +97,8 @@ int pv_sdec_fused_w8h_launch(const PvFused& f, int grid, bool ds, hipStream_t s)
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel);
 // waves per workgroup that publish a dL/d(hz) slot (sizes part_hz)
 int pv_sdec_fused_bf16_waves(bool x3, int64_t units, int sel);
+// whether the training launch of (x3, units, sel) writes PACKED gradient records (the 8-wave plain-bf16 kernel does)
+bool pv_sdec_fused_bf16_records_packed(bool x3, int64_t units, int sel);
 // whether `sel` (pv_ivae_plan.dec_kernel) names a decoder-kernel build this library contains for the fused mode
 bool pv_sdec_fused_sel_valid(int fused, int sel);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
@@ -108,13 +110,56 @@ int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOff
 // 64 float4 outputs x 4 slices of the workgroup range per 256-thread block (a wave reads 1 KB per record, eight
 // records in flight); slices combined in fixed order
 #define PV_FUSED_REDUCE_BLOCKS (((2 * FD_H * FD_H + 5 * FD_H + 1 + 3) / 4 + 63) / 64)
+// (round 6) PACKED records — the throughput kernel's (pv_sdec_fused_w8.hip): the two HxH weight-gradient partials as bf16 pairs,
+// word [m][row / 2][col] = (dW_m[row & ~1][col], dW_m[row | 1][col]) in the record's first H*H floats (the weights they update were
+// rounded to bf16 in the forward anyway; the reader sums in fp32), everything from float 2*H*H on unchanged.  Half the bytes a
+// decoder launch writes and the next launch reads (41 of the 49 MB were these matrices).
+#define PV_FUSED_REDUCE_MAT_BLOCKS_PACKED ((2 * (FD_H / 2) * FD_H / 4) / 64)            // 16-byte chunks of the packed matrices / 64
+#define PV_FUSED_REDUCE_BLOCKS_PACKED (PV_FUSED_REDUCE_MAT_BLOCKS_PACKED + ((5 * FD_H + 1 + 3) / 4 + 63) / 64)
+__host__ __device__ inline int pv_fused_reduce_blocks(int packed) { return packed ? PV_FUSED_REDUCE_BLOCKS_PACKED : PV_FUSED_REDUCE_BLOCKS; }
+__device__ __forceinline__ void pv_sdec_fused_reduce_block_packed(const float* __restrict__ part, int G_, float* __restrict__ Gr,
+                                                                  const PvFusedOffsets& o, int block, f32x4 (*sm)[64]) {
+  // chunk ch = 16 bytes = 4 words = columns 4 c4 .. +3 of the row pair rp of matrix m: 8 outputs
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int ch = block * 64 + c;                                   // < 2 * 64 * 32
+  const int per = (G_ + 3) / 4;
+  const int w0 = sl * per, w1 = min(G_, w0 + per);
+  f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = {0.0f, 0.0f, 0.0f, 0.0f};
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  const float* pbase = part + 4 * ch;
+#pragma unroll 8
+  for (int w = w0; w < w1; ++w) {
+    const u32x4_ v = *reinterpret_cast<const u32x4_*>(pbase + (int64_t)w * FD_REC);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] += __uint_as_float(v[i] << 16);                         // row 2 rp
+      hi[i] += __uint_as_float(v[i] & 0xffff0000u);                 // row 2 rp + 1
+    }
+  }
+  // two passes through the 4-slice combine buffer (fixed order, as the fp32 form)
+  f32x4 tot[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    sm[sl][c] = h == 0 ? lo : hi;
+    __syncthreads();
+    tot[h] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    __syncthreads();
+  }
+  if (sl != 0) return;
+  const int m = ch / (64 * 32), rp = (ch / 32) % 64, c4 = ch % 32;
+  float* dst = Gr + (m == 0 ? o.W1 : o.W2) + (2 * rp) * FD_H + 4 * c4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dst[i] = tot[0][i]; dst[FD_H + i] = tot[1][i]; }
+}
 __device__ __forceinline__ void pv_sdec_fused_reduce_block(const float* __restrict__ part, int G_,
                                                            float* __restrict__ Gr, const PvFusedOffsets& o, int cd,
-                                                           int dwo_slots, int block, f32x4 (*sm)[64]) {
+                                                           int dwo_slots, int block, f32x4 (*sm)[64], int packed = 0) {
   const int HH = FD_H * FD_H;
   const int total = 2 * HH + 5 * FD_H + 1;          // the record is padded well past this: whole float4s are readable
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int e = (block * 64 + c) * 4;
+  if (packed && block < PV_FUSED_REDUCE_MAT_BLOCKS_PACKED) { pv_sdec_fused_reduce_block_packed(part, G_, Gr, o, block, sm); return; }
+  // (packed: the blocks behind the matrices' take the vectors, which sit at float 2*H*H as in the fp32 form)
+  const int e = packed ? 2 * HH + ((block - PV_FUSED_REDUCE_MAT_BLOCKS_PACKED) * 64 + c) * 4 : (block * 64 + c) * 4;
   const int per = (G_ + 3) / 4;
   const int w0 = sl * per, w1 = min(G_, w0 + per);
   f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};

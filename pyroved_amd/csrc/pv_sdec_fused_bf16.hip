@@ -776,11 +776,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   const char* gimg = reinterpret_cast<const char*>(f.wimg);
 
   // ---- weight images by LDS-DMA, fp32 vectors by hand ----
+  // (round 6) Training launches of the two-piece builds wait for W2's images in every tile anyway (the barrier in front of the
+  // forward of layer 2: they are reloaded per tile), so the prologue only waits for W1's: W2's 64 KB are requested LAST — behind
+  // the vectors, the first unit's observations and its prefetch slots — and land under the first tile's coordinate layer and
+  // forward of layer 1.
+  constexpr bool LATE_W2 = OV && GRADS;
   fb_reload<IMG_BYTES>(gimg, lds0 + LL::W1H, wave, lane);
-  fb_reload<IMG_BYTES>(gimg + 2 * IMG_BYTES, lds0 + LL::W2H, wave, lane);
+  if (!LATE_W2) fb_reload<IMG_BYTES>(gimg + 2 * IMG_BYTES, lds0 + LL::W2H, wave, lane);
   if (PP::WP == 2) {
     fb_reload<IMG_BYTES>(gimg + IMG_BYTES, lds0 + LL::W1L, wave, lane);
-    fb_reload<IMG_BYTES>(gimg + 3 * IMG_BYTES, lds0 + LL::W2L, wave, lane);
+    if (!LATE_W2) fb_reload<IMG_BYTES>(gimg + 3 * IMG_BYTES, lds0 + LL::W2L, wave, lane);
   }
   // fp16 modes: the images' power-of-two scales (written by the preparation, pv_fb_layout.h); everything derived from them
   // is wave-uniform.  The forward un-scales in tanh's multiply (c1, c2); the backward carries kso * m down the dgrad chain
@@ -803,8 +808,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     vec[4 * FD_H + j] = f.b1[j] * s1;
     vec[5 * FD_H + j] = f.b2[j] * s2;
   }
-  fb_wait_vm0();
-  __syncthreads();
+  if (!LATE_W2) {
+    fb_wait_vm0();
+    __syncthreads();
+  }
   const float bo = f.bo[0];
 
   // persistent accumulators: dW1 / dW2 rows 16*(2*wave + s) .. +15, s = 0, 1 ; bias sums likewise
@@ -885,6 +892,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     fb_glds4(f.grid + (int64_t)n0 * f.cd + (lane & (16 * f.cd - 1)), lds0 + BO_CGR + wave * 256);
   };
   fetch_unit_inputs(pos_cur);
+  if (LATE_W2) {
+    // everything requested so far lands (W1's images, the first unit's observations and slots) — the observation registers are
+    // touched here so that the compiler's own wait for them stands HERE and not at their first use inside the tile, where it
+    // would drain W2's requests as well — then W2's images are requested and the tile loop starts without waiting for them
+    fb_wait_vm0();
+    asm volatile("" : "+v"(xv_next), "+v"(sw_next));
+    fb_reload<IMG_BYTES>(gimg + 2 * IMG_BYTES, lds0 + LL::W2H, wave, lane);
+    fb_reload<IMG_BYTES>(gimg + 3 * IMG_BYTES, lds0 + LL::W2L, wave, lane);
+    __syncthreads();
+  }
   int tile_no = -1;
   FB_KSTAMP(1);                                                          // prologue done
   for (int64_t ut = u_lo; ut < u_end; ut += TILE_UNITS) {
@@ -908,7 +925,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     const int bu = pos_cur.b;
     const int64_t row = (int64_t)unit * FD_UNIT + r;
     float x0, x1, u0c, u1c, sc;
-    fb_wait_vm0();                        // this wave's LDS-DMA of the tile's inputs (issued a tile ago)
+    // this wave's LDS-DMA of the tile's inputs (issued a tile ago; first tile: in front of W2's images, which stay in flight)
+    if (!(LATE_W2 && tile_no == 0)) fb_wait_vm0();
     {
       const float* t = ctp + opq;
       const float* gr = cgr + opq;
@@ -1517,6 +1535,10 @@ static int fb_kind_prec(int kind) {
 int pv_sdec_fused_bf16_waves(bool x3, int64_t units, int sel) {
   const int kind = x3 ? fb_x3_kind(units, true, sel) : 0;
   return (x3 ? (kind == 8 || fb_kind_w8h(kind)) : fb_use_w8(units, sel)) ? 8 : FB_WAVES;
+}
+bool pv_sdec_fused_bf16_records_packed(bool x3, int64_t units, int sel) {
+  static const int ablate = pv_exp_int("PV_FD_ABLATE", 0);          // (bit 1024: fp32 records from the 8-wave kernel, experiments build)
+  return !x3 && fb_use_w8(units, sel) && !(ablate & 1024);
 }
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel) {
 #ifdef PV_EXPERIMENTS

@@ -1298,19 +1298,40 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
   {
     const int jp = wave >> 1, kh = wave & 1;
+    // PACKED (pv_sdec_fused.h): rows 2k, 2k + 1 of a column as one word of two bf16 (round to nearest even) — the lane's
+    // registers i = 0, 1 and 2, 3 are such pairs: 32 four-byte stores per matrix and wave where the fp32 form issued 64
+    unsigned* recw = reinterpret_cast<unsigned*>(rec);
+    auto pack2 = [](float a, float b) {
+      typedef __bf16 bf2_ __attribute__((ext_vector_type(2)));
+      bf2_ h; h[0] = (__bf16)a; h[1] = (__bf16)b;
+      return __builtin_bit_cast(unsigned, h);
+    };
+    if (f.ablate & 1024) {                       // (experiments build: the fp32 form, for the A/B of profiles/r06*_records_ab.txt)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = (32 * jp + 16 * (s_ ^ kh) + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
+            rec[e] = accW1[s_][o][i] * -W8_RC;
+            rec[FD_H * FD_H + e] = accW2[s_][o][i];
+          }
+    } else
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
       for (int o = 0; o < 4; ++o)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int ip = 0; ip < 2; ++ip) {
           // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16 (s ^ kh) + 4q + i][64kh + 16o + r]  (w8_wgrad_consume's rotation)
-          const int e = (32 * jp + 16 * (s_ ^ kh) + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
+          const int rp = (32 * jp + 16 * (s_ ^ kh) + 4 * q + 2 * ip) >> 1;
+          const int e = rp * FD_H + 64 * kh + 16 * o + r;
 #if W8_ABL & 8
-          if (accW1[s_][o][i] == 1.2345e30f) rec[e] = accW2[s_][o][i];      // (timing ablation: no record stores)
+          if (accW1[s_][o][2 * ip] == 1.2345e30f) recw[e] = pack2(accW2[s_][o][2 * ip], 0.0f);      // (timing ablation: no record stores)
 #else
-          rec[e] = accW1[s_][o][i] * -W8_RC;                        // (accW1 / accB1 hold -C dW1 / -C db1)
-          rec[FD_H * FD_H + e] = accW2[s_][o][i];
+          recw[e] = pack2(accW1[s_][o][2 * ip] * -W8_RC, accW1[s_][o][2 * ip + 1] * -W8_RC);   // (accW1 / accB1 hold -C dW1 / -C db1)
+          recw[(FD_H / 2) * FD_H + e] = pack2(accW2[s_][o][2 * ip], accW2[s_][o][2 * ip + 1]);
 #endif
         }
     if (r == 0) {
@@ -1366,7 +1387,8 @@ bool pv_sdec_fused_w8_fold_ok(const PvFused& f, int grid) {
 
 int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream_t s, const PvEncFold* fold) {
   PvFused f = f_in;
-  f.ablate = 0;
+  static const int ablate = pv_exp_int("PV_FD_ABLATE", 0) & 1024;    // (experiments build: fp32 records, see the record stores)
+  f.ablate = ablate;
   const size_t lds = W8_LDS_BYTES;
   const void* fn = nullptr;
   PvEncFold e{};

@@ -1237,8 +1237,15 @@ def test_full_size_properties(gpu_device, cfgname, fused):
     #  summation order than the encoder launch the half batches take; under bf16 decoder operands a last-bit change of z moves
     #  roundings: measured 2.9e-6 there, 2e-6 everywhere else)
     folds = fused == 3 and bool(_abi.lib().pv_ivae_guide_folds(C.byref(eng._plan(b))))
-    assert rel_l2(g0 + g1, g_full) < (6e-6 if folds else 2e-6)
+    # (round 6: the throughput kernel writes its per-workgroup partial sums of the two hidden matrices' gradients as bf16 pairs —
+    #  half the record traffic, C2 0.1015 -> 0.0995 ms.  A partial is then rounded to 2^-9 before the cross-workgroup sum, so two
+    #  shardings of a batch agree to ~1e-4 of the gradient instead of to fp32 summation order — inside the mode's own distance
+    #  from the fp32 gradients (2e-4 .. 1.5e-2, test_bf16_mode_steps_vs_golden_and_oracle); the fp32-class paths keep 2e-6.)
+    assert rel_l2(g0 + g1, g_full) < (BF16_SHARD_TOL if fused == 3 else 2e-6)
     assert torch.isfinite(g_full).all()
+
+
+BF16_SHARD_TOL = 3e-4      # shard additivity of the throughput mode's gradients (packed bf16 partial records; see test_full_size_properties)
 
 
 def _props(eng, call, n_samples, sl):
@@ -1291,7 +1298,7 @@ def test_full_size_c3_jivae(gpu_device, fused):
     torch.manual_seed(1)
     eps = torch.empty(b, model.z_dim).normal_()
     xg, eg = x.cuda(), eps.cuda()
-    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 5e-6)
+    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, BF16_SHARD_TOL if fused == 3 else 5e-6)
     cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, discrete_dim=k_)
     # (round 3) the oracle's BACKWARD at this size too (4.0 M decoder rows under autograd: ~12 GB, tens of seconds on 8
     # threads): every gradient tensor, not only the scalars — a size-dependent but deterministic and additive gradient bug
@@ -1425,7 +1432,7 @@ def test_full_size_c4_conv_encoder(gpu_device, fused, draw):
     xg, eg = x.cuda(), eps.cuda()
     # (shard additivity: the half batches are 262 k decoder rows — the H231 build of the fp32-class kernel — the full batch 524 k,
     #  from which the one-piece-activation H221 build runs since round 5: two roundings of the same sums, 8e-6 apart)
-    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 2e-5 if fused == 2 else 5e-6)
+    s = _props(eng, lambda lo, hi: eng.loss_and_grads(xg[lo:hi], eg[lo:hi]), b, 2e-5 if fused == 2 else (BF16_SHARD_TOL if fused == 3 else 5e-6))
     cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv, conv_encoder=hid)
     # (round 3) backward at size too.  At 0.5 M decoder rows / 0.5 M conv pixels per layer the fp32 CPU oracle is itself
     # 1e-4 .. 2e-4 off float64 on the encoder tensors (sums of ~1e6 cancelling terms): the float64 oracle is the truth here,
