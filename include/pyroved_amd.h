@@ -257,6 +257,13 @@ int pv_experiments_build(void);
 #define PV_PLAN_ENC_NO_WAIT    4
 #define PV_PLAN_NO_DEC1D       8
 #define PV_PLAN_NO_ENC_FOLD    16
+/* (v16) PV_PLAN_ENC_TILED: keep the tiled one-launch fc encoder (first-layer tiles on the matrix cores + per-tile flags) for the
+ *   guide of a training step.  By default a step of up to 512 samples with the plain two-hidden-layer fc encoder on a fused
+ *   decoder path runs its guide as ONE launch with one workgroup per image (fp32 matrix-vector products straight from the
+ *   L2-resident weights, no cross-workgroup hand-off: 11-13 us where the tiled form spends 18-19 us of dependent latency);
+ *   PV_PLAN_ENC_TWO_LAUNCH / PV_PLAN_ENC_NO_WAIT, which are about the tiled form, imply it.  Results agree to fp32 rounding
+ *   (another summation order), not bit for bit.  Matches models/ivae.py:204-221, nets/fc.py:51-61. */
+#define PV_PLAN_ENC_TILED      32
 /* (v15) PV_PLAN_CONV_X3 (pv_ivae_plan with a convolutional encoder; pv_ved_plan / pv_convnet_plan say it as conv_bf16 == 0): the
  *   fp32-class kernel-3 convolutions with BOTH operands as two fp16 pieces and three products per multiply-add in EVERY direction
  *   (rounds 2-4's form, 3e-7 per convolution vs float64).  Default since round 5 (conv_bf16 == 4): the FORWARD unchanged (its outputs

@@ -17,6 +17,7 @@ PV_ABI_VERSION = 16
 # pv_ivae_plan.flags / pv_ved_plan.flags / pv_convnet_plan.flags
 PV_PLAN_ENC_TWO_LAUNCH, PV_PLAN_NO_SIDE_STREAM, PV_PLAN_ENC_NO_WAIT, PV_PLAN_NO_DEC1D, PV_PLAN_NO_ENC_FOLD = 1, 2, 4, 8, 16
 PV_PLAN_CONV_X3 = 64
+PV_PLAN_ENC_TILED = 32
 PV_MAX_LAYERS = 8
 
 # enum pv_act / pv_lik (include/pyroved_amd.h)

@@ -742,9 +742,15 @@ int guide_fwd(const pv_ivae_plan* p, const Layout& L, hipStream_t s, const PvFbP
 
 // the plan-side conditions of the folded guide (PvEncFold): plain-bf16 fused decoder, the plain two-hidden-layer fc encoder, no
 // conditioning vector / discrete latent / per-sample weights; the launch-side ones are pv_sdec_fused_fold_ok's
+// (plan_guide_one_image: the architecture one workgroup can run a whole image's guide for — the fold in the decoder launch and the
+//  per-image guide launch, pv_guide_img.hip)
+static bool plan_guide_one_image(const pv_ivae_plan* p, const Layout& L);
 static bool plan_guide_may_fold(const pv_ivae_plan* p, const Layout& L) {
+  return p->fused == 3 && !(p->flags & PV_PLAN_NO_ENC_FOLD) && plan_guide_one_image(p, L);
+}
+static bool plan_guide_one_image(const pv_ivae_plan* p, const Layout& L) {
   const int64_t z = p->z_dim;
-  return p->fused == 3 && L.fused && L.enc_compact && !L.enc_ext && !(p->flags & PV_PLAN_NO_ENC_FOLD) && plan_K(p) == 0 &&
+  return p->fused >= 2 && L.fused && L.enc_compact && !L.enc_ext && plan_K(p) == 0 &&
          p->c_dim == 0 && !p->row_w && !p->row_elbo && !p->dy && p->n_enc == 2 && p->enc[0].in_dim == p->n_pix &&
          p->enc[0].out_dim <= FD_H && p->enc[1].out_dim <= FD_H && p->head.out_dim == 2 * z && z <= 16 && plan_lat_in(p) <= 16 &&
          p->enc[0].w_off % 4 == 0 && p->enc[1].w_off % 4 == 0 && p->head.w_off % 4 == 0 && p->enc[1].in_dim % 4 == 0 &&
@@ -794,29 +800,40 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // launch, no weight-image copy, no hand-off: the step is decoder launch -> latent backward + record sums -> small weight gradients.
   PvEncFold ef{};
   bool fold = false;
+  auto fill_fold = [&]() {
+    ef.params = p->params; ef.enc0 = p->enc[0]; ef.enc1 = p->enc[1]; ef.head = p->head;
+    ef.x = p->x; ef.ldx = N; ef.eps = p->eps;
+    ef.eact0 = L.eact[0]; ef.eact1 = L.eact[1]; ef.head_out = L.head;
+    ef.z = L.z; ef.z_scale = L.z_scale; ef.z_loc_out = p->z_loc; ef.z_scale_out = p->z_scale;
+    ef.tp = L.tp; ef.kl_part = L.kl_part; ef.hz = L.hz; ef.Wz = p->params + p->fc_latent.w_off;
+    ef.lat_in = (int)lat_in; ef.z_dim = (int)z; ef.coord_dim = p->coord_dim;
+    ef.has_r = p->has_r; ef.has_t = p->has_t; ef.has_s = p->has_s;
+    ef.tp0 = p->t_prior[0]; ef.tp1 = p->t_prior[1]; ef.sc_prior = p->sc_prior; ef.beta = p->beta;
+  };
   if (plan_guide_may_fold(p, L)) {       // (no cross-workgroup hand-off in it: fine under stream capture too)
     f.hz_scale = 2.8853900817779268f;
     fold = pv_sdec_fused_fold_ok(f, L.f_grid, p->fused == 2);
-    if (fold) {
-      ef.params = p->params; ef.enc0 = p->enc[0]; ef.enc1 = p->enc[1]; ef.head = p->head;
-      ef.x = p->x; ef.ldx = N; ef.eps = p->eps;
-      ef.eact0 = L.eact[0]; ef.eact1 = L.eact[1]; ef.head_out = L.head;
-      ef.z = L.z; ef.z_scale = L.z_scale; ef.z_loc_out = p->z_loc; ef.z_scale_out = p->z_scale;
-      ef.tp = L.tp; ef.kl_part = L.kl_part; ef.hz = L.hz; ef.Wz = p->params + p->fc_latent.w_off;
-      ef.lat_in = (int)lat_in; ef.z_dim = (int)z; ef.coord_dim = p->coord_dim;
-      ef.has_r = p->has_r; ef.has_t = p->has_t; ef.has_s = p->has_s;
-      ef.tp0 = p->t_prior[0]; ef.tp1 = p->t_prior[1]; ef.sc_prior = p->sc_prior; ef.beta = p->beta;
-    } else {
-      f.hz_scale = 0.0f;
-    }
+    if (fold) fill_fold();
+    else f.hz_scale = 0.0f;
   }
-  const int kl_n = fold ? (int)B : L.kl_blocks;      // KL partial sums in L.kl_part: per sample when folded, else per 16-row block
+  int kl_n = fold ? (int)B : L.kl_blocks;            // KL partial sums in L.kl_part: per sample when a workgroup runs an image's guide, else per 16-row block
   if (fold) {
     // (nothing to launch before the decoder kernel)
   } else if (p->fused >= 2 && L.enc_compact) {
     const PvFbPrep prep = pv_sdec_fused_bf16_prep_args(f, want_grads != 0, p->fused == 2);
     f.hz_scale = prep.scale;                          // the compact encoder's last launch writes scale * hz directly
-    PV_TRY(guide_fwd(p, L, s, &prep, f.hz_scale));
+    // (round 6) the guide as one workgroup per image (pv_guide_img.hip: no tile hand-offs, 11-13 us where the tiled one-launch
+    // encoder takes 18-19) for the minibatch sizes where every image streaming the first-layer matrix from L2 is still cheaper
+    // than that latency; the flags that are about the tiled encoder's launch form keep the tiled encoder
+    fill_fold();
+    const bool per_image = plan_guide_one_image(p, L) && pv_guide_img_ok(ef, (int)B) &&
+                           !(p->flags & (PV_PLAN_ENC_TILED | PV_PLAN_ENC_TWO_LAUNCH | PV_PLAN_ENC_NO_WAIT));
+    if (per_image) {
+      PV_TRY(pv_guide_img_launch(ef, &prep, f.hz_scale, (int)B, s));
+      kl_n = (int)B;
+    } else {
+      PV_TRY(guide_fwd(p, L, s, &prep, f.hz_scale));
+    }
   } else {
     // conv encoder: the decoder's weight images ride in its weight-tiling launch; generic encoders: a launch of their own
     const bool prep_in_enc = p->fused >= 2 && L.enc_conv;

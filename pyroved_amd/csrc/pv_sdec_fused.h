@@ -64,6 +64,12 @@ struct PvEncFold {
   float tp0, tp1, sc_prior, beta;
   int img_per_wg;                  // images per workgroup (B / grid): 1
 };
+// the same guide as a launch of its own, one workgroup per image (pv_guide_img.hip; round 6): for the plans the fold cannot take.
+// prep != null: guest workgroups write the decoder's weight images / clear its dL/d(hz) slots; hz_mul: what hz leaves multiplied by
+#define PV_GUIDE_IMG_MAX_BATCH 384     // (measured, scripts/ab_guide_img.py: -7..-10 % of the step at batch 64, -6..-9 % at 128, -2..-4 % at 256, +-0 at 512)
+struct PvFbPrep;
+bool pv_guide_img_ok(const PvEncFold& e, int B);
+int pv_guide_img_launch(const PvEncFold& e, const PvFbPrep* prep, float hz_mul, int B, hipStream_t s);
 // whether the launch of (f, grads) can host the guide of `p`'s encoder (the caller checks the encoder's architecture)
 bool pv_sdec_fused_w8_fold_ok(const PvFused& f, int grid);
 // ... and whether the launcher will pick that kernel for (f, x3) at all

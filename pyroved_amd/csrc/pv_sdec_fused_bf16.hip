@@ -1179,7 +1179,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       const float xv = xv_next, swv = sw_next;
       f32x4 h0o[2], h1o[2], h2o[2], t2[2];
       bf16x4 oh[2], ol[2], pH0[8], pH1[8], pAh[8], pAl[8];
-      const bf16x4 z4 = __builtin_bit_cast(bf16x4, short4_{0, 0, 0, 0});
       // ---- coordinate layer, own blocks ----
 #pragma unroll
       for (int o = 0; o < 2; ++o) {

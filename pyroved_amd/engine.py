@@ -46,6 +46,7 @@ class IVAEEngine:
     enc_no_wait = False              # PV_PLAN_ENC_NO_WAIT: the one-launch encoder's consumers compute their tiles themselves
     side_stream = True               # PV_PLAN_NO_SIDE_STREAM when False
     dec1d = True                     # PV_PLAN_NO_DEC1D when False (VED's Conv1d decoder layer by layer)
+    enc_per_image = True             # the guide of a training step as one workgroup per image (False: PV_PLAN_ENC_TILED, the tiled one-launch encoder)
     conv_x3 = False                  # PV_PLAN_CONV_X3 / conv_bf16 = 0: fp32-class kernel-3 convolutions with both operands as two fp16 pieces
     enc_fold = True                  # PV_PLAN_NO_ENC_FOLD when False (the guide as its own launch even where the decoder launch could host it)
 
@@ -351,6 +352,7 @@ class IVAEEngine:
                 (_abi.PV_PLAN_ENC_NO_WAIT if getattr(self, "enc_no_wait", False) else 0) |
                 (0 if getattr(self, "dec1d", True) else _abi.PV_PLAN_NO_DEC1D) |
                 (0 if getattr(self, "enc_fold", True) else _abi.PV_PLAN_NO_ENC_FOLD) |
+                (0 if getattr(self, "enc_per_image", True) else _abi.PV_PLAN_ENC_TILED) |
                 (_abi.PV_PLAN_CONV_X3 if getattr(self, "conv_x3", False) else 0))
 
     def ensure_bound(self):

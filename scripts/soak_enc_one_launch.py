@@ -29,6 +29,7 @@ for i in range(steps):
     out = []
     for two in (0, 1):
         eng.enc_two_launch = bool(two)                   # plan flags (ABI v14 / v15)
+        eng.enc_per_image = False                        # (round 6: this soak is about the TILED encoder's hand-off)
         eng.enc_no_wait = bool(contend and two == 0 and i % 8 == 7)
         if contend:
             with torch.cuda.stream(side):

@@ -2325,6 +2325,62 @@ def test_guide_folded_into_the_decoder_launch(gpu_device, case):
         assert rel_l2(a["grad"][:eng.n_flat], c["grad"][:eng.n_flat]) < 2e-2       # (bf16 operands: a last-bit change of z moves roundings)
 
 
+@pytest.mark.parametrize("fused", [2, 3])
+@pytest.mark.parametrize("case", ["rt_b256", "r_b128", "rts_b6_8x8", "t1d_b5", "rts_b48_64x64", "none_t_b300"])
+def test_guide_per_image_launch_vs_tiled_encoder_and_oracle(gpu_device, case, fused):
+    """Round 6: a training step of up to 384 samples runs its guide — fcEncoderNet.forward (nets/fc.py:51-61), the reparameterised
+    sample and its KL terms (models/ivae.py:204-221), _split_latent (models/base.py:97-119), fc_latent — as ONE launch with one
+    workgroup per image (csrc/pv_guide_img.hip: fp32 matrix-vector products from the L2-resident weights, guest workgroups writing
+    the decoder's weight images) instead of the tiled one-launch encoder (PV_PLAN_ENC_TILED keeps that).  Both forms against the
+    ORACLE (loss 2e-5 / the throughput mode's 1e-4, every gradient at the path's bar), against each other (the encoder's outputs
+    to fp32 rounding), bit-reproducible, and the one-call step bit-identical to the two calls."""
+    torch.set_num_threads(8)
+    data_dim, inv, b = {"rt_b256": ((28, 28), ["r", "t"], 256), "r_b128": ((28, 28), ["r"], 128), "rts_b6_8x8": ((8, 8), ["r", "t", "s"], 6),
+                        "t1d_b5": ((16,), ["t"], 5), "rts_b48_64x64": ((64, 64), ["r", "t", "s"], 48),
+                        "none_t_b300": ((28, 28), ["t"], 300)}[case]
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(b, *data_dim, generator=g)
+    res = {}
+    for per_image in (True, False):
+        m = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+        eng = m.engine(fused=fused)
+        eng.enc_per_image = per_image
+        eng.enc_fold = False                                         # (both arms launch a guide)
+        eps = torch.randn(b, m.z_dim, generator=torch.Generator().manual_seed(5))
+        zl, zs = torch.empty(b, m.z_dim, device="cuda"), torch.empty(b, m.z_dim, device="cuda")
+        eng.loss_and_grads(x.cuda(), eps.cuda(), z_out=(zl, zs))
+        torch.cuda.synchronize()
+        rec = dict(scalars=eng.scalars.clone(), grad=eng.grad.clone(), zl=zl.clone(), zs=zs.clone())
+        eng.loss_and_grads(x.cuda(), eps.cuda())
+        assert torch.equal(rec["grad"], eng.grad) and torch.equal(rec["scalars"], eng.scalars)      # bit-reproducible
+        eng.loss_and_grads(x.cuda(), eps.cuda(), want_grads=False)
+        np.testing.assert_allclose(eng.scalars.cpu().numpy(), rec["scalars"].cpu().numpy(), rtol=2e-6)
+        cfg = orc.Config(data_dim=data_dim, latent_dim=2, invariances=inv)
+        o = orc.SVIOracle({k: v.cpu() for k, v in m.state_dict().items()}, cfg)
+        ref = o.step(x, eps)
+        small = b * int(np.prod(data_dim)) < 16384
+        np.testing.assert_allclose(rec["scalars"][0].item(), ref, rtol=(5e-4 if small else 1e-4) if fused == 3 else RTOL_ELBO)
+        np.testing.assert_allclose(zl.cpu().numpy(), o.last["z_loc"].detach().numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(zs.cpu().numpy(), o.last["z_scale"].detach().numpy(), rtol=1e-4, atol=2e-6)
+        for key in o.p:
+            lo = eng._layout[key]
+            err = rel_l2(rec["grad"][lo:lo + o.p[key].numel()].view_as(o.p[key]), o.last_grads[key])
+            assert err < (5e-2 if fused == 3 else RTOL_GRAD), "%s per_image=%s grad %s: rel l2 error %.3e vs oracle" % (case, per_image, key, err)
+        m2 = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+        e2 = m2.engine(fused=fused); e2.enc_per_image = per_image; e2.enc_fold = False
+        e2.loss_and_grads(x.cuda(), eps.cuda()); e2.adam_step()
+        m3 = pv.models.iVAE(data_dim, 2, inv, seed=1, device="cuda")
+        e3 = m3.engine(fused=fused); e3.enc_per_image = per_image; e3.enc_fold = False
+        e3.loss_and_grads(x.cuda(), eps.cuda(), step=True)
+        torch.cuda.synchronize()
+        assert torch.equal(e2.flat, e3.flat)
+        res[per_image] = rec
+    a, c = res[True], res[False]
+    np.testing.assert_allclose(a["zl"].cpu().numpy(), c["zl"].cpu().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(a["zs"].cpu().numpy(), c["zs"].cpu().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(a["scalars"].cpu().numpy(), c["scalars"].cpu().numpy(), rtol=1e-5 if fused == 2 else 2e-4)
+
+
 def test_one_launch_encoder_at_large_batch(gpu_device):
     """The compact encoder's one-launch form (csrc/pv_encoder.hip pv_enc_kernel: first-layer tiles and the rest of the encoder in
     one grid, hand-off through per-tile flags) at a batch whose grid (4 600 workgroups) does not fit the device at once: the
@@ -2369,6 +2425,7 @@ def test_one_launch_encoder_fallback_is_exact(gpu_device, b):
             eng.enc_two_launch = bool(two)               # pv_ivae_plan.flags: PV_PLAN_ENC_TWO_LAUNCH
             eng.enc_no_wait = spin == 0                  # ... PV_PLAN_ENC_NO_WAIT (ABI v15; a process-wide debug setter before)
             eng.enc_fold = False                         # (round 5: at batch 256 the guide would ride in the decoder launch)
+            eng.enc_per_image = False                    # (round 6: ... or run as one workgroup per image; this test is about the TILED encoder's hand-off)
             zl, zs = m.encode(x)
             eng.loss_and_grads(x, eps)
             torch.cuda.synchronize()
