@@ -79,7 +79,7 @@ CONFIGS = {
     "C5": dict(kind="ved", data_dim=(64, 64), out_dim=(128,), batch=256, flops_per_image=7.09e8, dec_passes=0, ring=2,
                desc="VED im2spec 64x64 image -> 128-point spectrum, default conv stacks"),
 }
-# HBM bytes per launch of a config's dominant kernel, from the committed rocprofv3 PMC passes (scripts/gpu_prof_r5.sh writes
+# HBM bytes per launch of a config's dominant kernel, from the committed rocprofv3 PMC passes (scripts/gpu_prof_r6.sh writes
 # profiles/traffic.json: FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, separate passes).  NOT collected by
 # this run: `traffic_source` says where from.  Keys "<config>:<mode>" (decoder kernel) and "<config>:<mode>:conv".
 TRAFFIC = {}

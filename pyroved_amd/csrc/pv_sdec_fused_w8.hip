@@ -123,9 +123,19 @@ __device__ __forceinline__ float w8_sum_q(float v) {
 // lane offsets (elements) of the weight reads, computed once per kernel and kept in registers (10 of them):
 //   forward: row 16*ob + r, logical chunk 4m + q -> physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])   (pv_fb_layout.h)
 //   dgrad  : lane i of 16-lane group q points at W[32m + 4q (+16) + r/4][...], swizzle 4*(r>>2) + SL[q]
-struct W8Addr { int fb, fx[4], db, dx[4]; };
+// W8_HSWAP (A/B build only; profiles/r06*_lds_swizzle_ab.txt): alternate 4-row groups of an image keep the two
+// 8-byte halves of every 16-byte chunk SWAPPED.  The dgrad's transposing 8-byte reads — 32 lanes = 8 rows x 4 chunks, all of
+// them wanting the same half: 2-way on every read in the shipped layout — then cover both halves of 16 chunks: conflict-free.
+// The price is the forward's operand read: its 8 k-values are no longer one ds_read_b128 but two ds_read_b64 at lane-dependent
+// halves (fs / hs below: which half comes first for this lane's rows).  Valid only where the kernel builds its own images (FOLD).
+#ifndef W8_HSWAP
+#define W8_HSWAP 0
+#endif
+struct W8Addr { int fb, fx[4], db, dx[4], fs, hs; };
 __device__ __forceinline__ W8Addr w8_addr(int r, int q) {
   W8Addr a;
+  a.fs = W8_HSWAP ? ((r >> 2) & 1) : 0;               // forward: rows 16 ob + r
+  a.hs = W8_HSWAP ? (q & 1) : 0;                      // dgrad: rows 32 m + 4 q (+ 16) + r / 4
   a.fb = r * LDB + 8 * (q ^ fb_sl(r >> 2));
   a.db = (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q));
 #pragma unroll
@@ -138,12 +148,29 @@ __device__ __forceinline__ void w8_layer_fwd(const __bf16* __restrict__ Wh, cons
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
   const __bf16* ah = Wh + ad.fb;
+#if W8_HSWAP
+  const __bf16* ah0 = ah + 4 * ad.fs;
+  const __bf16* ah1 = ah + 4 - 4 * ad.fs;
+  asm volatile("" : "+v"(ah0), "+v"(ah1));
+#endif
   const int (&xm)[4] = ad.fx;
   bf16x8 wh[2][2];
   auto load = [&](int g, bf16x8 (&h)[2]) {
     const int m = g >> 2, op = (g & 3) * 2;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) h[o] = *reinterpret_cast<const bf16x8*>(ah + 16 * (op + o) * LDB + xm[m]);
+    for (int o = 0; o < 2; ++o) {
+#if W8_HSWAP
+      // (two base registers: from ONE base the compiler merges the pair into a ds_read2_b64, whose banking — mod 32 over 16-lane
+      //  groups — conflicts where two ds_read_b64 do not: first cut of this experiment, conflict ratio 0.216 -> 0.283)
+      // (volatile: the compiler also pairs the reads of the two output blocks into ds_read2st64_b64 — the same half-rate form)
+      typedef const volatile bf16x4* vp4;
+      const bf16x4 lo4 = *reinterpret_cast<vp4>(ah0 + 16 * (op + o) * LDB + xm[m]);
+      const bf16x4 hi4 = *reinterpret_cast<vp4>(ah1 + 16 * (op + o) * LDB + xm[m]);
+      h[o] = w8_cat(lo4, hi4);
+#else
+      h[o] = *reinterpret_cast<const bf16x8*>(ah + 16 * (op + o) * LDB + xm[m]);
+#endif
+    }
   };
   load(0, wh[0]);
 #pragma unroll
@@ -170,7 +197,7 @@ __device__ __forceinline__ void w8_layer_dgrad(const __bf16* __restrict__ Wh, co
     const int m = g >> 2, kp = (g & 3) * 2;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-      const int off = 32 * m * LDB + xk[(kp + o) >> 1] + 4 * ((kp + o) & 1);
+      const int off = 32 * m * LDB + xk[(kp + o) >> 1] + (((kp + o) & 1) ? 4 - 4 * ad.hs : 4 * ad.hs);
       h[o] = w8_cat(w8_tr(ah + off), w8_tr(ah + off + 16 * LDB));
     }
   };
@@ -371,7 +398,13 @@ __device__ __forceinline__ f32x4 w8_tail_fwd(const __bf16* __restrict__ Wh, cons
   const __bf16* ah = Wh + ad.fb + 16 * wave * LDB;
   bf16x8 wh[4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) wh[m] = *reinterpret_cast<const bf16x8*>(ah + ad.fx[m]);
+  for (int m = 0; m < 4; ++m) {
+#if W8_HSWAP
+    wh[m] = w8_cat(*reinterpret_cast<const bf16x4*>(ah + ad.fx[m] + 4 * ad.fs), *reinterpret_cast<const bf16x4*>(ah + ad.fx[m] + 4 - 4 * ad.fs));
+#else
+    wh[m] = *reinterpret_cast<const bf16x8*>(ah + ad.fx[m]);
+#endif
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m) out = MFMA32(wh[m], w8_cat(ih[2 * m], ih[2 * m + 1]), out);
   return out;
@@ -380,7 +413,7 @@ __device__ __forceinline__ f32x4 w8_tail_fwd(const __bf16* __restrict__ Wh, cons
 __device__ __forceinline__ f32x4 w8_tail_dgrad(const __bf16* __restrict__ Wh, const bf16x4 (&ih)[8], const W8Addr& ad, int wave,
                                                int r) {
   f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
-  const __bf16* ah = Wh + ad.db + 32 * ((wave >> 1) ^ (r >> 2)) + 4 * (wave & 1);
+  const __bf16* ah = Wh + ad.db + 32 * ((wave >> 1) ^ (r >> 2)) + ((wave & 1) ? 4 - 4 * ad.hs : 4 * ad.hs);
   bf16x8 wh[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) wh[m] = w8_cat(w8_tr(ah + 32 * m * LDB), w8_tr(ah + 32 * m * LDB + 16 * LDB));
@@ -664,7 +697,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
         h1[i] = __builtin_bit_cast(unsigned short, (__bf16)(w1v[u][i] * W8_C));
         h2[i] = __builtin_bit_cast(unsigned short, (__bf16)(w2v[u][i] * W8_C));
       }
-      const int el = fb_wel(row, fb_pcol(4 * c4));
+      const int el = fb_wel(row, fb_pcol(4 * c4)) ^ (W8_HSWAP ? 4 * ((row >> 2) & 1) : 0);
       *reinterpret_cast<us4*>(i1 + el) = h1;
       *reinterpret_cast<us4*>(i2 + el) = h2;
     }

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 artefact run (as round 4's) on the GPU box (from the repo root): bench line, rocprofv3 kernel stats of the same command, step
+# Round-6 artefact run (as rounds 4 and 5) on the GPU box (from the repo root): bench line, rocprofv3 kernel stats of the same command, step
 # timelines (C2 bf16 / fp32-class, C4, C5), SQ counters of the headline decoder kernels, and FETCH_SIZE / WRITE_SIZE passes of
-# every config's dominant kernel(s) -> traffic.json (scripts/pmc_traffic.py).  Usage: bash scripts/gpu_prof_r5.sh <tag>
-TAG=${1:-r05}
+# every config's dominant kernel(s) -> traffic.json (scripts/pmc_traffic.py).  Usage: bash scripts/gpu_prof_r6.sh <tag>
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -49,7 +49,7 @@ for spec in "C2 3" "C2 2" "C1 3" "C1 2" "C3 3" "C3 2" "C4 3" "C4 2" "C4fc 3" "C4
   done
   ff=$(find /tmp/tr_${TAG}_${c}_${m}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
   fw=$(find /tmp/tr_${TAG}_${c}_${m}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-  [ -n "$ff" ] && [ -n "$fw" ] && python scripts/pmc_traffic.py "$c:$m" "$ff" "$fw" $OUT/traffic.json "profiles/${TAG}_traffic.json (scripts/gpu_prof_r5.sh)" | tee -a $OUT/traffic.log
+  [ -n "$ff" ] && [ -n "$fw" ] && python scripts/pmc_traffic.py "$c:$m" "$ff" "$fw" $OUT/traffic.json "profiles/${TAG}_traffic.json (scripts/gpu_prof_r6.sh)" | tee -a $OUT/traffic.log
 done
 echo "== soak: 3000 training steps in both precisions from the same seeds (the folded guide and the column-parallel tail on every step)"
 timeout 900 python scripts/soak_bf16.py > $OUT/soak_bf16.txt 2>&1; tail -3 $OUT/soak_bf16.txt

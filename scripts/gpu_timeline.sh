@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # a step starts at each enc_fwd kernel; take the 3rd-from-last complete step
-starts = [i for i, n in enumerate(names) if "enc_l1" in n or "pv_enc_kernel" in n]
+starts = [i for i, n in enumerate(names) if "enc_l1" in n or "pv_enc_kernel" in n or "pv_guide_img_kernel" in n]
 if len(starts) < 3:      # (round 5: the decoder launch hosts the guide — a step starts at that launch)
     starts = [i for i, n in enumerate(names) if "pv_sdec_w8_kernel<true, 0, true>" in n]
 a, b = starts[-3], starts[-2]
