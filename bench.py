@@ -723,7 +723,7 @@ def main():
         # latency-bound by design: 32 images per GPU at N = 8; DESIGN.md section 6 has the expected curve)
         strong = measure(args, name, cfg, args.fused, (pv, pvdist, td, dev, rank, world, b_cfg // world))
     c5w = None
-    if world > 1 and name == "C2" and not args.strong and args.batch is None and not args.no_alt:
+    if (world > 1 or FORCE_DIST) and name == "C2" and not args.strong and args.batch is None and not args.no_alt:
         # N > 1: the conv config too (weak scaling, 256 images per GPU) — its 0.75 ms step hides the all-reduce's latency far
         # better than C2's 0.12 ms, so it is the config whose curve can reach the >= 6x target
         try:
@@ -879,6 +879,7 @@ def main():
                                              "kernel_ms": out["roofline"].get("kernel_ms"), "frac": out["roofline"].get("frac"),
                                              **summ}), file=sys.stderr)
     if world > 1 or FORCE_DIST:
+        pvdist.close_native()                       # (the library's RCCL communicators first: nothing of ours outlives the group)
         td.destroy_process_group()
 
 

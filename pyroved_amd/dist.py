@@ -10,6 +10,7 @@ sum of the shard gradients, so no averaging is applied.
 """
 import ctypes as C
 import os
+import sys as _sys
 from typing import Optional, Tuple
 
 import torch
@@ -155,7 +156,10 @@ class NativeComm:
             self.handle = C.c_void_p()
 
     def __del__(self):
+        # (interpreter shutdown: the HIP runtime / RCCL may already be gone, and `import` no longer works — module-level sys)
         try:
+            if _sys is None or _sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass
@@ -180,3 +184,13 @@ def native_available(group=None) -> bool:
     if td.is_available() and td.is_initialized():
         return td.get_backend(group) == "nccl"
     return True
+
+
+def close_native() -> None:
+    """Destroys every NativeComm this process created through native_comm() (call before torch.distributed.destroy_process_group)."""
+    for c in list(_native.values()):
+        try:
+            c.close()
+        except Exception:
+            pass
+    _native.clear()

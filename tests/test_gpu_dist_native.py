@@ -171,3 +171,5 @@ def test_bench_multirank_path_over_nccl_world1(gpu_device):
     assert d["collective"].startswith("rccl-native"), d["collective"]
     assert d["allreduce_ms"] > 0 and d["fp32_class"]["allreduce_ms"] > 0
     assert abs(d["fp32_class"]["loss_per_image_step0"] - 544.5358) < 0.02
+    # the conv config's weak-scaling leg rides along as at N > 1: VED's one-call data-parallel step (pv_ved_dp_step) through bench.py
+    assert d["c5_weak"]["value"] > 0 and d["c5_weak"]["allreduce_ms"] > 0, d.get("c5_weak")
