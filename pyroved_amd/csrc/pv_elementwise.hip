@@ -1080,21 +1080,21 @@ __global__ __launch_bounds__(256) void pv_latent_bwd_kernel(PvLatentBwd p) { pv_
 // workgroups [0, PV_FUSED_REDUCE_BLOCKS) sum the per-workgroup gradient records, the rest run latent_bwd
 __global__ __launch_bounds__(256) void pv_latent_bwd_reduce_kernel(PvLatentBwd p, const float* __restrict__ part,
                                                                    int G_, float* __restrict__ Gr, PvFusedOffsets o,
-                                                                   int cd, int packed) {
+                                                                   int cd, int fmt) {
   __shared__ f32x4 smr[4][64];
 #ifndef LB_EXP
 #define LB_EXP 0                 // timing experiments (wrong results): 1 no record sums, 2 no latent backward
 #endif
-  const int nred = pv_fused_reduce_blocks(packed);
-  if ((int)blockIdx.x < nred) { if (!(LB_EXP & 1)) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, blockIdx.x, smr, packed); }
+  const int nred = pv_fused_reduce_blocks(fmt);
+  if ((int)blockIdx.x < nred) { if (!(LB_EXP & 1)) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, blockIdx.x, smr, fmt); }
   else if (!(LB_EXP & 2)) pv_latent_bwd_block(p, blockIdx.x - nred);
 }
 
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
-                         hipStream_t s, int packed) {
+                         hipStream_t s, int fmt) {
   if (p.H > 512 || p.lat_in > 64 + (p.K > 0 ? p.K : 0) || p.hb.z_dim > 256 || p.K > 128) return PV_EINVAL;
   // (a conv encoder's head weight gradient forks off this launch onto the side stream: it carries the fork event when one is armed)
-  PV_LAUNCH_FORK(pv_latent_bwd_reduce_kernel, dim3(pv_fused_reduce_blocks(packed) + p.hb.B), dim3(256), 0, s, p, part, grid, G, o, cd, packed);
+  PV_LAUNCH_FORK(pv_latent_bwd_reduce_kernel, dim3(pv_fused_reduce_blocks(fmt) + p.hb.B), dim3(256), 0, s, p, part, grid, G, o, cd, fmt);
   PV_LAUNCH_CHECK();
   return 0;
 }

@@ -156,7 +156,7 @@ int pv_row_elbo(const float* row_ll, const float* z, const float* head, const fl
 int pv_add_cols(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t B, int n, hipStream_t s);
 struct PvFusedOffsets;
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
-                         hipStream_t s, int packed = 0);
+                         hipStream_t s, int rec_fmt = 0);
 
 // pv_lik_elem + pv_segsum in one launch (one workgroup per sample; same summation order)
 int pv_lik_rows(const float* a, const float* x, int64_t B, int64_t per, int lik, int sigmoid_out, float sig, float* loc,

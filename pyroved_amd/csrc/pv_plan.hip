@@ -900,9 +900,9 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   const bool head_side = ab_side && L.enc_conv && !L.enc_ext && pv_side_stream_for(s, p->flags) && !pv_convhead_wgrad_uses_ws() &&
                          pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   if (head_side) pv_fork_arm();
-  // (the 8-wave throughput kernel writes the two hidden matrices' partials as packed bf16 pairs: pv_sdec_fused.h)
-  const int rec_packed = pv_sdec_fused_bf16_records_packed(p->fused == 2, R / FD_UNIT, p->dec_kernel) && p->fused == 3 ? 1 : 0;
-  PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s, rec_packed));
+  // (the record format the decoder launch above wrote: pv_sdec_fused.h PV_REC_*)
+  const int rec_fmt = p->fused >= 2 ? pv_sdec_fused_bf16_record_fmt(p->fused == 2, R / FD_UNIT, p->dec_kernel) : PV_REC_ROWMAJOR;
+  PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s, rec_fmt));
   // the loss scalars ride in the encoder dgrad launch (compact encoder), in the last weight-gradient launch (conv encoder) or get their own
   PvFinish fin{L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, kl_n, 1.0f /* scaled */};
   const bool fin_rides = L.enc_compact || (ab_fin && L.enc_conv && !L.enc_ext);

@@ -103,8 +103,8 @@ int pv_sdec_fused_w8h_launch(const PvFused& f, int grid, bool ds, hipStream_t s)
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel);
 // waves per workgroup that publish a dL/d(hz) slot (sizes part_hz)
 int pv_sdec_fused_bf16_waves(bool x3, int64_t units, int sel);
-// whether the training launch of (x3, units, sel) writes PACKED gradient records (the 8-wave plain-bf16 kernel does)
-bool pv_sdec_fused_bf16_records_packed(bool x3, int64_t units, int sel);
+// the record format (PV_REC_*) the training launch of (x3, units, sel) writes
+int pv_sdec_fused_bf16_record_fmt(bool x3, int64_t units, int sel);
 // whether `sel` (pv_ivae_plan.dec_kernel) names a decoder-kernel build this library contains for the fused mode
 bool pv_sdec_fused_sel_valid(int fused, int sel);
 // sums the per-workgroup records (ascending workgroup order) into the flat gradient buffer
@@ -116,56 +116,97 @@ int pv_sdec_fused_reduce(const float* part, int grid, float* G, const PvFusedOff
 // 64 float4 outputs x 4 slices of the workgroup range per 256-thread block (a wave reads 1 KB per record, eight
 // records in flight); slices combined in fixed order
 #define PV_FUSED_REDUCE_BLOCKS (((2 * FD_H * FD_H + 5 * FD_H + 1 + 3) / 4 + 63) / 64)
-// (round 6) PACKED records — the throughput kernel's (pv_sdec_fused_w8.hip): the two HxH weight-gradient partials as bf16 pairs,
-// word [m][row / 2][col] = (dW_m[row & ~1][col], dW_m[row | 1][col]) in the record's first H*H floats (the weights they update were
-// rounded to bf16 in the forward anyway; the reader sums in fp32), everything from float 2*H*H on unchanged.  Half the bytes a
-// decoder launch writes and the next launch reads (41 of the 49 MB were these matrices).
-#define PV_FUSED_REDUCE_MAT_BLOCKS_PACKED ((2 * (FD_H / 2) * FD_H / 4) / 64)            // 16-byte chunks of the packed matrices / 64
-#define PV_FUSED_REDUCE_BLOCKS_PACKED (PV_FUSED_REDUCE_MAT_BLOCKS_PACKED + ((5 * FD_H + 1 + 3) / 4 + 63) / 64)
-__host__ __device__ inline int pv_fused_reduce_blocks(int packed) { return packed ? PV_FUSED_REDUCE_BLOCKS_PACKED : PV_FUSED_REDUCE_BLOCKS; }
-__device__ __forceinline__ void pv_sdec_fused_reduce_block_packed(const float* __restrict__ part, int G_, float* __restrict__ Gr,
-                                                                  const PvFusedOffsets& o, int block, f32x4 (*sm)[64]) {
-  // chunk ch = 16 bytes = 4 words = columns 4 c4 .. +3 of the row pair rp of matrix m: 8 outputs
+// (round 6) Record FORMATS of the two HxH weight-gradient partials — a private contract between a decoder kernel's epilogue and
+// this reduction; everything from float 2*H*H on (bias / coordinate / output-layer vectors) is the same in all of them:
+//   PV_REC_ROWMAJOR  [m][row][col] fp32 (rounds 1-5; the f32-MFMA kernel and the experiments builds): a lane of the C/D layout
+//                    holds ONE column of four rows, so every store instruction wrote 4 x 64-byte segments — 128 (64) scattered
+//                    4-byte store instructions per wave, 6-12 k cycles of store issue per workgroup at the end of the launch;
+//   PV_REC_LANE_F32  LANE-NATIVE fp32 (the 4-wave kernels of pv_sdec_fused_bf16.hip): chunk (16 bytes)
+//                    [m][wave][s][kb][lane] = the lane's accumulator block accW_m[s][kb] as it sits in registers — rows
+//                    16 (2 wave + s) + 4 q + i (i = 0..3), column 16 kb + r: ONE 1 KB-contiguous store instruction per block;
+//   PV_REC_LANE_BF16 lane-native PACKED (the 8-wave throughput kernel, pv_sdec_fused_w8.hip): chunk [wave][s][o][lane] =
+//                    {W1 rows (i0, i1), W1 rows (i2, i3), W2 rows (i0, i1), W2 rows (i2, i3)} as bf16 pairs — rows
+//                    32 jp + 16 (s ^ kh) + 4 q + i, column 64 kh + 16 o + r (jp = wave >> 1, kh = wave & 1) — in the record's first H*H
+//                    floats: half the bytes (the weights they update were rounded to bf16 in the forward anyway; the reader sums in
+//                    fp32) and 8 store instructions per wave.
+// The reduction reads 16 bytes per thread and record either way and writes each output element once; per element the records are
+// summed in the same fixed order as before (four slices of ascending workgroups): the fp32 formats give the same bits.
+#define PV_REC_ROWMAJOR 0
+#define PV_REC_LANE_F32 1
+#define PV_REC_LANE_BF16 2
+#define PV_FUSED_REDUCE_VEC_BLOCKS (((5 * FD_H + 1 + 3) / 4 + 63) / 64)
+#define PV_FUSED_REDUCE_MAT_BLOCKS_F32 ((2 * FD_H * FD_H / 4) / 64)                     // 128
+#define PV_FUSED_REDUCE_MAT_BLOCKS_BF16 ((2 * (FD_H / 2) * FD_H / 4) / 64)              // 64
+__host__ __device__ inline int pv_fused_reduce_mat_blocks(int fmt) {
+  return fmt == PV_REC_LANE_BF16 ? PV_FUSED_REDUCE_MAT_BLOCKS_BF16 : PV_FUSED_REDUCE_MAT_BLOCKS_F32;
+}
+__host__ __device__ inline int pv_fused_reduce_blocks(int fmt) {
+  return fmt == PV_REC_ROWMAJOR ? PV_FUSED_REDUCE_BLOCKS : pv_fused_reduce_mat_blocks(fmt) + PV_FUSED_REDUCE_VEC_BLOCKS;
+}
+// one block = 64 chunks = ONE accumulator block of one wave (thread c = lane c of that wave), four slices of the workgroup range
+template <int FMT>
+__device__ __forceinline__ void pv_sdec_fused_reduce_block_lane(const float* __restrict__ part, int G_, float* __restrict__ Gr,
+                                                                const PvFusedOffsets& o, int block, f32x4 (*sm)[64]) {
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int ch = block * 64 + c;                                   // < 2 * 64 * 32
   const int per = (G_ + 3) / 4;
   const int w0 = sl * per, w1 = min(G_, w0 + per);
-  f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = {0.0f, 0.0f, 0.0f, 0.0f};
-  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-  const float* pbase = part + 4 * ch;
+  const float* pbase = part + 4 * (block * 64 + c);
+  f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (FMT == PV_REC_LANE_BF16) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 #pragma unroll 8
-  for (int w = w0; w < w1; ++w) {
-    const u32x4_ v = *reinterpret_cast<const u32x4_*>(pbase + (int64_t)w * FD_REC);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      lo[i] += __uint_as_float(v[i] << 16);                         // row 2 rp
-      hi[i] += __uint_as_float(v[i] & 0xffff0000u);                 // row 2 rp + 1
+    for (int w = w0; w < w1; ++w) {
+      const u32x4_ v = *reinterpret_cast<const u32x4_*>(pbase + (int64_t)w * FD_REC);
+      a[0] += __uint_as_float(v[0] << 16); a[1] += __uint_as_float(v[0] & 0xffff0000u);
+      a[2] += __uint_as_float(v[1] << 16); a[3] += __uint_as_float(v[1] & 0xffff0000u);
+      b[0] += __uint_as_float(v[2] << 16); b[1] += __uint_as_float(v[2] & 0xffff0000u);
+      b[2] += __uint_as_float(v[3] << 16); b[3] += __uint_as_float(v[3] & 0xffff0000u);
     }
+  } else {
+#pragma unroll 8
+    for (int w = w0; w < w1; ++w) a += *reinterpret_cast<const f32x4*>(pbase + (int64_t)w * FD_REC);
   }
-  // two passes through the 4-slice combine buffer (fixed order, as the fp32 form)
-  f32x4 tot[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    sm[sl][c] = h == 0 ? lo : hi;
+  sm[sl][c] = a;
+  __syncthreads();
+  const f32x4 ta = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+  f32x4 tb = b;
+  if (FMT == PV_REC_LANE_BF16) {
     __syncthreads();
-    tot[h] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    sm[sl][c] = b;
     __syncthreads();
+    tb = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
   }
   if (sl != 0) return;
-  const int m = ch / (64 * 32), rp = (ch / 32) % 64, c4 = ch % 32;
-  float* dst = Gr + (m == 0 ? o.W1 : o.W2) + (2 * rp) * FD_H + 4 * c4;
+  const int r = c & 15, q = c >> 4;
+  if (FMT == PV_REC_LANE_BF16) {
+    const int oo = block & 3, s_ = (block >> 2) & 1, wave = block >> 3, jp = wave >> 1, kh = wave & 1;
+    const int row0 = 32 * jp + 16 * (s_ ^ kh) + 4 * q, col = 64 * kh + 16 * oo + r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { dst[i] = tot[0][i]; dst[FD_H + i] = tot[1][i]; }
+    for (int i = 0; i < 4; ++i) {
+      Gr[o.W1 + (row0 + i) * FD_H + col] = ta[i];
+      Gr[o.W2 + (row0 + i) * FD_H + col] = tb[i];
+    }
+  } else {
+    const int kb = block & 7, s_ = (block >> 3) & 1, wave = (block >> 4) & 3, m = block >> 6;
+    const int row0 = 16 * (2 * wave + s_) + 4 * q, col = 16 * kb + r;
+    float* dst = Gr + (m == 0 ? o.W1 : o.W2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[(row0 + i) * FD_H + col] = ta[i];
+  }
 }
 __device__ __forceinline__ void pv_sdec_fused_reduce_block(const float* __restrict__ part, int G_,
                                                            float* __restrict__ Gr, const PvFusedOffsets& o, int cd,
-                                                           int dwo_slots, int block, f32x4 (*sm)[64], int packed = 0) {
+                                                           int dwo_slots, int block, f32x4 (*sm)[64], int fmt = PV_REC_ROWMAJOR) {
   const int HH = FD_H * FD_H;
   const int total = 2 * HH + 5 * FD_H + 1;          // the record is padded well past this: whole float4s are readable
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  if (packed && block < PV_FUSED_REDUCE_MAT_BLOCKS_PACKED) { pv_sdec_fused_reduce_block_packed(part, G_, Gr, o, block, sm); return; }
-  // (packed: the blocks behind the matrices' take the vectors, which sit at float 2*H*H as in the fp32 form)
-  const int e = packed ? 2 * HH + ((block - PV_FUSED_REDUCE_MAT_BLOCKS_PACKED) * 64 + c) * 4 : (block * 64 + c) * 4;
+  if (fmt != PV_REC_ROWMAJOR && block < pv_fused_reduce_mat_blocks(fmt)) {
+    if (fmt == PV_REC_LANE_BF16) pv_sdec_fused_reduce_block_lane<PV_REC_LANE_BF16>(part, G_, Gr, o, block, sm);
+    else pv_sdec_fused_reduce_block_lane<PV_REC_LANE_F32>(part, G_, Gr, o, block, sm);
+    return;
+  }
+  // (lane-native formats: the blocks behind the matrices' take the vectors, which sit at float 2*H*H in every format)
+  const int e = fmt != PV_REC_ROWMAJOR ? 2 * HH + ((block - pv_fused_reduce_mat_blocks(fmt)) * 64 + c) * 4 : (block * 64 + c) * 4;
   const int per = (G_ + 3) / 4;
   const int w0 = sl * per, w1 = min(G_, w0 + per);
   f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};

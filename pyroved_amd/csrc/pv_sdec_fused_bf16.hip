@@ -1387,14 +1387,25 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int j0 = 16 * (2 * wave + s);
+    if (f.ablate & 1024) {                   // (experiments build: the row-major form of rounds 1-5, 128 scattered 4-byte stores per wave)
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
+      for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // C/D layout: lane (col k' = r, q), reg i -> dW[j0 + 4*q + i][16*kb + r]
-        rec[(j0 + 4 * q + i) * FD_H + 16 * kb + r] = accW1[s][kb][i] * uw1;
-        rec[FD_H * FD_H + (j0 + 4 * q + i) * FD_H + 16 * kb + r] = accW2[s][kb][i] * uw2;
+        for (int i = 0; i < 4; ++i) {
+          // C/D layout: lane (col k' = r, q), reg i -> dW[j0 + 4*q + i][16*kb + r]
+          rec[(j0 + 4 * q + i) * FD_H + 16 * kb + r] = accW1[s][kb][i] * uw1;
+          rec[FD_H * FD_H + (j0 + 4 * q + i) * FD_H + 16 * kb + r] = accW2[s][kb][i] * uw2;
+        }
+    } else {
+      // LANE-NATIVE (pv_sdec_fused.h PV_REC_LANE_F32): every accumulator block as it sits in registers, one 1 KB-contiguous
+      // 16-byte-per-lane store each — 32 store instructions per wave instead of 128
+      f32x4* rec4 = reinterpret_cast<f32x4*>(rec);
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        rec4[(((0 * FB_WAVES + wave) * 2 + s) * 8 + kb) * 64 + lane] = accW1[s][kb] * uw1;
+        rec4[(((1 * FB_WAVES + wave) * 2 + s) * 8 + kb) * 64 + lane] = accW2[s][kb] * uw2;
       }
+    }
     // bias gradients: every column of accB holds the same sums; lane (col 0, q), reg i -> row j0 + 4q + i
     if (r == 0) {
 #pragma unroll
@@ -1535,9 +1546,11 @@ int pv_sdec_fused_bf16_waves(bool x3, int64_t units, int sel) {
   const int kind = x3 ? fb_x3_kind(units, true, sel) : 0;
   return (x3 ? (kind == 8 || fb_kind_w8h(kind)) : fb_use_w8(units, sel)) ? 8 : FB_WAVES;
 }
-bool pv_sdec_fused_bf16_records_packed(bool x3, int64_t units, int sel) {
-  static const int ablate = pv_exp_int("PV_FD_ABLATE", 0);          // (bit 1024: fp32 records from the 8-wave kernel, experiments build)
-  return !x3 && fb_use_w8(units, sel) && !(ablate & 1024);
+int pv_sdec_fused_bf16_record_fmt(bool x3, int64_t units, int sel) {
+  static const int ablate = pv_exp_int("PV_FD_ABLATE", 0);          // (experiments build, bit 1024: the row-major fp32 form from both kernels)
+  if (ablate & 1024) return PV_REC_ROWMAJOR;
+  if (!x3) return fb_use_w8(units, sel) ? PV_REC_LANE_BF16 : PV_REC_LANE_F32;
+  return fb_kind_here(fb_x3_kind(units, true, sel)) ? PV_REC_LANE_F32 : PV_REC_ROWMAJOR;   // (pv_sdec_fused_w8x3 / w8h.hip: row-major)
 }
 int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel) {
 #ifdef PV_EXPERIMENTS

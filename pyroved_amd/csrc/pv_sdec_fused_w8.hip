@@ -1241,42 +1241,41 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
   {
     const int jp = wave >> 1, kh = wave & 1;
-    // PACKED (pv_sdec_fused.h): rows 2k, 2k + 1 of a column as one word of two bf16 (round to nearest even) — the lane's
-    // registers i = 0, 1 and 2, 3 are such pairs: 32 four-byte stores per matrix and wave where the fp32 form issued 64
-    unsigned* recw = reinterpret_cast<unsigned*>(rec);
+    // LANE-NATIVE PACKED (pv_sdec_fused.h PV_REC_LANE_BF16): per accumulator block ONE 16-byte store per lane, 1 KB contiguous
+    // per instruction — {W1 rows (i0, i1), W1 (i2, i3), W2 (i0, i1), W2 (i2, i3)} as bf16 pairs (round to nearest even): 8 store
+    // instructions per wave where the row-major fp32 form issued 128 four-byte ones
     auto pack2 = [](float a, float b) {
       typedef __bf16 bf2_ __attribute__((ext_vector_type(2)));
       bf2_ h; h[0] = (__bf16)a; h[1] = (__bf16)b;
       return __builtin_bit_cast(unsigned, h);
     };
-    if (f.ablate & 1024) {                       // (experiments build: the fp32 form, for the A/B of profiles/r06*_records_ab.txt)
+    if (f.ablate & 1024) {                       // (experiments build: the row-major fp32 form, for the A/B of profiles/r06*_records_ab.txt)
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
         for (int o = 0; o < 4; ++o)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+            // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16 (s ^ kh) + 4q + i][64kh + 16o + r]  (w8_wgrad_consume's rotation)
             const int e = (32 * jp + 16 * (s_ ^ kh) + 4 * q + i) * FD_H + 64 * kh + 16 * o + r;
-            rec[e] = accW1[s_][o][i] * -W8_RC;
+            rec[e] = accW1[s_][o][i] * -W8_RC;                        // (accW1 / accB1 hold -C dW1 / -C db1)
             rec[FD_H * FD_H + e] = accW2[s_][o][i];
           }
-    } else
+    } else {
+      typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+      u32x4_* rec4 = reinterpret_cast<u32x4_*>(rec);
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_)
+      for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {
-          // C/D layout: lane (col = r, q), reg i -> dW[32jp + 16 (s ^ kh) + 4q + i][64kh + 16o + r]  (w8_wgrad_consume's rotation)
-          const int rp = (32 * jp + 16 * (s_ ^ kh) + 4 * q + 2 * ip) >> 1;
-          const int e = rp * FD_H + 64 * kh + 16 * o + r;
-#if W8_ABL & 8
-          if (accW1[s_][o][2 * ip] == 1.2345e30f) recw[e] = pack2(accW2[s_][o][2 * ip], 0.0f);      // (timing ablation: no record stores)
-#else
-          recw[e] = pack2(accW1[s_][o][2 * ip] * -W8_RC, accW1[s_][o][2 * ip + 1] * -W8_RC);   // (accW1 / accB1 hold -C dW1 / -C db1)
-          recw[(FD_H / 2) * FD_H + e] = pack2(accW2[s_][o][2 * ip], accW2[s_][o][2 * ip + 1]);
-#endif
+        for (int o = 0; o < 4; ++o) {
+          u32x4_ v;
+          v[0] = pack2(accW1[s_][o][0] * -W8_RC, accW1[s_][o][1] * -W8_RC);   // (accW1 / accB1 hold -C dW1 / -C db1)
+          v[1] = pack2(accW1[s_][o][2] * -W8_RC, accW1[s_][o][3] * -W8_RC);
+          v[2] = pack2(accW2[s_][o][0], accW2[s_][o][1]);
+          v[3] = pack2(accW2[s_][o][2], accW2[s_][o][3]);
+          rec4[((wave * 2 + s_) * 4 + o) * 64 + lane] = v;
         }
+    }
     if (r == 0) {
       const int j0 = 32 * jp + 16 * kh;
 #pragma unroll
