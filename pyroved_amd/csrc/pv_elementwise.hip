@@ -887,6 +887,31 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     const int64_t s = (int64_t)k * Bq + b;            // decoder sample (k, b)
     const int64_t r0 = s * p.N;
     float a[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (p.part_rs) {
+      // (round 6) the decoder launch already summed its rows per (sample, workgroup, wave): add the sample's kmax slots in ascending
+      // order — thread c < 5 takes quantity c, all its slot loads in flight at once — instead of loading and block-reducing 5 x N
+      // rows (7.7 k of this workgroup's 21.7 k cycles: 3.2 k until the row loads were even issued; scripts/gpu_trace_lb.py)
+      float v = 0.0f;
+      if (t < 5) {
+        const float* pr = p.part_rs + (s * p.kmax) * 8 + t;
+        for (int kk0 = 0; kk0 < p.kmax; kk0 += 16) {
+          float w[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) w[u] = pr[(int64_t)(kk0 + u < p.kmax ? kk0 + u : p.kmax - 1) * 8];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v += kk0 + u < p.kmax ? w[u] : 0.0f;
+        }
+      }
+      LB_STAMP(8);
+      if (k == 0 && chain) prefetch_chain();
+      LB_STAMP(9);
+      LB_STAMP(7);
+      if (t < 5) sm5[t][0] = v;
+      pv_lds_barrier();
+#pragma unroll
+      for (int c = 0; c < 5; ++c) a[c] = sm5[c][0];
+      pv_lds_barrier();                                 // (sm5 is rewritten by the next class pass)
+    } else {
     {
       // four rows per thread and array in flight at once.  The rows come in chunks of 1024 (thread t: rows t + 256 u of a chunk); every
       // chunk but the last is whole, the LAST one (the only one at 784 rows) is predicated and its loads are all issued — with the
@@ -935,6 +960,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
     pv_lds_barrier();
 #pragma unroll
     for (int c = 0; c < 5; ++c) a[c] = (sm5[c][0] + sm5[c][1]) + (sm5[c][2] + sm5[c][3]);
+    }
     if (t == 0) sh_ll[k] = a[0];
     LB_STAMP(1);
     if (p.fwd_only) continue;

@@ -108,6 +108,8 @@ struct PvLatentBwd {
   const float* llrow;    // (M)
   const float* rowtp;    // (4, M)
   const float* part_hz;  // (B*kmax, H)
+  const float* part_rs;  // (B*kmax, PV_RS_W) or null: the decoder's per-slot sums of {ll, d(phi), d(scale), d(tx), d(ty)} (pv_sdec_fused.h) —
+                         // then llrow / rowtp are not read
   const float* Wz;       // (H, lat_in) decoder.coord_latent.fc_latent.weight
   float* llb;            // (B)
   float* dhz;            // (B, H)

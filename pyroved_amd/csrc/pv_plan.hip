@@ -189,7 +189,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
       L.f_kmax = pv_sdec_fused_kmax((int)N, units, L.f_grid);
       if (p->fused >= 2) L.f_kmax *= pv_sdec_fused_bf16_waves(p->fused == 2, units, p->dec_kernel);   // the bf16 kernels publish dL/d(hz) per wave
       L.f_part = c.take((int64_t)L.f_grid * FD_REC);
-      L.f_part_hz = c.take(S * L.f_kmax * H0);
+      L.f_part_hz = c.take(S * L.f_kmax * (H0 + PV_RS_W));        // (+ the row-sum slots behind it: PvFused::part_rs, one zero fill)
       L.f_rowtp = c.take(4 * R);
       L.f_wimg = c.take(FB_WIMG_BYTES / (int64_t)sizeof(float));
       const int64_t park = (p->fused == 2 && !inference_only) ? pv_sdec_fused_bf16_park_bytes(true, units, L.f_grid, p->dec_kernel) : 0;
@@ -782,6 +782,13 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   f.W2 = p->params + p->dec[1].w_off; f.b2 = p->params + p->dec[1].b_off;
   f.wo = p->params + p->out.w_off; f.bo = p->params + p->out.b_off;
   f.llrow = L.llrow; f.loc = p->loc; f.rowtp = L.f_rowtp; f.part_hz = L.f_part_hz; f.part = L.f_part;
+  // (round 6) training launches of the 4-wave kernels (pv_sdec_fused_bf16.hip: the ones that write PV_REC_LANE_F32 records) hand
+  // over per-slot row sums instead of rows.  NOT the 8-wave throughput kernel: it has no registers for five running sums, and
+  // keeping them in LDS cost its in-order waves what the next launch saved (read-modify-write: +-0 on the step; ds_add_f32: +1.4 us
+  // on the kernel — profiles/r06h_row_sums_ab.txt)
+  f.part_rs = (want_grads && p->fused >= 2 && H == FD_H &&
+               pv_sdec_fused_bf16_record_fmt(p->fused == 2, R / FD_UNIT, p->dec_kernel) == PV_REC_LANE_F32)
+                  ? L.f_part_hz + S * L.f_kmax * H : nullptr;
   f.wimg = L.f_wimg; f.park = L.f_park;
   f.M = R; f.units = R / FD_UNIT; f.N = (int)N; f.cd = p->coord_dim; f.B = (int)S; f.lik = p->lik;
   f.sw = K > 0 ? L.sw : p->row_w; f.x_units = K > 0 ? B * N / FD_UNIT : 0;
@@ -859,6 +866,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // launch: the per-workgroup gradient records summed into the flat gradient
   PvLatentBwd lb{};
   lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;
+  lb.part_rs = f.part_rs;
   lb.llb = L.llb; lb.dhz = L.dhz; lb.M = R; lb.N = (int)N; lb.kmax = L.f_kmax; lb.H = H; lb.lat_in = (int)lat_in;
   PvHeadBwd& hb = lb.hb;
   hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;

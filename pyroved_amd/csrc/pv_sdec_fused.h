@@ -9,6 +9,7 @@
 // [dW1 HxH | dW2 HxH | db1 H | db2 H | dWc0 H | dWc1 H | dwo H | dbo (1, padded to H) | 8 spare slots x H]
 // (the spare slots are summed into dwo by the reduction when it is called with dwo_slots = 1; both kernels now
 //  sum their d(wo) in LDS and leave the slots unused)
+#define PV_RS_W 8               // floats per slot of PvFused::part_rs (5 used)
 #define FB_WIMG_BYTES (4 * FD_H * FD_H * 2 + 256)   // split-precision kernels: global copy of the four LDS weight images (+ the fp16 modes' scales)
 
 struct PvFused {
@@ -25,6 +26,11 @@ struct PvFused {
   float* loc;            // (M) decoder output or null
   float* rowtp;          // (4, M) per-row d(phi), d(scale), d(tx), d(ty)
   float* part_hz;        // (B * kmax, H) partial sums of dL/d(hz), zero-filled by the caller
+  float* part_rs;        // (round 6) (B * kmax, PV_RS_W) or null.  Not null (training launches of the kernels that support it):
+                         //   instead of writing llrow / rowtp per ROW the kernel publishes, in the slot of part_hz's scheme, the
+                         //   sums over a wave's rows of a sample of {ll, d(phi), d(scale), d(tx), d(ty)} — pv_latent_bwd_reduce then
+                         //   adds kmax slots per sample where it loaded and block-reduced 5 x N rows; zero-filled with part_hz
+                         //   (it FOLLOWS part_hz's B * kmax * H floats in memory)
   float* part;           // (G, FD_REC) per-workgroup partial gradients
   const float* sw;       // per-sample weight of dL/dlogit (jiVAE: alpha[b][k] of sample (k, b)); null: 1
   int64_t x_units;       // > 0: the observations repeat every x_units units (jiVAE: B*N/16; x is (B, N)); 0: x is (M)

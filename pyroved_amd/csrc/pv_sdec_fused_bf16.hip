@@ -837,13 +837,26 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   float2 cs_wo = float2{0.0f, 0.0f}, cs_hz = float2{0.0f, 0.0f}, cs_c0 = float2{0.0f, 0.0f}, cs_c1 = float2{0.0f, 0.0f};
   float2 cs_none = float2{0.0f, 0.0f};
 
+  // (round 6) f.part_rs: the wave's running sums over its rows of sample cur_b of {ll, d(phi), d(scale), d(tx), d(ty)} — every lane
+  // (r, q) carries row r's share (the four q copies are equal), published with dL/d(hz) instead of five stores per row and tile
+  float rs0 = 0.0f, rs1 = 0.0f, rs2 = 0.0f, rs3 = 0.0f, rs4 = 0.0f;
   auto flush_hz = [&](int b) {
     // the wave's rows of sample b end (or the workgroup's do): publish its partial dL/d(hz[b]) in its own slot
     // (kmax counts FB_WAVES slots per workgroup that can touch a sample; unused slots stay zero)
     const int64_t ub = (int64_t)b * upb;
     const int gfirst = (int)(((ub + 1) * G + f.units - 1) / f.units) - 1;
-    *reinterpret_cast<float2*>(f.part_hz + ((int64_t)b * f.kmax + (g - gfirst) * FB_WAVES + wave) * FD_H + 2 * lane) = cs_hz;
+    const int64_t slot = (int64_t)b * f.kmax + (g - gfirst) * FB_WAVES + wave;
+    *reinterpret_cast<float2*>(f.part_hz + slot * FD_H + 2 * lane) = cs_hz;
     cs_hz = float2{0.0f, 0.0f};
+    if (GRADS && f.part_rs) {
+      const float v0 = fb_row16_sum(rs0), v1 = fb_row16_sum(rs1), v2 = fb_row16_sum(rs2), v3 = fb_row16_sum(rs3), v4 = fb_row16_sum(rs4);
+      if (lane == 0) {
+        float* d = f.part_rs + slot * PV_RS_W;
+        *reinterpret_cast<f32x4*>(d) = f32x4{v0, v1, v2, v3};
+        d[4] = v4;
+      }
+      rs0 = rs1 = rs2 = rs3 = rs4 = 0.0f;
+    }
   };
 
   // A unit's sample b / offset inside the sample / observation unit are carried incrementally from tile to tile (round 2):
@@ -923,6 +936,12 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     const bool act = wave < nact;
     const int unit = (int)ut + (act ? wave : 0);
     const int bu = pos_cur.b;
+    // the wave's sample changes with this tile: publish the old one's sums first (round 6: at the TOP of the tile — nothing between
+    // here and the coordinate layer's column sums touches them — so that this tile's row sums can be added where they arise)
+    if (GRADS && act && bu != cur_b) {
+      if (cur_b >= 0) flush_hz(cur_b);
+      cur_b = bu;
+    }
     const int64_t row = (int64_t)unit * FD_UNIT + r;
     float x0, x1, u0c, u1c, sc;
     // this wave's LDS-DMA of the tile's inputs (issued a tile ago; first tile: in front of W2's images, which stay in flight)
@@ -1027,7 +1046,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       }
       FB_STAMP(18);
       dlda *= act ? swv : 0.0f;
-      if (q == 0 && act) {
+      if (GRADS && f.part_rs) {
+        rs0 += act ? ll : 0.0f;
+        if (q == 0 && act && f.loc) f.loc[row] = locv;
+      } else if (q == 0 && act) {
         if (f.llrow) f.llrow[row] = ll;
         if (f.loc) f.loc[row] = locv;
       }
@@ -1100,10 +1122,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       // ---- coordinate layer, cross-row part: dhz[b] = sum_rows dpre0, dWc_k = sum_rows dpre0 * x'_k.  Wave-local
       // (the unit's rows all belong to this wave and to one sample): W2's images are dead since the barrier above, so
       // the wave's own rows of the wgrad-1 staging area serve as the transpose buffer.  No workgroup barrier.
-      if (act && bu != cur_b) {
-        if (cur_b >= 0) flush_hz(cur_b);
-        cur_b = bu;
-      }
       if (F16) {
         if (q == 0) {
           info[16 * wave + r] = frow * x0; info[TILE_ROWS + 16 * wave + r] = frow * x1; info[2 * TILE_ROWS + 16 * wave + r] = frow;
@@ -1138,7 +1156,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       float d0 = fb_sum_q((d04[0] + d04[1]) + (d04[2] + d04[3]));
       float d1 = fb_sum_q((d14[0] + d14[1]) + (d14[2] + d14[3]));
       if (F16) { d0 *= frow; d1 *= frow; }
-      if (q == 0 && act) {
+      if (f.part_rs) {
+        if (act) {
+          rs1 += sc * (d1 * u0c - d0 * u1c);
+          rs2 += d0 * u0c + d1 * u1c;
+          rs3 += d0;
+          rs4 += d1;
+        }
+      } else if (q == 0 && act) {
         f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
         f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
         f.rowtp[2 * f.M + row] = d0;
@@ -1245,10 +1270,18 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         locv = pr;
       }
       dlda *= swv;
-      if (q == 0 && wave == 0) {
-        if (f.llrow) f.llrow[row] = ll;
-        if (f.loc) f.loc[row] = locv;
-        dbo += dlda;
+      if (wave == 0) {
+        // (the tail's row sums ride in wave 0's slot: its sample check first — the tile loop's, at the top of the tile)
+        if (bu != cur_b) {
+          if (cur_b >= 0) flush_hz(cur_b);
+          cur_b = bu;
+        }
+        if (f.part_rs) rs0 += ll;
+        if (q == 0) {
+          if (f.llrow && !f.part_rs) f.llrow[row] = ll;
+          if (f.loc) f.loc[row] = locv;
+          dbo += dlda;
+        }
       }
       // d(wo)[j] += sum_rows dlda h2[row][j], own blocks (transpose buffer: this wave's quarter of the not yet staged dpre arrays)
       {
@@ -1348,10 +1381,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       if (wave == 0) {
         const float* vv = reinterpret_cast<const float*>(smb + TL::V);
         const float* wov = reinterpret_cast<const float*>(smb + TL::WOV);
-        if (bu != cur_b) {
-          if (cur_b >= 0) flush_hz(cur_b);
-          cur_b = bu;
-        }
         const float2 a0 = *reinterpret_cast<const float2*>(vv + 2 * lane);
         const float2 a1 = *reinterpret_cast<const float2*>(vv + FD_H + 2 * lane);
         const float2 a2 = *reinterpret_cast<const float2*>(vv + 2 * FD_H + 2 * lane);
@@ -1360,14 +1389,21 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         cs_c0.x += a1.x; cs_c0.y += a1.y;
         cs_c1.x += a2.x; cs_c1.y += a2.y;
         cs_wo.x += aw.x; cs_wo.y += aw.y;
-        if (q == 0) {
+        {
           const float* dp = rp;
           const float d0 = ((dp[r] + dp[16 + r]) + (dp[32 + r] + dp[48 + r])) * frow;
           const float d1 = ((dp[64 + r] + dp[80 + r]) + (dp[96 + r] + dp[112 + r])) * frow;
-          f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
-          f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
-          f.rowtp[2 * f.M + row] = d0;
-          f.rowtp[3 * f.M + row] = d1;
+          if (f.part_rs) {
+            rs1 += sc * (d1 * u0c - d0 * u1c);
+            rs2 += d0 * u0c + d1 * u1c;
+            rs3 += d0;
+            rs4 += d1;
+          } else if (q == 0) {
+            f.rowtp[row] = sc * (d1 * u0c - d0 * u1c);
+            f.rowtp[f.M + row] = d0 * u0c + d1 * u1c;
+            f.rowtp[2 * f.M + row] = d0;
+            f.rowtp[3 * f.M + row] = d1;
+          }
         }
       }
     }
@@ -1585,7 +1621,7 @@ PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   static_assert(FB_WIMG_BYTES >= FB_SCALE_OFF + 16, "pv_sdec_fused.h and the LDS image layout disagree");
   PvFbPrep p{};
   p.W1 = f.W1; p.W2 = f.W2; p.img = f.wimg; p.zero = f.part_hz; p.wo = f.wo;
-  p.nzero4 = grads ? (int64_t)f.B * f.kmax * FD_H / 4 : 0;
+  p.nzero4 = grads ? (int64_t)f.B * f.kmax * (FD_H + (f.part_rs ? PV_RS_W : 0)) / 4 : 0;      // (dL/d(hz) slots + the row-sum slots behind them)
   const int kind = x3 ? fb_x3_kind(f.units, grads, f.sel) : -1;
   p.mode = fb_kind_w8h(kind) ? 2 : (kind > 8 ? 1 : 0);
   p.scale = (x3 ? !fb_kind_here(kind) : fb_use_w8(f.units, f.sel)) ? 2.8853900817779268f : 0.0f;     // (also what hz arrives multiplied by)
