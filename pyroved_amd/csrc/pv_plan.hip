@@ -822,6 +822,9 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     fold = pv_sdec_fused_fold_ok(f, L.f_grid, p->fused == 2);
     if (fold) fill_fold();
     else f.hz_scale = 0.0f;
+    // (the hosting launch owns whole images: it sums their per-row outputs itself in its epilogue — PvFused::part_rs, first slot)
+    static const int ab_fold_rs = pv_exp_int("PV_FOLD_RS", 1);      // (experiments build: 0 = the latent backward reduces the rows)
+    if (fold && want_grads && H == FD_H && f.llrow && ab_fold_rs) f.part_rs = L.f_part_hz + S * L.f_kmax * H;
   }
   int kl_n = fold ? (int)B : L.kl_blocks;            // KL partial sums in L.kl_part: per sample when a workgroup runs an image's guide, else per 16-row block
   if (fold) {

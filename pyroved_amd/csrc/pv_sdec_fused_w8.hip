@@ -517,6 +517,10 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       f32x4* zp = reinterpret_cast<f32x4*>(f.part_hz + b0 * f.kmax * FD_H);
       const int n4 = e.img_per_wg * f.kmax * (FD_H / 4);
       for (int i = tid; i < n4; i += W8_THREADS) zp[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (f.part_rs) {                                                // ... and its row-sum slots (filled in the epilogue below)
+        f32x4* zr = reinterpret_cast<f32x4*>(f.part_rs + b0 * f.kmax * PV_RS_W);
+        for (int i = tid; i < e.img_per_wg * f.kmax * (PV_RS_W / 4); i += W8_THREADS) zr[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
     }
   }
   // (FOLD: the guide first — its operand requests head the memory queue; the vectors and tables below need nothing from it)
@@ -1297,6 +1301,32 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   const float tb = pv_wave_sum(dbo);
   if (lane == 0) red[wave] = tb;
   __syncthreads();
+  if (FOLD && f.part_rs) {
+    // (round 6) ONE image per workgroup: its rows' five per-row outputs {ll, d(phi), d(scale), d(tx), d(ty)} were all written by this
+    // workgroup (every wave's stores are complete: the barrier above drains them) — summed here, from L2, into the image's first
+    // row-sum slot, so that the latent backward adds slots instead of loading and block-reducing 5 x N rows (the running sums the
+    // 4-wave kernels keep in registers do not fit this kernel: profiles/r06h_row_sums_ab.txt).  Fixed order: thread n takes rows
+    // n, n + 512, ...; wave sums; waves 0..7.
+    const int64_t r0 = (int64_t)g * f.N;
+    float a5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int n = tid; n < f.N; n += W8_THREADS) {
+      a5[0] += __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a5[1 + c] += __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) a5[c] = pv_wave_sum(a5[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) red[8 + 8 * c + wave] = a5[c];
+    }
+    __syncthreads();
+    if (tid < 5) {
+      float v = 0.0f;
+      for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * tid + w];
+      f.part_rs[((int64_t)g * f.kmax) * PV_RS_W + tid] = v;
+    }
+  }
   if (tid < FD_H) {
     const float* scr = reinterpret_cast<const float*>(smb + WO_SA);
     float vo = 0.0f, v0 = 0.0f, v1 = 0.0f;

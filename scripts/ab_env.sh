@@ -1,14 +1,10 @@
 #!/bin/bash
-# A/B of environment knobs on the GPU box (round 5: the knobs exist in the experiments build only — loaded here through PV_LIB_PATH): bench lines of the given configs under each "NAME=VALUE[,NAME=VALUE...]" setting ("-" = defaults).
-#   bash scripts/ab_env.sh <tag> "<cfg> ..." "<fused> ..." <setting> [<setting> ...]
-TAG=$1; CFGS=$2; FUSED=$3; shift 3
-OUT=gpurun_out/$TAG; mkdir -p $OUT
-for round in 1 2; do
-  for setting in "$@"; do
-    envs=(); [ "$setting" != "-" ] && IFS=',' read -ra envs <<< "$setting"
-    for cfg in $CFGS; do for f in $FUSED; do
-      echo -n "$setting $cfg fused=$f: "
-      env PV_LIB_PATH=${PV_LIB_PATH:-pyroved_amd/libpyroved_amd_exp.so} "${envs[@]}" timeout 300 python bench.py --config $cfg --fused $f --steps 50 --warmup 10 --repeats 3 --no-cpu-baseline --no-legs --no-alt --no-configs 2>>$OUT/err.log | python scripts/benchline.py
-    done; done
+# A/B of one environment switch of the experiments build on one box: scripts/ab_env.sh NAME "v1 v2" [bench args]
+name=$1; vals=$2; shift; shift
+args=${@:---steps 200 --warmup 5 --no-alt --no-configs --no-legs --no-cpu-baseline}
+export PV_LIB_PATH=$PWD/pyroved_amd/libpyroved_amd_exp.so
+for i in 1 2 3; do
+  for v in $vals; do
+    env $name=$v python bench.py $args 2>&1 | tail -1 | cut -c1-140 | sed "s/^/$name=$v /"
   done
-done | tee $OUT/ab.txt
+done
