@@ -786,7 +786,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // over per-slot row sums instead of rows.  NOT the 8-wave throughput kernel: it has no registers for five running sums, and
   // keeping them in LDS cost its in-order waves what the next launch saved (read-modify-write: +-0 on the step; ds_add_f32: +1.4 us
   // on the kernel — profiles/r06h_row_sums_ab.txt)
-  f.part_rs = (want_grads && p->fused >= 2 && H == FD_H &&
+  static const int ab_row_sums = pv_exp_int("PV_ROW_SUMS", 1);      // (experiments build: 0 = per-row outputs from the 4-wave kernels too)
+  f.part_rs = (want_grads && p->fused >= 2 && H == FD_H && ab_row_sums &&
                pv_sdec_fused_bf16_record_fmt(p->fused == 2, R / FD_UNIT, p->dec_kernel) == PV_REC_LANE_F32)
                   ? L.f_part_hz + S * L.f_kmax * H : nullptr;
   f.wimg = L.f_wimg; f.park = L.f_park;
