@@ -1292,6 +1292,22 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   // per-wave column sums -> LDS (the staging area is free: every wave is past the last tile's barrier 4 and its own
   // wave-local reads) -> summed over the waves in ascending order
   __syncthreads();
+  // (round 6, FOLD: the image's per-row outputs are complete in L2 — the barrier above drains every wave's stores — and are requested
+  //  HERE, so that their round trip runs under the column-sum phase below; they are added up behind its barrier)
+  float rsv[2][5] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
+  const bool fold_rs = FOLD && f.part_rs && f.N <= 2 * W8_THREADS;
+  if (fold_rs) {
+    const int64_t r0 = (int64_t)g * f.N;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = tid + u * W8_THREADS;
+      if (n < f.N) {
+        rsv[u][0] = __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rsv[u][1 + c] = __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   {
     float* scr = reinterpret_cast<float*>(smb + WO_SA);            // [wave][n][128] floats = 64 KB
 #pragma unroll
@@ -1309,10 +1325,15 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
     // n, n + 512, ...; wave sums; waves 0..7.
     const int64_t r0 = (int64_t)g * f.N;
     float a5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int n = tid; n < f.N; n += W8_THREADS) {
-      a5[0] += __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
+    if (fold_rs) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a5[1 + c] += __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int c = 0; c < 5; ++c) a5[c] = rsv[0][c] + rsv[1][c];       // (rows tid, tid + 512: requested above)
+    } else {
+      for (int n = tid; n < f.N; n += W8_THREADS) {
+        a5[0] += __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a5[1 + c] += __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) a5[c] = pv_wave_sum(a5[c]);
