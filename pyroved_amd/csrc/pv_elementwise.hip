@@ -971,6 +971,7 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
       // (the same four chains in the same order — slot kk < (kmax & ~3) to chain kk & 3, the rest to chain 0 — but 16 slots requested
       //  at once, past-the-end ones clamped and added as zeros: the rolled loops waited for memory once per group of four and once per
       //  leftover slot — three dependent round trips at the usual nine slots, ~2.4 k cycles of this launch's critical path)
+      if (p.dhz_ready) { sh_dhz[j] += p.dhz[s * p.H + j]; continue; }      // (the hosting decoder launch summed its waves' partials itself)
       const float* ph = p.part_hz + (s * p.kmax) * p.H + j;
       float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
       const int k4 = p.kmax & ~3;

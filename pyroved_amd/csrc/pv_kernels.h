@@ -113,6 +113,7 @@ struct PvLatentBwd {
   const float* Wz;       // (H, lat_in) decoder.coord_latent.fc_latent.weight
   float* llb;            // (B)
   float* dhz;            // (B, H)
+  int dhz_ready;         // 1: the decoder launch already wrote dhz (PvFused::dhz_out): part_hz is not read
   int64_t M;
   int N, kmax, H, lat_in;
   PvHeadBwd hb;          // dzc / dtp fields unused (values stay in LDS)

@@ -826,6 +826,9 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     // (the hosting launch owns whole images: it sums their per-row outputs itself in its epilogue — PvFused::part_rs, first slot)
     static const int ab_fold_rs = pv_exp_int("PV_FOLD_RS", 1);      // (experiments build: 0 = the latent backward reduces the rows)
     if (fold && want_grads && H == FD_H && f.llrow && ab_fold_rs) f.part_rs = L.f_part_hz + S * L.f_kmax * H;
+    // ... and its dL/d(hz): the eight waves' partials summed next to the other column sums (PvFused::dhz_out)
+    static const int ab_fold_dhz = pv_exp_int("PV_FOLD_DHZ", 1);
+    if (fold && want_grads && H == FD_H && ab_fold_dhz) f.dhz_out = L.dhz;
   }
   int kl_n = fold ? (int)B : L.kl_blocks;            // KL partial sums in L.kl_part: per sample when a workgroup runs an image's guide, else per 16-row block
   if (fold) {
@@ -871,6 +874,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   PvLatentBwd lb{};
   lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;
   lb.part_rs = f.part_rs;
+  lb.dhz_ready = f.dhz_out ? 1 : 0;
   lb.llb = L.llb; lb.dhz = L.dhz; lb.M = R; lb.N = (int)N; lb.kmax = L.f_kmax; lb.H = H; lb.lat_in = (int)lat_in;
   PvHeadBwd& hb = lb.hb;
   hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;

@@ -32,6 +32,9 @@ struct PvFused {
                          //   adds kmax slots per sample where it loaded and block-reduced 5 x N rows; zero-filled with part_hz
                          //   (it FOLLOWS part_hz's B * kmax * H floats in memory)
   float* part;           // (G, FD_REC) per-workgroup partial gradients
+  float* dhz_out;        // (round 6) (B, H) or null.  Not null (the launch that hosts the guide: one image per workgroup): the workgroup
+                         //   sums its waves' dL/d(hz) partials itself and writes the image's dL/d(hz) here — pv_latent_bwd_reduce then
+                         //   reads it instead of adding kmax slots of part_hz (PvLatentBwd::dhz_ready)
   const float* sw;       // per-sample weight of dL/dlogit (jiVAE: alpha[b][k] of sample (k, b)); null: 1
   int64_t x_units;       // > 0: the observations repeat every x_units units (jiVAE: B*N/16; x is (B, N)); 0: x is (M)
   void* wimg;            // bf16x3 kernel only: FB_WIMG_BYTES of pre-split weight images (pv_sdec_fused_bf16_prep)

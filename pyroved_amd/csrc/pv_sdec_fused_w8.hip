@@ -1241,7 +1241,9 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   if (!GRADS) return;
   W8_STAMP_K(2);
 
-  if (cur_b >= 0) flush_hz(cur_b);
+  // (FOLD with dhz_out: one image per workgroup — no slot was ever published; the waves' partials are summed with the column sums below)
+  const bool own_dhz = FOLD && f.dhz_out != nullptr;
+  if (cur_b >= 0 && !own_dhz) flush_hz(cur_b);
   // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
   {
     const int jp = wave >> 1, kh = wave & 1;
@@ -1350,14 +1352,16 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   }
   if (tid < FD_H) {
     const float* scr = reinterpret_cast<const float*>(smb + WO_SA);
-    float vo = 0.0f, v0 = 0.0f, v1 = 0.0f;
+    float vo = 0.0f, v0 = 0.0f, v1 = 0.0f, vh = 0.0f;
 #pragma unroll
     for (int w = 0; w < W8_WAVES; ++w) {
       const float* s_ = scr + (w * 16) * FD_H + tid;
+      vh += s_[0];                                                   // (column 0: the wave's dL/d(hz) partial, times C^2)
       v0 += s_[1 * FD_H] + s_[5 * FD_H];
       v1 += s_[2 * FD_H] + s_[6 * FD_H];
       vo += s_[3 * FD_H] + s_[4 * FD_H];
     }
+    if (own_dhz) f.dhz_out[(int64_t)g * FD_H + tid] = vh * W8_RC2;
     rec[2 * FD_H * FD_H + 2 * FD_H + tid] = v0 * W8_RC2;
     rec[2 * FD_H * FD_H + 3 * FD_H + tid] = v1 * W8_RC2;
     rec[2 * FD_H * FD_H + 4 * FD_H + tid] = vo;
