@@ -1009,11 +1009,15 @@ __device__ __forceinline__ void pv_latent_bwd_block(const PvLatentBwd& p, int b)
   }
   if (p.fwd_only) return;
   const int n_content = p.lat_in - (p.K > 0 ? p.K : 0);        // the one-hot class columns carry no gradient to z
-  for (int i = 0; i < n_content; ++i) {
-    float v = 0.0f;
-    for (int j = t; j < p.H; j += 256) v += sh_dhz[j] * p.Wz[j * p.lat_in + i];
-    v = block_sum_256(v, sm);
-    if (t == 0) sh_dzc[i] = v;
+  if (p.dzc_in) {                                     // (the hosting decoder launch contracted dL/d(hz) with Wz itself)
+    if (t < n_content) sh_dzc[t] = p.dzc_in[(int64_t)b * p.lat_in + t];
+  } else {
+    for (int i = 0; i < n_content; ++i) {
+      float v = 0.0f;
+      for (int j = t; j < p.H; j += 256) v += sh_dhz[j] * p.Wz[j * p.lat_in + i];
+      v = block_sum_256(v, sm);
+      if (t == 0) sh_dzc[i] = v;
+    }
   }
   pv_lds_barrier();
   LB_STAMP(3);

@@ -114,6 +114,7 @@ struct PvLatentBwd {
   float* llb;            // (B)
   float* dhz;            // (B, H)
   int dhz_ready;         // 1: the decoder launch already wrote dhz (PvFused::dhz_out): part_hz is not read
+  const float* dzc_in;   // not null (with dhz_ready, K == 0): ... and dL/dz content (B, lat_in) = dhz Wz (PvFused::dzc_out)
   int64_t M;
   int N, kmax, H, lat_in;
   PvHeadBwd hb;          // dzc / dtp fields unused (values stay in LDS)

@@ -828,7 +828,10 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     if (fold && want_grads && H == FD_H && f.llrow && ab_fold_rs) f.part_rs = L.f_part_hz + S * L.f_kmax * H;
     // ... and its dL/d(hz): the eight waves' partials summed next to the other column sums (PvFused::dhz_out)
     static const int ab_fold_dhz = pv_exp_int("PV_FOLD_DHZ", 1);
-    if (fold && want_grads && H == FD_H && ab_fold_dhz) f.dhz_out = L.dhz;
+    if (fold && want_grads && H == FD_H && ab_fold_dhz) {
+      f.dhz_out = L.dhz;
+      if (ab_fold_dhz > 1 || ab_fold_dhz == 1) f.dzc_out = (ab_fold_dhz == 2) ? nullptr : L.dzc;      // (PV_FOLD_DHZ=2: dhz only, A/B)
+    }
   }
   int kl_n = fold ? (int)B : L.kl_blocks;            // KL partial sums in L.kl_part: per sample when a workgroup runs an image's guide, else per 16-row block
   if (fold) {
@@ -875,6 +878,7 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;
   lb.part_rs = f.part_rs;
   lb.dhz_ready = f.dhz_out ? 1 : 0;
+  lb.dzc_in = f.dzc_out;
   lb.llb = L.llb; lb.dhz = L.dhz; lb.M = R; lb.N = (int)N; lb.kmax = L.f_kmax; lb.H = H; lb.lat_in = (int)lat_in;
   PvHeadBwd& hb = lb.hb;
   hb.z = L.z; hb.z_scale = L.z_scale; hb.eps = p->eps;

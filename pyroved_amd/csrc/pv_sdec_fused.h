@@ -35,6 +35,7 @@ struct PvFused {
   float* dhz_out;        // (round 6) (B, H) or null.  Not null (the launch that hosts the guide: one image per workgroup): the workgroup
                          //   sums its waves' dL/d(hz) partials itself and writes the image's dL/d(hz) here — pv_latent_bwd_reduce then
                          //   reads it instead of adding kmax slots of part_hz (PvLatentBwd::dhz_ready)
+  float* dzc_out;        // (round 6) (B, lat_in) or null, with dhz_out: ... and the image's dL/dz = dL/d(hz) Wz (PvLatentBwd::dzc_in)
   const float* sw;       // per-sample weight of dL/dlogit (jiVAE: alpha[b][k] of sample (k, b)); null: 1
   int64_t x_units;       // > 0: the observations repeat every x_units units (jiVAE: B*N/16; x is (B, N)); 0: x is (M)
   void* wimg;            // bf16x3 kernel only: FB_WIMG_BYTES of pre-split weight images (pv_sdec_fused_bf16_prep)

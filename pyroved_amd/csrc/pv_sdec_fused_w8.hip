@@ -1310,6 +1310,11 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       }
     }
   }
+  float wzv[4] = {0.0f, 0.0f, 0.0f, 0.0f};                           // (FOLD: fc_latent's row of this thread's hidden unit, for dL/dz below)
+  if (FOLD && f.dhz_out && f.dzc_out && tid < FD_H) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wzv[i] = i < e.lat_in ? e.Wz[(int64_t)tid * e.lat_in + i] : 0.0f;
+  }
   {
     float* scr = reinterpret_cast<float*>(smb + WO_SA);            // [wave][n][128] floats = 64 KB
 #pragma unroll
@@ -1319,37 +1324,9 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   const float tb = pv_wave_sum(dbo);
   if (lane == 0) red[wave] = tb;
   __syncthreads();
-  if (FOLD && f.part_rs) {
-    // (round 6) ONE image per workgroup: its rows' five per-row outputs {ll, d(phi), d(scale), d(tx), d(ty)} were all written by this
-    // workgroup (every wave's stores are complete: the barrier above drains them) — summed here, from L2, into the image's first
-    // row-sum slot, so that the latent backward adds slots instead of loading and block-reducing 5 x N rows (the running sums the
-    // 4-wave kernels keep in registers do not fit this kernel: profiles/r06h_row_sums_ab.txt).  Fixed order: thread n takes rows
-    // n, n + 512, ...; wave sums; waves 0..7.
-    const int64_t r0 = (int64_t)g * f.N;
-    float a5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (fold_rs) {
-#pragma unroll
-      for (int c = 0; c < 5; ++c) a5[c] = rsv[0][c] + rsv[1][c];       // (rows tid, tid + 512: requested above)
-    } else {
-      for (int n = tid; n < f.N; n += W8_THREADS) {
-        a5[0] += __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a5[1 + c] += __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 5; ++c) a5[c] = pv_wave_sum(a5[c]);
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < 5; ++c) red[8 + 8 * c + wave] = a5[c];
-    }
-    __syncthreads();
-    if (tid < 5) {
-      float v = 0.0f;
-      for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * tid + w];
-      f.part_rs[((int64_t)g * f.kmax) * PV_RS_W + tid] = v;
-    }
-  }
+  // ---- the column sums over the waves (threads 0 .. 127), then — where the workgroup owns a whole image (FOLD) — the image's row
+  // sums, dL/d(hz) and dL/dz for the latent backward (round 6: PvFused::part_rs / dhz_out / dzc_out), one more barrier for all three ----
+  float dhz_j = 0.0f;                                                // this thread's dL/d(hz[g][tid]) (tid < 128)
   if (tid < FD_H) {
     const float* scr = reinterpret_cast<const float*>(smb + WO_SA);
     float vo = 0.0f, v0 = 0.0f, v1 = 0.0f, vh = 0.0f;
@@ -1361,10 +1338,53 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       v1 += s_[2 * FD_H] + s_[6 * FD_H];
       vo += s_[3 * FD_H] + s_[4 * FD_H];
     }
-    if (own_dhz) f.dhz_out[(int64_t)g * FD_H + tid] = vh * W8_RC2;
+    dhz_j = vh * W8_RC2;
+    if (own_dhz) f.dhz_out[(int64_t)g * FD_H + tid] = dhz_j;
     rec[2 * FD_H * FD_H + 2 * FD_H + tid] = v0 * W8_RC2;
     rec[2 * FD_H * FD_H + 3 * FD_H + tid] = v1 * W8_RC2;
     rec[2 * FD_H * FD_H + 4 * FD_H + tid] = vo;
+  }
+  const bool own_dzc = own_dhz && f.dzc_out != nullptr;
+  if (FOLD && (f.part_rs || own_dzc)) {
+    // ONE image per workgroup.  Row sums: its rows' five per-row outputs {ll, d(phi), d(scale), d(tx), d(ty)} were all written by
+    // this workgroup (requested above, behind the barrier that drains every wave's stores) — summed into the image's first row-sum
+    // slot, so that the latent backward adds slots instead of loading and block-reducing 5 x N rows (the running sums the 4-wave
+    // kernels keep in registers do not fit this kernel: profiles/r06h_row_sums_ab.txt).  Fixed order: thread n takes rows n,
+    // n + 512; wave sums; waves 0..7.  dL/dz[i] = sum_j dL/d(hz[j]) Wz[j][i] (coord_latent.fc_latent, nets/fc.py:217,230): threads
+    // 0 .. 127 hold dL/d(hz[j]); wave sums of waves 0, 1.
+    if (f.part_rs) {
+      const int64_t r0 = (int64_t)g * f.N;
+      float a5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (fold_rs) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) a5[c] = rsv[0][c] + rsv[1][c];       // (rows tid, tid + 512: requested above)
+      } else {
+        for (int n = tid; n < f.N; n += W8_THREADS) {
+          a5[0] += __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a5[1 + c] += __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 5; ++c) a5[c] = pv_wave_sum(a5[c]);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) red[8 + 8 * c + wave] = a5[c];
+      }
+    }
+    if (own_dzc && wave < 2) {
+      for (int i = 0; i < e.lat_in; ++i) {
+        const float pz = pv_wave_sum(dhz_j * (i < 4 ? wzv[i] : e.Wz[(int64_t)tid * e.lat_in + i]));
+        if (lane == 0) info[16 * wave + i] = pz;
+      }
+    }
+    __syncthreads();
+    if (f.part_rs && tid < 5) {
+      float v = 0.0f;
+      for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * tid + w];
+      f.part_rs[((int64_t)g * f.kmax) * PV_RS_W + tid] = v;
+    }
+    if (own_dzc && tid < e.lat_in) f.dzc_out[(int64_t)g * e.lat_in + tid] = info[tid] + info[16 + tid];
   }
   if (tid == 0) {
     float v = 0.0f;
