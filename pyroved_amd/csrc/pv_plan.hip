@@ -876,6 +876,12 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   // launch: the per-workgroup gradient records summed into the flat gradient
   PvLatentBwd lb{};
   lb.llrow = L.llrow; lb.rowtp = L.f_rowtp; lb.part_hz = L.f_part_hz; lb.Wz = p->params + p->fc_latent.w_off;
+  // (round 6) the 4-wave kernels too, wherever every workgroup's units are exactly one sample (batch == grid, e.g. C2's 256 on 256 CUs)
+  static const int ab_own = pv_exp_int("PV_OWN_SAMPLE", 1);
+  if (ab_own && !f.dhz_out && f.part_rs && K == 0 && lat_in <= 16 && S == L.f_grid && f.units == S * (N / FD_UNIT) &&
+      !p->dy && pv_sdec_fused_bf16_record_fmt(p->fused == 2, R / FD_UNIT, p->dec_kernel) == PV_REC_LANE_F32) {
+    f.dhz_out = L.dhz; f.dzc_out = L.dzc; f.Wz = p->params + p->fc_latent.w_off; f.lat_in = (int)lat_in;
+  }
   lb.part_rs = f.part_rs;
   lb.dhz_ready = f.dhz_out ? 1 : 0;
   lb.dzc_in = f.dzc_out;

@@ -36,6 +36,9 @@ struct PvFused {
                          //   sums its waves' dL/d(hz) partials itself and writes the image's dL/d(hz) here — pv_latent_bwd_reduce then
                          //   reads it instead of adding kmax slots of part_hz (PvLatentBwd::dhz_ready)
   float* dzc_out;        // (round 6) (B, lat_in) or null, with dhz_out: ... and the image's dL/dz = dL/d(hz) Wz (PvLatentBwd::dzc_in)
+  const float* Wz;       //   coord_latent.fc_latent.weight (H, lat_in) and lat_in, for dzc_out (the 4-wave kernels; the hosting 8-wave
+  int lat_in;            //   launch has them in PvEncFold).  dhz_out / dzc_out are only set when every workgroup's unit range is exactly
+                         //   ONE sample (grid == B, units == B * N / 16, x_units == 0): the caller's promise, re-checked by the kernel
   const float* sw;       // per-sample weight of dL/dlogit (jiVAE: alpha[b][k] of sample (k, b)); null: 1
   int64_t x_units;       // > 0: the observations repeat every x_units units (jiVAE: B*N/16; x is (B, N)); 0: x is (M)
   void* wimg;            // bf16x3 kernel only: FB_WIMG_BYTES of pre-split weight images (pv_sdec_fused_bf16_prep)

@@ -1411,7 +1411,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   FB_KSTAMP(2);                                                          // last tile done
   if (!GRADS) return;
 
-  if (cur_b >= 0) flush_hz(cur_b);
+  // (round 6) this workgroup's units are exactly ONE sample (batch == grid): it hands the latent backward the sample's dL/d(hz),
+  // dL/dz and row sums itself — its four waves' partials summed next to the other column sums — instead of four slots each
+  const bool own = f.dhz_out != nullptr && u_lo == (int64_t)g * upb && u_hi - u_lo == upb;
+  if (cur_b >= 0 && !own) flush_hz(cur_b);
   if (PP::KEEP_WO) {
     // (every wave is past the last tile's barriers: the wgrad-2 staging rows are free)
     f32x4 t[8];
@@ -1460,7 +1463,24 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     *reinterpret_cast<float2*>(d + (3 * wave + 0) * FD_H + 2 * lane) = cs_wo;
     *reinterpret_cast<float2*>(d + (3 * wave + 1) * FD_H + 2 * lane) = cs_c0;
     *reinterpret_cast<float2*>(d + (3 * wave + 2) * FD_H + 2 * lane) = cs_c1;
+    float* dh = d + 3 * FB_WAVES * FD_H;                  // own: [wave][128] dL/d(hz) partials, then [wave][8] row sums, then [2][16] dz partials
+    float wzv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (own) {
+      *reinterpret_cast<float2*>(dh + wave * FD_H + 2 * lane) = cs_hz;
+      if (f.part_rs) {
+        const float v0 = fb_row16_sum(rs0), v1 = fb_row16_sum(rs1), v2 = fb_row16_sum(rs2), v3 = fb_row16_sum(rs3), v4 = fb_row16_sum(rs4);
+        if (lane == 0) {
+          float* rr = dh + FB_WAVES * FD_H + 8 * wave;
+          rr[0] = v0; rr[1] = v1; rr[2] = v2; rr[3] = v3; rr[4] = v4;
+        }
+      }
+      if (f.dzc_out && tid < FD_H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wzv[i] = i < f.lat_in ? f.Wz[(int64_t)tid * f.lat_in + i] : 0.0f;
+      }
+    }
     __syncthreads();
+    float dhz_j = 0.0f;
     if (tid < FD_H) {
       float vo = 0.0f, v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
@@ -1468,10 +1488,30 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         vo += d[(3 * w + 0) * FD_H + tid];
         v0 += d[(3 * w + 1) * FD_H + tid];
         v1 += d[(3 * w + 2) * FD_H + tid];
+        if (own) dhz_j += dh[w * FD_H + tid];
       }
       rec[2 * FD_H * FD_H + 2 * FD_H + tid] = v0;
       rec[2 * FD_H * FD_H + 3 * FD_H + tid] = v1;
       rec[2 * FD_H * FD_H + 4 * FD_H + tid] = vo;
+      if (own) f.dhz_out[(int64_t)g * FD_H + tid] = dhz_j;
+    }
+    if (own) {
+      if (f.part_rs && tid < 5) {
+        const float* rr = dh + FB_WAVES * FD_H + tid;
+        f.part_rs[((int64_t)g * f.kmax) * PV_RS_W + tid] = (rr[0] + rr[8]) + (rr[16] + rr[24]);      // (slot 0 of the sample; the others stay zero)
+      }
+      if (f.dzc_out) {
+        // dL/dz[i] = sum_j dL/d(hz[j]) Wz[j][i]: threads 0 .. 127 hold dL/d(hz[j]) (waves 0, 1)
+        float* dzp = dh + FB_WAVES * FD_H + 8 * FB_WAVES;
+        if (wave < 2) {
+          for (int i = 0; i < f.lat_in; ++i) {
+            const float pz = pv_wave_sum(dhz_j * (i < 4 ? wzv[i] : f.Wz[(int64_t)tid * f.lat_in + i]));
+            if (lane == 0) dzp[16 * wave + i] = pz;
+          }
+        }
+        __syncthreads();
+        if (tid < f.lat_in) f.dzc_out[(int64_t)g * f.lat_in + tid] = dzp[tid] + dzp[16 + tid];
+      }
     }
   }
   if (tid == 0) {
