@@ -803,7 +803,7 @@ def main():
             # what DESIGN.md section 6 expects on 8 GPUs of one node (no hardware run before round 4): the driver computes the
             # measured x from its own per-N runs; these are the predictions to hold them against
             out["expected_x8"] = {"c2_weak": "5.1-5.9 (one ncclAllReduce of 0.6 MB, ~30-50 us, enqueued by the library between the last "
-                                             "gradient launch and the Adam launch of a 0.100 ms step: latency-bound on xGMI; 6x needs <= 33 us "
+                                             "gradient launch and the Adam launch of a 0.098 ms step: latency-bound on xGMI; 6x needs <= 32 us "
                                              "for collective + Adam)",
                                   "c2_fp32_class_weak": "6.1-6.6 (0.175 ms step)",
                                   "c5_weak": "~7.4 (2.3 MB per 0.76-0.80 ms step)", "c2_strong": "1.1-1.3 (latency-bound by design)"}
