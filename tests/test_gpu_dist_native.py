@@ -173,3 +173,31 @@ def test_bench_multirank_path_over_nccl_world1(gpu_device):
     assert abs(d["fp32_class"]["loss_per_image_step0"] - 544.5358) < 0.02
     # the conv config's weak-scaling leg rides along as at N > 1: VED's one-call data-parallel step (pv_ved_dp_step) through bench.py
     assert d["c5_weak"]["value"] > 0 and d["c5_weak"]["allreduce_ms"] > 0, d.get("c5_weak")
+
+
+def test_dp_step_captured_in_a_hipgraph_replays_bit_identically(comm):
+    """pv_ivae_dp_step only ENQUEUES on the caller's stream (gradient launches, RCCL's all-reduce kernel, the optimizer launch): the
+    whole data-parallel step can be captured in a hipGraph.  A captured-and-replayed step must equal the eager step bit for bit
+    (scripts/dp_graph_capture.py is the stand-alone form)."""
+    import pyroved_amd as pv
+    mk = lambda: pv.models.iVAE((28, 28), 2, ["r", "t"], seed=1, device="cuda")
+    ma, mb = mk(), mk()
+    ea, eb = ma.engine(fused=3), mb.engine(fused=3)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(256, 28, 28, generator=g).cuda()
+    eps = torch.randn(256, ma.z_dim, generator=g).cuda()
+    ha, hb = torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda")
+    ea.loss_and_grads(x, eps, step=True, comm=comm, hist_out=ha)        # one eager step each: module load, RCCL's first call
+    eb.loss_and_grads(x, eps, step=True, comm=comm, hist_out=hb)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            eb.loss_and_grads(x, eps, step=True, comm=comm, hist_out=hb)    # (adam_step = 2 is baked into the captured launch)
+    torch.cuda.synchronize()
+    eb.adam_t -= 1                       # capture does not execute
+    graph.replay(); eb.adam_t += 1
+    ea.loss_and_grads(x, eps, step=True, comm=comm, hist_out=ha)
+    torch.cuda.synchronize()
+    assert torch.equal(ea.flat, eb.flat) and torch.equal(ha, hb) and torch.isfinite(ha).all()
