@@ -106,9 +106,11 @@ __global__ __launch_bounds__(GI_THREADS) void pv_guide_img_kernel(PvEncFold e, P
   if (wave == 0) {
     // z = mu + softplus(s) eps and the sampled-KL terms (torch Normal.log_prob), one lane per latent coordinate
     float lp = 0.0f, lq = 0.0f;
-    if (lane < zd) {
+    float rc_ = 1.0f, rs_ = 0.0f;                  // cos / sin of the rotation, by the lane that holds phi (coordinate 0): one range
+    if (lane < zd) {                                // reduction, next to the other lanes' log-density terms
       const float mu = hds[lane], sig = pv_softplus(hds[zd + lane]);
       const float z = mu + sig * pep;
+      if (lane == 0 && e.coord_dim == 2 && e.has_r) sincosf(z, &rs_, &rc_);
       e.z[b * zd + lane] = z;
       e.z_scale[b * zd + lane] = sig;
       if (e.z_loc_out) e.z_loc_out[b * zd + lane] = mu;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(GI_THREADS) void pv_guide_img_kernel(PvEncFold e, P
       if (e.coord_dim == 1) {
         if (e.has_t) { tx = zs[0] * e.tp0; idx = 1; }
       } else if (e.coord_dim == 2) {
-        if (e.has_r) { const float phi = zs[idx++]; c = cosf(phi); sn = sinf(phi); }
+        if (e.has_r) { ++idx; c = rc_; sn = rs_; }
         if (e.has_t) { tx = zs[idx] * e.tp0; ty = zs[idx + 1] * e.tp1; idx += 2; }
         if (e.has_s) { sc = 1.0f + e.sc_prior * zs[idx++]; }
       }
