@@ -24,11 +24,16 @@ __device__ __forceinline__ void fb_split(float x, __bf16& hi, __bf16& lo) {
 __device__ __forceinline__ int fb_pcol(int k) {
   return (k & ~31) | (((k >> 2) & 3) << 3) | (((k >> 4) & 1) << 2) | (k & 3);
 }
+// q-swapped form (PvFbPrep::qswap, round 6; the 4-wave kernel's images): the half a column block sits in is h ^ (q >> 1) — chunks
+// q = 2, 3 hold [h = 1 | h = 0].  The forward's operand stays one ds_read_b128 (its lanes of groups q >= 2 feed the activation
+// pieces in the same swapped order: fb_catq); the dgrad's transposing read of column block 2m + h now takes pieces q' = 0, 1 from
+// half h and q' = 2, 3 from the other one, so its 32 lanes (8 rows x 4 pieces) cover 16 chunks x BOTH halves = all 64 banks
+// once: conflict-free, where the plain form has every lane on the same half (2-way).
 // ... and every row R of an image has its sixteen 16-byte chunks XOR-swizzled by fb_swz(R) = 4*(R&3) + SL[(R>>2)&3],
 // SL = {0,2,3,1}: (a) the forward's ds_read_b128 (lane (r,q): row 16*ob + r, chunk 4m + q; serviced in the 16-lane
 // groups {0-3,12-15,20-27}, ...) touches 16 distinct chunks per group = all 64 banks; (b) the dgrad's transposing
-// 8-byte reads (32 lanes: 8 rows x 4 chunks, one half of each chunk) are 2-way, the minimum while all lanes want
-// the same half.  Unpadded rows make an image exactly 32 KB.
+// 8-byte reads (32 lanes: 8 rows x 4 chunks, one half of each chunk) are 2-way while all lanes want the same half (the
+// plain form; conflict-free in the q-swapped one).  Unpadded rows make an image exactly 32 KB.
 __device__ __forceinline__ int fb_sl(int t) { return (0x78 >> (2 * t)) & 3; }
 __device__ __forceinline__ int fb_swz(int R) { return 4 * (R & 3) + fb_sl((R >> 2) & 3); }
 // element index of (row R, permuted column pc) in an image
@@ -50,6 +55,7 @@ struct PvFbPrep {
   float scale;                        // mode 0: images hold scale * W (0: unscaled) — pv_sdec_fused_w8.hip's 2 log2(e)
   int mode;                           // 0: bf16 pieces, 1: normalised fp16 pieces, 2: fp16 pieces of C s W
   const float* wo;                    // mode 1: decoder.out weights (128), for s_o
+  int qswap;                          // the q-swapped column order (above)
 };
 // max |v| over float4s [lo4, hi4) of v, by one wave (every lane returns it); loads in independent batches of 16 per lane — a
 // loop of single dependent loads paid an L2 round trip per iteration: +23 us on the launch that hosts the preparation
@@ -132,7 +138,7 @@ __device__ __forceinline__ void pv_fb_prep(const PvFbPrep& p, int64_t t, int64_t
         fb_split(w2[i], x, y); h2[i] = __builtin_bit_cast(unsigned short, x); l2[i] = __builtin_bit_cast(unsigned short, y);
       }
     }
-    const int e = fb_wel(row, fb_pcol(4 * c4));
+    const int e = fb_wel(row, fb_pcol(4 * c4)) ^ (p.qswap ? 4 * ((c4 >> 1) & 1) : 0);
     *reinterpret_cast<us4*>(img + e) = h1;
     *reinterpret_cast<us4*>(img + W_IMG + e) = l1;
     *reinterpret_cast<us4*>(img + 2 * W_IMG + e) = h2;

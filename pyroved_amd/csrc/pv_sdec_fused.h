@@ -48,6 +48,7 @@ struct PvFused {
   int N, cd, B, lik, sigmoid_out, kmax;
   int ablate;            // profiling only (env PV_FD_ABLATE): 1 skip wgrad exchanges, 2 skip coord-layer exchange,
                          // 4 skip dgrad, 8 skip d(wo) reduction  -> wrong gradients, used to price the phases
+  int qswap;             // the weight images are in the q-swapped column order (pv_fb_layout.h; set by the 4-wave kernel's launcher)
   float sig;
   int sel;               // pv_ivae_plan.dec_kernel: which build of the decoder kernel runs (0: by problem size; pv_sdec_fused_bf16.hip)
   int dl_exp;            // fp16 modes (pv_sdec_fused_bf16.hip): exponent bias of the per-row dL/dlogit factor folded into the
@@ -105,6 +106,7 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
 // ... or, as arguments for a kernel that hosts the preparation (pv_fb_layout.h: pv_fb_prep)
 struct PvFbPrep;
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3);
+bool pv_sdec_fused_w8_qswap();          // the 8-wave plain-bf16 kernel's images are in the q-swapped column order (pv_fb_layout.h)
 int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s, const PvEncFold* fold = nullptr);
 int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s, const PvEncFold* fold = nullptr);
 // the 8-wave split-precision kernel (pv_sdec_fused_w8x3.hip; images pre-scaled by 2 log2(e) like the plain 8-wave kernel's)

@@ -164,6 +164,14 @@ __device__ __forceinline__ float fb_rcp(float x) { return __builtin_amdgcn_rcpf(
 __device__ __forceinline__ bf16x8 fb_cat(const bf16x4& a, const bf16x4& b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// the forward's activation operand under the q-swapped image layout (pv_fb_layout.h): lanes of groups q >= 2 hold their weight
+// chunk's halves in the other order (sw: per lane, loop-invariant)
+__device__ __forceinline__ bf16x8 fb_catq(bf16x4 a, bf16x4 b, bool sw) {
+  typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x2_ ua = __builtin_bit_cast(u32x2_, a), ub = __builtin_bit_cast(u32x2_, b);
+  const u32x2_ lo = {sw ? ub[0] : ua[0], sw ? ub[1] : ua[1]}, hi = {sw ? ua[0] : ub[0], sw ? ua[1] : ub[1]};
+  return fb_cat(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi));
+}
 
 // a zero the compiler cannot see through: lane-address arithmetic that depends on it is redone where it is used
 // instead of being hoisted out of the tile loop and held in (or spilled from) registers for the whole kernel
@@ -206,8 +214,9 @@ __device__ __forceinline__ void fb_reload(const char* __restrict__ gimg, unsigne
 template <int P>
 __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
                                              const float* __restrict__ bs, const bf16x4 (&ih)[8],
-                                             const bf16x4 (&il)[8], f32x4 (&out)[8], int r, int q) {
+                                             const bf16x4 (&il)[8], f32x4 (&out)[8], int r, int q, int qs) {
   constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::FWD_WLO, AL = FbP<P>::FWD_LO;
+  const bool sw = qs && q >= 2;                          // q-swapped images: this lane's chunk holds [h = 1 | h = 0]
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(bs + 16 * ob + 4 * q);
   // row 16*ob + r, logical chunk 4m + q  ->  physical chunk 4*(m ^ (r&3)) + (q ^ SL[r>>2])
@@ -234,13 +243,13 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
     const int m = g / FB_GPM, op = (g % FB_GPM) * FB_GB;
     if (g + 1 < 4 * FB_GPM) load(g + 1, wh[(g + 1) & 1], wl[(g + 1) & 1]);
     FB_FENCE();
-    const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]);
+    const bf16x8 bh = fb_catq(ih[2 * m], ih[2 * m + 1], sw);
     const bf16x8(&h)[FB_GB] = wh[g & 1];
     const bf16x8(&l)[FB_GB] = wl[g & 1];
 #pragma unroll
     for (int o = 0; o < FB_GB; ++o) out[op + o] = fb_mma<F16>(h[o], bh, out[op + o]);
     if (AL) {
-      const bf16x8 bl = fb_cat(il[2 * m], il[2 * m + 1]);
+      const bf16x8 bl = fb_catq(il[2 * m], il[2 * m + 1], sw);
 #pragma unroll
       for (int o = 0; o < FB_GB; ++o) out[op + o] = fb_mma<F16>(h[o], bl, out[op + o]);
     }
@@ -256,7 +265,7 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
 template <int P, bool AL>
 __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
                                                const bf16x4 (&ih)[8], const bf16x4 (&il)[8], f32x4 (&out)[8], int r,
-                                               int q) {
+                                               int q, int qs) {
   constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::WP == 2;
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) out[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -264,9 +273,11 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
   // lane k' holds W[j0 .. j0+3][16*kb + k']
   // (rows j0 + r/4 with j0 = 32m + 4q (+16): swizzle 4*(r>>2) + SL[q]; logical chunk 4*kk + (r&3), kk = kb/2)
   r |= fb_opaque0();
+  // (q-swapped images: piece r&3 of column block 2 kk + h sits in half h ^ ((r&3) >> 1))
   const int toff = (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q));
-  const __bf16* ah = Wh + toff;
-  const __bf16* al = Wl + toff;
+  const int hs = qs ? 4 * ((r >> 1) & 1) : 0;
+  const __bf16* ahx[2] = {Wh + toff + hs, Wh + toff + 4 - hs};
+  const __bf16* alx[2] = {Wl + toff + hs, Wl + toff + 4 - hs};
   int xk[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) xk[kk] = 32 * (kk ^ (r >> 2));
@@ -275,7 +286,9 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
     const int m = g / FB_GPM, kp = (g % FB_GPM) * FB_GB;
 #pragma unroll
     for (int o = 0; o < FB_GB; ++o) {
-      const int off = 32 * m * LDB + xk[(kp + o) >> 1] + 4 * ((kp + o) & 1);
+      const int off = 32 * m * LDB + xk[(kp + o) >> 1];
+      const __bf16* ah = ahx[(kp + o) & 1];
+      const __bf16* al = alx[(kp + o) & 1];
       h[o] = fb_cat(fb_tr(ah + off), fb_tr(ah + off + 16 * LDB));
       if (WL) l[o] = fb_cat(fb_tr(al + off), fb_tr(al + off + 16 * LDB));
     }
@@ -608,8 +621,9 @@ __device__ __forceinline__ void fb_xchg_get(const char* smb, int off, bf16x4 (&a
 template <int P>
 __device__ __forceinline__ void fb_tail_fwd(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
                                             const float* __restrict__ bs, const bf16x4 (&ih)[8], f32x4 (&out)[2], int wave,
-                                            int r, int q) {
+                                            int r, int q, int qs) {
   constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::FWD_WLO;
+  const bool sw = qs && q >= 2;
 #pragma unroll
   for (int o = 0; o < 2; ++o) out[o] = *reinterpret_cast<const f32x4*>(bs + 16 * (2 * wave + o) + 4 * q);
   const int lbase = r * LDB + 8 * (q ^ fb_sl(r >> 2)) + 32 * wave * LDB;
@@ -624,7 +638,7 @@ __device__ __forceinline__ void fb_tail_fwd(const __bf16* __restrict__ Wh, const
     }
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]);
+    const bf16x8 bh = fb_catq(ih[2 * m], ih[2 * m + 1], sw);
 #pragma unroll
     for (int o = 0; o < 2; ++o) out[o] = fb_mma<F16>(wh[m][o], bh, out[o]);
     if (WL) {
@@ -636,8 +650,9 @@ __device__ __forceinline__ void fb_tail_fwd(const __bf16* __restrict__ Wh, const
 // blocks 2 wave, 2 wave + 1 of a dgrad layer (fb_layer_dgrad's arithmetic: h x dp_hi, h x dp_lo, l x dp_hi)
 template <int P, bool AL>
 __device__ __forceinline__ void fb_tail_dgrad(const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl, const bf16x4 (&ih)[8],
-                                              const bf16x4 (&il)[8], f32x4 (&out)[2], int wave, int r, int q) {
+                                              const bf16x4 (&il)[8], f32x4 (&out)[2], int wave, int r, int q, int qs) {
   constexpr bool F16 = FbP<P>::F16, WL = FbP<P>::WP == 2;
+  const int hs = qs ? 4 * ((r >> 1) & 1) : 0;
 #pragma unroll
   for (int o = 0; o < 2; ++o) out[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   // (kb = 2 wave + o: kb >> 1 = wave, kb & 1 = o)
@@ -647,7 +662,7 @@ __device__ __forceinline__ void fb_tail_dgrad(const __bf16* __restrict__ Wh, con
     bf16x8 h[2], l[2];
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-      const int off = toff + 32 * m * LDB + 4 * o;
+      const int off = toff + 32 * m * LDB + (o ? 4 - hs : hs);
       h[o] = fb_cat(fb_tr(Wh + off), fb_tr(Wh + off + 16 * LDB));
       if (WL) l[o] = fb_cat(fb_tr(Wl + off), fb_tr(Wl + off + 16 * LDB));
     }
@@ -878,6 +893,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
   // (H231 build) a range of 4 n + 1 units ends with a column-parallel tail (below): the row-parallel tiles cover [u_lo, u_end), and
   // what a wave without a further unit prefetches is the TAIL unit's inputs (every wave takes part in the tail)
   constexpr bool TAIL = FB_TAIL && GRADS && PREC == FB_P_H231;
+#ifdef PV_EXPERIMENTS
+  const int qsw = f.qswap;                  // the images' column order (pv_fb_layout.h): plain in the shipped build
+#else
+  constexpr int qsw = 0;
+#endif
   const bool has_tail = TAIL && ((u_hi - u_lo) & (TILE_UNITS - 1)) == 1 && !(f.ablate & 512);   // (ablate: experiments build only)
   const int64_t u_end = has_tail ? u_hi - 1 : u_hi;
   const Pos pos_lo = pos_of(has_tail ? u_end : u_lo);   // what an out-of-range wave fetches instead (valid; unused without a tail)
@@ -994,7 +1014,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_reload<LL::RL_BYTES>(gimg + LL::RL2_SRC, lds0 + LL::RL2_LDS, wave, lane);
     }
     {
-      fb_layer_fwd<PREC>(W1h, W1l, b1s, pBh, pBl, tB, r, q);
+      fb_layer_fwd<PREC>(W1h, W1l, b1s, pBh, pBl, tB, r, q, qsw);
       fb_tanh8(tB, c1);                                          // tB = h1
       fb_presplit<F16, PP::HL>(tB, pBh, pBl);                    // feeds layer 2 and its wgrad
     }
@@ -1008,7 +1028,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     float frow = 0.0f;                                  // fp16 modes: what turns the row's normalised dL/dpre0 into the true one
     half4_ ph4 = half4_{};                              //             the row's 2^(e + dl_exp) as fp16 (staged activations)
     {
-      fb_layer_fwd<PREC>(W2h, W2l, b2s, pBh, pBl, tC, r, q);
+      fb_layer_fwd<PREC>(W2h, W2l, b2s, pBh, pBl, tC, r, q, qsw);
       FB_STAMP(16);
       fb_tanh8(tC, c2);                                          // tC = h2
       FB_STAMP(17);
@@ -1106,7 +1126,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_reload<LL::RL_BYTES>(gimg + LL::RL1_SRC, lds0 + LL::RL1_LDS, wave, lane);   // W1 comes back under the dgrad of layer 2
     }
     {
-      fb_layer_dgrad<PREC, PP::DGR2_LO>(W2h, W2l, pAh, pAl, tA, r, q);
+      fb_layer_dgrad<PREC, PP::DGR2_LO>(W2h, W2l, pAh, pAl, tA, r, q, qsw);
       fb_mul_dtanh(tA, tB);                                      // tA = dpre1 (fp16 modes: times s2 kso / m 2^e ... carried)
       fb_presplit<F16, PP::DL1>(tA, pAh, pAl);                   // feeds the dgrad and the wgrad of layer 1
     }
@@ -1117,7 +1137,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     }
     FB_STAMP(8);
     {
-      fb_layer_dgrad<PREC, PP::DGR1_LO>(W1h, W1l, pAh, pAl, tC, r, q);
+      fb_layer_dgrad<PREC, PP::DGR1_LO>(W1h, W1l, pAh, pAl, tC, r, q, qsw);
       fb_mul_dtanh(tC, h0);                                      // tC = dpre0 (fp16 modes: normalised; frow restores the row)
       // ---- coordinate layer, cross-row part: dhz[b] = sum_rows dpre0, dWc_k = sum_rows dpre0 * x'_k.  Wave-local
       // (the unit's rows all belong to this wave and to one sample): W2's images are dead since the barrier above, so
@@ -1226,7 +1246,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       __syncthreads();                                                   // exchange 0: h0
       FB_TSTAMP(2);
       fb_xchg_get(smb, TL::E, pH0, lane);
-      fb_tail_fwd<PREC>(W1h, W1l, b1s, pH0, h1o, wave, r, q);
+      fb_tail_fwd<PREC>(W1h, W1l, b1s, pH0, h1o, wave, r, q, qsw);
       fb_tanh2(h1o, c1);
       fb_presplit2<false>(h1o, oh, ol);
       fb_xchg_put(smb, TL::E + 4096, oh, wave, lane);
@@ -1236,7 +1256,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       __syncthreads();                                                   // exchange 1: h1; W2 landed
       FB_TSTAMP(5);
       fb_xchg_get(smb, TL::E + 4096, pH1, lane);
-      fb_tail_fwd<PREC>(W2h, W2l, b2s, pH1, h2o, wave, r, q);
+      fb_tail_fwd<PREC>(W2h, W2l, b2s, pH1, h2o, wave, r, q, qsw);
       fb_tanh2(h2o, c2);
       float* rp = reinterpret_cast<float*>(smb + TL::RP);
       {
@@ -1329,7 +1349,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_wgrad_consume16<PREC>(tsd, tsa, accW2, accB2, wave, r, q);
       FB_TSTAMP(12);
       // ---- dgrad of layer 2, own blocks ----
-      fb_tail_dgrad<PREC, PP::DGR2_LO>(W2h, W2l, pAh, pAl, t2, wave, r, q);
+      fb_tail_dgrad<PREC, PP::DGR2_LO>(W2h, W2l, pAh, pAl, t2, wave, r, q, qsw);
 #pragma unroll
       for (int o = 0; o < 2; ++o) t2[o] = t2[o] * (1.0f - h1o[o] * h1o[o]);          // dpre1 (carried scales as in the tile loop)
       fb_presplit2<true>(t2, oh, ol);
@@ -1341,7 +1361,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
       fb_xchg_get(smb, TL::E, pAh, lane);
       fb_xchg_get(smb, TL::E + 4096, pAl, lane);
       // ---- dgrad of layer 1, own blocks ----
-      fb_tail_dgrad<PREC, PP::DGR1_LO>(W1h, W1l, pAh, pAl, t2, wave, r, q);
+      fb_tail_dgrad<PREC, PP::DGR1_LO>(W1h, W1l, pAh, pAl, t2, wave, r, q, qsw);
 #pragma unroll
       for (int o = 0; o < 2; ++o) t2[o] = t2[o] * (1.0f - h0o[o] * h0o[o]);          // dpre0, normalised (frow restores the row)
       FB_TSTAMP(15);
@@ -1657,6 +1677,14 @@ extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, in
   return buf;
 }
 
+// which column order a launch's weight images are in (pv_fb_layout.h): the 8-wave plain-bf16 kernel reads the q-swapped one
+// (-0.6 % of its step); this file's 4-wave kernel the plain one — its transposing reads lose 80 % of their bank conflicts too
+// (SQ_LDS_BANK_CONFLICT 8.0 M -> 1.6 M per launch, LDS-array cycles -19 %) and the launch does not move (144.3 vs 144.8 us:
+// profiles/r06i_qswap_ab.txt), so it keeps the form without the operand selects.  PV_QSWAP=1 (experiments build) turns it on.
+static int fb_qswap_on() {
+  static const int v = pv_exp_int("PV_QSWAP", 0);
+  return v != 0;
+}
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   static_assert(FB_WIMG_BYTES >= FB_SCALE_OFF + 16, "pv_sdec_fused.h and the LDS image layout disagree");
   PvFbPrep p{};
@@ -1665,6 +1693,7 @@ PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3) {
   const int kind = x3 ? fb_x3_kind(f.units, grads, f.sel) : -1;
   p.mode = fb_kind_w8h(kind) ? 2 : (kind > 8 ? 1 : 0);
   p.scale = (x3 ? !fb_kind_here(kind) : fb_use_w8(f.units, f.sel)) ? 2.8853900817779268f : 0.0f;     // (also what hz arrives multiplied by)
+  p.qswap = p.scale == 0.0f ? fb_qswap_on() : (!x3 && pv_sdec_fused_w8_qswap());
   return p;
 }
 
@@ -1701,6 +1730,7 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3
   PvFused f = f_in;
   static const int ablate = pv_exp_int("PV_FD_ABLATE", 0);
   f.ablate = ablate;
+  f.qswap = fb_qswap_on();
   const size_t lds = FB_LDS_BYTES;
   const void* fn = nullptr;
 #define FB_PICK_P(G, L, P) fn = reinterpret_cast<const void*>(&pv_sdec_fused_bf16_kernel<G, L, P>)

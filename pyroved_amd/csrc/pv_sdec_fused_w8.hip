@@ -81,8 +81,27 @@ __device__ __forceinline__ float w8_tanhc(float cx) {
 __device__ __forceinline__ float w8_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float w8_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float w8_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#ifndef W8_HSWAP
+#define W8_HSWAP 0            // (A/B build only)
+#endif
+#ifndef W8_QSWAP
+#define W8_QSWAP 1            // the weight images' column order (below, at w8_addr)
+#endif
+bool pv_sdec_fused_w8_qswap() { return W8_QSWAP != 0; }
 __device__ __forceinline__ bf16x8 w8_cat(const bf16x4& a, const bf16x4& b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 w8_catq(const bf16x4& a, const bf16x4& b, int q) {
+#if W8_QSWAP
+  typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+  const bool sw = q >= 2;
+  const u32x2_ ua = __builtin_bit_cast(u32x2_, a), ub = __builtin_bit_cast(u32x2_, b);
+  const u32x2_ lo = {sw ? ub[0] : ua[0], sw ? ub[1] : ua[1]}, hi = {sw ? ua[0] : ub[0], sw ? ua[1] : ub[1]};
+  return w8_cat(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi));
+#else
+  (void)q;
+  return w8_cat(a, b);
+#endif
 }
 __device__ __forceinline__ int w8_opaque0() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 __device__ __forceinline__ bf16x4 w8_tr(const __bf16* p) {
@@ -128,14 +147,16 @@ __device__ __forceinline__ float w8_sum_q(float v) {
 // them wanting the same half: 2-way on every read in the shipped layout — then cover both halves of 16 chunks: conflict-free.
 // The price is the forward's operand read: its 8 k-values are no longer one ds_read_b128 but two ds_read_b64 at lane-dependent
 // halves (fs / hs below: which half comes first for this lane's rows).  Valid only where the kernel builds its own images (FOLD).
-#ifndef W8_HSWAP
-#define W8_HSWAP 0
-#endif
+// W8_QSWAP (the shipped form since round 6's second cut; profiles/r06i_qswap_ab.txt): the q-swapped column order of
+// pv_fb_layout.h — the half a column block sits in is h ^ (q >> 1).  The transposing reads are conflict-free as under W8_HSWAP, and
+// the forward keeps its ONE ds_read_b128: lanes of groups q >= 2 feed the activation pieces in the swapped order instead (w8_catq:
+// 4 v_cndmask per k-block).  Images written by the kernel itself (FOLD) and by pv_fb_prep (PvFbPrep::qswap) alike.
+
 struct W8Addr { int fb, fx[4], db, dx[4], fs, hs; };
 __device__ __forceinline__ W8Addr w8_addr(int r, int q) {
   W8Addr a;
   a.fs = W8_HSWAP ? ((r >> 2) & 1) : 0;               // forward: rows 16 ob + r
-  a.hs = W8_HSWAP ? (q & 1) : 0;                      // dgrad: rows 32 m + 4 q (+ 16) + r / 4
+  a.hs = W8_HSWAP ? (q & 1) : (W8_QSWAP ? ((r >> 1) & 1) : 0);   // dgrad: rows 32 m + 4 q (+ 16) + r / 4, piece r & 3
   a.fb = r * LDB + 8 * (q ^ fb_sl(r >> 2));
   a.db = (4 * q + (r >> 2)) * LDB + 8 * ((r & 3) ^ fb_sl(q));
 #pragma unroll
@@ -178,7 +199,7 @@ __device__ __forceinline__ void w8_layer_fwd(const __bf16* __restrict__ Wh, cons
     const int m = g >> 2, op = (g & 3) * 2;
     if (g + 1 < 16 && W8_ABL_LOADS(1, g + 1)) load(g + 1, wh[W8_ABL_BUF(1, g + 1)]);
     W8_FENCE();
-    const bf16x8 bh = w8_cat(ih[2 * m], ih[2 * m + 1]);
+    const bf16x8 bh = w8_catq(ih[2 * m], ih[2 * m + 1], q);
 #pragma unroll
     for (int o = 0; o < 2; ++o) out[op + o] = MFMA32(wh[W8_ABL_BUF(1, g)][o], bh, out[op + o]);
     W8_FENCE();
@@ -406,7 +427,7 @@ __device__ __forceinline__ f32x4 w8_tail_fwd(const __bf16* __restrict__ Wh, cons
 #endif
   }
 #pragma unroll
-  for (int m = 0; m < 4; ++m) out = MFMA32(wh[m], w8_cat(ih[2 * m], ih[2 * m + 1]), out);
+  for (int m = 0; m < 4; ++m) out = MFMA32(wh[m], w8_catq(ih[2 * m], ih[2 * m + 1], q), out);
   return out;
 }
 // block `wave` of a dgrad layer: out[k = 16 wave + 4q .. +3] = sum_j (C W)[j][k] dp[j]
@@ -703,7 +724,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
         h1[i] = __builtin_bit_cast(unsigned short, (__bf16)(w1v[u][i] * W8_C));
         h2[i] = __builtin_bit_cast(unsigned short, (__bf16)(w2v[u][i] * W8_C));
       }
-      const int el = fb_wel(row, fb_pcol(4 * c4)) ^ (W8_HSWAP ? 4 * ((row >> 2) & 1) : 0);
+      const int el = fb_wel(row, fb_pcol(4 * c4)) ^ (W8_HSWAP ? 4 * ((row >> 2) & 1) : 0) ^ (W8_QSWAP ? 4 * ((c4 >> 1) & 1) : 0);
       *reinterpret_cast<us4*>(i1 + el) = h1;
       *reinterpret_cast<us4*>(i2 + el) = h2;
     }

@@ -4,7 +4,7 @@
 # kernel time and SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the headline launch.
 export TMPDIR=/tmp
 R=$PWD
-V=$R/pyroved_amd/variants/lib_hswap.so
+V=$R/pyroved_amd/variants/lib_${1:-hswap}.so
 echo "== correctness of the variant (folded guide + decoder vs the oracle)"
 PV_LIB_PATH=$V python -m pytest tests/test_gpu_parity.py -q -k "guide_folded and rt_b256" 2>&1 | tail -1
 PV_LIB_PATH=$V python -m pytest tests/test_gpu_parity.py -q -k "bf16_mode_steps and rt_b256" 2>&1 | tail -1
