@@ -8,6 +8,7 @@
 // Reductions are tree/ordered (no float atomics): results are bit-reproducible run to run.
 #include "pv_common.h"
 #include "pv_kernels.h"
+#include "pv_wgrad_small.h"
 #include "pv_side.h"
 #include "pv_sdec_fused.h"
 
@@ -533,45 +534,6 @@ int pv_reduce_mid(const float* part, int nb, int nc, int n, float* out, hipStrea
 }
 
 // ---------------------------------------------------------------------------------------------
-// head_bwd: dL/d(mu), dL/d(softplus input) from the decoder's dL/dz and the sampled-KL terms.
-// dz_coord(c) returns d(phi), d(scale), d(tx), d(ty) of the sample for c = 0..3; dz_content(k) the gradient
-// w.r.t. the k-th column of the decoder's latent input.
-template <class FC, class FK>
-__device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int i, FC dz_coord, FK dz_content,
-                                                 float* dh_copy = nullptr) {
-  float dz;
-  if (h.coord_dim == 0) {
-    dz = dz_content(i);
-  } else {
-    int idx = 0;
-    dz = 0.0f;
-    bool done = false;
-    if (h.coord_dim == 1) {
-      if (h.has_t) { if (i == 0) { dz = dz_coord(2) * h.tp0; done = true; } idx = 1; }
-    } else {
-      if (h.has_r) { if (i == idx) { dz = dz_coord(0); done = true; } idx += 1; }
-      if (h.has_t) {
-        if (i == idx) { dz = dz_coord(2) * h.tp0; done = true; }
-        if (i == idx + 1) { dz = dz_coord(3) * h.tp1; done = true; }
-        idx += 2;
-      }
-      if (h.has_s) { if (i == idx) { dz = dz_coord(1) * h.sc_prior; done = true; } idx += 1; }
-    }
-    if (!done) dz = dz_content(i - idx);
-  }
-  const int e = b * h.z_dim + i;
-  const float z = h.z[e], sig = h.z_scale[e], ep = h.eps[e];
-  const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
-  const float sp = h.head[(int64_t)b * ldh + h.z_dim + i];
-  const float bw = h.w ? h.beta * h.w[b] : h.beta;
-  const float g = dz + bw * z;                     // d(-ll - beta*log p(z))/dz
-  const float dsig = g * ep - bw / sig;            // + beta * d(log q)/d(sigma) (total derivative)
-  const float sgm = h.scale_direct ? 1.0f : (sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp)));   // softplus'
-  h.dhead[(int64_t)b * ldh + i] = g;
-  h.dhead[(int64_t)b * ldh + h.z_dim + i] = dsig * sgm;
-  if (dh_copy) { dh_copy[i] = g; dh_copy[h.z_dim + i] = dsig * sgm; }
-}
-
 __global__ void pv_head_bwd_kernel(PvHeadBwd h) {
   const int total = h.B * h.z_dim;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1126,6 +1088,42 @@ int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, floa
   if (p.H > 512 || p.lat_in > 64 + (p.K > 0 ? p.K : 0) || p.hb.z_dim > 256 || p.K > 128) return PV_EINVAL;
   // (a conv encoder's head weight gradient forks off this launch onto the side stream: it carries the fork event when one is armed)
   PV_LAUNCH_FORK(pv_latent_bwd_reduce_kernel, dim3(pv_fused_reduce_blocks(fmt) + p.hb.B), dim3(256), 0, s, p, part, grid, G, o, cd, fmt);
+  PV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- the step's closing launch when nothing per-sample is left to do (round 6, third cut) ------------------------------------------
+// Where the decoder launch hosts the guide AND every sample's latent backward + encoder chain (one image per workgroup:
+// pv_sdec_fused_w8.hip, PvEncFold::chain), what remains of the step is three kinds of workgroups that need nothing from each other:
+//   blocks [0, nred)          : the record sums — with Adam applied to the decoder parameters they finalise;
+//   blocks [nred, + tiles)    : the small weight gradients (encoder layers, head, fc_latent), Adam in their epilogues (pv_wgrad_small.h);
+//   last block                : the loss scalars.
+// One launch (9-10 us) where the step ran [record sums | latent backward + chain] (9.9 us) and then the weight gradients (6.8 us).
+// (A first form kept the chain in this launch, the tiles waiting for an arrival counter behind agent-scope stores: 23.2 us against
+//  the two launches' 17.1 — at two workgroups per CU the waiting tiles get no slot before the producers are done, and 990
+//  workgroups take ~4 us just to dispatch: profiles/r06j_tail_launch.txt.)
+__global__ __launch_bounds__(256) void pv_rec_wgrad_kernel(const float* __restrict__ part, int G_, float* __restrict__ Gr, PvFusedOffsets o,
+                                                           int cd, int fmt, PvWgradSmall w, PvRecAdam ra) {
+  __shared__ f32x4 smr[4][64];
+  __shared__ float wpart[WG_WAVES][16][17];
+  __shared__ float wrpart[WG_WAVES][16];
+  const int nred = pv_fused_reduce_blocks(fmt), id = (int)blockIdx.x;
+  if (id < nred) { pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, id, smr, fmt, ra); return; }
+  pv_wgrad_small_block(w, id - nred, (int)gridDim.x - nred, wpart, wrpart);
+}
+
+// adam: every parameter must be finalised by a record block or a tile (no Adam guests here: the caller checked the coverage)
+int pv_rec_wgrad(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int fmt, const PvGemm* gs, int n,
+                 const PvAdamFuse* adam, const PvFinishArgs* fin, hipStream_t s) {
+  PvWgradSmall w;
+  int guests = 0;
+  const int tiles = pv_wgrad_small_fill(w, gs, n, adam, fin, &guests);
+  if (tiles < 0) return tiles;
+  const int fin_blocks = (fin && fin->scalars) ? 1 : 0;
+  PvRecAdam ra{};
+  if (adam) { ra.a = *adam; ra.on = 1; }
+  hipLaunchKernelGGL(pv_rec_wgrad_kernel, dim3(pv_fused_reduce_blocks(fmt) + tiles + fin_blocks), dim3(256), 0, s, part, grid, G, o, cd,
+                     fmt, w, ra);
   PV_LAUNCH_CHECK();
   return 0;
 }

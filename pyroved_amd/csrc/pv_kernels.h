@@ -104,6 +104,53 @@ struct PvHeadBwd {
 };
 int pv_head_bwd(const PvHeadBwd& h, hipStream_t s);
 
+// head_bwd: dL/d(mu), dL/d(softplus input) from the decoder's dL/dz and the sampled-KL terms.
+// dz_coord(c) returns d(phi), d(scale), d(tx), d(ty) of the sample for c = 0..3; dz_content(k) the gradient
+// w.r.t. the k-th column of the decoder's latent input.
+// (the two halves of the element function below, for callers that hold the sample's values in registers: pv_sdec_fused_w8.hip)
+template <class FC, class FK>
+__device__ __forceinline__ float pv_head_dz(const PvHeadBwd& h, int i, FC dz_coord, FK dz_content) {
+  if (h.coord_dim == 0) return dz_content(i);
+  int idx = 0;
+  float dz = 0.0f;
+  bool done = false;
+  if (h.coord_dim == 1) {
+    if (h.has_t) { if (i == 0) { dz = dz_coord(2) * h.tp0; done = true; } idx = 1; }
+  } else {
+    if (h.has_r) { if (i == idx) { dz = dz_coord(0); done = true; } idx += 1; }
+    if (h.has_t) {
+      if (i == idx) { dz = dz_coord(2) * h.tp0; done = true; }
+      if (i == idx + 1) { dz = dz_coord(3) * h.tp1; done = true; }
+      idx += 2;
+    }
+    if (h.has_s) { if (i == idx) { dz = dz_coord(1) * h.sc_prior; done = true; } idx += 1; }
+  }
+  if (!done) dz = dz_content(i - idx);
+  return dz;
+}
+// z, sig, ep, sp: the sample's z, z_scale, eps and softplus input of coordinate i; bw = beta (times the sample's weight)
+__device__ __forceinline__ void pv_head_bwd_math(float dz, float z, float sig, float ep, float sp, float bw, int scale_direct,
+                                                 float& g, float& ds) {
+  g = dz + bw * z;                                 // d(-ll - beta*log p(z))/dz
+  const float dsig = g * ep - bw / sig;            // + beta * d(log q)/d(sigma) (total derivative)
+  const float sgm = scale_direct ? 1.0f : (sp > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-sp)));   // softplus'
+  ds = dsig * sgm;
+}
+template <class FC, class FK>
+__device__ __forceinline__ void pv_head_bwd_elem(const PvHeadBwd& h, int b, int i, FC dz_coord, FK dz_content,
+                                                 float* dh_copy = nullptr) {
+  const float dz = pv_head_dz(h, i, dz_coord, dz_content);
+  const int e = b * h.z_dim + i;
+  const int ldh = h.ldh > 0 ? h.ldh : 2 * h.z_dim;
+  float g, ds;
+  pv_head_bwd_math(dz, h.z[e], h.z_scale[e], h.eps[e], h.head[(int64_t)b * ldh + h.z_dim + i], h.w ? h.beta * h.w[b] : h.beta,
+                   h.scale_direct, g, ds);
+  h.dhead[(int64_t)b * ldh + i] = g;
+  h.dhead[(int64_t)b * ldh + h.z_dim + i] = ds;
+  if (dh_copy) { dh_copy[i] = g; dh_copy[h.z_dim + i] = ds; }
+}
+
+
 struct PvLatentBwd {
   const float* llrow;    // (M)
   const float* rowtp;    // (4, M)
@@ -161,6 +208,11 @@ int pv_add_cols(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t 
 struct PvFusedOffsets;
 int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, float* G, const PvFusedOffsets& o, int cd,
                          hipStream_t s, int rec_fmt = 0);
+// the step's closing launch where the decoder launch already ran every sample's latent backward and encoder chain (PvEncFold::chain):
+// record sums (with Adam on the decoder parameters they finalise), the small weight gradients (Adam in their epilogues) and the
+// loss scalars — three kinds of workgroups that need nothing from each other (pv_elementwise.hip: pv_rec_wgrad_kernel)
+int pv_rec_wgrad(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int rec_fmt, const PvGemm* gs, int n,
+                 const PvAdamFuse* adam, const PvFinishArgs* fin, hipStream_t s);
 
 // pv_lik_elem + pv_segsum in one launch (one workgroup per sample; same summation order)
 int pv_lik_rows(const float* a, const float* x, int64_t B, int64_t per, int lik, int sigmoid_out, float sig, float* loc,

@@ -5,6 +5,7 @@
 //     -> pyro.optim.Adam -> zero_grads.
 // No allocation, no synchronisation, no retained state: everything lives in the caller's plan.
 #include "pv_common.h"
+#include <algorithm>
 #include <stdlib.h>
 #include "pv_kernels.h"
 #include "pv_sdec_fused.h"
@@ -623,6 +624,33 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
   return 0;
 }
 
+// the compact (fc) encoder's weight-gradient problems behind `extra` — what encoder_bwd hands its one-tile-per-workgroup launch;
+// -1 when one of them wants the split-K GEMM or they are more than that launch takes
+int compact_wgrad_problems(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int n_extra, PvGemm (&probs)[4]) {
+  const int64_t B = p->batch;
+  const int ne = p->n_enc;
+  if (B > 4096 || n_extra + 1 + ne > 4) return -1;
+  float* G = p->grads;
+  const pv_layer& hd = p->head;
+  int np = 0;
+  for (int i = 0; i < n_extra; ++i) {
+    const PvGemm& e = extra[i];
+    const int64_t tiles = (int64_t)((e.M + 15) / 16) * ((e.N + 15) / 16);
+    if (e.K > 1024 && tiles < 128 && pv_gemm_pick_splits(e.M, e.N, e.K) > 1) return -1;
+    probs[np++] = e;
+  }
+  probs[np++] = wgrad_problem(L.dhead, hd.out_dim, L.eact[ne - 1], hd.in_dim, G + hd.w_off, hd.b_off >= 0 ? G + hd.b_off : nullptr, B,
+                              hd.in_dim, hd.out_dim);
+  const float* xin = p->c_dim > 0 ? L.xin : p->x;
+  const int64_t ldx = p->n_pix + p->c_dim;
+  for (int i = ne - 1; i >= 0; --i) {
+    const pv_layer& l = p->enc[i];
+    probs[np++] = wgrad_problem(L.edp[i], l.out_dim, i > 0 ? L.eact[i - 1] : xin, i > 0 ? p->enc[i - 1].out_dim : ldx, G + l.w_off,
+                                l.b_off >= 0 ? G + l.b_off : nullptr, B, l.in_dim, l.out_dim);
+  }
+  return np;
+}
+
 // plan->row_w / row_elbo on the paths that form ll_b with pv_segsum: keep the unweighted ll_b, weight what the loss sums
 int weigh_llb(const pv_ivae_plan* p, const Layout& L, hipStream_t s) {
   if (p->row_elbo) {
@@ -903,6 +931,36 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     lb.enc_n = p->n_enc; lb.enc_params = p->params; lb.enc_head = p->head;
     for (int i = 0; i < p->n_enc; ++i) { lb.enc_l[i] = p->enc[i]; lb.enc_act[i] = L.eact[i]; lb.enc_dp[i] = L.edp[i]; }
   }
+  // (round 6, third cut) where the decoder launch hosts the guide — one image per workgroup — it also runs every image's latent
+  // backward and encoder chain in its epilogue (PvEncFold::chain), and the step closes with ONE launch of workgroups that need
+  // nothing from each other: record sums, small weight gradients, loss scalars (pv_elementwise.hip: pv_rec_wgrad_kernel).
+  // Needs what that epilogue is written for (the plain iVAE step: no per-sample weights / extra outputs, a head of <= 16 outputs)
+  // and — with the optimizer riding — records + tiles covering every parameter.
+  static const int ab_tail = pv_exp_int("PV_FOLD_CHAIN", 1);
+  const int rec_fmt = p->fused >= 2 ? pv_sdec_fused_bf16_record_fmt(p->fused == 2, R / FD_UNIT, p->dec_kernel) : PV_REC_ROWMAJOR;
+  const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
+  PvGemm tail_probs[4];
+  int tail_np = -1;
+  if (ab_tail && fold && want_grads && chain && f.part_rs && f.dhz_out && f.dzc_out && K == 0 && H == FD_H && !p->row_w &&
+      !p->row_elbo && !p->dy && p->head.out_dim <= 16 && p->n_enc == 2) {
+    tail_np = compact_wgrad_problems(p, L, &wz, 1, tail_probs);
+    if (tail_np > 0 && adam) {
+      // every PARAMETER must be finalised by a record block or a tile (the launch has no Adam guests): the plan's layers, counted,
+      // against what the records and the tiles cover.  What else the flat buffer holds — alignment padding, batch-norm statistics —
+      // never has a gradient or a moment, and Adam leaves such an element where it is.
+      auto lsz = [](const pv_layer& l) { return (int64_t)l.in_dim * l.out_dim + (l.b_off >= 0 ? l.out_dim : 0); };
+      int64_t want = lsz(p->head) + lsz(p->fc_coord) + lsz(p->fc_latent) + lsz(p->out);
+      for (int i = 0; i < p->n_enc; ++i) want += lsz(p->enc[i]);
+      for (int i = 0; i < p->n_dec; ++i) want += lsz(p->dec[i]);
+      int64_t cov = 2 * (int64_t)H * H + (int64_t)H * (3 + p->coord_dim) + 1;
+      for (int i = 0; i < tail_np; ++i) cov += (int64_t)tail_probs[i].M * tail_probs[i].N + (tail_probs[i].rowsumA ? tail_probs[i].M : 0);
+      if (cov != want || !adam_done || p->n_dec != 2) tail_np = -1;
+    }
+  }
+  const bool own_chain = tail_np > 0;
+  if (own_chain) {
+    ef.chain = 1; ef.dhead = L.dhead; ef.ldh = (int)plan_head_w(p); ef.edp0 = L.edp[0]; ef.edp1 = L.edp[1]; ef.llb = L.llb;
+  }
   if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
   if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s, fold ? &ef : nullptr));
   else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
@@ -926,8 +984,13 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   const bool head_side = ab_side && L.enc_conv && !L.enc_ext && pv_side_stream_for(s, p->flags) && !pv_convhead_wgrad_uses_ws() &&
                          pv_convhead_supported(L.cF, p->head.out_dim) && L.chead_wt;
   if (head_side) pv_fork_arm();
-  // (the record format the decoder launch above wrote: pv_sdec_fused.h PV_REC_*)
-  const int rec_fmt = p->fused >= 2 ? pv_sdec_fused_bf16_record_fmt(p->fused == 2, R / FD_UNIT, p->dec_kernel) : PV_REC_ROWMAJOR;
+  if (own_chain) {
+    const PvFinish fin{L.llb, (int)B, p->scalars, L.kl_part, kl_n, 1.0f /* scaled */};
+    PV_TRY(pv_rec_wgrad(L.f_part, L.f_grid, G, o, p->coord_dim, rec_fmt, tail_probs, tail_np, adam, &fin, s));
+    if (adam) *adam_done = true;
+    return extra_outputs(p, L, L.dzc, lat_in, s);
+  }
+  // (rec_fmt: the record format the decoder launch above wrote: pv_sdec_fused.h PV_REC_*)
   PV_TRY(pv_latent_bwd_reduce(lb, L.f_part, L.f_grid, G, o, p->coord_dim, s, rec_fmt));
   // the loss scalars ride in the encoder dgrad launch (compact encoder), in the last weight-gradient launch (conv encoder) or get their own
   PvFinish fin{L.llb, (int)B, p->scalars, (L.enc_compact || hzr.kl) ? L.kl_part : nullptr, kl_n, 1.0f /* scaled */};
@@ -935,7 +998,6 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   if (!fin_rides) PV_TRY(pv_finish_scalars(fin.llb, fin.B, fin.scalars, fin.kl_part, fin.n_part, fin.beta, s));
   // fc_latent: dWz = dhz^T zin; its row sums are fc_coord's bias gradient (dbc = sum_b dhz[b])
   // (jiVAE: over the K*B decoder samples, zin = [z content | onehot(k)])
-  const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
   PV_TRY(encoder_bwd(p, L, &wz, 1, s, fin_rides ? &fin : nullptr, adam, adam_done, chain, head_side));
   return extra_outputs(p, L, L.dzc, lat_in, s);
 }

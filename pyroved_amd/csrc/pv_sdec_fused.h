@@ -77,6 +77,14 @@ struct PvEncFold {
   int lat_in, z_dim, coord_dim, has_r, has_t, has_s;
   float tp0, tp1, sc_prior, beta;
   int img_per_wg;                  // images per workgroup (B / grid): 1
+  // (round 6, third cut) chain != 0: the workgroup also runs its image's latent backward (models/ivae.py's guide differentiated:
+  // head backward from dL/dz and the sampled-KL terms) and the encoder's input-gradient chain in the launch's EPILOGUE — it holds
+  // the image's row sums, dL/d(hz) and dL/dz there already (PvFused::part_rs / dhz_out / dzc_out) — so that the step's closing launch
+  // has no per-sample work left (pv_elementwise.hip: pv_rec_wgrad_kernel).  Needs head.out_dim <= 16.
+  int chain;
+  float* dhead; int ldh;           // (B, ldh) dL/d[mu | softplus input]
+  float* edp0; float* edp1;        // (B, 128) dL/dpre of the two hidden layers
+  float* llb;                      // (B) the image's log-likelihood
 };
 // the same guide as a launch of its own, one workgroup per image (pv_guide_img.hip; round 6): for the plans the fold cannot take.
 // prep != null: guest workgroups write the decoder's weight images / clear its dL/d(hz) slots; hz_mul: what hz leaves multiplied by
@@ -159,9 +167,17 @@ __host__ __device__ inline int pv_fused_reduce_blocks(int fmt) {
   return fmt == PV_REC_ROWMAJOR ? PV_FUSED_REDUCE_BLOCKS : pv_fused_reduce_mat_blocks(fmt) + PV_FUSED_REDUCE_VEC_BLOCKS;
 }
 // one block = 64 chunks = ONE accumulator block of one wave (thread c = lane c of that wave), four slices of the workgroup range
+// a finished gradient element: into the flat gradient, or (ad: pv_ivae_step's optimizer riding in the reducing launch) straight
+// through torch.optim.Adam's update of its parameter — the element's gradient slot is then left zeroed (pv_common.h: pv_adam_update)
+struct PvRecAdam { PvAdamFuse a; int on; };       // (by value: the address of a kernel argument would put it in scratch memory)
+__device__ __forceinline__ void pv_rec_out(float* __restrict__ Gr, int idx, float v, const PvRecAdam& ad) {
+  if (ad.on) pv_adam_update(ad.a.p, ad.a.g, ad.a.m, ad.a.v, (Gr - ad.a.g) + idx, v, ad.a.b1, ad.a.b2, ad.a.eps, ad.a.step_size, ad.a.bc2_sqrt);
+  else Gr[idx] = v;
+}
 template <int FMT>
 __device__ __forceinline__ void pv_sdec_fused_reduce_block_lane(const float* __restrict__ part, int G_, float* __restrict__ Gr,
-                                                                const PvFusedOffsets& o, int block, f32x4 (*sm)[64]) {
+                                                                const PvFusedOffsets& o, int block, f32x4 (*sm)[64],
+                                                                const PvRecAdam& ad = PvRecAdam{}) {
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int per = (G_ + 3) / 4;
   const int w0 = sl * per, w1 = min(G_, w0 + per);
@@ -198,26 +214,27 @@ __device__ __forceinline__ void pv_sdec_fused_reduce_block_lane(const float* __r
     const int row0 = 32 * jp + 16 * (s_ ^ kh) + 4 * q, col = 64 * kh + 16 * oo + r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      Gr[o.W1 + (row0 + i) * FD_H + col] = ta[i];
-      Gr[o.W2 + (row0 + i) * FD_H + col] = tb[i];
+      pv_rec_out(Gr, o.W1 + (row0 + i) * FD_H + col, ta[i], ad);
+      pv_rec_out(Gr, o.W2 + (row0 + i) * FD_H + col, tb[i], ad);
     }
   } else {
     const int kb = block & 7, s_ = (block >> 3) & 1, wave = (block >> 4) & 3, m = block >> 6;
     const int row0 = 16 * (2 * wave + s_) + 4 * q, col = 16 * kb + r;
-    float* dst = Gr + (m == 0 ? o.W1 : o.W2);
+    const int dst = m == 0 ? o.W1 : o.W2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dst[(row0 + i) * FD_H + col] = ta[i];
+    for (int i = 0; i < 4; ++i) pv_rec_out(Gr, dst + (row0 + i) * FD_H + col, ta[i], ad);
   }
 }
 __device__ __forceinline__ void pv_sdec_fused_reduce_block(const float* __restrict__ part, int G_,
                                                            float* __restrict__ Gr, const PvFusedOffsets& o, int cd,
-                                                           int dwo_slots, int block, f32x4 (*sm)[64], int fmt = PV_REC_ROWMAJOR) {
+                                                           int dwo_slots, int block, f32x4 (*sm)[64], int fmt = PV_REC_ROWMAJOR,
+                                                           const PvRecAdam& ad = PvRecAdam{}) {
   const int HH = FD_H * FD_H;
   const int total = 2 * HH + 5 * FD_H + 1;          // the record is padded well past this: whole float4s are readable
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
   if (fmt != PV_REC_ROWMAJOR && block < pv_fused_reduce_mat_blocks(fmt)) {
-    if (fmt == PV_REC_LANE_BF16) pv_sdec_fused_reduce_block_lane<PV_REC_LANE_BF16>(part, G_, Gr, o, block, sm);
-    else pv_sdec_fused_reduce_block_lane<PV_REC_LANE_F32>(part, G_, Gr, o, block, sm);
+    if (fmt == PV_REC_LANE_BF16) pv_sdec_fused_reduce_block_lane<PV_REC_LANE_BF16>(part, G_, Gr, o, block, sm, ad);
+    else pv_sdec_fused_reduce_block_lane<PV_REC_LANE_F32>(part, G_, Gr, o, block, sm, ad);
     return;
   }
   // (lane-native formats: the blocks behind the matrices' take the vectors, which sit at float 2*H*H in every format)
@@ -248,16 +265,16 @@ __device__ __forceinline__ void pv_sdec_fused_reduce_block(const float* __restri
   for (int i = 0; i < 4; ++i) {
     const int ei = e + i;
     if (ei >= total) break;
-    if (ei < HH) Gr[o.W1 + ei] = v[i];
-    else if (ei < 2 * HH) Gr[o.W2 + (ei - HH)] = v[i];
+    if (ei < HH) pv_rec_out(Gr, o.W1 + ei, v[i], ad);
+    else if (ei < 2 * HH) pv_rec_out(Gr, o.W2 + (ei - HH), v[i], ad);
     else {
       const int k = ei - 2 * HH, seg = k / FD_H, j = k % FD_H;
-      if (seg == 0) Gr[o.b1 + j] = v[i];
-      else if (seg == 1) Gr[o.b2 + j] = v[i];
-      else if (seg == 2) Gr[o.Wc + j * cd] = v[i];
-      else if (seg == 3) { if (cd == 2) Gr[o.Wc + j * 2 + 1] = v[i]; }
-      else if (seg == 4) Gr[o.wo + j] = v[i];
-      else Gr[o.bo] = v[i];
+      if (seg == 0) pv_rec_out(Gr, o.b1 + j, v[i], ad);
+      else if (seg == 1) pv_rec_out(Gr, o.b2 + j, v[i], ad);
+      else if (seg == 2) pv_rec_out(Gr, o.Wc + j * cd, v[i], ad);
+      else if (seg == 3) { if (cd == 2) pv_rec_out(Gr, o.Wc + j * 2 + 1, v[i], ad); }
+      else if (seg == 4) pv_rec_out(Gr, o.wo + j, v[i], ad);
+      else pv_rec_out(Gr, o.bo, v[i], ad);
     }
   }
 }

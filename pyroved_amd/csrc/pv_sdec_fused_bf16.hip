@@ -1662,7 +1662,8 @@ int64_t pv_sdec_fused_bf16_park_bytes(bool x3, int64_t units, int grid, int sel)
 // profiles/*_kernel_stats.csv by name
 extern "C" const char* pv_debug_decoder_kernel_name_fold(int grads, int lik) {      // (the launch that hosts the guide: pv_ivae_guide_folds)
   static thread_local char buf[128];
-  snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d, true>(PvFused, PvEncFold)", grads ? "true" : "false", lik);
+  // (training launches of the plain iVAE step also host the latent backward: build 2, pv_plan.hip's own_chain)
+  snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d, %d>(PvFused, PvEncFold)", grads ? "true" : "false", lik, grads ? 2 : 1);
   return buf;
 }
 extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, int grads, int lik) {
@@ -1671,7 +1672,7 @@ extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, in
   if (fused == 1) snprintf(buf, sizeof buf, "void pv_sdec_fused_kernel<%s>(PvFused)", g);
   else if (fused == 2 && fb_kind_w8h(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8h_kernel<%d, %s>(PvFused)", lik, fb_x3_kind(units, grads != 0, 0) == 48 ? "true" : "false");
   else if (fused == 2 && !fb_kind_here(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d, %d>(PvFused)", g, lik, fb_x3_kind(units, grads != 0, 0));
-  else if (fused == 3 && fb_use_w8(units, 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d, false>(PvFused, PvEncFold)", g, lik);
+  else if (fused == 3 && fb_use_w8(units, 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d, 0>(PvFused, PvEncFold)", g, lik);
   else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %d>(PvFused)", g, lik, fused == 2 ? fb_kind_prec(fb_x3_kind(units, grads != 0, 0)) : FB_P_BF16);
   else snprintf(buf, sizeof buf, "pv_gemm_kernel (layer-by-layer path)");
   return buf;

@@ -28,6 +28,7 @@
 // | per-wave prefetch slots.  Four workgroup barriers per 128-row tile.
 #include "pv_sdec_fused.h"
 #include "pv_fb_layout.h"
+#include "pv_kernels.h"        // PvHeadBwd, pv_head_dz / pv_head_bwd_math: the image's latent backward in the hosting launch's epilogue
 #include <stdlib.h>
 
 typedef short short4_ __attribute__((ext_vector_type(4)));
@@ -392,9 +393,16 @@ extern "C" int pv_debug_read_trace_w8(long long* out, int n) {
       w8_trace[136 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();                         \
     }                                                                                            \
   } while (0)
+// ... and of the epilogue's phases ([144 + k])
+#define W8_STAMP_E(k)                                                                             \
+  do {                                                                                           \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0)                   \
+      w8_trace[144 + (k)] = (long long)__builtin_readcyclecounter();                             \
+  } while (0)
 #else
 #define W8_STAMP(k) do { } while (0)
 #define W8_STAMP_K(k) do { } while (0)
+#define W8_STAMP_E(k) do { } while (0)
 #endif
 
 // ---- column-parallel tail helpers --------------------------------------------------------------------------------------
@@ -470,8 +478,11 @@ static_assert(WF_P + W8_WAVES * WF_P_WAVE <= WO_VEC, "guide scratch fits in the 
 #include "pv_gemv16.h"      // w8_gemv16, w8_gemv16_k128(_load): one wave's 16 rows of a matrix-vector product from L2-resident weights
 
 // LIK: the likelihood is a compile-time choice.  FOLD: the workgroup runs its images' guide itself (PvEncFold e; else unused)
-template <bool GRADS, int LIK, bool FOLD>
+// FOLDK: 0 plain; 1 = FOLD; 2 = FOLD + the image's latent backward and encoder chain in the epilogue (PvEncFold::chain) — a build
+// of its own: compiled into the FOLD build, the chain's registers cost the launch 2 us even when it is switched off
+template <bool GRADS, int LIK, int FOLDK>
 __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEncFold e) {
+  constexpr bool FOLD = FOLDK != 0, CHAIN = FOLDK == 2;
   extern __shared__ __attribute__((aligned(16))) char smb[];
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1267,7 +1278,62 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   // (FOLD with dhz_out: one image per workgroup — no slot was ever published; the waves' partials are summed with the column sums below)
   const bool own_dhz = FOLD && f.dhz_out != nullptr;
   if (cur_b >= 0 && !own_dhz) flush_hz(cur_b);
+  // Order of the epilogue (round 6, third cut): barrier -> every LOAD the rest of it needs -> the record stores -> LDS work.  The
+  // records are 71 KB per workgroup, 18 MB chip-wide within a microsecond: the memory pipeline takes ~3.5 us to drain them, and a
+  // load issued BEHIND them waits for that (scripts/gpu_trace_w8.py: 7.3 k cycles on ten row-sum loads); requested ahead of them,
+  // the loads' data arrives while the stores drain under the column sums and the latent backward below.
+  W8_STAMP_E(0);
+  __syncthreads();                                     // (every wave is past the last tile: its rows' outputs are in L2, the staging area is free)
+  W8_STAMP_E(1);
+  // (round 6, FOLD: the image's per-row outputs are complete in L2 — the barrier above drains every wave's stores — and are requested
+  //  HERE, so that their round trip runs under the column-sum phase below; they are added up behind its barrier)
+  float rsv[2][5] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
+  const bool fold_rs = FOLD && f.part_rs && f.N <= 2 * W8_THREADS;
+  if (fold_rs) {
+    const int64_t r0 = (int64_t)g * f.N;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = tid + u * W8_THREADS;
+      if (n < f.N) {
+        rsv[u][0] = __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rsv[u][1 + c] = __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  W8_STAMP_E(10);
+  float wzv[4] = {0.0f, 0.0f, 0.0f, 0.0f};                           // (FOLD: fc_latent's row of this thread's hidden unit, for dL/dz below)
+  if (FOLD && f.dhz_out && f.dzc_out && tid < FD_H) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wzv[i] = i < e.lat_in ? e.Wz[(int64_t)tid * e.lat_in + i] : 0.0f;
+  }
+  // (third cut, PvEncFold::chain) the image's latent backward and encoder chain follow below: their operands — the head's and the
+  // second hidden layer's weights (L2), the image's own activations, sample and noise — are requested HERE, three barriers and the
+  // column sums ahead of their first use.  (What this workgroup itself wrote in its prologue is read past the CU's L1.)
+  const bool own_chain = CHAIN && e.chain && f.part_rs && f.dhz_out && f.dzc_out;
+  float ch_whd[16], ch_w1[32], ch_a1 = 0.0f, ch_a0 = 0.0f, ch_z = 0.0f, ch_sig = 1.0f, ch_ep = 0.0f, ch_sp = 0.0f;
+  if (own_chain) {
+    auto ldc = [](const float* p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const int ho = e.head.out_dim;
+    if (tid < FD_H) {
+      const float* Wh = e.params + e.head.w_off + tid;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) ch_whd[o] = Wh[(o < ho ? o : ho - 1) * FD_H];          // (clamped: used below only for o < out_dim)
+      ch_a1 = ldc(e.eact1 + (int64_t)g * FD_H + tid);
+      ch_a0 = ldc(e.eact0 + (int64_t)g * FD_H + tid);
+    }
+    const float* W1c = e.params + e.enc1.w_off + (tid & 127) + (32 * (tid >> 7)) * FD_H;   // column k = tid & 127, rows 32 (tid >> 7) ..
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) ch_w1[jj] = W1c[jj * FD_H];
+    if (tid < e.z_dim) {
+      ch_z = ldc(e.z + (int64_t)g * e.z_dim + tid);
+      ch_sig = ldc(e.z_scale + (int64_t)g * e.z_dim + tid);
+      ch_ep = e.eps[(int64_t)g * e.z_dim + tid];
+      ch_sp = ldc(e.head_out + (int64_t)g * e.ldh + e.z_dim + tid);
+    }
+  }
   // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
+  W8_STAMP_E(11);
   {
     const int jp = wave >> 1, kh = wave & 1;
     // LANE-NATIVE PACKED (pv_sdec_fused.h PV_REC_LANE_BF16): per accumulator block ONE 16-byte store per lane, 1 KB contiguous
@@ -1314,30 +1380,9 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       }
     }
   }
-  // per-wave column sums -> LDS (the staging area is free: every wave is past the last tile's barrier 4 and its own
-  // wave-local reads) -> summed over the waves in ascending order
-  __syncthreads();
-  // (round 6, FOLD: the image's per-row outputs are complete in L2 — the barrier above drains every wave's stores — and are requested
-  //  HERE, so that their round trip runs under the column-sum phase below; they are added up behind its barrier)
-  float rsv[2][5] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
-  const bool fold_rs = FOLD && f.part_rs && f.N <= 2 * W8_THREADS;
-  if (fold_rs) {
-    const int64_t r0 = (int64_t)g * f.N;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int n = tid + u * W8_THREADS;
-      if (n < f.N) {
-        rsv[u][0] = __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rsv[u][1 + c] = __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  float wzv[4] = {0.0f, 0.0f, 0.0f, 0.0f};                           // (FOLD: fc_latent's row of this thread's hidden unit, for dL/dz below)
-  if (FOLD && f.dhz_out && f.dzc_out && tid < FD_H) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wzv[i] = i < e.lat_in ? e.Wz[(int64_t)tid * e.lat_in + i] : 0.0f;
-  }
+  W8_STAMP_E(12);
+  // per-wave column sums -> LDS -> summed over the waves in ascending order.  (The barriers from here on wait for LDS traffic only
+  // — pv_lds_barrier — not for the record stores in flight: everything the waves hand each other below goes through LDS.)
   {
     float* scr = reinterpret_cast<float*>(smb + WO_SA);            // [wave][n][128] floats = 64 KB
 #pragma unroll
@@ -1346,7 +1391,9 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   }
   const float tb = pv_wave_sum(dbo);
   if (lane == 0) red[wave] = tb;
-  __syncthreads();
+  W8_STAMP_E(2);
+  pv_lds_barrier();
+  W8_STAMP_E(3);
   // ---- the column sums over the waves (threads 0 .. 127), then — where the workgroup owns a whole image (FOLD) — the image's row
   // sums, dL/d(hz) and dL/dz for the latent backward (round 6: PvFused::part_rs / dhz_out / dzc_out), one more barrier for all three ----
   float dhz_j = 0.0f;                                                // this thread's dL/d(hz[g][tid]) (tid < 128)
@@ -1401,13 +1448,69 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
         if (lane == 0) info[16 * wave + i] = pz;
       }
     }
-    __syncthreads();
+    W8_STAMP_E(4);
+    pv_lds_barrier();
+    W8_STAMP_E(5);
+    float* cs = reinterpret_cast<float*>(smb + WO_SA);             // (the column-sum scratch is free behind the barrier above)
     if (f.part_rs && tid < 5) {
       float v = 0.0f;
       for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * tid + w];
       f.part_rs[((int64_t)g * f.kmax) * PV_RS_W + tid] = v;
+      if (own_chain) cs[tid] = v;
     }
-    if (own_dzc && tid < e.lat_in) f.dzc_out[(int64_t)g * e.lat_in + tid] = info[tid] + info[16 + tid];
+    if (own_dzc && tid < e.lat_in) {
+      const float v = info[tid] + info[16 + tid];
+      f.dzc_out[(int64_t)g * e.lat_in + tid] = v;
+      if (own_chain) cs[8 + tid] = v;
+    }
+    if (own_chain) {
+      // ---- the image's latent backward (pv_elementwise.hip: pv_latent_bwd_block, for the one sample this workgroup owns): head
+      // backward from the row sums {ll, d(phi), d(scale), d(tx), d(ty)} and dL/dz, then the encoder's input-gradient chain
+      //   edp1 = (dhead Whead) * act'(eact1),  edp0 = (edp1 W1) * act'(eact0)     (nn.Linear backward, ascending summation order)
+      // cs: [0..4] row sums, [8..] dL/dz content, [32..] dhead, [128..] edp1, [256..767] the four partial sums of edp0
+      pv_lds_barrier();
+      W8_STAMP_E(6);
+      PvHeadBwd hb{};
+      hb.coord_dim = e.coord_dim; hb.has_r = e.has_r; hb.has_t = e.has_t; hb.has_s = e.has_s;
+      hb.tp0 = e.tp0; hb.tp1 = e.tp1; hb.sc_prior = e.sc_prior;
+      if (tid < e.z_dim) {
+        const float dz = pv_head_dz(hb, tid, [&](int c) { return cs[1 + c]; }, [&](int k) { return cs[8 + k]; });
+        float g_, ds_;
+        pv_head_bwd_math(dz, ch_z, ch_sig, ch_ep, ch_sp, e.beta, 0, g_, ds_);
+        e.dhead[(int64_t)g * e.ldh + tid] = g_;
+        e.dhead[(int64_t)g * e.ldh + e.z_dim + tid] = ds_;
+        cs[32 + tid] = g_;
+        cs[32 + e.z_dim + tid] = ds_;
+      }
+      if (tid == 0) e.llb[g] = cs[0];
+      pv_lds_barrier();
+      W8_STAMP_E(7);
+      if (tid < FD_H) {
+        const int ho = e.head.out_dim;
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) v += o < ho ? cs[32 + o] * ch_whd[o] : 0.0f;
+        v *= pv_act_grad2(ch_a1, 0.0f, e.enc1.act);
+        e.edp1[(int64_t)g * FD_H + tid] = v;
+        cs[128 + tid] = v;
+      }
+      pv_lds_barrier();
+      W8_STAMP_E(8);
+      {
+        const float* ev = cs + 128 + 32 * (tid >> 7);
+        float acc = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) acc += ev[jj] * ch_w1[jj];
+        cs[256 + tid] = acc;
+      }
+      pv_lds_barrier();
+      W8_STAMP_E(9);
+      if (tid < FD_H) {
+        float y = (cs[256 + tid] + cs[384 + tid]) + (cs[512 + tid] + cs[640 + tid]);
+        y *= pv_act_grad2(ch_a0, 0.0f, e.enc0.act);
+        e.edp0[(int64_t)g * FD_H + tid] = y;
+      }
+    }
   }
   if (tid == 0) {
     float v = 0.0f;
@@ -1437,8 +1540,9 @@ int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream
     e = *fold;
     e.img_per_wg = f.B / grid;
   }
-#define W8_PICK(G, L) fn = fold ? reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, true>) \
-                                : reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, false>)
+#define W8_PICK(G, L) fn = !fold ? reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, 0>)                     \
+                               : (G && e.chain) ? reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, G ? 2 : 1>) \
+                                                : reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, 1>)
   if (grads) {
     if (f.lik == PV_LIK_BERNOULLI) W8_PICK(true, PV_LIK_BERNOULLI);
     else if (f.lik == PV_LIK_GAUSSIAN) W8_PICK(true, PV_LIK_GAUSSIAN);

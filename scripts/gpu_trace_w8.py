@@ -44,3 +44,17 @@ if k[0]:
     rt = [buf[136 + i] for i in range(4)]
     us = (rt[3] - rt[0]) / 100.0
     print("  entry -> record written: %d cycles in %.2f us of the constant 100 MHz counter = %.3f GHz" % (k[3] - k[0], us, (k[3] - k[0]) / us / 1e3))
+e = [buf[144 + i] for i in range(10)]
+if e[0] and k[2]:
+    nm = ["records stored", "barrier", "prefetch + scr stores", "barrier", "column sums, row/dz partials", "barrier", "cs fill + barrier", "head bwd + barrier",
+          "edp1 + barrier", "edp0 partials + barrier"]
+    prev = k[2]
+    out = []
+    for i in range(10):
+        if e[i]:
+            out.append("%s=%d" % (nm[i], e[i] - prev)); prev = e[i]
+    out.append("end=%d" % (k[3] - prev))
+    print("epilogue phases (cycles):", " ".join(out))
+x = [buf[144 + i] for i in (1, 10, 11, 12, 2)]
+if all(x):
+    print("  inside 'prefetch + scr stores': row-sum loads issued %d, other loads issued %d, record stores issued %d, scr stores + wave sum %d" % tuple(b - a for a, b in zip(x, x[1:])))
