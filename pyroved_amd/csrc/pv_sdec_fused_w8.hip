@@ -1287,18 +1287,20 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   W8_STAMP_E(1);
   // (round 6, FOLD: the image's per-row outputs are complete in L2 — the barrier above drains every wave's stores — and are requested
   //  HERE, so that their round trip runs under the column-sum phase below; they are added up behind its barrier)
+  // (thread n takes rows 2n, 2n + 1 — one 8-byte load per quantity: a load instruction costs this CU ~10 cycles of issue whatever its
+  //  width, and the epilogue is made of little else)
   float rsv[2][5] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
-  const bool fold_rs = FOLD && f.part_rs && f.N <= 2 * W8_THREADS;
+  const bool fold_rs = FOLD && f.part_rs && f.N <= 2 * W8_THREADS && f.N % 2 == 0;
   if (fold_rs) {
     const int64_t r0 = (int64_t)g * f.N;
+    if (2 * tid < f.N) {
+      auto ld2 = [](const float* p_, float& a, float& b) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past this CU's L1)
+        a = __uint_as_float((unsigned)v); b = __uint_as_float((unsigned)(v >> 32));
+      };
+      ld2(f.llrow + r0 + 2 * tid, rsv[0][0], rsv[1][0]);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int n = tid + u * W8_THREADS;
-      if (n < f.N) {
-        rsv[u][0] = __hip_atomic_load(f.llrow + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (past this CU's L1)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rsv[u][1 + c] = __hip_atomic_load(f.rowtp + (int64_t)c * f.M + r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      for (int c = 0; c < 4; ++c) ld2(f.rowtp + (int64_t)c * f.M + r0 + 2 * tid, rsv[0][1 + c], rsv[1][1 + c]);
     }
   }
   W8_STAMP_E(10);
@@ -1311,7 +1313,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   // second hidden layer's weights (L2), the image's own activations, sample and noise — are requested HERE, three barriers and the
   // column sums ahead of their first use.  (What this workgroup itself wrote in its prologue is read past the CU's L1.)
   const bool own_chain = CHAIN && e.chain && f.part_rs && f.dhz_out && f.dzc_out;
-  float ch_whd[16], ch_w1[32], ch_a1 = 0.0f, ch_a0 = 0.0f, ch_z = 0.0f, ch_sig = 1.0f, ch_ep = 0.0f, ch_sp = 0.0f;
+  float ch_whd[16], ch_a1 = 0.0f, ch_a0 = 0.0f, ch_z = 0.0f, ch_sig = 1.0f, ch_ep = 0.0f, ch_sp = 0.0f;
+  f32x4 ch_w1[8];
   if (own_chain) {
     auto ldc = [](const float* p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const int ho = e.head.out_dim;
@@ -1322,14 +1325,15 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       ch_a1 = ldc(e.eact1 + (int64_t)g * FD_H + tid);
       ch_a0 = ldc(e.eact0 + (int64_t)g * FD_H + tid);
     }
-    const float* W1c = e.params + e.enc1.w_off + (tid & 127) + (32 * (tid >> 7)) * FD_H;   // column k = tid & 127, rows 32 (tid >> 7) ..
+    // (second hidden layer: thread (c = tid & 31, jg = tid >> 5) holds W1[8 jg .. 8 jg + 7][4c .. 4c + 3] — eight 16-byte loads)
+    const float* W1c = e.params + e.enc1.w_off + 4 * (tid & 31) + (8 * (tid >> 5)) * FD_H;
 #pragma unroll
-    for (int jj = 0; jj < 32; ++jj) ch_w1[jj] = W1c[jj * FD_H];
-    if (tid < e.z_dim) {
-      ch_z = ldc(e.z + (int64_t)g * e.z_dim + tid);
-      ch_sig = ldc(e.z_scale + (int64_t)g * e.z_dim + tid);
-      ch_ep = e.eps[(int64_t)g * e.z_dim + tid];
-      ch_sp = ldc(e.head_out + (int64_t)g * e.ldh + e.z_dim + tid);
+    for (int jj = 0; jj < 8; ++jj) ch_w1[jj] = *reinterpret_cast<const f32x4*>(W1c + jj * FD_H);
+    if (lane < e.z_dim && wave < 2) {                  // (waves 0 and 1 each run the head backward for themselves below)
+      ch_z = ldc(e.z + (int64_t)g * e.z_dim + lane);
+      ch_sig = ldc(e.z_scale + (int64_t)g * e.z_dim + lane);
+      ch_ep = e.eps[(int64_t)g * e.z_dim + lane];
+      ch_sp = ldc(e.head_out + (int64_t)g * e.ldh + e.z_dim + lane);
     }
   }
   // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
@@ -1456,57 +1460,71 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       float v = 0.0f;
       for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * tid + w];
       f.part_rs[((int64_t)g * f.kmax) * PV_RS_W + tid] = v;
-      if (own_chain) cs[tid] = v;
     }
-    if (own_dzc && tid < e.lat_in) {
-      const float v = info[tid] + info[16 + tid];
-      f.dzc_out[(int64_t)g * e.lat_in + tid] = v;
-      if (own_chain) cs[8 + tid] = v;
-    }
+    if (own_dzc && tid < e.lat_in) f.dzc_out[(int64_t)g * e.lat_in + tid] = info[tid] + info[16 + tid];
     if (own_chain) {
       // ---- the image's latent backward (pv_elementwise.hip: pv_latent_bwd_block, for the one sample this workgroup owns): head
       // backward from the row sums {ll, d(phi), d(scale), d(tx), d(ty)} and dL/dz, then the encoder's input-gradient chain
-      //   edp1 = (dhead Whead) * act'(eact1),  edp0 = (edp1 W1) * act'(eact0)     (nn.Linear backward, ascending summation order)
-      // cs: [0..4] row sums, [8..] dL/dz content, [32..] dhead, [128..] edp1, [256..767] the four partial sums of edp0
-      pv_lds_barrier();
-      W8_STAMP_E(6);
-      PvHeadBwd hb{};
-      hb.coord_dim = e.coord_dim; hb.has_r = e.has_r; hb.has_t = e.has_t; hb.has_s = e.has_s;
-      hb.tp0 = e.tp0; hb.tp1 = e.tp1; hb.sc_prior = e.sc_prior;
-      if (tid < e.z_dim) {
-        const float dz = pv_head_dz(hb, tid, [&](int c) { return cs[1 + c]; }, [&](int k) { return cs[8 + k]; });
-        float g_, ds_;
-        pv_head_bwd_math(dz, ch_z, ch_sig, ch_ep, ch_sp, e.beta, 0, g_, ds_);
-        e.dhead[(int64_t)g * e.ldh + tid] = g_;
-        e.dhead[(int64_t)g * e.ldh + e.z_dim + tid] = ds_;
-        cs[32 + tid] = g_;
-        cs[32 + e.z_dim + tid] = ds_;
-      }
-      if (tid == 0) e.llb[g] = cs[0];
-      pv_lds_barrier();
-      W8_STAMP_E(7);
-      if (tid < FD_H) {
-        const int ho = e.head.out_dim;
+      //   edp1 = (dhead Whead) * act'(eact1),  edp0 = (edp1 W1) * act'(eact0)     (nn.Linear backward)
+      // Three phases, two barriers.  1: waves 0 and 1 — each runs the head backward for itself (lane i: coordinate i; the sums it
+      // needs straight from the waves' partials in LDS), hands dhead round with v_readlane, and takes 64 of edp1's 128 entries.
+      // 2: every thread contracts its 8 x 4 block of W1 with edp1.  3: threads 0 .. 127 add the 16 partial sums of their column.
+      // cs: [128 ..] edp1, [256 + 128 jg ..] the partial sums of row group jg
+      if (wave < 2) {
+        // (wave-private LDS words csw[0 .. 63]: a wave's LDS operations complete in order, so lanes of ONE wave hand values to each
+        //  other through them with a wait, no barrier.  [0..4] the five row sums, [8..] dL/dz content, [16..31] dhead, zero past its end)
+        float* csw = cs + 64 * wave;
+        if (lane < 5) {
+          float v = 0.0f;
+#pragma unroll
+          for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * lane + w];
+          csw[lane] = v;
+          if (tid == 0) e.llb[g] = v;
+        }
+        if (lane >= 8 && lane < 8 + e.lat_in) csw[lane] = info[lane - 8] + info[16 + lane - 8];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PvHeadBwd hb{};
+        hb.coord_dim = e.coord_dim; hb.has_r = e.has_r; hb.has_t = e.has_t; hb.has_s = e.has_s;
+        hb.tp0 = e.tp0; hb.tp1 = e.tp1; hb.sc_prior = e.sc_prior;
+        if (lane < 16) {
+          float g_ = 0.0f, ds_ = 0.0f;
+          if (lane < e.z_dim) {
+            const float dz = pv_head_dz(hb, lane, [&](int c) { return csw[1 + c]; }, [&](int k) { return csw[8 + k]; });
+            pv_head_bwd_math(dz, ch_z, ch_sig, ch_ep, ch_sp, e.beta, 0, g_, ds_);
+            if (wave == 0) {
+              e.dhead[(int64_t)g * e.ldh + lane] = g_;
+              e.dhead[(int64_t)g * e.ldh + e.z_dim + lane] = ds_;
+            }
+            csw[16 + lane] = g_;
+            csw[16 + e.z_dim + lane] = ds_;
+          } else if (lane + e.z_dim < 16) {
+            csw[16 + e.z_dim + lane] = 0.0f;                      // (entries 2 z_dim .. 15)
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float v = 0.0f;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) v += o < ho ? cs[32 + o] * ch_whd[o] : 0.0f;
+        for (int o = 0; o < 16; ++o) v += csw[16 + o] * ch_whd[o];     // (head rows past out_dim: a clamped weight times the zero above)
         v *= pv_act_grad2(ch_a1, 0.0f, e.enc1.act);
         e.edp1[(int64_t)g * FD_H + tid] = v;
         cs[128 + tid] = v;
       }
       pv_lds_barrier();
-      W8_STAMP_E(8);
+      W8_STAMP_E(6);
       {
-        const float* ev = cs + 128 + 32 * (tid >> 7);
-        float acc = 0.0f;
-#pragma unroll
-        for (int jj = 0; jj < 32; ++jj) acc += ev[jj] * ch_w1[jj];
-        cs[256 + tid] = acc;
+        const int c = tid & 31, jg = tid >> 5;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(cs + 128 + 8 * jg), e1 = *reinterpret_cast<const f32x4*>(cs + 132 + 8 * jg);
+        f32x4 acc = ch_w1[0] * e0[0];
+        acc += ch_w1[1] * e0[1]; acc += ch_w1[2] * e0[2]; acc += ch_w1[3] * e0[3];
+        acc += ch_w1[4] * e1[0]; acc += ch_w1[5] * e1[1]; acc += ch_w1[6] * e1[2]; acc += ch_w1[7] * e1[3];
+        *reinterpret_cast<f32x4*>(cs + 256 + 128 * jg + 4 * c) = acc;
       }
       pv_lds_barrier();
-      W8_STAMP_E(9);
+      W8_STAMP_E(7);
       if (tid < FD_H) {
-        float y = (cs[256 + tid] + cs[384 + tid]) + (cs[512 + tid] + cs[640 + tid]);
+        float y = 0.0f;
+#pragma unroll
+        for (int jg = 0; jg < 16; ++jg) y += cs[256 + 128 * jg + tid];
         y *= pv_act_grad2(ch_a0, 0.0f, e.enc0.act);
         e.edp0[(int64_t)g * FD_H + tid] = y;
       }

@@ -46,8 +46,8 @@ if k[0]:
     print("  entry -> record written: %d cycles in %.2f us of the constant 100 MHz counter = %.3f GHz" % (k[3] - k[0], us, (k[3] - k[0]) / us / 1e3))
 e = [buf[144 + i] for i in range(10)]
 if e[0] and k[2]:
-    nm = ["records stored", "barrier", "prefetch + scr stores", "barrier", "column sums, row/dz partials", "barrier", "cs fill + barrier", "head bwd + barrier",
-          "edp1 + barrier", "edp0 partials + barrier"]
+    nm = ["records stored", "barrier", "prefetch + scr stores", "barrier", "column sums, row/dz partials", "barrier", "head bwd + edp1 + barrier", "edp0 partials + barrier",
+          "-", "-"]
     prev = k[2]
     out = []
     for i in range(10):
