@@ -931,8 +931,9 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     lb.enc_n = p->n_enc; lb.enc_params = p->params; lb.enc_head = p->head;
     for (int i = 0; i < p->n_enc; ++i) { lb.enc_l[i] = p->enc[i]; lb.enc_act[i] = L.eact[i]; lb.enc_dp[i] = L.edp[i]; }
   }
-  // (round 6, third cut) where the decoder launch hosts the guide — one image per workgroup — it also runs every image's latent
-  // backward and encoder chain in its epilogue (PvEncFold::chain), and the step closes with ONE launch of workgroups that need
+  // (round 6, third cut) where every workgroup of the decoder launch owns one image — the launch that hosts the guide, or a 4-wave
+  // launch at batch == grid — it also runs the image's latent backward and encoder chain in its epilogue (PvEncFold::chain), and the
+  // step closes with ONE launch of workgroups that need
   // nothing from each other: record sums, small weight gradients, loss scalars (pv_elementwise.hip: pv_rec_wgrad_kernel).
   // Needs what that epilogue is written for (the plain iVAE step: no per-sample weights / extra outputs, a head of <= 16 outputs)
   // and — with the optimizer riding — records + tiles covering every parameter.
@@ -941,7 +942,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   const PvGemm wz = wgrad_problem(L.dhz, H, zin, ldz, G + p->fc_latent.w_off, G + p->fc_coord.b_off, S, lat_in, H);
   PvGemm tail_probs[4];
   int tail_np = -1;
-  if (ab_tail && fold && want_grads && chain && f.part_rs && f.dhz_out && f.dzc_out && K == 0 && H == FD_H && !p->row_w &&
+  // (f.dhz_out / dzc_out / part_rs together: the hosting 8-wave launch, or a 4-wave launch whose workgroups own one sample each)
+  if (ab_tail && want_grads && chain && f.part_rs && f.dhz_out && f.dzc_out && K == 0 && H == FD_H && !p->row_w &&
       !p->row_elbo && !p->dy && p->head.out_dim <= 16 && p->n_enc == 2) {
     tail_np = compact_wgrad_problems(p, L, &wz, 1, tail_probs);
     if (tail_np > 0 && adam) {
@@ -962,7 +964,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
     ef.chain = 1; ef.dhead = L.dhead; ef.ldh = (int)plan_head_w(p); ef.edp0 = L.edp[0]; ef.edp1 = L.edp[1]; ef.llb = L.llb;
   }
   if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
-  if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s, fold ? &ef : nullptr));
+  if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s, fold ? &ef : nullptr,
+                                                      (own_chain && !fold) ? &ef : nullptr));
   else PV_TRY(pv_sdec_fused_launch(f, L.f_grid, want_grads != 0, s));
   if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_stop, s);
   if (!want_grads && K > 0) {                        // llb[b] = sum_k alpha_bk ll_kb

@@ -86,6 +86,21 @@ struct PvEncFold {
   float* edp0; float* edp1;        // (B, 128) dL/dpre of the two hidden layers
   float* llb;                      // (B) the image's log-likelihood
 };
+// A kernel (PvFused f, PvEncFold e) whose EPILOGUE alone needs `e` reads it there through this pointer into the kernarg segment, made
+// opaque at the point of use: named directly, the compiler fetches the fields at kernel entry and carries them — spilled — through
+// the tile loop (pv_sdec_fused_bf16.hip: 51 -> 92 spilled SGPRs and +3 us on the launch; with the pointer: 42).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) PvEncFold* PvEncFoldArg;
+__device__ __forceinline__ PvEncFoldArg pv_kernarg_fold() {
+  const __attribute__((address_space(4))) char* k = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  PvEncFoldArg p = (PvEncFoldArg)(k + ((sizeof(PvFused) + alignof(PvEncFold) - 1) / alignof(PvEncFold)) * alignof(PvEncFold));
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#else
+typedef const PvEncFold* PvEncFoldArg;
+__device__ inline PvEncFoldArg pv_kernarg_fold() { return nullptr; }      // (host pass of the same source: never called)
+#endif
 // the same guide as a launch of its own, one workgroup per image (pv_guide_img.hip; round 6): for the plans the fold cannot take.
 // prep != null: guest workgroups write the decoder's weight images / clear its dL/d(hz) slots; hz_mul: what hz leaves multiplied by
 #define PV_GUIDE_IMG_MAX_BATCH 384     // (measured, scripts/ab_guide_img.py: -7..-10 % of the step at batch 64, -6..-9 % at 128, -2..-4 % at 256, +-0 at 512)
@@ -115,7 +130,8 @@ int pv_sdec_fused_bf16_prep(const PvFused& f, bool grads, bool x3, hipStream_t s
 struct PvFbPrep;
 PvFbPrep pv_sdec_fused_bf16_prep_args(const PvFused& f, bool grads, bool x3);
 bool pv_sdec_fused_w8_qswap();          // the 8-wave plain-bf16 kernel's images are in the q-swapped column order (pv_fb_layout.h)
-int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s, const PvEncFold* fold = nullptr);
+int pv_sdec_fused_bf16_launch(const PvFused& f, int grid, bool grads, bool x3, hipStream_t s, const PvEncFold* fold = nullptr,
+                              const PvEncFold* chain = nullptr);      // chain: the 4-wave kernels' own-sample epilogue (PvEncFold::chain)
 int pv_sdec_fused_w8_launch(const PvFused& f, int grid, bool grads, hipStream_t s, const PvEncFold* fold = nullptr);
 // the 8-wave split-precision kernel (pv_sdec_fused_w8x3.hip; images pre-scaled by 2 log2(e) like the plain 8-wave kernel's)
 int pv_sdec_fused_w8x3_launch(const PvFused& f, int grid, bool grads, hipStream_t s, int waves);   // waves: 8 or 4

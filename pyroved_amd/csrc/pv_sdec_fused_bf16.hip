@@ -35,6 +35,7 @@
 //     transposes through the wave's own rows of whichever staging area is dead at that moment (fb_colsum).
 #include "pv_sdec_fused.h"
 #include "pv_fb_layout.h"
+#include "pv_kernels.h"        // PvHeadBwd, pv_head_dz / pv_head_bwd_math: the own-sample epilogue's latent backward
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -768,7 +769,8 @@ __global__ __launch_bounds__(256) void pv_fb_prep_kernel(PvFbPrep p) {
 // LIK: the likelihood is a compile-time choice (the rarely used ones must not cost the Bernoulli kernel registers)
 // PREC: FB_P_* (above)
 template <bool GRADS, int LIK, int PREC>
-__global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f) {
+__global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFused f, PvEncFold e_arg) {
+  (void)e_arg;                                   // (read in the epilogue only, through the kernarg pointer: see there)
   using PP = FbP<PREC>;
   using LL = FbLds<PREC>;
   constexpr bool F16 = PP::F16, OV = LL::OV;
@@ -1443,6 +1445,34 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
     fb_colsum<0>(t, reinterpret_cast<float*>(st2) + (16 * wave) * (LDS2 / 2), cs_wo, cs_none, cs_none, nullptr, nullptr,
                  lane, r, q);
   }
+  // (round 6, third cut: PvEncFold::chain) a workgroup that owns its sample also runs the sample's latent backward and encoder
+  // chain below (pv_sdec_fused_w8.hip has the story); the operands are requested here, ahead of the 138 KB of record stores
+  // (`e` is read through an opaque pointer into the kernarg segment HERE: named directly, the compiler fetches its fields at kernel
+  //  entry and carries them — spilled, 51 -> 92 SGPRs — through the tile loop: +3 us on the launch even with the chain switched off)
+  const PvEncFoldArg ep_ = pv_kernarg_fold();
+  const bool own_chain = own && ep_->chain && f.part_rs && f.dzc_out;
+  float ch_whd[16], ch_a1 = 0.0f, ch_a0 = 0.0f, ch_z = 0.0f, ch_sig = 1.0f, ch_ep = 0.0f, ch_sp = 0.0f;
+  f32x4 ch_w1[16];
+  if (own_chain) {
+    const int ho = ep_->head.out_dim;
+    if (tid < FD_H) {
+      const float* Wh = ep_->params + ep_->head.w_off + tid;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) ch_whd[o] = Wh[(o < ho ? o : ho - 1) * FD_H];          // (clamped: multiplied by a zero below)
+      ch_a1 = ep_->eact1[(int64_t)g * FD_H + tid];
+      ch_a0 = ep_->eact0[(int64_t)g * FD_H + tid];
+    }
+    // (second hidden layer: thread (c = tid & 31, jg = tid >> 5) holds W1[16 jg .. 16 jg + 15][4c .. 4c + 3])
+    const float* W1c = ep_->params + ep_->enc1.w_off + 4 * (tid & 31) + (16 * (tid >> 5)) * FD_H;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) ch_w1[jj] = *reinterpret_cast<const f32x4*>(W1c + jj * FD_H);
+    if (lane < ep_->z_dim && wave < 2) {
+      ch_z = ep_->z[(int64_t)g * ep_->z_dim + lane];
+      ch_sig = ep_->z_scale[(int64_t)g * ep_->z_dim + lane];
+      ch_ep = ep_->eps[(int64_t)g * ep_->z_dim + lane];
+      ch_sp = ep_->head_out[(int64_t)g * ep_->ldh + ep_->z_dim + lane];
+    }
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int j0 = 16 * (2 * wave + s);
@@ -1531,6 +1561,70 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pv_sdec_fused_bf16_kernel(PvFus
         }
         __syncthreads();
         if (tid < f.lat_in) f.dzc_out[(int64_t)g * f.lat_in + tid] = dzp[tid] + dzp[16 + tid];
+      }
+      if (own_chain) {
+        // ---- the sample's latent backward + encoder chain (pv_sdec_fused_w8.hip's epilogue, for this kernel's four waves):
+        //   dhead from the row sums and dL/dz;  edp1 = (dhead Whead) * act'(eact1);  edp0 = (edp1 W1) * act'(eact0)
+        // waves 0 and 1 run the head backward each for itself (wave-private LDS words, no barrier) and take 64 entries of edp1;
+        // every thread contracts its 16 x 4 block of W1; threads 0 .. 127 add the 8 partial sums of their column.
+        const float* rr = dh + FB_WAVES * FD_H;
+        const float* dzp = dh + FB_WAVES * FD_H + 8 * FB_WAVES;
+        float* cs = dh + FB_WAVES * FD_H + 8 * FB_WAVES + 64;        // [0..127] two waves' words, [128..255] edp1, [256 + 128 jg ..] partials
+        if (wave < 2) {
+          float* csw = cs + 64 * wave;
+          if (lane < 5) {
+            const float v = (rr[lane] + rr[8 + lane]) + (rr[16 + lane] + rr[24 + lane]);
+            csw[lane] = v;
+            if (tid == 0) ep_->llb[g] = v;
+          }
+          if (lane >= 8 && lane < 8 + f.lat_in) csw[lane] = dzp[lane - 8] + dzp[16 + lane - 8];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          PvHeadBwd hb{};
+          hb.coord_dim = ep_->coord_dim; hb.has_r = ep_->has_r; hb.has_t = ep_->has_t; hb.has_s = ep_->has_s;
+          hb.tp0 = ep_->tp0; hb.tp1 = ep_->tp1; hb.sc_prior = ep_->sc_prior;
+          if (lane < 16) {
+            if (lane < ep_->z_dim) {
+              float g_, ds_;
+              const float dz = pv_head_dz(hb, lane, [&](int c) { return csw[1 + c]; }, [&](int k) { return csw[8 + k]; });
+              pv_head_bwd_math(dz, ch_z, ch_sig, ch_ep, ch_sp, ep_->beta, 0, g_, ds_);
+              if (wave == 0) {
+                ep_->dhead[(int64_t)g * ep_->ldh + lane] = g_;
+                ep_->dhead[(int64_t)g * ep_->ldh + ep_->z_dim + lane] = ds_;
+              }
+              csw[16 + lane] = g_;
+              csw[16 + ep_->z_dim + lane] = ds_;
+            } else if (lane + ep_->z_dim < 16) {
+              csw[16 + ep_->z_dim + lane] = 0.0f;                      // (entries 2 z_dim .. 15)
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          float v = 0.0f;
+#pragma unroll
+          for (int o = 0; o < 16; ++o) v += csw[16 + o] * ch_whd[o];
+          v *= pv_act_grad2(ch_a1, 0.0f, ep_->enc1.act);
+          ep_->edp1[(int64_t)g * FD_H + tid] = v;
+          cs[128 + tid] = v;
+        }
+        __syncthreads();
+        {
+          const int c = tid & 31, jg = tid >> 5;
+          f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(cs + 128 + 16 * jg + 4 * u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc += ch_w1[4 * u + i] * ev[i];
+          }
+          *reinterpret_cast<f32x4*>(cs + 256 + 128 * jg + 4 * c) = acc;
+        }
+        __syncthreads();
+        if (tid < FD_H) {
+          float y = 0.0f;
+#pragma unroll
+          for (int jg = 0; jg < 8; ++jg) y += cs[256 + 128 * jg + tid];
+          y *= pv_act_grad2(ch_a0, 0.0f, ep_->enc0.act);
+          ep_->edp0[(int64_t)g * FD_H + tid] = y;
+        }
       }
     }
   }
@@ -1673,7 +1767,7 @@ extern "C" const char* pv_debug_decoder_kernel_name(int fused, int64_t units, in
   else if (fused == 2 && fb_kind_w8h(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8h_kernel<%d, %s>(PvFused)", lik, fb_x3_kind(units, grads != 0, 0) == 48 ? "true" : "false");
   else if (fused == 2 && !fb_kind_here(fb_x3_kind(units, grads != 0, 0))) snprintf(buf, sizeof buf, "void pv_sdec_w8x3_kernel<%s, %d, %d>(PvFused)", g, lik, fb_x3_kind(units, grads != 0, 0));
   else if (fused == 3 && fb_use_w8(units, 0)) snprintf(buf, sizeof buf, "void pv_sdec_w8_kernel<%s, %d, 0>(PvFused, PvEncFold)", g, lik);
-  else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %d>(PvFused)", g, lik, fused == 2 ? fb_kind_prec(fb_x3_kind(units, grads != 0, 0)) : FB_P_BF16);
+  else if (fused >= 2) snprintf(buf, sizeof buf, "void pv_sdec_fused_bf16_kernel<%s, %d, %d>(PvFused, PvEncFold)", g, lik, fused == 2 ? fb_kind_prec(fb_x3_kind(units, grads != 0, 0)) : FB_P_BF16);
   else snprintf(buf, sizeof buf, "pv_gemm_kernel (layer-by-layer path)");
   return buf;
 }
@@ -1713,7 +1807,8 @@ bool pv_sdec_fused_fold_ok(const PvFused& f, int grid, bool x3) {
   return !x3 && fb_use_w8(f.units, f.sel) && pv_sdec_fused_w8_fold_ok(f, grid);
 }
 
-int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s, const PvEncFold* fold) {
+int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3, hipStream_t s, const PvEncFold* fold,
+                              const PvEncFold* chain) {
   if (fold && (x3 || !fb_use_w8(f_in.units, f_in.sel))) return PV_EINVAL;      // (the folded guide lives in the 8-wave plain-bf16 kernel)
   int prec = FB_P_BF16;
   if (x3) {
@@ -1772,7 +1867,9 @@ int pv_sdec_fused_bf16_launch(const PvFused& f_in, int grid, bool grads, bool x3
 #undef FB_PICK_P
   // (per device: a process may drive several; idempotent: a race between host threads only repeats the call)
   PV_TRY(pv_set_dynamic_lds(fn, (int)lds));          // (per device and kernel)
-  void* args[] = {&f};
+  PvEncFold ec{};                                   // (chain: the own-sample epilogue's latent backward, PvEncFold::chain)
+  if (chain && grads) ec = *chain;
+  void* args[] = {&f, &ec};
   hipError_t e2 = hipLaunchKernel(fn, dim3(grid), dim3(FB_THREADS), args, lds, s);
   if (e2 != hipSuccess) return (int)e2;
   PV_LAUNCH_CHECK();

@@ -1276,6 +1276,9 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   W8_STAMP_K(2);
 
   // (FOLD with dhz_out: one image per workgroup — no slot was ever published; the waves' partials are summed with the column sums below)
+  // (from here on `e` is read through an opaque pointer into the kernarg segment: named directly, the fields the epilogue needs are
+  //  fetched at kernel entry and carried — spilled — through the tile loop)
+  const PvEncFoldArg ep_ = pv_kernarg_fold();
   const bool own_dhz = FOLD && f.dhz_out != nullptr;
   if (cur_b >= 0 && !own_dhz) flush_hz(cur_b);
   // Order of the epilogue (round 6, third cut): barrier -> every LOAD the rest of it needs -> the record stores -> LDS work.  The
@@ -1307,33 +1310,33 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   float wzv[4] = {0.0f, 0.0f, 0.0f, 0.0f};                           // (FOLD: fc_latent's row of this thread's hidden unit, for dL/dz below)
   if (FOLD && f.dhz_out && f.dzc_out && tid < FD_H) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wzv[i] = i < e.lat_in ? e.Wz[(int64_t)tid * e.lat_in + i] : 0.0f;
+    for (int i = 0; i < 4; ++i) wzv[i] = i < ep_->lat_in ? ep_->Wz[(int64_t)tid * ep_->lat_in + i] : 0.0f;
   }
   // (third cut, PvEncFold::chain) the image's latent backward and encoder chain follow below: their operands — the head's and the
   // second hidden layer's weights (L2), the image's own activations, sample and noise — are requested HERE, three barriers and the
   // column sums ahead of their first use.  (What this workgroup itself wrote in its prologue is read past the CU's L1.)
-  const bool own_chain = CHAIN && e.chain && f.part_rs && f.dhz_out && f.dzc_out;
+  const bool own_chain = CHAIN && ep_->chain && f.part_rs && f.dhz_out && f.dzc_out;
   float ch_whd[16], ch_a1 = 0.0f, ch_a0 = 0.0f, ch_z = 0.0f, ch_sig = 1.0f, ch_ep = 0.0f, ch_sp = 0.0f;
   f32x4 ch_w1[8];
   if (own_chain) {
     auto ldc = [](const float* p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    const int ho = e.head.out_dim;
+    const int ho = ep_->head.out_dim;
     if (tid < FD_H) {
-      const float* Wh = e.params + e.head.w_off + tid;
+      const float* Wh = ep_->params + ep_->head.w_off + tid;
 #pragma unroll
       for (int o = 0; o < 16; ++o) ch_whd[o] = Wh[(o < ho ? o : ho - 1) * FD_H];          // (clamped: used below only for o < out_dim)
-      ch_a1 = ldc(e.eact1 + (int64_t)g * FD_H + tid);
-      ch_a0 = ldc(e.eact0 + (int64_t)g * FD_H + tid);
+      ch_a1 = ldc(ep_->eact1 + (int64_t)g * FD_H + tid);
+      ch_a0 = ldc(ep_->eact0 + (int64_t)g * FD_H + tid);
     }
     // (second hidden layer: thread (c = tid & 31, jg = tid >> 5) holds W1[8 jg .. 8 jg + 7][4c .. 4c + 3] — eight 16-byte loads)
-    const float* W1c = e.params + e.enc1.w_off + 4 * (tid & 31) + (8 * (tid >> 5)) * FD_H;
+    const float* W1c = ep_->params + ep_->enc1.w_off + 4 * (tid & 31) + (8 * (tid >> 5)) * FD_H;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) ch_w1[jj] = *reinterpret_cast<const f32x4*>(W1c + jj * FD_H);
-    if (lane < e.z_dim && wave < 2) {                  // (waves 0 and 1 each run the head backward for themselves below)
-      ch_z = ldc(e.z + (int64_t)g * e.z_dim + lane);
-      ch_sig = ldc(e.z_scale + (int64_t)g * e.z_dim + lane);
-      ch_ep = e.eps[(int64_t)g * e.z_dim + lane];
-      ch_sp = ldc(e.head_out + (int64_t)g * e.ldh + e.z_dim + lane);
+    if (lane < ep_->z_dim && wave < 2) {                  // (waves 0 and 1 each run the head backward for themselves below)
+      ch_z = ldc(ep_->z + (int64_t)g * ep_->z_dim + lane);
+      ch_sig = ldc(ep_->z_scale + (int64_t)g * ep_->z_dim + lane);
+      ch_ep = ep_->eps[(int64_t)g * ep_->z_dim + lane];
+      ch_sp = ldc(ep_->head_out + (int64_t)g * ep_->ldh + ep_->z_dim + lane);
     }
   }
   // ---- the workgroup's gradient record (pv_sdec_fused.h: FD_REC) ----
@@ -1447,8 +1450,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       }
     }
     if (own_dzc && wave < 2) {
-      for (int i = 0; i < e.lat_in; ++i) {
-        const float pz = pv_wave_sum(dhz_j * (i < 4 ? wzv[i] : e.Wz[(int64_t)tid * e.lat_in + i]));
+      for (int i = 0; i < ep_->lat_in; ++i) {
+        const float pz = pv_wave_sum(dhz_j * (i < 4 ? wzv[i] : ep_->Wz[(int64_t)tid * ep_->lat_in + i]));
         if (lane == 0) info[16 * wave + i] = pz;
       }
     }
@@ -1461,7 +1464,7 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
       for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * tid + w];
       f.part_rs[((int64_t)g * f.kmax) * PV_RS_W + tid] = v;
     }
-    if (own_dzc && tid < e.lat_in) f.dzc_out[(int64_t)g * e.lat_in + tid] = info[tid] + info[16 + tid];
+    if (own_dzc && tid < ep_->lat_in) f.dzc_out[(int64_t)g * ep_->lat_in + tid] = info[tid] + info[16 + tid];
     if (own_chain) {
       // ---- the image's latent backward (pv_elementwise.hip: pv_latent_bwd_block, for the one sample this workgroup owns): head
       // backward from the row sums {ll, d(phi), d(scale), d(tx), d(ty)} and dL/dz, then the encoder's input-gradient chain
@@ -1479,34 +1482,34 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
 #pragma unroll
           for (int w = 0; w < W8_WAVES; ++w) v += red[8 + 8 * lane + w];
           csw[lane] = v;
-          if (tid == 0) e.llb[g] = v;
+          if (tid == 0) ep_->llb[g] = v;
         }
-        if (lane >= 8 && lane < 8 + e.lat_in) csw[lane] = info[lane - 8] + info[16 + lane - 8];
+        if (lane >= 8 && lane < 8 + ep_->lat_in) csw[lane] = info[lane - 8] + info[16 + lane - 8];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PvHeadBwd hb{};
-        hb.coord_dim = e.coord_dim; hb.has_r = e.has_r; hb.has_t = e.has_t; hb.has_s = e.has_s;
-        hb.tp0 = e.tp0; hb.tp1 = e.tp1; hb.sc_prior = e.sc_prior;
+        hb.coord_dim = ep_->coord_dim; hb.has_r = ep_->has_r; hb.has_t = ep_->has_t; hb.has_s = ep_->has_s;
+        hb.tp0 = ep_->tp0; hb.tp1 = ep_->tp1; hb.sc_prior = ep_->sc_prior;
         if (lane < 16) {
           float g_ = 0.0f, ds_ = 0.0f;
-          if (lane < e.z_dim) {
+          if (lane < ep_->z_dim) {
             const float dz = pv_head_dz(hb, lane, [&](int c) { return csw[1 + c]; }, [&](int k) { return csw[8 + k]; });
-            pv_head_bwd_math(dz, ch_z, ch_sig, ch_ep, ch_sp, e.beta, 0, g_, ds_);
+            pv_head_bwd_math(dz, ch_z, ch_sig, ch_ep, ch_sp, ep_->beta, 0, g_, ds_);
             if (wave == 0) {
-              e.dhead[(int64_t)g * e.ldh + lane] = g_;
-              e.dhead[(int64_t)g * e.ldh + e.z_dim + lane] = ds_;
+              ep_->dhead[(int64_t)g * ep_->ldh + lane] = g_;
+              ep_->dhead[(int64_t)g * ep_->ldh + ep_->z_dim + lane] = ds_;
             }
             csw[16 + lane] = g_;
-            csw[16 + e.z_dim + lane] = ds_;
-          } else if (lane + e.z_dim < 16) {
-            csw[16 + e.z_dim + lane] = 0.0f;                      // (entries 2 z_dim .. 15)
+            csw[16 + ep_->z_dim + lane] = ds_;
+          } else if (lane + ep_->z_dim < 16) {
+            csw[16 + ep_->z_dim + lane] = 0.0f;                      // (entries 2 z_dim .. 15)
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float v = 0.0f;
 #pragma unroll
         for (int o = 0; o < 16; ++o) v += csw[16 + o] * ch_whd[o];     // (head rows past out_dim: a clamped weight times the zero above)
-        v *= pv_act_grad2(ch_a1, 0.0f, e.enc1.act);
-        e.edp1[(int64_t)g * FD_H + tid] = v;
+        v *= pv_act_grad2(ch_a1, 0.0f, ep_->enc1.act);
+        ep_->edp1[(int64_t)g * FD_H + tid] = v;
         cs[128 + tid] = v;
       }
       pv_lds_barrier();
@@ -1525,8 +1528,8 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
         float y = 0.0f;
 #pragma unroll
         for (int jg = 0; jg < 16; ++jg) y += cs[256 + 128 * jg + tid];
-        y *= pv_act_grad2(ch_a0, 0.0f, e.enc0.act);
-        e.edp0[(int64_t)g * FD_H + tid] = y;
+        y *= pv_act_grad2(ch_a0, 0.0f, ep_->enc0.act);
+        ep_->edp0[(int64_t)g * FD_H + tid] = y;
       }
     }
   }
