@@ -1103,12 +1103,14 @@ int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, floa
 //  the two launches' 17.1 — at two workgroups per CU the waiting tiles get no slot before the producers are done, and 990
 //  workgroups take ~4 us just to dispatch: profiles/r06j_tail_launch.txt.)
 __global__ __launch_bounds__(256) void pv_rec_wgrad_kernel(const float* __restrict__ part, int G_, float* __restrict__ Gr, PvFusedOffsets o,
-                                                           int cd, int fmt, PvWgradSmall w, PvRecAdam ra) {
+                                                           int cd, int fmt, PvWgradSmall w, PvRecAdam ra, int rwx) {
+  // (rwx: timing experiments of the experiments build — 1 no record sums, 2 no tiles: wrong results; 0 in the shipped build)
   __shared__ f32x4 smr[4][64];
   __shared__ float wpart[WG_WAVES][16][17];
   __shared__ float wrpart[WG_WAVES][16];
   const int nred = pv_fused_reduce_blocks(fmt), id = (int)blockIdx.x;
-  if (id < nred) { pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, id, smr, fmt, ra); return; }
+  if (id < nred) { if (!(rwx & 1)) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, id, smr, fmt, ra); return; }
+  if (rwx & 2) return;
   pv_wgrad_small_block(w, id - nred, (int)gridDim.x - nred, wpart, wrpart);
 }
 
@@ -1122,8 +1124,9 @@ int pv_rec_wgrad(const float* part, int grid, float* G, const PvFusedOffsets& o,
   const int fin_blocks = (fin && fin->scalars) ? 1 : 0;
   PvRecAdam ra{};
   if (adam) { ra.a = *adam; ra.on = 1; }
+  static const int rwx = pv_exp_int("PV_RW_EXP", 0);
   hipLaunchKernelGGL(pv_rec_wgrad_kernel, dim3(pv_fused_reduce_blocks(fmt) + tiles + fin_blocks), dim3(256), 0, s, part, grid, G, o, cd,
-                     fmt, w, ra);
+                     fmt, w, ra, rwx);
   PV_LAUNCH_CHECK();
   return 0;
 }

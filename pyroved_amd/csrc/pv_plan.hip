@@ -944,7 +944,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   int tail_np = -1;
   // (f.dhz_out / dzc_out / part_rs together: the hosting 8-wave launch, or a 4-wave launch whose workgroups own one sample each)
   if (ab_tail && want_grads && chain && f.part_rs && f.dhz_out && f.dzc_out && K == 0 && H == FD_H && !p->row_w &&
-      !p->row_elbo && !p->dy && p->head.out_dim <= 16 && p->n_enc == 2) {
+      !p->row_elbo && !p->dy && p->head.out_dim <= 16 && p->n_enc == 2 && p->enc[0].out_dim == FD_H && p->enc[1].in_dim == FD_H &&
+      p->enc[1].out_dim == FD_H && p->head.in_dim == FD_H) {      // (the epilogue's chain is written for two hidden layers of width 128)
     tail_np = compact_wgrad_problems(p, L, &wz, 1, tail_probs);
     if (tail_np > 0 && adam) {
       // every PARAMETER must be finalised by a record block or a tile (the launch has no Adam guests): the plan's layers, counted,

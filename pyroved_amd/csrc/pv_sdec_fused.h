@@ -185,6 +185,9 @@ __host__ __device__ inline int pv_fused_reduce_blocks(int fmt) {
 // one block = 64 chunks = ONE accumulator block of one wave (thread c = lane c of that wave), four slices of the workgroup range
 // a finished gradient element: into the flat gradient, or (ad: pv_ivae_step's optimizer riding in the reducing launch) straight
 // through torch.optim.Adam's update of its parameter — the element's gradient slot is then left zeroed (pv_common.h: pv_adam_update)
+#ifndef PV_RED_UNROLL
+#define PV_RED_UNROLL 8          // records in flight per thread of a reducing block
+#endif
 struct PvRecAdam { PvAdamFuse a; int on; };       // (by value: the address of a kernel argument would put it in scratch memory)
 __device__ __forceinline__ void pv_rec_out(float* __restrict__ Gr, int idx, float v, const PvRecAdam& ad) {
   if (ad.on) pv_adam_update(ad.a.p, ad.a.g, ad.a.m, ad.a.v, (Gr - ad.a.g) + idx, v, ad.a.b1, ad.a.b2, ad.a.eps, ad.a.step_size, ad.a.bc2_sqrt);
@@ -201,7 +204,7 @@ __device__ __forceinline__ void pv_sdec_fused_reduce_block_lane(const float* __r
   f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};
   if (FMT == PV_REC_LANE_BF16) {
     typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-#pragma unroll 8
+#pragma unroll PV_RED_UNROLL
     for (int w = w0; w < w1; ++w) {
       const u32x4_ v = *reinterpret_cast<const u32x4_*>(pbase + (int64_t)w * FD_REC);
       a[0] += __uint_as_float(v[0] << 16); a[1] += __uint_as_float(v[0] & 0xffff0000u);
@@ -210,7 +213,7 @@ __device__ __forceinline__ void pv_sdec_fused_reduce_block_lane(const float* __r
       b[2] += __uint_as_float(v[3] << 16); b[3] += __uint_as_float(v[3] & 0xffff0000u);
     }
   } else {
-#pragma unroll 8
+#pragma unroll PV_RED_UNROLL
     for (int w = w0; w < w1; ++w) a += *reinterpret_cast<const f32x4*>(pbase + (int64_t)w * FD_REC);
   }
   sm[sl][c] = a;
@@ -269,7 +272,7 @@ __device__ __forceinline__ void pv_sdec_fused_reduce_block(const float* __restri
       }
     } else {
       const float* p = part + e;
-#pragma unroll 8
+#pragma unroll PV_RED_UNROLL
       for (int w = w0; w < w1; ++w) v += *reinterpret_cast<const f32x4*>(p + (int64_t)w * FD_REC);
     }
   }

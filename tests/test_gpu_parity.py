@@ -1784,15 +1784,18 @@ def test_manifold2d_matches_decode_and_plots(gpu_device):
     plt.close("all")
 
 
-@pytest.mark.parametrize("kind", ["ivae_f2", "ivae_f3", "ivae_f0", "jivae", "cvae", "convenc", "b5000"])
+@pytest.mark.parametrize("kind", ["ivae_f2", "ivae_f3", "ivae_f0", "jivae", "cvae", "convenc", "b5000", "ivae_f2_b256", "ivae_f3_b256"])
 def test_one_call_step_is_bit_identical(gpu_device, kind):
     """loss_and_grads(step=True) (pv_ivae_step: on the fused path Adam rides in the last gradient launch, every element
     updated by the workgroup that finalises its gradient + guest workgroups for the rest) against loss_and_grads() +
     adam_step(): parameters, both Adam moments, the zeroed gradients and the loss scalars must be bit-identical over
     several steps; with a conv encoder (round 4) Adam rides in the launch of fc_latent's weight gradient, the step's last; paths
-    that cannot fuse (layered decoder, long batches) fall back to the same pair."""
+    that cannot fuse (layered decoder, long batches) fall back to the same pair.
+    (round 6, *_b256: at batch == number of CUs every decoder workgroup owns one image, runs its latent backward and encoder chain
+    itself, and the step closes with ONE launch — record sums with Adam applied by the blocks that finalise them, the small
+    weight gradients with Adam in their epilogues, no guest workgroups: pv_rec_wgrad_kernel.)"""
     torch.manual_seed(3)
-    b = 5000 if kind == "b5000" else 37
+    b = 5000 if kind == "b5000" else (256 if kind.endswith("_b256") else 37)
     def make():
         if kind == "jivae":
             m = pv.models.jiVAE((28, 28), 2, 3, ["r", "t"], seed=1, device="cuda")
@@ -1802,7 +1805,7 @@ def test_one_call_step_is_bit_identical(gpu_device, kind):
             m = pv.models.iVAE((28, 28) if kind != "convenc" else (16, 16), 2, ["r", "t"], seed=1, device="cuda")
             if kind == "convenc":
                 m.set_encoder(pv.nets.convEncoderNet((16, 16), latent_dim=m.z_dim, hidden_dim=[(8,), (8, 8)]))
-        return m, m.engine(fused={"ivae_f3": 3, "ivae_f0": 0}.get(kind, 2))
+        return m, m.engine(fused={"ivae_f3": 3, "ivae_f0": 0, "ivae_f3_b256": 3}.get(kind, 2))
     (m1, e1), (m2, e2) = make(), make()
     dd = m1.data_dim
     x = torch.rand(b, *dd).cuda()
