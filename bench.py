@@ -763,8 +763,9 @@ def main():
         out["roofline"]["step_frac"] = main_leg["step_algorithmic_tflops"] / MFMA_BF16_PEAK_TFLOPS
         if unfolded is not None:
             out["roofline"]["note"] = ("this launch also runs the guide (fc encoder, sample, split, fc_latent: fp32 matrix-vector "
-                                       "products, no matrix-core work); decoder_only_* = the same workload with the guide in its "
-                                       "own launch (PV_PLAN_NO_ENC_FOLD)")
+                                       "products, no matrix-core work) and, since round 6, every image's latent backward + encoder "
+                                       "input-gradient chain in its epilogue; decoder_only_* = the same workload with the guide and "
+                                       "the latent backward in launches of their own (PV_PLAN_NO_ENC_FOLD)")
             out["roofline"]["decoder_only_kernel"] = unfolded["roofline"].get("kernel")
             out["roofline"]["decoder_only_kernel_ms"] = unfolded["roofline"].get("kernel_ms")
             out["roofline"]["decoder_only_frac"] = unfolded["roofline"].get("frac")

@@ -26,7 +26,7 @@ def steps_of(rows):
     for r in rows:
         cur.append(r)
         n = r["Kernel_Name"]
-        if "pv_adam" in n or "pv_wgrad_small" in n:
+        if "pv_adam" in n or "pv_wgrad_small" in n or "pv_rec_wgrad" in n:
             out.append(cur); cur = []
     return out[2:] if len(out) > 4 else out          # (drop the first steps: warm-up / allocation effects)
 
