@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256) void pv_rec_wgrad_kernel(const float* __restri
   __shared__ float wpart[WG_WAVES][16][17];
   __shared__ float wrpart[WG_WAVES][16];
   const int nred = pv_fused_reduce_blocks(fmt), id = (int)blockIdx.x;
-  if (id < nred) { if (!(rwx & 1)) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, id, smr, fmt, ra); return; }
+  if (id < nred) { if (!(rwx & 1)) pv_sdec_fused_reduce_block(part, G_, Gr, o, cd, 0, id, smr, fmt, (rwx & 4) ? PvRecAdam{} : ra); return; }
   if (rwx & 2) return;
   pv_wgrad_small_block(w, id - nred, (int)gridDim.x - nred, wpart, wrpart);
 }
