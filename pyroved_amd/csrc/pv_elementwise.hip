@@ -1116,12 +1116,14 @@ __global__ __launch_bounds__(256) void pv_rec_wgrad_kernel(const float* __restri
 
 // adam: every parameter must be finalised by a record block or a tile (no Adam guests here: the caller checked the coverage)
 int pv_rec_wgrad(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int fmt, const PvGemm* gs, int n,
-                 const PvAdamFuse* adam, const PvFinishArgs* fin, hipStream_t s) {
+                 const PvAdamFuse* adam, const PvFinishArgs* fin, hipStream_t s, unsigned* tick) {
   PvWgradSmall w;
   int guests = 0;
   const int tiles = pv_wgrad_small_fill(w, gs, n, adam, fin, &guests);
   if (tiles < 0) return tiles;
   const int fin_blocks = (fin && fin->scalars) ? 1 : 0;
+  if (tick && !fin_blocks) return PV_EINVAL;           // (the loss block carries the increment)
+  w.tick = tick;
   PvRecAdam ra{};
   if (adam) { ra.a = *adam; ra.on = 1; }
   static const int rwx = pv_exp_int("PV_RW_EXP", 0);

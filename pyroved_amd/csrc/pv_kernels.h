@@ -212,7 +212,7 @@ int pv_latent_bwd_reduce(const PvLatentBwd& p, const float* part, int grid, floa
 // record sums (with Adam on the decoder parameters they finalise), the small weight gradients (Adam in their epilogues) and the
 // loss scalars — three kinds of workgroups that need nothing from each other (pv_elementwise.hip: pv_rec_wgrad_kernel)
 int pv_rec_wgrad(const float* part, int grid, float* G, const PvFusedOffsets& o, int cd, int rec_fmt, const PvGemm* gs, int n,
-                 const PvAdamFuse* adam, const PvFinishArgs* fin, hipStream_t s);
+                 const PvAdamFuse* adam, const PvFinishArgs* fin, hipStream_t s, unsigned* tick = nullptr);
 
 // pv_lik_elem + pv_segsum in one launch (one workgroup per sample; same summation order)
 int pv_lik_rows(const float* a, const float* x, int64_t B, int64_t per, int lik, int sigmoid_out, float sig, float* loc,

@@ -42,6 +42,7 @@ struct Layout {
   float* edp[PV_MAX_LAYERS];               // dL/d(pre-activation) of every encoder hidden layer
   bool enc_compact; float* kl_part; int kl_blocks;   // compact encoder kernels (pv_encoder.hip)
   unsigned* enc_flags;                               // ... their merged launch's tile flags (8 per row block; any content)
+  unsigned* coop_flags;                              // the shared first layer's hand-off tags (PvEncFold::coop_flags; any content)
   // decoder
   float* hz; float* h0; float* dact[PV_MAX_LAYERS]; float* dpre_[PV_MAX_LAYERS];
   float* logits; float* llrow; float* llb; float* dbuf[2];
@@ -168,6 +169,7 @@ void carve(const pv_ivae_plan* p, char* base, Layout& L, bool inference_only = f
   L.kl_blocks = (int)((B + 15) / 16);
   L.kl_part = c.take(2 * (B > L.kl_blocks ? B : L.kl_blocks));   // (per 16-row block — or per sample when the guide rides in the decoder launch)
   L.enc_flags = reinterpret_cast<unsigned*>(c.take(8 * L.kl_blocks));     // (the merged encoder launch's tile flags)
+  L.coop_flags = reinterpret_cast<unsigned*>(c.take(1024 + 16));
   int64_t maxd = 0;
   L.fused = p->fused && pv_sdec_fused_supported(p) && !(K > 0 && !L.enc_compact);   // (jiVAE + generic encoder: layered)
   L.f_grid = L.f_kmax = 0;
@@ -963,6 +965,10 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   const bool own_chain = tail_np > 0;
   if (own_chain) {
     ef.chain = 1; ef.dhead = L.dhead; ef.ldh = (int)plan_head_w(p); ef.edp0 = L.edp[0]; ef.edp1 = L.edp[1]; ef.llb = L.llb;
+    // ... and, in the hosting launch, the guide's first layer shared among the workgroups of a group (pv_sdec_fused_w8.hip, build 3):
+    // its hand-off tags live in coop_flags, whose last word this step's closing launch increments
+    static const int ab_coop = pv_exp_int("PV_COOP_L0", 0);          // (experiments build only; measured slower than every workgroup for itself)
+    if (fold && ab_coop && L.f_grid <= 1024) { ef.coop = 1; ef.coop_flags = L.coop_flags; }
   }
   if (p->ev_start && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_start, s);
   if (p->fused >= 2) PV_TRY(pv_sdec_fused_bf16_launch(f, L.f_grid, want_grads != 0, p->fused == 2, s, fold ? &ef : nullptr,
@@ -990,7 +996,8 @@ int loss_and_grads_fused(const pv_ivae_plan* p, const Layout& L, int want_grads,
   if (head_side) pv_fork_arm();
   if (own_chain) {
     const PvFinish fin{L.llb, (int)B, p->scalars, L.kl_part, kl_n, 1.0f /* scaled */};
-    PV_TRY(pv_rec_wgrad(L.f_part, L.f_grid, G, o, p->coord_dim, rec_fmt, tail_probs, tail_np, adam, &fin, s));
+    PV_TRY(pv_rec_wgrad(L.f_part, L.f_grid, G, o, p->coord_dim, rec_fmt, tail_probs, tail_np, adam, &fin, s,
+                        (fold && ef.coop) ? L.coop_flags + L.f_grid : nullptr));
     if (adam) *adam_done = true;
     return extra_outputs(p, L, L.dzc, lat_in, s);
   }

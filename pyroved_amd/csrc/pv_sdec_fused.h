@@ -85,6 +85,11 @@ struct PvEncFold {
   float* dhead; int ldh;           // (B, ldh) dL/d[mu | softplus input]
   float* edp0; float* edp1;        // (B, 128) dL/dpre of the two hidden layers
   float* llb;                      // (B) the image's log-likelihood
+  // (round 6, fourth cut) coop != 0 (with chain, grid == 256): the guide's first layer is shared among the 32 workgroups of a group
+  // (pv_sdec_fused_w8.hip).  coop_flags: grid + 1 words of any content — [g] workgroup g's hand-off tag, [grid] a word that the
+  // step's closing launch increments (PvWgradSmall::tick), so that no launch's tag repeats an earlier one's
+  int coop;
+  unsigned* coop_flags;
 };
 // A kernel (PvFused f, PvEncFold e) whose EPILOGUE alone needs `e` reads it there through this pointer into the kernarg segment, made
 // opaque at the point of use: named directly, the compiler fetches the fields at kernel entry and carries them — spilled — through

@@ -478,11 +478,20 @@ static_assert(WF_P + W8_WAVES * WF_P_WAVE <= WO_VEC, "guide scratch fits in the 
 #include "pv_gemv16.h"      // w8_gemv16, w8_gemv16_k128(_load): one wave's 16 rows of a matrix-vector product from L2-resident weights
 
 // LIK: the likelihood is a compile-time choice.  FOLD: the workgroup runs its images' guide itself (PvEncFold e; else unused)
+// the shared first layer's bounded wait (FOLDK == 3): polls of ~0.5 us before a consumer computes its layer alone, and how often that
+// happened in this process (observability, tests: pv_debug_coop_late_count)
+#define W8_COOP_SPINS 4096
+__device__ unsigned w8_coop_late_total;
+extern "C" int pv_debug_coop_late_count(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w8_coop_late_total), sizeof(unsigned));
+}
 // FOLDK: 0 plain; 1 = FOLD; 2 = FOLD + the image's latent backward and encoder chain in the epilogue (PvEncFold::chain) — a build
-// of its own: compiled into the FOLD build, the chain's registers cost the launch 2 us even when it is switched off
+// of its own: compiled into the FOLD build, the chain's registers cost the launch 2 us even when it is switched off; 3 = 2 + the
+// guide's first layer shared among the 32 workgroups of a group (PvEncFold::coop, below; experiments build: measured SLOWER —
+// 86.7 vs 85.0 us, the hand-off's 7 k cycles cost what the smaller L2 stream saves: profiles/r06k_coop_first_layer.txt)
 template <bool GRADS, int LIK, int FOLDK>
 __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEncFold e) {
-  constexpr bool FOLD = FOLDK != 0, CHAIN = FOLDK == 2;
+  constexpr bool FOLD = FOLDK != 0, CHAIN = FOLDK >= 2, COOP = FOLDK == 3;
   extern __shared__ __attribute__((aligned(16))) char smb[];
   const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -498,7 +507,24 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
   const char* gimg = reinterpret_cast<const char*>(f.wimg);
   W8_STAMP_K(0);
   f32x4 xr[4], xpk;                                   // FOLD: the workgroup's image, float4 columns lane + 64 c (c < 4); w8_gemv16's packed group
-  if (FOLD) {
+  // COOP: the FOUR images this wave serves in the shared first layer (group k = g & 7: images 8 mm + k, mm = 4 wave + i), float4
+  // columns lane + 64 c; and the tag this launch's hand-offs carry (a word the step's closing launch increments: no value repeats)
+  f32x4 xc[4][4];
+  unsigned coop_tag = 0;
+  if (COOP) {
+    coop_tag = e.coop_flags[G] + 1u;
+    const int K4 = (int)(e.ldx >> 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* xg = e.x + (int64_t)(8 * (4 * wave + i) + (g & 7)) * e.ldx;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k4 = lane + 64 * c;
+        xc[i][c] = *reinterpret_cast<const f32x4*>(xg + 4 * (k4 < K4 ? k4 : 0));
+      }
+    }
+  }
+  if (FOLD && !COOP) {
     const int K4 = (int)(e.ldx >> 2);
     const float* xg = e.x + (int64_t)g * e.ldx;
 #pragma unroll
@@ -579,21 +605,107 @@ __global__ __launch_bounds__(W8_THREADS) void pv_sdec_w8_kernel(PvFused f, PvEnc
 #pragma unroll
         for (int i = 0; i < 4; ++i) pwz[i] = i < e.lat_in ? e.Wz[(int64_t)tid * e.lat_in + i] : 0.0f;
       }
-      {
+      // the first layer for THIS image by this workgroup alone: every workgroup streams the whole 400 KB matrix from L2 (12.8 MB per
+      // XCD through an L2 that delivers ~1-2 KB per clock: the layer is bound by that, ~19 k cycles)
+      auto layer0_alone = [&](const f32x4 (&xr_)[4], const f32x4& xpk_, bool load_next) {
         // (every workgroup reads the same 400 KB matrix at the same time: which wave takes which 16 rows rotates with the
         //  workgroup index, so that the chip's requests spread over the L2 channels instead of marching through them in step)
         const int jr = 16 * ((wave + g) & (W8_WAVES - 1));
-        const float v = w8_gemv16(e.params + e.enc0.w_off, N, e.enc0.out_dim, jr, xr, xpk, P, lane,
+        const float v = w8_gemv16(e.params + e.enc0.w_off, N, e.enc0.out_dim, jr, xr_, xpk_, P, lane,
                                   [&]() {     // (issued behind the first pass's loads)
-                                    w8_gemv16_k128_load(e.params + e.enc1.w_off, e.enc1.in_dim, e.enc1.out_dim, 16 * wave, lane, wl1);
+                                    if (load_next) w8_gemv16_k128_load(e.params + e.enc1.w_off, e.enc1.in_dim, e.enc1.out_dim, 16 * wave, lane, wl1);
                                   });
-        if (16 * wave < e.head.out_dim)     // (the head's, once the first layer's operand registers are free: under layer 1)
+        if (load_next && 16 * wave < e.head.out_dim)     // (the head's, once the first layer's operand registers are free: under layer 1)
           w8_gemv16_k128_load(e.params + e.head.w_off, e.head.in_dim, e.head.out_dim, 16 * wave, lane, wlh);
         const int j = jr + r_;
         if (q_ == 0 && j < e.enc0.out_dim) {
           const float y = pv_act_fwd2(v + (e.enc0.b_off >= 0 ? e.params[e.enc0.b_off + j] : 0.0f), e.enc0.act);
           h1s[j] = y;
           e.eact0[b * e.enc0.out_dim + j] = y;
+        }
+      };
+      if constexpr (!COOP) {
+        layer0_alone(xr, xpk, true);
+      } else {
+        // ---- the first layer SHARED (round 6, fourth cut): the 32 workgroups g = 8 mm + k of a group (one XCD's, where workgroups are
+        // dealt round-robin — placement only matters for speed) each take FOUR rows of the matrix (12.5 KB, staged in LDS) for all
+        // 32 images of the group (100 KB of observations, read by the whole group from the same L2): 3.6 MB per XCD instead of 12.8.
+        // Member mm writes act(W0[4mm .. 4mm+3] x_b + b0) for the group's images with agent-scope stores and publishes the launch's
+        // tag; every member then waits for its 32 producers' tags (bounded: a consumer whose producers do not show up — a GPU
+        // shared with another process, CUs masked off — computes its image's layer ALONE, as the other build does) and reads its
+        // image's 128 activations past its L1.  Same fp32 multiply-adds in another order than the alone form: equal to rounding.
+        const int kg = g & 7, mm = g >> 3, K4 = N >> 2;
+        float* w0s = reinterpret_cast<float*>(smb + WO_SB);            // [4][N]: the wgrad-1 staging area is free until the tile loop
+        {
+          const float* wsrc = e.params + e.enc0.w_off + (int64_t)(4 * mm) * N;
+          for (int idx = tid; idx < K4 * 4; idx += W8_THREADS) reinterpret_cast<f32x4*>(w0s)[idx] = reinterpret_cast<const f32x4*>(wsrc)[idx];
+        }
+        w8_gemv16_k128_load(e.params + e.enc1.w_off, e.enc1.in_dim, e.enc1.out_dim, 16 * wave, lane, wl1);
+        if (16 * wave < e.head.out_dim)
+          w8_gemv16_k128_load(e.params + e.head.w_off, e.head.in_dim, e.head.out_dim, 16 * wave, lane, wlh);
+        const float pb0 = (lane < 16 && e.enc0.b_off >= 0) ? e.params[e.enc0.b_off + 4 * mm + (lane & 3)] : 0.0f;
+        W8_STAMP_E(20);
+        pv_lds_barrier();                                              // the four rows are staged
+        W8_STAMP_E(21);
+        float acc[16];                                                 // [image i][row]: 4 i + row
+#pragma unroll
+        for (int a = 0; a < 16; ++a) acc[a] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k4 = lane + 64 * c;
+          const bool okc = k4 < K4;
+          if (64 * c >= K4) break;                                     // (wave-uniform)
+#pragma unroll
+          for (int row = 0; row < 4; ++row) {
+            f32x4 wv = *reinterpret_cast<const f32x4*>(w0s + row * N + 4 * (okc ? k4 : 0));
+            if (!okc) wv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};             // (a column that does not exist contributes 0 * x)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * i + row] = w8_dot4(wv, xc[i][c], acc[4 * i + row]);
+          }
+        }
+        // 64 x 16 partial sums -> this wave's transpose buffer -> lane (r, q) sums column r over its 16 lanes, then over q
+        W8_STAMP_E(22);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) P[lane * 17 + a] = acc[a];
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += P[(16 * q_ + i) * 17 + r_];
+        v = pv_sum_rows(v);
+        if (q_ == 0) {                                                 // lane r: image i = r >> 2 of this wave, row r & 3
+          const int bb = 8 * (4 * wave + (r_ >> 2)) + kg, j = 4 * mm + (r_ & 3);
+          const float y = pv_act_fwd2(v + pb0, e.enc0.act);
+          __hip_atomic_store(e.eact0 + (int64_t)bb * e.enc0.out_dim + j, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        W8_STAMP_E(23);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every thread's write-through stores acknowledged
+        W8_STAMP_E(24);
+        pv_lds_barrier();
+        if (tid == 0) __hip_atomic_store(e.coop_flags + g, coop_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        W8_STAMP_E(25);
+        int late = 0;
+        if (tid < 32) {
+          const unsigned* fl = e.coop_flags + 8 * tid + kg;
+          late = 1;
+          for (int spin = 0; spin < W8_COOP_SPINS; ++spin) {
+            if (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == coop_tag) { late = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        W8_STAMP_E(26);
+        if (__syncthreads_or(late) != 0) {                            // (workgroup-uniform) the bounded wait ran out: alone
+          if (tid == 0) atomicAdd(&w8_coop_late_total, 1u);
+          f32x4 xa[4], xpa;
+          const float* xg = e.x + (int64_t)g * e.ldx;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k4 = lane + 64 * c;
+            xa[c] = *reinterpret_cast<const f32x4*>(xg + 4 * (k4 < K4 ? k4 : 0));
+          }
+          const int kp = 64 * (((K4 + 63) >> 6) - 1) + (lane & 3);
+          xpa = *reinterpret_cast<const f32x4*>(xg + 4 * (kp < K4 ? kp : 0));
+          layer0_alone(xa, xpa, false);
+        } else if (tid < FD_H) {
+          h1s[tid] = __hip_atomic_load(e.eact0 + b * e.enc0.out_dim + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       W8_STAMP_K(4);
@@ -1560,8 +1672,19 @@ int pv_sdec_fused_w8_launch(const PvFused& f_in, int grid, bool grads, hipStream
     if (!pv_sdec_fused_w8_fold_ok(f, grid)) return PV_EINVAL;
     e = *fold;
     e.img_per_wg = f.B / grid;
+    // (the shared first layer is written for 8 groups of 32 workgroups, four of the layer's 128 rows each)
+    if (e.coop && !(grid == 256 && e.enc0.out_dim == FD_H && e.coop_flags && e.chain)) e.coop = 0;
+#ifndef PV_EXPERIMENTS
+    e.coop = 0;
+#endif
   }
+#ifdef PV_EXPERIMENTS                  // (build 3 — the shared first layer, measured slower: profiles/r06k_coop_first_layer.txt — exists in the experiments library only)
+#define W8_COOP_BUILD 3
+#else
+#define W8_COOP_BUILD 2
+#endif
 #define W8_PICK(G, L) fn = !fold ? reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, 0>)                     \
+                               : (G && e.chain && e.coop) ? reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, G ? W8_COOP_BUILD : 1>) \
                                : (G && e.chain) ? reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, G ? 2 : 1>) \
                                                 : reinterpret_cast<const void*>(&pv_sdec_w8_kernel<G, L, 1>)
   if (grads) {

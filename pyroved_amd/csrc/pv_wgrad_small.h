@@ -19,6 +19,7 @@ struct PvWgradSmall {
   int64_t rng_lo[8], rng_hi[8];
   // one more guest (the last block) when fin_scalars is set: the step's loss scalars (pv_finish_scalars)
   const float* fin_llb; float* fin_scalars; const float* fin_kl_part; int fin_B, fin_n_part; float fin_beta;
+  unsigned* tick;              // not null: a word the loss block increments — the step's hand-off generation (PvEncFold::coop_flags)
 };
 // fills w from the problems (validation as pv_wgrad_small's); returns the tile count or a negative error
 int pv_wgrad_small_fill(PvWgradSmall& w, const PvGemm* gs, int n, const PvAdamFuse* adam, const PvFinishArgs* fin, int* guests);
@@ -29,6 +30,7 @@ __device__ __forceinline__ void pv_wgrad_small_block(const PvWgradSmall& w, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (w.fin_scalars && t == nblk - 1) {
     pv_finish_scalars_block(w.fin_llb, w.fin_B, w.fin_scalars, w.fin_kl_part, w.fin_n_part, w.fin_beta, &part[0][0][0]);
+    if (w.tick && tid == 0) *w.tick = *w.tick + 1u;
     return;
   }
   if (w.adam_on && t >= w.tile_end[3]) {              // guest: Adam over everything this launch does not produce

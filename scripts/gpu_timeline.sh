@@ -11,7 +11,7 @@ names = [r["Kernel_Name"] for r in rows]
 # a step starts at each enc_fwd kernel; take the 3rd-from-last complete step
 starts = [i for i, n in enumerate(names) if "enc_l1" in n or "pv_enc_kernel" in n or "pv_guide_img_kernel" in n]
 if len(starts) < 3:      # (round 5: the decoder launch hosts the guide — a step starts at that launch)
-    starts = [i for i, n in enumerate(names) if "pv_sdec_w8_kernel<true, " in n and ("true>" in n or ", 1>" in n or ", 2>" in n)]
+    starts = [i for i, n in enumerate(names) if "pv_sdec_w8_kernel<true, " in n and ("true>" in n or ", 1>" in n or ", 2>" in n or ", 3>" in n)]
 a, b = starts[-3], starts[-2]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = None
 tot_k = 0

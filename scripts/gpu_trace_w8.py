@@ -58,3 +58,7 @@ if e[0] and k[2]:
 x = [buf[144 + i] for i in (1, 10, 11, 12, 2)]
 if all(x):
     print("  inside 'prefetch + scr stores': row-sum loads issued %d, other loads issued %d, record stores issued %d, scr stores + wave sum %d" % tuple(b - a for a, b in zip(x, x[1:])))
+c = [buf[128]] + [buf[144 + i] for i in range(20, 27)] + [buf[128 + 4]]
+if all(c[1:8]):
+    print("  coop layer 0 (cycles): entry -> rows + loads requested %d, staged %d, multiply-adds %d, transpose + stores issued %d, stores acknowledged %d, barrier + tag %d, producers' tags seen %d, h1 read %d"
+          % tuple(b - a for a, b in zip(c, c[1:])))
