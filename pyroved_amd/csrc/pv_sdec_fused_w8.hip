@@ -68,7 +68,10 @@ static_assert(2 * IMG_BYTES % (W8_WAVES * 1024) == 0, "image load: whole 1 KB LD
 #define W8_RC2 (W8_RC * W8_RC)
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define BERN_EPS 1.1920928955078125e-07f
-#define W8_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef W8_FENCE_MASK
+#define W8_FENCE_MASK 0          // __builtin_amdgcn_sched_barrier's mask: 0 = nothing crosses a stage fence
+#endif
+#define W8_FENCE() __builtin_amdgcn_sched_barrier(W8_FENCE_MASK)
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x4 w8_mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
