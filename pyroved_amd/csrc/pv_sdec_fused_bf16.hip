@@ -157,6 +157,24 @@ static_assert(FB_LDS_BYTES <= 160 * 1024, "LDS budget");
 #else
 #define FB_FENCE() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK)
 #endif
+// (per group of sites, for the experiment of profiles/r06l_sched_strategy.txt: A forward layer loop, B dgrad layer loop, C tanh stages,
+//  D weight-gradient consume loop)
+#ifndef FB_FENCE_MASK_A
+#define FB_FENCE_MASK_A FB_FENCE_MASK
+#endif
+#ifndef FB_FENCE_MASK_B
+#define FB_FENCE_MASK_B FB_FENCE_MASK
+#endif
+#ifndef FB_FENCE_MASK_C
+#define FB_FENCE_MASK_C FB_FENCE_MASK
+#endif
+#ifndef FB_FENCE_MASK_D
+#define FB_FENCE_MASK_D FB_FENCE_MASK
+#endif
+#define FB_FENCE_A() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_A)
+#define FB_FENCE_B() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_B)
+#define FB_FENCE_C() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_C)
+#define FB_FENCE_D() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_D)
 typedef _Float16 half4_ __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
 // 16-bit operands travel as bf16x4 / bf16x8 bit containers in every mode; F16 picks the instruction that reads them
@@ -254,7 +272,7 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
   for (int g = 0; g < 4 * FB_GPM; ++g) {
     const int m = g / FB_GPM, op = (g % FB_GPM) * FB_GB;
     if (g + 1 < 4 * FB_GPM) load(g + 1, wh[(g + 1) & 1], wl[(g + 1) & 1]);
-    FB_FENCE();
+    FB_FENCE_A();
     const bf16x8 bh = fb_catq(ih[2 * m], ih[2 * m + 1], sw);
     const bf16x8(&h)[FB_GB] = wh[g & 1];
     const bf16x8(&l)[FB_GB] = wl[g & 1];
@@ -269,7 +287,7 @@ __device__ __forceinline__ void fb_layer_fwd(const __bf16* __restrict__ Wh, cons
 #pragma unroll
       for (int o = 0; o < FB_GB; ++o) out[op + o] = fb_mma<F16>(l[o], bh, out[op + o]);
     }
-    FB_FENCE();
+    FB_FENCE_A();
   }
 }
 
@@ -311,7 +329,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
   for (int g = 0; g < 4 * FB_GPM; ++g) {
     const int m = g / FB_GPM, kp = (g % FB_GPM) * FB_GB;
     if (g + FB_DGD < 4 * FB_GPM) load(g + FB_DGD, wh[(g + FB_DGD) % (FB_DGD + 1)], wl[(g + FB_DGD) % (FB_DGD + 1)]);
-    FB_FENCE();
+    FB_FENCE_B();
     const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]);
     const bf16x8(&h)[FB_GB] = wh[g % (FB_DGD + 1)];
     const bf16x8(&l)[FB_GB] = wl[g % (FB_DGD + 1)];
@@ -326,7 +344,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
 #pragma unroll
       for (int o = 0; o < FB_GB; ++o) out[kp + o] = fb_mma<F16>(l[o], bh, out[kp + o]);
     }
-    FB_FENCE();
+    FB_FENCE_B();
   }
 }
 
@@ -337,23 +355,23 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
 __device__ __forceinline__ void fb_tanh8(f32x4 (&v)[8], float c = FB_C) {       // c: C / (scale carried by v)
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) v[ob] = v[ob] * c;
-  FB_FENCE();
+  FB_FENCE_C();
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[ob][i] = __builtin_amdgcn_exp2f(v[ob][i]);
-  FB_FENCE();
+  FB_FENCE_C();
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) v[ob] = v[ob] + 1.0f;
-  FB_FENCE();
+  FB_FENCE_C();
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[ob][i] = __builtin_amdgcn_rcpf(v[ob][i]);
-  FB_FENCE();
+  FB_FENCE_C();
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) v[ob] = 1.0f - 2.0f * v[ob];
-  FB_FENCE();
+  FB_FENCE_C();
 }
 
 __device__ __forceinline__ void fb_mul_dtanh(f32x4 (&out)[8], const f32x4 (&h)[8]) {
@@ -474,7 +492,7 @@ __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)
     for (int g = 0; g < 4; ++g) {
       const int kp = 2 * g;
       if (g + 1 < 4) load(kp + 2, bh[(g + 1) & 1], bl[(g + 1) & 1]);
-      FB_FENCE();
+      FB_FENCE_D();
       const bf16x8(&h)[2] = bh[g & 1];
       const bf16x8(&l)[2] = bl[g & 1];
 #pragma unroll
@@ -491,7 +509,7 @@ __device__ __forceinline__ void fb_wgrad_consume(const __bf16* st, f32x4 (&accW)
 #pragma unroll
           for (int s = 0; s < 2; ++s) accW[s][kp + o] = fb_mma<F16>(a_l[s], h[o], accW[s][kp + o]);
       }
-      FB_FENCE();
+      FB_FENCE_D();
     }
     la += 2 * ROW16; lb += 2 * ROW16;
   }
