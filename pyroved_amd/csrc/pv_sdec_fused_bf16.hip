@@ -172,7 +172,14 @@ static_assert(FB_LDS_BYTES <= 160 * 1024, "LDS budget");
 #define FB_FENCE_MASK_D FB_FENCE_MASK
 #endif
 #define FB_FENCE_A() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_A)
-#define FB_FENCE_B() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_B)
+#ifndef FB_FENCE_MASK_B1
+#define FB_FENCE_MASK_B1 FB_FENCE_MASK_B
+#endif
+#ifndef FB_FENCE_MASK_B2
+#define FB_FENCE_MASK_B2 FB_FENCE_MASK_B
+#endif
+#define FB_FENCE_B1() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_B1)      // dgrad loop: between the operand requests and the MFMA group
+#define FB_FENCE_B2() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_B2)      // dgrad loop: behind the MFMA group
 #define FB_FENCE_C() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_C)
 #define FB_FENCE_D() __builtin_amdgcn_sched_barrier(FB_FENCE_MASK_D)
 typedef _Float16 half4_ __attribute__((ext_vector_type(4)));
@@ -329,7 +336,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
   for (int g = 0; g < 4 * FB_GPM; ++g) {
     const int m = g / FB_GPM, kp = (g % FB_GPM) * FB_GB;
     if (g + FB_DGD < 4 * FB_GPM) load(g + FB_DGD, wh[(g + FB_DGD) % (FB_DGD + 1)], wl[(g + FB_DGD) % (FB_DGD + 1)]);
-    FB_FENCE_B();
+    FB_FENCE_B1();
     const bf16x8 bh = fb_cat(ih[2 * m], ih[2 * m + 1]);
     const bf16x8(&h)[FB_GB] = wh[g % (FB_DGD + 1)];
     const bf16x8(&l)[FB_GB] = wl[g % (FB_DGD + 1)];
@@ -344,7 +351,7 @@ __device__ __forceinline__ void fb_layer_dgrad(const __bf16* __restrict__ Wh, co
 #pragma unroll
       for (int o = 0; o < FB_GB; ++o) out[kp + o] = fb_mma<F16>(l[o], bh, out[kp + o]);
     }
-    FB_FENCE_B();
+    FB_FENCE_B2();
   }
 }
 
