@@ -587,6 +587,7 @@ int encoder_bwd(const pv_ivae_plan* p, const Layout& L, const PvGemm* extra, int
                           s));
     }
   }
+  // (the same list, as a pure function, for the launch that closes an own-sample step: compact_wgrad_problems below — keep the two in step)
   PvGemm probs[PV_MAX_LAYERS + 4];
   int np = 0;
   for (int i = 0; i < n_extra; ++i) {
